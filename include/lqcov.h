@@ -1,0 +1,168 @@
+/* include/lqcov.h -- C ABI of liblqcov.so: the MI355X-native stand-in for LongQC's
+ * `minimap2-coverage` subprocess (the hot path behind `longQC.py sampleqc`).
+ *
+ * The reference has no FFI for this path: the boundary is a process boundary --
+ * lq_exec.py:13-38 (`LqExec.exec(*argv, out=, err=)` -> Popen) driven by longQC.py:438-446 and
+ * polled at longQC.py:520-526; the C side of it is `main` (minimap2-coverage.c:206) and, one level
+ * down, the in-process seam `lq_map_file` (minimap2-coverage.h:41-42; lqmap.c:852).  This header
+ * therefore offers two levels, each citing what it replaces:
+ *
+ *   1. lqcov_main / lqcov_run_files     == the subprocess: same argv in, same 9-column table out
+ *                                          (minimap2-coverage.c:166-195 options, :545-617 rows).
+ *   2. handle + read-set + part calls    == main's body (minimap2-coverage.c:406-458) and
+ *                                          lq_map_file (lqmap.c:852): caller owns the reads, the
+ *                                          library owns the device state and the accumulators.
+ *
+ * All pointers are plain host pointers unless a name ends in _dev (HIP device pointers, used by
+ * bench.py and the multi-GPU driver to keep data resident / exchange it over RCCL).  No torch or
+ * C++ types cross this boundary.  Every int-returning call yields 0 on success and a negative
+ * LQCOV_E_* code on failure; the message is available from lqcov_last_error().  Handles are not
+ * thread-safe; one handle drives one HIP device and one stream.
+ */
+#ifndef LQCOV_H
+#define LQCOV_H
+#include <stdint.h>
+#include <stddef.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LQCOV_ABI_VERSION 1
+
+#define LQCOV_E_ARG     (-1)   /* bad argument / bad option value                     */
+#define LQCOV_E_IO      (-2)   /* cannot open / read / write a file                   */
+#define LQCOV_E_DEVICE  (-3)   /* HIP error (no device, out of memory, launch failed) */
+#define LQCOV_E_STATE   (-4)   /* call sequence violated                              */
+#define LQCOV_E_DOMAIN  (-5)   /* input outside the supported domain  */
+
+typedef struct lqcov_handle lqcov_handle;
+
+/* Effective parameters == what minimap2-coverage echoes on stderr (minimap2-coverage.c:392-404).
+ * Defaults are the binary's own (minimap2-coverage.c:252-388, map.c:12-44, index.c:31-37). */
+typedef struct lqcov_params {
+	int32_t  k;                /* -k  (default 12)                                   */
+	int32_t  w;                /* -w  (default 5)                                    */
+	int32_t  hpc;              /* -H  homopolymer-compressed k-mers                  */
+	uint64_t batch_size;       /* -I  bases per index part (default 4G)              */
+	int32_t  idx_mini_batch;   /* 50,000,000: part boundaries fall on these (index.c:35,244) */
+	int32_t  max_gap;          /* -g  (default 10000), both axes                     */
+	int32_t  min_cnt;          /* -n  (default 3)                                    */
+	int32_t  min_chain_score;  /* -m  (default 40)                                   */
+	int32_t  min_score_med;    /* -p  (default m)                                    */
+	int32_t  min_score_good;   /* -q  (default m)                                    */
+	int32_t  max_chain_skip;   /* -s  (default 25)                                   */
+	int32_t  bw;               /* 500 (map.c:20)                                     */
+	int32_t  max_overhang;     /* -a  (default 2000)                                 */
+	int32_t  min_ovlp;         /* -l  (default 1000; parsed, unused by lq_cnt_match) */
+	int32_t  min_coverage;     /* -c  (default 3)                                    */
+	double   min_ratio;        /* -r  (default 0.4)                                  */
+	float    mid_occ_frac;     /* 2e-4f (map.c:16)                                   */
+	int32_t  no_self;          /* -Y or -X: skip the self diagonal (lqmap.c:185)     */
+	int32_t  ava;              /* -X: also skip cmp>0 pairs (lqmap.c:187)            */
+	int32_t  filter_flag;      /* --filter row format (minimap2-coverage.c:586-588)  */
+	int32_t  n_threads;        /* -t: accepted, ignored (the device is the pool)     */
+} lqcov_params;
+
+/* One output row before text formatting (minimap2-coverage.c:545-605). Regions live in the pools
+ * returned by lqcov_get_regions(). */
+typedef struct lqcov_row {
+	uint64_t lambda;           /* column 3  */
+	uint64_t lambda2;          /* numerator of column 9 */
+	double   qual_psum;        /* sum of q2p[q-33] over the read (lqutils.c:51-56); NaN-free, host takes log10 */
+	uint32_t qlen;             /* column 2  */
+	uint32_t n_mini;           /* mv.n      (minimap2-coverage.c:422) */
+	uint32_t n_match;          /* #counters above the integer mean (minimap2-coverage.c:552-561) */
+	float    avg_k;            /* esterr.c:93-97 */
+	uint32_t reg_off, n_reg;   /* regs  (column 4) */
+	uint32_t mreg_off, n_mreg; /* mregs (column 5) */
+	uint32_t has_qual;         /* 0 for FASTA queries: meanQ prints as the reference's NaN */
+	uint32_t flags;            /* LQCOV_ROW_* */
+} lqcov_row;
+#define LQCOV_ROW_SATURATED 1u /* a uint16 match counter reached 65535: esterr.c:130,136 order dependence, row not guaranteed */
+
+typedef struct lqcov_region { uint32_t start, end; } lqcov_region;
+
+/* Per-stage device time of the calls made so far on the handle (ms, HIP events on the handle's
+ * stream); filled when profiling was switched on with lqcov_set_profiling(). */
+typedef struct lqcov_stage_time {
+	char     name[48];
+	double   total_ms;
+	uint64_t launches;
+	uint64_t algo_bytes;       /* algorithmic (compulsory) bytes moved, SURVEY.md section 8(d) */
+} lqcov_stage_time;
+
+/* ---- level 1: the subprocess ------------------------------------------------------------- */
+/* == `minimap2-coverage argv...` with stdout -> out_path (NULL: stdout), stderr -> err_path
+ * (NULL: stderr).  Returns the process exit status the reference would give (0 / 1), or a
+ * negative LQCOV_E_* for device errors.                         minimap2-coverage.c:206-734 */
+int lqcov_main(int argc, const char *const *argv, const char *out_path, const char *err_path, int device);
+
+/* same, on an existing handle and with explicit paths (NULL out: stdout, NULL err: stderr) */
+int lqcov_run_files(lqcov_handle *h, const char *target_path, const char *query_path, const char *out_path, const char *err_path);
+
+/* ---- level 2: handle ---------------------------------------------------------------------- */
+void lqcov_params_default(lqcov_params *p);                                /* minimap2-coverage.c:229-388 */
+/* parse the reference's option table; fills target/query with pointers into argv.   :166-197 */
+int  lqcov_parse_args(int argc, const char *const *argv, lqcov_params *p, const char **target, const char **query,
+                      const char **dump_path, char *errbuf, size_t errbuf_len);
+lqcov_handle *lqcov_create(const lqcov_params *p, int device);            /* NULL if no HIP device */
+void lqcov_destroy(lqcov_handle *h);
+const char *lqcov_last_error(const lqcov_handle *h);
+int  lqcov_abi_version(void);
+int  lqcov_set_profiling(lqcov_handle *h, int on);
+int  lqcov_set_debug(lqcov_handle *h, unsigned flags);                     /* bit0: record chains for lqcov_get_chains */
+int  lqcov_get_stage_times(lqcov_handle *h, lqcov_stage_time *out, int max_out);   /* returns count */
+
+/* Query reads (the subsample): n reads, bases seq[seq_off[i] .. seq_off[i+1]) as ASCII, optional
+ * qualities with the same offsets, names as n NUL-terminated strings name[name_off[i]...].
+ * Uploads, 2-bit packs and sketches them; sizes the per-query accumulators.
+ * == main pass 1 (minimap2-coverage.c:406-444) + mm_bseq_read2 (bseq.c:68-102).              */
+int lqcov_set_queries(lqcov_handle *h, uint32_t n, const uint8_t *seq, const uint64_t *seq_off,
+                      const uint8_t *qual, const char *names, const uint64_t *name_off);
+
+/* Index parts == iterations of the loop at minimap2-coverage.c:449-458.  The caller decides the
+ * part boundaries (lqcov_run_files applies the reference's rule, index.c:244,311-316). */
+int lqcov_part_begin(lqcov_handle *h);                                     /* returns part id >= 0 */
+int lqcov_part_add_targets(lqcov_handle *h, int part, uint32_t n, const uint8_t *seq, const uint64_t *seq_off,
+                           const char *names, const uint64_t *name_off);   /* == mm_idx_gen step 0 (index.c:240-288) */
+int lqcov_part_build(lqcov_handle *h, int part);    /* sketch + index (+ mid_occ once): index.c:291-330, map.c:46-54 */
+int lqcov_part_map(lqcov_handle *h, int part);      /* == lq_map_file (lqmap.c:852): accumulates into the handle */
+int lqcov_part_release(lqcov_handle *h, int part);  /* == mm_idx_destroy (minimap2-coverage.c:457) */
+int lqcov_reset(lqcov_handle *h);                   /* zero the accumulators, keep resident reads (bench) */
+int lqcov_sync(lqcov_handle *h);                    /* wait for the handle's stream */
+
+/* == main pass 2 up to, not including, printf (minimap2-coverage.c:545-566). */
+int lqcov_finish(lqcov_handle *h);
+int lqcov_n_queries(const lqcov_handle *h);
+int lqcov_get_rows(lqcov_handle *h, lqcov_row *rows, uint32_t n_rows);
+int lqcov_get_regions(lqcov_handle *h, const lqcov_region **regs, uint32_t *n_regs, const lqcov_region **mregs, uint32_t *n_mregs);
+/* Text of the table, rows in query order (minimap2-coverage.c:567-605). names as in lqcov_set_queries. */
+int lqcov_write_table(lqcov_handle *h, const char *out_path);
+
+/* ---- parity / inspection ------------------------------------------------------------------ */
+int32_t  lqcov_mid_occ(const lqcov_handle *h);                             /* map.c:50 */
+uint64_t lqcov_part_n_minimizers(const lqcov_handle *h, int part);
+uint64_t lqcov_part_n_keys(const lqcov_handle *h, int part);
+uint64_t lqcov_last_n_anchors(const lqcov_handle *h);
+/* minimizers of the query set / of a part, reference encoding (sketch.c:70-72): xy[2*i], xy[2*i+1];
+ * off[n+1] per-read offsets.  Pass NULL buffers to get the total in *n_total. */
+int lqcov_get_query_minimizers(lqcov_handle *h, uint64_t *xy, uint64_t *off, uint64_t *n_total);
+int lqcov_get_part_minimizers(lqcov_handle *h, int part, uint64_t *xy, uint64_t *off, uint64_t *n_total);
+/* chains of the last lqcov_part_map call: 9 int32 per chain
+ * (query, rid, rev, score, cnt, qs, qe, rs, re), unordered. */
+int lqcov_get_chains(lqcov_handle *h, int32_t *out, uint64_t cap, uint64_t *n_total);
+
+/* ---- multi-GPU plumbing (device pointers; torch.distributed/RCCL moves the bytes) ----------- */
+/* minimizers of a built part as two device arrays (x = hash<<8|span, y = rid<<32|pos<<1|strand) */
+int lqcov_part_minimizers_dev(lqcov_handle *h, int part, const uint64_t **x_dev, const uint64_t **y_dev, uint64_t *n);
+/* sketch only (no index): step 1 of mm_idx_gen (index.c:291-302) on this rank's share of the part */
+int lqcov_part_sketch(lqcov_handle *h, int part);
+/* replace the part's minimizer set by caller-provided device arrays (rank-concatenated, y-sorted),
+ * with the part-global target lengths and names, then (re)build the index from them */
+int lqcov_part_build_from_minimizers_dev(lqcov_handle *h, int part, const uint64_t *x_dev, const uint64_t *y_dev, uint64_t n,
+                                         uint32_t n_targets, const uint32_t *target_len, const char *names, const uint64_t *name_off);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,325 @@
+"""ctypes binding of include/lqcov.h.
+
+The product path: there is no CPU fallback -- if liblqcov.so (the hipcc/gfx950 build) is missing
+or no HIP device is present, loading / Engine() raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+class LqcovError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__("lqcov error %d: %s" % (code, msg))
+        self.code = code
+
+
+class Params(C.Structure):
+    """mirror of lqcov_params (include/lqcov.h)"""
+    _fields_ = [
+        ("k", C.c_int32), ("w", C.c_int32), ("hpc", C.c_int32),
+        ("batch_size", C.c_uint64), ("idx_mini_batch", C.c_int32),
+        ("max_gap", C.c_int32), ("min_cnt", C.c_int32), ("min_chain_score", C.c_int32),
+        ("min_score_med", C.c_int32), ("min_score_good", C.c_int32), ("max_chain_skip", C.c_int32),
+        ("bw", C.c_int32), ("max_overhang", C.c_int32), ("min_ovlp", C.c_int32), ("min_coverage", C.c_int32),
+        ("min_ratio", C.c_double), ("mid_occ_frac", C.c_float),
+        ("no_self", C.c_int32), ("ava", C.c_int32), ("filter_flag", C.c_int32), ("n_threads", C.c_int32),
+    ]
+
+
+class Row(C.Structure):
+    _fields_ = [
+        ("lambda_", C.c_uint64), ("lambda2", C.c_uint64), ("qual_psum", C.c_double),
+        ("qlen", C.c_uint32), ("n_mini", C.c_uint32), ("n_match", C.c_uint32), ("avg_k", C.c_float),
+        ("reg_off", C.c_uint32), ("n_reg", C.c_uint32), ("mreg_off", C.c_uint32), ("n_mreg", C.c_uint32),
+        ("has_qual", C.c_uint32), ("flags", C.c_uint32),
+    ]
+
+
+class StageTime(C.Structure):
+    _fields_ = [("name", C.c_char * 48), ("total_ms", C.c_double), ("launches", C.c_uint64), ("algo_bytes", C.c_uint64)]
+
+
+def library_path() -> str:
+    return os.environ.get("LQCOV_LIBRARY", os.path.join(_HERE, "liblqcov.so"))
+
+
+def load_library(path: Optional[str] = None):
+    """Load liblqcov.so (the gfx950 build).  Raises OSError if it has not been built."""
+    global _LIB
+    if _LIB is not None and path is None:
+        return _LIB
+    p = path or library_path()
+    if not os.path.exists(p):
+        raise OSError("%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                      "(hipcc --offload-arch=gfx950); there is no CPU fallback" % p)
+    lib = C.CDLL(p)
+    H = C.c_void_p
+    u8p, u64p, i32p = C.POINTER(C.c_uint8), C.POINTER(C.c_uint64), C.POINTER(C.c_int32)
+    sig = {
+        "lqcov_abi_version": (C.c_int, []),
+        "lqcov_params_default": (None, [C.POINTER(Params)]),
+        "lqcov_parse_args": (C.c_int, [C.c_int, C.POINTER(C.c_char_p), C.POINTER(Params), C.POINTER(C.c_char_p),
+                                       C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.c_char_p, C.c_size_t]),
+        "lqcov_main": (C.c_int, [C.c_int, C.POINTER(C.c_char_p), C.c_char_p, C.c_char_p, C.c_int]),
+        "lqcov_create": (H, [C.POINTER(Params), C.c_int]),
+        "lqcov_destroy": (None, [H]),
+        "lqcov_last_error": (C.c_char_p, [H]),
+        "lqcov_set_profiling": (C.c_int, [H, C.c_int]),
+        "lqcov_set_debug": (C.c_int, [H, C.c_uint]),
+        "lqcov_get_stage_times": (C.c_int, [H, C.POINTER(StageTime), C.c_int]),
+        "lqcov_set_queries": (C.c_int, [H, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+        "lqcov_part_begin": (C.c_int, [H]),
+        "lqcov_part_add_targets": (C.c_int, [H, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+        "lqcov_part_build": (C.c_int, [H, C.c_int]),
+        "lqcov_part_sketch": (C.c_int, [H, C.c_int]),
+        "lqcov_part_map": (C.c_int, [H, C.c_int]),
+        "lqcov_part_release": (C.c_int, [H, C.c_int]),
+        "lqcov_reset": (C.c_int, [H]),
+        "lqcov_sync": (C.c_int, [H]),
+        "lqcov_finish": (C.c_int, [H]),
+        "lqcov_n_queries": (C.c_int, [H]),
+        "lqcov_get_rows": (C.c_int, [H, C.POINTER(Row), C.c_uint32]),
+        "lqcov_get_regions": (C.c_int, [H, C.POINTER(C.c_void_p), C.POINTER(C.c_uint32), C.POINTER(C.c_void_p), C.POINTER(C.c_uint32)]),
+        "lqcov_write_table": (C.c_int, [H, C.c_char_p]),
+        "lqcov_run_files": (C.c_int, [H, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p]),
+        "lqcov_mid_occ": (C.c_int32, [H]),
+        "lqcov_part_n_minimizers": (C.c_uint64, [H, C.c_int]),
+        "lqcov_part_n_keys": (C.c_uint64, [H, C.c_int]),
+        "lqcov_last_n_anchors": (C.c_uint64, [H]),
+        "lqcov_get_query_minimizers": (C.c_int, [H, C.c_void_p, C.c_void_p, u64p]),
+        "lqcov_get_part_minimizers": (C.c_int, [H, C.c_int, C.c_void_p, C.c_void_p, u64p]),
+        "lqcov_get_chains": (C.c_int, [H, C.c_void_p, C.c_uint64, u64p]),
+        "lqcov_part_minimizers_dev": (C.c_int, [H, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), u64p]),
+        "lqcov_part_build_from_minimizers_dev": (C.c_int, [H, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32,
+                                                           C.c_void_p, C.c_void_p, C.c_void_p]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)          # AttributeError here == the library does not export the ABI
+        fn.restype = res
+        fn.argtypes = args
+    if lib.lqcov_abi_version() != 1:
+        raise OSError("liblqcov.so ABI version mismatch")
+    lib._sig_names = sorted(sig)
+    if path is None:
+        _LIB = lib
+    return lib
+
+
+def default_params(**kw) -> Params:
+    lib = load_library()
+    p = Params()
+    lib.lqcov_params_default(C.byref(p))
+    for k, v in kw.items():
+        if not hasattr(p, k):
+            raise AttributeError(k)
+        setattr(p, k, v)
+    return p
+
+
+def parse_args(argv: Sequence[str]) -> Tuple[Params, Optional[str], Optional[str]]:
+    """argv WITHOUT the program name, e.g. ['-Y','-l','0',...,'all.fq','sub.fq'] (longQC.py:440-445)."""
+    lib = load_library()
+    full = [b"minimap2-coverage"] + [str(a).encode() for a in argv]
+    arr = (C.c_char_p * len(full))(*full)
+    p = Params()
+    t, q, d = C.c_char_p(), C.c_char_p(), C.c_char_p()
+    err = C.create_string_buffer(256)
+    rc = lib.lqcov_parse_args(len(full), arr, C.byref(p), C.byref(t), C.byref(q), C.byref(d), err, 256)
+    if rc:
+        raise LqcovError(rc, err.value.decode())
+    return p, (t.value.decode() if t.value else None), (q.value.decode() if q.value else None)
+
+
+def _flat(seqs: Sequence[np.ndarray]) -> Tuple[np.ndarray, np.ndarray]:
+    off = np.zeros(len(seqs) + 1, dtype=np.uint64)
+    if len(seqs):
+        off[1:] = np.cumsum([int(s.shape[0]) for s in seqs], dtype=np.uint64)
+    flat = np.concatenate(seqs).astype(np.uint8, copy=False) if len(seqs) else np.zeros(0, dtype=np.uint8)
+    return np.ascontiguousarray(flat), off
+
+
+def _names(names: Sequence[str]) -> Tuple[bytes, np.ndarray]:
+    off = np.zeros(len(names) + 1, dtype=np.uint64)
+    parts = []
+    pos = 0
+    for i, n in enumerate(names):
+        b = n.encode() + b"\0"
+        parts.append(b)
+        pos += len(b)
+        off[i + 1] = pos
+    return b"".join(parts), off
+
+
+class Engine:
+    """One handle == one HIP device + stream (include/lqcov.h level 2)."""
+
+    def __init__(self, params: Optional[Params] = None, device: int = 0, lib=None):
+        self.lib = lib or load_library()
+        self.params = params or default_params(no_self=1)
+        self.h = self.lib.lqcov_create(C.byref(self.params), device)
+        if not self.h:
+            raise LqcovError(-3, self.lib.lqcov_last_error(None).decode() or "lqcov_create failed (no HIP device?)")
+        self._keep = []
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.lqcov_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc: int) -> int:
+        if rc < 0:
+            raise LqcovError(rc, self.lib.lqcov_last_error(self.h).decode())
+        return rc
+
+    # -- data in --
+    def set_queries(self, names: Sequence[str], seqs: Sequence[np.ndarray], quals: Optional[Sequence[np.ndarray]] = None):
+        flat, off = _flat(seqs)
+        nb, noff = _names(names)
+        q = None
+        if quals is not None:
+            q, _ = _flat(quals)
+        self._ck(self.lib.lqcov_set_queries(self.h, len(seqs), flat.ctypes.data, off.ctypes.data,
+                                            q.ctypes.data if q is not None else None, nb, noff.ctypes.data))
+
+    def part_begin(self) -> int:
+        return self._ck(self.lib.lqcov_part_begin(self.h))
+
+    def part_add_targets(self, part: int, names: Sequence[str], seqs: Sequence[np.ndarray]):
+        flat, off = _flat(seqs)
+        nb, noff = _names(names)
+        self._ck(self.lib.lqcov_part_add_targets(self.h, part, len(seqs), flat.ctypes.data, off.ctypes.data, nb, noff.ctypes.data))
+
+    def part_build(self, part: int):
+        self._ck(self.lib.lqcov_part_build(self.h, part))
+
+    def part_sketch(self, part: int):
+        self._ck(self.lib.lqcov_part_sketch(self.h, part))
+
+    def part_map(self, part: int):
+        self._ck(self.lib.lqcov_part_map(self.h, part))
+
+    def part_release(self, part: int):
+        self._ck(self.lib.lqcov_part_release(self.h, part))
+
+    def reset(self):
+        self._ck(self.lib.lqcov_reset(self.h))
+
+    def sync(self):
+        self._ck(self.lib.lqcov_sync(self.h))
+
+    def finish(self):
+        self._ck(self.lib.lqcov_finish(self.h))
+
+    def run_files(self, target: str, query: str, out: Optional[str] = None, err: Optional[str] = None):
+        self._ck(self.lib.lqcov_run_files(self.h, target.encode(), query.encode(),
+                                          out.encode() if out else None, err.encode() if err else None))
+
+    # -- results --
+    def rows(self) -> List[dict]:
+        n = self.lib.lqcov_n_queries(self.h)
+        arr = (Row * max(n, 1))()
+        self._ck(self.lib.lqcov_get_rows(self.h, arr, n))
+        rp, mp = C.c_void_p(), C.c_void_p()
+        nr, nm = C.c_uint32(), C.c_uint32()
+        self._ck(self.lib.lqcov_get_regions(self.h, C.byref(rp), C.byref(nr), C.byref(mp), C.byref(nm)))
+        regs = np.ctypeslib.as_array(C.cast(rp, C.POINTER(C.c_uint32)), shape=(nr.value, 2)).copy() if nr.value else np.zeros((0, 2), np.uint32)
+        mregs = np.ctypeslib.as_array(C.cast(mp, C.POINTER(C.c_uint32)), shape=(nm.value, 2)).copy() if nm.value else np.zeros((0, 2), np.uint32)
+        out = []
+        for i in range(n):
+            r = arr[i]
+            out.append(dict(lambda_=r.lambda_, lambda2=r.lambda2, qual_psum=r.qual_psum, qlen=r.qlen, n_mini=r.n_mini,
+                            n_match=r.n_match, avg_k=r.avg_k, flags=r.flags,
+                            regs=regs[r.reg_off:r.reg_off + r.n_reg].tolist(),
+                            mregs=mregs[r.mreg_off:r.mreg_off + r.n_mreg].tolist()))
+        return out
+
+    def write_table(self, path: str):
+        self._ck(self.lib.lqcov_write_table(self.h, path.encode()))
+
+    def table_text(self) -> str:
+        import tempfile
+        with tempfile.NamedTemporaryFile("r", suffix=".tsv") as f:
+            self.write_table(f.name)
+            return open(f.name).read()
+
+    # -- inspection --
+    @property
+    def mid_occ(self) -> int:
+        return int(self.lib.lqcov_mid_occ(self.h))
+
+    @property
+    def last_n_anchors(self) -> int:
+        return int(self.lib.lqcov_last_n_anchors(self.h))
+
+    def part_n_minimizers(self, part: int) -> int:
+        return int(self.lib.lqcov_part_n_minimizers(self.h, part))
+
+    def part_n_keys(self, part: int) -> int:
+        return int(self.lib.lqcov_part_n_keys(self.h, part))
+
+    def _minimizers(self, fn, *pre) -> Tuple[np.ndarray, np.ndarray]:
+        n = C.c_uint64()
+        self._ck(fn(self.h, *pre, None, None, C.byref(n)))
+        nq = self.lib.lqcov_n_queries(self.h) if not pre else None
+        xy = np.zeros((n.value, 2), dtype=np.uint64)
+        return xy, n
+
+    def query_minimizers(self) -> Tuple[np.ndarray, np.ndarray]:
+        n = C.c_uint64()
+        self._ck(self.lib.lqcov_get_query_minimizers(self.h, None, None, C.byref(n)))
+        xy = np.zeros((n.value, 2), dtype=np.uint64)
+        off = np.zeros(self.lib.lqcov_n_queries(self.h) + 1, dtype=np.uint64)
+        self._ck(self.lib.lqcov_get_query_minimizers(self.h, xy.ctypes.data, off.ctypes.data, C.byref(n)))
+        return xy, off
+
+    def part_minimizers(self, part: int, n_reads: int) -> Tuple[np.ndarray, np.ndarray]:
+        n = C.c_uint64()
+        self._ck(self.lib.lqcov_get_part_minimizers(self.h, part, None, None, C.byref(n)))
+        xy = np.zeros((n.value, 2), dtype=np.uint64)
+        off = np.zeros(n_reads + 1, dtype=np.uint64)
+        self._ck(self.lib.lqcov_get_part_minimizers(self.h, part, xy.ctypes.data, off.ctypes.data, C.byref(n)))
+        return xy, off
+
+    def set_debug(self, flags: int):
+        self._ck(self.lib.lqcov_set_debug(self.h, flags))
+
+    def chains(self) -> np.ndarray:
+        """(n,9) int32: query, rid, rev, score, cnt, qs, qe, rs, re of the last part_map (needs set_debug(1))."""
+        n = C.c_uint64()
+        self._ck(self.lib.lqcov_get_chains(self.h, None, 0, C.byref(n)))
+        out = np.zeros((n.value, 9), dtype=np.int32)
+        self._ck(self.lib.lqcov_get_chains(self.h, out.ctypes.data, n.value, C.byref(n)))
+        return out
+
+    def set_profiling(self, on: bool):
+        self._ck(self.lib.lqcov_set_profiling(self.h, 1 if on else 0))
+
+    def stage_times(self) -> List[dict]:
+        arr = (StageTime * 64)()
+        n = self._ck(self.lib.lqcov_get_stage_times(self.h, arr, 64))
+        return [dict(name=arr[i].name.decode(), total_ms=arr[i].total_ms, launches=arr[i].launches, algo_bytes=arr[i].algo_bytes)
+                for i in range(n)]
+
+    def part_minimizers_dev(self, part: int) -> Tuple[int, int, int]:
+        x, y, n = C.c_void_p(), C.c_void_p(), C.c_uint64()
+        self._ck(self.lib.lqcov_part_minimizers_dev(self.h, part, C.byref(x), C.byref(y), C.byref(n)))
+        return x.value or 0, y.value or 0, n.value
+
+    def part_build_from_minimizers_dev(self, part: int, x_ptr: int, y_ptr: int, n: int, target_len: np.ndarray, names: Sequence[str]):
+        tl = np.ascontiguousarray(target_len, dtype=np.uint32)
+        nb, noff = _names(names)
+        self._ck(self.lib.lqcov_part_build_from_minimizers_dev(self.h, part, x_ptr, y_ptr, n, len(tl), tl.ctypes.data, nb, noff.ctypes.data))

@@ -1,0 +1,366 @@
+// longqc_amd/csrc/api.cpp -- the C ABI of liblqcov.so (include/lqcov.h): argument handling of the
+// reference's option table (minimap2-coverage.c:63-197, defaults :229-388) and thin extern "C"
+// wrappers that turn C++ exceptions into status codes.
+#include "engine.hpp"
+#include <cstdio>
+#include <cstring>
+#include <cstdlib>
+#include <string>
+#include <stdexcept>
+#include <ios>
+#include <algorithm>
+#include <vector>
+
+static thread_local std::string g_create_error;
+
+template <class F> static int guard(lqcov_handle *h, F &&f)
+{
+	if (!h) return LQCOV_E_ARG;
+	try { f(); return 0; }
+	catch (const std::invalid_argument &e) { h->err = e.what(); return LQCOV_E_ARG; }
+	catch (const std::domain_error &e) { h->err = e.what(); return LQCOV_E_DOMAIN; }
+	catch (const std::logic_error &e) { h->err = e.what(); return LQCOV_E_STATE; }
+	catch (const std::ios_base::failure &e) { h->err = e.what(); return LQCOV_E_IO; }
+	catch (const std::runtime_error &e) {
+		h->err = e.what();
+		return h->err.find("failed to open") != std::string::npos ? LQCOV_E_IO : LQCOV_E_DEVICE;
+	}
+	catch (const std::exception &e) { h->err = e.what(); return LQCOV_E_DEVICE; }
+}
+
+extern "C" {
+
+int lqcov_abi_version(void) { return LQCOV_ABI_VERSION; }
+
+void lqcov_params_default(lqcov_params *p)
+{
+	memset(p, 0, sizeof(*p));
+	p->k = 12; p->w = 5; p->hpc = 0;                         // minimap2-coverage.c:252-266
+	p->batch_size = 4000000000ULL; p->idx_mini_batch = 50000000;   // index.c:35-36
+	p->max_gap = 10000; p->min_cnt = 3; p->min_chain_score = 40;   // :302-321
+	p->min_score_med = 40; p->min_score_good = 40;           // :324-332
+	p->max_chain_skip = 25; p->bw = 500;                     // :362-367, map.c:20
+	p->max_overhang = 2000; p->min_ovlp = 1000; p->min_coverage = 3; p->min_ratio = 0.4;   // :290-295, :369-388
+	p->mid_occ_frac = 2e-4f;                                 // map.c:16
+	p->no_self = 0; p->ava = 0; p->filter_flag = 0; p->n_threads = 1;
+}
+
+static int64_t parse_num(const char *str)                   // mm_parse_num (minimap2-coverage.c:22-31)
+{
+	char *p;
+	double x = strtod(str, &p);
+	if (*p == 'G' || *p == 'g') x *= 1e9;
+	else if (*p == 'M' || *p == 'm') x *= 1e6;
+	else if (*p == 'K' || *p == 'k') x *= 1e3;
+	return (int64_t)(x + .499);
+}
+
+struct LongOpt { const char *name; char key; };
+static const LongOpt kLong[] = {                            // minimap2-coverage.c:166-195
+	{"homopolymer", 'H'}, {"k-mer", 'k'}, {"window", 'w'}, {"index-size", 'I'}, {"dump-index", 'd'},
+	{"max-gap-length", 'g'}, {"min-cnt", 'n'}, {"min-score", 'm'}, {"min-score-t2", 'p'}, {"min-score-t3", 'q'},
+	{"max-chain-skip", 's'}, {"skip-self-ava", 'X'}, {"skip-self", 'Y'}, {"max-overhang", 'a'},
+	{"min-overlap-len", 'l'}, {"min-coverage", 'c'}, {"min-overlap-ratio", 'r'}, {"num-subset", 'u'},
+	{"threads", 't'}, {"minimizer-cnt", 'z'}, {"filter", 'f'},
+};
+
+int lqcov_parse_args(int argc, const char *const *argv, lqcov_params *p, const char **target, const char **query,
+                     const char **dump_path, char *errbuf, size_t errbuf_len)
+{
+	// "0 / -1 means default" exactly like the reference's ARGP_KEY_INIT block (minimap2-coverage.c:150-160)
+	int k = 0, w = 0, max_gap = 0, min_cnt = 0, m = 0, pm = 0, qg = 0, skip = -1, ohang = -1, ovlp = -1, cov = -1;
+	double ratio = 0.0;
+	uint64_t I = 0;
+	int X = 0, Y = 0, H = 0, f = 0, threads = 1;
+	const char *pos[2] = {nullptr, nullptr}, *dump = nullptr;
+	int npos = 0;
+	auto fail = [&](const std::string &msg) { if (errbuf && errbuf_len) snprintf(errbuf, errbuf_len, "%s", msg.c_str()); return LQCOV_E_ARG; };
+	auto apply = [&](char key, const char *v) -> bool {
+		switch (key) {
+		case 'H': H = 1; return true;
+		case 'X': X = 1; return true;
+		case 'Y': Y = 1; return true;
+		case 'f': f = 1; return true;
+		case 'z': return true;
+		case 'k': k = atoi(v); return true;
+		case 'w': w = atoi(v); return true;
+		case 'I': I = (uint64_t)parse_num(v); return true;
+		case 'd': dump = v; return true;
+		case 'g': max_gap = atoi(v); return true;
+		case 'n': min_cnt = atoi(v); return true;
+		case 'm': m = atoi(v); return true;
+		case 'p': pm = atoi(v); return true;
+		case 'q': qg = atoi(v); return true;
+		case 's': skip = atoi(v); return true;
+		case 'a': ohang = atoi(v); return true;
+		case 'l': ovlp = atoi(v); return true;
+		case 'c': cov = atoi(v); return true;
+		case 'r': ratio = atof(v); return true;
+		case 'u': return true;
+		case 't': threads = atoi(v); return true;
+		}
+		return false;
+	};
+	const std::string flags = "HXYfz";
+	for (int i = 1; i < argc; ++i) {
+		const char *a = argv[i];
+		if (a[0] == '-' && a[1] == '-' && a[2]) {
+			std::string name(a + 2), val;
+			bool has_val = false;
+			size_t eq = name.find('=');
+			if (eq != std::string::npos) { val = name.substr(eq + 1); name = name.substr(0, eq); has_val = true; }
+			char key = 0;
+			for (const LongOpt &lo : kLong) if (name == lo.name) key = lo.key;
+			if (!key) return fail("unrecognized option '--" + name + "'");
+			if (flags.find(key) != std::string::npos) { apply(key, nullptr); continue; }
+			if (!has_val) { if (i + 1 >= argc) return fail("option '--" + name + "' requires an argument"); val = argv[++i]; }
+			apply(key, val.c_str());
+		} else if (a[0] == '-' && a[1]) {
+			for (int j = 1; a[j]; ++j) {
+				char key = a[j];
+				if (flags.find(key) != std::string::npos) { apply(key, nullptr); continue; }
+				const char *v = a[j + 1] ? &a[j + 1] : (i + 1 < argc ? argv[++i] : nullptr);
+				if (!v) return fail(std::string("option requires an argument -- '") + key + "'");
+				if (!apply(key, v)) return fail(std::string("invalid option -- '") + key + "'");
+				break;
+			}
+		} else {
+			if (npos >= 2) return fail("too many arguments");
+			pos[npos++] = a;
+		}
+	}
+	if (!dump && npos < 2) return fail("not enough arguments: <target.seqs> <query.seqs>");
+	lqcov_params_default(p);
+	if (X && Y) return fail("Error: -X and -Y are mutually exclusive");
+	if (!X && !Y && !dump) return fail("Error: Choose either -X (all-vs-all) or -Y (all-vs-sub)");
+	if (X) { p->no_self = 1; p->ava = 1; } else if (Y) { p->no_self = 1; }
+	p->hpc = H;
+	if (k) p->k = k;
+	if (w) p->w = w;
+	if (I) p->batch_size = I;
+	if (cov != -1) p->min_coverage = cov;
+	if (max_gap) p->max_gap = max_gap;
+	if (min_cnt) p->min_cnt = min_cnt;
+	if (m) p->min_chain_score = m;
+	p->min_score_med = pm ? pm : p->min_chain_score;
+	p->min_score_good = qg ? qg : p->min_chain_score;
+	if (p->min_score_med < p->min_chain_score) return fail("Error: -p must be larger than or equal to -m.");
+	if (p->min_score_good < p->min_chain_score || p->min_score_good < p->min_score_med) return fail("Error: -q must be larger than or equal to -m and -p.");
+	if (skip != -1) p->max_chain_skip = skip;
+	if (ohang != -1) p->max_overhang = ohang;
+	if (ovlp != -1) p->min_ovlp = ovlp;
+	if (ratio != 0.0) p->min_ratio = ratio;
+	p->filter_flag = f;
+	p->n_threads = threads;
+	if (target) *target = pos[0];
+	if (query) *query = pos[1];
+	if (dump_path) *dump_path = dump;
+	return 0;
+}
+
+lqcov_handle *lqcov_create(const lqcov_params *p, int device)
+{
+	try { return new lqcov_handle(*p, device); }
+	catch (const std::exception &e) { g_create_error = e.what(); fprintf(stderr, "lqcov_create: %s\n", e.what()); return nullptr; }
+}
+void lqcov_destroy(lqcov_handle *h) { delete h; }
+const char *lqcov_last_error(const lqcov_handle *h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+int lqcov_set_profiling(lqcov_handle *h, int on) { if (!h) return LQCOV_E_ARG; h->profiling = on != 0; if (!on) { h->stages.clear(); h->stage_order.clear(); } return 0; }
+int lqcov_set_debug(lqcov_handle *h, unsigned flags) { if (!h) return LQCOV_E_ARG; h->debug_flags = flags; return 0; }
+
+int lqcov_get_stage_times(lqcov_handle *h, lqcov_stage_time *out, int max_out)
+{
+	if (!h) return LQCOV_E_ARG;
+	int n = 0;
+	for (const std::string &name : h->stage_order) {
+		if (n >= max_out) break;
+		const StageAcc &s = h->stages[name];
+		memset(&out[n], 0, sizeof(out[n]));
+		snprintf(out[n].name, sizeof(out[n].name), "%s", name.c_str());
+		out[n].total_ms = s.ms; out[n].launches = s.launches; out[n].algo_bytes = s.bytes;
+		++n;
+	}
+	return n;
+}
+
+int lqcov_set_queries(lqcov_handle *h, uint32_t n, const uint8_t *seq, const uint64_t *seq_off, const uint8_t *qual, const char *names, const uint64_t *name_off)
+{
+	return guard(h, [&] { if (!seq_off || (n && !seq)) throw std::invalid_argument("null read buffers"); h->set_queries(n, seq, seq_off, qual, names, name_off); });
+}
+
+int lqcov_part_begin(lqcov_handle *h)
+{
+	int id = -1;
+	int rc = guard(h, [&] { h->parts.emplace_back(new Part()); id = (int)h->parts.size() - 1; h->parts[id]->live = true; });
+	return rc ? rc : id;
+}
+
+int lqcov_part_add_targets(lqcov_handle *h, int part, uint32_t n, const uint8_t *seq, const uint64_t *seq_off, const char *names, const uint64_t *name_off)
+{
+	return guard(h, [&] {
+		if (!seq_off || (n && !seq)) throw std::invalid_argument("null read buffers");
+		Part &pt = h->part(part);
+		if (pt.built) throw std::logic_error("part already built");
+		h->add_reads(pt.rs, n, seq, seq_off, names, name_off);
+	});
+}
+
+int lqcov_part_build(lqcov_handle *h, int part) { return guard(h, [&] { h->build_part(h->part(part)); }); }
+int lqcov_part_map(lqcov_handle *h, int part) { return guard(h, [&] { h->map_part(h->part(part)); }); }
+int lqcov_part_release(lqcov_handle *h, int part) { return guard(h, [&] { h->part(part); h->parts[part].reset(); }); }
+int lqcov_reset(lqcov_handle *h) { return guard(h, [&] { if (!h->have_queries) throw std::logic_error("no queries"); h->reset(); }); }
+int lqcov_sync(lqcov_handle *h) { return guard(h, [&] { LQ_HIP_CHECK(hipStreamSynchronize(h->stream)); }); }
+int lqcov_finish(lqcov_handle *h) { return guard(h, [&] { if (!h->have_queries) throw std::logic_error("no queries"); h->finish(); }); }
+int lqcov_n_queries(const lqcov_handle *h) { return h ? (int)h->q.n : LQCOV_E_ARG; }
+
+int lqcov_get_rows(lqcov_handle *h, lqcov_row *rows, uint32_t n_rows)
+{
+	return guard(h, [&] {
+		if (!h->finished) throw std::logic_error("finish() has not run");
+		if (n_rows < h->rows.size()) throw std::invalid_argument("row buffer too small");
+		if (!h->rows.empty()) memcpy(rows, h->rows.data(), h->rows.size() * sizeof(lqcov_row));
+	});
+}
+
+int lqcov_get_regions(lqcov_handle *h, const lqcov_region **regs, uint32_t *n_regs, const lqcov_region **mregs, uint32_t *n_mregs)
+{
+	return guard(h, [&] {
+		if (!h->finished) throw std::logic_error("finish() has not run");
+		*regs = h->regs.data(); *n_regs = (uint32_t)h->regs.size(); *mregs = h->mregs.data(); *n_mregs = (uint32_t)h->mregs.size();
+	});
+}
+
+int lqcov_write_table(lqcov_handle *h, const char *out_path)
+{
+	return guard(h, [&] {
+		FILE *o = out_path ? fopen(out_path, "w") : stdout;
+		if (!o) throw std::runtime_error(std::string("failed to open file '") + out_path + "'");
+		try { h->write_table(o); } catch (...) { if (out_path) fclose(o); throw; }
+		if (out_path) fclose(o); else fflush(o);
+	});
+}
+
+int32_t lqcov_mid_occ(const lqcov_handle *h) { return h ? h->mid_occ : -1; }
+uint64_t lqcov_part_n_minimizers(const lqcov_handle *h, int part) { return (h && part >= 0 && (size_t)part < h->parts.size() && h->parts[part]) ? h->parts[part]->rs.n_mini : 0; }
+uint64_t lqcov_part_n_keys(const lqcov_handle *h, int part) { return (h && part >= 0 && (size_t)part < h->parts.size() && h->parts[part]) ? h->parts[part]->n_keys : 0; }
+uint64_t lqcov_last_n_anchors(const lqcov_handle *h) { return h ? h->last_n_anchors : 0; }
+
+static void copy_minimizers(lqcov_handle *h, ReadSetDev &rs, uint64_t *xy, uint64_t *off, uint64_t *n_total)
+{
+	if (!rs.sketched) throw std::logic_error("read set not sketched");
+	if (n_total) *n_total = rs.n_mini;
+	if (off) { LQ_HIP_CHECK(hipMemcpy(off, rs.moff.p, (rs.n + 1) * 8, hipMemcpyDeviceToHost)); }
+	if (xy && rs.n_mini) {
+		std::vector<u64> x(rs.n_mini), y(rs.n_mini);
+		LQ_HIP_CHECK(hipMemcpy(x.data(), rs.mx.p, rs.n_mini * 8, hipMemcpyDeviceToHost));
+		LQ_HIP_CHECK(hipMemcpy(y.data(), rs.my.p, rs.n_mini * 8, hipMemcpyDeviceToHost));
+		for (u64 i = 0; i < rs.n_mini; ++i) { xy[2 * i] = x[i]; xy[2 * i + 1] = y[i]; }
+	}
+}
+
+int lqcov_get_query_minimizers(lqcov_handle *h, uint64_t *xy, uint64_t *off, uint64_t *n_total)
+{
+	return guard(h, [&] { if (!h->have_queries) throw std::logic_error("no queries"); copy_minimizers(h, h->q, xy, off, n_total); });
+}
+int lqcov_get_part_minimizers(lqcov_handle *h, int part, uint64_t *xy, uint64_t *off, uint64_t *n_total)
+{
+	return guard(h, [&] { copy_minimizers(h, h->part(part).rs, xy, off, n_total); });
+}
+
+int lqcov_get_chains(lqcov_handle *h, int32_t *out, uint64_t cap, uint64_t *n_total)
+{
+	return guard(h, [&] {
+		if (!(h->debug_flags & 1)) throw std::logic_error("chain recording is off (lqcov_set_debug(h, 1))");
+		if (n_total) *n_total = h->n_dbg_host;
+		u64 n = std::min<u64>(h->n_dbg_host, std::min<u64>(cap, h->dbg_cap));
+		static_assert(sizeof(ChainRec) == 9 * sizeof(int32_t), "chain record layout");
+		if (out && n) LQ_HIP_CHECK(hipMemcpy(out, h->dbg_chains.p, n * sizeof(ChainRec), hipMemcpyDeviceToHost));
+	});
+}
+
+int lqcov_part_minimizers_dev(lqcov_handle *h, int part, const uint64_t **x_dev, const uint64_t **y_dev, uint64_t *n)
+{
+	return guard(h, [&] {
+		Part &pt = h->part(part);
+		if (!pt.rs.sketched) throw std::logic_error("part not sketched");
+		*x_dev = pt.rs.mx.as<u64>(); *y_dev = pt.rs.my.as<u64>(); *n = pt.rs.n_mini;
+	});
+}
+
+int lqcov_part_sketch(lqcov_handle *h, int part)
+{
+	return guard(h, [&] { if (!h->have_queries) throw std::logic_error("set the queries first"); h->sketch(h->part(part).rs, true); });
+}
+
+int lqcov_part_build_from_minimizers_dev(lqcov_handle *h, int part, const uint64_t *x_dev, const uint64_t *y_dev, uint64_t n,
+                                         uint32_t n_targets, const uint32_t *target_len, const char *names, const uint64_t *name_off)
+{
+	return guard(h, [&] {
+		Part &pt = h->part(part);
+		ReadSetDev &rs = pt.rs;
+		rs.mx.ensure(n * 8 + 8); rs.my.ensure(n * 8 + 8);
+		if (n) {
+			LQ_HIP_CHECK(hipMemcpyAsync(rs.mx.p, x_dev, n * 8, hipMemcpyDeviceToDevice, h->stream));
+			LQ_HIP_CHECK(hipMemcpyAsync(rs.my.p, y_dev, n * 8, hipMemcpyDeviceToDevice, h->stream));
+		}
+		rs.n_mini = n; rs.n = n_targets;
+		rs.h_len.assign(target_len, target_len + n_targets);
+		rs.names.clear();
+		for (uint32_t i = 0; i < n_targets; ++i) rs.names.emplace_back(names ? names + name_off[i] : "");
+		rs.d_len.ensure((n_targets + 1) * 4);
+		if (n_targets) LQ_HIP_CHECK(hipMemcpyAsync(rs.d_len.p, target_len, n_targets * 4, hipMemcpyHostToDevice, h->stream));
+		LQ_HIP_CHECK(hipStreamSynchronize(h->stream));
+		rs.sketched = true;
+		h->build_index(pt);
+	});
+}
+
+int lqcov_run_files(lqcov_handle *h, const char *target, const char *query, const char *out_path, const char *err_path)
+{
+	return guard(h, [&] {
+		FILE *o = out_path ? fopen(out_path, "w") : stdout;
+		if (!o) throw std::runtime_error(std::string("failed to open file '") + out_path + "'");
+		FILE *e = err_path ? fopen(err_path, "a") : stderr;
+		try { h->run_files(target, query, o, e); }
+		catch (...) { if (out_path) fclose(o); if (err_path && e) fclose(e); throw; }
+		if (out_path) fclose(o); else fflush(o);
+		if (err_path && e) fclose(e);
+	});
+}
+
+// == the subprocess (minimap2-coverage.c:206-734)
+int lqcov_main(int argc, const char *const *argv, const char *out_path, const char *err_path, int device)
+{
+	FILE *e = err_path ? fopen(err_path, "w") : stderr;
+	if (!e) return 1;
+	lqcov_params p;
+	const char *target = nullptr, *query = nullptr, *dump = nullptr;
+	char errbuf[256] = {0};
+	int rc = lqcov_parse_args(argc, argv, &p, &target, &query, &dump, errbuf, sizeof(errbuf));
+	if (rc) { fprintf(e, "%s\n", errbuf); if (err_path) fclose(e); return 1; }
+	if (dump) { fprintf(e, "Error: -d (index dump) is not implemented by the MI355X engine yet.\n"); if (err_path) fclose(e); return 1; }
+	// effective parameters, as the reference echoes them (minimap2-coverage.c:392-404)
+	fprintf(e, "=== Parameters are listed below === \nInputs are target: %s, query: %s\n", target, query);
+	fprintf(e, "kmer %d, window %d, index loading size %llu\n", p.k, p.w, (unsigned long long)p.batch_size);
+	fprintf(e, "min-score %d, min-score-med %d, min-score-good %d, max-gap %d, min-cnt %d\n", p.min_chain_score, p.min_score_med, p.min_score_good, p.max_gap, p.min_cnt);
+	fprintf(e, "Homo-polymer compression: %d, Filtering: %d\n", p.hpc, p.filter_flag);
+	fprintf(e, "max-overhang %d, min-overlaplen %d, min-overapratio %.2f\n===\n", p.max_overhang, p.min_ovlp, p.min_ratio);
+	fflush(e);
+	{	// unopenable target: exit 1 with the reference's message (minimap2-coverage.c:276-279)
+		FILE *t = fopen(target, "rb");
+		if (!t) { fprintf(e, "ERROR: failed to open file '%s'\n", target); if (err_path) fclose(e); return 1; }
+		fclose(t);
+	}
+	lqcov_handle *h = lqcov_create(&p, device);
+	if (!h) { fprintf(e, "ERROR: %s\n", g_create_error.c_str()); if (err_path) fclose(e); return LQCOV_E_DEVICE; }
+	if (err_path) { fclose(e); e = nullptr; }
+	rc = lqcov_run_files(h, target, query, out_path, err_path);
+	if (rc) {
+		FILE *e2 = err_path ? fopen(err_path, "a") : stderr;
+		if (e2) { fprintf(e2, "ERROR: %s\n", h->err.c_str()); if (err_path) fclose(e2); }
+	}
+	lqcov_destroy(h);
+	return rc == 0 ? 0 : (rc == LQCOV_E_IO ? 1 : rc);
+}
+
+} // extern "C"

@@ -1,0 +1,618 @@
+// longqc_amd/csrc/engine.cpp -- see engine.hpp.  Compiled by hipcc for gfx950 (liblqcov.so).
+#include "engine.hpp"
+#include "kernels_sketch.hpp"
+#include "kernels_index.hpp"
+#include "kernels_sort.hpp"
+#include "kernels_chain.hpp"
+#include "fastx.hpp"
+#include <cstdio>
+#include <cstring>
+#include <cmath>
+#include <cinttypes>
+#include <algorithm>
+#include <unordered_map>
+
+static inline u32 nblk(u64 n, u32 bs)
+{
+	u64 b = (n + bs - 1) / bs;
+	if (b > 0x7fffffffULL) throw std::runtime_error("launch too large");
+	return (u32)b;
+}
+
+template <class T> static void h2d(T *dst, const T *src, size_t n, hipStream_t s)
+{
+	if (n) LQ_HIP_CHECK(hipMemcpyAsync(dst, src, n * sizeof(T), hipMemcpyHostToDevice, s));
+}
+template <class T> static void d2h(T *dst, const T *src, size_t n, hipStream_t s)
+{
+	if (n) { LQ_HIP_CHECK(hipMemcpyAsync(dst, src, n * sizeof(T), hipMemcpyDeviceToHost, s)); LQ_HIP_CHECK(hipStreamSynchronize(s)); }
+}
+static void dzero(void *p, size_t bytes, hipStream_t s) { if (bytes) LQ_HIP_CHECK(hipMemsetAsync(p, 0, bytes, s)); }
+static void check_launch() { LQ_HIP_CHECK(hipGetLastError()); }
+
+// ---- stage timing ---------------------------------------------------------------------------
+StageTimer::StageTimer(lqcov_handle *h_, const char *name_, u64 bytes_) : h(h_), name(name_), bytes(bytes_)
+{
+	if (!h->profiling) return;
+	hipEventCreate(&a); hipEventCreate(&b);
+	hipEventRecord(a, h->stream);
+}
+StageTimer::~StageTimer()
+{
+	if (!h->profiling) return;
+	hipEventRecord(b, h->stream);
+	hipEventSynchronize(b);
+	float ms = 0; hipEventElapsedTime(&ms, a, b);
+	hipEventDestroy(a); hipEventDestroy(b);
+	auto it = h->stages.find(name);
+	if (it == h->stages.end()) { h->stage_order.push_back(name); it = h->stages.emplace(name, StageAcc()).first; }
+	it->second.ms += ms; it->second.launches += 1; it->second.bytes += bytes;
+}
+
+// ---- handle ---------------------------------------------------------------------------------
+lqcov_handle::lqcov_handle(const lqcov_params &p, int dev) : P(p), device(dev)
+{
+	if (P.k < 1 || P.k > 28 || P.w < 1 || P.w > 255) throw std::invalid_argument("k must be in [1,28] and w in [1,255] (sketch.c:83)");
+	if (P.min_score_med >= 65536 || P.min_score_good >= 65536 || P.min_score_med < 0 || P.min_score_good < 0)
+		throw std::invalid_argument("-p and -q must be below 65536 (lqmap.c:841 packs them into 16 bits each)");
+	if (P.ava) throw std::invalid_argument("-X (all-vs-all, MM_F_AVA) is outside the sampleqc path and not supported; use -Y");
+	int ndev = 0;
+	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) throw std::runtime_error("no HIP device available");
+	if (dev < 0 || dev >= ndev) throw std::runtime_error("HIP device index out of range");
+	LQ_HIP_CHECK(hipSetDevice(dev));
+	LQ_HIP_CHECK(hipStreamCreate(&stream));
+	prim.stream = stream;
+	mp.k = P.k; mp.w = P.w; mp.hpc = P.hpc;
+	mp.max_gap = P.max_gap; mp.bw = P.bw; mp.max_skip = P.max_chain_skip; mp.min_cnt = P.min_cnt; mp.min_sc = P.min_chain_score;
+	mp.min_sc_med = P.min_score_med; mp.min_sc_good = P.min_score_good;
+	mp.max_overhang = P.max_overhang; mp.min_coverage = P.min_coverage; mp.min_ratio = P.min_ratio;
+	mp.no_self = P.no_self; mp.ava = P.ava;
+	const char *e = getenv("LQCOV_ANCHOR_BUDGET");
+	anchor_budget = e ? strtoull(e, 0, 10) : 0;
+	if (anchor_budget == 0) {
+		size_t fr = 0, tot = 0;
+		hipMemGetInfo(&fr, &tot);
+		anchor_budget = (u64)(fr / 2 / 96);                // ~96 B of work space per anchor, use half of free HBM
+	}
+	if (anchor_budget > (1ULL << 31)) anchor_budget = 1ULL << 31;
+	if (anchor_budget < 1024) anchor_budget = 1024;
+}
+
+lqcov_handle::~lqcov_handle()
+{
+	if (stream) { hipStreamSynchronize(stream); hipStreamDestroy(stream); }
+}
+
+Part &lqcov_handle::part(int id)
+{
+	if (id < 0 || (size_t)id >= parts.size() || !parts[id] || !parts[id]->live) throw std::logic_error("no such index part");
+	return *parts[id];
+}
+
+// ---- read sets ------------------------------------------------------------------------------
+static void grow_keep(DBuf &b, size_t old_bytes, size_t new_bytes, hipStream_t s)
+{
+	if (new_bytes <= b.cap) return;
+	void *np = nullptr;
+	size_t want = new_bytes + new_bytes / 2 + 4096;
+	LQ_HIP_CHECK(hipMalloc(&np, want));
+	if (old_bytes) LQ_HIP_CHECK(hipMemcpyAsync(np, b.p, old_bytes, hipMemcpyDeviceToDevice, s));
+	LQ_HIP_CHECK(hipStreamSynchronize(s));
+	if (b.p) hipFree(b.p);
+	b.p = np; b.cap = want;
+}
+
+// upload n reads (ASCII) and append them, 2-bit packed, to the set   (index.c:240-288 step 0)
+void lqcov_handle::add_reads(ReadSetDev &rs, u32 n, const u8 *seq, const u64 *seq_off, const char *names, const u64 *name_off)
+{
+	if (n == 0) return;
+	if ((u64)rs.n + n > 0x7fffffffULL) throw std::domain_error("too many reads in one set");
+	std::vector<u64> coff_local(n + 1, 0);
+	for (u32 i = 0; i < n; ++i) {
+		u64 len = seq_off[i + 1] - seq_off[i];
+		if (len > 0x7fffffffULL) throw std::domain_error("read longer than 2^31-1 bases (bseq.c:80)");
+		coff_local[i + 1] = coff_local[i] + (len + LQ_CHUNK - 1) / LQ_CHUNK;
+		rs.h_len.push_back((u32)len);
+		rs.h_coff.push_back(rs.n_chunks + coff_local[i + 1]);
+		rs.names.emplace_back(names ? names + name_off[i] : "");
+	}
+	const u64 n_bases = seq_off[n] - seq_off[0], new_chunks = coff_local[n], n_words = new_chunks * LQ_CHUNK_WORDS;
+	DBuf d_ascii, d_soff, d_coff;
+	d_ascii.ensure(n_bases + 16); d_soff.ensure((n + 1) * 8); d_coff.ensure((n + 1) * 8);
+	std::vector<u64> soff(n + 1);
+	for (u32 i = 0; i <= n; ++i) soff[i] = seq_off[i] - seq_off[0];
+	h2d(d_ascii.as<u8>(), seq + seq_off[0], n_bases, stream);
+	h2d(d_soff.as<u64>(), soff.data(), n + 1, stream);
+	h2d(d_coff.as<u64>(), coff_local.data(), n + 1, stream);
+	grow_keep(rs.codes, rs.n_chunks * LQ_CHUNK_WORDS * 8, (rs.n_chunks + new_chunks) * LQ_CHUNK_WORDS * 8, stream);
+	grow_keep(rs.amb, rs.n_chunks * LQ_CHUNK_WORDS * 4, (rs.n_chunks + new_chunks) * LQ_CHUNK_WORDS * 4, stream);
+	if (n_words) {
+		StageTimer t(this, "k_pack", n_bases + n_words * 12);
+		LQ_LAUNCH(k_pack, nblk(n_words, 256), 256, stream, d_ascii.as<u8>(), d_soff.as<u64>(), d_coff.as<u64>(), n, n_words,
+		          rs.codes.as<u64>() + rs.n_chunks * LQ_CHUNK_WORDS, rs.amb.as<u32>() + rs.n_chunks * LQ_CHUNK_WORDS);
+		check_launch();
+	}
+	LQ_HIP_CHECK(hipStreamSynchronize(stream));              // staging buffers die here
+	rs.n += n; rs.n_chunks += new_chunks; rs.n_bases += n_bases;
+	rs.sketched = false;
+}
+
+// minimizers of every read of the set, in (read, position) order   (sketch.c:76-142)
+void lqcov_handle::sketch(ReadSetDev &rs, bool rid_in_y)
+{
+	rs.d_coff.ensure((rs.n + 1) * 8); rs.d_len.ensure((rs.n + 1) * 4);
+	h2d(rs.d_coff.as<u64>(), rs.h_coff.data(), rs.n + 1, stream);
+	h2d(rs.d_len.as<u32>(), rs.h_len.data(), rs.n, stream);
+	rs.moff.ensure((rs.n + 1) * 8);
+	rs.n_mini = 0;
+	const u64 nc = rs.n_chunks;
+	if (nc) {
+		SkParams sp; sp.k = P.k; sp.w = P.w; sp.hpc = P.hpc; sp.mask = (1ULL << 2 * P.k) - 1; sp.shift1 = 2 * (P.k - 1);
+		DBuf cnt, off;
+		cnt.ensure(nc * 4); off.ensure(nc * 8);
+		const u64 in_bytes = nc * (LQ_CHUNK_WORDS * 12);
+		{
+			StageTimer t(this, "k_sketch_count", in_bytes + nc * 4);
+			if (P.w <= 16) LQ_LAUNCH((k_sketch<16, false>), nblk(nc, 256), 256, stream, rs.codes.as<u64>(), rs.amb.as<u32>(), rs.d_coff.as<u64>(), rs.d_len.as<u32>(), rs.n, nc, sp, (int)rid_in_y, cnt.as<u32>(), (const u64*)nullptr, (u64*)nullptr, (u64*)nullptr);
+			else LQ_LAUNCH((k_sketch<256, false>), nblk(nc, 64), 64, stream, rs.codes.as<u64>(), rs.amb.as<u32>(), rs.d_coff.as<u64>(), rs.d_len.as<u32>(), rs.n, nc, sp, (int)rid_in_y, cnt.as<u32>(), (const u64*)nullptr, (u64*)nullptr, (u64*)nullptr);
+			check_launch();
+		}
+		{ StageTimer t(this, "scan"); prim.exclusive_scan_u32_u64(cnt.as<u32>(), off.as<u64>(), nc); }
+		u64 last_off = 0; u32 last_cnt = 0;
+		d2h(&last_off, off.as<u64>() + nc - 1, 1, stream);
+		d2h(&last_cnt, cnt.as<u32>() + nc - 1, 1, stream);
+		rs.n_mini = last_off + last_cnt;
+		rs.mx.ensure(rs.n_mini * 8 + 8); rs.my.ensure(rs.n_mini * 8 + 8);
+		{
+			StageTimer t(this, "k_sketch_emit", in_bytes + nc * 8 + rs.n_mini * 16);
+			if (P.w <= 16) LQ_LAUNCH((k_sketch<16, true>), nblk(nc, 256), 256, stream, rs.codes.as<u64>(), rs.amb.as<u32>(), rs.d_coff.as<u64>(), rs.d_len.as<u32>(), rs.n, nc, sp, (int)rid_in_y, (u32*)nullptr, off.as<u64>(), rs.mx.as<u64>(), rs.my.as<u64>());
+			else LQ_LAUNCH((k_sketch<256, true>), nblk(nc, 64), 64, stream, rs.codes.as<u64>(), rs.amb.as<u32>(), rs.d_coff.as<u64>(), rs.d_len.as<u32>(), rs.n, nc, sp, (int)rid_in_y, (u32*)nullptr, off.as<u64>(), rs.mx.as<u64>(), rs.my.as<u64>());
+			check_launch();
+		}
+		LQ_LAUNCH(k_read_moff, nblk(rs.n + 1, 256), 256, stream, rs.d_coff.as<u64>(), off.as<u64>(), rs.n, nc, rs.n_mini, rs.moff.as<u64>());
+		check_launch();
+		LQ_HIP_CHECK(hipStreamSynchronize(stream));
+	} else {
+		dzero(rs.moff.p, (rs.n + 1) * 8, stream);
+	}
+	rs.sketched = true;
+}
+
+// meanQ's table (lqutils.c:26-49): 10^(-q/10) rounded to 15 decimals, Q0..Q126
+static void make_q2p(double *t)
+{
+	for (int q = 0; q < 127; ++q) {
+		char buf[64];
+		snprintf(buf, sizeof(buf), "%.15f", pow(10.0, -q / 10.0));
+		t[q] = strtod(buf, nullptr);
+	}
+}
+
+// == main pass 1 (minimap2-coverage.c:406-444)
+void lqcov_handle::set_queries(u32 n, const u8 *seq, const u64 *seq_off, const u8 *qual, const char *names, const u64 *name_off)
+{
+	if (have_queries) throw std::logic_error("queries already set");
+	if (seq_off[n] - seq_off[0] >= 500000000ULL && n > 1) {
+		// reference: a second 500-Mbase query mini-batch aliases the accumulator slots and crashes (lqmap.c:714,735)
+		u64 but_last = seq_off[n - 1] - seq_off[0];
+		if (but_last >= 500000000ULL) throw std::domain_error("query set spans more than one 500-Mbase mini-batch: outside the reference's domain (lqmap.c:714)");
+	}
+	add_reads(q, n, seq, seq_off, names, name_off);
+	q.n = n;                                                // (add_reads returns early for n == 0)
+	sketch(q, false);
+	have_queries = true;
+	q_has_qual = qual != nullptr;
+	const u64 nm = q.n_mini;
+	q_owner.ensure(nm * 4 + 4);
+	if (nm) { LQ_LAUNCH(k_minimizer_owner, nblk(nm, 256), 256, stream, q.moff.as<u64>(), n, nm, q_owner.as<u32>()); check_launch(); }
+	lambda.ensure((n + 1) * 8); lambda2.ensure((n + 1) * 8); avg_k.ensure((n + 1) * 4); qflags.ensure((n + 1) * 4);
+	cnts.ensure(nm * 4 + 4); qual_psum.ensure((n + 1) * 8);
+	n_pv.ensure(4);
+	reset();
+	dzero(qual_psum.p, (n + 1) * 8, stream);
+	if (qual && n) {
+		const u64 nb = seq_off[n] - seq_off[0];
+		DBuf dq, dso, dtab;
+		dq.ensure(nb + 16); dso.ensure((n + 1) * 8); dtab.ensure(127 * 8);
+		std::vector<u64> soff(n + 1);
+		for (u32 i = 0; i <= n; ++i) soff[i] = seq_off[i] - seq_off[0];
+		double tab[127]; make_q2p(tab);
+		h2d(dq.as<u8>(), qual + seq_off[0], nb, stream);
+		h2d(dso.as<u64>(), soff.data(), n + 1, stream);
+		h2d(dtab.as<double>(), tab, 127, stream);
+		{
+			StageTimer t(this, "k_qual_sum", nb);
+			LQ_LAUNCH(k_qual_sum, nblk(n, 64), 64, stream, dq.as<u8>(), dso.as<u64>(), n, dtab.as<double>(), qual_psum.as<double>());
+			check_launch();
+		}
+		LQ_HIP_CHECK(hipStreamSynchronize(stream));
+	}
+}
+
+void lqcov_handle::reset()
+{
+	const u32 n = q.n;
+	dzero(lambda.p, (n + 1) * 8, stream); dzero(lambda2.p, (n + 1) * 8, stream);
+	dzero(avg_k.p, (n + 1) * 4, stream); dzero(qflags.p, (n + 1) * 4, stream);
+	dzero(cnts.p, q.n_mini * 4 + 4, stream);
+	dzero(n_pv.p, 4, stream);
+	mid_occ = -1;
+	finished = false;
+	LQ_HIP_CHECK(hipStreamSynchronize(stream));
+}
+
+// ---- index part -------------------------------------------------------------------------------
+// hash -> occurrences sorted by y (index.c:150-201), mid_occ (index.c:123-144)
+void lqcov_handle::build_index(Part &pt)
+{
+	ReadSetDev &rs = pt.rs;
+	const u64 M = rs.n_mini;
+	pt.n_keys = 0; pt.cap_bits = 4;
+	pt.pos.ensure(M * 8 + 8);
+	if (M) {
+		DBuf key, key2, head, uidx, ukey, ustart, ucnt;
+		key.ensure(M * 8); key2.ensure(M * 8); head.ensure(M * 4); uidx.ensure(M * 8);
+		LQ_LAUNCH(k_sort_keys, nblk(M, 256), 256, stream, rs.mx.as<u64>(), M, key.as<u64>()); check_launch();
+		{ StageTimer t(this, "index_radix_sort", M * 32); prim.sort_pairs_u64(key.as<u64>(), key2.as<u64>(), rs.my.as<u64>(), pt.pos.as<u64>(), M, (unsigned)(2 * P.k)); }
+		LQ_LAUNCH(k_mark_heads, nblk(M, 256), 256, stream, key2.as<u64>(), M, head.as<u32>()); check_launch();
+		prim.exclusive_scan_u32_u64(head.as<u32>(), uidx.as<u64>(), M);
+		u64 lu = 0; u32 lh = 0;
+		d2h(&lu, uidx.as<u64>() + M - 1, 1, stream); d2h(&lh, head.as<u32>() + M - 1, 1, stream);
+		const u64 K = lu + lh;
+		pt.n_keys = K;
+		ukey.ensure(K * 8); ustart.ensure(K * 8); ucnt.ensure(K * 4);
+		LQ_LAUNCH(k_fill_unique, nblk(M, 256), 256, stream, key2.as<u64>(), head.as<u32>(), uidx.as<u64>(), M, ukey.as<u64>(), ustart.as<u64>()); check_launch();
+		LQ_LAUNCH(k_unique_counts, nblk(K, 256), 256, stream, ustart.as<u64>(), K, M, ucnt.as<u32>()); check_launch();
+		u32 bits = 4;
+		while (((u64)1 << bits) < 2 * K) ++bits;
+		pt.cap_bits = bits;
+		const u64 cap = (u64)1 << bits;
+		pt.tkey.ensure(cap * 8); pt.tstart.ensure(cap * 8); pt.tcnt.ensure(cap * 4);
+		LQ_HIP_CHECK(hipMemsetAsync(pt.tkey.p, 0xff, cap * 8, stream));
+		{
+			StageTimer t(this, "k_table_insert", K * 20 + cap * 8);
+			LQ_LAUNCH(k_table_insert, nblk(K, 256), 256, stream, ukey.as<u64>(), ustart.as<u64>(), ucnt.as<u32>(), K, pt.tkey.as<u64>(), pt.tstart.as<u64>(), pt.tcnt.as<u32>(), bits);
+			check_launch();
+		}
+		if (mid_occ <= 0) {                                   // map.c:50: from the first part only
+			if (P.mid_occ_frac <= 0.0f) mid_occ = INT32_MAX;
+			else {
+				DBuf sorted; sorted.ensure(K * 4);
+				prim.sort_keys_u32(ucnt.as<u32>(), sorted.as<u32>(), K);
+				const u32 kth = (u32)((1. - P.mid_occ_frac) * (double)K);   // index.c:141
+				u32 v = 0;
+				d2h(&v, sorted.as<u32>() + kth, 1, stream);
+				mid_occ = (i32)(v + 1);
+			}
+		}
+		LQ_HIP_CHECK(hipStreamSynchronize(stream));
+	} else {
+		const u64 cap = (u64)1 << pt.cap_bits;
+		pt.tkey.ensure(cap * 8); pt.tstart.ensure(cap * 8); pt.tcnt.ensure(cap * 4);
+		LQ_HIP_CHECK(hipMemsetAsync(pt.tkey.p, 0xff, cap * 8, stream));
+		if (mid_occ <= 0) mid_occ = P.mid_occ_frac <= 0.0f ? INT32_MAX : 1;   // reference reads an empty array here; unobservable
+	}
+	// same-name targets per query (self diagonal, lqmap.c:180-186)
+	std::vector<u32> soff(q.n + 1, 0), srid;
+	if (P.no_self && q.n) {
+		std::unordered_map<std::string, std::vector<u32>> byname;
+		for (u32 i = 0; i < q.n; ++i) byname[q.names[i]].push_back(i);
+		std::vector<std::vector<u32>> per(q.n);
+		for (u32 r = 0; r < rs.n; ++r) {
+			auto it = byname.find(rs.names[r]);
+			if (it != byname.end()) for (u32 qi : it->second) per[qi].push_back(r);
+		}
+		for (u32 i = 0; i < q.n; ++i) { soff[i + 1] = soff[i] + (u32)per[i].size(); srid.insert(srid.end(), per[i].begin(), per[i].end()); }
+	}
+	pt.self_off.ensure((q.n + 1) * 4); pt.self_rid.ensure(srid.size() * 4 + 4);
+	h2d(pt.self_off.as<u32>(), soff.data(), q.n + 1, stream);
+	h2d(pt.self_rid.as<u32>(), srid.data(), srid.size(), stream);
+	LQ_HIP_CHECK(hipStreamSynchronize(stream));
+	pt.built = true;
+}
+
+void lqcov_handle::build_part(Part &pt)
+{
+	if (!have_queries) throw std::logic_error("set the queries before building a part");
+	sketch(pt.rs, true);
+	build_index(pt);
+}
+
+// ---- map every query against one part (lqmap.c:207-326) -----------------------------------------
+void lqcov_handle::map_part(Part &pt)
+{
+	if (!pt.built) throw std::logic_error("part not built");
+	finished = false;
+	const u32 n_q = q.n;
+	const u64 n_qm = q.n_mini;
+	last_n_anchors = 0;
+	n_dbg_host = 0;
+	if (n_q == 0) return;
+	hit_start.ensure(n_qm * 8 + 8); hit_n.ensure(n_qm * 4 + 4); a_cnt.ensure(n_qm * 4 + 4); keep.ensure(n_qm * 4 + 4);
+	a_off.ensure(n_qm * 8 + 8); mp_off.ensure(n_qm * 8 + 8);
+	aq_off.ensure((n_q + 1) * 8); mpq_off.ensure((n_q + 1) * 8); avg_qspan.ensure((n_q + 1) * 4); skip.ensure((n_q + 1) * 4);
+	u64 nA_total = 0, n_mp_total = 0;
+	if (n_qm) {
+		{
+			StageTimer t(this, "k_seed_probe", n_qm * (16 + 16 + 20));
+			LQ_LAUNCH(k_seed_probe, nblk(n_qm, 256), 256, stream, q.mx.as<u64>(), q.my.as<u64>(), q_owner.as<u32>(), n_qm,
+			          pt.tkey.as<u64>(), pt.tstart.as<u64>(), pt.tcnt.as<u32>(), pt.cap_bits, pt.pos.as<u64>(),
+			          mid_occ, (int)P.no_self, pt.self_off.as<u32>(), pt.self_rid.as<u32>(),
+			          hit_start.as<u64>(), hit_n.as<u32>(), a_cnt.as<u32>(), keep.as<u32>());
+			check_launch();
+		}
+		prim.exclusive_scan_u32_u64(a_cnt.as<u32>(), a_off.as<u64>(), n_qm);
+		prim.exclusive_scan_u32_u64(keep.as<u32>(), mp_off.as<u64>(), n_qm);
+		u64 lo[2]; u32 lc[2];
+		d2h(&lo[0], a_off.as<u64>() + n_qm - 1, 1, stream); d2h(&lc[0], a_cnt.as<u32>() + n_qm - 1, 1, stream);
+		d2h(&lo[1], mp_off.as<u64>() + n_qm - 1, 1, stream); d2h(&lc[1], keep.as<u32>() + n_qm - 1, 1, stream);
+		nA_total = lo[0] + lc[0]; n_mp_total = lo[1] + lc[1];
+	}
+	last_n_anchors = nA_total;
+	mini_pos.ensure(n_mp_total * 8 + 8);
+	LQ_LAUNCH(k_query_prep, nblk(n_q + 1, 128), 128, stream, q.moff.as<u64>(), a_off.as<u64>(), mp_off.as<u64>(), n_qm, nA_total, n_mp_total, n_q,
+	          q.mx.as<u64>(), a_cnt.as<u32>(), keep.as<u32>(), q.d_len.as<u32>(),
+	          aq_off.as<u64>(), mpq_off.as<u64>(), avg_qspan.as<float>(), lambda.as<u64>(), avg_k.as<float>(), skip.as<u32>());
+	check_launch();
+	std::vector<u64> h_aq(n_q + 1), h_qmoff(n_q + 1);
+	d2h(h_aq.data(), aq_off.as<u64>(), n_q + 1, stream);
+	d2h(h_qmoff.data(), q.moff.as<u64>(), n_q + 1, stream);
+
+	const bool dbg = (debug_flags & 1) != 0;
+	if (dbg) {
+		dbg_cap = nA_total / (P.min_cnt > 0 ? P.min_cnt : 1) + 16;
+		dbg_chains.ensure(dbg_cap * sizeof(ChainRec)); n_dbg.ensure(8);
+		dzero(n_dbg.p, 8, stream);
+	}
+	n_segs.ensure(8); n_ivl.ensure(4);
+
+	u32 q0 = 0;
+	while (q0 < n_q) {
+		// a batch of queries whose anchors fit the work space
+		u32 q1 = q0 + 1;
+		while (q1 < n_q && h_aq[q1 + 1] - h_aq[q0] <= anchor_budget) ++q1;
+		const u64 a_base = h_aq[q0], nA = h_aq[q1] - a_base;
+		const u32 nqb = q1 - q0;
+		const u64 j0 = h_qmoff[q0], nj = h_qmoff[q1] - j0;
+		if (nA > 0xfffffff0ULL) throw std::domain_error("a single query produces more than 2^32 anchors against this part");
+		A.ensure((nA + 1) * 16); B.ensure((nA + 1) * 16);
+		mm128 *dA = A.as<mm128>(), *dB = B.as<mm128>();
+		if (nj) {
+			StageTimer t(this, "k_seed_emit", nj * 32 + nA * 24);
+			LQ_LAUNCH(k_seed_emit, nblk(nj, 256), 256, stream, q.mx.as<u64>(), q.my.as<u64>(), q_owner.as<u32>(), q.moff.as<u64>(), j0, nj,
+			          pt.pos.as<u64>(), hit_start.as<u64>(), hit_n.as<u32>(), keep.as<u32>(),
+			          a_off.as<u64>(), a_base, mp_off.as<u64>(), q.d_len.as<u32>(),
+			          (int)P.no_self, pt.self_off.as<u32>(), pt.self_rid.as<u32>(), dA, mini_pos.as<u64>());
+			check_launch();
+		}
+		if (nA) {
+			const u64 *aqb = aq_off.as<u64>() + q0;          // batch view of the per-query anchor offsets
+			// ---- klib-order sort (lqmap.c:238) ----
+			{
+				const u64 max_segs = nA / (LQ_RS_MIN + 1) + nqb + 1;
+				segs0.ensure(max_segs * sizeof(SortSeg)); segs1.ensure(max_segs * sizeof(SortSeg));
+				dzero(n_segs.p, 8, stream);
+				{
+					StageTimer t(this, "k_sort_init");
+					LQ_LAUNCH(k_sort_init, nblk(nqb, 64), 64, stream, aqb, a_base, nqb, dA, segs0.as<SortSeg>(), n_segs.as<u32>());
+					check_launch();
+				}
+				u32 ns = 0;
+				d2h(&ns, n_segs.as<u32>(), 1, stream);
+				SortSeg *cur = segs0.as<SortSeg>(), *nxt = segs1.as<SortSeg>();
+				for (int level = 0; level < 8 && ns > 0; ++level) {
+					hist.ensure((u64)ns * 1024); begs.ensure((u64)ns * 1024);
+					dzero(hist.p, (u64)ns * 1024, stream);
+					dzero(n_segs.as<u32>() + 1, 4, stream);
+					{
+						StageTimer t(this, "k_sort_copy_hist", nA * 32);
+						LQ_LAUNCH(k_sort_copy_hist, ns, 256, stream, cur, ns, dA, dB, hist.as<u32>());
+						check_launch();
+					}
+					{
+						StageTimer t(this, "k_sort_walk", nA * 32);
+						u32 blocks = nblk(ns, LQ_WALK_LANES);
+						if (blocks > 4096) blocks = 4096;
+						LQ_LAUNCH(k_sort_walk, blocks, LQ_WALK_LANES, stream, cur, ns, dA, dB, hist.as<u32>(), begs.as<u32>());
+						check_launch();
+					}
+					{
+						StageTimer t(this, "k_sort_children");
+						LQ_LAUNCH(k_sort_children, nblk((u64)ns * 256, 256), 256, stream, cur, ns, dA, hist.as<u32>(), begs.as<u32>(), nxt, n_segs.as<u32>() + 1);
+						check_launch();
+					}
+					d2h(&ns, n_segs.as<u32>() + 1, 1, stream);
+					std::swap(cur, nxt);
+				}
+			}
+			// ---- (strand, rid) runs ----
+			head.ensure(nA * 4); gid.ensure(nA * 8);
+			dzero(head.p, nA * 4, stream);
+			LQ_LAUNCH(k_mark_qstart, nblk(nqb, 256), 256, stream, aqb, a_base, nqb, head.as<u32>()); check_launch();
+			LQ_LAUNCH(k_group_heads, nblk(nA, 256), 256, stream, dA, nA, head.as<u32>()); check_launch();
+			prim.exclusive_scan_u32_u64(head.as<u32>(), gid.as<u64>(), nA);
+			u64 lg = 0; u32 lh = 0;
+			d2h(&lg, gid.as<u64>() + nA - 1, 1, stream); d2h(&lh, head.as<u32>() + nA - 1, 1, stream);
+			const u64 n_groups = lg + lh;
+			gstart.ensure((n_groups + 1) * 8);
+			LQ_LAUNCH(k_group_starts, nblk(nA, 256), 256, stream, head.as<u32>(), gid.as<u64>(), nA, n_groups, gstart.as<u64>()); check_launch();
+			// ---- chain + coverage ----
+			cf.ensure(nA * 4); cp.ensure(nA * 4); ct.ensure(nA * 4); cv.ensure(nA * 4); cu.ensure(nA * 8);
+			const u32 ivl_cap = (u32)std::min<u64>(nA / (P.min_cnt > 0 ? P.min_cnt : 1) + 16, 0xfffffff0ULL);
+			ivl.ensure((u64)ivl_cap * sizeof(Ivl));
+			dzero(n_ivl.p, 4, stream);
+			ChainBufs cb; cb.f = cf.as<i32>(); cb.p = cp.as<i32>(); cb.t = ct.as<i32>(); cb.v = cv.as<i32>(); cb.u = cu.as<u64>();
+			CovState cs;
+			cs.lambda = lambda.as<unsigned long long>(); cs.lambda2 = lambda2.as<unsigned long long>();
+			cs.cnts = cnts.as<u32>(); cs.qflags = qflags.as<u32>(); cs.skip = skip.as<u32>(); cs.qmoff = q.moff.as<u64>();
+			cs.mini_pos = mini_pos.as<u64>(); cs.mpq_off = mpq_off.as<u64>(); cs.qlen = q.d_len.as<u32>(); cs.tlen = pt.rs.d_len.as<u32>();
+			cs.ivl = ivl.as<Ivl>(); cs.n_ivl = n_ivl.as<u32>(); cs.ivl_cap = ivl_cap;
+			cs.dbg = dbg ? dbg_chains.as<ChainRec>() : nullptr; cs.n_dbg = n_dbg.as<unsigned long long>(); cs.dbg_cap = dbg_cap;
+			{
+				StageTimer t(this, "k_chain", nA * 16);
+				LQ_LAUNCH(k_chain, nblk(n_groups, 64), 64, stream, dA, gstart.as<u64>(), n_groups, aqb, a_base, nqb, q0, avg_qspan.as<float>(), mp, cb, cs);
+				check_launch();
+			}
+			// ---- filter_redundant_coords per query (lqmap.c:287) ----
+			u32 ni = 0;
+			d2h(&ni, n_ivl.as<u32>(), 1, stream);
+			if (ni > ivl_cap) throw std::runtime_error("interval pool overflow");
+			if (ni) {
+				iv_q.ensure((u64)ni * 4); iv_q2.ensure((u64)ni * 4); iv_se.ensure((u64)ni * 8); iv_se2.ensure((u64)ni * 8);
+				ivq_off.ensure((n_q + 1) * 4); iv_scratch.ensure((u64)ni * 16);
+				LQ_LAUNCH(k_split_ivl, nblk(ni, 256), 256, stream, ivl.as<Ivl>(), ni, iv_q.as<u32>(), iv_se.as<u64>()); check_launch();
+				prim.sort_pairs_u32_u64(iv_q.as<u32>(), iv_q2.as<u32>(), iv_se.as<u64>(), iv_se2.as<u64>(), ni, 32);
+				LQ_LAUNCH(k_ivl_offsets, nblk(n_q + 1, 256), 256, stream, iv_q2.as<u32>(), ni, n_q, ivq_off.as<u32>()); check_launch();
+				u32 npv = 0;
+				d2h(&npv, n_pv.as<u32>(), 1, stream);
+				const u64 need = (u64)npv + 2 * (u64)ni;
+				if (need > 0xfffffff0ULL) throw std::domain_error("too many persisted intervals");
+				if (need > pv_cap) { grow_keep(pv, (u64)npv * sizeof(Ivl), need * sizeof(Ivl) * 2, stream); pv_cap = (u32)std::min<u64>(pv.cap / sizeof(Ivl), 0xfffffff0ULL); }
+				StageTimer t(this, "k_filter_redundant");
+				LQ_LAUNCH(k_filter_redundant, nblk(n_q, 64), 64, stream, iv_se2.as<u64>(), ivq_off.as<u32>(), n_q, (u32)P.min_coverage,
+				          iv_scratch.as<u32>(), pv.as<Ivl>(), n_pv.as<u32>(), pv_cap);
+				check_launch();
+			}
+		}
+		q0 = q1;
+	}
+	if (dbg) { unsigned long long nd = 0; d2h(&nd, n_dbg.as<unsigned long long>(), 1, stream); n_dbg_host = nd; }
+	LQ_HIP_CHECK(hipStreamSynchronize(stream));
+}
+
+// ---- pass 2 (minimap2-coverage.c:545-566) ---------------------------------------------------------
+void lqcov_handle::finish()
+{
+	const u32 n_q = q.n;
+	rows.assign(n_q, lqcov_row());
+	regs.clear(); mregs.clear();
+	if (n_q == 0) { finished = true; return; }
+	u32 npv = 0;
+	d2h(&npv, n_pv.as<u32>(), 1, stream);
+	DBuf rowdev, pvq_off, k1, k2, s1, s2, scratch, dregs, dmregs, cnt2;
+	rowdev.ensure((u64)n_q * sizeof(RowDev)); dzero(rowdev.p, (u64)n_q * sizeof(RowDev), stream);
+	pvq_off.ensure((n_q + 1) * 4); cnt2.ensure(8); dzero(cnt2.p, 8, stream);
+	k1.ensure((u64)npv * 4 + 4); k2.ensure((u64)npv * 4 + 4); s1.ensure((u64)npv * 8 + 8); s2.ensure((u64)npv * 8 + 8);
+	scratch.ensure((u64)npv * 8 + 8);
+	dregs.ensure(((u64)npv + 1) * sizeof(RegionT)); dmregs.ensure(((u64)npv + 1) * sizeof(RegionT));
+	if (npv) {
+		LQ_LAUNCH(k_split_ivl, nblk(npv, 256), 256, stream, pv.as<Ivl>(), npv, k1.as<u32>(), s1.as<u64>()); check_launch();
+		prim.sort_pairs_u32_u64(k1.as<u32>(), k2.as<u32>(), s1.as<u64>(), s2.as<u64>(), npv, 32);
+	}
+	LQ_LAUNCH(k_ivl_offsets, nblk(n_q + 1, 256), 256, stream, k2.as<u32>(), npv, n_q, pvq_off.as<u32>()); check_launch();
+	{
+		StageTimer t(this, "k_reliable");
+		LQ_LAUNCH(k_reliable, nblk(n_q, 64), 64, stream, s2.as<u64>(), pvq_off.as<u32>(), n_q, (u32)P.min_coverage, scratch.as<u32>(),
+		          dregs.as<RegionT>(), cnt2.as<u32>(), dmregs.as<RegionT>(), cnt2.as<u32>() + 1, rowdev.as<RowDev>());
+		check_launch();
+	}
+	{
+		StageTimer t(this, "k_cnt_stats", q.n_mini * 8);
+		LQ_LAUNCH(k_cnt_stats, nblk(n_q, 64), 64, stream, cnts.as<u32>(), q.moff.as<u64>(), n_q, rowdev.as<RowDev>());
+		check_launch();
+	}
+	std::vector<RowDev> hr(n_q);
+	std::vector<u64> hl(n_q), hl2(n_q), hmoff(n_q + 1);
+	std::vector<float> hk(n_q);
+	std::vector<u32> hf(n_q);
+	std::vector<double> hp(n_q);
+	u32 nr[2] = {0, 0};
+	d2h(hr.data(), rowdev.as<RowDev>(), n_q, stream);
+	d2h(hl.data(), lambda.as<u64>(), n_q, stream); d2h(hl2.data(), lambda2.as<u64>(), n_q, stream);
+	d2h(hk.data(), avg_k.as<float>(), n_q, stream); d2h(hf.data(), qflags.as<u32>(), n_q, stream);
+	d2h(hp.data(), qual_psum.as<double>(), n_q, stream);
+	d2h(hmoff.data(), q.moff.as<u64>(), n_q + 1, stream);
+	d2h(nr, cnt2.as<u32>(), 2, stream);
+	regs.resize(nr[0]); mregs.resize(nr[1]);
+	static_assert(sizeof(RegionT) == sizeof(lqcov_region), "region layout");
+	d2h((RegionT*)regs.data(), dregs.as<RegionT>(), nr[0], stream);
+	d2h((RegionT*)mregs.data(), dmregs.as<RegionT>(), nr[1], stream);
+	for (u32 i = 0; i < n_q; ++i) {
+		lqcov_row &r = rows[i];
+		r.lambda = hl[i]; r.lambda2 = hl2[i]; r.qual_psum = hp[i]; r.qlen = q.h_len[i];
+		r.n_mini = (u32)(hmoff[i + 1] - hmoff[i]); r.n_match = hr[i].n_match; r.avg_k = hk[i];
+		r.reg_off = hr[i].reg_off; r.n_reg = hr[i].n_reg; r.mreg_off = hr[i].mreg_off; r.n_mreg = hr[i].n_mreg;
+		r.has_qual = q_has_qual ? 1u : 0u; r.flags = hf[i];
+	}
+	finished = true;
+}
+
+// rows as text (minimap2-coverage.c:567-605)
+void lqcov_handle::write_table(FILE *out)
+{
+	if (!finished) throw std::logic_error("finish() has not run");
+	std::string line;
+	char buf[128];
+	for (u32 i = 0; i < q.n; ++i) {
+		const lqcov_row &r = rows[i];
+		const double div = r.n_match > 0 ? logf((float)r.n_mini / (float)(int32_t)r.n_match) / r.avg_k : 1.0;   // :563
+		double mq;
+		if (r.has_qual) mq = -10 * log10(r.qual_psum / (int)r.qlen);                                          // lqutils.c:57
+		else { volatile double z = 0.0; volatile int zl = 0; mq = -10 * log10(z / zl); }                                      // FASTA query: the reference's 0/0
+		line.clear();
+		line += q.names[i]; line += '\t';
+		snprintf(buf, sizeof(buf), "%d\t%" PRIu64 "\t", (int)r.qlen, r.lambda); line += buf;
+		if (r.n_reg > 0) {
+			u32 tot = 0;
+			for (u32 k = 0; k < r.n_reg; ++k) {
+				const lqcov_region &g = regs[r.reg_off + k];
+				snprintf(buf, sizeof(buf), "%s%d-%d", k ? "," : "", (int)g.start, (int)g.end); line += buf;
+				tot += g.end - g.start;
+			}
+			line += '\t';
+			if (r.n_mreg > 0) {
+				for (u32 k = 0; k < r.n_mreg; ++k) {
+					const lqcov_region &g = mregs[r.mreg_off + k];
+					snprintf(buf, sizeof(buf), "%s%d-%d", k ? "," : "", (int)g.start, (int)g.end); line += buf;
+				}
+			} else line += '0';
+			if (P.filter_flag) snprintf(buf, sizeof(buf), "\t%.3f\t%.3f\t%.3f\t0.0\n", (double)tot / (int)r.qlen, mq, div);
+			else snprintf(buf, sizeof(buf), "\t%.3f\t%.3f\t%.3f\t%.3f\n", (double)r.lambda / tot, mq, div, (double)r.lambda2 / tot);
+			line += buf;
+		} else {
+			snprintf(buf, sizeof(buf), "0\t0\t0.0\t%.3f\t%.3f\t0.0\n", mq, div); line += buf;
+		}
+		fwrite(line.data(), 1, line.size(), out);
+	}
+}
+
+// ---- the whole run from files (minimap2-coverage.c:406-617) -----------------------------------------
+int lqcov_handle::run_files(const char *target, const char *query, FILE *out, FILE *log)
+{
+	{
+		FastxReader fq(query);
+		ReadBatch qb;
+		while (fq.read_minibatch(INT64_MAX, qb, true) > 0) {}
+		set_queries(qb.size(), qb.seq.data(), qb.seq_off.data(), qb.any_qual ? qb.qual.data() : nullptr, qb.names.data(), qb.name_off.data());
+		if (log) fprintf(log, "[lqcov] loaded %u query sequence(s), %" PRIu64 " bases, %" PRIu64 " minimizers\n", qb.size(), qb.bases(), q.n_mini);
+	}
+	FastxReader ft(target);
+	const int64_t chunk = (int)((u64)P.idx_mini_batch < P.batch_size ? (u64)P.idx_mini_batch : P.batch_size);   // index.c:316
+	int n_parts = 0;
+	for (;;) {
+		// one part: mini-batches while the running total is <= -I (index.c:244)
+		int id = -1;
+		u64 sum_len = 0;
+		ReadBatch tb;
+		for (;;) {
+			if (sum_len > P.batch_size) break;
+			tb.clear();
+			if (ft.read_minibatch(chunk, tb, false) == 0) break;
+			if (id < 0) { parts.emplace_back(new Part()); id = (int)parts.size() - 1; parts[id]->live = true; }
+			add_reads(parts[id]->rs, tb.size(), tb.seq.data(), tb.seq_off.data(), tb.names.data(), tb.name_off.data());
+			sum_len += tb.bases();
+		}
+		if (id < 0) break;
+		Part &pt = *parts[id];
+		build_part(pt);
+		if (log) fprintf(log, "[lqcov] part %d: %u target sequence(s), %" PRIu64 " bases, %" PRIu64 " minimizers, %" PRIu64 " distinct, mid_occ = %d\n",
+		                 n_parts, pt.rs.n, pt.rs.n_bases, pt.rs.n_mini, pt.n_keys, mid_occ);
+		map_part(pt);
+		if (log) fprintf(log, "[lqcov] part %d: mapped %u queries, %" PRIu64 " anchors\n", n_parts, q.n, last_n_anchors);
+		parts[id].reset();
+		++n_parts;
+	}
+	finish();
+	write_table(out);
+	return 0;
+}

@@ -1,0 +1,101 @@
+// longqc_amd/csrc/engine.hpp -- host-side orchestration of the MI355X coverage engine.
+//
+// Mirrors the structure of the reference's main (minimap2-coverage.c:206-734): query set once
+// (pass 1, :406-444), then per index part: build (index.c:311-330) + mid_occ on the first part
+// (map.c:46-54) + map every query (lqmap.c:852 -> :207-326), then pass 2 (:545-617).  All state
+// that the reference keeps per query on the host (lambdas, lambdas2, avg_ks, m_cnts, ovlp_coords)
+// lives in HBM here; the host sees it only in finish().
+#pragma once
+#include "lq_common.hpp"
+#include "prim.hpp"
+#include "../../include/lqcov.h"
+#include <string>
+#include <vector>
+#include <map>
+#include <memory>
+
+struct StageAcc { double ms = 0; u64 launches = 0; u64 bytes = 0; };
+
+struct ReadSetDev {                       // a read set 2-bit packed in HBM, chunk aligned
+	u32 n = 0;
+	u64 n_chunks = 0, n_bases = 0;
+	std::vector<u64> h_coff{0};           // chunk offset of every read (+ total)
+	std::vector<u32> h_len;
+	std::vector<std::string> names;
+	DBuf codes, amb;                      // 4 x u64 / 4 x u32 per chunk
+	u64 cap_chunks = 0;
+	DBuf d_coff, d_len;                   // device copies of h_coff / h_len
+	DBuf mx, my, moff;                    // minimizers (x, y) in emission order + per-read offsets
+	u64 n_mini = 0;
+	bool sketched = false;
+};
+
+struct Part {
+	bool live = false, built = false;
+	ReadSetDev rs;
+	DBuf pos;                             // y of every minimizer, grouped by hash, ascending (index.c:188)
+	DBuf tkey, tstart, tcnt;              // open-addressed table
+	u32 cap_bits = 0;
+	u64 n_keys = 0;
+	DBuf self_off, self_rid;              // per query: same-name targets (lqmap.c:180-186)
+};
+
+struct lqcov_handle {
+	lqcov_params P;
+	MapParams mp;
+	int device = 0;
+	hipStream_t stream = nullptr;
+	Prim prim;
+	std::string err;
+	bool profiling = false;
+	u32 debug_flags = 0;
+	std::map<std::string, StageAcc> stages;
+	std::vector<std::string> stage_order;
+
+	// query set and per-query accumulators
+	ReadSetDev q;
+	bool have_queries = false, q_has_qual = false;
+	DBuf q_owner;                         // query of every query minimizer
+	DBuf lambda, lambda2, avg_k, cnts, qflags, qual_psum;
+	DBuf pv; DBuf n_pv; u32 pv_cap = 0;   // persisted intervals + markers (ovlp_coords)
+	i32 mid_occ = -1;
+
+	std::vector<std::unique_ptr<Part>> parts;
+
+	// work buffers of part_map
+	DBuf hit_start, hit_n, a_cnt, keep, a_off, mp_off, mini_pos, aq_off, mpq_off, avg_qspan, skip;
+	DBuf A, B, segs0, segs1, n_segs, hist, begs;
+	DBuf head, gid, gstart, cf, cp, ct, cv, cu;
+	DBuf ivl, n_ivl, iv_q, iv_q2, iv_se, iv_se2, ivq_off, iv_scratch;
+	DBuf dbg_chains, n_dbg; u64 dbg_cap = 0; u64 n_dbg_host = 0;
+	DBuf misc;
+	u64 last_n_anchors = 0;
+	u64 anchor_budget = 0;
+
+	// finish()
+	bool finished = false;
+	std::vector<lqcov_row> rows;
+	std::vector<lqcov_region> regs, mregs;
+
+	lqcov_handle(const lqcov_params &p, int dev);
+	~lqcov_handle();
+
+	void add_reads(ReadSetDev &rs, u32 n, const u8 *seq, const u64 *seq_off, const char *names, const u64 *name_off);
+	void sketch(ReadSetDev &rs, bool rid_in_y);
+	void set_queries(u32 n, const u8 *seq, const u64 *seq_off, const u8 *qual, const char *names, const u64 *name_off);
+	void build_index(Part &pt);
+	void build_part(Part &pt);
+	void map_part(Part &pt);
+	void reset();
+	void finish();
+	void write_table(FILE *out);
+	int run_files(const char *target, const char *query, FILE *out, FILE *log);
+	Part &part(int id);
+};
+
+struct StageTimer {
+	lqcov_handle *h; const char *name; u64 bytes;
+	hipEvent_t a = nullptr, b = nullptr;
+	StageTimer(lqcov_handle *h_, const char *name_, u64 bytes_ = 0);
+	~StageTimer();
+};

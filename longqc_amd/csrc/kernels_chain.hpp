@@ -1,0 +1,395 @@
+// longqc_amd/csrc/kernels_chain.hpp -- co-linear chaining and coverage accumulation.
+//
+// mm_chain_dp (reference chain.c:22-157) never lets anchors of different (strand, target) interact:
+// x carries rev and rid in its high 32 bits, so the `st` window (chain.c:47), the DP, the peak
+// bookkeeping and the backtrack are independent per (strand, rid) run of the sorted anchors; only
+// avg_qspan is global to the query (chain.c:37-38) and is computed from the unfiltered totals in
+// k_query_prep.  Runs shorter than min_cnt can never yield a chain (chain.c:119-121) and are
+// skipped.  One thread owns one run and executes the reference's loop order literally (the
+// accept / skip / break logic of chain.c:48-77 is order dependent), then turns each chain into
+// the reg coordinates of mm_reg_set_coor (hit.c:23-38) and applies lq_cnt_match (esterr.c:99-138)
+// with atomics into the per-query accumulators -- sums and counters commute, so the unspecified
+// order of chains is unobservable (the uint16 saturation quirk of esterr.c:130,136 is detected
+// and flagged instead).
+#pragma once
+#include "lq_common.hpp"
+#include "kernels_sketch.hpp"
+
+__global__ void k_mark_qstart(const u64 *aq_off, u64 a_base, u32 n_q, u32 *head)
+{
+	u32 q = blockIdx.x * blockDim.x + threadIdx.x;
+	if (q >= n_q) return;
+	if (aq_off[q] < aq_off[q + 1]) head[aq_off[q] - a_base] = 1;
+}
+
+__global__ void k_group_heads(const mm128 *A, u64 n, u32 *head)
+{
+	u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	if (i == 0) { head[0] = 1; return; }
+	if (!head[i]) head[i] = (A[i].x >> 32) != (A[i - 1].x >> 32) ? 1u : 0u;
+}
+
+__global__ void k_group_starts(const u32 *head, const u64 *gid, u64 n, u64 n_groups, u64 *gstart)
+{
+	u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i == 0) gstart[n_groups] = n;
+	if (i >= n) return;
+	if (head[i]) gstart[gid[i]] = i;
+}
+
+__device__ __forceinline__ int lq_ilog2_32(u32 v) { return 31 - __clz(v); }   // chain.c:15-20 for v > 0
+
+__device__ __forceinline__ void lq_heapsort_u64(u64 *a, i64 n)
+{
+	if (n < 2) return;
+	for (i64 start = n / 2 - 1; start >= 0; --start) {
+		i64 root = start; u64 v = a[root];
+		for (;;) {
+			i64 ch = 2 * root + 1;
+			if (ch >= n) break;
+			if (ch + 1 < n && a[ch + 1] > a[ch]) ++ch;
+			if (a[ch] <= v) break;
+			a[root] = a[ch]; root = ch;
+		}
+		a[root] = v;
+	}
+	for (i64 end = n - 1; end > 0; --end) {
+		u64 v = a[end]; a[end] = a[0];
+		i64 root = 0;
+		for (;;) {
+			i64 ch = 2 * root + 1;
+			if (ch >= end) break;
+			if (ch + 1 < end && a[ch + 1] > a[ch]) ++ch;
+			if (a[ch] <= v) break;
+			a[root] = a[ch]; root = ch;
+		}
+		a[root] = v;
+	}
+}
+
+__device__ __forceinline__ void lq_heapsort_u32(u32 *a, i64 n)
+{
+	if (n < 2) return;
+	for (i64 start = n / 2 - 1; start >= 0; --start) {
+		i64 root = start; u32 v = a[root];
+		for (;;) {
+			i64 ch = 2 * root + 1;
+			if (ch >= n) break;
+			if (ch + 1 < n && a[ch + 1] > a[ch]) ++ch;
+			if (a[ch] <= v) break;
+			a[root] = a[ch]; root = ch;
+		}
+		a[root] = v;
+	}
+	for (i64 end = n - 1; end > 0; --end) {
+		u32 v = a[end]; a[end] = a[0];
+		i64 root = 0;
+		for (;;) {
+			i64 ch = 2 * root + 1;
+			if (ch >= end) break;
+			if (ch + 1 < end && a[ch + 1] > a[ch]) ++ch;
+			if (a[ch] <= v) break;
+			a[root] = a[ch]; root = ch;
+		}
+		a[root] = v;
+	}
+}
+
+// esterr.c:17-24
+__device__ __forceinline__ i32 lq_fwd_qpos(i32 qlen, const mm128 &a)
+{
+	i32 x = (i32)a.y, q_span = (i32)(a.y >> 32 & 0xff);
+	if (a.x >> 63) x = qlen - 1 - (x + 1 - q_span);
+	return x;
+}
+
+struct ChainBufs {
+	i32 *f, *p, *t, *v;        // per anchor scratch (chain.c:31-35)
+	u64 *u;                    // per anchor scratch: chain ends / chains
+};
+
+struct CovState {              // per-query accumulators (minimap2-coverage.c:435-444)
+	unsigned long long *lambda, *lambda2;
+	u32 *cnts;                 // match counters, one per unfiltered query minimizer (uint16 in the reference)
+	u32 *qflags;               // LQCOV_ROW_* bits
+	const u32 *skip;           // esterr.c:85-91 verdict of this (query, part)
+	const u64 *qmoff;          // counter array offsets
+	const u64 *mini_pos;       // this part's filtered minimizer list (lqmap.c:174)
+	const u64 *mpq_off;
+	const u32 *qlen;
+	const u32 *tlen;           // target lengths of this part
+	Ivl *ivl; u32 *n_ivl; u32 ivl_cap;             // this part's intervals (esterr.c:122-126)
+	ChainRec *dbg; unsigned long long *n_dbg; u64 dbg_cap;   // optional chain dump
+};
+
+// aq_off: the batch's view of the per-query anchor offsets (n_q+1 entries, absolute; the batch's
+// anchors start at a_base); q0: global index of the batch's first query.
+__global__ void k_chain(const mm128 *A, const u64 *gstart, u64 n_groups, const u64 *aq_off, u64 a_base, u32 n_q, u32 q0,
+                        const float *avg_qspan_q, MapParams P, ChainBufs B, CovState C)
+{
+	u64 g = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+	if (g >= n_groups) return;
+	const u64 gs = gstart[g];
+	const i64 n = (i64)(gstart[g + 1] - gs);
+	if (n < P.min_cnt) return;
+	const u32 q = q0 + lq_find_seg(aq_off, n_q, gs + a_base);
+	const bool accumulate = !C.skip[q];
+	if (!accumulate && !C.dbg) return;
+	const mm128 *a = A + gs;
+	i32 *f = B.f + gs, *p = B.p + gs, *t = B.t + gs, *v = B.v + gs;
+	u64 *u = B.u + gs;
+	const float avg_qspan = avg_qspan_q[q];
+	const i32 max_dist = P.max_gap, bw = P.bw, max_skip = P.max_skip, min_sc = P.min_sc;
+	i64 st = 0;
+	for (i64 i = 0; i < n; ++i) t[i] = 0;
+	// fill the score and backtrack arrays (chain.c:41-81)
+	for (i64 i = 0; i < n; ++i) {
+		const u64 ri = a[i].x;
+		i64 max_j = -1;
+		const i32 qi = (i32)a[i].y, q_span = (i32)(a[i].y >> 32 & 0xff);
+		i32 max_f = q_span, n_skip = 0;
+		while (st < i && ri - a[st].x > (u64)max_dist) ++st;
+		for (i64 j = i - 1; j >= st; --j) {
+			const i64 dr = (i64)(ri - a[j].x);
+			const i32 dq = qi - (i32)a[j].y;
+			if (dr == 0 || dq <= 0) continue;
+			if (dq > max_dist) continue;
+			const i32 dd = dr > dq ? (i32)(dr - dq) : (i32)(dq - dr);
+			if (dd > bw) continue;
+			const i32 min_d = dq < dr ? dq : (i32)dr;
+			i32 sc = min_d > q_span ? q_span : min_d;
+			const i32 log_dd = dd ? lq_ilog2_32((u32)dd) : 0;
+			sc -= (i32)((double)dd * .01 * (double)avg_qspan) + (log_dd >> 1);     // chain.c:67
+			sc += f[j];
+			if (sc > max_f) {
+				max_f = sc; max_j = j;
+				if (n_skip > 0) --n_skip;
+			} else if (t[j] == (i32)i) {
+				if (++n_skip > max_skip) break;
+			}
+			if (p[j] >= 0) t[p[j]] = (i32)i;
+		}
+		f[i] = max_f; p[i] = (i32)max_j;
+		v[i] = max_j >= 0 && v[max_j] > max_f ? v[max_j] : max_f;
+	}
+	// chain ends (chain.c:84-101)
+	for (i64 i = 0; i < n; ++i) t[i] = 0;
+	for (i64 i = 0; i < n; ++i) if (p[i] >= 0) t[p[i]] = 1;
+	i64 n_u = 0;
+	for (i64 i = 0; i < n; ++i) {
+		if (t[i] == 0 && v[i] >= min_sc) {
+			i64 j = i;
+			while (j >= 0 && f[j] < v[j]) j = p[j];
+			if (j < 0) j = i;
+			u[n_u++] = (u64)(u32)f[j] << 32 | (u64)j;
+		}
+	}
+	if (n_u == 0) return;
+	lq_heapsort_u64(u, n_u);                                   // keys are distinct: any sort == radix_sort_64 (chain.c:102)
+	// backtrack from the best end (chain.c:108-125); u[] is ascending, so walk it from the top
+	for (i64 i = 0; i < n; ++i) t[i] = 0;
+	i64 n_v = 0;
+	const i32 qlen = (i32)C.qlen[q];
+	const u64 *mp = C.mini_pos + C.mpq_off[q];
+	const i32 n_mp = (i32)(C.mpq_off[q + 1] - C.mpq_off[q]);
+	for (i64 ui = n_u - 1; ui >= 0; --ui) {
+		const i64 n_v0 = n_v;
+		const u64 ue = u[ui];
+		i64 j = (i64)(i32)ue;
+		do { v[n_v++] = (i32)j; t[j] = 1; j = p[j]; } while (j >= 0 && t[j] == 0);
+		const i32 cnt = (i32)(n_v - n_v0);
+		i32 score;
+		bool keep = false;
+		if (j < 0) { score = (i32)(ue >> 32); keep = cnt >= P.min_cnt; }
+		else { score = (i32)(ue >> 32) - f[j]; keep = score >= min_sc && cnt >= P.min_cnt; }
+		if (!keep) { n_v = n_v0; continue; }
+		// the chain's anchors in ascending x: a[v[n_v-1]], ..., a[v[n_v0]]   (chain.c:131-137)
+		const mm128 first = a[v[n_v - 1]], last = a[v[n_v0]];
+		// mm_reg_set_coor (hit.c:23-38)
+		const i32 q_span = (i32)(first.y >> 32 & 0xff);
+		const u32 rev = (u32)(first.x >> 63);
+		const i32 rid = (i32)(first.x << 1 >> 33);
+		const i32 rs = (i32)first.x + 1 > q_span ? (i32)first.x + 1 - q_span : 0;
+		const i32 re = (i32)last.x + 1;
+		i32 qs, qe;
+		if (!rev) { qs = (i32)first.y + 1 - q_span; qe = (i32)last.y + 1; }
+		else { qs = qlen - ((i32)last.y + 1); qe = qlen - ((i32)first.y + 1 - q_span); }
+		if (C.dbg) {
+			unsigned long long d = atomicAdd(C.n_dbg, 1ULL);
+			if (d < C.dbg_cap) { ChainRec r; r.q = (i32)q; r.rid = rid; r.rev = (i32)rev; r.score = score; r.cnt = cnt; r.qs = qs; r.qe = qe; r.rs = rs; r.re = re; C.dbg[d] = r; }
+		}
+		if (!accumulate) continue;
+		// lq_cnt_match for this reg (esterr.c:99-138)
+		const i32 x0 = lq_fwd_qpos(qlen, rev ? last : first);
+		i32 L = 0, R = n_mp - 1, sti = -1;
+		while (L <= R) {                                           // get_mini_idx (esterr.c:26-38)
+			const i32 m = (i32)(((u64)L + (u64)R) >> 1), y = (i32)mp[m];
+			if (y < x0) L = m + 1; else if (y > x0) R = m - 1; else { sti = m; break; }
+		}
+		if (sti < 0) continue;
+		const u32 rl = C.tlen[rid];
+		const u32 uqs = (u32)qs, uqe = (u32)qe, urs = (u32)rs, ure = (u32)re;
+		const u32 hang5 = uqs < urs ? uqs : urs;
+		const u32 hang3 = (u32)qlen - uqe < rl - ure ? (u32)qlen - uqe : rl - ure;
+		if ((double)(uqe - uqs) < (double)(uqe - uqs + hang5 + hang3) * P.min_ratio || hang5 > (u32)P.max_overhang || hang3 > (u32)P.max_overhang)
+			continue;
+		atomicAdd(&C.lambda[q], (unsigned long long)(u32)(uqe - uqs + 1));
+		u32 flag = score >= (i32)(u16)P.min_sc_med ? 2u : 0u;
+		{
+			u32 s = atomicAdd(C.n_ivl, 1u);
+			if (s < C.ivl_cap) { Ivl iv; iv.q = q; iv.start = uqs << 3 | flag; iv.end = uqe << 3 | flag | 1u; C.ivl[s] = iv; }
+		}
+		if (score < (i32)(u16)P.min_sc_good) continue;
+		atomicAdd(&C.lambda2[q], (unsigned long long)(u32)(uqe - uqs + 1));
+		u32 *cn = C.cnts + C.qmoff[q];
+		u32 old = atomicAdd(&cn[sti], 1u);
+		if (old + 1 >= 65535u) atomicOr(&C.qflags[q], 1u);        // esterr.c:130: saturation regime, order would matter
+		i32 k = 1;
+		for (i32 jj = sti + 1; jj < n_mp && k < cnt; ++jj) {
+			const mm128 ak = rev ? a[v[n_v0 + k]] : a[v[n_v - 1 - k]];
+			if (lq_fwd_qpos(qlen, ak) == (i32)mp[jj]) {
+				++k;
+				u32 o2 = atomicAdd(&cn[jj], 1u);
+				if (o2 + 1 >= 65535u) atomicOr(&C.qflags[q], 1u);
+			}
+		}
+	}
+}
+
+// ---- filter_redundant_coords (lqmap.c:25-100), one thread per query, on this part's intervals ----
+// ivl is sorted by q; ivq_off[q] = first interval of query q.
+__global__ void k_ivl_offsets(const u32 *qkey, u32 n_ivl, u32 n_q, u32 *ivq_off)
+{
+	u32 q = blockIdx.x * blockDim.x + threadIdx.x;
+	if (q > n_q) return;
+	u32 lo = 0, hi = n_ivl;                                 // first index with qkey >= q
+	while (lo < hi) { u32 mid = lo + ((hi - lo) >> 1); if (qkey[mid] < q) lo = mid + 1; else hi = mid; }
+	ivq_off[q] = lo;
+}
+
+__global__ void k_filter_redundant(const u64 *se /* start | end<<32, sorted by query */, const u32 *ivq_off, u32 n_q, u32 min_cov,
+                                   u32 *scratch /* 4 u32 per interval */, Ivl *pv, u32 *n_pv, u32 pv_cap)
+{
+	u32 q = blockIdx.x * blockDim.x + threadIdx.x;
+	if (q >= n_q) return;
+	const u32 lo = ivq_off[q], n = ivq_off[q + 1] - lo;
+	if (n == 0) return;
+	const u64 *cv = se + lo;
+	u32 *vc = scratch + (u64)lo * 4, *mc = vc + 2 * (u64)n;
+	for (u32 i = 0; i < n; ++i) { vc[2 * i] = (u32)cv[i]; vc[2 * i + 1] = (u32)(cv[i] >> 32); }
+	lq_heapsort_u32(vc, 2 * (i64)n);
+	u32 med_start = 0, med_cov = 0, n_mc = 0;
+	for (u32 j = 0; j < 2 * n; ++j) {
+		const u32 e = vc[j], old = med_cov;
+		if (e & 2) {
+			if (e & 1) { if (e & 4) med_cov -= min_cov; else --med_cov; }
+			else       { if (e & 4) med_cov += min_cov; else ++med_cov; }
+		}
+		if (old < min_cov && med_cov >= min_cov) med_start = e;
+		else if (old >= min_cov && med_cov < min_cov) {
+			const u32 mlen = (e >> 3) - med_start;                // sic (lqmap.c:63): decoded minus encoded
+			if (mlen > 0) {
+				mc[2 * n_mc] = med_start; mc[2 * n_mc + 1] = e; ++n_mc;
+				u32 s = atomicAdd(n_pv, 1u);
+				if (s < pv_cap) { Ivl m; m.q = q; m.start = med_start | 4u; m.end = e | 4u; pv[s] = m; }
+			}
+		}
+	}
+	for (u32 i = 0; i < n; ++i) {
+		const u32 s0 = (u32)cv[i], e0 = (u32)(cv[i] >> 32);
+		bool inside = false;
+		for (u32 j = 0; j < n_mc; ++j) if (s0 >= mc[2 * j] && e0 <= mc[2 * j + 1]) { inside = true; break; }
+		if (!inside) {
+			u32 s = atomicAdd(n_pv, 1u);
+			if (s < pv_cap) { Ivl m; m.q = q; m.start = s0; m.end = e0; pv[s] = m; }
+		}
+	}
+}
+
+__global__ void k_split_ivl(const Ivl *iv, u32 n, u32 *qkey, u64 *se)
+{
+	u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	qkey[i] = iv[i].q; se[i] = (u64)iv[i].start | (u64)iv[i].end << 32;
+}
+
+// ---- pass 2 (minimap2-coverage.c:545-566): compute_reliable_region (lqutils.c:83-155) ----------
+// one thread per query over its persisted intervals (sorted by query); two sweeps: count, write.
+struct RegionT { u32 start, end; };
+
+template <bool WRITE>
+__device__ __forceinline__ void lq_sweep(const u32 *vc, u32 n2, u32 min_cov, RegionT *regs, RegionT *mregs, u32 &n_reg, u32 &n_mreg)
+{
+	u32 start = 0, cov = 0, med_start = 0, med_cov = 0;
+	n_reg = n_mreg = 0;
+	for (u32 j = 0; j < n2; ++j) {
+		const u32 e = vc[j], old_cov = cov, old_med = med_cov;
+		if (e & 1) {
+			--cov;
+			if (e & 2) { if (e & 4) { med_cov -= min_cov; cov -= (min_cov - 1); } else --med_cov; }
+		} else {
+			++cov;
+			if (e & 2) { if (e & 4) { med_cov += min_cov; cov += (min_cov - 1); } else ++med_cov; }
+		}
+		if (old_cov < min_cov && cov >= min_cov) {
+			start = e >> 3;
+			if (old_med < min_cov && med_cov >= min_cov) med_start = e >> 3;
+		} else if (old_cov >= min_cov && cov < min_cov) {
+			if ((e >> 3) - start > 0) { if (WRITE) { regs[n_reg].start = start; regs[n_reg].end = e >> 3; } ++n_reg; }
+			if (old_med >= min_cov && med_cov < min_cov)
+				if ((e >> 3) - med_start > 0) { if (WRITE) { mregs[n_mreg].start = med_start; mregs[n_mreg].end = e >> 3; } ++n_mreg; }
+		} else if (old_med < min_cov && med_cov >= min_cov) {
+			med_start = e >> 3;
+		} else if (old_med >= min_cov && med_cov < min_cov) {
+			if ((e >> 3) - med_start > 0) { if (WRITE) { mregs[n_mreg].start = med_start; mregs[n_mreg].end = e >> 3; } ++n_mreg; }
+		}
+	}
+}
+
+struct RowDev {               // device-side mirror of lqcov_row's integer part
+	u32 n_match, reg_off, n_reg, mreg_off, n_mreg;
+};
+
+__global__ void k_reliable(const u64 *se, const u32 *pvq_off, u32 n_q, u32 min_cov, u32 *scratch /* 2 u32 per interval */,
+                           RegionT *regs, u32 *n_regs, RegionT *mregs, u32 *n_mregs, RowDev *rows)
+{
+	u32 q = blockIdx.x * blockDim.x + threadIdx.x;
+	if (q >= n_q) return;
+	const u32 lo = pvq_off[q], n = pvq_off[q + 1] - lo;
+	u32 *vc = scratch + (u64)lo * 2;
+	for (u32 i = 0; i < n; ++i) { vc[2 * i] = (u32)se[lo + i]; vc[2 * i + 1] = (u32)(se[lo + i] >> 32); }
+	lq_heapsort_u32(vc, 2 * (i64)n);
+	u32 nr, nm;
+	lq_sweep<false>(vc, 2 * n, min_cov, nullptr, nullptr, nr, nm);
+	u32 ro = nr ? atomicAdd(n_regs, nr) : 0, mo = nm ? atomicAdd(n_mregs, nm) : 0;
+	lq_sweep<true>(vc, 2 * n, min_cov, regs + ro, mregs + mo, nr, nm);
+	rows[q].reg_off = ro; rows[q].n_reg = nr; rows[q].mreg_off = mo; rows[q].n_mreg = nm;
+}
+
+// minimap2-coverage.c:552-561: integer mean of the uint16 counters, count of those above it
+__global__ void k_cnt_stats(const u32 *cnts, const u64 *qmoff, u32 n_q, RowDev *rows)
+{
+	u32 q = blockIdx.x * blockDim.x + threadIdx.x;
+	if (q >= n_q) return;
+	const u64 lo = qmoff[q], hi = qmoff[q + 1];
+	u32 sum = 0, n = (u32)(hi - lo), nm = 0;
+	for (u64 j = lo; j < hi; ++j) sum += cnts[j] & 0xffffu;        // uint16 storage wraps (esterr.c:136)
+	if (n) sum /= n;
+	for (u64 j = lo; j < hi; ++j) if ((cnts[j] & 0xffffu) > sum) ++nm;
+	rows[q].n_match = nm;
+}
+
+// meanQ's accumulation (lqutils.c:51-56): a sequential double sum per read, in read order
+__global__ void k_qual_sum(const u8 *qual, const u64 *seq_off, u32 n_q, const double *q2p, double *psum)
+{
+	u32 q = blockIdx.x * blockDim.x + threadIdx.x;
+	if (q >= n_q) return;
+	double s = 0.0;
+	for (u64 i = seq_off[q]; i < seq_off[q + 1]; ++i) {
+		int v = (int)(signed char)qual[i] - 33;
+		v = v < 0 ? 0 : v > 126 ? 126 : v;                         // the reference indexes out of bounds outside Q0..Q126
+		s += q2p[v];
+	}
+	psum[q] = s;
+}

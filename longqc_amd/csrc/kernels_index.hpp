@@ -1,0 +1,185 @@
+// longqc_amd/csrc/kernels_index.hpp -- GPU-resident minimizer index of one part and seed collection.
+//
+// Index (reference index.c:150-236, semantic result "hash -> occurrences sorted by y"): the part's
+// minimizers are produced in ascending y by k_sketch, a stable LSD radix sort on the 2k-bit hash
+// groups them (rocPRIM device radix sort), run heads become the distinct keys, and an
+// open-addressed, linearly probed table (16-B aligned key / start / count arrays, capacity a power
+// of two >= 2*K_t) maps hash -> (start, n) into the sorted position array: one 8-byte probe per
+// lookup in the common case, neighbouring lanes probing neighbouring query minimizers.
+//
+// Seeds (reference lqmap.c:140-205): per query minimizer one probe; occurrences >= mid_occ are
+// skipped; survivors yield mini_pos entries and anchors in (minimizer, hit) order, minus the self
+// diagonal.  Count, exclusive scan, fill -> anchors land in the reference's emission order.
+#pragma once
+#include "lq_common.hpp"
+#include "kernels_sketch.hpp"
+
+#define LQ_EMPTY_KEY LQ_U64MAX
+
+__device__ __forceinline__ u64 lq_slot_of(u64 key, u32 cap_bits)
+{	// Fibonacci hashing of the (already well mixed) minimizer hash
+	return (key * 0x9E3779B97F4A7C15ULL) >> (64 - cap_bits);
+}
+
+__global__ void k_sort_keys(const u64 *x, u64 n, u64 *key)
+{
+	u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) key[i] = x[i] >> 8;
+}
+
+__global__ void k_mark_heads(const u64 *key, u64 n, u32 *head)
+{
+	u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) head[i] = (i == 0 || key[i] != key[i - 1]) ? 1u : 0u;
+}
+
+// uidx = exclusive scan of head; every head writes its key and start
+__global__ void k_fill_unique(const u64 *key, const u32 *head, const u64 *uidx, u64 n, u64 *ukey, u64 *ustart)
+{
+	u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	if (head[i]) { ukey[uidx[i]] = key[i]; ustart[uidx[i]] = i; }
+}
+
+__global__ void k_unique_counts(const u64 *ustart, u64 n_keys, u64 n_mini, u32 *ucnt)
+{
+	u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n_keys) return;
+	u64 e = i + 1 < n_keys ? ustart[i + 1] : n_mini;
+	ucnt[i] = (u32)(e - ustart[i]);
+}
+
+__global__ void k_table_insert(const u64 *ukey, const u64 *ustart, const u32 *ucnt, u64 n_keys,
+                               u64 *tkey, u64 *tstart, u32 *tcnt, u32 cap_bits)
+{
+	u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n_keys) return;
+	u64 key = ukey[i], mask = ((u64)1 << cap_bits) - 1;
+	u64 h = lq_slot_of(key, cap_bits);
+	for (;;) {
+		unsigned long long old = atomicCAS((unsigned long long*)&tkey[h], (unsigned long long)LQ_EMPTY_KEY, (unsigned long long)key);
+		if (old == LQ_EMPTY_KEY) { tstart[h] = ustart[i]; tcnt[h] = ucnt[i]; return; }
+		h = (h + 1) & mask;
+	}
+}
+
+// mm_idx_get (index.c:69-86)
+__device__ __forceinline__ u32 lq_table_get(const u64 *tkey, const u64 *tstart, const u32 *tcnt, u32 cap_bits, u64 key, u64 &start)
+{
+	u64 mask = ((u64)1 << cap_bits) - 1;
+	u64 h = lq_slot_of(key, cap_bits);
+	for (;;) {
+		u64 kk = tkey[h];
+		if (kk == key) { start = tstart[h]; return tcnt[h]; }
+		if (kk == LQ_EMPTY_KEY) { start = 0; return 0; }
+		h = (h + 1) & mask;
+	}
+}
+
+// query of every query minimizer (qmoff has n_q+1 entries)
+__global__ void k_minimizer_owner(const u64 *qmoff, u32 n_q, u64 n_qm, u32 *owner)
+{
+	u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+	if (j < n_qm) owner[j] = lq_find_seg(qmoff, n_q, j);
+}
+
+// is target `rid` one of query q's same-name targets of this part? (lqmap.c:180-186: strcmp == 0)
+__device__ __forceinline__ bool lq_is_self(const u32 *self_off, const u32 *self_rid, u32 q, u32 rid)
+{
+	for (u32 s = self_off[q]; s < self_off[q + 1]; ++s) if (self_rid[s] == rid) return true;
+	return false;
+}
+
+// pass A of collect_seed_hits: probe, apply mid_occ, count surviving hits
+__global__ void k_seed_probe(const u64 *qx, const u64 *qy, const u32 *owner, u64 n_qm,
+                             const u64 *tkey, const u64 *tstart, const u32 *tcnt, u32 cap_bits, const u64 *pos,
+                             i32 mid_occ, int no_self, const u32 *self_off, const u32 *self_rid,
+                             u64 *hit_start, u32 *hit_n, u32 *a_cnt, u32 *keep)
+{
+	u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+	if (j >= n_qm) return;
+	u64 st;
+	u32 n = lq_table_get(tkey, tstart, tcnt, cap_bits, qx[j] >> 8, st);
+	hit_start[j] = st; hit_n[j] = n;
+	if ((i64)n >= (i64)mid_occ) { a_cnt[j] = 0; keep[j] = 0; return; }     // lqmap.c:166-173
+	u32 c = n;
+	u32 q = owner[j];
+	if (no_self && self_off[q] != self_off[q + 1]) {
+		u32 qpos = (u32)qy[j] >> 1;
+		for (u32 t = 0; t < n; ++t) {
+			u64 r = pos[st + t];
+			if (((u32)r >> 1) == qpos && lq_is_self(self_off, self_rid, q, (u32)(r >> 32))) --c;
+		}
+	}
+	a_cnt[j] = c; keep[j] = 1;
+}
+
+// pass B: anchors (lqmap.c:175-200) and mini_pos (lqmap.c:174)
+// (a batch of queries = minimizers [j0, j0+nj); anchors are written relative to a_base)
+__global__ void k_seed_emit(const u64 *qx, const u64 *qy, const u32 *owner, const u64 *qmoff, u64 j0, u64 nj,
+                            const u64 *pos, const u64 *hit_start, const u32 *hit_n, const u32 *keep,
+                            const u64 *a_off, u64 a_base, const u64 *mp_off, const u32 *qlen,
+                            int no_self, const u32 *self_off, const u32 *self_rid,
+                            mm128 *anchors, u64 *mini_pos)
+{
+	u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+	if (j >= nj) return;
+	j += j0;
+	if (!keep[j]) return;
+	u32 q = owner[j];
+	u64 x = qx[j];
+	u32 q_span = (u32)(x & 0xff), qp = (u32)qy[j];
+	u32 qpos = qp >> 1;
+	mini_pos[mp_off[j]] = (u64)q_span << 32 | qpos;
+	bool tandem = false;
+	if (j > qmoff[q] && (qx[j - 1] >> 8) == (x >> 8)) tandem = true;
+	if (j + 1 < qmoff[q + 1] && (qx[j + 1] >> 8) == (x >> 8)) tandem = true;
+	bool check_self = no_self && self_off[q] != self_off[q + 1];
+	u32 n = hit_n[j];
+	u64 st = hit_start[j];
+	mm128 *out = anchors + (a_off[j] - a_base);
+	i32 ql = (i32)qlen[q];
+	for (u32 t = 0; t < n; ++t) {
+		u64 r = pos[st + t];
+		u32 rpos = (u32)r >> 1;
+		if (check_self && rpos == qpos && lq_is_self(self_off, self_rid, q, (u32)(r >> 32))) continue;
+		mm128 a;
+		if ((r & 1) == (qp & 1)) {
+			a.x = (r & 0xffffffff00000000ULL) | rpos;
+			a.y = (u64)q_span << 32 | qpos;
+		} else {
+			a.x = 1ULL << 63 | (r & 0xffffffff00000000ULL) | rpos;
+			a.y = (u64)q_span << 32 | (u32)(ql - (i32)(qpos + 1 - q_span) - 1);
+		}
+		if (tandem) a.y |= LQ_SEED_TANDEM;
+		*out++ = a;
+	}
+}
+
+// per query: anchor range, mini_pos range, avg_qspan (chain.c:37-38), lq_cnt_match prologue
+// (esterr.c:85-97): skip flag and avg_k.
+__global__ void k_query_prep(const u64 *qmoff, const u64 *a_off, const u64 *mp_off, u64 n_qm, u64 n_anchor_total, u64 n_mp_total, u32 n_q,
+                             const u64 *qx, const u32 *a_cnt, const u32 *keep, const u32 *qlen,
+                             u64 *aq_off, u64 *mpq_off, float *avg_qspan, const u64 *lambda, float *avg_k, u32 *skip)
+{
+	u32 q = blockIdx.x * blockDim.x + threadIdx.x;
+	if (q > n_q) return;
+	u64 j0 = qmoff[q];
+	u64 a0 = j0 < n_qm ? a_off[j0] : n_anchor_total;
+	u64 m0 = j0 < n_qm ? mp_off[j0] : n_mp_total;
+	aq_off[q] = a0; mpq_off[q] = m0;
+	if (q == n_q) return;
+	u64 j1 = qmoff[q + 1];
+	u64 sum_span = 0, n_a = 0, sum_k = 0, n_mp = 0;
+	for (u64 j = j0; j < j1; ++j) {
+		u64 span = qx[j] & 0xff;
+		sum_span += span * a_cnt[j]; n_a += a_cnt[j];
+		if (keep[j]) { sum_k += span; ++n_mp; }
+	}
+	avg_qspan[q] = n_a ? __fdiv_rn((float)sum_span, (float)(i64)n_a) : 0.0f;
+	u32 sk = 0;
+	if (n_mp == 0) sk = 1;                                             // esterr.c:85
+	else if (lambda[q] / (u64)qlen[q] > LQ_COVT && avg_k[q] != 0.0f) sk = 1;   // esterr.c:87
+	else if (avg_k[q] == 0.0f) avg_k[q] = __fdiv_rn((float)sum_k, (float)(i32)n_mp);   // esterr.c:93-97
+	skip[q] = sk;
+}

@@ -1,0 +1,268 @@
+// longqc_amd/csrc/kernels_sketch.hpp -- read packing and (w,k)-minimizer extraction on gfx950.
+//
+// What it computes: exactly the list mm_sketch emits (reference sketch.c:76-142: hash64 :27-37,
+// canonical strand :105-108, palindrome skip :107, window ring :115, first-window ties :116-121,
+// new-min / leave-window rules :122-137, final flush :140-141, HPC runs :93-104), in the same
+// order, for every read of a read set.
+//
+// How (MI355X): reads sit in HBM 2-bit packed (+1 "ambiguous" bit/base), chunk-aligned.  One
+// thread owns the loop iterations that *start* inside one 128-base chunk; the 64 lanes of a wave
+// therefore stream 64 consecutive chunks = 3 KiB of packed bases with perfectly coalesced 16-B
+// loads.  mm_sketch is a sequential state machine, but its state is a bounded function of recent
+// history: the last k valid bases (k-mers), min(l, w+k) (emission thresholds) and the last w ring
+// slots.  A thread re-creates it by running the machine silently over a short halo before its
+// chunk and proving convergence (see sk_warm below); if the proof fails (palindrome / N-rich
+// context) the halo is extended, down to the read start where the state is known exactly.
+// Two passes (count, exclusive scan, emit) give every thread its output offset, so the minimizer
+// array comes out in (read, position) order == the reference's emission order, deterministically.
+#pragma once
+#include "lq_common.hpp"
+
+__device__ __forceinline__ int lq_nt4(u8 c)
+{	// seq_nt4_table (sketch.c:8-25): A/C/G/T/U in either case, raw 0..3; everything else ambiguous
+	if (c < 4) return c;
+	switch (c | 0x20) {
+	case 'a': return 0;
+	case 'c': return 1;
+	case 'g': return 2;
+	case 't': case 'u': return 3;
+	}
+	return 4;
+}
+
+// largest r with off[r] <= v  (off has n+1 non-decreasing entries, off[0] = 0, v < off[n])
+__device__ __forceinline__ u32 lq_find_seg(const u64 *off, u32 n, u64 v)
+{
+	u32 lo = 0, hi = n;         // invariant: off[lo] <= v < off[hi]
+	while (hi - lo > 1) {
+		u32 mid = lo + ((hi - lo) >> 1);
+		if (off[mid] <= v) lo = mid; else hi = mid;
+	}
+	return lo;
+}
+
+// ---- pack: ASCII -> 2-bit codes + ambiguity mask, one thread per 32-base word -------------------
+__global__ void k_pack(const u8 *ascii, const u64 *seq_off, const u64 *coff, u32 n_reads, u64 n_words,
+                       u64 *codes, u32 *amb)
+{
+	u64 g = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+	if (g >= n_words) return;
+	u32 r = lq_find_seg(coff, n_reads, g >> 2);
+	u64 p0 = (g - coff[r] * LQ_CHUNK_WORDS) * 32;
+	u64 len = seq_off[r + 1] - seq_off[r];
+	const u8 *s = ascii + seq_off[r];
+	u64 w = 0; u32 m = 0;
+	for (int j = 0; j < 32; ++j) {
+		u64 pos = p0 + j;
+		int c = pos < len ? lq_nt4(s[pos]) : 4;
+		if (c < 4) w |= (u64)c << (2 * j); else m |= 1u << j;
+	}
+	codes[g] = w; amb[g] = m;
+}
+
+// ---- the state machine ------------------------------------------------------------------------
+struct SkParams { i32 k, w, hpc; u64 mask; u32 shift1; };
+
+__device__ __forceinline__ u64 lq_hash64(u64 key, u64 mask)
+{	// sketch.c:27-37 (Thomas Wang's invertible integer hash, masked to 2k bits)
+	key = (~key + (key << 21)) & mask;
+	key = key ^ key >> 24;
+	key = ((key + (key << 3)) + (key << 8)) & mask;
+	key = key ^ key >> 14;
+	key = ((key + (key << 2)) + (key << 4)) & mask;
+	key = key ^ key >> 28;
+	key = (key + (key << 31)) & mask;
+	return key;
+}
+
+struct ReadView {
+	const u64 *codes; const u32 *amb; u32 len;
+	u32 cw; u64 ccodes; u32 camb;                       // one cached word
+	__device__ __forceinline__ void init(const u64 *c, const u32 *a, u32 l) { codes = c; amb = a; len = l; cw = 0xffffffffu; }
+	__device__ __forceinline__ int at(u32 pos)
+	{
+		u32 wi = pos >> 5, b = pos & 31;
+		if (wi != cw) { cw = wi; ccodes = codes[wi]; camb = amb[wi]; }
+		return ((camb >> b) & 1) ? 4 : (int)((ccodes >> (2 * b)) & 3);
+	}
+	// is `pos` the start of a loop iteration of mm_sketch in HPC mode? (sketch.c:93-104)
+	__device__ __forceinline__ bool run_start(u32 pos)
+	{
+		if (pos == 0) return true;
+		int c = at(pos);
+		if (c >= 4) return true;
+		return at(pos - 1) != c;
+	}
+};
+
+template <int RCAP>
+struct SkState {
+	u64 fw, rv, best_x;
+	u32 best_y;
+	i32 l, slot, best_slot, span;
+	i32 rq_front, rq_count;
+	u64 rx[RCAP];
+	u32 ry[RCAP];
+	i32 rq[32];
+	__device__ __forceinline__ void reset(int w)
+	{
+		fw = rv = 0; best_x = LQ_U64MAX; best_y = 0xffffffffu;
+		l = slot = best_slot = span = 0; rq_front = rq_count = 0;
+		for (int j = 0; j < w; ++j) { rx[j] = LQ_U64MAX; ry[j] = 0xffffffffu; }
+	}
+};
+
+struct SkOut {
+	u64 n;            // emitted so far by this thread
+	u64 *x, *y;       // destination (emit pass) or null (count pass)
+	u64 y_hi;         // rid << 32
+};
+
+template <bool EMIT>
+__device__ __forceinline__ void sk_push(SkOut &o, bool live, u64 x, u32 y32)
+{
+	if (!live) return;
+	if (EMIT) { o.x[o.n] = x; o.y[o.n] = o.y_hi | y32; }
+	++o.n;
+}
+
+// One loop iteration of mm_sketch whose (last) base is at `pos` with code c (4 = ambiguous),
+// run = homopolymer run length (1 unless HPC).  Returns true if a ring slot was produced.
+template <int RCAP, bool EMIT>
+__device__ __forceinline__ bool sk_step(SkState<RCAP> &s, const SkParams &P, int c, u32 pos, int run, bool live, SkOut &o, bool &was_pal)
+{
+	const int w = P.w, k = P.k;
+	u64 cx = LQ_U64MAX; u32 cy = 0xffffffffu;
+	was_pal = false;
+	if (c < 4) {
+		if (P.hpc) {
+			s.rq[(s.rq_count++ + s.rq_front) & 0x1f] = run;
+			s.span += run;
+			if (s.rq_count > k) { s.span -= s.rq[s.rq_front++]; s.rq_front &= 0x1f; --s.rq_count; }
+		} else s.span = s.l + 1 < k ? s.l + 1 : k;
+		s.fw = (s.fw << 2 | (u64)c) & P.mask;
+		s.rv = (s.rv >> 2) | (3ULL ^ (u64)c) << P.shift1;
+		if (s.fw == s.rv) { was_pal = true; return false; }       // sketch.c:107: no slot, l unchanged
+		int z = s.fw < s.rv ? 0 : 1;
+		++s.l;
+		if (s.l >= k && s.span < 256) {
+			cx = lq_hash64(z ? s.rv : s.fw, P.mask) << 8 | (u64)s.span;
+			cy = pos << 1 | (u32)z;
+		}
+	} else { s.l = 0; s.rq_count = s.rq_front = 0; s.span = 0; }   // sketch.c:114
+	const int slot = s.slot;
+	s.rx[slot] = cx; s.ry[slot] = cy;
+	if (s.l == w + k - 1 && s.best_x != LQ_U64MAX) {              // sketch.c:116-121
+		for (int j = slot + 1; j < w; ++j) if (s.rx[j] == s.best_x && s.ry[j] != s.best_y) sk_push<EMIT>(o, live, s.rx[j], s.ry[j]);
+		for (int j = 0; j < slot; ++j)     if (s.rx[j] == s.best_x && s.ry[j] != s.best_y) sk_push<EMIT>(o, live, s.rx[j], s.ry[j]);
+	}
+	if (cx <= s.best_x) {                                          // sketch.c:122-124
+		if (s.l >= w + k && s.best_x != LQ_U64MAX) sk_push<EMIT>(o, live, s.best_x, s.best_y);
+		s.best_x = cx; s.best_y = cy; s.best_slot = slot;
+	} else if (slot == s.best_slot) {                              // sketch.c:125-137
+		if (s.l >= w + k - 1 && s.best_x != LQ_U64MAX) sk_push<EMIT>(o, live, s.best_x, s.best_y);
+		s.best_x = LQ_U64MAX;
+		for (int j = slot + 1; j < w; ++j) if (s.best_x >= s.rx[j]) { s.best_x = s.rx[j]; s.best_y = s.ry[j]; s.best_slot = j; }
+		for (int j = 0; j <= slot; ++j)    if (s.best_x >= s.rx[j]) { s.best_x = s.rx[j]; s.best_y = s.ry[j]; s.best_slot = j; }
+		if (s.l >= w + k - 1 && s.best_x != LQ_U64MAX) {
+			for (int j = slot + 1; j < w; ++j) if (s.rx[j] == s.best_x && s.ry[j] != s.best_y) sk_push<EMIT>(o, live, s.rx[j], s.ry[j]);
+			for (int j = 0; j <= slot; ++j)    if (s.rx[j] == s.best_x && s.ry[j] != s.best_y) sk_push<EMIT>(o, live, s.rx[j], s.ry[j]);
+		}
+	}
+	s.slot = slot + 1 == w ? 0 : slot + 1;
+	return true;
+}
+
+// Fetch the loop iteration that starts at i: its code, run length and the index of its last base.
+__device__ __forceinline__ void sk_fetch(ReadView &rv, const SkParams &P, u32 i, int &c, int &run, u32 &last)
+{
+	c = rv.at(i); run = 1; last = i;
+	if (P.hpc && c < 4) {
+		u32 j = i + 1;
+		while (j < rv.len && rv.at(j) == c) ++j;
+		run = (int)(j - i); last = j - 1;
+	}
+}
+
+// Bring `s` to the state mm_sketch has just before the iteration starting at i0 (i0 is an
+// iteration start).  Runs the machine silently from a halo start s0 < i0 and accepts the result
+// only when it provably equals the true state:
+//   * k k-mer updates have happened since s0                      -> fw/rv (and the HPC run queue) exact;
+//   * since then, either an ambiguous base reset l (l exact from there on) or lsim >= w+k
+//     non-palindromic steps were seen (every threshold test on l then agrees with the true l);
+//   * the last w ring slots were all produced in that exact regime.
+// Otherwise the halo is widened (x4) until it reaches the read start, where the state is exact.
+template <int RCAP>
+__device__ __forceinline__ void sk_warm(SkState<RCAP> &s, ReadView &rv, const SkParams &P, u32 i0)
+{
+	u32 halo = 64;
+	SkOut none; none.n = 0; none.x = none.y = nullptr; none.y_hi = 0;
+	for (;;) {
+		u32 s0 = i0 > halo ? i0 - halo : 0;
+		if (P.hpc) while (s0 > 0 && !rv.run_start(s0)) --s0;
+		s.reset(P.w);
+		if (s0 == i0) return;
+		int nk = 0, lsim = 0, exact_run = 0;
+		bool lx = false;
+		u32 i = s0;
+		while (i < i0) {
+			int c, run; u32 last; bool pal;
+			sk_fetch(rv, P, i, c, run, last);
+			bool slot = sk_step<RCAP, false>(s, P, c, last, run, false, none, pal);
+			if (c >= 4) { lx = nk >= P.k; lsim = 0; ++exact_run; }   // an N slot is (MAX,MAX) whatever the history
+			else {
+				++nk;
+				if (nk < P.k) exact_run = 0;
+				else if (slot) {
+					++lsim;
+					exact_run = (lx || lsim >= P.k) ? exact_run + 1 : 0;
+				}
+			}
+			i = last + 1;
+		}
+		if (s0 == 0) return;
+		if (nk >= P.k && exact_run >= P.w && (lx || lsim >= P.w + P.k)) return;
+		halo = halo >= 4096 ? 0xffffffffu : halo * 4;
+	}
+}
+
+// count pass: cnt[g] = minimizers decided by chunk g;  emit pass: written at off[g]...
+template <int RCAP, bool EMIT>
+__global__ void k_sketch(const u64 *codes, const u32 *amb, const u64 *coff, const u32 *rlen, u32 n_reads, u64 n_chunks,
+                         SkParams P, int rid_in_y, u32 *cnt, const u64 *off, u64 *out_x, u64 *out_y)
+{
+	u64 g = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+	if (g >= n_chunks) return;
+	u32 r = lq_find_seg(coff, n_reads, g);
+	u32 len = rlen[r];
+	u32 pos0 = (u32)(g - coff[r]) * LQ_CHUNK;
+	u32 pos1 = pos0 + LQ_CHUNK < len ? pos0 + LQ_CHUNK : len;
+	ReadView rv; rv.init(codes + coff[r] * LQ_CHUNK_WORDS, amb + coff[r] * LQ_CHUNK_WORDS, len);
+	u32 i = pos0;
+	if (P.hpc) while (i < len && !rv.run_start(i)) ++i;        // first iteration this chunk owns
+	SkOut o; o.n = 0; o.y_hi = rid_in_y ? (u64)r << 32 : 0;
+	o.x = o.y = nullptr;
+	if (EMIT) { o.x = out_x + off[g]; o.y = out_y + off[g]; }
+	if (i < pos1) {
+		SkState<RCAP> s;
+		sk_warm<RCAP>(s, rv, P, i);
+		while (i < pos1) {
+			int c, run; u32 last; bool pal;
+			sk_fetch(rv, P, i, c, run, last);
+			sk_step<RCAP, EMIT>(s, P, c, last, run, true, o, pal);
+			i = last + 1;
+		}
+		if (i >= len && s.best_x != LQ_U64MAX)                    // this thread ran the read's last iteration: sketch.c:140-141
+			sk_push<EMIT>(o, true, s.best_x, s.best_y);
+	}
+	if (!EMIT) cnt[g] = (u32)o.n;
+}
+
+// per-read minimizer offsets from per-chunk offsets
+__global__ void k_read_moff(const u64 *coff, const u64 *chunk_off, u32 n_reads, u64 n_chunks, u64 total, u64 *moff)
+{
+	u32 r = blockIdx.x * blockDim.x + threadIdx.x;
+	if (r > n_reads) return;
+	u64 c = coff[r];
+	moff[r] = c < n_chunks ? chunk_off[c] : total;
+}

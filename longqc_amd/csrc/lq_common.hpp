@@ -1,0 +1,47 @@
+// longqc_amd/csrc/lq_common.hpp -- shared types of the MI355X coverage engine.
+#pragma once
+#ifndef LQ_EMU
+#include <hip/hip_runtime.h>
+#define LQ_LAUNCH(kern, grid, block, stream, ...) hipLaunchKernelGGL(kern, dim3(grid), dim3(block), 0, stream, __VA_ARGS__)
+#endif
+#include <cstdint>
+#include <cstddef>
+
+typedef uint8_t u8;
+typedef uint16_t u16;
+typedef uint32_t u32;
+typedef uint64_t u64;
+typedef int32_t i32;
+typedef int64_t i64;
+
+#define LQ_U64MAX 0xffffffffffffffffULL
+
+// One sketch thread owns the loop iterations that start inside one 128-base chunk of a read.
+// Reads are laid out chunk-aligned in the packed arrays: 4 x u64 of 2-bit codes and 4 x u32 of
+// "ambiguous" bits per chunk.
+#define LQ_CHUNK       128
+#define LQ_CHUNK_WORDS 4
+
+#define LQ_COVT 150            // minimap2-coverage.h:20
+#define LQ_SEED_TANDEM (1ULL << 42)   // mmpriv.h:18
+#define LQ_RS_MIN 64           // ksort.h:81
+
+struct alignas(16) mm128 { u64 x, y; };        // minimap.h:42
+
+// A sub-array the klib-order sort still has to partition by the byte at `shift` (ksort.h:99-129)
+struct alignas(16) SortSeg { u64 off; u32 len; u32 shift; };
+
+// interval tagged with its query: pos<<3 | flags (bit0 end, bit1 medium score, bit2 marker),
+// minimap2-coverage.h:22-25, esterr.c:122-125, lqmap.c:69-71
+struct Ivl { u32 q, start, end; };
+
+struct ChainRec { i32 q, rid, rev, score, cnt, qs, qe, rs, re; };
+
+struct MapParams {
+	i32 k, w, hpc;
+	i32 max_gap, bw, max_skip, min_cnt, min_sc;
+	i32 min_sc_med, min_sc_good;
+	i32 max_overhang, min_coverage;
+	double min_ratio;
+	i32 no_self, ava;
+};
