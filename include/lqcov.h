@@ -162,6 +162,23 @@ int lqcov_part_sketch(lqcov_handle *h, int part);
 int lqcov_part_build_from_minimizers_dev(lqcov_handle *h, int part, const uint64_t *x_dev, const uint64_t *y_dev, uint64_t n,
                                          uint32_t n_targets, const uint32_t *target_len, const char *names, const uint64_t *name_off);
 
+/* Index parts on different GPUs == the reference's own -I partitioning (minimap2-coverage.c:449-458) run in
+ * parallel.  Parts only interact through (i) mid_occ, frozen from part 0 (map.c:50), (ii) the COVT cap, which
+ * drops part p for a query whose lambda/qlen already exceeds 150 (esterr.c:87), and (iii) avg_k, set by the first
+ * part that sees the query (esterr.c:93-97).  In distributed mode a handle therefore maps its part with fresh
+ * accumulators and no cap; the driver (longqc_amd/multigpu.py) exchanges the per-part accumulators over RCCL,
+ * replays (ii) and (iii) in part order, and imports the sums for lqcov_finish().                            */
+int lqcov_set_distributed(lqcov_handle *h, int on);
+int lqcov_set_mid_occ(lqcov_handle *h, int32_t mid_occ);
+int lqcov_accum_sizes(lqcov_handle *h, uint32_t *n_queries, uint64_t *n_counters, uint32_t *n_intervals);
+/* copy the accumulators to caller-owned device buffers: lambda/lambda2 [n_queries] u64, avg_k [n_queries] f32,
+ * flags [n_queries] u32, counters [n_counters] u32 with their query index counter_owner [n_counters] u32,
+ * intervals [n_intervals][3] u32 = (query, start, end) encoded as lqmap.c:69-71.  NULL pointers are skipped. */
+int lqcov_accum_export_dev(lqcov_handle *h, uint64_t *lambda_dev, uint64_t *lambda2_dev, float *avg_k_dev, uint32_t *flags_dev,
+                           uint32_t *counters_dev, uint32_t *counter_owner_dev, uint32_t *intervals_dev);
+int lqcov_accum_import_dev(lqcov_handle *h, const uint64_t *lambda_dev, const uint64_t *lambda2_dev, const float *avg_k_dev, const uint32_t *flags_dev,
+                           const uint32_t *counters_dev, const uint32_t *intervals_dev, uint32_t n_intervals);
+
 #ifdef __cplusplus
 }
 #endif

@@ -98,6 +98,11 @@ def load_library(path: Optional[str] = None):
         "lqcov_get_part_minimizers": (C.c_int, [H, C.c_int, C.c_void_p, C.c_void_p, u64p]),
         "lqcov_get_chains": (C.c_int, [H, C.c_void_p, C.c_uint64, u64p]),
         "lqcov_part_minimizers_dev": (C.c_int, [H, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), u64p]),
+        "lqcov_set_distributed": (C.c_int, [H, C.c_int]),
+        "lqcov_set_mid_occ": (C.c_int, [H, C.c_int32]),
+        "lqcov_accum_sizes": (C.c_int, [H, C.POINTER(C.c_uint32), u64p, C.POINTER(C.c_uint32)]),
+        "lqcov_accum_export_dev": (C.c_int, [H] + [C.c_void_p] * 7),
+        "lqcov_accum_import_dev": (C.c_int, [H] + [C.c_void_p] * 6 + [C.c_uint32]),
         "lqcov_part_build_from_minimizers_dev": (C.c_int, [H, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32,
                                                            C.c_void_p, C.c_void_p, C.c_void_p]),
     }
@@ -313,6 +318,24 @@ class Engine:
         n = self._ck(self.lib.lqcov_get_stage_times(self.h, arr, 64))
         return [dict(name=arr[i].name.decode(), total_ms=arr[i].total_ms, launches=arr[i].launches, algo_bytes=arr[i].algo_bytes)
                 for i in range(n)]
+
+    # -- multi-GPU plumbing (pointers are device pointers, e.g. torch tensors' data_ptr()) --
+    def set_distributed(self, on: bool):
+        self._ck(self.lib.lqcov_set_distributed(self.h, 1 if on else 0))
+
+    def set_mid_occ(self, v: int):
+        self._ck(self.lib.lqcov_set_mid_occ(self.h, int(v)))
+
+    def accum_sizes(self) -> Tuple[int, int, int]:
+        a, b, c = C.c_uint32(), C.c_uint64(), C.c_uint32()
+        self._ck(self.lib.lqcov_accum_sizes(self.h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
+    def accum_export(self, lam, lam2, avgk, flags, cnts, owner, ivl):
+        self._ck(self.lib.lqcov_accum_export_dev(self.h, lam, lam2, avgk, flags, cnts, owner, ivl))
+
+    def accum_import(self, lam, lam2, avgk, flags, cnts, ivl, n_ivl: int):
+        self._ck(self.lib.lqcov_accum_import_dev(self.h, lam, lam2, avgk, flags, cnts, ivl, n_ivl))
 
     def part_minimizers_dev(self, part: int) -> Tuple[int, int, int]:
         x, y, n = C.c_void_p(), C.c_void_p(), C.c_uint64()

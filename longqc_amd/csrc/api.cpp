@@ -315,6 +315,63 @@ int lqcov_part_build_from_minimizers_dev(lqcov_handle *h, int part, const uint64
 	});
 }
 
+// ---- multi-GPU plumbing: per-part accumulators in / out (device pointers) ------------------------
+int lqcov_set_distributed(lqcov_handle *h, int on) { if (!h) return LQCOV_E_ARG; h->distributed = on != 0; return 0; }
+int lqcov_set_mid_occ(lqcov_handle *h, int32_t v) { if (!h) return LQCOV_E_ARG; h->mid_occ = v; return 0; }
+
+int lqcov_accum_sizes(lqcov_handle *h, uint32_t *n_queries, uint64_t *n_counters, uint32_t *n_intervals)
+{
+	return guard(h, [&] {
+		if (!h->have_queries) throw std::logic_error("no queries");
+		u32 npv = 0;
+		LQ_HIP_CHECK(hipMemcpy(&npv, h->n_pv.p, 4, hipMemcpyDeviceToHost));
+		if (n_queries) *n_queries = h->q.n;
+		if (n_counters) *n_counters = h->q.n_mini;
+		if (n_intervals) *n_intervals = npv;
+	});
+}
+
+static void dcopy(void *dst, const void *src, size_t bytes, hipStream_t s)
+{
+	if (bytes && dst && src) LQ_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, s));
+}
+
+int lqcov_accum_export_dev(lqcov_handle *h, uint64_t *lambda_dev, uint64_t *lambda2_dev, float *avg_k_dev, uint32_t *flags_dev,
+                           uint32_t *counters_dev, uint32_t *counter_owner_dev, uint32_t *intervals_dev)
+{
+	return guard(h, [&] {
+		if (!h->have_queries) throw std::logic_error("no queries");
+		const u32 n = h->q.n;
+		u32 npv = 0;
+		LQ_HIP_CHECK(hipMemcpy(&npv, h->n_pv.p, 4, hipMemcpyDeviceToHost));
+		dcopy(lambda_dev, h->lambda.p, (size_t)n * 8, h->stream); dcopy(lambda2_dev, h->lambda2.p, (size_t)n * 8, h->stream);
+		dcopy(avg_k_dev, h->avg_k.p, (size_t)n * 4, h->stream); dcopy(flags_dev, h->qflags.p, (size_t)n * 4, h->stream);
+		dcopy(counters_dev, h->cnts.p, (size_t)h->q.n_mini * 4, h->stream);
+		dcopy(counter_owner_dev, h->q_owner.p, (size_t)h->q.n_mini * 4, h->stream);
+		dcopy(intervals_dev, h->pv.p, (size_t)npv * sizeof(Ivl), h->stream);
+		LQ_HIP_CHECK(hipStreamSynchronize(h->stream));
+	});
+}
+
+int lqcov_accum_import_dev(lqcov_handle *h, const uint64_t *lambda_dev, const uint64_t *lambda2_dev, const float *avg_k_dev, const uint32_t *flags_dev,
+                           const uint32_t *counters_dev, const uint32_t *intervals_dev, uint32_t n_intervals)
+{
+	return guard(h, [&] {
+		if (!h->have_queries) throw std::logic_error("no queries");
+		const u32 n = h->q.n;
+		static_assert(sizeof(Ivl) == 12, "interval layout");
+		h->pv.ensure((size_t)n_intervals * sizeof(Ivl) + 16);
+		h->pv_cap = (u32)std::min<u64>(h->pv.cap / sizeof(Ivl), 0xfffffff0ULL);
+		dcopy(h->lambda.p, lambda_dev, (size_t)n * 8, h->stream); dcopy(h->lambda2.p, lambda2_dev, (size_t)n * 8, h->stream);
+		dcopy(h->avg_k.p, avg_k_dev, (size_t)n * 4, h->stream); dcopy(h->qflags.p, flags_dev, (size_t)n * 4, h->stream);
+		dcopy(h->cnts.p, counters_dev, (size_t)h->q.n_mini * 4, h->stream);
+		dcopy(h->pv.p, intervals_dev, (size_t)n_intervals * sizeof(Ivl), h->stream);
+		LQ_HIP_CHECK(hipMemcpyAsync(h->n_pv.p, &n_intervals, 4, hipMemcpyHostToDevice, h->stream));
+		LQ_HIP_CHECK(hipStreamSynchronize(h->stream));
+		h->finished = false;
+	});
+}
+
 int lqcov_run_files(lqcov_handle *h, const char *target, const char *query, const char *out_path, const char *err_path)
 {
 	return guard(h, [&] {

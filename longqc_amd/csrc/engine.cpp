@@ -236,7 +236,7 @@ void lqcov_handle::reset()
 	dzero(avg_k.p, (n + 1) * 4, stream); dzero(qflags.p, (n + 1) * 4, stream);
 	dzero(cnts.p, q.n_mini * 4 + 4, stream);
 	dzero(n_pv.p, 4, stream);
-	mid_occ = -1;
+	if (!distributed) mid_occ = -1;
 	finished = false;
 	LQ_HIP_CHECK(hipStreamSynchronize(stream));
 }
@@ -352,7 +352,7 @@ void lqcov_handle::map_part(Part &pt)
 	mini_pos.ensure(n_mp_total * 8 + 8);
 	LQ_LAUNCH(k_query_prep, nblk(n_q + 1, 128), 128, stream, q.moff.as<u64>(), a_off.as<u64>(), mp_off.as<u64>(), n_qm, nA_total, n_mp_total, n_q,
 	          q.mx.as<u64>(), a_cnt.as<u32>(), keep.as<u32>(), q.d_len.as<u32>(),
-	          aq_off.as<u64>(), mpq_off.as<u64>(), avg_qspan.as<float>(), lambda.as<u64>(), avg_k.as<float>(), skip.as<u32>());
+	          aq_off.as<u64>(), mpq_off.as<u64>(), avg_qspan.as<float>(), lambda.as<u64>(), avg_k.as<float>(), skip.as<u32>(), distributed ? 0 : 1);
 	check_launch();
 	std::vector<u64> h_aq(n_q + 1), h_qmoff(n_q + 1);
 	d2h(h_aq.data(), aq_off.as<u64>(), n_q + 1, stream);
@@ -508,7 +508,7 @@ void lqcov_handle::finish()
 	}
 	{
 		StageTimer t(this, "k_cnt_stats", q.n_mini * 8);
-		LQ_LAUNCH(k_cnt_stats, nblk(n_q, 64), 64, stream, cnts.as<u32>(), q.moff.as<u64>(), n_q, rowdev.as<RowDev>());
+		LQ_LAUNCH(k_cnt_stats, nblk(n_q, 64), 64, stream, cnts.as<u32>(), q.moff.as<u64>(), n_q, rowdev.as<RowDev>(), qflags.as<u32>());
 		check_launch();
 	}
 	std::vector<RowDev> hr(n_q);

@@ -49,6 +49,7 @@ struct lqcov_handle {
 	std::string err;
 	bool profiling = false;
 	u32 debug_flags = 0;
+	bool distributed = false;             // per-part accumulators, COVT replayed by the caller (multi-GPU)
 	std::map<std::string, StageAcc> stages;
 	std::vector<std::string> stage_order;
 

@@ -160,7 +160,7 @@ __global__ void k_seed_emit(const u64 *qx, const u64 *qy, const u32 *owner, cons
 // (esterr.c:85-97): skip flag and avg_k.
 __global__ void k_query_prep(const u64 *qmoff, const u64 *a_off, const u64 *mp_off, u64 n_qm, u64 n_anchor_total, u64 n_mp_total, u32 n_q,
                              const u64 *qx, const u32 *a_cnt, const u32 *keep, const u32 *qlen,
-                             u64 *aq_off, u64 *mpq_off, float *avg_qspan, const u64 *lambda, float *avg_k, u32 *skip)
+                             u64 *aq_off, u64 *mpq_off, float *avg_qspan, const u64 *lambda, float *avg_k, u32 *skip, int covt_on)
 {
 	u32 q = blockIdx.x * blockDim.x + threadIdx.x;
 	if (q > n_q) return;
@@ -179,7 +179,7 @@ __global__ void k_query_prep(const u64 *qmoff, const u64 *a_off, const u64 *mp_o
 	avg_qspan[q] = n_a ? __fdiv_rn((float)sum_span, (float)(i64)n_a) : 0.0f;
 	u32 sk = 0;
 	if (n_mp == 0) sk = 1;                                             // esterr.c:85
-	else if (lambda[q] / (u64)qlen[q] > LQ_COVT && avg_k[q] != 0.0f) sk = 1;   // esterr.c:87
+	else if (covt_on && lambda[q] / (u64)qlen[q] > LQ_COVT && avg_k[q] != 0.0f) sk = 1;   // esterr.c:87
 	else if (avg_k[q] == 0.0f) avg_k[q] = __fdiv_rn((float)sum_k, (float)(i32)n_mp);   // esterr.c:93-97
 	skip[q] = sk;
 }

@@ -1,0 +1,157 @@
+"""Index parts across GPUs: one process per GPU, `torch.distributed` (backend "nccl" == RCCL over xGMI on
+the GPU box, "gloo" in CPU tests) moves the per-part accumulators; every byte of compute stays in the HIP
+engine behind the C ABI.
+
+Why this sharding is exact.  The reference already splits the target set into index parts (-I,
+index.c:244,311-316) and runs every query against every part in file order with persistent accumulators
+(minimap2-coverage.c:449-458).  Within a part nothing depends on other parts except
+  (i)   mid_occ, computed from part 0 only (map.c:50)                      -> broadcast from part 0's owner;
+  (ii)  the COVT cap: part p is skipped for a query once lambda/qlen > 150 (esterr.c:87), lambda being the
+        sum over the parts < p that were not skipped                       -> replayed here in part order
+        from the all-gathered per-part lambdas (a few KB per part);
+  (iii) avg_k, taken from the first part that sees the query (esterr.c:93-97) -> same replay.
+Everything else a part contributes -- lambda, lambda2, the uint16 match counters (indexed by that part's
+own filtered minimizer list, esterr.c:131-137) and the intervals that survive filter_redundant_coords for
+that (query, part) (lqmap.c:287) -- is additive / concatenative, so parts can run concurrently on
+different GPUs and be reduced: all_reduce(SUM) for the sums and counters, all_gather for the intervals.
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+COVT = 150  # minimap2-coverage.h:20
+
+
+def covt_replay(lam_parts: torch.Tensor, avgk_parts: torch.Tensor, qlen: torch.Tensor,
+                lam0: Optional[torch.Tensor] = None, avgk0: Optional[torch.Tensor] = None):
+    """Replays lq_cnt_match's prologue (esterr.c:85-97) over parts in order.
+    lam_parts [P, n_q] int64: lambda each part would add if it is not skipped; avgk_parts [P, n_q] float32:
+    the part's avg_k candidate, 0 where the part has no usable minimizer for the query (n == 0).
+    Returns (include [P, n_q] bool, lam_total, avg_k)."""
+    P, n_q = lam_parts.shape
+    lam = torch.zeros(n_q, dtype=torch.int64, device=lam_parts.device) if lam0 is None else lam0.clone()
+    avgk = torch.zeros(n_q, dtype=torch.float32, device=lam_parts.device) if avgk0 is None else avgk0.clone()
+    ql = qlen.to(torch.int64).clamp(min=1)
+    inc = torch.zeros((P, n_q), dtype=torch.bool, device=lam_parts.device)
+    for p in range(P):
+        seen = avgk_parts[p] != 0                                 # n > 0 (esterr.c:85)
+        capped = (torch.div(lam, ql, rounding_mode="floor") > COVT) & (avgk != 0)   # esterr.c:87 (integer division)
+        use = seen & ~capped
+        avgk = torch.where(use & (avgk == 0), avgk_parts[p], avgk)                 # esterr.c:93-97
+        lam = lam + torch.where(use, lam_parts[p], torch.zeros_like(lam))
+        inc[p] = use
+    return inc, lam, avgk
+
+
+def split_parts(lengths, batch_size: int, mini_batch: int = 50000000):
+    """Read-index ranges [(start, end), ...] of the reference's index parts: mini-batches of min(50M, -I) bases
+    (a mini-batch ends with the read that reaches the size, bseq.c:86-98) are appended while the running total
+    is <= -I, checked before each mini-batch (index.c:244,311-316)."""
+    chunk = min(int(mini_batch), int(batch_size))
+    parts, i, n = [], 0, len(lengths)
+    while i < n:
+        start, total = i, 0
+        while i < n and not total > batch_size:
+            size = 0
+            while i < n:
+                size += int(lengths[i]); i += 1
+                if size >= chunk:
+                    break
+            total += size
+        parts.append((start, i))
+    return parts
+
+
+class PartRunner:
+    """Drives one handle per rank through rounds of `world` concurrent parts and keeps the combined
+    accumulators; `finalize()` imports them into the handle so that lqcov_finish() produces the rows."""
+
+    def __init__(self, eng, world: int, rank: int, device: torch.device, query_lengths, group=None):
+        self.eng, self.world, self.rank, self.dev, self.group = eng, world, rank, device, group
+        eng.set_distributed(True)
+        n_q, n_cnt, _ = eng.accum_sizes()
+        self.n_q, self.n_cnt = n_q, n_cnt
+        self.qlen = torch.as_tensor(np.asarray(query_lengths, dtype=np.int64), device=self.dev)
+        assert self.qlen.shape[0] == n_q
+        self.begin()
+
+    def begin(self):
+        """start a new job (== the reference binary starting): running totals to zero, mid_occ unset"""
+        self.eng.set_mid_occ(-1)
+        z = lambda n, dt: torch.zeros(max(n, 1), dtype=dt, device=self.dev)
+        self.lam, self.lam2 = z(self.n_q, torch.int64), z(self.n_q, torch.int64)
+        self.avgk, self.flags = z(self.n_q, torch.float32), z(self.n_q, torch.int32)
+        self.cnts = z(self.n_cnt, torch.int32)
+        self.ivl: List[torch.Tensor] = []
+
+    def share_mid_occ(self, owner_rank: int = 0):
+        """mid_occ comes from part 0 (map.c:50): its owner broadcasts it after building."""
+        t = torch.tensor([self.eng.mid_occ], dtype=torch.int32, device=self.dev)
+        if self.world > 1:
+            dist.broadcast(t, src=owner_rank, group=self.group)
+        self.eng.set_mid_occ(int(t.item()))
+
+    def map_and_combine(self, part: Optional[int], part_index: int, mid_occ_owner: int = 0, share_mid_occ: bool = True):
+        """One round: this rank maps `part` (its handle-local id; None if it has no part this round), which is part
+        `part_index` of the global order; all ranks then combine the round.  Parts of a round are consecutive:
+        rank r holds part round_base + r."""
+        eng, dev = self.eng, self.dev
+        if share_mid_occ:
+            self.share_mid_occ(mid_occ_owner)
+        n_q, n_cnt = self.n_q, self.n_cnt
+        lam, lam2 = torch.zeros(max(n_q, 1), dtype=torch.int64, device=dev), torch.zeros(max(n_q, 1), dtype=torch.int64, device=dev)
+        avgk, flags = torch.zeros(max(n_q, 1), dtype=torch.float32, device=dev), torch.zeros(max(n_q, 1), dtype=torch.int32, device=dev)
+        cnts, owner = torch.zeros(max(n_cnt, 1), dtype=torch.int32, device=dev), torch.zeros(max(n_cnt, 1), dtype=torch.int32, device=dev)
+        ivl = torch.zeros((0, 3), dtype=torch.int32, device=dev)
+        if part is not None:
+            eng.reset()                                           # per-part accumulators (mid_occ survives in distributed mode)
+            eng.part_map(part)
+            _, _, n_ivl = eng.accum_sizes()
+            ivl = torch.zeros((max(n_ivl, 1), 3), dtype=torch.int32, device=dev)
+            eng.accum_export(lam.data_ptr(), lam2.data_ptr(), avgk.data_ptr(), flags.data_ptr(), cnts.data_ptr(), owner.data_ptr(), ivl.data_ptr())
+            ivl = ivl[:n_ivl]
+        # (ii)/(iii): replay the cap and avg_k over this round's parts, in part order
+        if self.world > 1:
+            lam_all = [torch.empty_like(lam) for _ in range(self.world)]
+            avgk_all = [torch.empty_like(avgk) for _ in range(self.world)]
+            dist.all_gather(lam_all, lam, group=self.group)
+            dist.all_gather(avgk_all, avgk, group=self.group)
+            lam_parts, avgk_parts = torch.stack(lam_all), torch.stack(avgk_all)
+        else:
+            lam_parts, avgk_parts = lam[None], avgk[None]
+        inc, lam_tot, avgk_tot = covt_replay(lam_parts[:, :n_q], avgk_parts[:, :n_q], self.qlen, self.lam[:n_q], self.avgk[:n_q])
+        mine = inc[self.rank] if part is not None else torch.zeros(n_q, dtype=torch.bool, device=dev)
+        lam2c = torch.where(mine, lam2[:n_q], torch.zeros_like(lam2[:n_q]))
+        cntc = torch.where(mine[owner[:n_cnt].long()], cnts[:n_cnt], torch.zeros_like(cnts[:n_cnt])) if n_cnt else cnts[:0]
+        flagc = torch.where(mine, flags[:n_q], torch.zeros_like(flags[:n_q]))
+        ivlc = ivl[mine[ivl[:, 0].long()]] if ivl.shape[0] else ivl
+        if self.world > 1:
+            dist.all_reduce(lam2c, group=self.group)
+            if n_cnt:
+                dist.all_reduce(cntc, group=self.group)
+            dist.all_reduce(flagc, op=dist.ReduceOp.MAX, group=self.group)
+            sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(self.world)]
+            dist.all_gather(sizes, torch.tensor([ivlc.shape[0]], dtype=torch.int64, device=dev), group=self.group)
+            mx = int(max(int(s.item()) for s in sizes))
+            pad = torch.zeros((max(mx, 1), 3), dtype=torch.int32, device=dev)
+            pad[:ivlc.shape[0]] = ivlc
+            got = [torch.empty_like(pad) for _ in range(self.world)]
+            dist.all_gather(got, pad, group=self.group)
+            ivlc = torch.cat([g[:int(s.item())] for g, s in zip(got, sizes)], dim=0)
+        self.lam[:n_q], self.avgk[:n_q] = lam_tot, avgk_tot
+        self.lam2[:n_q] += lam2c
+        if n_cnt:
+            self.cnts[:n_cnt] += cntc
+        self.flags[:n_q] = torch.maximum(self.flags[:n_q], flagc)
+        self.ivl.append(ivlc)
+        self.finalize()
+
+    def finalize(self):
+        ivl = torch.cat(self.ivl, dim=0).contiguous() if self.ivl else torch.zeros((0, 3), dtype=torch.int32, device=self.dev)
+        self._ivl_keep = ivl if ivl.shape[0] else torch.zeros((1, 3), dtype=torch.int32, device=self.dev)
+        self.eng.accum_import(self.lam.data_ptr(), self.lam2.data_ptr(), self.avgk.data_ptr(), self.flags.data_ptr(),
+                              self.cnts.data_ptr(), self._ivl_keep.data_ptr(), int(ivl.shape[0]))

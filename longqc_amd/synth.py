@@ -133,16 +133,17 @@ class ReadSet:
 
 
 def make_reads(cfg: SynthConfig, genome: Optional[np.ndarray] = None, n_reads: Optional[int] = None,
-               read_offset: int = 0) -> ReadSet:
-    """Generate reads [read_offset, read_offset + n_reads) of the config (each read has its own RNG
-    stream so that any slice of the set can be regenerated independently, e.g. one shard per rank)."""
+               read_offset: int = 0, indices: Optional[Sequence[int]] = None) -> ReadSet:
+    """Generate reads [read_offset, read_offset + n_reads) of the config, or exactly `indices` (each
+    read has its own RNG stream so that any slice of the set can be regenerated independently, e.g.
+    one shard per rank, or just the query subsample)."""
     if genome is None:
         genome = make_genome(cfg)
     G = genome.shape[0]
     n = cfg.n_reads if n_reads is None else n_reads
     names, seqs, quals = [], [], []
     scale = cfg.mean_len / cfg.gamma_shape
-    for i in range(read_offset, read_offset + n):
+    for i in (indices if indices is not None else range(read_offset, read_offset + n)):
         rng = np.random.default_rng([cfg.seed, 77, i])
         L = int(rng.gamma(cfg.gamma_shape, scale))
         L = max(cfg.min_len, min(L, 10 * cfg.mean_len, G))

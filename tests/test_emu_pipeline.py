@@ -1,0 +1,142 @@
+"""Kernel-logic tests without a GPU: the product's kernel sources, compiled as plain C++ against the
+serial HIP stand-in (tests/emu), must reproduce the reference's golden vectors and agree with the
+oracle bit for bit.  This validates indexing, the sketch state machine with its halo warm-up, the
+klib-order sort walk, chaining and coverage arithmetic -- not the GPU execution itself (the -m gpu
+tests do that through the real liblqcov.so)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from longqc_amd import api
+from tests import oracle_bind
+from tests.conftest import GOLDEN, read_gz
+from tests.helpers import ONT, parse_chain_dump, parse_sketch_dump, read_fastx, run_main
+
+
+def _cases(kind):
+    return [c for c in json.load(open(os.path.join(GOLDEN, "cases.json"))) if c["kind"] == kind]
+
+
+@pytest.mark.parametrize("case", _cases("table"), ids=lambda c: c["name"])
+def test_emulated_pipeline_reproduces_reference_tables(emu_lib, case):
+    rc, out, err = run_main(emu_lib, case["argv"], cwd=GOLDEN)
+    assert rc == 0, err
+    assert out == read_gz(case["expect"])
+
+
+def _engine(lib, **kw):
+    p = api.Params()
+    lib.lqcov_params_default(p)
+    p.no_self = 1; p.min_ovlp = 0; p.min_score_med = 160; p.min_score_good = 160
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return api.Engine(p, 0, lib=lib)
+
+
+@pytest.mark.parametrize("name,k,w,hpc,fn", [
+    ("tiny_sketch_k12w5", 12, 5, 0, "tiny_sub.fq.gz"),
+    ("adv_sketch_k12w5", 12, 5, 0, "adv_sub.fq.gz"),
+    ("adv_sketch_k15w10hpc", 15, 10, 1, "adv_sub.fq.gz"),
+    ("adv_sketch_k19w10", 19, 10, 0, "adv_sub.fq.gz"),
+    ("adv_sketch_k6w30", 6, 30, 0, "adv_sub.fq.gz"),
+])
+def test_emulated_sketch_equals_mm_sketch_fixture(emu_lib, name, k, w, hpc, fn):
+    want = parse_sketch_dump(read_gz(name + ".dump.gz"))
+    names, seqs, quals = read_fastx(os.path.join(GOLDEN, fn))
+    eng = _engine(emu_lib, k=k, w=w, hpc=hpc, min_score_med=40, min_score_good=40)
+    eng.set_queries(names, seqs, quals)
+    xy, off = eng.query_minimizers()
+    assert len(want) == len(names)
+    for i, (nm, ln, mm) in enumerate(want):
+        got = [(int(x), int(y)) for x, y in xy[int(off[i]):int(off[i + 1])]]
+        # the harness sketches read i with rid=i; queries are sketched with rid 0 (lqmap.c:131)
+        exp = [(x, y & 0xffffffff) for x, y in mm]
+        assert got == exp, (nm, ln)
+    eng.close()
+
+
+def test_emulated_sketch_halo_adversarial(emu_lib):
+    """palindromic / N-rich / homopolymer contexts around every chunk boundary: the warm-up must widen its halo"""
+    rng = np.random.default_rng(5)
+    A = np.frombuffer(b"ACGT", dtype=np.uint8)
+    seqs = []
+    seqs.append(np.frombuffer(b"AT" * 700, dtype=np.uint8))                                  # all 12-mers palindromic
+    seqs.append(np.concatenate([A[rng.integers(0, 4, 100)], np.frombuffer(b"AT" * 400, np.uint8), A[rng.integers(0, 4, 600)]]))
+    s = A[rng.integers(0, 4, 2000)].copy(); s[::37] = ord("N"); seqs.append(s)                # N every 37 bases
+    s = A[rng.integers(0, 4, 1500)].copy(); s[120:135] = ord("N"); s[250:390] = ord("N"); seqs.append(s)
+    seqs.append(np.repeat(A[rng.integers(0, 4, 120)], rng.integers(1, 40, 120)))              # long homopolymers
+    seqs.append(np.frombuffer(b"A" * 1000, dtype=np.uint8))
+    seqs.append(np.frombuffer(b"ACG" * 500, dtype=np.uint8))
+    seqs.append(np.concatenate([np.frombuffer(b"G" * 300, np.uint8), A[rng.integers(0, 4, 300)], np.frombuffer(b"TA" * 200, np.uint8)]))
+    names = ["s%d" % i for i in range(len(seqs))]
+    import tempfile
+    from longqc_amd import synth
+    with tempfile.TemporaryDirectory() as d:
+        fn = os.path.join(d, "x.fa")
+        synth.write_fastq(fn, synth.ReadSet(names, seqs, [None] * len(seqs)), fasta=True)
+        for k, w, hpc in [(12, 5, 0), (15, 10, 1), (4, 3, 0), (28, 50, 0), (10, 1, 0), (15, 5, 1)]:
+            want = parse_sketch_dump(oracle_bind.dump("sketch", ["-k", str(k), "-w", str(w)] + (["-H"] if hpc else []), [fn]))
+            eng = _engine(emu_lib, k=k, w=w, hpc=hpc, min_score_med=40, min_score_good=40)
+            eng.set_queries(names, seqs, None)
+            xy, off = eng.query_minimizers()
+            for i, (nm, ln, mm) in enumerate(want):
+                got = [(int(x), int(y)) for x, y in xy[int(off[i]):int(off[i + 1])]]
+                assert got == [(x, y & 0xffffffff) for x, y in mm], (k, w, hpc, nm)
+            eng.close()
+
+
+def _canon_chains(arr, q):
+    return sorted(tuple(int(v) for v in r[1:]) for r in arr if r[0] == q)
+
+
+@pytest.mark.parametrize("name,tfn,qfn", [("tiny_chains", "tiny_all.fq.gz", "tiny_sub.fq.gz"), ("adv_chains", "adv_all.fa.gz", "adv_sub.fq.gz")])
+def test_emulated_chains_mid_occ_and_accumulators(emu_lib, name, tfn, qfn):
+    mid, want = parse_chain_dump(read_gz(name + ".dump.gz"))
+    tn, ts, _ = read_fastx(os.path.join(GOLDEN, tfn))
+    qn, qs, qq = read_fastx(os.path.join(GOLDEN, qfn))
+    eng = _engine(emu_lib)
+    eng.set_debug(1)
+    eng.set_queries(qn, qs, qq)
+    pt = eng.part_begin()
+    half = len(tn) // 2
+    eng.part_add_targets(pt, tn[:half], ts[:half])             # two uploads, one part (mini-batches of mm_idx_gen)
+    eng.part_add_targets(pt, tn[half:], ts[half:])
+    eng.part_build(pt)
+    assert eng.mid_occ == mid
+    eng.part_map(pt)
+    ch = eng.chains()
+    eng.finish()
+    rows = eng.rows()
+    for qi, w in want.items():
+        # (rid, rev, score, cnt, qs, qe, rs, re)
+        assert _canon_chains(ch, qi) == sorted(w["chains"]), (qi, w["name"])
+        assert rows[qi]["lambda_"] == w["lambda_"] and rows[qi]["lambda2"] == w["lambda2"], w["name"]
+    eng.close()
+
+
+def test_emulated_query_batching_is_invisible(emu_lib, datasets, monkeypatch):
+    tf, qf = datasets("small")
+    argv = ["-Y", "-l", "0", "-q", "160", "-k", "12", "-w", "5", "-I", "700K", "-p", "160", tf, qf]
+    want = oracle_bind.table(argv)
+    monkeypatch.setenv("LQCOV_ANCHOR_BUDGET", "3000")
+    rc, out, err = run_main(emu_lib, argv)
+    assert rc == 0, err
+    assert out == want
+
+
+def test_emulated_reset_and_rerun(emu_lib):
+    tn, ts, _ = read_fastx(os.path.join(GOLDEN, "tiny_all.fq.gz"))
+    qn, qs, qq = read_fastx(os.path.join(GOLDEN, "tiny_sub.fq.gz"))
+    eng = _engine(emu_lib)
+    eng.set_queries(qn, qs, qq)
+    pt = eng.part_begin()
+    eng.part_add_targets(pt, tn, ts)
+    tables = []
+    for _ in range(2):
+        eng.reset()
+        eng.part_build(pt); eng.part_map(pt); eng.finish()
+        tables.append(eng.table_text())
+    assert tables[0] == tables[1] == read_gz("tiny_ont.table.gz")
+    eng.close()

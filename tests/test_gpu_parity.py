@@ -1,0 +1,153 @@
+"""-m gpu: the real thing.  Everything here goes through liblqcov.so (hipcc, gfx950) on cuda:0 via the
+C ABI and is compared bit for bit with (a) the reference's golden vectors, (b) the oracle on seeded
+inputs, (c) size-independent properties at larger sizes."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import tests.test_emu_pipeline as E
+import tests.test_host as H
+from longqc_amd import api, synth
+from tests import oracle_bind
+from tests.conftest import GOLDEN, read_gz
+from tests.helpers import ONT, run_main
+
+pytestmark = pytest.mark.gpu
+
+
+def _cases(kind):
+    return [c for c in json.load(open(os.path.join(GOLDEN, "cases.json"))) if c["kind"] == kind]
+
+
+@pytest.mark.parametrize("case", _cases("table"), ids=lambda c: c["name"])
+def test_gpu_tables_equal_reference_fixtures(gpu_lib, case):
+    E.test_emulated_pipeline_reproduces_reference_tables(gpu_lib, case)
+
+
+@pytest.mark.parametrize("name,k,w,hpc,fn", [
+    ("tiny_sketch_k12w5", 12, 5, 0, "tiny_sub.fq.gz"),
+    ("adv_sketch_k12w5", 12, 5, 0, "adv_sub.fq.gz"),
+    ("adv_sketch_k15w10hpc", 15, 10, 1, "adv_sub.fq.gz"),
+    ("adv_sketch_k19w10", 19, 10, 0, "adv_sub.fq.gz"),
+    ("adv_sketch_k6w30", 6, 30, 0, "adv_sub.fq.gz"),
+])
+def test_gpu_sketch_equals_mm_sketch_fixture(gpu_lib, name, k, w, hpc, fn):
+    E.test_emulated_sketch_equals_mm_sketch_fixture(gpu_lib, name, k, w, hpc, fn)
+
+
+def test_gpu_sketch_halo_adversarial(gpu_lib):
+    E.test_emulated_sketch_halo_adversarial(gpu_lib)
+
+
+@pytest.mark.parametrize("name,tfn,qfn", [("tiny_chains", "tiny_all.fq.gz", "tiny_sub.fq.gz"), ("adv_chains", "adv_all.fa.gz", "adv_sub.fq.gz")])
+def test_gpu_chains_mid_occ_and_accumulators(gpu_lib, name, tfn, qfn):
+    E.test_emulated_chains_mid_occ_and_accumulators(gpu_lib, name, tfn, qfn)
+
+
+def test_gpu_reset_and_rerun(gpu_lib):
+    E.test_emulated_reset_and_rerun(gpu_lib)
+
+
+def test_gpu_input_dialects(gpu_lib, tmp_path):
+    H.test_input_dialects_agree_with_reference_semantics(gpu_lib, tmp_path)
+
+
+def test_gpu_empty_inputs(gpu_lib, tmp_path):
+    H.test_empty_query_file_and_empty_target_file(gpu_lib, tmp_path)
+
+
+VARIANTS = {
+    "ont": ONT,
+    "pb": ["-Y", "-l", "0", "-q", "160", "-k", "12", "-w", "5", "-I", "4G", "-p", "80", "-t", "4"],
+    "fast_k15": ["-Y", "-l", "0", "-q", "160", "-k", "15", "-w", "5", "-I", "4G", "-p", "160", "-t", "4"],
+    "hifi_k19w10": ["-Y", "-l", "0", "-q", "160", "-k", "19", "-w", "10", "-I", "4G", "-p", "160", "-t", "4"],
+    "parts": ["-Y", "-l", "0", "-q", "160", "-k", "12", "-w", "5", "-I", "1M", "-p", "160", "-t", "4"],
+    "spike_hpc": ["-Y", "-Hk15", "-w", "10", "-c", "1", "-l", "0", "--filter", "-t", "4"],
+}
+
+
+@pytest.mark.parametrize("variant", sorted(VARIANTS))
+@pytest.mark.parametrize("name", ["small", "cfg1"])
+def test_gpu_table_equals_oracle_on_synthetic_sets(gpu_lib, datasets, name, variant):
+    """BASELINE.json configs[0] (cfg1: 1k ONT reads ~10 kb 5x, all reads as queries) and a smaller set"""
+    tf, qf = datasets(name)
+    argv = VARIANTS[variant] + [tf, qf]
+    rc, out, err = run_main(gpu_lib, argv)
+    assert rc == 0, err
+    assert out == oracle_bind.table(argv)
+
+
+def test_gpu_query_batching_is_invisible(gpu_lib, datasets, monkeypatch):
+    E.test_emulated_query_batching_is_invisible(gpu_lib, datasets, monkeypatch)
+
+
+def test_gpu_midsize_slice_of_cfg2_vs_reference_or_oracle(gpu_lib, tmp_path):
+    """a 6 % slice of BASELINE.json configs[1] (3000 of the 50k ONT reads ~15 kb, 600 queries): big enough that
+    per-query anchor arrays reach 10^4..10^5 and the klib walk recurses several levels"""
+    import dataclasses
+    cfg = dataclasses.replace(synth.CONFIGS["cfg2"], n_reads=3000, nsample=600, depth=15.0)
+    T, Q = synth.make_dataset(cfg)
+    tf, qf = str(tmp_path / "all.fq"), str(tmp_path / "sub.fq")
+    synth.write_fastq(tf, T); synth.write_fastq(qf, Q)
+    argv = ONT + [tf, qf]
+    rc, out, err = run_main(gpu_lib, argv)
+    assert rc == 0, err
+    want = oracle_bind.ref_table(argv) if oracle_bind.have_ref() else oracle_bind.table(argv)
+    assert out == want
+
+
+def test_gpu_properties_at_scale(gpu_lib, tmp_path):
+    """Size-independent properties on a larger run (20k reads ~15 kb = 40 % of configs[1]; LQCOV_FULL_SCALE=1 runs
+    the full 50k): determinism, query independence (a query's row does not depend on which other queries ride
+    along or on the anchor batching), row sanity, and spot rows against the reference binary."""
+    import dataclasses
+    n = 50000 if os.environ.get("LQCOV_FULL_SCALE") else 20000
+    cfg = dataclasses.replace(synth.CONFIGS["cfg2"], n_reads=n, nsample=2000)
+    genome = synth.make_genome(cfg)
+    T = synth.make_reads(cfg, genome)
+    qi = synth.reservoir_subsample(len(T), cfg.nsample)
+    Q = T.subset(qi)
+    p = api.default_params(no_self=1, min_ovlp=0, min_score_med=160, min_score_good=160)
+    eng = api.Engine(p, 0, lib=gpu_lib)
+    eng.set_queries(Q.names, Q.seqs, Q.quals)
+    pt = eng.part_begin()
+    step = 2500
+    for i in range(0, len(T), step):
+        eng.part_add_targets(pt, T.names[i:i + step], T.seqs[i:i + step])
+    eng.part_build(pt); eng.part_map(pt); eng.finish()
+    t1 = eng.table_text()
+    eng.reset(); eng.part_build(pt); eng.part_map(pt); eng.finish()
+    assert eng.table_text() == t1                                     # deterministic
+    rows = t1.splitlines()
+    assert len(rows) == len(Q)
+    for r, nm, s in zip(rows, Q.names, Q.seqs):
+        f = r.split("\t")
+        assert f[0] == nm and int(f[1]) == s.shape[0]
+        if f[3] != "0":
+            for seg in f[3].split(","):
+                a, b = seg.split("-"); assert 0 <= int(a) < int(b) <= s.shape[0]
+    assert sum(1 for r in rows if r.split("\t")[2] != "0") > 0.9 * len(rows)
+    # query independence: 40 of the queries alone, tiny anchor budget, same rows
+    sel = list(range(0, len(Q), len(Q) // 40))[:40]
+    os.environ["LQCOV_ANCHOR_BUDGET"] = "200000"
+    try:
+        eng2 = api.Engine(p, 0, lib=gpu_lib)
+    finally:
+        del os.environ["LQCOV_ANCHOR_BUDGET"]
+    sub = Q.subset(sel)
+    eng2.set_queries(sub.names, sub.seqs, sub.quals)
+    pt2 = eng2.part_begin()
+    for i in range(0, len(T), step):
+        eng2.part_add_targets(pt2, T.names[i:i + step], T.seqs[i:i + step])
+    eng2.part_build(pt2); eng2.part_map(pt2); eng2.finish()
+    t2 = eng2.table_text().splitlines()
+    assert t2 == [rows[i] for i in sel]
+    eng2.close(); eng.close()
+    # spot rows against the reference binary itself (it is deterministic across -t)
+    if oracle_bind.have_ref():
+        tf, qf = str(tmp_path / "all.fq"), str(tmp_path / "sub.fq")
+        synth.write_fastq(tf, T); synth.write_fastq(qf, sub)
+        want = oracle_bind.ref_table(["-Y", "-l", "0", "-q", "160", "-k", "12", "-w", "5", "-I", "4G", "-p", "160", "-t", str(os.cpu_count() or 4), tf, qf]).splitlines()
+        assert t2 == want
