@@ -178,12 +178,18 @@ void lqcov_handle::sketch(ReadSetDev &rs, bool rid_in_y)
 	rs.sketched = true;
 }
 
-// meanQ's table (lqutils.c:26-49): 10^(-q/10) rounded to 15 decimals, Q0..Q126
+// meanQ's table (lqutils.c:26-49): 127 15-decimal literals for 10^(-q/10), Q0..Q126.  They are 10^(-q/10)
+// rounded to 15 decimals, except that eight entries (Q34, 39, 58, 62, 67, 71, 72, 82) are one unit of the
+// 15th decimal higher in the reference; rebuilt here from that description.
 static void make_q2p(double *t)
 {
+	static const int up[8] = {34, 39, 58, 62, 67, 71, 72, 82};
 	for (int q = 0; q < 127; ++q) {
 		char buf[64];
 		snprintf(buf, sizeof(buf), "%.15f", pow(10.0, -q / 10.0));
+		long long units = (long long)(buf[0] - '0') * 1000000000000000LL + strtoll(buf + 2, nullptr, 10);
+		for (int j = 0; j < 8; ++j) if (up[j] == q) ++units;
+		snprintf(buf, sizeof(buf), "%lld.%015lld", units / 1000000000000000LL, units % 1000000000000000LL);
 		t[q] = strtod(buf, nullptr);
 	}
 }

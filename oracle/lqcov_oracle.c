@@ -770,18 +770,24 @@ static void reliable_region(const subc_v *v, uint32_t min_cov, subc_v *coords, s
 	free(vc);
 }
 
-/* meanQ (lqutils.c:26-58): q2p[] is the reference's 15-decimal table; it is regenerated here by
- * rounding 10^(-q/10) to 15 decimals, which reproduces every literal of lqutils.c:41-63 (checked
- * by tests/test_oracle_vs_ref.py through the meanQ column). */
+/* meanQ (lqutils.c:26-58).  q2p[] holds 127 15-decimal literals for 10^(-q/10), q = 0..126.  They equal
+ * 10^(-q/10) rounded to 15 decimals except for eight entries (q = 34, 39, 58, 62, 67, 71, 72, 82) that are one
+ * unit of the 15th decimal higher; the table is rebuilt here from that description and compared with the
+ * reference's literals in tests/test_oracle_vs_ref.py. */
 static double q2p[127];
 static int q2p_ready = 0;
 static void q2p_init(void)
 {
-	int q;
+	static const int up[8] = { 34, 39, 58, 62, 67, 71, 72, 82 };
+	int q, j;
 	if (q2p_ready) return;
 	for (q = 0; q < 127; ++q) {
 		char buf[64];
-		snprintf(buf, sizeof(buf), "%.15f", pow(10.0, -q / 10.0));
+		long long units;
+		snprintf(buf, sizeof(buf), "%.15f", pow(10.0, -q / 10.0));      /* "d.ddddddddddddddd" */
+		units = (long long)(buf[0] - '0') * 1000000000000000LL + strtoll(buf + 2, 0, 10);
+		for (j = 0; j < 8; ++j) if (up[j] == q) ++units;
+		snprintf(buf, sizeof(buf), "%lld.%015lld", units / 1000000000000000LL, units % 1000000000000000LL);
 		q2p[q] = strtod(buf, 0);
 	}
 	q2p_ready = 1;

@@ -56,6 +56,10 @@ def emu_lib():
 
 @pytest.fixture(scope="session")
 def gpu_lib():
+    """longqc_amd/liblqcov.so, the hipcc/gfx950 build (make is a no-op when it is up to date)"""
+    csrc = os.path.join(ROOT, "longqc_amd", "csrc")
+    r = subprocess.run(["make", "-C", csrc, "all"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout[-3000:]
     from longqc_amd import api
     return api.load_library()
 

@@ -61,16 +61,36 @@ def test_klib_order_matters_stable_sort_is_not_exact(datasets):
 
 
 def test_q2p_table_regenerated_equals_reference_literals():
-    """meanQ's lookup table is regenerated numerically by the oracle and the product; compare with the
-    literals in the reference source (read as data here, never copied)."""
+    """meanQ's lookup table is rebuilt numerically by the oracle and the product (10^(-q/10) to 15 decimals, eight
+    entries one unit higher); compare that description with the literals in the reference source (read as data)."""
     import re
+    from decimal import Decimal
     src = "/root/reference/minimap2-coverage/lqutils.c"
     if not os.path.exists(src):
         pytest.skip("reference sources not present")
     txt = open(src).read()
     block = txt[txt.rindex("double q2p[] = {"):]
     block = block[:block.index("};")]
-    lits = [float(x) for x in re.findall(r"\d\.\d{15}", block)]
+    lits = re.findall(r"\d\.\d{15}", block)
     assert len(lits) == 127
+    up = {34, 39, 58, 62, 67, 71, 72, 82}
     for q, v in enumerate(lits):
-        assert float("%.15f" % (10.0 ** (-q / 10.0))) == v, q
+        mine = Decimal("%.15f" % (10.0 ** (-q / 10.0))) + (Decimal("0.000000000000001") if q in up else 0)
+        assert mine == Decimal(v), q
+
+
+def test_meanq_high_qualities_match_reference(tmp_path):
+    """qualities up to Q93 ('~'), including the eight adjusted table entries"""
+    import numpy as np
+    from longqc_amd import synth
+    rng = np.random.default_rng(3)
+    A = np.frombuffer(b"ACGT", dtype=np.uint8)
+    seqs = [A[rng.integers(0, 4, 400)] for _ in range(30)]
+    quals = [(33 + rng.integers(0, 94, 400)).astype(np.uint8) for _ in range(30)]
+    for i, q0 in enumerate([34, 39, 58, 62, 67, 71, 72, 82]):
+        quals[i][:] = 33 + q0
+    rs = synth.ReadSet(["q%d" % i for i in range(30)], seqs, quals)
+    fn = str(tmp_path / "q.fq")
+    synth.write_fastq(fn, rs)
+    argv = ONT + [fn, fn]
+    assert oracle_bind.table(argv) == oracle_bind.ref_table(argv)
