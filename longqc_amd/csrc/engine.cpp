@@ -72,7 +72,7 @@ lqcov_handle::lqcov_handle(const lqcov_params &p, int dev) : P(p), device(dev)
 	if (anchor_budget == 0) {
 		size_t fr = 0, tot = 0;
 		hipMemGetInfo(&fr, &tot);
-		anchor_budget = (u64)(fr / 2 / 96);                // ~96 B of work space per anchor, use half of free HBM
+		anchor_budget = (u64)(fr / 2 / 128);               // ~128 B of work space per anchor, use half of free HBM
 	}
 	if (anchor_budget > (1ULL << 31)) anchor_budget = 1ULL << 31;
 	if (anchor_budget < 1024) anchor_budget = 1024;
@@ -370,7 +370,7 @@ void lqcov_handle::map_part(Part &pt)
 		dbg_chains.ensure(dbg_cap * sizeof(ChainRec)); n_dbg.ensure(8);
 		dzero(n_dbg.p, 8, stream);
 	}
-	n_segs.ensure(8); n_ivl.ensure(4);
+	n_segs.ensure(16); n_ivl.ensure(4);
 
 	u32 q0 = 0;
 	while (q0 < n_q) {
@@ -397,7 +397,7 @@ void lqcov_handle::map_part(Part &pt)
 			{
 				const u64 max_segs = nA / (LQ_RS_MIN + 1) + nqb + 1;
 				segs0.ensure(max_segs * sizeof(SortSeg)); segs1.ensure(max_segs * sizeof(SortSeg));
-				dzero(n_segs.p, 8, stream);
+				dzero(n_segs.p, 16, stream);
 				{
 					StageTimer t(this, "k_sort_init");
 					LQ_LAUNCH(k_sort_init, nblk(nqb, 64), 64, stream, aqb, a_base, nqb, dA, segs0.as<SortSeg>(), n_segs.as<u32>());
@@ -406,20 +406,48 @@ void lqcov_handle::map_part(Part &pt)
 				u32 ns = 0;
 				d2h(&ns, n_segs.as<u32>(), 1, stream);
 				SortSeg *cur = segs0.as<SortSeg>(), *nxt = segs1.as<SortSeg>();
+				sort_d.ensure(nA + 16); sort_dst.ensure((nA + 1) * 4);
 				for (int level = 0; level < 8 && ns > 0; ++level) {
 					hist.ensure((u64)ns * 1024); begs.ensure((u64)ns * 1024);
+					seg_info.ensure((u64)ns * sizeof(SegInfo)); walk_list.ensure((u64)ns * 4); two_list.ensure((u64)ns * 4);
 					dzero(hist.p, (u64)ns * 1024, stream);
-					dzero(n_segs.as<u32>() + 1, 4, stream);
+					dzero(n_segs.as<u32>() + 1, 12, stream);           // [1] next-level count, [2] n_walk, [3] n_two
 					{
-						StageTimer t(this, "k_sort_copy_hist", nA * 32);
-						LQ_LAUNCH(k_sort_copy_hist, ns, 256, stream, cur, ns, dA, dB, hist.as<u32>());
+						StageTimer t(this, "k_sort_copy_hist", nA * 33);
+						LQ_LAUNCH(k_sort_copy_hist, ns, 256, stream, cur, ns, dA, dB, sort_d.as<u8>(), hist.as<u32>());
 						check_launch();
 					}
-					{
-						StageTimer t(this, "k_sort_walk", nA * 32);
-						u32 blocks = nblk(ns, LQ_WALK_LANES);
-						if (blocks > 4096) blocks = 4096;
-						LQ_LAUNCH(k_sort_walk, blocks, LQ_WALK_LANES, stream, cur, ns, dA, dB, hist.as<u32>(), begs.as<u32>());
+					LQ_LAUNCH(k_sort_classify, nblk(ns, 64), 64, stream, cur, ns, hist.as<u32>(), begs.as<u32>(), seg_info.as<SegInfo>(),
+					          walk_list.as<u32>(), two_list.as<u32>(), n_segs.as<u32>() + 2);
+					check_launch();
+					u32 cw[2] = {0, 0};
+					d2h(cw, n_segs.as<u32>() + 2, 2, stream);
+					const u32 n_walk = cw[0], n_two = cw[1];
+					if (n_two) {                                        // closed-form two-bucket passes (the strand bit at the top level)
+						StageTimer t(this, "k_sort_two_bucket", nA * 60);
+						fx.ensure((nA + 1) * 4); fy.ensure((nA + 1) * 4); sx.ensure((nA + 1) * 4); sy.ensure((nA + 1) * 4);
+						hx.ensure((nA + 1) * 4); py.ensure((nA + 1) * 4);
+						dzero(fx.p, (nA + 1) * 4, stream); dzero(fy.p, (nA + 1) * 4, stream);
+						LQ_LAUNCH(k_two_flags, n_two, 256, stream, cur, seg_info.as<SegInfo>(), two_list.as<u32>(), n_two, sort_d.as<u8>(), fx.as<u32>(), fy.as<u32>());
+						check_launch();
+						prim.exclusive_scan_u32_u32(fx.as<u32>(), sx.as<u32>(), nA + 1);
+						prim.exclusive_scan_u32_u32(fy.as<u32>(), sy.as<u32>(), nA + 1);
+						LQ_LAUNCH(k_two_positions, n_two, 256, stream, cur, two_list.as<u32>(), n_two, fx.as<u32>(), fy.as<u32>(), sx.as<u32>(), sy.as<u32>(), hx.as<u32>(), py.as<u32>());
+						check_launch();
+						LQ_LAUNCH(k_two_dst, n_two, 256, stream, cur, seg_info.as<SegInfo>(), two_list.as<u32>(), n_two, sort_d.as<u8>(),
+						          sx.as<u32>(), sy.as<u32>(), hx.as<u32>(), py.as<u32>(), sort_dst.as<u32>());
+						check_launch();
+					}
+					if (n_walk) {
+						StageTimer t(this, "k_sort_walk", nA * 5);
+						u32 blocks = nblk(n_walk, LQ_WALK_LANES);
+						if (blocks > 8192) blocks = 8192;
+						LQ_LAUNCH(k_sort_walk, blocks, LQ_WALK_LANES, stream, cur, walk_list.as<u32>(), n_walk, sort_d.as<u8>(), hist.as<u32>(), begs.as<u32>(), sort_dst.as<u32>());
+						check_launch();
+					}
+					if (n_walk || n_two) {
+						StageTimer t(this, "k_sort_scatter", nA * 36);
+						LQ_LAUNCH(k_sort_scatter, ns, 256, stream, cur, seg_info.as<SegInfo>(), ns, dA, dB, sort_dst.as<u32>());
 						check_launch();
 					}
 					{

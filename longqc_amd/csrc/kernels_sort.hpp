@@ -10,14 +10,18 @@
 // klib's pass over a sub-array is a token walk: the token sits on a bucket, takes that bucket's
 // next unread element (original slot order) and jumps to the bucket the element belongs to; an
 // element is written to the next free slot of its own bucket when it is taken; the outer bucket
-// only advances when full.  The walk is inherently sequential, but sub-arrays are independent,
-// so the GPU runs it level-synchronously: per level (byte 7 .. byte 0) and per live sub-array,
-//   k_sort_copy_hist : cooperative copy A->B (the pristine source) + 256-bin histogram,
-//   k_sort_walk      : one lane per sub-array walks B and scatters into A; the 256 bucket
-//                      cursors of each lane live in LDS ([256][64] u32 = 64 KiB per wave,
-//                      lane-minor so that the 32-lane halves never bank-conflict),
+// only advances when full.  Only the *digits* (one byte per element) drive the walk, so each level
+// (byte 7 .. byte 0) runs, for all live sub-arrays at once:
+//   k_sort_copy_hist : cooperative copy A->B (the pristine source), digit byte array D, histogram;
+//   k_sort_classify  : per sub-array: bucket offsets; identity (one bucket), two-bucket, or general;
+//   two-bucket passes (the top level: strand bit) have a closed form -- every element's destination
+//                      follows from two prefix counts -- and run fully parallel (k_two_*);
+//   k_sort_walk      : general passes: one lane per sub-array walks the digit bytes (1 B/element
+//                      instead of 16) with its 256 bucket cursors in LDS ([256][64] u32, lane-minor:
+//                      the 32-lane halves never bank-conflict) and records dst[src];
+//   k_sort_scatter   : A[dst[i]] = B[i], cooperative;
 //   k_sort_children  : buckets > 64 elements become next-level sub-arrays, smaller ones are
-//                      finished with the (stable) insertion sort klib uses (ksort.h:87-97).
+//                      finished with the (stable, hence unique) insertion sort klib uses (ksort.h:87-97).
 #pragma once
 #include "lq_common.hpp"
 
@@ -26,6 +30,12 @@
 #else
 #define LQ_SHARED __shared__
 #endif
+
+#define LQ_SEG_GENERAL  0
+#define LQ_SEG_IDENTITY 1
+#define LQ_SEG_TWO      2
+
+struct SegInfo { u32 kind, c0, c1, cnt0; };
 
 __device__ __forceinline__ void lq_insertion_sort_x(mm128 *a, u32 n)
 {
@@ -52,62 +62,149 @@ __global__ void k_sort_init(const u64 *aq_off, u64 a_base, u32 n_q, mm128 *A, So
 	} else if (len > 1) lq_insertion_sort_x(A + off, (u32)len);
 }
 
-// one block per sub-array: B <- A, hist[seg][digit]++
-__global__ void k_sort_copy_hist(const SortSeg *segs, u32 n_segs, const mm128 *A, mm128 *B, u32 *hist)
+// one block per sub-array: B <- A, D <- digit, hist[seg][digit]++
+__global__ void k_sort_copy_hist(const SortSeg *segs, u32 n_segs, const mm128 *A, mm128 *B, u8 *D, u32 *hist)
 {
 	u32 sgi = blockIdx.x;
 	if (sgi >= n_segs) return;
 	SortSeg sg = segs[sgi];
 	const mm128 *a = A + sg.off;
 	mm128 *b = B + sg.off;
+	u8 *d = D + sg.off;
 	u32 *h = hist + (u64)sgi * 256;
 	for (u32 i = threadIdx.x; i < sg.len; i += blockDim.x) {
 		mm128 e = a[i];
-		b[i] = e;
-		atomicAdd(&h[(e.x >> sg.shift) & 0xff], 1u);
+		u32 dg = (u32)(e.x >> sg.shift) & 0xff;
+		b[i] = e; d[i] = (u8)dg;
+		atomicAdd(&h[dg], 1u);
 	}
 }
 
+// one thread per sub-array: bucket offsets and the kind of pass; lists of general / two-bucket sub-arrays
+__global__ void k_sort_classify(const SortSeg *segs, u32 n_segs, const u32 *hist, u32 *begs, SegInfo *info,
+                                u32 *walk_list, u32 *two_list, u32 *counters /* [2]: n_walk, n_two */)
+{
+	u32 sgi = blockIdx.x * blockDim.x + threadIdx.x;
+	if (sgi >= n_segs) return;
+	const u32 *cnt = hist + (u64)sgi * 256;
+	u32 *bg = begs + (u64)sgi * 256;
+	u32 acc = 0, nz = 0, c0 = 0, c1 = 0;
+	for (u32 c = 0; c < 256; ++c) {
+		u32 n = cnt[c];
+		bg[c] = acc; acc += n;
+		if (n) { if (nz == 0) c0 = c; else if (nz == 1) c1 = c; ++nz; }
+	}
+	SegInfo si; si.c0 = c0; si.c1 = c1; si.cnt0 = cnt[c0];
+	if (nz <= 1) si.kind = LQ_SEG_IDENTITY;                  // one bucket holds everything: the pass is the identity
+	else if (nz == 2) { si.kind = LQ_SEG_TWO; two_list[atomicAdd(&counters[1], 1u)] = sgi; }
+	else { si.kind = LQ_SEG_GENERAL; walk_list[atomicAdd(&counters[0], 1u)] = sgi; }
+	info[sgi] = si;
+}
+
+// ---- two-bucket pass, closed form ------------------------------------------------------------
+// Regions R0 = [0,cnt0) and R1 = [cnt0,len).  X_t = t-th element of R0 that belongs to bucket c1,
+// Y_t = t-th element of R1 that belongs to c0 (same count m).  klib's walk leaves bucket-c0 elements
+// of R0 in place and drops Y_t into the hole of X_t; in R1 it cuts the slots into runs that end at
+// Y_0, Y_1, ...: X_t lands on the first slot of run t and the run's own elements shift right by one;
+// everything after Y_{m-1} stays.
+__global__ void k_two_flags(const SortSeg *segs, const SegInfo *info, const u32 *two_list, u32 n_two, const u8 *D, u32 *fX, u32 *fY)
+{
+	u32 li = blockIdx.x;
+	if (li >= n_two) return;
+	const u32 sgi = two_list[li];
+	const SortSeg sg = segs[sgi];
+	const SegInfo si = info[sgi];
+	for (u32 i = threadIdx.x; i < sg.len; i += blockDim.x) {
+		const bool in0 = i < si.cnt0, is1 = D[sg.off + i] == si.c1;
+		if (in0 && is1) fX[sg.off + i] = 1u;
+		else if (!in0 && !is1) fY[sg.off + i] = 1u;
+	}
+}
+
+__global__ void k_two_positions(const SortSeg *segs, const u32 *two_list, u32 n_two, const u32 *fX, const u32 *fY,
+                                const u32 *sX, const u32 *sY, u32 *HX, u32 *PY)
+{
+	u32 li = blockIdx.x;
+	if (li >= n_two) return;
+	const SortSeg sg = segs[two_list[li]];
+	for (u32 i = threadIdx.x; i < sg.len; i += blockDim.x) {
+		const u64 g = sg.off + i;
+		if (fX[g]) HX[sX[g]] = (u32)g;
+		if (fY[g]) PY[sY[g]] = (u32)g;
+	}
+}
+
+__global__ void k_two_dst(const SortSeg *segs, const SegInfo *info, const u32 *two_list, u32 n_two, const u8 *D,
+                          const u32 *sX, const u32 *sY, const u32 *HX, const u32 *PY, u32 *dst)
+{
+	u32 li = blockIdx.x;
+	if (li >= n_two) return;
+	const u32 sgi = two_list[li];
+	const SortSeg sg = segs[sgi];
+	const SegInfo si = info[sgi];
+	const u32 off = (u32)sg.off, cnt0 = si.cnt0;
+	const u32 bx = sX[sg.off], by = sY[sg.off];
+	const u32 m = sX[sg.off + sg.len] - bx;
+	for (u32 i = threadIdx.x; i < sg.len; i += blockDim.x) {
+		const u64 g = sg.off + i;
+		const bool in0 = i < cnt0, is1 = D[g] == si.c1;
+		u32 d;
+		if (in0) {
+			if (!is1) d = i;
+			else { const u32 t = sX[g] - bx; d = t == 0 ? cnt0 : PY[by + t - 1] - off + 1; }
+		} else {
+			const u32 t = sY[g] - by;
+			if (!is1) d = HX[bx + t] - off;
+			else d = t < m ? i + 1 : i;
+		}
+		dst[g] = d;
+	}
+}
+
+// ---- general pass: the token walk over digit bytes ---------------------------------------------
 #define LQ_WALK_LANES 64
-// one lane per sub-array (grid-stride over the level's work list)
 __global__ void __launch_bounds__(LQ_WALK_LANES)
-k_sort_walk(const SortSeg *segs, u32 n_segs, mm128 *A, const mm128 *B, const u32 *hist, u32 *begs)
+k_sort_walk(const SortSeg *segs, const u32 *walk_list, u32 n_walk, const u8 *D, const u32 *hist, const u32 *begs, u32 *dst)
 {
 	LQ_SHARED u32 nxt[256][LQ_WALK_LANES];
 	const u32 lane = threadIdx.x;
-	for (u64 sgi = (u64)blockIdx.x * LQ_WALK_LANES + lane; sgi < n_segs; sgi += (u64)gridDim.x * LQ_WALK_LANES) {
-		SortSeg sg = segs[sgi];
-		const u32 *cnt = hist + sgi * 256;
-		u32 *bg = begs + sgi * 256;
-		u32 acc = 0;
-		bool single = false;
-		for (int c = 0; c < 256; ++c) {
-			u32 n = cnt[c];
-			nxt[c][lane] = acc; bg[c] = acc;
-			if (n == sg.len) single = true;
-			acc += n;
-		}
-		if (single) continue;                               // one bucket holds everything: the pass is the identity
-		mm128 *a = A + sg.off;
-		const mm128 *b = B + sg.off;
-		const u32 sh = sg.shift;
-		u32 endk = 0;
+	for (u64 wi = (u64)blockIdx.x * LQ_WALK_LANES + lane; wi < n_walk; wi += (u64)gridDim.x * LQ_WALK_LANES) {
+		const u32 sgi = walk_list[wi];
+		const SortSeg sg = segs[sgi];
+		const u32 *cnt = hist + (u64)sgi * 256, *bg = begs + (u64)sgi * 256;
+		for (int c = 0; c < 256; ++c) nxt[c][lane] = bg[c];
+		const u8 *d = D + sg.off;
+		u32 *ds = dst + sg.off;
 		for (u32 k = 0; k < 256; ++k) {
-			endk += cnt[k];                                 // = beg[k] + cnt[k]
+			const u32 n = cnt[k];
+			if (n == 0) continue;
+			const u32 endk = bg[k] + n;
 			while (nxt[k][lane] < endk) {
-				mm128 e = b[nxt[k][lane]];
-				u32 l = (u32)(e.x >> sh) & 0xff;
+				u32 src = nxt[k][lane];                       // the hole this cycle leaves in bucket k
+				u32 l = d[src];
 				while (l != k) {
-					u32 s = nxt[l][lane]++;
-					mm128 t = b[s];
-					a[s] = e;
-					e = t;
-					l = (u32)(e.x >> sh) & 0xff;
+					const u32 t = nxt[l][lane]++;             // slot the carried element takes; its occupant is carried on
+					ds[src] = t;
+					src = t;
+					l = d[t];
 				}
-				a[nxt[k][lane]++] = e;
+				ds[src] = nxt[k][lane]++;
 			}
 		}
 	}
+}
+
+// one block per sub-array: A[dst[i]] = B[i]  (identity passes are skipped)
+__global__ void k_sort_scatter(const SortSeg *segs, const SegInfo *info, u32 n_segs, mm128 *A, const mm128 *B, const u32 *dst)
+{
+	u32 sgi = blockIdx.x;
+	if (sgi >= n_segs) return;
+	if (info[sgi].kind == LQ_SEG_IDENTITY) return;
+	const SortSeg sg = segs[sgi];
+	mm128 *a = A + sg.off;
+	const mm128 *b = B + sg.off;
+	const u32 *ds = dst + sg.off;
+	for (u32 i = threadIdx.x; i < sg.len; i += blockDim.x) a[ds[i]] = b[i];
 }
 
 // one thread per (sub-array, bucket): recurse or finish (ksort.h:121-128)

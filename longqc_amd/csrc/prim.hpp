@@ -57,6 +57,20 @@ struct Prim {
 #endif
 	}
 
+	void exclusive_scan_u32_u32(const u32 *in, u32 *out, size_t n)
+	{
+		if (n == 0) return;
+#ifndef LQ_EMU
+		size_t bytes = 0;
+		LQ_HIP_CHECK(rocprim::exclusive_scan(nullptr, bytes, in, out, (u32)0, n, rocprim::plus<u32>(), stream));
+		tmp.ensure(bytes);
+		LQ_HIP_CHECK(rocprim::exclusive_scan(tmp.p, bytes, in, out, (u32)0, n, rocprim::plus<u32>(), stream));
+#else
+		u32 acc = 0;
+		for (size_t i = 0; i < n; ++i) { u32 v = in[i]; out[i] = acc; acc += v; }
+#endif
+	}
+
 	// stable sort of (key,value) pairs on key bits [0, end_bit)
 	void sort_pairs_u64(const u64 *kin, u64 *kout, const u64 *vin, u64 *vout, size_t n, unsigned end_bit)
 	{
