@@ -370,7 +370,7 @@ void lqcov_handle::map_part(Part &pt)
 		dbg_chains.ensure(dbg_cap * sizeof(ChainRec)); n_dbg.ensure(8);
 		dzero(n_dbg.p, 8, stream);
 	}
-	n_segs.ensure(16); n_ivl.ensure(4);
+	n_segs.ensure(64); n_ivl.ensure(4);
 
 	u32 q0 = 0;
 	while (q0 < n_q) {
@@ -397,7 +397,7 @@ void lqcov_handle::map_part(Part &pt)
 			{
 				const u64 max_segs = nA / (LQ_RS_MIN + 1) + nqb + 1;
 				segs0.ensure(max_segs * sizeof(SortSeg)); segs1.ensure(max_segs * sizeof(SortSeg));
-				dzero(n_segs.p, 16, stream);
+				dzero(n_segs.p, 64, stream);
 				{
 					StageTimer t(this, "k_sort_init");
 					LQ_LAUNCH(k_sort_init, nblk(nqb, 64), 64, stream, aqb, a_base, nqb, dA, segs0.as<SortSeg>(), n_segs.as<u32>());
@@ -406,23 +406,26 @@ void lqcov_handle::map_part(Part &pt)
 				u32 ns = 0;
 				d2h(&ns, n_segs.as<u32>(), 1, stream);
 				SortSeg *cur = segs0.as<SortSeg>(), *nxt = segs1.as<SortSeg>();
+				WalkCaps wcaps; wcaps.c[0] = 4096; wcaps.c[1] = 16384; wcaps.c[2] = 65536; wcaps.c[3] = 159744;
+				if (const char *ws = getenv("LQCOV_WALK_SHIFT")) for (int c = 0; c < 4; ++c) wcaps.c[c] >>= atoi(ws);   // test knob
 				sort_d.ensure(nA + 16); sort_dst.ensure((nA + 1) * 4);
 				for (int level = 0; level < 8 && ns > 0; ++level) {
 					hist.ensure((u64)ns * 1024); begs.ensure((u64)ns * 1024);
-					seg_info.ensure((u64)ns * sizeof(SegInfo)); walk_list.ensure((u64)ns * 4); two_list.ensure((u64)ns * 4);
-					dzero(hist.p, (u64)ns * 1024, stream);
-					dzero(n_segs.as<u32>() + 1, 12, stream);           // [1] next-level count, [2] n_walk, [3] n_two
+					seg_info.ensure((u64)ns * sizeof(SegInfo)); walk_list.ensure((u64)ns * 4 * LQ_WALK_CLASSES); two_list.ensure((u64)ns * 4);
+					dzero(n_segs.as<u32>() + 1, 4 * (2 + LQ_WALK_CLASSES), stream);   // [1] next-level count, [2] n_two, [3..] n_walk per size class
 					{
 						StageTimer t(this, "k_sort_copy_hist", nA * 33);
 						LQ_LAUNCH(k_sort_copy_hist, ns, 256, stream, cur, ns, dA, dB, sort_d.as<u8>(), hist.as<u32>());
 						check_launch();
 					}
 					LQ_LAUNCH(k_sort_classify, nblk(ns, 64), 64, stream, cur, ns, hist.as<u32>(), begs.as<u32>(), seg_info.as<SegInfo>(),
-					          walk_list.as<u32>(), two_list.as<u32>(), n_segs.as<u32>() + 2);
+					          walk_list.as<u32>(), two_list.as<u32>(), n_segs.as<u32>() + 2, wcaps);
 					check_launch();
-					u32 cw[2] = {0, 0};
-					d2h(cw, n_segs.as<u32>() + 2, 2, stream);
-					const u32 n_walk = cw[0], n_two = cw[1];
+					u32 cw[1 + LQ_WALK_CLASSES];
+					d2h(cw, n_segs.as<u32>() + 2, 1 + LQ_WALK_CLASSES, stream);
+					const u32 n_two = cw[0];
+					u32 n_walk = 0;
+					for (int c = 0; c < LQ_WALK_CLASSES; ++c) n_walk += cw[1 + c];
 					if (n_two) {                                        // closed-form two-bucket passes (the strand bit at the top level)
 						StageTimer t(this, "k_sort_two_bucket", nA * 60);
 						fx.ensure((nA + 1) * 4); fy.ensure((nA + 1) * 4); sx.ensure((nA + 1) * 4); sy.ensure((nA + 1) * 4);
@@ -440,10 +443,20 @@ void lqcov_handle::map_part(Part &pt)
 					}
 					if (n_walk) {
 						StageTimer t(this, "k_sort_walk", nA * 5);
-						u32 blocks = nblk(n_walk, LQ_WALK_LANES);
-						if (blocks > 8192) blocks = 8192;
-						LQ_LAUNCH(k_sort_walk, blocks, LQ_WALK_LANES, stream, cur, walk_list.as<u32>(), n_walk, sort_d.as<u8>(), hist.as<u32>(), begs.as<u32>(), sort_dst.as<u32>());
-						check_launch();
+						const u8 *dD = sort_d.as<u8>(); const u32 *dH = hist.as<u32>(), *dBg = begs.as<u32>(); u32 *dDst = sort_dst.as<u32>();
+						const u32 *wl = walk_list.as<u32>();
+						if (cw[1]) { LQ_LAUNCH((k_sort_walk_lds<4096>), cw[1], 64, stream, cur, wl + (u64)0 * ns, cw[1], dD, dH, dBg, dDst); check_launch(); }
+						if (cw[2]) { LQ_LAUNCH((k_sort_walk_lds<16384>), cw[2], 64, stream, cur, wl + (u64)1 * ns, cw[2], dD, dH, dBg, dDst); check_launch(); }
+						if (cw[3]) { LQ_LAUNCH((k_sort_walk_lds<65536>), cw[3], 256, stream, cur, wl + (u64)2 * ns, cw[3], dD, dH, dBg, dDst); check_launch(); }
+						if (cw[4]) { LQ_LAUNCH((k_sort_walk_lds<159744>), cw[4], 256, stream, cur, wl + (u64)3 * ns, cw[4], dD, dH, dBg, dDst); check_launch(); }
+						if (cw[5]) {                                    // digits do not fit LDS: lane-per-sub-array walk over global digits, longest first
+							const u32 nw = cw[5];
+							wkey.ensure((u64)nw * 4); wkey2.ensure((u64)nw * 4); walk_list2.ensure((u64)nw * 4);
+							LQ_LAUNCH(k_walk_keys, nblk(nw, 256), 256, stream, cur, wl + (u64)4 * ns, nw, wkey.as<u32>()); check_launch();
+							prim.sort_pairs_u32_u32(wkey.as<u32>(), wkey2.as<u32>(), wl + (u64)4 * ns, walk_list2.as<u32>(), nw);
+							LQ_LAUNCH(k_sort_walk, nblk(nw, LQ_WALK_LANES), LQ_WALK_LANES, stream, cur, walk_list2.as<u32>(), nw, dD, dH, dBg, dDst);
+							check_launch();
+						}
 					}
 					if (n_walk || n_two) {
 						StageTimer t(this, "k_sort_scatter", nA * 36);
@@ -482,9 +495,29 @@ void lqcov_handle::map_part(Part &pt)
 			cs.mini_pos = mini_pos.as<u64>(); cs.mpq_off = mpq_off.as<u64>(); cs.qlen = q.d_len.as<u32>(); cs.tlen = pt.rs.d_len.as<u32>();
 			cs.ivl = ivl.as<Ivl>(); cs.n_ivl = n_ivl.as<u32>(); cs.ivl_cap = ivl_cap;
 			cs.dbg = dbg ? dbg_chains.as<ChainRec>() : nullptr; cs.n_dbg = n_dbg.as<unsigned long long>(); cs.dbg_cap = dbg_cap;
-			{
+			// work list of the runs that can hold a chain.  Default: all runs, one thread each, in array order (most
+			// lanes retire at once; the few long runs of a wave then keep their working set in the CU's L1).
+			// LQCOV_CHAIN_DENSE=1: compacted, longest-first list (every lane busy, but 64 unrelated working sets per wave).
+			if (n_groups > 0xfffffff0ULL) throw std::domain_error("too many anchor runs in one batch");
+			static const bool chain_dense = getenv("LQCOV_CHAIN_DENSE") && atoi(getenv("LQCOV_CHAIN_DENSE")) != 0;
+			if (chain_dense) {
+				gflag.ensure(n_groups * 4 + 4); gidx.ensure(n_groups * 4 + 4);
+				LQ_LAUNCH(k_group_flags, nblk(n_groups, 256), 256, stream, gstart.as<u64>(), n_groups, (i32)P.min_cnt, gflag.as<u32>()); check_launch();
+				prim.exclusive_scan_u32_u32(gflag.as<u32>(), gidx.as<u32>(), n_groups);
+				u32 lgi = 0, lgf = 0;
+				d2h(&lgi, gidx.as<u32>() + n_groups - 1, 1, stream); d2h(&lgf, gflag.as<u32>() + n_groups - 1, 1, stream);
+				const u32 n_sel = lgi + lgf;
+				if (n_sel) {
+					gsel.ensure((u64)n_sel * 4); gkey.ensure((u64)n_sel * 4); gsel2.ensure((u64)n_sel * 4); gkey2.ensure((u64)n_sel * 4);
+					LQ_LAUNCH(k_group_compact, nblk(n_groups, 256), 256, stream, gstart.as<u64>(), gflag.as<u32>(), gidx.as<u32>(), n_groups, gsel.as<u32>(), gkey.as<u32>()); check_launch();
+					prim.sort_pairs_u32_u32(gkey.as<u32>(), gkey2.as<u32>(), gsel.as<u32>(), gsel2.as<u32>(), n_sel);
+					StageTimer t(this, "k_chain", nA * 16);
+					LQ_LAUNCH(k_chain, nblk(n_sel, 64), 64, stream, dA, gstart.as<u64>(), gsel2.as<u32>(), n_sel, aqb, a_base, nqb, q0, avg_qspan.as<float>(), mp, cb, cs);
+					check_launch();
+				}
+			} else {
 				StageTimer t(this, "k_chain", nA * 16);
-				LQ_LAUNCH(k_chain, nblk(n_groups, 64), 64, stream, dA, gstart.as<u64>(), n_groups, aqb, a_base, nqb, q0, avg_qspan.as<float>(), mp, cb, cs);
+				LQ_LAUNCH(k_chain, nblk(n_groups, 64), 64, stream, dA, gstart.as<u64>(), (const u32*)nullptr, (u32)n_groups, aqb, a_base, nqb, q0, avg_qspan.as<float>(), mp, cb, cs);
 				check_launch();
 			}
 			// ---- filter_redundant_coords per query (lqmap.c:287) ----

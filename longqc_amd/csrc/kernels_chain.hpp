@@ -123,13 +123,30 @@ struct CovState {              // per-query accumulators (minimap2-coverage.c:43
 	ChainRec *dbg; unsigned long long *n_dbg; u64 dbg_cap;   // optional chain dump
 };
 
-// aq_off: the batch's view of the per-query anchor offsets (n_q+1 entries, absolute; the batch's
-// anchors start at a_base); q0: global index of the batch's first query.
-__global__ void k_chain(const mm128 *A, const u64 *gstart, u64 n_groups, const u64 *aq_off, u64 a_base, u32 n_q, u32 q0,
-                        const float *avg_qspan_q, MapParams P, ChainBufs B, CovState C)
+// runs that can hold a chain (>= min_cnt anchors), as a dense work list; key = ~size so that an ascending
+// radix sort yields longest-first (lanes of one wave then own runs of similar length, long ones start first)
+__global__ void k_group_flags(const u64 *gstart, u64 n_groups, i32 min_cnt, u32 *flag)
 {
 	u64 g = (u64)blockIdx.x * blockDim.x + threadIdx.x;
 	if (g >= n_groups) return;
+	flag[g] = (i64)(gstart[g + 1] - gstart[g]) >= (i64)min_cnt ? 1u : 0u;
+}
+
+__global__ void k_group_compact(const u64 *gstart, const u32 *flag, const u32 *idx, u64 n_groups, u32 *sel, u32 *key)
+{
+	u64 g = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+	if (g >= n_groups) return;
+	if (flag[g]) { sel[idx[g]] = (u32)g; key[idx[g]] = 0xffffffffu - (u32)(gstart[g + 1] - gstart[g]); }
+}
+
+// aq_off: the batch's view of the per-query anchor offsets (n_q+1 entries, absolute; the batch's
+// anchors start at a_base); q0: global index of the batch's first query.
+__global__ void k_chain(const mm128 *A, const u64 *gstart, const u32 *glist, u32 n_list, const u64 *aq_off, u64 a_base, u32 n_q, u32 q0,
+                        const float *avg_qspan_q, MapParams P, ChainBufs B, CovState C)
+{
+	u32 gi = blockIdx.x * blockDim.x + threadIdx.x;
+	if (gi >= n_list) return;
+	const u32 g = glist ? glist[gi] : gi;
 	const u64 gs = gstart[g];
 	const i64 n = (i64)(gstart[g + 1] - gs);
 	if (n < P.min_cnt) return;
@@ -143,35 +160,49 @@ __global__ void k_chain(const mm128 *A, const u64 *gstart, u64 n_groups, const u
 	const i32 max_dist = P.max_gap, bw = P.bw, max_skip = P.max_skip, min_sc = P.min_sc;
 	i64 st = 0;
 	for (i64 i = 0; i < n; ++i) t[i] = 0;
-	// fill the score and backtrack arrays (chain.c:41-81)
-	for (i64 i = 0; i < n; ++i) {
-		const u64 ri = a[i].x;
-		i64 max_j = -1;
-		const i32 qi = (i32)a[i].y, q_span = (i32)(a[i].y >> 32 & 0xff);
-		i32 max_f = q_span, n_skip = 0;
-		while (st < i && ri - a[st].x > (u64)max_dist) ++st;
-		for (i64 j = i - 1; j >= st; --j) {
-			const i64 dr = (i64)(ri - a[j].x);
-			const i32 dq = qi - (i32)a[j].y;
-			if (dr == 0 || dq <= 0) continue;
-			if (dq > max_dist) continue;
-			const i32 dd = dr > dq ? (i32)(dr - dq) : (i32)(dq - dr);
-			if (dd > bw) continue;
-			const i32 min_d = dq < dr ? dq : (i32)dr;
-			i32 sc = min_d > q_span ? q_span : min_d;
-			const i32 log_dd = dd ? lq_ilog2_32((u32)dd) : 0;
-			sc -= (i32)((double)dd * .01 * (double)avg_qspan) + (log_dd >> 1);     // chain.c:67
-			sc += f[j];
-			if (sc > max_f) {
-				max_f = sc; max_j = j;
-				if (n_skip > 0) --n_skip;
-			} else if (t[j] == (i32)i) {
-				if (++n_skip > max_skip) break;
+	// fill the score and backtrack arrays (chain.c:41-81).  Flat form: one candidate predecessor per loop trip,
+	// so that the lanes of a wave (different runs) do not wait for each other's inner loops to finish.
+	{
+		i64 i = 0, j = -1, max_j = -1;
+		u64 ri = 0;
+		i32 qi = 0, q_span = 0, max_f = 0, n_skip = 0;
+		bool setup = true;
+		while (i < n) {
+			if (setup) {
+				ri = a[i].x; qi = (i32)a[i].y; q_span = (i32)(a[i].y >> 32 & 0xff);
+				max_f = q_span; max_j = -1; n_skip = 0;
+				while (st < i && ri - a[st].x > (u64)max_dist) ++st;
+				j = i - 1; setup = false;
 			}
-			if (p[j] >= 0) t[p[j]] = (i32)i;
+			if (j >= st) {
+				const i64 dr = (i64)(ri - a[j].x);
+				const i32 dq = qi - (i32)a[j].y;
+				if (!(dr == 0 || dq <= 0 || dq > max_dist)) {
+					const i32 dd = dr > dq ? (i32)(dr - dq) : (i32)(dq - dr);
+					if (dd <= bw) {
+						const i32 min_d = dq < dr ? dq : (i32)dr;
+						i32 sc = min_d > q_span ? q_span : min_d;
+						const i32 log_dd = dd ? lq_ilog2_32((u32)dd) : 0;
+						sc -= (i32)((double)dd * .01 * (double)avg_qspan) + (log_dd >> 1);     // chain.c:67
+						sc += f[j];
+						bool brk = false;
+						if (sc > max_f) {
+							max_f = sc; max_j = j;
+							if (n_skip > 0) --n_skip;
+						} else if (t[j] == (i32)i) {
+							if (++n_skip > max_skip) brk = true;                      // chain.c:72-73
+						}
+						if (brk) j = st;                                              // leave the candidate loop
+						else if (p[j] >= 0) t[p[j]] = (i32)i;
+					}
+				}
+				--j;
+			} else {
+				f[i] = max_f; p[i] = (i32)max_j;
+				v[i] = max_j >= 0 && v[max_j] > max_f ? v[max_j] : max_f;
+				++i; setup = true;
+			}
 		}
-		f[i] = max_f; p[i] = (i32)max_j;
-		v[i] = max_j >= 0 && v[max_j] > max_f ? v[max_j] : max_f;
 	}
 	// chain ends (chain.c:84-101)
 	for (i64 i = 0; i < n; ++i) t[i] = 0;

@@ -25,10 +25,17 @@
 #pragma once
 #include "lq_common.hpp"
 
+// Block-cooperative kernels are written in phases: LQ_BLOCK_LOOP(t) { ... } runs its body once per thread of
+// the block (t = thread index), LQ_BLOCK_SYNC() separates phases.  On the GPU that is the thread itself and
+// __syncthreads(); the serial test emulator lets thread 0 play every thread of the block, phase by phase.
 #ifdef LQ_EMU
 #define LQ_SHARED static
+#define LQ_BLOCK_LOOP(t) if (threadIdx.x == 0) for (u32 t = 0; t < blockDim.x; ++t)
+#define LQ_BLOCK_SYNC()
 #else
 #define LQ_SHARED __shared__
+#define LQ_BLOCK_LOOP(t) for (u32 t = threadIdx.x, lq_once_ = 1; lq_once_; lq_once_ = 0)
+#define LQ_BLOCK_SYNC() __syncthreads()
 #endif
 
 #define LQ_SEG_GENERAL  0
@@ -62,27 +69,43 @@ __global__ void k_sort_init(const u64 *aq_off, u64 a_base, u32 n_q, mm128 *A, So
 	} else if (len > 1) lq_insertion_sort_x(A + off, (u32)len);
 }
 
-// one block per sub-array: B <- A, D <- digit, hist[seg][digit]++
+// one block per sub-array: B <- A, D <- digit, hist[seg][*] = digit histogram (built in LDS, stored once)
 __global__ void k_sort_copy_hist(const SortSeg *segs, u32 n_segs, const mm128 *A, mm128 *B, u8 *D, u32 *hist)
 {
-	u32 sgi = blockIdx.x;
+	LQ_SHARED u32 lh[256];
+	const u32 sgi = blockIdx.x;
 	if (sgi >= n_segs) return;
-	SortSeg sg = segs[sgi];
+	const SortSeg sg = segs[sgi];
 	const mm128 *a = A + sg.off;
 	mm128 *b = B + sg.off;
 	u8 *d = D + sg.off;
 	u32 *h = hist + (u64)sgi * 256;
-	for (u32 i = threadIdx.x; i < sg.len; i += blockDim.x) {
-		mm128 e = a[i];
-		u32 dg = (u32)(e.x >> sg.shift) & 0xff;
-		b[i] = e; d[i] = (u8)dg;
-		atomicAdd(&h[dg], 1u);
+	LQ_BLOCK_LOOP(t) { for (u32 c = t; c < 256; c += blockDim.x) lh[c] = 0; }
+	LQ_BLOCK_SYNC();
+	LQ_BLOCK_LOOP(t) {
+		for (u32 i = t; i < sg.len; i += blockDim.x) {
+			const mm128 e = a[i];
+			const u32 dg = (u32)(e.x >> sg.shift) & 0xff;
+			b[i] = e; d[i] = (u8)dg;
+			atomicAdd(&lh[dg], 1u);
+		}
 	}
+	LQ_BLOCK_SYNC();
+	LQ_BLOCK_LOOP(t) { for (u32 c = t; c < 256; c += blockDim.x) h[c] = lh[c]; }
 }
 
 // one thread per sub-array: bucket offsets and the kind of pass; lists of general / two-bucket sub-arrays
+// size classes of general passes: digits of the sub-array fit a 4 / 16 / 64 / 156 KiB LDS window, or not at all
+#define LQ_WALK_CLASSES 5
+struct WalkCaps { u32 c[4]; };        // default {4096, 16384, 65536, 159744}; tests shrink them to reach every class
+__device__ __forceinline__ u32 lq_walk_class(u32 len, const WalkCaps &w)
+{
+	return len <= w.c[0] ? 0u : len <= w.c[1] ? 1u : len <= w.c[2] ? 2u : len <= w.c[3] ? 3u : 4u;
+}
+
+// walk_list holds LQ_WALK_CLASSES lists of n_segs entries each; counters = [n_two, n_walk[0..4]]
 __global__ void k_sort_classify(const SortSeg *segs, u32 n_segs, const u32 *hist, u32 *begs, SegInfo *info,
-                                u32 *walk_list, u32 *two_list, u32 *counters /* [2]: n_walk, n_two */)
+                                u32 *walk_list, u32 *two_list, u32 *counters, WalkCaps caps)
 {
 	u32 sgi = blockIdx.x * blockDim.x + threadIdx.x;
 	if (sgi >= n_segs) return;
@@ -96,8 +119,12 @@ __global__ void k_sort_classify(const SortSeg *segs, u32 n_segs, const u32 *hist
 	}
 	SegInfo si; si.c0 = c0; si.c1 = c1; si.cnt0 = cnt[c0];
 	if (nz <= 1) si.kind = LQ_SEG_IDENTITY;                  // one bucket holds everything: the pass is the identity
-	else if (nz == 2) { si.kind = LQ_SEG_TWO; two_list[atomicAdd(&counters[1], 1u)] = sgi; }
-	else { si.kind = LQ_SEG_GENERAL; walk_list[atomicAdd(&counters[0], 1u)] = sgi; }
+	else if (nz == 2) { si.kind = LQ_SEG_TWO; two_list[atomicAdd(&counters[0], 1u)] = sgi; }
+	else {
+		si.kind = LQ_SEG_GENERAL;
+		const u32 wc = lq_walk_class(segs[sgi].len, caps);
+		walk_list[(u64)wc * n_segs + atomicAdd(&counters[1 + wc], 1u)] = sgi;
+	}
 	info[sgi] = si;
 }
 
@@ -161,6 +188,12 @@ __global__ void k_two_dst(const SortSeg *segs, const SegInfo *info, const u32 *t
 	}
 }
 
+__global__ void k_walk_keys(const SortSeg *segs, const u32 *walk_list, u32 n_walk, u32 *key)
+{
+	u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n_walk) key[i] = 0xffffffffu - segs[walk_list[i]].len;
+}
+
 // ---- general pass: the token walk over digit bytes ---------------------------------------------
 #define LQ_WALK_LANES 64
 __global__ void __launch_bounds__(LQ_WALK_LANES)
@@ -175,20 +208,81 @@ k_sort_walk(const SortSeg *segs, const u32 *walk_list, u32 n_walk, const u8 *D, 
 		for (int c = 0; c < 256; ++c) nxt[c][lane] = bg[c];
 		const u8 *d = D + sg.off;
 		u32 *ds = dst + sg.off;
-		for (u32 k = 0; k < 256; ++k) {
-			const u32 n = cnt[k];
-			if (n == 0) continue;
-			const u32 endk = bg[k] + n;
-			while (nxt[k][lane] < endk) {
-				u32 src = nxt[k][lane];                       // the hole this cycle leaves in bucket k
-				u32 l = d[src];
-				while (l != k) {
-					const u32 t = nxt[l][lane]++;             // slot the carried element takes; its occupant is carried on
-					ds[src] = t;
-					src = t;
-					l = d[t];
-				}
-				ds[src] = nxt[k][lane]++;
+		// Flat form of the walk: every loop trip takes exactly one element, so the 64 lanes of the wave (64
+		// different sub-arrays) advance in lockstep instead of waiting for each other's cycles to close.
+		u32 k = 0, endk = bg[0] + cnt[0], src = 0, l = 0;
+		bool carrying = false;
+		for (;;) {
+			if (!carrying) {
+				while (k < 256 && nxt[k][lane] >= endk) { ++k; if (k < 256) endk = bg[k] + cnt[k]; }
+				if (k >= 256) break;
+				src = nxt[k][lane];                           // the hole this cycle leaves in bucket k
+				l = d[src];
+				carrying = true;
+			} else {
+				const u32 t = nxt[l][lane]++;                 // slot the carried element takes; its occupant is carried on
+				ds[src] = t;
+				src = t;
+				l = d[t];
+			}
+			if (l == k) { ds[src] = nxt[k][lane]++; carrying = false; }
+		}
+	}
+}
+
+// The same walk with the sub-array's digits staged in LDS: one block per sub-array; all threads load the
+// digit bytes, then one lane walks.  Each bucket keeps {cursor (24 bit), digit of the element under the cursor
+// (8 bit)} in a single LDS word, so the serial chain is one LDS round trip per element (~50 ns) instead of a
+// global-memory round trip (microseconds under load); the refill of the word is off the critical path.
+template <int CAP>
+__global__ void k_sort_walk_lds(const SortSeg *segs, const u32 *list, u32 n_list, const u8 *D, const u32 *hist, const u32 *begs, u32 *dst)
+{
+	LQ_SHARED u8 dig[CAP + 16];
+	LQ_SHARED u32 entry[256];
+	LQ_SHARED u32 endb[256];
+	if (blockIdx.x >= n_list) return;
+	const u32 sgi = list[blockIdx.x];
+	const SortSeg sg = segs[sgi];
+	const u32 *cnt = hist + (u64)sgi * 256, *bg = begs + (u64)sgi * 256;
+	const u8 *d = D + sg.off;
+	u32 *ds = dst + sg.off;
+	const u32 len = sg.len;
+	LQ_BLOCK_LOOP(t) {
+		for (u32 i = t; i < len; i += blockDim.x) dig[i] = d[i];
+		if (t == 0) dig[len] = 0;
+	}
+	LQ_BLOCK_SYNC();
+	LQ_BLOCK_LOOP(t) {
+		for (u32 c = t; c < 256; c += blockDim.x) {
+			const u32 b = bg[c];
+			endb[c] = b + cnt[c];
+			entry[c] = b | (u32)dig[b < len ? b : len] << 24;
+		}
+	}
+	LQ_BLOCK_SYNC();
+	if (threadIdx.x == 0) {
+		u32 k = 0, src = 0, l = 0;
+		bool carrying = false;
+		for (;;) {
+			if (!carrying) {
+				while (k < 256 && (entry[k] & 0xffffffu) >= endb[k]) ++k;
+				if (k >= 256) break;
+				const u32 e = entry[k];
+				src = e & 0xffffffu; l = e >> 24;                 // the hole this cycle leaves in bucket k
+				carrying = true;
+			} else {
+				const u32 e = entry[l];
+				const u32 t = e & 0xffffffu;                      // slot the carried element takes ...
+				ds[src] = t;
+				src = t;
+				entry[l] = (t + 1) | (u32)dig[t + 1] << 24;
+				l = e >> 24;                                      // ... and its occupant is carried on
+			}
+			if (l == k) {
+				const u32 c = entry[k] & 0xffffffu;
+				ds[src] = c;
+				entry[k] = (c + 1) | (u32)dig[c + 1] << 24;
+				carrying = false;
 			}
 		}
 	}

@@ -105,6 +105,22 @@ struct Prim {
 #endif
 	}
 
+	void sort_pairs_u32_u32(const u32 *kin, u32 *kout, const u32 *vin, u32 *vout, size_t n)
+	{
+		if (n == 0) return;
+#ifndef LQ_EMU
+		size_t bytes = 0;
+		LQ_HIP_CHECK(rocprim::radix_sort_pairs(nullptr, bytes, kin, kout, vin, vout, n, 0u, 32u, stream));
+		tmp.ensure(bytes);
+		LQ_HIP_CHECK(rocprim::radix_sort_pairs(tmp.p, bytes, kin, kout, vin, vout, n, 0u, 32u, stream));
+#else
+		std::vector<size_t> idx(n);
+		std::iota(idx.begin(), idx.end(), (size_t)0);
+		std::stable_sort(idx.begin(), idx.end(), [&](size_t a, size_t b) { return kin[a] < kin[b]; });
+		for (size_t i = 0; i < n; ++i) { kout[i] = kin[idx[i]]; vout[i] = vin[idx[i]]; }
+#endif
+	}
+
 	void sort_keys_u32(const u32 *kin, u32 *kout, size_t n)
 	{
 		if (n == 0) return;
