@@ -406,22 +406,26 @@ void lqcov_handle::map_part(Part &pt)
 				u32 ns = 0;
 				d2h(&ns, n_segs.as<u32>(), 1, stream);
 				SortSeg *cur = segs0.as<SortSeg>(), *nxt = segs1.as<SortSeg>();
+				WalkCaps wcaps; wcaps.c[0] = 4096; wcaps.c[1] = 16384; wcaps.c[2] = 65536; wcaps.c[3] = 159744;
+				if (const char *ws = getenv("LQCOV_WALK_SHIFT")) for (int c = 0; c < 4; ++c) wcaps.c[c] >>= atoi(ws);   // test knob
 				sort_d.ensure(nA + 16); sort_dst.ensure((nA + 1) * 4);
 				for (int level = 0; level < 8 && ns > 0; ++level) {
 					hist.ensure((u64)ns * 1024); begs.ensure((u64)ns * 1024);
-					seg_info.ensure((u64)ns * sizeof(SegInfo)); walk_list.ensure((u64)ns * 4); two_list.ensure((u64)ns * 4);
-					dzero(n_segs.as<u32>() + 1, 12, stream);           // [1] next-level count, [2] n_two, [3] n_walk
+					seg_info.ensure((u64)ns * sizeof(SegInfo)); walk_list.ensure((u64)ns * 4 * LQ_WALK_CLASSES); two_list.ensure((u64)ns * 4);
+					dzero(n_segs.as<u32>() + 1, 4 * (2 + LQ_WALK_CLASSES), stream);   // [1] next-level count, [2] n_two, [3..] n_walk per size class
 					{
 						StageTimer t(this, "k_sort_copy_hist", nA * 33);
 						LQ_LAUNCH(k_sort_copy_hist, ns, 256, stream, cur, ns, dA, dB, sort_d.as<u8>(), hist.as<u32>());
 						check_launch();
 					}
 					LQ_LAUNCH(k_sort_classify, nblk(ns, 64), 64, stream, cur, ns, hist.as<u32>(), begs.as<u32>(), seg_info.as<SegInfo>(),
-					          walk_list.as<u32>(), two_list.as<u32>(), n_segs.as<u32>() + 2);
+					          walk_list.as<u32>(), two_list.as<u32>(), n_segs.as<u32>() + 2, wcaps);
 					check_launch();
-					u32 cw[2] = {0, 0};
-					d2h(cw, n_segs.as<u32>() + 2, 2, stream);
-					const u32 n_two = cw[0], n_walk = cw[1];
+					u32 cw[1 + LQ_WALK_CLASSES];
+					d2h(cw, n_segs.as<u32>() + 2, 1 + LQ_WALK_CLASSES, stream);
+					const u32 n_two = cw[0];
+					u32 n_walk = 0;
+					for (int c = 0; c < LQ_WALK_CLASSES; ++c) n_walk += cw[1 + c];
 					if (n_two) {                                        // closed-form two-bucket passes (the strand bit at the top level)
 						StageTimer t(this, "k_sort_two_bucket", nA * 60);
 						fx.ensure((nA + 1) * 4); fy.ensure((nA + 1) * 4); sx.ensure((nA + 1) * 4); sy.ensure((nA + 1) * 4);
@@ -438,13 +442,27 @@ void lqcov_handle::map_part(Part &pt)
 						check_launch();
 					}
 					if (n_walk) {
-						// longest sub-arrays first; neighbours in the list (= lanes of one wave) have similar lengths
-						wkey.ensure((u64)n_walk * 4); wkey2.ensure((u64)n_walk * 4); walk_list2.ensure((u64)n_walk * 4);
-						LQ_LAUNCH(k_walk_keys, nblk(n_walk, 256), 256, stream, cur, walk_list.as<u32>(), n_walk, wkey.as<u32>()); check_launch();
-						prim.sort_pairs_u32_u32(wkey.as<u32>(), wkey2.as<u32>(), walk_list.as<u32>(), walk_list2.as<u32>(), n_walk);
 						StageTimer t(this, "k_sort_walk", nA * 5);
-						LQ_LAUNCH(k_sort_walk, nblk(n_walk, LQ_WALK_LANES), LQ_WALK_LANES, stream, cur, walk_list2.as<u32>(), n_walk, sort_d.as<u8>(), hist.as<u32>(), begs.as<u32>(), sort_dst.as<u32>());
-						check_launch();
+						const u8 *dD = sort_d.as<u8>(); const u32 *dH = hist.as<u32>(), *dBg = begs.as<u32>(); u32 *dDst = sort_dst.as<u32>();
+						const u32 *wl = walk_list.as<u32>();
+						if (cw[1]) { LQ_LAUNCH((k_sort_walk_lds<4096>), cw[1], 64, stream, cur, wl + (u64)0 * ns, cw[1], dD, dH, dBg, dDst); check_launch(); }
+						if (cw[2]) { LQ_LAUNCH((k_sort_walk_lds<16384>), cw[2], 64, stream, cur, wl + (u64)1 * ns, cw[2], dD, dH, dBg, dDst); check_launch(); }
+						const u32 n_long = cw[3] + cw[4] + cw[5];
+						if (n_long) {
+							// longer sub-arrays: one lane each over the global digit bytes (64 independent walks per wave keep more
+							// memory transactions in flight than a single LDS-resident walker can), longest first.
+							// The three size classes are contiguous in the list only per class, so gather them.
+							wkey.ensure((u64)n_long * 4); wkey2.ensure((u64)n_long * 4); walk_list2.ensure((u64)n_long * 4); walk_list3.ensure((u64)n_long * 4);
+							u32 o = 0;
+							for (int c = 2; c < LQ_WALK_CLASSES; ++c) if (cw[1 + c]) {
+								LQ_HIP_CHECK(hipMemcpyAsync(walk_list3.as<u32>() + o, wl + (u64)c * ns, (u64)cw[1 + c] * 4, hipMemcpyDeviceToDevice, stream));
+								o += cw[1 + c];
+							}
+							LQ_LAUNCH(k_walk_keys, nblk(n_long, 256), 256, stream, cur, walk_list3.as<u32>(), n_long, wkey.as<u32>()); check_launch();
+							prim.sort_pairs_u32_u32(wkey.as<u32>(), wkey2.as<u32>(), walk_list3.as<u32>(), walk_list2.as<u32>(), n_long);
+							LQ_LAUNCH(k_sort_walk, nblk(n_long, LQ_WALK_LANES), LQ_WALK_LANES, stream, cur, walk_list2.as<u32>(), n_long, dD, dH, dBg, dDst);
+							check_launch();
+						}
 					}
 					if (n_walk || n_two) {
 						StageTimer t(this, "k_sort_scatter", nA * 36);

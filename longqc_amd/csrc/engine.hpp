@@ -66,7 +66,7 @@ struct lqcov_handle {
 	// work buffers of part_map
 	DBuf hit_start, hit_n, a_cnt, keep, a_off, mp_off, mini_pos, aq_off, mpq_off, avg_qspan, skip;
 	DBuf A, B, segs0, segs1, n_segs, hist, begs;
-	DBuf sort_d, sort_dst, seg_info, walk_list, two_list, fx, fy, sx, sy, hx, py, wkey, wkey2, walk_list2;
+	DBuf sort_d, sort_dst, seg_info, walk_list, two_list, fx, fy, sx, sy, hx, py, wkey, wkey2, walk_list2, walk_list3;
 	DBuf gflag, gidx, gsel, gkey, gsel2, gkey2;
 	DBuf head, gid, gstart, cf, cp, ct, cv, cu;
 	DBuf ivl, n_ivl, iv_q, iv_q2, iv_se, iv_se2, ivq_off, iv_scratch;

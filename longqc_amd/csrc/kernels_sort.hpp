@@ -95,9 +95,17 @@ __global__ void k_sort_copy_hist(const SortSeg *segs, u32 n_segs, const mm128 *A
 }
 
 // one thread per sub-array: bucket offsets and the kind of pass; lists of general / two-bucket sub-arrays
-// counters = [n_two, n_walk]
+// size classes of general passes: digits of the sub-array fit a 4 / 16 / 64 / 156 KiB LDS window, or not at all
+#define LQ_WALK_CLASSES 5
+struct WalkCaps { u32 c[4]; };        // default {4096, 16384, 65536, 159744}; tests shrink them to reach every class
+__device__ __forceinline__ u32 lq_walk_class(u32 len, const WalkCaps &w)
+{
+	return len <= w.c[0] ? 0u : len <= w.c[1] ? 1u : len <= w.c[2] ? 2u : len <= w.c[3] ? 3u : 4u;
+}
+
+// walk_list holds LQ_WALK_CLASSES lists of n_segs entries each; counters = [n_two, n_walk[0..4]]
 __global__ void k_sort_classify(const SortSeg *segs, u32 n_segs, const u32 *hist, u32 *begs, SegInfo *info,
-                                u32 *walk_list, u32 *two_list, u32 *counters)
+                                u32 *walk_list, u32 *two_list, u32 *counters, WalkCaps caps)
 {
 	u32 sgi = blockIdx.x * blockDim.x + threadIdx.x;
 	if (sgi >= n_segs) return;
@@ -112,7 +120,11 @@ __global__ void k_sort_classify(const SortSeg *segs, u32 n_segs, const u32 *hist
 	SegInfo si; si.c0 = c0; si.c1 = c1; si.cnt0 = cnt[c0];
 	if (nz <= 1) si.kind = LQ_SEG_IDENTITY;                  // one bucket holds everything: the pass is the identity
 	else if (nz == 2) { si.kind = LQ_SEG_TWO; two_list[atomicAdd(&counters[0], 1u)] = sgi; }
-	else { si.kind = LQ_SEG_GENERAL; walk_list[atomicAdd(&counters[1], 1u)] = sgi; }
+	else {
+		si.kind = LQ_SEG_GENERAL;
+		const u32 wc = lq_walk_class(segs[sgi].len, caps);
+		walk_list[(u64)wc * n_segs + atomicAdd(&counters[1 + wc], 1u)] = sgi;
+	}
 	info[sgi] = si;
 }
 
@@ -183,83 +195,95 @@ __global__ void k_walk_keys(const SortSeg *segs, const u32 *walk_list, u32 n_wal
 }
 
 // ---- general pass: the token walk over digit bytes ---------------------------------------------
-// One lane per sub-array, 64 sub-arrays per wave.  Per lane and bucket, LDS holds the cursor (u32, top bit =
-// "digit refill in flight") and the digit of the element under the cursor (u8): [256][64], lane-minor.  A loop
-// trip is one "visit" of a bucket: read {cursor, digit} from LDS, record dst[src] = cursor, advance the cursor
-// and *asynchronously* refetch the digit under the new cursor from global memory.  The refill lands in a
-// register ring (R slots; the loop is unrolled R times so the ring is statically indexed) and is committed to
-// LDS R trips later, so the HBM/L2 latency of the byte load is paid once per R trips instead of once per trip
-// and the serial chain of a trip is one LDS round trip.  A bucket that is visited again while its refill is
-// still in flight is committed on the spot.  Flat control flow (START / CARRY / CLOSE share one code path)
-// keeps the 64 lanes of a wave in lockstep.
 #define LQ_WALK_LANES 64
-#define LQ_WALK_RING 32
-#define LQ_WM_START 0
-#define LQ_WM_CARRY 1
-#define LQ_WM_CLOSE 2
-#define LQ_WM_DONE  3
-#define LQ_PEND 0x80000000u
 __global__ void __launch_bounds__(LQ_WALK_LANES)
 k_sort_walk(const SortSeg *segs, const u32 *walk_list, u32 n_walk, const u8 *D, const u32 *hist, const u32 *begs, u32 *dst)
 {
-	LQ_SHARED u32 cur[256][LQ_WALK_LANES];
-	LQ_SHARED u8 nd[256][LQ_WALK_LANES];
+	LQ_SHARED u32 nxt[256][LQ_WALK_LANES];
 	const u32 lane = threadIdx.x;
-	const u64 wi = (u64)blockIdx.x * LQ_WALK_LANES + lane;
-	u32 mode = LQ_WM_DONE;
-	const u8 *d = D;
-	u32 *ds = dst;
-	const u32 *cnt = hist, *bg = begs;
-	u32 len = 0;
-	if (wi < n_walk) {
+	for (u64 wi = (u64)blockIdx.x * LQ_WALK_LANES + lane; wi < n_walk; wi += (u64)gridDim.x * LQ_WALK_LANES) {
 		const u32 sgi = walk_list[wi];
 		const SortSeg sg = segs[sgi];
-		cnt = hist + (u64)sgi * 256; bg = begs + (u64)sgi * 256;
-		d = D + sg.off; ds = dst + sg.off; len = sg.len;
-		for (int c = 0; c < 256; ++c) {
-			const u32 b = bg[c];
-			cur[c][lane] = b;
-			nd[c][lane] = b < len ? d[b] : 0;
+		const u32 *cnt = hist + (u64)sgi * 256, *bg = begs + (u64)sgi * 256;
+		for (int c = 0; c < 256; ++c) nxt[c][lane] = bg[c];
+		const u8 *d = D + sg.off;
+		u32 *ds = dst + sg.off;
+		// Flat form of the walk: every loop trip takes exactly one element, so the 64 lanes of the wave (64
+		// different sub-arrays) advance in lockstep instead of waiting for each other's cycles to close.
+		u32 k = 0, endk = bg[0] + cnt[0], src = 0, l = 0;
+		bool carrying = false;
+		for (;;) {
+			if (!carrying) {
+				while (k < 256 && nxt[k][lane] >= endk) { ++k; if (k < 256) endk = bg[k] + cnt[k]; }
+				if (k >= 256) break;
+				src = nxt[k][lane];                           // the hole this cycle leaves in bucket k
+				l = d[src];
+				carrying = true;
+			} else {
+				const u32 t = nxt[l][lane]++;                 // slot the carried element takes; its occupant is carried on
+				ds[src] = t;
+				src = t;
+				l = d[t];
+			}
+			if (l == k) { ds[src] = nxt[k][lane]++; carrying = false; }
 		}
-		mode = LQ_WM_START;
 	}
-	u32 k = 0, endk = mode == LQ_WM_START ? bg[0] + cnt[0] : 0, src = 0, l = 0;
-	u32 pb[LQ_WALK_RING];                                     // bucket whose digit refill is in flight (0xffff: none)
-	u32 pv[LQ_WALK_RING];                                     // the refilled digit: a raw load result, touched only at commit
-#pragma unroll
-	for (int r = 0; r < LQ_WALK_RING; ++r) { pb[r] = 0xffffu; pv[r] = 0; }
-	while (mode != LQ_WM_DONE) {
-#pragma unroll
-		for (int r = 0; r < LQ_WALK_RING; ++r) {
-			if (mode == LQ_WM_START) {                        // next bucket that still has unread slots
-				while (k < 256 && (cur[k][lane] & ~LQ_PEND) >= endk) { ++k; if (k < 256) endk = bg[k] + cnt[k]; }
-				if (k >= 256) mode = LQ_WM_DONE;
+}
+
+// The same walk with the sub-array's digits staged in LDS: one block per sub-array; all threads load the
+// digit bytes, then one lane walks.  Each bucket keeps {cursor (24 bit), digit of the element under the cursor
+// (8 bit)} in a single LDS word, so the serial chain is one LDS round trip per element (~50 ns) instead of a
+// global-memory round trip (microseconds under load); the refill of the word is off the critical path.
+template <int CAP>
+__global__ void k_sort_walk_lds(const SortSeg *segs, const u32 *list, u32 n_list, const u8 *D, const u32 *hist, const u32 *begs, u32 *dst)
+{
+	LQ_SHARED u8 dig[CAP + 16];
+	LQ_SHARED u32 entry[256];
+	LQ_SHARED u32 endb[256];
+	if (blockIdx.x >= n_list) return;
+	const u32 sgi = list[blockIdx.x];
+	const SortSeg sg = segs[sgi];
+	const u32 *cnt = hist + (u64)sgi * 256, *bg = begs + (u64)sgi * 256;
+	const u8 *d = D + sg.off;
+	u32 *ds = dst + sg.off;
+	const u32 len = sg.len;
+	LQ_BLOCK_LOOP(t) {
+		for (u32 i = t; i < len; i += blockDim.x) dig[i] = d[i];
+		if (t == 0) dig[len] = 0;
+	}
+	LQ_BLOCK_SYNC();
+	LQ_BLOCK_LOOP(t) {
+		for (u32 c = t; c < 256; c += blockDim.x) {
+			const u32 b = bg[c];
+			endb[c] = b + cnt[c];
+			entry[c] = b | (u32)dig[b < len ? b : len] << 24;
+		}
+	}
+	LQ_BLOCK_SYNC();
+	if (threadIdx.x == 0) {
+		u32 k = 0, src = 0, l = 0;
+		bool carrying = false;
+		for (;;) {
+			if (!carrying) {
+				while (k < 256 && (entry[k] & 0xffffffu) >= endb[k]) ++k;
+				if (k >= 256) break;
+				const u32 e = entry[k];
+				src = e & 0xffffffu; l = e >> 24;                 // the hole this cycle leaves in bucket k
+				carrying = true;
+			} else {
+				const u32 e = entry[l];
+				const u32 t = e & 0xffffffu;                      // slot the carried element takes ...
+				ds[src] = t;
+				src = t;
+				entry[l] = (t + 1) | (u32)dig[t + 1] << 24;
+				l = e >> 24;                                      // ... and its occupant is carried on
 			}
-			u32 na = 0;                                       // idle lanes refetch d[0]: the load below must be unconditional
-			if (mode != LQ_WM_DONE) {
-				const u32 b = mode == LQ_WM_CARRY ? l : k;
-				// the ring slot of this trip: commit what it holds (issued R trips ago), then reuse it
-				if (pb[r] != 0xffffu) { nd[pb[r]][lane] = (u8)pv[r]; cur[pb[r]][lane] &= ~LQ_PEND; }
-				pb[r] = 0xffffu;
-				u32 c = cur[b][lane];
-				if (c & LQ_PEND) {                            // b's digit is still in flight (same bucket within R trips): commit it now
-#pragma unroll
-					for (int q = 0; q < LQ_WALK_RING; ++q) if (pb[q] == b) { nd[b][lane] = (u8)pv[q]; pb[q] = 0xffffu; }
-					c &= ~LQ_PEND;
-				}
-				const u32 dg = nd[b][lane];
-				const bool adv = mode != LQ_WM_START;         // START only peeks: the element under k's cursor is picked up
-				if (adv) ds[src] = c;                         // the carried element takes slot c of bucket b
-				const u32 nc = adv ? c + 1 : c;
-				cur[b][lane] = nc | LQ_PEND;
-				pb[r] = b;
-				na = nc < len ? nc : len - 1;
-				if (mode != LQ_WM_CLOSE) { src = c; l = dg; mode = l == k ? LQ_WM_CLOSE : LQ_WM_CARRY; }
-				else mode = LQ_WM_START;                      // cycle closed: the hole of bucket k is filled
+			if (l == k) {
+				const u32 c = entry[k] & 0xffffffu;
+				ds[src] = c;
+				entry[k] = (c + 1) | (u32)dig[c + 1] << 24;
+				carrying = false;
 			}
-			// asynchronous (re)fetch of the digit under the cursor.  Issued by every lane on every trip so that the
-			// compiler can count on younger loads when an older slot is committed (s_waitcnt vmcnt(n > 0)).
-			pv[r] = d[na];
 		}
 	}
 }

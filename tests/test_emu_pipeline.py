@@ -140,3 +140,16 @@ def test_emulated_reset_and_rerun(emu_lib):
         tables.append(eng.table_text())
     assert tables[0] == tables[1] == read_gz("tiny_ont.table.gz")
     eng.close()
+
+
+@pytest.mark.parametrize("shift", ["4", "7", "12"])
+def test_emulated_every_walk_size_class(emu_lib, datasets, monkeypatch, shift):
+    """shrinks the LDS-window thresholds of the klib-order sort so that small inputs exercise every size class
+    of the digit walk, including the global-memory lane walker used when a sub-array exceeds 156 KiB"""
+    tf, qf = datasets("small")
+    argv = ["-Y", "-l", "0", "-q", "160", "-k", "12", "-w", "5", "-I", "2M", "-p", "160", tf, qf]
+    want = oracle_bind.table(argv)
+    monkeypatch.setenv("LQCOV_WALK_SHIFT", shift)
+    rc, out, err = run_main(emu_lib, argv)
+    assert rc == 0, err
+    assert out == want

@@ -151,3 +151,8 @@ def test_gpu_properties_at_scale(gpu_lib, tmp_path):
         synth.write_fastq(tf, T); synth.write_fastq(qf, sub)
         want = oracle_bind.ref_table(["-Y", "-l", "0", "-q", "160", "-k", "12", "-w", "5", "-I", "4G", "-p", "160", "-t", str(os.cpu_count() or 4), tf, qf]).splitlines()
         assert t2 == want
+
+
+@pytest.mark.parametrize("shift", ["4", "7", "12"])
+def test_gpu_every_walk_size_class(gpu_lib, datasets, monkeypatch, shift):
+    E.test_emulated_every_walk_size_class(gpu_lib, datasets, monkeypatch, shift)
