@@ -26,6 +26,42 @@ import torch.distributed as dist
 COVT = 150  # minimap2-coverage.h:20
 
 
+# Collectives.  On the GPU box the backend is "nccl" (= RCCL over xGMI) and tensors stay on the device; the
+# gloo backend (CPU tests, or two test ranks sharing one GPU) gets host staging for device tensors.
+def _staged(t: torch.Tensor, group) -> bool:
+    return t.is_cuda and dist.get_backend(group) == "gloo"
+
+
+def _all_gather(t: torch.Tensor, world: int, group) -> List[torch.Tensor]:
+    if _staged(t, group):
+        h = t.cpu()
+        out = [torch.empty_like(h) for _ in range(world)]
+        dist.all_gather(out, h, group=group)
+        return [o.to(t.device) for o in out]
+    out = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(out, t, group=group)
+    return out
+
+
+def _all_reduce(t: torch.Tensor, group, op=None) -> None:
+    op = op if op is not None else dist.ReduceOp.SUM
+    if _staged(t, group):
+        h = t.cpu()
+        dist.all_reduce(h, op=op, group=group)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=op, group=group)
+
+
+def _broadcast(t: torch.Tensor, src: int, group) -> None:
+    if _staged(t, group):
+        h = t.cpu()
+        dist.broadcast(h, src=src, group=group)
+        t.copy_(h)
+    else:
+        dist.broadcast(t, src=src, group=group)
+
+
 def covt_replay(lam_parts: torch.Tensor, avgk_parts: torch.Tensor, qlen: torch.Tensor,
                 lam0: Optional[torch.Tensor] = None, avgk0: Optional[torch.Tensor] = None):
     """Replays lq_cnt_match's prologue (esterr.c:85-97) over parts in order.
@@ -92,7 +128,7 @@ class PartRunner:
         """mid_occ comes from part 0 (map.c:50): its owner broadcasts it after building."""
         t = torch.tensor([self.eng.mid_occ], dtype=torch.int32, device=self.dev)
         if self.world > 1:
-            dist.broadcast(t, src=owner_rank, group=self.group)
+            _broadcast(t, owner_rank, self.group)
         self.eng.set_mid_occ(int(t.item()))
 
     def map_and_combine(self, part: Optional[int], part_index: int, mid_occ_owner: int = 0, share_mid_occ: bool = True):
@@ -116,11 +152,8 @@ class PartRunner:
             ivl = ivl[:n_ivl]
         # (ii)/(iii): replay the cap and avg_k over this round's parts, in part order
         if self.world > 1:
-            lam_all = [torch.empty_like(lam) for _ in range(self.world)]
-            avgk_all = [torch.empty_like(avgk) for _ in range(self.world)]
-            dist.all_gather(lam_all, lam, group=self.group)
-            dist.all_gather(avgk_all, avgk, group=self.group)
-            lam_parts, avgk_parts = torch.stack(lam_all), torch.stack(avgk_all)
+            lam_parts = torch.stack(_all_gather(lam, self.world, self.group))
+            avgk_parts = torch.stack(_all_gather(avgk, self.world, self.group))
         else:
             lam_parts, avgk_parts = lam[None], avgk[None]
         inc, lam_tot, avgk_tot = covt_replay(lam_parts[:, :n_q], avgk_parts[:, :n_q], self.qlen, self.lam[:n_q], self.avgk[:n_q])
@@ -130,17 +163,15 @@ class PartRunner:
         flagc = torch.where(mine, flags[:n_q], torch.zeros_like(flags[:n_q]))
         ivlc = ivl[mine[ivl[:, 0].long()]] if ivl.shape[0] else ivl
         if self.world > 1:
-            dist.all_reduce(lam2c, group=self.group)
+            lam2c = lam2c.contiguous(); _all_reduce(lam2c, self.group)
             if n_cnt:
-                dist.all_reduce(cntc, group=self.group)
-            dist.all_reduce(flagc, op=dist.ReduceOp.MAX, group=self.group)
-            sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(self.world)]
-            dist.all_gather(sizes, torch.tensor([ivlc.shape[0]], dtype=torch.int64, device=dev), group=self.group)
+                cntc = cntc.contiguous(); _all_reduce(cntc, self.group)
+            flagc = flagc.contiguous(); _all_reduce(flagc, self.group, dist.ReduceOp.MAX)
+            sizes = _all_gather(torch.tensor([ivlc.shape[0]], dtype=torch.int64, device=dev), self.world, self.group)
             mx = int(max(int(s.item()) for s in sizes))
             pad = torch.zeros((max(mx, 1), 3), dtype=torch.int32, device=dev)
             pad[:ivlc.shape[0]] = ivlc
-            got = [torch.empty_like(pad) for _ in range(self.world)]
-            dist.all_gather(got, pad, group=self.group)
+            got = _all_gather(pad, self.world, self.group)
             ivlc = torch.cat([g[:int(s.item())] for g, s in zip(got, sizes)], dim=0)
         self.lam[:n_q], self.avgk[:n_q] = lam_tot, avgk_tot
         self.lam2[:n_q] += lam2c

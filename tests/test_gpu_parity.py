@@ -156,3 +156,13 @@ def test_gpu_properties_at_scale(gpu_lib, tmp_path):
 @pytest.mark.parametrize("shift", ["4", "7", "12"])
 def test_gpu_every_walk_size_class(gpu_lib, datasets, monkeypatch, shift):
     E.test_emulated_every_walk_size_class(gpu_lib, datasets, monkeypatch, shift)
+
+
+def test_gpu_two_ranks_share_the_device_exchange_accumulators(gpu_lib, tmp_path):
+    """the N > 1 driver with real device pointers: two ranks (gloo, both on cuda:0 -- a 1-GPU box cannot host two
+    RCCL ranks) split the 10 parts of the COVT fixture and must reproduce the reference's sequential table"""
+    import torch.multiprocessing as mp
+    import tests.test_multigpu_cpu as M
+    out = str(tmp_path / "t.tsv")
+    mp.spawn(M._worker, args=(2, M._free_port(), 100000, out, True), nprocs=2, join=True)
+    assert open(out).read() == read_gz("adv_parts.table.gz")

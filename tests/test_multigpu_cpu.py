@@ -47,11 +47,11 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _worker(rank, world, port, argv_I, out_path):
+def _worker(rank, world, port, argv_I, out_path, use_gpu=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        lib = api.load_library(os.path.join(ROOT, "tests", "emu", "liblqcov_emu.so"))
+        lib = api.load_library() if use_gpu else api.load_library(os.path.join(ROOT, "tests", "emu", "liblqcov_emu.so"))
         tn, ts, _ = read_fastx(os.path.join(GOLDEN, "adv_all.fa.gz"))
         qn, qs, qq = read_fastx(os.path.join(GOLDEN, "adv_sub.fq.gz"))
         p = api.Params(); lib.lqcov_params_default(p)
@@ -59,7 +59,7 @@ def _worker(rank, world, port, argv_I, out_path):
         eng = api.Engine(p, 0, lib=lib)
         eng.set_queries(qn, qs, qq)
         parts = multigpu.split_parts([int(s.shape[0]) for s in ts], argv_I)
-        runner = multigpu.PartRunner(eng, world, rank, torch.device("cpu"), [int(s.shape[0]) for s in qs])
+        runner = multigpu.PartRunner(eng, world, rank, torch.device("cuda", 0) if use_gpu else torch.device("cpu"), [int(s.shape[0]) for s in qs])
         runner.begin()
         for base in range(0, len(parts), world):
             mine = base + rank

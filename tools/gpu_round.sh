@@ -1,14 +1,33 @@
 #!/bin/bash
-# one GPU session: pytest -m gpu, smoke, bench (N=1), rocprof kernel-trace summary -> gpurun_out/
+# one GPU session: pytest -m gpu, smoke, bench (N=1), rocprof kernel-trace summary, PMC passes -> gpurun_out/
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
 T0=$(date +%s)
 ( timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -15 ) > gpurun_out/pytest_gpu.log 2>&1
 echo "pytest done $(( $(date +%s) - T0 )) s" >> gpurun_out/pytest_gpu.log
 ( timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -5 ) > gpurun_out/smoke.log 2>&1
-( timeout 600 python bench.py --steps 3 --warmup 1 2>&1 | tail -5 ) > gpurun_out/bench.log 2>&1
+( timeout 900 python bench.py --steps 3 --warmup 1 2>&1 | tail -5 ) > gpurun_out/bench.log 2>&1
 echo "bench done $(( $(date +%s) - T0 )) s" >> gpurun_out/bench.log
 cd /tmp && export TMPDIR=/tmp
-( timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -o b -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --reads 20000 --nsample 2000 --no-cpu-baseline 2>&1 | tail -3 ) > $GRAFT_REPO_ROOT/gpurun_out/rocprof.log 2>&1
-find /tmp/prof -name "*stats*.csv" -exec cp {} $GRAFT_REPO_ROOT/gpurun_out/ \; 2>/dev/null
-ls -la /tmp/prof/* >> $GRAFT_REPO_ROOT/gpurun_out/rocprof.log 2>&1
-cd $GRAFT_REPO_ROOT; tail -3 gpurun_out/pytest_gpu.log gpurun_out/smoke.log gpurun_out/bench.log
+B="python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline"
+( timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -o b -- $B 2>&1 | tail -3 ) > $GRAFT_REPO_ROOT/gpurun_out/rocprof.log 2>&1
+cp /tmp/prof/b_kernel_stats.csv $GRAFT_REPO_ROOT/gpurun_out/ 2>/dev/null
+for C in FETCH_SIZE WRITE_SIZE; do
+  ( timeout 600 rocprofv3 --pmc $C --kernel-trace --output-format csv -d /tmp/pmc_$C -o p -- $B --reads 20000 --nsample 2000 2>&1 | tail -3 ) > $GRAFT_REPO_ROOT/gpurun_out/pmc_$C.log 2>&1
+  ls -la /tmp/pmc_$C >> $GRAFT_REPO_ROOT/gpurun_out/pmc_$C.log 2>&1
+  python - "$C" <<'PY' >> $GRAFT_REPO_ROOT/gpurun_out/pmc_summary.txt 2>&1
+import csv, glob, sys, collections
+c = sys.argv[1]
+f = glob.glob('/tmp/pmc_%s/*counter_collection.csv' % c)
+if not f:
+    print(c, "no counter file"); sys.exit()
+agg = collections.defaultdict(lambda: [0.0, 0])
+for row in csv.DictReader(open(f[0])):
+    if row.get('Counter_Name') != c: continue
+    k = row['Kernel_Name'].split('(')[0][:60]
+    agg[k][0] += float(row['Counter_Value']); agg[k][1] += 1
+print("== %s: kernel, dispatches, sum, mean per dispatch (raw counter units)" % c)
+for k, (s, n) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:25]:
+    print("%-60s %6d %16.1f %14.1f" % (k, n, s, s / n))
+PY
+done
+cd $GRAFT_REPO_ROOT; tail -3 gpurun_out/pytest_gpu.log gpurun_out/smoke.log gpurun_out/bench.log; cat gpurun_out/pmc_summary.txt | head -60
