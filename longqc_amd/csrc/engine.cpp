@@ -408,7 +408,7 @@ void lqcov_handle::map_part(Part &pt)
 				SortSeg *cur = segs0.as<SortSeg>(), *nxt = segs1.as<SortSeg>();
 				WalkCaps wcaps; wcaps.c[0] = 4096; wcaps.c[1] = 16384; wcaps.c[2] = 65536; wcaps.c[3] = 159744;
 				if (const char *ws = getenv("LQCOV_WALK_SHIFT")) for (int c = 0; c < 4; ++c) wcaps.c[c] >>= atoi(ws);   // test knob
-				sort_d.ensure(nA + 16); sort_dst.ensure((nA + 1) * 4);
+				sort_d.ensure(nA + 64); sort_dst.ensure((nA + 1) * 4);
 				for (int level = 0; level < 8 && ns > 0; ++level) {
 					hist.ensure((u64)ns * 1024); begs.ensure((u64)ns * 1024);
 					seg_info.ensure((u64)ns * sizeof(SegInfo)); walk_list.ensure((u64)ns * 4 * LQ_WALK_CLASSES); two_list.ensure((u64)ns * 4);
@@ -442,11 +442,10 @@ void lqcov_handle::map_part(Part &pt)
 						check_launch();
 					}
 					if (n_walk) {
-						StageTimer t(this, "k_sort_walk", nA * 5);
 						const u8 *dD = sort_d.as<u8>(); const u32 *dH = hist.as<u32>(), *dBg = begs.as<u32>(); u32 *dDst = sort_dst.as<u32>();
 						const u32 *wl = walk_list.as<u32>();
-						if (cw[1]) { LQ_LAUNCH((k_sort_walk_lds<4096>), cw[1], 64, stream, cur, wl + (u64)0 * ns, cw[1], dD, dH, dBg, dDst); check_launch(); }
-						if (cw[2]) { LQ_LAUNCH((k_sort_walk_lds<16384>), cw[2], 64, stream, cur, wl + (u64)1 * ns, cw[2], dD, dH, dBg, dDst); check_launch(); }
+						if (cw[1]) { StageTimer t(this, "k_sort_walk_lds<4096>"); LQ_LAUNCH((k_sort_walk_lds<4096>), cw[1], 64, stream, cur, wl + (u64)0 * ns, cw[1], dD, dH, dBg, dDst); check_launch(); }
+						if (cw[2]) { StageTimer t(this, "k_sort_walk_lds<16384>"); LQ_LAUNCH((k_sort_walk_lds<16384>), cw[2], 64, stream, cur, wl + (u64)1 * ns, cw[2], dD, dH, dBg, dDst); check_launch(); }
 						const u32 n_long = cw[3] + cw[4] + cw[5];
 						if (n_long) {
 							// longer sub-arrays: one lane each over the global digit bytes (64 independent walks per wave keep more
@@ -460,6 +459,14 @@ void lqcov_handle::map_part(Part &pt)
 							}
 							LQ_LAUNCH(k_walk_keys, nblk(n_long, 256), 256, stream, cur, walk_list3.as<u32>(), n_long, wkey.as<u32>()); check_launch();
 							prim.sort_pairs_u32_u32(wkey.as<u32>(), wkey2.as<u32>(), walk_list3.as<u32>(), walk_list2.as<u32>(), n_long);
+							// algorithmic bytes of a walk: one digit byte in, one 4-byte destination out per element
+							u64 long_elems = 0;
+							{
+								std::vector<u32> hk(n_long);
+								d2h(hk.data(), wkey2.as<u32>(), n_long, stream);
+								for (u32 v : hk) long_elems += 0xffffffffu - v;
+							}
+							StageTimer t(this, "k_sort_walk", long_elems * 5);
 							LQ_LAUNCH(k_sort_walk, nblk(n_long, LQ_WALK_LANES), LQ_WALK_LANES, stream, cur, walk_list2.as<u32>(), n_long, dD, dH, dBg, dDst);
 							check_launch();
 						}
@@ -501,29 +508,16 @@ void lqcov_handle::map_part(Part &pt)
 			cs.mini_pos = mini_pos.as<u64>(); cs.mpq_off = mpq_off.as<u64>(); cs.qlen = q.d_len.as<u32>(); cs.tlen = pt.rs.d_len.as<u32>();
 			cs.ivl = ivl.as<Ivl>(); cs.n_ivl = n_ivl.as<u32>(); cs.ivl_cap = ivl_cap;
 			cs.dbg = dbg ? dbg_chains.as<ChainRec>() : nullptr; cs.n_dbg = n_dbg.as<unsigned long long>(); cs.dbg_cap = dbg_cap;
-			// work list of the runs that can hold a chain.  Default: all runs, one thread each, in array order (most
-			// lanes retire at once; the few long runs of a wave then keep their working set in the CU's L1).
-			// LQCOV_CHAIN_DENSE=1: compacted, longest-first list (every lane busy, but 64 unrelated working sets per wave).
 			if (n_groups > 0xfffffff0ULL) throw std::domain_error("too many anchor runs in one batch");
-			static const bool chain_dense = getenv("LQCOV_CHAIN_DENSE") && atoi(getenv("LQCOV_CHAIN_DENSE")) != 0;
-			if (chain_dense) {
-				gflag.ensure(n_groups * 4 + 4); gidx.ensure(n_groups * 4 + 4);
-				LQ_LAUNCH(k_group_flags, nblk(n_groups, 256), 256, stream, gstart.as<u64>(), n_groups, (i32)P.min_cnt, gflag.as<u32>()); check_launch();
-				prim.exclusive_scan_u32_u32(gflag.as<u32>(), gidx.as<u32>(), n_groups);
-				u32 lgi = 0, lgf = 0;
-				d2h(&lgi, gidx.as<u32>() + n_groups - 1, 1, stream); d2h(&lgf, gflag.as<u32>() + n_groups - 1, 1, stream);
-				const u32 n_sel = lgi + lgf;
-				if (n_sel) {
-					gsel.ensure((u64)n_sel * 4); gkey.ensure((u64)n_sel * 4); gsel2.ensure((u64)n_sel * 4); gkey2.ensure((u64)n_sel * 4);
-					LQ_LAUNCH(k_group_compact, nblk(n_groups, 256), 256, stream, gstart.as<u64>(), gflag.as<u32>(), gidx.as<u32>(), n_groups, gsel.as<u32>(), gkey.as<u32>()); check_launch();
-					prim.sort_pairs_u32_u32(gkey.as<u32>(), gkey2.as<u32>(), gsel.as<u32>(), gsel2.as<u32>(), n_sel);
-					StageTimer t(this, "k_chain", nA * 16);
-					LQ_LAUNCH(k_chain, nblk(n_sel, 64), 64, stream, dA, gstart.as<u64>(), gsel2.as<u32>(), n_sel, aqb, a_base, nqb, q0, avg_qspan.as<float>(), mp, cb, cs);
-					check_launch();
-				}
-			} else {
+			{	// short runs (<= LQ_CHAIN_SMALL anchors): private-array DP, one thread per run
+				StageTimer t(this, "k_chain_small", nA * 16);
+				LQ_LAUNCH(k_chain_small, nblk(n_groups, 64), 64, stream, dA, gstart.as<u64>(), n_groups, aqb, a_base, nqb, q0, avg_qspan.as<float>(), mp, cs);
+				check_launch();
+			}
+			{	// long runs: global-scratch DP, one thread per run (array order: the few long runs of a wave keep their
+				// working set in the CU's L1)
 				StageTimer t(this, "k_chain", nA * 16);
-				LQ_LAUNCH(k_chain, nblk(n_groups, 64), 64, stream, dA, gstart.as<u64>(), (const u32*)nullptr, (u32)n_groups, aqb, a_base, nqb, q0, avg_qspan.as<float>(), mp, cb, cs);
+				LQ_LAUNCH(k_chain, nblk(n_groups, 64), 64, stream, dA, gstart.as<u64>(), (const u32*)nullptr, (u32)n_groups, aqb, a_base, nqb, q0, avg_qspan.as<float>(), mp, cb, cs, (i32)(LQ_CHAIN_SMALL + 1));
 				check_launch();
 			}
 			// ---- filter_redundant_coords per query (lqmap.c:287) ----

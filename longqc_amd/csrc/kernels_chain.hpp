@@ -139,23 +139,11 @@ __global__ void k_group_compact(const u64 *gstart, const u32 *flag, const u32 *i
 	if (flag[g]) { sel[idx[g]] = (u32)g; key[idx[g]] = 0xffffffffu - (u32)(gstart[g + 1] - gstart[g]); }
 }
 
-// aq_off: the batch's view of the per-query anchor offsets (n_q+1 entries, absolute; the batch's
-// anchors start at a_base); q0: global index of the batch's first query.
-__global__ void k_chain(const mm128 *A, const u64 *gstart, const u32 *glist, u32 n_list, const u64 *aq_off, u64 a_base, u32 n_q, u32 q0,
-                        const float *avg_qspan_q, MapParams P, ChainBufs B, CovState C)
+// One (strand, rid) run of a query: mm_chain_dp on a[0..n), then per chain mm_reg_set_coor and lq_cnt_match.
+// a, f, p, t, v, u may live in global memory (long runs) or in the calling thread's private arrays (short runs).
+__device__ __forceinline__ void lq_chain_run(const mm128 *a, const i64 n, i32 *f, i32 *p, i32 *t, i32 *v, u64 *u,
+                                             const u32 q, const bool accumulate, const float *avg_qspan_q, const MapParams &P, const CovState &C)
 {
-	u32 gi = blockIdx.x * blockDim.x + threadIdx.x;
-	if (gi >= n_list) return;
-	const u32 g = glist ? glist[gi] : gi;
-	const u64 gs = gstart[g];
-	const i64 n = (i64)(gstart[g + 1] - gs);
-	if (n < P.min_cnt) return;
-	const u32 q = q0 + lq_find_seg(aq_off, n_q, gs + a_base);
-	const bool accumulate = !C.skip[q];
-	if (!accumulate && !C.dbg) return;
-	const mm128 *a = A + gs;
-	i32 *f = B.f + gs, *p = B.p + gs, *t = B.t + gs, *v = B.v + gs;
-	u64 *u = B.u + gs;
 	const float avg_qspan = avg_qspan_q[q];
 	const i32 max_dist = P.max_gap, bw = P.bw, max_skip = P.max_skip, min_sc = P.min_sc;
 	i64 st = 0;
@@ -286,6 +274,61 @@ __global__ void k_chain(const mm128 *A, const u64 *gstart, const u32 *glist, u32
 			}
 		}
 	}
+}
+
+// does the run have any chance to yield a chain?  A chain of c anchors scores at most the sum of their spans
+// (every step adds min(dq, dr, span) <= span minus a non-negative gap cost, chain.c:57-67), and chains below
+// min_sc are dropped (chain.c:86-101,119-121); so runs with fewer than min_cnt anchors or with a span total
+// below min_sc can be skipped without looking at them.
+__device__ __forceinline__ bool lq_run_viable(const mm128 *a, i64 n, const MapParams &P)
+{
+	if (n < P.min_cnt) return false;
+	if (n * 255 < P.min_sc) return false;
+	i64 tot = 0;
+	for (i64 i = 0; i < n && tot < P.min_sc; ++i) tot += (i64)(a[i].y >> 32 & 0xff);
+	return tot >= P.min_sc;
+}
+
+// aq_off: the batch's view of the per-query anchor offsets (n_q+1 entries, absolute; the batch's
+// anchors start at a_base); q0: global index of the batch's first query.
+// Long runs: one thread per run, DP state in global scratch (indexed like the anchors).
+__global__ void k_chain(const mm128 *A, const u64 *gstart, const u32 *glist, u32 n_list, const u64 *aq_off, u64 a_base, u32 n_q, u32 q0,
+                        const float *avg_qspan_q, MapParams P, ChainBufs B, CovState C, i32 min_len)
+{
+	u32 gi = blockIdx.x * blockDim.x + threadIdx.x;
+	if (gi >= n_list) return;
+	const u32 g = glist ? glist[gi] : gi;
+	const u64 gs = gstart[g];
+	const i64 n = (i64)(gstart[g + 1] - gs);
+	if (n < min_len) return;
+	if (!lq_run_viable(A + gs, n, P)) return;
+	const u32 q = q0 + lq_find_seg(aq_off, n_q, gs + a_base);
+	const bool accumulate = !C.skip[q];
+	if (!accumulate && !C.dbg) return;
+	lq_chain_run(A + gs, n, B.f + gs, B.p + gs, B.t + gs, B.v + gs, B.u + gs, q, accumulate, avg_qspan_q, P, C);
+}
+
+// Short runs (the bulk: chance hits put a handful of anchors on most (strand, target) pairs): one thread per run
+// with the anchors and the whole DP state in private arrays -- lane-interleaved scratch instead of 64 unrelated
+// global working sets per wave.
+#define LQ_CHAIN_SMALL 24
+__global__ void k_chain_small(const mm128 *A, const u64 *gstart, u64 n_groups, const u64 *aq_off, u64 a_base, u32 n_q, u32 q0,
+                              const float *avg_qspan_q, MapParams P, CovState C)
+{
+	u64 g = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+	if (g >= n_groups) return;
+	const u64 gs = gstart[g];
+	const i64 n = (i64)(gstart[g + 1] - gs);
+	if (n > LQ_CHAIN_SMALL) return;
+	if (!lq_run_viable(A + gs, n, P)) return;
+	const u32 q = q0 + lq_find_seg(aq_off, n_q, gs + a_base);
+	const bool accumulate = !C.skip[q];
+	if (!accumulate && !C.dbg) return;
+	mm128 la[LQ_CHAIN_SMALL];
+	i32 f[LQ_CHAIN_SMALL], p[LQ_CHAIN_SMALL], t[LQ_CHAIN_SMALL], v[LQ_CHAIN_SMALL];
+	u64 u[LQ_CHAIN_SMALL];
+	for (i64 i = 0; i < n; ++i) la[i] = A[gs + i];
+	lq_chain_run(la, n, f, p, t, v, u, q, accumulate, avg_qspan_q, P, C);
 }
 
 // ---- filter_redundant_coords (lqmap.c:25-100), one thread per query, on this part's intervals ----

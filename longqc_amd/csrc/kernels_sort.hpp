@@ -195,37 +195,62 @@ __global__ void k_walk_keys(const SortSeg *segs, const u32 *walk_list, u32 n_wal
 }
 
 // ---- general pass: the token walk over digit bytes ---------------------------------------------
+// Lane-per-sub-array form (used for sub-arrays too long for the LDS window below): 64 independent walks per
+// wave.  What bounds it is the latency of scattered memory operations inside the serial chain, so:
+//  * each bucket keeps, next to its cursor, the aligned 4-byte word of digits that contains the cursor position
+//    ([256][64] u32 each, lane-minor): the digit stream of a bucket is contiguous, hence only every fourth
+//    visit of a bucket touches global memory for its digit;
+//  * destinations are staged in LDS and written out every LQ_WALK_FLUSH trips by all lanes together: on gfx9
+//    stores share vmcnt with loads, so a store issued every trip would put its acknowledgement latency in
+//    front of every digit refill.
 #define LQ_WALK_LANES 64
+#define LQ_WALK_FLUSH 8
 __global__ void __launch_bounds__(LQ_WALK_LANES)
 k_sort_walk(const SortSeg *segs, const u32 *walk_list, u32 n_walk, const u8 *D, const u32 *hist, const u32 *begs, u32 *dst)
 {
 	LQ_SHARED u32 nxt[256][LQ_WALK_LANES];
+	LQ_SHARED u32 wrd[256][LQ_WALK_LANES];
+	LQ_SHARED u32 sq_src[LQ_WALK_FLUSH][LQ_WALK_LANES];
+	LQ_SHARED u32 sq_dst[LQ_WALK_FLUSH][LQ_WALK_LANES];
 	const u32 lane = threadIdx.x;
 	for (u64 wi = (u64)blockIdx.x * LQ_WALK_LANES + lane; wi < n_walk; wi += (u64)gridDim.x * LQ_WALK_LANES) {
 		const u32 sgi = walk_list[wi];
 		const SortSeg sg = segs[sgi];
 		const u32 *cnt = hist + (u64)sgi * 256, *bg = begs + (u64)sgi * 256;
-		for (int c = 0; c < 256; ++c) nxt[c][lane] = bg[c];
-		const u8 *d = D + sg.off;
+		const u64 base = sg.off;                              // D is 4-byte aligned; digits of this sub-array start at D[base]
+		for (int c = 0; c < 256; ++c) {
+			const u32 b = bg[c];
+			nxt[c][lane] = b;
+			wrd[c][lane] = *(const u32*)(D + ((base + b) & ~(u64)3));
+		}
 		u32 *ds = dst + sg.off;
-		// Flat form of the walk: every loop trip takes exactly one element, so the 64 lanes of the wave (64
+		// Flat form of the walk: every loop trip takes at most one element, so the 64 lanes of the wave (64
 		// different sub-arrays) advance in lockstep instead of waiting for each other's cycles to close.
-		u32 k = 0, endk = bg[0] + cnt[0], src = 0, l = 0;
-		bool carrying = false;
-		for (;;) {
+		u32 k = 0, endk = bg[0] + cnt[0], src = 0, l = 0, nq = 0, trip = 0;
+		bool carrying = false, alive = true;
+		while (alive) {
 			if (!carrying) {
 				while (k < 256 && nxt[k][lane] >= endk) { ++k; if (k < 256) endk = bg[k] + cnt[k]; }
-				if (k >= 256) break;
-				src = nxt[k][lane];                           // the hole this cycle leaves in bucket k
-				l = d[src];
-				carrying = true;
+				if (k >= 256) alive = false;
+				else {
+					src = nxt[k][lane];                       // the hole this cycle leaves in bucket k
+					l = (wrd[k][lane] >> (8 * (u32)((base + src) & 3))) & 0xff;
+					carrying = true;
+				}
 			} else {
-				const u32 t = nxt[l][lane]++;                 // slot the carried element takes; its occupant is carried on
-				ds[src] = t;
-				src = t;
-				l = d[t];
+				const u32 bl = l == k ? k : l;                // the bucket visited: l, or k itself when the cycle closes
+				const u32 t = nxt[bl][lane];                  // slot the carried element takes; its occupant is carried on
+				const u32 w = wrd[bl][lane];
+				sq_src[nq][lane] = src; sq_dst[nq][lane] = t; ++nq;
+				nxt[bl][lane] = t + 1;
+				if (l == k) carrying = false;                 // closed: the hole of bucket k is filled
+				else { src = t; l = (w >> (8 * (u32)((base + t) & 3))) & 0xff; }
+				if (((base + t + 1) & 3) == 0) wrd[bl][lane] = *(const u32*)(D + base + t + 1);   // next word of bl's digit stream
 			}
-			if (l == k) { ds[src] = nxt[k][lane]++; carrying = false; }
+			if (++trip == LQ_WALK_FLUSH || !alive) {          // same trip count in every lane of the wave: a uniform flush
+				for (u32 i = 0; i < nq; ++i) ds[sq_src[i][lane]] = sq_dst[i][lane];
+				nq = 0; trip = 0;
+			}
 		}
 	}
 }
