@@ -168,6 +168,20 @@ def main():
     if world > 1:
         barrier()
     if rank == 0:
+        # HBM traffic of the dominant kernel from the PMC passes of this workload, if they were collected
+        # (tools/gpu_round.sh -> profiles/*pmc_traffic.json; separate rocprofv3 --pmc runs, never inside a timed run)
+        if roof and not args.reads and not args.nsample:
+            import glob
+            for fn in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")), reverse=True):
+                try:
+                    kk = json.load(open(fn))["kernels"]
+                except Exception:
+                    continue
+                hit = [v for k, v in kk.items() if k.split("<")[0] == roof["kernel"].split("<")[0]]
+                if hit:
+                    roof["traffic"] = round(hit[0]["hbm_bytes_per_launch"] / 1e9, 3)
+                    roof["traffic_unit"] = "GB per launch (PMC: (2*FETCH_SIZE+WRITE_SIZE)*1024, %s)" % os.path.basename(fn)
+                    break
         line = {
             "metric": "Mbases/sec all-vs-all overlap coverage (sampleqc hot path)", "value": round(value, 3), "unit": "Mbases/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),

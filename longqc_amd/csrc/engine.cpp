@@ -509,15 +509,12 @@ void lqcov_handle::map_part(Part &pt)
 			cs.ivl = ivl.as<Ivl>(); cs.n_ivl = n_ivl.as<u32>(); cs.ivl_cap = ivl_cap;
 			cs.dbg = dbg ? dbg_chains.as<ChainRec>() : nullptr; cs.n_dbg = n_dbg.as<unsigned long long>(); cs.dbg_cap = dbg_cap;
 			if (n_groups > 0xfffffff0ULL) throw std::domain_error("too many anchor runs in one batch");
-			{	// short runs (<= LQ_CHAIN_SMALL anchors): private-array DP, one thread per run
-				StageTimer t(this, "k_chain_small", nA * 16);
-				LQ_LAUNCH(k_chain_small, nblk(n_groups, 64), 64, stream, dA, gstart.as<u64>(), n_groups, aqb, a_base, nqb, q0, avg_qspan.as<float>(), mp, cs);
-				check_launch();
-			}
-			{	// long runs: global-scratch DP, one thread per run (array order: the few long runs of a wave keep their
-				// working set in the CU's L1)
+			{	// one thread per run, in array order (most lanes retire at once; the few long runs of a wave then keep their
+				// working set in the CU's L1).  Measured alternatives that were slower on MI355X: a compacted longest-first
+				// work list (64 unrelated working sets per wave: 409 vs 292 ms at configs[1]) and private-array DP for short
+				// runs (k_chain_small: 147 + 208 ms).
 				StageTimer t(this, "k_chain", nA * 16);
-				LQ_LAUNCH(k_chain, nblk(n_groups, 64), 64, stream, dA, gstart.as<u64>(), (const u32*)nullptr, (u32)n_groups, aqb, a_base, nqb, q0, avg_qspan.as<float>(), mp, cb, cs, (i32)(LQ_CHAIN_SMALL + 1));
+				LQ_LAUNCH(k_chain, nblk(n_groups, 64), 64, stream, dA, gstart.as<u64>(), (const u32*)nullptr, (u32)n_groups, aqb, a_base, nqb, q0, avg_qspan.as<float>(), mp, cb, cs, (i32)P.min_cnt);
 				check_launch();
 			}
 			// ---- filter_redundant_coords per query (lqmap.c:287) ----

@@ -12,22 +12,7 @@ B="python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline"
 ( timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -o b -- $B 2>&1 | tail -3 ) > $GRAFT_REPO_ROOT/gpurun_out/rocprof.log 2>&1
 cp /tmp/prof/b_kernel_stats.csv $GRAFT_REPO_ROOT/gpurun_out/ 2>/dev/null
 for C in FETCH_SIZE WRITE_SIZE; do
-  ( timeout 600 rocprofv3 --pmc $C --kernel-trace --output-format csv -d /tmp/pmc_$C -o p -- $B --reads 20000 --nsample 2000 2>&1 | tail -3 ) > $GRAFT_REPO_ROOT/gpurun_out/pmc_$C.log 2>&1
-  ls -la /tmp/pmc_$C >> $GRAFT_REPO_ROOT/gpurun_out/pmc_$C.log 2>&1
-  python - "$C" <<'PY' >> $GRAFT_REPO_ROOT/gpurun_out/pmc_summary.txt 2>&1
-import csv, glob, sys, collections
-c = sys.argv[1]
-f = glob.glob('/tmp/pmc_%s/*counter_collection.csv' % c)
-if not f:
-    print(c, "no counter file"); sys.exit()
-agg = collections.defaultdict(lambda: [0.0, 0])
-for row in csv.DictReader(open(f[0])):
-    if row.get('Counter_Name') != c: continue
-    k = row['Kernel_Name'].split('(')[0][:60]
-    agg[k][0] += float(row['Counter_Value']); agg[k][1] += 1
-print("== %s: kernel, dispatches, sum, mean per dispatch (raw counter units)" % c)
-for k, (s, n) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:25]:
-    print("%-60s %6d %16.1f %14.1f" % (k, n, s, s / n))
-PY
+  ( timeout 600 rocprofv3 --pmc $C --kernel-trace --output-format csv -d /tmp/pmc_$C -o p -- $B 2>&1 | tail -3 ) > $GRAFT_REPO_ROOT/gpurun_out/pmc_$C.log 2>&1
 done
-cd $GRAFT_REPO_ROOT; tail -3 gpurun_out/pytest_gpu.log gpurun_out/smoke.log gpurun_out/bench.log; cat gpurun_out/pmc_summary.txt | head -60
+python $GRAFT_REPO_ROOT/tools/pmc_to_json.py /tmp/pmc_FETCH_SIZE /tmp/pmc_WRITE_SIZE $GRAFT_REPO_ROOT/gpurun_out/pmc_traffic.json "bench.py default (configs[1]: 50000 reads, 5000 queries), 4 steps" > $GRAFT_REPO_ROOT/gpurun_out/pmc_summary.txt 2>&1
+cd $GRAFT_REPO_ROOT; tail -3 gpurun_out/pytest_gpu.log gpurun_out/smoke.log gpurun_out/bench.log; cat gpurun_out/pmc_summary.txt | head -20
