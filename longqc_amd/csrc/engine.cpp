@@ -151,10 +151,16 @@ void lqcov_handle::sketch(ReadSetDev &rs, bool rid_in_y)
 		DBuf cnt, off;
 		cnt.ensure(nc * 4); off.ensure(nc * 8);
 		const u64 in_bytes = nc * (LQ_CHUNK_WORDS * 12);
+		// ring capacity 8 / 16 (LDS) or 256 (private), -H on/off: pick the instantiation
+#define LQ_SK_LAUNCH(RC, EM, HP, BS, ...) LQ_LAUNCH((k_sketch<RC, EM, HP>), nblk(nc, BS), BS, stream, rs.codes.as<u64>(), rs.amb.as<u32>(), rs.d_coff.as<u64>(), rs.d_len.as<u32>(), rs.n, nc, sp, (int)rid_in_y, __VA_ARGS__)
+#define LQ_SK_DISPATCH(EM, ...) do { \
+		if (P.w <= 8)       { if (P.hpc) LQ_SK_LAUNCH(8, EM, true, LQ_SK_BLOCK, __VA_ARGS__);   else LQ_SK_LAUNCH(8, EM, false, LQ_SK_BLOCK, __VA_ARGS__); } \
+		else if (P.w <= 16) { if (P.hpc) LQ_SK_LAUNCH(16, EM, true, LQ_SK_BLOCK, __VA_ARGS__);  else LQ_SK_LAUNCH(16, EM, false, LQ_SK_BLOCK, __VA_ARGS__); } \
+		else                { if (P.hpc) LQ_SK_LAUNCH(256, EM, true, 64, __VA_ARGS__);          else LQ_SK_LAUNCH(256, EM, false, 64, __VA_ARGS__); } \
+	} while (0)
 		{
 			StageTimer t(this, "k_sketch_count", in_bytes + nc * 4);
-			if (P.w <= 16) LQ_LAUNCH((k_sketch<16, false>), nblk(nc, 256), 256, stream, rs.codes.as<u64>(), rs.amb.as<u32>(), rs.d_coff.as<u64>(), rs.d_len.as<u32>(), rs.n, nc, sp, (int)rid_in_y, cnt.as<u32>(), (const u64*)nullptr, (u64*)nullptr, (u64*)nullptr);
-			else LQ_LAUNCH((k_sketch<256, false>), nblk(nc, 64), 64, stream, rs.codes.as<u64>(), rs.amb.as<u32>(), rs.d_coff.as<u64>(), rs.d_len.as<u32>(), rs.n, nc, sp, (int)rid_in_y, cnt.as<u32>(), (const u64*)nullptr, (u64*)nullptr, (u64*)nullptr);
+			LQ_SK_DISPATCH(false, cnt.as<u32>(), (const u64*)nullptr, (u64*)nullptr, (u64*)nullptr);
 			check_launch();
 		}
 		{ StageTimer t(this, "scan"); prim.exclusive_scan_u32_u64(cnt.as<u32>(), off.as<u64>(), nc); }
@@ -165,8 +171,7 @@ void lqcov_handle::sketch(ReadSetDev &rs, bool rid_in_y)
 		rs.mx.ensure(rs.n_mini * 8 + 8); rs.my.ensure(rs.n_mini * 8 + 8);
 		{
 			StageTimer t(this, "k_sketch_emit", in_bytes + nc * 8 + rs.n_mini * 16);
-			if (P.w <= 16) LQ_LAUNCH((k_sketch<16, true>), nblk(nc, 256), 256, stream, rs.codes.as<u64>(), rs.amb.as<u32>(), rs.d_coff.as<u64>(), rs.d_len.as<u32>(), rs.n, nc, sp, (int)rid_in_y, (u32*)nullptr, off.as<u64>(), rs.mx.as<u64>(), rs.my.as<u64>());
-			else LQ_LAUNCH((k_sketch<256, true>), nblk(nc, 64), 64, stream, rs.codes.as<u64>(), rs.amb.as<u32>(), rs.d_coff.as<u64>(), rs.d_len.as<u32>(), rs.n, nc, sp, (int)rid_in_y, (u32*)nullptr, off.as<u64>(), rs.mx.as<u64>(), rs.my.as<u64>());
+			LQ_SK_DISPATCH(true, (u32*)nullptr, off.as<u64>(), rs.mx.as<u64>(), rs.my.as<u64>());
 			check_launch();
 		}
 		LQ_LAUNCH(k_read_moff, nblk(rs.n + 1, 256), 256, stream, rs.d_coff.as<u64>(), off.as<u64>(), rs.n, nc, rs.n_mini, rs.moff.as<u64>());

@@ -95,20 +95,27 @@ struct ReadView {
 	}
 };
 
-template <int RCAP>
+// Ring (last w slots) and HPC run queue live outside the struct: in LDS, one column per thread (STRIDE = block
+// size, lane-minor, conflict-free while lanes are in step), or in a private array (STRIDE = 1) for w > 16.
+// (With the ring as a struct member the dynamic slot index sent it to scratch memory: rocprofv3 counted ~190 GB
+// of HBM traffic per launch for a kernel whose algorithmic traffic is 4.4 GB.)
+template <int STRIDE>
 struct SkState {
 	u64 fw, rv, best_x;
 	u32 best_y;
 	i32 l, slot, best_slot, span;
 	i32 rq_front, rq_count;
-	u64 rx[RCAP];
-	u32 ry[RCAP];
-	i32 rq[32];
+	u64 *rx;
+	u32 *ry;
+	i32 *rq;
+	__device__ __forceinline__ u64 &RX(int j) { return rx[j * STRIDE]; }
+	__device__ __forceinline__ u32 &RY(int j) { return ry[j * STRIDE]; }
+	__device__ __forceinline__ i32 &RQ(int j) { return rq[j * STRIDE]; }
 	__device__ __forceinline__ void reset(int w)
 	{
 		fw = rv = 0; best_x = LQ_U64MAX; best_y = 0xffffffffu;
 		l = slot = best_slot = span = 0; rq_front = rq_count = 0;
-		for (int j = 0; j < w; ++j) { rx[j] = LQ_U64MAX; ry[j] = 0xffffffffu; }
+		for (int j = 0; j < w; ++j) { RX(j) = LQ_U64MAX; RY(j) = 0xffffffffu; }
 	}
 };
 
@@ -128,17 +135,17 @@ __device__ __forceinline__ void sk_push(SkOut &o, bool live, u64 x, u32 y32)
 
 // One loop iteration of mm_sketch whose (last) base is at `pos` with code c (4 = ambiguous),
 // run = homopolymer run length (1 unless HPC).  Returns true if a ring slot was produced.
-template <int RCAP, bool EMIT>
-__device__ __forceinline__ bool sk_step(SkState<RCAP> &s, const SkParams &P, int c, u32 pos, int run, bool live, SkOut &o, bool &was_pal)
+template <int STRIDE, bool EMIT>
+__device__ __forceinline__ bool sk_step(SkState<STRIDE> &s, const SkParams &P, int c, u32 pos, int run, bool live, SkOut &o, bool &was_pal)
 {
 	const int w = P.w, k = P.k;
 	u64 cx = LQ_U64MAX; u32 cy = 0xffffffffu;
 	was_pal = false;
 	if (c < 4) {
 		if (P.hpc) {
-			s.rq[(s.rq_count++ + s.rq_front) & 0x1f] = run;
+			s.RQ((s.rq_count++ + s.rq_front) & 0x1f) = run;
 			s.span += run;
-			if (s.rq_count > k) { s.span -= s.rq[s.rq_front++]; s.rq_front &= 0x1f; --s.rq_count; }
+			if (s.rq_count > k) { s.span -= s.RQ(s.rq_front++); s.rq_front &= 0x1f; --s.rq_count; }
 		} else s.span = s.l + 1 < k ? s.l + 1 : k;
 		s.fw = (s.fw << 2 | (u64)c) & P.mask;
 		s.rv = (s.rv >> 2) | (3ULL ^ (u64)c) << P.shift1;
@@ -151,10 +158,10 @@ __device__ __forceinline__ bool sk_step(SkState<RCAP> &s, const SkParams &P, int
 		}
 	} else { s.l = 0; s.rq_count = s.rq_front = 0; s.span = 0; }   // sketch.c:114
 	const int slot = s.slot;
-	s.rx[slot] = cx; s.ry[slot] = cy;
+	s.RX(slot) = cx; s.RY(slot) = cy;
 	if (s.l == w + k - 1 && s.best_x != LQ_U64MAX) {              // sketch.c:116-121
-		for (int j = slot + 1; j < w; ++j) if (s.rx[j] == s.best_x && s.ry[j] != s.best_y) sk_push<EMIT>(o, live, s.rx[j], s.ry[j]);
-		for (int j = 0; j < slot; ++j)     if (s.rx[j] == s.best_x && s.ry[j] != s.best_y) sk_push<EMIT>(o, live, s.rx[j], s.ry[j]);
+		for (int j = slot + 1; j < w; ++j) if (s.RX(j) == s.best_x && s.RY(j) != s.best_y) sk_push<EMIT>(o, live, s.RX(j), s.RY(j));
+		for (int j = 0; j < slot; ++j)     if (s.RX(j) == s.best_x && s.RY(j) != s.best_y) sk_push<EMIT>(o, live, s.RX(j), s.RY(j));
 	}
 	if (cx <= s.best_x) {                                          // sketch.c:122-124
 		if (s.l >= w + k && s.best_x != LQ_U64MAX) sk_push<EMIT>(o, live, s.best_x, s.best_y);
@@ -162,11 +169,11 @@ __device__ __forceinline__ bool sk_step(SkState<RCAP> &s, const SkParams &P, int
 	} else if (slot == s.best_slot) {                              // sketch.c:125-137
 		if (s.l >= w + k - 1 && s.best_x != LQ_U64MAX) sk_push<EMIT>(o, live, s.best_x, s.best_y);
 		s.best_x = LQ_U64MAX;
-		for (int j = slot + 1; j < w; ++j) if (s.best_x >= s.rx[j]) { s.best_x = s.rx[j]; s.best_y = s.ry[j]; s.best_slot = j; }
-		for (int j = 0; j <= slot; ++j)    if (s.best_x >= s.rx[j]) { s.best_x = s.rx[j]; s.best_y = s.ry[j]; s.best_slot = j; }
+		for (int j = slot + 1; j < w; ++j) if (s.best_x >= s.RX(j)) { s.best_x = s.RX(j); s.best_y = s.RY(j); s.best_slot = j; }
+		for (int j = 0; j <= slot; ++j)    if (s.best_x >= s.RX(j)) { s.best_x = s.RX(j); s.best_y = s.RY(j); s.best_slot = j; }
 		if (s.l >= w + k - 1 && s.best_x != LQ_U64MAX) {
-			for (int j = slot + 1; j < w; ++j) if (s.rx[j] == s.best_x && s.ry[j] != s.best_y) sk_push<EMIT>(o, live, s.rx[j], s.ry[j]);
-			for (int j = 0; j <= slot; ++j)    if (s.rx[j] == s.best_x && s.ry[j] != s.best_y) sk_push<EMIT>(o, live, s.rx[j], s.ry[j]);
+			for (int j = slot + 1; j < w; ++j) if (s.RX(j) == s.best_x && s.RY(j) != s.best_y) sk_push<EMIT>(o, live, s.RX(j), s.RY(j));
+			for (int j = 0; j <= slot; ++j)    if (s.RX(j) == s.best_x && s.RY(j) != s.best_y) sk_push<EMIT>(o, live, s.RX(j), s.RY(j));
 		}
 	}
 	s.slot = slot + 1 == w ? 0 : slot + 1;
@@ -192,8 +199,8 @@ __device__ __forceinline__ void sk_fetch(ReadView &rv, const SkParams &P, u32 i,
 //     non-palindromic steps were seen (every threshold test on l then agrees with the true l);
 //   * the last w ring slots were all produced in that exact regime.
 // Otherwise the halo is widened (x4) until it reaches the read start, where the state is exact.
-template <int RCAP>
-__device__ __forceinline__ void sk_warm(SkState<RCAP> &s, ReadView &rv, const SkParams &P, u32 i0)
+template <int STRIDE>
+__device__ __forceinline__ void sk_warm(SkState<STRIDE> &s, ReadView &rv, const SkParams &P, u32 i0)
 {
 	u32 halo = 64;
 	SkOut none; none.n = 0; none.x = none.y = nullptr; none.y_hi = 0;
@@ -208,7 +215,7 @@ __device__ __forceinline__ void sk_warm(SkState<RCAP> &s, ReadView &rv, const Sk
 		while (i < i0) {
 			int c, run; u32 last; bool pal;
 			sk_fetch(rv, P, i, c, run, last);
-			bool slot = sk_step<RCAP, false>(s, P, c, last, run, false, none, pal);
+			bool slot = sk_step<STRIDE, false>(s, P, c, last, run, false, none, pal);
 			if (c >= 4) { lx = nk >= P.k; lsim = 0; ++exact_run; }   // an N slot is (MAX,MAX) whatever the history
 			else {
 				++nk;
@@ -227,10 +234,25 @@ __device__ __forceinline__ void sk_warm(SkState<RCAP> &s, ReadView &rv, const Sk
 }
 
 // count pass: cnt[g] = minimizers decided by chunk g;  emit pass: written at off[g]...
-template <int RCAP, bool EMIT>
+// RCAP <= 16: ring in LDS (block of LQ_SK_BLOCK threads); RCAP = 256: private ring, any w < 256.
+#define LQ_SK_BLOCK 256
+template <int RCAP, bool EMIT, bool HPC>
 __global__ void k_sketch(const u64 *codes, const u32 *amb, const u64 *coff, const u32 *rlen, u32 n_reads, u64 n_chunks,
                          SkParams P, int rid_in_y, u32 *cnt, const u64 *off, u64 *out_x, u64 *out_y)
 {
+	constexpr int STRIDE = RCAP <= 16 ? LQ_SK_BLOCK : 1;
+#ifdef LQ_EMU
+	static u64 s_rx[RCAP <= 16 ? RCAP : 1][LQ_SK_BLOCK];
+	static u32 s_ry[RCAP <= 16 ? RCAP : 1][LQ_SK_BLOCK];
+	static i32 s_rq[RCAP <= 16 && HPC ? 32 : 1][LQ_SK_BLOCK];
+#else
+	__shared__ u64 s_rx[RCAP <= 16 ? RCAP : 1][LQ_SK_BLOCK];
+	__shared__ u32 s_ry[RCAP <= 16 ? RCAP : 1][LQ_SK_BLOCK];
+	__shared__ i32 s_rq[RCAP <= 16 && HPC ? 32 : 1][LQ_SK_BLOCK];   // homopolymer run queue (sketch.c:39-58), -H only
+#endif
+	u64 p_rx[RCAP <= 16 ? 1 : RCAP];
+	u32 p_ry[RCAP <= 16 ? 1 : RCAP];
+	i32 p_rq[RCAP <= 16 ? 1 : 32];
 	u64 g = (u64)blockIdx.x * blockDim.x + threadIdx.x;
 	if (g >= n_chunks) return;
 	u32 r = lq_find_seg(coff, n_reads, g);
@@ -244,12 +266,14 @@ __global__ void k_sketch(const u64 *codes, const u32 *amb, const u64 *coff, cons
 	o.x = o.y = nullptr;
 	if (EMIT) { o.x = out_x + off[g]; o.y = out_y + off[g]; }
 	if (i < pos1) {
-		SkState<RCAP> s;
-		sk_warm<RCAP>(s, rv, P, i);
+		SkState<STRIDE> s;
+		if (RCAP <= 16) { s.rx = &s_rx[0][threadIdx.x]; s.ry = &s_ry[0][threadIdx.x]; s.rq = &s_rq[0][threadIdx.x]; }
+		else { s.rx = p_rx; s.ry = p_ry; s.rq = p_rq; }
+		sk_warm<STRIDE>(s, rv, P, i);
 		while (i < pos1) {
 			int c, run; u32 last; bool pal;
 			sk_fetch(rv, P, i, c, run, last);
-			sk_step<RCAP, EMIT>(s, P, c, last, run, true, o, pal);
+			sk_step<STRIDE, EMIT>(s, P, c, last, run, true, o, pal);
 			i = last + 1;
 		}
 		if (i >= len && s.best_x != LQ_U64MAX)                    // this thread ran the read's last iteration: sketch.c:140-141
