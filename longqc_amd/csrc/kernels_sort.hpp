@@ -196,133 +196,63 @@ __global__ void k_walk_keys(const SortSeg *segs, const u32 *walk_list, u32 n_wal
 
 // ---- general pass: the token walk over digit bytes ---------------------------------------------
 // Lane-per-sub-array form (used for sub-arrays too long for the LDS window below): 64 independent walks per
-// wave (= per block).  What bounds a walk is the latency inside its serial chain, so nothing in the chain
-// touches global memory:
-//  * per bucket, LDS holds the cursor (top bit: "refill in flight") and the aligned 4-byte word of digits that
-//    contains the cursor position ([256][64] u32 each, lane-minor);
-//  * when a cursor crosses into the next word, the lane issues an LDS-DMA load (global_load_lds_dword) of that
-//    word into ring[trip % R][lane] -- the landing row is wave-uniform, as the instruction requires -- and
-//    carries on; R trips later the word is moved to the bucket (s_waitcnt vmcnt(R-1): every trip issues exactly
-//    one DMA instruction, idle lanes re-read a cached address).  A bucket revisited while its refill is in
-//    flight drains the ring first (rare: same bucket of 256 within R trips at a word boundary);
-//  * destinations are staged in LDS and written out by all lanes together every LQ_WALK_FLUSH trips (on gfx9
-//    stores share vmcnt with loads; a store per trip would put its acknowledgement in front of every wait).
+// wave.  What bounds it is the latency of scattered memory operations inside the serial chain, so:
+//  * each bucket keeps, next to its cursor, the aligned 4-byte word of digits that contains the cursor position
+//    ([256][64] u32 each, lane-minor): the digit stream of a bucket is contiguous, hence only every fourth
+//    visit of a bucket touches global memory for its digit;
+//  * destinations are staged in LDS and written out every LQ_WALK_FLUSH trips by all lanes together: on gfx9
+//    stores share vmcnt with loads, so a store issued every trip would put its acknowledgement latency in
+//    front of every digit refill.
 #define LQ_WALK_LANES 64
 #define LQ_WALK_FLUSH 8
-#define LQ_WALK_RING 16
-#define LQ_PEND 0x80000000u
-#define LQ_NOBKT 0xffffffffu
-#ifdef LQ_EMU
-#define LQ_DMA_LOAD_U32(gptr, lds_row, lane) ((lds_row)[lane] = *(const u32*)(gptr))
-#define LQ_WAIT_VMCNT_RING() ((void)0)
-#define LQ_WAIT_VMCNT_0() ((void)0)
-#define LQ_RING_READ(p) (*(p))
-#else
-// Read of a DMA landing word after our own counted wait.  hipcc would put an s_waitcnt vmcnt(0) in front of an
-// ordinary read of the landing array (it cannot know how many younger DMAs may be in flight); the read is
-// therefore issued as inline asm with its own lgkmcnt wait.
-__device__ __forceinline__ u32 lq_ring_read(const u32 *p)
-{
-	u32 v;
-	const u32 a = (u32)(size_t)(__attribute__((address_space(3))) const void*)p;
-	asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(a) : "memory");
-	return v;
-}
-#define LQ_RING_READ(p) lq_ring_read(p)
-#define LQ_DMA_LOAD_U32(gptr, lds_row, lane) \
-	__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr), (__attribute__((address_space(3))) void*)(lds_row), 4, 0, 0)
-// gfx9 s_waitcnt immediate: vmcnt[3:0] | expcnt(7) << 4 | lgkmcnt(15) << 8 | vmcnt[5:4] << 14
-#define LQ_WAIT_VMCNT_RING() __builtin_amdgcn_s_waitcnt(((LQ_WALK_RING - 1) & 15) | (7 << 4) | (15 << 8) | (((LQ_WALK_RING - 1) >> 4) << 14))
-#define LQ_WAIT_VMCNT_0() __builtin_amdgcn_s_waitcnt(0 | (7 << 4) | (15 << 8))
-#endif
 __global__ void __launch_bounds__(LQ_WALK_LANES)
 k_sort_walk(const SortSeg *segs, const u32 *walk_list, u32 n_walk, const u8 *D, const u32 *hist, const u32 *begs, u32 *dst)
 {
 	LQ_SHARED u32 nxt[256][LQ_WALK_LANES];
 	LQ_SHARED u32 wrd[256][LQ_WALK_LANES];
-	LQ_SHARED u32 ring[LQ_WALK_RING][LQ_WALK_LANES];
-	LQ_SHARED u32 rbk[LQ_WALK_RING][LQ_WALK_LANES];
-	LQ_SHARED u32 rcur[LQ_WALK_RING][LQ_WALK_LANES];
 	LQ_SHARED u32 sq_src[LQ_WALK_FLUSH][LQ_WALK_LANES];
 	LQ_SHARED u32 sq_dst[LQ_WALK_FLUSH][LQ_WALK_LANES];
 	const u32 lane = threadIdx.x;
-	const u64 wi = (u64)blockIdx.x * LQ_WALK_LANES + lane;
-	bool alive = wi < n_walk;
-	const u32 sgi = alive ? walk_list[wi] : 0;
-	SortSeg sg; sg.off = 0; sg.len = 0; sg.shift = 0;
-	if (alive) sg = segs[sgi];
-	const u32 *cnt = hist + (u64)sgi * 256, *bg = begs + (u64)sgi * 256;
-	const u64 base = sg.off;                                  // D is 4-byte aligned; digits of this sub-array start at D[base]
-	const u8 *idle_addr = D + (base & ~(u64)3);
-	if (alive) {
+	for (u64 wi = (u64)blockIdx.x * LQ_WALK_LANES + lane; wi < n_walk; wi += (u64)gridDim.x * LQ_WALK_LANES) {
+		const u32 sgi = walk_list[wi];
+		const SortSeg sg = segs[sgi];
+		const u32 *cnt = hist + (u64)sgi * 256, *bg = begs + (u64)sgi * 256;
+		const u64 base = sg.off;                              // D is 4-byte aligned; digits of this sub-array start at D[base]
 		for (int c = 0; c < 256; ++c) {
 			const u32 b = bg[c];
 			nxt[c][lane] = b;
 			wrd[c][lane] = *(const u32*)(D + ((base + b) & ~(u64)3));
 		}
-	}
-	for (int r = 0; r < LQ_WALK_RING; ++r) rbk[r][lane] = LQ_NOBKT;
-	u32 *ds = dst + sg.off;
-	u32 k = 0, endk = alive ? bg[0] + cnt[0] : 0, src = 0, l = 0, nq = 0, trip = 0, slot = 0;
-	bool carrying = false;
-	// every lane of the wave runs the same number of trips (the wave ends when its last walk does)
-	for (;;) {
-#ifdef LQ_EMU
-		if (!alive) break;
-#else
-		if (!__any(alive)) break;
-#endif
-		// 1. the DMA that was issued into this ring row R trips ago has landed: hand its word to its bucket
-		LQ_WAIT_VMCNT_RING();
-		{
-			const u32 b0 = rbk[slot][lane];
-			if (b0 != LQ_NOBKT) { wrd[b0][lane] = LQ_RING_READ(&ring[slot][lane]); nxt[b0][lane] = rcur[slot][lane]; rbk[slot][lane] = LQ_NOBKT; }
-		}
-		// 2. one step of the walk (flat: START, CARRY and CLOSE take one trip each)
-		const u8 *refill = idle_addr;
-		u32 refill_bkt = LQ_NOBKT;
-		if (alive) {
+		u32 *ds = dst + sg.off;
+		// Flat form of the walk: every loop trip takes at most one element, so the 64 lanes of the wave (64
+		// different sub-arrays) advance in lockstep instead of waiting for each other's cycles to close.
+		u32 k = 0, endk = bg[0] + cnt[0], src = 0, l = 0, nq = 0, trip = 0;
+		bool carrying = false, alive = true;
+		while (alive) {
 			if (!carrying) {
-				while (k < 256 && (nxt[k][lane] & ~LQ_PEND) >= endk) { ++k; if (k < 256) endk = bg[k] + cnt[k]; }
+				while (k < 256 && nxt[k][lane] >= endk) { ++k; if (k < 256) endk = bg[k] + cnt[k]; }
 				if (k >= 256) alive = false;
-			}
-			if (alive) {
-				const u32 bl = carrying ? l : k;              // bucket visited this trip (l == k: the cycle closes)
-				u32 c = nxt[bl][lane];
-				if (c & LQ_PEND) {                            // its digit word is still in flight: drain the ring
-					LQ_WAIT_VMCNT_0();
-					for (int q = 0; q < LQ_WALK_RING; ++q)
-						if (rbk[q][lane] == bl) { wrd[bl][lane] = ring[q][lane]; rbk[q][lane] = LQ_NOBKT; }
-					c &= ~LQ_PEND;
+				else {
+					src = nxt[k][lane];                       // the hole this cycle leaves in bucket k
+					l = (wrd[k][lane] >> (8 * (u32)((base + src) & 3))) & 0xff;
+					carrying = true;
 				}
-				const u32 dg = (wrd[bl][lane] >> (8 * (u32)((base + c) & 3))) & 0xff;
-				if (!carrying) {                              // START: pick up the element under k's cursor, leaving a hole
-					src = c; l = dg; carrying = true;
-					nxt[bl][lane] = c;
-				} else {
-					sq_src[nq][lane] = src; sq_dst[nq][lane] = c; ++nq;   // the carried element takes slot c of bucket bl
-					if (l == k) carrying = false;             // closed: the hole of bucket k is filled
-					else { src = c; l = dg; }
-					if (((base + c + 1) & 3) == 0) {          // cursor enters the next digit word: fetch it asynchronously
-						refill = D + base + c + 1; refill_bkt = bl;
-						nxt[bl][lane] = (c + 1) | LQ_PEND;
-						rcur[slot][lane] = c + 1;             // the cursor cannot move before the word is committed
-					} else nxt[bl][lane] = c + 1;
-				}
+			} else {
+				const u32 bl = l == k ? k : l;                // the bucket visited: l, or k itself when the cycle closes
+				const u32 t = nxt[bl][lane];                  // slot the carried element takes; its occupant is carried on
+				const u32 w = wrd[bl][lane];
+				sq_src[nq][lane] = src; sq_dst[nq][lane] = t; ++nq;
+				nxt[bl][lane] = t + 1;
+				if (l == k) carrying = false;                 // closed: the hole of bucket k is filled
+				else { src = t; l = (w >> (8 * (u32)((base + t) & 3))) & 0xff; }
+				if (((base + t + 1) & 3) == 0) wrd[bl][lane] = *(const u32*)(D + base + t + 1);   // next word of bl's digit stream
 			}
-		}
-		// 3. exactly one LDS-DMA instruction per trip (idle lanes re-read a cached word)
-		rbk[slot][lane] = refill_bkt;
-		LQ_DMA_LOAD_U32(refill, &ring[slot][0], lane);
-		slot = slot + 1 == LQ_WALK_RING ? 0 : slot + 1;
-		// 4. uniform flush of the staged destinations
-		if (++trip == LQ_WALK_FLUSH) {
-			for (u32 i = 0; i < nq; ++i) ds[sq_src[i][lane]] = sq_dst[i][lane];
-			nq = 0; trip = 0;
+			if (++trip == LQ_WALK_FLUSH || !alive) {          // same trip count in every lane of the wave: a uniform flush
+				for (u32 i = 0; i < nq; ++i) ds[sq_src[i][lane]] = sq_dst[i][lane];
+				nq = 0; trip = 0;
+			}
 		}
 	}
-	for (u32 i = 0; i < nq; ++i) ds[sq_src[i][lane]] = sq_dst[i][lane];
-	LQ_WAIT_VMCNT_0();
 }
 
 // The same walk with the sub-array's digits staged in LDS: one block per sub-array; all threads load the
