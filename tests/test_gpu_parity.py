@@ -166,3 +166,10 @@ def test_gpu_two_ranks_share_the_device_exchange_accumulators(gpu_lib, tmp_path)
     out = str(tmp_path / "t.tsv")
     mp.spawn(M._worker, args=(2, M._free_port(), 100000, out, True), nprocs=2, join=True)
     assert open(out).read() == read_gz("adv_parts.table.gz")
+
+
+def test_gpu_in_memory_sampleqc_path(gpu_lib):
+    """longqc_amd.sampleqc.coverage_in_memory: subsample handed over in memory, input streamed in chunks, parts cut
+    by the reference's rule -- same table as the file-based reference run"""
+    import tests.test_sampleqc as S
+    S.check_in_memory_equals_file_path(gpu_lib)
