@@ -76,9 +76,13 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    # test hook for 1-GPU boxes: LQCOV_BENCH_ONE_DEVICE=1 puts every rank on cuda:0 and uses gloo (RCCL needs one GPU per rank)
+    one_dev = os.environ.get("LQCOV_BENCH_ONE_DEVICE") == "1"
+    if one_dev:
+        local = 0
     torch.cuda.set_device(local)
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group("gloo" if one_dev else "nccl", rank=rank, world_size=world)
 
     import dataclasses
     from longqc_amd import api, synth, multigpu
@@ -196,6 +200,8 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(T, Q, args.cpu_sample, max(50, args.cpu_sample // 10))
+        if one_dev:
+            line["note"] = "LQCOV_BENCH_ONE_DEVICE test mode: all ranks share cuda:0 over gloo; not a scaling measurement"
         print(json.dumps(line), flush=True)
     eng.close()
     if world > 1:

@@ -462,6 +462,7 @@ void lqcov_handle::map_part(Part &pt)
 								LQ_HIP_CHECK(hipMemcpyAsync(walk_list3.as<u32>() + o, wl + (u64)c * ns, (u64)cw[1 + c] * 4, hipMemcpyDeviceToDevice, stream));
 								o += cw[1 + c];
 							}
+							static const bool lane_walker = getenv("LQCOV_WALK") && !strcmp(getenv("LQCOV_WALK"), "lane");   // A/B knob
 							LQ_LAUNCH(k_walk_keys, nblk(n_long, 256), 256, stream, cur, walk_list3.as<u32>(), n_long, wkey.as<u32>()); check_launch();
 							prim.sort_pairs_u32_u32(wkey.as<u32>(), wkey2.as<u32>(), walk_list3.as<u32>(), walk_list2.as<u32>(), n_long);
 							// algorithmic bytes of a walk: one digit byte in, one 4-byte destination out per element
@@ -471,9 +472,15 @@ void lqcov_handle::map_part(Part &pt)
 								d2h(hk.data(), wkey2.as<u32>(), n_long, stream);
 								for (u32 v : hk) long_elems += 0xffffffffu - v;
 							}
-							StageTimer t(this, "k_sort_walk", long_elems * 5);
-							LQ_LAUNCH(k_sort_walk, nblk(n_long, LQ_WALK_LANES), LQ_WALK_LANES, stream, cur, walk_list2.as<u32>(), n_long, dD, dH, dBg, dDst);
-							check_launch();
+							if (lane_walker) {
+								StageTimer t(this, "k_sort_walk", long_elems * 5);
+								LQ_LAUNCH(k_sort_walk, nblk(n_long, LQ_WALK_LANES), LQ_WALK_LANES, stream, cur, walk_list2.as<u32>(), n_long, dD, dH, dBg, dDst);
+								check_launch();
+							} else {
+								StageTimer t(this, "k_sort_walk_solo", long_elems * 5);
+								LQ_LAUNCH(k_sort_walk_solo, n_long, 64, stream, cur, walk_list2.as<u32>(), n_long, dD, dH, dBg, dDst);
+								check_launch();
+							}
 						}
 					}
 					if (n_walk || n_two) {

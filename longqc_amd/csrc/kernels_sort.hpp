@@ -313,6 +313,87 @@ __global__ void k_sort_walk_lds(const SortSeg *segs, const u32 *list, u32 n_list
 	}
 }
 
+// ---- general pass, long sub-arrays: one walker per wave ("solo"), digit windows in LDS -------------------
+// A walk kernel ends when its longest walk ends (measured: 158k trips x ~2.4 us in the 64-walks-per-wave form,
+// where every trip waits for some lane's global digit load).  Here a wave runs ONE walk on lane 0: per bucket LDS
+// holds the cursor and a 16-byte window of the bucket's digit stream; when the cursor enters the next window,
+// lane 0 starts an LDS-DMA (global_load_lds_dwordx4 straight into that bucket's window -- with a single active
+// lane the wave-uniform LDS address the instruction needs is simply this lane's) and walks on; the window is only
+// waited for if the token returns to that bucket before the data has landed.  The serial chain of a trip is then
+// LDS-only.  ~6.5 KiB of LDS per walk lets ~24 walks share a CU.
+#define LQ_SOLO_FLUSH 16
+#ifdef LQ_EMU
+#define LQ_DMA_WIN16(gptr, ldsptr) memcpy((ldsptr), (gptr), 16)
+#define LQ_WAIT_VM0() ((void)0)
+#define LQ_LDS_U8(p) (*(p))
+#else
+#define LQ_DMA_WIN16(gptr, ldsptr) \
+	__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr), (__attribute__((address_space(3))) void*)(ldsptr), 16, 0, 0)
+#define LQ_WAIT_VM0() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+// digit read from a DMA-filled window after our own wait (an ordinary read would make hipcc wait for every DMA in flight)
+__device__ __forceinline__ u32 lq_lds_u8(const u8 *p)
+{
+	u32 v;
+	const u32 a = (u32)(size_t)(__attribute__((address_space(3))) const void*)p;
+	asm volatile("ds_read_u8 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(a) : "memory");
+	return v;
+}
+#define LQ_LDS_U8(p) lq_lds_u8(p)
+#endif
+#define LQ_SOLO_PEND 0x80000000u
+__global__ void __launch_bounds__(64)
+k_sort_walk_solo(const SortSeg *segs, const u32 *list, u32 n_list, const u8 *D, const u32 *hist, const u32 *begs, u32 *dst)
+{
+	LQ_SHARED __attribute__((aligned(16))) u8 win[256][16];
+	LQ_SHARED u32 cur[256];
+	LQ_SHARED u32 endb[256];
+	LQ_SHARED u32 sq_src[LQ_SOLO_FLUSH];
+	LQ_SHARED u32 sq_dst[LQ_SOLO_FLUSH];
+	if (blockIdx.x >= n_list) return;
+	const u32 sgi = list[blockIdx.x];
+	const SortSeg sg = segs[sgi];
+	const u32 *cnt = hist + (u64)sgi * 256, *bg = begs + (u64)sgi * 256;
+	const u64 base = sg.off;                                  // D is 16-byte aligned; this sub-array's digits start at D[base]
+	u32 *ds = dst + sg.off;
+	LQ_BLOCK_LOOP(t) {
+		for (u32 c = t; c < 256; c += blockDim.x) {
+			const u32 b = bg[c];
+			cur[c] = b; endb[c] = b + cnt[c];
+			const u8 *w = D + ((base + b) & ~(u64)15);
+			for (int i = 0; i < 16; ++i) win[c][i] = w[i];
+		}
+	}
+	LQ_BLOCK_SYNC();
+	if (threadIdx.x != 0) return;
+	u32 k = 0, src = 0, l = 0, nq = 0;
+	bool carrying = false;
+	for (;;) {
+		if (!carrying) {
+			while (k < 256 && (cur[k] & ~LQ_SOLO_PEND) >= endb[k]) ++k;
+			if (k >= 256) break;
+		}
+		const u32 b = carrying ? l : k;                       // bucket visited this trip (l == k: the cycle closes)
+		u32 c = cur[b];
+		if (c & LQ_SOLO_PEND) { LQ_WAIT_VM0(); c &= ~LQ_SOLO_PEND; }   // its window is still in flight
+		const u32 dg = LQ_LDS_U8(&win[b][(base + c) & 15]);
+		if (!carrying) {                                      // START: pick up the element under k's cursor, leaving a hole
+			src = c; l = dg; carrying = true;
+			cur[b] = c;
+		} else {
+			sq_src[nq] = src; sq_dst[nq] = c; ++nq;           // the carried element takes slot c of bucket b
+			if (l == k) carrying = false;                     // closed: the hole of bucket k is filled
+			else { src = c; l = dg; }
+			if (((base + c + 1) & 15) == 0) {                 // the cursor enters the next 16-digit window: fetch it asynchronously
+				LQ_DMA_WIN16(D + base + c + 1, &win[b][0]);
+				cur[b] = (c + 1) | LQ_SOLO_PEND;
+			} else cur[b] = c + 1;
+			if (nq == LQ_SOLO_FLUSH) { for (u32 i = 0; i < LQ_SOLO_FLUSH; ++i) ds[sq_src[i]] = sq_dst[i]; nq = 0; }
+		}
+	}
+	for (u32 i = 0; i < nq; ++i) ds[sq_src[i]] = sq_dst[i];
+	LQ_WAIT_VM0();
+}
+
 // one block per sub-array: A[dst[i]] = B[i]  (identity passes are skipped)
 __global__ void k_sort_scatter(const SortSeg *segs, const SegInfo *info, u32 n_segs, mm128 *A, const mm128 *B, const u32 *dst)
 {
