@@ -347,8 +347,6 @@ k_sort_walk_solo(const SortSeg *segs, const u32 *list, u32 n_list, const u8 *D, 
 	LQ_SHARED __attribute__((aligned(16))) u8 win[256][16];
 	LQ_SHARED u32 cur[256];
 	LQ_SHARED u32 endb[256];
-	LQ_SHARED u32 sq_src[LQ_SOLO_FLUSH];
-	LQ_SHARED u32 sq_dst[LQ_SOLO_FLUSH];
 	if (blockIdx.x >= n_list) return;
 	const u32 sgi = list[blockIdx.x];
 	const SortSeg sg = segs[sgi];
@@ -365,32 +363,35 @@ k_sort_walk_solo(const SortSeg *segs, const u32 *list, u32 n_list, const u8 *D, 
 	}
 	LQ_BLOCK_SYNC();
 	if (threadIdx.x != 0) return;
-	u32 k = 0, src = 0, l = 0, nq = 0;
-	bool carrying = false;
+	const u32 b15 = (u32)(base & 15);
+	u32 k = 0;
 	for (;;) {
-		if (!carrying) {
-			while (k < 256 && (cur[k] & ~LQ_SOLO_PEND) >= endb[k]) ++k;
-			if (k >= 256) break;
+		// START: next bucket with unread slots; the element under its cursor is picked up, leaving a hole there
+		while (k < 256 && (cur[k] & ~LQ_SOLO_PEND) >= endb[k]) ++k;
+		if (k >= 256) break;
+		u32 hole = cur[k];
+		if (hole & LQ_SOLO_PEND) { LQ_WAIT_VM0(); hole &= ~LQ_SOLO_PEND; cur[k] = hole; }
+		u32 src = hole;
+		u32 l = LQ_LDS_U8(&win[k][(b15 + hole) & 15]);
+		// CARRY: the carried element takes the slot under its bucket's cursor; that slot's occupant is carried on
+		while (l != k) {
+			u32 c = cur[l];
+			if (c & LQ_SOLO_PEND) { LQ_WAIT_VM0(); c &= ~LQ_SOLO_PEND; }   // l's window is still in flight
+			const u32 dg = LQ_LDS_U8(&win[l][(b15 + c) & 15]);
+			ds[src] = c;
+			if (((b15 + c + 1) & 15) == 0) {                  // the cursor enters the next 16-digit window: fetch it asynchronously
+				LQ_DMA_WIN16(D + base + c + 1, &win[l][0]);
+				cur[l] = (c + 1) | LQ_SOLO_PEND;
+			} else cur[l] = c + 1;
+			src = c; l = dg;
 		}
-		const u32 b = carrying ? l : k;                       // bucket visited this trip (l == k: the cycle closes)
-		u32 c = cur[b];
-		if (c & LQ_SOLO_PEND) { LQ_WAIT_VM0(); c &= ~LQ_SOLO_PEND; }   // its window is still in flight
-		const u32 dg = LQ_LDS_U8(&win[b][(base + c) & 15]);
-		if (!carrying) {                                      // START: pick up the element under k's cursor, leaving a hole
-			src = c; l = dg; carrying = true;
-			cur[b] = c;
-		} else {
-			sq_src[nq] = src; sq_dst[nq] = c; ++nq;           // the carried element takes slot c of bucket b
-			if (l == k) carrying = false;                     // closed: the hole of bucket k is filled
-			else { src = c; l = dg; }
-			if (((base + c + 1) & 15) == 0) {                 // the cursor enters the next 16-digit window: fetch it asynchronously
-				LQ_DMA_WIN16(D + base + c + 1, &win[b][0]);
-				cur[b] = (c + 1) | LQ_SOLO_PEND;
-			} else cur[b] = c + 1;
-			if (nq == LQ_SOLO_FLUSH) { for (u32 i = 0; i < LQ_SOLO_FLUSH; ++i) ds[sq_src[i]] = sq_dst[i]; nq = 0; }
-		}
+		// CLOSE: the hole of bucket k is filled
+		ds[src] = hole;
+		if (((b15 + hole + 1) & 15) == 0) {
+			LQ_DMA_WIN16(D + base + hole + 1, &win[k][0]);
+			cur[k] = (hole + 1) | LQ_SOLO_PEND;
+		} else cur[k] = hole + 1;
 	}
-	for (u32 i = 0; i < nq; ++i) ds[sq_src[i]] = sq_dst[i];
 	LQ_WAIT_VM0();
 }
 
