@@ -462,7 +462,7 @@ void lqcov_handle::map_part(Part &pt)
 								LQ_HIP_CHECK(hipMemcpyAsync(walk_list3.as<u32>() + o, wl + (u64)c * ns, (u64)cw[1 + c] * 4, hipMemcpyDeviceToDevice, stream));
 								o += cw[1 + c];
 							}
-							static const bool lane_walker = getenv("LQCOV_WALK") && !strcmp(getenv("LQCOV_WALK"), "lane");   // A/B knob
+							const bool lane_walker = getenv("LQCOV_WALK") && !strcmp(getenv("LQCOV_WALK"), "lane");   // A/B knob
 							LQ_LAUNCH(k_walk_keys, nblk(n_long, 256), 256, stream, cur, walk_list3.as<u32>(), n_long, wkey.as<u32>()); check_launch();
 							prim.sort_pairs_u32_u32(wkey.as<u32>(), wkey2.as<u32>(), walk_list3.as<u32>(), walk_list2.as<u32>(), n_long);
 							// algorithmic bytes of a walk: one digit byte in, one 4-byte destination out per element
@@ -521,13 +521,29 @@ void lqcov_handle::map_part(Part &pt)
 			cs.ivl = ivl.as<Ivl>(); cs.n_ivl = n_ivl.as<u32>(); cs.ivl_cap = ivl_cap;
 			cs.dbg = dbg ? dbg_chains.as<ChainRec>() : nullptr; cs.n_dbg = n_dbg.as<unsigned long long>(); cs.dbg_cap = dbg_cap;
 			if (n_groups > 0xfffffff0ULL) throw std::domain_error("too many anchor runs in one batch");
-			{	// one thread per run, in array order (most lanes retire at once; the few long runs of a wave then keep their
-				// working set in the CU's L1).  Measured alternatives that were slower on MI355X: a compacted longest-first
-				// work list (64 unrelated working sets per wave: 409 vs 292 ms at configs[1]) and private-array DP for short
-				// runs (k_chain_small: 147 + 208 ms).
+			const int wave_min = getenv("LQCOV_CHAIN_WAVE_MIN") ? std::max(1, atoi(getenv("LQCOV_CHAIN_WAVE_MIN"))) : LQ_CHAIN_WAVE_MIN;   // test knob
+			{	// one thread per run, in array order (most lanes retire at once; the few longer runs of a wave then keep
+				// their working set in the CU's L1).  Measured alternatives that were slower on MI355X: a compacted
+				// longest-first work list for all runs (409 vs 292 ms at configs[1]) and private-array DP for short runs.
 				StageTimer t(this, "k_chain", nA * 16);
-				LQ_LAUNCH(k_chain, nblk(n_groups, 64), 64, stream, dA, gstart.as<u64>(), (const u32*)nullptr, (u32)n_groups, aqb, a_base, nqb, q0, avg_qspan.as<float>(), mp, cb, cs, (i32)P.min_cnt);
+				LQ_LAUNCH(k_chain, nblk(n_groups, 64), 64, stream, dA, gstart.as<u64>(), (const u32*)nullptr, (u32)n_groups, aqb, a_base, nqb, q0, avg_qspan.as<float>(), mp, cb, cs, (i32)P.min_cnt, (i32)(wave_min - 1));
 				check_launch();
+			}
+			{	// long runs (the tail of the kernel above if left there): one wave per run, longest first
+				gflag.ensure(n_groups * 4 + 4); gidx.ensure(n_groups * 4 + 4);
+				LQ_LAUNCH(k_group_flags, nblk(n_groups, 256), 256, stream, gstart.as<u64>(), n_groups, (i32)wave_min, gflag.as<u32>()); check_launch();
+				prim.exclusive_scan_u32_u32(gflag.as<u32>(), gidx.as<u32>(), n_groups);
+				u32 lgi = 0, lgf = 0;
+				d2h(&lgi, gidx.as<u32>() + n_groups - 1, 1, stream); d2h(&lgf, gflag.as<u32>() + n_groups - 1, 1, stream);
+				const u32 n_sel = lgi + lgf;
+				if (n_sel) {
+					gsel.ensure((u64)n_sel * 4); gkey.ensure((u64)n_sel * 4); gsel2.ensure((u64)n_sel * 4); gkey2.ensure((u64)n_sel * 4);
+					LQ_LAUNCH(k_group_compact, nblk(n_groups, 256), 256, stream, gstart.as<u64>(), gflag.as<u32>(), gidx.as<u32>(), n_groups, gsel.as<u32>(), gkey.as<u32>()); check_launch();
+					prim.sort_pairs_u32_u32(gkey.as<u32>(), gkey2.as<u32>(), gsel.as<u32>(), gsel2.as<u32>(), n_sel);
+					StageTimer t(this, "k_chain_wave", nA * 16);
+					LQ_LAUNCH(k_chain_wave, n_sel, 64, stream, dA, gstart.as<u64>(), gsel2.as<u32>(), n_sel, aqb, a_base, nqb, q0, avg_qspan.as<float>(), mp, cb, cs);
+					check_launch();
+				}
 			}
 			// ---- filter_redundant_coords per query (lqmap.c:287) ----
 			u32 ni = 0;

@@ -14,6 +14,7 @@
 #pragma once
 #include "lq_common.hpp"
 #include "kernels_sketch.hpp"
+#include "kernels_sort.hpp"   // LQ_BLOCK_LOOP / LQ_BLOCK_SYNC / LQ_SHARED
 
 __global__ void k_mark_qstart(const u64 *aq_off, u64 a_base, u32 n_q, u32 *head)
 {
@@ -139,13 +140,10 @@ __global__ void k_group_compact(const u64 *gstart, const u32 *flag, const u32 *i
 	if (flag[g]) { sel[idx[g]] = (u32)g; key[idx[g]] = 0xffffffffu - (u32)(gstart[g + 1] - gstart[g]); }
 }
 
-// One (strand, rid) run of a query: mm_chain_dp on a[0..n), then per chain mm_reg_set_coor and lq_cnt_match.
-// a, f, p, t, v, u may live in global memory (long runs) or in the calling thread's private arrays (short runs).
-__device__ __forceinline__ void lq_chain_run(const mm128 *a, const i64 n, i32 *f, i32 *p, i32 *t, i32 *v, u64 *u,
-                                             const u32 q, const bool accumulate, const float *avg_qspan_q, const MapParams &P, const CovState &C)
+// mm_chain_dp, first half (chain.c:41-81): scores f, predecessors p, peak scores v of one run, serially
+__device__ __forceinline__ void lq_chain_fill(const mm128 *a, const i64 n, i32 *f, i32 *p, i32 *t, i32 *v, const float avg_qspan, const MapParams &P)
 {
-	const float avg_qspan = avg_qspan_q[q];
-	const i32 max_dist = P.max_gap, bw = P.bw, max_skip = P.max_skip, min_sc = P.min_sc;
+	const i32 max_dist = P.max_gap, bw = P.bw, max_skip = P.max_skip;
 	i64 st = 0;
 	for (i64 i = 0; i < n; ++i) t[i] = 0;
 	// fill the score and backtrack arrays (chain.c:41-81).  Flat form: one candidate predecessor per loop trip,
@@ -192,6 +190,13 @@ __device__ __forceinline__ void lq_chain_run(const mm128 *a, const i64 n, i32 *f
 			}
 		}
 	}
+}
+
+// mm_chain_dp, second half (chain.c:84-137) + mm_reg_set_coor (hit.c:23-38) + lq_cnt_match (esterr.c:99-138)
+__device__ __forceinline__ void lq_chain_finish(const mm128 *a, const i64 n, i32 *f, i32 *p, i32 *t, i32 *v, u64 *u,
+                                                const u32 q, const bool accumulate, const MapParams &P, const CovState &C)
+{
+	const i32 min_sc = P.min_sc;
 	// chain ends (chain.c:84-101)
 	for (i64 i = 0; i < n; ++i) t[i] = 0;
 	for (i64 i = 0; i < n; ++i) if (p[i] >= 0) t[p[i]] = 1;
@@ -276,6 +281,15 @@ __device__ __forceinline__ void lq_chain_run(const mm128 *a, const i64 n, i32 *f
 	}
 }
 
+// One (strand, rid) run of a query: mm_chain_dp on a[0..n), then per chain mm_reg_set_coor and lq_cnt_match.
+// a, f, p, t, v, u may live in global memory (long runs) or in the calling thread's private arrays (short runs).
+__device__ __forceinline__ void lq_chain_run(const mm128 *a, const i64 n, i32 *f, i32 *p, i32 *t, i32 *v, u64 *u,
+                                             const u32 q, const bool accumulate, const float *avg_qspan_q, const MapParams &P, const CovState &C)
+{
+	lq_chain_fill(a, n, f, p, t, v, avg_qspan_q[q], P);
+	lq_chain_finish(a, n, f, p, t, v, u, q, accumulate, P, C);
+}
+
 // does the run have any chance to yield a chain?  A chain of c anchors scores at most the sum of their spans
 // (every step adds min(dq, dr, span) <= span minus a non-negative gap cost, chain.c:57-67), and chains below
 // min_sc are dropped (chain.c:86-101,119-121); so runs with fewer than min_cnt anchors or with a span total
@@ -293,19 +307,119 @@ __device__ __forceinline__ bool lq_run_viable(const mm128 *a, i64 n, const MapPa
 // anchors start at a_base); q0: global index of the batch's first query.
 // Long runs: one thread per run, DP state in global scratch (indexed like the anchors).
 __global__ void k_chain(const mm128 *A, const u64 *gstart, const u32 *glist, u32 n_list, const u64 *aq_off, u64 a_base, u32 n_q, u32 q0,
-                        const float *avg_qspan_q, MapParams P, ChainBufs B, CovState C, i32 min_len)
+                        const float *avg_qspan_q, MapParams P, ChainBufs B, CovState C, i32 min_len, i32 max_len)
 {
 	u32 gi = blockIdx.x * blockDim.x + threadIdx.x;
 	if (gi >= n_list) return;
 	const u32 g = glist ? glist[gi] : gi;
 	const u64 gs = gstart[g];
 	const i64 n = (i64)(gstart[g + 1] - gs);
-	if (n < min_len) return;
+	if (n < min_len || n > max_len) return;
 	if (!lq_run_viable(A + gs, n, P)) return;
 	const u32 q = q0 + lq_find_seg(aq_off, n_q, gs + a_base);
 	const bool accumulate = !C.skip[q];
 	if (!accumulate && !C.dbg) return;
 	lq_chain_run(A + gs, n, B.f + gs, B.p + gs, B.t + gs, B.v + gs, B.u + gs, q, accumulate, avg_qspan_q, P, C);
+}
+
+// Long runs, one wave per run.  A chain kernel ends when its longest run ends, and the serial DP of a repeat-rich
+// run (thousands of anchors, tens of candidate predecessors each, several dependent loads per candidate) is that
+// tail.  Here the 64 lanes score 64 candidate predecessors j = i-1, i-2, ... of anchor i at once (coalesced loads
+// of a[j], f[j], p[j]); the order-dependent part of chain.c:48-77 -- strict '>' keeps the nearest best, the skip
+// counter counts candidates that an already-scanned anchor chose as predecessor (t[j] == i), and the scan breaks
+// after max_skip of them -- is then replayed by lane 0 over the 64 results in scan order.  Marks t[p[j]] = i are
+// written for the whole chunk before the stamps are read: a mark can only concern a later-scanned candidate
+// (p[j] < j), and marks of candidates beyond the break are never looked at.  DP state stays in global memory;
+// __syncthreads() orders it inside the workgroup.  The second half (chain ends, backtrack, regs, coverage) is the
+// serial lq_chain_finish on lane 0.
+#define LQ_CHAIN_WAVE_MIN 192
+struct WaveCand { i32 sc, j, flags; };                      // flags: bit0 = passes the filters, bit1 = t[j] == i
+__global__ void __launch_bounds__(64)
+k_chain_wave(const mm128 *A, const u64 *gstart, const u32 *glist, u32 n_list, const u64 *aq_off, u64 a_base, u32 n_q, u32 q0,
+             const float *avg_qspan_q, MapParams P, ChainBufs B, CovState C)
+{
+	LQ_SHARED WaveCand cand[64];
+	LQ_SHARED i32 st_sh[4];                                  // [0] max_f, [1] max_j, [2] n_skip, [3] done
+	if (blockIdx.x >= n_list) return;
+#ifdef LQ_EMU
+	if (threadIdx.x != 0) return;                            // thread 0 plays every lane, phase by phase
+#endif
+	const u32 g = glist[blockIdx.x];
+	const u64 gs = gstart[g];
+	const i64 n = (i64)(gstart[g + 1] - gs);
+	const mm128 *a = A + gs;
+	if (!lq_run_viable(a, n, P)) return;
+	const u32 q = q0 + lq_find_seg(aq_off, n_q, gs + a_base);
+	const bool accumulate = !C.skip[q];
+	if (!accumulate && !C.dbg) return;
+	i32 *f = B.f + gs, *p = B.p + gs, *t = B.t + gs, *v = B.v + gs;
+	u64 *u = B.u + gs;
+	const float avg_qspan = avg_qspan_q[q];
+	const i32 max_dist = P.max_gap, bw = P.bw, max_skip = P.max_skip;
+	LQ_BLOCK_LOOP(ln) { for (i64 i = ln; i < n; i += blockDim.x) t[i] = 0; }
+	LQ_BLOCK_SYNC();
+	i64 st = 0;
+	for (i64 i = 0; i < n; ++i) {
+		const u64 ri = a[i].x;
+		const i32 qi = (i32)a[i].y, q_span = (i32)(a[i].y >> 32 & 0xff);
+		while (st < i && ri - a[st].x > (u64)max_dist) ++st;    // uniform: every lane computes the same st
+		LQ_BLOCK_LOOP(ln) { if (ln == 0) { st_sh[0] = q_span; st_sh[1] = -1; st_sh[2] = 0; st_sh[3] = 0; } }
+		LQ_BLOCK_SYNC();
+		for (i64 top = i - 1; top >= st; top -= 64) {
+			// phase 1: 64 candidates in parallel
+			LQ_BLOCK_LOOP(ln) {
+				const i64 j = top - (i64)ln;
+				WaveCand c; c.sc = 0; c.j = (i32)j; c.flags = 0;
+				if (j >= st) {
+					const mm128 aj = a[j];
+					const i64 dr = (i64)(ri - aj.x);
+					const i32 dq = qi - (i32)aj.y;
+					if (!(dr == 0 || dq <= 0 || dq > max_dist)) {
+						const i32 dd = dr > dq ? (i32)(dr - dq) : (i32)(dq - dr);
+						if (dd <= bw) {
+							const i32 min_d = dq < dr ? dq : (i32)dr;
+							i32 sc = min_d > q_span ? q_span : min_d;
+							const i32 log_dd = dd ? lq_ilog2_32((u32)dd) : 0;
+							sc -= (i32)((double)dd * .01 * (double)avg_qspan) + (log_dd >> 1);     // chain.c:67
+							c.sc = sc + f[j];
+							c.flags = 1;
+							const i32 pj = p[j];
+							if (pj >= 0) t[pj] = (i32)i;                  // chain.c:76 (see the note on marks above)
+						}
+					}
+				}
+				cand[ln] = c;
+			}
+			LQ_BLOCK_SYNC();
+			LQ_BLOCK_LOOP(ln) { if (cand[ln].flags & 1) { if (t[cand[ln].j] == (i32)i) cand[ln].flags |= 2; } }
+			LQ_BLOCK_SYNC();
+			// phase 2: the scan order semantics, on lane 0
+			LQ_BLOCK_LOOP(ln) {
+				if (ln == 0) {
+					i32 max_f = st_sh[0], max_j = st_sh[1], n_skip = st_sh[2], done = 0;
+					const i64 cnt = top - st + 1 < 64 ? top - st + 1 : 64;
+					for (i64 c = 0; c < cnt; ++c) {
+						const WaveCand w = cand[c];
+						if (!(w.flags & 1)) continue;
+						if (w.sc > max_f) { max_f = w.sc; max_j = w.j; if (n_skip > 0) --n_skip; }
+						else if (w.flags & 2) { if (++n_skip > max_skip) { done = 1; break; } }      // chain.c:72-73
+					}
+					st_sh[0] = max_f; st_sh[1] = max_j; st_sh[2] = n_skip; st_sh[3] = done;
+				}
+			}
+			LQ_BLOCK_SYNC();
+			if (st_sh[3]) break;
+		}
+		LQ_BLOCK_LOOP(ln) {
+			if (ln == 0) {
+				const i32 max_f = st_sh[0], max_j = st_sh[1];
+				f[i] = max_f; p[i] = max_j;
+				v[i] = max_j >= 0 && v[max_j] > max_f ? v[max_j] : max_f;
+			}
+		}
+		LQ_BLOCK_SYNC();
+	}
+	LQ_BLOCK_LOOP(ln) { if (ln == 0) lq_chain_finish(a, n, f, p, t, v, u, q, accumulate, P, C); }
 }
 
 // Short runs (the bulk: chance hits put a handful of anchors on most (strand, target) pairs): one thread per run

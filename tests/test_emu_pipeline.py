@@ -153,3 +153,12 @@ def test_emulated_every_walk_size_class(emu_lib, datasets, monkeypatch, shift):
     rc, out, err = run_main(emu_lib, argv)
     assert rc == 0, err
     assert out == want
+
+
+@pytest.mark.parametrize("case", [c for c in _cases("table") if c["name"] in ("tiny_ont", "adv_ont", "adv_parts", "tiny_spike")], ids=lambda c: c["name"])
+def test_emulated_wave_chain_kernel_on_every_run(emu_lib, case, monkeypatch):
+    """LQCOV_CHAIN_WAVE_MIN=3 sends every viable run through the cooperative (64 candidates per step) chain kernel"""
+    monkeypatch.setenv("LQCOV_CHAIN_WAVE_MIN", "3")
+    rc, out, err = run_main(emu_lib, case["argv"], cwd=GOLDEN)
+    assert rc == 0, err
+    assert out == read_gz(case["expect"])

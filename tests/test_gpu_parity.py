@@ -173,3 +173,21 @@ def test_gpu_in_memory_sampleqc_path(gpu_lib):
     by the reference's rule -- same table as the file-based reference run"""
     import tests.test_sampleqc as S
     S.check_in_memory_equals_file_path(gpu_lib)
+
+
+@pytest.mark.parametrize("case", [c for c in _cases("table") if c["name"] in ("tiny_ont", "adv_ont", "adv_parts", "tiny_spike")], ids=lambda c: c["name"])
+def test_gpu_wave_chain_kernel_on_every_run(gpu_lib, case, monkeypatch):
+    E.test_emulated_wave_chain_kernel_on_every_run(gpu_lib, case, monkeypatch)
+
+
+def test_gpu_wave_chain_and_lane_walker_variants_on_cfg1(gpu_lib, datasets, monkeypatch):
+    """cfg1 in 1-Mbase parts (the klib-order-sensitive case) with every run in the cooperative chain kernel and the
+    lane walker instead of the solo walker"""
+    tf, qf = datasets("cfg1")
+    argv = ["-Y", "-l", "0", "-q", "160", "-k", "12", "-w", "5", "-I", "1M", "-p", "160", tf, qf]
+    want = oracle_bind.table(argv)
+    monkeypatch.setenv("LQCOV_CHAIN_WAVE_MIN", "3")
+    monkeypatch.setenv("LQCOV_WALK", "lane")
+    rc, out, err = run_main(gpu_lib, argv)
+    assert rc == 0, err
+    assert out == want
