@@ -522,11 +522,17 @@ void lqcov_handle::map_part(Part &pt)
 			cs.dbg = dbg ? dbg_chains.as<ChainRec>() : nullptr; cs.n_dbg = n_dbg.as<unsigned long long>(); cs.dbg_cap = dbg_cap;
 			if (n_groups > 0xfffffff0ULL) throw std::domain_error("too many anchor runs in one batch");
 			const int wave_min = getenv("LQCOV_CHAIN_WAVE_MIN") ? std::max(1, atoi(getenv("LQCOV_CHAIN_WAVE_MIN"))) : LQ_CHAIN_WAVE_MIN;   // test knob
+			const int small_max = getenv("LQCOV_CHAIN_SMALL") && !atoi(getenv("LQCOV_CHAIN_SMALL")) ? 0 : std::min<int>(LQ_CHAIN_SMALL, wave_min - 1);   // A/B knob
 			{	// one thread per run, in array order (most lanes retire at once; the few longer runs of a wave then keep
 				// their working set in the CU's L1).  Measured alternatives that were slower on MI355X: a compacted
 				// longest-first work list for all runs (409 vs 292 ms at configs[1]) and private-array DP for short runs.
 				StageTimer t(this, "k_chain", nA * 16);
-				LQ_LAUNCH(k_chain, nblk(n_groups, 64), 64, stream, dA, gstart.as<u64>(), (const u32*)nullptr, (u32)n_groups, aqb, a_base, nqb, q0, avg_qspan.as<float>(), mp, cb, cs, (i32)P.min_cnt, (i32)(wave_min - 1));
+				LQ_LAUNCH(k_chain, nblk(n_groups, 64), 64, stream, dA, gstart.as<u64>(), (const u32*)nullptr, (u32)n_groups, aqb, a_base, nqb, q0, avg_qspan.as<float>(), mp, cb, cs, (i32)(small_max + 1), (i32)(wave_min - 1));
+				check_launch();
+			}
+			if (small_max >= P.min_cnt) {	// short runs: DP state in LDS
+				StageTimer t(this, "k_chain_small", nA * 16);
+				LQ_LAUNCH(k_chain_small, nblk(n_groups, 64), 64, stream, dA, gstart.as<u64>(), n_groups, aqb, a_base, nqb, q0, avg_qspan.as<float>(), mp, cs, (i32)small_max);
 				check_launch();
 			}
 			{	// long runs (the tail of the kernel above if left there): one wave per run, longest first

@@ -41,7 +41,8 @@ __global__ void k_group_starts(const u32 *head, const u64 *gid, u64 n, u64 n_gro
 
 __device__ __forceinline__ int lq_ilog2_32(u32 v) { return 31 - __clz(v); }   // chain.c:15-20 for v > 0
 
-__device__ __forceinline__ void lq_heapsort_u64(u64 *a, i64 n)
+template <class UP>
+__device__ __forceinline__ void lq_heapsort_u64(UP a, i64 n)
 {
 	if (n < 2) return;
 	for (i64 start = n / 2 - 1; start >= 0; --start) {
@@ -141,7 +142,8 @@ __global__ void k_group_compact(const u64 *gstart, const u32 *flag, const u32 *i
 }
 
 // mm_chain_dp, first half (chain.c:41-81): scores f, predecessors p, peak scores v of one run, serially
-__device__ __forceinline__ void lq_chain_fill(const mm128 *a, const i64 n, i32 *f, i32 *p, i32 *t, i32 *v, const float avg_qspan, const MapParams &P)
+template <class AP, class IP>
+__device__ __forceinline__ void lq_chain_fill(AP a, const i64 n, IP f, IP p, IP t, IP v, const float avg_qspan, const MapParams &P)
 {
 	const i32 max_dist = P.max_gap, bw = P.bw, max_skip = P.max_skip;
 	i64 st = 0;
@@ -193,7 +195,8 @@ __device__ __forceinline__ void lq_chain_fill(const mm128 *a, const i64 n, i32 *
 }
 
 // mm_chain_dp, second half (chain.c:84-137) + mm_reg_set_coor (hit.c:23-38) + lq_cnt_match (esterr.c:99-138)
-__device__ __forceinline__ void lq_chain_finish(const mm128 *a, const i64 n, i32 *f, i32 *p, i32 *t, i32 *v, u64 *u,
+template <class AP, class IP, class UP>
+__device__ __forceinline__ void lq_chain_finish(AP a, const i64 n, IP f, IP p, IP t, IP v, UP u,
                                                 const u32 q, const bool accumulate, const MapParams &P, const CovState &C)
 {
 	const i32 min_sc = P.min_sc;
@@ -283,7 +286,8 @@ __device__ __forceinline__ void lq_chain_finish(const mm128 *a, const i64 n, i32
 
 // One (strand, rid) run of a query: mm_chain_dp on a[0..n), then per chain mm_reg_set_coor and lq_cnt_match.
 // a, f, p, t, v, u may live in global memory (long runs) or in the calling thread's private arrays (short runs).
-__device__ __forceinline__ void lq_chain_run(const mm128 *a, const i64 n, i32 *f, i32 *p, i32 *t, i32 *v, u64 *u,
+template <class AP, class IP, class UP>
+__device__ __forceinline__ void lq_chain_run(AP a, const i64 n, IP f, IP p, IP t, IP v, UP u,
                                              const u32 q, const bool accumulate, const float *avg_qspan_q, const MapParams &P, const CovState &C)
 {
 	lq_chain_fill(a, n, f, p, t, v, avg_qspan_q[q], P);
@@ -294,7 +298,8 @@ __device__ __forceinline__ void lq_chain_run(const mm128 *a, const i64 n, i32 *f
 // (every step adds min(dq, dr, span) <= span minus a non-negative gap cost, chain.c:57-67), and chains below
 // min_sc are dropped (chain.c:86-101,119-121); so runs with fewer than min_cnt anchors or with a span total
 // below min_sc can be skipped without looking at them.
-__device__ __forceinline__ bool lq_run_viable(const mm128 *a, i64 n, const MapParams &P)
+template <class AP>
+__device__ __forceinline__ bool lq_run_viable(AP a, i64 n, const MapParams &P)
 {
 	if (n < P.min_cnt) return false;
 	if (n * 255 < P.min_sc) return false;
@@ -332,7 +337,7 @@ __global__ void k_chain(const mm128 *A, const u64 *gstart, const u32 *glist, u32
 // (p[j] < j), and marks of candidates beyond the break are never looked at.  DP state stays in global memory;
 // __syncthreads() orders it inside the workgroup.  The second half (chain ends, backtrack, regs, coverage) is the
 // serial lq_chain_finish on lane 0.
-#define LQ_CHAIN_WAVE_MIN 192
+#define LQ_CHAIN_WAVE_MIN 48      // measured on MI355X at configs[1]: 192 -> 206 ms, 96 -> 193, 48 -> 184, 24 -> 197 (k_chain + k_chain_wave)
 struct WaveCand { i32 sc, j, flags; };                      // flags: bit0 = passes the filters, bit1 = t[j] == i
 __global__ void __launch_bounds__(64)
 k_chain_wave(const mm128 *A, const u64 *gstart, const u32 *glist, u32 n_list, const u64 *aq_off, u64 a_base, u32 n_q, u32 q0,
@@ -423,24 +428,33 @@ k_chain_wave(const mm128 *A, const u64 *gstart, const u32 *glist, u32 n_list, co
 }
 
 // Short runs (the bulk: chance hits put a handful of anchors on most (strand, target) pairs): one thread per run
-// with the anchors and the whole DP state in private arrays -- lane-interleaved scratch instead of 64 unrelated
-// global working sets per wave.
-#define LQ_CHAIN_SMALL 24
-__global__ void k_chain_small(const mm128 *A, const u64 *gstart, u64 n_groups, const u64 *aq_off, u64 a_base, u32 n_q, u32 q0,
-                              const float *avg_qspan_q, MapParams P, CovState C)
+// with the anchors and the whole DP state in LDS, one column per lane ([slot][64], lane-minor) -- instead of 64
+// unrelated global working sets per wave (rocprofv3: k_chain wrote 51 GiB per launch for 12.6 GB of anchors).
+#define LQ_CHAIN_SMALL 16
+template <class T> struct LanePtr {                          // element i of this lane's column
+	T *b;
+	__device__ __forceinline__ T &operator[](i64 i) const { return b[i * 64]; }
+};
+__global__ void __launch_bounds__(64)
+k_chain_small(const mm128 *A, const u64 *gstart, u64 n_groups, const u64 *aq_off, u64 a_base, u32 n_q, u32 q0,
+              const float *avg_qspan_q, MapParams P, CovState C, i32 max_len)
 {
+	LQ_SHARED mm128 s_a[LQ_CHAIN_SMALL][64];
+	LQ_SHARED i32 s_f[LQ_CHAIN_SMALL][64], s_p[LQ_CHAIN_SMALL][64], s_t[LQ_CHAIN_SMALL][64], s_v[LQ_CHAIN_SMALL][64];
+	LQ_SHARED u64 s_u[LQ_CHAIN_SMALL][64];
 	u64 g = (u64)blockIdx.x * blockDim.x + threadIdx.x;
 	if (g >= n_groups) return;
 	const u64 gs = gstart[g];
 	const i64 n = (i64)(gstart[g + 1] - gs);
-	if (n > LQ_CHAIN_SMALL) return;
+	if (n > max_len || n > LQ_CHAIN_SMALL) return;
 	if (!lq_run_viable(A + gs, n, P)) return;
 	const u32 q = q0 + lq_find_seg(aq_off, n_q, gs + a_base);
 	const bool accumulate = !C.skip[q];
 	if (!accumulate && !C.dbg) return;
-	mm128 la[LQ_CHAIN_SMALL];
-	i32 f[LQ_CHAIN_SMALL], p[LQ_CHAIN_SMALL], t[LQ_CHAIN_SMALL], v[LQ_CHAIN_SMALL];
-	u64 u[LQ_CHAIN_SMALL];
+	const u32 ln = threadIdx.x;
+	LanePtr<mm128> la; la.b = &s_a[0][ln];
+	LanePtr<i32> f, p, t, v; f.b = &s_f[0][ln]; p.b = &s_p[0][ln]; t.b = &s_t[0][ln]; v.b = &s_v[0][ln];
+	LanePtr<u64> u; u.b = &s_u[0][ln];
 	for (i64 i = 0; i < n; ++i) la[i] = A[gs + i];
 	lq_chain_run(la, n, f, p, t, v, u, q, accumulate, avg_qspan_q, P, C);
 }
