@@ -522,7 +522,9 @@ void lqcov_handle::map_part(Part &pt)
 			cs.dbg = dbg ? dbg_chains.as<ChainRec>() : nullptr; cs.n_dbg = n_dbg.as<unsigned long long>(); cs.dbg_cap = dbg_cap;
 			if (n_groups > 0xfffffff0ULL) throw std::domain_error("too many anchor runs in one batch");
 			const int wave_min = getenv("LQCOV_CHAIN_WAVE_MIN") ? std::max(1, atoi(getenv("LQCOV_CHAIN_WAVE_MIN"))) : LQ_CHAIN_WAVE_MIN;   // test knob
-			const int small_max = getenv("LQCOV_CHAIN_SMALL") && !atoi(getenv("LQCOV_CHAIN_SMALL")) ? 0 : std::min<int>(LQ_CHAIN_SMALL, wave_min - 1);   // A/B knob
+			// LDS-resident DP for runs <= 16 anchors: off by default -- measured slower on MI355X (54 KiB of LDS per 64 lanes caps
+			// occupancy at 3 waves per CU: 160 + 40 ms vs 113 ms for the global-scratch kernel at configs[1]); LQCOV_CHAIN_SMALL=1 enables
+			const int small_max = getenv("LQCOV_CHAIN_SMALL") && atoi(getenv("LQCOV_CHAIN_SMALL")) ? std::min<int>(LQ_CHAIN_SMALL, wave_min - 1) : (int)P.min_cnt - 1;
 			{	// one thread per run, in array order (most lanes retire at once; the few longer runs of a wave then keep
 				// their working set in the CU's L1).  Measured alternatives that were slower on MI355X: a compacted
 				// longest-first work list for all runs (409 vs 292 ms at configs[1]) and private-array DP for short runs.
