@@ -326,6 +326,7 @@ __global__ void k_sort_walk_lds(const SortSeg *segs, const u32 *list, u32 n_list
 #define LQ_DMA_WIN16(gptr, ldsptr) memcpy((ldsptr), (gptr), 16)
 #define LQ_WAIT_VM0() ((void)0)
 #define LQ_LDS_U8(p) (*(p))
+#define LQ_LDS_U32(p) (*(const u32*)(p))
 #else
 #define LQ_DMA_WIN16(gptr, ldsptr) \
 	__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr), (__attribute__((address_space(3))) void*)(ldsptr), 16, 0, 0)
@@ -339,59 +340,71 @@ __device__ __forceinline__ u32 lq_lds_u8(const u8 *p)
 	return v;
 }
 #define LQ_LDS_U8(p) lq_lds_u8(p)
+__device__ __forceinline__ u32 lq_lds_u32(const u8 *p)
+{
+	u32 v;
+	const u32 a = (u32)(size_t)(__attribute__((address_space(3))) const void*)p;
+	asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(a) : "memory");
+	return v;
+}
+#define LQ_LDS_U32(p) lq_lds_u32(p)
 #endif
 #define LQ_SOLO_PEND 0x80000000u
 __global__ void __launch_bounds__(64)
 k_sort_walk_solo(const SortSeg *segs, const u32 *list, u32 n_list, const u8 *D, const u32 *hist, const u32 *begs, u32 *dst)
 {
-	LQ_SHARED __attribute__((aligned(16))) u8 win[256][16];
-	LQ_SHARED u32 cur[256];
+	LQ_SHARED __attribute__((aligned(16))) u8 win[256][16];   // DMA landing windows: 16 digits of each bucket's stream
+	LQ_SHARED u64 ent[256];                                   // low: cursor | PEND, high: the digits from the cursor to the next 4-byte boundary
 	LQ_SHARED u32 endb[256];
 	if (blockIdx.x >= n_list) return;
 	const u32 sgi = list[blockIdx.x];
 	const SortSeg sg = segs[sgi];
 	const u32 *cnt = hist + (u64)sgi * 256, *bg = begs + (u64)sgi * 256;
 	const u64 base = sg.off;                                  // D is 16-byte aligned; this sub-array's digits start at D[base]
+	const u32 b15 = (u32)(base & 15);
 	u32 *ds = dst + sg.off;
 	LQ_BLOCK_LOOP(t) {
 		for (u32 c = t; c < 256; c += blockDim.x) {
 			const u32 b = bg[c];
-			cur[c] = b; endb[c] = b + cnt[c];
+			endb[c] = b + cnt[c];
 			const u8 *w = D + ((base + b) & ~(u64)15);
 			for (int i = 0; i < 16; ++i) win[c][i] = w[i];
+			const u32 o = (b15 + b) & 15;
+			const u32 dq = (*(const u32*)(w + (o & ~3u))) >> (8 * (o & 3));
+			ent[c] = (u64)b | (u64)dq << 32;
 		}
 	}
 	LQ_BLOCK_SYNC();
 	if (threadIdx.x != 0) return;
-	const u32 b15 = (u32)(base & 15);
+	// One step over bucket `bk` whose entry is (c, dq): the slot under the cursor is taken; store the entry for cursor c+1.
+#define LQ_SOLO_ADVANCE(bk, c, dq) do { \
+		const u32 nc_ = (c) + 1, o_ = (b15 + nc_) & 15; \
+		if (o_ & 3) ent[bk] = (u64)nc_ | (u64)((dq) >> 8) << 32; \
+		else if (o_) ent[bk] = (u64)nc_ | (u64)LQ_LDS_U32(&win[bk][o_]) << 32; \
+		else { LQ_DMA_WIN16(D + base + nc_, &win[bk][0]); ent[bk] = (u64)(nc_ | LQ_SOLO_PEND); }   /* next window: fetch it asynchronously */ \
+	} while (0)
 	u32 k = 0;
 	for (;;) {
 		// START: next bucket with unread slots; the element under its cursor is picked up, leaving a hole there
-		while (k < 256 && (cur[k] & ~LQ_SOLO_PEND) >= endb[k]) ++k;
+		while (k < 256 && ((u32)ent[k] & ~LQ_SOLO_PEND) >= endb[k]) ++k;
 		if (k >= 256) break;
-		u32 hole = cur[k];
-		if (hole & LQ_SOLO_PEND) { LQ_WAIT_VM0(); hole &= ~LQ_SOLO_PEND; cur[k] = hole; }
-		u32 src = hole;
-		u32 l = LQ_LDS_U8(&win[k][(b15 + hole) & 15]);
+		u32 hole = (u32)ent[k], hdq = (u32)(ent[k] >> 32);
+		if (hole & LQ_SOLO_PEND) { LQ_WAIT_VM0(); hole &= ~LQ_SOLO_PEND; hdq = LQ_LDS_U32(&win[k][0]); }
+		u32 src = hole, l = hdq & 0xff;
 		// CARRY: the carried element takes the slot under its bucket's cursor; that slot's occupant is carried on
 		while (l != k) {
-			u32 c = cur[l];
-			if (c & LQ_SOLO_PEND) { LQ_WAIT_VM0(); c &= ~LQ_SOLO_PEND; }   // l's window is still in flight
-			const u32 dg = LQ_LDS_U8(&win[l][(b15 + c) & 15]);
+			const u64 e = ent[l];
+			u32 c = (u32)e, dq = (u32)(e >> 32);
+			if (c & LQ_SOLO_PEND) { LQ_WAIT_VM0(); c &= ~LQ_SOLO_PEND; dq = LQ_LDS_U32(&win[l][0]); }   // l's window was in flight
 			ds[src] = c;
-			if (((b15 + c + 1) & 15) == 0) {                  // the cursor enters the next 16-digit window: fetch it asynchronously
-				LQ_DMA_WIN16(D + base + c + 1, &win[l][0]);
-				cur[l] = (c + 1) | LQ_SOLO_PEND;
-			} else cur[l] = c + 1;
-			src = c; l = dg;
+			LQ_SOLO_ADVANCE(l, c, dq);
+			src = c; l = dq & 0xff;
 		}
 		// CLOSE: the hole of bucket k is filled
 		ds[src] = hole;
-		if (((b15 + hole + 1) & 15) == 0) {
-			LQ_DMA_WIN16(D + base + hole + 1, &win[k][0]);
-			cur[k] = (hole + 1) | LQ_SOLO_PEND;
-		} else cur[k] = hole + 1;
+		LQ_SOLO_ADVANCE(k, hole, hdq);
 	}
+#undef LQ_SOLO_ADVANCE
 	LQ_WAIT_VM0();
 }
 
