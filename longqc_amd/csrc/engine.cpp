@@ -31,16 +31,17 @@ static void dzero(void *p, size_t bytes, hipStream_t s) { if (bytes) LQ_HIP_CHEC
 static void check_launch() { LQ_HIP_CHECK(hipGetLastError()); }
 
 // ---- stage timing ---------------------------------------------------------------------------
-StageTimer::StageTimer(lqcov_handle *h_, const char *name_, u64 bytes_) : h(h_), name(name_), bytes(bytes_)
+StageTimer::StageTimer(lqcov_handle *h_, hipStream_t s_, const char *name_, u64 bytes_) : h(h_), s(s_), name(name_), bytes(bytes_)
 {
 	if (!h->profiling) return;
 	hipEventCreate(&a); hipEventCreate(&b);
-	hipEventRecord(a, h->stream);
+	hipEventRecord(a, s);
 }
+StageTimer::StageTimer(lqcov_handle *h_, const char *name_, u64 bytes_) : StageTimer(h_, h_->stream, name_, bytes_) {}
 StageTimer::~StageTimer()
 {
 	if (!h->profiling) return;
-	hipEventRecord(b, h->stream);
+	hipEventRecord(b, s);
 	hipEventSynchronize(b);
 	float ms = 0; hipEventElapsedTime(&ms, a, b);
 	hipEventDestroy(a); hipEventDestroy(b);
@@ -69,10 +70,12 @@ lqcov_handle::lqcov_handle(const lqcov_params &p, int dev) : P(p), device(dev)
 	mp.no_self = P.no_self; mp.ava = P.ava;
 	const char *e = getenv("LQCOV_ANCHOR_BUDGET");
 	anchor_budget = e ? strtoull(e, 0, 10) : 0;
+	const char *el = getenv("LQCOV_LANES");
+	n_lanes = el ? std::min(8, std::max(1, atoi(el))) : 2;
 	if (anchor_budget == 0) {
 		size_t fr = 0, tot = 0;
 		hipMemGetInfo(&fr, &tot);
-		anchor_budget = (u64)(fr / 2 / 128);               // ~128 B of work space per anchor, use half of free HBM
+		anchor_budget = (u64)(fr / 5 * 4 / 104 / n_lanes);  // ~61 B of work space per anchor + per-sub-array tables, 80% of free HBM
 	}
 	if (anchor_budget > (1ULL << 31)) anchor_budget = 1ULL << 31;
 	if (anchor_budget < 1024) anchor_budget = 1024;
@@ -80,6 +83,7 @@ lqcov_handle::lqcov_handle(const lqcov_params &p, int dev) : P(p), device(dev)
 
 lqcov_handle::~lqcov_handle()
 {
+	for (auto &L : lanes) if (L->stream) { hipStreamSynchronize(L->stream); hipStreamDestroy(L->stream); }
 	if (stream) { hipStreamSynchronize(stream); hipStreamDestroy(stream); }
 }
 
@@ -148,7 +152,7 @@ void lqcov_handle::sketch(ReadSetDev &rs, bool rid_in_y)
 	const u64 nc = rs.n_chunks;
 	if (nc) {
 		SkParams sp; sp.k = P.k; sp.w = P.w; sp.hpc = P.hpc; sp.mask = (1ULL << 2 * P.k) - 1; sp.shift1 = 2 * (P.k - 1);
-		DBuf cnt, off;
+		DBuf &cnt = sk_cnt, &off = sk_off;
 		cnt.ensure(nc * 4); off.ensure(nc * 8);
 		const u64 in_bytes = nc * (LQ_CHUNK_WORDS * 12);
 		// ring capacity 8 / 16 (LDS) or 256 (private), -H on/off: pick the instantiation
@@ -261,7 +265,7 @@ void lqcov_handle::build_index(Part &pt)
 	pt.n_keys = 0; pt.cap_bits = 4;
 	pt.pos.ensure(M * 8 + 8);
 	if (M) {
-		DBuf key, key2, head, uidx, ukey, ustart, ucnt;
+		DBuf &key = ix_key, &key2 = ix_key2, &head = ix_head, &uidx = ix_uidx, &ukey = ix_ukey, &ustart = ix_ustart, &ucnt = ix_ucnt;   // workspaces live with the handle: repeated builds do not re-allocate
 		key.ensure(M * 8); key2.ensure(M * 8); head.ensure(M * 4); uidx.ensure(M * 8);
 		LQ_LAUNCH(k_sort_keys, nblk(M, 256), 256, stream, rs.mx.as<u64>(), M, key.as<u64>()); check_launch();
 		{ StageTimer t(this, "index_radix_sort", M * 32); prim.sort_pairs_u64(key.as<u64>(), key2.as<u64>(), rs.my.as<u64>(), pt.pos.as<u64>(), M, (unsigned)(2 * P.k)); }
@@ -288,7 +292,7 @@ void lqcov_handle::build_index(Part &pt)
 		if (mid_occ <= 0) {                                   // map.c:50: from the first part only
 			if (P.mid_occ_frac <= 0.0f) mid_occ = INT32_MAX;
 			else {
-				DBuf sorted; sorted.ensure(K * 4);
+				DBuf &sorted = ix_sorted; sorted.ensure(K * 4);
 				prim.sort_keys_u32(ucnt.as<u32>(), sorted.as<u32>(), K);
 				const u32 kth = (u32)((1. - P.mid_occ_frac) * (double)K);   // index.c:141
 				u32 v = 0;
@@ -327,6 +331,217 @@ void lqcov_handle::build_part(Part &pt)
 	if (!have_queries) throw std::logic_error("set the queries before building a part");
 	sketch(pt.rs, true);
 	build_index(pt);
+}
+
+// one batch of queries [q0, q1) against one part, on lane L: seed emit -> klib-order sort -> chains -> per-query intervals
+void lqcov_handle::map_batch(MapLane &L, Part &pt, u32 q0, u32 q1, const std::vector<u64> &h_aq, const std::vector<u64> &h_qmoff, bool dbg)
+{
+	const u32 n_q = q.n;
+	L.n_segs.ensure(64); L.n_ivl.ensure(4);
+	const u64 a_base = h_aq[q0], nA = h_aq[q1] - a_base;
+	const u32 nqb = q1 - q0;
+	const u64 j0 = h_qmoff[q0], nj = h_qmoff[q1] - j0;
+	if (nA > 0xfffffff0ULL) throw std::domain_error("a single query produces more than 2^32 anchors against this part");
+	L.A.ensure((nA + 1) * 16); L.B.ensure((nA + 1) * 16);
+	mm128 *dA = L.A.as<mm128>(), *dB = L.B.as<mm128>();
+	// 24 B per anchor of scratch with two lives: the six u32 arrays of the two-bucket passes during the sort, then the run
+	// heads / ids and the chain's u[] afterwards.  The chain's f/p/t/v (16 B per anchor) reuse B, which is dead once sorted.
+	const u64 nA4 = ((nA + 1) * 4 + 15) & ~(u64)15;
+	L.scr.ensure(nA4 * 6 + 64);
+	u32 *fx = (u32*)L.scr.p, *fy = (u32*)((u8*)L.scr.p + nA4), *sx = (u32*)((u8*)L.scr.p + 2 * nA4), *sy = (u32*)((u8*)L.scr.p + 3 * nA4),
+	    *hx = (u32*)((u8*)L.scr.p + 4 * nA4), *py = (u32*)((u8*)L.scr.p + 5 * nA4);
+	u32 *d_head = fx; u64 *d_gid = (u64*)((u8*)L.scr.p + nA4), *d_cu = (u64*)((u8*)L.scr.p + 3 * nA4);
+	i32 *d_cf = (i32*)L.B.p, *d_cp = (i32*)((u8*)L.B.p + nA4), *d_ct = (i32*)((u8*)L.B.p + 2 * nA4), *d_cv = (i32*)((u8*)L.B.p + 3 * nA4);
+	if (nj) {
+		StageTimer t(this, L.stream, "k_seed_emit", nj * 32 + nA * 24);
+		LQ_LAUNCH(k_seed_emit, nblk(nj, 256), 256, L.stream, q.mx.as<u64>(), q.my.as<u64>(), q_owner.as<u32>(), q.moff.as<u64>(), j0, nj,
+		          pt.pos.as<u64>(), hit_start.as<u64>(), hit_n.as<u32>(), keep.as<u32>(),
+		          a_off.as<u64>(), a_base, mp_off.as<u64>(), q.d_len.as<u32>(),
+		          (int)P.no_self, pt.self_off.as<u32>(), pt.self_rid.as<u32>(), dA, mini_pos.as<u64>());
+		check_launch();
+	}
+	if (nA) {
+		const u64 *aqb = aq_off.as<u64>() + q0;          // batch view of the per-query anchor offsets
+		// ---- klib-order sort (lqmap.c:238) ----
+		{
+			const u64 max_segs = nA / (LQ_RS_MIN + 1) + nqb + 1;
+			L.segs0.ensure(max_segs * sizeof(SortSeg)); L.segs1.ensure(max_segs * sizeof(SortSeg));
+			dzero(L.n_segs.p, 64, L.stream);
+			{
+				StageTimer t(this, L.stream, "k_sort_init");
+				LQ_LAUNCH(k_sort_init, nblk(nqb, 64), 64, L.stream, aqb, a_base, nqb, dA, L.segs0.as<SortSeg>(), L.n_segs.as<u32>());
+				check_launch();
+			}
+			u32 ns = 0;
+			d2h(&ns, L.n_segs.as<u32>(), 1, L.stream);
+			SortSeg *cur = L.segs0.as<SortSeg>(), *nxt = L.segs1.as<SortSeg>();
+			WalkCaps wcaps; wcaps.c[0] = 4096; wcaps.c[1] = 16384; wcaps.c[2] = 65536; wcaps.c[3] = 159744;
+			if (const char *ws = getenv("LQCOV_WALK_SHIFT")) for (int c = 0; c < 4; ++c) wcaps.c[c] >>= atoi(ws);   // test knob
+			L.sort_d.ensure(nA + 64); L.sort_dst.ensure((nA + 1) * 4);
+			for (int level = 0; level < 8 && ns > 0; ++level) {
+				L.hist.ensure((u64)ns * 1024); L.begs.ensure((u64)ns * 1024);
+				L.seg_info.ensure((u64)ns * sizeof(SegInfo)); L.walk_list.ensure((u64)ns * 4 * LQ_WALK_CLASSES); L.two_list.ensure((u64)ns * 4);
+				dzero(L.n_segs.as<u32>() + 1, 4 * (2 + LQ_WALK_CLASSES), L.stream);   // [1] next-level count, [2] n_two, [3..] n_walk per size class
+				{
+					StageTimer t(this, L.stream, "k_sort_copy_hist", nA * 33);
+					LQ_LAUNCH(k_sort_copy_hist, ns, 256, L.stream, cur, ns, dA, dB, L.sort_d.as<u8>(), L.hist.as<u32>());
+					check_launch();
+				}
+				LQ_LAUNCH(k_sort_classify, nblk(ns, 64), 64, L.stream, cur, ns, L.hist.as<u32>(), L.begs.as<u32>(), L.seg_info.as<SegInfo>(),
+				          L.walk_list.as<u32>(), L.two_list.as<u32>(), L.n_segs.as<u32>() + 2, wcaps);
+				check_launch();
+				u32 cw[1 + LQ_WALK_CLASSES];
+				d2h(cw, L.n_segs.as<u32>() + 2, 1 + LQ_WALK_CLASSES, L.stream);
+				const u32 n_two = cw[0];
+				u32 n_walk = 0;
+				for (int c = 0; c < LQ_WALK_CLASSES; ++c) n_walk += cw[1 + c];
+				if (n_two) {                                        // closed-form two-bucket passes (the strand bit at the top level)
+					StageTimer t(this, L.stream, "k_sort_two_bucket", nA * 60);
+					dzero(fx, (nA + 1) * 4, L.stream); dzero(fy, (nA + 1) * 4, L.stream);
+					LQ_LAUNCH(k_two_flags, n_two, 256, L.stream, cur, L.seg_info.as<SegInfo>(), L.two_list.as<u32>(), n_two, L.sort_d.as<u8>(), fx, fy);
+					check_launch();
+					L.prim.exclusive_scan_u32_u32(fx, sx, nA + 1);
+					L.prim.exclusive_scan_u32_u32(fy, sy, nA + 1);
+					LQ_LAUNCH(k_two_positions, n_two, 256, L.stream, cur, L.two_list.as<u32>(), n_two, fx, fy, sx, sy, hx, py);
+					check_launch();
+					LQ_LAUNCH(k_two_dst, n_two, 256, L.stream, cur, L.seg_info.as<SegInfo>(), L.two_list.as<u32>(), n_two, L.sort_d.as<u8>(),
+					          sx, sy, hx, py, L.sort_dst.as<u32>());
+					check_launch();
+				}
+				if (n_walk) {
+					const u8 *dD = L.sort_d.as<u8>(); const u32 *dH = L.hist.as<u32>(), *dBg = L.begs.as<u32>(); u32 *dDst = L.sort_dst.as<u32>();
+					const u32 *wl = L.walk_list.as<u32>();
+					if (cw[1]) { StageTimer t(this, L.stream, "k_sort_walk_lds<4096>"); LQ_LAUNCH((k_sort_walk_lds<4096>), cw[1], 64, L.stream, cur, wl + (u64)0 * ns, cw[1], dD, dH, dBg, dDst); check_launch(); }
+					if (cw[2]) { StageTimer t(this, L.stream, "k_sort_walk_lds<16384>"); LQ_LAUNCH((k_sort_walk_lds<16384>), cw[2], 64, L.stream, cur, wl + (u64)1 * ns, cw[2], dD, dH, dBg, dDst); check_launch(); }
+					const u32 n_long = cw[3] + cw[4] + cw[5];
+					if (n_long) {
+						// longer sub-arrays: one lane each over the global digit bytes (64 independent walks per wave keep more
+						// memory transactions in flight than a single LDS-resident walker can), longest first.
+						// The three size classes are contiguous in the list only per class, so gather them.
+						L.wkey.ensure((u64)n_long * 4); L.wkey2.ensure((u64)n_long * 4); L.walk_list2.ensure((u64)n_long * 4); L.walk_list3.ensure((u64)n_long * 4);
+						u32 o = 0;
+						for (int c = 2; c < LQ_WALK_CLASSES; ++c) if (cw[1 + c]) {
+							LQ_HIP_CHECK(hipMemcpyAsync(L.walk_list3.as<u32>() + o, wl + (u64)c * ns, (u64)cw[1 + c] * 4, hipMemcpyDeviceToDevice, L.stream));
+							o += cw[1 + c];
+						}
+						const bool lane_walker = getenv("LQCOV_WALK") && !strcmp(getenv("LQCOV_WALK"), "lane");   // A/B knob
+						LQ_LAUNCH(k_walk_keys, nblk(n_long, 256), 256, L.stream, cur, L.walk_list3.as<u32>(), n_long, L.wkey.as<u32>()); check_launch();
+						L.prim.sort_pairs_u32_u32(L.wkey.as<u32>(), L.wkey2.as<u32>(), L.walk_list3.as<u32>(), L.walk_list2.as<u32>(), n_long);
+						// algorithmic bytes of a walk: one digit byte in, one 4-byte destination out per element
+						u64 long_elems = 0;
+						{
+							std::vector<u32> hk(n_long);
+							d2h(hk.data(), L.wkey2.as<u32>(), n_long, L.stream);
+							for (u32 v : hk) long_elems += 0xffffffffu - v;
+						}
+						if (lane_walker) {
+							StageTimer t(this, L.stream, "k_sort_walk", long_elems * 5);
+							LQ_LAUNCH(k_sort_walk, nblk(n_long, LQ_WALK_LANES), LQ_WALK_LANES, L.stream, cur, L.walk_list2.as<u32>(), n_long, dD, dH, dBg, dDst);
+							check_launch();
+						} else {
+							StageTimer t(this, L.stream, "k_sort_walk_solo", long_elems * 5);
+							LQ_LAUNCH(k_sort_walk_solo, n_long, 64, L.stream, cur, L.walk_list2.as<u32>(), n_long, dD, dH, dBg, dDst);
+							check_launch();
+						}
+					}
+				}
+				if (n_walk || n_two) {
+					StageTimer t(this, L.stream, "k_sort_scatter", nA * 36);
+					LQ_LAUNCH(k_sort_scatter, ns, 256, L.stream, cur, L.seg_info.as<SegInfo>(), ns, dA, dB, L.sort_dst.as<u32>());
+					check_launch();
+				}
+				{
+					StageTimer t(this, L.stream, "k_sort_children");
+					LQ_LAUNCH(k_sort_children, nblk((u64)ns * 256, 256), 256, L.stream, cur, ns, dA, L.hist.as<u32>(), L.begs.as<u32>(), nxt, L.n_segs.as<u32>() + 1);
+					check_launch();
+				}
+				d2h(&ns, L.n_segs.as<u32>() + 1, 1, L.stream);
+				std::swap(cur, nxt);
+			}
+		}
+		// ---- (strand, rid) runs ----
+		dzero(d_head, nA * 4, L.stream);
+		LQ_LAUNCH(k_mark_qstart, nblk(nqb, 256), 256, L.stream, aqb, a_base, nqb, d_head); check_launch();
+		LQ_LAUNCH(k_group_heads, nblk(nA, 256), 256, L.stream, dA, nA, d_head); check_launch();
+		L.prim.exclusive_scan_u32_u64(d_head, d_gid, nA);
+		u64 lg = 0; u32 lh = 0;
+		d2h(&lg, d_gid + nA - 1, 1, L.stream); d2h(&lh, d_head + nA - 1, 1, L.stream);
+		const u64 n_groups = lg + lh;
+		L.gstart.ensure((n_groups + 1) * 8);
+		LQ_LAUNCH(k_group_starts, nblk(nA, 256), 256, L.stream, d_head, d_gid, nA, n_groups, L.gstart.as<u64>()); check_launch();
+		// ---- chain + coverage ----
+		const u32 ivl_cap = (u32)std::min<u64>(nA / (P.min_cnt > 0 ? P.min_cnt : 1) + 16, 0xfffffff0ULL);
+		L.ivl.ensure((u64)ivl_cap * sizeof(Ivl));
+		dzero(L.n_ivl.p, 4, L.stream);
+		ChainBufs cb; cb.f = d_cf; cb.p = d_cp; cb.t = d_ct; cb.v = d_cv; cb.u = d_cu;
+		CovState cs;
+		cs.lambda = lambda.as<unsigned long long>(); cs.lambda2 = lambda2.as<unsigned long long>();
+		cs.cnts = cnts.as<u32>(); cs.qflags = qflags.as<u32>(); cs.skip = skip.as<u32>(); cs.qmoff = q.moff.as<u64>();
+		cs.mini_pos = mini_pos.as<u64>(); cs.mpq_off = mpq_off.as<u64>(); cs.qlen = q.d_len.as<u32>(); cs.tlen = pt.rs.d_len.as<u32>();
+		cs.ivl = L.ivl.as<Ivl>(); cs.n_ivl = L.n_ivl.as<u32>(); cs.ivl_cap = ivl_cap;
+		cs.dbg = dbg ? dbg_chains.as<ChainRec>() : nullptr; cs.n_dbg = n_dbg.as<unsigned long long>(); cs.dbg_cap = dbg_cap;
+		if (n_groups > 0xfffffff0ULL) throw std::domain_error("too many anchor runs in one batch");
+		const int wave_min = getenv("LQCOV_CHAIN_WAVE_MIN") ? std::max(1, atoi(getenv("LQCOV_CHAIN_WAVE_MIN"))) : LQ_CHAIN_WAVE_MIN;   // test knob
+		// LDS-resident DP for runs <= 16 anchors: off by default -- measured slower on MI355X (54 KiB of LDS per 64 lanes caps
+		// occupancy at 3 waves per CU: 160 + 40 ms vs 113 ms for the global-scratch kernel at configs[1]); LQCOV_CHAIN_SMALL=1 enables
+		const int small_max = getenv("LQCOV_CHAIN_SMALL") && atoi(getenv("LQCOV_CHAIN_SMALL")) ? std::min<int>(LQ_CHAIN_SMALL, wave_min - 1) : (int)P.min_cnt - 1;
+		{	// one thread per run, in array order (most lanes retire at once; the few longer runs of a wave then keep
+			// their working set in the CU's L1).  Measured alternatives that were slower on MI355X: a compacted
+			// longest-first work list for all runs (409 vs 292 ms at configs[1]) and private-array DP for short runs.
+			StageTimer t(this, L.stream, "k_chain", nA * 16);
+			LQ_LAUNCH(k_chain, nblk(n_groups, 64), 64, L.stream, dA, L.gstart.as<u64>(), (const u32*)nullptr, (u32)n_groups, aqb, a_base, nqb, q0, avg_qspan.as<float>(), mp, cb, cs, (i32)(small_max + 1), (i32)(wave_min - 1));
+			check_launch();
+		}
+		if (small_max >= P.min_cnt) {	// short runs: DP state in LDS
+			StageTimer t(this, L.stream, "k_chain_small", nA * 16);
+			LQ_LAUNCH(k_chain_small, nblk(n_groups, 64), 64, L.stream, dA, L.gstart.as<u64>(), n_groups, aqb, a_base, nqb, q0, avg_qspan.as<float>(), mp, cs, (i32)small_max);
+			check_launch();
+		}
+		{	// long runs (the tail of the kernel above if left there): one wave per run, longest first
+			L.gflag.ensure(n_groups * 4 + 4); L.gidx.ensure(n_groups * 4 + 4);
+			LQ_LAUNCH(k_group_flags, nblk(n_groups, 256), 256, L.stream, L.gstart.as<u64>(), n_groups, (i32)wave_min, L.gflag.as<u32>()); check_launch();
+			L.prim.exclusive_scan_u32_u32(L.gflag.as<u32>(), L.gidx.as<u32>(), n_groups);
+			u32 lgi = 0, lgf = 0;
+			d2h(&lgi, L.gidx.as<u32>() + n_groups - 1, 1, L.stream); d2h(&lgf, L.gflag.as<u32>() + n_groups - 1, 1, L.stream);
+			const u32 n_sel = lgi + lgf;
+			if (n_sel) {
+				L.gsel.ensure((u64)n_sel * 4); L.gkey.ensure((u64)n_sel * 4); L.gsel2.ensure((u64)n_sel * 4); L.gkey2.ensure((u64)n_sel * 4);
+				LQ_LAUNCH(k_group_compact, nblk(n_groups, 256), 256, L.stream, L.gstart.as<u64>(), L.gflag.as<u32>(), L.gidx.as<u32>(), n_groups, L.gsel.as<u32>(), L.gkey.as<u32>()); check_launch();
+				L.prim.sort_pairs_u32_u32(L.gkey.as<u32>(), L.gkey2.as<u32>(), L.gsel.as<u32>(), L.gsel2.as<u32>(), n_sel);
+				StageTimer t(this, L.stream, "k_chain_wave", nA * 16);
+				LQ_LAUNCH(k_chain_wave, n_sel, 64, L.stream, dA, L.gstart.as<u64>(), L.gsel2.as<u32>(), n_sel, aqb, a_base, nqb, q0, avg_qspan.as<float>(), mp, cb, cs);
+				check_launch();
+			}
+		}
+		// ---- filter_redundant_coords per query (lqmap.c:287) ----
+		u32 ni = 0;
+		d2h(&ni, L.n_ivl.as<u32>(), 1, L.stream);
+		if (ni > ivl_cap) throw std::runtime_error("interval pool overflow");
+		if (ni) {
+			L.iv_q.ensure((u64)ni * 4); L.iv_q2.ensure((u64)ni * 4); L.iv_se.ensure((u64)ni * 8); L.iv_se2.ensure((u64)ni * 8);
+			L.ivq_off.ensure((n_q + 1) * 4); L.iv_scratch.ensure((u64)ni * 16);
+			LQ_LAUNCH(k_split_ivl, nblk(ni, 256), 256, L.stream, L.ivl.as<Ivl>(), ni, L.iv_q.as<u32>(), L.iv_se.as<u64>()); check_launch();
+			L.prim.sort_pairs_u32_u64(L.iv_q.as<u32>(), L.iv_q2.as<u32>(), L.iv_se.as<u64>(), L.iv_se2.as<u64>(), ni, 32);
+			LQ_LAUNCH(k_ivl_offsets, nblk(n_q + 1, 256), 256, L.stream, L.iv_q2.as<u32>(), ni, n_q, L.ivq_off.as<u32>()); check_launch();
+			// pv (the persisted intervals of all parts) is shared by the lanes: reserve the worst case under the lock, and grow
+			// it only with every lane's kernels drained
+			std::lock_guard<std::mutex> guard(pv_mu);
+			const u64 need = pv_reserved + 2 * (u64)ni;
+			if (need > 0xfffffff0ULL) throw std::domain_error("too many persisted intervals");
+			if (need > pv_cap) {
+				LQ_HIP_CHECK(hipDeviceSynchronize());
+				u32 npv = 0;
+				d2h(&npv, n_pv.as<u32>(), 1, L.stream);
+				grow_keep(pv, (u64)npv * sizeof(Ivl), need * sizeof(Ivl) * 2, L.stream);
+				pv_cap = (u32)std::min<u64>(pv.cap / sizeof(Ivl), 0xfffffff0ULL);
+			}
+			pv_reserved = need;
+			StageTimer t(this, L.stream, "k_filter_redundant");
+			LQ_LAUNCH(k_filter_redundant, nblk(n_q, 64), 64, L.stream, L.iv_se2.as<u64>(), L.ivq_off.as<u32>(), n_q, (u32)P.min_coverage,
+			          L.iv_scratch.as<u32>(), pv.as<Ivl>(), n_pv.as<u32>(), pv_cap);
+			check_launch();
+		}
+	}
 }
 
 // ---- map every query against one part (lqmap.c:207-326) -----------------------------------------
@@ -375,206 +590,63 @@ void lqcov_handle::map_part(Part &pt)
 		dbg_chains.ensure(dbg_cap * sizeof(ChainRec)); n_dbg.ensure(8);
 		dzero(n_dbg.p, 8, stream);
 	}
-	n_segs.ensure(64); n_ivl.ensure(4);
-
-	u32 q0 = 0;
-	while (q0 < n_q) {
-		// a batch of queries whose anchors fit the work space
-		u32 q1 = q0 + 1;
-		while (q1 < n_q && h_aq[q1 + 1] - h_aq[q0] <= anchor_budget) ++q1;
-		const u64 a_base = h_aq[q0], nA = h_aq[q1] - a_base;
-		const u32 nqb = q1 - q0;
-		const u64 j0 = h_qmoff[q0], nj = h_qmoff[q1] - j0;
-		if (nA > 0xfffffff0ULL) throw std::domain_error("a single query produces more than 2^32 anchors against this part");
-		A.ensure((nA + 1) * 16); B.ensure((nA + 1) * 16);
-		mm128 *dA = A.as<mm128>(), *dB = B.as<mm128>();
-		if (nj) {
-			StageTimer t(this, "k_seed_emit", nj * 32 + nA * 24);
-			LQ_LAUNCH(k_seed_emit, nblk(nj, 256), 256, stream, q.mx.as<u64>(), q.my.as<u64>(), q_owner.as<u32>(), q.moff.as<u64>(), j0, nj,
-			          pt.pos.as<u64>(), hit_start.as<u64>(), hit_n.as<u32>(), keep.as<u32>(),
-			          a_off.as<u64>(), a_base, mp_off.as<u64>(), q.d_len.as<u32>(),
-			          (int)P.no_self, pt.self_off.as<u32>(), pt.self_rid.as<u32>(), dA, mini_pos.as<u64>());
-			check_launch();
+	// batches of queries whose anchors fit one lane's work space; lanes (own stream + work space) take batches as they
+	// finish, so the serial tail of one batch (its longest walk / chain) overlaps the wide kernels of another
+	std::vector<std::pair<u32, u32>> batches;
+	{	// as few batches as the work space allows, a multiple of the lane count, of about equal anchor totals: every batch
+		// has a serial critical path (its longest walk and chain) that does not shrink with the batch
+		u64 nb = (nA_total + anchor_budget - 1) / anchor_budget;
+		if (nb < (u64)n_lanes && nA_total >= ((u64)n_lanes << 24)) nb = n_lanes;
+		if (nb > (u64)n_lanes) nb = (nb + n_lanes - 1) / n_lanes * n_lanes;
+		if (nb == 0) nb = 1;
+		u64 left = nb;
+		for (u32 q0 = 0; q0 < n_q; ) {
+			const u64 rem = h_aq[n_q] - h_aq[q0];
+			const u64 lim = std::min(anchor_budget, left > 1 ? (rem + left - 1) / left : rem);
+			u32 q1 = q0 + 1;
+			while (q1 < n_q && h_aq[q1 + 1] - h_aq[q0] <= lim) ++q1;
+			batches.emplace_back(q0, q1);
+			q0 = q1;
+			if (left > 1) --left;
 		}
-		if (nA) {
-			const u64 *aqb = aq_off.as<u64>() + q0;          // batch view of the per-query anchor offsets
-			// ---- klib-order sort (lqmap.c:238) ----
-			{
-				const u64 max_segs = nA / (LQ_RS_MIN + 1) + nqb + 1;
-				segs0.ensure(max_segs * sizeof(SortSeg)); segs1.ensure(max_segs * sizeof(SortSeg));
-				dzero(n_segs.p, 64, stream);
-				{
-					StageTimer t(this, "k_sort_init");
-					LQ_LAUNCH(k_sort_init, nblk(nqb, 64), 64, stream, aqb, a_base, nqb, dA, segs0.as<SortSeg>(), n_segs.as<u32>());
-					check_launch();
-				}
-				u32 ns = 0;
-				d2h(&ns, n_segs.as<u32>(), 1, stream);
-				SortSeg *cur = segs0.as<SortSeg>(), *nxt = segs1.as<SortSeg>();
-				WalkCaps wcaps; wcaps.c[0] = 4096; wcaps.c[1] = 16384; wcaps.c[2] = 65536; wcaps.c[3] = 159744;
-				if (const char *ws = getenv("LQCOV_WALK_SHIFT")) for (int c = 0; c < 4; ++c) wcaps.c[c] >>= atoi(ws);   // test knob
-				sort_d.ensure(nA + 64); sort_dst.ensure((nA + 1) * 4);
-				for (int level = 0; level < 8 && ns > 0; ++level) {
-					hist.ensure((u64)ns * 1024); begs.ensure((u64)ns * 1024);
-					seg_info.ensure((u64)ns * sizeof(SegInfo)); walk_list.ensure((u64)ns * 4 * LQ_WALK_CLASSES); two_list.ensure((u64)ns * 4);
-					dzero(n_segs.as<u32>() + 1, 4 * (2 + LQ_WALK_CLASSES), stream);   // [1] next-level count, [2] n_two, [3..] n_walk per size class
-					{
-						StageTimer t(this, "k_sort_copy_hist", nA * 33);
-						LQ_LAUNCH(k_sort_copy_hist, ns, 256, stream, cur, ns, dA, dB, sort_d.as<u8>(), hist.as<u32>());
-						check_launch();
+	}
+	while (lanes.size() < (size_t)n_lanes) {
+		lanes.emplace_back(new MapLane());
+		LQ_HIP_CHECK(hipStreamCreate(&lanes.back()->stream));
+		lanes.back()->prim.stream = lanes.back()->stream;
+	}
+	{
+		u32 npv = 0;
+		d2h(&npv, n_pv.as<u32>(), 1, stream);
+		pv_reserved = npv;
+	}
+#ifndef LQ_EMU
+	const bool concurrent = n_lanes > 1 && batches.size() > 1 && !profiling && !dbg;
+#else
+	const bool concurrent = false;
+#endif
+	if (!concurrent) {
+		for (size_t i = 0; i < batches.size(); ++i) map_batch(*lanes[i % n_lanes], pt, batches[i].first, batches[i].second, h_aq, h_qmoff, dbg);
+		for (auto &L : lanes) LQ_HIP_CHECK(hipStreamSynchronize(L->stream));
+	} else {
+		std::atomic<size_t> next(0);
+		std::vector<std::exception_ptr> errs(n_lanes);
+		std::vector<std::thread> th;
+		for (int li = 0; li < n_lanes; ++li)
+			th.emplace_back([&, li]() {
+				try {
+					LQ_HIP_CHECK(hipSetDevice(device));
+					MapLane &L = *lanes[li];
+					for (;;) {
+						const size_t i = next.fetch_add(1);
+						if (i >= batches.size()) break;
+						map_batch(L, pt, batches[i].first, batches[i].second, h_aq, h_qmoff, dbg);
 					}
-					LQ_LAUNCH(k_sort_classify, nblk(ns, 64), 64, stream, cur, ns, hist.as<u32>(), begs.as<u32>(), seg_info.as<SegInfo>(),
-					          walk_list.as<u32>(), two_list.as<u32>(), n_segs.as<u32>() + 2, wcaps);
-					check_launch();
-					u32 cw[1 + LQ_WALK_CLASSES];
-					d2h(cw, n_segs.as<u32>() + 2, 1 + LQ_WALK_CLASSES, stream);
-					const u32 n_two = cw[0];
-					u32 n_walk = 0;
-					for (int c = 0; c < LQ_WALK_CLASSES; ++c) n_walk += cw[1 + c];
-					if (n_two) {                                        // closed-form two-bucket passes (the strand bit at the top level)
-						StageTimer t(this, "k_sort_two_bucket", nA * 60);
-						fx.ensure((nA + 1) * 4); fy.ensure((nA + 1) * 4); sx.ensure((nA + 1) * 4); sy.ensure((nA + 1) * 4);
-						hx.ensure((nA + 1) * 4); py.ensure((nA + 1) * 4);
-						dzero(fx.p, (nA + 1) * 4, stream); dzero(fy.p, (nA + 1) * 4, stream);
-						LQ_LAUNCH(k_two_flags, n_two, 256, stream, cur, seg_info.as<SegInfo>(), two_list.as<u32>(), n_two, sort_d.as<u8>(), fx.as<u32>(), fy.as<u32>());
-						check_launch();
-						prim.exclusive_scan_u32_u32(fx.as<u32>(), sx.as<u32>(), nA + 1);
-						prim.exclusive_scan_u32_u32(fy.as<u32>(), sy.as<u32>(), nA + 1);
-						LQ_LAUNCH(k_two_positions, n_two, 256, stream, cur, two_list.as<u32>(), n_two, fx.as<u32>(), fy.as<u32>(), sx.as<u32>(), sy.as<u32>(), hx.as<u32>(), py.as<u32>());
-						check_launch();
-						LQ_LAUNCH(k_two_dst, n_two, 256, stream, cur, seg_info.as<SegInfo>(), two_list.as<u32>(), n_two, sort_d.as<u8>(),
-						          sx.as<u32>(), sy.as<u32>(), hx.as<u32>(), py.as<u32>(), sort_dst.as<u32>());
-						check_launch();
-					}
-					if (n_walk) {
-						const u8 *dD = sort_d.as<u8>(); const u32 *dH = hist.as<u32>(), *dBg = begs.as<u32>(); u32 *dDst = sort_dst.as<u32>();
-						const u32 *wl = walk_list.as<u32>();
-						if (cw[1]) { StageTimer t(this, "k_sort_walk_lds<4096>"); LQ_LAUNCH((k_sort_walk_lds<4096>), cw[1], 64, stream, cur, wl + (u64)0 * ns, cw[1], dD, dH, dBg, dDst); check_launch(); }
-						if (cw[2]) { StageTimer t(this, "k_sort_walk_lds<16384>"); LQ_LAUNCH((k_sort_walk_lds<16384>), cw[2], 64, stream, cur, wl + (u64)1 * ns, cw[2], dD, dH, dBg, dDst); check_launch(); }
-						const u32 n_long = cw[3] + cw[4] + cw[5];
-						if (n_long) {
-							// longer sub-arrays: one lane each over the global digit bytes (64 independent walks per wave keep more
-							// memory transactions in flight than a single LDS-resident walker can), longest first.
-							// The three size classes are contiguous in the list only per class, so gather them.
-							wkey.ensure((u64)n_long * 4); wkey2.ensure((u64)n_long * 4); walk_list2.ensure((u64)n_long * 4); walk_list3.ensure((u64)n_long * 4);
-							u32 o = 0;
-							for (int c = 2; c < LQ_WALK_CLASSES; ++c) if (cw[1 + c]) {
-								LQ_HIP_CHECK(hipMemcpyAsync(walk_list3.as<u32>() + o, wl + (u64)c * ns, (u64)cw[1 + c] * 4, hipMemcpyDeviceToDevice, stream));
-								o += cw[1 + c];
-							}
-							const bool lane_walker = getenv("LQCOV_WALK") && !strcmp(getenv("LQCOV_WALK"), "lane");   // A/B knob
-							LQ_LAUNCH(k_walk_keys, nblk(n_long, 256), 256, stream, cur, walk_list3.as<u32>(), n_long, wkey.as<u32>()); check_launch();
-							prim.sort_pairs_u32_u32(wkey.as<u32>(), wkey2.as<u32>(), walk_list3.as<u32>(), walk_list2.as<u32>(), n_long);
-							// algorithmic bytes of a walk: one digit byte in, one 4-byte destination out per element
-							u64 long_elems = 0;
-							{
-								std::vector<u32> hk(n_long);
-								d2h(hk.data(), wkey2.as<u32>(), n_long, stream);
-								for (u32 v : hk) long_elems += 0xffffffffu - v;
-							}
-							if (lane_walker) {
-								StageTimer t(this, "k_sort_walk", long_elems * 5);
-								LQ_LAUNCH(k_sort_walk, nblk(n_long, LQ_WALK_LANES), LQ_WALK_LANES, stream, cur, walk_list2.as<u32>(), n_long, dD, dH, dBg, dDst);
-								check_launch();
-							} else {
-								StageTimer t(this, "k_sort_walk_solo", long_elems * 5);
-								LQ_LAUNCH(k_sort_walk_solo, n_long, 64, stream, cur, walk_list2.as<u32>(), n_long, dD, dH, dBg, dDst);
-								check_launch();
-							}
-						}
-					}
-					if (n_walk || n_two) {
-						StageTimer t(this, "k_sort_scatter", nA * 36);
-						LQ_LAUNCH(k_sort_scatter, ns, 256, stream, cur, seg_info.as<SegInfo>(), ns, dA, dB, sort_dst.as<u32>());
-						check_launch();
-					}
-					{
-						StageTimer t(this, "k_sort_children");
-						LQ_LAUNCH(k_sort_children, nblk((u64)ns * 256, 256), 256, stream, cur, ns, dA, hist.as<u32>(), begs.as<u32>(), nxt, n_segs.as<u32>() + 1);
-						check_launch();
-					}
-					d2h(&ns, n_segs.as<u32>() + 1, 1, stream);
-					std::swap(cur, nxt);
-				}
-			}
-			// ---- (strand, rid) runs ----
-			head.ensure(nA * 4); gid.ensure(nA * 8);
-			dzero(head.p, nA * 4, stream);
-			LQ_LAUNCH(k_mark_qstart, nblk(nqb, 256), 256, stream, aqb, a_base, nqb, head.as<u32>()); check_launch();
-			LQ_LAUNCH(k_group_heads, nblk(nA, 256), 256, stream, dA, nA, head.as<u32>()); check_launch();
-			prim.exclusive_scan_u32_u64(head.as<u32>(), gid.as<u64>(), nA);
-			u64 lg = 0; u32 lh = 0;
-			d2h(&lg, gid.as<u64>() + nA - 1, 1, stream); d2h(&lh, head.as<u32>() + nA - 1, 1, stream);
-			const u64 n_groups = lg + lh;
-			gstart.ensure((n_groups + 1) * 8);
-			LQ_LAUNCH(k_group_starts, nblk(nA, 256), 256, stream, head.as<u32>(), gid.as<u64>(), nA, n_groups, gstart.as<u64>()); check_launch();
-			// ---- chain + coverage ----
-			cf.ensure(nA * 4); cp.ensure(nA * 4); ct.ensure(nA * 4); cv.ensure(nA * 4); cu.ensure(nA * 8);
-			const u32 ivl_cap = (u32)std::min<u64>(nA / (P.min_cnt > 0 ? P.min_cnt : 1) + 16, 0xfffffff0ULL);
-			ivl.ensure((u64)ivl_cap * sizeof(Ivl));
-			dzero(n_ivl.p, 4, stream);
-			ChainBufs cb; cb.f = cf.as<i32>(); cb.p = cp.as<i32>(); cb.t = ct.as<i32>(); cb.v = cv.as<i32>(); cb.u = cu.as<u64>();
-			CovState cs;
-			cs.lambda = lambda.as<unsigned long long>(); cs.lambda2 = lambda2.as<unsigned long long>();
-			cs.cnts = cnts.as<u32>(); cs.qflags = qflags.as<u32>(); cs.skip = skip.as<u32>(); cs.qmoff = q.moff.as<u64>();
-			cs.mini_pos = mini_pos.as<u64>(); cs.mpq_off = mpq_off.as<u64>(); cs.qlen = q.d_len.as<u32>(); cs.tlen = pt.rs.d_len.as<u32>();
-			cs.ivl = ivl.as<Ivl>(); cs.n_ivl = n_ivl.as<u32>(); cs.ivl_cap = ivl_cap;
-			cs.dbg = dbg ? dbg_chains.as<ChainRec>() : nullptr; cs.n_dbg = n_dbg.as<unsigned long long>(); cs.dbg_cap = dbg_cap;
-			if (n_groups > 0xfffffff0ULL) throw std::domain_error("too many anchor runs in one batch");
-			const int wave_min = getenv("LQCOV_CHAIN_WAVE_MIN") ? std::max(1, atoi(getenv("LQCOV_CHAIN_WAVE_MIN"))) : LQ_CHAIN_WAVE_MIN;   // test knob
-			// LDS-resident DP for runs <= 16 anchors: off by default -- measured slower on MI355X (54 KiB of LDS per 64 lanes caps
-			// occupancy at 3 waves per CU: 160 + 40 ms vs 113 ms for the global-scratch kernel at configs[1]); LQCOV_CHAIN_SMALL=1 enables
-			const int small_max = getenv("LQCOV_CHAIN_SMALL") && atoi(getenv("LQCOV_CHAIN_SMALL")) ? std::min<int>(LQ_CHAIN_SMALL, wave_min - 1) : (int)P.min_cnt - 1;
-			{	// one thread per run, in array order (most lanes retire at once; the few longer runs of a wave then keep
-				// their working set in the CU's L1).  Measured alternatives that were slower on MI355X: a compacted
-				// longest-first work list for all runs (409 vs 292 ms at configs[1]) and private-array DP for short runs.
-				StageTimer t(this, "k_chain", nA * 16);
-				LQ_LAUNCH(k_chain, nblk(n_groups, 64), 64, stream, dA, gstart.as<u64>(), (const u32*)nullptr, (u32)n_groups, aqb, a_base, nqb, q0, avg_qspan.as<float>(), mp, cb, cs, (i32)(small_max + 1), (i32)(wave_min - 1));
-				check_launch();
-			}
-			if (small_max >= P.min_cnt) {	// short runs: DP state in LDS
-				StageTimer t(this, "k_chain_small", nA * 16);
-				LQ_LAUNCH(k_chain_small, nblk(n_groups, 64), 64, stream, dA, gstart.as<u64>(), n_groups, aqb, a_base, nqb, q0, avg_qspan.as<float>(), mp, cs, (i32)small_max);
-				check_launch();
-			}
-			{	// long runs (the tail of the kernel above if left there): one wave per run, longest first
-				gflag.ensure(n_groups * 4 + 4); gidx.ensure(n_groups * 4 + 4);
-				LQ_LAUNCH(k_group_flags, nblk(n_groups, 256), 256, stream, gstart.as<u64>(), n_groups, (i32)wave_min, gflag.as<u32>()); check_launch();
-				prim.exclusive_scan_u32_u32(gflag.as<u32>(), gidx.as<u32>(), n_groups);
-				u32 lgi = 0, lgf = 0;
-				d2h(&lgi, gidx.as<u32>() + n_groups - 1, 1, stream); d2h(&lgf, gflag.as<u32>() + n_groups - 1, 1, stream);
-				const u32 n_sel = lgi + lgf;
-				if (n_sel) {
-					gsel.ensure((u64)n_sel * 4); gkey.ensure((u64)n_sel * 4); gsel2.ensure((u64)n_sel * 4); gkey2.ensure((u64)n_sel * 4);
-					LQ_LAUNCH(k_group_compact, nblk(n_groups, 256), 256, stream, gstart.as<u64>(), gflag.as<u32>(), gidx.as<u32>(), n_groups, gsel.as<u32>(), gkey.as<u32>()); check_launch();
-					prim.sort_pairs_u32_u32(gkey.as<u32>(), gkey2.as<u32>(), gsel.as<u32>(), gsel2.as<u32>(), n_sel);
-					StageTimer t(this, "k_chain_wave", nA * 16);
-					LQ_LAUNCH(k_chain_wave, n_sel, 64, stream, dA, gstart.as<u64>(), gsel2.as<u32>(), n_sel, aqb, a_base, nqb, q0, avg_qspan.as<float>(), mp, cb, cs);
-					check_launch();
-				}
-			}
-			// ---- filter_redundant_coords per query (lqmap.c:287) ----
-			u32 ni = 0;
-			d2h(&ni, n_ivl.as<u32>(), 1, stream);
-			if (ni > ivl_cap) throw std::runtime_error("interval pool overflow");
-			if (ni) {
-				iv_q.ensure((u64)ni * 4); iv_q2.ensure((u64)ni * 4); iv_se.ensure((u64)ni * 8); iv_se2.ensure((u64)ni * 8);
-				ivq_off.ensure((n_q + 1) * 4); iv_scratch.ensure((u64)ni * 16);
-				LQ_LAUNCH(k_split_ivl, nblk(ni, 256), 256, stream, ivl.as<Ivl>(), ni, iv_q.as<u32>(), iv_se.as<u64>()); check_launch();
-				prim.sort_pairs_u32_u64(iv_q.as<u32>(), iv_q2.as<u32>(), iv_se.as<u64>(), iv_se2.as<u64>(), ni, 32);
-				LQ_LAUNCH(k_ivl_offsets, nblk(n_q + 1, 256), 256, stream, iv_q2.as<u32>(), ni, n_q, ivq_off.as<u32>()); check_launch();
-				u32 npv = 0;
-				d2h(&npv, n_pv.as<u32>(), 1, stream);
-				const u64 need = (u64)npv + 2 * (u64)ni;
-				if (need > 0xfffffff0ULL) throw std::domain_error("too many persisted intervals");
-				if (need > pv_cap) { grow_keep(pv, (u64)npv * sizeof(Ivl), need * sizeof(Ivl) * 2, stream); pv_cap = (u32)std::min<u64>(pv.cap / sizeof(Ivl), 0xfffffff0ULL); }
-				StageTimer t(this, "k_filter_redundant");
-				LQ_LAUNCH(k_filter_redundant, nblk(n_q, 64), 64, stream, iv_se2.as<u64>(), ivq_off.as<u32>(), n_q, (u32)P.min_coverage,
-				          iv_scratch.as<u32>(), pv.as<Ivl>(), n_pv.as<u32>(), pv_cap);
-				check_launch();
-			}
-		}
-		q0 = q1;
+					LQ_HIP_CHECK(hipStreamSynchronize(L.stream));
+				} catch (...) { errs[li] = std::current_exception(); next.store(batches.size()); }
+			});
+		for (auto &t : th) t.join();
+		for (auto &e : errs) if (e) { hipDeviceSynchronize(); std::rethrow_exception(e); }
 	}
 	if (dbg) { unsigned long long nd = 0; d2h(&nd, n_dbg.as<unsigned long long>(), 1, stream); n_dbg_host = nd; }
 	LQ_HIP_CHECK(hipStreamSynchronize(stream));

@@ -13,6 +13,10 @@
 #include <vector>
 #include <map>
 #include <memory>
+#include <mutex>
+#include <thread>
+#include <atomic>
+#include <exception>
 
 struct StageAcc { double ms = 0; u64 launches = 0; u64 bytes = 0; };
 
@@ -40,6 +44,17 @@ struct Part {
 	DBuf self_off, self_rid;              // per query: same-name targets (lqmap.c:180-186)
 };
 
+// One mapping lane: a stream with its own scan/sort scratch and per-batch work space.  Query batches of a part are
+// independent (lqmap.c:170-330 runs one query at a time), so lanes run them concurrently.
+struct MapLane {
+	hipStream_t stream = nullptr;
+	Prim prim;
+	DBuf A, B, segs0, segs1, n_segs, hist, begs;
+	DBuf sort_d, sort_dst, seg_info, walk_list, two_list, scr, wkey, wkey2, walk_list2, walk_list3;
+	DBuf gflag, gidx, gsel, gkey, gsel2, gkey2, gstart;
+	DBuf ivl, n_ivl, iv_q, iv_q2, iv_se, iv_se2, ivq_off, iv_scratch;
+};
+
 struct lqcov_handle {
 	lqcov_params P;
 	MapParams mp;
@@ -65,13 +80,13 @@ struct lqcov_handle {
 
 	// work buffers of part_map
 	DBuf hit_start, hit_n, a_cnt, keep, a_off, mp_off, mini_pos, aq_off, mpq_off, avg_qspan, skip;
-	DBuf A, B, segs0, segs1, n_segs, hist, begs;
-	DBuf sort_d, sort_dst, seg_info, walk_list, two_list, fx, fy, sx, sy, hx, py, wkey, wkey2, walk_list2, walk_list3;
-	DBuf gflag, gidx, gsel, gkey, gsel2, gkey2;
-	DBuf head, gid, gstart, cf, cp, ct, cv, cu;
-	DBuf ivl, n_ivl, iv_q, iv_q2, iv_se, iv_se2, ivq_off, iv_scratch;
+	std::vector<std::unique_ptr<MapLane>> lanes;
+	int n_lanes = 2;
+	std::mutex pv_mu; u64 pv_reserved = 0;
 	DBuf dbg_chains, n_dbg; u64 dbg_cap = 0; u64 n_dbg_host = 0;
 	DBuf misc;
+	DBuf ix_key, ix_key2, ix_head, ix_uidx, ix_ukey, ix_ustart, ix_ucnt, ix_sorted;   // build_index workspaces
+	DBuf sk_cnt, sk_off;                  // sketch: per-chunk minimizer counts / offsets
 	u64 last_n_anchors = 0;
 	u64 anchor_budget = 0;
 
@@ -89,6 +104,7 @@ struct lqcov_handle {
 	void build_index(Part &pt);
 	void build_part(Part &pt);
 	void map_part(Part &pt);
+	void map_batch(MapLane &L, Part &pt, u32 q0, u32 q1, const std::vector<u64> &h_aq, const std::vector<u64> &h_qmoff, bool dbg);
 	void reset();
 	void finish();
 	void write_table(FILE *out);
@@ -97,8 +113,9 @@ struct lqcov_handle {
 };
 
 struct StageTimer {
-	lqcov_handle *h; const char *name; u64 bytes;
+	lqcov_handle *h; hipStream_t s; const char *name; u64 bytes;
 	hipEvent_t a = nullptr, b = nullptr;
 	StageTimer(lqcov_handle *h_, const char *name_, u64 bytes_ = 0);
+	StageTimer(lqcov_handle *h_, hipStream_t s_, const char *name_, u64 bytes_ = 0);
 	~StageTimer();
 };

@@ -327,6 +327,7 @@ __global__ void k_sort_walk_lds(const SortSeg *segs, const u32 *list, u32 n_list
 #define LQ_WAIT_VM0() ((void)0)
 #define LQ_LDS_U8(p) (*(p))
 #define LQ_LDS_U32(p) (*(const u32*)(p))
+#define LQ_LDS_U64(p) (*(p))
 #else
 #define LQ_DMA_WIN16(gptr, ldsptr) \
 	__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr), (__attribute__((address_space(3))) void*)(ldsptr), 16, 0, 0)
@@ -348,6 +349,16 @@ __device__ __forceinline__ u32 lq_lds_u32(const u8 *p)
 	return v;
 }
 #define LQ_LDS_U32(p) lq_lds_u32(p)
+// The compiler cannot tell an LDS-DMA landing zone from any other LDS array and drains vmcnt (i.e. waits for every
+// outstanding dst store) before each ordinary LDS read in the loop; the walk reads its entries with raw ds_read instead.
+__device__ __forceinline__ u64 lq_lds_u64(const u64 *p)
+{
+	u64 v;
+	const u32 a = (u32)(size_t)(__attribute__((address_space(3))) const void*)p;
+	asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(a) : "memory");
+	return v;
+}
+#define LQ_LDS_U64(p) lq_lds_u64(p)
 #endif
 #define LQ_SOLO_PEND 0x80000000u
 __global__ void __launch_bounds__(64)
@@ -386,14 +397,15 @@ k_sort_walk_solo(const SortSeg *segs, const u32 *list, u32 n_list, const u8 *D, 
 	u32 k = 0;
 	for (;;) {
 		// START: next bucket with unread slots; the element under its cursor is picked up, leaving a hole there
-		while (k < 256 && ((u32)ent[k] & ~LQ_SOLO_PEND) >= endb[k]) ++k;
+		while (k < 256 && ((u32)LQ_LDS_U64(&ent[k]) & ~LQ_SOLO_PEND) >= endb[k]) ++k;
 		if (k >= 256) break;
-		u32 hole = (u32)ent[k], hdq = (u32)(ent[k] >> 32);
+		const u64 he = LQ_LDS_U64(&ent[k]);
+		u32 hole = (u32)he, hdq = (u32)(he >> 32);
 		if (hole & LQ_SOLO_PEND) { LQ_WAIT_VM0(); hole &= ~LQ_SOLO_PEND; hdq = LQ_LDS_U32(&win[k][0]); }
 		u32 src = hole, l = hdq & 0xff;
 		// CARRY: the carried element takes the slot under its bucket's cursor; that slot's occupant is carried on
 		while (l != k) {
-			const u64 e = ent[l];
+			const u64 e = LQ_LDS_U64(&ent[l]);
 			u32 c = (u32)e, dq = (u32)(e >> 32);
 			if (c & LQ_SOLO_PEND) { LQ_WAIT_VM0(); c &= ~LQ_SOLO_PEND; dq = LQ_LDS_U32(&win[l][0]); }   // l's window was in flight
 			ds[src] = c;
