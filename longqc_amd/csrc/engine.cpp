@@ -452,7 +452,7 @@ void lqcov_handle::map_batch(MapLane &L, Part &pt, u32 q0, u32 q1, const std::ve
 				}
 				{
 					StageTimer t(this, L.stream, "k_sort_children");
-					LQ_LAUNCH(k_sort_children, nblk((u64)ns * 256, 256), 256, L.stream, cur, ns, dA, L.hist.as<u32>(), L.begs.as<u32>(), nxt, L.n_segs.as<u32>() + 1);
+					LQ_LAUNCH(k_sort_children, nblk((u64)ns * 256, LQ_CHILD_THREADS), LQ_CHILD_THREADS, L.stream, cur, ns, dA, L.hist.as<u32>(), L.begs.as<u32>(), nxt, L.n_segs.as<u32>() + 1);
 					check_launch();
 				}
 				d2h(&ns, L.n_segs.as<u32>() + 1, 1, L.stream);

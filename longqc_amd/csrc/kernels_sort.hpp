@@ -434,7 +434,12 @@ __global__ void k_sort_scatter(const SortSeg *segs, const SegInfo *info, u32 n_s
 }
 
 // one thread per (sub-array, bucket): recurse or finish (ksort.h:121-128)
-__global__ void k_sort_children(const SortSeg *segs, u32 n_segs, mm128 *A, const u32 *hist, const u32 *begs,
+// Buckets of <= 64 elements are finished by klib's insertion sort (ksort.h:87-97), which is stable, so its result is the
+// unique stable order by x: the wave finishes them cooperatively instead.  The 64 buckets of a wave are adjacent in
+// memory; whole buckets are packed into chunks of <= 64 elements, one element per lane, and every lane ranks its
+// element among the elements of its own bucket (ties by original position) and stores it at that rank.
+#define LQ_CHILD_THREADS 64
+__global__ void __launch_bounds__(LQ_CHILD_THREADS) k_sort_children(const SortSeg *segs, u32 n_segs, mm128 *A, const u32 *hist, const u32 *begs,
                                 SortSeg *next, u32 *n_next)
 {
 	u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -447,5 +452,47 @@ __global__ void k_sort_children(const SortSeg *segs, u32 n_segs, mm128 *A, const
 		u32 s = atomicAdd(n_next, 1u);
 		SortSeg c; c.off = sg.off + bg; c.len = n; c.shift = sg.shift > 8 ? sg.shift - 8 : 0;
 		next[s] = c;
-	} else if (n > 1) lq_insertion_sort_x(A + sg.off + bg, n);
+	}
+#ifdef LQ_EMU
+	else if (n > 1) lq_insertion_sort_x(A + sg.off + bg, n);
+#else
+	__shared__ u64 xs[64];
+	__shared__ u32 flag[64];
+	const u32 lane = threadIdx.x;
+	mm128 *seg = A + sg.off;
+	u64 todo = __ballot(n >= 2 && n <= LQ_RS_MIN);
+	while (todo) {                                            // uniform: one chunk of whole buckets per turn
+		const u32 f = (u32)__builtin_ctzll(todo);             // first bucket still to finish
+		const u32 base = __builtin_amdgcn_readlane(bg, f);
+		const u64 fit = __ballot(lane >= f && bg + n - base <= 64);   // bg + n grows with the lane: a run of lanes starting at f
+		const u32 e = 64 - (u32)__builtin_clzll(fit);
+		const u32 total = __builtin_amdgcn_readlane(bg + n, e - 1) - base;
+		const bool member = (fit >> lane) & 1;
+		flag[lane] = 0;
+		__syncthreads();
+		if (member && n) flag[bg - base] = 1;
+		__syncthreads();
+		const u64 M = __ballot(flag[lane] != 0);              // bit i: a bucket starts at element i of the chunk
+		const u32 i = lane;
+		const bool act = i < total;
+		const u32 lo = 63 - (u32)__builtin_clzll((M & (~0ULL >> (63 - i))) | 1ULL);
+		const u64 above = i == 63 ? 0 : (M >> (i + 1)) << (i + 1);
+		const u32 hi = above ? (u32)__builtin_ctzll(above) : total;
+		const u32 myn = act ? hi - lo : 0;
+		mm128 el; el.x = 0; el.y = 0;
+		if (act) { el = seg[base + i]; xs[i] = el.x; }
+		__syncthreads();
+		u32 cnt = 0;
+		for (u32 jj = 0; __ballot(jj < myn) != 0; ++jj) {
+			if (jj < myn) {
+				const u32 j = lo + jj;
+				const u64 xj = xs[j];
+				cnt += j < i ? (xj <= el.x) : (xj < el.x);
+			}
+		}
+		if (myn > 1 && cnt != i - lo) seg[base + lo + cnt] = el;
+		__syncthreads();
+		todo &= ~fit;
+	}
+#endif
 }
