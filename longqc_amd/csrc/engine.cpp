@@ -344,13 +344,12 @@ void lqcov_handle::map_batch(MapLane &L, Part &pt, u32 q0, u32 q1, const std::ve
 	if (nA > 0xfffffff0ULL) throw std::domain_error("a single query produces more than 2^32 anchors against this part");
 	L.A.ensure((nA + 1) * 16); L.B.ensure((nA + 1) * 16);
 	mm128 *dA = L.A.as<mm128>(), *dB = L.B.as<mm128>();
-	// 24 B per anchor of scratch with two lives: the six u32 arrays of the two-bucket passes during the sort, then the run
-	// heads / ids and the chain's u[] afterwards.  The chain's f/p/t/v (16 B per anchor) reuse B, which is dead once sorted.
+	// 20 B per anchor of scratch with two lives: the X / Y position lists of the two-bucket passes during the sort, then the
+	// run heads / ids and the chain's u[] afterwards.  The chain's f/p/t/v (16 B per anchor) reuse B, which is dead once sorted.
 	const u64 nA4 = ((nA + 1) * 4 + 15) & ~(u64)15;
-	L.scr.ensure(nA4 * 6 + 64);
-	u32 *fx = (u32*)L.scr.p, *fy = (u32*)((u8*)L.scr.p + nA4), *sx = (u32*)((u8*)L.scr.p + 2 * nA4), *sy = (u32*)((u8*)L.scr.p + 3 * nA4),
-	    *hx = (u32*)((u8*)L.scr.p + 4 * nA4), *py = (u32*)((u8*)L.scr.p + 5 * nA4);
-	u32 *d_head = fx; u64 *d_gid = (u64*)((u8*)L.scr.p + nA4), *d_cu = (u64*)((u8*)L.scr.p + 3 * nA4);
+	L.scr.ensure(nA4 * 5 + 64);
+	u32 *hx = (u32*)L.scr.p, *py = (u32*)((u8*)L.scr.p + nA4);
+	u32 *d_head = (u32*)L.scr.p; u64 *d_gid = (u64*)((u8*)L.scr.p + nA4), *d_cu = (u64*)((u8*)L.scr.p + 3 * nA4);
 	i32 *d_cf = (i32*)L.B.p, *d_cp = (i32*)((u8*)L.B.p + nA4), *d_ct = (i32*)((u8*)L.B.p + 2 * nA4), *d_cv = (i32*)((u8*)L.B.p + 3 * nA4);
 	if (nj) {
 		StageTimer t(this, L.stream, "k_seed_emit", nj * 32 + nA * 24);
@@ -396,16 +395,8 @@ void lqcov_handle::map_batch(MapLane &L, Part &pt, u32 q0, u32 q1, const std::ve
 				u32 n_walk = 0;
 				for (int c = 0; c < LQ_WALK_CLASSES; ++c) n_walk += cw[1 + c];
 				if (n_two) {                                        // closed-form two-bucket passes (the strand bit at the top level)
-					StageTimer t(this, L.stream, "k_sort_two_bucket", nA * 60);
-					dzero(fx, (nA + 1) * 4, L.stream); dzero(fy, (nA + 1) * 4, L.stream);
-					LQ_LAUNCH(k_two_flags, n_two, 256, L.stream, cur, L.seg_info.as<SegInfo>(), L.two_list.as<u32>(), n_two, L.sort_d.as<u8>(), fx, fy);
-					check_launch();
-					L.prim.exclusive_scan_u32_u32(fx, sx, nA + 1);
-					L.prim.exclusive_scan_u32_u32(fy, sy, nA + 1);
-					LQ_LAUNCH(k_two_positions, n_two, 256, L.stream, cur, L.two_list.as<u32>(), n_two, fx, fy, sx, sy, hx, py);
-					check_launch();
-					LQ_LAUNCH(k_two_dst, n_two, 256, L.stream, cur, L.seg_info.as<SegInfo>(), L.two_list.as<u32>(), n_two, L.sort_d.as<u8>(),
-					          sx, sy, hx, py, L.sort_dst.as<u32>());
+					StageTimer t(this, L.stream, "k_sort_two", nA * 6);
+					LQ_LAUNCH(k_sort_two, n_two, LQ_TWO_THREADS, L.stream, cur, L.seg_info.as<SegInfo>(), L.two_list.as<u32>(), n_two, L.sort_d.as<u8>(), hx, py, L.sort_dst.as<u32>());
 					check_launch();
 				}
 				if (n_walk) {

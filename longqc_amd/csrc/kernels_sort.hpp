@@ -134,57 +134,89 @@ __global__ void k_sort_classify(const SortSeg *segs, u32 n_segs, const u32 *hist
 // of R0 in place and drops Y_t into the hole of X_t; in R1 it cuts the slots into runs that end at
 // Y_0, Y_1, ...: X_t lands on the first slot of run t and the run's own elements shift right by one;
 // everything after Y_{m-1} stays.
-__global__ void k_two_flags(const SortSeg *segs, const SegInfo *info, const u32 *two_list, u32 n_two, const u8 *D, u32 *fX, u32 *fY)
+// One block per sub-array, two sweeps over its digit bytes in tiles of 256 x 16 elements; every tile counts its X / Y
+// elements per thread, scans the counts in LDS and carries the running totals.  Sweep 1 lists the positions of X_0.. (HX)
+// and Y_0.. (PY) in this sub-array's slice of two scratch arrays, sweep 2 recomputes the same ranks and writes dst.
+#define LQ_TWO_THREADS 256
+#define LQ_TWO_TILE (LQ_TWO_THREADS * 16)
+struct TwoTile { u32 x, y; };
+// exclusive ranks of thread t's 16 elements among the tile's X / Y elements; totals of the tile in tot
+#define LQ_TWO_SCAN_TILE() \
+		LQ_BLOCK_LOOP(t) { \
+			const u64 p = tile + (u64)t * 16; \
+			u32 cx = 0, cy = 0; \
+			if (p < abs1) for (u32 k = 0; k < 16; ++k) { \
+				const u64 g = p + k; \
+				if (g >= off && g < abs1) { const u32 i = (u32)(g - off); const bool in0 = i < cnt0, is1 = D[g] == c1; cx += in0 && is1; cy += !in0 && !is1; } \
+			} \
+			cX[t] = cx; cY[t] = cy; \
+		} \
+		LQ_BLOCK_SYNC(); \
+		LQ_BLOCK_LOOP(t) { \
+			if (t < 16) { \
+				u32 ax = 0, ay = 0; \
+				for (u32 k = 0; k < 16; ++k) { const u32 vx = cX[t * 16 + k], vy = cY[t * 16 + k]; cX[t * 16 + k] = ax; cY[t * 16 + k] = ay; ax += vx; ay += vy; } \
+				gX[t] = ax; gY[t] = ay; \
+			} \
+		} \
+		LQ_BLOCK_SYNC();
+__global__ void __launch_bounds__(LQ_TWO_THREADS)
+k_sort_two(const SortSeg *segs, const SegInfo *info, const u32 *two_list, u32 n_two, const u8 *D, u32 *HX, u32 *PY, u32 *dst)
 {
-	u32 li = blockIdx.x;
+	LQ_SHARED u32 cX[LQ_TWO_THREADS], cY[LQ_TWO_THREADS], gX[16], gY[16];
+	const u32 li = blockIdx.x;
 	if (li >= n_two) return;
 	const u32 sgi = two_list[li];
 	const SortSeg sg = segs[sgi];
 	const SegInfo si = info[sgi];
-	for (u32 i = threadIdx.x; i < sg.len; i += blockDim.x) {
-		const bool in0 = i < si.cnt0, is1 = D[sg.off + i] == si.c1;
-		if (in0 && is1) fX[sg.off + i] = 1u;
-		else if (!in0 && !is1) fY[sg.off + i] = 1u;
-	}
-}
-
-__global__ void k_two_positions(const SortSeg *segs, const u32 *two_list, u32 n_two, const u32 *fX, const u32 *fY,
-                                const u32 *sX, const u32 *sY, u32 *HX, u32 *PY)
-{
-	u32 li = blockIdx.x;
-	if (li >= n_two) return;
-	const SortSeg sg = segs[two_list[li]];
-	for (u32 i = threadIdx.x; i < sg.len; i += blockDim.x) {
-		const u64 g = sg.off + i;
-		if (fX[g]) HX[sX[g]] = (u32)g;
-		if (fY[g]) PY[sY[g]] = (u32)g;
-	}
-}
-
-__global__ void k_two_dst(const SortSeg *segs, const SegInfo *info, const u32 *two_list, u32 n_two, const u8 *D,
-                          const u32 *sX, const u32 *sY, const u32 *HX, const u32 *PY, u32 *dst)
-{
-	u32 li = blockIdx.x;
-	if (li >= n_two) return;
-	const u32 sgi = two_list[li];
-	const SortSeg sg = segs[sgi];
-	const SegInfo si = info[sgi];
-	const u32 off = (u32)sg.off, cnt0 = si.cnt0;
-	const u32 bx = sX[sg.off], by = sY[sg.off];
-	const u32 m = sX[sg.off + sg.len] - bx;
-	for (u32 i = threadIdx.x; i < sg.len; i += blockDim.x) {
-		const u64 g = sg.off + i;
-		const bool in0 = i < cnt0, is1 = D[g] == si.c1;
-		u32 d;
-		if (in0) {
-			if (!is1) d = i;
-			else { const u32 t = sX[g] - bx; d = t == 0 ? cnt0 : PY[by + t - 1] - off + 1; }
-		} else {
-			const u32 t = sY[g] - by;
-			if (!is1) d = HX[bx + t] - off;
-			else d = t < m ? i + 1 : i;
+	const u64 off = sg.off, abs0 = off & ~(u64)15, abs1 = off + sg.len;
+	const u32 cnt0 = si.cnt0, c1 = si.c1;
+	u32 *hx = HX + off, *py = PY + off;
+	u32 bx = 0, by = 0;                                      // X / Y elements before this tile (block-uniform)
+	for (u64 tile = abs0; tile < abs1; tile += LQ_TWO_TILE) {
+		LQ_TWO_SCAN_TILE()
+		LQ_BLOCK_LOOP(t) {
+			u32 rx = bx + cX[t], ry = by + cY[t];
+			for (u32 g16 = 0; g16 < t / 16; ++g16) { rx += gX[g16]; ry += gY[g16]; }
+			const u64 p = tile + (u64)t * 16;
+			if (p < abs1) for (u32 k = 0; k < 16; ++k) {
+				const u64 g = p + k;
+				if (g >= off && g < abs1) {
+					const u32 i = (u32)(g - off); const bool in0 = i < cnt0, is1 = D[g] == c1;
+					if (in0 && is1) hx[rx++] = i;
+					else if (!in0 && !is1) py[ry++] = i;
+				}
+			}
 		}
-		dst[g] = d;
+		for (u32 g16 = 0; g16 < 16; ++g16) { bx += gX[g16]; by += gY[g16]; }
+		LQ_BLOCK_SYNC();
+	}
+	const u32 m = bx;                                        // as many X as Y
+	bx = 0; by = 0;
+	for (u64 tile = abs0; tile < abs1; tile += LQ_TWO_TILE) {
+		LQ_TWO_SCAN_TILE()
+		LQ_BLOCK_LOOP(t) {
+			u32 rx = bx + cX[t], ry = by + cY[t];
+			for (u32 g16 = 0; g16 < t / 16; ++g16) { rx += gX[g16]; ry += gY[g16]; }
+			const u64 p = tile + (u64)t * 16;
+			if (p < abs1) for (u32 k = 0; k < 16; ++k) {
+				const u64 g = p + k;
+				if (g >= off && g < abs1) {
+					const u32 i = (u32)(g - off); const bool in0 = i < cnt0, is1 = D[g] == c1;
+					u32 d;
+					if (in0) {
+						if (!is1) d = i;
+						else { d = rx == 0 ? cnt0 : py[rx - 1] + 1; ++rx; }      // X_t takes the first slot of run t
+					} else {
+						if (!is1) { d = hx[ry]; ++ry; }                           // Y_t drops into the hole of X_t
+						else d = ry < m ? i + 1 : i;                              // run elements shift right by one
+					}
+					dst[g] = d;
+				}
+			}
+		}
+		for (u32 g16 = 0; g16 < 16; ++g16) { bx += gX[g16]; by += gY[g16]; }
+		LQ_BLOCK_SYNC();
 	}
 }
 
