@@ -139,15 +139,20 @@ __global__ void k_sort_classify(const SortSeg *segs, u32 n_segs, const u32 *hist
 // and Y_0.. (PY) in this sub-array's slice of two scratch arrays, sweep 2 recomputes the same ranks and writes dst.
 #define LQ_TWO_THREADS 256
 #define LQ_TWO_TILE (LQ_TWO_THREADS * 16)
-struct TwoTile { u32 x, y; };
+struct alignas(16) TwoW16 { u32 w[4]; };
+// digit k of the 16 loaded at a 16-byte aligned position
+#define LQ_TWO_DIGIT(W, k) (((W).w[(k) >> 2] >> (((k) & 3) * 8)) & 0xffu)
 // exclusive ranks of thread t's 16 elements among the tile's X / Y elements; totals of the tile in tot
 #define LQ_TWO_SCAN_TILE() \
 		LQ_BLOCK_LOOP(t) { \
 			const u64 p = tile + (u64)t * 16; \
 			u32 cx = 0, cy = 0; \
-			if (p < abs1) for (u32 k = 0; k < 16; ++k) { \
-				const u64 g = p + k; \
-				if (g >= off && g < abs1) { const u32 i = (u32)(g - off); const bool in0 = i < cnt0, is1 = D[g] == c1; cx += in0 && is1; cy += !in0 && !is1; } \
+			if (p < abs1) { \
+				const TwoW16 W = *(const TwoW16*)(D + p); \
+				for (u32 k = 0; k < 16; ++k) { \
+					const u64 g = p + k; \
+					if (g >= off && g < abs1) { const u32 i = (u32)(g - off); const bool in0 = i < cnt0, is1 = LQ_TWO_DIGIT(W, k) == c1; cx += in0 && is1; cy += !in0 && !is1; } \
+				} \
 			} \
 			cX[t] = cx; cY[t] = cy; \
 		} \
@@ -179,12 +184,15 @@ k_sort_two(const SortSeg *segs, const SegInfo *info, const u32 *two_list, u32 n_
 			u32 rx = bx + cX[t], ry = by + cY[t];
 			for (u32 g16 = 0; g16 < t / 16; ++g16) { rx += gX[g16]; ry += gY[g16]; }
 			const u64 p = tile + (u64)t * 16;
-			if (p < abs1) for (u32 k = 0; k < 16; ++k) {
-				const u64 g = p + k;
-				if (g >= off && g < abs1) {
-					const u32 i = (u32)(g - off); const bool in0 = i < cnt0, is1 = D[g] == c1;
-					if (in0 && is1) hx[rx++] = i;
-					else if (!in0 && !is1) py[ry++] = i;
+			if (p < abs1) {
+				const TwoW16 W = *(const TwoW16*)(D + p);
+				for (u32 k = 0; k < 16; ++k) {
+					const u64 g = p + k;
+					if (g >= off && g < abs1) {
+						const u32 i = (u32)(g - off); const bool in0 = i < cnt0, is1 = LQ_TWO_DIGIT(W, k) == c1;
+						if (in0 && is1) hx[rx++] = i;
+						else if (!in0 && !is1) py[ry++] = i;
+					}
 				}
 			}
 		}
@@ -199,10 +207,12 @@ k_sort_two(const SortSeg *segs, const SegInfo *info, const u32 *two_list, u32 n_
 			u32 rx = bx + cX[t], ry = by + cY[t];
 			for (u32 g16 = 0; g16 < t / 16; ++g16) { rx += gX[g16]; ry += gY[g16]; }
 			const u64 p = tile + (u64)t * 16;
-			if (p < abs1) for (u32 k = 0; k < 16; ++k) {
+			if (p < abs1) {
+				const TwoW16 W = *(const TwoW16*)(D + p);
+				for (u32 k = 0; k < 16; ++k) {
 				const u64 g = p + k;
 				if (g >= off && g < abs1) {
-					const u32 i = (u32)(g - off); const bool in0 = i < cnt0, is1 = D[g] == c1;
+					const u32 i = (u32)(g - off); const bool in0 = i < cnt0, is1 = LQ_TWO_DIGIT(W, k) == c1;
 					u32 d;
 					if (in0) {
 						if (!is1) d = i;
@@ -212,6 +222,7 @@ k_sort_two(const SortSeg *segs, const SegInfo *info, const u32 *two_list, u32 n_
 						else d = ry < m ? i + 1 : i;                              // run elements shift right by one
 					}
 					dst[g] = d;
+				}
 				}
 			}
 		}
