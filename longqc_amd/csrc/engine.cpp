@@ -337,6 +337,8 @@ void lqcov_handle::build_part(Part &pt)
 void lqcov_handle::map_batch(MapLane &L, Part &pt, u32 q0, u32 q1, const std::vector<u64> &h_aq, const std::vector<u64> &h_qmoff, bool dbg)
 {
 	const u32 n_q = q.n;
+	L.gate_passed = false;
+	struct GateGuard { lqcov_handle *h; MapLane &L; ~GateGuard() { if (!L.gate_passed) { L.gate_passed = true; h->open_gate(); } } } gate_guard{this, L};
 	L.n_segs.ensure(64); L.n_ivl.ensure(4);
 	const u64 a_base = h_aq[q0], nA = h_aq[q1] - a_base;
 	const u32 nqb = q1 - q0;
@@ -386,7 +388,7 @@ void lqcov_handle::map_batch(MapLane &L, Part &pt, u32 q0, u32 q1, const std::ve
 					LQ_LAUNCH(k_sort_copy_hist, ns, 256, L.stream, cur, ns, dA, dB, L.sort_d.as<u8>(), L.hist.as<u32>());
 					check_launch();
 				}
-				LQ_LAUNCH(k_sort_classify, nblk(ns, 64), 64, L.stream, cur, ns, L.hist.as<u32>(), L.begs.as<u32>(), L.seg_info.as<SegInfo>(),
+				LQ_LAUNCH(k_sort_classify, ns, LQ_CLASSIFY_THREADS, L.stream, cur, ns, L.hist.as<u32>(), L.begs.as<u32>(), L.seg_info.as<SegInfo>(),
 				          L.walk_list.as<u32>(), L.two_list.as<u32>(), L.n_segs.as<u32>() + 2, wcaps);
 				check_launch();
 				u32 cw[1 + LQ_WALK_CLASSES];
@@ -430,6 +432,8 @@ void lqcov_handle::map_batch(MapLane &L, Part &pt, u32 q0, u32 q1, const std::ve
 							LQ_LAUNCH(k_sort_walk, nblk(n_long, LQ_WALK_LANES), LQ_WALK_LANES, L.stream, cur, L.walk_list2.as<u32>(), n_long, dD, dH, dBg, dDst);
 							check_launch();
 						} else {
+							// the longest of these walks outlasts everything else in the batch on a handful of CUs: let the next lane start now
+							if (!L.gate_passed) { L.gate_passed = true; open_gate(); }
 							StageTimer t(this, L.stream, "k_sort_walk_solo", long_elems * 5);
 							LQ_LAUNCH(k_sort_walk_solo, n_long, 64, L.stream, cur, L.walk_list2.as<u32>(), n_long, dD, dH, dBg, dDst);
 							check_launch();
@@ -473,19 +477,14 @@ void lqcov_handle::map_batch(MapLane &L, Part &pt, u32 q0, u32 q1, const std::ve
 		cs.dbg = dbg ? dbg_chains.as<ChainRec>() : nullptr; cs.n_dbg = n_dbg.as<unsigned long long>(); cs.dbg_cap = dbg_cap;
 		if (n_groups > 0xfffffff0ULL) throw std::domain_error("too many anchor runs in one batch");
 		const int wave_min = getenv("LQCOV_CHAIN_WAVE_MIN") ? std::max(1, atoi(getenv("LQCOV_CHAIN_WAVE_MIN"))) : LQ_CHAIN_WAVE_MIN;   // test knob
-		// LDS-resident DP for runs <= 16 anchors: off by default -- measured slower on MI355X (54 KiB of LDS per 64 lanes caps
-		// occupancy at 3 waves per CU: 160 + 40 ms vs 113 ms for the global-scratch kernel at configs[1]); LQCOV_CHAIN_SMALL=1 enables
-		const int small_max = getenv("LQCOV_CHAIN_SMALL") && atoi(getenv("LQCOV_CHAIN_SMALL")) ? std::min<int>(LQ_CHAIN_SMALL, wave_min - 1) : (int)P.min_cnt - 1;
-		{	// one thread per run, in array order (most lanes retire at once; the few longer runs of a wave then keep
-			// their working set in the CU's L1).  Measured alternatives that were slower on MI355X: a compacted
-			// longest-first work list for all runs (409 vs 292 ms at configs[1]) and private-array DP for short runs.
+		{	// one thread per run, in array order, DP state of a wave's runs packed into LDS.  Measured alternatives that were
+			// slower on MI355X: a compacted longest-first work list for all runs (409 vs 292 ms at configs[1]), private-array
+			// DP for short runs, and a fixed [16][64] LDS column per lane (54 KiB per wave: 160 + 40 ms vs 113 ms).
 			StageTimer t(this, L.stream, "k_chain", nA * 16);
-			LQ_LAUNCH(k_chain, nblk(n_groups, 64), 64, L.stream, dA, L.gstart.as<u64>(), (const u32*)nullptr, (u32)n_groups, aqb, a_base, nqb, q0, avg_qspan.as<float>(), mp, cb, cs, (i32)(small_max + 1), (i32)(wave_min - 1));
-			check_launch();
-		}
-		if (small_max >= P.min_cnt) {	// short runs: DP state in LDS
-			StageTimer t(this, L.stream, "k_chain_small", nA * 16);
-			LQ_LAUNCH(k_chain_small, nblk(n_groups, 64), 64, L.stream, dA, L.gstart.as<u64>(), n_groups, aqb, a_base, nqb, q0, avg_qspan.as<float>(), mp, cs, (i32)small_max);
+			const int cap = getenv("LQCOV_CHAIN_CAP") ? atoi(getenv("LQCOV_CHAIN_CAP")) : 128;   // A/B + test knob: LDS anchors per wave
+#define LQ_CHAIN_LAUNCH(CAP) LQ_LAUNCH((k_chain<CAP>), nblk(n_groups, 64), 64, L.stream, dA, L.gstart.as<u64>(), (const u32*)nullptr, (u32)n_groups, aqb, a_base, nqb, q0, avg_qspan.as<float>(), mp, cb, cs, (i32)P.min_cnt, (i32)(wave_min - 1))
+			if (cap <= 16) { LQ_CHAIN_LAUNCH(16); } else if (cap <= 128) { LQ_CHAIN_LAUNCH(128); } else { LQ_CHAIN_LAUNCH(256); }
+#undef LQ_CHAIN_LAUNCH
 			check_launch();
 		}
 		{	// long runs (the tail of the kernel above if left there): one wave per run, longest first
@@ -533,6 +532,12 @@ void lqcov_handle::map_batch(MapLane &L, Part &pt, u32 q0, u32 q1, const std::ve
 			check_launch();
 		}
 	}
+}
+
+void lqcov_handle::open_gate()
+{
+	{ std::lock_guard<std::mutex> lk(gate_mu); ++gate_count; }
+	gate_cv.notify_all();
 }
 
 // ---- map every query against one part (lqmap.c:207-326) -----------------------------------------
@@ -621,6 +626,7 @@ void lqcov_handle::map_part(Part &pt)
 		for (auto &L : lanes) LQ_HIP_CHECK(hipStreamSynchronize(L->stream));
 	} else {
 		std::atomic<size_t> next(0);
+		{ std::lock_guard<std::mutex> lk(gate_mu); gate_count = 0; }
 		std::vector<std::exception_ptr> errs(n_lanes);
 		std::vector<std::thread> th;
 		for (int li = 0; li < n_lanes; ++li)
@@ -628,13 +634,18 @@ void lqcov_handle::map_part(Part &pt)
 				try {
 					LQ_HIP_CHECK(hipSetDevice(device));
 					MapLane &L = *lanes[li];
+					{	// staggered start: lane li begins when li batches have reached their long walks (or ended), so that
+						// one lane's serial tails run under another lane's wide kernels instead of side by side
+						std::unique_lock<std::mutex> lk(gate_mu);
+						gate_cv.wait(lk, [&] { return gate_count >= li || next.load() >= batches.size(); });
+					}
 					for (;;) {
 						const size_t i = next.fetch_add(1);
 						if (i >= batches.size()) break;
 						map_batch(L, pt, batches[i].first, batches[i].second, h_aq, h_qmoff, dbg);
 					}
 					LQ_HIP_CHECK(hipStreamSynchronize(L.stream));
-				} catch (...) { errs[li] = std::current_exception(); next.store(batches.size()); }
+				} catch (...) { errs[li] = std::current_exception(); next.store(batches.size()); gate_cv.notify_all(); }
 			});
 		for (auto &t : th) t.join();
 		for (auto &e : errs) if (e) { hipDeviceSynchronize(); std::rethrow_exception(e); }

@@ -14,6 +14,7 @@
 #include <map>
 #include <memory>
 #include <mutex>
+#include <condition_variable>
 #include <thread>
 #include <atomic>
 #include <exception>
@@ -49,6 +50,7 @@ struct Part {
 struct MapLane {
 	hipStream_t stream = nullptr;
 	Prim prim;
+	bool gate_passed = false;             // this batch has reached its long walks (see map_part)
 	DBuf A, B, segs0, segs1, n_segs, hist, begs;
 	DBuf sort_d, sort_dst, seg_info, walk_list, two_list, scr, wkey, wkey2, walk_list2, walk_list3;
 	DBuf gflag, gidx, gsel, gkey, gsel2, gkey2, gstart;
@@ -83,6 +85,7 @@ struct lqcov_handle {
 	std::vector<std::unique_ptr<MapLane>> lanes;
 	int n_lanes = 2;
 	std::mutex pv_mu; u64 pv_reserved = 0;
+	std::mutex gate_mu; std::condition_variable gate_cv; int gate_count = 0;   // staggered lane start
 	DBuf dbg_chains, n_dbg; u64 dbg_cap = 0; u64 n_dbg_host = 0;
 	DBuf misc;
 	DBuf ix_key, ix_key2, ix_head, ix_uidx, ix_ukey, ix_ustart, ix_ucnt, ix_sorted;   // build_index workspaces
@@ -103,6 +106,7 @@ struct lqcov_handle {
 	void set_queries(u32 n, const u8 *seq, const u64 *seq_off, const u8 *qual, const char *names, const u64 *name_off);
 	void build_index(Part &pt);
 	void build_part(Part &pt);
+	void open_gate();
 	void map_part(Part &pt);
 	void map_batch(MapLane &L, Part &pt, u32 q0, u32 q1, const std::vector<u64> &h_aq, const std::vector<u64> &h_qmoff, bool dbg);
 	void reset();

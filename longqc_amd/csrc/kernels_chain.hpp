@@ -310,21 +310,55 @@ __device__ __forceinline__ bool lq_run_viable(AP a, i64 n, const MapParams &P)
 
 // aq_off: the batch's view of the per-query anchor offsets (n_q+1 entries, absolute; the batch's
 // anchors start at a_base); q0: global index of the batch's first query.
-// Long runs: one thread per run, DP state in global scratch (indexed like the anchors).
-__global__ void k_chain(const mm128 *A, const u64 *gstart, const u32 *glist, u32 n_list, const u64 *aq_off, u64 a_base, u32 n_q, u32 q0,
-                        const float *avg_qspan_q, MapParams P, ChainBufs B, CovState C, i32 min_len, i32 max_len)
+// One thread per run of min_len..max_len anchors, in array order.  The serial DP is a chain of dependent, scattered
+// accesses to the run's anchors and DP arrays; with 64 unrelated working sets per wave those are L2 round trips.  So
+// the wave packs the runs it will actually chain (most runs are too short or cannot reach min_sc) into LDS -- anchors
+// plus f/p/t/v/u, 40 B per anchor, offsets from a scan of the run lengths -- and each lane works on its slice there.
+// Runs that do not fit the LDS budget use the global scratch arrays (indexed like the anchors).
+template <int LQ_CHAIN_LDS_CAP>
+__global__ void __launch_bounds__(64)
+k_chain(const mm128 *A, const u64 *gstart, const u32 *glist, u32 n_list, const u64 *aq_off, u64 a_base, u32 n_q, u32 q0,
+        const float *avg_qspan_q, MapParams P, ChainBufs B, CovState C, i32 min_len, i32 max_len)
 {
-	u32 gi = blockIdx.x * blockDim.x + threadIdx.x;
-	if (gi >= n_list) return;
-	const u32 g = glist ? glist[gi] : gi;
-	const u64 gs = gstart[g];
-	const i64 n = (i64)(gstart[g + 1] - gs);
-	if (n < min_len || n > max_len) return;
-	if (!lq_run_viable(A + gs, n, P)) return;
-	const u32 q = q0 + lq_find_seg(aq_off, n_q, gs + a_base);
-	const bool accumulate = !C.skip[q];
-	if (!accumulate && !C.dbg) return;
-	lq_chain_run(A + gs, n, B.f + gs, B.p + gs, B.t + gs, B.v + gs, B.u + gs, q, accumulate, avg_qspan_q, P, C);
+	LQ_SHARED mm128 s_a[LQ_CHAIN_LDS_CAP];
+	LQ_SHARED i32 s_f[LQ_CHAIN_LDS_CAP], s_p[LQ_CHAIN_LDS_CAP], s_t[LQ_CHAIN_LDS_CAP], s_v[LQ_CHAIN_LDS_CAP];
+	LQ_SHARED u64 s_u[LQ_CHAIN_LDS_CAP];
+	LQ_SHARED u32 s_n[64], s_q[64];
+	const u32 gi0 = blockIdx.x * blockDim.x;
+	LQ_BLOCK_LOOP(ln) {
+		u32 todo = 0;
+		const u32 gi = gi0 + ln;
+		if (gi < n_list) {
+			const u32 g = glist ? glist[gi] : gi;
+			const u64 gs = gstart[g];
+			const i64 n = (i64)(gstart[g + 1] - gs);
+			if (n >= min_len && n <= max_len && lq_run_viable(A + gs, n, P)) {
+				const u32 q = q0 + lq_find_seg(aq_off, n_q, gs + a_base);
+				if (!C.skip[q] || C.dbg) { todo = (u32)n; s_q[ln] = q; }
+			}
+		}
+		s_n[ln] = todo;
+	}
+	LQ_BLOCK_SYNC();
+	LQ_BLOCK_LOOP(ln) {
+		const u32 n32 = s_n[ln];
+		if (n32) {
+			u32 off = 0;
+			for (u32 z = 0; z < ln; ++z) off += s_n[z];
+			const u32 gi = gi0 + ln;
+			const u32 g = glist ? glist[gi] : gi;
+			const u64 gs = gstart[g];
+			const i64 n = (i64)n32;
+			const u32 q = s_q[ln];
+			const bool accumulate = !C.skip[q];
+			if (off + n32 <= LQ_CHAIN_LDS_CAP) {
+				mm128 *la = s_a + off;
+				for (i64 i = 0; i < n; ++i) la[i] = A[gs + i];
+				lq_chain_run(la, n, s_f + off, s_p + off, s_t + off, s_v + off, s_u + off, q, accumulate, avg_qspan_q, P, C);
+			} else
+				lq_chain_run(A + gs, n, B.f + gs, B.p + gs, B.t + gs, B.v + gs, B.u + gs, q, accumulate, avg_qspan_q, P, C);
+		}
+	}
 }
 
 // Long runs, one wave per run.  A chain kernel ends when its longest run ends, and the serial DP of a repeat-rich
@@ -425,38 +459,6 @@ k_chain_wave(const mm128 *A, const u64 *gstart, const u32 *glist, u32 n_list, co
 		LQ_BLOCK_SYNC();
 	}
 	LQ_BLOCK_LOOP(ln) { if (ln == 0) lq_chain_finish(a, n, f, p, t, v, u, q, accumulate, P, C); }
-}
-
-// Short runs (the bulk: chance hits put a handful of anchors on most (strand, target) pairs): one thread per run
-// with the anchors and the whole DP state in LDS, one column per lane ([slot][64], lane-minor) -- instead of 64
-// unrelated global working sets per wave (rocprofv3: k_chain wrote 51 GiB per launch for 12.6 GB of anchors).
-#define LQ_CHAIN_SMALL 16
-template <class T> struct LanePtr {                          // element i of this lane's column
-	T *b;
-	__device__ __forceinline__ T &operator[](i64 i) const { return b[i * 64]; }
-};
-__global__ void __launch_bounds__(64)
-k_chain_small(const mm128 *A, const u64 *gstart, u64 n_groups, const u64 *aq_off, u64 a_base, u32 n_q, u32 q0,
-              const float *avg_qspan_q, MapParams P, CovState C, i32 max_len)
-{
-	LQ_SHARED mm128 s_a[LQ_CHAIN_SMALL][64];
-	LQ_SHARED i32 s_f[LQ_CHAIN_SMALL][64], s_p[LQ_CHAIN_SMALL][64], s_t[LQ_CHAIN_SMALL][64], s_v[LQ_CHAIN_SMALL][64];
-	LQ_SHARED u64 s_u[LQ_CHAIN_SMALL][64];
-	u64 g = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-	if (g >= n_groups) return;
-	const u64 gs = gstart[g];
-	const i64 n = (i64)(gstart[g + 1] - gs);
-	if (n > max_len || n > LQ_CHAIN_SMALL) return;
-	if (!lq_run_viable(A + gs, n, P)) return;
-	const u32 q = q0 + lq_find_seg(aq_off, n_q, gs + a_base);
-	const bool accumulate = !C.skip[q];
-	if (!accumulate && !C.dbg) return;
-	const u32 ln = threadIdx.x;
-	LanePtr<mm128> la; la.b = &s_a[0][ln];
-	LanePtr<i32> f, p, t, v; f.b = &s_f[0][ln]; p.b = &s_p[0][ln]; t.b = &s_t[0][ln]; v.b = &s_v[0][ln];
-	LanePtr<u64> u; u.b = &s_u[0][ln];
-	for (i64 i = 0; i < n; ++i) la[i] = A[gs + i];
-	lq_chain_run(la, n, f, p, t, v, u, q, accumulate, avg_qspan_q, P, C);
 }
 
 // ---- filter_redundant_coords (lqmap.c:25-100), one thread per query, on this part's intervals ----

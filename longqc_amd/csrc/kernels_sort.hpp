@@ -104,19 +104,51 @@ __device__ __forceinline__ u32 lq_walk_class(u32 len, const WalkCaps &w)
 }
 
 // walk_list holds LQ_WALK_CLASSES lists of n_segs entries each; counters = [n_two, n_walk[0..4]]
-__global__ void k_sort_classify(const SortSeg *segs, u32 n_segs, const u32 *hist, u32 *begs, SegInfo *info,
-                                u32 *walk_list, u32 *two_list, u32 *counters, WalkCaps caps)
+// One wave per sub-array: bucket offsets (exclusive scan of the 256 counts, four per lane) and the kind of pass.
+#define LQ_CLASSIFY_THREADS 64
+__global__ void __launch_bounds__(LQ_CLASSIFY_THREADS)
+k_sort_classify(const SortSeg *segs, u32 n_segs, const u32 *hist, u32 *begs, SegInfo *info,
+                u32 *walk_list, u32 *two_list, u32 *counters, WalkCaps caps)
 {
-	u32 sgi = blockIdx.x * blockDim.x + threadIdx.x;
+	const u32 sgi = blockIdx.x;
 	if (sgi >= n_segs) return;
 	const u32 *cnt = hist + (u64)sgi * 256;
 	u32 *bg = begs + (u64)sgi * 256;
-	u32 acc = 0, nz = 0, c0 = 0, c1 = 0;
+	u32 nz = 0, c0 = 0, c1 = 0;
+#ifdef LQ_EMU
+	if (threadIdx.x != 0) return;
+	u32 acc = 0;
 	for (u32 c = 0; c < 256; ++c) {
 		u32 n = cnt[c];
 		bg[c] = acc; acc += n;
 		if (n) { if (nz == 0) c0 = c; else if (nz == 1) c1 = c; ++nz; }
 	}
+#else
+	const u32 lane = threadIdx.x;
+	const uint4 v = *(const uint4*)(cnt + 4 * lane);
+	const u32 s1 = v.x, s2 = s1 + v.y, s3 = s2 + v.z, s4 = s3 + v.w;
+	u32 inc = s4;                                             // inclusive scan of the lane sums
+	for (int d = 1; d < 64; d <<= 1) { const u32 o = __shfl_up(inc, d); if ((int)lane >= d) inc += o; }
+	const u32 ex = inc - s4;
+	uint4 o4; o4.x = ex; o4.y = ex + s1; o4.z = ex + s2; o4.w = ex + s3;
+	*(uint4*)(bg + 4 * lane) = o4;
+	const u32 m4 = (v.x != 0) | (v.y != 0) << 1 | (v.z != 0) << 2 | (v.w != 0) << 3;
+	const u32 nzl = __popc(m4);
+	nz = __popcll(__ballot(nzl & 1)) + 2 * __popcll(__ballot(nzl & 2)) + 4 * __popcll(__ballot(nzl & 4));
+	const u64 any = __ballot(m4 != 0);
+	if (any) {
+		const u32 f = (u32)__builtin_ctzll(any);
+		const u32 mf = (u32)__builtin_amdgcn_readlane((int)m4, (int)f);
+		c0 = 4 * f + (u32)__builtin_ctz(mf);
+		const u32 rest = mf & (mf - 1);
+		if (rest) c1 = 4 * f + (u32)__builtin_ctz(rest);
+		else {
+			const u64 any2 = any & (any - 1);
+			if (any2) { const u32 g = (u32)__builtin_ctzll(any2); c1 = 4 * g + (u32)__builtin_ctz((u32)__builtin_amdgcn_readlane((int)m4, (int)g)); }
+		}
+	}
+	if (lane != 0) return;
+#endif
 	SegInfo si; si.c0 = c0; si.c1 = c1; si.cnt0 = cnt[c0];
 	if (nz <= 1) si.kind = LQ_SEG_IDENTITY;                  // one bucket holds everything: the pass is the identity
 	else if (nz == 2) { si.kind = LQ_SEG_TWO; two_list[atomicAdd(&counters[0], 1u)] = sgi; }

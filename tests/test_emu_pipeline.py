@@ -116,11 +116,15 @@ def test_emulated_chains_mid_occ_and_accumulators(emu_lib, name, tfn, qfn):
     eng.close()
 
 
-def test_emulated_query_batching_is_invisible(emu_lib, datasets, monkeypatch):
+@pytest.mark.parametrize("lanes", ["1", "2", "3"])
+def test_emulated_query_batching_is_invisible(emu_lib, datasets, monkeypatch, lanes):
+    """many small query batches dealt to 1..3 mapping lanes (own stream + work space each; concurrent threads on the GPU,
+    round-robin in the emulator): same table"""
     tf, qf = datasets("small")
     argv = ["-Y", "-l", "0", "-q", "160", "-k", "12", "-w", "5", "-I", "700K", "-p", "160", tf, qf]
     want = oracle_bind.table(argv)
     monkeypatch.setenv("LQCOV_ANCHOR_BUDGET", "3000")
+    monkeypatch.setenv("LQCOV_LANES", lanes)
     rc, out, err = run_main(emu_lib, argv)
     assert rc == 0, err
     assert out == want
@@ -159,6 +163,16 @@ def test_emulated_every_walk_size_class(emu_lib, datasets, monkeypatch, shift):
 def test_emulated_wave_chain_kernel_on_every_run(emu_lib, case, monkeypatch):
     """LQCOV_CHAIN_WAVE_MIN=3 sends every viable run through the cooperative (64 candidates per step) chain kernel"""
     monkeypatch.setenv("LQCOV_CHAIN_WAVE_MIN", "3")
+    rc, out, err = run_main(emu_lib, case["argv"], cwd=GOLDEN)
+    assert rc == 0, err
+    assert out == read_gz(case["expect"])
+
+
+@pytest.mark.parametrize("case", [c for c in _cases("table") if c["name"] in ("tiny_ont", "adv_ont", "adv_parts", "tiny_spike")], ids=lambda c: c["name"])
+def test_emulated_chain_lds_budget_overflow(emu_lib, case, monkeypatch):
+    """LQCOV_CHAIN_CAP=16: only 16 anchors per wave fit the LDS staging of k_chain, every other run takes the
+    global-scratch path"""
+    monkeypatch.setenv("LQCOV_CHAIN_CAP", "16")
     rc, out, err = run_main(emu_lib, case["argv"], cwd=GOLDEN)
     assert rc == 0, err
     assert out == read_gz(case["expect"])

@@ -80,7 +80,7 @@ def test_gpu_table_equals_oracle_on_synthetic_sets(gpu_lib, datasets, name, vari
 
 
 def test_gpu_query_batching_is_invisible(gpu_lib, datasets, monkeypatch):
-    E.test_emulated_query_batching_is_invisible(gpu_lib, datasets, monkeypatch)
+    E.test_emulated_query_batching_is_invisible(gpu_lib, datasets, monkeypatch, "2")
 
 
 def test_gpu_midsize_slice_of_cfg2_vs_reference_or_oracle(gpu_lib, tmp_path):
@@ -191,3 +191,14 @@ def test_gpu_wave_chain_and_lane_walker_variants_on_cfg1(gpu_lib, datasets, monk
     rc, out, err = run_main(gpu_lib, argv)
     assert rc == 0, err
     assert out == want
+
+
+@pytest.mark.parametrize("lanes", ["1", "3"])
+def test_gpu_concurrent_mapping_lanes(gpu_lib, datasets, monkeypatch, lanes):
+    """small query batches on 1 and 3 concurrent mapping lanes (threads + streams) against the oracle"""
+    E.test_emulated_query_batching_is_invisible(gpu_lib, datasets, monkeypatch, lanes)
+
+
+@pytest.mark.parametrize("case", [c for c in _cases("table") if c["name"] in ("tiny_ont", "adv_parts")], ids=lambda c: c["name"])
+def test_gpu_chain_lds_budget_overflow(gpu_lib, case, monkeypatch):
+    E.test_emulated_chain_lds_budget_overflow(gpu_lib, case, monkeypatch)
