@@ -135,6 +135,9 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    # per-kernel HIP events on the streams the kernels are launched on, recorded during the timed steps themselves
+    # (level 2: nothing waits for them; they are read after the closing barrier)
+    eng.set_profiling(2)
     barrier()
     t0 = time.time()
     for _ in range(args.steps):
@@ -152,12 +155,8 @@ def main():
     ms_per_step = dt / max(args.steps, 1) * 1e3
     value = total_bases / (ms_per_step / 1e3) / 1e6
 
-    # one more, profiled, step: per-kernel device time from HIP events on the engine's stream
-    eng.set_profiling(True)
-    step()
-    eng.sync()
     st = [s for s in eng.stage_times() if s["name"].startswith("k_") or s["name"].startswith("index_")]
-    eng.set_profiling(False)
+    eng.set_profiling(0)
     n_anchors = eng.last_n_anchors
     roof = None
     if st:
@@ -165,10 +164,13 @@ def main():
         per_launch_ms = dom["total_ms"] / max(dom["launches"], 1)
         per_launch_bytes = dom["algo_bytes"] / max(dom["launches"], 1)
         ach = per_launch_bytes / (per_launch_ms / 1e3) / 1e9 if per_launch_ms > 0 else 0.0
+        k = max(args.steps, 1)
         roof = {"kernel": dom["name"], "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None,
                 "launches": dom["launches"], "avg_launch_ms": round(per_launch_ms, 4), "algo_bytes_per_launch": int(per_launch_bytes),
-                "kernel_ms": {s["name"]: round(s["total_ms"], 3) for s in sorted(st, key=lambda s: -s["total_ms"])}}
+                "timing": "HIP events around every launch inside the timed steps, on the launching stream; mapping lanes overlap, "
+                          "so the per-step kernel times below add up to more than ms_per_step",
+                "kernel_ms_per_step": {s["name"]: round(s["total_ms"] / k, 3) for s in sorted(st, key=lambda s: -s["total_ms"])}}
     if world > 1:
         barrier()
     if rank == 0:

@@ -109,7 +109,7 @@ lqcov_handle *lqcov_create(const lqcov_params *p, int device);            /* NUL
 void lqcov_destroy(lqcov_handle *h);
 const char *lqcov_last_error(const lqcov_handle *h);
 int  lqcov_abi_version(void);
-int  lqcov_set_profiling(lqcov_handle *h, int on);
+int  lqcov_set_profiling(lqcov_handle *h, int on);                         /* 0 off; 1 wait for every kernel (exclusive per-kernel times); 2 record events only, no waits */
 int  lqcov_set_debug(lqcov_handle *h, unsigned flags);                     /* bit0: record chains for lqcov_get_chains */
 int  lqcov_get_stage_times(lqcov_handle *h, lqcov_stage_time *out, int max_out);   /* returns count */
 

@@ -311,7 +311,7 @@ class Engine:
         return out
 
     def set_profiling(self, on: bool):
-        self._ck(self.lib.lqcov_set_profiling(self.h, 1 if on else 0))
+        self._ck(self.lib.lqcov_set_profiling(self.h, int(on)))
 
     def stage_times(self) -> List[dict]:
         arr = (StageTime * 64)()

@@ -165,12 +165,20 @@ lqcov_handle *lqcov_create(const lqcov_params *p, int device)
 }
 void lqcov_destroy(lqcov_handle *h) { delete h; }
 const char *lqcov_last_error(const lqcov_handle *h) { return h ? h->err.c_str() : g_create_error.c_str(); }
-int lqcov_set_profiling(lqcov_handle *h, int on) { if (!h) return LQCOV_E_ARG; h->profiling = on != 0; if (!on) { h->stages.clear(); h->stage_order.clear(); } return 0; }
+int lqcov_set_profiling(lqcov_handle *h, int on)
+{
+	if (!h) return LQCOV_E_ARG;
+	h->drain_stages();
+	h->profiling = on < 0 ? 0 : on > 2 ? 2 : on;
+	if (!on) { h->stages.clear(); h->stage_order.clear(); }
+	return 0;
+}
 int lqcov_set_debug(lqcov_handle *h, unsigned flags) { if (!h) return LQCOV_E_ARG; h->debug_flags = flags; return 0; }
 
 int lqcov_get_stage_times(lqcov_handle *h, lqcov_stage_time *out, int max_out)
 {
 	if (!h) return LQCOV_E_ARG;
+	h->drain_stages();
 	int n = 0;
 	for (const std::string &name : h->stage_order) {
 		if (n >= max_out) break;

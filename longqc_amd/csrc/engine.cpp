@@ -42,12 +42,22 @@ StageTimer::~StageTimer()
 {
 	if (!h->profiling) return;
 	hipEventRecord(b, s);
-	hipEventSynchronize(b);
+	if (h->profiling == 1) { hipEventSynchronize(b); h->account_stage(name, a, b, bytes); }
+	else { std::lock_guard<std::mutex> g(h->stage_mu); h->stage_pending.push_back(lqcov_handle::StagePending{name, a, b, bytes}); }   // read later: nothing waits here
+}
+void lqcov_handle::account_stage(const char *name, hipEvent_t a, hipEvent_t b, u64 bytes)
+{
 	float ms = 0; hipEventElapsedTime(&ms, a, b);
 	hipEventDestroy(a); hipEventDestroy(b);
-	auto it = h->stages.find(name);
-	if (it == h->stages.end()) { h->stage_order.push_back(name); it = h->stages.emplace(name, StageAcc()).first; }
+	auto it = stages.find(name);
+	if (it == stages.end()) { stage_order.push_back(name); it = stages.emplace(name, StageAcc()).first; }
 	it->second.ms += ms; it->second.launches += 1; it->second.bytes += bytes;
+}
+void lqcov_handle::drain_stages()
+{
+	std::lock_guard<std::mutex> g(stage_mu);
+	for (lqcov_handle::StagePending &sp : stage_pending) { hipEventSynchronize(sp.b); account_stage(sp.name, sp.a, sp.b, sp.bytes); }
+	stage_pending.clear();
 }
 
 // ---- handle ---------------------------------------------------------------------------------
@@ -83,6 +93,7 @@ lqcov_handle::lqcov_handle(const lqcov_params &p, int dev) : P(p), device(dev)
 
 lqcov_handle::~lqcov_handle()
 {
+	drain_stages();
 	for (auto &L : lanes) if (L->stream) { hipStreamSynchronize(L->stream); hipStreamDestroy(L->stream); }
 	if (stream) { hipStreamSynchronize(stream); hipStreamDestroy(stream); }
 }
@@ -617,7 +628,7 @@ void lqcov_handle::map_part(Part &pt)
 		pv_reserved = npv;
 	}
 #ifndef LQ_EMU
-	const bool concurrent = n_lanes > 1 && batches.size() > 1 && !profiling && !dbg;
+	const bool concurrent = n_lanes > 1 && batches.size() > 1 && profiling != 1 && !dbg;
 #else
 	const bool concurrent = false;
 #endif

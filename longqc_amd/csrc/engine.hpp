@@ -64,7 +64,11 @@ struct lqcov_handle {
 	hipStream_t stream = nullptr;
 	Prim prim;
 	std::string err;
-	bool profiling = false;
+	int profiling = 0;                    // 0 off, 1 per-kernel (waits for every kernel, lanes run in turn), 2 events only (read when asked)
+	struct StagePending { const char *name; hipEvent_t a, b; u64 bytes; };
+	std::vector<StagePending> stage_pending; std::mutex stage_mu;
+	void account_stage(const char *name, hipEvent_t a, hipEvent_t b, u64 bytes);
+	void drain_stages();
 	u32 debug_flags = 0;
 	bool distributed = false;             // per-part accumulators, COVT replayed by the caller (multi-GPU)
 	std::map<std::string, StageAcc> stages;
