@@ -110,6 +110,7 @@ void lqcov_destroy(lqcov_handle *h);
 const char *lqcov_last_error(const lqcov_handle *h);
 int  lqcov_abi_version(void);
 int  lqcov_set_profiling(lqcov_handle *h, int on);                         /* 0 off; 1 wait for every kernel (exclusive per-kernel times); 2 record events only, no waits */
+int  lqcov_set_profiling_only(lqcov_handle *h, const char *stage);         /* time only the named stage (NULL / "": all) */
 int  lqcov_set_debug(lqcov_handle *h, unsigned flags);                     /* bit0: record chains for lqcov_get_chains */
 int  lqcov_get_stage_times(lqcov_handle *h, lqcov_stage_time *out, int max_out);   /* returns count */
 

@@ -73,6 +73,7 @@ def load_library(path: Optional[str] = None):
         "lqcov_destroy": (None, [H]),
         "lqcov_last_error": (C.c_char_p, [H]),
         "lqcov_set_profiling": (C.c_int, [H, C.c_int]),
+        "lqcov_set_profiling_only": (C.c_int, [H, C.c_char_p]),
         "lqcov_set_debug": (C.c_int, [H, C.c_uint]),
         "lqcov_get_stage_times": (C.c_int, [H, C.POINTER(StageTime), C.c_int]),
         "lqcov_set_queries": (C.c_int, [H, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -310,7 +311,9 @@ class Engine:
         self._ck(self.lib.lqcov_get_chains(self.h, out.ctypes.data, n.value, C.byref(n)))
         return out
 
-    def set_profiling(self, on: bool):
+    def set_profiling(self, on, only: Optional[str] = None):
+        """0 off; 1 waits for every kernel (exclusive times, lanes in turn); 2 events only.  only: time just that stage"""
+        self._ck(self.lib.lqcov_set_profiling_only(self.h, only.encode() if only else None))
         self._ck(self.lib.lqcov_set_profiling(self.h, int(on)))
 
     def stage_times(self) -> List[dict]:

@@ -175,6 +175,13 @@ int lqcov_set_profiling(lqcov_handle *h, int on)
 }
 int lqcov_set_debug(lqcov_handle *h, unsigned flags) { if (!h) return LQCOV_E_ARG; h->debug_flags = flags; return 0; }
 
+int lqcov_set_profiling_only(lqcov_handle *h, const char *stage)
+{
+	if (!h) return LQCOV_E_ARG;
+	h->profile_only = stage ? stage : "";
+	return 0;
+}
+
 int lqcov_get_stage_times(lqcov_handle *h, lqcov_stage_time *out, int max_out)
 {
 	if (!h) return LQCOV_E_ARG;

@@ -33,14 +33,15 @@ static void check_launch() { LQ_HIP_CHECK(hipGetLastError()); }
 // ---- stage timing ---------------------------------------------------------------------------
 StageTimer::StageTimer(lqcov_handle *h_, hipStream_t s_, const char *name_, u64 bytes_) : h(h_), s(s_), name(name_), bytes(bytes_)
 {
-	if (!h->profiling) return;
+	on = h->profiling && (h->profile_only.empty() || h->profile_only == name_);
+	if (!on) return;
 	hipEventCreate(&a); hipEventCreate(&b);
 	hipEventRecord(a, s);
 }
 StageTimer::StageTimer(lqcov_handle *h_, const char *name_, u64 bytes_) : StageTimer(h_, h_->stream, name_, bytes_) {}
 StageTimer::~StageTimer()
 {
-	if (!h->profiling) return;
+	if (!on) return;
 	hipEventRecord(b, s);
 	if (h->profiling == 1) { hipEventSynchronize(b); h->account_stage(name, a, b, bytes); }
 	else { std::lock_guard<std::mutex> g(h->stage_mu); h->stage_pending.push_back(lqcov_handle::StagePending{name, a, b, bytes}); }   // read later: nothing waits here

@@ -65,6 +65,7 @@ struct lqcov_handle {
 	Prim prim;
 	std::string err;
 	int profiling = 0;                    // 0 off, 1 per-kernel (waits for every kernel, lanes run in turn), 2 events only (read when asked)
+	std::string profile_only;             // if not empty: only this stage is timed
 	struct StagePending { const char *name; hipEvent_t a, b; u64 bytes; };
 	std::vector<StagePending> stage_pending; std::mutex stage_mu;
 	void account_stage(const char *name, hipEvent_t a, hipEvent_t b, u64 bytes);
@@ -122,7 +123,7 @@ struct lqcov_handle {
 
 struct StageTimer {
 	lqcov_handle *h; hipStream_t s; const char *name; u64 bytes;
-	hipEvent_t a = nullptr, b = nullptr;
+	hipEvent_t a = nullptr, b = nullptr; bool on = false;
 	StageTimer(lqcov_handle *h_, const char *name_, u64 bytes_ = 0);
 	StageTimer(lqcov_handle *h_, hipStream_t s_, const char *name_, u64 bytes_ = 0);
 	~StageTimer();

@@ -122,6 +122,7 @@ __global__ void k_seed_emit(const u64 *qx, const u64 *qy, const u32 *owner, cons
                             int no_self, const u32 *self_off, const u32 *self_rid,
                             mm128 *anchors, u64 *mini_pos)
 {
+#ifdef LQ_EMU
 	u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
 	if (j >= nj) return;
 	j += j0;
@@ -154,6 +155,58 @@ __global__ void k_seed_emit(const u64 *qx, const u64 *qy, const u32 *owner, cons
 		if (tandem) a.y |= LQ_SEED_TANDEM;
 		*out++ = a;
 	}
+#else
+	// One query minimizer per lane for the set-up, then the wave emits the anchors of one minimizer at a time, a hit per
+	// lane: the occurrence list is read and the anchors are written as contiguous runs (a thread walking its own list
+	// wrote 16-byte pieces 1 KiB apart: rocprofv3 counted 108 GB of HBM traffic per launch for 19 GB of anchors).
+	const u64 jt = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+	const u32 lane = threadIdx.x & 63;
+	const u64 j = j0 + (jt < nj ? jt : 0);
+	const bool act = jt < nj && keep[j];
+	u32 q = 0, q_span = 0, qp = 0, n = 0, flags = 0;
+	u64 st = 0, out0 = 0;
+	i32 ql = 0;
+	if (act) {
+		q = owner[j];
+		const u64 x = qx[j];
+		q_span = (u32)(x & 0xff); qp = (u32)qy[j];
+		mini_pos[mp_off[j]] = (u64)q_span << 32 | (qp >> 1);
+		if (j > qmoff[q] && (qx[j - 1] >> 8) == (x >> 8)) flags |= 1;            // tandem
+		if (j + 1 < qmoff[q + 1] && (qx[j + 1] >> 8) == (x >> 8)) flags |= 1;
+		if (no_self && self_off[q] != self_off[q + 1]) flags |= 2;              // some target carries this query's name
+		n = hit_n[j]; st = hit_start[j]; out0 = a_off[j] - a_base; ql = (i32)qlen[q];
+	}
+	u64 todo = __ballot(n > 0);
+	while (todo) {
+		const int f = __builtin_ctzll(todo);
+		todo &= todo - 1;
+		const u32 b_n = (u32)__builtin_amdgcn_readlane((int)n, f), b_q = (u32)__builtin_amdgcn_readlane((int)q, f);
+		const u32 b_span = (u32)__builtin_amdgcn_readlane((int)q_span, f), b_qp = (u32)__builtin_amdgcn_readlane((int)qp, f);
+		const u32 b_flags = (u32)__builtin_amdgcn_readlane((int)flags, f);
+		const i32 b_ql = __builtin_amdgcn_readlane(ql, f);
+		const u64 b_st = (u64)(u32)__builtin_amdgcn_readlane((int)(u32)st, f) | (u64)(u32)__builtin_amdgcn_readlane((int)(u32)(st >> 32), f) << 32;
+		const u64 b_out = (u64)(u32)__builtin_amdgcn_readlane((int)(u32)out0, f) | (u64)(u32)__builtin_amdgcn_readlane((int)(u32)(out0 >> 32), f) << 32;
+		const u32 b_qpos = b_qp >> 1;
+		const u64 y_same = (u64)b_span << 32 | b_qpos | ((b_flags & 1) ? LQ_SEED_TANDEM : 0);
+		const u64 y_rev = (u64)b_span << 32 | (u32)(b_ql - (i32)(b_qpos + 1 - b_span) - 1) | ((b_flags & 1) ? LQ_SEED_TANDEM : 0);
+		u32 skipped = 0;
+		for (u32 t0 = 0; t0 < b_n; t0 += 64) {
+			const u32 t = t0 + lane;
+			const bool valid = t < b_n;
+			const u64 r = valid ? pos[b_st + t] : 0;
+			const u32 rpos = (u32)r >> 1;
+			const bool skip = valid && (b_flags & 2) && rpos == b_qpos && lq_is_self(self_off, self_rid, b_q, (u32)(r >> 32));
+			const u64 sm = __ballot(skip);
+			if (valid && !skip) {
+				mm128 a;
+				if ((r & 1) == (b_qp & 1)) { a.x = (r & 0xffffffff00000000ULL) | rpos; a.y = y_same; }
+				else { a.x = 1ULL << 63 | (r & 0xffffffff00000000ULL) | rpos; a.y = y_rev; }
+				anchors[b_out + t - skipped - (u32)__popcll(sm & ((1ULL << lane) - 1))] = a;
+			}
+			skipped += (u32)__popcll(sm);
+		}
+	}
+#endif
 }
 
 // per query: anchor range, mini_pos range, avg_qspan (chain.c:37-38), lq_cnt_match prologue
