@@ -88,7 +88,7 @@ struct lqcov_handle {
 	// work buffers of part_map
 	DBuf hit_start, hit_n, a_cnt, keep, a_off, mp_off, mini_pos, aq_off, mpq_off, avg_qspan, skip;
 	std::vector<std::unique_ptr<MapLane>> lanes;
-	int n_lanes = 2;
+	int n_lanes = 3;
 	std::mutex pv_mu; u64 pv_reserved = 0;
 	std::mutex gate_mu; std::condition_variable gate_cv; int gate_count = 0;   // staggered lane start
 	DBuf dbg_chains, n_dbg; u64 dbg_cap = 0; u64 n_dbg_host = 0;

@@ -515,7 +515,7 @@ __global__ void k_sort_scatter(const SortSeg *segs, const SegInfo *info, u32 n_s
 // element among the elements of its own bucket (ties by original position) and stores it at that rank.
 #define LQ_CHILD_THREADS 64
 __global__ void __launch_bounds__(LQ_CHILD_THREADS) k_sort_children(const SortSeg *segs, u32 n_segs, mm128 *A, const u32 *hist, const u32 *begs,
-                                SortSeg *next, u32 *n_next)
+                                SortSeg *next, u32 *n_next, u32 const_levels)
 {
 	u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
 	if (t >= (u64)n_segs * 256) return;
@@ -525,7 +525,12 @@ __global__ void __launch_bounds__(LQ_CHILD_THREADS) k_sort_children(const SortSe
 	u32 n = hist[t], bg = begs[t];
 	if (n > LQ_RS_MIN) {
 		u32 s = atomicAdd(n_next, 1u);
-		SortSeg c; c.off = sg.off + bg; c.len = n; c.shift = sg.shift > 8 ? sg.shift - 8 : 0;
+		// the next digit that can differ: levels whose byte is the same in every anchor of the part (bits of rid above the
+		// target count, bits of the position above the longest target) are identity passes in klib (one bucket holds the
+		// whole sub-array, which is recursed into unchanged: ksort.h:121-128) and are stepped over
+		u32 sh = sg.shift - 8;
+		while (sh > 0 && (const_levels >> (sh >> 3) & 1)) sh -= 8;
+		SortSeg c; c.off = sg.off + bg; c.len = n; c.shift = sh;
 		next[s] = c;
 	}
 #ifdef LQ_EMU

@@ -176,3 +176,15 @@ def test_emulated_chain_lds_budget_overflow(emu_lib, case, monkeypatch):
     rc, out, err = run_main(emu_lib, case["argv"], cwd=GOLDEN)
     assert rc == 0, err
     assert out == read_gz(case["expect"])
+
+
+def test_emulated_constant_digit_levels_can_be_walked_or_skipped(emu_lib, datasets, monkeypatch):
+    """levels of the klib-order sort whose key byte is the same in every anchor of a part are stepped over by default;
+    LQCOV_NO_LEVEL_SKIP=1 runs them as identity passes like klib does: same table"""
+    tf, qf = datasets("small")
+    argv = ["-Y", "-l", "0", "-q", "160", "-k", "12", "-w", "5", "-I", "700K", "-p", "160", tf, qf]
+    want = oracle_bind.table(argv)
+    monkeypatch.setenv("LQCOV_NO_LEVEL_SKIP", "1")
+    rc, out, err = run_main(emu_lib, argv)
+    assert rc == 0, err
+    assert out == want
