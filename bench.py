@@ -67,7 +67,7 @@ def main():
     ap.add_argument("--reads", type=int, default=0, help="override reads per GPU (default: the config's 50000)")
     ap.add_argument("--nsample", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=20000, help="target reads in the CPU baseline sample (~20-30 s of reference time)")
+    ap.add_argument("--cpu-sample", type=int, default=35000, help="target reads in the CPU baseline sample (~20-30 s of reference time)")
     args = ap.parse_args()
 
     import torch

@@ -15,4 +15,4 @@ for C in FETCH_SIZE WRITE_SIZE; do
   ( timeout 600 rocprofv3 --pmc $C --kernel-trace --output-format csv -d /tmp/pmc_$C -o p -- $B 2>&1 | tail -3 ) > $GRAFT_REPO_ROOT/gpurun_out/pmc_$C.log 2>&1
 done
 python $GRAFT_REPO_ROOT/tools/pmc_to_json.py /tmp/pmc_FETCH_SIZE /tmp/pmc_WRITE_SIZE $GRAFT_REPO_ROOT/gpurun_out/pmc_traffic.json "bench.py default (configs[1]: 50000 reads, 5000 queries), 4 steps" > $GRAFT_REPO_ROOT/gpurun_out/pmc_summary.txt 2>&1
-cd $GRAFT_REPO_ROOT; tail -3 gpurun_out/pytest_gpu.log gpurun_out/smoke.log gpurun_out/bench.log; cat gpurun_out/pmc_summary.txt | head -20
+cd $GRAFT_REPO_ROOT; for f in pytest_gpu smoke bench; do tail -n 3 gpurun_out/$f.log | cut -c1-600; done; head -n 20 gpurun_out/pmc_summary.txt
