@@ -34,6 +34,7 @@ extern "C" {
 #define LQCOV_E_DEVICE  (-3)   /* HIP error (no device, out of memory, launch failed) */
 #define LQCOV_E_STATE   (-4)   /* call sequence violated                              */
 #define LQCOV_E_DOMAIN  (-5)   /* input outside the supported domain  */
+#define LQCOV_EOF       (-100) /* lqcov_part_load: no further part in the file        */
 
 typedef struct lqcov_handle lqcov_handle;
 
@@ -99,6 +100,12 @@ int lqcov_main(int argc, const char *const *argv, const char *out_path, const ch
 
 /* same, on an existing handle and with explicit paths (NULL out: stdout, NULL err: stderr) */
 int lqcov_run_files(lqcov_handle *h, const char *target_path, const char *query_path, const char *out_path, const char *err_path);
+/* same with the reference's -d: every index part is also appended to dump_path in the reference's .mmi layout
+ * (mm_idx_dump, index.c:390-426); query_path may be NULL (index only, minimap2-coverage.c:460-468).  target_path may
+ * itself be such a file -- from the reference or from here -- (mm_idx_load, index.c:428-479): its k, w and -H then
+ * override the handle's for the mapping, as in the reference (index.c:529-531).                                        */
+int lqcov_run_files_ex(lqcov_handle *h, const char *target_path, const char *query_path, const char *dump_path,
+                       const char *out_path, const char *err_path);
 
 /* ---- level 2: handle ---------------------------------------------------------------------- */
 void lqcov_params_default(lqcov_params *p);                                /* minimap2-coverage.c:229-388 */
@@ -129,6 +136,11 @@ int lqcov_part_add_targets(lqcov_handle *h, int part, uint32_t n, const uint8_t 
 int lqcov_part_build(lqcov_handle *h, int part);    /* sketch + index (+ mid_occ once): index.c:291-330, map.c:46-54 */
 int lqcov_part_map(lqcov_handle *h, int part);      /* == lq_map_file (lqmap.c:852): accumulates into the handle */
 int lqcov_part_release(lqcov_handle *h, int part);  /* == mm_idx_destroy (minimap2-coverage.c:457) */
+/* .mmi parts.  lqcov_part_dump writes a built part in the reference's layout (append != 0: after the parts already in
+ * the file).  lqcov_part_load reads the part that starts at *offset of an .mmi file into a new, built part: returns its
+ * id and advances *offset; LQCOV_EOF when no part starts there; the file's k / w / -H must be the handle's.            */
+int lqcov_part_dump(lqcov_handle *h, int part, const char *path, int append);               /* index.c:390-426 */
+int lqcov_part_load(lqcov_handle *h, const char *path, uint64_t *offset);                   /* index.c:428-479 */
 int lqcov_reset(lqcov_handle *h);                   /* zero the accumulators, keep resident reads (bench) */
 int lqcov_sync(lqcov_handle *h);                    /* wait for the handle's stream */
 

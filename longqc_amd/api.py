@@ -51,6 +51,9 @@ def library_path() -> str:
     return os.environ.get("LQCOV_LIBRARY", os.path.join(_HERE, "liblqcov.so"))
 
 
+LQCOV_EOF = -100
+
+
 def load_library(path: Optional[str] = None):
     """Load liblqcov.so (the gfx950 build).  Raises OSError if it has not been built."""
     global _LIB
@@ -91,6 +94,9 @@ def load_library(path: Optional[str] = None):
         "lqcov_get_regions": (C.c_int, [H, C.POINTER(C.c_void_p), C.POINTER(C.c_uint32), C.POINTER(C.c_void_p), C.POINTER(C.c_uint32)]),
         "lqcov_write_table": (C.c_int, [H, C.c_char_p]),
         "lqcov_run_files": (C.c_int, [H, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p]),
+        "lqcov_run_files_ex": (C.c_int, [H, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p]),
+        "lqcov_part_dump": (C.c_int, [H, C.c_int, C.c_char_p, C.c_int]),
+        "lqcov_part_load": (C.c_int, [H, C.c_char_p, u64p]),
         "lqcov_mid_occ": (C.c_int32, [H]),
         "lqcov_part_n_minimizers": (C.c_uint64, [H, C.c_int]),
         "lqcov_part_n_keys": (C.c_uint64, [H, C.c_int]),
@@ -230,9 +236,22 @@ class Engine:
     def finish(self):
         self._ck(self.lib.lqcov_finish(self.h))
 
-    def run_files(self, target: str, query: str, out: Optional[str] = None, err: Optional[str] = None):
-        self._ck(self.lib.lqcov_run_files(self.h, target.encode(), query.encode(),
-                                          out.encode() if out else None, err.encode() if err else None))
+    def run_files(self, target: str, query: Optional[str], out: Optional[str] = None, err: Optional[str] = None,
+                  dump: Optional[str] = None):
+        """target: FASTA/Q(.gz) or an .mmi index (the reference's or ours); dump: also write the index there (-d)"""
+        enc = lambda v: v.encode() if v else None
+        self._ck(self.lib.lqcov_run_files_ex(self.h, target.encode(), enc(query), enc(dump), enc(out), enc(err)))
+
+    def part_dump(self, part: int, path: str, append: bool = False):
+        self._ck(self.lib.lqcov_part_dump(self.h, part, path.encode(), 1 if append else 0))
+
+    def part_load(self, path: str, offset: int = 0) -> Tuple[Optional[int], int]:
+        """-> (part id or None at the end of the file, offset of the next part)"""
+        off = C.c_uint64(offset)
+        rc = self.lib.lqcov_part_load(self.h, path.encode(), C.byref(off))
+        if rc == LQCOV_EOF:
+            return None, off.value
+        return self._ck(rc), off.value
 
     # -- results --
     def rows(self) -> List[dict]:

@@ -387,17 +387,54 @@ int lqcov_accum_import_dev(lqcov_handle *h, const uint64_t *lambda_dev, const ui
 	});
 }
 
-int lqcov_run_files(lqcov_handle *h, const char *target, const char *query, const char *out_path, const char *err_path)
+int lqcov_run_files_ex(lqcov_handle *h, const char *target_path, const char *query_path, const char *dump_path, const char *out_path, const char *err_path)
 {
 	return guard(h, [&] {
+		if (!target_path) throw std::invalid_argument("no target");
+		if (!query_path && !dump_path) throw std::invalid_argument("neither a query file nor an index dump was asked for");
 		FILE *o = out_path ? fopen(out_path, "w") : stdout;
 		if (!o) throw std::runtime_error(std::string("failed to open file '") + out_path + "'");
 		FILE *e = err_path ? fopen(err_path, "a") : stderr;
-		try { h->run_files(target, query, o, e); }
+		try { h->run_files(target_path, query_path, o, e, dump_path); }
 		catch (...) { if (out_path) fclose(o); if (err_path && e) fclose(e); throw; }
 		if (out_path) fclose(o); else fflush(o);
 		if (err_path && e) fclose(e);
 	});
+}
+
+int lqcov_run_files(lqcov_handle *h, const char *target, const char *query, const char *out_path, const char *err_path)
+{
+	return lqcov_run_files_ex(h, target, query, nullptr, out_path, err_path);
+}
+
+int lqcov_part_dump(lqcov_handle *h, int part, const char *path, int append)
+{
+	return guard(h, [&] {
+		FILE *fp = fopen(path, append ? "ab" : "wb");
+		if (!fp) throw std::runtime_error(std::string("failed to open file '") + path + "'");
+		try { h->dump_part(h->part(part), fp); } catch (...) { fclose(fp); throw; }
+		fclose(fp);
+	});
+}
+
+int lqcov_part_load(lqcov_handle *h, const char *path, uint64_t *offset)
+{
+	int id = -1;
+	int rc = guard(h, [&] {
+		if (!offset) throw std::invalid_argument("null offset");
+		FILE *fp = fopen(path, "rb");
+		if (!fp) throw std::runtime_error(std::string("failed to open file '") + path + "'");
+		try {
+			if (fseeko(fp, (off_t)*offset, SEEK_SET) != 0) throw std::runtime_error("seek failed");
+			h->parts.emplace_back(new Part());
+			const int pid = (int)h->parts.size() - 1;
+			h->parts[pid]->live = true;
+			if (h->load_part(fp, *h->parts[pid])) { id = pid; *offset = (uint64_t)ftello(fp); }
+			else h->parts[pid].reset();
+		} catch (...) { fclose(fp); throw; }
+		fclose(fp);
+	});
+	return rc ? rc : (id < 0 ? LQCOV_EOF : id);
 }
 
 // == the subprocess (minimap2-coverage.c:206-734)
@@ -410,9 +447,9 @@ int lqcov_main(int argc, const char *const *argv, const char *out_path, const ch
 	char errbuf[256] = {0};
 	int rc = lqcov_parse_args(argc, argv, &p, &target, &query, &dump, errbuf, sizeof(errbuf));
 	if (rc) { fprintf(e, "%s\n", errbuf); if (err_path) fclose(e); return 1; }
-	if (dump) { fprintf(e, "Error: -d (index dump) is not implemented by the MI355X engine yet.\n"); if (err_path) fclose(e); return 1; }
 	// effective parameters, as the reference echoes them (minimap2-coverage.c:392-404)
-	fprintf(e, "=== Parameters are listed below === \nInputs are target: %s, query: %s\n", target, query);
+	if (query) fprintf(e, "=== Parameters are listed below === \nInputs are target: %s, query: %s\n", target, query);
+	else fprintf(e, "=== Parameters are listed below === \nInputs is target: %s\n", target);
 	fprintf(e, "kmer %d, window %d, index loading size %llu\n", p.k, p.w, (unsigned long long)p.batch_size);
 	fprintf(e, "min-score %d, min-score-med %d, min-score-good %d, max-gap %d, min-cnt %d\n", p.min_chain_score, p.min_score_med, p.min_score_good, p.max_gap, p.min_cnt);
 	fprintf(e, "Homo-polymer compression: %d, Filtering: %d\n", p.hpc, p.filter_flag);
@@ -426,7 +463,7 @@ int lqcov_main(int argc, const char *const *argv, const char *out_path, const ch
 	lqcov_handle *h = lqcov_create(&p, device);
 	if (!h) { fprintf(e, "ERROR: %s\n", g_create_error.c_str()); if (err_path) fclose(e); return LQCOV_E_DEVICE; }
 	if (err_path) { fclose(e); e = nullptr; }
-	rc = lqcov_run_files(h, target, query, out_path, err_path);
+	rc = lqcov_run_files_ex(h, target, query, dump, out_path, err_path);
 	if (rc) {
 		FILE *e2 = err_path ? fopen(err_path, "a") : stderr;
 		if (e2) { fprintf(e2, "ERROR: %s\n", h->err.c_str()); if (err_path) fclose(e2); }

@@ -261,7 +261,7 @@ void lqcov_handle::reset()
 	const u32 n = q.n;
 	dzero(lambda.p, (n + 1) * 8, stream); dzero(lambda2.p, (n + 1) * 8, stream);
 	dzero(avg_k.p, (n + 1) * 4, stream); dzero(qflags.p, (n + 1) * 4, stream);
-	dzero(cnts.p, q.n_mini * 4 + 4, stream);
+	dzero(cnts.p, cnt_count() * 4 + 4, stream);
 	dzero(n_pv.p, 4, stream);
 	if (!distributed) mid_occ = -1;
 	finished = false;
@@ -494,7 +494,7 @@ void lqcov_handle::map_batch(MapLane &L, Part &pt, u32 q0, u32 q1, const std::ve
 		ChainBufs cb; cb.f = d_cf; cb.p = d_cp; cb.t = d_ct; cb.v = d_cv; cb.u = d_cu;
 		CovState cs;
 		cs.lambda = lambda.as<unsigned long long>(); cs.lambda2 = lambda2.as<unsigned long long>();
-		cs.cnts = cnts.as<u32>(); cs.qflags = qflags.as<u32>(); cs.skip = skip.as<u32>(); cs.qmoff = q.moff.as<u64>();
+		cs.cnts = cnts.as<u32>(); cs.qflags = qflags.as<u32>(); cs.skip = skip.as<u32>(); cs.qmoff = cnt_off_dev();
 		cs.mini_pos = mini_pos.as<u64>(); cs.mpq_off = mpq_off.as<u64>(); cs.qlen = q.d_len.as<u32>(); cs.tlen = pt.rs.d_len.as<u32>();
 		cs.ivl = L.ivl.as<Ivl>(); cs.n_ivl = L.n_ivl.as<u32>(); cs.ivl_cap = ivl_cap;
 		cs.dbg = dbg ? dbg_chains.as<ChainRec>() : nullptr; cs.n_dbg = n_dbg.as<unsigned long long>(); cs.dbg_cap = dbg_cap;
@@ -705,7 +705,7 @@ void lqcov_handle::finish()
 	}
 	{
 		StageTimer t(this, "k_cnt_stats", q.n_mini * 8);
-		LQ_LAUNCH(k_cnt_stats, nblk(n_q, 64), 64, stream, cnts.as<u32>(), q.moff.as<u64>(), n_q, rowdev.as<RowDev>(), qflags.as<u32>());
+		LQ_LAUNCH(k_cnt_stats, nblk(n_q, 64), 64, stream, cnts.as<u32>(), cnt_off_dev(), own_cnt_layout ? d_nsize.as<u32>() : (const u32*)nullptr, n_q, rowdev.as<RowDev>(), qflags.as<u32>());
 		check_launch();
 	}
 	std::vector<RowDev> hr(n_q);
@@ -724,10 +724,14 @@ void lqcov_handle::finish()
 	static_assert(sizeof(RegionT) == sizeof(lqcov_region), "region layout");
 	d2h((RegionT*)regs.data(), dregs.as<RegionT>(), nr[0], stream);
 	d2h((RegionT*)mregs.data(), dmregs.as<RegionT>(), nr[1], stream);
+	for (u32 i = 0; i < n_q; ++i)
+		if (hf[i] & 2u)
+			throw std::domain_error("query " + q.names[i] + ": a chain matched a minimizer beyond the counters sized from the command line's -k/-w/-H; "
+			                        "the reference overruns its counter array there (minimap2-coverage.c:422, esterr.c:131) -- pass the prebuilt index's -k/-w/-H");
 	for (u32 i = 0; i < n_q; ++i) {
 		lqcov_row &r = rows[i];
 		r.lambda = hl[i]; r.lambda2 = hl2[i]; r.qual_psum = hp[i]; r.qlen = q.h_len[i];
-		r.n_mini = (u32)(hmoff[i + 1] - hmoff[i]); r.n_match = hr[i].n_match; r.avg_k = hk[i];
+		r.n_mini = own_cnt_layout ? h_nsize[i] : (u32)(hmoff[i + 1] - hmoff[i]); r.n_match = hr[i].n_match; r.avg_k = hk[i];
 		r.reg_off = hr[i].reg_off; r.n_reg = hr[i].n_reg; r.mreg_off = hr[i].mreg_off; r.n_mreg = hr[i].n_mreg;
 		r.has_qual = q_has_qual ? 1u : 0u; r.flags = hf[i];
 	}
@@ -774,41 +778,271 @@ void lqcov_handle::write_table(FILE *out)
 }
 
 // ---- the whole run from files (minimap2-coverage.c:406-617) -----------------------------------------
-int lqcov_handle::run_files(const char *target, const char *query, FILE *out, FILE *log)
+// ---- prebuilt indexes: the reference's .mmi files (index.c:385-540) ----------------------------------
+#define LQ_MMI_MAGIC "MMI\2"
+#define LQ_MMI_BUCKET_BITS 14           // mm_idxopt_init (index.c:33); the option table has no switch for it
+#define LQ_MMI_NO_SEQ 0x2
+
+static void fwrite_or_throw(const void *p, size_t sz, size_t n, FILE *fp)
 {
+	if (n && fwrite(p, sz, n, fp) != n) throw std::runtime_error("write to the index dump failed");
+}
+
+// A prebuilt index brings its own k, w and -H (index.c:529-531), which the mapping then uses (lqmap.c:126-138), while the
+// reference has already sized every query's counter array -- and with it the n of the count statistics -- from a sketch
+// with the command-line values (minimap2-coverage.c:419-422, 552-563).  Keep those sizes, sketch the queries again with
+// the index's values.  A query may then have more minimizers than counters; the reference writes past its array if a good
+// chain matches one of the surplus minimizers (esterr.c:131-137; glibc aborts it on test data).  Here the array is long
+// enough, the statistics look at the first n counters like the reference, and finish() refuses the run if a surplus
+// counter was touched (outside the parity domain).
+void lqcov_handle::adopt_index_params(i32 k, i32 w, i32 hpc)
+{
+	if (k == P.k && w == P.w && (hpc != 0) == (P.hpc != 0)) return;
+	if (k < 1 || k > 28 || w < 1 || w > 255) throw std::domain_error("prebuilt index with k or w outside [1,28] / [1,255]");
+	if (!parts.empty()) for (auto &p : parts) if (p && p->live) throw std::logic_error("index parameters change with live parts");
+	std::vector<u64> old(q.n + 1, 0);
+	if (have_queries && q.n) d2h(old.data(), q.moff.as<u64>(), q.n + 1, stream);
+	P.k = k; P.w = w; P.hpc = hpc ? 1 : 0;
+	mp.k = k; mp.w = w; mp.hpc = P.hpc;
+	if (!have_queries) return;
+	q.sketched = false;
+	sketch(q, false);
+	const u64 nm = q.n_mini;
+	q_owner.ensure(nm * 4 + 4);
+	if (nm) { LQ_LAUNCH(k_minimizer_owner, nblk(nm, 256), 256, stream, q.moff.as<u64>(), q.n, nm, q_owner.as<u32>()); check_launch(); }
+	std::vector<u64> now(q.n + 1, 0), off(q.n + 1, 0);
+	if (q.n) d2h(now.data(), q.moff.as<u64>(), q.n + 1, stream);
+	h_nsize.resize(q.n);
+	for (u32 i = 0; i < q.n; ++i) {
+		h_nsize[i] = (u32)(old[i + 1] - old[i]);
+		off[i + 1] = off[i] + std::max<u64>(h_nsize[i], now[i + 1] - now[i]);
+	}
+	cnt_total = off[q.n];
+	cnt_off.ensure((q.n + 1) * 8); d_nsize.ensure((q.n + 1) * 4);
+	h2d(cnt_off.as<u64>(), off.data(), q.n + 1, stream);
+	h2d(d_nsize.as<u32>(), h_nsize.data(), q.n, stream);
+	own_cnt_layout = true;
+	cnts.ensure(cnt_total * 4 + 4);
+	reset();
+}
+
+void lqcov_handle::build_part_from_host_minimizers(Part &pt, const std::vector<u64> &x, const std::vector<u64> &y,
+                                                   std::vector<std::string> &&names, std::vector<u32> &&lens)
+{
+	ReadSetDev &rs = pt.rs;
+	const u64 n = x.size();
+	rs.mx.ensure(n * 8 + 8); rs.my.ensure(n * 8 + 8);
+	h2d(rs.mx.as<u64>(), x.data(), n, stream);
+	h2d(rs.my.as<u64>(), y.data(), n, stream);
+	rs.n_mini = n; rs.n = (u32)lens.size();
+	rs.h_len = std::move(lens);
+	rs.names = std::move(names);
+	rs.n_bases = 0;
+	for (u32 v : rs.h_len) rs.n_bases += v;
+	rs.d_len.ensure((rs.n + 1) * 4);
+	h2d(rs.d_len.as<u32>(), rs.h_len.data(), rs.n, stream);
+	LQ_HIP_CHECK(hipStreamSynchronize(stream));
+	rs.sketched = true;
+	build_index(pt);
+}
+
+// One part in the reference's on-disk layout.  What a reader needs is reproduced exactly (header, names with their
+// one-byte length, per-bucket position arrays with every list ascending, key = minimizer>>b<<1 | singleton, value = the
+// position or start<<32 | n, 4-bit sequences); the order of the (key, value) pairs inside a bucket is ascending key here,
+// khash slot order in the reference -- mm_idx_load re-inserts them one by one, so the order is immaterial.
+void lqcov_handle::dump_part(Part &pt, FILE *fp)
+{
+	if (!pt.built) throw std::logic_error("part not built");
+	ReadSetDev &rs = pt.rs;
+	const u64 M = rs.n_mini, K = pt.n_keys;
+	const u32 b = LQ_MMI_BUCKET_BITS, nb = 1u << b;
+	std::vector<u64> hkey(K), hstart(K), hpos(M);
+	std::vector<u32> hcnt(K);
+	if (K) {
+		d2h(hkey.data(), ix_ukey.as<u64>(), K, stream); d2h(hstart.data(), ix_ustart.as<u64>(), K, stream);
+		d2h(hcnt.data(), ix_ucnt.as<u32>(), K, stream); d2h(hpos.data(), pt.pos.as<u64>(), M, stream);
+	}
+	u32 hdr[5] = {(u32)P.w, (u32)P.k, b, rs.n, (u32)(P.hpc ? 1 : 0)};
+	fwrite_or_throw(LQ_MMI_MAGIC, 1, 4, fp);
+	fwrite_or_throw(hdr, 4, 5, fp);
+	u64 sum_len = 0;
+	std::vector<u64> boff(rs.n + 1, 0);
+	for (u32 i = 0; i < rs.n; ++i) {
+		const u8 l = (u8)rs.names[i].size();                    // index.c:401: the length is stored in one byte
+		fwrite_or_throw(&l, 1, 1, fp);
+		fwrite_or_throw(rs.names[i].data(), 1, l, fp);
+		fwrite_or_throw(&rs.h_len[i], 4, 1, fp);
+		sum_len += rs.h_len[i]; boff[i + 1] = sum_len;
+	}
+	// keys by bucket (low b bits); hkey is ascending, so every bucket's keys stay ascending
+	std::vector<u64> bstart(nb + 1, 0);
+	for (u64 i = 0; i < K; ++i) ++bstart[(hkey[i] & (nb - 1)) + 1];
+	for (u32 i = 0; i < nb; ++i) bstart[i + 1] += bstart[i];
+	std::vector<u64> order(K), fill(bstart.begin(), bstart.end() - 1);
+	for (u64 i = 0; i < K; ++i) order[fill[hkey[i] & (nb - 1)]++] = i;
+	std::vector<u64> pbuf, kv;
+	for (u32 bi = 0; bi < nb; ++bi) {
+		pbuf.clear(); kv.clear();
+		for (u64 t = bstart[bi]; t < bstart[bi + 1]; ++t) {
+			const u64 i = order[t];
+			const u64 key = hkey[i] >> b << 1;
+			if (hcnt[i] == 1) { kv.push_back(key | 1); kv.push_back(hpos[hstart[i]]); }
+			else {
+				kv.push_back(key); kv.push_back((u64)pbuf.size() << 32 | hcnt[i]);
+				pbuf.insert(pbuf.end(), hpos.begin() + hstart[i], hpos.begin() + hstart[i] + hcnt[i]);
+			}
+		}
+		if (pbuf.size() > 0x7fffffffULL) throw std::domain_error("index bucket too large for the .mmi format");
+		const i32 n_p = (i32)pbuf.size();
+		const u32 size = (u32)(kv.size() / 2);
+		fwrite_or_throw(&n_p, 4, 1, fp);
+		fwrite_or_throw(pbuf.data(), 8, pbuf.size(), fp);
+		fwrite_or_throw(&size, 4, 1, fp);
+		fwrite_or_throw(kv.data(), 8, kv.size(), fp);
+	}
+	// mi->S
+	const u64 n_words = (sum_len + 7) / 8;
+	if (n_words) {
+		if (rs.codes.p == nullptr) throw std::logic_error("this part has no sequences to dump (it was loaded from an index)");
+		DBuf d_boff, d_out;
+		d_boff.ensure((rs.n + 1) * 8); d_out.ensure(n_words * 4);
+		h2d(d_boff.as<u64>(), boff.data(), rs.n + 1, stream);
+		LQ_LAUNCH(k_seq4, nblk(n_words, 256), 256, stream, rs.codes.as<u64>(), rs.amb.as<u32>(), rs.d_coff.as<u64>(), d_boff.as<u64>(), rs.n, n_words, d_out.as<u32>());
+		check_launch();
+		std::vector<u32> hs(n_words);
+		d2h(hs.data(), d_out.as<u32>(), n_words, stream);
+		fwrite_or_throw(hs.data(), 4, n_words, fp);
+	}
+	fflush(fp);
+}
+
+static bool fread_exact(void *p, size_t sz, size_t n, FILE *fp) { return n == 0 || fread(p, sz, n, fp) == n; }
+
+bool lqcov_handle::load_part(FILE *fp, Part &pt)
+{
+	char magic[4];
+	if (fread(magic, 1, 4, fp) != 4) return false;              // end of file (index.c:436)
+	if (memcmp(magic, LQ_MMI_MAGIC, 4) != 0) return false;
+	u32 hdr[5];
+	if (!fread_exact(hdr, 4, 5, fp)) throw std::runtime_error("truncated index file");
+	const i32 w = (i32)hdr[0], k = (i32)hdr[1]; const u32 b = hdr[2], n_seq = hdr[3], flag = hdr[4];
+	if (k != P.k || w != P.w || ((flag & 1) != 0) != (P.hpc != 0)) throw std::logic_error("index part with other k / w / -H than the handle's (adopt_index_params first)");
+	if (b > 30) throw std::runtime_error("corrupt index file (bucket bits)");
+	std::vector<std::string> names(n_seq);
+	std::vector<u32> lens(n_seq);
+	u64 sum_len = 0;
+	for (u32 i = 0; i < n_seq; ++i) {
+		u8 l;
+		char buf[256];
+		if (!fread_exact(&l, 1, 1, fp) || !fread_exact(buf, 1, l, fp) || !fread_exact(&lens[i], 4, 1, fp)) throw std::runtime_error("truncated index file");
+		names[i].assign(buf, strnlen(buf, l));                     // the reference holds it as a C string (index.c:448-450)
+		sum_len += lens[i];
+	}
+	std::vector<u64> x, y, pbuf;
+	for (u32 bi = 0; bi < (1u << b); ++bi) {
+		i32 n_p; u32 size;
+		if (!fread_exact(&n_p, 4, 1, fp) || n_p < 0) throw std::runtime_error("truncated index file");
+		pbuf.resize((size_t)n_p);
+		if (!fread_exact(pbuf.data(), 8, (size_t)n_p, fp) || !fread_exact(&size, 4, 1, fp)) throw std::runtime_error("truncated index file");
+		for (u32 j = 0; j < size; ++j) {
+			u64 kv[2];
+			if (!fread_exact(kv, 8, 2, fp)) throw std::runtime_error("truncated index file");
+			const u64 minier = (kv[0] >> 1) << b | bi;             // index.c:69-86 read backwards
+			if (kv[0] & 1) { x.push_back(minier << 8); y.push_back(kv[1]); }
+			else {
+				const u64 st = kv[1] >> 32, n = (u32)kv[1];
+				if (st + n > (u64)n_p) throw std::runtime_error("corrupt index file (position list)");
+				for (u64 t = 0; t < n; ++t) { x.push_back(minier << 8); y.push_back(pbuf[st + t]); }
+			}
+		}
+	}
+	if (!(flag & LQ_MMI_NO_SEQ)) {                                // mi->S: not used on this path; skipped
+		const u64 bytes = (sum_len + 7) / 8 * 4;
+		if (fseeko(fp, (off_t)bytes, SEEK_CUR) != 0) throw std::runtime_error("truncated index file");
+	}
+	build_part_from_host_minimizers(pt, x, y, std::move(names), std::move(lens));
+	return true;
+}
+
+int lqcov_handle::run_files(const char *target, const char *query, FILE *out, FILE *log, const char *dump_path)
+{
+	bool is_idx = false;
+	i32 ik = 0, iw = 0, ihpc = 0;
 	{
+		FILE *t = fopen(target, "rb");
+		if (!t) throw std::runtime_error(std::string("failed to open file '") + target + "'");
+		char magic[4]; u32 hdr[5];
+		if (fread(magic, 1, 4, t) == 4 && memcmp(magic, LQ_MMI_MAGIC, 4) == 0) {       // mm_idx_is_idx (index.c:481-498)
+			is_idx = true;
+			if (fread(hdr, 4, 5, t) != 5) { fclose(t); throw std::runtime_error("truncated index file"); }
+			iw = (i32)hdr[0]; ik = (i32)hdr[1]; ihpc = (i32)(hdr[4] & 1);
+		}
+		fclose(t);
+	}
+	if (is_idx && dump_path) throw std::domain_error("-d with a prebuilt index as the target is not supported");
+	if (query) {
 		FastxReader fq(query);
 		ReadBatch qb;
 		while (fq.read_minibatch(INT64_MAX, qb, true) > 0) {}
 		set_queries(qb.size(), qb.seq.data(), qb.seq_off.data(), qb.any_qual ? qb.qual.data() : nullptr, qb.names.data(), qb.name_off.data());
 		if (log) fprintf(log, "[lqcov] loaded %u query sequence(s), %" PRIu64 " bases, %" PRIu64 " minimizers\n", qb.size(), qb.bases(), q.n_mini);
 	}
-	FastxReader ft(target);
-	const int64_t chunk = (int)((u64)P.idx_mini_batch < P.batch_size ? (u64)P.idx_mini_batch : P.batch_size);   // index.c:316
+	FILE *dump = nullptr;
+	if (dump_path) { dump = fopen(dump_path, "wb"); if (!dump) throw std::runtime_error(std::string("failed to open file '") + dump_path + "'"); }
+	struct Closer { FILE *f; ~Closer() { if (f) fclose(f); } } dump_closer{dump};
 	int n_parts = 0;
-	for (;;) {
-		// one part: mini-batches while the running total is <= -I (index.c:244)
-		int id = -1;
-		u64 sum_len = 0;
-		ReadBatch tb;
-		for (;;) {
-			if (sum_len > P.batch_size) break;
-			tb.clear();
-			if (ft.read_minibatch(chunk, tb, false) == 0) break;
-			if (id < 0) { parts.emplace_back(new Part()); id = (int)parts.size() - 1; parts[id]->live = true; }
-			add_reads(parts[id]->rs, tb.size(), tb.seq.data(), tb.seq_off.data(), tb.names.data(), tb.name_off.data());
-			sum_len += tb.bases();
+	if (is_idx) {
+		if (ik != P.k || iw != P.w || (ihpc != 0) != (P.hpc != 0)) {
+			if (log) fprintf(log, "[WARNING] Indexing parameters (-k, -w or -H) overridden by parameters used in the prebuilt index.\n");
+			adopt_index_params(ik, iw, ihpc);
 		}
-		if (id < 0) break;
-		Part &pt = *parts[id];
-		build_part(pt);
-		if (log) fprintf(log, "[lqcov] part %d: %u target sequence(s), %" PRIu64 " bases, %" PRIu64 " minimizers, %" PRIu64 " distinct, mid_occ = %d\n",
-		                 n_parts, pt.rs.n, pt.rs.n_bases, pt.rs.n_mini, pt.n_keys, mid_occ);
-		map_part(pt);
-		if (log) fprintf(log, "[lqcov] part %d: mapped %u queries, %" PRIu64 " anchors\n", n_parts, q.n, last_n_anchors);
-		parts[id].reset();
-		++n_parts;
+		FILE *fi = fopen(target, "rb");
+		if (!fi) throw std::runtime_error(std::string("failed to open file '") + target + "'");
+		Closer fi_closer{fi};
+		for (;;) {
+			parts.emplace_back(new Part());
+			const int id = (int)parts.size() - 1;
+			parts[id]->live = true;
+			if (!load_part(fi, *parts[id])) { parts[id].reset(); break; }
+			Part &pt = *parts[id];
+			if (log) fprintf(log, "[lqcov] part %d (prebuilt): %u target sequence(s), %" PRIu64 " minimizers, %" PRIu64 " distinct, mid_occ = %d\n",
+			                 n_parts, pt.rs.n, pt.rs.n_mini, pt.n_keys, mid_occ);
+			if (query) map_part(pt);
+			parts[id].reset();
+			++n_parts;
+		}
+	} else {
+		FastxReader ft(target);
+		const int64_t chunk = (int)((u64)P.idx_mini_batch < P.batch_size ? (u64)P.idx_mini_batch : P.batch_size);   // index.c:316
+		for (;;) {
+			// one part: mini-batches while the running total is <= -I (index.c:244)
+			int id = -1;
+			u64 sum_len = 0;
+			ReadBatch tb;
+			for (;;) {
+				if (sum_len > P.batch_size) break;
+				tb.clear();
+				if (ft.read_minibatch(chunk, tb, false) == 0) break;
+				if (id < 0) { parts.emplace_back(new Part()); id = (int)parts.size() - 1; parts[id]->live = true; }
+				add_reads(parts[id]->rs, tb.size(), tb.seq.data(), tb.seq_off.data(), tb.names.data(), tb.name_off.data());
+				sum_len += tb.bases();
+			}
+			if (id < 0) break;
+			Part &pt = *parts[id];
+			sketch(pt.rs, true);
+			build_index(pt);
+			if (log) fprintf(log, "[lqcov] part %d: %u target sequence(s), %" PRIu64 " bases, %" PRIu64 " minimizers, %" PRIu64 " distinct, mid_occ = %d\n",
+			                 n_parts, pt.rs.n, pt.rs.n_bases, pt.rs.n_mini, pt.n_keys, mid_occ);
+			if (dump) dump_part(pt, dump);                        // mm_idx_reader_read (index.c:533)
+			if (query) {
+				map_part(pt);
+				if (log) fprintf(log, "[lqcov] part %d: mapped %u queries, %" PRIu64 " anchors\n", n_parts, q.n, last_n_anchors);
+			}
+			parts[id].reset();
+			++n_parts;
+		}
 	}
+	if (!query) return 0;                                         // index only (minimap2-coverage.c:460-468)
 	finish();
 	write_table(out);
 	return 0;

@@ -80,6 +80,11 @@ struct lqcov_handle {
 	bool have_queries = false, q_has_qual = false;
 	DBuf q_owner;                         // query of every query minimizer
 	DBuf lambda, lambda2, avg_k, cnts, qflags, qual_psum;
+	// counter layout: normally the query minimizer offsets; after adopt_index_params() (prebuilt index with other -k/-w/-H)
+	// the reference's sizes (from the command-line sketch, minimap2-coverage.c:419-422) and the mapping's differ
+	bool own_cnt_layout = false; DBuf cnt_off, d_nsize; std::vector<u32> h_nsize; u64 cnt_total = 0;
+	const u64 *cnt_off_dev() const { return own_cnt_layout ? cnt_off.as<u64>() : q.moff.as<u64>(); }
+	u64 cnt_count() const { return own_cnt_layout ? cnt_total : q.n_mini; }
 	DBuf pv; DBuf n_pv; u32 pv_cap = 0;   // persisted intervals + markers (ovlp_coords)
 	i32 mid_occ = -1;
 
@@ -117,7 +122,12 @@ struct lqcov_handle {
 	void reset();
 	void finish();
 	void write_table(FILE *out);
-	int run_files(const char *target, const char *query, FILE *out, FILE *log);
+	int run_files(const char *target, const char *query, FILE *out, FILE *log, const char *dump_path = nullptr);
+	void adopt_index_params(i32 k, i32 w, i32 hpc);
+	void dump_part(Part &pt, FILE *fp);                      // mm_idx_dump (index.c:390-426)
+	bool load_part(FILE *fp, Part &pt);                      // mm_idx_load (index.c:428-479); false at end of file
+	void build_part_from_host_minimizers(Part &pt, const std::vector<u64> &x, const std::vector<u64> &y,
+	                                     std::vector<std::string> &&names, std::vector<u32> &&lens);
 	Part &part(int id);
 };
 

@@ -572,15 +572,20 @@ __global__ void k_reliable(const u64 *se, const u32 *pvq_off, u32 n_q, u32 min_c
 }
 
 // minimap2-coverage.c:552-561: integer mean of the uint16 counters, count of those above it
-__global__ void k_cnt_stats(const u32 *cnts, const u64 *qmoff, u32 n_q, RowDev *rows, u32 *qflags)
+__global__ void k_cnt_stats(const u32 *cnts, const u64 *cnt_off, const u32 *nsize, u32 n_q, RowDev *rows, u32 *qflags)
 {
 	u32 q = blockIdx.x * blockDim.x + threadIdx.x;
 	if (q >= n_q) return;
-	const u64 lo = qmoff[q], hi = qmoff[q + 1];
+	const u64 lo = cnt_off[q], hi = nsize ? lo + nsize[q] : cnt_off[q + 1];   // mv.n counters (minimap2-coverage.c:552-561)
 	u32 sum = 0, n = (u32)(hi - lo), nm = 0;
 	bool sat = false;
 	for (u64 j = lo; j < hi; ++j) { sum += cnts[j] & 0xffffu; if (cnts[j] >= 65535u) sat = true; }   // uint16 storage wraps (esterr.c:136)
 	if (sat) atomicOr(&qflags[q], 1u);
+	if (nsize) {                                            // counters the reference never allocated (see adopt_index_params)
+		bool over = false;
+		for (u64 j = hi; j < cnt_off[q + 1]; ++j) if (cnts[j]) over = true;
+		if (over) atomicOr(&qflags[q], 2u);
+	}
 	if (n) sum /= n;
 	for (u64 j = lo; j < hi; ++j) if ((cnts[j] & 0xffffu) > sum) ++nm;
 	rows[q].n_match = nm;

@@ -236,3 +236,24 @@ __global__ void k_query_prep(const u64 *qmoff, const u64 *a_off, const u64 *mp_o
 	else if (avg_k[q] == 0.0f) avg_k[q] = __fdiv_rn((float)sum_k, (float)(i32)n_mp);   // esterr.c:93-97
 	skip[q] = sk;
 }
+
+// mi->S of an index dump (index.c:278-284, mmpriv.h mm_seq4_set): 4 bits per base, 8 bases per word, all reads back to
+// back (read r starts at base boff[r]); code = nt4 (0..3, 4 for anything else).  One thread per output word.
+__global__ void k_seq4(const u64 *codes, const u32 *amb, const u64 *coff, const u64 *boff, u32 n_reads, u64 n_words, u32 *out)
+{
+	u64 g = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+	if (g >= n_words) return;
+	const u64 total = boff[n_reads];
+	u64 o = g * 8;
+	u32 r = lq_find_seg(boff, n_reads, o);
+	u32 w = 0;
+	for (int j = 0; j < 8 && o < total; ++j, ++o) {
+		while (o >= boff[r + 1]) ++r;                        // (empty reads are stepped over)
+		const u64 p = o - boff[r];
+		const u64 wi = coff[r] * LQ_CHUNK_WORDS + (p >> 5);
+		const u32 b = (u32)(p & 31);
+		const u32 c = (amb[wi] >> b & 1) ? 4u : (u32)(codes[wi] >> (2 * b) & 3);
+		w |= c << (4 * j);
+	}
+	out[g] = w;
+}

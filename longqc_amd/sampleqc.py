@@ -48,6 +48,25 @@ def coverage_argv(preset: str, fastx_path: str, sample_path: str, ncpu: int = 4,
     return shlex.split("%s %s -p %d -t %d %s %s" % (MINIMAP2_PARAMS, db_params(preset, fast, inds), med, ncpu, fastx_path, sample_path))
 
 
+def db_build_argv(preset: str, tempdb_path: str, fastx_path: str, fast: bool = False, inds: str = "4G", short: bool = False) -> List[str]:
+    """`sampleqc --db`, first call: index every read into a prebuilt .mmi (longQC.py:266-277); short=True gives the
+    t_db_minimap2_short variant (-k 12 -w 5)."""
+    params = "-k 12 -w 5 -I %s" % inds if short else db_params(preset, fast, inds)
+    return shlex.split("%s -d %s %s" % (params, tempdb_path, fastx_path))
+
+
+def db_coverage_argv(preset: str, tempdb_path: str, sample_path: str, ncpu: int = 4, short: bool = False) -> List[str]:
+    """`sampleqc --db`, second call: map the subsample against the prebuilt index; no -k/-w on this command line
+    (longQC.py:440-442, 531-533), so the binary sizes its counters with its defaults (k=12, w=5) while the index's
+    own k / w drive the mapping."""
+    if preset not in PRESET_MED_SCORE:
+        raise ValueError("unknown preset %r" % preset)
+    med, med_short = PRESET_MED_SCORE[preset]
+    if short and med_short is None:
+        raise ValueError("--short is not defined for %s" % preset)
+    return shlex.split("%s -p %d -t %d %s %s" % (MINIMAP2_PARAMS, med_short if short else med, ncpu, tempdb_path, sample_path))
+
+
 def spikein_argv(filter_ref: str, sample_path: str, ncpu: int = 4) -> List[str]:
     """longQC.py:555-556"""
     return shlex.split("%s -t %d %s %s" % (MINIMAP2_FILTERING_PARAMS, ncpu, filter_ref, sample_path))

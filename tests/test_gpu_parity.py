@@ -202,3 +202,25 @@ def test_gpu_concurrent_mapping_lanes(gpu_lib, datasets, monkeypatch, lanes):
 @pytest.mark.parametrize("case", [c for c in _cases("table") if c["name"] in ("tiny_ont", "adv_parts")], ids=lambda c: c["name"])
 def test_gpu_chain_lds_budget_overflow(gpu_lib, case, monkeypatch):
     E.test_emulated_chain_lds_budget_overflow(gpu_lib, case, monkeypatch)
+
+
+# ---- the reference's index files ----
+import tests.test_mmi as MMI  # noqa: E402
+
+
+@pytest.mark.parametrize("case", MMI.CASES, ids=lambda c: c["name"])
+def test_gpu_maps_from_the_reference_index_file(gpu_lib, case, tmp_path):
+    MMI.check_maps_from_reference_index(gpu_lib, case, tmp_path)
+
+
+@pytest.mark.parametrize("case", MMI.CASES, ids=lambda c: c["name"])
+def test_gpu_index_dump_equals_the_reference_dump_and_loads_back(gpu_lib, case, tmp_path):
+    MMI.test_emulated_index_dump_equals_the_reference_dump_and_loads_back(gpu_lib, case, tmp_path)
+
+
+def test_gpu_dump_while_mapping_and_part_level_calls(gpu_lib, tmp_path):
+    MMI.test_emulated_dump_while_mapping_and_part_level_calls(gpu_lib, tmp_path)
+
+
+def test_gpu_index_with_more_minimizers_than_counters_is_refused(gpu_lib, tmp_path):
+    MMI.test_emulated_index_with_more_minimizers_than_counters_is_refused(gpu_lib, tmp_path)

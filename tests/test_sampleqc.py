@@ -53,6 +53,11 @@ def test_argv_table_matches_longqc():
     assert sampleqc.coverage_argv("ont-rapid", "a", "b", short=True) == "-Y -l 0 -q 160 -k 12 -w 5 -I 4G -p 140 -t 4 a b".split()
     assert sampleqc.spikein_argv("refs/Sequel_control_reference.fasta", "sub.fq", 4) == \
         "-Y -Hk15 -w 10 -c 1 -l 0 --filter -t 4 refs/Sequel_control_reference.fasta sub.fq".split()
+    # sampleqc --db (longQC.py:266-277, 440-442): index first, then map against the prebuilt index without -k/-w
+    assert sampleqc.db_build_argv("ont-ligation", "t_db", "in.fq") == "-k 12 -w 5 -I 4G -d t_db in.fq".split()
+    assert sampleqc.db_build_argv("pb-hifi", "t_db", "in.fq", fast=True) == "-k 19 -w 10 -I 4G -d t_db in.fq".split()
+    assert sampleqc.db_build_argv("pb-sequel", "t_db_s", "in.fq", short=True) == "-k 12 -w 5 -I 4G -d t_db_s in.fq".split()
+    assert sampleqc.db_coverage_argv("ont-ligation", "t_db", "sub.fq", ncpu=8) == "-Y -l 0 -q 160 -p 160 -t 8 t_db sub.fq".split()
 
 
 def test_replace_masked_and_write_fastq(tmp_path):
