@@ -192,6 +192,16 @@ int lqcov_accum_export_dev(lqcov_handle *h, uint64_t *lambda_dev, uint64_t *lamb
 int lqcov_accum_import_dev(lqcov_handle *h, const uint64_t *lambda_dev, const uint64_t *lambda2_dev, const float *avg_k_dev, const uint32_t *flags_dev,
                            const uint32_t *counters_dev, const uint32_t *intervals_dev, uint32_t n_intervals);
 
+/* ---- the reference's second binary, `sdust` (low-complexity table of every read) ---------------- */
+/* == `sdust [-w W] [-t T] <in.fa|fq[.gz]>` with stdout -> out_path (NULL: stdout), stderr -> err_path: one row per read,
+ * name, masked bases, length, masked/length %.3f, meanQ %.3f, #qualities above Q7.            sdust.c:181-222 */
+int lqsdust_main(int argc, const char *const *argv, const char *out_path, const char *err_path, int device);
+/* buffer level: reads as ASCII (seq_off has n+1 entries; qual NULL or parallel to seq, zero bytes = no qualities);
+ * per read the masked bases (sdust_core, sdust.c:136-171), the sum of 10^(-q/10) over its qualities in read order
+ * (meanQ = -10 log10(sum / length), lqutils.c:51-58) and getQV(qual, 7) (lqutils.c:61-69).  W in [3, 66].           */
+int lqsdust_reads(int device, uint32_t n, const uint8_t *seq, const uint64_t *seq_off, const uint8_t *qual, int W, int T,
+                  uint32_t *masked, double *qual_psum, uint32_t *n_above_q7, char *errbuf, size_t errbuf_len);
+
 #ifdef __cplusplus
 }
 #endif

@@ -120,12 +120,13 @@ public:
 
 	// mm_bseq_read2 (bseq.c:68-102): append records until their bases reach `chunk`; U -> T
 	// (bseq.c:61-63).  Returns the number of records appended.
-	uint32_t read_minibatch(int64_t chunk, ReadBatch &out, bool keep_qual)
+	// raw = true: plain kseq records, bases untouched (what `sdust` reads, sdust.c:199).
+	uint32_t read_minibatch(int64_t chunk, ReadBatch &out, bool keep_qual, bool raw = false)
 	{
 		int64_t size = 0;
 		uint32_t n = 0;
 		while (next(name_, seq_, qual_)) {
-			for (auto &ch : seq_) if (ch == 'u' || ch == 'U') --ch;
+			if (!raw) for (auto &ch : seq_) if (ch == 'u' || ch == 'U') --ch;
 			out.add(name_, seq_, qual_, keep_qual);
 			++n; size += (int64_t)seq_.size();
 			if (size >= chunk) break;

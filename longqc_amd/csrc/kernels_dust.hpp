@@ -1,0 +1,130 @@
+// longqc_amd/csrc/kernels_dust.hpp -- SURVEY 8(f)-4: the low-complexity scan of the reference's second binary,
+// `sdust` (sdust.c:136-171 sdust_core, symmetric DUST), plus the two quality columns of its table (lqutils.c:51-69).
+//
+// The scan is a sequential state machine over a read: a window of the last <= W-2 triplet words with their counts, the
+// "v" suffix of that window, the list of perfect intervals of the window and the last masked interval, which may still
+// grow.  An N ends the run of words and closes the pending intervals but leaves the window and its counts as they are
+// (sdust.c:163-167), so a read cannot be cut into independent pieces: one thread walks one read.  The window, the three
+// count tables (64 one-byte entries each) live in LDS, lane-minor; the perfect-interval list, touched only inside
+// low-complexity sequence, lives in a per-thread slice of global scratch; a thread takes reads tid, tid + n_threads, ...
+#pragma once
+#include "lq_common.hpp"
+#ifndef LQ_SHARED
+#ifdef LQ_EMU
+#define LQ_SHARED static
+#else
+#define LQ_SHARED __shared__
+#endif
+#endif
+
+#define LQ_DUST_THREADS 64
+#define LQ_DUST_PCAP 4096       // perfect intervals of one window: <= 62 starts x <= 62 finishes (1431..1638 on the test sets)
+#define LQ_DUST_MAX_THREADS 16384  // threads per launch (each owns LQ_DUST_PCAP entries of scratch = 1 GiB in all); reads are strided over them
+struct DustPI { i32 start, finish, r, l; };
+
+__global__ void __launch_bounds__(LQ_DUST_THREADS)
+k_sdust(const u8 *seq, const u8 *qual, const u64 *seq_off, u32 n_reads, i32 W, i32 T, const double *q2p,
+        DustPI *pi_scratch, u32 *masked_out, double *psum_out, u32 *qv_out, u32 *overflow)
+{
+	LQ_SHARED u8 s_q[64][LQ_DUST_THREADS], s_cw[64][LQ_DUST_THREADS], s_cv[64][LQ_DUST_THREADS], s_c[64][LQ_DUST_THREADS];
+	const u32 tid = blockIdx.x * blockDim.x + threadIdx.x, n_threads = gridDim.x * blockDim.x;
+	const u32 ln = threadIdx.x;
+	DustPI *P = pi_scratch + (u64)tid * LQ_DUST_PCAP;
+	for (u32 r = tid; r < n_reads; r += n_threads) {
+	const u64 off = seq_off[r];
+	const i32 len = (i32)(seq_off[r + 1] - off);
+	const u8 *s = seq + off;
+	for (int i = 0; i < 64; ++i) { s_cw[i][ln] = 0; s_cv[i][ln] = 0; }
+	i32 qn = 0, qh = 0, rw = 0, rv = 0, L = 0, np = 0;
+	i32 l = 0, have_last = 0, ls = 0, lf = 0;
+	u32 t = 0;
+	i64 masked = 0;
+	bool over = false;
+	// close the perfect intervals that start before `start` (sdust.c:93-108)
+#define LQ_DUST_FLUSH(start_) do { \
+		const i32 st_ = (start_); \
+		if (np != 0 && P[np - 1].start < st_) { \
+			const DustPI p_ = P[np - 1]; \
+			if (have_last && p_.start <= lf) { if (p_.finish > lf) lf = p_.finish; } \
+			else { if (have_last) masked += lf - ls; have_last = 1; ls = p_.start; lf = p_.finish; } \
+			i32 i_ = np - 1; \
+			while (i_ >= 0 && P[i_].start < st_) --i_; \
+			np = i_ + 1; \
+		} \
+	} while (0)
+	for (i32 i = 0; i <= len; ++i) {
+		const u32 ch = i < len ? s[i] : 0u;
+		const u32 cu = ch & 0xdfu;                             // upper case
+		const i32 b = cu == 'A' ? 0 : cu == 'C' ? 1 : cu == 'G' ? 2 : cu == 'T' ? 3 : -1;   // seq_nt4_table of sdust.c:25-42
+		if (b >= 0) {
+			++l; t = (t << 2 | (u32)b) & 63u;
+			if (l >= 3) {
+				const i32 start = (l - W > 0 ? l - W : 0) + (i + 1 - l);
+				LQ_DUST_FLUSH(start);
+				// shift_window (sdust.c:70-91)
+				if (qn >= W - 3 + 1) {
+					const u32 so = s_q[qh][ln]; qh = (qh + 1) & 63; --qn;
+					rw -= --s_cw[so][ln];
+					if (L > qn) { --L; rv -= --s_cv[so][ln]; }
+				}
+				s_q[(qh + qn) & 63][ln] = (u8)t; ++qn;
+				++L;
+				rw += s_cw[t][ln]++;
+				rv += s_cv[t][ln]++;
+				if ((i32)s_cv[t][ln] * 10 > T << 1) {
+					u32 so;
+					do {
+						so = s_q[(qh + qn - L) & 63][ln];
+						rv -= --s_cv[so][ln];
+						--L;
+					} while (so != t);
+				}
+				if (rw * 10 > L * T) {
+					// find_perfect (sdust.c:110-134)
+					for (int z = 0; z < 64; ++z) s_c[z][ln] = s_cv[z][ln];
+					i32 rr = rv, max_r = 0, max_l = 0;
+					for (i32 wi = qn - L - 1; wi >= 0; --wi) {
+						const u32 tw = s_q[(qh + wi) & 63][ln];
+						rr += s_c[tw][ln]++;
+						const i32 new_r = rr, new_l = qn - wi - 1;
+						if (new_r * 10 > T * new_l) {
+							i32 j = 0;
+							for (; j < np && P[j].start >= wi + start; ++j) {
+								const DustPI p = P[j];
+								if (max_r == 0 || p.r * max_l > max_r * p.l) { max_r = p.r; max_l = p.l; }
+							}
+							if (max_r == 0 || new_r * max_l >= max_r * new_l) {
+								max_r = new_r; max_l = new_l;
+								if (np >= LQ_DUST_PCAP) over = true;
+								else {
+									for (i32 m = np; m > j; --m) P[m] = P[m - 1];
+									++np;
+									DustPI e; e.start = wi + start; e.finish = qn + 2 + start; e.r = new_r; e.l = new_l;
+									P[j] = e;
+								}
+							}
+						}
+					}
+				}
+			}
+		} else {
+			i32 start = (l - W + 1 > 0 ? l - W + 1 : 0) + (i + 1 - l);
+			while (np) { LQ_DUST_FLUSH(start); ++start; }
+			l = 0; t = 0;
+		}
+	}
+#undef LQ_DUST_FLUSH
+	if (have_last) masked += lf - ls;
+	masked_out[r] = (u32)masked;
+	if (over) atomicOr(overflow, 1u);
+	// meanQ's sum (lqutils.c:51-56: sequential, in read order) and getQV(qual, 7) (lqutils.c:61-69); a record without
+	// qualities arrives as zero bytes
+	double ps = 0.0;
+	u32 qv = 0;
+	if (qual && len > 0 && qual[off] != 0) {
+		const u8 *q = qual + off;
+		for (i32 i = 0; i < len; ++i) { const i32 v = (i32)q[i]; ps += q2p[v - 33]; if (v > 7 + 33) ++qv; }
+	}
+	psum_out[r] = ps; qv_out[r] = qv;
+	}
+}

@@ -29,10 +29,12 @@
 // the block (t = thread index), LQ_BLOCK_SYNC() separates phases.  On the GPU that is the thread itself and
 // __syncthreads(); the serial test emulator lets thread 0 play every thread of the block, phase by phase.
 #ifdef LQ_EMU
+#undef LQ_SHARED
 #define LQ_SHARED static
 #define LQ_BLOCK_LOOP(t) if (threadIdx.x == 0) for (u32 t = 0; t < blockDim.x; ++t)
 #define LQ_BLOCK_SYNC()
 #else
+#undef LQ_SHARED
 #define LQ_SHARED __shared__
 #define LQ_BLOCK_LOOP(t) for (u32 t = threadIdx.x, lq_once_ = 1; lq_once_; lq_once_ = 0)
 #define LQ_BLOCK_SYNC() __syncthreads()

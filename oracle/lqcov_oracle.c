@@ -1093,3 +1093,150 @@ int lqo_dump_paths(const lqo_params *p, const char *what, const char *target_fn,
 	fclose(o);
 	return r;
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * the low-complexity table of the reference's second binary, `sdust` (sdust.c:136-217):
+ * symmetric DUST (window W of 3-mers, threshold T) over every read, one row per read:
+ * name, masked bases, length, masked/length, meanQ, #qualities > Q7 (lqutils.c:51-69).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct { int start, finish, r, l; } dust_pi;                 /* a perfect interval of the current window */
+typedef struct {
+	int q[256], qn, qh;        /* the last <= W-2 words, oldest first (ring) */
+	int cw[64], cv[64];        /* word counts over the window / over its last L words */
+	int rw, rv, L;
+	dust_pi *P; size_t np, mp; /* descending start, then ascending finish */
+	int have_last, ls, lf;     /* the last masked interval (may still grow) */
+	int64_t masked;            /* total length of the closed masked intervals */
+} dust_t;
+
+static inline int dust_at(const dust_t *d, int i) { return d->q[(d->qh + i) & 255]; }
+
+/* sdust.c:93-108 */
+static void dust_flush(dust_t *d, int start)
+{
+	long i;
+	const dust_pi *p;
+	if (d->np == 0 || d->P[d->np - 1].start >= start) return;
+	p = &d->P[d->np - 1];
+	if (d->have_last && p->start <= d->lf) { if (p->finish > d->lf) d->lf = p->finish; }   /* overlaps / touches the last one */
+	else {
+		if (d->have_last) d->masked += d->lf - d->ls;
+		d->have_last = 1; d->ls = p->start; d->lf = p->finish;
+	}
+	for (i = (long)d->np - 1; i >= 0 && d->P[i].start < start; --i) {}
+	d->np = (size_t)(i + 1);
+}
+
+/* sdust.c:70-91 */
+static void dust_shift(dust_t *d, int t, int T, int W)
+{
+	int s;
+	if (d->qn >= W - 3 + 1) {
+		s = d->q[d->qh]; d->qh = (d->qh + 1) & 255; --d->qn;
+		d->rw -= --d->cw[s];
+		if (d->L > d->qn) { --d->L; d->rv -= --d->cv[s]; }
+	}
+	d->q[(d->qh + d->qn) & 255] = t; ++d->qn;
+	++d->L;
+	d->rw += d->cw[t]++;
+	d->rv += d->cv[t]++;
+	if (d->cv[t] * 10 > T << 1) {
+		do {
+			s = dust_at(d, d->qn - d->L);
+			d->rv -= --d->cv[s];
+			--d->L;
+		} while (s != t);
+	}
+}
+
+/* sdust.c:110-134 */
+static void dust_find(dust_t *d, int T, int start)
+{
+	int c[64], r = d->rv, i, max_r = 0, max_l = 0;
+	memcpy(c, d->cv, sizeof(c));
+	for (i = d->qn - d->L - 1; i >= 0; --i) {
+		const int t = dust_at(d, i);
+		int new_r, new_l;
+		size_t j;
+		r += c[t]++;
+		new_r = r; new_l = d->qn - i - 1;
+		if (new_r * 10 > T * new_l) {
+			for (j = 0; j < d->np && d->P[j].start >= i + start; ++j) {
+				const dust_pi *p = &d->P[j];
+				if (max_r == 0 || p->r * max_l > max_r * p->l) { max_r = p->r; max_l = p->l; }
+			}
+			if (max_r == 0 || new_r * max_l >= max_r * new_l) {
+				max_r = new_r; max_l = new_l;
+				if (d->np == d->mp) { d->mp = d->mp ? d->mp * 2 : 16; d->P = (dust_pi*)realloc(d->P, d->mp * sizeof(dust_pi)); }
+				memmove(&d->P[j + 1], &d->P[j], (d->np - j) * sizeof(dust_pi));
+				++d->np;
+				d->P[j].start = i + start; d->P[j].finish = d->qn + 2 + start; d->P[j].r = new_r; d->P[j].l = new_l;
+			}
+		}
+	}
+}
+
+/* sdust_core (sdust.c:136-171): the number of masked bases of one read.  Note that an N ends the run of words (l, t)
+ * and closes the pending intervals but leaves the window and its counts as they are. */
+uint32_t lqo_sdust_masked(const char *seq, int l_seq, int T, int W)
+{
+	static const signed char nt4[128] = { ['A'] = 1, ['C'] = 2, ['G'] = 3, ['T'] = 4, ['a'] = 1, ['c'] = 2, ['g'] = 3, ['t'] = 4 };
+	dust_t d;
+	int i, l = 0, start;
+	unsigned t = 0;
+	uint32_t total;
+	memset(&d, 0, sizeof(d));
+	for (i = 0; i <= l_seq; ++i) {
+		const int ch = i < l_seq ? (unsigned char)seq[i] : 0;
+		const int b = ch < 128 ? nt4[ch] - 1 : -1;
+		if (b >= 0) {
+			++l; t = (t << 2 | (unsigned)b) & 63;
+			if (l >= 3) {
+				start = (l - W > 0 ? l - W : 0) + (i + 1 - l);
+				dust_flush(&d, start);
+				dust_shift(&d, (int)t, T, W);
+				if (d.rw * 10 > d.L * T) dust_find(&d, T, start);
+			}
+		} else {
+			start = (l - W + 1 > 0 ? l - W + 1 : 0) + (i + 1 - l);
+			while (d.np) dust_flush(&d, start++);
+			l = 0; t = 0;
+		}
+	}
+	if (d.have_last) d.masked += d.lf - d.ls;
+	total = (uint32_t)d.masked;
+	free(d.P);
+	return total;
+}
+
+/* sdust's main (sdust.c:181-222) */
+int lqo_sdust_file(const char *fn, int W, int T, FILE *out)
+{
+	fx_t f;
+	cstr name = {0,0,0}, seq = {0,0,0}, qual = {0,0,0};
+	int l;
+	if (W > 254 || W < 3) return -1;
+	if (fx_open(&f, fn) != 0) return -1;
+	while ((l = fx_next(&f, &name, &seq, &qual)) >= 0) {
+		uint32_t masked, qv = 0;
+		size_t i;
+		vpush(name, 0);
+		masked = lqo_sdust_masked(seq.a, (int)seq.n, T, W);
+		for (i = 0; i < qual.n; ++i) if ((int)qual.a[i] > 7 + 33) ++qv;            /* getQV (lqutils.c:61-69) */
+		fprintf(out, "%s\t%d\t%d\t%.3f\t%.3f\t%d\n", name.a, (int)masked, (int)seq.n, (double)masked / seq.n,
+		        mean_q(qual.a, (int)qual.n), (int)qv);
+	}
+	free(name.a); free(seq.a); free(qual.a);
+	fx_close(&f);
+	return 0;
+}
+
+int lqo_sdust_path(const char *fn, int W, int T, const char *out_fn)
+{
+	FILE *o = fopen(out_fn, "w");
+	int rc;
+	if (!o) return -1;
+	rc = lqo_sdust_file(fn, W, T, o);
+	fclose(o);
+	return rc;
+}

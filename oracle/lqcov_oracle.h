@@ -68,6 +68,11 @@ void lqo_sort_128x(lqo_mm128 *a, size_t n);
 void lqo_sort_64(uint64_t *a, size_t n);
 void lqo_sort_32(uint32_t *a, size_t n);
 
+/* the reference's `sdust` binary (sdust.c): masked bases of one read, and its whole table */
+uint32_t lqo_sdust_masked(const char *seq, int l_seq, int T, int W);
+int lqo_sdust_file(const char *fn, int W, int T, FILE *out);
+int lqo_sdust_path(const char *fn, int W, int T, const char *out_fn);
+
 /* timing breakdown of the last lqo_run_files call, seconds: [0]=parse [1]=sketch+index [2]=map [3]=format */
 void lqo_last_timing(double t[4]);
 

@@ -29,7 +29,20 @@ int main(int argc, char **argv)
 	lqo_params p;
 	const char *pos[4];
 	int npos = 0, i, p_set = 0, q_set = 0;
-	if (argc < 3) { fprintf(stderr, "usage: lqcov_oracle table|sketch|index|chains [opts] files...\n"); return 2; }
+	if (argc < 3) { fprintf(stderr, "usage: lqcov_oracle table|sketch|index|chains [opts] files... | sdust [-w W] [-t T] <reads>\n"); return 2; }
+	if (!strcmp(argv[1], "sdust")) {                        /* == `sdust [-w 64] [-t 20] <in.fa>` (sdust.c:181-196) */
+		int W = 64, T = 20, i2;
+		const char *fn = 0;
+		for (i2 = 2; i2 < argc; ++i2) {
+			const char *a2 = argv[i2];                       /* getopt "w:t:": -w 16 and -w16 */
+			if (a2[0] == '-' && (a2[1] == 'w' || a2[1] == 't')) {
+				const char *v = a2[2] ? a2 + 2 : (i2 + 1 < argc ? argv[++i2] : "0");
+				if (a2[1] == 'w') W = atoi(v); else T = atoi(v);
+			} else if (!fn) fn = a2;
+		}
+		if (!fn) return 2;
+		return lqo_sdust_file(fn, W, T, stdout) ? 1 : 0;
+	}
 	lqo_params_default(&p);
 	p.min_ovlp = 1000;
 	for (i = 2; i < argc; ++i) {

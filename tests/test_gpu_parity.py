@@ -224,3 +224,43 @@ def test_gpu_dump_while_mapping_and_part_level_calls(gpu_lib, tmp_path):
 
 def test_gpu_index_with_more_minimizers_than_counters_is_refused(gpu_lib, tmp_path):
     MMI.test_emulated_index_with_more_minimizers_than_counters_is_refused(gpu_lib, tmp_path)
+
+
+# ---- the low-complexity table (sdust) ----
+import tests.test_sdust as SD  # noqa: E402
+
+
+@pytest.mark.parametrize("case", SD.CASES, ids=lambda c: c["name"])
+def test_gpu_sdust_main_equals_the_reference_table(gpu_lib, case, tmp_path):
+    SD.check_main_equals_fixture(gpu_lib, case, tmp_path)
+
+
+def test_gpu_sdust_in_memory_rows_and_errors(gpu_lib, tmp_path):
+    SD.check_in_memory_rows(gpu_lib, tmp_path)
+
+
+def test_gpu_sdust_edge_reads(gpu_lib, tmp_path):
+    SD.test_emulated_sdust_edge_reads(gpu_lib, tmp_path)
+
+
+def test_gpu_sdust_midsize_vs_oracle(gpu_lib, tmp_path):
+    """3 000 synthetic ONT reads (44 Mbases) with planted low-complexity stretches: the GPU table vs the oracle's"""
+    import dataclasses
+    import subprocess
+    cfg = dataclasses.replace(synth.CONFIGS["cfg2"], n_reads=3000, nsample=10)
+    T, _ = synth.make_dataset(cfg)
+    rng = np.random.default_rng(5)
+    for i in range(0, len(T), 7):                                  # poly-A, dinucleotide and triplet repeats, N runs
+        s = T.seqs[i].copy()
+        if s.shape[0] > 900:
+            a = int(rng.integers(0, s.shape[0] - 800))
+            s[a:a + 200] = ord("A"); s[a + 300:a + 500] = np.frombuffer(b"AT" * 100, dtype=np.uint8)
+            s[a + 520:a + 526] = ord("N"); s[a + 600:a + 780] = np.frombuffer(b"CAG" * 60, dtype=np.uint8)
+            T.seqs[i] = s
+    fq = str(tmp_path / "t.fq")
+    synth.write_fastq(fq, T)
+    want = subprocess.run([oracle_bind.ensure_oracle(), "sdust", fq], stdout=subprocess.PIPE, check=True).stdout.decode()
+    rc, out, err = SD.run_sdust_main(gpu_lib, [fq], tmp=tmp_path)
+    assert rc == 0, err
+    assert out == want
+    assert sum(int(l.split("\t")[1]) for l in out.splitlines()) > 100000

@@ -1,0 +1,100 @@
+"""the low-complexity table of the reference's second binary `sdust` (sdust.c).  Oracle
+restatement vs fixtures written by the reference binary (tests/golden/make_sdust_golden.py), the product's kernel under
+the serial HIP stand-in vs the same fixtures.  GPU versions: test_gpu_parity.py."""
+import ctypes as C
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from tests import oracle_bind
+from tests.conftest import GOLDEN, read_gz
+from tests.helpers import read_fastx
+
+CASES = json.load(open(os.path.join(GOLDEN, "sdust_cases.json")))
+
+
+def run_sdust_main(lib, argv, cwd=None, tmp=None):
+    full = [b"sdust"] + [str(a).encode() for a in argv]
+    arr = (C.c_char_p * len(full))(*full)
+    lib.lqsdust_main.restype = C.c_int
+    lib.lqsdust_main.argtypes = [C.c_int, C.POINTER(C.c_char_p), C.c_char_p, C.c_char_p, C.c_int]
+    out, err = os.path.join(str(tmp), "o"), os.path.join(str(tmp), "e")
+    old = os.getcwd()
+    try:
+        if cwd:
+            os.chdir(cwd)
+        rc = lib.lqsdust_main(len(full), arr, out.encode(), err.encode(), 0)
+    finally:
+        os.chdir(old)
+    return rc, (open(out).read() if os.path.exists(out) else ""), (open(err).read() if os.path.exists(err) else "")
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: c["name"])
+def test_oracle_sdust_equals_the_reference_table(case, tmp_path):
+    exe = oracle_bind.ensure_oracle()
+    r = subprocess.run([exe, "sdust"] + case["argv"], cwd=GOLDEN, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 0, r.stderr.decode()
+    assert r.stdout.decode() == read_gz(case["expect"])
+    assert case["masked_total"] > 0                               # the fixture does exercise the masking
+
+
+def test_oracle_sdust_vs_reference_binary_on_synthetic_reads(datasets):
+    ref = os.path.join(os.path.dirname(oracle_bind.REF_BIN), "sdust")
+    if not os.path.exists(ref):
+        pytest.skip("oracle/_ref/sdust not built (needs /root/reference)")
+    tf, _ = datasets("small")
+    for extra in ([], ["-w", "20"], ["-t", "12"]):
+        a = subprocess.run([ref] + extra + [tf], stdout=subprocess.PIPE, check=True).stdout
+        b = subprocess.run([oracle_bind.ensure_oracle(), "sdust"] + extra + [tf], stdout=subprocess.PIPE, check=True).stdout
+        assert a == b
+
+
+def check_main_equals_fixture(lib, case, tmp_path):
+    rc, out, err = run_sdust_main(lib, case["argv"], cwd=GOLDEN, tmp=tmp_path)
+    assert rc == 0, err
+    assert out == read_gz(case["expect"])
+
+
+def check_in_memory_rows(lib, tmp_path):
+    from longqc_amd import sdust
+    for fn, exp in (("adv_sub.fq.gz", "adv_sub.sdust.gz"), ("adv_all.fa.gz", "adv_all.sdust.gz")):
+        names, seqs, quals = read_fastx(os.path.join(GOLDEN, fn))
+        rows = sdust.sdust_rows(names, seqs, quals, lib=lib)
+        assert "\n".join(rows) + "\n" == read_gz(exp)
+    out = str(tmp_path / "t.txt")
+    sdust.run_sdust(os.path.join(GOLDEN, "tiny_all.fq.gz"), out, lib=lib)
+    assert open(out).read() == read_gz("tiny_all.sdust.gz")
+    with pytest.raises(Exception):
+        sdust.run_sdust(os.path.join(GOLDEN, "tiny_all.fq.gz"), out, w=200, lib=lib)      # window beyond the supported range
+    with pytest.raises(Exception):
+        sdust.run_sdust(os.path.join(GOLDEN, "no_such_file.fq"), out, lib=lib)
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: c["name"])
+def test_emulated_sdust_main_equals_the_reference_table(emu_lib, case, tmp_path):
+    check_main_equals_fixture(emu_lib, case, tmp_path)
+
+
+def test_emulated_sdust_in_memory_rows_and_errors(emu_lib, tmp_path):
+    check_in_memory_rows(emu_lib, tmp_path)
+
+
+def test_emulated_sdust_edge_reads(emu_lib, tmp_path):
+    """empty read, read shorter than a word, all-N, a homopolymer, N in the middle of a low-complexity run"""
+    p = str(tmp_path / "e.fq")
+    recs = [("empty", ""), ("two", "AC"), ("alln", "N" * 70), ("polya", "A" * 200), ("split", "AT" * 40 + "N" + "AT" * 40),
+            ("mixed", "ACGTTGCA" * 5 + "a" * 30 + "ACGGTCAGTC" * 4)]
+    with open(p, "w") as f:
+        for n, s in recs:
+            f.write("@%s\n%s\n+\n%s\n" % (n, s, "5" * len(s)))
+    exe = oracle_bind.ensure_oracle()
+    want = subprocess.run([exe, "sdust", p], stdout=subprocess.PIPE, check=True).stdout.decode()
+    rc, out, err = run_sdust_main(emu_lib, [p], tmp=tmp_path)
+    assert rc == 0, err
+    assert out == want
+    ref = os.path.join(os.path.dirname(oracle_bind.REF_BIN), "sdust")
+    if os.path.exists(ref):
+        assert subprocess.run([ref, p], stdout=subprocess.PIPE, check=True).stdout.decode() == want
