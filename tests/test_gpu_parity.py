@@ -243,6 +243,10 @@ def test_gpu_sdust_edge_reads(gpu_lib, tmp_path):
     SD.test_emulated_sdust_edge_reads(gpu_lib, tmp_path)
 
 
+def test_gpu_sdust_repeat_rich_reads(gpu_lib, tmp_path):
+    SD.check_repeat_rich(gpu_lib, tmp_path)
+
+
 def test_gpu_sdust_midsize_vs_oracle(gpu_lib, tmp_path):
     """3 000 synthetic ONT reads (44 Mbases) with planted low-complexity stretches: the GPU table vs the oracle's"""
     import dataclasses

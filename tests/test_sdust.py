@@ -98,3 +98,50 @@ def test_emulated_sdust_edge_reads(emu_lib, tmp_path):
     ref = os.path.join(os.path.dirname(oracle_bind.REF_BIN), "sdust")
     if os.path.exists(ref):
         assert subprocess.run([ref, p], stdout=subprocess.PIPE, check=True).stdout.decode() == want
+
+
+def write_repeat_rich_reads(path, n=150, seed=11):
+    """reads made mostly of short tandem repeats (unit 1..6, 3 % substitutions), lower-case two-letter stretches and N
+    runs between random sequence: most bases end up masked, the perfect-interval list gets long"""
+    rng = np.random.default_rng(seed)
+    A = np.frombuffer(b"ACGT", dtype=np.uint8)
+    with open(path, "w") as f:
+        for i in range(n):
+            parts = []
+            for _ in range(int(rng.integers(1, 12))):
+                k = rng.random()
+                if k < 0.35:
+                    parts.append(A[rng.integers(0, 4, size=int(rng.integers(20, 800)))].tobytes().decode())
+                elif k < 0.85:
+                    u = A[rng.integers(0, 4, size=int(rng.integers(1, 7)))].tobytes().decode()
+                    rep = list(u * int(rng.integers(5, 400)))
+                    for j in range(len(rep)):
+                        if rng.random() < 0.03:
+                            rep[j] = "ACGT"[int(rng.integers(0, 4))]
+                    parts.append("".join(rep))
+                elif k < 0.93:
+                    parts.append("N" * int(rng.integers(1, 5)))
+                else:
+                    parts.append(A[rng.integers(0, 2, size=int(rng.integers(30, 300)))].tobytes().decode().lower())
+            s = "".join(parts)
+            f.write("@s%d\n%s\n+\n%s\n" % (i, s, "".join(chr(33 + int(x)) for x in rng.integers(2, 45, size=len(s)))))
+
+
+def check_repeat_rich(lib, tmp_path, variants=(("64", "20"), ("64", "8"), ("20", "15"), ("66", "30"))):
+    p = str(tmp_path / "stress.fq")
+    write_repeat_rich_reads(p)
+    exe = oracle_bind.ensure_oracle()
+    ref = os.path.join(os.path.dirname(oracle_bind.REF_BIN), "sdust")
+    for w, t in variants:
+        want = subprocess.run([exe, "sdust", "-w", w, "-t", t, p], stdout=subprocess.PIPE, check=True).stdout.decode()
+        if os.path.exists(ref):
+            assert subprocess.run([ref, "-w", w, "-t", t, p], stdout=subprocess.PIPE, check=True).stdout.decode() == want
+        rc, out, err = run_sdust_main(lib, ["-w", w, "-t", t, p], tmp=tmp_path)
+        assert rc == 0, err
+        assert out == want
+        tot = sum(int(l.split("\t")[1]) for l in out.splitlines()); ln = sum(int(l.split("\t")[2]) for l in out.splitlines())
+        assert tot > 0.3 * ln
+
+
+def test_emulated_sdust_repeat_rich_reads(emu_lib, tmp_path):
+    check_repeat_rich(emu_lib, tmp_path)
