@@ -499,14 +499,17 @@ void lqcov_handle::map_batch(MapLane &L, Part &pt, u32 q0, u32 q1, const std::ve
 		cs.ivl = L.ivl.as<Ivl>(); cs.n_ivl = L.n_ivl.as<u32>(); cs.ivl_cap = ivl_cap;
 		cs.dbg = dbg ? dbg_chains.as<ChainRec>() : nullptr; cs.n_dbg = n_dbg.as<unsigned long long>(); cs.dbg_cap = dbg_cap;
 		if (n_groups > 0xfffffff0ULL) throw std::domain_error("too many anchor runs in one batch");
-		const int wave_min = getenv("LQCOV_CHAIN_WAVE_MIN") ? std::max(1, atoi(getenv("LQCOV_CHAIN_WAVE_MIN"))) : LQ_CHAIN_WAVE_MIN;   // test knob
-		{	// one thread per run, in array order, DP state of a wave's runs packed into LDS.  Measured alternatives that were
-			// slower on MI355X: a compacted longest-first work list for all runs (409 vs 292 ms at configs[1]), private-array
-			// DP for short runs, and a fixed [16][64] LDS column per lane (54 KiB per wave: 160 + 40 ms vs 113 ms).
+		const int cap_env = getenv("LQCOV_CHAIN_CAP") ? atoi(getenv("LQCOV_CHAIN_CAP")) : 128;   // A/B + test knob: anchors of LDS per wave in k_chain
+		const int cap = cap_env <= 64 ? 64 : cap_env <= 128 ? 128 : 256;
+		// runs of >= wave_min anchors take the cooperative kernel; a run must fit k_chain's LDS budget on its own
+		const int wave_min = std::min(cap + 1, getenv("LQCOV_CHAIN_WAVE_MIN") ? std::max(1, atoi(getenv("LQCOV_CHAIN_WAVE_MIN"))) : LQ_CHAIN_WAVE_MIN);   // test knob
+		{	// one thread per run, in array order, DP state of a wave's runs packed into LDS (in rounds if they exceed the budget).
+			// Measured alternatives that were slower on MI355X: a compacted longest-first work list for all runs (409 vs 292 ms at
+			// configs[1]), private-array DP for short runs, and a fixed [16][64] LDS column per lane (54 KiB per wave: 160 + 40 ms
+			// vs 113 ms).  wave_min - 1 <= 47 < the smallest budget, so every run fits.
 			StageTimer t(this, L.stream, "k_chain", nA * 16);
-			const int cap = getenv("LQCOV_CHAIN_CAP") ? atoi(getenv("LQCOV_CHAIN_CAP")) : 128;   // A/B + test knob: LDS anchors per wave
-#define LQ_CHAIN_LAUNCH(CAP) LQ_LAUNCH((k_chain<CAP>), nblk(n_groups, 64), 64, L.stream, dA, L.gstart.as<u64>(), (const u32*)nullptr, (u32)n_groups, aqb, a_base, nqb, q0, avg_qspan.as<float>(), mp, cb, cs, (i32)P.min_cnt, (i32)(wave_min - 1))
-			if (cap <= 16) { LQ_CHAIN_LAUNCH(16); } else if (cap <= 128) { LQ_CHAIN_LAUNCH(128); } else { LQ_CHAIN_LAUNCH(256); }
+#define LQ_CHAIN_LAUNCH(CAP) LQ_LAUNCH((k_chain<CAP>), nblk(n_groups, 64), 64, L.stream, dA, L.gstart.as<u64>(), (const u32*)nullptr, (u32)n_groups, aqb, a_base, nqb, q0, avg_qspan.as<float>(), mp, cs, (i32)P.min_cnt, (i32)(wave_min - 1))
+			if (cap == 64) { LQ_CHAIN_LAUNCH(64); } else if (cap == 128) { LQ_CHAIN_LAUNCH(128); } else { LQ_CHAIN_LAUNCH(256); }
 #undef LQ_CHAIN_LAUNCH
 			check_launch();
 		}

@@ -311,19 +311,22 @@ __device__ __forceinline__ bool lq_run_viable(AP a, i64 n, const MapParams &P)
 // aq_off: the batch's view of the per-query anchor offsets (n_q+1 entries, absolute; the batch's
 // anchors start at a_base); q0: global index of the batch's first query.
 // One thread per run of min_len..max_len anchors, in array order.  The serial DP is a chain of dependent, scattered
-// accesses to the run's anchors and DP arrays; with 64 unrelated working sets per wave those are L2 round trips.  So
-// the wave packs the runs it will actually chain (most runs are too short or cannot reach min_sc) into LDS -- anchors
-// plus f/p/t/v/u, 40 B per anchor, offsets from a scan of the run lengths -- and each lane works on its slice there.
-// Runs that do not fit the LDS budget use the global scratch arrays (indexed like the anchors).
+// accesses to the run's anchors and DP arrays; with 64 unrelated working sets per wave in global memory those are L2
+// round trips and partial-line writes (rocprofv3: 18 GB written per launch for 8 GB of anchors).  So the wave packs the
+// runs it will actually chain (most runs are too short or cannot reach min_sc) into LDS -- anchors plus f/p/t/v/u, 40 B
+// per anchor, offsets from a scan of the run lengths -- and each lane works on its slice there.  When the runs of a wave
+// exceed the LDS budget they are taken in rounds: the runs that fit go now, the others wait for the next round.
+// Measured on MI355X at configs[1] (k_chain per step): DP state in global scratch 113 ms; first version of the LDS
+// packing, overflow runs in global scratch: budget of 384 anchors per wave 127 ms (10 waves per CU), 256: 107, 128: 97.
 template <int LQ_CHAIN_LDS_CAP>
 __global__ void __launch_bounds__(64)
 k_chain(const mm128 *A, const u64 *gstart, const u32 *glist, u32 n_list, const u64 *aq_off, u64 a_base, u32 n_q, u32 q0,
-        const float *avg_qspan_q, MapParams P, ChainBufs B, CovState C, i32 min_len, i32 max_len)
+        const float *avg_qspan_q, MapParams P, CovState C, i32 min_len, i32 max_len)
 {
 	LQ_SHARED mm128 s_a[LQ_CHAIN_LDS_CAP];
 	LQ_SHARED i32 s_f[LQ_CHAIN_LDS_CAP], s_p[LQ_CHAIN_LDS_CAP], s_t[LQ_CHAIN_LDS_CAP], s_v[LQ_CHAIN_LDS_CAP];
 	LQ_SHARED u64 s_u[LQ_CHAIN_LDS_CAP];
-	LQ_SHARED u32 s_n[64], s_q[64];
+	LQ_SHARED u32 s_n[64], s_q[64], s_done[64];
 	const u32 gi0 = blockIdx.x * blockDim.x;
 	LQ_BLOCK_LOOP(ln) {
 		u32 todo = 0;
@@ -332,32 +335,39 @@ k_chain(const mm128 *A, const u64 *gstart, const u32 *glist, u32 n_list, const u
 			const u32 g = glist ? glist[gi] : gi;
 			const u64 gs = gstart[g];
 			const i64 n = (i64)(gstart[g + 1] - gs);
-			if (n >= min_len && n <= max_len && lq_run_viable(A + gs, n, P)) {
+			if (n >= min_len && n <= max_len && n <= LQ_CHAIN_LDS_CAP && lq_run_viable(A + gs, n, P)) {
 				const u32 q = q0 + lq_find_seg(aq_off, n_q, gs + a_base);
 				if (!C.skip[q] || C.dbg) { todo = (u32)n; s_q[ln] = q; }
 			}
 		}
-		s_n[ln] = todo;
+		s_n[ln] = todo; s_done[ln] = 0;
 	}
 	LQ_BLOCK_SYNC();
-	LQ_BLOCK_LOOP(ln) {
-		const u32 n32 = s_n[ln];
-		if (n32) {
-			u32 off = 0;
-			for (u32 z = 0; z < ln; ++z) off += s_n[z];
-			const u32 gi = gi0 + ln;
-			const u32 g = glist ? glist[gi] : gi;
-			const u64 gs = gstart[g];
-			const i64 n = (i64)n32;
-			const u32 q = s_q[ln];
-			const bool accumulate = !C.skip[q];
-			if (off + n32 <= LQ_CHAIN_LDS_CAP) {
-				mm128 *la = s_a + off;
-				for (i64 i = 0; i < n; ++i) la[i] = A[gs + i];
-				lq_chain_run(la, n, s_f + off, s_p + off, s_t + off, s_v + off, s_u + off, q, accumulate, avg_qspan_q, P, C);
-			} else
-				lq_chain_run(A + gs, n, B.f + gs, B.p + gs, B.t + gs, B.v + gs, B.u + gs, q, accumulate, avg_qspan_q, P, C);
+	for (;;) {
+		u32 left = 0;                                        // block-uniform: runs still waiting
+		for (u32 z = 0; z < 64; ++z) left += s_n[z] != 0;
+		if (left == 0) break;
+		LQ_BLOCK_LOOP(ln) {
+			const u32 n32 = s_n[ln];
+			if (n32) {
+				u32 off = 0;
+				for (u32 z = 0; z < ln; ++z) off += s_n[z];
+				if (off + n32 <= LQ_CHAIN_LDS_CAP) {             // the first waiting run always fits
+					const u32 gi = gi0 + ln;
+					const u32 g = glist ? glist[gi] : gi;
+					const u64 gs = gstart[g];
+					const i64 n = (i64)n32;
+					const u32 q = s_q[ln];
+					mm128 *la = s_a + off;
+					for (i64 i = 0; i < n; ++i) la[i] = A[gs + i];
+					lq_chain_run(la, n, s_f + off, s_p + off, s_t + off, s_v + off, s_u + off, q, !C.skip[q], avg_qspan_q, P, C);
+					s_done[ln] = 1;
+				}
+			}
 		}
+		LQ_BLOCK_SYNC();
+		LQ_BLOCK_LOOP(ln) { if (s_done[ln]) { s_n[ln] = 0; s_done[ln] = 0; } }
+		LQ_BLOCK_SYNC();
 	}
 }
 

@@ -170,9 +170,10 @@ def test_emulated_wave_chain_kernel_on_every_run(emu_lib, case, monkeypatch):
 
 @pytest.mark.parametrize("case", [c for c in _cases("table") if c["name"] in ("tiny_ont", "adv_ont", "adv_parts", "tiny_spike")], ids=lambda c: c["name"])
 def test_emulated_chain_lds_budget_overflow(emu_lib, case, monkeypatch):
-    """LQCOV_CHAIN_CAP=16: only 16 anchors per wave fit the LDS staging of k_chain, every other run takes the
-    global-scratch path"""
-    monkeypatch.setenv("LQCOV_CHAIN_CAP", "16")
+    """LQCOV_CHAIN_CAP=64 with LQCOV_CHAIN_WAVE_MIN=200: the smallest LDS budget of k_chain (64 anchors per wave) with every run
+    up to 64 anchors in that kernel: the runs of a wave are chained in several rounds"""
+    monkeypatch.setenv("LQCOV_CHAIN_CAP", "64")
+    monkeypatch.setenv("LQCOV_CHAIN_WAVE_MIN", "200")
     rc, out, err = run_main(emu_lib, case["argv"], cwd=GOLDEN)
     assert rc == 0, err
     assert out == read_gz(case["expect"])
