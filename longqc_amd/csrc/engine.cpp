@@ -336,6 +336,12 @@ void lqcov_handle::build_index(Part &pt)
 	h2d(pt.self_rid.as<u32>(), srid.data(), srid.size(), stream);
 	LQ_HIP_CHECK(hipStreamSynchronize(stream));
 	pt.built = true;
+	// the build workspaces stay with the handle so that repeated builds do not re-allocate; for parts of the reference's
+	// default size (4 Gbases: ~60 GB of them) the mapping work space is the better use of that HBM.  (The dump of a part
+	// reads three of them, so it runs before this point is reached again -- run_files dumps right after the build.)
+	if (ix_key.cap + ix_key2.cap + ix_head.cap + ix_uidx.cap + ix_ukey.cap + ix_ustart.cap + ix_ucnt.cap + ix_sorted.cap > (32ULL << 30)) {
+		ix_key.release(); ix_key2.release(); ix_head.release(); ix_uidx.release(); ix_sorted.release();
+	}
 }
 
 void lqcov_handle::build_part(Part &pt)
