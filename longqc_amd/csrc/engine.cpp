@@ -11,6 +11,7 @@
 #include <cinttypes>
 #include <algorithm>
 #include <unordered_map>
+#include <future>
 
 static inline u32 nblk(u64 n, u32 bs)
 {
@@ -1023,20 +1024,31 @@ int lqcov_handle::run_files(const char *target, const char *query, FILE *out, FI
 	} else {
 		FastxReader ft(target);
 		const int64_t chunk = (int)((u64)P.idx_mini_batch < P.batch_size ? (u64)P.idx_mini_batch : P.batch_size);   // index.c:316
-		for (;;) {
-			// one part: mini-batches while the running total is <= -I (index.c:244)
-			int id = -1;
+		// one part = mini-batches while the running total is <= -I (index.c:244).  The host parses the next part while the
+		// device sketches, indexes and maps the current one.
+		auto read_part = [&ft, chunk, this]() {
+			std::vector<ReadBatch> bs;
 			u64 sum_len = 0;
-			ReadBatch tb;
 			for (;;) {
 				if (sum_len > P.batch_size) break;
-				tb.clear();
-				if (ft.read_minibatch(chunk, tb, false) == 0) break;
-				if (id < 0) { parts.emplace_back(new Part()); id = (int)parts.size() - 1; parts[id]->live = true; }
-				add_reads(parts[id]->rs, tb.size(), tb.seq.data(), tb.seq_off.data(), tb.names.data(), tb.name_off.data());
-				sum_len += tb.bases();
+				bs.emplace_back();
+				if (ft.read_minibatch(chunk, bs.back(), false) == 0) { bs.pop_back(); break; }
+				sum_len += bs.back().bases();
 			}
-			if (id < 0) break;
+			return bs;
+		};
+		std::future<std::vector<ReadBatch>> next_part = std::async(std::launch::async, read_part);   // (declared after `ft`: its destructor joins the reader first)
+		for (;;) {
+			std::vector<ReadBatch> bs = next_part.get();
+			if (bs.empty()) break;
+			next_part = std::async(std::launch::async, read_part);
+			parts.emplace_back(new Part());
+			const int id = (int)parts.size() - 1;
+			parts[id]->live = true;
+			for (ReadBatch &tb : bs) {
+				add_reads(parts[id]->rs, tb.size(), tb.seq.data(), tb.seq_off.data(), tb.names.data(), tb.name_off.data());
+				tb = ReadBatch();
+			}
 			Part &pt = *parts[id];
 			sketch(pt.rs, true);
 			build_index(pt);
