@@ -14,7 +14,7 @@ static inline dim3 nblk_d(u64 n, u32 b) { return dim3((unsigned)((n + b - 1) / b
 namespace {
 struct DustDev {
 	hipStream_t stream = nullptr;
-	DBuf seq, qual, off, pi, masked, psum, qv, q2p, flag;
+	DBuf seq, qual, off, pi, masked, psum, qv, q2p;
 	bool tab_ready = false;
 	~DustDev() { if (stream) { hipStreamSynchronize(stream); hipStreamDestroy(stream); } }
 };
@@ -44,7 +44,7 @@ void dust_batch(DustDev &D, u32 n, const u8 *seq, const u64 *seq_off, const u8 *
 	for (u32 i = 0; i <= n; ++i) off[i] = seq_off[i] - seq_off[0];
 	D.seq.ensure(nb + 16); D.off.ensure((n + 1) * 8); const u32 n_thr = (u32)std::min<u64>(((u64)n + LQ_DUST_THREADS - 1) / LQ_DUST_THREADS * LQ_DUST_THREADS, LQ_DUST_MAX_THREADS);
 	D.pi.ensure((u64)n_thr * LQ_DUST_PCAP * sizeof(DustPI));
-	D.masked.ensure(n * 4 + 4); D.psum.ensure(n * 8 + 8); D.qv.ensure(n * 4 + 4); D.flag.ensure(4);
+	D.masked.ensure(n * 4 + 4); D.psum.ensure(n * 8 + 8); D.qv.ensure(n * 4 + 4);
 	if (!D.tab_ready) {
 		double tab[127]; make_q2p_table(tab);
 		D.q2p.ensure(127 * 8);
@@ -58,17 +58,13 @@ void dust_batch(DustDev &D, u32 n, const u8 *seq, const u64 *seq_off, const u8 *
 		D.qual.ensure(nb + 16);
 		LQ_HIP_CHECK(hipMemcpyAsync(D.qual.p, qual + seq_off[0], nb, hipMemcpyHostToDevice, D.stream));
 	}
-	LQ_HIP_CHECK(hipMemsetAsync(D.flag.p, 0, 4, D.stream));
 	LQ_LAUNCH(k_sdust, nblk_d(n_thr, LQ_DUST_THREADS), LQ_DUST_THREADS, D.stream, D.seq.as<u8>(), qual ? D.qual.as<u8>() : (const u8*)nullptr,
-	          D.off.as<u64>(), n, (i32)W, (i32)T, D.q2p.as<double>(), D.pi.as<DustPI>(), D.masked.as<u32>(), D.psum.as<double>(), D.qv.as<u32>(), D.flag.as<u32>());
+	          D.off.as<u64>(), n, (i32)W, (i32)T, D.q2p.as<double>(), D.pi.as<DustPI>(), D.masked.as<u32>(), D.psum.as<double>(), D.qv.as<u32>());
 	LQ_HIP_CHECK(hipGetLastError());
-	u32 fl = 0;
 	LQ_HIP_CHECK(hipMemcpyAsync(masked, D.masked.p, n * 4, hipMemcpyDeviceToHost, D.stream));
 	LQ_HIP_CHECK(hipMemcpyAsync(psum, D.psum.p, n * 8, hipMemcpyDeviceToHost, D.stream));
 	LQ_HIP_CHECK(hipMemcpyAsync(qv, D.qv.p, n * 4, hipMemcpyDeviceToHost, D.stream));
-	LQ_HIP_CHECK(hipMemcpyAsync(&fl, D.flag.p, 4, hipMemcpyDeviceToHost, D.stream));
 	LQ_HIP_CHECK(hipStreamSynchronize(D.stream));
-	(void)fl;
 }
 
 void set_err(char *err, size_t n, const char *msg) { if (err && n) snprintf(err, n, "%s", msg); }

@@ -32,7 +32,7 @@ struct DustPI { i32 finish; u32 rl; };                         // newest finish;
 
 __global__ void __launch_bounds__(LQ_DUST_THREADS)
 k_sdust(const u8 *seq, const u8 *qual, const u64 *seq_off, u32 n_reads, i32 W, i32 T, const double *q2p,
-        DustPI *pi_scratch, u32 *masked_out, double *psum_out, u32 *qv_out, u32 *overflow)
+        DustPI *pi_scratch, u32 *masked_out, double *psum_out, u32 *qv_out)
 {
 	LQ_SHARED u8 s_q[64][LQ_DUST_THREADS], s_cw[64][LQ_DUST_THREADS], s_cv[64][LQ_DUST_THREADS], s_c[64][LQ_DUST_THREADS];
 	const u32 tid = blockIdx.x * blockDim.x + threadIdx.x, n_threads = gridDim.x * blockDim.x;

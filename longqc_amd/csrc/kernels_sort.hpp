@@ -398,7 +398,6 @@ __global__ void k_sort_walk_lds(const SortSeg *segs, const u32 *list, u32 n_list
 // lane the wave-uniform LDS address the instruction needs is simply this lane's) and walks on; the window is only
 // waited for if the token returns to that bucket before the data has landed.  The serial chain of a trip is then
 // LDS-only.  ~6.5 KiB of LDS per walk lets ~24 walks share a CU.
-#define LQ_SOLO_FLUSH 16
 #ifdef LQ_EMU
 #define LQ_DMA_WIN16(gptr, ldsptr) memcpy((ldsptr), (gptr), 16)
 #define LQ_WAIT_VM0() ((void)0)
