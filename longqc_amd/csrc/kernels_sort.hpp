@@ -404,6 +404,7 @@ __global__ void k_sort_walk_lds(const SortSeg *segs, const u32 *list, u32 n_list
 #define LQ_LDS_U8(p) (*(p))
 #define LQ_LDS_U32(p) (*(const u32*)(p))
 #define LQ_LDS_U64(p) (*(p))
+#define LQ_UNI(v) (v)
 #else
 #define LQ_DMA_WIN16(gptr, ldsptr) \
 	__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr), (__attribute__((address_space(3))) void*)(ldsptr), 16, 0, 0)
@@ -435,6 +436,9 @@ __device__ __forceinline__ u64 lq_lds_u64(const u64 *p)
 	return v;
 }
 #define LQ_LDS_U64(p) lq_lds_u64(p)
+// only lane 0 walks: moving what it reads from LDS into scalar registers makes the walk's control flow scalar branches
+// instead of exec-mask sequences
+#define LQ_UNI(v) ((u32)__builtin_amdgcn_readfirstlane((int)(v)))
 #endif
 #define LQ_SOLO_PEND 0x80000000u
 __global__ void __launch_bounds__(64)
@@ -467,23 +471,23 @@ k_sort_walk_solo(const SortSeg *segs, const u32 *list, u32 n_list, const u8 *D, 
 #define LQ_SOLO_ADVANCE(bk, c, dq) do { \
 		const u32 nc_ = (c) + 1, o_ = (b15 + nc_) & 15; \
 		if (o_ & 3) ent[bk] = (u64)nc_ | (u64)((dq) >> 8) << 32; \
-		else if (o_) ent[bk] = (u64)nc_ | (u64)LQ_LDS_U32(&win[bk][o_]) << 32; \
+		else if (o_) ent[bk] = (u64)nc_ | (u64)LQ_UNI(LQ_LDS_U32(&win[bk][o_])) << 32; \
 		else { LQ_DMA_WIN16(D + base + nc_, &win[bk][0]); ent[bk] = (u64)(nc_ | LQ_SOLO_PEND); }   /* next window: fetch it asynchronously */ \
 	} while (0)
 	u32 k = 0;
 	for (;;) {
 		// START: next bucket with unread slots; the element under its cursor is picked up, leaving a hole there
-		while (k < 256 && ((u32)LQ_LDS_U64(&ent[k]) & ~LQ_SOLO_PEND) >= endb[k]) ++k;
+		while (k < 256 && (LQ_UNI((u32)LQ_LDS_U64(&ent[k])) & ~LQ_SOLO_PEND) >= LQ_UNI(endb[k])) ++k;
 		if (k >= 256) break;
 		const u64 he = LQ_LDS_U64(&ent[k]);
-		u32 hole = (u32)he, hdq = (u32)(he >> 32);
-		if (hole & LQ_SOLO_PEND) { LQ_WAIT_VM0(); hole &= ~LQ_SOLO_PEND; hdq = LQ_LDS_U32(&win[k][0]); }
+		u32 hole = LQ_UNI((u32)he), hdq = LQ_UNI((u32)(he >> 32));
+		if (hole & LQ_SOLO_PEND) { LQ_WAIT_VM0(); hole &= ~LQ_SOLO_PEND; hdq = LQ_UNI(LQ_LDS_U32(&win[k][0])); }
 		u32 src = hole, l = hdq & 0xff;
 		// CARRY: the carried element takes the slot under its bucket's cursor; that slot's occupant is carried on
 		while (l != k) {
 			const u64 e = LQ_LDS_U64(&ent[l]);
-			u32 c = (u32)e, dq = (u32)(e >> 32);
-			if (c & LQ_SOLO_PEND) { LQ_WAIT_VM0(); c &= ~LQ_SOLO_PEND; dq = LQ_LDS_U32(&win[l][0]); }   // l's window was in flight
+			u32 c = LQ_UNI((u32)e), dq = LQ_UNI((u32)(e >> 32));
+			if (c & LQ_SOLO_PEND) { LQ_WAIT_VM0(); c &= ~LQ_SOLO_PEND; dq = LQ_UNI(LQ_LDS_U32(&win[l][0])); }   // l's window was in flight
 			ds[src] = c;
 			LQ_SOLO_ADVANCE(l, c, dq);
 			src = c; l = dq & 0xff;
