@@ -144,3 +144,16 @@ def test_emulated_index_with_more_minimizers_than_counters_is_refused(emu_lib, t
     want = oracle_bind.table(["-Y", "-l", "0", "-q", "160", "-p", "160", "-k", "15", "-w", "5", "-I", "4G",
                               os.path.join(GOLDEN, "adv_all.fa.gz"), os.path.join(GOLDEN, "adv_sub.fq.gz")])
     assert out == want
+
+
+def test_emulated_rejected_combinations(emu_lib, tmp_path):
+    """-d with an index file as the target, a truncated index file, neither query nor -d"""
+    mmi = gunzip_to(os.path.join(GOLDEN, "adv_k19w10.mmi.gz"), str(tmp_path / "a.mmi"))
+    rc, out, err = run_main(emu_lib, ["-d", str(tmp_path / "b.mmi"), mmi])
+    assert rc != 0 and "not supported" in err
+    cut = str(tmp_path / "cut.mmi")
+    open(cut, "wb").write(open(mmi, "rb").read()[:100000])
+    rc, out, err = run_main(emu_lib, ["-Y", "-l", "0", "-q", "160", "-p", "160", "-k", "19", "-w", "10", cut, os.path.join(GOLDEN, "adv_sub.fq.gz")])
+    assert rc != 0 and "truncated" in err
+    rc, out, err = run_main(emu_lib, ["-Y", mmi])
+    assert rc != 0
