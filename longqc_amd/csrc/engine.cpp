@@ -438,9 +438,8 @@ void lqcov_handle::map_batch(MapLane &L, Part &pt, u32 q0, u32 q1, const std::ve
 					if (cw[2]) { StageTimer t(this, L.stream, "k_sort_walk_lds<16384>"); LQ_LAUNCH((k_sort_walk_lds<16384>), cw[2], 64, L.stream, cur, wl + (u64)1 * ns, cw[2], dD, dH, dBg, dDst); check_launch(); }
 					const u32 n_long = cw[3] + cw[4] + cw[5];
 					if (n_long) {
-						// longer sub-arrays: one lane each over the global digit bytes (64 independent walks per wave keep more
-						// memory transactions in flight than a single LDS-resident walker can), longest first.
-						// The three size classes are contiguous in the list only per class, so gather them.
+						// longer sub-arrays: one wave per walk (k_sort_walk_solo: walk state and 16-byte digit windows in LDS), longest
+						// first.  The three size classes are contiguous in the list only per class, so gather them.
 						L.wkey.ensure((u64)n_long * 4); L.wkey2.ensure((u64)n_long * 4); L.walk_list2.ensure((u64)n_long * 4); L.walk_list3.ensure((u64)n_long * 4);
 						u32 o = 0;
 						for (int c = 2; c < LQ_WALK_CLASSES; ++c) if (cw[1 + c]) {
