@@ -147,6 +147,10 @@ int lqcov_sync(lqcov_handle *h);                    /* wait for the handle's str
 /* == main pass 2 up to, not including, printf (minimap2-coverage.c:545-566). */
 int lqcov_finish(lqcov_handle *h);
 int lqcov_n_queries(const lqcov_handle *h);
+/* The engine holds the queries longest first; perm[i] = the caller's index of the i-th query in that order.  Only the
+ * per-query arrays of lqcov_accum_export_dev / lqcov_accum_import_dev are in the engine's order; rows, regions, minimizer
+ * and chain dumps are in the caller's. */
+int lqcov_query_order(lqcov_handle *h, uint32_t *perm, uint32_t n);
 int lqcov_get_rows(lqcov_handle *h, lqcov_row *rows, uint32_t n_rows);
 int lqcov_get_regions(lqcov_handle *h, const lqcov_region **regs, uint32_t *n_regs, const lqcov_region **mregs, uint32_t *n_mregs);
 /* Text of the table, rows in query order (minimap2-coverage.c:567-605). names as in lqcov_set_queries. */

@@ -90,6 +90,7 @@ def load_library(path: Optional[str] = None):
         "lqcov_sync": (C.c_int, [H]),
         "lqcov_finish": (C.c_int, [H]),
         "lqcov_n_queries": (C.c_int, [H]),
+        "lqcov_query_order": (C.c_int, [H, C.c_void_p, C.c_uint32]),
         "lqcov_get_rows": (C.c_int, [H, C.POINTER(Row), C.c_uint32]),
         "lqcov_get_regions": (C.c_int, [H, C.POINTER(C.c_void_p), C.POINTER(C.c_uint32), C.POINTER(C.c_void_p), C.POINTER(C.c_uint32)]),
         "lqcov_write_table": (C.c_int, [H, C.c_char_p]),
@@ -347,6 +348,13 @@ class Engine:
 
     def set_mid_occ(self, v: int):
         self._ck(self.lib.lqcov_set_mid_occ(self.h, int(v)))
+
+    def query_order(self) -> np.ndarray:
+        """perm[i] = the caller's index of the i-th query in the engine's own (longest first) order"""
+        n = self.lib.lqcov_n_queries(self.h)
+        perm = np.zeros(max(n, 1), dtype=np.uint32)
+        self._ck(self.lib.lqcov_query_order(self.h, perm.ctypes.data, n))
+        return perm[:n]
 
     def accum_sizes(self) -> Tuple[int, int, int]:
         a, b, c = C.c_uint32(), C.c_uint64(), C.c_uint32()

@@ -228,6 +228,15 @@ int lqcov_sync(lqcov_handle *h) { return guard(h, [&] { LQ_HIP_CHECK(hipStreamSy
 int lqcov_finish(lqcov_handle *h) { return guard(h, [&] { if (!h->have_queries) throw std::logic_error("no queries"); h->finish(); }); }
 int lqcov_n_queries(const lqcov_handle *h) { return h ? (int)h->q.n : LQCOV_E_ARG; }
 
+int lqcov_query_order(lqcov_handle *h, uint32_t *perm, uint32_t n)
+{
+	return guard(h, [&] {
+		if (!h->have_queries) throw std::logic_error("no queries");
+		if (n < h->q.n || !perm) throw std::invalid_argument("buffer too small");
+		for (u32 i = 0; i < h->q.n; ++i) perm[i] = h->q_perm[i];
+	});
+}
+
 int lqcov_get_rows(lqcov_handle *h, lqcov_row *rows, uint32_t n_rows)
 {
 	return guard(h, [&] {
@@ -275,7 +284,25 @@ static void copy_minimizers(lqcov_handle *h, ReadSetDev &rs, uint64_t *xy, uint6
 
 int lqcov_get_query_minimizers(lqcov_handle *h, uint64_t *xy, uint64_t *off, uint64_t *n_total)
 {
-	return guard(h, [&] { if (!h->have_queries) throw std::logic_error("no queries"); copy_minimizers(h, h->q, xy, off, n_total); });
+	return guard(h, [&] {
+		if (!h->have_queries) throw std::logic_error("no queries");
+		// the engine keeps the queries in its own order (engine.hpp: q_perm); hand the lists out in the caller's
+		const u32 n = h->q.n;
+		std::vector<u64> ioff(n + 1, 0), ixy;
+		u64 tot = 0;
+		copy_minimizers(h, h->q, nullptr, ioff.data(), &tot);
+		if (n_total) *n_total = tot;
+		if (xy) { ixy.resize(2 * tot + 2); copy_minimizers(h, h->q, ixy.data(), nullptr, nullptr); }
+		u64 o = 0;
+		for (u32 c = 0; c < n; ++c) {                           // c: caller's index
+			const u32 i = h->q_inv[c];
+			const u64 cnt = ioff[i + 1] - ioff[i];
+			if (off) off[c] = o;
+			if (xy && cnt) memcpy(xy + 2 * o, ixy.data() + 2 * ioff[i], cnt * 16);
+			o += cnt;
+		}
+		if (off) off[n] = o;
+	});
 }
 int lqcov_get_part_minimizers(lqcov_handle *h, int part, uint64_t *xy, uint64_t *off, uint64_t *n_total)
 {
@@ -289,7 +316,11 @@ int lqcov_get_chains(lqcov_handle *h, int32_t *out, uint64_t cap, uint64_t *n_to
 		if (n_total) *n_total = h->n_dbg_host;
 		u64 n = std::min<u64>(h->n_dbg_host, std::min<u64>(cap, h->dbg_cap));
 		static_assert(sizeof(ChainRec) == 9 * sizeof(int32_t), "chain record layout");
-		if (out && n) LQ_HIP_CHECK(hipMemcpy(out, h->dbg_chains.p, n * sizeof(ChainRec), hipMemcpyDeviceToHost));
+		if (out && n) {
+			LQ_HIP_CHECK(hipMemcpy(out, h->dbg_chains.p, n * sizeof(ChainRec), hipMemcpyDeviceToHost));
+			ChainRec *r = (ChainRec*)out;
+			for (u64 i = 0; i < n; ++i) r[i].q = (i32)h->q_perm[(u32)r[i].q];     // engine order -> caller's order
+		}
 	});
 }
 

@@ -217,9 +217,35 @@ static void make_q2p(double *t)
 }
 
 // == main pass 1 (minimap2-coverage.c:406-444)
-void lqcov_handle::set_queries(u32 n, const u8 *seq, const u64 *seq_off, const u8 *qual, const char *names, const u64 *name_off)
+void lqcov_handle::set_queries(u32 n, const u8 *seq_in, const u64 *seq_off_in, const u8 *qual_in, const char *names_in, const u64 *name_off_in)
 {
 	if (have_queries) throw std::logic_error("queries already set");
+	// internal order: longest first (stable); LQCOV_QUERY_ORDER=file keeps the caller's order (A/B and test knob)
+	q_perm.resize(n); q_inv.resize(n);
+	for (u32 i = 0; i < n; ++i) q_perm[i] = i;
+	if (!(getenv("LQCOV_QUERY_ORDER") && !strcmp(getenv("LQCOV_QUERY_ORDER"), "file")))
+		std::stable_sort(q_perm.begin(), q_perm.end(), [&](u32 a, u32 b) { return seq_off_in[a + 1] - seq_off_in[a] > seq_off_in[b + 1] - seq_off_in[b]; });
+	for (u32 i = 0; i < n; ++i) q_inv[q_perm[i]] = i;
+	std::vector<u8> pseq, pqual;
+	std::vector<u64> pseq_off(n + 1, 0), pname_off(n + 1, 0);
+	std::vector<char> pnames;
+	{
+		const u64 nb = n ? seq_off_in[n] - seq_off_in[0] : 0;
+		pseq.resize(nb + 1); if (qual_in) pqual.resize(nb + 1);
+		for (u32 i = 0; i < n; ++i) {
+			const u32 o = q_perm[i];
+			const u64 len = seq_off_in[o + 1] - seq_off_in[o];
+			memcpy(pseq.data() + pseq_off[i], seq_in + seq_off_in[o], len);
+			if (qual_in) memcpy(pqual.data() + pseq_off[i], qual_in + seq_off_in[o], len);
+			pseq_off[i + 1] = pseq_off[i] + len;
+			const char *nm = names_in ? names_in + name_off_in[o] : "";
+			pnames.insert(pnames.end(), nm, nm + strlen(nm) + 1);
+			pname_off[i + 1] = pnames.size();
+		}
+	}
+	const u8 *seq = pseq.data(), *qual = qual_in ? pqual.data() : nullptr;
+	const u64 *seq_off = pseq_off.data(), *name_off = pname_off.data();
+	const char *names = pnames.data();
 	if (seq_off[n] - seq_off[0] >= 500000000ULL && n > 1) {
 		// reference: a second 500-Mbase query mini-batch aliases the accumulator slots and crashes (lqmap.c:714,735)
 		u64 but_last = seq_off[n - 1] - seq_off[0];
@@ -738,7 +764,7 @@ void lqcov_handle::finish()
 			throw std::domain_error("query " + q.names[i] + ": a chain matched a minimizer beyond the counters sized from the command line's -k/-w/-H; "
 			                        "the reference overruns its counter array there (minimap2-coverage.c:422, esterr.c:131) -- pass the prebuilt index's -k/-w/-H");
 	for (u32 i = 0; i < n_q; ++i) {
-		lqcov_row &r = rows[i];
+		lqcov_row &r = rows[q_perm[i]];
 		r.lambda = hl[i]; r.lambda2 = hl2[i]; r.qual_psum = hp[i]; r.qlen = q.h_len[i];
 		r.n_mini = own_cnt_layout ? h_nsize[i] : (u32)(hmoff[i + 1] - hmoff[i]); r.n_match = hr[i].n_match; r.avg_k = hk[i];
 		r.reg_off = hr[i].reg_off; r.n_reg = hr[i].n_reg; r.mreg_off = hr[i].mreg_off; r.n_mreg = hr[i].n_mreg;
@@ -760,7 +786,7 @@ void lqcov_handle::write_table(FILE *out)
 		if (r.has_qual) mq = -10 * log10(r.qual_psum / (int)r.qlen);                                          // lqutils.c:57
 		else { volatile double z = 0.0; volatile int zl = 0; mq = -10 * log10(z / zl); }                                      // FASTA query: the reference's 0/0
 		line.clear();
-		line += q.names[i]; line += '\t';
+		line += q.names[q_inv[i]]; line += '\t';
 		snprintf(buf, sizeof(buf), "%d\t%" PRIu64 "\t", (int)r.qlen, r.lambda); line += buf;
 		if (r.n_reg > 0) {
 			u32 tot = 0;

@@ -78,6 +78,11 @@ struct lqcov_handle {
 	// query set and per-query accumulators
 	ReadSetDev q;
 	bool have_queries = false, q_has_qual = false;
+	// queries are held longest first (anchors per query grow with its length: the batch with the longest serial walks then
+	// starts first and the last batch has the shortest); q_perm[internal] = position in the caller's order, q_inv the inverse.
+	// Everything per query inside the engine (and in the accumulator exchange of the multi-GPU path) uses the internal order;
+	// rows, regions, minimizer and chain dumps are handed out in the caller's order.
+	std::vector<u32> q_perm, q_inv;
 	DBuf q_owner;                         // query of every query minimizer
 	DBuf lambda, lambda2, avg_k, cnts, qflags, qual_psum;
 	// counter layout: normally the query minimizer offsets; after adopt_index_params() (prebuilt index with other -k/-w/-H)

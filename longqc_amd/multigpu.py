@@ -111,8 +111,10 @@ class PartRunner:
         eng.set_distributed(True)
         n_q, n_cnt, _ = eng.accum_sizes()
         self.n_q, self.n_cnt = n_q, n_cnt
-        self.qlen = torch.as_tensor(np.asarray(query_lengths, dtype=np.int64), device=self.dev)
-        assert self.qlen.shape[0] == n_q
+        # the exchanged per-query arrays are in the engine's own query order (longest first): lengths in that order too
+        ql = np.asarray(query_lengths, dtype=np.int64)
+        assert ql.shape[0] == n_q
+        self.qlen = torch.as_tensor(ql[eng.query_order().astype(np.int64)], device=self.dev)
         self.begin()
 
     def begin(self):
