@@ -68,7 +68,6 @@ lqcov_handle::lqcov_handle(const lqcov_params &p, int dev) : P(p), device(dev)
 	if (P.k < 1 || P.k > 28 || P.w < 1 || P.w > 255) throw std::invalid_argument("k must be in [1,28] and w in [1,255] (sketch.c:83)");
 	if (P.min_score_med >= 65536 || P.min_score_good >= 65536 || P.min_score_med < 0 || P.min_score_good < 0)
 		throw std::invalid_argument("-p and -q must be below 65536 (lqmap.c:841 packs them into 16 bits each)");
-	if (P.ava) throw std::invalid_argument("-X (all-vs-all, MM_F_AVA) is outside the sampleqc path and not supported; use -Y");
 	int ndev = 0;
 	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) throw std::runtime_error("no HIP device available");
 	if (dev < 0 || dev >= ndev) throw std::runtime_error("HIP device index out of range");
@@ -358,6 +357,18 @@ void lqcov_handle::build_index(Part &pt)
 		}
 		for (u32 i = 0; i < q.n; ++i) { soff[i + 1] = soff[i] + (u32)per[i].size(); srid.insert(srid.end(), per[i].begin(), per[i].end()); }
 	}
+	if (P.ava) {	// -X: strcmp(qname, tname) > 0 drops the hit (lqmap.c:187) -> ranks among the part's distinct names
+		std::vector<std::string> names(rs.names.begin(), rs.names.end());
+		std::sort(names.begin(), names.end());
+		names.erase(std::unique(names.begin(), names.end()), names.end());
+		std::vector<u32> tr(rs.n + 1, 0), ql(q.n + 1, 0);
+		for (u32 r = 0; r < rs.n; ++r) tr[r] = (u32)(std::lower_bound(names.begin(), names.end(), rs.names[r]) - names.begin());
+		for (u32 i = 0; i < q.n; ++i) ql[i] = (u32)(std::lower_bound(names.begin(), names.end(), q.names[i]) - names.begin());
+		pt.t_rank.ensure((rs.n + 1) * 4); pt.q_lo.ensure((q.n + 1) * 4);
+		h2d(pt.t_rank.as<u32>(), tr.data(), rs.n + 1, stream);
+		h2d(pt.q_lo.as<u32>(), ql.data(), q.n + 1, stream);
+		LQ_HIP_CHECK(hipStreamSynchronize(stream));
+	}
 	pt.self_off.ensure((q.n + 1) * 4); pt.self_rid.ensure(srid.size() * 4 + 4);
 	h2d(pt.self_off.as<u32>(), soff.data(), q.n + 1, stream);
 	h2d(pt.self_rid.as<u32>(), srid.data(), srid.size(), stream);
@@ -403,7 +414,7 @@ void lqcov_handle::map_batch(MapLane &L, Part &pt, u32 q0, u32 q1, const std::ve
 		LQ_LAUNCH(k_seed_emit, nblk(nj, 256), 256, L.stream, q.mx.as<u64>(), q.my.as<u64>(), q_owner.as<u32>(), q.moff.as<u64>(), j0, nj,
 		          pt.pos.as<u64>(), hit_start.as<u64>(), hit_n.as<u32>(), keep.as<u32>(),
 		          a_off.as<u64>(), a_base, mp_off.as<u64>(), q.d_len.as<u32>(),
-		          (int)P.no_self, pt.self_off.as<u32>(), pt.self_rid.as<u32>(), dA, mini_pos.as<u64>());
+		          (int)P.no_self, pt.self_off.as<u32>(), pt.self_rid.as<u32>(), AvaView{P.ava ? pt.t_rank.as<u32>() : nullptr, P.ava ? pt.q_lo.as<u32>() : nullptr}, dA, mini_pos.as<u64>());
 		check_launch();
 	}
 	if (nA) {
@@ -617,7 +628,7 @@ void lqcov_handle::map_part(Part &pt)
 			StageTimer t(this, "k_seed_probe", n_qm * (16 + 16 + 20));
 			LQ_LAUNCH(k_seed_probe, nblk(n_qm, 256), 256, stream, q.mx.as<u64>(), q.my.as<u64>(), q_owner.as<u32>(), n_qm,
 			          pt.tkey.as<u64>(), pt.tstart.as<u64>(), pt.tcnt.as<u32>(), pt.cap_bits, pt.pos.as<u64>(),
-			          mid_occ, (int)P.no_self, pt.self_off.as<u32>(), pt.self_rid.as<u32>(),
+			          mid_occ, (int)P.no_self, pt.self_off.as<u32>(), pt.self_rid.as<u32>(), AvaView{P.ava ? pt.t_rank.as<u32>() : nullptr, P.ava ? pt.q_lo.as<u32>() : nullptr},
 			          hit_start.as<u64>(), hit_n.as<u32>(), a_cnt.as<u32>(), keep.as<u32>());
 			check_launch();
 		}

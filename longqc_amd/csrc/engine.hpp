@@ -43,6 +43,7 @@ struct Part {
 	u32 cap_bits = 0;
 	u64 n_keys = 0;
 	DBuf self_off, self_rid;              // per query: same-name targets (lqmap.c:180-186)
+	DBuf t_rank, q_lo;                    // -X only: name ranks for strcmp(qname, tname) > 0 (lqmap.c:187)
 };
 
 // One mapping lane: a stream with its own scan/sort scratch and per-batch work space.  Query batches of a part are

@@ -90,10 +90,14 @@ __device__ __forceinline__ bool lq_is_self(const u32 *self_off, const u32 *self_
 	return false;
 }
 
+// -X (MM_F_AVA, lqmap.c:187): a hit is dropped when strcmp(qname, tname) > 0.  t_rank[rid] = rank of the target's name
+// among the part's distinct names, q_lo[q] = number of distinct target names below the query's: tname < qname <=> rank < q_lo.
+struct AvaView { const u32 *t_rank, *q_lo; };     // both null without -X
+
 // pass A of collect_seed_hits: probe, apply mid_occ, count surviving hits
 __global__ void k_seed_probe(const u64 *qx, const u64 *qy, const u32 *owner, u64 n_qm,
                              const u64 *tkey, const u64 *tstart, const u32 *tcnt, u32 cap_bits, const u64 *pos,
-                             i32 mid_occ, int no_self, const u32 *self_off, const u32 *self_rid,
+                             i32 mid_occ, int no_self, const u32 *self_off, const u32 *self_rid, AvaView ava,
                              u64 *hit_start, u32 *hit_n, u32 *a_cnt, u32 *keep)
 {
 	u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -104,11 +108,14 @@ __global__ void k_seed_probe(const u64 *qx, const u64 *qy, const u32 *owner, u64
 	if ((i64)n >= (i64)mid_occ) { a_cnt[j] = 0; keep[j] = 0; return; }     // lqmap.c:166-173
 	u32 c = n;
 	u32 q = owner[j];
-	if (no_self && self_off[q] != self_off[q + 1]) {
+	const bool check_self = no_self && self_off[q] != self_off[q + 1];
+	if (check_self || ava.t_rank) {
 		u32 qpos = (u32)qy[j] >> 1;
+		const u32 qlo = ava.t_rank ? ava.q_lo[q] : 0;
 		for (u32 t = 0; t < n; ++t) {
 			u64 r = pos[st + t];
-			if (((u32)r >> 1) == qpos && lq_is_self(self_off, self_rid, q, (u32)(r >> 32))) --c;
+			if (check_self && ((u32)r >> 1) == qpos && lq_is_self(self_off, self_rid, q, (u32)(r >> 32))) --c;
+			else if (ava.t_rank && ava.t_rank[(u32)(r >> 32)] < qlo) --c;
 		}
 	}
 	a_cnt[j] = c; keep[j] = 1;
@@ -119,7 +126,7 @@ __global__ void k_seed_probe(const u64 *qx, const u64 *qy, const u32 *owner, u64
 __global__ void k_seed_emit(const u64 *qx, const u64 *qy, const u32 *owner, const u64 *qmoff, u64 j0, u64 nj,
                             const u64 *pos, const u64 *hit_start, const u32 *hit_n, const u32 *keep,
                             const u64 *a_off, u64 a_base, const u64 *mp_off, const u32 *qlen,
-                            int no_self, const u32 *self_off, const u32 *self_rid,
+                            int no_self, const u32 *self_off, const u32 *self_rid, AvaView ava,
                             mm128 *anchors, u64 *mini_pos)
 {
 #ifdef LQ_EMU
@@ -144,6 +151,7 @@ __global__ void k_seed_emit(const u64 *qx, const u64 *qy, const u32 *owner, cons
 		u64 r = pos[st + t];
 		u32 rpos = (u32)r >> 1;
 		if (check_self && rpos == qpos && lq_is_self(self_off, self_rid, q, (u32)(r >> 32))) continue;
+		if (ava.t_rank && ava.t_rank[(u32)(r >> 32)] < ava.q_lo[q]) continue;
 		mm128 a;
 		if ((r & 1) == (qp & 1)) {
 			a.x = (r & 0xffffffff00000000ULL) | rpos;
@@ -195,7 +203,8 @@ __global__ void k_seed_emit(const u64 *qx, const u64 *qy, const u32 *owner, cons
 			const bool valid = t < b_n;
 			const u64 r = valid ? pos[b_st + t] : 0;
 			const u32 rpos = (u32)r >> 1;
-			const bool skip = valid && (b_flags & 2) && rpos == b_qpos && lq_is_self(self_off, self_rid, b_q, (u32)(r >> 32));
+			const bool skip = valid && (((b_flags & 2) && rpos == b_qpos && lq_is_self(self_off, self_rid, b_q, (u32)(r >> 32))) ||
+			                            (ava.t_rank && ava.t_rank[(u32)(r >> 32)] < ava.q_lo[b_q]));
 			const u64 sm = __ballot(skip);
 			if (valid && !skip) {
 				mm128 a;

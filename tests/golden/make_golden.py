@@ -106,6 +106,9 @@ def main():
         "adv_spike": ["-Y", "-Hk15", "-w", "10", "-c", "1", "-l", "0", "--filter", "-t", "4", "adv_all.fa.gz", "adv_sub.fq.gz"],
         "adv_defaults": ["-Y", "-t", "2", "adv_all.fa.gz", "adv_sub.fq.gz"],
         "adv_w20": ["-Y", "-l", "0", "-k", "11", "-w", "20", "-m", "30", "-n", "2", "-t", "2", "adv_all.fa.gz", "adv_sub.fq.gz"],
+        # -X (MM_F_AVA): hits on targets whose name sorts before the query's are dropped (lqmap.c:187)
+        "tiny_ava": ["-X", "-l", "0", "-q", "160", "-k", "12", "-w", "5", "-I", "4G", "-p", "160", "-t", "4", "tiny_all.fq.gz", "tiny_sub.fq.gz"],
+        "adv_ava_parts": ["-X", "-l", "0", "-q", "160", "-k", "12", "-w", "5", "-I", "100K", "-p", "160", "-t", "4", "adv_all.fa.gz", "adv_sub.fq.gz"],
     }
     os.chdir(HERE)
     for name, argv in tables.items():
