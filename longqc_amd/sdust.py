@@ -75,6 +75,44 @@ def sdust_rows(names: Sequence[str], seqs: Sequence[np.ndarray], quals: Optional
     return rows
 
 
+class LqMaskMI355X:
+    """Counterpart of lq_mask.LqMask for the chunk loop of longQC.py (lq_mask.py:25-41, 99-121): submit_sdust(reads,
+    chunk_n) per chunk, close_pool() at the end, get_outfile_path() -> analysis table `longqc_sdust<suffix>.txt` with one
+    row per read in submission order.  Reads are LongQC's [name, seq, qual, ...] records (str or bytes); no temporary
+    FASTQ files, no process pool: every chunk is one call into the device.  The plots of LqMask are out of scope."""
+
+    def __init__(self, work_dir: str, suffix: Optional[str] = None, device: int = 0, lib=None):
+        self.suffix = "_" + suffix if suffix else ""
+        os.makedirs(work_dir, exist_ok=True)
+        self.wdir, self.device, self.lib = work_dir, device, lib
+        self.outf = os.path.join(work_dir, "longqc_sdust" + self.suffix + ".txt")
+        self._chunks = {}
+
+    @staticmethod
+    def _arr(v):
+        if v is None:
+            return None
+        if isinstance(v, str):
+            v = v.encode()
+        return np.frombuffer(bytes(v), dtype=np.uint8)
+
+    def submit_sdust(self, reads, chunk_n):
+        names = [r[0].decode() if isinstance(r[0], (bytes, bytearray)) else str(r[0]) for r in reads]
+        seqs = [self._arr(r[1]) for r in reads]
+        quals = [self._arr(r[2]) if len(r) > 2 and r[2] else None for r in reads]
+        self._chunks[chunk_n] = sdust_rows(names, seqs, quals, device=self.device, lib=self.lib)
+
+    def close_pool(self):
+        with open(self.outf, "w") as out:                      # lq_mask.py:83-88 concatenates the chunk tables in submission order
+            for k in self._chunks:
+                for row in self._chunks[k]:
+                    out.write(row + "\n")
+        self._chunks = {}
+
+    def get_outfile_path(self):
+        return self.outf
+
+
 def _c_div(a: float, b: int) -> float:
     return a / b if b else math.nan                       # C: 0.0 / 0 (x86: the default NaN, printed "-nan")
 

@@ -145,3 +145,16 @@ def check_repeat_rich(lib, tmp_path, variants=(("64", "20"), ("64", "8"), ("20",
 
 def test_emulated_sdust_repeat_rich_reads(emu_lib, tmp_path):
     check_repeat_rich(emu_lib, tmp_path)
+
+
+def test_emulated_lqmask_counterpart(emu_lib, tmp_path):
+    """LqMaskMI355X: the chunk loop of lq_mask.LqMask (submit_sdust / close_pool / get_outfile_path) without temporary files"""
+    from longqc_amd import sdust
+    names, seqs, quals = read_fastx(os.path.join(GOLDEN, "adv_sub.fq.gz"))
+    reads = [[n, bytes(s).decode(), bytes(q).decode()] for n, s, q in zip(names, seqs, quals)]
+    lm = sdust.LqMaskMI355X(str(tmp_path / "out"), suffix="x", lib=emu_lib)
+    lm.submit_sdust(reads[:7], 0)
+    lm.submit_sdust(reads[7:], 1)
+    lm.close_pool()
+    assert lm.get_outfile_path().endswith("longqc_sdust_x.txt")
+    assert open(lm.get_outfile_path()).read() == read_gz("adv_sub.sdust.gz")
