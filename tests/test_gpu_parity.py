@@ -239,6 +239,10 @@ def test_gpu_sdust_in_memory_rows_and_errors(gpu_lib, tmp_path):
     SD.check_in_memory_rows(gpu_lib, tmp_path)
 
 
+def test_gpu_lqmask_counterpart(gpu_lib, tmp_path):
+    SD.test_emulated_lqmask_counterpart(gpu_lib, tmp_path)
+
+
 def test_gpu_sdust_edge_reads(gpu_lib, tmp_path):
     SD.test_emulated_sdust_edge_reads(gpu_lib, tmp_path)
 
