@@ -1,18 +1,20 @@
 #!/usr/bin/env python3
-"""bench.py -- throughput of the sampleqc hot path (all reads -> index, subsample -> coverage table)
+"""bench.py -- throughput of the sampleqc hot path (all reads -> index parts, subsample -> coverage table)
 on N MI355X GPUs of one node.
 
     python bench.py --gpus 1 --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
 
-Workload (BASELINE.json configs[1]): 50k synthetic ONT reads ~15 kb, 15x, ont-ligation preset
-(-Y -l 0 -q 160 -k 12 -w 5 -p 160), query set = LongQC's seed-7 subsample of 5000 reads.  One "step" =
-one pass of the hot path over the resident reads: reset accumulators -> sketch + index the targets
--> seed / klib-order sort / chain / coverage for every query -> rows (D2H).  Reads are 2-bit packed
-in HBM before the timed region starts.  At N > 1 every rank owns one index part of that size (the
-reference's own -I partitioning of a N-times larger read set, DESIGN.md section "multi-GPU"), the
-per-part accumulators are combined over RCCL inside the timed region, and value = all ranks'
-target bases / max-over-ranks time (weak scaling).
+Workload at N=1 (BASELINE.json configs[2], the largest single-GPU configuration): 500k synthetic PacBio
+Sequel CLR reads ~10 kb, 30x, pb-sequel preset (-Y -l 0 -q 160 -k 12 -w 5 -I 4G -p 80, longQC.py:171-220);
+the reference's -I rule (index.c:244,311-316) cuts them into two index parts (4.0 + 1.0 Gbases); query set
+= LongQC's seed-7 subsample of 5000 reads.  `--config cfg2` selects configs[1] (50k ONT reads ~15 kb, 15x).
+
+One "step" = one whole job by SURVEY.md 8(d)'s clock: reset accumulators -> for every index part: H2D of
+the 2-bit packed reads from page-locked host memory -> sketch -> index (+ mid_occ) -> seed / klib-order sort
+/ chain / coverage for every query -> rows (D2H).  What happens before the clock: FASTQ parse (here: the
+synthetic generator) and the host-side 2-bit packing that the parser thread does (reported as host_pack_s).
+`value` = target bases / step time.  `hbm_resident_value` leaves the H2D out (reads already packed in HBM).
 """
 import argparse
 import json
@@ -29,19 +31,30 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 
+PRESET = {   # the argv longQC.py issues for the config's platform (longQC.py:177-231,440-445)
+    "cfg2": ("ont-ligation", ["-Y", "-l", "0", "-q", "160", "-k", "12", "-w", "5", "-I", "4G", "-p", "160"]),
+    "cfg3": ("pb-sequel", ["-Y", "-l", "0", "-q", "160", "-k", "12", "-w", "5", "-I", "4G", "-p", "80"]),
+}
+CONFIG_LABEL = {
+    "cfg2": "BASELINE configs[1]: %d synthetic ONT reads ~%d kb %gx, ont-ligation preset (-Y -l 0 -q 160 -k 12 -w 5 -I 4G -p 160)",
+    "cfg3": "BASELINE configs[2]: %d synthetic PacBio Sequel CLR reads ~%d kb %gx, pb-sequel preset (-Y -l 0 -q 160 -k 12 -w 5 -I 4G -p 80)",
+}
 
-def cpu_baseline(T, Q, n_t, n_q):
+
+def cpu_baseline(cfg_name, F, Q, n_t, n_q):
     """The reference's own minimap2-coverage (oracle/_ref, kind "reference") or the C restatement
     (kind "port") on a bounded sample of the same workload, timed on this host's cores."""
     from longqc_amd import synth
     from tests import oracle_bind
     cores = os.cpu_count() or 1
-    sub_t = T.subset(range(min(n_t, len(T))))
-    sub_q = Q.subset(range(min(n_q, len(Q))))
+    n_t = min(n_t, len(F)); n_q = min(n_q, len(Q))
+    sub_q = Q.subset(range(n_q))
     with tempfile.TemporaryDirectory() as d:
-        tf, qf = os.path.join(d, "t.fq"), os.path.join(d, "q.fq")
-        synth.write_fastq(tf, sub_t); synth.write_fastq(qf, sub_q)
-        argv = ["-Y", "-l", "0", "-q", "160", "-k", "12", "-w", "5", "-I", "4G", "-p", "160"]
+        tf, qf = os.path.join(d, "t.fa"), os.path.join(d, "q.fq")
+        sub_t = synth.FlatReads(F.first, F.flat[:int(F.off[n_t])], F.off[:n_t + 1])
+        synth.write_flat_fasta(tf, sub_t)
+        synth.write_fastq(qf, sub_q)
+        argv = PRESET[cfg_name][1]
         if oracle_bind.have_ref():
             kind, used = "reference", cores
             cmd = [oracle_bind.REF_BIN] + argv + ["-t", str(cores), tf, qf]
@@ -55,8 +68,22 @@ def cpu_baseline(T, Q, n_t, n_q):
             return None
     return {"value": round(sub_t.n_bases / dt / 1e6, 3), "unit": "Mbases/s", "cores": used, "kind": kind,
             "seconds": round(dt, 2),
-            "sample": "first %d target reads (%.1f Mbases) + first %d subsample reads as queries, same argv, "
-                      "FASTQ parse included; index build is ~serial in the reference (3 fixed threads)" % (len(sub_t), sub_t.n_bases / 1e6, len(sub_q))}
+            "sample": "first %d target reads (%.1f Mbases, FASTA) + first %d subsample reads as queries, same argv, "
+                      "file parse included; the reference's sketch/index step is ~serial (3 fixed threads, index.c:293-300), "
+                      "so the full %d-read job would take ~%.0f s" % (n_t, sub_t.n_bases / 1e6, n_q, len(F), dt * F.n_bases / max(sub_t.n_bases, 1))}
+
+
+def golden_check(cfg_name, table_text):
+    """rows of the reference itself for 40 of the queries, made on the whole read set in the build container
+    (tests/golden/make_scale_golden.py); None if the fixture is not there or the run is not the full config"""
+    fn = os.path.join(ROOT, "tests", "golden", cfg_name + "_rows.json")
+    if not os.path.exists(fn):
+        return None
+    g = json.load(open(fn))
+    lines = table_text.splitlines()
+    bad = [s for s, row in zip(g["subsample_slots"], g["rows"]) if s >= len(lines) or lines[s] != row]
+    return {"rows_checked": len(g["rows"]), "rows_identical": len(g["rows"]) - len(bad), "first_mismatch_slot": bad[0] if bad else None,
+            "fixture": os.path.basename(fn), "note": "rows printed by the reference binary for these queries against the whole read set"}
 
 
 def main():
@@ -64,10 +91,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--reads", type=int, default=0, help="override reads per GPU (default: the config's 50000)")
+    ap.add_argument("--config", default="cfg3", choices=sorted(PRESET))
+    ap.add_argument("--reads", type=int, default=0, help="override the number of reads (default: the config's)")
     ap.add_argument("--nsample", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=35000, help="target reads in the CPU baseline sample (~20-30 s of reference time)")
+    ap.add_argument("--cpu-sample", type=int, default=0, help="target reads in the CPU baseline sample (~20-30 s of reference time)")
+    ap.add_argument("--workers", type=int, default=0, help="processes of the synthetic generator (0: one per core, at most 64)")
     args = ap.parse_args()
 
     import torch
@@ -80,58 +109,68 @@ def main():
     one_dev = os.environ.get("LQCOV_BENCH_ONE_DEVICE") == "1"
     if one_dev:
         local = 0
-    torch.cuda.set_device(local)
+    have_cuda = torch.cuda.is_available()        # False only in the CPU dry run of this script's logic (LQCOV_LIBRARY = the test emulator)
+    if have_cuda:
+        torch.cuda.set_device(local)
     if world > 1:
         dist.init_process_group("gloo" if one_dev else "nccl", rank=rank, world_size=world)
 
     import dataclasses
     from longqc_amd import api, synth, multigpu
-    cfg = synth.CONFIGS["cfg2"]
+    cfg = synth.CONFIGS[args.config]
+    full_config = not args.reads and not args.nsample
     if args.reads:
         cfg = dataclasses.replace(cfg, n_reads=args.reads)
     if args.nsample:
         cfg = dataclasses.replace(cfg, nsample=args.nsample)
-    per_gpu = cfg.n_reads
+    argv = PRESET[args.config][1]
+    p, _, _ = api.parse_args(argv + ["t", "q"])
+
     t0 = time.time()
     genome = synth.make_genome(cfg)
-    T = synth.make_reads(cfg, genome, n_reads=per_gpu, read_offset=rank * per_gpu)          # this rank's index part
-    qidx = synth.reservoir_subsample(per_gpu, cfg.nsample)                                   # subsample of part 0
-    Q = T.subset(qidx) if rank == 0 else synth.make_reads(cfg, genome, indices=qidx)
+    F = synth.make_reads_flat(cfg, genome, workers=args.workers)                 # every read of the config, flat ASCII
+    qidx = synth.reservoir_subsample(cfg.n_reads, cfg.nsample)                   # LongQC's seed-7 subsample (lq_utils.py:371-411)
+    Q = synth.make_reads(cfg, genome, indices=qidx)
     t_gen = time.time() - t0
-
-    p = api.default_params(no_self=1, min_ovlp=0, min_score_med=160, min_score_good=160, k=12, w=5)
-    eng = api.Engine(p, device=local)
+    lens = np.diff(F.off).astype(np.int64)
+    parts = multigpu.split_parts(lens, int(p.batch_size), int(p.idx_mini_batch))  # index.c:244,311-316
     t0 = time.time()
+    P = api.PackedReads(F.flat, F.off, F.names())                                # what the parser thread does: 2-bit pack into pinned memory
+    t_pack = time.time() - t0
+    total_bases = float(F.n_bases)
+
+    eng = api.Engine(p, device=local)
     eng.set_queries(Q.names, Q.seqs, Q.quals)
     pt = eng.part_begin()
-    # upload in 50-Mbase mini-batches like mm_idx_gen (index.c:246); packed 2-bit in HBM afterwards
-    i = 0
-    while i < len(T):
-        j, b = i, 0
-        while j < len(T) and b < 50000000:
-            b += int(T.seqs[j].shape[0]); j += 1
-        eng.part_add_targets(pt, T.names[i:j], T.seqs[i:j])
-        i = j
-    eng.sync()
-    t_upload = time.time() - t0
-    my_bases = T.n_bases
-    runner = multigpu.PartRunner(eng, world=world, rank=rank, device=torch.device("cuda", local), query_lengths=[int(s.shape[0]) for s in Q.seqs]) if world > 1 else None
+    anchors = [0]
 
-    def step():
-        if runner is None:
-            eng.reset()
+    def step(h2d=True):
+        eng.reset()
+        a = 0
+        for (lo, hi) in parts:
+            if h2d or len(parts) > 1:
+                eng.part_clear(pt)
+                eng.part_add_packed(pt, P, lo, hi)
             eng.part_build(pt)
             eng.part_map(pt)
-        else:
-            runner.begin()
-            eng.part_build(pt)
-            runner.map_and_combine(pt, part_index=rank)
+            a += eng.last_n_anchors
         eng.finish()
+        anchors[0] = a
 
     def barrier():
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        if have_cuda:
+            torch.cuda.synchronize()
+
+    def timed(n, **kw):
+        barrier()
+        t0 = time.time()
+        for _ in range(n):
+            step(**kw)
+        eng.sync()
+        barrier()
+        return time.time() - t0
 
     for _ in range(args.warmup):
         step()
@@ -139,33 +178,27 @@ def main():
     # table and the name of the dominant kernel; the timed steps then carry events around that kernel only
     eng.set_profiling(2)
     step()
-    all_st = [s for s in eng.stage_times() if s["name"].startswith("k_") or s["name"].startswith("index_")]
-    dom_name = max(all_st, key=lambda s: s["total_ms"])["name"] if all_st else None
+    all_st = [s for s in eng.stage_times() if s["name"].startswith("k_") or s["name"].startswith("index_") or s["name"].startswith("h2d_")]
+    kern = [s for s in all_st if not s["name"].startswith("h2d_")]
+    dom_name = max(kern, key=lambda s: s["total_ms"])["name"] if kern else None
     eng.set_profiling(0)
     eng.set_profiling(2, only=dom_name)
-    barrier()
-    t0 = time.time()
-    for _ in range(args.steps):
-        step()
-    eng.sync()
-    barrier()
-    dt = time.time() - t0
-    tt = torch.tensor([dt, float(my_bases)], dtype=torch.float64, device="cuda")
-    if world > 1:
-        tmax = tt.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        tsum = tt.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
-        dt, total_bases = float(tmax[0]), float(tsum[1])
-    else:
-        total_bases = float(my_bases)
+    dt = timed(args.steps)
     ms_per_step = dt / max(args.steps, 1) * 1e3
     value = total_bases / (ms_per_step / 1e3) / 1e6
-
-    st = [s for s in eng.stage_times() if s["name"].startswith("k_") or s["name"].startswith("index_")]
+    st = [s for s in eng.stage_times() if s["name"] == dom_name]
     eng.set_profiling(0)
-    n_anchors = eng.last_n_anchors
+    n_anchors = anchors[0]
+    table = eng.table_text()
+    # the same job with the reads already resident in HBM (single-part workloads only: a multi-part job re-uses the part's buffers)
+    resident = None
+    if len(parts) == 1:
+        dt_r = timed(max(1, args.steps), h2d=False)
+        resident = total_bases / (dt_r / max(1, args.steps)) / 1e6
+
     roof = None
     if st:
-        dom = max(st, key=lambda s: s["total_ms"])
+        dom = st[0]
         per_launch_ms = dom["total_ms"] / max(dom["launches"], 1)
         per_launch_bytes = dom["algo_bytes"] / max(dom["launches"], 1)
         ach = per_launch_bytes / (per_launch_ms / 1e3) / 1e9 if per_launch_ms > 0 else 0.0
@@ -173,40 +206,46 @@ def main():
                 "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None,
                 "launches": dom["launches"], "avg_launch_ms": round(per_launch_ms, 4), "algo_bytes_per_launch": int(per_launch_bytes),
                 "timing": "HIP events around every launch of this kernel inside the timed steps, on the launching stream; "
-                          "kernel_ms_one_step: the same for every kernel in one extra untimed step (mapping lanes overlap, "
-                          "so those add up to more than ms_per_step)",
+                          "kernel_ms_one_step: the same for every kernel in one extra untimed step (concurrent streams overlap, "
+                          "so those can add up to more than ms_per_step)",
                 "kernel_ms_one_step": {s["name"]: round(s["total_ms"], 3) for s in sorted(all_st, key=lambda s: -s["total_ms"])}}
-    if world > 1:
-        barrier()
     if rank == 0:
         # HBM traffic of the dominant kernel from the PMC passes of this workload, if they were collected
         # (tools/gpu_round.sh -> profiles/*pmc_traffic.json; separate rocprofv3 --pmc runs, never inside a timed run)
-        if roof and not args.reads and not args.nsample:
+        if roof and full_config:
             import glob
-            for fn in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")), reverse=True):
+            for fn in sorted(glob.glob(os.path.join(ROOT, "profiles", "r02*pmc_traffic*.json")), reverse=True):
                 try:
-                    kk = json.load(open(fn))["kernels"]
+                    js = json.load(open(fn))
+                    kk = js["kernels"]
                 except Exception:
+                    continue
+                if args.config not in js.get("workload", ""):
                     continue
                 hit = [v for k, v in kk.items() if k.split("<")[0] == roof["kernel"].split("<")[0]]
                 if hit:
                     roof["traffic"] = round(hit[0]["hbm_bytes_per_launch"] / 1e9, 3)
-                    roof["traffic_unit"] = "GB per launch (PMC: (2*FETCH_SIZE+WRITE_SIZE)*1024, %s)" % os.path.basename(fn)
+                    roof["traffic_unit"] = "GB per launch (PMC: (2*FETCH_SIZE+WRITE_SIZE)*1024, from the committed %s, not from this run)" % os.path.basename(fn)
                     break
         line = {
             "metric": "Mbases/sec all-vs-all overlap coverage (sampleqc hot path)", "value": round(value, 3), "unit": "Mbases/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-            "config": {"workload": "%d synthetic ONT reads ~%d kb %gx per GPU (BASELINE configs[1]), ont-ligation preset "
-                                   "(-Y -l 0 -q 160 -k 12 -w 5 -p 160), %d subsample queries" % (per_gpu, cfg.mean_len // 1000, cfg.depth, len(Q)),
-                       "target_bases_per_gpu": int(my_bases), "query_bases": int(Q.n_bases), "anchors_per_step": int(n_anchors),
-                       "parallelism": "1 index part per GPU, accumulators combined over RCCL" if world > 1 else "single GPU"},
+            "config": {"workload": (CONFIG_LABEL[args.config] % (cfg.n_reads, cfg.mean_len // 1000, cfg.depth)) + ", %d subsample queries" % len(Q),
+                       "index_parts": [int(F.off[hi] - F.off[lo]) for lo, hi in parts],
+                       "target_bases": int(total_bases), "query_bases": int(Q.n_bases), "anchors_per_step": int(n_anchors),
+                       "clock": "H2D of the packed reads (pinned) -> sketch -> index -> seed -> sort -> chain -> coverage -> rows D2H, all parts (SURVEY 8d)",
+                       "parallelism": "single GPU"},
             "roofline": roof,
-            "upload_pack_s": round(t_upload, 3), "synth_gen_s": round(t_gen, 2),
-            "pcie_inclusive_value": round(total_bases / (ms_per_step / 1e3 + t_upload) / 1e6, 3),
+            "host_pack_s": round(t_pack, 3), "synth_gen_s": round(t_gen, 2),
+            "hbm_resident_value": round(resident, 3) if resident else None,
+            "anchors_per_s": round(n_anchors / (ms_per_step / 1e3), 1),
         }
+        if full_config:
+            line["golden_rows"] = golden_check(args.config, table)
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(T, Q, args.cpu_sample, max(50, args.cpu_sample // 10))
+            n_t = args.cpu_sample or (25000 if args.config == "cfg3" else 35000)
+            line["cpu_baseline"] = cpu_baseline(args.config, F, Q, n_t, max(50, n_t // 100))
         if one_dev:
             line["note"] = "LQCOV_BENCH_ONE_DEVICE test mode: all ranks share cuda:0 over gloo; not a scaling measurement"
         print(json.dumps(line), flush=True)

@@ -133,6 +133,19 @@ int lqcov_set_queries(lqcov_handle *h, uint32_t n, const uint8_t *seq, const uin
 int lqcov_part_begin(lqcov_handle *h);                                     /* returns part id >= 0 */
 int lqcov_part_add_targets(lqcov_handle *h, int part, uint32_t n, const uint8_t *seq, const uint64_t *seq_off,
                            const char *names, const uint64_t *name_off);   /* == mm_idx_gen step 0 (index.c:240-288) */
+/* The same reads handed over 2-bit packed, as the parser thread of lqcov_run_files does it (0.375 B per base cross
+ * PCIe instead of the ASCII byte; seq_nt4_table, sketch.c:8-25).  Layout: every read starts on a 128-base chunk; a chunk
+ * is 4 x uint64 of codes (base j of a word at bits 2j..2j+1) in `codes` and 4 x uint32 of "not A/C/G/T/U" bits in `amb`
+ * (bits beyond the read's end set).  lqcov_packed_chunks gives the chunk count of n reads, lqcov_pack_reads fills
+ * caller-owned buffers of 32 / 16 bytes per chunk on the host (n_threads <= 0: up to 16), lqcov_host_alloc / _free hand
+ * out page-locked host memory so that the upload runs at PCIe speed.                                               */
+uint64_t lqcov_packed_chunks(uint32_t n, const uint64_t *seq_off);
+int   lqcov_pack_reads(uint32_t n, const uint8_t *seq, const uint64_t *seq_off, uint64_t *codes, uint32_t *amb, int n_threads);
+void *lqcov_host_alloc(size_t bytes);
+void  lqcov_host_free(void *p);
+int lqcov_part_add_packed(lqcov_handle *h, int part, uint32_t n, const uint64_t *codes, const uint32_t *amb, const uint32_t *lens,
+                          const char *names, const uint64_t *name_off);
+int lqcov_part_clear(lqcov_handle *h, int part);    /* forget the part's reads and index, keep its device buffers (bench: the same part object every step) */
 int lqcov_part_build(lqcov_handle *h, int part);    /* sketch + index (+ mid_occ once): index.c:291-330, map.c:46-54 */
 int lqcov_part_map(lqcov_handle *h, int part);      /* == lq_map_file (lqmap.c:852): accumulates into the handle */
 int lqcov_part_release(lqcov_handle *h, int part);  /* == mm_idx_destroy (minimap2-coverage.c:457) */

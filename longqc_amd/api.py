@@ -82,6 +82,12 @@ def load_library(path: Optional[str] = None):
         "lqcov_set_queries": (C.c_int, [H, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
         "lqcov_part_begin": (C.c_int, [H]),
         "lqcov_part_add_targets": (C.c_int, [H, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+        "lqcov_packed_chunks": (C.c_uint64, [C.c_uint32, C.c_void_p]),
+        "lqcov_pack_reads": (C.c_int, [C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
+        "lqcov_host_alloc": (C.c_void_p, [C.c_size_t]),
+        "lqcov_host_free": (None, [C.c_void_p]),
+        "lqcov_part_add_packed": (C.c_int, [H, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+        "lqcov_part_clear": (C.c_int, [H, C.c_int]),
         "lqcov_part_build": (C.c_int, [H, C.c_int]),
         "lqcov_part_sketch": (C.c_int, [H, C.c_int]),
         "lqcov_part_map": (C.c_int, [H, C.c_int]),
@@ -171,6 +177,47 @@ def _names(names: Sequence[str]) -> Tuple[bytes, np.ndarray]:
     return b"".join(parts), off
 
 
+class PackedReads:
+    """Reads 2-bit packed on the host into page-locked buffers (lqcov_pack_reads / lqcov_host_alloc): what the parser
+    thread of lqcov_run_files produces, for callers that hold the reads in memory (bench.py, in-memory sampleqc)."""
+
+    def __init__(self, flat: np.ndarray, off: np.ndarray, names: Sequence[str], threads: int = 0, lib=None):
+        self.lib = lib or load_library()
+        off = np.ascontiguousarray(off, dtype=np.uint64)
+        flat = np.ascontiguousarray(flat, dtype=np.uint8)
+        n = int(off.shape[0] - 1)
+        self.n = n
+        self.lens = np.ascontiguousarray(np.diff(off).astype(np.uint32))
+        self.coff = np.zeros(n + 1, dtype=np.uint64)
+        self.coff[1:] = np.cumsum((self.lens.astype(np.uint64) + 127) // 128, dtype=np.uint64)
+        self.n_chunks = int(self.coff[-1])
+        assert self.n_chunks == int(self.lib.lqcov_packed_chunks(n, off.ctypes.data))
+        self.n_bases = int(off[-1] - off[0])
+        self.codes_ptr = self.lib.lqcov_host_alloc(max(self.n_chunks, 1) * 32)
+        self.amb_ptr = self.lib.lqcov_host_alloc(max(self.n_chunks, 1) * 16)
+        if not self.codes_ptr or not self.amb_ptr:
+            raise MemoryError("lqcov_host_alloc failed")
+        rc = self.lib.lqcov_pack_reads(n, flat.ctypes.data, off.ctypes.data, self.codes_ptr, self.amb_ptr, threads)
+        if rc:
+            raise LqcovError(rc, "lqcov_pack_reads failed")
+        self.names_blob, self.name_off = _names(names)
+
+    def __len__(self):
+        return self.n
+
+    def close(self):
+        if getattr(self, "codes_ptr", None):
+            self.lib.lqcov_host_free(self.codes_ptr); self.codes_ptr = None
+        if getattr(self, "amb_ptr", None):
+            self.lib.lqcov_host_free(self.amb_ptr); self.amb_ptr = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class Engine:
     """One handle == one HIP device + stream (include/lqcov.h level 2)."""
 
@@ -215,6 +262,19 @@ class Engine:
         flat, off = _flat(seqs)
         nb, noff = _names(names)
         self._ck(self.lib.lqcov_part_add_targets(self.h, part, len(seqs), flat.ctypes.data, off.ctypes.data, nb, noff.ctypes.data))
+
+    def part_add_packed(self, part: int, packed: "PackedReads", lo: int = 0, hi: Optional[int] = None):
+        """reads [lo, hi) of a PackedReads (2-bit packed on the host, page-locked): H2D only, no device-side packing"""
+        hi = len(packed) if hi is None else hi
+        c0 = int(packed.coff[lo])
+        lens = np.ascontiguousarray(packed.lens[lo:hi])
+        noff = np.ascontiguousarray(packed.name_off[lo:hi + 1] - packed.name_off[lo])
+        blob = packed.names_blob[int(packed.name_off[lo]):int(packed.name_off[hi])]
+        self._ck(self.lib.lqcov_part_add_packed(self.h, part, hi - lo, packed.codes_ptr + c0 * 32, packed.amb_ptr + c0 * 16,
+                                                lens.ctypes.data, blob, noff.ctypes.data))
+
+    def part_clear(self, part: int):
+        self._ck(self.lib.lqcov_part_clear(self.h, part))
 
     def part_build(self, part: int):
         self._ck(self.lib.lqcov_part_build(self.h, part))

@@ -220,6 +220,46 @@ int lqcov_part_add_targets(lqcov_handle *h, int part, uint32_t n, const uint8_t 
 	});
 }
 
+// ---- packed reads: the host side of the upload (the parser thread packs, 0.375 B per base cross PCIe) ----
+uint64_t lqcov_packed_chunks(uint32_t n, const uint64_t *seq_off) { return seq_off ? lq_packed_chunks(n, seq_off) : 0; }
+
+int lqcov_pack_reads(uint32_t n, const uint8_t *seq, const uint64_t *seq_off, uint64_t *codes, uint32_t *amb, int n_threads)
+{
+	if (!seq_off || (n && (!seq || !codes || !amb))) return LQCOV_E_ARG;
+	try { lq_pack_host(n, seq, seq_off, codes, amb, n_threads); } catch (...) { return LQCOV_E_DEVICE; }
+	return 0;
+}
+
+void *lqcov_host_alloc(size_t bytes)
+{
+	void *p = nullptr;
+	if (hipHostMalloc(&p, bytes ? bytes : 1, 0) != hipSuccess) return nullptr;
+	return p;
+}
+void lqcov_host_free(void *p) { if (p) hipHostFree(p); }
+
+int lqcov_part_add_packed(lqcov_handle *h, int part, uint32_t n, const uint64_t *codes, const uint32_t *amb, const uint32_t *lens,
+                          const char *names, const uint64_t *name_off)
+{
+	return guard(h, [&] {
+		if (n && (!codes || !amb || !lens)) throw std::invalid_argument("null read buffers");
+		Part &pt = h->part(part);
+		if (pt.built) throw std::logic_error("part already built");
+		h->add_reads_packed(pt.rs, n, codes, amb, lens, names, name_off);
+	});
+}
+
+int lqcov_part_clear(lqcov_handle *h, int part)
+{
+	return guard(h, [&] {
+		Part &pt = h->part(part);
+		ReadSetDev &rs = pt.rs;
+		rs.n = 0; rs.n_chunks = 0; rs.n_bases = 0; rs.n_mini = 0; rs.sketched = false;
+		rs.h_coff.assign(1, 0); rs.h_len.clear(); rs.names.clear();
+		pt.built = false; pt.n_keys = 0;
+	});
+}
+
 int lqcov_part_build(lqcov_handle *h, int part) { return guard(h, [&] { h->build_part(h->part(part)); }); }
 int lqcov_part_map(lqcov_handle *h, int part) { return guard(h, [&] { h->map_part(h->part(part)); }); }
 int lqcov_part_release(lqcov_handle *h, int part) { return guard(h, [&] { h->part(part); h->parts[part].reset(); }); }

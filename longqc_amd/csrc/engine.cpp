@@ -153,6 +153,92 @@ void lqcov_handle::add_reads(ReadSetDev &rs, u32 n, const u8 *seq, const u64 *se
 	rs.sketched = false;
 }
 
+// ---- packed reads from the host -----------------------------------------------------------------
+// The same layout k_pack produces (2-bit codes in u64 words + one "ambiguous" bit per base in u32 words, every read
+// starting on a 128-base chunk), built on the host by the thread that parses the reads, so that 0.375 B per base cross
+// PCIe instead of the ASCII byte (seq_nt4_table, sketch.c:8-25).
+u64 lq_packed_chunks(u32 n, const u64 *seq_off)
+{
+	u64 c = 0;
+	for (u32 i = 0; i < n; ++i) c += (seq_off[i + 1] - seq_off[i] + LQ_CHUNK - 1) / LQ_CHUNK;
+	return c;
+}
+
+void lq_pack_host(u32 n, const u8 *seq, const u64 *seq_off, u64 *codes, u32 *amb, int n_threads)
+{
+	static u8 tab[256];
+	static std::once_flag once;
+	std::call_once(once, [] {
+		for (int c = 0; c < 256; ++c) tab[c] = 4;
+		tab[0] = 0; tab[1] = 1; tab[2] = 2; tab[3] = 3;
+		tab['A'] = tab['a'] = 0; tab['C'] = tab['c'] = 1; tab['G'] = tab['g'] = 2; tab['T'] = tab['t'] = tab['U'] = tab['u'] = 3;
+	});
+	std::vector<u64> coff(n + 1, 0);
+	for (u32 i = 0; i < n; ++i) coff[i + 1] = coff[i] + (seq_off[i + 1] - seq_off[i] + LQ_CHUNK - 1) / LQ_CHUNK;
+	auto work = [&](u32 r0, u32 r1) {
+		for (u32 r = r0; r < r1; ++r) {
+			const u8 *s = seq + seq_off[r];
+			const u64 len = seq_off[r + 1] - seq_off[r];
+			u64 *cw = codes + coff[r] * LQ_CHUNK_WORDS;
+			u32 *aw = amb + coff[r] * LQ_CHUNK_WORDS;
+			const u64 nw = (coff[r + 1] - coff[r]) * LQ_CHUNK_WORDS;
+			for (u64 wi = 0; wi < nw; ++wi) {
+				const u64 p0 = wi * 32;
+				u64 w = 0; u32 m = 0;
+				const u64 lim = p0 >= len ? 0 : (len - p0 < 32 ? len - p0 : 32);
+				for (u64 j = 0; j < lim; ++j) {
+					const u32 c = tab[s[p0 + j]];
+					if (c < 4) w |= (u64)c << (2 * j); else m |= 1u << j;
+				}
+				if (lim < 32) m |= lim == 0 ? 0xffffffffu : ~0u << lim;      // beyond the read: ambiguous, as k_pack marks it
+				cw[wi] = w; aw[wi] = m;
+			}
+		}
+	};
+	if (n_threads <= 0) n_threads = (int)std::min<unsigned>(16, std::max(1u, std::thread::hardware_concurrency()));
+	const u64 total = seq_off[n] - seq_off[0];
+	if (n_threads == 1 || total < (1u << 22)) { work(0, n); return; }
+	std::vector<std::thread> th;
+	u32 r0 = 0;
+	for (int t = 0; t < n_threads; ++t) {                          // equal shares of bases
+		const u64 want = seq_off[0] + total * (u64)(t + 1) / (u64)n_threads;
+		u32 r1 = t + 1 == n_threads ? n : (u32)(std::upper_bound(seq_off + r0, seq_off + n + 1, want) - seq_off);
+		if (r1 > n) r1 = n;
+		if (r1 < r0) r1 = r0;
+		if (r1 > r0) th.emplace_back(work, r0, r1);
+		r0 = r1;
+	}
+	for (auto &t : th) t.join();
+}
+
+// append n reads that are already packed (lq_pack_host layout for exactly these reads) to the set
+void lqcov_handle::add_reads_packed(ReadSetDev &rs, u32 n, const u64 *codes, const u32 *amb, const u32 *lens, const char *names, const u64 *name_off)
+{
+	if (n == 0) return;
+	if ((u64)rs.n + n > 0x7fffffffULL) throw std::domain_error("too many reads in one set");
+	u64 new_chunks = 0, n_bases = 0;
+	rs.h_len.reserve(rs.h_len.size() + n); rs.h_coff.reserve(rs.h_coff.size() + n); rs.names.reserve(rs.names.size() + n);
+	for (u32 i = 0; i < n; ++i) {
+		if (lens[i] > 0x7fffffffu) throw std::domain_error("read longer than 2^31-1 bases (bseq.c:80)");
+		new_chunks += ((u64)lens[i] + LQ_CHUNK - 1) / LQ_CHUNK;
+		n_bases += lens[i];
+		rs.h_len.push_back(lens[i]);
+		rs.h_coff.push_back(rs.n_chunks + new_chunks);
+		rs.names.emplace_back(names ? names + name_off[i] : "");
+	}
+	const u64 n_words = new_chunks * LQ_CHUNK_WORDS;
+	grow_keep(rs.codes, rs.n_chunks * LQ_CHUNK_WORDS * 8, (rs.n_chunks + new_chunks) * LQ_CHUNK_WORDS * 8, stream);
+	grow_keep(rs.amb, rs.n_chunks * LQ_CHUNK_WORDS * 4, (rs.n_chunks + new_chunks) * LQ_CHUNK_WORDS * 4, stream);
+	{
+		StageTimer t(this, "h2d_packed_reads", n_words * 12);
+		h2d(rs.codes.as<u64>() + rs.n_chunks * LQ_CHUNK_WORDS, codes, n_words, stream);
+		h2d(rs.amb.as<u32>() + rs.n_chunks * LQ_CHUNK_WORDS, amb, n_words, stream);
+	}
+	LQ_HIP_CHECK(hipStreamSynchronize(stream));               // the caller's buffers are free again
+	rs.n += n; rs.n_chunks += new_chunks; rs.n_bases += n_bases;
+	rs.sketched = false;
+}
+
 // minimizers of every read of the set, in (read, position) order   (sketch.c:76-142)
 void lqcov_handle::sketch(ReadSetDev &rs, bool rid_in_y)
 {

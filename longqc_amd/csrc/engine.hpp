@@ -118,6 +118,7 @@ struct lqcov_handle {
 	~lqcov_handle();
 
 	void add_reads(ReadSetDev &rs, u32 n, const u8 *seq, const u64 *seq_off, const char *names, const u64 *name_off);
+	void add_reads_packed(ReadSetDev &rs, u32 n, const u64 *codes, const u32 *amb, const u32 *lens, const char *names, const u64 *name_off);
 	void sketch(ReadSetDev &rs, bool rid_in_y);
 	void set_queries(u32 n, const u8 *seq, const u64 *seq_off, const u8 *qual, const char *names, const u64 *name_off);
 	void build_index(Part &pt);
@@ -136,6 +137,9 @@ struct lqcov_handle {
 	                                     std::vector<std::string> &&names, std::vector<u32> &&lens);
 	Part &part(int id);
 };
+
+u64 lq_packed_chunks(u32 n, const u64 *seq_off);
+void lq_pack_host(u32 n, const u8 *seq, const u64 *seq_off, u64 *codes, u32 *amb, int n_threads);
 
 struct StageTimer {
 	lqcov_handle *h; hipStream_t s; const char *name; u64 bytes;

@@ -390,9 +390,6 @@ k_chain_wave(const mm128 *A, const u64 *gstart, const u32 *glist, u32 n_list, co
 	LQ_SHARED WaveCand cand[64];
 	LQ_SHARED i32 st_sh[4];                                  // [0] max_f, [1] max_j, [2] n_skip, [3] done
 	if (blockIdx.x >= n_list) return;
-#ifdef LQ_EMU
-	if (threadIdx.x != 0) return;                            // thread 0 plays every lane, phase by phase
-#endif
 	const u32 g = glist[blockIdx.x];
 	const u64 gs = gstart[g];
 	const i64 n = (i64)(gstart[g + 1] - gs);

@@ -18,11 +18,7 @@
 #pragma once
 #include "lq_common.hpp"
 #ifndef LQ_SHARED
-#ifdef LQ_EMU
-#define LQ_SHARED static
-#else
 #define LQ_SHARED __shared__
-#endif
 #endif
 
 #define LQ_DUST_THREADS 64

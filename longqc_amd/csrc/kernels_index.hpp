@@ -129,41 +129,6 @@ __global__ void k_seed_emit(const u64 *qx, const u64 *qy, const u32 *owner, cons
                             int no_self, const u32 *self_off, const u32 *self_rid, AvaView ava,
                             mm128 *anchors, u64 *mini_pos)
 {
-#ifdef LQ_EMU
-	u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-	if (j >= nj) return;
-	j += j0;
-	if (!keep[j]) return;
-	u32 q = owner[j];
-	u64 x = qx[j];
-	u32 q_span = (u32)(x & 0xff), qp = (u32)qy[j];
-	u32 qpos = qp >> 1;
-	mini_pos[mp_off[j]] = (u64)q_span << 32 | qpos;
-	bool tandem = false;
-	if (j > qmoff[q] && (qx[j - 1] >> 8) == (x >> 8)) tandem = true;
-	if (j + 1 < qmoff[q + 1] && (qx[j + 1] >> 8) == (x >> 8)) tandem = true;
-	bool check_self = no_self && self_off[q] != self_off[q + 1];
-	u32 n = hit_n[j];
-	u64 st = hit_start[j];
-	mm128 *out = anchors + (a_off[j] - a_base);
-	i32 ql = (i32)qlen[q];
-	for (u32 t = 0; t < n; ++t) {
-		u64 r = pos[st + t];
-		u32 rpos = (u32)r >> 1;
-		if (check_self && rpos == qpos && lq_is_self(self_off, self_rid, q, (u32)(r >> 32))) continue;
-		if (ava.t_rank && ava.t_rank[(u32)(r >> 32)] < ava.q_lo[q]) continue;
-		mm128 a;
-		if ((r & 1) == (qp & 1)) {
-			a.x = (r & 0xffffffff00000000ULL) | rpos;
-			a.y = (u64)q_span << 32 | qpos;
-		} else {
-			a.x = 1ULL << 63 | (r & 0xffffffff00000000ULL) | rpos;
-			a.y = (u64)q_span << 32 | (u32)(ql - (i32)(qpos + 1 - q_span) - 1);
-		}
-		if (tandem) a.y |= LQ_SEED_TANDEM;
-		*out++ = a;
-	}
-#else
 	// One query minimizer per lane for the set-up, then the wave emits the anchors of one minimizer at a time, a hit per
 	// lane: the occurrence list is read and the anchors are written as contiguous runs (a thread walking its own list
 	// wrote 16-byte pieces 1 KiB apart: rocprofv3 counted 108 GB of HBM traffic per launch for 19 GB of anchors).
@@ -215,7 +180,6 @@ __global__ void k_seed_emit(const u64 *qx, const u64 *qy, const u32 *owner, cons
 			skipped += (u32)__popcll(sm);
 		}
 	}
-#endif
 }
 
 // per query: anchor range, mini_pos range, avg_qspan (chain.c:37-38), lq_cnt_match prologue

@@ -241,15 +241,9 @@ __global__ void k_sketch(const u64 *codes, const u32 *amb, const u64 *coff, cons
                          SkParams P, int rid_in_y, u32 *cnt, const u64 *off, u64 *out_x, u64 *out_y)
 {
 	constexpr int STRIDE = RCAP <= 16 ? LQ_SK_BLOCK : 1;
-#ifdef LQ_EMU
-	static u64 s_rx[RCAP <= 16 ? RCAP : 1][LQ_SK_BLOCK];
-	static u32 s_ry[RCAP <= 16 ? RCAP : 1][LQ_SK_BLOCK];
-	static i32 s_rq[RCAP <= 16 && HPC ? 32 : 1][LQ_SK_BLOCK];
-#else
 	__shared__ u64 s_rx[RCAP <= 16 ? RCAP : 1][LQ_SK_BLOCK];
 	__shared__ u32 s_ry[RCAP <= 16 ? RCAP : 1][LQ_SK_BLOCK];
 	__shared__ i32 s_rq[RCAP <= 16 && HPC ? 32 : 1][LQ_SK_BLOCK];   // homopolymer run queue (sketch.c:39-58), -H only
-#endif
 	u64 p_rx[RCAP <= 16 ? 1 : RCAP];
 	u32 p_ry[RCAP <= 16 ? 1 : RCAP];
 	i32 p_rq[RCAP <= 16 ? 1 : 32];

@@ -26,19 +26,10 @@
 #include "lq_common.hpp"
 
 // Block-cooperative kernels are written in phases: LQ_BLOCK_LOOP(t) { ... } runs its body once per thread of
-// the block (t = thread index), LQ_BLOCK_SYNC() separates phases.  On the GPU that is the thread itself and
-// __syncthreads(); the serial test emulator lets thread 0 play every thread of the block, phase by phase.
-#ifdef LQ_EMU
-#undef LQ_SHARED
-#define LQ_SHARED static
-#define LQ_BLOCK_LOOP(t) if (threadIdx.x == 0) for (u32 t = 0; t < blockDim.x; ++t)
-#define LQ_BLOCK_SYNC()
-#else
-#undef LQ_SHARED
+// the block (t = thread index), LQ_BLOCK_SYNC() separates phases.
 #define LQ_SHARED __shared__
 #define LQ_BLOCK_LOOP(t) for (u32 t = threadIdx.x, lq_once_ = 1; lq_once_; lq_once_ = 0)
 #define LQ_BLOCK_SYNC() __syncthreads()
-#endif
 
 #define LQ_SEG_GENERAL  0
 #define LQ_SEG_IDENTITY 1
@@ -117,15 +108,6 @@ k_sort_classify(const SortSeg *segs, u32 n_segs, const u32 *hist, u32 *begs, Seg
 	const u32 *cnt = hist + (u64)sgi * 256;
 	u32 *bg = begs + (u64)sgi * 256;
 	u32 nz = 0, c0 = 0, c1 = 0;
-#ifdef LQ_EMU
-	if (threadIdx.x != 0) return;
-	u32 acc = 0;
-	for (u32 c = 0; c < 256; ++c) {
-		u32 n = cnt[c];
-		bg[c] = acc; acc += n;
-		if (n) { if (nz == 0) c0 = c; else if (nz == 1) c1 = c; ++nz; }
-	}
-#else
 	const u32 lane = threadIdx.x;
 	const uint4 v = *(const uint4*)(cnt + 4 * lane);
 	const u32 s1 = v.x, s2 = s1 + v.y, s3 = s2 + v.z, s4 = s3 + v.w;
@@ -150,7 +132,6 @@ k_sort_classify(const SortSeg *segs, u32 n_segs, const u32 *hist, u32 *begs, Seg
 		}
 	}
 	if (lane != 0) return;
-#endif
 	SegInfo si; si.c0 = c0; si.c1 = c1; si.cnt0 = cnt[c0];
 	if (nz <= 1) si.kind = LQ_SEG_IDENTITY;                  // one bucket holds everything: the pass is the identity
 	else if (nz == 2) { si.kind = LQ_SEG_TWO; two_list[atomicAdd(&counters[0], 1u)] = sgi; }
@@ -538,9 +519,6 @@ __global__ void __launch_bounds__(LQ_CHILD_THREADS) k_sort_children(const SortSe
 		SortSeg c; c.off = sg.off + bg; c.len = n; c.shift = sh;
 		next[s] = c;
 	}
-#ifdef LQ_EMU
-	else if (n > 1) lq_insertion_sort_x(A + sg.off + bg, n);
-#else
 	__shared__ u64 xs[64];
 	__shared__ u32 flag[64];
 	const u32 lane = threadIdx.x;
@@ -579,5 +557,4 @@ __global__ void __launch_bounds__(LQ_CHILD_THREADS) k_sort_children(const SortSe
 		__syncthreads();
 		todo &= ~fit;
 	}
-#endif
 }

@@ -132,6 +132,34 @@ class ReadSet:
         return ReadSet([self.names[i] for i in idx], [self.seqs[i] for i in idx], [self.quals[i] for i in idx])
 
 
+def _one_read(cfg: SynthConfig, genome: np.ndarray, i: int, want_qual: bool = True):
+    """read i of the config: its own RNG stream, so any slice of the set can be regenerated independently"""
+    G = genome.shape[0]
+    scale = cfg.mean_len / cfg.gamma_shape
+    rng = np.random.default_rng([cfg.seed, 77, i])
+    L = int(rng.gamma(cfg.gamma_shape, scale))
+    L = max(cfg.min_len, min(L, 10 * cfg.mean_len, G))
+    if rng.random() < cfg.junk_frac:
+        s = _ACGT[rng.integers(0, 4, size=L, dtype=np.uint8)]
+    else:
+        st = int(rng.integers(0, G - L + 1))
+        s = genome[st:st + L]
+        if rng.random() < 0.5:
+            s = _COMP[s[::-1]]
+        s = _mutate(s, rng, cfg.err, cfg.err_mix)
+    if cfg.n_frac > 0 and rng.random() < cfg.n_frac and s.shape[0] > 200:
+        s = s.copy()
+        p = int(rng.integers(0, s.shape[0] - 20))
+        s[p:p + int(rng.integers(1, 20))] = ord("N")
+    if not want_qual:
+        q = None
+    elif cfg.qual == "none":
+        q = np.full(s.shape[0], ord("!"), dtype=np.uint8)
+    else:
+        q = (33 + rng.integers(3, 26, size=s.shape[0])).astype(np.uint8)
+    return np.ascontiguousarray(s), q
+
+
 def make_reads(cfg: SynthConfig, genome: Optional[np.ndarray] = None, n_reads: Optional[int] = None,
                read_offset: int = 0, indices: Optional[Sequence[int]] = None) -> ReadSet:
     """Generate reads [read_offset, read_offset + n_reads) of the config, or exactly `indices` (each
@@ -139,34 +167,89 @@ def make_reads(cfg: SynthConfig, genome: Optional[np.ndarray] = None, n_reads: O
     one shard per rank, or just the query subsample)."""
     if genome is None:
         genome = make_genome(cfg)
-    G = genome.shape[0]
     n = cfg.n_reads if n_reads is None else n_reads
     names, seqs, quals = [], [], []
-    scale = cfg.mean_len / cfg.gamma_shape
     for i in (indices if indices is not None else range(read_offset, read_offset + n)):
-        rng = np.random.default_rng([cfg.seed, 77, i])
-        L = int(rng.gamma(cfg.gamma_shape, scale))
-        L = max(cfg.min_len, min(L, 10 * cfg.mean_len, G))
-        if rng.random() < cfg.junk_frac:
-            s = _ACGT[rng.integers(0, 4, size=L, dtype=np.uint8)]
-        else:
-            st = int(rng.integers(0, G - L + 1))
-            s = genome[st:st + L]
-            if rng.random() < 0.5:
-                s = _COMP[s[::-1]]
-            s = _mutate(s, rng, cfg.err, cfg.err_mix)
-        if cfg.n_frac > 0 and rng.random() < cfg.n_frac and s.shape[0] > 200:
-            s = s.copy()
-            p = int(rng.integers(0, s.shape[0] - 20))
-            s[p:p + int(rng.integers(1, 20))] = ord("N")
-        if cfg.qual == "none":
-            q = np.full(s.shape[0], ord("!"), dtype=np.uint8)
-        else:
-            q = (33 + rng.integers(3, 26, size=s.shape[0])).astype(np.uint8)
+        s, q = _one_read(cfg, genome, i)
         names.append("r%07d" % i)
-        seqs.append(np.ascontiguousarray(s))
+        seqs.append(s)
         quals.append(q)
     return ReadSet(names, seqs, quals)
+
+
+@dataclasses.dataclass
+class FlatReads:
+    """the same reads as one flat base array (the layout the C ABI takes); no qualities (index targets)"""
+    first: int                 # index of the first read in the config
+    flat: np.ndarray           # uint8 ASCII, all reads back to back
+    off: np.ndarray            # uint64 [n+1]
+
+    def __len__(self) -> int:
+        return int(self.off.shape[0] - 1)
+
+    @property
+    def n_bases(self) -> int:
+        return int(self.off[-1])
+
+    def names(self) -> List[str]:
+        return ["r%07d" % (self.first + i) for i in range(len(self))]
+
+    def seq(self, i: int) -> np.ndarray:
+        return self.flat[int(self.off[i]):int(self.off[i + 1])]
+
+
+_W_CFG = None
+_W_GENOME = None
+
+
+def _flat_chunk(rng_):
+    lo, hi = rng_
+    seqs = [_one_read(_W_CFG, _W_GENOME, i, want_qual=False)[0] for i in range(lo, hi)]
+    lens = np.array([s.shape[0] for s in seqs], dtype=np.uint64)
+    return lo, (np.concatenate(seqs) if seqs else np.zeros(0, np.uint8)), lens
+
+
+def make_reads_flat(cfg: SynthConfig, genome: Optional[np.ndarray] = None, n_reads: Optional[int] = None,
+                    read_offset: int = 0, workers: int = 0, chunk: int = 2000) -> FlatReads:
+    """reads [read_offset, read_offset + n_reads) -- bit-identical to make_reads -- generated by `workers`
+    forked processes (0: one per core, at most 64) straight into one flat array"""
+    global _W_CFG, _W_GENOME
+    import multiprocessing as mp
+    import os
+    if genome is None:
+        genome = make_genome(cfg)
+    n = cfg.n_reads if n_reads is None else n_reads
+    if workers <= 0:
+        workers = min(64, os.cpu_count() or 1)
+    _W_CFG, _W_GENOME = cfg, genome
+    jobs = [(lo, min(lo + chunk, read_offset + n)) for lo in range(read_offset, read_offset + n, chunk)]
+    res = {}
+    if workers > 1 and len(jobs) > 1:
+        with mp.get_context("fork").Pool(workers) as pool:
+            for lo, flat, lens in pool.imap_unordered(_flat_chunk, jobs):
+                res[lo] = (flat, lens)
+    else:
+        for j in jobs:
+            lo, flat, lens = _flat_chunk(j)
+            res[lo] = (flat, lens)
+    lens = np.concatenate([res[lo][1] for lo, _ in jobs]) if jobs else np.zeros(0, np.uint64)
+    off = np.zeros(n + 1, dtype=np.uint64)
+    off[1:] = np.cumsum(lens, dtype=np.uint64)
+    flat = np.empty(int(off[-1]), dtype=np.uint8)
+    pos = 0
+    for lo, _ in jobs:
+        f = res.pop(lo)[0]
+        flat[pos:pos + f.shape[0]] = f
+        pos += f.shape[0]
+    return FlatReads(read_offset, flat, off)
+
+
+def write_flat_fasta(path: str, fr: FlatReads) -> None:
+    with open(path, "wb") as f:
+        for i in range(len(fr)):
+            f.write(b">r%07d\n" % (fr.first + i))
+            f.write(fr.seq(i).tobytes())
+            f.write(b"\n")
 
 
 def reservoir_subsample(n_total: int, num: int, s_seed: int = 7) -> List[int]:
