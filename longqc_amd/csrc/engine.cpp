@@ -3,6 +3,8 @@
 #include "kernels_sketch.hpp"
 #include "kernels_index.hpp"
 #include "kernels_sort.hpp"
+#include "kernels_walk.hpp"
+#include "kernels_psort.hpp"
 #include "kernels_chain.hpp"
 #include "fastx.hpp"
 #include <cstdio>
@@ -95,7 +97,12 @@ lqcov_handle::lqcov_handle(const lqcov_params &p, int dev) : P(p), device(dev)
 lqcov_handle::~lqcov_handle()
 {
 	drain_stages();
-	for (auto &L : lanes) if (L->stream) { hipStreamSynchronize(L->stream); hipStreamDestroy(L->stream); }
+	for (auto &L : lanes) {
+		if (L->stream) { hipStreamSynchronize(L->stream); hipStreamDestroy(L->stream); }
+		if (L->stream2) { hipStreamSynchronize(L->stream2); hipStreamDestroy(L->stream2); }
+		if (L->ev_fork) hipEventDestroy(L->ev_fork);
+		if (L->ev_join) hipEventDestroy(L->ev_join);
+	}
 	if (stream) { hipStreamSynchronize(stream); hipStreamDestroy(stream); }
 }
 
@@ -497,115 +504,15 @@ void lqcov_handle::map_batch(MapLane &L, Part &pt, u32 q0, u32 q1, const std::ve
 	i32 *d_cf = (i32*)L.B.p, *d_cp = (i32*)((u8*)L.B.p + nA4), *d_ct = (i32*)((u8*)L.B.p + 2 * nA4), *d_cv = (i32*)((u8*)L.B.p + 3 * nA4);
 	if (nj) {
 		StageTimer t(this, L.stream, "k_seed_emit", nj * 32 + nA * 24);
-		LQ_LAUNCH(k_seed_emit, nblk(nj, 256), 256, L.stream, q.mx.as<u64>(), q.my.as<u64>(), q_owner.as<u32>(), q.moff.as<u64>(), j0, nj,
-		          pt.pos.as<u64>(), hit_start.as<u64>(), hit_n.as<u32>(), keep.as<u32>(),
+		LQ_LAUNCH(k_seed_emit, nblk(nj, LQ_EMIT_THREADS), LQ_EMIT_THREADS, L.stream, q.mx.as<u64>(), q.my.as<u64>(), q_owner.as<u32>(), q.moff.as<u64>(), j0, nj,
+		          pt.pos.as<u64>(), hit_start.as<u64>(), hit_n.as<u32>(), keep.as<u32>(), dup.as<u32>(),
 		          a_off.as<u64>(), a_base, mp_off.as<u64>(), q.d_len.as<u32>(),
 		          (int)P.no_self, pt.self_off.as<u32>(), pt.self_rid.as<u32>(), AvaView{P.ava ? pt.t_rank.as<u32>() : nullptr, P.ava ? pt.q_lo.as<u32>() : nullptr}, dA, mini_pos.as<u64>());
 		check_launch();
 	}
 	if (nA) {
 		const u64 *aqb = aq_off.as<u64>() + q0;          // batch view of the per-query anchor offsets
-		// ---- klib-order sort (lqmap.c:238) ----
-		{
-			const u64 max_segs = nA / (LQ_RS_MIN + 1) + nqb + 1;
-			L.segs0.ensure(max_segs * sizeof(SortSeg)); L.segs1.ensure(max_segs * sizeof(SortSeg));
-			dzero(L.n_segs.p, 64, L.stream);
-			{
-				StageTimer t(this, L.stream, "k_sort_init");
-				LQ_LAUNCH(k_sort_init, nblk(nqb, 64), 64, L.stream, aqb, a_base, nqb, dA, L.segs0.as<SortSeg>(), L.n_segs.as<u32>());
-				check_launch();
-			}
-			u32 ns = 0;
-			d2h(&ns, L.n_segs.as<u32>(), 1, L.stream);
-			SortSeg *cur = L.segs0.as<SortSeg>(), *nxt = L.segs1.as<SortSeg>();
-			// key bytes that are zero in every anchor of this part: x = strand:1 | rid:31 | position:32 (lqmap.c:190-196)
-			u32 const_levels = 0;
-			if (!getenv("LQCOV_NO_LEVEL_SKIP")) {
-				u32 max_len = 0;
-				for (u32 v : pt.rs.h_len) max_len = std::max(max_len, v);
-				if (pt.rs.n <= (1u << 16)) const_levels |= 1u << 6;
-				if (pt.rs.n <= (1u << 8)) const_levels |= 1u << 5;
-				if (max_len <= (1u << 24)) const_levels |= 1u << 3;
-				if (max_len <= (1u << 16)) const_levels |= 1u << 2;
-				if (max_len <= (1u << 8)) const_levels |= 1u << 1;
-			}
-			WalkCaps wcaps; wcaps.c[0] = 4096; wcaps.c[1] = 16384; wcaps.c[2] = 65536; wcaps.c[3] = 159744;
-			if (const char *ws = getenv("LQCOV_WALK_SHIFT")) for (int c = 0; c < 4; ++c) wcaps.c[c] >>= atoi(ws);   // test knob
-			L.sort_d.ensure(nA + 64); L.sort_dst.ensure((nA + 1) * 4);
-			for (int level = 0; level < 8 && ns > 0; ++level) {
-				L.hist.ensure((u64)ns * 1024); L.begs.ensure((u64)ns * 1024);
-				L.seg_info.ensure((u64)ns * sizeof(SegInfo)); L.walk_list.ensure((u64)ns * 4 * LQ_WALK_CLASSES); L.two_list.ensure((u64)ns * 4);
-				dzero(L.n_segs.as<u32>() + 1, 4 * (2 + LQ_WALK_CLASSES), L.stream);   // [1] next-level count, [2] n_two, [3..] n_walk per size class
-				{
-					StageTimer t(this, L.stream, "k_sort_copy_hist", nA * 33);
-					LQ_LAUNCH(k_sort_copy_hist, ns, 256, L.stream, cur, ns, dA, dB, L.sort_d.as<u8>(), L.hist.as<u32>());
-					check_launch();
-				}
-				LQ_LAUNCH(k_sort_classify, ns, LQ_CLASSIFY_THREADS, L.stream, cur, ns, L.hist.as<u32>(), L.begs.as<u32>(), L.seg_info.as<SegInfo>(),
-				          L.walk_list.as<u32>(), L.two_list.as<u32>(), L.n_segs.as<u32>() + 2, wcaps);
-				check_launch();
-				u32 cw[1 + LQ_WALK_CLASSES];
-				d2h(cw, L.n_segs.as<u32>() + 2, 1 + LQ_WALK_CLASSES, L.stream);
-				const u32 n_two = cw[0];
-				u32 n_walk = 0;
-				for (int c = 0; c < LQ_WALK_CLASSES; ++c) n_walk += cw[1 + c];
-				if (n_two) {                                        // closed-form two-bucket passes (the strand bit at the top level)
-					StageTimer t(this, L.stream, "k_sort_two", nA * 6);
-					LQ_LAUNCH(k_sort_two, n_two, LQ_TWO_THREADS, L.stream, cur, L.seg_info.as<SegInfo>(), L.two_list.as<u32>(), n_two, L.sort_d.as<u8>(), hx, py, L.sort_dst.as<u32>());
-					check_launch();
-				}
-				if (n_walk) {
-					const u8 *dD = L.sort_d.as<u8>(); const u32 *dH = L.hist.as<u32>(), *dBg = L.begs.as<u32>(); u32 *dDst = L.sort_dst.as<u32>();
-					const u32 *wl = L.walk_list.as<u32>();
-					if (cw[1]) { StageTimer t(this, L.stream, "k_sort_walk_lds<4096>"); LQ_LAUNCH((k_sort_walk_lds<4096>), cw[1], 64, L.stream, cur, wl + (u64)0 * ns, cw[1], dD, dH, dBg, dDst); check_launch(); }
-					if (cw[2]) { StageTimer t(this, L.stream, "k_sort_walk_lds<16384>"); LQ_LAUNCH((k_sort_walk_lds<16384>), cw[2], 64, L.stream, cur, wl + (u64)1 * ns, cw[2], dD, dH, dBg, dDst); check_launch(); }
-					const u32 n_long = cw[3] + cw[4] + cw[5];
-					if (n_long) {
-						// longer sub-arrays: one wave per walk (k_sort_walk_solo: walk state and 16-byte digit windows in LDS), longest
-						// first.  The three size classes are contiguous in the list only per class, so gather them.
-						L.wkey.ensure((u64)n_long * 4); L.wkey2.ensure((u64)n_long * 4); L.walk_list2.ensure((u64)n_long * 4); L.walk_list3.ensure((u64)n_long * 4);
-						u32 o = 0;
-						for (int c = 2; c < LQ_WALK_CLASSES; ++c) if (cw[1 + c]) {
-							LQ_HIP_CHECK(hipMemcpyAsync(L.walk_list3.as<u32>() + o, wl + (u64)c * ns, (u64)cw[1 + c] * 4, hipMemcpyDeviceToDevice, L.stream));
-							o += cw[1 + c];
-						}
-						const bool lane_walker = getenv("LQCOV_WALK") && !strcmp(getenv("LQCOV_WALK"), "lane");   // A/B knob
-						LQ_LAUNCH(k_walk_keys, nblk(n_long, 256), 256, L.stream, cur, L.walk_list3.as<u32>(), n_long, L.wkey.as<u32>()); check_launch();
-						L.prim.sort_pairs_u32_u32(L.wkey.as<u32>(), L.wkey2.as<u32>(), L.walk_list3.as<u32>(), L.walk_list2.as<u32>(), n_long);
-						// algorithmic bytes of a walk: one digit byte in, one 4-byte destination out per element
-						u64 long_elems = 0;
-						{
-							std::vector<u32> hk(n_long);
-							d2h(hk.data(), L.wkey2.as<u32>(), n_long, L.stream);
-							for (u32 v : hk) long_elems += 0xffffffffu - v;
-						}
-						if (lane_walker) {
-							StageTimer t(this, L.stream, "k_sort_walk", long_elems * 5);
-							LQ_LAUNCH(k_sort_walk, nblk(n_long, LQ_WALK_LANES), LQ_WALK_LANES, L.stream, cur, L.walk_list2.as<u32>(), n_long, dD, dH, dBg, dDst);
-							check_launch();
-						} else {
-							// the longest of these walks outlasts everything else in the batch on a handful of CUs: let the next lane start now
-							if (!L.gate_passed) { L.gate_passed = true; open_gate(); }
-							StageTimer t(this, L.stream, "k_sort_walk_solo", long_elems * 5);
-							LQ_LAUNCH(k_sort_walk_solo, n_long, 64, L.stream, cur, L.walk_list2.as<u32>(), n_long, dD, dH, dBg, dDst);
-							check_launch();
-						}
-					}
-				}
-				if (n_walk || n_two) {
-					StageTimer t(this, L.stream, "k_sort_scatter", nA * 36);
-					LQ_LAUNCH(k_sort_scatter, ns, 256, L.stream, cur, L.seg_info.as<SegInfo>(), ns, dA, dB, L.sort_dst.as<u32>());
-					check_launch();
-				}
-				{
-					StageTimer t(this, L.stream, "k_sort_children");
-					LQ_LAUNCH(k_sort_children, nblk((u64)ns * 256, LQ_CHILD_THREADS), LQ_CHILD_THREADS, L.stream, cur, ns, dA, L.hist.as<u32>(), L.begs.as<u32>(), nxt, L.n_segs.as<u32>() + 1, const_levels);
-					check_launch();
-				}
-				d2h(&ns, L.n_segs.as<u32>() + 1, 1, L.stream);
-				std::swap(cur, nxt);
-			}
-		}
+		sort_batch(L, pt, q0, nqb, a_base, nA);           // lqmap.c:238
 		// ---- (strand, rid) runs ----
 		dzero(d_head, nA * 4, L.stream);
 		LQ_LAUNCH(k_mark_qstart, nblk(nqb, 256), 256, L.stream, aqb, a_base, nqb, d_head); check_launch();
@@ -689,6 +596,197 @@ void lqcov_handle::map_batch(MapLane &L, Part &pt, u32 q0, u32 q1, const std::ve
 	}
 }
 
+static u32 ps_shift() { const char *e = getenv("LQCOV_PS_SHIFT"); return e ? (u32)std::min(12, std::max(0, atoi(e))) : 0; }   // test knob: shrinks the size classes of the parallel sort
+
+static PsLists ps_lists(MapLane &L, int set)
+{
+	PsWork &W = L.ps[set];
+	PsLists Ls;
+	Ls.big[0] = W.big[0].as<PSeg>(); Ls.big[1] = W.big[1].as<PSeg>(); Ls.fin_s = W.fin_s.as<PSeg>(); Ls.fin_b = W.fin_b.as<PSeg>();
+	Ls.cnt = L.sort_cnt.as<u32>() + (set ? LQ_C_PS1 : LQ_C_PS0);
+	Ls.cap_big = (u32)std::min<u64>(W.big[0].cap / sizeof(PSeg), 0xfffffff0ULL); Ls.cap_fin = (u32)std::min<u64>(W.fin_s.cap / sizeof(PSeg), 0xfffffff0ULL);
+	const u32 sh = ps_shift();
+	Ls.fin_s_max = std::max<u32>(LQ_PS_FIN_SMALL >> sh, 2); Ls.fin_b_max = std::max<u32>(LQ_PS_FIN_BIG >> sh, 4); Ls.child_target = std::max<u32>(LQ_PS_TILE >> sh, 2);
+	return Ls;
+}
+
+// The parallel sort of the segments of one list set (kernels_psort.hpp): partition passes while segments above the
+// LDS capacity remain, then the two finishing kernels.  Everything is sized by upper bounds and strides over device-side
+// counts: no host round trip.
+void lqcov_handle::psort_run(MapLane &L, int set, hipStream_t s, u64 nA, const KeyMap &km)
+{
+	PsWork &W = L.ps[set];
+	u32 *cnt = L.sort_cnt.as<u32>() + (set ? LQ_C_PS1 : LQ_C_PS0);
+	const PsLists Ls = ps_lists(L, set);
+	const u32 cap_cnt = (u32)std::min<u64>(W.gcnt.cap / 4, 0xfffffff0ULL);
+	const u32 g_tiles = (u32)std::min<u64>((nA + LQ_PS_TILE - 1) / LQ_PS_TILE + 1, 16384);
+	const u32 g_segs = (u32)std::min<u64>(Ls.cap_big, 4096);
+	mm128 *dA = L.A.as<mm128>(), *dB = L.B.as<mm128>();
+	const int max_pass = ps_shift() ? 16 : 6;
+	for (int pass = 0; pass < max_pass; ++pass) {
+		const u32 cur = pass & 1, nxt = cur ^ 1;
+		dzero(cnt + (nxt ? LQ_P_BIG1 : LQ_P_BIG0), 4, s);
+		LQ_LAUNCH(k_ps_plan, 1, 256, s, Ls.big[cur], cnt + (cur ? LQ_P_BIG1 : LQ_P_BIG0), W.plan.as<PPlan>(), cnt, cap_cnt, Ls.child_target); check_launch();
+		dzero(W.gcnt.p, (size_t)cap_cnt * 4, s);
+		{
+			StageTimer t(this, s, "k_ps_hist", nA * 16);
+			LQ_LAUNCH(k_ps_hist, g_tiles, LQ_PS_THREADS, s, Ls.big[cur], cnt + (cur ? LQ_P_BIG1 : LQ_P_BIG0), W.plan.as<PPlan>(), cnt, dA, dB, km, W.gcnt.as<u32>()); check_launch();
+		}
+		LQ_LAUNCH(k_ps_scan, g_segs, 256, s, Ls.big[cur], cnt + (cur ? LQ_P_BIG1 : LQ_P_BIG0), W.plan.as<PPlan>(), W.gcnt.as<u32>(), W.gcur.as<u32>(), Ls, (u32)(nxt ? LQ_P_BIG1 : LQ_P_BIG0)); check_launch();
+		{
+			StageTimer t(this, s, "k_ps_scatter", nA * 32);
+			LQ_LAUNCH(k_ps_scatter, g_tiles, LQ_PS_THREADS, s, Ls.big[cur], cnt + (cur ? LQ_P_BIG1 : LQ_P_BIG0), W.plan.as<PPlan>(), cnt, dA, dB, km, W.gcur.as<u32>()); check_launch();
+		}
+	}
+	{
+		StageTimer t(this, s, "k_ps_finish<8192>", nA * 32);
+		LQ_LAUNCH((k_ps_finish<LQ_PS_FIN_BIG, 1024>), (u32)std::min<u64>(Ls.cap_fin, 2048), 1024, s, Ls.fin_b, cnt + LQ_P_FIN_B, dA, dB, km); check_launch();
+	}
+	{
+		StageTimer t(this, s, "k_ps_finish<1024>", nA * 32);
+		LQ_LAUNCH((k_ps_finish<LQ_PS_FIN_SMALL, 256>), (u32)std::min<u64>(Ls.cap_fin, 16384), 256, s, Ls.fin_s, cnt + LQ_P_FIN_S, dA, dB, km); check_launch();
+	}
+}
+
+// Sort every query's anchors by x, in klib's order wherever that order can be told apart (lqmap.c:238).
+//   * queries without repeated (hash, strand) minimizers hold no equal x: the parallel sort, on the lane's second stream;
+//   * the others go through klib's passes byte by byte (kernels_sort.hpp); buckets of a pass that received fewer than
+//     two marked anchors leave for the parallel sort as well (set 1, after the last pass).
+void lqcov_handle::sort_batch(MapLane &L, Part &pt, u32 q0, u32 nqb, u64 a_base, u64 nA)
+{
+	const u64 *aqb = aq_off.as<u64>() + q0;
+	mm128 *dA = L.A.as<mm128>(), *dB = L.B.as<mm128>();
+	hipStream_t sD = L.stream, sC = L.stream2;
+	const bool all_klib = getenv("LQCOV_SORT") && !strcmp(getenv("LQCOV_SORT"), "klib");   // A/B + test knob: every query through klib's passes
+	// varying key bits of this part: x = strand:1 | rid:31 | position:32 (lqmap.c:190-196)
+	u32 max_len = 0;
+	for (u32 v : pt.rs.h_len) max_len = std::max(max_len, v);
+	KeyMap km; km.pbits = 1; km.rbits = 0;
+	while (km.pbits < 32 && ((u64)1 << km.pbits) < (u64)max_len) ++km.pbits;
+	while (km.rbits < 31 && ((u64)1 << km.rbits) < (u64)pt.rs.n) ++km.rbits;
+	u32 const_levels = 0;                                    // key bytes that are zero in every anchor of this part
+	if (!getenv("LQCOV_NO_LEVEL_SKIP")) {
+		if (pt.rs.n <= (1u << 16)) const_levels |= 1u << 6;
+		if (pt.rs.n <= (1u << 8)) const_levels |= 1u << 5;
+		if (max_len <= (1u << 24)) const_levels |= 1u << 3;
+		if (max_len <= (1u << 16)) const_levels |= 1u << 2;
+		if (max_len <= (1u << 8)) const_levels |= 1u << 1;
+	}
+	// list capacities: a segment in any list has more than 64 elements
+	const u64 max_segs = nA / (LQ_RS_MIN + 1) + nqb + 1;
+	const u64 cap_big = nA / ((LQ_PS_FIN_BIG >> ps_shift()) + 1) + nqb + 16;
+	L.sort_cnt.ensure(LQ_C_N * 4);
+	for (int set = 0; set < 2; ++set) {
+		PsWork &W = L.ps[set];
+		W.big[0].ensure(cap_big * sizeof(PSeg)); W.big[1].ensure(cap_big * sizeof(PSeg)); W.plan.ensure((cap_big + 1) * sizeof(PPlan));
+		// (a finishing list takes klib buckets and whole queries -- more than 64 elements each -- and the children of the partition
+		// passes, at most 256 per segment and pass)
+		const u64 cap_fin = max_segs + 512 * cap_big;
+		W.fin_s.ensure(cap_fin * sizeof(PSeg)); W.fin_b.ensure(cap_fin * sizeof(PSeg));
+		W.gcnt.ensure(cap_big * 256 * 4); W.gcur.ensure(cap_big * 256 * 4);
+	}
+	L.segs0.ensure(max_segs * sizeof(SortSeg)); L.segs1.ensure(max_segs * sizeof(SortSeg));
+	dzero(L.sort_cnt.p, LQ_C_N * 4, sD);
+	auto lists = [&](int set) { return ps_lists(L, set); };
+	u32 *cnt = L.sort_cnt.as<u32>();
+	{
+		StageTimer t(this, sD, "k_sort_init");
+		LQ_LAUNCH(k_sort_init, nblk(nqb, 64), 64, sD, aqb, a_base, nqb, qdirty.as<u32>() + q0, dA, L.segs0.as<SortSeg>(), cnt, lists(0), km, (int)all_klib);
+		check_launch();
+	}
+	// the parallel sort of the clean queries runs beside klib's passes
+	LQ_HIP_CHECK(hipEventRecord(L.ev_fork, sD));
+	LQ_HIP_CHECK(hipStreamWaitEvent(sC, L.ev_fork, 0));
+	psort_run(L, 0, sC, nA, km);
+	LQ_HIP_CHECK(hipEventRecord(L.ev_join, sC));
+	// ---- klib's passes over the queries with repeated minimizers ----
+	u32 ns = 0;
+	d2h(&ns, cnt + LQ_C_KLIB0, 1, sD);
+	if (ns) {
+		const u64 nA4 = ((nA + 1) * 4 + 15) & ~(u64)15;
+		u32 *hx = (u32*)L.scr.p, *py = (u32*)((u8*)L.scr.p + nA4);
+		WalkCaps wcaps; wcaps.c[0] = 4096; wcaps.c[1] = 16384; wcaps.c[2] = 65536; wcaps.c[3] = 159744;
+		if (const char *ws = getenv("LQCOV_WALK_SHIFT")) for (int c = 0; c < 4; ++c) wcaps.c[c] >>= atoi(ws);   // test knob
+		const bool reg_walker = !(getenv("LQCOV_WALK") && !strcmp(getenv("LQCOV_WALK"), "solo"));   // A/B knob
+		L.sort_d.ensure(nA + 64); L.sort_dst.ensure((nA + 1) * 4);
+		SortSeg *cur = L.segs0.as<SortSeg>(), *nxt = L.segs1.as<SortSeg>();
+		u32 cur_slot = LQ_C_KLIB0, nxt_slot = LQ_C_KLIB1;
+		u32 shift = 56;
+		bool gated = false;
+		for (int level = 0; level < 8 && ns > 0; ++level) {
+			L.hist.ensure((u64)ns * 1024); L.begs.ensure((u64)ns * 1024); L.mhist.ensure((u64)ns * 1024);
+			L.seg_info.ensure((u64)ns * sizeof(SegInfo)); L.walk_list.ensure((u64)ns * 4 * LQ_WALK_CLASSES); L.two_list.ensure((u64)ns * 4);
+			dzero(cnt + nxt_slot, 4, sD); dzero(cnt + LQ_C_TWO, 4 * (1 + LQ_WALK_CLASSES), sD);
+			const u32 g_seg = std::min<u32>(ns, 1u << 18);
+			{
+				StageTimer t(this, sD, "k_sort_copy_hist", nA * 33);
+				LQ_LAUNCH(k_sort_copy_hist, g_seg, 256, sD, cur, cnt + cur_slot, dA, dB, L.sort_d.as<u8>(), L.hist.as<u32>(), L.mhist.as<u32>());
+				check_launch();
+			}
+			LQ_LAUNCH(k_sort_classify, g_seg, LQ_CLASSIFY_THREADS, sD, cur, cnt + cur_slot, ns, L.hist.as<u32>(), L.begs.as<u32>(), L.seg_info.as<SegInfo>(),
+			          L.walk_list.as<u32>(), L.two_list.as<u32>(), cnt + LQ_C_TWO, cnt + LQ_C_WALK0, wcaps);
+			check_launch();
+			{	// closed-form two-bucket passes (the strand bit at the top level)
+				StageTimer t(this, sD, "k_sort_two", nA * 6);
+				LQ_LAUNCH(k_sort_two, std::min<u32>(ns, 16384), LQ_TWO_THREADS, sD, cur, L.seg_info.as<SegInfo>(), L.two_list.as<u32>(), cnt + LQ_C_TWO, L.sort_d.as<u8>(), hx, py, L.sort_dst.as<u32>());
+				check_launch();
+			}
+			{
+				const u8 *dD = L.sort_d.as<u8>(); const u32 *dH = L.hist.as<u32>(), *dBg = L.begs.as<u32>(); u32 *dDst = L.sort_dst.as<u32>();
+				const u32 *wl = L.walk_list.as<u32>();
+				// the largest digit of this level decides how many register groups the long walker needs
+				u32 max_digit = 255;
+				if (shift == 48) max_digit = (pt.rs.n ? pt.rs.n - 1 : 0) >> 16;
+				else if (shift == 40 && pt.rs.n <= (1u << 16)) max_digit = (pt.rs.n ? pt.rs.n - 1 : 0) >> 8;
+				else if (shift == 32 && pt.rs.n <= (1u << 8)) max_digit = pt.rs.n ? pt.rs.n - 1 : 0;
+				else if (shift == 24) max_digit = (max_len ? max_len - 1 : 0) >> 24;
+				else if (shift == 16 && max_len <= (1u << 24)) max_digit = (max_len ? max_len - 1 : 0) >> 16;
+				else if (shift == 8 && max_len <= (1u << 16)) max_digit = (max_len ? max_len - 1 : 0) >> 8;
+				if (getenv("LQCOV_DEBUG_SORT")) {
+					u32 hc[LQ_C_N]; d2h(hc, cnt, LQ_C_N, sD);
+					fprintf(stderr, "[sort] level %d shift %u max_digit %u ns %u two %u walk %u %u %u %u %u nA %llu\n", level, shift, max_digit, ns, hc[LQ_C_TWO],
+					        hc[LQ_C_WALK0], hc[LQ_C_WALK1], hc[LQ_C_WALK2], hc[LQ_C_WALK3], hc[LQ_C_WALK4], (unsigned long long)nA);
+					fflush(stderr);
+				}
+				// long walks first: they outlast everything else of the level on a handful of CUs
+				for (int c = LQ_WALK_CLASSES - 1; c >= 2; --c) {
+					if (!gated && !L.gate_passed) { L.gate_passed = true; open_gate(); gated = true; }   // let the next lane start under these walks
+					const u32 g = std::min<u32>(ns, 8192);
+					if (reg_walker && max_digit < 64) { StageTimer t(this, sD, "k_sort_walk_reg<1>", nA * 5); LQ_LAUNCH((k_sort_walk_reg<1>), g, 64, sD, cur, wl + (u64)c * ns, cnt + LQ_C_WALK0 + c, dD, dH, dBg, dDst); }
+					else if (reg_walker && max_digit < 128) { StageTimer t(this, sD, "k_sort_walk_reg<2>", nA * 5); LQ_LAUNCH((k_sort_walk_reg<2>), g, 64, sD, cur, wl + (u64)c * ns, cnt + LQ_C_WALK0 + c, dD, dH, dBg, dDst); }
+					else { StageTimer t(this, sD, "k_sort_walk_solo", nA * 5); LQ_LAUNCH(k_sort_walk_solo, g, 64, sD, cur, wl + (u64)c * ns, cnt + LQ_C_WALK0 + c, dD, dH, dBg, dDst); }
+					check_launch();
+					if (getenv("LQCOV_DEBUG_SORT")) { LQ_HIP_CHECK(hipStreamSynchronize(sD)); fprintf(stderr, "[sort] level %d class %d done\n", level, c); fflush(stderr); }
+				}
+				{ StageTimer t(this, sD, "k_sort_walk_lds<16384>"); LQ_LAUNCH((k_sort_walk_lds<16384>), std::min<u32>(ns, 8192), 64, sD, cur, wl + (u64)1 * ns, cnt + LQ_C_WALK1, dD, dH, dBg, dDst); check_launch(); }
+				{ StageTimer t(this, sD, "k_sort_walk_lds<4096>"); LQ_LAUNCH((k_sort_walk_lds<4096>), std::min<u32>(ns, 1u << 16), 64, sD, cur, wl + (u64)0 * ns, cnt + LQ_C_WALK0, dD, dH, dBg, dDst); check_launch(); }
+			}
+			{
+				StageTimer t(this, sD, "k_sort_scatter", nA * 36);
+				LQ_LAUNCH(k_sort_scatter, g_seg, 256, sD, cur, L.seg_info.as<SegInfo>(), cnt + cur_slot, dA, dB, L.sort_dst.as<u32>());
+				check_launch();
+			}
+			{
+				StageTimer t(this, sD, "k_sort_children");
+				LQ_LAUNCH(k_sort_children, (u32)std::min<u64>((u64)ns * 4, 1u << 20), LQ_CHILD_THREADS, sD, cur, cnt + cur_slot, dA, L.hist.as<u32>(), L.mhist.as<u32>(), L.begs.as<u32>(),
+				          nxt, cnt + nxt_slot, const_levels, lists(1), km, (int)all_klib);
+				check_launch();
+			}
+			d2h(&ns, cnt + nxt_slot, 1, sD);
+			std::swap(cur, nxt); std::swap(cur_slot, nxt_slot);
+			if (shift >= 8) { shift -= 8; while (shift > 0 && (const_levels >> (shift >> 3) & 1)) shift -= 8; }
+		}
+		psort_run(L, 1, sD, nA, km);                          // the buckets that left klib's passes
+	}
+	LQ_HIP_CHECK(hipStreamWaitEvent(sD, L.ev_join, 0));
+	{
+		u32 hc[LQ_C_N];
+		d2h(hc, cnt, LQ_C_N, sD);
+		if (hc[LQ_C_PS0 + LQ_P_OVERFLOW] || hc[LQ_C_PS1 + LQ_P_OVERFLOW]) throw std::runtime_error("parallel sort: list or counter space overflow");
+		if (hc[LQ_C_PS0 + LQ_P_BIG0] || hc[LQ_C_PS1 + LQ_P_BIG0]) throw std::domain_error("parallel sort: segments above the LDS capacity left after the last pass");
+	}
+}
+
 void lqcov_handle::open_gate()
 {
 	{ std::lock_guard<std::mutex> lk(gate_mu); ++gate_count; }
@@ -705,6 +803,7 @@ void lqcov_handle::map_part(Part &pt)
 	last_n_anchors = 0;
 	n_dbg_host = 0;
 	if (n_q == 0) return;
+	dup.ensure(n_qm * 4 + 4); qdirty.ensure((u64)n_q * 4 + 4);
 	hit_start.ensure(n_qm * 8 + 8); hit_n.ensure(n_qm * 4 + 4); a_cnt.ensure(n_qm * 4 + 4); keep.ensure(n_qm * 4 + 4);
 	a_off.ensure(n_qm * 8 + 8); mp_off.ensure(n_qm * 8 + 8);
 	aq_off.ensure((n_q + 1) * 8); mpq_off.ensure((n_q + 1) * 8); avg_qspan.ensure((n_q + 1) * 4); skip.ensure((n_q + 1) * 4);
@@ -716,6 +815,16 @@ void lqcov_handle::map_part(Part &pt)
 			          pt.tkey.as<u64>(), pt.tstart.as<u64>(), pt.tcnt.as<u32>(), pt.cap_bits, pt.pos.as<u64>(),
 			          mid_occ, (int)P.no_self, pt.self_off.as<u32>(), pt.self_rid.as<u32>(), AvaView{P.ava ? pt.t_rank.as<u32>() : nullptr, P.ava ? pt.q_lo.as<u32>() : nullptr},
 			          hit_start.as<u64>(), hit_n.as<u32>(), a_cnt.as<u32>(), keep.as<u32>());
+			check_launch();
+		}
+		{	// minimizers / queries whose anchors can repeat an x (kernels_psort.hpp): everything else is sorted without klib's walks
+			u32 tbits = 10;
+			while (((u64)1 << tbits) < 2 * n_qm && tbits < 31) ++tbits;
+			dup.ensure(n_qm * 4 + 4); qdirty.ensure((u64)n_q * 4 + 4); dup_table.ensure(((u64)1 << tbits) * 4);
+			dzero(dup.p, n_qm * 4, stream); dzero(qdirty.p, (u64)n_q * 4, stream); dzero(dup_table.p, ((u64)1 << tbits) * 4, stream);
+			StageTimer t(this, "k_dup_mark", n_qm * 24);
+			LQ_LAUNCH(k_dup_mark, nblk(n_qm, 256), 256, stream, q.mx.as<u64>(), q.my.as<u64>(), q_owner.as<u32>(), a_cnt.as<u32>(), n_qm,
+			          dup_table.as<u32>(), tbits, dup.as<u32>(), qdirty.as<u32>());
 			check_launch();
 		}
 		prim.exclusive_scan_u32_u64(a_cnt.as<u32>(), a_off.as<u64>(), n_qm);
@@ -764,6 +873,9 @@ void lqcov_handle::map_part(Part &pt)
 	while (lanes.size() < (size_t)n_lanes) {
 		lanes.emplace_back(new MapLane());
 		LQ_HIP_CHECK(hipStreamCreate(&lanes.back()->stream));
+		LQ_HIP_CHECK(hipStreamCreate(&lanes.back()->stream2));
+		LQ_HIP_CHECK(hipEventCreateWithFlags(&lanes.back()->ev_fork, hipEventDisableTiming));
+		LQ_HIP_CHECK(hipEventCreateWithFlags(&lanes.back()->ev_join, hipEventDisableTiming));
 		lanes.back()->prim.stream = lanes.back()->stream;
 	}
 	{

@@ -8,6 +8,7 @@
 #pragma once
 #include "lq_common.hpp"
 #include "prim.hpp"
+struct KeyMap;
 #include "../../include/lqcov.h"
 #include <string>
 #include <vector>
@@ -48,8 +49,16 @@ struct Part {
 
 // One mapping lane: a stream with its own scan/sort scratch and per-batch work space.  Query batches of a part are
 // independent (lqmap.c:170-330 runs one query at a time), so lanes run them concurrently.
+struct PsWork {                           // one set of psort lists + the scratch of its partition passes (kernels_psort.hpp)
+	DBuf big[2], fin_s, fin_b, plan, gcnt, gcur;
+};
+
 struct MapLane {
-	hipStream_t stream = nullptr;
+	hipStream_t stream = nullptr;         // klib's passes (queries with repeated minimizers), then runs and chains
+	hipStream_t stream2 = nullptr;        // the parallel sort of every other query, meanwhile
+	hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+	DBuf sort_cnt, mhist;
+	PsWork ps[2];
 	Prim prim;
 	bool gate_passed = false;             // this batch has reached its long walks (see map_part)
 	DBuf A, B, segs0, segs1, n_segs, hist, begs;
@@ -86,6 +95,7 @@ struct lqcov_handle {
 	std::vector<u32> q_perm, q_inv;
 	DBuf q_owner;                         // query of every query minimizer
 	DBuf lambda, lambda2, avg_k, cnts, qflags, qual_psum;
+	DBuf dup, qdirty, dup_table;          // k_dup_mark: minimizers / queries whose anchors can repeat an x (per part)
 	// counter layout: normally the query minimizer offsets; after adopt_index_params() (prebuilt index with other -k/-w/-H)
 	// the reference's sizes (from the command-line sketch, minimap2-coverage.c:419-422) and the mapping's differ
 	bool own_cnt_layout = false; DBuf cnt_off, d_nsize; std::vector<u32> h_nsize; u64 cnt_total = 0;
@@ -126,6 +136,8 @@ struct lqcov_handle {
 	void open_gate();
 	void map_part(Part &pt);
 	void map_batch(MapLane &L, Part &pt, u32 q0, u32 q1, const std::vector<u64> &h_aq, const std::vector<u64> &h_qmoff, bool dbg);
+	void sort_batch(MapLane &L, Part &pt, u32 q0, u32 nqb, u64 a_base, u64 nA);
+	void psort_run(MapLane &L, int set, hipStream_t s, u64 nA, const KeyMap &km);
 	void reset();
 	void finish();
 	void write_table(FILE *out);

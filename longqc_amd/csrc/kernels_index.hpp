@@ -94,6 +94,16 @@ __device__ __forceinline__ bool lq_is_self(const u32 *self_off, const u32 *self_
 // among the part's distinct names, q_lo[q] = number of distinct target names below the query's: tname < qname <=> rank < q_lo.
 struct AvaView { const u32 *t_rank, *q_lo; };     // both null without -X
 
+// is y = (rid, pos, either strand) in the ascending occurrence list pos[st .. st+n)?  (index.c:188 keeps every list
+// ascending in y = rid<<32 | pos<<1 | strand, and one (rid, pos) holds one minimizer: at most one entry matches)
+__device__ __forceinline__ bool lq_list_has(const u64 *pos, u64 st, u32 n, u32 rid, u32 rpos)
+{
+	const u64 want = (u64)rid << 32 | (u64)rpos << 1;
+	u32 lo = 0, hi = n;                                     // first entry >= want
+	while (lo < hi) { const u32 mid = lo + ((hi - lo) >> 1); if (pos[st + mid] < want) lo = mid + 1; else hi = mid; }
+	return lo < n && (pos[st + lo] >> 1) == (want >> 1);
+}
+
 // pass A of collect_seed_hits: probe, apply mid_occ, count surviving hits
 __global__ void k_seed_probe(const u64 *qx, const u64 *qy, const u32 *owner, u64 n_qm,
                              const u64 *tkey, const u64 *tstart, const u32 *tcnt, u32 cap_bits, const u64 *pos,
@@ -107,77 +117,111 @@ __global__ void k_seed_probe(const u64 *qx, const u64 *qy, const u32 *owner, u64
 	hit_start[j] = st; hit_n[j] = n;
 	if ((i64)n >= (i64)mid_occ) { a_cnt[j] = 0; keep[j] = 0; return; }     // lqmap.c:166-173
 	u32 c = n;
-	u32 q = owner[j];
-	const bool check_self = no_self && self_off[q] != self_off[q + 1];
-	if (check_self || ava.t_rank) {
-		u32 qpos = (u32)qy[j] >> 1;
-		const u32 qlo = ava.t_rank ? ava.q_lo[q] : 0;
+	const u32 q = owner[j];
+	const u32 qpos = (u32)qy[j] >> 1;
+	if (ava.t_rank) {                                       // -X: every hit has to be looked at (lqmap.c:187)
+		const bool check_self = no_self && self_off[q] != self_off[q + 1];
+		const u32 qlo = ava.q_lo[q];
 		for (u32 t = 0; t < n; ++t) {
 			u64 r = pos[st + t];
 			if (check_self && ((u32)r >> 1) == qpos && lq_is_self(self_off, self_rid, q, (u32)(r >> 32))) --c;
-			else if (ava.t_rank && ava.t_rank[(u32)(r >> 32)] < qlo) --c;
+			else if (ava.t_rank[(u32)(r >> 32)] < qlo) --c;
 		}
+	} else if (no_self && n) {
+		// the self diagonal (lqmap.c:180-186): a hit on a same-name target at the query's own position.  The list is
+		// ascending in (rid, pos), so each same-name target costs one binary search instead of a scan of the list.
+		for (u32 s = self_off[q]; s < self_off[q + 1]; ++s) if (lq_list_has(pos, st, n, self_rid[s], qpos)) --c;
 	}
 	a_cnt[j] = c; keep[j] = 1;
 }
 
+// Query minimizers that share (hash, strand) with another anchor-bearing minimizer of the same query.  Two anchors of a
+// query can only have the same x = (rev, rid, rpos) when two of its minimizers hit the same target occurrence, i.e.
+// carry the same hash, and the same rev needs the same query strand: anchors of unmarked minimizers are unique in x,
+// so any correct sort puts them where klib's unstable radix sort does (kernels_sort.hpp), and a query without a
+// marked minimizer needs no klib-order walk at all.  One open-addressed table for the whole query set: slot -> j + 1.
+__global__ void k_dup_mark(const u64 *qx, const u64 *qy, const u32 *owner, const u32 *a_cnt, u64 n_qm,
+                           u32 *table, u32 tbits, u32 *dup, u32 *qdirty)
+{
+	const u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+	if (j >= n_qm || a_cnt[j] == 0) return;
+	const u64 key = qx[j] >> 8;
+	const u32 strand = (u32)qy[j] & 1, q = owner[j];
+	const u32 mask = (1u << tbits) - 1;
+	u32 h = (u32)((((key << 1 | strand) ^ (u64)q * 0xD6E8FEB86659FD93ULL) * 0x9E3779B97F4A7C15ULL) >> (64 - tbits));
+	for (;;) {
+		const u32 old = atomicCAS(&table[h], 0u, (u32)j + 1);
+		if (old == 0) return;
+		const u32 jo = old - 1;
+		if (owner[jo] == q && (qx[jo] >> 8) == key && ((u32)qy[jo] & 1) == strand) { dup[j] = 1; dup[jo] = 1; qdirty[q] = 1; return; }
+		h = (h + 1) & mask;
+	}
+}
+
 // pass B: anchors (lqmap.c:175-200) and mini_pos (lqmap.c:174)
 // (a batch of queries = minimizers [j0, j0+nj); anchors are written relative to a_base)
-__global__ void k_seed_emit(const u64 *qx, const u64 *qy, const u32 *owner, const u64 *qmoff, u64 j0, u64 nj,
-                            const u64 *pos, const u64 *hit_start, const u32 *hit_n, const u32 *keep,
-                            const u64 *a_off, u64 a_base, const u64 *mp_off, const u32 *qlen,
-                            int no_self, const u32 *self_off, const u32 *self_rid, AvaView ava,
-                            mm128 *anchors, u64 *mini_pos)
+// One query minimizer per lane for the set-up, which is parked in LDS; then the wave emits the anchors of one minimizer
+// at a time, a hit per lane: the occurrence list is read and the anchors are written as contiguous runs (a thread
+// walking its own list wrote 16-byte pieces 1 KiB apart: rocprofv3 counted 108 GB of HBM traffic per launch for 19 GB
+// of anchors).  Anchors of minimizers marked by k_dup_mark carry LQ_TIE_MARK in y (never read downstream, like
+// MM_SEED_TANDEM): the sort counts them to tell where klib's order can matter.
+#define LQ_EMIT_THREADS 256
+struct EmitSetup { u64 st, out0; u32 n, q, span, qp, flags; i32 ql; };
+__global__ void __launch_bounds__(LQ_EMIT_THREADS)
+k_seed_emit(const u64 *qx, const u64 *qy, const u32 *owner, const u64 *qmoff, u64 j0, u64 nj,
+            const u64 *pos, const u64 *hit_start, const u32 *hit_n, const u32 *keep, const u32 *dup,
+            const u64 *a_off, u64 a_base, const u64 *mp_off, const u32 *qlen,
+            int no_self, const u32 *self_off, const u32 *self_rid, AvaView ava,
+            mm128 *anchors, u64 *mini_pos)
 {
-	// One query minimizer per lane for the set-up, then the wave emits the anchors of one minimizer at a time, a hit per
-	// lane: the occurrence list is read and the anchors are written as contiguous runs (a thread walking its own list
-	// wrote 16-byte pieces 1 KiB apart: rocprofv3 counted 108 GB of HBM traffic per launch for 19 GB of anchors).
+	__shared__ EmitSetup su[LQ_EMIT_THREADS];
 	const u64 jt = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-	const u32 lane = threadIdx.x & 63;
+	const u32 lane = threadIdx.x & 63, w0 = threadIdx.x & ~63u;
 	const u64 j = j0 + (jt < nj ? jt : 0);
 	const bool act = jt < nj && keep[j];
-	u32 q = 0, q_span = 0, qp = 0, n = 0, flags = 0;
-	u64 st = 0, out0 = 0;
-	i32 ql = 0;
+	EmitSetup e; e.st = 0; e.out0 = 0; e.n = 0; e.q = 0; e.span = 0; e.qp = 0; e.flags = 0; e.ql = 0;
 	if (act) {
-		q = owner[j];
+		e.q = owner[j];
 		const u64 x = qx[j];
-		q_span = (u32)(x & 0xff); qp = (u32)qy[j];
-		mini_pos[mp_off[j]] = (u64)q_span << 32 | (qp >> 1);
-		if (j > qmoff[q] && (qx[j - 1] >> 8) == (x >> 8)) flags |= 1;            // tandem
-		if (j + 1 < qmoff[q + 1] && (qx[j + 1] >> 8) == (x >> 8)) flags |= 1;
-		if (no_self && self_off[q] != self_off[q + 1]) flags |= 2;              // some target carries this query's name
-		n = hit_n[j]; st = hit_start[j]; out0 = a_off[j] - a_base; ql = (i32)qlen[q];
+		e.span = (u32)(x & 0xff); e.qp = (u32)qy[j];
+		mini_pos[mp_off[j]] = (u64)e.span << 32 | (e.qp >> 1);
+		if (j > qmoff[e.q] && (qx[j - 1] >> 8) == (x >> 8)) e.flags |= 1;            // tandem
+		if (j + 1 < qmoff[e.q + 1] && (qx[j + 1] >> 8) == (x >> 8)) e.flags |= 1;
+		if (no_self && self_off[e.q] != self_off[e.q + 1]) e.flags |= 2;             // some target carries this query's name
+		if (dup[j]) e.flags |= 4;
+		e.n = hit_n[j]; e.st = hit_start[j]; e.out0 = a_off[j] - a_base; e.ql = (i32)qlen[e.q];
 	}
-	u64 todo = __ballot(n > 0);
-	while (todo) {
-		const int f = __builtin_ctzll(todo);
-		todo &= todo - 1;
-		const u32 b_n = (u32)__builtin_amdgcn_readlane((int)n, f), b_q = (u32)__builtin_amdgcn_readlane((int)q, f);
-		const u32 b_span = (u32)__builtin_amdgcn_readlane((int)q_span, f), b_qp = (u32)__builtin_amdgcn_readlane((int)qp, f);
-		const u32 b_flags = (u32)__builtin_amdgcn_readlane((int)flags, f);
-		const i32 b_ql = __builtin_amdgcn_readlane(ql, f);
-		const u64 b_st = (u64)(u32)__builtin_amdgcn_readlane((int)(u32)st, f) | (u64)(u32)__builtin_amdgcn_readlane((int)(u32)(st >> 32), f) << 32;
-		const u64 b_out = (u64)(u32)__builtin_amdgcn_readlane((int)(u32)out0, f) | (u64)(u32)__builtin_amdgcn_readlane((int)(u32)(out0 >> 32), f) << 32;
-		const u32 b_qpos = b_qp >> 1;
-		const u64 y_same = (u64)b_span << 32 | b_qpos | ((b_flags & 1) ? LQ_SEED_TANDEM : 0);
-		const u64 y_rev = (u64)b_span << 32 | (u32)(b_ql - (i32)(b_qpos + 1 - b_span) - 1) | ((b_flags & 1) ? LQ_SEED_TANDEM : 0);
+	su[threadIdx.x] = e;
+	__syncthreads();
+	for (u32 f = 0; f < 64; ++f) {
+		const EmitSetup b = su[w0 + f];                         // the same entry in every lane of the wave
+		if (b.n == 0) continue;
+		const u32 b_qpos = b.qp >> 1;
+		const u64 ybits = ((b.flags & 1) ? LQ_SEED_TANDEM : 0) | ((b.flags & 4) ? LQ_TIE_MARK : 0);
+		const u64 y_same = (u64)b.span << 32 | b_qpos | ybits;
+		const u64 y_rev = (u64)b.span << 32 | (u32)(b.ql - (i32)(b_qpos + 1 - b.span) - 1) | ybits;
+		const bool filter = (b.flags & 2) || ava.t_rank;        // wave-uniform
 		u32 skipped = 0;
-		for (u32 t0 = 0; t0 < b_n; t0 += 64) {
+		for (u32 t0 = 0; t0 < b.n; t0 += 64) {
 			const u32 t = t0 + lane;
-			const bool valid = t < b_n;
-			const u64 r = valid ? pos[b_st + t] : 0;
+			const bool valid = t < b.n;
+			const u64 r = valid ? pos[b.st + t] : 0;
 			const u32 rpos = (u32)r >> 1;
-			const bool skip = valid && (((b_flags & 2) && rpos == b_qpos && lq_is_self(self_off, self_rid, b_q, (u32)(r >> 32))) ||
-			                            (ava.t_rank && ava.t_rank[(u32)(r >> 32)] < ava.q_lo[b_q]));
-			const u64 sm = __ballot(skip);
+			u32 before = 0;
+			bool skip = false;
+			if (filter) {
+				skip = valid && (((b.flags & 2) && rpos == b_qpos && lq_is_self(self_off, self_rid, b.q, (u32)(r >> 32))) ||
+				                 (ava.t_rank && ava.t_rank[(u32)(r >> 32)] < ava.q_lo[b.q]));
+				const u64 sm = __ballot(skip);
+				before = skipped + (u32)__popcll(sm & ((1ULL << lane) - 1));
+				skipped += (u32)__popcll(sm);
+			}
 			if (valid && !skip) {
 				mm128 a;
-				if ((r & 1) == (b_qp & 1)) { a.x = (r & 0xffffffff00000000ULL) | rpos; a.y = y_same; }
+				if ((r & 1) == (b.qp & 1)) { a.x = (r & 0xffffffff00000000ULL) | rpos; a.y = y_same; }
 				else { a.x = 1ULL << 63 | (r & 0xffffffff00000000ULL) | rpos; a.y = y_rev; }
-				anchors[b_out + t - skipped - (u32)__popcll(sm & ((1ULL << lane) - 1))] = a;
+				anchors[b.out0 + t - before] = a;
 			}
-			skipped += (u32)__popcll(sm);
 		}
 	}
 }

@@ -1,0 +1,352 @@
+// longqc_amd/csrc/kernels_psort.hpp -- sort by x where klib's order cannot be observed.
+//
+// The reference sorts a query's anchors with klib's unstable in-place radix sort (lqmap.c:238, ksort.h:99-134), and
+// the chaining DP sees the array order of anchors with equal x.  kernels_sort.hpp reproduces that order with serial
+// token walks.  But a sub-array whose anchors all differ in x has exactly one sorted arrangement -- klib's, and
+// every other correct sort's.  Equal x needs two minimizers of the query with the same (hash, strand)
+// (k_dup_mark, kernels_index.hpp): sub-arrays holding fewer than two anchors of such minimizers (a whole query
+// without marked minimizers, or a bucket of a klib pass that received at most one marked anchor) come here and are
+// sorted with plain parallel passes: no klib levels, no walks, free choice of digits.
+//
+// Key: only the bits of x that vary inside the part count -- strand (bit 63), the low `rbits` of rid (bits 32..),
+// the low `pbits` of the position; lq_ckey packs them into a compact key of K = 1 + rbits + pbits bits.  A segment
+// carries `rem`, the number of low key bits it still has to be sorted by (the bits above are equal inside it).
+//   * segments of more than LQ_PS_FIN_BIG elements: one partition pass on the top nbits <= 8 of the remaining bits
+//     (per 4096-element tile: histogram -> one atomic range reservation per digit -> LDS-staged, run-contiguous
+//     writes into the other buffer; the order inside a bucket is whatever the atomics give, which is fine: the
+//     keys are distinct and the finish below looks at all remaining bits);
+//   * segments up to LQ_PS_FIN_BIG (8192) / LQ_PS_FIN_SMALL (1024) elements: finished by one block in LDS: split
+//     by the next 8 key bits, then every element ranks itself among the (few) elements of its sub-bucket by the full
+//     remaining key; written to A whatever buffer the segment was in.
+// All list lengths live on the device; kernels take upper-bound grids and stride over the lists.
+#pragma once
+#include "lq_common.hpp"
+#include "kernels_sort.hpp"
+
+struct KeyMap { u32 pbits, rbits; };                 // varying low bits of the position and of rid in this part
+struct alignas(16) PSeg { u64 off; u32 len; u8 rem; u8 buf; u8 nbits; u8 pad; };   // buf: 0 = data in A, 1 = in B
+struct PPlan { u32 tile0, cnt0; };                   // first tile / first counter of a big segment
+
+#define LQ_PS_FIN_SMALL 1024
+#define LQ_PS_FIN_BIG   8192
+#define LQ_PS_TILE      4096
+#define LQ_PS_THREADS   256
+
+// counters of one batch's sort (device): indices into L.sort_cnt.  Two sets of psort lists: set 0 takes whole queries
+// (k_sort_init) and is sorted on its own stream while klib's passes run; set 1 collects the buckets that leave them.
+enum { LQ_C_KLIB0 = 0, LQ_C_KLIB1, LQ_C_TWO, LQ_C_WALK0, LQ_C_WALK1, LQ_C_WALK2, LQ_C_WALK3, LQ_C_WALK4, LQ_C_OVERFLOW,
+       LQ_C_PS0 = 16, LQ_C_PS1 = 32, LQ_C_N = 48 };
+enum { LQ_P_BIG0 = 0, LQ_P_BIG1, LQ_P_FIN_S, LQ_P_FIN_B, LQ_P_TILES, LQ_P_CNT, LQ_P_OVERFLOW };   // offsets inside a set's counters
+struct PsLists { struct PSeg *big[2], *fin_s, *fin_b; u32 *cnt; u32 cap_big, cap_fin;
+                 u32 fin_s_max, fin_b_max, child_target; };   // size limits of the two finishing kernels, aimed child size of a pass (tests shrink them)
+
+__device__ __forceinline__ u64 lq_ckey(u64 x, const KeyMap km)
+{
+	return (x & ((1ULL << km.pbits) - 1)) | ((x >> 32) & ((1ULL << km.rbits) - 1)) << km.pbits | (x >> 63) << (km.pbits + km.rbits);
+}
+// key bits below bit `shift` of x (a klib bucket made by the pass on the byte at `shift` still differs there only)
+__device__ __forceinline__ u32 lq_rem_below(u32 shift, const KeyMap km)
+{
+	if (shift <= 32) return shift < km.pbits ? shift : km.pbits;
+	const u32 r = shift - 32;
+	return km.pbits + (r < km.rbits ? r : km.rbits) + (shift > 63 ? 1u : 0u);
+}
+
+// append a segment to the list its size asks for (big_slot: LQ_P_BIG0 or LQ_P_BIG1)
+__device__ __forceinline__ void lq_ps_route(PSeg sg, const PsLists L, u32 big_slot)
+{
+	if (sg.len <= L.fin_s_max) { const u32 s = atomicAdd(&L.cnt[LQ_P_FIN_S], 1u); if (s < L.cap_fin) L.fin_s[s] = sg; else atomicOr(&L.cnt[LQ_P_OVERFLOW], 1u); }
+	else if (sg.len <= L.fin_b_max) { const u32 s = atomicAdd(&L.cnt[LQ_P_FIN_B], 1u); if (s < L.cap_fin) L.fin_b[s] = sg; else atomicOr(&L.cnt[LQ_P_OVERFLOW], 1u); }
+	else { const u32 s = atomicAdd(&L.cnt[big_slot], 1u); if (s < L.cap_big) L.big[big_slot][s] = sg; else atomicOr(&L.cnt[LQ_P_OVERFLOW], 1u); }
+}
+
+// block-wide exclusive scan of v[0..256) in LDS (256 or more threads; returns with the result in v, total in *tot)
+__device__ __forceinline__ void lq_scan256(u32 *v, u32 *tmp, u32 *tot)
+{
+	const u32 t = threadIdx.x;
+	for (u32 d = 1; d < 256; d <<= 1) {
+		u32 a = 0;
+		if (t < 256) a = v[t] + (t >= d ? v[t - d] : 0);
+		__syncthreads();
+		if (t < 256) v[t] = a;
+		__syncthreads();
+	}
+	if (t < 256) tmp[t] = t ? v[t - 1] : 0;
+	if (t == 255 && tot) *tot = v[255];
+	__syncthreads();
+	if (t < 256) v[t] = tmp[t];
+	__syncthreads();
+}
+
+// ---- plan of one partition pass: digits, tiles and counters of every big segment (one block) ----------------
+__global__ void __launch_bounds__(256)
+k_ps_plan(PSeg *segs, const u32 *n_p, PPlan *plan, u32 *cnt, u32 cap_cnt, u32 child_target)
+{
+	__shared__ u32 st[256], sc[256], tmp[256], tot_t, tot_c, base_t, base_c;
+	const u32 n = *n_p, t = threadIdx.x;
+	if (t == 0) { base_t = 0; base_c = 0; }
+	__syncthreads();
+	for (u32 s0 = 0; s0 < n; s0 += 256) {
+		const u32 s = s0 + t;
+		u32 nt = 0, nc = 0;
+		if (s < n) {
+			PSeg sg = segs[s];
+			u32 nb = 1;
+			while (nb < 8 && ((u64)child_target << nb) < sg.len) ++nb;   // children of about one tile
+			if (nb > sg.rem) nb = sg.rem;
+			sg.nbits = (u8)nb;
+			segs[s] = sg;
+			nt = (sg.len + LQ_PS_TILE - 1) / LQ_PS_TILE; nc = 1u << nb;
+		}
+		st[t] = nt; sc[t] = nc;
+		__syncthreads();
+		lq_scan256(st, tmp, &tot_t);
+		lq_scan256(sc, tmp, &tot_c);
+		if (s < n) { PPlan p; p.tile0 = base_t + st[t]; p.cnt0 = base_c + sc[t]; plan[s] = p; }
+		__syncthreads();
+		if (t == 0) { base_t += tot_t; base_c += tot_c; }
+		__syncthreads();
+	}
+	if (t == 0) {
+		PPlan e; e.tile0 = base_t; e.cnt0 = base_c; plan[n] = e;    // sentinel: totals
+		cnt[LQ_P_TILES] = base_t; cnt[LQ_P_CNT] = base_c;
+		if (base_c > cap_cnt) atomicOr(&cnt[LQ_P_OVERFLOW], 2u);
+	}
+}
+
+__device__ __forceinline__ u32 lq_ps_seg_of_tile(const PPlan *plan, u32 n, u32 tile)
+{
+	u32 lo = 0, hi = n;                                      // plan[lo].tile0 <= tile < plan[hi].tile0
+	while (hi - lo > 1) { const u32 mid = lo + ((hi - lo) >> 1); if (plan[mid].tile0 <= tile) lo = mid; else hi = mid; }
+	return lo;
+}
+
+// ---- histogram of the pass's digit, per big segment (tiles stride over the grid) ------------------------------
+__global__ void __launch_bounds__(LQ_PS_THREADS)
+k_ps_hist(const PSeg *segs, const u32 *n_p, const PPlan *plan, const u32 *cnt, const mm128 *A, const mm128 *B, KeyMap km, u32 *gcnt)
+{
+	__shared__ u32 lh[256];
+	const u32 n = *n_p;
+	if (n == 0 || (cnt[LQ_P_OVERFLOW] & 2u)) return;
+	const u32 n_tiles = cnt[LQ_P_TILES], t = threadIdx.x;
+	for (u32 tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+		const u32 s = lq_ps_seg_of_tile(plan, n, tile);
+		const PSeg sg = segs[s];
+		const PPlan pl = plan[s];
+		const u32 i0 = (tile - pl.tile0) * LQ_PS_TILE, i1 = i0 + LQ_PS_TILE < sg.len ? i0 + LQ_PS_TILE : sg.len;
+		const mm128 *src = (sg.buf ? B : A) + sg.off;
+		const u32 sh = sg.rem - sg.nbits, dm = (1u << sg.nbits) - 1;
+		lh[t] = 0;
+		__syncthreads();
+		for (u32 i = i0 + t; i < i1; i += LQ_PS_THREADS) atomicAdd(&lh[(u32)(lq_ckey(src[i].x, km) >> sh) & dm], 1u);
+		__syncthreads();
+		if (t <= dm && lh[t]) atomicAdd(&gcnt[pl.cnt0 + t], lh[t]);
+		__syncthreads();
+	}
+}
+
+// ---- bucket offsets and children of every big segment (one block per segment, strided) ----------------------
+__global__ void __launch_bounds__(256)
+k_ps_scan(const PSeg *segs, const u32 *n_p, const PPlan *plan, const u32 *gcnt, u32 *gcur, PsLists L, u32 big_next_slot)
+{
+	__shared__ u32 v[256], tmp[256];
+	const u32 n = *n_p, t = threadIdx.x;
+	if (L.cnt[LQ_P_OVERFLOW] & 2u) return;
+	for (u32 s = blockIdx.x; s < n; s += gridDim.x) {
+		const PSeg sg = segs[s];
+		const PPlan pl = plan[s];
+		const u32 nb = 1u << sg.nbits;
+		const u32 c = t < nb ? gcnt[pl.cnt0 + t] : 0;
+		v[t] = c;
+		__syncthreads();
+		lq_scan256(v, tmp, nullptr);
+		if (t < nb) {
+			gcur[pl.cnt0 + t] = v[t];
+			if (c) {
+				PSeg ch; ch.off = sg.off + v[t]; ch.len = c; ch.rem = (u8)(sg.rem - sg.nbits); ch.buf = sg.buf ^ 1; ch.nbits = 0; ch.pad = 0;
+				if (ch.rem == 0 || c == 1) { if (ch.buf) { ch.rem = 0; lq_ps_route(ch, L, big_next_slot); } }   // nothing left to sort: only bring it home to A
+				else lq_ps_route(ch, L, big_next_slot);
+			}
+		}
+		__syncthreads();
+	}
+}
+
+// ---- the partition pass: every tile moves its elements into their buckets in the other buffer ---------------
+__global__ void __launch_bounds__(LQ_PS_THREADS)
+k_ps_scatter(const PSeg *segs, const u32 *n_p, const PPlan *plan, const u32 *cnt, mm128 *A, mm128 *B, KeyMap km, u32 *gcur)
+{
+	__shared__ mm128 stage[LQ_PS_TILE];
+	__shared__ u32 lh[256], lo[256], fill[256], gb[256], tmp[256];
+	const u32 n = *n_p;
+	if (n == 0 || (cnt[LQ_P_OVERFLOW] & 2u)) return;
+	const u32 n_tiles = cnt[LQ_P_TILES], t = threadIdx.x;
+	constexpr u32 PER = LQ_PS_TILE / LQ_PS_THREADS;
+	for (u32 tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+		const u32 s = lq_ps_seg_of_tile(plan, n, tile);
+		const PSeg sg = segs[s];
+		const PPlan pl = plan[s];
+		const u32 i0 = (tile - pl.tile0) * LQ_PS_TILE, i1 = i0 + LQ_PS_TILE < sg.len ? i0 + LQ_PS_TILE : sg.len;
+		const mm128 *src = (sg.buf ? B : A) + sg.off;
+		mm128 *dst = (sg.buf ? A : B) + sg.off;
+		const u32 sh = sg.rem - sg.nbits, dm = (1u << sg.nbits) - 1;
+		lh[t] = 0; fill[t] = 0;
+		__syncthreads();
+		mm128 e[PER];
+		for (u32 k = 0; k < PER; ++k) {
+			const u32 i = i0 + t + k * LQ_PS_THREADS;
+			if (i < i1) { e[k] = src[i]; atomicAdd(&lh[(u32)(lq_ckey(e[k].x, km) >> sh) & dm], 1u); }
+		}
+		__syncthreads();
+		const u32 mine = lh[t];
+		lo[t] = mine;
+		if (mine) gb[t] = atomicAdd(&gcur[pl.cnt0 + t], mine);  // this tile's run inside bucket t
+		__syncthreads();
+		lq_scan256(lo, tmp, nullptr);
+		for (u32 k = 0; k < PER; ++k) {
+			const u32 i = i0 + t + k * LQ_PS_THREADS;
+			if (i < i1) { const u32 d = (u32)(lq_ckey(e[k].x, km) >> sh) & dm; stage[lo[d] + atomicAdd(&fill[d], 1u)] = e[k]; }
+		}
+		__syncthreads();
+		for (u32 p = t; p < i1 - i0; p += LQ_PS_THREADS) {       // run-contiguous writes
+			const mm128 a = stage[p];
+			const u32 d = (u32)(lq_ckey(a.x, km) >> sh) & dm;
+			dst[gb[d] + (p - lo[d])] = a;
+		}
+		__syncthreads();
+	}
+}
+
+// ---- finish: one block sorts a segment by all its remaining key bits in LDS and writes it to A ----------------
+template <int CAP, int THREADS>
+__global__ void __launch_bounds__(THREADS)
+k_ps_finish(const PSeg *segs, const u32 *n_p, mm128 *A, const mm128 *B, KeyMap km)
+{
+	__shared__ mm128 e[CAP];
+	__shared__ u16 perm[CAP];
+	__shared__ u32 hist[256], beg[256], fill[256], tmp[256];
+	const u32 n_seg = *n_p, t = threadIdx.x;
+	for (u32 s = blockIdx.x; s < n_seg; s += gridDim.x) {
+		const PSeg sg = segs[s];
+		const u32 n = sg.len;
+		const mm128 *src = (sg.buf ? B : A) + sg.off;
+		mm128 *out = A + sg.off;
+		if (sg.rem == 0 || n == 1) {                             // already in order: home to A
+			if (sg.buf) for (u32 i = t; i < n; i += THREADS) out[i] = src[i];
+			continue;
+		}
+		const u32 nb = sg.rem < 8 ? sg.rem : 8, sh = sg.rem - nb, dm = (1u << nb) - 1;
+		const u64 km_mask = sg.rem >= 64 ? ~0ULL : ((1ULL << sg.rem) - 1);
+		if (t < 256) { hist[t] = 0; fill[t] = 0; }
+		__syncthreads();
+		for (u32 i = t; i < n; i += THREADS) { const mm128 a = src[i]; e[i] = a; atomicAdd(&hist[(u32)(lq_ckey(a.x, km) >> sh) & dm], 1u); }
+		__syncthreads();
+		if (t < 256) beg[t] = hist[t];
+		__syncthreads();
+		lq_scan256(beg, tmp, nullptr);
+		for (u32 i = t; i < n; i += THREADS) { const u32 d = (u32)(lq_ckey(e[i].x, km) >> sh) & dm; perm[beg[d] + atomicAdd(&fill[d], 1u)] = (u16)i; }
+		__syncthreads();
+		for (u32 p = t; p < n; p += THREADS) {
+			const mm128 a = e[perm[p]];
+			const u64 key = lq_ckey(a.x, km) & km_mask;
+			const u32 d = (u32)(key >> sh), b0 = beg[d], b1 = b0 + hist[d];
+			u32 r = 0;
+			for (u32 j = b0; j < b1; ++j) r += (lq_ckey(e[perm[j]].x, km) & km_mask) < key;
+			out[b0 + r] = a;
+		}
+		__syncthreads();
+	}
+}
+
+// ---- the two entrances from the klib side -----------------------------------------------------------------
+// radix_sort_128x entry (ksort.h:130-134) for every query of the batch: arrays of <= 64 elements are insertion sorted;
+// a query with marked minimizers starts klib's passes at the top byte; every other query is free of equal x.
+__global__ void k_sort_init(const u64 *aq_off, u64 a_base, u32 n_q, const u32 *qdirty, mm128 *A, SortSeg *klib, u32 *cnt,
+                            PsLists L, KeyMap km, int all_klib)
+{
+	const u32 q = blockIdx.x * blockDim.x + threadIdx.x;
+	if (q >= n_q) return;
+	const u64 off = aq_off[q] - a_base, len = aq_off[q + 1] - aq_off[q];
+	if (len <= LQ_RS_MIN) { if (len > 1) lq_insertion_sort_x(A + off, (u32)len); return; }
+	if (qdirty[q] || all_klib) {
+		const u32 s = atomicAdd(&cnt[LQ_C_KLIB0], 1u);
+		SortSeg sg; sg.off = off; sg.len = (u32)len; sg.shift = 56;
+		klib[s] = sg;
+	} else {
+		PSeg sg; sg.off = off; sg.len = (u32)len; sg.rem = (u8)(km.pbits + km.rbits + 1); sg.buf = 0; sg.nbits = 0; sg.pad = 0;
+		lq_ps_route(sg, L, LQ_P_BIG0);
+	}
+}
+
+// one wave per 64 buckets of a finished klib pass: recurse, hand over, or finish (ksort.h:121-128).
+// Buckets of > 64 elements that received fewer than two marked anchors hold no equal x: they leave klib's passes for the
+// parallel sort above; the others become next-level sub-arrays.  Buckets of <= 64 elements are finished by klib's
+// insertion sort (ksort.h:87-97), which is stable, so its result is the unique stable order by x: the wave finishes them
+// cooperatively instead.  The 64 buckets of a wave are adjacent in memory; whole buckets are packed into chunks of <= 64
+// elements, one element per lane, and every lane ranks its element among the elements of its own bucket (ties by
+// original position) and stores it at that rank.
+#define LQ_CHILD_THREADS 64
+__global__ void __launch_bounds__(LQ_CHILD_THREADS)
+k_sort_children(const SortSeg *segs, const u32 *n_segs_p, mm128 *A, const u32 *hist, const u32 *mhist, const u32 *begs,
+                SortSeg *next, u32 *n_next, u32 const_levels, PsLists L, KeyMap km, int all_klib)
+{
+	__shared__ u64 xs[64];
+	__shared__ u32 flag[64];
+	const u32 n_segs = *n_segs_p;
+	const u32 lane = threadIdx.x;
+	for (u64 w = blockIdx.x; w < (u64)n_segs * 4; w += gridDim.x) {
+		const u64 t = w * 64 + lane;
+		const u32 sgi = (u32)(t >> 8);
+		const SortSeg sg = segs[sgi];
+		if (sg.shift == 0) continue;                            // (uniform: one sub-array per wave)
+		const u32 n = hist[t], bg = begs[t];
+		if (n > LQ_RS_MIN) {
+			if (mhist[t] < 2 && !all_klib) {
+				PSeg ch; ch.off = sg.off + bg; ch.len = n; ch.rem = (u8)lq_rem_below(sg.shift, km); ch.buf = 0; ch.nbits = 0; ch.pad = 0;
+				if (ch.rem) lq_ps_route(ch, L, LQ_P_BIG0);
+			} else {
+				const u32 s = atomicAdd(n_next, 1u);
+				// the next digit that can differ: levels whose byte is the same in every anchor of the part (bits of rid above the
+				// target count, bits of the position above the longest target) are identity passes in klib (one bucket holds the
+				// whole sub-array, which is recursed into unchanged: ksort.h:121-128) and are stepped over
+				u32 sh = sg.shift - 8;
+				while (sh > 0 && (const_levels >> (sh >> 3) & 1)) sh -= 8;
+				SortSeg c; c.off = sg.off + bg; c.len = n; c.shift = sh;
+				next[s] = c;
+			}
+		}
+		mm128 *seg = A + sg.off;
+		u64 todo = __ballot(n >= 2 && n <= LQ_RS_MIN);
+		while (todo) {                                            // uniform: one chunk of whole buckets per turn
+			const u32 f = (u32)__builtin_ctzll(todo);             // first bucket still to finish
+			const u32 base = __builtin_amdgcn_readlane(bg, f);
+			const u64 fit = __ballot(lane >= f && bg + n - base <= 64);   // bg + n grows with the lane: a run of lanes starting at f
+			const u32 e = 64 - (u32)__builtin_clzll(fit);
+			const u32 total = __builtin_amdgcn_readlane(bg + n, e - 1) - base;
+			const bool member = (fit >> lane) & 1;
+			flag[lane] = 0;
+			__syncthreads();
+			if (member && n) flag[bg - base] = 1;
+			__syncthreads();
+			const u64 M = __ballot(flag[lane] != 0);              // bit i: a bucket starts at element i of the chunk
+			const u32 i = lane;
+			const bool act = i < total;
+			const u32 lo = 63 - (u32)__builtin_clzll((M & (~0ULL >> (63 - i))) | 1ULL);
+			const u64 above = i == 63 ? 0 : (M >> (i + 1)) << (i + 1);
+			const u32 hi = above ? (u32)__builtin_ctzll(above) : total;
+			const u32 myn = act ? hi - lo : 0;
+			mm128 el; el.x = 0; el.y = 0;
+			if (act) { el = seg[base + i]; xs[i] = el.x; }
+			__syncthreads();
+			u32 rk = 0;
+			for (u32 jj = 0; jj < myn; ++jj) {
+				const u32 j = lo + jj;
+				const u64 xj = xs[j];
+				rk += j < i ? (xj <= el.x) : (xj < el.x);
+			}
+			__syncthreads();
+			if (myn > 1 && rk != i - lo) seg[base + lo + rk] = el;
+			todo &= ~fit;
+		}
+	}
+}

@@ -49,42 +49,30 @@ __device__ __forceinline__ void lq_insertion_sort_x(mm128 *a, u32 n)
 	}
 }
 
-// radix_sort_128x entry (ksort.h:130-134): arrays of <= 64 elements are insertion sorted
-__global__ void k_sort_init(const u64 *aq_off, u64 a_base, u32 n_q, mm128 *A, SortSeg *segs, u32 *n_segs)
+// one block per sub-array (strided over the device-side list): B <- A, D <- digit, hist[seg][*] = digit histogram,
+// mhist[seg][*] = how many anchors of each bucket carry LQ_TIE_MARK (both built in LDS, stored once)
+__global__ void k_sort_copy_hist(const SortSeg *segs, const u32 *n_segs_p, const mm128 *A, mm128 *B, u8 *D, u32 *hist, u32 *mhist)
 {
-	u32 q = blockIdx.x * blockDim.x + threadIdx.x;
-	if (q >= n_q) return;
-	u64 off = aq_off[q] - a_base, len = aq_off[q + 1] - aq_off[q];
-	if (len > LQ_RS_MIN) {
-		u32 s = atomicAdd(n_segs, 1u);
-		SortSeg sg; sg.off = off; sg.len = (u32)len; sg.shift = 56;
-		segs[s] = sg;
-	} else if (len > 1) lq_insertion_sort_x(A + off, (u32)len);
-}
-
-// one block per sub-array: B <- A, D <- digit, hist[seg][*] = digit histogram (built in LDS, stored once)
-__global__ void k_sort_copy_hist(const SortSeg *segs, u32 n_segs, const mm128 *A, mm128 *B, u8 *D, u32 *hist)
-{
-	LQ_SHARED u32 lh[256];
-	const u32 sgi = blockIdx.x;
-	if (sgi >= n_segs) return;
-	const SortSeg sg = segs[sgi];
-	const mm128 *a = A + sg.off;
-	mm128 *b = B + sg.off;
-	u8 *d = D + sg.off;
-	u32 *h = hist + (u64)sgi * 256;
-	LQ_BLOCK_LOOP(t) { for (u32 c = t; c < 256; c += blockDim.x) lh[c] = 0; }
-	LQ_BLOCK_SYNC();
-	LQ_BLOCK_LOOP(t) {
-		for (u32 i = t; i < sg.len; i += blockDim.x) {
+	__shared__ u32 lh[256], lm[256];
+	const u32 n_segs = *n_segs_p;
+	for (u32 sgi = blockIdx.x; sgi < n_segs; sgi += gridDim.x) {
+		const SortSeg sg = segs[sgi];
+		const mm128 *a = A + sg.off;
+		mm128 *b = B + sg.off;
+		u8 *d = D + sg.off;
+		for (u32 c = threadIdx.x; c < 256; c += blockDim.x) { lh[c] = 0; lm[c] = 0; }
+		__syncthreads();
+		for (u32 i = threadIdx.x; i < sg.len; i += blockDim.x) {
 			const mm128 e = a[i];
 			const u32 dg = (u32)(e.x >> sg.shift) & 0xff;
 			b[i] = e; d[i] = (u8)dg;
 			atomicAdd(&lh[dg], 1u);
+			if (e.y & LQ_TIE_MARK) atomicAdd(&lm[dg], 1u);
 		}
+		__syncthreads();
+		for (u32 c = threadIdx.x; c < 256; c += blockDim.x) { hist[(u64)sgi * 256 + c] = lh[c]; mhist[(u64)sgi * 256 + c] = lm[c]; }
+		__syncthreads();
 	}
-	LQ_BLOCK_SYNC();
-	LQ_BLOCK_LOOP(t) { for (u32 c = t; c < 256; c += blockDim.x) h[c] = lh[c]; }
 }
 
 // one thread per sub-array: bucket offsets and the kind of pass; lists of general / two-bucket sub-arrays
@@ -100,47 +88,49 @@ __device__ __forceinline__ u32 lq_walk_class(u32 len, const WalkCaps &w)
 // One wave per sub-array: bucket offsets (exclusive scan of the 256 counts, four per lane) and the kind of pass.
 #define LQ_CLASSIFY_THREADS 64
 __global__ void __launch_bounds__(LQ_CLASSIFY_THREADS)
-k_sort_classify(const SortSeg *segs, u32 n_segs, const u32 *hist, u32 *begs, SegInfo *info,
-                u32 *walk_list, u32 *two_list, u32 *counters, WalkCaps caps)
+k_sort_classify(const SortSeg *segs, const u32 *n_segs_p, u32 list_cap, const u32 *hist, u32 *begs, SegInfo *info,
+                u32 *walk_list, u32 *two_list, u32 *n_two, u32 *n_walk, WalkCaps caps)
 {
-	const u32 sgi = blockIdx.x;
-	if (sgi >= n_segs) return;
-	const u32 *cnt = hist + (u64)sgi * 256;
-	u32 *bg = begs + (u64)sgi * 256;
-	u32 nz = 0, c0 = 0, c1 = 0;
+	const u32 n_segs = *n_segs_p;
 	const u32 lane = threadIdx.x;
-	const uint4 v = *(const uint4*)(cnt + 4 * lane);
-	const u32 s1 = v.x, s2 = s1 + v.y, s3 = s2 + v.z, s4 = s3 + v.w;
-	u32 inc = s4;                                             // inclusive scan of the lane sums
-	for (int d = 1; d < 64; d <<= 1) { const u32 o = __shfl_up(inc, d); if ((int)lane >= d) inc += o; }
-	const u32 ex = inc - s4;
-	uint4 o4; o4.x = ex; o4.y = ex + s1; o4.z = ex + s2; o4.w = ex + s3;
-	*(uint4*)(bg + 4 * lane) = o4;
-	const u32 m4 = (v.x != 0) | (v.y != 0) << 1 | (v.z != 0) << 2 | (v.w != 0) << 3;
-	const u32 nzl = __popc(m4);
-	nz = __popcll(__ballot(nzl & 1)) + 2 * __popcll(__ballot(nzl & 2)) + 4 * __popcll(__ballot(nzl & 4));
-	const u64 any = __ballot(m4 != 0);
-	if (any) {
-		const u32 f = (u32)__builtin_ctzll(any);
-		const u32 mf = (u32)__builtin_amdgcn_readlane((int)m4, (int)f);
-		c0 = 4 * f + (u32)__builtin_ctz(mf);
-		const u32 rest = mf & (mf - 1);
-		if (rest) c1 = 4 * f + (u32)__builtin_ctz(rest);
-		else {
+	for (u32 sgi = blockIdx.x; sgi < n_segs; sgi += gridDim.x) {
+		const u32 *cnt = hist + (u64)sgi * 256;
+		u32 *bg = begs + (u64)sgi * 256;
+		u32 nz = 0, c0 = 0, c1 = 0;
+		const uint4 v = *(const uint4*)(cnt + 4 * lane);
+		const u32 s1 = v.x, s2 = s1 + v.y, s3 = s2 + v.z, s4 = s3 + v.w;
+		u32 inc = s4;                                             // inclusive scan of the lane sums
+		for (int d = 1; d < 64; d <<= 1) { const u32 o = __shfl_up(inc, d); if ((int)lane >= d) inc += o; }
+		const u32 ex = inc - s4;
+		uint4 o4; o4.x = ex; o4.y = ex + s1; o4.z = ex + s2; o4.w = ex + s3;
+		*(uint4*)(bg + 4 * lane) = o4;
+		const u32 m4 = (v.x != 0) | (v.y != 0) << 1 | (v.z != 0) << 2 | (v.w != 0) << 3;
+		const u32 nzl = __popc(m4);
+		nz = __popcll(__ballot(nzl & 1)) + 2 * __popcll(__ballot(nzl & 2)) + 4 * __popcll(__ballot(nzl & 4));
+		const u64 any = __ballot(m4 != 0);
+		if (any) {
+			const u32 f = (u32)__builtin_ctzll(any);
+			const u32 mf = (u32)__builtin_amdgcn_readlane((int)m4, (int)f);
+			c0 = 4 * f + (u32)__builtin_ctz(mf);
+			const u32 rest = mf & (mf - 1);
 			const u64 any2 = any & (any - 1);
-			if (any2) { const u32 g = (u32)__builtin_ctzll(any2); c1 = 4 * g + (u32)__builtin_ctz((u32)__builtin_amdgcn_readlane((int)m4, (int)g)); }
+			const u32 g = any2 ? (u32)__builtin_ctzll(any2) : 0;
+			const u32 mg = (u32)__builtin_amdgcn_readlane((int)m4, (int)g);
+			if (rest) c1 = 4 * f + (u32)__builtin_ctz(rest);
+			else if (any2) c1 = 4 * g + (u32)__builtin_ctz(mg);
+		}
+		if (lane == 0) {
+			SegInfo si; si.c0 = c0; si.c1 = c1; si.cnt0 = cnt[c0];
+			if (nz <= 1) si.kind = LQ_SEG_IDENTITY;                  // one bucket holds everything: the pass is the identity
+			else if (nz == 2) { si.kind = LQ_SEG_TWO; two_list[atomicAdd(n_two, 1u)] = sgi; }
+			else {
+				si.kind = LQ_SEG_GENERAL;
+				const u32 wc = lq_walk_class(segs[sgi].len, caps);
+				walk_list[(u64)wc * list_cap + atomicAdd(&n_walk[wc], 1u)] = sgi;
+			}
+			info[sgi] = si;
 		}
 	}
-	if (lane != 0) return;
-	SegInfo si; si.c0 = c0; si.c1 = c1; si.cnt0 = cnt[c0];
-	if (nz <= 1) si.kind = LQ_SEG_IDENTITY;                  // one bucket holds everything: the pass is the identity
-	else if (nz == 2) { si.kind = LQ_SEG_TWO; two_list[atomicAdd(&counters[0], 1u)] = sgi; }
-	else {
-		si.kind = LQ_SEG_GENERAL;
-		const u32 wc = lq_walk_class(segs[sgi].len, caps);
-		walk_list[(u64)wc * n_segs + atomicAdd(&counters[1 + wc], 1u)] = sgi;
-	}
-	info[sgi] = si;
 }
 
 // ---- two-bucket pass, closed form ------------------------------------------------------------
@@ -181,11 +171,11 @@ struct alignas(16) TwoW16 { u32 w[4]; };
 		} \
 		LQ_BLOCK_SYNC();
 __global__ void __launch_bounds__(LQ_TWO_THREADS)
-k_sort_two(const SortSeg *segs, const SegInfo *info, const u32 *two_list, u32 n_two, const u8 *D, u32 *HX, u32 *PY, u32 *dst)
+k_sort_two(const SortSeg *segs, const SegInfo *info, const u32 *two_list, const u32 *n_two_p, const u8 *D, u32 *HX, u32 *PY, u32 *dst)
 {
 	LQ_SHARED u32 cX[LQ_TWO_THREADS], cY[LQ_TWO_THREADS], gX[16], gY[16];
-	const u32 li = blockIdx.x;
-	if (li >= n_two) return;
+	const u32 n_two = *n_two_p;
+	for (u32 li = blockIdx.x; li < n_two; li += gridDim.x) {
 	const u32 sgi = two_list[li];
 	const SortSeg sg = segs[sgi];
 	const SegInfo si = info[sgi];
@@ -244,87 +234,23 @@ k_sort_two(const SortSeg *segs, const SegInfo *info, const u32 *two_list, u32 n_
 		for (u32 g16 = 0; g16 < 16; ++g16) { bx += gX[g16]; by += gY[g16]; }
 		LQ_BLOCK_SYNC();
 	}
-}
-
-__global__ void k_walk_keys(const SortSeg *segs, const u32 *walk_list, u32 n_walk, u32 *key)
-{
-	u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-	if (i < n_walk) key[i] = 0xffffffffu - segs[walk_list[i]].len;
-}
-
-// ---- general pass: the token walk over digit bytes ---------------------------------------------
-// Lane-per-sub-array form (used for sub-arrays too long for the LDS window below): 64 independent walks per
-// wave.  What bounds it is the latency of scattered memory operations inside the serial chain, so:
-//  * each bucket keeps, next to its cursor, the aligned 4-byte word of digits that contains the cursor position
-//    ([256][64] u32 each, lane-minor): the digit stream of a bucket is contiguous, hence only every fourth
-//    visit of a bucket touches global memory for its digit;
-//  * destinations are staged in LDS and written out every LQ_WALK_FLUSH trips by all lanes together: on gfx9
-//    stores share vmcnt with loads, so a store issued every trip would put its acknowledgement latency in
-//    front of every digit refill.
-#define LQ_WALK_LANES 64
-#define LQ_WALK_FLUSH 8
-__global__ void __launch_bounds__(LQ_WALK_LANES)
-k_sort_walk(const SortSeg *segs, const u32 *walk_list, u32 n_walk, const u8 *D, const u32 *hist, const u32 *begs, u32 *dst)
-{
-	LQ_SHARED u32 nxt[256][LQ_WALK_LANES];
-	LQ_SHARED u32 wrd[256][LQ_WALK_LANES];
-	LQ_SHARED u32 sq_src[LQ_WALK_FLUSH][LQ_WALK_LANES];
-	LQ_SHARED u32 sq_dst[LQ_WALK_FLUSH][LQ_WALK_LANES];
-	const u32 lane = threadIdx.x;
-	for (u64 wi = (u64)blockIdx.x * LQ_WALK_LANES + lane; wi < n_walk; wi += (u64)gridDim.x * LQ_WALK_LANES) {
-		const u32 sgi = walk_list[wi];
-		const SortSeg sg = segs[sgi];
-		const u32 *cnt = hist + (u64)sgi * 256, *bg = begs + (u64)sgi * 256;
-		const u64 base = sg.off;                              // D is 4-byte aligned; digits of this sub-array start at D[base]
-		for (int c = 0; c < 256; ++c) {
-			const u32 b = bg[c];
-			nxt[c][lane] = b;
-			wrd[c][lane] = *(const u32*)(D + ((base + b) & ~(u64)3));
-		}
-		u32 *ds = dst + sg.off;
-		// Flat form of the walk: every loop trip takes at most one element, so the 64 lanes of the wave (64
-		// different sub-arrays) advance in lockstep instead of waiting for each other's cycles to close.
-		u32 k = 0, endk = bg[0] + cnt[0], src = 0, l = 0, nq = 0, trip = 0;
-		bool carrying = false, alive = true;
-		while (alive) {
-			if (!carrying) {
-				while (k < 256 && nxt[k][lane] >= endk) { ++k; if (k < 256) endk = bg[k] + cnt[k]; }
-				if (k >= 256) alive = false;
-				else {
-					src = nxt[k][lane];                       // the hole this cycle leaves in bucket k
-					l = (wrd[k][lane] >> (8 * (u32)((base + src) & 3))) & 0xff;
-					carrying = true;
-				}
-			} else {
-				const u32 bl = l == k ? k : l;                // the bucket visited: l, or k itself when the cycle closes
-				const u32 t = nxt[bl][lane];                  // slot the carried element takes; its occupant is carried on
-				const u32 w = wrd[bl][lane];
-				sq_src[nq][lane] = src; sq_dst[nq][lane] = t; ++nq;
-				nxt[bl][lane] = t + 1;
-				if (l == k) carrying = false;                 // closed: the hole of bucket k is filled
-				else { src = t; l = (w >> (8 * (u32)((base + t) & 3))) & 0xff; }
-				if (((base + t + 1) & 3) == 0) wrd[bl][lane] = *(const u32*)(D + base + t + 1);   // next word of bl's digit stream
-			}
-			if (++trip == LQ_WALK_FLUSH || !alive) {          // same trip count in every lane of the wave: a uniform flush
-				for (u32 i = 0; i < nq; ++i) ds[sq_src[i][lane]] = sq_dst[i][lane];
-				nq = 0; trip = 0;
-			}
-		}
 	}
 }
 
+// ---- general pass: the token walk over digit bytes ---------------------------------------------
 // The same walk with the sub-array's digits staged in LDS: one block per sub-array; all threads load the
 // digit bytes, then one lane walks.  Each bucket keeps {cursor (24 bit), digit of the element under the cursor
 // (8 bit)} in a single LDS word, so the serial chain is one LDS round trip per element (~50 ns) instead of a
 // global-memory round trip (microseconds under load); the refill of the word is off the critical path.
 template <int CAP>
-__global__ void k_sort_walk_lds(const SortSeg *segs, const u32 *list, u32 n_list, const u8 *D, const u32 *hist, const u32 *begs, u32 *dst)
+__global__ void k_sort_walk_lds(const SortSeg *segs, const u32 *list, const u32 *n_list_p, const u8 *D, const u32 *hist, const u32 *begs, u32 *dst)
 {
 	LQ_SHARED u8 dig[CAP + 16];
 	LQ_SHARED u32 entry[256];
 	LQ_SHARED u32 endb[256];
-	if (blockIdx.x >= n_list) return;
-	const u32 sgi = list[blockIdx.x];
+	const u32 n_list = *n_list_p;
+	for (u32 li = blockIdx.x; li < n_list; li += gridDim.x) {
+	const u32 sgi = list[li];
 	const SortSeg sg = segs[sgi];
 	const u32 *cnt = hist + (u64)sgi * 256, *bg = begs + (u64)sgi * 256;
 	const u8 *d = D + sg.off;
@@ -368,6 +294,8 @@ __global__ void k_sort_walk_lds(const SortSeg *segs, const u32 *list, u32 n_list
 				carrying = false;
 			}
 		}
+	}
+	LQ_BLOCK_SYNC();
 	}
 }
 
@@ -423,13 +351,14 @@ __device__ __forceinline__ u64 lq_lds_u64(const u64 *p)
 #endif
 #define LQ_SOLO_PEND 0x80000000u
 __global__ void __launch_bounds__(64)
-k_sort_walk_solo(const SortSeg *segs, const u32 *list, u32 n_list, const u8 *D, const u32 *hist, const u32 *begs, u32 *dst)
+k_sort_walk_solo(const SortSeg *segs, const u32 *list, const u32 *n_list_p, const u8 *D, const u32 *hist, const u32 *begs, u32 *dst)
 {
 	LQ_SHARED __attribute__((aligned(16))) u8 win[256][16];   // DMA landing windows: 16 digits of each bucket's stream
 	LQ_SHARED u64 ent[256];                                   // low: cursor | PEND, high: the digits from the cursor to the next 4-byte boundary
 	LQ_SHARED u32 endb[256];
-	if (blockIdx.x >= n_list) return;
-	const u32 sgi = list[blockIdx.x];
+	const u32 n_list = *n_list_p;
+	for (u32 li = blockIdx.x; li < n_list; li += gridDim.x) {
+	const u32 sgi = list[li];
 	const SortSeg sg = segs[sgi];
 	const u32 *cnt = hist + (u64)sgi * 256, *bg = begs + (u64)sgi * 256;
 	const u64 base = sg.off;                                  // D is 16-byte aligned; this sub-array's digits start at D[base]
@@ -447,7 +376,7 @@ k_sort_walk_solo(const SortSeg *segs, const u32 *list, u32 n_list, const u8 *D, 
 		}
 	}
 	LQ_BLOCK_SYNC();
-	if (threadIdx.x != 0) return;
+	if (threadIdx.x == 0) {
 	// One step over bucket `bk` whose entry is (c, dq): the slot under the cursor is taken; store the entry for cursor c+1.
 #define LQ_SOLO_ADVANCE(bk, c, dq) do { \
 		const u32 nc_ = (c) + 1, o_ = (b15 + nc_) & 15; \
@@ -479,82 +408,21 @@ k_sort_walk_solo(const SortSeg *segs, const u32 *list, u32 n_list, const u8 *D, 
 	}
 #undef LQ_SOLO_ADVANCE
 	LQ_WAIT_VM0();
-}
-
-// one block per sub-array: A[dst[i]] = B[i]  (identity passes are skipped)
-__global__ void k_sort_scatter(const SortSeg *segs, const SegInfo *info, u32 n_segs, mm128 *A, const mm128 *B, const u32 *dst)
-{
-	u32 sgi = blockIdx.x;
-	if (sgi >= n_segs) return;
-	if (info[sgi].kind == LQ_SEG_IDENTITY) return;
-	const SortSeg sg = segs[sgi];
-	mm128 *a = A + sg.off;
-	const mm128 *b = B + sg.off;
-	const u32 *ds = dst + sg.off;
-	for (u32 i = threadIdx.x; i < sg.len; i += blockDim.x) a[ds[i]] = b[i];
-}
-
-// one thread per (sub-array, bucket): recurse or finish (ksort.h:121-128)
-// Buckets of <= 64 elements are finished by klib's insertion sort (ksort.h:87-97), which is stable, so its result is the
-// unique stable order by x: the wave finishes them cooperatively instead.  The 64 buckets of a wave are adjacent in
-// memory; whole buckets are packed into chunks of <= 64 elements, one element per lane, and every lane ranks its
-// element among the elements of its own bucket (ties by original position) and stores it at that rank.
-#define LQ_CHILD_THREADS 64
-__global__ void __launch_bounds__(LQ_CHILD_THREADS) k_sort_children(const SortSeg *segs, u32 n_segs, mm128 *A, const u32 *hist, const u32 *begs,
-                                SortSeg *next, u32 *n_next, u32 const_levels)
-{
-	u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-	if (t >= (u64)n_segs * 256) return;
-	u32 sgi = (u32)(t >> 8);
-	SortSeg sg = segs[sgi];
-	if (sg.shift == 0) return;
-	u32 n = hist[t], bg = begs[t];
-	if (n > LQ_RS_MIN) {
-		u32 s = atomicAdd(n_next, 1u);
-		// the next digit that can differ: levels whose byte is the same in every anchor of the part (bits of rid above the
-		// target count, bits of the position above the longest target) are identity passes in klib (one bucket holds the
-		// whole sub-array, which is recursed into unchanged: ksort.h:121-128) and are stepped over
-		u32 sh = sg.shift - 8;
-		while (sh > 0 && (const_levels >> (sh >> 3) & 1)) sh -= 8;
-		SortSeg c; c.off = sg.off + bg; c.len = n; c.shift = sh;
-		next[s] = c;
 	}
-	__shared__ u64 xs[64];
-	__shared__ u32 flag[64];
-	const u32 lane = threadIdx.x;
-	mm128 *seg = A + sg.off;
-	u64 todo = __ballot(n >= 2 && n <= LQ_RS_MIN);
-	while (todo) {                                            // uniform: one chunk of whole buckets per turn
-		const u32 f = (u32)__builtin_ctzll(todo);             // first bucket still to finish
-		const u32 base = __builtin_amdgcn_readlane(bg, f);
-		const u64 fit = __ballot(lane >= f && bg + n - base <= 64);   // bg + n grows with the lane: a run of lanes starting at f
-		const u32 e = 64 - (u32)__builtin_clzll(fit);
-		const u32 total = __builtin_amdgcn_readlane(bg + n, e - 1) - base;
-		const bool member = (fit >> lane) & 1;
-		flag[lane] = 0;
-		__syncthreads();
-		if (member && n) flag[bg - base] = 1;
-		__syncthreads();
-		const u64 M = __ballot(flag[lane] != 0);              // bit i: a bucket starts at element i of the chunk
-		const u32 i = lane;
-		const bool act = i < total;
-		const u32 lo = 63 - (u32)__builtin_clzll((M & (~0ULL >> (63 - i))) | 1ULL);
-		const u64 above = i == 63 ? 0 : (M >> (i + 1)) << (i + 1);
-		const u32 hi = above ? (u32)__builtin_ctzll(above) : total;
-		const u32 myn = act ? hi - lo : 0;
-		mm128 el; el.x = 0; el.y = 0;
-		if (act) { el = seg[base + i]; xs[i] = el.x; }
-		__syncthreads();
-		u32 cnt = 0;
-		for (u32 jj = 0; __ballot(jj < myn) != 0; ++jj) {
-			if (jj < myn) {
-				const u32 j = lo + jj;
-				const u64 xj = xs[j];
-				cnt += j < i ? (xj <= el.x) : (xj < el.x);
-			}
-		}
-		if (myn > 1 && cnt != i - lo) seg[base + lo + cnt] = el;
-		__syncthreads();
-		todo &= ~fit;
+	LQ_BLOCK_SYNC();
+	}
+}
+
+// one block per sub-array (strided): A[dst[i]] = B[i]  (identity passes are skipped)
+__global__ void k_sort_scatter(const SortSeg *segs, const SegInfo *info, const u32 *n_segs_p, mm128 *A, const mm128 *B, const u32 *dst)
+{
+	const u32 n_segs = *n_segs_p;
+	for (u32 sgi = blockIdx.x; sgi < n_segs; sgi += gridDim.x) {
+		if (info[sgi].kind == LQ_SEG_IDENTITY) continue;
+		const SortSeg sg = segs[sgi];
+		mm128 *a = A + sg.off;
+		const mm128 *b = B + sg.off;
+		const u32 *ds = dst + sg.off;
+		for (u32 i = threadIdx.x; i < sg.len; i += blockDim.x) a[ds[i]] = b[i];
 	}
 }

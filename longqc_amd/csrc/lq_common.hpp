@@ -24,6 +24,7 @@ typedef int64_t i64;
 
 #define LQ_COVT 150            // minimap2-coverage.h:20
 #define LQ_SEED_TANDEM (1ULL << 42)   // mmpriv.h:18
+#define LQ_TIE_MARK (1ULL << 63)      // y bit of anchors whose x may repeat inside their query (k_dup_mark); never read downstream
 #define LQ_RS_MIN 64           // ksort.h:81
 
 struct alignas(16) mm128 { u64 x, y; };        // minimap.h:42
