@@ -140,22 +140,49 @@ def main():
     total_bases = float(F.n_bases)
 
     eng = api.Engine(p, device=local)
-    eng.set_queries(Q.names, Q.seqs, Q.quals)
-    pt = eng.part_begin()
     anchors = [0]
+    if world == 1:
+        eng.set_queries(Q.names, Q.seqs, Q.quals)
+        pt = eng.part_begin()
 
-    def step(h2d=True):
-        eng.reset()
-        a = 0
+        def step(h2d=True):
+            eng.reset()
+            a = 0
+            for (lo, hi) in parts:
+                if h2d or len(parts) > 1:
+                    eng.part_clear(pt)
+                    eng.part_add_packed(pt, P, lo, hi)
+                eng.part_build(pt)
+                eng.part_map(pt)
+                a += eng.last_n_anchors
+            eng.finish()
+            anchors[0] = a
+    else:
+        # N GPUs, the north-star split (longqc_amd/multigpu.py): every rank sketches 1/N of each part, the minimizers are
+        # all-gathered over RCCL, every rank builds the same index and maps its 1/N of the queries; rows gathered on rank 0.
+        # The same job on N GPUs: strong scaling.
+        dev = torch.device("cuda", local) if have_cuda else torch.device("cpu")
+        runner = multigpu.QueryShardRunner(eng, world, rank, dev)
+        runner.set_queries(Q.names, Q.seqs, Q.quals)
+        pt = eng.part_begin()
+        names_all = F.names()
+        plan = []
         for (lo, hi) in parts:
-            if h2d or len(parts) > 1:
+            a, b = multigpu.balanced_ranges(lens[lo:hi], world)[rank]
+            plan.append((lo + a, lo + b, a, api.encode_names(names_all[lo:hi]), lens[lo:hi].astype(np.uint32)))
+        table = [None]
+
+        def step(h2d=True):
+            eng.reset()
+            a = 0
+            for (s0, s1, rid_base, nm, ln) in plan:
                 eng.part_clear(pt)
-                eng.part_add_packed(pt, P, lo, hi)
-            eng.part_build(pt)
-            eng.part_map(pt)
-            a += eng.last_n_anchors
-        eng.finish()
-        anchors[0] = a
+                if s1 > s0:
+                    eng.part_add_packed(pt, P, s0, s1)
+                runner.map_part(pt, rid_base, nm, ln)
+                a += eng.last_n_anchors
+            table[0] = runner.gather_table()
+            anchors[0] = a
 
     def barrier():
         if world > 1:
@@ -189,10 +216,20 @@ def main():
     st = [s for s in eng.stage_times() if s["name"] == dom_name]
     eng.set_profiling(0)
     n_anchors = anchors[0]
-    table = eng.table_text()
+    if world > 1:
+        ta = torch.tensor([float(n_anchors)], dtype=torch.float64, device="cuda" if have_cuda else "cpu")
+        dist.all_reduce(ta, op=dist.ReduceOp.SUM)
+        tm = torch.tensor([dt], dtype=torch.float64, device="cuda" if have_cuda else "cpu")
+        dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+        n_anchors = int(ta.item()); dt = float(tm.item())
+        ms_per_step = dt / max(args.steps, 1) * 1e3
+        value = total_bases / (ms_per_step / 1e3) / 1e6
+        table = table[0] or ""
+    else:
+        table = eng.table_text()
     # the same job with the reads already resident in HBM (single-part workloads only: a multi-part job re-uses the part's buffers)
     resident = None
-    if len(parts) == 1:
+    if len(parts) == 1 and world == 1:
         dt_r = timed(max(1, args.steps), h2d=False)
         resident = total_bases / (dt_r / max(1, args.steps)) / 1e6
 
@@ -230,12 +267,13 @@ def main():
         line = {
             "metric": "Mbases/sec all-vs-all overlap coverage (sampleqc hot path)", "value": round(value, 3), "unit": "Mbases/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak" if world == 1 else "strong", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "config": {"workload": (CONFIG_LABEL[args.config] % (cfg.n_reads, cfg.mean_len // 1000, cfg.depth)) + ", %d subsample queries" % len(Q),
                        "index_parts": [int(F.off[hi] - F.off[lo]) for lo, hi in parts],
                        "target_bases": int(total_bases), "query_bases": int(Q.n_bases), "anchors_per_step": int(n_anchors),
                        "clock": "H2D of the packed reads (pinned) -> sketch -> index -> seed -> sort -> chain -> coverage -> rows D2H, all parts (SURVEY 8d)",
-                       "parallelism": "single GPU"},
+                       "parallelism": "single GPU" if world == 1 else "%d GPUs: queries sharded 1/N, index replicated (each rank sketches 1/N of a part, "
+                                      "minimizers all-gathered over RCCL, identical index everywhere), rows gathered on rank 0" % world},
             "roofline": roof,
             "host_pack_s": round(t_pack, 3), "synth_gen_s": round(t_gen, 2),
             "hbm_resident_value": round(resident, 3) if resident else None,

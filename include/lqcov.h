@@ -185,6 +185,9 @@ int lqcov_get_chains(lqcov_handle *h, int32_t *out, uint64_t cap, uint64_t *n_to
 /* ---- multi-GPU plumbing (device pointers; torch.distributed/RCCL moves the bytes) ----------- */
 /* minimizers of a built part as two device arrays (x = hash<<8|span, y = rid<<32|pos<<1|strand) */
 int lqcov_part_minimizers_dev(lqcov_handle *h, int part, const uint64_t **x_dev, const uint64_t **y_dev, uint64_t *n);
+/* the same into caller-owned device buffers of `cap` entries each (e.g. the send buffers of an all-gather), with rid_base
+ * added to every rid: the part-global index of this rank's first read */
+int lqcov_part_minimizers_export_dev(lqcov_handle *h, int part, uint64_t *x_dev, uint64_t *y_dev, uint64_t cap, uint32_t rid_base);
 /* sketch only (no index): step 1 of mm_idx_gen (index.c:291-302) on this rank's share of the part */
 int lqcov_part_sketch(lqcov_handle *h, int part);
 /* replace the part's minimizer set by caller-provided device arrays (rank-concatenated, y-sorted),

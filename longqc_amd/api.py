@@ -112,6 +112,7 @@ def load_library(path: Optional[str] = None):
         "lqcov_get_part_minimizers": (C.c_int, [H, C.c_int, C.c_void_p, C.c_void_p, u64p]),
         "lqcov_get_chains": (C.c_int, [H, C.c_void_p, C.c_uint64, u64p]),
         "lqcov_part_minimizers_dev": (C.c_int, [H, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), u64p]),
+        "lqcov_part_minimizers_export_dev": (C.c_int, [H, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32]),
         "lqcov_set_distributed": (C.c_int, [H, C.c_int]),
         "lqcov_set_mid_occ": (C.c_int, [H, C.c_int32]),
         "lqcov_accum_sizes": (C.c_int, [H, C.POINTER(C.c_uint32), u64p, C.POINTER(C.c_uint32)]),
@@ -175,6 +176,11 @@ def _names(names: Sequence[str]) -> Tuple[bytes, np.ndarray]:
         pos += len(b)
         off[i + 1] = pos
     return b"".join(parts), off
+
+
+def encode_names(names: Sequence[str]):
+    """names as the C ABI takes them (NUL-terminated blob + offsets): encode once when the same list is passed repeatedly"""
+    return _names(names)
 
 
 class PackedReads:
@@ -432,7 +438,10 @@ class Engine:
         self._ck(self.lib.lqcov_part_minimizers_dev(self.h, part, C.byref(x), C.byref(y), C.byref(n)))
         return x.value or 0, y.value or 0, n.value
 
+    def part_minimizers_export(self, part: int, x_ptr: int, y_ptr: int, cap: int, rid_base: int):
+        self._ck(self.lib.lqcov_part_minimizers_export_dev(self.h, part, x_ptr, y_ptr, cap, rid_base))
+
     def part_build_from_minimizers_dev(self, part: int, x_ptr: int, y_ptr: int, n: int, target_len: np.ndarray, names: Sequence[str]):
         tl = np.ascontiguousarray(target_len, dtype=np.uint32)
-        nb, noff = _names(names)
+        nb, noff = names if isinstance(names, tuple) else _names(names)      # (blob, offsets) from encode_names() skips the encoding
         self._ck(self.lib.lqcov_part_build_from_minimizers_dev(self.h, part, x_ptr, y_ptr, n, len(tl), tl.ctypes.data, nb, noff.ctypes.data))

@@ -373,6 +373,17 @@ int lqcov_part_minimizers_dev(lqcov_handle *h, int part, const uint64_t **x_dev,
 	});
 }
 
+// this rank's minimizers into caller-owned device buffers, rid moved up by rid_base (the part-global index of the rank's first read)
+int lqcov_part_minimizers_export_dev(lqcov_handle *h, int part, uint64_t *x_dev, uint64_t *y_dev, uint64_t cap, uint32_t rid_base)
+{
+	return guard(h, [&] {
+		Part &pt = h->part(part);
+		if (!pt.rs.sketched) throw std::logic_error("part not sketched");
+		if (cap < pt.rs.n_mini) throw std::invalid_argument("minimizer buffers too small");
+		h->export_minimizers(pt.rs, x_dev, y_dev, rid_base);
+	});
+}
+
 int lqcov_part_sketch(lqcov_handle *h, int part)
 {
 	return guard(h, [&] { if (!h->have_queries) throw std::logic_error("set the queries first"); h->sketch(h->part(part).rs, true); });

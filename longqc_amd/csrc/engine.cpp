@@ -292,6 +292,15 @@ void lqcov_handle::sketch(ReadSetDev &rs, bool rid_in_y)
 	rs.sketched = true;
 }
 
+void lqcov_handle::export_minimizers(ReadSetDev &rs, u64 *x_dev, u64 *y_dev, u32 rid_base)
+{
+	const u64 n = rs.n_mini;
+	if (!n) return;
+	LQ_HIP_CHECK(hipMemcpyAsync(x_dev, rs.mx.p, n * 8, hipMemcpyDeviceToDevice, stream));
+	LQ_LAUNCH(k_rebase_y, nblk(n, 256), 256, stream, rs.my.as<u64>(), n, (u64)rid_base << 32, y_dev); check_launch();
+	LQ_HIP_CHECK(hipStreamSynchronize(stream));
+}
+
 // meanQ's table (lqutils.c:26-49): 127 15-decimal literals for 10^(-q/10), Q0..Q126.  They are 10^(-q/10)
 // rounded to 15 decimals, except that eight entries (Q34, 39, 58, 62, 67, 71, 72, 82) are one unit of the
 // 15th decimal higher in the reference; rebuilt here from that description.

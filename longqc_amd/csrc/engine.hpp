@@ -130,6 +130,7 @@ struct lqcov_handle {
 	void add_reads(ReadSetDev &rs, u32 n, const u8 *seq, const u64 *seq_off, const char *names, const u64 *name_off);
 	void add_reads_packed(ReadSetDev &rs, u32 n, const u64 *codes, const u32 *amb, const u32 *lens, const char *names, const u64 *name_off);
 	void sketch(ReadSetDev &rs, bool rid_in_y);
+	void export_minimizers(ReadSetDev &rs, u64 *x_dev, u64 *y_dev, u32 rid_base);
 	void set_queries(u32 n, const u8 *seq, const u64 *seq_off, const u8 *qual, const char *names, const u64 *name_off);
 	void build_index(Part &pt);
 	void build_part(Part &pt);

@@ -27,6 +27,13 @@ __global__ void k_sort_keys(const u64 *x, u64 n, u64 *key)
 	if (i < n) key[i] = x[i] >> 8;
 }
 
+// y of a rank's share of a part, rid made part-global (multi-GPU: ranks sketch contiguous read ranges)
+__global__ void k_rebase_y(const u64 *y, u64 n, u64 add, u64 *out)
+{
+	u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) out[i] = y[i] + add;
+}
+
 __global__ void k_mark_heads(const u64 *key, u64 n, u32 *head)
 {
 	u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;

@@ -1,4 +1,13 @@
-"""Index parts across GPUs: one process per GPU, `torch.distributed` (backend "nccl" == RCCL over xGMI on
+"""Two exact ways to put the path on N GPUs, one process per GPU, `torch.distributed` for the exchange:
+
+1. QueryShardRunner (the default of bench.py --gpus N; BASELINE.json's north star): queries are split across the ranks,
+   the index of every part is replicated.  Per part, rank r sketches a contiguous 1/N of the part's reads, the ranks
+   all-gather the minimizer arrays (RCCL over xGMI: the only data-path collective), every rank builds the same index --
+   hence the same mid_occ -- and maps its own queries; after the last part rank 0 gathers the rows.  Exact because every
+   query owns its accumulators (minimap2-coverage.c:434, lqmap.c:788): nothing else crosses queries.
+2. PartRunner: index parts across GPUs (below), for inputs of at least N parts.
+
+Index parts across GPUs: one process per GPU, `torch.distributed` (backend "nccl" == RCCL over xGMI on
 the GPU box, "gloo" in CPU tests) moves the per-part accumulators; every byte of compute stays in the HIP
 engine behind the C ABI.
 
@@ -188,3 +197,93 @@ class PartRunner:
         self._ivl_keep = ivl if ivl.shape[0] else torch.zeros((1, 3), dtype=torch.int32, device=self.dev)
         self.eng.accum_import(self.lam.data_ptr(), self.lam2.data_ptr(), self.avgk.data_ptr(), self.flags.data_ptr(),
                               self.cnts.data_ptr(), self._ivl_keep.data_ptr(), int(ivl.shape[0]))
+
+
+# ---- queries sharded, index replicated (the north-star split) --------------------------------------------------
+def balanced_ranges(lengths, world: int) -> List[tuple]:
+    """world contiguous index ranges of about equal base totals (the ranks' shares of a part's reads)"""
+    lens = np.asarray(lengths, dtype=np.int64)
+    cum = np.concatenate([[0], np.cumsum(lens)])
+    total = int(cum[-1])
+    cuts = [0]
+    for r in range(1, world):
+        cuts.append(int(np.searchsorted(cum, total * r // world, side="left")))
+    cuts.append(len(lens))
+    for i in range(1, len(cuts)):
+        cuts[i] = max(cuts[i], cuts[i - 1])
+    return [(cuts[r], cuts[r + 1]) for r in range(world)]
+
+
+def shard_queries(lengths, world: int) -> List[List[int]]:
+    """query indices per rank: longest first, each to the rank with the fewest bases so far (anchors, and with them the
+    mapping time, grow with the query's length); every rank's list ascending"""
+    order = sorted(range(len(lengths)), key=lambda i: (-int(lengths[i]), i))
+    load = [0] * world
+    out: List[List[int]] = [[] for _ in range(world)]
+    for i in order:
+        r = min(range(world), key=lambda k: (load[k], k))
+        out[r].append(i); load[r] += int(lengths[i])
+    return [sorted(v) for v in out]
+
+
+class QueryShardRunner:
+    """One engine handle per rank holding this rank's queries; map_part() replicates the index of one part and maps them."""
+
+    def __init__(self, eng, world: int, rank: int, device: torch.device, group=None):
+        self.eng, self.world, self.rank, self.dev, self.group = eng, world, rank, device, group
+        self.my_queries: List[int] = []
+        self.n_queries = 0
+
+    def set_queries(self, names, seqs, quals=None):
+        """every rank passes the whole query set; the handle receives this rank's share"""
+        self.n_queries = len(names)
+        self.my_queries = shard_queries([int(s.shape[0]) for s in seqs], self.world)[self.rank]
+        self.eng.set_queries([names[i] for i in self.my_queries], [seqs[i] for i in self.my_queries],
+                             [quals[i] for i in self.my_queries] if quals is not None else None)
+
+    def map_part(self, part: int, rid_base: int, all_names, all_lens):
+        """`part` holds this rank's contiguous share of the index part's reads (reads [rid_base, ...) of the part, possibly
+        none); all_names / all_lens describe every read of the part in order.  Sketch the share, all-gather the minimizers,
+        build the replicated index, map this rank's queries.  The part can be cleared / released afterwards."""
+        eng, dev, world = self.eng, self.dev, self.world
+        eng.part_sketch(part)
+        n_mine = eng.part_n_minimizers(part)
+        if world > 1:
+            sizes = _all_gather(torch.tensor([n_mine], dtype=torch.int64, device=dev), world, self.group)
+            sizes = [int(t.item()) for t in sizes]
+        else:
+            sizes = [n_mine]
+        cap = max(max(sizes), 1)
+        xs = torch.zeros(cap, dtype=torch.int64, device=dev); ys = torch.zeros(cap, dtype=torch.int64, device=dev)
+        eng.part_minimizers_export(part, xs.data_ptr(), ys.data_ptr(), cap, rid_base)
+        if world > 1:
+            gx = _all_gather(xs, world, self.group); gy = _all_gather(ys, world, self.group)   # RCCL all-gather over xGMI
+            x = torch.cat([g[:n] for g, n in zip(gx, sizes)]).contiguous(); y = torch.cat([g[:n] for g, n in zip(gy, sizes)]).contiguous()
+            del gx, gy
+        else:
+            x, y = xs[:n_mine].contiguous(), ys[:n_mine].contiguous()
+        del xs, ys
+        n = int(x.shape[0])
+        if n == 0:
+            x = torch.zeros(1, dtype=torch.int64, device=dev); y = torch.zeros(1, dtype=torch.int64, device=dev)
+        eng.part_clear(part)                                      # the share's reads are no longer needed: the part becomes the whole index part
+        eng.part_build_from_minimizers_dev(part, x.data_ptr(), y.data_ptr(), n, np.asarray(all_lens, dtype=np.uint32), all_names)
+        del x, y
+        eng.part_map(part)
+
+    def gather_table(self) -> Optional[str]:
+        """finish on every rank; rank 0 returns the table of all queries in the caller's order, the others None"""
+        self.eng.finish()
+        lines = self.eng.table_text().splitlines(keepends=True)
+        assert len(lines) == len(self.my_queries)
+        if self.world == 1:
+            return "".join(lines)
+        got = [None] * self.world if self.rank == 0 else None
+        dist.gather_object((self.my_queries, lines), got, dst=0, group=self.group)
+        if self.rank != 0:
+            return None
+        out = [None] * self.n_queries
+        for idx, ls in got:
+            for i, l in zip(idx, ls):
+                out[i] = l
+        return "".join(out)

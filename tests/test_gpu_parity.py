@@ -168,6 +168,17 @@ def test_gpu_two_ranks_share_the_device_exchange_accumulators(gpu_lib, tmp_path)
     assert open(out).read() == read_gz("adv_parts.table.gz")
 
 
+@pytest.mark.parametrize("I,expect", [(100000, "adv_parts.table.gz"), (4000000000, "adv_ont.table.gz")])
+def test_gpu_two_ranks_share_the_device_query_sharded_replicated_index(gpu_lib, tmp_path, I, expect):
+    """the north-star split with real device pointers: two ranks (gloo, both on cuda:0) each sketch half of every part,
+    all-gather the minimizers, build the same index and map half of the queries; rank 0 gathers the rows"""
+    import torch.multiprocessing as mp
+    import tests.test_multigpu_cpu as M
+    out = str(tmp_path / "t.tsv")
+    mp.spawn(M._worker_qshard, args=(2, M._free_port(), I, out, True), nprocs=2, join=True)
+    assert open(out).read() == read_gz(expect)
+
+
 def test_gpu_in_memory_sampleqc_path(gpu_lib):
     """longqc_amd.sampleqc.coverage_in_memory: subsample handed over in memory, input streamed in chunks, parts cut
     by the reference's rule -- same table as the file-based reference run"""

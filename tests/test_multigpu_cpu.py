@@ -87,3 +87,51 @@ def test_two_ranks_gloo_equal_reference_multipart_table(emu_lib, tmp_path, world
     out = str(tmp_path / "t.tsv")
     mp.spawn(_worker, args=(world, _free_port(), 100000, out), nprocs=world, join=True)
     assert open(out).read() == read_gz("adv_parts.table.gz")
+
+
+# ---- queries sharded, index replicated (BASELINE.json's north star) ----
+def _worker_qshard(rank, world, port, argv_I, out_path, use_gpu=False):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        lib = api.load_library() if use_gpu else api.load_library(os.path.join(ROOT, "tests", "emu", "liblqcov_emu.so"))
+        tn, ts, _ = read_fastx(os.path.join(GOLDEN, "adv_all.fa.gz"))
+        qn, qs, qq = read_fastx(os.path.join(GOLDEN, "adv_sub.fq.gz"))
+        p = api.Params(); lib.lqcov_params_default(p)
+        p.no_self = 1; p.min_ovlp = 0; p.min_score_med = 160; p.min_score_good = 160; p.batch_size = argv_I
+        eng = api.Engine(p, 0, lib=lib)
+        runner = multigpu.QueryShardRunner(eng, world, rank, torch.device("cuda", 0) if use_gpu else torch.device("cpu"))
+        runner.set_queries(qn, qs, qq)
+        lens = [int(s.shape[0]) for s in ts]
+        pid = eng.part_begin()
+        for (s, e) in multigpu.split_parts(lens, argv_I):
+            lo, hi = multigpu.balanced_ranges(lens[s:e], world)[rank]
+            eng.part_clear(pid)
+            if hi > lo:
+                eng.part_add_targets(pid, tn[s + lo:s + hi], ts[s + lo:s + hi])
+            runner.map_part(pid, lo, tn[s:e], lens[s:e])
+        table = runner.gather_table()
+        if rank == 0:
+            open(out_path, "w").write(table)
+        eng.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,I,expect", [(2, 100000, "adv_parts.table.gz"), (3, 100000, "adv_parts.table.gz"), (2, 4000000000, "adv_ont.table.gz")])
+def test_query_sharded_replicated_index_equals_reference_table(emu_lib, tmp_path, world, I, expect):
+    """the north-star split: every rank sketches a share of each part, the minimizers are all-gathered, every rank builds the
+    same index and maps its share of the queries; rows gathered on rank 0.  10 parts with the COVT cap, and one part."""
+    out = str(tmp_path / "t.tsv")
+    mp.spawn(_worker_qshard, args=(world, _free_port(), I, out), nprocs=world, join=True)
+    assert open(out).read() == read_gz(expect)
+
+
+def test_balanced_ranges_and_query_shards():
+    lens = [5, 1, 1, 1, 8, 2, 2]
+    r = multigpu.balanced_ranges(lens, 3)
+    assert r[0][0] == 0 and r[-1][1] == len(lens) and all(a[1] == b[0] for a, b in zip(r, r[1:]))
+    sh = multigpu.shard_queries(lens, 2)
+    assert sorted(sum(sh, [])) == list(range(len(lens)))
+    assert abs(sum(lens[i] for i in sh[0]) - sum(lens[i] for i in sh[1])) <= 2
+    assert multigpu.balanced_ranges([3, 3], 4)[-1][1] == 2            # more ranks than reads: empty shares
