@@ -757,15 +757,65 @@ void lqcov_handle::sort_batch(MapLane &L, Part &pt, u32 q0, u32 nqb, u64 a_base,
 					        hc[LQ_C_WALK0], hc[LQ_C_WALK1], hc[LQ_C_WALK2], hc[LQ_C_WALK3], hc[LQ_C_WALK4], (unsigned long long)nA);
 					fflush(stderr);
 				}
+				// Passes with few buckets over long sub-arrays (the byte of rid above 65536 targets: the (query, strand) arrays of
+				// the longest queries, millions of anchors each): the walk's state at evenly spread checkpoints is computed
+				// without walking (kernels_ckpt.hpp) and one walker per checkpoint runs a short piece.
+				int first_plain_class = LQ_WALK_CLASSES - 1;
+				if (reg_walker && max_digit < LQ_CK_B && !(getenv("LQCOV_CKPT") && !strcmp(getenv("LQCOV_CKPT"), "0")) && ns <= (1u << 20)) {
+					u32 hc[LQ_C_N]; d2h(hc, cnt, LQ_C_N, sD);
+					const u32 n3 = hc[LQ_C_WALK3], n4 = hc[LQ_C_WALK4];
+					if (n3 + n4) {
+						std::vector<u32> ids(n3 + n4);
+						if (n3) d2h(ids.data(), wl + (u64)3 * ns, n3, sD);
+						if (n4) d2h(ids.data() + n3, wl + (u64)4 * ns, n4, sD);
+						std::vector<SortSeg> hs(ns);
+						d2h(hs.data(), cur, ns, sD);
+						const u32 unit = std::max<u32>(16384u >> (getenv("LQCOV_WALK_SHIFT") ? atoi(getenv("LQCOV_WALK_SHIFT")) : 0), 8);
+						std::vector<CkSeg> hck(ids.size());
+						u64 tiles = 0, cks_total = 0;
+						for (size_t i = 0; i < ids.size(); ++i) {
+							const u32 len = hs[ids[i]].len;
+							CkSeg c; c.sgi = ids[i]; c.tile0 = (u32)tiles; c.ck0 = (u32)cks_total;
+							c.n_ck = std::min<u32>(512, std::max<u32>(2, len / unit));
+							hck[i] = c;
+							tiles += len / LQ_CK_TILE + 1; cks_total += c.n_ck;
+						}
+						if (tiles < 0xfffffff0ULL && cks_total < 0xfffffff0ULL) {
+							const u32 n_cks = (u32)hck.size(), n_tiles = (u32)tiles, n_ck = (u32)cks_total;
+							L.ck_segs.ensure(hck.size() * sizeof(CkSeg)); L.ck_T.ensure(tiles * LQ_CK_B * 4); L.ck_E.ensure((u64)n_cks * LQ_CK_B * LQ_CK_B * 4);
+							L.ck_S.ensure(cks_total * LQ_CK_B * 4); L.ck_slot.ensure(cks_total * 4 + 4); L.ck_n.ensure(4);
+							h2d(L.ck_segs.as<CkSeg>(), hck.data(), hck.size(), sD);
+							h2d(L.ck_n.as<u32>(), &n_ck, 1, sD);
+							LQ_HIP_CHECK(hipStreamSynchronize(sD));              // (the host vectors die with this scope)
+							const CkSeg *dck = L.ck_segs.as<CkSeg>();
+							if (!gated && !L.gate_passed) { L.gate_passed = true; open_gate(); gated = true; }
+							{
+								StageTimer t(this, sD, "k_ck_prefix", nA);
+								LQ_LAUNCH(k_ck_tilehist, std::min<u32>(n_tiles, 1u << 16), 256, sD, dck, n_cks, n_tiles, cur, dD, L.ck_T.as<u32>()); check_launch();
+								LQ_LAUNCH(k_ck_tilescan, std::min<u32>(n_cks, 8192), 256, sD, dck, n_cks, cur, L.ck_T.as<u32>()); check_launch();
+							}
+							{
+								StageTimer t(this, sD, "k_ck_solve");
+								LQ_LAUNCH(k_ck_phases, std::min<u32>(n_cks, 1u << 16), 64, sD, dck, n_cks, cur, dD, dH, dBg, L.ck_T.as<u32>(), L.ck_E.as<u32>()); check_launch();
+								LQ_LAUNCH(k_ck_solve, std::min<u32>(n_ck, 1u << 18), 64, sD, dck, n_cks, n_ck, cur, dD, dH, dBg, L.ck_T.as<u32>(), L.ck_E.as<u32>(), L.ck_S.as<u32>(), L.ck_slot.as<u32>()); check_launch();
+							}
+							{
+								StageTimer t(this, sD, "k_sort_walk_reg<1>ck", nA * 5);
+								LQ_LAUNCH((k_sort_walk_reg<1>), std::min<u32>(n_ck, 1u << 18), 64, sD, cur, (const u32*)nullptr, L.ck_n.as<u32>(), dD, dH, dBg, dDst, dck, n_cks, L.ck_S.as<u32>(), L.ck_slot.as<u32>()); check_launch();
+							}
+							first_plain_class = 2;
+						}
+					}
+				}
 				// long walks first: they outlast everything else of the level on a handful of CUs
-				for (int c = LQ_WALK_CLASSES - 1; c >= 2; --c) {
+				for (int c = first_plain_class; c >= 2; --c) {
 					if (!gated && !L.gate_passed) { L.gate_passed = true; open_gate(); gated = true; }   // let the next lane start under these walks
 					const u32 g = std::min<u32>(ns, 8192);
-					if (reg_walker && max_digit < 64) { StageTimer t(this, sD, "k_sort_walk_reg<1>", nA * 5); LQ_LAUNCH((k_sort_walk_reg<1>), g, 64, sD, cur, wl + (u64)c * ns, cnt + LQ_C_WALK0 + c, dD, dH, dBg, dDst); }
-					else if (reg_walker && max_digit < 128) { StageTimer t(this, sD, "k_sort_walk_reg<2>", nA * 5); LQ_LAUNCH((k_sort_walk_reg<2>), g, 64, sD, cur, wl + (u64)c * ns, cnt + LQ_C_WALK0 + c, dD, dH, dBg, dDst); }
+					const CkSeg *nock = nullptr;
+					if (reg_walker && max_digit < 64) { StageTimer t(this, sD, "k_sort_walk_reg<1>", nA * 5); LQ_LAUNCH((k_sort_walk_reg<1>), g, 64, sD, cur, wl + (u64)c * ns, cnt + LQ_C_WALK0 + c, dD, dH, dBg, dDst, nock, 0u, (const u32*)nullptr, (const u32*)nullptr); }
+					else if (reg_walker && max_digit < 128) { StageTimer t(this, sD, "k_sort_walk_reg<2>", nA * 5); LQ_LAUNCH((k_sort_walk_reg<2>), g, 64, sD, cur, wl + (u64)c * ns, cnt + LQ_C_WALK0 + c, dD, dH, dBg, dDst, nock, 0u, (const u32*)nullptr, (const u32*)nullptr); }
 					else { StageTimer t(this, sD, "k_sort_walk_solo", nA * 5); LQ_LAUNCH(k_sort_walk_solo, g, 64, sD, cur, wl + (u64)c * ns, cnt + LQ_C_WALK0 + c, dD, dH, dBg, dDst); }
 					check_launch();
-					if (getenv("LQCOV_DEBUG_SORT")) { LQ_HIP_CHECK(hipStreamSynchronize(sD)); fprintf(stderr, "[sort] level %d class %d done\n", level, c); fflush(stderr); }
 				}
 				{ StageTimer t(this, sD, "k_sort_walk_lds<16384>"); LQ_LAUNCH((k_sort_walk_lds<16384>), std::min<u32>(ns, 8192), 64, sD, cur, wl + (u64)1 * ns, cnt + LQ_C_WALK1, dD, dH, dBg, dDst); check_launch(); }
 				{ StageTimer t(this, sD, "k_sort_walk_lds<4096>"); LQ_LAUNCH((k_sort_walk_lds<4096>), std::min<u32>(ns, 1u << 16), 64, sD, cur, wl + (u64)0 * ns, cnt + LQ_C_WALK0, dD, dH, dBg, dDst); check_launch(); }

@@ -58,6 +58,7 @@ struct MapLane {
 	hipStream_t stream2 = nullptr;        // the parallel sort of every other query, meanwhile
 	hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 	DBuf sort_cnt, mhist;
+	DBuf ck_segs, ck_T, ck_E, ck_S, ck_slot, ck_n;   // checkpointed walks (kernels_ckpt.hpp)
 	PsWork ps[2];
 	Prim prim;
 	bool gate_passed = false;             // this batch has reached its long walks (see map_part)

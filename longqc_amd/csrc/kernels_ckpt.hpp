@@ -1,0 +1,195 @@
+// longqc_amd/csrc/kernels_ckpt.hpp -- cutting one long klib token walk into segments that run side by side.
+//
+// A general pass of klib's radix sort (ksort.h:99-129) over one sub-array is a serial token walk (kernels_sort.hpp,
+// kernels_walk.hpp), ~120 ns per element: the (query, strand) sub-arrays of the longest queries hold millions of anchors
+// and their top pass alone would take most of a second.  The walk cannot be split by looking at the elements -- but its
+// state at chosen moments can be computed without walking:
+//
+//   The outer loop of the pass fills the slots in ascending order; consider the moment it is about to look at slot s of
+//   bucket k (buckets < k full, the token at rest).  Let A_c be the cursor of bucket c then.  Exactly the first
+//   A_c - beg_c elements of every region R_c have been picked up, and every picked-up element sits in its bucket, so
+//       A_c - beg_c = #{picked-up elements with digit c} = sum over regions l of n_{l,c}(A_l - beg_l)   for c > k,
+//   with A_c = end_c for c < k and A_k = s, where n_{l,c}(m) counts digit c among the first m elements of R_l.  The
+//   right-hand side is monotone in A.  The walk's own state solves the system, and the walk can never get ahead of ANY
+//   solution A' that lies above an earlier state of it: look at the first moment a cursor would pass A'_c -- the element
+//   arriving at c was picked up from the first A'_l - beg_l elements of some R_l and has digit c, and A'_c already counts
+//   all of those.  Hence the state is the LEAST solution above the state at the end of the previous phase (bucket k-1
+//   full), and monotone iteration from there (A <- max(A, F(A))) finds it: no walking, only prefix counts of digits
+//   (per-tile histograms, scanned) and a few dozen rounds -- the increments shrink by about (B-1)/B per round, so this is
+//   for passes with few buckets (B <= 16: the byte of rid above 65536 targets), which is where the giant walks are.
+//
+// So: k_ck_tilehist + k_ck_tilescan build the prefix counts of every long sub-array, k_ck_phases finds the state at the
+// end of every phase, k_ck_solve the state at evenly weighted checkpoints in between, and k_sort_walk_ck runs one walker
+// per checkpoint (kernels_walk.hpp) from its state up to the next checkpoint's slot.  Every element is moved by exactly
+// one walker, with the destination the single serial walk gives it.
+#pragma once
+#include "lq_common.hpp"
+#include "kernels_sort.hpp"
+
+#define LQ_CK_B 16                 // buckets a checkpointed pass may have (digits 0..15)
+#define LQ_CK_TILE 1024            // elements per prefix-count tile
+
+struct CkSeg { u32 sgi, tile0, ck0, n_ck; };      // one long sub-array: its segment, first tile, first checkpoint, checkpoints
+
+// digit counts of every tile (raw), strided over all tiles of all listed sub-arrays
+__global__ void __launch_bounds__(256)
+k_ck_tilehist(const CkSeg *cks, u32 n_cks, u32 n_tiles, const SortSeg *segs, const u8 *D, u32 *T)
+{
+	__shared__ u32 lh[LQ_CK_B];
+	const u32 t = threadIdx.x;
+	for (u32 tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+		u32 lo = 0, hi = n_cks;
+		while (hi - lo > 1) { const u32 mid = lo + ((hi - lo) >> 1); if (cks[mid].tile0 <= tile) lo = mid; else hi = mid; }
+		const CkSeg ck = cks[lo];
+		const SortSeg sg = segs[ck.sgi];
+		const u32 i0 = (tile - ck.tile0) * LQ_CK_TILE, i1 = i0 + LQ_CK_TILE < sg.len ? i0 + LQ_CK_TILE : sg.len;
+		if (t < LQ_CK_B) lh[t] = 0;
+		__syncthreads();
+		const u8 *d = D + sg.off;
+		for (u32 i = i0 + t; i < i1; i += 256) atomicAdd(&lh[d[i] & (LQ_CK_B - 1)], 1u);
+		__syncthreads();
+		if (t < LQ_CK_B) T[(u64)tile * LQ_CK_B + t] = lh[t];
+		__syncthreads();
+	}
+}
+
+// exclusive scan of the tile counts along each sub-array: T[tile][d] = count of digit d before the tile
+__global__ void __launch_bounds__(256)
+k_ck_tilescan(const CkSeg *cks, u32 n_cks, const SortSeg *segs, u32 *T)
+{
+	__shared__ u32 part[256][LQ_CK_B + 1];
+	const u32 t = threadIdx.x;
+	for (u32 j = blockIdx.x; j < n_cks; j += gridDim.x) {
+		const CkSeg ck = cks[j];
+		const u32 nt = segs[ck.sgi].len / LQ_CK_TILE + 1;        // one more than needed: the last entry holds the totals
+		const u32 per = (nt + 255) / 256, a = t * per < nt ? t * per : nt, b = a + per < nt ? a + per : nt;
+		u32 acc[LQ_CK_B];
+		for (int d = 0; d < LQ_CK_B; ++d) acc[d] = 0;
+		for (u32 x = a; x < b; ++x) for (int d = 0; d < LQ_CK_B; ++d) acc[d] += T[(u64)(ck.tile0 + x) * LQ_CK_B + d];
+		for (int d = 0; d < LQ_CK_B; ++d) part[t][d] = acc[d];
+		__syncthreads();
+		if (t < LQ_CK_B) { u32 run = 0; for (u32 x = 0; x < 256; ++x) { const u32 v = part[x][t]; part[x][t] = run; run += v; } }
+		__syncthreads();
+		for (int d = 0; d < LQ_CK_B; ++d) acc[d] = part[t][d];
+		for (u32 x = a; x < b; ++x) for (int d = 0; d < LQ_CK_B; ++d) { u32 *p = &T[(u64)(ck.tile0 + x) * LQ_CK_B + d]; const u32 v = *p; *p = acc[d]; acc[d] += v; }
+		__syncthreads();
+	}
+}
+
+// One wave solves for states; lane c < 16 owns bucket c.  lq_ck_prefix: counts of digit `lane` in the first x elements of
+// the sub-array (tile table + the partial tile, histogrammed by the whole wave in LDS).
+__device__ __forceinline__ u32 lq_ck_prefix(const u8 *d, const u32 *T, u32 x, u32 *lh, u32 lane)
+{
+	const u32 tile = x / LQ_CK_TILE, r0 = tile * LQ_CK_TILE;
+	if (lane < LQ_CK_B) lh[lane] = 0;
+	__syncthreads();
+	for (u32 i = r0 + lane; i < x; i += 64) atomicAdd(&lh[d[i] & (LQ_CK_B - 1)], 1u);
+	__syncthreads();
+	u32 v = 0;
+	if (lane < LQ_CK_B) v = T[(u64)tile * LQ_CK_B + lane] + lh[lane];
+	__syncthreads();
+	return v;
+}
+
+// least solution above the state in `A` (lane c: cursor of bucket c, absolute slot index in the sub-array) with the
+// buckets below k full and bucket k held at its value; pbeg[l] = prefix counts (of this lane's digit) at beg[l]
+__device__ __forceinline__ u32 lq_ck_iterate(const u8 *d, const u32 *T, u32 k, u32 nb, u32 A, const u32 (&pbeg)[LQ_CK_B], const u32 (&pend)[LQ_CK_B],
+                                            u32 my_beg, u32 *lh, u32 *sh, u32 lane)
+{
+	for (;;) {
+		if (lane < LQ_CK_B) sh[lane] = A;
+		__syncthreads();
+		u32 acc = 0;
+#pragma unroll
+		for (u32 l = 0; l < LQ_CK_B; ++l) {                     // uniform loop over the regions
+			if (l >= nb) break;
+			const u32 x = sh[l];
+			__syncthreads();
+			if (l < k) acc += pend[l] - pbeg[l];                    // a full region has given everything it has of this digit
+			else acc += lq_ck_prefix(d, T, x, lh, lane) - pbeg[l];
+		}
+		u32 nA = A;
+		if (lane < nb && lane > k) { const u32 f = my_beg + acc; if (f > A) nA = f; }
+		const u64 changed = __ballot(nA != A);
+		A = nA;
+		if (!changed) break;
+	}
+	return A;
+}
+
+// state at the end of every phase: E[j][k][c] = cursors when bucket k has just become full (one wave per sub-array)
+__global__ void __launch_bounds__(64)
+k_ck_phases(const CkSeg *cks, u32 n_cks, const SortSeg *segs, const u8 *D, const u32 *hist, const u32 *begs, const u32 *T, u32 *E)
+{
+	__shared__ u32 lh[LQ_CK_B], sh[LQ_CK_B];
+	const u32 lane = threadIdx.x;
+	for (u32 j = blockIdx.x; j < n_cks; j += gridDim.x) {
+		const CkSeg ck = cks[j];
+		const SortSeg sg = segs[ck.sgi];
+		const u8 *d = D + sg.off;
+		const u32 *Tj = T + (u64)ck.tile0 * LQ_CK_B;
+		const u32 *bg = begs + (u64)ck.sgi * 256, *cn = hist + (u64)ck.sgi * 256;
+		const u32 my_beg = lane < LQ_CK_B ? bg[lane] : 0, my_end = lane < LQ_CK_B ? my_beg + cn[lane] : 0;
+		u32 nb = 1;
+		for (u32 c = 0; c < LQ_CK_B; ++c) if (cn[c]) nb = c + 1;      // buckets in use
+		u32 pbeg[LQ_CK_B], pend[LQ_CK_B];
+		for (u32 l = 0; l < LQ_CK_B; ++l) { pbeg[l] = 0; pend[l] = 0; }
+#pragma unroll
+		for (u32 l = 0; l < LQ_CK_B; ++l) if (l < nb) { pbeg[l] = lq_ck_prefix(d, Tj, bg[l], lh, lane); pend[l] = lq_ck_prefix(d, Tj, bg[l] + cn[l], lh, lane); }
+		u32 A = my_beg;
+		for (u32 k = 0; k < LQ_CK_B; ++k) {
+			if (lane == k) A = my_end;                              // the outer loop has filled bucket k
+			if (k < nb) A = lq_ck_iterate(d, Tj, k, nb, A, pbeg, pend, my_beg, lh, sh, lane);
+			if (lane < LQ_CK_B) E[((u64)j * LQ_CK_B + k) * LQ_CK_B + lane] = A;
+		}
+	}
+}
+
+// state at every checkpoint (one wave each): checkpoint i of sub-array j sits at slot s of bucket k, picked so that the
+// weights w_k = number of buckets >= k (the expected length of a cycle started in bucket k) are spread evenly
+__global__ void __launch_bounds__(64)
+k_ck_solve(const CkSeg *cks, u32 n_cks, u32 n_ck_total, const SortSeg *segs, const u8 *D, const u32 *hist, const u32 *begs, const u32 *T,
+           const u32 *E, u32 *S, u32 *CKS)
+{
+	__shared__ u32 lh[LQ_CK_B], sh[LQ_CK_B];
+	const u32 lane = threadIdx.x;
+	for (u32 ci = blockIdx.x; ci < n_ck_total; ci += gridDim.x) {
+		u32 lo = 0, hi = n_cks;
+		while (hi - lo > 1) { const u32 mid = lo + ((hi - lo) >> 1); if (cks[mid].ck0 <= ci) lo = mid; else hi = mid; }
+		const u32 j = lo;
+		const CkSeg ck = cks[j];
+		const u32 i = ci - ck.ck0;
+		const SortSeg sg = segs[ck.sgi];
+		const u8 *d = D + sg.off;
+		const u32 *Tj = T + (u64)ck.tile0 * LQ_CK_B;
+		const u32 *bg = begs + (u64)ck.sgi * 256, *cn = hist + (u64)ck.sgi * 256;
+		const u32 my_beg = lane < LQ_CK_B ? bg[lane] : 0;
+		// slot of this checkpoint: weight w_k per slot of bucket k, target = i / n_ck of the total
+		u64 wtot = 0;
+		for (u32 c = 0; c < LQ_CK_B; ++c) wtot += (u64)cn[c] * (LQ_CK_B - c);
+		u64 want = wtot / ck.n_ck * i + wtot % ck.n_ck * i / ck.n_ck;
+		u32 k = 0, s = 0;
+		for (k = 0; k < LQ_CK_B; ++k) {
+			const u64 wk = (u64)cn[k] * (LQ_CK_B - k);
+			if (want < wk || k == LQ_CK_B - 1) { const u64 m = want / (LQ_CK_B - k); s = bg[k] + (u32)(m < cn[k] ? m : cn[k]); break; }
+			want -= wk;
+		}
+		if (i == 0) { k = 0; s = 0; }
+		u32 A;
+		if (k == 0) A = my_beg;
+		else A = lane < LQ_CK_B ? E[((u64)j * LQ_CK_B + (k - 1)) * LQ_CK_B + lane] : 0;
+		// the outer loop only ever looks at slots from bucket k's cursor on: an earlier target slot means "its first look"
+		const u32 ak = (u32)__builtin_amdgcn_readlane((int)A, (int)k);
+		if (s < ak) s = ak;
+		if (lane == k) A = s;
+		u32 nb = 1;
+		for (u32 c = 0; c < LQ_CK_B; ++c) if (cn[c]) nb = c + 1;
+		u32 pbeg[LQ_CK_B], pend[LQ_CK_B];
+		for (u32 l = 0; l < LQ_CK_B; ++l) { pbeg[l] = 0; pend[l] = 0; }
+#pragma unroll
+		for (u32 l = 0; l < LQ_CK_B; ++l) if (l < nb) { pbeg[l] = lq_ck_prefix(d, Tj, bg[l], lh, lane); pend[l] = lq_ck_prefix(d, Tj, bg[l] + cn[l], lh, lane); }
+		if (k < nb) A = lq_ck_iterate(d, Tj, k, nb, A, pbeg, pend, my_beg, lh, sh, lane);
+		if (lane < LQ_CK_B) S[(u64)ci * LQ_CK_B + lane] = A;
+		if (lane == 0) CKS[ci] = s;
+	}
+}

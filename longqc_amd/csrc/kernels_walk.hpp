@@ -17,6 +17,7 @@
 #pragma once
 #include "lq_common.hpp"
 #include "kernels_sort.hpp"
+#include "kernels_ckpt.hpp"
 
 #ifndef LQ_EMU
 #define LQ_RL(v, lane) ((u32)__builtin_amdgcn_readlane((int)(v), (int)(lane)))
@@ -56,16 +57,28 @@ static inline void lq_walk_dma16(const u8 *g, u8 *lds) { LQ_DMA_WIN16(g, lds); }
 		       else { if ((bk) < 192) { constexpr int G = 2 % NG; __VA_ARGS__ } else { constexpr int G = 3 % NG; __VA_ARGS__ } } } \
 	} while (0)
 
-// NG = register groups of 64 buckets: 1 (every digit of the pass below 64), 2, or 4
+// NG = register groups of 64 buckets: 1 (every digit of the pass below 64), 2, or 4.
+// Two ways to name the work: a list of sub-arrays (cks == null: every block takes whole walks), or the checkpoints of
+// kernels_ckpt.hpp (cks != null: work item = one checkpoint; the walker starts from the checkpoint's cursors ck_S and
+// stops when the outer loop reaches the next checkpoint's slot ck_slot).
 template <int NG>
 __global__ void __launch_bounds__(64)
-k_sort_walk_reg(const SortSeg *segs, const u32 *list, const u32 *n_list_p, const u8 *D, const u32 *hist, const u32 *begs, u32 *dst)
+k_sort_walk_reg(const SortSeg *segs, const u32 *list, const u32 *n_list_p, const u8 *D, const u32 *hist, const u32 *begs, u32 *dst,
+                const CkSeg *cks, u32 n_cks, const u32 *ck_S, const u32 *ck_slot)
 {
 	LQ_SHARED __attribute__((aligned(16))) u8 win[NG * 64][16];   // DMA landing windows: 16 digits of each bucket's stream
 	const u32 n_list = *n_list_p;
 	const u32 lane = threadIdx.x;
 	for (u32 li = blockIdx.x; li < n_list; li += gridDim.x) {
-		const u32 sgi = list[li];
+		u32 sgi, s_end = 0xffffffffu;
+		const u32 *start = nullptr;
+		if (cks) {
+			u32 lo = 0, hi = n_cks;
+			while (hi - lo > 1) { const u32 mid = lo + ((hi - lo) >> 1); if (cks[mid].ck0 <= li) lo = mid; else hi = mid; }
+			sgi = cks[lo].sgi;
+			start = ck_S + (u64)li * LQ_CK_B;
+			if (li + 1 < cks[lo].ck0 + cks[lo].n_ck) s_end = ck_slot[li + 1];
+		} else sgi = list[li];
 		const SortSeg sg = segs[sgi];
 		const u32 *cnt = hist + (u64)sgi * 256, *bg = begs + (u64)sgi * 256;
 		const u64 base = sg.off;                              // D is 16-byte aligned; this sub-array's digits start at D[base]
@@ -80,12 +93,12 @@ k_sort_walk_reg(const SortSeg *segs, const u32 *list, const u32 *n_list_p, const
 		LQ_WALK_REGS(vcur); LQ_WALK_REGS(vend); LQ_WALK_REGS(vwin);   // per bucket: cursor | PEND, end, digits from the cursor to the next 4-byte boundary
 		for (int g = 0; g < NG; ++g) {                        // every lane sets up its own buckets
 			const u32 c = (u32)g * 64 + lane;
-			const u32 b = bg[c];
+			const u32 b = (start && c < LQ_CK_B) ? start[c] : bg[c];
 			const u8 *w = D + ((base + b) & ~(u64)15);
 			*(uint4*)&win[c][0] = *(const uint4*)w;
 			const u32 o = (b15 + b) & 15;
 			const u32 dq = (*(const u32*)(w + (o & ~3u))) >> (8 * (o & 3));
-			LQ_WALK_LANE_INIT(vcur, g, b); LQ_WALK_LANE_INIT(vend, g, b + cnt[c]); LQ_WALK_LANE_INIT(vwin, g, dq);
+			LQ_WALK_LANE_INIT(vcur, g, b); LQ_WALK_LANE_INIT(vend, g, bg[c] + cnt[c]); LQ_WALK_LANE_INIT(vwin, g, dq);
 		}
 		LQ_BLOCK_SYNC();
 #ifdef LQ_EMU
@@ -103,6 +116,7 @@ k_sort_walk_reg(const SortSeg *segs, const u32 *list, const u32 *n_list_p, const
 					if ((hole & ~LQ_SOLO_PEND) < hend) break;
 				}
 				if (k >= (u32)NG * 64) break;
+				if ((hole & ~LQ_SOLO_PEND) >= s_end) break;          // the next checkpoint's walker takes over from this slot
 				if (hole & LQ_SOLO_PEND) { LQ_WAIT_VM0(); hole &= ~LQ_SOLO_PEND; hdq = LQ_UNI(LQ_LDS_U32(&win[k][0])); }
 				u32 src = hole, l = hdq & 0xff;
 				// CARRY: the carried element takes the slot under its bucket's cursor; that slot's occupant is carried on

@@ -199,3 +199,49 @@ def test_emulated_query_order_is_internal_only(emu_lib, case, monkeypatch):
     rc, out, err = run_main(emu_lib, case["argv"], cwd=GOLDEN)
     assert rc == 0, err
     assert out == read_gz(case["expect"])
+
+
+def _few_targets_dataset(tmp_path, n_targets=14, tlen=25000, n_queries=6, qlen=20000, glen=30000, seed=11):
+    """few, long targets over a small genome: the pass on the rid byte has <= 16 buckets and every (query, strand)
+    sub-array holds tens of thousands of anchors -- the shape of the top pass of a 4-Gbase part (kernels_ckpt.hpp)"""
+    from longqc_amd import synth
+    rng = np.random.default_rng(seed)
+    A = synth._ACGT
+    g = A[rng.integers(0, 4, size=glen, dtype=np.uint8)]
+    g[5000:5400] = np.tile(g[4900:5000], 4)                              # a tandem repeat: repeated minimizers inside queries
+    names, seqs, quals = [], [], []
+
+    def read(L):
+        st = int(rng.integers(0, glen - L + 1)) if L < glen else 0
+        s = g[st:st + L]
+        if rng.random() < 0.5:
+            s = synth._COMP[s[::-1]]
+        return synth._mutate(s, rng, 0.06, (3, 3, 4))
+    for i in range(n_targets):
+        s = read(min(tlen, glen)); names.append("t%02d" % i); seqs.append(s); quals.append((33 + rng.integers(3, 30, size=s.shape[0])).astype(np.uint8))
+    T = synth.ReadSet(names, seqs, quals)
+    qn, qs, qq = [], [], []
+    for i in range(n_queries):
+        s = read(min(qlen, glen)); qn.append("q%02d" % i); qs.append(s); qq.append((33 + rng.integers(3, 30, size=s.shape[0])).astype(np.uint8))
+    Q = synth.ReadSet(qn, qs, qq)
+    tf, qf = str(tmp_path / "ft_all.fq"), str(tmp_path / "ft_sub.fq")
+    synth.write_fastq(tf, T); synth.write_fastq(qf, Q)
+    return tf, qf
+
+
+@pytest.mark.parametrize("variant", ["ckpt", "ckpt_all_klib", "plain"])
+def test_emulated_checkpointed_walks(emu_lib, tmp_path, monkeypatch, variant):
+    """long sub-arrays of a few-bucket pass are walked in pieces from computed checkpoint states (kernels_ckpt.hpp):
+    same table as the oracle, with the size classes shrunk so that this small input reaches them"""
+    tf, qf = _few_targets_dataset(tmp_path)
+    argv = ONT + [tf, qf]
+    want = oracle_bind.table(argv)
+    monkeypatch.setenv("LQCOV_WALK_SHIFT", "4")
+    if variant == "ckpt_all_klib":
+        monkeypatch.setenv("LQCOV_SORT", "klib")
+    if variant == "plain":
+        monkeypatch.setenv("LQCOV_CKPT", "0")
+    rc, out, err = run_main(emu_lib, argv)
+    assert rc == 0, err
+    assert out == want
+    assert sum(1 for l in out.splitlines() if l.split("\t")[2] != "0") >= 4

@@ -32,7 +32,7 @@ int main(int argc, char **argv)
 	const int copies_hi = argc > 2 ? atoi(argv[2]) : 1024;
 	const int only_b = argc > 3 ? atoi(argv[3]) : 0;
 	struct Case { const char *name; int B; int runs; };
-	const Case cases[] = { {"B=6 random", 6, 1}, {"B=6 runs of 37", 6, 37}, {"B=50 random", 50, 1}, {"B=79 random", 79, 1}, {"B=100 random", 100, 1}, {"B=196 random", 196, 1}, {"B=256 random", 256, 1} };
+	const Case cases[] = { {"B=6 random", 6, 1}, {"B=6 runs of 37", 6, 37}, {"B=16 random", 16, 1}, {"B=3 runs of 5", 3, 5}, {"B=50 random", 50, 1}, {"B=79 random", 79, 1}, {"B=100 random", 100, 1}, {"B=196 random", 196, 1}, {"B=256 random", 256, 1} };
 	for (const Case &cs : cases) {
 		if (only_b && cs.B != only_b) continue;
 		std::mt19937_64 rng(12345 + cs.B);
@@ -73,9 +73,33 @@ int main(int argc, char **argv)
 				fflush(stdout);
 			};
 			run("solo (LDS state)", [&] { hipLaunchKernelGGL(k_sort_walk_solo, dim3(copies), dim3(64), 0, 0, dS, dList, dN, dD, dH, dB, dDst); });
-			if (cs.B <= 64) run("reg<1>", [&] { hipLaunchKernelGGL((k_sort_walk_reg<1>), dim3(copies), dim3(64), 0, 0, dS, dList, dN, dD, dH, dB, dDst); });
-			if (cs.B <= 128) run("reg<2>", [&] { hipLaunchKernelGGL((k_sort_walk_reg<2>), dim3(copies), dim3(64), 0, 0, dS, dList, dN, dD, dH, dB, dDst); });
-			run("reg<4>", [&] { hipLaunchKernelGGL((k_sort_walk_reg<4>), dim3(copies), dim3(64), 0, 0, dS, dList, dN, dD, dH, dB, dDst); });
+			const CkSeg *nock = nullptr; const u32 *nou = nullptr;
+			if (cs.B <= 64) run("reg<1>", [&] { hipLaunchKernelGGL((k_sort_walk_reg<1>), dim3(copies), dim3(64), 0, 0, dS, dList, dN, dD, dH, dB, dDst, nock, 0u, nou, nou); });
+			if (cs.B <= 128) run("reg<2>", [&] { hipLaunchKernelGGL((k_sort_walk_reg<2>), dim3(copies), dim3(64), 0, 0, dS, dList, dN, dD, dH, dB, dDst, nock, 0u, nou, nou); });
+			run("reg<4>", [&] { hipLaunchKernelGGL((k_sort_walk_reg<4>), dim3(copies), dim3(64), 0, 0, dS, dList, dN, dD, dH, dB, dDst, nock, 0u, nou, nou); });
+			if (cs.B <= LQ_CK_B) {
+				// checkpointed: the walk of every copy cut into n_ck pieces from computed states (kernels_ckpt.hpp)
+				const u32 n_ck1 = std::min<u32>(512, std::max<u32>(2, N / 16384));
+				std::vector<CkSeg> hck(copies);
+				u32 tiles = 0, ckt = 0;
+				for (int c = 0; c < copies; ++c) { hck[c].sgi = c; hck[c].tile0 = tiles; hck[c].ck0 = ckt; hck[c].n_ck = n_ck1; tiles += N / LQ_CK_TILE + 1; ckt += n_ck1; }
+				CkSeg *dck; u32 *dT, *dE, *dSt, *dSl, *dNck;
+				CK(hipMalloc(&dck, sizeof(CkSeg) * copies)); CK(hipMalloc(&dT, (u64)tiles * LQ_CK_B * 4)); CK(hipMalloc(&dE, (u64)copies * LQ_CK_B * LQ_CK_B * 4));
+				CK(hipMalloc(&dSt, (u64)ckt * LQ_CK_B * 4)); CK(hipMalloc(&dSl, (u64)ckt * 4 + 4)); CK(hipMalloc(&dNck, 4));
+				CK(hipMemcpy(dck, hck.data(), sizeof(CkSeg) * copies, hipMemcpyHostToDevice)); CK(hipMemcpy(dNck, &ckt, 4, hipMemcpyHostToDevice));
+				char nm[64]; snprintf(nm, sizeof(nm), "ckpt x%u (all kernels)", n_ck1);
+				run(nm, [&] {
+					hipLaunchKernelGGL(k_ck_tilehist, dim3(std::min<u32>(tiles, 65536)), dim3(256), 0, 0, dck, (u32)copies, tiles, dS, dD, dT);
+					hipLaunchKernelGGL(k_ck_tilescan, dim3(copies), dim3(256), 0, 0, dck, (u32)copies, dS, dT);
+					hipLaunchKernelGGL(k_ck_phases, dim3(copies), dim3(64), 0, 0, dck, (u32)copies, dS, dD, dH, dB, dT, dE);
+					hipLaunchKernelGGL(k_ck_solve, dim3(std::min<u32>(ckt, 1u << 18)), dim3(64), 0, 0, dck, (u32)copies, ckt, dS, dD, dH, dB, dT, dE, dSt, dSl);
+					hipLaunchKernelGGL((k_sort_walk_reg<1>), dim3(std::min<u32>(ckt, 1u << 18)), dim3(64), 0, 0, dS, nou, dNck, dD, dH, dB, dDst, dck, (u32)copies, dSt, dSl);
+				});
+				run("  of which walk pieces", [&] {
+					hipLaunchKernelGGL((k_sort_walk_reg<1>), dim3(std::min<u32>(ckt, 1u << 18)), dim3(64), 0, 0, dS, nou, dNck, dD, dH, dB, dDst, dck, (u32)copies, dSt, dSl);
+				});
+				hipFree(dck); hipFree(dT); hipFree(dE); hipFree(dSt); hipFree(dSl); hipFree(dNck);
+			}
 			hipFree(dD); hipFree(dH); hipFree(dB); hipFree(dDst); hipFree(dList); hipFree(dN); hipFree(dS);
 		}
 	}
