@@ -24,6 +24,11 @@ import sys
 import tempfile
 import time
 
+# HIP multiplexes its streams onto GPU_MAX_HW_QUEUES hardware queues (default 4); kernels of streams that share a queue run
+# one after the other.  The engine drives 2 streams per mapping lane + 1: ask for enough queues before the runtime starts
+# (liblqcov.so does the same in lqcov_create when it is the first HIP user of the process).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", os.environ.get("LQCOV_HW_QUEUES", "4"))
+
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))

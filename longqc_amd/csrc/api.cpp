@@ -160,6 +160,10 @@ int lqcov_parse_args(int argc, const char *const *argv, lqcov_params *p, const c
 
 lqcov_handle *lqcov_create(const lqcov_params *p, int device)
 {
+	// HIP multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and kernels of streams that share a queue
+	// run one after the other: the mapping lanes (2 streams each) need their own.  Only effective when the HIP runtime has
+	// not started yet in this process (the CLI, LongQC's exec); hosts that initialise HIP first set it themselves (bench.py).
+	if (getenv("LQCOV_HW_QUEUES")) setenv("GPU_MAX_HW_QUEUES", getenv("LQCOV_HW_QUEUES"), 0);
 	try { return new lqcov_handle(*p, device); }
 	catch (const std::exception &e) { g_create_error = e.what(); fprintf(stderr, "lqcov_create: %s\n", e.what()); return nullptr; }
 }

@@ -75,6 +75,7 @@ lqcov_handle::lqcov_handle(const lqcov_params &p, int dev) : P(p), device(dev)
 	if (dev < 0 || dev >= ndev) throw std::runtime_error("HIP device index out of range");
 	LQ_HIP_CHECK(hipSetDevice(dev));
 	LQ_HIP_CHECK(hipStreamCreate(&stream));
+	lq_pool_keep_memory(dev);
 	prim.stream = stream;
 	mp.k = P.k; mp.w = P.w; mp.hpc = P.hpc;
 	mp.max_gap = P.max_gap; mp.bw = P.bw; mp.max_skip = P.max_chain_skip; mp.min_cnt = P.min_cnt; mp.min_sc = P.min_chain_score;
@@ -84,7 +85,7 @@ lqcov_handle::lqcov_handle(const lqcov_params &p, int dev) : P(p), device(dev)
 	const char *e = getenv("LQCOV_ANCHOR_BUDGET");
 	anchor_budget = e ? strtoull(e, 0, 10) : 0;
 	const char *el = getenv("LQCOV_LANES");
-	n_lanes = el ? std::min(8, std::max(1, atoi(el))) : 3;   // measured at configs[1]: 1 lane 0.80 s per step, 2: 0.61, 3: 0.59, 4: 0.59, 6: 0.72
+	n_lanes = el ? std::min(8, std::max(1, atoi(el))) : 4;   // measured at configs[2] (round 2): 2 lanes 2.23 s per step, 3: 2.05, 4: 1.82, 6: 1.88
 	if (anchor_budget == 0) {
 		size_t fr = 0, tot = 0;
 		hipMemGetInfo(&fr, &tot);
@@ -98,10 +99,18 @@ lqcov_handle::~lqcov_handle()
 {
 	drain_stages();
 	for (auto &L : lanes) {
-		if (L->stream) { hipStreamSynchronize(L->stream); hipStreamDestroy(L->stream); }
-		if (L->stream2) { hipStreamSynchronize(L->stream2); hipStreamDestroy(L->stream2); }
-		if (L->ev_fork) hipEventDestroy(L->ev_fork);
-		if (L->ev_join) hipEventDestroy(L->ev_join);
+		hipStream_t s1 = L->stream, s2 = L->stream2, s3 = L->streamW;
+		hipEvent_t e1 = L->ev_fork, e2 = L->ev_join, e3 = L->ev_w0, e4 = L->ev_w1;
+		if (s1) hipStreamSynchronize(s1);
+		if (s2) hipStreamSynchronize(s2);
+		if (s3) { hipStreamSynchronize(s3); hipStreamDestroy(s3); }
+		if (e3) hipEventDestroy(e3);
+		if (e4) hipEventDestroy(e4);
+		L.reset();                                              // the lane's buffers go back to the pool while its stream still exists
+		if (s1) { hipStreamSynchronize(s1); hipStreamDestroy(s1); }
+		if (s2) hipStreamDestroy(s2);
+		if (e1) hipEventDestroy(e1);
+		if (e2) hipEventDestroy(e2);
 	}
 	if (stream) { hipStreamSynchronize(stream); hipStreamDestroy(stream); }
 }
@@ -121,8 +130,8 @@ static void grow_keep(DBuf &b, size_t old_bytes, size_t new_bytes, hipStream_t s
 	LQ_HIP_CHECK(hipMalloc(&np, want));
 	if (old_bytes) LQ_HIP_CHECK(hipMemcpyAsync(np, b.p, old_bytes, hipMemcpyDeviceToDevice, s));
 	LQ_HIP_CHECK(hipStreamSynchronize(s));
-	if (b.p) hipFree(b.p);
-	b.p = np; b.cap = want;
+	if (b.p) { void *old = b.p; b.p = nullptr; DBuf tmp; tmp.p = old; tmp.cap = 1; tmp.pool_stream = b.pool_stream; }   // (freed the way it was allocated)
+	b.p = np; b.cap = want; b.pool_stream = nullptr;
 }
 
 // upload n reads (ASCII) and append them, 2-bit packed, to the set   (index.c:240-288 step 0)
@@ -615,7 +624,7 @@ static PsLists ps_lists(MapLane &L, int set)
 	Ls.cnt = L.sort_cnt.as<u32>() + (set ? LQ_C_PS1 : LQ_C_PS0);
 	Ls.cap_big = (u32)std::min<u64>(W.big[0].cap / sizeof(PSeg), 0xfffffff0ULL); Ls.cap_fin = (u32)std::min<u64>(W.fin_s.cap / sizeof(PSeg), 0xfffffff0ULL);
 	const u32 sh = ps_shift();
-	Ls.fin_s_max = std::max<u32>(LQ_PS_FIN_SMALL >> sh, 2); Ls.fin_b_max = std::max<u32>(LQ_PS_FIN_BIG >> sh, 4); Ls.child_target = std::max<u32>(LQ_PS_TILE >> sh, 2);
+	Ls.fin_s_max = std::max<u32>(LQ_PS_FIN_SMALL >> sh, 2); Ls.fin_b_max = std::max<u32>(LQ_PS_FIN_BIG >> sh, 4); Ls.child_target = std::max<u32>(LQ_PS_CHILD >> sh, 2);
 	return Ls;
 }
 
@@ -649,11 +658,11 @@ void lqcov_handle::psort_run(MapLane &L, int set, hipStream_t s, u64 nA, const K
 	}
 	{
 		StageTimer t(this, s, "k_ps_finish<8192>", nA * 32);
-		LQ_LAUNCH((k_ps_finish<LQ_PS_FIN_BIG, 1024>), (u32)std::min<u64>(Ls.cap_fin, 2048), 1024, s, Ls.fin_b, cnt + LQ_P_FIN_B, dA, dB, km); check_launch();
+		LQ_LAUNCH((k_ps_finish<LQ_PS_FIN_BIG, 1024, 10>), (u32)std::min<u64>(Ls.cap_fin, 4096), 1024, s, Ls.fin_b, cnt + LQ_P_FIN_B, dA, dB, km); check_launch();
 	}
 	{
 		StageTimer t(this, s, "k_ps_finish<1024>", nA * 32);
-		LQ_LAUNCH((k_ps_finish<LQ_PS_FIN_SMALL, 256>), (u32)std::min<u64>(Ls.cap_fin, 16384), 256, s, Ls.fin_s, cnt + LQ_P_FIN_S, dA, dB, km); check_launch();
+		LQ_LAUNCH((k_ps_finish<LQ_PS_FIN_SMALL, 256, 8>), (u32)std::min<u64>(Ls.cap_fin, 32768), 256, s, Ls.fin_s, cnt + LQ_P_FIN_S, dA, dB, km); check_launch();
 	}
 }
 
@@ -743,6 +752,7 @@ void lqcov_handle::sort_batch(MapLane &L, Part &pt, u32 q0, u32 nqb, u64 a_base,
 			{
 				const u8 *dD = L.sort_d.as<u8>(); const u32 *dH = L.hist.as<u32>(), *dBg = L.begs.as<u32>(); u32 *dDst = L.sort_dst.as<u32>();
 				const u32 *wl = L.walk_list.as<u32>();
+				hipStream_t sW = L.streamW;
 				// the largest digit of this level decides how many register groups the long walker needs
 				u32 max_digit = 255;
 				if (shift == 48) max_digit = (pt.rs.n ? pt.rs.n - 1 : 0) >> 16;
@@ -757,13 +767,18 @@ void lqcov_handle::sort_batch(MapLane &L, Part &pt, u32 q0, u32 nqb, u64 a_base,
 					        hc[LQ_C_WALK0], hc[LQ_C_WALK1], hc[LQ_C_WALK2], hc[LQ_C_WALK3], hc[LQ_C_WALK4], (unsigned long long)nA);
 					fflush(stderr);
 				}
+				// the walkers' stream starts where this one stands, and this one resumes when they are done
 				// Passes with few buckets over long sub-arrays (the byte of rid above 65536 targets: the (query, strand) arrays of
 				// the longest queries, millions of anchors each): the walk's state at evenly spread checkpoints is computed
 				// without walking (kernels_ckpt.hpp) and one walker per checkpoint runs a short piece.
 				int first_plain_class = LQ_WALK_CLASSES - 1;
-				if (reg_walker && max_digit < LQ_CK_B && !(getenv("LQCOV_CKPT") && !strcmp(getenv("LQCOV_CKPT"), "0")) && ns <= (1u << 20)) {
+				bool forked = false;
+				auto fork_w = [&]() { if (!forked) { LQ_HIP_CHECK(hipEventRecord(L.ev_w0, sD)); LQ_HIP_CHECK(hipStreamWaitEvent(sW, L.ev_w0, 0)); forked = true; } };
+				const bool ck_small = reg_walker && max_digit < LQ_CK_B;      // few buckets: states from prefix counts (k_ck_phases / k_ck_solve); else: k_ck_chain256
+				if (!(getenv("LQCOV_CKPT") && !strcmp(getenv("LQCOV_CKPT"), "0")) && ns <= (1u << 20)) {
 					u32 hc[LQ_C_N]; d2h(hc, cnt, LQ_C_N, sD);
-					const u32 n3 = hc[LQ_C_WALK3], n4 = hc[LQ_C_WALK4];
+					// (with many buckets finding the states costs about as much as walking 50-100 k elements: only the longest class)
+					const u32 n3 = ck_small ? hc[LQ_C_WALK3] : 0, n4 = hc[LQ_C_WALK4];
 					if (n3 + n4) {
 						std::vector<u32> ids(n3 + n4);
 						if (n3) d2h(ids.data(), wl + (u64)3 * ns, n3, sD);
@@ -776,50 +791,66 @@ void lqcov_handle::sort_batch(MapLane &L, Part &pt, u32 q0, u32 nqb, u64 a_base,
 						for (size_t i = 0; i < ids.size(); ++i) {
 							const u32 len = hs[ids[i]].len;
 							CkSeg c; c.sgi = ids[i]; c.tile0 = (u32)tiles; c.ck0 = (u32)cks_total;
-							c.n_ck = std::min<u32>(512, std::max<u32>(2, len / unit));
+							c.n_ck = std::min<u32>(ck_small ? 512 : 64, std::max<u32>(2, len / unit));
 							hck[i] = c;
 							tiles += len / LQ_CK_TILE + 1; cks_total += c.n_ck;
 						}
 						if (tiles < 0xfffffff0ULL && cks_total < 0xfffffff0ULL) {
 							const u32 n_cks = (u32)hck.size(), n_tiles = (u32)tiles, n_ck = (u32)cks_total;
-							L.ck_segs.ensure(hck.size() * sizeof(CkSeg)); L.ck_T.ensure(tiles * LQ_CK_B * 4); L.ck_E.ensure((u64)n_cks * LQ_CK_B * LQ_CK_B * 4);
-							L.ck_S.ensure(cks_total * LQ_CK_B * 4); L.ck_slot.ensure(cks_total * 4 + 4); L.ck_n.ensure(4);
+							const u32 per_ck = ck_small ? LQ_CK_B : 256;          // cursors per checkpoint
+							L.ck_segs.ensure(hck.size() * sizeof(CkSeg)); L.ck_S.ensure(cks_total * per_ck * 4); L.ck_slot.ensure(cks_total * 4 + 4); L.ck_n.ensure(4);
+							if (ck_small) { L.ck_T.ensure(tiles * LQ_CK_B * 4); L.ck_E.ensure((u64)n_cks * LQ_CK_B * LQ_CK_B * 4); }
 							h2d(L.ck_segs.as<CkSeg>(), hck.data(), hck.size(), sD);
 							h2d(L.ck_n.as<u32>(), &n_ck, 1, sD);
 							LQ_HIP_CHECK(hipStreamSynchronize(sD));              // (the host vectors die with this scope)
 							const CkSeg *dck = L.ck_segs.as<CkSeg>();
+							fork_w();
 							if (!gated && !L.gate_passed) { L.gate_passed = true; open_gate(); gated = true; }
-							{
-								StageTimer t(this, sD, "k_ck_prefix", nA);
-								LQ_LAUNCH(k_ck_tilehist, std::min<u32>(n_tiles, 1u << 16), 256, sD, dck, n_cks, n_tiles, cur, dD, L.ck_T.as<u32>()); check_launch();
-								LQ_LAUNCH(k_ck_tilescan, std::min<u32>(n_cks, 8192), 256, sD, dck, n_cks, cur, L.ck_T.as<u32>()); check_launch();
+							if (ck_small) {
+								{
+									StageTimer t(this, sW, "k_ck_prefix", nA);
+									LQ_LAUNCH(k_ck_tilehist, std::min<u32>(n_tiles, 1u << 16), 256, sW, dck, n_cks, n_tiles, cur, dD, L.ck_T.as<u32>()); check_launch();
+									LQ_LAUNCH(k_ck_tilescan, std::min<u32>(n_cks, 8192), 256, sW, dck, n_cks, cur, L.ck_T.as<u32>()); check_launch();
+								}
+								{
+									StageTimer t(this, sW, "k_ck_solve");
+									LQ_LAUNCH(k_ck_phases, std::min<u32>(n_cks, 1u << 16), 64, sW, dck, n_cks, cur, dD, dH, dBg, L.ck_T.as<u32>(), L.ck_E.as<u32>()); check_launch();
+									LQ_LAUNCH(k_ck_solve, std::min<u32>(n_ck, 1u << 18), 64, sW, dck, n_cks, n_ck, cur, dD, dH, dBg, L.ck_T.as<u32>(), L.ck_E.as<u32>(), L.ck_S.as<u32>(), L.ck_slot.as<u32>()); check_launch();
+								}
+								{
+									StageTimer t(this, sW, "k_sort_walk_reg<1>ck", nA * 5);
+									LQ_LAUNCH((k_sort_walk_reg<1>), std::min<u32>(n_ck, 1u << 18), 64, sW, cur, (const u32*)nullptr, L.ck_n.as<u32>(), dD, dH, dBg, dDst, dck, n_cks, L.ck_S.as<u32>(), L.ck_slot.as<u32>()); check_launch();
+								}
+							} else {
+								{
+									StageTimer t(this, sW, "k_ck_chain256", nA);
+									LQ_LAUNCH(k_ck_chain256, std::min<u32>(n_cks, 1u << 16), 64, sW, dck, n_cks, cur, dD, dH, dBg, L.ck_S.as<u32>(), L.ck_slot.as<u32>()); check_launch();
+								}
+								{
+									StageTimer t(this, sW, "k_sort_walk_solo_ck", nA * 5);
+									LQ_LAUNCH(k_sort_walk_solo, std::min<u32>(n_ck, 1u << 18), 64, sW, cur, (const u32*)nullptr, L.ck_n.as<u32>(), dD, dH, dBg, dDst, dck, n_cks, L.ck_S.as<u32>(), L.ck_slot.as<u32>()); check_launch();
+								}
 							}
-							{
-								StageTimer t(this, sD, "k_ck_solve");
-								LQ_LAUNCH(k_ck_phases, std::min<u32>(n_cks, 1u << 16), 64, sD, dck, n_cks, cur, dD, dH, dBg, L.ck_T.as<u32>(), L.ck_E.as<u32>()); check_launch();
-								LQ_LAUNCH(k_ck_solve, std::min<u32>(n_ck, 1u << 18), 64, sD, dck, n_cks, n_ck, cur, dD, dH, dBg, L.ck_T.as<u32>(), L.ck_E.as<u32>(), L.ck_S.as<u32>(), L.ck_slot.as<u32>()); check_launch();
-							}
-							{
-								StageTimer t(this, sD, "k_sort_walk_reg<1>ck", nA * 5);
-								LQ_LAUNCH((k_sort_walk_reg<1>), std::min<u32>(n_ck, 1u << 18), 64, sD, cur, (const u32*)nullptr, L.ck_n.as<u32>(), dD, dH, dBg, dDst, dck, n_cks, L.ck_S.as<u32>(), L.ck_slot.as<u32>()); check_launch();
-							}
-							first_plain_class = 2;
+							first_plain_class = ck_small ? 2 : 3;
 						}
 					}
 				}
 				// long walks first: they outlast everything else of the level on a handful of CUs
+				fork_w();
 				for (int c = first_plain_class; c >= 2; --c) {
 					if (!gated && !L.gate_passed) { L.gate_passed = true; open_gate(); gated = true; }   // let the next lane start under these walks
 					const u32 g = std::min<u32>(ns, 8192);
 					const CkSeg *nock = nullptr;
-					if (reg_walker && max_digit < 64) { StageTimer t(this, sD, "k_sort_walk_reg<1>", nA * 5); LQ_LAUNCH((k_sort_walk_reg<1>), g, 64, sD, cur, wl + (u64)c * ns, cnt + LQ_C_WALK0 + c, dD, dH, dBg, dDst, nock, 0u, (const u32*)nullptr, (const u32*)nullptr); }
-					else if (reg_walker && max_digit < 128) { StageTimer t(this, sD, "k_sort_walk_reg<2>", nA * 5); LQ_LAUNCH((k_sort_walk_reg<2>), g, 64, sD, cur, wl + (u64)c * ns, cnt + LQ_C_WALK0 + c, dD, dH, dBg, dDst, nock, 0u, (const u32*)nullptr, (const u32*)nullptr); }
-					else { StageTimer t(this, sD, "k_sort_walk_solo", nA * 5); LQ_LAUNCH(k_sort_walk_solo, g, 64, sD, cur, wl + (u64)c * ns, cnt + LQ_C_WALK0 + c, dD, dH, dBg, dDst); }
+					if (reg_walker && max_digit < 64) { StageTimer t(this, sW, "k_sort_walk_reg<1>", nA * 5); LQ_LAUNCH((k_sort_walk_reg<1>), g, 64, sW, cur, wl + (u64)c * ns, cnt + LQ_C_WALK0 + c, dD, dH, dBg, dDst, nock, 0u, (const u32*)nullptr, (const u32*)nullptr); }
+					else if (reg_walker && max_digit < 128) { StageTimer t(this, sW, "k_sort_walk_reg<2>", nA * 5); LQ_LAUNCH((k_sort_walk_reg<2>), g, 64, sW, cur, wl + (u64)c * ns, cnt + LQ_C_WALK0 + c, dD, dH, dBg, dDst, nock, 0u, (const u32*)nullptr, (const u32*)nullptr); }
+					else { StageTimer t(this, sW, "k_sort_walk_solo", nA * 5); LQ_LAUNCH(k_sort_walk_solo, g, 64, sW, cur, wl + (u64)c * ns, cnt + LQ_C_WALK0 + c, dD, dH, dBg, dDst, nock, 0u, (const u32*)nullptr, (const u32*)nullptr); }
 					check_launch();
 				}
-				{ StageTimer t(this, sD, "k_sort_walk_lds<16384>"); LQ_LAUNCH((k_sort_walk_lds<16384>), std::min<u32>(ns, 8192), 64, sD, cur, wl + (u64)1 * ns, cnt + LQ_C_WALK1, dD, dH, dBg, dDst); check_launch(); }
-				{ StageTimer t(this, sD, "k_sort_walk_lds<4096>"); LQ_LAUNCH((k_sort_walk_lds<4096>), std::min<u32>(ns, 1u << 16), 64, sD, cur, wl + (u64)0 * ns, cnt + LQ_C_WALK0, dD, dH, dBg, dDst); check_launch(); }
+				{ StageTimer t(this, sW, "k_sort_walk_lds<16384>"); LQ_LAUNCH((k_sort_walk_lds<16384>), std::min<u32>(ns, 8192), 64, sW, cur, wl + (u64)1 * ns, cnt + LQ_C_WALK1, dD, dH, dBg, dDst); check_launch(); }
+				{ StageTimer t(this, sW, "k_sort_walk_lds<4096>"); LQ_LAUNCH((k_sort_walk_lds<4096>), std::min<u32>(ns, 1u << 16), 64, sW, cur, wl + (u64)0 * ns, cnt + LQ_C_WALK0, dD, dH, dBg, dDst); check_launch(); }
 			}
+			LQ_HIP_CHECK(hipEventRecord(L.ev_w1, L.streamW));
+			LQ_HIP_CHECK(hipStreamWaitEvent(sD, L.ev_w1, 0));
 			{
 				StageTimer t(this, sD, "k_sort_scatter", nA * 36);
 				LQ_LAUNCH(k_sort_scatter, g_seg, 256, sD, cur, L.seg_info.as<SegInfo>(), cnt + cur_slot, dA, dB, L.sort_dst.as<u32>());
@@ -933,6 +964,15 @@ void lqcov_handle::map_part(Part &pt)
 		lanes.emplace_back(new MapLane());
 		LQ_HIP_CHECK(hipStreamCreate(&lanes.back()->stream));
 		LQ_HIP_CHECK(hipStreamCreate(&lanes.back()->stream2));
+		{	// Token walks are latency-bound single-lane waves that live for milliseconds: left alone they fill the wave slots and
+			// the LDS of every CU and the bandwidth kernels of the other streams crawl (rocprofv3, configs[2]: k_ps_scatter 66 ms
+			// alone, 1100 ms beside the walkers).  Their stream may only use every fourth CU; 64 CUs x 32 waves are plenty for them.
+			uint32_t mask[8];
+			for (int i = 0; i < 8; ++i) mask[i] = getenv("LQCOV_WALK_CUS") ? (uint32_t)strtoul(getenv("LQCOV_WALK_CUS"), 0, 16) : 0x11111111u;
+			if (hipExtStreamCreateWithCUMask(&lanes.back()->streamW, 8, mask) != hipSuccess) { (void)hipGetLastError(); LQ_HIP_CHECK(hipStreamCreate(&lanes.back()->streamW)); }
+		}
+		LQ_HIP_CHECK(hipEventCreateWithFlags(&lanes.back()->ev_w0, hipEventDisableTiming));
+		LQ_HIP_CHECK(hipEventCreateWithFlags(&lanes.back()->ev_w1, hipEventDisableTiming));
 		LQ_HIP_CHECK(hipEventCreateWithFlags(&lanes.back()->ev_fork, hipEventDisableTiming));
 		LQ_HIP_CHECK(hipEventCreateWithFlags(&lanes.back()->ev_join, hipEventDisableTiming));
 		lanes.back()->prim.stream = lanes.back()->stream;
@@ -941,6 +981,12 @@ void lqcov_handle::map_part(Part &pt)
 		u32 npv = 0;
 		d2h(&npv, n_pv.as<u32>(), 1, stream);
 		pv_reserved = npv;
+		// room for this part's intervals up front: growing the pool later means draining every lane (map_batch)
+		const u64 want = std::min<u64>((u64)npv + nA_total / 16 + 4096, 0xfffffff0ULL);
+		if (want > pv_cap) {
+			grow_keep(pv, (u64)npv * sizeof(Ivl), want * sizeof(Ivl), stream);
+			pv_cap = (u32)std::min<u64>(pv.cap / sizeof(Ivl), 0xfffffff0ULL);
+		}
 	}
 #ifndef LQ_EMU
 	const bool concurrent = n_lanes > 1 && batches.size() > 1 && profiling != 1 && !dbg;
@@ -948,7 +994,11 @@ void lqcov_handle::map_part(Part &pt)
 	const bool concurrent = false;
 #endif
 	if (!concurrent) {
-		for (size_t i = 0; i < batches.size(); ++i) map_batch(*lanes[i % n_lanes], pt, batches[i].first, batches[i].second, h_aq, h_qmoff, dbg);
+		for (size_t i = 0; i < batches.size(); ++i) {
+			lq_alloc_stream = lanes[i % n_lanes]->stream;
+			map_batch(*lanes[i % n_lanes], pt, batches[i].first, batches[i].second, h_aq, h_qmoff, dbg);
+			lq_alloc_stream = nullptr;
+		}
 		for (auto &L : lanes) LQ_HIP_CHECK(hipStreamSynchronize(L->stream));
 	} else {
 		std::atomic<size_t> next(0);

@@ -56,7 +56,8 @@ struct PsWork {                           // one set of psort lists + the scratc
 struct MapLane {
 	hipStream_t stream = nullptr;         // klib's passes (queries with repeated minimizers), then runs and chains
 	hipStream_t stream2 = nullptr;        // the parallel sort of every other query, meanwhile
-	hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+	hipStream_t streamW = nullptr;        // the serial token walks: a stream confined to a quarter of the CUs (see map_part)
+	hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_w0 = nullptr, ev_w1 = nullptr;
 	DBuf sort_cnt, mhist;
 	DBuf ck_segs, ck_T, ck_E, ck_S, ck_slot, ck_n;   // checkpointed walks (kernels_ckpt.hpp)
 	PsWork ps[2];

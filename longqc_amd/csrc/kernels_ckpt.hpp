@@ -29,7 +29,6 @@
 #define LQ_CK_B 16                 // buckets a checkpointed pass may have (digits 0..15)
 #define LQ_CK_TILE 1024            // elements per prefix-count tile
 
-struct CkSeg { u32 sgi, tile0, ck0, n_ck; };      // one long sub-array: its segment, first tile, first checkpoint, checkpoints
 
 // digit counts of every tile (raw), strided over all tiles of all listed sub-arrays
 __global__ void __launch_bounds__(256)
@@ -145,8 +144,7 @@ k_ck_phases(const CkSeg *cks, u32 n_cks, const SortSeg *segs, const u8 *D, const
 	}
 }
 
-// state at every checkpoint (one wave each): checkpoint i of sub-array j sits at slot s of bucket k, picked so that the
-// weights w_k = number of buckets >= k (the expected length of a cycle started in bucket k) are spread evenly
+// state at every checkpoint (one wave each): checkpoint i of sub-array j sits at slot s of bucket k
 __global__ void __launch_bounds__(64)
 k_ck_solve(const CkSeg *cks, u32 n_cks, u32 n_ck_total, const SortSeg *segs, const u8 *D, const u32 *hist, const u32 *begs, const u32 *T,
            const u32 *E, u32 *S, u32 *CKS)
@@ -164,15 +162,30 @@ k_ck_solve(const CkSeg *cks, u32 n_cks, u32 n_ck_total, const SortSeg *segs, con
 		const u32 *Tj = T + (u64)ck.tile0 * LQ_CK_B;
 		const u32 *bg = begs + (u64)ck.sgi * 256, *cn = hist + (u64)ck.sgi * 256;
 		const u32 my_beg = lane < LQ_CK_B ? bg[lane] : 0;
-		// slot of this checkpoint: weight w_k per slot of bucket k, target = i / n_ck of the total
-		u64 wtot = 0;
-		for (u32 c = 0; c < LQ_CK_B; ++c) wtot += (u64)cn[c] * (LQ_CK_B - c);
+		// slot of this checkpoint: the checkpoints are shared out over the phases by the work each phase does (the elements
+		// picked up during it: known from the phase-end states) and spread evenly over the slots the phase looks at
+		u64 wtot = 0, wk_[LQ_CK_B];
+		{
+			u32 prev = 0;
+			for (u32 c = 0; c < LQ_CK_B; ++c) prev += bg[c];         // (sum of the starting cursors)
+			u64 before = prev;
+			for (u32 q = 0; q < LQ_CK_B; ++q) {
+				u64 sum = 0;
+				for (u32 c = 0; c < LQ_CK_B; ++c) sum += E[((u64)j * LQ_CK_B + q) * LQ_CK_B + c];
+				wk_[q] = sum - before; before = sum; wtot += wk_[q];
+			}
+		}
 		u64 want = wtot / ck.n_ck * i + wtot % ck.n_ck * i / ck.n_ck;
 		u32 k = 0, s = 0;
 		for (k = 0; k < LQ_CK_B; ++k) {
-			const u64 wk = (u64)cn[k] * (LQ_CK_B - k);
-			if (want < wk || k == LQ_CK_B - 1) { const u64 m = want / (LQ_CK_B - k); s = bg[k] + (u32)(m < cn[k] ? m : cn[k]); break; }
-			want -= wk;
+			if (want < wk_[k] || k == LQ_CK_B - 1) {
+				const u32 a0 = k ? E[((u64)j * LQ_CK_B + (k - 1)) * LQ_CK_B + k] : bg[k], e0 = bg[k] + cn[k];   // slots the phase looks at: [cursor at its start, end)
+				const u64 span = e0 > a0 ? e0 - a0 : 0;
+				s = a0 + (u32)(wk_[k] ? span * want / wk_[k] : 0);
+				if (s > e0) s = e0;
+				break;
+			}
+			want -= wk_[k];
 		}
 		if (i == 0) { k = 0; s = 0; }
 		u32 A;
@@ -191,5 +204,93 @@ k_ck_solve(const CkSeg *cks, u32 n_cks, u32 n_ck_total, const SortSeg *segs, con
 		if (k < nb) A = lq_ck_iterate(d, Tj, k, nb, A, pbeg, pend, my_beg, lh, sh, lane);
 		if (lane < LQ_CK_B) S[(u64)ci * LQ_CK_B + lane] = A;
 		if (lane == 0) CKS[ci] = s;
+	}
+}
+
+// ---- passes with many buckets (up to 256): the same states by following the elements in bulk ----------------------
+// With B buckets the rounds of the iteration above number about B ln(mass) and each would cost B prefix look-ups.  Here
+// the solver keeps, per bucket, the cursor A_c up to which the region has been read and the number of elements seen so
+// far with digit c (arr[c], in LDS); "bucket c has A_c - beg_c < arr[c]" means arrivals are waiting: the lane that owns c
+// reads the next elements of R_c and counts their digits.  Any order of doing that ends in the same least fixed point
+// (chaotic iteration of a monotone system), and every element is read once per sub-array.  One wave walks the outer
+// loop's slots in steps sized by the yield of the previous step (slots of the phase's bucket worth about len / n_ck
+// picked-up elements: a bigger step costs only logarithmically more rounds), and writes a checkpoint -- all 256 cursors and
+// the slot -- after each: the pieces come out balanced whatever the data looks like.
+#define LQ_CKW_STEP 16
+__global__ void __launch_bounds__(64)
+k_ck_chain256(const CkSeg *cks, u32 n_cks, const SortSeg *segs, const u8 *D, const u32 *hist, const u32 *begs, u32 *S, u32 *CKS)
+{
+	__shared__ u32 arr[256];
+	__shared__ u32 red[64];
+	const u32 lane = threadIdx.x;
+	for (u32 j = blockIdx.x; j < n_cks; j += gridDim.x) {
+		const CkSeg ck = cks[j];
+		const SortSeg sg = segs[ck.sgi];
+		const u8 *d = D + sg.off;
+		const u32 *bg = begs + (u64)ck.sgi * 256, *cn = hist + (u64)ck.sgi * 256;
+		u32 A[4], B0[4], E0[4];
+		for (int g = 0; g < 4; ++g) { const u32 c = (u32)g * 64 + lane; B0[g] = bg[c]; E0[g] = B0[g] + cn[c]; A[g] = B0[g]; arr[c] = 0; }
+		__syncthreads();
+		const u64 target = (u64)sg.len / ck.n_ck + 1;
+		u64 picked_at_last = 0, picked_before = 0;
+		u32 n_out = 0, est = LQ_CKW_STEP;                       // slots of the phase's bucket that are worth about `target` picked-up elements
+		// checkpoint 0: the start
+		for (int g = 0; g < 4; ++g) S[((u64)ck.ck0 + 0) * 256 + (u32)g * 64 + lane] = B0[g];
+		if (lane == 0) CKS[ck.ck0] = 0;
+		n_out = 1;
+		for (u32 k = 0; k < 256; ++k) {                          // phases of the outer loop
+			const u32 kl = k & 63, kg = k >> 6;
+			u32 ek = 0, ak = 0;
+			for (int g = 0; g < 4; ++g) if ((u32)g == kg) { ek = (u32)__builtin_amdgcn_readlane((int)E0[g], (int)kl); ak = (u32)__builtin_amdgcn_readlane((int)A[g], (int)kl); }
+			while (ak < ek) {
+				const u32 step = est;
+				u32 s = ek - ak > step ? ak + step : ek;                // the outer loop reaches slot s of bucket k
+				// fixed point with bucket k held at s
+				for (;;) {
+					bool pending = false;
+					for (int g = 0; g < 4; ++g) {
+						const u32 c = (u32)g * 64 + lane;
+						u32 need = c == k ? s : B0[g] + arr[c];
+						if (need > E0[g]) need = E0[g];
+						if (A[g] < need) {
+							for (u32 i = A[g]; i < need; ++i) atomicAdd(&arr[d[i]], 1u);
+							A[g] = need;
+							pending = true;
+						}
+					}
+					__syncthreads();
+					if (!__ballot(pending)) break;
+				}
+				// bucket k's cursor: slots filled = held value, unless arrivals already pushed it further
+				for (int g = 0; g < 4; ++g) if ((u32)g == kg) ak = (u32)__builtin_amdgcn_readlane((int)A[g], (int)kl);
+				if (ak < s) ak = s;
+				// elements picked up so far
+				u32 mine = 0;
+				for (int g = 0; g < 4; ++g) mine += A[g] - B0[g];
+				red[lane] = mine;
+				__syncthreads();
+				u64 picked = 0;
+				for (u32 x = 0; x < 64; ++x) picked += red[x];
+				__syncthreads();
+				{	// one step per checkpoint: the next step covers the slots that the last one's yield says are worth `target`
+					const u64 got = picked - picked_before;
+					picked_before = picked;
+					u64 e2 = got ? (u64)step * target / got : (u64)step * 4;
+					if (e2 > (u64)step * 4) e2 = (u64)step * 4;
+					est = (u32)(e2 < LQ_CKW_STEP ? LQ_CKW_STEP : e2 > (1u << 24) ? (1u << 24) : e2);
+				}
+				if (picked - picked_at_last >= target / 2 && n_out < ck.n_ck && ak < ek) {
+					for (int g = 0; g < 4; ++g) S[((u64)ck.ck0 + n_out) * 256 + (u32)g * 64 + lane] = A[g];
+					if (lane == 0) CKS[ck.ck0 + n_out] = ak;
+					++n_out; picked_at_last = picked;
+				}
+			}
+		}
+		// unused checkpoints: the final state (their walkers find nothing to do)
+		for (; n_out < ck.n_ck; ++n_out) {
+			for (int g = 0; g < 4; ++g) S[((u64)ck.ck0 + n_out) * 256 + (u32)g * 64 + lane] = E0[g];
+			if (lane == 0) CKS[ck.ck0 + n_out] = sg.len;
+		}
+		__syncthreads();
 	}
 }

@@ -15,9 +15,9 @@
 //     (per 4096-element tile: histogram -> one atomic range reservation per digit -> LDS-staged, run-contiguous
 //     writes into the other buffer; the order inside a bucket is whatever the atomics give, which is fine: the
 //     keys are distinct and the finish below looks at all remaining bits);
-//   * segments up to LQ_PS_FIN_BIG (8192) / LQ_PS_FIN_SMALL (1024) elements: finished by one block in LDS: split
-//     by the next 8 key bits, then every element ranks itself among the (few) elements of its sub-bucket by the full
-//     remaining key; written to A whatever buffer the segment was in.
+//   * segments up to LQ_PS_FIN_BIG (8192) / LQ_PS_FIN_SMALL (1024) elements: finished by one block: elements in
+//     registers, keys in LDS, split by the next 10 / 8 key bits, then every element ranks itself among the (few) elements
+//     of its sub-bucket by the full remaining key; written to A whatever buffer the segment was in.
 // All list lengths live on the device; kernels take upper-bound grids and stride over the lists.
 #pragma once
 #include "lq_common.hpp"
@@ -30,6 +30,7 @@ struct PPlan { u32 tile0, cnt0; };                   // first tile / first count
 #define LQ_PS_FIN_SMALL 1024
 #define LQ_PS_FIN_BIG   8192
 #define LQ_PS_TILE      4096
+#define LQ_PS_CHILD     4096      // aimed child size of a partition pass: half of what the finish takes
 #define LQ_PS_THREADS   256
 
 // counters of one batch's sort (device): indices into L.sort_cnt.  Two sets of psort lists: set 0 takes whole queries
@@ -217,14 +218,20 @@ k_ps_scatter(const PSeg *segs, const u32 *n_p, const PPlan *plan, const u32 *cnt
 	}
 }
 
-// ---- finish: one block sorts a segment by all its remaining key bits in LDS and writes it to A ----------------
-template <int CAP, int THREADS>
+// ---- finish: one block sorts a segment by all its remaining key bits and writes it to A -------------------------
+// Every thread keeps the elements it loaded in registers; LDS holds their keys, the sub-bucket histogram (the next
+// SB bits of the key) and the elements' indices grouped by sub-bucket.  An element's place = start of its sub-bucket +
+// the number of smaller keys in it (a handful of elements: about n / 2^SB).  All loads are done before the first store,
+// so the segment may be sorted in place.
+template <int CAP, int THREADS, int SB>
 __global__ void __launch_bounds__(THREADS)
 k_ps_finish(const PSeg *segs, const u32 *n_p, mm128 *A, const mm128 *B, KeyMap km)
 {
-	__shared__ mm128 e[CAP];
+	constexpr int NSB = 1 << SB, PER = CAP / THREADS, SPT = NSB / THREADS > 0 ? NSB / THREADS : 1;
+	static_assert(CAP % THREADS == 0 && (NSB % THREADS == 0 || NSB < THREADS), "shape");
+	__shared__ u64 keys[CAP];
 	__shared__ u16 perm[CAP];
-	__shared__ u32 hist[256], beg[256], fill[256], tmp[256];
+	__shared__ u32 hist[NSB], beg[NSB], fill[NSB], wsum[THREADS / 64 + 1];
 	const u32 n_seg = *n_p, t = threadIdx.x;
 	for (u32 s = blockIdx.x; s < n_seg; s += gridDim.x) {
 		const PSeg sg = segs[s];
@@ -235,24 +242,48 @@ k_ps_finish(const PSeg *segs, const u32 *n_p, mm128 *A, const mm128 *B, KeyMap k
 			if (sg.buf) for (u32 i = t; i < n; i += THREADS) out[i] = src[i];
 			continue;
 		}
-		const u32 nb = sg.rem < 8 ? sg.rem : 8, sh = sg.rem - nb, dm = (1u << nb) - 1;
+		const u32 nb = sg.rem < SB ? sg.rem : SB, sh = sg.rem - nb;
 		const u64 km_mask = sg.rem >= 64 ? ~0ULL : ((1ULL << sg.rem) - 1);
-		if (t < 256) { hist[t] = 0; fill[t] = 0; }
+		for (u32 c = t; c < NSB; c += THREADS) { hist[c] = 0; fill[c] = 0; }
 		__syncthreads();
-		for (u32 i = t; i < n; i += THREADS) { const mm128 a = src[i]; e[i] = a; atomicAdd(&hist[(u32)(lq_ckey(a.x, km) >> sh) & dm], 1u); }
+		mm128 e[PER];
+		for (int k = 0; k < PER; ++k) {
+			const u32 i = t + (u32)k * THREADS;
+			if (i < n) { e[k] = src[i]; const u64 key = lq_ckey(e[k].x, km) & km_mask; keys[i] = key; atomicAdd(&hist[(u32)(key >> sh)], 1u); }
+		}
 		__syncthreads();
-		if (t < 256) beg[t] = hist[t];
+		{	// exclusive scan of hist -> beg: SPT counters per thread, wave scan, wave totals through LDS
+			u32 v[SPT], sum = 0;
+			for (int q = 0; q < SPT; ++q) { const u32 c = t * SPT + q; v[q] = c < (u32)NSB ? hist[c] : 0; sum += v[q]; }
+			u32 inc = sum;
+			for (int d = 1; d < 64; d <<= 1) { const u32 o = __shfl_up(inc, d); if ((int)(t & 63) >= d) inc += o; }
+			if ((t & 63) == 63) wsum[t >> 6] = inc;
+			__syncthreads();
+			u32 base = 0;
+			for (u32 w = 0; w < (t >> 6); ++w) base += wsum[w];
+			u32 run = base + inc - sum;
+			for (int q = 0; q < SPT; ++q) { const u32 c = t * SPT + q; if (c < (u32)NSB) beg[c] = run; run += v[q]; }
+		}
 		__syncthreads();
-		lq_scan256(beg, tmp, nullptr);
-		for (u32 i = t; i < n; i += THREADS) { const u32 d = (u32)(lq_ckey(e[i].x, km) >> sh) & dm; perm[beg[d] + atomicAdd(&fill[d], 1u)] = (u16)i; }
+		for (int k = 0; k < PER; ++k) {
+			const u32 i = t + (u32)k * THREADS;
+			if (i < n) { const u32 d = (u32)(keys[i] >> sh); perm[beg[d] + atomicAdd(&fill[d], 1u)] = (u16)i; }
+		}
 		__syncthreads();
-		for (u32 p = t; p < n; p += THREADS) {
-			const mm128 a = e[perm[p]];
-			const u64 key = lq_ckey(a.x, km) & km_mask;
-			const u32 d = (u32)(key >> sh), b0 = beg[d], b1 = b0 + hist[d];
-			u32 r = 0;
-			for (u32 j = b0; j < b1; ++j) r += (lq_ckey(e[perm[j]].x, km) & km_mask) < key;
-			out[b0 + r] = a;
+		u32 pos[PER];
+		for (int k = 0; k < PER; ++k) {
+			const u32 i = t + (u32)k * THREADS;
+			if (i < n) {
+				const u64 key = keys[i];
+				const u32 d = (u32)(key >> sh), b0 = beg[d], b1 = b0 + hist[d];
+				u32 r = 0;
+				for (u32 j = b0; j < b1; ++j) r += keys[perm[j]] < key;
+				pos[k] = b0 + r;
+			}
+		}
+		for (int k = 0; k < PER; ++k) {
+			const u32 i = t + (u32)k * THREADS;
+			if (i < n) out[pos[k]] = e[k];
 		}
 		__syncthreads();
 	}

@@ -24,6 +24,7 @@
 //                      finished with the (stable, hence unique) insertion sort klib uses (ksort.h:87-97).
 #pragma once
 #include "lq_common.hpp"
+struct CkSeg { u32 sgi, tile0, ck0, n_ck; };      // one long sub-array of a checkpointed pass (kernels_ckpt.hpp): its segment, first prefix tile, first checkpoint, checkpoints
 
 // Block-cooperative kernels are written in phases: LQ_BLOCK_LOOP(t) { ... } runs its body once per thread of
 // the block (t = thread index), LQ_BLOCK_SYNC() separates phases.
@@ -351,14 +352,25 @@ __device__ __forceinline__ u64 lq_lds_u64(const u64 *p)
 #endif
 #define LQ_SOLO_PEND 0x80000000u
 __global__ void __launch_bounds__(64)
-k_sort_walk_solo(const SortSeg *segs, const u32 *list, const u32 *n_list_p, const u8 *D, const u32 *hist, const u32 *begs, u32 *dst)
+k_sort_walk_solo(const SortSeg *segs, const u32 *list, const u32 *n_list_p, const u8 *D, const u32 *hist, const u32 *begs, u32 *dst,
+                 const CkSeg *cks, u32 n_cks, const u32 *ck_S, const u32 *ck_slot)
 {
 	LQ_SHARED __attribute__((aligned(16))) u8 win[256][16];   // DMA landing windows: 16 digits of each bucket's stream
 	LQ_SHARED u64 ent[256];                                   // low: cursor | PEND, high: the digits from the cursor to the next 4-byte boundary
 	LQ_SHARED u32 endb[256];
 	const u32 n_list = *n_list_p;
 	for (u32 li = blockIdx.x; li < n_list; li += gridDim.x) {
-	const u32 sgi = list[li];
+	// work item: a whole sub-array of the list, or (cks != null) one checkpoint of kernels_ckpt.hpp: start from its cursors,
+	// stop when the outer loop reaches the next checkpoint's slot
+	u32 sgi, s_end = 0xffffffffu;
+	const u32 *start = nullptr;
+	if (cks) {
+		u32 lo = 0, hi = n_cks;
+		while (hi - lo > 1) { const u32 mid = lo + ((hi - lo) >> 1); if (cks[mid].ck0 <= li) lo = mid; else hi = mid; }
+		sgi = cks[lo].sgi;
+		start = ck_S + (u64)li * 256;
+		if (li + 1 < cks[lo].ck0 + cks[lo].n_ck) s_end = ck_slot[li + 1];
+	} else sgi = list[li];
 	const SortSeg sg = segs[sgi];
 	const u32 *cnt = hist + (u64)sgi * 256, *bg = begs + (u64)sgi * 256;
 	const u64 base = sg.off;                                  // D is 16-byte aligned; this sub-array's digits start at D[base]
@@ -366,8 +378,8 @@ k_sort_walk_solo(const SortSeg *segs, const u32 *list, const u32 *n_list_p, cons
 	u32 *ds = dst + sg.off;
 	LQ_BLOCK_LOOP(t) {
 		for (u32 c = t; c < 256; c += blockDim.x) {
-			const u32 b = bg[c];
-			endb[c] = b + cnt[c];
+			const u32 b = start ? start[c] : bg[c];
+			endb[c] = bg[c] + cnt[c];
 			const u8 *w = D + ((base + b) & ~(u64)15);
 			for (int i = 0; i < 16; ++i) win[c][i] = w[i];
 			const u32 o = (b15 + b) & 15;
@@ -391,6 +403,7 @@ k_sort_walk_solo(const SortSeg *segs, const u32 *list, const u32 *n_list_p, cons
 		if (k >= 256) break;
 		const u64 he = LQ_LDS_U64(&ent[k]);
 		u32 hole = LQ_UNI((u32)he), hdq = LQ_UNI((u32)(he >> 32));
+		if ((hole & ~LQ_SOLO_PEND) >= s_end) break;               // the next checkpoint's walker takes over from this slot
 		if (hole & LQ_SOLO_PEND) { LQ_WAIT_VM0(); hole &= ~LQ_SOLO_PEND; hdq = LQ_UNI(LQ_LDS_U32(&win[k][0])); }
 		u32 src = hole, l = hdq & 0xff;
 		// CARRY: the carried element takes the slot under its bucket's cursor; that slot's occupant is carried on

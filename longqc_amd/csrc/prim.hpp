@@ -19,19 +19,75 @@
 	throw std::runtime_error(std::string(#expr) + ": emu error"); } while (0)
 #endif
 
-// grow-only device buffer
+// grow-only device buffer.  Inside the mapping lanes growth must not stall the device: hipFree / hipMalloc wait for every
+// stream (rocprofv3 showed 80-120 ms holes in a lane's kernel chain whenever one of its work buffers grew while the other
+// lanes were inside long kernels).  A lane thread therefore names its stream in lq_alloc_stream and its buffers are taken
+// from and returned to HIP's stream-ordered pool (hipMallocAsync / hipFreeAsync, release threshold raised so that
+// returned blocks stay cached).
+#ifndef LQ_EMU
+inline thread_local hipStream_t lq_alloc_stream = nullptr;
+inline void lq_pool_keep_memory(int device)
+{
+	hipMemPool_t pool = nullptr;
+	if (hipDeviceGetDefaultMemPool(&pool, device) == hipSuccess && pool) {
+		uint64_t keep = ~0ULL;
+		hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+	}
+}
+#else
+inline thread_local hipStream_t lq_alloc_stream = nullptr;
+inline void lq_pool_keep_memory(int) {}
+#endif
+
 struct DBuf {
 	void *p = nullptr; size_t cap = 0;
+	hipStream_t pool_stream = nullptr;     // not null: the block came from the stream-ordered pool on this stream
 	void ensure(size_t bytes)
 	{
 		if (bytes <= cap) return;
-		if (p) LQ_HIP_CHECK(hipFree(p));
-		p = nullptr; cap = 0;
+		release();
 		size_t want = bytes + bytes / 8 + 256;
-		LQ_HIP_CHECK(hipMalloc(&p, want));
+#ifndef LQ_EMU
+		if (lq_alloc_stream) {
+			want = bytes + bytes / 4 + 4096;                       // a little more head room: regrowth is what this is about
+			hipError_t e = hipMallocAsync(&p, want, lq_alloc_stream);
+			if (e == hipErrorOutOfMemory) {
+				(void)hipGetLastError();
+				(void)hipDeviceSynchronize();
+				int dev = 0; hipMemPool_t pool = nullptr;
+				if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess && pool) (void)hipMemPoolTrimTo(pool, 0);
+				e = hipMallocAsync(&p, want, lq_alloc_stream);
+			}
+			LQ_HIP_CHECK(e);
+			pool_stream = lq_alloc_stream;
+			cap = want;
+			return;
+		}
+#endif
+		hipError_t e = hipMalloc(&p, want);
+#ifndef LQ_EMU
+		if (e == hipErrorOutOfMemory) {                            // blocks cached by the stream-ordered pool count as used: hand them back and try again
+			(void)hipGetLastError();
+			(void)hipDeviceSynchronize();
+			int dev = 0; hipMemPool_t pool = nullptr;
+			if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess && pool) (void)hipMemPoolTrimTo(pool, 0);
+			e = hipMalloc(&p, want);
+		}
+#endif
+		LQ_HIP_CHECK(e);
 		cap = want;
 	}
-	void release() { if (p) hipFree(p); p = nullptr; cap = 0; }
+	void release()
+	{
+		if (p) {
+#ifndef LQ_EMU
+			if (pool_stream) (void)hipFreeAsync(p, lq_alloc_stream ? lq_alloc_stream : pool_stream);
+			else
+#endif
+			(void)hipFree(p);
+		}
+		p = nullptr; cap = 0; pool_stream = nullptr;
+	}
 	template <class T> T *as() const { return (T*)p; }
 	~DBuf() { release(); }
 	DBuf() {}

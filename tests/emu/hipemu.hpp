@@ -52,6 +52,7 @@ inline hipError_t hipGetDeviceCount(int *n) { *n = 1; return hipSuccess; }
 inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
 inline hipError_t hipStreamCreate(hipStream_t *s) { *s = nullptr; return hipSuccess; }
 inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
+inline hipError_t hipExtStreamCreateWithCUMask(hipStream_t *s, unsigned, const unsigned *) { *s = nullptr; return hipSuccess; }
 inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 inline hipError_t hipStreamWaitEvent(hipStream_t, void *, unsigned = 0) { return hipSuccess; }
 inline hipError_t hipMalloc(void **p, size_t n) { *p = std::malloc(n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }

@@ -1,6 +1,6 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
-for L in 6 8; do
+for L in 2 4 6; do
   LQCOV_LANES=$L timeout 300 python bench.py --steps 2 --warmup 1 --no-cpu-baseline 2>&1 | tail -1 | python -c "
 import sys, json
 j = json.loads(sys.stdin.read())

@@ -32,7 +32,7 @@ int main(int argc, char **argv)
 	const int copies_hi = argc > 2 ? atoi(argv[2]) : 1024;
 	const int only_b = argc > 3 ? atoi(argv[3]) : 0;
 	struct Case { const char *name; int B; int runs; };
-	const Case cases[] = { {"B=6 random", 6, 1}, {"B=6 runs of 37", 6, 37}, {"B=16 random", 16, 1}, {"B=3 runs of 5", 3, 5}, {"B=50 random", 50, 1}, {"B=79 random", 79, 1}, {"B=100 random", 100, 1}, {"B=196 random", 196, 1}, {"B=256 random", 256, 1} };
+	const Case cases[] = { {"B=6 random", 6, 1}, {"B=6 runs of 37", 6, 37}, {"B=16 random", 16, 1}, {"B=3 runs of 5", 3, 5}, {"B=50 random", 50, 1}, {"B=79 random", 79, 1}, {"B=100 random", 100, 1}, {"B=196 random", 196, 1}, {"B=200 runs of 3", 200, 3}, {"B=256 random", 256, 1} };
 	for (const Case &cs : cases) {
 		if (only_b && cs.B != only_b) continue;
 		std::mt19937_64 rng(12345 + cs.B);
@@ -72,11 +72,31 @@ int main(int argc, char **argv)
 				printf("%-16s copies %5d  %-22s %9.3f ms  %7.1f ns/trip  %s\n", cs.name, copies, name, ms, ms * 1e6 / N, ok ? "ok" : "MISMATCH");
 				fflush(stdout);
 			};
-			run("solo (LDS state)", [&] { hipLaunchKernelGGL(k_sort_walk_solo, dim3(copies), dim3(64), 0, 0, dS, dList, dN, dD, dH, dB, dDst); });
+			run("solo (LDS state)", [&] { hipLaunchKernelGGL(k_sort_walk_solo, dim3(copies), dim3(64), 0, 0, dS, dList, dN, dD, dH, dB, dDst, (const CkSeg*)nullptr, 0u, (const u32*)nullptr, (const u32*)nullptr); });
 			const CkSeg *nock = nullptr; const u32 *nou = nullptr;
 			if (cs.B <= 64) run("reg<1>", [&] { hipLaunchKernelGGL((k_sort_walk_reg<1>), dim3(copies), dim3(64), 0, 0, dS, dList, dN, dD, dH, dB, dDst, nock, 0u, nou, nou); });
 			if (cs.B <= 128) run("reg<2>", [&] { hipLaunchKernelGGL((k_sort_walk_reg<2>), dim3(copies), dim3(64), 0, 0, dS, dList, dN, dD, dH, dB, dDst, nock, 0u, nou, nou); });
 			run("reg<4>", [&] { hipLaunchKernelGGL((k_sort_walk_reg<4>), dim3(copies), dim3(64), 0, 0, dS, dList, dN, dD, dH, dB, dDst, nock, 0u, nou, nou); });
+			if (cs.B > LQ_CK_B) {
+				// many buckets: states by following the elements in bulk (k_ck_chain256), pieces by the solo walker
+				const u32 n_ck1 = std::min<u32>(64, std::max<u32>(2, N / 16384));
+				std::vector<CkSeg> hck(copies);
+				u32 ckt = 0;
+				for (int c = 0; c < copies; ++c) { hck[c].sgi = c; hck[c].tile0 = 0; hck[c].ck0 = ckt; hck[c].n_ck = n_ck1; ckt += n_ck1; }
+				CkSeg *dck; u32 *dSt, *dSl, *dNck;
+				CK(hipMalloc(&dck, sizeof(CkSeg) * copies)); CK(hipMalloc(&dSt, (u64)ckt * 256 * 4)); CK(hipMalloc(&dSl, (u64)ckt * 4 + 4)); CK(hipMalloc(&dNck, 4));
+				CK(hipMemcpy(dck, hck.data(), sizeof(CkSeg) * copies, hipMemcpyHostToDevice)); CK(hipMemcpy(dNck, &ckt, 4, hipMemcpyHostToDevice));
+				char nm[64]; snprintf(nm, sizeof(nm), "ckpt256 x%u (all)", n_ck1);
+				const u32 *nou2 = nullptr;
+				run(nm, [&] {
+					hipLaunchKernelGGL(k_ck_chain256, dim3(copies), dim3(64), 0, 0, dck, (u32)copies, dS, dD, dH, dB, dSt, dSl);
+					hipLaunchKernelGGL(k_sort_walk_solo, dim3(std::min<u32>(ckt, 1u << 18)), dim3(64), 0, 0, dS, nou2, dNck, dD, dH, dB, dDst, dck, (u32)copies, dSt, dSl);
+				});
+				run("  of which walk pieces", [&] {
+					hipLaunchKernelGGL(k_sort_walk_solo, dim3(std::min<u32>(ckt, 1u << 18)), dim3(64), 0, 0, dS, nou2, dNck, dD, dH, dB, dDst, dck, (u32)copies, dSt, dSl);
+				});
+				hipFree(dck); hipFree(dSt); hipFree(dSl); hipFree(dNck);
+			}
 			if (cs.B <= LQ_CK_B) {
 				// checkpointed: the walk of every copy cut into n_ck pieces from computed states (kernels_ckpt.hpp)
 				const u32 n_ck1 = std::min<u32>(512, std::max<u32>(2, N / 16384));
