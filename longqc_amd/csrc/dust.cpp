@@ -117,8 +117,11 @@ int lqsdust_main(int argc, const char *const *argv, const char *out_path, const 
 			const char *v = a[2] ? a + 2 : (i + 1 < argc ? argv[++i] : nullptr);
 			if (!v) { fprintf(e, "sdust: option requires an argument -- '%c'\n", a[1]); if (err_path) fclose(e); return 1; }
 			if (a[1] == 'w') W = atoi(v); else T = atoi(v);
+		} else if (a[0] == '-' && a[1]) {                      // getopt rejects what "w:t:" does not name
+			fprintf(e, "sdust: invalid option -- '%c'\nUsage: sdust [-w %d] [-t %d] <in.fa>\n", a[1], W, T); if (err_path) fclose(e); return 1;
 		} else if (!in) in = a;
 	}
+	if (in && !strcmp(in, "-")) in = "/dev/stdin";            // sdust.c:197: "-" reads standard input
 	if (!in) { fprintf(e, "Usage: sdust [-w %d] [-t %d] <in.fa>\n", W, T); if (err_path) fclose(e); return 1; }
 	char err[512] = {0};
 	int rc = guarded(err, sizeof(err), [&] {

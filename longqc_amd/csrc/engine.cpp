@@ -658,11 +658,11 @@ void lqcov_handle::psort_run(MapLane &L, int set, hipStream_t s, u64 nA, const K
 	}
 	{
 		StageTimer t(this, s, "k_ps_finish<8192>", nA * 32);
-		LQ_LAUNCH((k_ps_finish<LQ_PS_FIN_BIG, 1024, 10>), (u32)std::min<u64>(Ls.cap_fin, 4096), 1024, s, Ls.fin_b, cnt + LQ_P_FIN_B, dA, dB, km); check_launch();
+		LQ_LAUNCH((k_ps_finish<LQ_PS_FIN_BIG, 1024, 10>), (u32)std::min<u64>(std::min<u64>(Ls.cap_fin, nA / LQ_PS_FIN_SMALL + 64), 4096), 1024, s, Ls.fin_b, cnt + LQ_P_FIN_B, dA, dB, km); check_launch();
 	}
 	{
 		StageTimer t(this, s, "k_ps_finish<1024>", nA * 32);
-		LQ_LAUNCH((k_ps_finish<LQ_PS_FIN_SMALL, 256, 8>), (u32)std::min<u64>(Ls.cap_fin, 32768), 256, s, Ls.fin_s, cnt + LQ_P_FIN_S, dA, dB, km); check_launch();
+		LQ_LAUNCH((k_ps_finish<LQ_PS_FIN_SMALL, 256, 8>), (u32)std::min<u64>(std::min<u64>(Ls.cap_fin, nA / 16 + 256), 32768), 256, s, Ls.fin_s, cnt + LQ_P_FIN_S, dA, dB, km); check_launch();
 	}
 }
 
@@ -1409,5 +1409,14 @@ int lqcov_handle::run_files(const char *target, const char *query, FILE *out, FI
 	if (!query) return 0;                                         // index only (minimap2-coverage.c:460-468)
 	finish();
 	write_table(out);
+	// A uint16 match counter that reaches 65535 makes the reference's result depend on the order in which it happened to
+	// process the chains (esterr.c:130,136 test a[st], not a[j]); the row is printed, but the run says so and does not
+	// report success.
+	u32 n_sat = 0;
+	for (u32 i = 0; i < q.n; ++i) if (rows[i].flags & LQCOV_ROW_SATURATED) {
+		if (log && n_sat < 10) fprintf(log, "[WARNING] query %s: a match counter reached 65535 (esterr.c:130,136): its row is not guaranteed to equal the reference's\n", q.names[q_inv[i]].c_str());
+		++n_sat;
+	}
+	if (n_sat) throw std::domain_error(std::to_string(n_sat) + " quer" + (n_sat == 1 ? "y" : "ies") + " with a saturated uint16 match counter (esterr.c:130,136): table written, rows flagged LQCOV_ROW_SATURATED are not guaranteed");
 	return 0;
 }

@@ -62,6 +62,7 @@ class FastxReader {
 	{
 		if (dret) *dret = 0;
 		if (begin_ >= end_ && eof_) return false;
+		bool got_any = false;                                  // a byte or a delimiter was consumed
 		for (;;) {
 			if (begin_ >= end_) {
 				if (eof_) break;
@@ -74,9 +75,11 @@ class FastxReader {
 			if (space_delim) while (i < end_ && !isspace(buf_[i])) ++i;
 			else while (i < end_ && buf_[i] != '\n') ++i;
 			s.append((const char*)buf_.data() + begin_, (size_t)(i - begin_));
+			if (i > begin_ || i < end_) got_any = true;
 			begin_ = i + 1;
 			if (i < end_) { if (dret) *dret = buf_[i]; break; }
 		}
+		if (!got_any) return false;                            // the stream ended exactly here: no record (kseq.h: ks_getuntil2 returns -1)
 		if (!space_delim && s.size() > 1 && s.back() == '\r') s.pop_back();
 		return true;
 	}

@@ -137,7 +137,12 @@ k_sdust(const u8 *seq, const u8 *qual, const u64 *seq_off, u32 n_reads, i32 W, i
 	u32 qv = 0;
 	if (qual && len > 0 && qual[off] != 0) {
 		const u8 *q = qual + off;
-		for (i32 i = 0; i < len; ++i) { const i32 v = (i32)q[i]; ps += q2p[v - 33]; if (v > 7 + 33) ++qv; }
+		for (i32 i = 0; i < len; ++i) {
+			const i32 v = (i32)(signed char)q[i];                       // (char arithmetic, as lqutils.c:51-56 and k_qual_sum)
+			const i32 t = v - 33;
+			ps += q2p[t < 0 ? 0 : t > 126 ? 126 : t];                  // the reference indexes out of bounds outside Q0..Q126: clamped, like k_qual_sum
+			if (v > 7 + 33) ++qv;
+		}
 	}
 	psum_out[r] = ps; qv_out[r] = qv;
 	}

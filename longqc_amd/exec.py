@@ -15,12 +15,21 @@ from __future__ import annotations
 import ctypes as C
 import os
 import subprocess
+import tempfile
 import threading
 from typing import Optional, Sequence
 
 from . import api
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
+# in-process runs on one device take turns: every handle sizes its work space from the HBM that is free when it is created
+_DEVICE_LOCKS = {}
+_DEVICE_LOCKS_GUARD = threading.Lock()
+
+
+def _device_lock(device: int) -> threading.Lock:
+    with _DEVICE_LOCKS_GUARD:
+        return _DEVICE_LOCKS.setdefault(device, threading.Lock())
 
 
 def run_argv(argv: Sequence[str], out: Optional[str] = None, err: Optional[str] = None, device: int = 0) -> int:
@@ -40,6 +49,7 @@ class LqCovExec:
         self._thread = None
         self._rc = None
         self._err_path = None
+        self.out_path = None
 
     def exec(self, *args, out=None, err=None):
         self._err_path = err
@@ -57,9 +67,17 @@ class LqCovExec:
                     ferr.close()
             return
 
+        # the reference pipes what the caller does not name (and never reads the pipes): here such output goes to files of
+        # its own instead of the host process's stdout / stderr
+        if out is None:
+            out = self.out_path = tempfile.NamedTemporaryFile(prefix="lqcov_out_", suffix=".tsv", delete=False).name
+        if err is None:
+            err = self._err_path = tempfile.NamedTemporaryFile(prefix="lqcov_err_", suffix=".log", delete=False).name
+
         def work():
             try:
-                self._rc = run_argv(args, out=out, err=err, device=self.device)
+                with _device_lock(self.device):
+                    self._rc = run_argv(args, out=out, err=err, device=self.device)
             except Exception as e:  # library missing etc.: surface it through get_poll()/get_error()
                 self._exc = e
                 self._rc = -3

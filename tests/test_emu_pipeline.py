@@ -245,3 +245,22 @@ def test_emulated_checkpointed_walks(emu_lib, tmp_path, monkeypatch, variant):
     assert rc == 0, err
     assert out == want
     assert sum(1 for l in out.splitlines() if l.split("\t")[2] != "0") >= 4
+
+
+def test_emulated_ultra_long_reads(emu_lib, tmp_path):
+    """reads of 100-350 kb at 30x (the shape of BASELINE configs[4]): (query, strand) sub-arrays of 10^5 anchors and runs
+    of thousands per target; the three longest as queries, against the reference binary (or the oracle)"""
+    import dataclasses
+    from longqc_amd import synth
+    cfg = dataclasses.replace(synth.CONFIGS["cfg5"], n_reads=200, nsample=200, depth=30.0)
+    genome = synth.make_genome(cfg)
+    T = synth.make_reads(cfg, genome)
+    order = sorted(range(len(T)), key=lambda i: -int(T.seqs[i].shape[0]))[:3]
+    Q = T.subset(order)
+    tf, qf = str(tmp_path / "all.fq"), str(tmp_path / "sub.fq")
+    synth.write_fastq(tf, T); synth.write_fastq(qf, Q)
+    argv = ONT + [tf, qf]
+    rc, out, err = run_main(emu_lib, argv)
+    assert rc == 0, err
+    want = oracle_bind.ref_table(argv) if oracle_bind.have_ref() else oracle_bind.table(argv)
+    assert out == want

@@ -99,11 +99,11 @@ def test_gpu_midsize_slice_of_cfg2_vs_reference_or_oracle(gpu_lib, tmp_path):
 
 
 def test_gpu_properties_at_scale(gpu_lib, tmp_path):
-    """Size-independent properties on a larger run (20k reads ~15 kb = 40 % of configs[1]; LQCOV_FULL_SCALE=1 runs
-    the full 50k): determinism, query independence (a query's row does not depend on which other queries ride
+    """Size-independent properties at the size of BASELINE configs[1] (50k ONT reads ~15 kb, 744 Mbases; LQCOV_QUICK_SCALE=1
+    runs 20k): determinism, query independence (a query's row does not depend on which other queries ride
     along or on the anchor batching), row sanity, and spot rows against the reference binary."""
     import dataclasses
-    n = 50000 if os.environ.get("LQCOV_FULL_SCALE") else 20000
+    n = 20000 if os.environ.get("LQCOV_QUICK_SCALE") else 50000        # all of configs[1] unless asked otherwise
     cfg = dataclasses.replace(synth.CONFIGS["cfg2"], n_reads=n, nsample=2000)
     genome = synth.make_genome(cfg)
     T = synth.make_reads(cfg, genome)
@@ -151,6 +151,88 @@ def test_gpu_properties_at_scale(gpu_lib, tmp_path):
         synth.write_fastq(tf, T); synth.write_fastq(qf, sub)
         want = oracle_bind.ref_table(["-Y", "-l", "0", "-q", "160", "-k", "12", "-w", "5", "-I", "4G", "-p", "160", "-t", str(os.cpu_count() or 4), tf, qf]).splitlines()
         assert t2 == want
+
+
+def test_gpu_slice_of_configs2_vs_reference(gpu_lib, tmp_path):
+    """1 % of BASELINE configs[2] (5000 of the 500k PacBio CLR reads ~10 kb, pb-sequel preset -p 80, 100 queries) against
+    the reference binary"""
+    import dataclasses
+    cfg = dataclasses.replace(synth.CONFIGS["cfg3"], n_reads=5000, nsample=100)
+    T, Q = synth.make_dataset(cfg)
+    tf, qf = str(tmp_path / "all.fq"), str(tmp_path / "sub.fq")
+    synth.write_fastq(tf, T); synth.write_fastq(qf, Q)
+    argv = ["-Y", "-l", "0", "-q", "160", "-k", "12", "-w", "5", "-I", "4G", "-p", "80", "-t", "8", tf, qf]
+    rc, out, err = run_main(gpu_lib, argv)
+    assert rc == 0, err
+    want = oracle_bind.ref_table(argv) if oracle_bind.have_ref() else oracle_bind.table(argv)
+    assert out == want
+
+
+def test_gpu_full_configs2_rows_equal_the_reference_fixture(gpu_lib):
+    """ALL of BASELINE configs[2] as targets (500k reads, 5.2 Gbases: a 4.0-Gbase and a 1.2-Gbase index part by the rule of
+    index.c:244) and the 40 queries for which the reference binary's rows were recorded in the build container
+    (tests/golden/make_scale_golden.py -> cfg3_rows.json): byte-identical rows.  LQCOV_SKIP_FULL_CFG3=1 skips it."""
+    if os.environ.get("LQCOV_SKIP_FULL_CFG3"):
+        pytest.skip("asked to skip the full-size run")
+    from longqc_amd import multigpu
+    g = json.load(open(os.path.join(GOLDEN, "cfg3_rows.json")))
+    cfg = synth.CONFIGS["cfg3"]
+    genome = synth.make_genome(cfg)
+    F = synth.make_reads_flat(cfg, genome)
+    Q = synth.make_reads(cfg, genome, indices=g["read_indices"])
+    assert [int(s.shape[0]) for s in Q.seqs] == g["query_lengths"]
+    p, _, _ = api.parse_args(g["argv"] + ["t", "q"])
+    lens = np.diff(F.off).astype(np.int64)
+    parts = multigpu.split_parts(lens, int(p.batch_size), int(p.idx_mini_batch))
+    assert len(parts) == 2
+    P = api.PackedReads(F.flat, F.off, F.names(), lib=gpu_lib)
+    eng = api.Engine(p, 0, lib=gpu_lib)
+    eng.set_queries(Q.names, Q.seqs, Q.quals)
+    pt = eng.part_begin()
+    for lo, hi in parts:
+        eng.part_clear(pt)
+        eng.part_add_packed(pt, P, lo, hi)
+        eng.part_build(pt); eng.part_map(pt)
+    eng.finish()
+    rows = eng.table_text().splitlines()
+    eng.close(); P.close()
+    assert rows == g["rows"]
+
+
+def test_gpu_ultra_long_reads_vs_reference(gpu_lib, tmp_path):
+    """the shape of BASELINE configs[4]: reads of 100-600 kb (N50 ~100 kb) at 30x over a small genome -- every query meets
+    every target, (query, strand, target) runs of 10^4+ anchors, sub-arrays of 10^6 -- against the reference binary"""
+    import dataclasses
+    cfg = dataclasses.replace(synth.CONFIGS["cfg5"], n_reads=200, nsample=200, depth=30.0)
+    genome = synth.make_genome(cfg)
+    T = synth.make_reads(cfg, genome)
+    order = sorted(range(len(T)), key=lambda i: -int(T.seqs[i].shape[0]))[:24]
+    Q = T.subset(order)
+    assert max(int(s.shape[0]) for s in Q.seqs) > 200000
+    tf, qf = str(tmp_path / "all.fq"), str(tmp_path / "sub.fq")
+    synth.write_fastq(tf, T); synth.write_fastq(qf, Q)
+    argv = ONT + [tf, qf]
+    rc, out, err = run_main(gpu_lib, argv)
+    assert rc == 0, err
+    want = oracle_bind.ref_table(argv) if oracle_bind.have_ref() else oracle_bind.table(argv)
+    assert out == want
+
+
+@pytest.mark.parametrize("shift", ["3", "7"])
+def test_gpu_parallel_sort_size_classes(gpu_lib, datasets, monkeypatch, shift):
+    """the parallel sort (kernels_psort.hpp) with its size classes shrunk: several partition passes on small inputs"""
+    tf, qf = datasets("cfg1")
+    argv = ONT + [tf, qf]
+    want = oracle_bind.table(argv)
+    monkeypatch.setenv("LQCOV_PS_SHIFT", shift)
+    rc, out, err = run_main(gpu_lib, argv)
+    assert rc == 0, err
+    assert out == want
+
+
+@pytest.mark.parametrize("variant", ["ckpt", "ckpt_all_klib", "plain"])
+def test_gpu_checkpointed_walks(gpu_lib, tmp_path, monkeypatch, variant):
+    E.test_emulated_checkpointed_walks(gpu_lib, tmp_path, monkeypatch, variant)
 
 
 @pytest.mark.parametrize("shift", ["4", "7", "12"])

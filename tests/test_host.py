@@ -53,6 +53,22 @@ def test_truncated_quality_ends_the_stream_like_kseq(emu_lib, tmp_path):
     assert [l.split("\t")[0] for l in out.splitlines()] == ["a"]
 
 
+def test_lone_header_character_at_the_end_is_no_record(emu_lib, tmp_path):
+    """a stream that ends right after a '@' / '>' yields no further record (kseq.h: ks_getuntil2 returns -1 there),
+    neither as a query nor as a target"""
+    seq = b"ACGTACGTACGTAAGGCCTTACGATCGATCGACTAGCTAGCATCGA"
+    q = str(tmp_path / "q.fq")
+    _write(q, b"@a\n" + seq + b"\n+\n" + b"I" * len(seq) + b"\n@")
+    t = str(tmp_path / "t.fa")
+    _write(t, b">t0\n" + seq + b"\n>")
+    argv = ONT + [t, q]
+    rc, out, err = run_main(emu_lib, argv)
+    assert rc == 0, err
+    assert [l.split("\t")[0] for l in out.splitlines()] == ["a"]
+    if oracle_bind.have_ref():
+        assert out == oracle_bind.ref_table(argv)
+
+
 def test_unopenable_inputs(emu_lib, tmp_path):
     rc, out, err = run_main(emu_lib, ONT + [str(tmp_path / "missing.fq"), os.path.join(GOLDEN, "tiny_sub.fq.gz")])
     assert rc == 1 and "failed to open file" in err        # minimap2-coverage.c:276-279
