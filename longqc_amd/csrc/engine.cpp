@@ -656,13 +656,20 @@ void lqcov_handle::psort_run(MapLane &L, int set, hipStream_t s, u64 nA, const K
 			LQ_LAUNCH(k_ps_scatter, g_tiles, LQ_PS_THREADS, s, Ls.big[cur], cnt + (cur ? LQ_P_BIG1 : LQ_P_BIG0), W.plan.as<PPlan>(), cnt, dA, dB, km, W.gcur.as<u32>()); check_launch();
 		}
 	}
+	const bool k32 = km.pbits + km.rbits + 1 <= 32 + 8;          // the key bits below the sub-bucket digit fit 32 bits (both kernels' digits are >= 8 bits)
 	{
 		StageTimer t(this, s, "k_ps_finish<8192>", nA * 32);
-		LQ_LAUNCH((k_ps_finish<LQ_PS_FIN_BIG, 1024, 10>), (u32)std::min<u64>(std::min<u64>(Ls.cap_fin, nA / LQ_PS_FIN_SMALL + 64), 4096), 1024, s, Ls.fin_b, cnt + LQ_P_FIN_B, dA, dB, km); check_launch();
+		const u32 g = (u32)std::min<u64>(std::min<u64>(Ls.cap_fin, nA / LQ_PS_FIN_SMALL + 64), 4096);
+		if (k32) LQ_LAUNCH((k_ps_finish<LQ_PS_FIN_BIG, 1024, 10, u32>), g, 1024, s, Ls.fin_b, cnt + LQ_P_FIN_B, dA, dB, km);
+		else LQ_LAUNCH((k_ps_finish<LQ_PS_FIN_BIG, 1024, 10, u64>), g, 1024, s, Ls.fin_b, cnt + LQ_P_FIN_B, dA, dB, km);
+		check_launch();
 	}
 	{
 		StageTimer t(this, s, "k_ps_finish<1024>", nA * 32);
-		LQ_LAUNCH((k_ps_finish<LQ_PS_FIN_SMALL, 256, 8>), (u32)std::min<u64>(std::min<u64>(Ls.cap_fin, nA / 16 + 256), 32768), 256, s, Ls.fin_s, cnt + LQ_P_FIN_S, dA, dB, km); check_launch();
+		const u32 g = (u32)std::min<u64>(std::min<u64>(Ls.cap_fin, nA / 16 + 256), 32768);
+		if (k32) LQ_LAUNCH((k_ps_finish<LQ_PS_FIN_SMALL, 256, 8, u32>), g, 256, s, Ls.fin_s, cnt + LQ_P_FIN_S, dA, dB, km);
+		else LQ_LAUNCH((k_ps_finish<LQ_PS_FIN_SMALL, 256, 8, u64>), g, 256, s, Ls.fin_s, cnt + LQ_P_FIN_S, dA, dB, km);
+		check_launch();
 	}
 }
 

@@ -12,7 +12,7 @@
 // the low `pbits` of the position; lq_ckey packs them into a compact key of K = 1 + rbits + pbits bits.  A segment
 // carries `rem`, the number of low key bits it still has to be sorted by (the bits above are equal inside it).
 //   * segments of more than LQ_PS_FIN_BIG elements: one partition pass on the top nbits <= 8 of the remaining bits
-//     (per 4096-element tile: histogram -> one atomic range reservation per digit -> LDS-staged, run-contiguous
+//     (per 2048-element tile: histogram -> one atomic range reservation per digit -> LDS-staged, run-contiguous
 //     writes into the other buffer; the order inside a bucket is whatever the atomics give, which is fine: the
 //     keys are distinct and the finish below looks at all remaining bits);
 //   * segments up to LQ_PS_FIN_BIG (8192) / LQ_PS_FIN_SMALL (1024) elements: finished by one block: elements in
@@ -29,7 +29,7 @@ struct PPlan { u32 tile0, cnt0; };                   // first tile / first count
 
 #define LQ_PS_FIN_SMALL 1024
 #define LQ_PS_FIN_BIG   8192
-#define LQ_PS_TILE      4096
+#define LQ_PS_TILE      2048
 #define LQ_PS_CHILD     4096      // aimed child size of a partition pass: half of what the finish takes
 #define LQ_PS_THREADS   256
 
@@ -223,13 +223,15 @@ k_ps_scatter(const PSeg *segs, const u32 *n_p, const PPlan *plan, const u32 *cnt
 // SB bits of the key) and the elements' indices grouped by sub-bucket.  An element's place = start of its sub-bucket +
 // the number of smaller keys in it (a handful of elements: about n / 2^SB).  All loads are done before the first store,
 // so the segment may be sorted in place.
-template <int CAP, int THREADS, int SB>
+// KEY = u32 when the key bits below the sub-bucket digit fit 32 bits for every segment of the part (K - SB <= 32, the
+// usual case: half the LDS, two blocks per CU), u64 otherwise.
+template <int CAP, int THREADS, int SB, class KEY>
 __global__ void __launch_bounds__(THREADS)
 k_ps_finish(const PSeg *segs, const u32 *n_p, mm128 *A, const mm128 *B, KeyMap km)
 {
 	constexpr int NSB = 1 << SB, PER = CAP / THREADS, SPT = NSB / THREADS > 0 ? NSB / THREADS : 1;
 	static_assert(CAP % THREADS == 0 && (NSB % THREADS == 0 || NSB < THREADS), "shape");
-	__shared__ u64 keys[CAP];
+	__shared__ KEY keys[CAP];                                  // the key bits below the sub-bucket digit
 	__shared__ u16 perm[CAP];
 	__shared__ u32 hist[NSB], beg[NSB], fill[NSB], wsum[THREADS / 64 + 1];
 	const u32 n_seg = *n_p, t = threadIdx.x;
@@ -243,13 +245,14 @@ k_ps_finish(const PSeg *segs, const u32 *n_p, mm128 *A, const mm128 *B, KeyMap k
 			continue;
 		}
 		const u32 nb = sg.rem < SB ? sg.rem : SB, sh = sg.rem - nb;
-		const u64 km_mask = sg.rem >= 64 ? ~0ULL : ((1ULL << sg.rem) - 1);
+		const u64 km_mask = sg.rem >= 64 ? ~0ULL : ((1ULL << sg.rem) - 1), lo_mask = ((u64)1 << sh) - 1;
 		for (u32 c = t; c < NSB; c += THREADS) { hist[c] = 0; fill[c] = 0; }
 		__syncthreads();
 		mm128 e[PER];
+		u32 dg[PER];
 		for (int k = 0; k < PER; ++k) {
 			const u32 i = t + (u32)k * THREADS;
-			if (i < n) { e[k] = src[i]; const u64 key = lq_ckey(e[k].x, km) & km_mask; keys[i] = key; atomicAdd(&hist[(u32)(key >> sh)], 1u); }
+			if (i < n) { e[k] = src[i]; const u64 key = lq_ckey(e[k].x, km) & km_mask; keys[i] = (KEY)(key & lo_mask); dg[k] = (u32)(key >> sh); atomicAdd(&hist[dg[k]], 1u); }
 		}
 		__syncthreads();
 		{	// exclusive scan of hist -> beg: SPT counters per thread, wave scan, wave totals through LDS
@@ -267,15 +270,15 @@ k_ps_finish(const PSeg *segs, const u32 *n_p, mm128 *A, const mm128 *B, KeyMap k
 		__syncthreads();
 		for (int k = 0; k < PER; ++k) {
 			const u32 i = t + (u32)k * THREADS;
-			if (i < n) { const u32 d = (u32)(keys[i] >> sh); perm[beg[d] + atomicAdd(&fill[d], 1u)] = (u16)i; }
+			if (i < n) perm[beg[dg[k]] + atomicAdd(&fill[dg[k]], 1u)] = (u16)i;
 		}
 		__syncthreads();
 		u32 pos[PER];
 		for (int k = 0; k < PER; ++k) {
 			const u32 i = t + (u32)k * THREADS;
 			if (i < n) {
-				const u64 key = keys[i];
-				const u32 d = (u32)(key >> sh), b0 = beg[d], b1 = b0 + hist[d];
+				const KEY key = keys[i];
+				const u32 b0 = beg[dg[k]], b1 = b0 + hist[dg[k]];
 				u32 r = 0;
 				for (u32 j = b0; j < b1; ++j) r += keys[perm[j]] < key;
 				pos[k] = b0 + r;
