@@ -62,6 +62,14 @@ void lqcov_handle::drain_stages()
 	std::lock_guard<std::mutex> g(stage_mu);
 	for (lqcov_handle::StagePending &sp : stage_pending) { hipEventSynchronize(sp.b); account_stage(sp.name, sp.a, sp.b, sp.bytes); }
 	stage_pending.clear();
+	for (auto &kv : late_bytes) { auto it = stages.find(kv.first); if (it != stages.end()) it->second.bytes += kv.second; }
+	late_bytes.clear();
+}
+void lqcov_handle::add_stage_bytes(const char *name, u64 bytes)
+{
+	if (!profiling || !bytes) return;
+	std::lock_guard<std::mutex> g(stage_mu);
+	late_bytes[name] += bytes;
 }
 
 // ---- handle ---------------------------------------------------------------------------------
@@ -647,28 +655,31 @@ void lqcov_handle::psort_run(MapLane &L, int set, hipStream_t s, u64 nA, const K
 		LQ_LAUNCH(k_ps_plan, 1, 256, s, Ls.big[cur], cnt + (cur ? LQ_P_BIG1 : LQ_P_BIG0), W.plan.as<PPlan>(), cnt, cap_cnt, Ls.child_target); check_launch();
 		dzero(W.gcnt.p, (size_t)cap_cnt * 4, s);
 		{
-			StageTimer t(this, s, "k_ps_hist", nA * 16);
+			StageTimer t(this, s, "k_ps_hist");
 			LQ_LAUNCH(k_ps_hist, g_tiles, LQ_PS_THREADS, s, Ls.big[cur], cnt + (cur ? LQ_P_BIG1 : LQ_P_BIG0), W.plan.as<PPlan>(), cnt, dA, dB, km, W.gcnt.as<u32>()); check_launch();
 		}
-		LQ_LAUNCH(k_ps_scan, g_segs, 256, s, Ls.big[cur], cnt + (cur ? LQ_P_BIG1 : LQ_P_BIG0), W.plan.as<PPlan>(), W.gcnt.as<u32>(), W.gcur.as<u32>(), Ls, (u32)(nxt ? LQ_P_BIG1 : LQ_P_BIG0)); check_launch();
+		LQ_LAUNCH(k_ps_scan, g_segs, 256, s, Ls.big[cur], cnt + (cur ? LQ_P_BIG1 : LQ_P_BIG0), W.plan.as<PPlan>(), W.gcnt.as<u32>(), W.gcur.as<u32>(), Ls, (u32)(nxt ? LQ_P_BIG1 : LQ_P_BIG0),
+		          (unsigned long long*)(L.sort_cnt.as<u32>() + (set ? LQ_C_PART1 : LQ_C_PART0))); check_launch();
 		{
-			StageTimer t(this, s, "k_ps_scatter", nA * 32);
+			StageTimer t(this, s, "k_ps_scatter");
 			LQ_LAUNCH(k_ps_scatter, g_tiles, LQ_PS_THREADS, s, Ls.big[cur], cnt + (cur ? LQ_P_BIG1 : LQ_P_BIG0), W.plan.as<PPlan>(), cnt, dA, dB, km, W.gcur.as<u32>()); check_launch();
 		}
 	}
 	const bool k32 = km.pbits + km.rbits + 1 <= 32 + 8;          // the key bits below the sub-bucket digit fit 32 bits (both kernels' digits are >= 8 bits)
 	{
-		StageTimer t(this, s, "k_ps_finish<8192>", nA * 32);
+		StageTimer t(this, s, "k_ps_finish<8192>");
+		unsigned long long *tl = (unsigned long long*)(L.sort_cnt.as<u32>() + (set ? LQ_C_FINB1 : LQ_C_FINB0));
 		const u32 g = (u32)std::min<u64>(std::min<u64>(Ls.cap_fin, nA / LQ_PS_FIN_SMALL + 64), 4096);
-		if (k32) LQ_LAUNCH((k_ps_finish<LQ_PS_FIN_BIG, 1024, 10, u32>), g, 1024, s, Ls.fin_b, cnt + LQ_P_FIN_B, dA, dB, km);
-		else LQ_LAUNCH((k_ps_finish<LQ_PS_FIN_BIG, 1024, 10, u64>), g, 1024, s, Ls.fin_b, cnt + LQ_P_FIN_B, dA, dB, km);
+		if (k32) LQ_LAUNCH((k_ps_finish<LQ_PS_FIN_BIG, 1024, 10, u32>), g, 1024, s, Ls.fin_b, cnt + LQ_P_FIN_B, dA, dB, km, tl);
+		else LQ_LAUNCH((k_ps_finish<LQ_PS_FIN_BIG, 1024, 10, u64>), g, 1024, s, Ls.fin_b, cnt + LQ_P_FIN_B, dA, dB, km, tl);
 		check_launch();
 	}
 	{
-		StageTimer t(this, s, "k_ps_finish<1024>", nA * 32);
+		StageTimer t(this, s, "k_ps_finish<1024>");
+		unsigned long long *tl = (unsigned long long*)(L.sort_cnt.as<u32>() + (set ? LQ_C_FINS1 : LQ_C_FINS0));
 		const u32 g = (u32)std::min<u64>(std::min<u64>(Ls.cap_fin, nA / 16 + 256), 32768);
-		if (k32) LQ_LAUNCH((k_ps_finish<LQ_PS_FIN_SMALL, 256, 8, u32>), g, 256, s, Ls.fin_s, cnt + LQ_P_FIN_S, dA, dB, km);
-		else LQ_LAUNCH((k_ps_finish<LQ_PS_FIN_SMALL, 256, 8, u64>), g, 256, s, Ls.fin_s, cnt + LQ_P_FIN_S, dA, dB, km);
+		if (k32) LQ_LAUNCH((k_ps_finish<LQ_PS_FIN_SMALL, 256, 8, u32>), g, 256, s, Ls.fin_s, cnt + LQ_P_FIN_S, dA, dB, km, tl);
+		else LQ_LAUNCH((k_ps_finish<LQ_PS_FIN_SMALL, 256, 8, u64>), g, 256, s, Ls.fin_s, cnt + LQ_P_FIN_S, dA, dB, km, tl);
 		check_launch();
 	}
 }
@@ -744,8 +755,8 @@ void lqcov_handle::sort_batch(MapLane &L, Part &pt, u32 q0, u32 nqb, u64 a_base,
 			dzero(cnt + nxt_slot, 4, sD); dzero(cnt + LQ_C_TWO, 4 * (1 + LQ_WALK_CLASSES), sD);
 			const u32 g_seg = std::min<u32>(ns, 1u << 18);
 			{
-				StageTimer t(this, sD, "k_sort_copy_hist", nA * 33);
-				LQ_LAUNCH(k_sort_copy_hist, g_seg, 256, sD, cur, cnt + cur_slot, dA, dB, L.sort_d.as<u8>(), L.hist.as<u32>(), L.mhist.as<u32>());
+				StageTimer t(this, sD, "k_sort_copy_hist");
+				LQ_LAUNCH(k_sort_copy_hist, g_seg, 256, sD, cur, cnt + cur_slot, dA, dB, L.sort_d.as<u8>(), L.hist.as<u32>(), L.mhist.as<u32>(), (unsigned long long*)(cnt + LQ_C_COPIED));
 				check_launch();
 			}
 			LQ_LAUNCH(k_sort_classify, g_seg, LQ_CLASSIFY_THREADS, sD, cur, cnt + cur_slot, ns, L.hist.as<u32>(), L.begs.as<u32>(), L.seg_info.as<SegInfo>(),
@@ -859,8 +870,8 @@ void lqcov_handle::sort_batch(MapLane &L, Part &pt, u32 q0, u32 nqb, u64 a_base,
 			LQ_HIP_CHECK(hipEventRecord(L.ev_w1, L.streamW));
 			LQ_HIP_CHECK(hipStreamWaitEvent(sD, L.ev_w1, 0));
 			{
-				StageTimer t(this, sD, "k_sort_scatter", nA * 36);
-				LQ_LAUNCH(k_sort_scatter, g_seg, 256, sD, cur, L.seg_info.as<SegInfo>(), cnt + cur_slot, dA, dB, L.sort_dst.as<u32>());
+				StageTimer t(this, sD, "k_sort_scatter");
+				LQ_LAUNCH(k_sort_scatter, g_seg, 256, sD, cur, L.seg_info.as<SegInfo>(), cnt + cur_slot, dA, dB, L.sort_dst.as<u32>(), (unsigned long long*)(cnt + LQ_C_SCATTERED));
 				check_launch();
 			}
 			{
@@ -880,6 +891,15 @@ void lqcov_handle::sort_batch(MapLane &L, Part &pt, u32 q0, u32 nqb, u64 a_base,
 		u32 hc[LQ_C_N];
 		d2h(hc, cnt, LQ_C_N, sD);
 		if (hc[LQ_C_PS0 + LQ_P_OVERFLOW] || hc[LQ_C_PS1 + LQ_P_OVERFLOW]) throw std::runtime_error("parallel sort: list or counter space overflow");
+		if (profiling) {	// algorithmic bytes of the sort's stages from what the kernels really moved (16-byte anchors)
+			auto t64 = [&](int i) { return (u64)hc[i] | (u64)hc[i + 1] << 32; };
+			add_stage_bytes("k_sort_copy_hist", t64(LQ_C_COPIED) * 33);          // anchor in, anchor + digit byte out
+			add_stage_bytes("k_sort_scatter", t64(LQ_C_SCATTERED) * 36);          // anchor + 4-byte destination in, anchor out
+			add_stage_bytes("k_ps_hist", (t64(LQ_C_PART0) + t64(LQ_C_PART1)) * 16);
+			add_stage_bytes("k_ps_scatter", (t64(LQ_C_PART0) + t64(LQ_C_PART1)) * 32);
+			add_stage_bytes("k_ps_finish<8192>", (t64(LQ_C_FINB0) + t64(LQ_C_FINB1)) * 32);
+			add_stage_bytes("k_ps_finish<1024>", (t64(LQ_C_FINS0) + t64(LQ_C_FINS1)) * 32);
+		}
 		if (hc[LQ_C_PS0 + LQ_P_BIG0] || hc[LQ_C_PS1 + LQ_P_BIG0]) throw std::domain_error("parallel sort: segments above the LDS capacity left after the last pass");
 	}
 }

@@ -81,6 +81,8 @@ struct lqcov_handle {
 	struct StagePending { const char *name; hipEvent_t a, b; u64 bytes; };
 	std::vector<StagePending> stage_pending; std::mutex stage_mu;
 	void account_stage(const char *name, hipEvent_t a, hipEvent_t b, u64 bytes);
+	void add_stage_bytes(const char *name, u64 bytes);       // algorithmic bytes known only after the fact (device-side tallies)
+	std::map<std::string, u64> late_bytes;
 	void drain_stages();
 	u32 debug_flags = 0;
 	bool distributed = false;             // per-part accumulators, COVT replayed by the caller (multi-GPU)

@@ -36,7 +36,9 @@ struct PPlan { u32 tile0, cnt0; };                   // first tile / first count
 // counters of one batch's sort (device): indices into L.sort_cnt.  Two sets of psort lists: set 0 takes whole queries
 // (k_sort_init) and is sorted on its own stream while klib's passes run; set 1 collects the buckets that leave them.
 enum { LQ_C_KLIB0 = 0, LQ_C_KLIB1, LQ_C_TWO, LQ_C_WALK0, LQ_C_WALK1, LQ_C_WALK2, LQ_C_WALK3, LQ_C_WALK4, LQ_C_OVERFLOW,
-       LQ_C_PS0 = 16, LQ_C_PS1 = 32, LQ_C_N = 48 };
+       LQ_C_PS0 = 16, LQ_C_PS1 = 32,
+       // 64-bit tallies of the elements each kind of kernel really moved (algorithmic bytes of the stage times)
+       LQ_C_COPIED = 48, LQ_C_SCATTERED = 50, LQ_C_PART0 = 52, LQ_C_FINS0 = 54, LQ_C_FINB0 = 56, LQ_C_PART1 = 58, LQ_C_FINS1 = 60, LQ_C_FINB1 = 62, LQ_C_N = 64 };
 enum { LQ_P_BIG0 = 0, LQ_P_BIG1, LQ_P_FIN_S, LQ_P_FIN_B, LQ_P_TILES, LQ_P_CNT, LQ_P_OVERFLOW };   // offsets inside a set's counters
 struct PsLists { struct PSeg *big[2], *fin_s, *fin_b; u32 *cnt; u32 cap_big, cap_fin;
                  u32 fin_s_max, fin_b_max, child_target; };   // size limits of the two finishing kernels, aimed child size of a pass (tests shrink them)
@@ -148,7 +150,7 @@ k_ps_hist(const PSeg *segs, const u32 *n_p, const PPlan *plan, const u32 *cnt, c
 
 // ---- bucket offsets and children of every big segment (one block per segment, strided) ----------------------
 __global__ void __launch_bounds__(256)
-k_ps_scan(const PSeg *segs, const u32 *n_p, const PPlan *plan, const u32 *gcnt, u32 *gcur, PsLists L, u32 big_next_slot)
+k_ps_scan(const PSeg *segs, const u32 *n_p, const PPlan *plan, const u32 *gcnt, u32 *gcur, PsLists L, u32 big_next_slot, unsigned long long *tally)
 {
 	__shared__ u32 v[256], tmp[256];
 	const u32 n = *n_p, t = threadIdx.x;
@@ -157,6 +159,7 @@ k_ps_scan(const PSeg *segs, const u32 *n_p, const PPlan *plan, const u32 *gcnt, 
 		const PSeg sg = segs[s];
 		const PPlan pl = plan[s];
 		const u32 nb = 1u << sg.nbits;
+		if (t == 0 && tally) atomicAdd(tally, (unsigned long long)sg.len);
 		const u32 c = t < nb ? gcnt[pl.cnt0 + t] : 0;
 		v[t] = c;
 		__syncthreads();
@@ -227,7 +230,7 @@ k_ps_scatter(const PSeg *segs, const u32 *n_p, const PPlan *plan, const u32 *cnt
 // usual case: half the LDS, two blocks per CU), u64 otherwise.
 template <int CAP, int THREADS, int SB, class KEY>
 __global__ void __launch_bounds__(THREADS)
-k_ps_finish(const PSeg *segs, const u32 *n_p, mm128 *A, const mm128 *B, KeyMap km)
+k_ps_finish(const PSeg *segs, const u32 *n_p, mm128 *A, const mm128 *B, KeyMap km, unsigned long long *tally)
 {
 	constexpr int NSB = 1 << SB, PER = CAP / THREADS, SPT = NSB / THREADS > 0 ? NSB / THREADS : 1;
 	static_assert(CAP % THREADS == 0 && (NSB % THREADS == 0 || NSB < THREADS), "shape");
@@ -240,6 +243,7 @@ k_ps_finish(const PSeg *segs, const u32 *n_p, mm128 *A, const mm128 *B, KeyMap k
 		const u32 n = sg.len;
 		const mm128 *src = (sg.buf ? B : A) + sg.off;
 		mm128 *out = A + sg.off;
+		if (t == 0 && tally) atomicAdd(tally, (unsigned long long)n);
 		if (sg.rem == 0 || n == 1) {                             // already in order: home to A
 			if (sg.buf) for (u32 i = t; i < n; i += THREADS) out[i] = src[i];
 			continue;

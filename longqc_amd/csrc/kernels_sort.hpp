@@ -52,7 +52,7 @@ __device__ __forceinline__ void lq_insertion_sort_x(mm128 *a, u32 n)
 
 // one block per sub-array (strided over the device-side list): B <- A, D <- digit, hist[seg][*] = digit histogram,
 // mhist[seg][*] = how many anchors of each bucket carry LQ_TIE_MARK (both built in LDS, stored once)
-__global__ void k_sort_copy_hist(const SortSeg *segs, const u32 *n_segs_p, const mm128 *A, mm128 *B, u8 *D, u32 *hist, u32 *mhist)
+__global__ void k_sort_copy_hist(const SortSeg *segs, const u32 *n_segs_p, const mm128 *A, mm128 *B, u8 *D, u32 *hist, u32 *mhist, unsigned long long *tally)
 {
 	__shared__ u32 lh[256], lm[256];
 	const u32 n_segs = *n_segs_p;
@@ -61,6 +61,7 @@ __global__ void k_sort_copy_hist(const SortSeg *segs, const u32 *n_segs_p, const
 		const mm128 *a = A + sg.off;
 		mm128 *b = B + sg.off;
 		u8 *d = D + sg.off;
+		if (threadIdx.x == 0 && tally) atomicAdd(tally, (unsigned long long)sg.len);
 		for (u32 c = threadIdx.x; c < 256; c += blockDim.x) { lh[c] = 0; lm[c] = 0; }
 		__syncthreads();
 		for (u32 i = threadIdx.x; i < sg.len; i += blockDim.x) {
@@ -427,7 +428,7 @@ k_sort_walk_solo(const SortSeg *segs, const u32 *list, const u32 *n_list_p, cons
 }
 
 // one block per sub-array (strided): A[dst[i]] = B[i]  (identity passes are skipped)
-__global__ void k_sort_scatter(const SortSeg *segs, const SegInfo *info, const u32 *n_segs_p, mm128 *A, const mm128 *B, const u32 *dst)
+__global__ void k_sort_scatter(const SortSeg *segs, const SegInfo *info, const u32 *n_segs_p, mm128 *A, const mm128 *B, const u32 *dst, unsigned long long *tally)
 {
 	const u32 n_segs = *n_segs_p;
 	for (u32 sgi = blockIdx.x; sgi < n_segs; sgi += gridDim.x) {
@@ -436,6 +437,7 @@ __global__ void k_sort_scatter(const SortSeg *segs, const SegInfo *info, const u
 		mm128 *a = A + sg.off;
 		const mm128 *b = B + sg.off;
 		const u32 *ds = dst + sg.off;
+		if (threadIdx.x == 0 && tally) atomicAdd(tally, (unsigned long long)sg.len);
 		for (u32 i = threadIdx.x; i < sg.len; i += blockDim.x) a[ds[i]] = b[i];
 	}
 }

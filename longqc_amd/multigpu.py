@@ -269,6 +269,8 @@ class QueryShardRunner:
         eng.part_clear(part)                                      # the share's reads are no longer needed: the part becomes the whole index part
         eng.part_build_from_minimizers_dev(part, x.data_ptr(), y.data_ptr(), n, np.asarray(all_lens, dtype=np.uint32), all_names)
         del x, y
+        if dev.type == "cuda":
+            torch.cuda.empty_cache()                              # the exchange buffers go back to the device: the mapping sizes its work space from what is free
         eng.part_map(part)
 
     def gather_table(self) -> Optional[str]:
