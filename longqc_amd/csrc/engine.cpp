@@ -670,8 +670,12 @@ void lqcov_handle::psort_run(MapLane &L, int set, hipStream_t s, u64 nA, const K
 		StageTimer t(this, s, "k_ps_finish<8192>");
 		unsigned long long *tl = (unsigned long long*)(L.sort_cnt.as<u32>() + (set ? LQ_C_FINB1 : LQ_C_FINB0));
 		const u32 g = (u32)std::min<u64>(std::min<u64>(Ls.cap_fin, nA / LQ_PS_FIN_SMALL + 64), 4096);
-		if (k32) LQ_LAUNCH((k_ps_finish<LQ_PS_FIN_BIG, 1024, 10, u32>), g, 1024, s, Ls.fin_b, cnt + LQ_P_FIN_B, dA, dB, km, tl);
-		else LQ_LAUNCH((k_ps_finish<LQ_PS_FIN_BIG, 1024, 10, u64>), g, 1024, s, Ls.fin_b, cnt + LQ_P_FIN_B, dA, dB, km, tl);
+		// block size (A/B knob): beside the other lanes' kernels a launch takes ~24 ms against ~2.4 ms alone, whatever the block size
+		const int ft = getenv("LQCOV_FIN_THREADS") ? atoi(getenv("LQCOV_FIN_THREADS")) : 1024;   // measured at configs[2], 4 lanes: 256 threads 2.40 s per step, 512: 2.25, 1024: 2.1-2.2
+		if (!k32) LQ_LAUNCH((k_ps_finish<LQ_PS_FIN_BIG, 1024, 10, u64>), g, 1024, s, Ls.fin_b, cnt + LQ_P_FIN_B, dA, dB, km, tl);
+		else if (ft >= 1024) LQ_LAUNCH((k_ps_finish<LQ_PS_FIN_BIG, 1024, 10, u32>), g, 1024, s, Ls.fin_b, cnt + LQ_P_FIN_B, dA, dB, km, tl);
+		else if (ft >= 512) LQ_LAUNCH((k_ps_finish<LQ_PS_FIN_BIG, 512, 10, u32>), g * 2, 512, s, Ls.fin_b, cnt + LQ_P_FIN_B, dA, dB, km, tl);
+		else LQ_LAUNCH((k_ps_finish<LQ_PS_FIN_BIG, 256, 10, u32>), g * 2, 256, s, Ls.fin_b, cnt + LQ_P_FIN_B, dA, dB, km, tl);
 		check_launch();
 	}
 	{
@@ -771,6 +775,9 @@ void lqcov_handle::sort_batch(MapLane &L, Part &pt, u32 q0, u32 nqb, u64 a_base,
 				const u8 *dD = L.sort_d.as<u8>(); const u32 *dH = L.hist.as<u32>(), *dBg = L.begs.as<u32>(); u32 *dDst = L.sort_dst.as<u32>();
 				const u32 *wl = L.walk_list.as<u32>();
 				hipStream_t sW = L.streamW;
+				// resident walker waves are capped: every one of them holds a wave slot for milliseconds with one lane at work, and
+				// blocks of 1024 threads (the parallel sort's finish) cannot start on a CU whose slots are taken by them
+				const u32 wgrid = getenv("LQCOV_WALK_GRID") ? (u32)std::max(64, atoi(getenv("LQCOV_WALK_GRID"))) : (1u << 18);
 				// the largest digit of this level decides how many register groups the long walker needs
 				u32 max_digit = 255;
 				if (shift == 48) max_digit = (pt.rs.n ? pt.rs.n - 1 : 0) >> 16;
@@ -833,20 +840,20 @@ void lqcov_handle::sort_batch(MapLane &L, Part &pt, u32 q0, u32 nqb, u64 a_base,
 								{
 									StageTimer t(this, sW, "k_ck_solve");
 									LQ_LAUNCH(k_ck_phases, std::min<u32>(n_cks, 1u << 16), 64, sW, dck, n_cks, cur, dD, dH, dBg, L.ck_T.as<u32>(), L.ck_E.as<u32>()); check_launch();
-									LQ_LAUNCH(k_ck_solve, std::min<u32>(n_ck, 1u << 18), 64, sW, dck, n_cks, n_ck, cur, dD, dH, dBg, L.ck_T.as<u32>(), L.ck_E.as<u32>(), L.ck_S.as<u32>(), L.ck_slot.as<u32>()); check_launch();
+									LQ_LAUNCH(k_ck_solve, std::min<u32>(n_ck, wgrid), 64, sW, dck, n_cks, n_ck, cur, dD, dH, dBg, L.ck_T.as<u32>(), L.ck_E.as<u32>(), L.ck_S.as<u32>(), L.ck_slot.as<u32>()); check_launch();
 								}
 								{
 									StageTimer t(this, sW, "k_sort_walk_reg<1>ck", nA * 5);
-									LQ_LAUNCH((k_sort_walk_reg<1>), std::min<u32>(n_ck, 1u << 18), 64, sW, cur, (const u32*)nullptr, L.ck_n.as<u32>(), dD, dH, dBg, dDst, dck, n_cks, L.ck_S.as<u32>(), L.ck_slot.as<u32>()); check_launch();
+									LQ_LAUNCH((k_sort_walk_reg<1>), std::min<u32>(n_ck, wgrid), 64, sW, cur, (const u32*)nullptr, L.ck_n.as<u32>(), dD, dH, dBg, dDst, dck, n_cks, L.ck_S.as<u32>(), L.ck_slot.as<u32>()); check_launch();
 								}
 							} else {
 								{
 									StageTimer t(this, sW, "k_ck_chain256", nA);
-									LQ_LAUNCH(k_ck_chain256, std::min<u32>(n_cks, 1u << 16), 64, sW, dck, n_cks, cur, dD, dH, dBg, L.ck_S.as<u32>(), L.ck_slot.as<u32>()); check_launch();
+									LQ_LAUNCH(k_ck_chain256, std::min<u32>(n_cks, wgrid), 64, sW, dck, n_cks, cur, dD, dH, dBg, L.ck_S.as<u32>(), L.ck_slot.as<u32>()); check_launch();
 								}
 								{
 									StageTimer t(this, sW, "k_sort_walk_solo_ck", nA * 5);
-									LQ_LAUNCH(k_sort_walk_solo, std::min<u32>(n_ck, 1u << 18), 64, sW, cur, (const u32*)nullptr, L.ck_n.as<u32>(), dD, dH, dBg, dDst, dck, n_cks, L.ck_S.as<u32>(), L.ck_slot.as<u32>()); check_launch();
+									LQ_LAUNCH(k_sort_walk_solo, std::min<u32>(n_ck, wgrid), 64, sW, cur, (const u32*)nullptr, L.ck_n.as<u32>(), dD, dH, dBg, dDst, dck, n_cks, L.ck_S.as<u32>(), L.ck_slot.as<u32>()); check_launch();
 								}
 							}
 							first_plain_class = ck_small ? 2 : 3;
@@ -857,15 +864,15 @@ void lqcov_handle::sort_batch(MapLane &L, Part &pt, u32 q0, u32 nqb, u64 a_base,
 				fork_w();
 				for (int c = first_plain_class; c >= 2; --c) {
 					if (!gated && !L.gate_passed) { L.gate_passed = true; open_gate(); gated = true; }   // let the next lane start under these walks
-					const u32 g = std::min<u32>(ns, 8192);
+					const u32 g = std::min<u32>(ns, std::min<u32>(8192, wgrid));
 					const CkSeg *nock = nullptr;
 					if (reg_walker && max_digit < 64) { StageTimer t(this, sW, "k_sort_walk_reg<1>", nA * 5); LQ_LAUNCH((k_sort_walk_reg<1>), g, 64, sW, cur, wl + (u64)c * ns, cnt + LQ_C_WALK0 + c, dD, dH, dBg, dDst, nock, 0u, (const u32*)nullptr, (const u32*)nullptr); }
 					else if (reg_walker && max_digit < 128) { StageTimer t(this, sW, "k_sort_walk_reg<2>", nA * 5); LQ_LAUNCH((k_sort_walk_reg<2>), g, 64, sW, cur, wl + (u64)c * ns, cnt + LQ_C_WALK0 + c, dD, dH, dBg, dDst, nock, 0u, (const u32*)nullptr, (const u32*)nullptr); }
 					else { StageTimer t(this, sW, "k_sort_walk_solo", nA * 5); LQ_LAUNCH(k_sort_walk_solo, g, 64, sW, cur, wl + (u64)c * ns, cnt + LQ_C_WALK0 + c, dD, dH, dBg, dDst, nock, 0u, (const u32*)nullptr, (const u32*)nullptr); }
 					check_launch();
 				}
-				{ StageTimer t(this, sW, "k_sort_walk_lds<16384>"); LQ_LAUNCH((k_sort_walk_lds<16384>), std::min<u32>(ns, 8192), 64, sW, cur, wl + (u64)1 * ns, cnt + LQ_C_WALK1, dD, dH, dBg, dDst); check_launch(); }
-				{ StageTimer t(this, sW, "k_sort_walk_lds<4096>"); LQ_LAUNCH((k_sort_walk_lds<4096>), std::min<u32>(ns, 1u << 16), 64, sW, cur, wl + (u64)0 * ns, cnt + LQ_C_WALK0, dD, dH, dBg, dDst); check_launch(); }
+				{ StageTimer t(this, sW, "k_sort_walk_lds<16384>"); LQ_LAUNCH((k_sort_walk_lds<16384>), std::min<u32>(ns, std::min<u32>(8192, wgrid)), 64, sW, cur, wl + (u64)1 * ns, cnt + LQ_C_WALK1, dD, dH, dBg, dDst); check_launch(); }
+				{ StageTimer t(this, sW, "k_sort_walk_lds<4096>"); LQ_LAUNCH((k_sort_walk_lds<4096>), std::min<u32>(ns, std::min<u32>(1u << 16, wgrid * 4)), 64, sW, cur, wl + (u64)0 * ns, cnt + LQ_C_WALK0, dD, dH, dBg, dDst); check_launch(); }
 			}
 			LQ_HIP_CHECK(hipEventRecord(L.ev_w1, L.streamW));
 			LQ_HIP_CHECK(hipStreamWaitEvent(sD, L.ev_w1, 0));
