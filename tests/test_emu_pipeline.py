@@ -26,6 +26,26 @@ def test_emulated_pipeline_reproduces_reference_tables(emu_lib, case):
     assert out == read_gz(case["expect"])
 
 
+def test_emulated_tables_read_like_the_reference_consumer(emu_lib, tmp_path):
+    """the table the engine writes (main call + spike-in call), read by the consumer's parser, gives the
+    figures the reference's LqCoverage computed from the reference's table (tests/golden/consumer.json)."""
+    from longqc_amd.covtable import CoverageTable
+    by_name = {c["name"]: c for c in _cases("table")}
+    want = [c for c in json.load(open(os.path.join(GOLDEN, "consumer.json"))) if c["control"]]
+    assert want
+    for w in want:
+        paths = []
+        for fixture in (w["table"], w["control"]):
+            case = by_name[fixture[:-len(".table.gz")]]
+            rc, out, err = run_main(emu_lib, case["argv"], cwd=GOLDEN)
+            assert rc == 0, err
+            fn = tmp_path / fixture[:-3]; fn.write_text(out); paths.append(str(fn))
+        ct = CoverageTable(paths[0], control_filtering=paths[1])
+        assert (len(ct), ct.control_reads, ct.unmapped_frac_trimmed, ct.unmapped_frac_untrimmed, ct.get_unmapped_med_frac(), ct.get_high_div_frac(),
+                ct.get_control_frac()) == (w["n_rows"], w["control_reads"], w["unmapped_frac_trimmed"], w["unmapped_frac_untrimmed"], w["unmapped_med_frac"],
+                                           w["high_div_frac"], w["control_frac"])
+
+
 def _engine(lib, **kw):
     p = api.Params()
     lib.lqcov_params_default(p)

@@ -26,6 +26,10 @@ def test_gpu_tables_equal_reference_fixtures(gpu_lib, case):
     E.test_emulated_pipeline_reproduces_reference_tables(gpu_lib, case)
 
 
+def test_gpu_tables_read_like_the_reference_consumer(gpu_lib, tmp_path):
+    E.test_emulated_tables_read_like_the_reference_consumer(gpu_lib, tmp_path)
+
+
 @pytest.mark.parametrize("name,k,w,hpc,fn", [
     ("tiny_sketch_k12w5", 12, 5, 0, "tiny_sub.fq.gz"),
     ("adv_sketch_k12w5", 12, 5, 0, "adv_sub.fq.gz"),

@@ -98,3 +98,28 @@ def check_in_memory_equals_file_path(lib):
 
 def test_in_memory_coverage_equals_file_based(emu_lib):
     check_in_memory_equals_file_path(emu_lib)
+
+
+# ---- the consumer's reading of the table ----
+def _consumer_cases():
+    import json
+    return json.load(open(os.path.join(GOLDEN, "consumer.json")))
+
+
+@pytest.mark.parametrize("case", _consumer_cases(), ids=lambda c: c["table"] + ("+ctl" if c["control"] else ""))
+def test_table_reads_like_the_reference_consumer(case, tmp_path):
+    """tests/golden/consumer.json = what the reference's LqCoverage computes from each golden table
+    (make_consumer_golden.py); CoverageTable must give the same figures from the same bytes."""
+    import gzip
+    from longqc_amd.covtable import CoverageTable
+    t = tmp_path / "t.txt"; t.write_bytes(gzip.open(os.path.join(GOLDEN, case["table"])).read())
+    c = None
+    if case["control"]:
+        c = tmp_path / "c.txt"; c.write_bytes(gzip.open(os.path.join(GOLDEN, case["control"])).read())
+    ct = CoverageTable(str(t), control_filtering=str(c) if c else None)
+    assert len(ct) == case["n_rows"] and ct.control_reads == case["control_reads"]
+    assert ct.unmapped_frac_trimmed == case["unmapped_frac_trimmed"]
+    assert ct.unmapped_frac_untrimmed == case["unmapped_frac_untrimmed"]
+    assert ct.get_unmapped_med_frac() == case["unmapped_med_frac"]
+    assert ct.get_high_div_frac() == case["high_div_frac"]
+    assert ct.get_control_num() == case["control_num"] and ct.get_control_frac() == case["control_frac"]
