@@ -156,6 +156,10 @@ int lqcov_part_dump(lqcov_handle *h, int part, const char *path, int append);   
 int lqcov_part_load(lqcov_handle *h, const char *path, uint64_t *offset);                   /* index.c:428-479 */
 int lqcov_reset(lqcov_handle *h);                   /* zero the accumulators, keep resident reads (bench) */
 int lqcov_sync(lqcov_handle *h);                    /* wait for the handle's stream */
+/* Hand the work space the mapping lanes keep between calls (HIP's stream-ordered pool, kept so that the next part does not
+ * pay for it again) back to the device: for a host that needs the HBM for buffers of its own between two parts, e.g. the
+ * all-gather buffers of the query-sharded multi-GPU split.  Waits for the device.  No counterpart in the reference. */
+int lqcov_workspace_trim(lqcov_handle *h);
 
 /* == main pass 2 up to, not including, printf (minimap2-coverage.c:545-566). */
 int lqcov_finish(lqcov_handle *h);

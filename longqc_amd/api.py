@@ -94,6 +94,7 @@ def load_library(path: Optional[str] = None):
         "lqcov_part_release": (C.c_int, [H, C.c_int]),
         "lqcov_reset": (C.c_int, [H]),
         "lqcov_sync": (C.c_int, [H]),
+        "lqcov_workspace_trim": (C.c_int, [H]),
         "lqcov_finish": (C.c_int, [H]),
         "lqcov_n_queries": (C.c_int, [H]),
         "lqcov_query_order": (C.c_int, [H, C.c_void_p, C.c_uint32]),
@@ -299,6 +300,9 @@ class Engine:
 
     def sync(self):
         self._ck(self.lib.lqcov_sync(self.h))
+
+    def workspace_trim(self):
+        self._ck(self.lib.lqcov_workspace_trim(self.h))
 
     def finish(self):
         self._ck(self.lib.lqcov_finish(self.h))

@@ -269,6 +269,16 @@ int lqcov_part_map(lqcov_handle *h, int part) { return guard(h, [&] { h->map_par
 int lqcov_part_release(lqcov_handle *h, int part) { return guard(h, [&] { h->part(part); h->parts[part].reset(); }); }
 int lqcov_reset(lqcov_handle *h) { return guard(h, [&] { if (!h->have_queries) throw std::logic_error("no queries"); h->reset(); }); }
 int lqcov_sync(lqcov_handle *h) { return guard(h, [&] { LQ_HIP_CHECK(hipStreamSynchronize(h->stream)); }); }
+int lqcov_workspace_trim(lqcov_handle *h)
+{
+	return guard(h, [&] {
+		LQ_HIP_CHECK(hipDeviceSynchronize());
+#ifndef LQ_EMU
+		hipMemPool_t pool = nullptr;
+		if (hipDeviceGetDefaultMemPool(&pool, h->device) == hipSuccess && pool) (void)hipMemPoolTrimTo(pool, 0);
+#endif
+	});
+}
 int lqcov_finish(lqcov_handle *h) { return guard(h, [&] { if (!h->have_queries) throw std::logic_error("no queries"); h->finish(); }); }
 int lqcov_n_queries(const lqcov_handle *h) { return h ? (int)h->q.n : LQCOV_E_ARG; }
 

@@ -254,6 +254,12 @@ class QueryShardRunner:
         else:
             sizes = [n_mine]
         cap = max(max(sizes), 1)
+        if dev.type == "cuda" and world > 1:
+            # the exchange needs (2 + 4 world) cap words at its peak; the lanes' work space of the previous part is still held by
+            # the engine's pool, which torch's allocator cannot draw from: give it back first if what is free would not do
+            need = (2 + 4 * world) * cap * 8
+            if torch.cuda.mem_get_info(dev)[0] < need + need // 4:
+                eng.workspace_trim()
         xs = torch.zeros(cap, dtype=torch.int64, device=dev); ys = torch.zeros(cap, dtype=torch.int64, device=dev)
         eng.part_minimizers_export(part, xs.data_ptr(), ys.data_ptr(), cap, rid_base)
         if world > 1:
