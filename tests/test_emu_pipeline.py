@@ -267,6 +267,63 @@ def test_emulated_checkpointed_walks(emu_lib, tmp_path, monkeypatch, variant):
     assert sum(1 for l in out.splitlines() if l.split("\t")[2] != "0") >= 4
 
 
+def _repeat_rich_dataset(tmp_path, seed, n_targets=60, n_queries=8, glen=40000):
+    """a genome full of tandem repeats (unit 30-300, 3-12 copies) and dispersed copies of 300-1500-base segments, reads with
+    few errors: most queries carry the same (minimizer, strand) several times, so anchors with equal x -- whose final order is
+    klib's and decides chains and rows -- are everywhere"""
+    from longqc_amd import synth
+    rng = np.random.default_rng(1000 + seed)
+    A = synth._ACGT
+    g = A[rng.integers(0, 4, size=glen, dtype=np.uint8)]
+    for _ in range(12):
+        u = int(rng.integers(30, 300)); c = int(rng.integers(3, 12)); at = int(rng.integers(0, glen - u * c))
+        g[at:at + u * c] = np.tile(g[at:at + u], c)
+    for _ in range(10):
+        L = int(rng.integers(300, 1500)); src = int(rng.integers(0, glen - L)); dst = int(rng.integers(0, glen - L))
+        seg = g[src:src + L].copy()
+        g[dst:dst + L] = synth._COMP[seg[::-1]] if rng.random() < 0.5 else seg
+    err = float(rng.choice([0.01, 0.04, 0.08]))
+
+    def read(lo, hi):
+        L = int(rng.integers(lo, hi)); st = int(rng.integers(0, glen - L))
+        s = g[st:st + L]
+        if rng.random() < 0.5:
+            s = synth._COMP[s[::-1]]
+        return synth._mutate(s, rng, err, (3, 3, 4))
+
+    def readset(prefix, n, lo, hi):
+        seqs = [read(lo, hi) for _ in range(n)]
+        return synth.ReadSet(["%s%03d" % (prefix, i) for i in range(n)], seqs, [(33 + rng.integers(3, 30, size=x.shape[0])).astype(np.uint8) for x in seqs])
+    T, Q = readset("t", n_targets, 3000, 12000), readset("q", n_queries, 6000, 20000)
+    tf, qf = str(tmp_path / ("rr%d_all.fq" % seed)), str(tmp_path / ("rr%d_sub.fq" % seed))
+    synth.write_fastq(tf, T); synth.write_fastq(qf, Q)
+    return tf, qf
+
+
+def check_repeat_rich_randomised(lib, tmp_path, monkeypatch, seed):
+    tf, qf = _repeat_rich_dataset(tmp_path, seed)
+    argv = ONT + [tf, qf]
+    want = oracle_bind.ref_table(argv) if oracle_bind.have_ref() else oracle_bind.table(argv)
+    # the size classes of the walks and of the parallel sort move with the seed, so that small inputs reach each of them
+    monkeypatch.setenv("LQCOV_WALK_SHIFT", str([0, 4, 7, 10][seed % 4]))
+    monkeypatch.setenv("LQCOV_PS_SHIFT", str([0, 3, 7][seed % 3]))
+    rc, out, err = run_main(lib, argv)
+    assert rc == 0, err
+    assert out == want
+    return argv, want
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_emulated_repeat_rich_randomised(emu_lib, tmp_path, monkeypatch, seed):
+    """equal-x anchors everywhere (repeats inside the queries): rows equal the reference binary's, whichever path the sub-arrays
+    take (parallel passes for those without a tie, klib's walk for the others); and the input has teeth: a stable sort by x
+    gives a different table"""
+    argv, want = check_repeat_rich_randomised(emu_lib, tmp_path, monkeypatch, seed)
+    assert sum(1 for l in want.splitlines() if l.split("\t")[2] != "0") >= 4
+    if seed == 0:
+        assert oracle_bind.table(argv, ["--stable-sort"]) != want
+
+
 def test_emulated_ultra_long_reads(emu_lib, tmp_path):
     """reads of 100-350 kb at 30x (the shape of BASELINE configs[4]): (query, strand) sub-arrays of 10^5 anchors and runs
     of thousands per target; the three longest as queries, against the reference binary (or the oracle)"""

@@ -234,6 +234,11 @@ def test_gpu_parallel_sort_size_classes(gpu_lib, datasets, monkeypatch, shift):
     assert out == want
 
 
+@pytest.mark.parametrize("seed", list(range(3, 11)))
+def test_gpu_repeat_rich_randomised(gpu_lib, tmp_path, monkeypatch, seed):
+    E.check_repeat_rich_randomised(gpu_lib, tmp_path, monkeypatch, seed)
+
+
 @pytest.mark.parametrize("variant", ["ckpt", "ckpt_all_klib", "plain"])
 def test_gpu_checkpointed_walks(gpu_lib, tmp_path, monkeypatch, variant):
     E.test_emulated_checkpointed_walks(gpu_lib, tmp_path, monkeypatch, variant)
