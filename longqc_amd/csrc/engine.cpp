@@ -540,15 +540,36 @@ void lqcov_handle::map_batch(MapLane &L, Part &pt, u32 q0, u32 q1, const std::ve
 		const u64 *aqb = aq_off.as<u64>() + q0;          // batch view of the per-query anchor offsets
 		sort_batch(L, pt, q0, nqb, a_base, nA);           // lqmap.c:238
 		// ---- (strand, rid) runs ----
-		dzero(d_head, nA * 4, L.stream);
-		LQ_LAUNCH(k_mark_qstart, nblk(nqb, 256), 256, L.stream, aqb, a_base, nqb, d_head); check_launch();
-		LQ_LAUNCH(k_group_heads, nblk(nA, 256), 256, L.stream, dA, nA, d_head); check_launch();
-		L.prim.exclusive_scan_u32_u64(d_head, d_gid, nA);
-		u64 lg = 0; u32 lh = 0;
-		d2h(&lg, d_gid + nA - 1, 1, L.stream); d2h(&lh, d_head + nA - 1, 1, L.stream);
-		const u64 n_groups = lg + lh;
-		L.gstart.ensure((n_groups + 1) * 8);
-		LQ_LAUNCH(k_group_starts, nblk(nA, 256), 256, L.stream, d_head, d_gid, nA, n_groups, L.gstart.as<u64>()); check_launch();
+		// (LQCOV_RUNS=scan: the head / id arrays and library scans of round 1, kept for one round of A/B)
+		const bool runs_two_pass = !(getenv("LQCOV_RUNS") && !strcmp(getenv("LQCOV_RUNS"), "scan"));
+		u64 n_groups = 0;
+		if (runs_two_pass) {
+			const u32 n_tiles = (u32)((nA + LQ_RUN_TILE - 1) / LQ_RUN_TILE);
+			L.run_tiles.ensure(((u64)n_tiles + 2) * 4);
+			u32 *tiles = L.run_tiles.as<u32>();
+			const u32 g = std::min<u32>(n_tiles, 1u << 16);
+			{
+				StageTimer t(this, L.stream, "k_run_count", nA * 16);
+				LQ_LAUNCH(k_run_count, g, LQ_RUN_THREADS, L.stream, dA, nA, aqb, a_base, nqb, n_tiles, tiles); check_launch();
+			}
+			LQ_LAUNCH(k_tile_scan, 1, LQ_TSCAN_THREADS, L.stream, tiles, n_tiles); check_launch();
+			u32 ng = 0;
+			d2h(&ng, tiles + n_tiles, 1, L.stream);
+			n_groups = ng;
+			L.gstart.ensure((n_groups + 1) * 8);
+			StageTimer t(this, L.stream, "k_run_starts", nA * 16 + n_groups * 8);
+			LQ_LAUNCH(k_run_starts, g, LQ_RUN_THREADS, L.stream, dA, nA, aqb, a_base, nqb, n_tiles, tiles, L.gstart.as<u64>()); check_launch();
+		} else {
+			dzero(d_head, nA * 4, L.stream);
+			LQ_LAUNCH(k_mark_qstart, nblk(nqb, 256), 256, L.stream, aqb, a_base, nqb, d_head); check_launch();
+			LQ_LAUNCH(k_group_heads, nblk(nA, 256), 256, L.stream, dA, nA, d_head); check_launch();
+			L.prim.exclusive_scan_u32_u64(d_head, d_gid, nA);
+			u64 lg = 0; u32 lh = 0;
+			d2h(&lg, d_gid + nA - 1, 1, L.stream); d2h(&lh, d_head + nA - 1, 1, L.stream);
+			n_groups = lg + lh;
+			L.gstart.ensure((n_groups + 1) * 8);
+			LQ_LAUNCH(k_group_starts, nblk(nA, 256), 256, L.stream, d_head, d_gid, nA, n_groups, L.gstart.as<u64>()); check_launch();
+		}
 		// ---- chain + coverage ----
 		const u32 ivl_cap = (u32)std::min<u64>(nA / (P.min_cnt > 0 ? P.min_cnt : 1) + 16, 0xfffffff0ULL);
 		L.ivl.ensure((u64)ivl_cap * sizeof(Ivl));
@@ -576,15 +597,29 @@ void lqcov_handle::map_batch(MapLane &L, Part &pt, u32 q0, u32 q1, const std::ve
 			check_launch();
 		}
 		{	// long runs (the tail of the kernel above if left there): one wave per run, longest first
-			L.gflag.ensure(n_groups * 4 + 4); L.gidx.ensure(n_groups * 4 + 4);
-			LQ_LAUNCH(k_group_flags, nblk(n_groups, 256), 256, L.stream, L.gstart.as<u64>(), n_groups, (i32)wave_min, L.gflag.as<u32>()); check_launch();
-			L.prim.exclusive_scan_u32_u32(L.gflag.as<u32>(), L.gidx.as<u32>(), n_groups);
-			u32 lgi = 0, lgf = 0;
-			d2h(&lgi, L.gidx.as<u32>() + n_groups - 1, 1, L.stream); d2h(&lgf, L.gflag.as<u32>() + n_groups - 1, 1, L.stream);
-			const u32 n_sel = lgi + lgf;
+			u32 n_sel = 0;
+			if (runs_two_pass) {
+				const u32 n_tiles = (u32)((n_groups + LQ_RUN_TILE - 1) / LQ_RUN_TILE);
+				L.sel_tiles.ensure(((u64)n_tiles + 2) * 4);
+				LQ_LAUNCH(k_sel_count, std::min<u32>(std::max<u32>(n_tiles, 1), 1u << 16), LQ_RUN_THREADS, L.stream, L.gstart.as<u64>(), n_groups, (i32)wave_min, n_tiles, L.sel_tiles.as<u32>()); check_launch();
+				LQ_LAUNCH(k_tile_scan, 1, LQ_TSCAN_THREADS, L.stream, L.sel_tiles.as<u32>(), n_tiles); check_launch();
+				d2h(&n_sel, L.sel_tiles.as<u32>() + n_tiles, 1, L.stream);
+			} else {
+				L.gflag.ensure(n_groups * 4 + 4); L.gidx.ensure(n_groups * 4 + 4);
+				LQ_LAUNCH(k_group_flags, nblk(n_groups, 256), 256, L.stream, L.gstart.as<u64>(), n_groups, (i32)wave_min, L.gflag.as<u32>()); check_launch();
+				L.prim.exclusive_scan_u32_u32(L.gflag.as<u32>(), L.gidx.as<u32>(), n_groups);
+				u32 lgi = 0, lgf = 0;
+				d2h(&lgi, L.gidx.as<u32>() + n_groups - 1, 1, L.stream); d2h(&lgf, L.gflag.as<u32>() + n_groups - 1, 1, L.stream);
+				n_sel = lgi + lgf;
+			}
 			if (n_sel) {
 				L.gsel.ensure((u64)n_sel * 4); L.gkey.ensure((u64)n_sel * 4); L.gsel2.ensure((u64)n_sel * 4); L.gkey2.ensure((u64)n_sel * 4);
-				LQ_LAUNCH(k_group_compact, nblk(n_groups, 256), 256, L.stream, L.gstart.as<u64>(), L.gflag.as<u32>(), L.gidx.as<u32>(), n_groups, L.gsel.as<u32>(), L.gkey.as<u32>()); check_launch();
+				if (runs_two_pass) {
+					const u32 n_tiles = (u32)((n_groups + LQ_RUN_TILE - 1) / LQ_RUN_TILE);
+					LQ_LAUNCH(k_sel_write, std::min<u32>(n_tiles, 1u << 16), LQ_RUN_THREADS, L.stream, L.gstart.as<u64>(), n_groups, (i32)wave_min, n_tiles, L.sel_tiles.as<u32>(), L.gsel.as<u32>(), L.gkey.as<u32>()); check_launch();
+				} else {
+					LQ_LAUNCH(k_group_compact, nblk(n_groups, 256), 256, L.stream, L.gstart.as<u64>(), L.gflag.as<u32>(), L.gidx.as<u32>(), n_groups, L.gsel.as<u32>(), L.gkey.as<u32>()); check_launch();
+				}
 				L.prim.sort_pairs_u32_u32(L.gkey.as<u32>(), L.gkey2.as<u32>(), L.gsel.as<u32>(), L.gsel2.as<u32>(), n_sel);
 				StageTimer t(this, L.stream, "k_chain_wave", nA * 16);
 				LQ_LAUNCH(k_chain_wave, n_sel, 64, L.stream, dA, L.gstart.as<u64>(), L.gsel2.as<u32>(), n_sel, aqb, a_base, nqb, q0, avg_qspan.as<float>(), mp, cb, cs);

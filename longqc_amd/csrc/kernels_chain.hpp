@@ -39,6 +39,116 @@ __global__ void k_group_starts(const u32 *head, const u64 *gid, u64 n, u64 n_gro
 	if (head[i]) gstart[gid[i]] = i;
 }
 
+// ---- the same list of run starts in two light passes (count per tile, tiny scan, write) ----------------------------------
+// A run starts at the first anchor of the batch, at the first anchor of every query and wherever the high word of x (strand,
+// rid) changes.  Both passes read only the anchors (no head / id arrays of 4 + 8 bytes per anchor, no library scan over them),
+// have no dependency between blocks and no global atomics: pass 1 counts the starts of every 4096-anchor tile, one block scans
+// the tile counts, pass 2 finds the same starts again and writes them at tile offset + rank in the tile.
+#define LQ_RUN_TILE 4096
+#define LQ_RUN_THREADS 256
+#define LQ_RUN_ROWS (LQ_RUN_TILE / LQ_RUN_THREADS)
+#define LQ_RUN_WAVES (LQ_RUN_THREADS / 64)
+
+// ballots of "a run starts here" for the rows of one tile (row j = anchors base + j * 256 + [0, 256)); qbits: LDS bitmap of
+// the query starts inside the tile
+__device__ __forceinline__ void lq_run_heads(const mm128 *A, u64 n, const u64 *aq_off, u64 a_base, u32 n_q, u64 base, u32 *qbits, u64 (&bal)[LQ_RUN_ROWS])
+{
+	const u32 t = threadIdx.x, lane = t & 63;
+	if (t < LQ_RUN_TILE / 32) qbits[t] = 0;
+	__syncthreads();
+	{	// queries that start in [base, base + tile): the first candidate is the query that holds `base`
+		u32 lo = 0, hi = n_q;                                 // invariant: aq_off[lo] - a_base <= base
+		while (hi - lo > 1) { const u32 mid = lo + ((hi - lo) >> 1); if (aq_off[mid] - a_base <= base) lo = mid; else hi = mid; }
+		for (u32 q = lo + t; q < n_q; q += LQ_RUN_THREADS) {
+			const u64 p = aq_off[q] - a_base;
+			if (p >= base + LQ_RUN_TILE) break;
+			if (p >= base && aq_off[q] < aq_off[q + 1]) atomicOr(&qbits[(u32)(p - base) >> 5], 1u << ((u32)(p - base) & 31));
+		}
+	}
+	__syncthreads();
+#pragma unroll
+	for (int j = 0; j < LQ_RUN_ROWS; ++j) {
+		const u32 o = (u32)j * LQ_RUN_THREADS + t;
+		const u64 i = base + o;
+		const u32 hi32 = i < n ? (u32)(A[i].x >> 32) : 0u;
+		u32 prev = __shfl_up(hi32, 1);
+		if (lane == 0) prev = (i > 0 && i < n) ? (u32)(A[i - 1].x >> 32) : ~hi32;
+		const bool head = i < n && (i == 0 || hi32 != prev || (qbits[o >> 5] >> (o & 31) & 1));
+		bal[j] = __ballot(head);
+	}
+}
+
+__global__ void __launch_bounds__(LQ_RUN_THREADS)
+k_run_count(const mm128 *A, u64 n, const u64 *aq_off, u64 a_base, u32 n_q, u32 n_tiles, u32 *tile_cnt)
+{
+	__shared__ u32 qbits[LQ_RUN_TILE / 32];
+	__shared__ u32 tot;
+	for (u32 T = blockIdx.x; T < n_tiles; T += gridDim.x) {
+		if (threadIdx.x == 0) tot = 0;
+		u64 bal[LQ_RUN_ROWS];
+		lq_run_heads(A, n, aq_off, a_base, n_q, (u64)T * LQ_RUN_TILE, qbits, bal);   // (its barriers order the reset of tot)
+		u32 c = 0;
+#pragma unroll
+		for (int j = 0; j < LQ_RUN_ROWS; ++j) c += (u32)__popcll(bal[j]);
+		if ((threadIdx.x & 63) == 0) atomicAdd(&tot, c);
+		__syncthreads();
+		if (threadIdx.x == 0) tile_cnt[T] = tot;
+		__syncthreads();
+	}
+}
+
+// exclusive scan of n counts in place, the total in cnt[n]; one block
+#define LQ_TSCAN_THREADS 1024
+__global__ void __launch_bounds__(LQ_TSCAN_THREADS)
+k_tile_scan(u32 *cnt, u32 n)
+{
+	__shared__ u32 wsum[LQ_TSCAN_THREADS / 64];
+	const u32 t = threadIdx.x, lane = t & 63, w = t >> 6;
+	const u32 per = (n + LQ_TSCAN_THREADS - 1) / LQ_TSCAN_THREADS;
+	const u32 a = (u64)t * per < n ? t * per : n, b = a + per < n ? a + per : n;
+	u32 sum = 0;
+	for (u32 x = a; x < b; ++x) sum += cnt[x];
+	u32 inc = sum;
+	for (int d = 1; d < 64; d <<= 1) { const u32 o = __shfl_up(inc, d); if ((int)lane >= d) inc += o; }
+	if (lane == 63) wsum[w] = inc;
+	__syncthreads();
+	if (t == 0) { u32 run = 0; for (u32 x = 0; x < LQ_TSCAN_THREADS / 64; ++x) { const u32 v = wsum[x]; wsum[x] = run; run += v; } cnt[n] = run; }
+	__syncthreads();
+	u32 run = wsum[w] + inc - sum;
+	for (u32 x = a; x < b; ++x) { const u32 v = cnt[x]; cnt[x] = run; run += v; }
+}
+
+__global__ void __launch_bounds__(LQ_RUN_THREADS)
+k_run_starts(const mm128 *A, u64 n, const u64 *aq_off, u64 a_base, u32 n_q, u32 n_tiles, const u32 *tile_off, u64 *gstart)
+{
+	__shared__ u32 qbits[LQ_RUN_TILE / 32];
+	__shared__ u32 pre[LQ_RUN_ROWS * LQ_RUN_WAVES];
+	const u32 t = threadIdx.x, lane = t & 63, w = t >> 6;
+	if (blockIdx.x == 0 && t == 0) gstart[tile_off[n_tiles]] = n;
+	for (u32 T = blockIdx.x; T < n_tiles; T += gridDim.x) {
+		const u64 base = (u64)T * LQ_RUN_TILE;
+		u64 bal[LQ_RUN_ROWS];
+		lq_run_heads(A, n, aq_off, a_base, n_q, base, qbits, bal);
+		if (lane == 0) {
+#pragma unroll
+			for (int j = 0; j < LQ_RUN_ROWS; ++j) pre[j * LQ_RUN_WAVES + w] = (u32)__popcll(bal[j]);
+		}
+		__syncthreads();
+		if (t < 64) {                                             // exclusive scan of the 64 (row, wave) counts: index order
+			const u32 v = pre[t];
+			u32 inc = v;
+			for (int d = 1; d < 64; d <<= 1) { const u32 o = __shfl_up(inc, d); if ((int)lane >= d) inc += o; }
+			pre[t] = inc - v;
+		}
+		__syncthreads();
+		const u32 off = tile_off[T];
+#pragma unroll
+		for (int j = 0; j < LQ_RUN_ROWS; ++j)
+			if (bal[j] >> lane & 1) gstart[off + pre[j * LQ_RUN_WAVES + w] + (u32)__popcll(bal[j] & ((1ULL << lane) - 1))] = base + (u32)j * LQ_RUN_THREADS + t;
+		__syncthreads();
+	}
+}
+
 __device__ __forceinline__ int lq_ilog2_32(u32 v) { return 31 - __clz(v); }   // chain.c:15-20 for v > 0
 
 template <class UP>
@@ -139,6 +249,66 @@ __global__ void k_group_compact(const u64 *gstart, const u32 *flag, const u32 *i
 	u64 g = (u64)blockIdx.x * blockDim.x + threadIdx.x;
 	if (g >= n_groups) return;
 	if (flag[g]) { sel[idx[g]] = (u32)g; key[idx[g]] = 0xffffffffu - (u32)(gstart[g + 1] - gstart[g]); }
+}
+
+// the same work list in two light passes over the run starts (count per tile, scan of the tile counts, write)
+__global__ void __launch_bounds__(LQ_RUN_THREADS)
+k_sel_count(const u64 *gstart, u64 n_groups, i32 min_cnt, u32 n_tiles, u32 *tile_cnt)
+{
+	__shared__ u32 tot;
+	for (u32 T = blockIdx.x; T < n_tiles; T += gridDim.x) {
+		if (threadIdx.x == 0) tot = 0;
+		__syncthreads();
+		u32 c = 0;
+		for (int j = 0; j < LQ_RUN_ROWS; ++j) {
+			const u64 g = (u64)T * LQ_RUN_TILE + (u32)j * LQ_RUN_THREADS + threadIdx.x;
+			i64 l = 0;
+			if (g < n_groups) l = (i64)(gstart[g + 1] - gstart[g]);
+			c += (u32)__popcll(__ballot(g < n_groups && l >= (i64)min_cnt));
+		}
+		if ((threadIdx.x & 63) == 0) atomicAdd(&tot, c);
+		__syncthreads();
+		if (threadIdx.x == 0) tile_cnt[T] = tot;
+		__syncthreads();
+	}
+}
+
+__global__ void __launch_bounds__(LQ_RUN_THREADS)
+k_sel_write(const u64 *gstart, u64 n_groups, i32 min_cnt, u32 n_tiles, const u32 *tile_off, u32 *sel, u32 *key)
+{
+	__shared__ u32 pre[LQ_RUN_ROWS * LQ_RUN_WAVES];
+	const u32 t = threadIdx.x, lane = t & 63, w = t >> 6;
+	for (u32 T = blockIdx.x; T < n_tiles; T += gridDim.x) {
+		u64 bal[LQ_RUN_ROWS];
+		u32 len[LQ_RUN_ROWS];
+#pragma unroll
+		for (int j = 0; j < LQ_RUN_ROWS; ++j) {
+			const u64 g = (u64)T * LQ_RUN_TILE + (u32)j * LQ_RUN_THREADS + t;
+			const u64 l = g < n_groups ? gstart[g + 1] - gstart[g] : 0;
+			len[j] = (u32)l;
+			bal[j] = __ballot(g < n_groups && (i64)l >= (i64)min_cnt);
+		}
+		if (lane == 0) {
+#pragma unroll
+			for (int j = 0; j < LQ_RUN_ROWS; ++j) pre[j * LQ_RUN_WAVES + w] = (u32)__popcll(bal[j]);
+		}
+		__syncthreads();
+		if (t < 64) {
+			const u32 v = pre[t];
+			u32 inc = v;
+			for (int d = 1; d < 64; d <<= 1) { const u32 o = __shfl_up(inc, d); if ((int)lane >= d) inc += o; }
+			pre[t] = inc - v;
+		}
+		__syncthreads();
+		const u32 off = tile_off[T];
+#pragma unroll
+		for (int j = 0; j < LQ_RUN_ROWS; ++j)
+			if (bal[j] >> lane & 1) {
+				const u32 r = off + pre[j * LQ_RUN_WAVES + w] + (u32)__popcll(bal[j] & ((1ULL << lane) - 1));
+				sel[r] = (u32)((u64)T * LQ_RUN_TILE + (u32)j * LQ_RUN_THREADS + t); key[r] = 0xffffffffu - len[j];
+			}
+		__syncthreads();
+	}
 }
 
 // mm_chain_dp, first half (chain.c:41-81): scores f, predecessors p, peak scores v of one run, serially

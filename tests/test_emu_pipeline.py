@@ -267,6 +267,51 @@ def test_emulated_checkpointed_walks(emu_lib, tmp_path, monkeypatch, variant):
     assert sum(1 for l in out.splitlines() if l.split("\t")[2] != "0") >= 4
 
 
+def _many_short_queries_dataset(tmp_path, n_targets=60, n_queries=500, seed=5):
+    """hundreds of queries of 150-500 bases: a few dozen anchors each, so that dozens of queries start inside one
+    4096-anchor tile of the run list (kernels_chain.hpp: k_run_count / k_run_starts), some of them without any anchor"""
+    from longqc_amd import synth
+    rng = np.random.default_rng(seed)
+    A = synth._ACGT
+    g = A[rng.integers(0, 4, size=30000, dtype=np.uint8)]
+
+    def read(lo, hi, err):
+        L = int(rng.integers(lo, hi)); st = int(rng.integers(0, g.shape[0] - L))
+        s = g[st:st + L]
+        if rng.random() < 0.5:
+            s = synth._COMP[s[::-1]]
+        return synth._mutate(s, rng, err, (3, 3, 4))
+
+    def readset(prefix, seqs):
+        return synth.ReadSet(["%s%04d" % (prefix, i) for i in range(len(seqs))], seqs, [(33 + rng.integers(3, 30, size=x.shape[0])).astype(np.uint8) for x in seqs])
+    T = readset("t", [read(2000, 6000, 0.05) for _ in range(n_targets)])
+    qs = [read(150, 500, 0.03) for _ in range(n_queries)]
+    for i in range(0, n_queries, 17):
+        qs[i] = A[rng.integers(0, 4, size=int(rng.integers(30, 200)), dtype=np.uint8)]      # unrelated: no anchors at all
+    Q = readset("q", qs)
+    tf, qf = str(tmp_path / "msq_all.fq"), str(tmp_path / "msq_sub.fq")
+    synth.write_fastq(tf, T); synth.write_fastq(qf, Q)
+    return tf, qf
+
+
+def check_run_list_variants(lib, tmp_path, monkeypatch):
+    tf, qf = _many_short_queries_dataset(tmp_path)
+    argv = ["-Y", "-l", "0", "-q", "40", "-k", "12", "-w", "5", "-I", "4G", "-p", "40", "-m", "20", "-t", "4", tf, qf]
+    want = oracle_bind.ref_table(argv) if oracle_bind.have_ref() else oracle_bind.table(argv)
+    assert sum(1 for l in want.splitlines() if l.split("\t")[2] != "0") >= 100
+    for runs in ("", "scan"):                      # two light passes over the anchors (default) | round 1's head / id arrays
+        monkeypatch.setenv("LQCOV_RUNS", runs)
+        for budget in ("", "3000"):                # one batch | batches of a few queries (run lists of a few tiles)
+            monkeypatch.setenv("LQCOV_ANCHOR_BUDGET", budget) if budget else monkeypatch.delenv("LQCOV_ANCHOR_BUDGET", raising=False)
+            rc, out, err = run_main(lib, argv)
+            assert rc == 0, err
+            assert out == want, (runs, budget)
+
+
+def test_emulated_run_list_variants(emu_lib, tmp_path, monkeypatch):
+    check_run_list_variants(emu_lib, tmp_path, monkeypatch)
+
+
 def _repeat_rich_dataset(tmp_path, seed, n_targets=60, n_queries=8, glen=40000):
     """a genome full of tandem repeats (unit 30-300, 3-12 copies) and dispersed copies of 300-1500-base segments, reads with
     few errors: most queries carry the same (minimizer, strand) several times, so anchors with equal x -- whose final order is

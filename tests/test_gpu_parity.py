@@ -234,6 +234,10 @@ def test_gpu_parallel_sort_size_classes(gpu_lib, datasets, monkeypatch, shift):
     assert out == want
 
 
+def test_gpu_run_list_variants(gpu_lib, tmp_path, monkeypatch):
+    E.check_run_list_variants(gpu_lib, tmp_path, monkeypatch)
+
+
 @pytest.mark.parametrize("seed", list(range(3, 11)))
 def test_gpu_repeat_rich_randomised(gpu_lib, tmp_path, monkeypatch, seed):
     E.check_repeat_rich_randomised(gpu_lib, tmp_path, monkeypatch, seed)
