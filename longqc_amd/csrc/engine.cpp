@@ -838,7 +838,9 @@ void lqcov_handle::sort_batch(MapLane &L, Part &pt, u32 q0, u32 nqb, u64 a_base,
 				if (!(getenv("LQCOV_CKPT") && !strcmp(getenv("LQCOV_CKPT"), "0")) && ns <= (1u << 20)) {
 					u32 hc[LQ_C_N]; d2h(hc, cnt, LQ_C_N, sD);
 					// (with many buckets finding the states costs about as much as walking 50-100 k elements: only the longest class)
-					const u32 n3 = ck_small ? hc[LQ_C_WALK3] : 0, n4 = hc[LQ_C_WALK4];
+					// (LQCOV_CKPT3=1: the 65-160 k class of a many-bucket pass as well -- to be measured)
+					const bool ck3 = ck_small || (getenv("LQCOV_CKPT3") && atoi(getenv("LQCOV_CKPT3")) > 0);
+					const u32 n3 = ck3 ? hc[LQ_C_WALK3] : 0, n4 = hc[LQ_C_WALK4];
 					if (n3 + n4) {
 						std::vector<u32> ids(n3 + n4);
 						if (n3) d2h(ids.data(), wl + (u64)3 * ns, n3, sD);
@@ -891,7 +893,7 @@ void lqcov_handle::sort_batch(MapLane &L, Part &pt, u32 q0, u32 nqb, u64 a_base,
 									LQ_LAUNCH(k_sort_walk_solo, std::min<u32>(n_ck, wgrid), 64, sW, cur, (const u32*)nullptr, L.ck_n.as<u32>(), dD, dH, dBg, dDst, dck, n_cks, L.ck_S.as<u32>(), L.ck_slot.as<u32>()); check_launch();
 								}
 							}
-							first_plain_class = ck_small ? 2 : 3;
+							first_plain_class = ck3 ? 2 : 3;
 						}
 					}
 				}
