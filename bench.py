@@ -101,6 +101,7 @@ def main():
     ap.add_argument("--nsample", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0, help="target reads in the CPU baseline sample (~20-30 s of reference time)")
+    ap.add_argument("--cache", default="", help="directory for the generated reads (re-used by later runs of the same config on this machine)")
     ap.add_argument("--workers", type=int, default=0, help="processes of the synthetic generator (0: one per core, at most 64)")
     args = ap.parse_args()
 
@@ -133,7 +134,17 @@ def main():
 
     t0 = time.time()
     genome = synth.make_genome(cfg)
-    F = synth.make_reads_flat(cfg, genome, workers=args.workers)                 # every read of the config, flat ASCII
+    F = None
+    cache = None
+    if args.cache:                                                                # A/B loops on one box: generate the reads once
+        cache = os.path.join(args.cache, "lqcov_%s_%d_seed%d" % (args.config, cfg.n_reads, cfg.seed))
+        if os.path.exists(cache + ".off.npy"):
+            F = synth.FlatReads(0, np.load(cache + ".flat.npy"), np.load(cache + ".off.npy"))
+    if F is None:
+        F = synth.make_reads_flat(cfg, genome, workers=args.workers)             # every read of the config, flat ASCII
+        if cache and rank == 0:
+            os.makedirs(args.cache, exist_ok=True)
+            np.save(cache + ".flat.npy", F.flat); np.save(cache + ".off.tmp.npy", F.off); os.replace(cache + ".off.tmp.npy", cache + ".off.npy")
     qidx = synth.reservoir_subsample(cfg.n_reads, cfg.nsample)                   # LongQC's seed-7 subsample (lq_utils.py:371-411)
     Q = synth.make_reads(cfg, genome, indices=qidx)
     t_gen = time.time() - t0

@@ -1,0 +1,19 @@
+#!/bin/bash
+# A/B of engine knobs on the bench workload in ONE gpurun call: the reads are generated once (bench.py --cache), every
+# variant is one bench run under its own time limit; one line per variant in gpurun_out/ab.log.
+#   VARIANTS="base|LQCOV_RUNS=scan|LQCOV_CKPT3=1|LQCOV_LANES=3 LQCOV_CKPT3=1"  CFG=cfg3  STEPS=3  bash tools/gpu_ab.sh
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out; : > gpurun_out/ab.log
+IFS='|' read -ra VS <<< "${VARIANTS:-base|LQCOV_RUNS=scan|LQCOV_CKPT3=1}"
+for V in "${VS[@]}"; do
+  E="$V"; [ "$V" = base ] && E=""
+  env $E timeout ${LIMIT:-300} python bench.py --config ${CFG:-cfg3} --steps ${STEPS:-3} --warmup 1 --no-cpu-baseline --cache /tmp/lqcov_cache 2>gpurun_out/ab_err.log | tail -1 | python -c "
+import sys, json
+try:
+    j = json.loads(sys.stdin.read())
+    print('%-40s %9.1f Mbases/s %8.1f ms  rows %s  %s' % ('$V', j['value'], j['ms_per_step'], (j.get('golden_rows') or {}).get('rows_identical'),
+          {k: round(v) for k, v in list(j['roofline']['kernel_ms_one_step'].items())[:10]}))
+except Exception as e:
+    print('%-40s failed: %r' % ('$V', e)); print(open('gpurun_out/ab_err.log').read()[-600:])
+" >> gpurun_out/ab.log 2>&1
+done
+cat gpurun_out/ab.log

@@ -6,7 +6,7 @@ for C in ${CFGS:-cfg3}; do
   python -c "
 import sys, json
 j = json.loads(open('gpurun_out/bench_$C.json').read())
-print('$C', j['value'], j['ms_per_step'], j['golden_rows'] and j['golden_rows']['rows_identical'], j['roofline']['kernel'], j['roofline']['frac'])
+print('$C', j['value'], j['ms_per_step'], (j.get('golden_rows') or {}).get('rows_identical'), j['roofline']['kernel'], j['roofline']['frac'])
 print({k: round(v) for k, v in list(j['roofline']['kernel_ms_one_step'].items())[:16]})
 "
 done
