@@ -783,6 +783,7 @@ void lqcov_handle::sort_batch(MapLane &L, Part &pt, u32 q0, u32 nqb, u64 a_base,
 		WalkCaps wcaps; wcaps.c[0] = 4096; wcaps.c[1] = 16384; wcaps.c[2] = 65536; wcaps.c[3] = 159744;
 		if (const char *ws = getenv("LQCOV_WALK_SHIFT")) for (int c = 0; c < 4; ++c) wcaps.c[c] >>= atoi(ws);   // test knob
 		const bool reg_walker = !(getenv("LQCOV_WALK") && !strcmp(getenv("LQCOV_WALK"), "solo"));   // A/B knob
+		const bool sort_tiles = !(getenv("LQCOV_SORT_TILES") && !strcmp(getenv("LQCOV_SORT_TILES"), "0"));   // A/B knob
 		L.sort_d.ensure(nA + 64); L.sort_dst.ensure((nA + 1) * 4);
 		SortSeg *cur = L.segs0.as<SortSeg>(), *nxt = L.segs1.as<SortSeg>();
 		u32 cur_slot = LQ_C_KLIB0, nxt_slot = LQ_C_KLIB1;
@@ -793,9 +794,20 @@ void lqcov_handle::sort_batch(MapLane &L, Part &pt, u32 q0, u32 nqb, u64 a_base,
 			L.seg_info.ensure((u64)ns * sizeof(SegInfo)); L.walk_list.ensure((u64)ns * 4 * LQ_WALK_CLASSES); L.two_list.ensure((u64)ns * 4);
 			dzero(cnt + nxt_slot, 4, sD); dzero(cnt + LQ_C_TWO, 4 * (1 + LQ_WALK_CLASSES), sD);
 			const u32 g_seg = std::min<u32>(ns, 1u << 18);
+			// tiles of the level's sub-arrays for the two streaming kernels (LQCOV_SORT_TILES=0: one block per sub-array, as in round 1)
+			const u32 tile = getenv("LQCOV_SORT_TILE") ? (u32)std::max(64, atoi(getenv("LQCOV_SORT_TILE"))) : LQ_SORT_TILE;   // test / tuning knob
+			const u64 max_tiles = nA / tile + ns + 1;
+			const u32 g_tile = (u32)std::min<u64>(max_tiles, 1u << 18);
+			if (sort_tiles) {
+				L.tile_list.ensure(max_tiles * sizeof(SortTile));
+				dzero(cnt + LQ_C_TILES, 4, sD);
+				LQ_LAUNCH(k_sort_tiles, std::min<u32>(ns / 256 + 1, 4096), 256, sD, cur, cnt + cur_slot, tile, L.tile_list.as<SortTile>(), cnt + LQ_C_TILES, L.hist.as<u32>(), L.mhist.as<u32>());
+				check_launch();
+			}
 			{
 				StageTimer t(this, sD, "k_sort_copy_hist");
-				LQ_LAUNCH(k_sort_copy_hist, g_seg, 256, sD, cur, cnt + cur_slot, dA, dB, L.sort_d.as<u8>(), L.hist.as<u32>(), L.mhist.as<u32>(), (unsigned long long*)(cnt + LQ_C_COPIED));
+				if (sort_tiles) LQ_LAUNCH(k_sort_copy_hist_tiled, g_tile, 256, sD, cur, L.tile_list.as<SortTile>(), cnt + LQ_C_TILES, tile, dA, dB, L.sort_d.as<u8>(), L.hist.as<u32>(), L.mhist.as<u32>(), (unsigned long long*)(cnt + LQ_C_COPIED));
+				else LQ_LAUNCH(k_sort_copy_hist, g_seg, 256, sD, cur, cnt + cur_slot, dA, dB, L.sort_d.as<u8>(), L.hist.as<u32>(), L.mhist.as<u32>(), (unsigned long long*)(cnt + LQ_C_COPIED));
 				check_launch();
 			}
 			LQ_LAUNCH(k_sort_classify, g_seg, LQ_CLASSIFY_THREADS, sD, cur, cnt + cur_slot, ns, L.hist.as<u32>(), L.begs.as<u32>(), L.seg_info.as<SegInfo>(),
@@ -915,7 +927,8 @@ void lqcov_handle::sort_batch(MapLane &L, Part &pt, u32 q0, u32 nqb, u64 a_base,
 			LQ_HIP_CHECK(hipStreamWaitEvent(sD, L.ev_w1, 0));
 			{
 				StageTimer t(this, sD, "k_sort_scatter");
-				LQ_LAUNCH(k_sort_scatter, g_seg, 256, sD, cur, L.seg_info.as<SegInfo>(), cnt + cur_slot, dA, dB, L.sort_dst.as<u32>(), (unsigned long long*)(cnt + LQ_C_SCATTERED));
+				if (sort_tiles) LQ_LAUNCH(k_sort_scatter_tiled, g_tile, 256, sD, cur, L.seg_info.as<SegInfo>(), L.tile_list.as<SortTile>(), cnt + LQ_C_TILES, tile, dA, dB, L.sort_dst.as<u32>(), (unsigned long long*)(cnt + LQ_C_SCATTERED));
+				else LQ_LAUNCH(k_sort_scatter, g_seg, 256, sD, cur, L.seg_info.as<SegInfo>(), cnt + cur_slot, dA, dB, L.sort_dst.as<u32>(), (unsigned long long*)(cnt + LQ_C_SCATTERED));
 				check_launch();
 			}
 			{

@@ -77,6 +77,91 @@ __global__ void k_sort_copy_hist(const SortSeg *segs, const u32 *n_segs_p, const
 	}
 }
 
+// ---- the same two streaming kernels over tiles of the sub-arrays -------------------------------------------------
+// The top passes of a batch have few, long sub-arrays (one per (query, strand) at first: a few hundred of ~10^5..10^6 anchors);
+// one block per sub-array leaves most of the chip idle and every CU with four waves' worth of loads in flight.  Here the level's
+// sub-arrays are cut into tiles of LQ_SORT_TILE anchors (a launch parameter: tests shrink it) (k_sort_tiles: a device-side list, one atomic per wave) and the
+// copy + histogram and the scatter run one block per tile; a sub-array of several tiles adds its tile histograms with atomics
+// into rows zeroed by k_sort_tiles, a sub-array of one tile stores its row as before.
+#define LQ_SORT_TILE 8192
+struct SortTile { u32 sgi, tile; };
+
+__global__ void __launch_bounds__(256)
+k_sort_tiles(const SortSeg *segs, const u32 *n_segs_p, u32 tile, SortTile *tiles, u32 *n_tiles, u32 *hist, u32 *mhist)
+{
+	const u32 n_segs = *n_segs_p;
+	const u32 lane = threadIdx.x & 63;
+	for (u32 base = blockIdx.x * blockDim.x; base < n_segs; base += gridDim.x * blockDim.x) {
+		const u32 sgi = base + threadIdx.x;
+		u32 nt = 0;
+		if (sgi < n_segs) { nt = (segs[sgi].len + tile - 1) / tile; if (nt == 0) nt = 1; }
+		u32 inc = nt;
+		for (int d = 1; d < 64; d <<= 1) { const u32 o = __shfl_up(inc, d); if ((int)lane >= d) inc += o; }
+		u32 wbase = 0;
+		if (lane == 63 && inc) wbase = atomicAdd(n_tiles, inc);
+		wbase = __shfl(wbase, 63);
+		const u32 at = wbase + inc - nt;
+		for (u32 t = 0; t < nt; ++t) { SortTile e; e.sgi = sgi; e.tile = t; tiles[at + t] = e; }
+		if (nt > 1) for (u32 c = 0; c < 256; ++c) { hist[(u64)sgi * 256 + c] = 0; mhist[(u64)sgi * 256 + c] = 0; }
+	}
+}
+
+__global__ void __launch_bounds__(256)
+k_sort_copy_hist_tiled(const SortSeg *segs, const SortTile *tiles, const u32 *n_tiles_p, u32 tile, const mm128 *A, mm128 *B, u8 *D, u32 *hist, u32 *mhist, unsigned long long *tally)
+{
+	__shared__ u32 lh[256], lm[256];
+	const u32 n_tiles = *n_tiles_p;
+	for (u32 ti = blockIdx.x; ti < n_tiles; ti += gridDim.x) {
+		const SortTile tl = tiles[ti];
+		const SortSeg sg = segs[tl.sgi];
+		const u32 i0 = tl.tile * tile, i1 = sg.len - i0 < tile ? sg.len : i0 + tile;
+		const mm128 *a = A + sg.off;
+		mm128 *b = B + sg.off;
+		u8 *d = D + sg.off;
+		if (tl.tile == 0 && threadIdx.x == 0 && tally) atomicAdd(tally, (unsigned long long)sg.len);
+		for (u32 c = threadIdx.x; c < 256; c += blockDim.x) { lh[c] = 0; lm[c] = 0; }
+		__syncthreads();
+		for (u32 i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
+			const mm128 e = a[i];
+			const u32 dg = (u32)(e.x >> sg.shift) & 0xff;
+			b[i] = e; d[i] = (u8)dg;
+			atomicAdd(&lh[dg], 1u);
+			if (e.y & LQ_TIE_MARK) atomicAdd(&lm[dg], 1u);
+		}
+		__syncthreads();
+		u32 *hrow = hist + (u64)tl.sgi * 256, *mrow = mhist + (u64)tl.sgi * 256;
+		if (sg.len <= tile) {
+			for (u32 c = threadIdx.x; c < 256; c += blockDim.x) { hrow[c] = lh[c]; mrow[c] = lm[c]; }
+		} else {
+			for (u32 c = threadIdx.x; c < 256; c += blockDim.x) { if (lh[c]) atomicAdd(&hrow[c], lh[c]); if (lm[c]) atomicAdd(&mrow[c], lm[c]); }
+		}
+		__syncthreads();
+	}
+}
+
+__global__ void __launch_bounds__(256)
+k_sort_scatter_tiled(const SortSeg *segs, const SegInfo *info, const SortTile *tiles, const u32 *n_tiles_p, u32 tile, mm128 *A, const mm128 *B, const u32 *dst, unsigned long long *tally)
+{
+	const u32 n_tiles = *n_tiles_p;
+	for (u32 ti = blockIdx.x; ti < n_tiles; ti += gridDim.x) {
+		const SortTile tl = tiles[ti];
+		if (info[tl.sgi].kind == LQ_SEG_IDENTITY) continue;
+		const SortSeg sg = segs[tl.sgi];
+		const u32 i0 = tl.tile * tile, i1 = sg.len - i0 < tile ? sg.len : i0 + tile;
+		uint4 *a = (uint4*)(A + sg.off);                         // (an anchor as one 16-byte register quad)
+		const uint4 *b = (const uint4*)(B + sg.off);
+		const u32 *ds = dst + sg.off;
+		if (tl.tile == 0 && threadIdx.x == 0 && tally) atomicAdd(tally, (unsigned long long)sg.len);
+		u32 i = i0 + threadIdx.x;
+		for (; i + 3 * 256 < i1; i += 4 * 256) {                 // four independent loads in flight per thread
+			const u32 d0 = ds[i], d1 = ds[i + 256], d2 = ds[i + 512], d3 = ds[i + 768];
+			const uint4 e0 = b[i], e1 = b[i + 256], e2 = b[i + 512], e3 = b[i + 768];
+			a[d0] = e0; a[d1] = e1; a[d2] = e2; a[d3] = e3;
+		}
+		for (; i < i1; i += 256) a[ds[i]] = b[i];
+	}
+}
+
 // one thread per sub-array: bucket offsets and the kind of pass; lists of general / two-bucket sub-arrays
 // size classes of general passes: digits of the sub-array fit a 4 / 16 / 64 / 156 KiB LDS window, or not at all
 #define LQ_WALK_CLASSES 5

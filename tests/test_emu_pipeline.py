@@ -352,6 +352,7 @@ def check_repeat_rich_randomised(lib, tmp_path, monkeypatch, seed):
     # the size classes of the walks and of the parallel sort move with the seed, so that small inputs reach each of them
     monkeypatch.setenv("LQCOV_WALK_SHIFT", str([0, 4, 7, 10][seed % 4]))
     monkeypatch.setenv("LQCOV_PS_SHIFT", str([0, 3, 7][seed % 3]))
+    monkeypatch.setenv("LQCOV_SORT_TILE", str([8192, 64, 1000][seed % 3]))      # tiles of the streaming kernels: one per sub-array | many
     monkeypatch.setenv("LQCOV_CKPT3", str(seed & 1))          # odd seeds: checkpoints for the second-longest class of many-bucket passes too
     rc, out, err = run_main(lib, argv)
     assert rc == 0, err
