@@ -927,7 +927,7 @@ void lqcov_handle::sort_batch(MapLane &L, Part &pt, u32 q0, u32 nqb, u64 a_base,
 			LQ_HIP_CHECK(hipStreamWaitEvent(sD, L.ev_w1, 0));
 			{
 				StageTimer t(this, sD, "k_sort_scatter");
-				if (sort_tiles) LQ_LAUNCH(k_sort_scatter_tiled, g_tile, 256, sD, cur, L.seg_info.as<SegInfo>(), L.tile_list.as<SortTile>(), cnt + LQ_C_TILES, tile, dA, dB, L.sort_dst.as<u32>(), (unsigned long long*)(cnt + LQ_C_SCATTERED));
+				if (sort_tiles) LQ_LAUNCH(k_sort_scatter_tiled, g_tile, 256, sD, cur, L.seg_info.as<SegInfo>(), L.tile_list.as<SortTile>(), cnt + LQ_C_TILES, tile, dA, dB, L.sort_dst.as<u32>(), (unsigned long long*)(cnt + LQ_C_SCATTERED), (unsigned long long*)(cnt + LQ_C_MOVED));
 				else LQ_LAUNCH(k_sort_scatter, g_seg, 256, sD, cur, L.seg_info.as<SegInfo>(), cnt + cur_slot, dA, dB, L.sort_dst.as<u32>(), (unsigned long long*)(cnt + LQ_C_SCATTERED));
 				check_launch();
 			}
@@ -951,7 +951,8 @@ void lqcov_handle::sort_batch(MapLane &L, Part &pt, u32 q0, u32 nqb, u64 a_base,
 		if (profiling) {	// algorithmic bytes of the sort's stages from what the kernels really moved (16-byte anchors)
 			auto t64 = [&](int i) { return (u64)hc[i] | (u64)hc[i + 1] << 32; };
 			add_stage_bytes("k_sort_copy_hist", t64(LQ_C_COPIED) * 33);          // anchor in, anchor + digit byte out
-			add_stage_bytes("k_sort_scatter", t64(LQ_C_SCATTERED) * 36);          // anchor + 4-byte destination in, anchor out
+			// 4-byte destination in; anchor in, anchor out for the anchors that move (all of them in the per-sub-array form)
+			add_stage_bytes("k_sort_scatter", t64(LQ_C_SCATTERED) * 4 + (t64(LQ_C_MOVED) ? t64(LQ_C_MOVED) : t64(LQ_C_SCATTERED)) * 32);
 			add_stage_bytes("k_ps_hist", (t64(LQ_C_PART0) + t64(LQ_C_PART1)) * 16);
 			add_stage_bytes("k_ps_scatter", (t64(LQ_C_PART0) + t64(LQ_C_PART1)) * 32);
 			add_stage_bytes("k_ps_finish<8192>", (t64(LQ_C_FINB0) + t64(LQ_C_FINB1)) * 32);

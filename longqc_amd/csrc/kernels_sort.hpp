@@ -140,7 +140,8 @@ k_sort_copy_hist_tiled(const SortSeg *segs, const SortTile *tiles, const u32 *n_
 }
 
 __global__ void __launch_bounds__(256)
-k_sort_scatter_tiled(const SortSeg *segs, const SegInfo *info, const SortTile *tiles, const u32 *n_tiles_p, u32 tile, mm128 *A, const mm128 *B, const u32 *dst, unsigned long long *tally)
+k_sort_scatter_tiled(const SortSeg *segs, const SegInfo *info, const SortTile *tiles, const u32 *n_tiles_p, u32 tile, mm128 *A, const mm128 *B, const u32 *dst, unsigned long long *tally,
+                     unsigned long long *moved)
 {
 	const u32 n_tiles = *n_tiles_p;
 	for (u32 ti = blockIdx.x; ti < n_tiles; ti += gridDim.x) {
@@ -152,13 +153,28 @@ k_sort_scatter_tiled(const SortSeg *segs, const SegInfo *info, const SortTile *t
 		const uint4 *b = (const uint4*)(B + sg.off);
 		const u32 *ds = dst + sg.off;
 		if (tl.tile == 0 && threadIdx.x == 0 && tally) atomicAdd(tally, (unsigned long long)sg.len);
-		u32 i = i0 + threadIdx.x;
+		u32 i = i0 + threadIdx.x, nm = 0;
+		// An element that stays where it is (klib leaves the elements of a bucket's own region alone: half of a two-bucket
+		// pass, a quarter of a four-bucket one) is neither read nor written: A still holds it.
 		for (; i + 3 * 256 < i1; i += 4 * 256) {                 // four independent loads in flight per thread
 			const u32 d0 = ds[i], d1 = ds[i + 256], d2 = ds[i + 512], d3 = ds[i + 768];
-			const uint4 e0 = b[i], e1 = b[i + 256], e2 = b[i + 512], e3 = b[i + 768];
-			a[d0] = e0; a[d1] = e1; a[d2] = e2; a[d3] = e3;
+			const bool m0 = d0 != i, m1 = d1 != i + 256, m2 = d2 != i + 512, m3 = d3 != i + 768;
+			uint4 e0 = {}, e1 = {}, e2 = {}, e3 = {};
+			if (m0) e0 = b[i];
+			if (m1) e1 = b[i + 256];
+			if (m2) e2 = b[i + 512];
+			if (m3) e3 = b[i + 768];
+			if (m0) a[d0] = e0;
+			if (m1) a[d1] = e1;
+			if (m2) a[d2] = e2;
+			if (m3) a[d3] = e3;
+			nm += (u32)m0 + (u32)m1 + (u32)m2 + (u32)m3;
 		}
-		for (; i < i1; i += 256) a[ds[i]] = b[i];
+		for (; i < i1; i += 256) { const u32 d = ds[i]; if (d != i) { a[d] = b[i]; ++nm; } }
+		if (moved) {
+			for (int o = 32; o > 0; o >>= 1) nm += __shfl_down(nm, o);
+			if ((threadIdx.x & 63) == 0 && nm) atomicAdd(moved, (unsigned long long)nm);
+		}
 	}
 }
 
