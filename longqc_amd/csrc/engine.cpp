@@ -784,6 +784,7 @@ void lqcov_handle::sort_batch(MapLane &L, Part &pt, u32 q0, u32 nqb, u64 a_base,
 		if (const char *ws = getenv("LQCOV_WALK_SHIFT")) for (int c = 0; c < 4; ++c) wcaps.c[c] >>= atoi(ws);   // test knob
 		const bool reg_walker = !(getenv("LQCOV_WALK") && !strcmp(getenv("LQCOV_WALK"), "solo"));   // A/B knob
 		const bool sort_tiles = !(getenv("LQCOV_SORT_TILES") && !strcmp(getenv("LQCOV_SORT_TILES"), "0"));   // A/B knob
+		const bool two_tiles = getenv("LQCOV_TWO_TILES") && atoi(getenv("LQCOV_TWO_TILES")) > 0;   // tiled two-bucket pass: written after the last GPU run of round 2, off until measured
 		L.sort_d.ensure(nA + 64); L.sort_dst.ensure((nA + 1) * 4);
 		SortSeg *cur = L.segs0.as<SortSeg>(), *nxt = L.segs1.as<SortSeg>();
 		u32 cur_slot = LQ_C_KLIB0, nxt_slot = LQ_C_KLIB1;
@@ -815,8 +816,21 @@ void lqcov_handle::sort_batch(MapLane &L, Part &pt, u32 q0, u32 nqb, u64 a_base,
 			check_launch();
 			{	// closed-form two-bucket passes (the strand bit at the top level)
 				StageTimer t(this, sD, "k_sort_two", nA * 6);
-				LQ_LAUNCH(k_sort_two, std::min<u32>(ns, 16384), LQ_TWO_THREADS, sD, cur, L.seg_info.as<SegInfo>(), L.two_list.as<u32>(), cnt + LQ_C_TWO, L.sort_d.as<u8>(), hx, py, L.sort_dst.as<u32>());
-				check_launch();
+				if (sort_tiles && two_tiles) {
+					L.two_tiles.ensure(max_tiles * sizeof(SortTile)); L.two_tile0.ensure((u64)ns * 4); L.two_tcnt.ensure(max_tiles * 8); L.two_m.ensure((u64)ns * 4);
+					dzero(cnt + LQ_C_TWO_TILES, 4, sD);
+					const SortTile *tt = L.two_tiles.as<SortTile>();
+					const u32 *ntt = cnt + LQ_C_TWO_TILES;
+					const u32 g_two = std::min<u32>(g_tile, 8192);         // grid-stride: a level without two-bucket sub-arrays costs three near-empty launches
+					LQ_LAUNCH(k_two_tiles, std::min<u32>(ns / 256 + 1, 4096), 256, sD, cur, L.two_list.as<u32>(), cnt + LQ_C_TWO, tile, L.two_tiles.as<SortTile>(), cnt + LQ_C_TWO_TILES, L.two_tile0.as<u32>()); check_launch();
+					LQ_LAUNCH((k_sort_two_tiled<0>), g_two, 256, sD, cur, L.seg_info.as<SegInfo>(), tt, ntt, tile, L.sort_d.as<u8>(), L.two_tcnt.as<u32>(), L.two_m.as<u32>(), hx, py, L.sort_dst.as<u32>()); check_launch();
+					LQ_LAUNCH(k_sort_two_scan, std::min<u32>(ns, 16384), 64, sD, cur, L.two_list.as<u32>(), cnt + LQ_C_TWO, tile, L.two_tile0.as<u32>(), L.two_tcnt.as<u32>(), L.two_m.as<u32>()); check_launch();
+					LQ_LAUNCH((k_sort_two_tiled<1>), g_two, 256, sD, cur, L.seg_info.as<SegInfo>(), tt, ntt, tile, L.sort_d.as<u8>(), L.two_tcnt.as<u32>(), L.two_m.as<u32>(), hx, py, L.sort_dst.as<u32>()); check_launch();
+					LQ_LAUNCH((k_sort_two_tiled<2>), g_two, 256, sD, cur, L.seg_info.as<SegInfo>(), tt, ntt, tile, L.sort_d.as<u8>(), L.two_tcnt.as<u32>(), L.two_m.as<u32>(), hx, py, L.sort_dst.as<u32>()); check_launch();
+				} else {
+					LQ_LAUNCH(k_sort_two, std::min<u32>(ns, 16384), LQ_TWO_THREADS, sD, cur, L.seg_info.as<SegInfo>(), L.two_list.as<u32>(), cnt + LQ_C_TWO, L.sort_d.as<u8>(), hx, py, L.sort_dst.as<u32>());
+					check_launch();
+				}
 			}
 			{
 				const u8 *dD = L.sort_d.as<u8>(); const u32 *dH = L.hist.as<u32>(), *dBg = L.begs.as<u32>(); u32 *dDst = L.sort_dst.as<u32>();

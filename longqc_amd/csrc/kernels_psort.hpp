@@ -36,6 +36,7 @@ struct PPlan { u32 tile0, cnt0; };                   // first tile / first count
 // counters of one batch's sort (device): indices into L.sort_cnt.  Two sets of psort lists: set 0 takes whole queries
 // (k_sort_init) and is sorted on its own stream while klib's passes run; set 1 collects the buckets that leave them.
 enum { LQ_C_KLIB0 = 0, LQ_C_KLIB1, LQ_C_TWO, LQ_C_WALK0, LQ_C_WALK1, LQ_C_WALK2, LQ_C_WALK3, LQ_C_WALK4, LQ_C_OVERFLOW, LQ_C_TILES,
+       LQ_C_TWO_TILES = 12,    // tiles of the level's two-bucket sub-arrays
        LQ_C_MOVED = 10,        // (64-bit) anchors the tiled scatter really moved
        LQ_C_PS0 = 16, LQ_C_PS1 = 32,
        // 64-bit tallies of the elements each kind of kernel really moved (algorithmic bytes of the stage times)

@@ -46,6 +46,16 @@ def test_emulated_tables_read_like_the_reference_consumer(emu_lib, tmp_path):
                                            w["high_div_frac"], w["control_frac"])
 
 
+@pytest.mark.parametrize("case", [c for c in _cases("table") if c["name"] in ("tiny_ont", "adv_ont", "adv_parts", "adv_defaults")], ids=lambda c: c["name"])
+@pytest.mark.parametrize("tile", ["64", "8192"])
+def test_emulated_two_bucket_pass_over_tiles(emu_lib, case, tile, monkeypatch):
+    """LQCOV_TWO_TILES=1: the strand pass of every dirty query as count / scan / list / destination kernels over tiles"""
+    monkeypatch.setenv("LQCOV_TWO_TILES", "1"); monkeypatch.setenv("LQCOV_SORT_TILE", tile); monkeypatch.setenv("LQCOV_SORT", "klib")
+    rc, out, err = run_main(emu_lib, case["argv"], cwd=GOLDEN)
+    assert rc == 0, err
+    assert out == read_gz(case["expect"])
+
+
 def _engine(lib, **kw):
     p = api.Params()
     lib.lqcov_params_default(p)
@@ -345,7 +355,7 @@ def _repeat_rich_dataset(tmp_path, seed, n_targets=60, n_queries=8, glen=40000):
     return tf, qf
 
 
-def check_repeat_rich_randomised(lib, tmp_path, monkeypatch, seed):
+def check_repeat_rich_randomised(lib, tmp_path, monkeypatch, seed, two_tiles=False):
     tf, qf = _repeat_rich_dataset(tmp_path, seed)
     argv = ONT + [tf, qf]
     want = oracle_bind.ref_table(argv) if oracle_bind.have_ref() else oracle_bind.table(argv)
@@ -353,6 +363,7 @@ def check_repeat_rich_randomised(lib, tmp_path, monkeypatch, seed):
     monkeypatch.setenv("LQCOV_WALK_SHIFT", str([0, 4, 7, 10][seed % 4]))
     monkeypatch.setenv("LQCOV_PS_SHIFT", str([0, 3, 7][seed % 3]))
     monkeypatch.setenv("LQCOV_SORT_TILE", str([8192, 64, 1000][seed % 3]))      # tiles of the streaming kernels: one per sub-array | many
+    monkeypatch.setenv("LQCOV_TWO_TILES", "1" if two_tiles else "0")             # the two-bucket pass over tiles (off by default until measured)
     monkeypatch.setenv("LQCOV_CKPT3", str(seed & 1))          # odd seeds: checkpoints for the second-longest class of many-bucket passes too
     rc, out, err = run_main(lib, argv)
     assert rc == 0, err
@@ -365,7 +376,7 @@ def test_emulated_repeat_rich_randomised(emu_lib, tmp_path, monkeypatch, seed):
     """equal-x anchors everywhere (repeats inside the queries): rows equal the reference binary's, whichever path the sub-arrays
     take (parallel passes for those without a tie, klib's walk for the others); and the input has teeth: a stable sort by x
     gives a different table"""
-    argv, want = check_repeat_rich_randomised(emu_lib, tmp_path, monkeypatch, seed)
+    argv, want = check_repeat_rich_randomised(emu_lib, tmp_path, monkeypatch, seed, two_tiles=seed != 0)
     assert sum(1 for l in want.splitlines() if l.split("\t")[2] != "0") >= 4
     if seed == 0:
         assert oracle_bind.table(argv, ["--stable-sort"]) != want
