@@ -784,6 +784,7 @@ void lqcov_handle::sort_batch(MapLane &L, Part &pt, u32 q0, u32 nqb, u64 a_base,
 		if (const char *ws = getenv("LQCOV_WALK_SHIFT")) for (int c = 0; c < 4; ++c) wcaps.c[c] >>= atoi(ws);   // test knob
 		const bool reg_walker = !(getenv("LQCOV_WALK") && !strcmp(getenv("LQCOV_WALK"), "solo"));   // A/B knob
 		const bool sort_tiles = !(getenv("LQCOV_SORT_TILES") && !strcmp(getenv("LQCOV_SORT_TILES"), "0"));   // A/B knob
+		const int xcd_order = !(getenv("LQCOV_XCD") && !strcmp(getenv("LQCOV_XCD"), "0"));   // A/B knob: tile list in XCD-major order
 		const bool two_tiles = getenv("LQCOV_TWO_TILES") && atoi(getenv("LQCOV_TWO_TILES")) > 0;   // tiled two-bucket pass: written after the last GPU run of round 2, off until measured
 		L.sort_d.ensure(nA + 64); L.sort_dst.ensure((nA + 1) * 4);
 		SortSeg *cur = L.segs0.as<SortSeg>(), *nxt = L.segs1.as<SortSeg>();
@@ -798,7 +799,7 @@ void lqcov_handle::sort_batch(MapLane &L, Part &pt, u32 q0, u32 nqb, u64 a_base,
 			// tiles of the level's sub-arrays for the two streaming kernels (LQCOV_SORT_TILES=0: one block per sub-array, as in round 1)
 			const u32 tile = getenv("LQCOV_SORT_TILE") ? (u32)std::max(64, atoi(getenv("LQCOV_SORT_TILE"))) : LQ_SORT_TILE;   // test / tuning knob
 			const u64 max_tiles = nA / tile + ns + 1;
-			const u32 g_tile = (u32)std::min<u64>(max_tiles, 1u << 18);
+			const u32 g_tile = ((u32)std::min<u64>(max_tiles, 1u << 18) + 7) & ~7u;      // a multiple of the XCD count (LQ_TILE_LOOP)
 			if (sort_tiles) {
 				L.tile_list.ensure(max_tiles * sizeof(SortTile));
 				dzero(cnt + LQ_C_TILES, 4, sD);
@@ -807,7 +808,7 @@ void lqcov_handle::sort_batch(MapLane &L, Part &pt, u32 q0, u32 nqb, u64 a_base,
 			}
 			{
 				StageTimer t(this, sD, "k_sort_copy_hist");
-				if (sort_tiles) LQ_LAUNCH(k_sort_copy_hist_tiled, g_tile, 256, sD, cur, L.tile_list.as<SortTile>(), cnt + LQ_C_TILES, tile, dA, dB, L.sort_d.as<u8>(), L.hist.as<u32>(), L.mhist.as<u32>(), (unsigned long long*)(cnt + LQ_C_COPIED));
+				if (sort_tiles) LQ_LAUNCH(k_sort_copy_hist_tiled, g_tile, 256, sD, cur, L.tile_list.as<SortTile>(), cnt + LQ_C_TILES, tile, xcd_order, dA, dB, L.sort_d.as<u8>(), L.hist.as<u32>(), L.mhist.as<u32>(), (unsigned long long*)(cnt + LQ_C_COPIED));
 				else LQ_LAUNCH(k_sort_copy_hist, g_seg, 256, sD, cur, cnt + cur_slot, dA, dB, L.sort_d.as<u8>(), L.hist.as<u32>(), L.mhist.as<u32>(), (unsigned long long*)(cnt + LQ_C_COPIED));
 				check_launch();
 			}
@@ -941,7 +942,7 @@ void lqcov_handle::sort_batch(MapLane &L, Part &pt, u32 q0, u32 nqb, u64 a_base,
 			LQ_HIP_CHECK(hipStreamWaitEvent(sD, L.ev_w1, 0));
 			{
 				StageTimer t(this, sD, "k_sort_scatter");
-				if (sort_tiles) LQ_LAUNCH(k_sort_scatter_tiled, g_tile, 256, sD, cur, L.seg_info.as<SegInfo>(), L.tile_list.as<SortTile>(), cnt + LQ_C_TILES, tile, dA, dB, L.sort_dst.as<u32>(), (unsigned long long*)(cnt + LQ_C_SCATTERED), (unsigned long long*)(cnt + LQ_C_MOVED));
+				if (sort_tiles) LQ_LAUNCH(k_sort_scatter_tiled, g_tile, 256, sD, cur, L.seg_info.as<SegInfo>(), L.tile_list.as<SortTile>(), cnt + LQ_C_TILES, tile, xcd_order, dA, dB, L.sort_dst.as<u32>(), (unsigned long long*)(cnt + LQ_C_SCATTERED), (unsigned long long*)(cnt + LQ_C_MOVED));
 				else LQ_LAUNCH(k_sort_scatter, g_seg, 256, sD, cur, L.seg_info.as<SegInfo>(), cnt + cur_slot, dA, dB, L.sort_dst.as<u32>(), (unsigned long long*)(cnt + LQ_C_SCATTERED));
 				check_launch();
 			}

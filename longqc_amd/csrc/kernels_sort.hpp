@@ -85,6 +85,14 @@ __global__ void k_sort_copy_hist(const SortSeg *segs, const u32 *n_segs_p, const
 // into rows zeroed by k_sort_tiles, a sub-array of one tile stores its row as before.
 #define LQ_SORT_TILE 8192
 struct SortTile { u32 sgi, tile; };
+// The tile list in XCD-major order.  Blocks are dealt to the 8 XCDs round-robin (observed, not promised: block b runs on XCD
+// b % 8 -- a pure speed assumption), and every XCD has its own L2: XCD x takes the x-th eighth of the list, so the tiles of one
+// sub-array (adjacent in the list) write their destination lines through the same L2.  Needs gridDim.x % 8 == 0; every tile is
+// visited exactly once whatever the placement really is.  xcd == 0: plain block-strided order.
+#define LQ_XCDS 8
+#define LQ_TILE_LOOP(ti, n_tiles, xcd) \
+	for (u32 per_ = (xcd) ? ((n_tiles) + LQ_XCDS - 1) / LQ_XCDS : (n_tiles), x_ = (xcd) ? blockIdx.x % LQ_XCDS : 0, st_ = (xcd) ? gridDim.x / LQ_XCDS : gridDim.x, \
+	         j_ = (xcd) ? blockIdx.x / LQ_XCDS : blockIdx.x, ti = x_ * per_ + j_; j_ < per_; j_ += st_, ti = x_ * per_ + j_) if (ti < (n_tiles))
 
 __global__ void __launch_bounds__(256)
 k_sort_tiles(const SortSeg *segs, const u32 *n_segs_p, u32 tile, SortTile *tiles, u32 *n_tiles, u32 *hist, u32 *mhist)
@@ -107,11 +115,11 @@ k_sort_tiles(const SortSeg *segs, const u32 *n_segs_p, u32 tile, SortTile *tiles
 }
 
 __global__ void __launch_bounds__(256)
-k_sort_copy_hist_tiled(const SortSeg *segs, const SortTile *tiles, const u32 *n_tiles_p, u32 tile, const mm128 *A, mm128 *B, u8 *D, u32 *hist, u32 *mhist, unsigned long long *tally)
+k_sort_copy_hist_tiled(const SortSeg *segs, const SortTile *tiles, const u32 *n_tiles_p, u32 tile, int xcd, const mm128 *A, mm128 *B, u8 *D, u32 *hist, u32 *mhist, unsigned long long *tally)
 {
 	__shared__ u32 lh[256], lm[256];
 	const u32 n_tiles = *n_tiles_p;
-	for (u32 ti = blockIdx.x; ti < n_tiles; ti += gridDim.x) {
+	LQ_TILE_LOOP(ti, n_tiles, xcd) {
 		const SortTile tl = tiles[ti];
 		const SortSeg sg = segs[tl.sgi];
 		const u32 i0 = tl.tile * tile, i1 = sg.len - i0 < tile ? sg.len : i0 + tile;
@@ -140,11 +148,11 @@ k_sort_copy_hist_tiled(const SortSeg *segs, const SortTile *tiles, const u32 *n_
 }
 
 __global__ void __launch_bounds__(256)
-k_sort_scatter_tiled(const SortSeg *segs, const SegInfo *info, const SortTile *tiles, const u32 *n_tiles_p, u32 tile, mm128 *A, const mm128 *B, const u32 *dst, unsigned long long *tally,
+k_sort_scatter_tiled(const SortSeg *segs, const SegInfo *info, const SortTile *tiles, const u32 *n_tiles_p, u32 tile, int xcd, mm128 *A, const mm128 *B, const u32 *dst, unsigned long long *tally,
                      unsigned long long *moved)
 {
 	const u32 n_tiles = *n_tiles_p;
-	for (u32 ti = blockIdx.x; ti < n_tiles; ti += gridDim.x) {
+	LQ_TILE_LOOP(ti, n_tiles, xcd) {
 		const SortTile tl = tiles[ti];
 		if (info[tl.sgi].kind == LQ_SEG_IDENTITY) continue;
 		const SortSeg sg = segs[tl.sgi];
