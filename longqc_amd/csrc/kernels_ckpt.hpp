@@ -76,36 +76,54 @@ k_ck_tilescan(const CkSeg *cks, u32 n_cks, const SortSeg *segs, u32 *T)
 }
 
 // One wave solves for states; lane c < 16 owns bucket c.  lq_ck_prefix: counts of digit `lane` in the first x elements of
-// the sub-array (tile table + the partial tile, histogrammed by the whole wave in LDS).
-__device__ __forceinline__ u32 lq_ck_prefix(const u8 *d, const u32 *T, u32 x, u32 *lh, u32 lane)
+// the sub-array = tile table + the partial tile.  The partial tile (< 1024 digits) is read as aligned 16-byte words, one per
+// lane (one more for lane 0 if the alignment asks for a 65th), counted into sixteen 16-bit fields in registers and summed
+// over the wave by shuffles: no LDS, no barrier -- the look-ups of one round are independent loads.
+__device__ __forceinline__ u32 lq_ck_prefix(const u8 *d, const u32 *T, u32 x, u32 lane)
 {
 	const u32 tile = x / LQ_CK_TILE, r0 = tile * LQ_CK_TILE;
-	if (lane < LQ_CK_B) lh[lane] = 0;
-	__syncthreads();
-	for (u32 i = r0 + lane; i < x; i += 64) atomicAdd(&lh[d[i] & (LQ_CK_B - 1)], 1u);
-	__syncthreads();
+	const u8 *p_lo = d + r0, *p_hi = d + x;
+	const u8 *a0 = (const u8*)((size_t)p_lo & ~(size_t)15);
+	const u32 n_words = (u32)((size_t)(p_hi - a0 + 15) >> 4);
+	u64 f0 = 0, f1 = 0, f2 = 0, f3 = 0;
+	for (u32 w = lane; w < n_words; w += 64) {
+		const u8 *wa = a0 + (size_t)w * 16;
+		const uint4 W = *(const uint4*)wa;
+		const u32 ww[4] = { W.x, W.y, W.z, W.w };
+#pragma unroll
+		for (u32 k = 0; k < 16; ++k) {
+			const u8 *g = wa + k;
+			if (g >= p_lo && g < p_hi) {
+				const u32 dg = (ww[k >> 2] >> ((k & 3) * 8)) & (LQ_CK_B - 1);
+				const u64 inc = 1ULL << ((dg & 3) * 16);
+				const u32 q = dg >> 2;
+				f0 += q == 0 ? inc : 0; f1 += q == 1 ? inc : 0; f2 += q == 2 ? inc : 0; f3 += q == 3 ? inc : 0;
+			}
+		}
+	}
+	for (int o = 32; o > 0; o >>= 1) { f0 += __shfl_xor(f0, o); f1 += __shfl_xor(f1, o); f2 += __shfl_xor(f2, o); f3 += __shfl_xor(f3, o); }
 	u32 v = 0;
-	if (lane < LQ_CK_B) v = T[(u64)tile * LQ_CK_B + lane] + lh[lane];
-	__syncthreads();
+	if (lane < LQ_CK_B) {
+		const u32 q = lane >> 2;
+		const u64 f = q == 0 ? f0 : q == 1 ? f1 : q == 2 ? f2 : f3;
+		v = T[(u64)tile * LQ_CK_B + lane] + (u32)((f >> ((lane & 3) * 16)) & 0xffff);
+	}
 	return v;
 }
 
 // least solution above the state in `A` (lane c: cursor of bucket c, absolute slot index in the sub-array) with the
 // buckets below k full and bucket k held at its value; pbeg[l] = prefix counts (of this lane's digit) at beg[l]
 __device__ __forceinline__ u32 lq_ck_iterate(const u8 *d, const u32 *T, u32 k, u32 nb, u32 A, const u32 (&pbeg)[LQ_CK_B], const u32 (&pend)[LQ_CK_B],
-                                            u32 my_beg, u32 *lh, u32 *sh, u32 lane)
+                                            u32 my_beg, u32 lane)
 {
 	for (;;) {
-		if (lane < LQ_CK_B) sh[lane] = A;
-		__syncthreads();
 		u32 acc = 0;
 #pragma unroll
 		for (u32 l = 0; l < LQ_CK_B; ++l) {                     // uniform loop over the regions
 			if (l >= nb) break;
-			const u32 x = sh[l];
-			__syncthreads();
+			const u32 x = __shfl(A, (int)l);
 			if (l < k) acc += pend[l] - pbeg[l];                    // a full region has given everything it has of this digit
-			else acc += lq_ck_prefix(d, T, x, lh, lane) - pbeg[l];
+			else acc += lq_ck_prefix(d, T, x, lane) - pbeg[l];
 		}
 		u32 nA = A;
 		if (lane < nb && lane > k) { const u32 f = my_beg + acc; if (f > A) nA = f; }
@@ -120,7 +138,6 @@ __device__ __forceinline__ u32 lq_ck_iterate(const u8 *d, const u32 *T, u32 k, u
 __global__ void __launch_bounds__(64)
 k_ck_phases(const CkSeg *cks, u32 n_cks, const SortSeg *segs, const u8 *D, const u32 *hist, const u32 *begs, const u32 *T, u32 *E)
 {
-	__shared__ u32 lh[LQ_CK_B], sh[LQ_CK_B];
 	const u32 lane = threadIdx.x;
 	for (u32 j = blockIdx.x; j < n_cks; j += gridDim.x) {
 		const CkSeg ck = cks[j];
@@ -134,11 +151,11 @@ k_ck_phases(const CkSeg *cks, u32 n_cks, const SortSeg *segs, const u8 *D, const
 		u32 pbeg[LQ_CK_B], pend[LQ_CK_B];
 		for (u32 l = 0; l < LQ_CK_B; ++l) { pbeg[l] = 0; pend[l] = 0; }
 #pragma unroll
-		for (u32 l = 0; l < LQ_CK_B; ++l) if (l < nb) { pbeg[l] = lq_ck_prefix(d, Tj, bg[l], lh, lane); pend[l] = lq_ck_prefix(d, Tj, bg[l] + cn[l], lh, lane); }
+		for (u32 l = 0; l < LQ_CK_B; ++l) if (l < nb) { pbeg[l] = lq_ck_prefix(d, Tj, bg[l], lane); pend[l] = lq_ck_prefix(d, Tj, bg[l] + cn[l], lane); }
 		u32 A = my_beg;
 		for (u32 k = 0; k < LQ_CK_B; ++k) {
 			if (lane == k) A = my_end;                              // the outer loop has filled bucket k
-			if (k < nb) A = lq_ck_iterate(d, Tj, k, nb, A, pbeg, pend, my_beg, lh, sh, lane);
+			if (k < nb) A = lq_ck_iterate(d, Tj, k, nb, A, pbeg, pend, my_beg, lane);
 			if (lane < LQ_CK_B) E[((u64)j * LQ_CK_B + k) * LQ_CK_B + lane] = A;
 		}
 	}
@@ -149,7 +166,6 @@ __global__ void __launch_bounds__(64)
 k_ck_solve(const CkSeg *cks, u32 n_cks, u32 n_ck_total, const SortSeg *segs, const u8 *D, const u32 *hist, const u32 *begs, const u32 *T,
            const u32 *E, u32 *S, u32 *CKS)
 {
-	__shared__ u32 lh[LQ_CK_B], sh[LQ_CK_B];
 	const u32 lane = threadIdx.x;
 	for (u32 ci = blockIdx.x; ci < n_ck_total; ci += gridDim.x) {
 		u32 lo = 0, hi = n_cks;
@@ -200,8 +216,8 @@ k_ck_solve(const CkSeg *cks, u32 n_cks, u32 n_ck_total, const SortSeg *segs, con
 		u32 pbeg[LQ_CK_B], pend[LQ_CK_B];
 		for (u32 l = 0; l < LQ_CK_B; ++l) { pbeg[l] = 0; pend[l] = 0; }
 #pragma unroll
-		for (u32 l = 0; l < LQ_CK_B; ++l) if (l < nb) { pbeg[l] = lq_ck_prefix(d, Tj, bg[l], lh, lane); pend[l] = lq_ck_prefix(d, Tj, bg[l] + cn[l], lh, lane); }
-		if (k < nb) A = lq_ck_iterate(d, Tj, k, nb, A, pbeg, pend, my_beg, lh, sh, lane);
+		for (u32 l = 0; l < LQ_CK_B; ++l) if (l < nb) { pbeg[l] = lq_ck_prefix(d, Tj, bg[l], lane); pend[l] = lq_ck_prefix(d, Tj, bg[l] + cn[l], lane); }
+		if (k < nb) A = lq_ck_iterate(d, Tj, k, nb, A, pbeg, pend, my_beg, lane);
 		if (lane < LQ_CK_B) S[(u64)ci * LQ_CK_B + lane] = A;
 		if (lane == 0) CKS[ci] = s;
 	}
