@@ -233,6 +233,21 @@ k_ck_solve(const CkSeg *cks, u32 n_cks, u32 n_ck_total, const SortSeg *segs, con
 // picked-up elements: a bigger step costs only logarithmically more rounds), and writes a checkpoint -- all 256 cursors and
 // the slot -- after each: the pieces come out balanced whatever the data looks like.
 #define LQ_CKW_STEP 16
+// arr[digit] += 1 for the elements [lo, hi) of the sub-array, read as aligned 16-byte words (a lane's backlog of hundreds of
+// elements costs a sixteenth of the load latencies it would byte by byte)
+__device__ __forceinline__ void lq_ck_count_range(const u8 *d, u32 lo, u32 hi, u32 *arr)
+{
+	const u8 *p_lo = d + lo, *p_hi = d + hi;
+	for (const u8 *wa = (const u8*)((size_t)p_lo & ~(size_t)15); wa < p_hi; wa += 16) {
+		const uint4 W = *(const uint4*)wa;
+		const u32 ww[4] = { W.x, W.y, W.z, W.w };
+#pragma unroll
+		for (u32 k = 0; k < 16; ++k) {
+			const u8 *g = wa + k;
+			if (g >= p_lo && g < p_hi) atomicAdd(&arr[(ww[k >> 2] >> ((k & 3) * 8)) & 0xff], 1u);
+		}
+	}
+}
 __global__ void __launch_bounds__(64)
 k_ck_chain256(const CkSeg *cks, u32 n_cks, const SortSeg *segs, const u8 *D, const u32 *hist, const u32 *begs, u32 *S, u32 *CKS)
 {
@@ -269,7 +284,7 @@ k_ck_chain256(const CkSeg *cks, u32 n_cks, const SortSeg *segs, const u8 *D, con
 						u32 need = c == k ? s : B0[g] + arr[c];
 						if (need > E0[g]) need = E0[g];
 						if (A[g] < need) {
-							for (u32 i = A[g]; i < need; ++i) atomicAdd(&arr[d[i]], 1u);
+							lq_ck_count_range(d, A[g], need, arr);
 							A[g] = need;
 							pending = true;
 						}
