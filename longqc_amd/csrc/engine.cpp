@@ -590,18 +590,34 @@ void lqcov_handle::map_batch(MapLane &L, Part &pt, u32 q0, u32 q1, const std::ve
 			// Measured alternatives that were slower on MI355X: a compacted longest-first work list for all runs (409 vs 292 ms at
 			// configs[1]), private-array DP for short runs, and a fixed [16][64] LDS column per lane (54 KiB per wave: 160 + 40 ms
 			// vs 113 ms).  wave_min - 1 <= 47 < the smallest budget, so every run fits.
-			StageTimer t(this, L.stream, "k_chain", nA * 16);
-#define LQ_CHAIN_LAUNCH(CAP) LQ_LAUNCH((k_chain<CAP>), nblk(n_groups, 64), 64, L.stream, dA, L.gstart.as<u64>(), (const u32*)nullptr, (u32)n_groups, aqb, a_base, nqb, q0, avg_qspan.as<float>(), mp, cs, (i32)P.min_cnt, (i32)(wave_min - 1))
-			if (cap == 64) { LQ_CHAIN_LAUNCH(64); } else if (cap == 128) { LQ_CHAIN_LAUNCH(128); } else { LQ_CHAIN_LAUNCH(256); }
+			// LQCOV_CHAIN_COMPACT=1 (to be measured): the runs of min_cnt .. wave_min - 1 anchors as a dense list in array order --
+			// most runs are shorter, and their lanes idle through the DP of the few that are not
+			const u32 *small_list = nullptr;
+			u32 n_small = (u32)n_groups;
+			if (runs_two_pass && getenv("LQCOV_CHAIN_COMPACT") && atoi(getenv("LQCOV_CHAIN_COMPACT")) > 0 && wave_min - 1 >= (int)P.min_cnt) {
+				const u32 n_tiles = (u32)((n_groups + LQ_RUN_TILE - 1) / LQ_RUN_TILE);
+				L.sel_tiles.ensure(((u64)n_tiles + 2) * 4);
+				LQ_LAUNCH(k_sel_count, std::min<u32>(std::max<u32>(n_tiles, 1), 1u << 16), LQ_RUN_THREADS, L.stream, L.gstart.as<u64>(), n_groups, (i32)P.min_cnt, (i32)(wave_min - 1), n_tiles, L.sel_tiles.as<u32>()); check_launch();
+				LQ_LAUNCH(k_tile_scan, 1, LQ_TSCAN_THREADS, L.stream, L.sel_tiles.as<u32>(), n_tiles); check_launch();
+				d2h(&n_small, L.sel_tiles.as<u32>() + n_tiles, 1, L.stream);
+				L.gsmall.ensure((u64)n_small * 4 + 4);
+				if (n_small) { LQ_LAUNCH(k_sel_write, std::min<u32>(n_tiles, 1u << 16), LQ_RUN_THREADS, L.stream, L.gstart.as<u64>(), n_groups, (i32)P.min_cnt, (i32)(wave_min - 1), n_tiles, L.sel_tiles.as<u32>(), L.gsmall.as<u32>(), (u32*)nullptr); check_launch(); }
+				small_list = L.gsmall.as<u32>();
+			}
+			if (n_small) {
+				StageTimer t(this, L.stream, "k_chain", nA * 16);
+#define LQ_CHAIN_LAUNCH(CAP) LQ_LAUNCH((k_chain<CAP>), nblk(n_small, 64), 64, L.stream, dA, L.gstart.as<u64>(), small_list, n_small, aqb, a_base, nqb, q0, avg_qspan.as<float>(), mp, cs, (i32)P.min_cnt, (i32)(wave_min - 1))
+				if (cap == 64) { LQ_CHAIN_LAUNCH(64); } else if (cap == 128) { LQ_CHAIN_LAUNCH(128); } else { LQ_CHAIN_LAUNCH(256); }
 #undef LQ_CHAIN_LAUNCH
-			check_launch();
+				check_launch();
+			}
 		}
 		{	// long runs (the tail of the kernel above if left there): one wave per run, longest first
 			u32 n_sel = 0;
 			if (runs_two_pass) {
 				const u32 n_tiles = (u32)((n_groups + LQ_RUN_TILE - 1) / LQ_RUN_TILE);
 				L.sel_tiles.ensure(((u64)n_tiles + 2) * 4);
-				LQ_LAUNCH(k_sel_count, std::min<u32>(std::max<u32>(n_tiles, 1), 1u << 16), LQ_RUN_THREADS, L.stream, L.gstart.as<u64>(), n_groups, (i32)wave_min, n_tiles, L.sel_tiles.as<u32>()); check_launch();
+				LQ_LAUNCH(k_sel_count, std::min<u32>(std::max<u32>(n_tiles, 1), 1u << 16), LQ_RUN_THREADS, L.stream, L.gstart.as<u64>(), n_groups, (i32)wave_min, (i32)0x7fffffff, n_tiles, L.sel_tiles.as<u32>()); check_launch();
 				LQ_LAUNCH(k_tile_scan, 1, LQ_TSCAN_THREADS, L.stream, L.sel_tiles.as<u32>(), n_tiles); check_launch();
 				d2h(&n_sel, L.sel_tiles.as<u32>() + n_tiles, 1, L.stream);
 			} else {
@@ -616,7 +632,7 @@ void lqcov_handle::map_batch(MapLane &L, Part &pt, u32 q0, u32 q1, const std::ve
 				L.gsel.ensure((u64)n_sel * 4); L.gkey.ensure((u64)n_sel * 4); L.gsel2.ensure((u64)n_sel * 4); L.gkey2.ensure((u64)n_sel * 4);
 				if (runs_two_pass) {
 					const u32 n_tiles = (u32)((n_groups + LQ_RUN_TILE - 1) / LQ_RUN_TILE);
-					LQ_LAUNCH(k_sel_write, std::min<u32>(n_tiles, 1u << 16), LQ_RUN_THREADS, L.stream, L.gstart.as<u64>(), n_groups, (i32)wave_min, n_tiles, L.sel_tiles.as<u32>(), L.gsel.as<u32>(), L.gkey.as<u32>()); check_launch();
+					LQ_LAUNCH(k_sel_write, std::min<u32>(n_tiles, 1u << 16), LQ_RUN_THREADS, L.stream, L.gstart.as<u64>(), n_groups, (i32)wave_min, (i32)0x7fffffff, n_tiles, L.sel_tiles.as<u32>(), L.gsel.as<u32>(), L.gkey.as<u32>()); check_launch();
 				} else {
 					LQ_LAUNCH(k_group_compact, nblk(n_groups, 256), 256, L.stream, L.gstart.as<u64>(), L.gflag.as<u32>(), L.gidx.as<u32>(), n_groups, L.gsel.as<u32>(), L.gkey.as<u32>()); check_launch();
 				}

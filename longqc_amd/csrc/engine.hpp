@@ -66,7 +66,7 @@ struct MapLane {
 	DBuf A, B, segs0, segs1, n_segs, hist, begs;
 	DBuf tile_list, two_tiles, two_tile0, two_tcnt, two_m;
 	DBuf sort_d, sort_dst, seg_info, walk_list, two_list, scr, wkey, wkey2, walk_list2, walk_list3;
-	DBuf gflag, gidx, gsel, gkey, gsel2, gkey2, gstart, run_tiles, sel_tiles;
+	DBuf gflag, gidx, gsel, gkey, gsel2, gkey2, gstart, run_tiles, sel_tiles, gsmall;
 	DBuf ivl, n_ivl, iv_q, iv_q2, iv_se, iv_se2, ivq_off, iv_scratch;
 };
 

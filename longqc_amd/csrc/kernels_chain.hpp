@@ -253,7 +253,7 @@ __global__ void k_group_compact(const u64 *gstart, const u32 *flag, const u32 *i
 
 // the same work list in two light passes over the run starts (count per tile, scan of the tile counts, write)
 __global__ void __launch_bounds__(LQ_RUN_THREADS)
-k_sel_count(const u64 *gstart, u64 n_groups, i32 min_cnt, u32 n_tiles, u32 *tile_cnt)
+k_sel_count(const u64 *gstart, u64 n_groups, i32 min_cnt, i32 max_cnt, u32 n_tiles, u32 *tile_cnt)
 {
 	__shared__ u32 tot;
 	for (u32 T = blockIdx.x; T < n_tiles; T += gridDim.x) {
@@ -264,7 +264,7 @@ k_sel_count(const u64 *gstart, u64 n_groups, i32 min_cnt, u32 n_tiles, u32 *tile
 			const u64 g = (u64)T * LQ_RUN_TILE + (u32)j * LQ_RUN_THREADS + threadIdx.x;
 			i64 l = 0;
 			if (g < n_groups) l = (i64)(gstart[g + 1] - gstart[g]);
-			c += (u32)__popcll(__ballot(g < n_groups && l >= (i64)min_cnt));
+			c += (u32)__popcll(__ballot(g < n_groups && l >= (i64)min_cnt && l <= (i64)max_cnt));
 		}
 		if ((threadIdx.x & 63) == 0) atomicAdd(&tot, c);
 		__syncthreads();
@@ -274,7 +274,7 @@ k_sel_count(const u64 *gstart, u64 n_groups, i32 min_cnt, u32 n_tiles, u32 *tile
 }
 
 __global__ void __launch_bounds__(LQ_RUN_THREADS)
-k_sel_write(const u64 *gstart, u64 n_groups, i32 min_cnt, u32 n_tiles, const u32 *tile_off, u32 *sel, u32 *key)
+k_sel_write(const u64 *gstart, u64 n_groups, i32 min_cnt, i32 max_cnt, u32 n_tiles, const u32 *tile_off, u32 *sel, u32 *key)
 {
 	__shared__ u32 pre[LQ_RUN_ROWS * LQ_RUN_WAVES];
 	const u32 t = threadIdx.x, lane = t & 63, w = t >> 6;
@@ -286,7 +286,7 @@ k_sel_write(const u64 *gstart, u64 n_groups, i32 min_cnt, u32 n_tiles, const u32
 			const u64 g = (u64)T * LQ_RUN_TILE + (u32)j * LQ_RUN_THREADS + t;
 			const u64 l = g < n_groups ? gstart[g + 1] - gstart[g] : 0;
 			len[j] = (u32)l;
-			bal[j] = __ballot(g < n_groups && (i64)l >= (i64)min_cnt);
+			bal[j] = __ballot(g < n_groups && (i64)l >= (i64)min_cnt && (i64)l <= (i64)max_cnt);
 		}
 		if (lane == 0) {
 #pragma unroll
@@ -305,7 +305,8 @@ k_sel_write(const u64 *gstart, u64 n_groups, i32 min_cnt, u32 n_tiles, const u32
 		for (int j = 0; j < LQ_RUN_ROWS; ++j)
 			if (bal[j] >> lane & 1) {
 				const u32 r = off + pre[j * LQ_RUN_WAVES + w] + (u32)__popcll(bal[j] & ((1ULL << lane) - 1));
-				sel[r] = (u32)((u64)T * LQ_RUN_TILE + (u32)j * LQ_RUN_THREADS + t); key[r] = 0xffffffffu - len[j];
+				sel[r] = (u32)((u64)T * LQ_RUN_TILE + (u32)j * LQ_RUN_THREADS + t);
+				if (key) key[r] = 0xffffffffu - len[j];
 			}
 		__syncthreads();
 	}

@@ -309,8 +309,9 @@ def check_run_list_variants(lib, tmp_path, monkeypatch):
     argv = ["-Y", "-l", "0", "-q", "40", "-k", "12", "-w", "5", "-I", "4G", "-p", "40", "-m", "20", "-t", "4", tf, qf]
     want = oracle_bind.ref_table(argv) if oracle_bind.have_ref() else oracle_bind.table(argv)
     assert sum(1 for l in want.splitlines() if l.split("\t")[2] != "0") >= 100
-    for runs in ("", "scan"):                      # two light passes over the anchors (default) | round 1's head / id arrays
-        monkeypatch.setenv("LQCOV_RUNS", runs)
+    for runs in ("", "scan", "compact"):           # two light passes over the anchors (default) | round 1's head / id arrays | + dense list of short runs
+        monkeypatch.setenv("LQCOV_RUNS", "" if runs == "compact" else runs)
+        monkeypatch.setenv("LQCOV_CHAIN_COMPACT", "1" if runs == "compact" else "0")
         for budget in ("", "3000"):                # one batch | batches of a few queries (run lists of a few tiles)
             monkeypatch.setenv("LQCOV_ANCHOR_BUDGET", budget) if budget else monkeypatch.delenv("LQCOV_ANCHOR_BUDGET", raising=False)
             rc, out, err = run_main(lib, argv)
