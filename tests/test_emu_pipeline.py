@@ -263,7 +263,7 @@ def _few_targets_dataset(tmp_path, n_targets=14, tlen=25000, n_queries=6, qlen=2
 def test_emulated_checkpointed_walks(emu_lib, tmp_path, monkeypatch, variant):
     """long sub-arrays of a few-bucket pass are walked in pieces from computed checkpoint states (kernels_ckpt.hpp):
     same table as the oracle, with the size classes shrunk so that this small input reaches them"""
-    tf, qf = _few_targets_dataset(tmp_path)
+    tf, qf = _few_targets_dataset(tmp_path, n_queries=3, qlen=17000)
     argv = ONT + [tf, qf]
     want = oracle_bind.table(argv)
     monkeypatch.setenv("LQCOV_WALK_SHIFT", "4")
@@ -274,7 +274,7 @@ def test_emulated_checkpointed_walks(emu_lib, tmp_path, monkeypatch, variant):
     rc, out, err = run_main(emu_lib, argv)
     assert rc == 0, err
     assert out == want
-    assert sum(1 for l in out.splitlines() if l.split("\t")[2] != "0") >= 4
+    assert sum(1 for l in out.splitlines() if l.split("\t")[2] != "0") >= 2
 
 
 def _many_short_queries_dataset(tmp_path, n_targets=60, n_queries=500, seed=5):
