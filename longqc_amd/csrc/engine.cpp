@@ -801,6 +801,7 @@ void lqcov_handle::sort_batch(MapLane &L, Part &pt, u32 q0, u32 nqb, u64 a_base,
 		const bool reg_walker = !(getenv("LQCOV_WALK") && !strcmp(getenv("LQCOV_WALK"), "solo"));   // A/B knob
 		const bool sort_tiles = !(getenv("LQCOV_SORT_TILES") && !strcmp(getenv("LQCOV_SORT_TILES"), "0"));   // A/B knob
 		const int xcd_order = !(getenv("LQCOV_XCD") && !strcmp(getenv("LQCOV_XCD"), "0"));   // A/B knob: tile list in XCD-major order
+		const bool gather = getenv("LQCOV_SCATTER") && !strcmp(getenv("LQCOV_SCATTER"), "gather");   // to be measured
 		const bool two_tiles = getenv("LQCOV_TWO_TILES") && atoi(getenv("LQCOV_TWO_TILES")) > 0;   // tiled two-bucket pass: written after the last GPU run of round 2, off until measured
 		L.sort_d.ensure(nA + 64); L.sort_dst.ensure((nA + 1) * 4);
 		SortSeg *cur = L.segs0.as<SortSeg>(), *nxt = L.segs1.as<SortSeg>();
@@ -958,7 +959,11 @@ void lqcov_handle::sort_batch(MapLane &L, Part &pt, u32 q0, u32 nqb, u64 a_base,
 			LQ_HIP_CHECK(hipStreamWaitEvent(sD, L.ev_w1, 0));
 			{
 				StageTimer t(this, sD, "k_sort_scatter");
-				if (sort_tiles) LQ_LAUNCH(k_sort_scatter_tiled, g_tile, 256, sD, cur, L.seg_info.as<SegInfo>(), L.tile_list.as<SortTile>(), cnt + LQ_C_TILES, tile, xcd_order, dA, dB, L.sort_dst.as<u32>(), (unsigned long long*)(cnt + LQ_C_SCATTERED), (unsigned long long*)(cnt + LQ_C_MOVED));
+				if (sort_tiles && gather) {
+					// (hx, the X position list of the level's two-bucket passes, is dead by now: the inverse permutation takes its place)
+					LQ_LAUNCH(k_sort_invert_tiled, g_tile, 256, sD, cur, L.seg_info.as<SegInfo>(), L.tile_list.as<SortTile>(), cnt + LQ_C_TILES, tile, xcd_order, L.sort_dst.as<u32>(), hx); check_launch();
+					LQ_LAUNCH(k_sort_gather_tiled, g_tile, 256, sD, cur, L.seg_info.as<SegInfo>(), L.tile_list.as<SortTile>(), cnt + LQ_C_TILES, tile, xcd_order, dA, dB, hx, (unsigned long long*)(cnt + LQ_C_SCATTERED), (unsigned long long*)(cnt + LQ_C_MOVED));
+				} else if (sort_tiles) LQ_LAUNCH(k_sort_scatter_tiled, g_tile, 256, sD, cur, L.seg_info.as<SegInfo>(), L.tile_list.as<SortTile>(), cnt + LQ_C_TILES, tile, xcd_order, dA, dB, L.sort_dst.as<u32>(), (unsigned long long*)(cnt + LQ_C_SCATTERED), (unsigned long long*)(cnt + LQ_C_MOVED));
 				else LQ_LAUNCH(k_sort_scatter, g_seg, 256, sD, cur, L.seg_info.as<SegInfo>(), cnt + cur_slot, dA, dB, L.sort_dst.as<u32>(), (unsigned long long*)(cnt + LQ_C_SCATTERED));
 				check_launch();
 			}

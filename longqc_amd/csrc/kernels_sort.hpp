@@ -186,6 +186,61 @@ k_sort_scatter_tiled(const SortSeg *segs, const SegInfo *info, const SortTile *t
 	}
 }
 
+// The same move as a gather (LQCOV_SCATTER=gather, to be measured against the scatter): the permutation is inverted first
+// (4-byte stores into the destination streams instead of 16-byte ones), then every destination slot reads its anchor: the
+// 16-byte stores become sequential, the scattered side becomes 16-byte reads, which caches can serve.
+__global__ void __launch_bounds__(256)
+k_sort_invert_tiled(const SortSeg *segs, const SegInfo *info, const SortTile *tiles, const u32 *n_tiles_p, u32 tile, int xcd, const u32 *dst, u32 *inv)
+{
+	const u32 n_tiles = *n_tiles_p;
+	LQ_TILE_LOOP(ti, n_tiles, xcd) {
+		const SortTile tl = tiles[ti];
+		if (info[tl.sgi].kind == LQ_SEG_IDENTITY) continue;
+		const SortSeg sg = segs[tl.sgi];
+		const u32 i0 = tl.tile * tile, i1 = sg.len - i0 < tile ? sg.len : i0 + tile;
+		const u32 *ds = dst + sg.off;
+		u32 *iv = inv + sg.off;
+		for (u32 i = i0 + threadIdx.x; i < i1; i += 256) iv[ds[i]] = i;
+	}
+}
+
+__global__ void __launch_bounds__(256)
+k_sort_gather_tiled(const SortSeg *segs, const SegInfo *info, const SortTile *tiles, const u32 *n_tiles_p, u32 tile, int xcd, mm128 *A, const mm128 *B, const u32 *inv,
+                    unsigned long long *tally, unsigned long long *moved)
+{
+	const u32 n_tiles = *n_tiles_p;
+	LQ_TILE_LOOP(ti, n_tiles, xcd) {
+		const SortTile tl = tiles[ti];
+		if (info[tl.sgi].kind == LQ_SEG_IDENTITY) continue;
+		const SortSeg sg = segs[tl.sgi];
+		const u32 i0 = tl.tile * tile, i1 = sg.len - i0 < tile ? sg.len : i0 + tile;
+		uint4 *a = (uint4*)(A + sg.off);
+		const uint4 *b = (const uint4*)(B + sg.off);
+		const u32 *iv = inv + sg.off;
+		if (tl.tile == 0 && threadIdx.x == 0 && tally) atomicAdd(tally, (unsigned long long)sg.len);
+		u32 j = i0 + threadIdx.x, nm = 0;
+		for (; j + 3 * 256 < i1; j += 4 * 256) {
+			const u32 s0 = iv[j], s1 = iv[j + 256], s2 = iv[j + 512], s3 = iv[j + 768];
+			const bool m0 = s0 != j, m1 = s1 != j + 256, m2 = s2 != j + 512, m3 = s3 != j + 768;
+			uint4 e0 = {}, e1 = {}, e2 = {}, e3 = {};
+			if (m0) e0 = b[s0];
+			if (m1) e1 = b[s1];
+			if (m2) e2 = b[s2];
+			if (m3) e3 = b[s3];
+			if (m0) a[j] = e0;
+			if (m1) a[j + 256] = e1;
+			if (m2) a[j + 512] = e2;
+			if (m3) a[j + 768] = e3;
+			nm += (u32)m0 + (u32)m1 + (u32)m2 + (u32)m3;
+		}
+		for (; j < i1; j += 256) { const u32 sidx = iv[j]; if (sidx != j) { a[j] = b[sidx]; ++nm; } }
+		if (moved) {
+			for (int o = 32; o > 0; o >>= 1) nm += __shfl_down(nm, o);
+			if ((threadIdx.x & 63) == 0 && nm) atomicAdd(moved, (unsigned long long)nm);
+		}
+	}
+}
+
 // one thread per sub-array: bucket offsets and the kind of pass; lists of general / two-bucket sub-arrays
 // size classes of general passes: digits of the sub-array fit a 4 / 16 / 64 / 156 KiB LDS window, or not at all
 #define LQ_WALK_CLASSES 5
