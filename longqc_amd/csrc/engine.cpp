@@ -824,7 +824,7 @@ void lqcov_handle::sort_batch(MapLane &L, Part &pt, u32 q0, u32 nqb, u64 a_base,
 				check_launch();
 			}
 			{
-				StageTimer t(this, sD, "k_sort_copy_hist");
+				StageTimer t(this, sD, sort_tiles ? "k_sort_copy_hist_tiled" : "k_sort_copy_hist");
 				if (sort_tiles) LQ_LAUNCH(k_sort_copy_hist_tiled, g_tile, 256, sD, cur, L.tile_list.as<SortTile>(), cnt + LQ_C_TILES, tile, xcd_order, dA, dB, L.sort_d.as<u8>(), L.hist.as<u32>(), L.mhist.as<u32>(), (unsigned long long*)(cnt + LQ_C_COPIED));
 				else LQ_LAUNCH(k_sort_copy_hist, g_seg, 256, sD, cur, cnt + cur_slot, dA, dB, L.sort_d.as<u8>(), L.hist.as<u32>(), L.mhist.as<u32>(), (unsigned long long*)(cnt + LQ_C_COPIED));
 				check_launch();
@@ -958,7 +958,7 @@ void lqcov_handle::sort_batch(MapLane &L, Part &pt, u32 q0, u32 nqb, u64 a_base,
 			LQ_HIP_CHECK(hipEventRecord(L.ev_w1, L.streamW));
 			LQ_HIP_CHECK(hipStreamWaitEvent(sD, L.ev_w1, 0));
 			{
-				StageTimer t(this, sD, "k_sort_scatter");
+				StageTimer t(this, sD, sort_tiles ? (gather ? "k_sort_gather_tiled" : "k_sort_scatter_tiled") : "k_sort_scatter");
 				if (sort_tiles && gather) {
 					// (hx, the X position list of the level's two-bucket passes, is dead by now: the inverse permutation takes its place)
 					LQ_LAUNCH(k_sort_invert_tiled, g_tile, 256, sD, cur, L.seg_info.as<SegInfo>(), L.tile_list.as<SortTile>(), cnt + LQ_C_TILES, tile, xcd_order, L.sort_dst.as<u32>(), hx); check_launch();
@@ -986,9 +986,11 @@ void lqcov_handle::sort_batch(MapLane &L, Part &pt, u32 q0, u32 nqb, u64 a_base,
 		if (hc[LQ_C_PS0 + LQ_P_OVERFLOW] || hc[LQ_C_PS1 + LQ_P_OVERFLOW]) throw std::runtime_error("parallel sort: list or counter space overflow");
 		if (profiling) {	// algorithmic bytes of the sort's stages from what the kernels really moved (16-byte anchors)
 			auto t64 = [&](int i) { return (u64)hc[i] | (u64)hc[i + 1] << 32; };
-			add_stage_bytes("k_sort_copy_hist", t64(LQ_C_COPIED) * 33);          // anchor in, anchor + digit byte out
+			const bool tiled_names = !(getenv("LQCOV_SORT_TILES") && !strcmp(getenv("LQCOV_SORT_TILES"), "0"));
+			const bool gather_name = tiled_names && getenv("LQCOV_SCATTER") && !strcmp(getenv("LQCOV_SCATTER"), "gather");
+			add_stage_bytes(tiled_names ? "k_sort_copy_hist_tiled" : "k_sort_copy_hist", t64(LQ_C_COPIED) * 33);          // anchor in, anchor + digit byte out
 			// 4-byte destination in; anchor in, anchor out for the anchors that move (all of them in the per-sub-array form)
-			add_stage_bytes("k_sort_scatter", t64(LQ_C_SCATTERED) * 4 + (t64(LQ_C_MOVED) ? t64(LQ_C_MOVED) : t64(LQ_C_SCATTERED)) * 32);
+			add_stage_bytes(tiled_names ? (gather_name ? "k_sort_gather_tiled" : "k_sort_scatter_tiled") : "k_sort_scatter", t64(LQ_C_SCATTERED) * 4 + (t64(LQ_C_MOVED) ? t64(LQ_C_MOVED) : t64(LQ_C_SCATTERED)) * 32);
 			add_stage_bytes("k_ps_hist", (t64(LQ_C_PART0) + t64(LQ_C_PART1)) * 16);
 			add_stage_bytes("k_ps_scatter", (t64(LQ_C_PART0) + t64(LQ_C_PART1)) * 32);
 			add_stage_bytes("k_ps_finish<8192>", (t64(LQ_C_FINB0) + t64(LQ_C_FINB1)) * 32);

@@ -7,7 +7,7 @@ B="python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --cache /tmp/lqcov_
 # (a plain run first: it pages torch in and fills the cache, so that the counter passes spend their limit on the step itself)
 timeout 200 $B > $R/gpurun_out/pmc_plain.log 2>&1
 for C in FETCH_SIZE WRITE_SIZE; do
-  ( timeout ${PMC_LIMIT:-240} rocprofv3 --pmc $C --kernel-trace --kernel-include-regex 'k_sort_scatter|k_sort_copy_hist' --output-format csv -d /tmp/pmc_$C -o p -- $B 2>&1 | tail -3 ) > $R/gpurun_out/pmc_$C.log 2>&1
+  ( timeout ${PMC_LIMIT:-240} rocprofv3 --pmc $C --kernel-trace --kernel-include-regex 'k_sort_scatter_tiled|k_sort_copy_hist_tiled' --output-format csv -d /tmp/pmc_$C -o p -- $B 2>&1 | tail -3 ) > $R/gpurun_out/pmc_$C.log 2>&1
 done
-python $R/tools/pmc_to_json.py /tmp/pmc_FETCH_SIZE /tmp/pmc_WRITE_SIZE $R/gpurun_out/pmc_traffic.json "bench.py --config cfg3 (configs[2]: 500000 reads, 5000 queries), 2 passes; counters for k_sort_scatter, k_sort_copy_hist only" > $R/gpurun_out/pmc_summary.txt 2>&1
+python $R/tools/pmc_to_json.py /tmp/pmc_FETCH_SIZE /tmp/pmc_WRITE_SIZE $R/gpurun_out/pmc_traffic.json "bench.py --config cfg3 (configs[2]: 500000 reads, 5000 queries), 2 passes; counters for k_sort_scatter_tiled, k_sort_copy_hist_tiled only" > $R/gpurun_out/pmc_summary.txt 2>&1
 cat $R/gpurun_out/pmc_summary.txt; tail -n 2 $R/gpurun_out/pmc_*.log | cut -c1-300
