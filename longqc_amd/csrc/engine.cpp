@@ -1085,13 +1085,20 @@ void lqcov_handle::map_part(Part &pt)
 	}
 	while (lanes.size() < (size_t)n_lanes) {
 		lanes.emplace_back(new MapLane());
-		LQ_HIP_CHECK(hipStreamCreate(&lanes.back()->stream));
-		LQ_HIP_CHECK(hipStreamCreate(&lanes.back()->stream2));
+		// LQCOV_WALK_EXCL=1 (to be measured): the wide kernels of the lanes stay off the walkers' CUs -- rocprofv3 at configs[2] shows
+		// walk kernels of up to 100 ms beside them where the longest walk alone takes 19
+		const uint32_t wmask = getenv("LQCOV_WALK_CUS") ? (uint32_t)strtoul(getenv("LQCOV_WALK_CUS"), 0, 16) : 0x11111111u;
+		const bool excl = getenv("LQCOV_WALK_EXCL") && atoi(getenv("LQCOV_WALK_EXCL")) > 0 && wmask != 0xffffffffu;
+		for (hipStream_t *ps : { &lanes.back()->stream, &lanes.back()->stream2 }) {
+			uint32_t inv[8];
+			for (int i = 0; i < 8; ++i) inv[i] = ~wmask;
+			if (!excl || hipExtStreamCreateWithCUMask(ps, 8, inv) != hipSuccess) { if (excl) (void)hipGetLastError(); LQ_HIP_CHECK(hipStreamCreate(ps)); }
+		}
 		{	// Token walks are latency-bound single-lane waves that live for milliseconds: left alone they fill the wave slots and
 			// the LDS of every CU and the bandwidth kernels of the other streams crawl (rocprofv3, configs[2]: k_ps_scatter 66 ms
 			// alone, 1100 ms beside the walkers).  Their stream may only use every fourth CU; 64 CUs x 32 waves are plenty for them.
 			uint32_t mask[8];
-			for (int i = 0; i < 8; ++i) mask[i] = getenv("LQCOV_WALK_CUS") ? (uint32_t)strtoul(getenv("LQCOV_WALK_CUS"), 0, 16) : 0x11111111u;
+			for (int i = 0; i < 8; ++i) mask[i] = wmask;
 			if (hipExtStreamCreateWithCUMask(&lanes.back()->streamW, 8, mask) != hipSuccess) { (void)hipGetLastError(); LQ_HIP_CHECK(hipStreamCreate(&lanes.back()->streamW)); }
 		}
 		LQ_HIP_CHECK(hipEventCreateWithFlags(&lanes.back()->ev_w0, hipEventDisableTiming));
