@@ -234,13 +234,15 @@ k_ck_solve(const CkSeg *cks, u32 n_cks, u32 n_ck_total, const SortSeg *segs, con
 // the slot -- after each: the pieces come out balanced whatever the data looks like.
 #define LQ_CKW_STEP 16
 // arr[digit] += 1 for the elements [lo, hi) of the sub-array, read as aligned 16-byte words (a lane's backlog of hundreds of
-// elements costs a sixteenth of the load latencies it would byte by byte)
-__device__ __forceinline__ void lq_ck_count_range(const u8 *d, u32 lo, u32 hi, u32 *arr)
+// elements costs a sixteenth of the load latencies it would byte by byte).  The last word read stays in registers (cw, tag
+// cwa = its address): in the long tail of a fixed point a bucket takes in an element or two per round, and sixteen of them
+// then cost one load.
+__device__ __forceinline__ void lq_ck_count_range(const u8 *d, u32 lo, u32 hi, u32 *arr, uint4 &cw, size_t &cwa)
 {
 	const u8 *p_lo = d + lo, *p_hi = d + hi;
 	for (const u8 *wa = (const u8*)((size_t)p_lo & ~(size_t)15); wa < p_hi; wa += 16) {
-		const uint4 W = *(const uint4*)wa;
-		const u32 ww[4] = { W.x, W.y, W.z, W.w };
+		if ((size_t)wa != cwa) { cw = *(const uint4*)wa; cwa = (size_t)wa; }
+		const u32 ww[4] = { cw.x, cw.y, cw.z, cw.w };
 #pragma unroll
 		for (u32 k = 0; k < 16; ++k) {
 			const u8 *g = wa + k;
@@ -260,6 +262,8 @@ k_ck_chain256(const CkSeg *cks, u32 n_cks, const SortSeg *segs, const u8 *D, con
 		const u8 *d = D + sg.off;
 		const u32 *bg = begs + (u64)ck.sgi * 256, *cn = hist + (u64)ck.sgi * 256;
 		u32 A[4], B0[4], E0[4];
+		uint4 cw[4]; size_t cwa[4];
+		for (int g = 0; g < 4; ++g) { cw[g] = uint4{0, 0, 0, 0}; cwa[g] = 0; }
 		for (int g = 0; g < 4; ++g) { const u32 c = (u32)g * 64 + lane; B0[g] = bg[c]; E0[g] = B0[g] + cn[c]; A[g] = B0[g]; arr[c] = 0; }
 		__syncthreads();
 		const u64 target = (u64)sg.len / ck.n_ck + 1;
@@ -284,7 +288,7 @@ k_ck_chain256(const CkSeg *cks, u32 n_cks, const SortSeg *segs, const u8 *D, con
 						u32 need = c == k ? s : B0[g] + arr[c];
 						if (need > E0[g]) need = E0[g];
 						if (A[g] < need) {
-							lq_ck_count_range(d, A[g], need, arr);
+							lq_ck_count_range(d, A[g], need, arr, cw[g], cwa[g]);
 							A[g] = need;
 							pending = true;
 						}
