@@ -930,7 +930,9 @@ void lqcov_handle::sort_batch(MapLane &L, Part &pt, u32 q0, u32 nqb, u64 a_base,
 							} else {
 								{
 									StageTimer t(this, sW, "k_ck_chain256", nA);
-									LQ_LAUNCH(k_ck_chain256, std::min<u32>(n_cks, wgrid), 64, sW, dck, n_cks, cur, dD, dH, dBg, L.ck_S.as<u32>(), L.ck_slot.as<u32>()); check_launch();
+									// LQCOV_CK_SEGS=n (to be measured): up to n coarse parts per sub-array, solved side by side
+									const u32 ck_segs = getenv("LQCOV_CK_SEGS") ? (u32)std::min(16, std::max(1, atoi(getenv("LQCOV_CK_SEGS")))) : 1;
+									LQ_LAUNCH(k_ck_chain256, std::min<u32>(n_cks * ck_segs, wgrid), 64, sW, dck, n_cks, ck_segs, cur, dD, dH, dBg, L.ck_S.as<u32>(), L.ck_slot.as<u32>()); check_launch();
 								}
 								{
 									StageTimer t(this, sW, "k_sort_walk_solo_ck", nA * 5);

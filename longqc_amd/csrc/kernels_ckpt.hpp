@@ -250,14 +250,32 @@ __device__ __forceinline__ void lq_ck_count_range(const u8 *d, u32 lo, u32 hi, u
 		}
 	}
 }
+// Coarse segments (max_segs > 1): the chain above is serial per sub-array -- tens of milliseconds for a sub-array of 10^6
+// elements.  But the state at ANY slot is the least solution above the start state (the argument at the top of this file
+// never used where the iteration starts), so it can be found without the states before it: the outer loop's slots up to the
+// end U of the first bucket that matters (nearly all picking-up happens while the first non-trivial bucket is filled) are cut
+// into NC - 1 equal parts, the rest is the last part; one wave per part finds the state at its first slot from scratch
+// (the buckets before the slot's own are read whole, that one up to the slot) and then chains through its part as above,
+// writing its share of the checkpoints.  max_segs = 1 is the serial chain.
+__device__ __forceinline__ u32 lq_ck_nsegs(u32 n_ck, u32 max_segs)
+{
+	const u32 a = n_ck / 4;
+	return a < 1 ? 1 : a < max_segs ? a : max_segs;
+}
+
 __global__ void __launch_bounds__(64)
-k_ck_chain256(const CkSeg *cks, u32 n_cks, const SortSeg *segs, const u8 *D, const u32 *hist, const u32 *begs, u32 *S, u32 *CKS)
+k_ck_chain256(const CkSeg *cks, u32 n_cks, u32 max_segs, const SortSeg *segs, const u8 *D, const u32 *hist, const u32 *begs, u32 *S, u32 *CKS)
 {
 	__shared__ u32 arr[256];
 	__shared__ u32 red[64];
 	const u32 lane = threadIdx.x;
-	for (u32 j = blockIdx.x; j < n_cks; j += gridDim.x) {
+	for (u32 wi = blockIdx.x; wi < n_cks * max_segs; wi += gridDim.x) {
+		const u32 j = wi / max_segs, seg = wi % max_segs;
 		const CkSeg ck = cks[j];
+		const u32 NC = lq_ck_nsegs(ck.n_ck, max_segs);
+		if (seg >= NC) continue;
+		const u32 per = ck.n_ck / NC;                           // checkpoints of a part; the last part also owns the remainder
+		const u32 my_ck0 = ck.ck0 + seg * per, my_n = seg + 1 == NC ? ck.n_ck - seg * per : per;
 		const SortSeg sg = segs[ck.sgi];
 		const u8 *d = D + sg.off;
 		const u32 *bg = begs + (u64)ck.sgi * 256, *cn = hist + (u64)ck.sgi * 256;
@@ -266,47 +284,74 @@ k_ck_chain256(const CkSeg *cks, u32 n_cks, const SortSeg *segs, const u8 *D, con
 		for (int g = 0; g < 4; ++g) { cw[g] = uint4{0, 0, 0, 0}; cwa[g] = 0; }
 		for (int g = 0; g < 4; ++g) { const u32 c = (u32)g * 64 + lane; B0[g] = bg[c]; E0[g] = B0[g] + cn[c]; A[g] = B0[g]; arr[c] = 0; }
 		__syncthreads();
+		// slots [u_lo, u_hi) of the outer loop (absolute slot indices: the buckets' regions follow each other)
+		u32 u_lo = 0, u_hi = sg.len;
+		if (NC > 1) {
+			const u32 thr = (sg.len >> 8) ? (sg.len >> 8) : 1;
+			u32 U = sg.len;
+			for (int g = 0; g < 4; ++g) if (E0[g] >= thr && E0[g] < U) U = E0[g];
+			for (int o = 32; o > 0; o >>= 1) { const u32 v = __shfl_xor(U, o); if (v < U) U = v; }
+			u_lo = seg == 0 ? 0 : (u32)((u64)U * seg / (NC - 1));
+			u_hi = seg + 1 == NC ? sg.len : (u32)((u64)U * (seg + 1) / (NC - 1));
+		}
+		// phase of a slot: the buckets that end at or before it come first
+		u32 k_lo = 0, k_hi = 0;
+		for (int g = 0; g < 4; ++g) { k_lo += (u32)__popcll(__ballot(E0[g] <= u_lo)); k_hi += (u32)__popcll(__ballot(E0[g] <= u_hi)); }
+		if (u_lo == 0) k_lo = 0;
+		if (u_hi >= sg.len) k_hi = 256;
+		// fixed point with the buckets before k full and bucket k held at s
+#define LQ_CK_FIXED_POINT(k, s) \
+		for (;;) { \
+			bool pending = false; \
+			for (int g = 0; g < 4; ++g) { \
+				const u32 c = (u32)g * 64 + lane; \
+				u32 need = c < (k) ? E0[g] : B0[g] + arr[c]; \
+				if (c == (k) && need < (s)) need = (s);            /* held at s -- or further, where arrivals filled the bucket beyond s before its phase began */ \
+				if (need > E0[g]) need = E0[g]; \
+				if (A[g] < need) { lq_ck_count_range(d, A[g], need, arr, cw[g], cwa[g]); A[g] = need; pending = true; } \
+			} \
+			__syncthreads(); \
+			if (!__ballot(pending)) break; \
+		}
+#define LQ_CK_PICKED(out) do { \
+			u32 mine_ = 0; \
+			for (int g = 0; g < 4; ++g) mine_ += A[g] - B0[g]; \
+			red[lane] = mine_; \
+			__syncthreads(); \
+			u64 p_ = 0; \
+			for (u32 x = 0; x < 64; ++x) p_ += red[x]; \
+			__syncthreads(); \
+			(out) = p_; \
+		} while (0)
+		// the state at this part's first slot, from scratch.  (A slot that arrivals had filled before the outer loop reached its
+		// bucket is never looked at: the state is then the one at the bucket's first look, and the cursor says where that is.)
+		if (u_lo > 0 && k_lo < 256) {
+			LQ_CK_FIXED_POINT(k_lo, u_lo)
+			for (int g = 0; g < 4; ++g) if ((u32)g == (k_lo >> 6)) u_lo = (u32)__builtin_amdgcn_readlane((int)A[g], (int)(k_lo & 63));
+		}
 		const u64 target = (u64)sg.len / ck.n_ck + 1;
 		u64 picked_at_last = 0, picked_before = 0;
+		LQ_CK_PICKED(picked_before);
+		picked_at_last = picked_before;
 		u32 n_out = 0, est = LQ_CKW_STEP;                       // slots of the phase's bucket that are worth about `target` picked-up elements
-		// checkpoint 0: the start
-		for (int g = 0; g < 4; ++g) S[((u64)ck.ck0 + 0) * 256 + (u32)g * 64 + lane] = B0[g];
-		if (lane == 0) CKS[ck.ck0] = 0;
+		// first checkpoint of the part: its first slot
+		for (int g = 0; g < 4; ++g) S[((u64)my_ck0 + 0) * 256 + (u32)g * 64 + lane] = A[g];
+		if (lane == 0) CKS[my_ck0] = u_lo;
 		n_out = 1;
-		for (u32 k = 0; k < 256; ++k) {                          // phases of the outer loop
+		for (u32 k = k_lo; k < 256 && k <= k_hi; ++k) {          // phases of the outer loop
 			const u32 kl = k & 63, kg = k >> 6;
 			u32 ek = 0, ak = 0;
 			for (int g = 0; g < 4; ++g) if ((u32)g == kg) { ek = (u32)__builtin_amdgcn_readlane((int)E0[g], (int)kl); ak = (u32)__builtin_amdgcn_readlane((int)A[g], (int)kl); }
+			if (k == k_hi && u_hi < ek) ek = u_hi;                  // the part ends inside this bucket
 			while (ak < ek) {
 				const u32 step = est;
 				u32 s = ek - ak > step ? ak + step : ek;                // the outer loop reaches slot s of bucket k
-				// fixed point with bucket k held at s
-				for (;;) {
-					bool pending = false;
-					for (int g = 0; g < 4; ++g) {
-						const u32 c = (u32)g * 64 + lane;
-						u32 need = c == k ? s : B0[g] + arr[c];
-						if (need > E0[g]) need = E0[g];
-						if (A[g] < need) {
-							lq_ck_count_range(d, A[g], need, arr, cw[g], cwa[g]);
-							A[g] = need;
-							pending = true;
-						}
-					}
-					__syncthreads();
-					if (!__ballot(pending)) break;
-				}
+				LQ_CK_FIXED_POINT(k, s)
 				// bucket k's cursor: slots filled = held value, unless arrivals already pushed it further
 				for (int g = 0; g < 4; ++g) if ((u32)g == kg) ak = (u32)__builtin_amdgcn_readlane((int)A[g], (int)kl);
 				if (ak < s) ak = s;
-				// elements picked up so far
-				u32 mine = 0;
-				for (int g = 0; g < 4; ++g) mine += A[g] - B0[g];
-				red[lane] = mine;
-				__syncthreads();
-				u64 picked = 0;
-				for (u32 x = 0; x < 64; ++x) picked += red[x];
-				__syncthreads();
+				u64 picked;
+				LQ_CK_PICKED(picked);
 				{	// one step per checkpoint: the next step covers the slots that the last one's yield says are worth `target`
 					const u64 got = picked - picked_before;
 					picked_before = picked;
@@ -314,17 +359,19 @@ k_ck_chain256(const CkSeg *cks, u32 n_cks, const SortSeg *segs, const u8 *D, con
 					if (e2 > (u64)step * 4) e2 = (u64)step * 4;
 					est = (u32)(e2 < LQ_CKW_STEP ? LQ_CKW_STEP : e2 > (1u << 24) ? (1u << 24) : e2);
 				}
-				if (picked - picked_at_last >= target / 2 && n_out < ck.n_ck && ak < ek) {
-					for (int g = 0; g < 4; ++g) S[((u64)ck.ck0 + n_out) * 256 + (u32)g * 64 + lane] = A[g];
-					if (lane == 0) CKS[ck.ck0 + n_out] = ak;
+				if (picked - picked_at_last >= target / 2 && n_out < my_n && ak < ek) {
+					for (int g = 0; g < 4; ++g) S[((u64)my_ck0 + n_out) * 256 + (u32)g * 64 + lane] = A[g];
+					if (lane == 0) CKS[my_ck0 + n_out] = ak;
 					++n_out; picked_at_last = picked;
 				}
 			}
 		}
-		// unused checkpoints: the final state (their walkers find nothing to do)
-		for (; n_out < ck.n_ck; ++n_out) {
-			for (int g = 0; g < 4; ++g) S[((u64)ck.ck0 + n_out) * 256 + (u32)g * 64 + lane] = E0[g];
-			if (lane == 0) CKS[ck.ck0 + n_out] = sg.len;
+#undef LQ_CK_FIXED_POINT
+#undef LQ_CK_PICKED
+		// unused checkpoints: the state at the part's end -- the next part's first checkpoint (their walkers find nothing to do)
+		for (; n_out < my_n; ++n_out) {
+			for (int g = 0; g < 4; ++g) S[((u64)my_ck0 + n_out) * 256 + (u32)g * 64 + lane] = u_hi >= sg.len ? E0[g] : A[g];
+			if (lane == 0) CKS[my_ck0 + n_out] = u_hi >= sg.len ? sg.len : u_hi;
 		}
 		__syncthreads();
 	}

@@ -366,6 +366,7 @@ def check_repeat_rich_randomised(lib, tmp_path, monkeypatch, seed, two_tiles=Fal
     monkeypatch.setenv("LQCOV_SORT_TILE", str([8192, 64, 1000][seed % 3]))      # tiles of the streaming kernels: one per sub-array | many
     monkeypatch.setenv("LQCOV_TWO_TILES", "1" if two_tiles else "0")             # the two-bucket pass over tiles (off by default until measured)
     monkeypatch.setenv("LQCOV_SCATTER", "gather" if two_tiles and seed == 2 else "scatter")   # the move as a gather (likewise)
+    monkeypatch.setenv("LQCOV_CK_SEGS", str([1, 4, 16][seed % 3]) if two_tiles else "1")      # coarse parts of the many-bucket checkpoint solver (likewise)
     monkeypatch.setenv("LQCOV_CKPT3", str(seed & 1))          # odd seeds: checkpoints for the second-longest class of many-bucket passes too
     rc, out, err = run_main(lib, argv)
     assert rc == 0, err
