@@ -14,7 +14,12 @@
 //   solution A' that lies above an earlier state of it: look at the first moment a cursor would pass A'_c -- the element
 //   arriving at c was picked up from the first A'_l - beg_l elements of some R_l and has digit c, and A'_c already counts
 //   all of those.  Hence the state is the LEAST solution above the state at the end of the previous phase (bucket k-1
-//   full), and monotone iteration from there (A <- max(A, F(A))) finds it: no walking, only prefix counts of digits
+//   full) -- and, by the same argument, above the pass's start state: a state can be found from scratch, without the
+//   states before it (the coarse parts of k_ck_chain256).  One caveat: only slots the outer loop really looks at name a
+//   state.  Arrivals fill the head of bucket k before its phase begins; a slot s below the cursor that bucket k has
+//   when the buckets before it are full is never looked at, and "k held at s, or further if its arrivals say so"
+//   (A_k >= s and A_k - beg_k >= arrivals) then yields the state at the bucket's first look.
+//   Monotone iteration from a state below (A <- max(A, F(A))) finds the least solution: no walking, only prefix counts of digits
 //   (per-tile histograms, scanned) and a few dozen rounds -- the increments shrink by about (B-1)/B per round, so this is
 //   for passes with few buckets (B <= 16: the byte of rid above 65536 targets), which is where the giant walks are.
 //
