@@ -920,7 +920,7 @@ void lqcov_handle::sort_batch(MapLane &L, Part &pt, u32 q0, u32 nqb, u64 a_base,
 								}
 								{
 									StageTimer t(this, sW, "k_ck_solve");
-									LQ_LAUNCH(k_ck_phases, std::min<u32>(n_cks, 1u << 16), 64, sW, dck, n_cks, cur, dD, dH, dBg, L.ck_T.as<u32>(), L.ck_E.as<u32>()); check_launch();
+									LQ_LAUNCH(k_ck_phases, (u32)std::min<u64>((u64)n_cks * LQ_CK_B, 1u << 16), 64, sW, dck, n_cks, cur, dD, dH, dBg, L.ck_T.as<u32>(), L.ck_E.as<u32>()); check_launch();
 									LQ_LAUNCH(k_ck_solve, std::min<u32>(n_ck, wgrid), 64, sW, dck, n_cks, n_ck, cur, dD, dH, dBg, L.ck_T.as<u32>(), L.ck_E.as<u32>(), L.ck_S.as<u32>(), L.ck_slot.as<u32>()); check_launch();
 								}
 								{

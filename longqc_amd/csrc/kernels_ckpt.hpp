@@ -139,12 +139,15 @@ __device__ __forceinline__ u32 lq_ck_iterate(const u8 *d, const u32 *T, u32 k, u
 	return A;
 }
 
-// state at the end of every phase: E[j][k][c] = cursors when bucket k has just become full (one wave per sub-array)
+// state at the end of every phase: E[j][k][c] = cursors when bucket k has just become full.  One wave per (sub-array, phase):
+// every phase end is found from scratch (the least solution above the start state with the buckets up to k full) instead
+// of from the phase before -- the phases of a sub-array then cost the time of the slowest, not their sum.
 __global__ void __launch_bounds__(64)
 k_ck_phases(const CkSeg *cks, u32 n_cks, const SortSeg *segs, const u8 *D, const u32 *hist, const u32 *begs, const u32 *T, u32 *E)
 {
 	const u32 lane = threadIdx.x;
-	for (u32 j = blockIdx.x; j < n_cks; j += gridDim.x) {
+	for (u32 wi = blockIdx.x; wi < n_cks * LQ_CK_B; wi += gridDim.x) {
+		const u32 j = wi / LQ_CK_B, k = wi % LQ_CK_B;
 		const CkSeg ck = cks[j];
 		const SortSeg sg = segs[ck.sgi];
 		const u8 *d = D + sg.off;
@@ -153,16 +156,15 @@ k_ck_phases(const CkSeg *cks, u32 n_cks, const SortSeg *segs, const u8 *D, const
 		const u32 my_beg = lane < LQ_CK_B ? bg[lane] : 0, my_end = lane < LQ_CK_B ? my_beg + cn[lane] : 0;
 		u32 nb = 1;
 		for (u32 c = 0; c < LQ_CK_B; ++c) if (cn[c]) nb = c + 1;      // buckets in use
-		u32 pbeg[LQ_CK_B], pend[LQ_CK_B];
-		for (u32 l = 0; l < LQ_CK_B; ++l) { pbeg[l] = 0; pend[l] = 0; }
+		u32 A = lane <= k ? my_end : my_beg;                        // the outer loop has filled the buckets up to k
+		if (k < nb) {
+			u32 pbeg[LQ_CK_B], pend[LQ_CK_B];
+			for (u32 l = 0; l < LQ_CK_B; ++l) { pbeg[l] = 0; pend[l] = 0; }
 #pragma unroll
-		for (u32 l = 0; l < LQ_CK_B; ++l) if (l < nb) { pbeg[l] = lq_ck_prefix(d, Tj, bg[l], lane); pend[l] = lq_ck_prefix(d, Tj, bg[l] + cn[l], lane); }
-		u32 A = my_beg;
-		for (u32 k = 0; k < LQ_CK_B; ++k) {
-			if (lane == k) A = my_end;                              // the outer loop has filled bucket k
-			if (k < nb) A = lq_ck_iterate(d, Tj, k, nb, A, pbeg, pend, my_beg, lane);
-			if (lane < LQ_CK_B) E[((u64)j * LQ_CK_B + k) * LQ_CK_B + lane] = A;
-		}
+			for (u32 l = 0; l < LQ_CK_B; ++l) if (l < nb) { pbeg[l] = lq_ck_prefix(d, Tj, bg[l], lane); pend[l] = lq_ck_prefix(d, Tj, bg[l] + cn[l], lane); }
+			A = lq_ck_iterate(d, Tj, k, nb, A, pbeg, pend, my_beg, lane);
+		} else A = my_end;                                          // past the last bucket in use: the final state
+		if (lane < LQ_CK_B) E[((u64)j * LQ_CK_B + k) * LQ_CK_B + lane] = A;
 	}
 }
 
