@@ -278,7 +278,9 @@ void lqcov_handle::sketch(ReadSetDev &rs, bool rid_in_y)
 		cnt.ensure(nc * 4); off.ensure(nc * 8);
 		const u64 in_bytes = nc * (LQ_CHUNK_WORDS * 12);
 		// ring capacity 8 / 16 (LDS) or 256 (private), -H on/off: pick the instantiation
-#define LQ_SK_LAUNCH(RC, EM, HP, BS, ...) LQ_LAUNCH((k_sketch<RC, EM, HP>), nblk(nc, BS), BS, stream, rs.codes.as<u64>(), rs.amb.as<u32>(), rs.d_coff.as<u64>(), rs.d_len.as<u32>(), rs.n, nc, sp, (int)rid_in_y, __VA_ARGS__)
+		// chunks per thread: the halo before a thread's first chunk is walked once per kpt chunks (LQCOV_SKETCH_KPT=1: every chunk its own thread, as measured in round 2)
+		const u32 kpt = getenv("LQCOV_SKETCH_KPT") ? (u32)std::min(64, std::max(1, atoi(getenv("LQCOV_SKETCH_KPT")))) : 4;
+#define LQ_SK_LAUNCH(RC, EM, HP, BS, ...) LQ_LAUNCH((k_sketch<RC, EM, HP>), nblk((nc + kpt - 1) / kpt, BS), BS, stream, rs.codes.as<u64>(), rs.amb.as<u32>(), rs.d_coff.as<u64>(), rs.d_len.as<u32>(), rs.n, nc, kpt, sp, (int)rid_in_y, __VA_ARGS__)
 #define LQ_SK_DISPATCH(EM, ...) do { \
 		if (P.w <= 8)       { if (P.hpc) LQ_SK_LAUNCH(8, EM, true, LQ_SK_BLOCK, __VA_ARGS__);   else LQ_SK_LAUNCH(8, EM, false, LQ_SK_BLOCK, __VA_ARGS__); } \
 		else if (P.w <= 16) { if (P.hpc) LQ_SK_LAUNCH(16, EM, true, LQ_SK_BLOCK, __VA_ARGS__);  else LQ_SK_LAUNCH(16, EM, false, LQ_SK_BLOCK, __VA_ARGS__); } \

@@ -237,7 +237,7 @@ __device__ __forceinline__ void sk_warm(SkState<STRIDE> &s, ReadView &rv, const 
 // RCAP <= 16: ring in LDS (block of LQ_SK_BLOCK threads); RCAP = 256: private ring, any w < 256.
 #define LQ_SK_BLOCK 256
 template <int RCAP, bool EMIT, bool HPC>
-__global__ void k_sketch(const u64 *codes, const u32 *amb, const u64 *coff, const u32 *rlen, u32 n_reads, u64 n_chunks,
+__global__ void k_sketch(const u64 *codes, const u32 *amb, const u64 *coff, const u32 *rlen, u32 n_reads, u64 n_chunks, u32 kpt,
                          SkParams P, int rid_in_y, u32 *cnt, const u64 *off, u64 *out_x, u64 *out_y)
 {
 	constexpr int STRIDE = RCAP <= 16 ? LQ_SK_BLOCK : 1;
@@ -247,33 +247,43 @@ __global__ void k_sketch(const u64 *codes, const u32 *amb, const u64 *coff, cons
 	u64 p_rx[RCAP <= 16 ? 1 : RCAP];
 	u32 p_ry[RCAP <= 16 ? 1 : RCAP];
 	i32 p_rq[RCAP <= 16 ? 1 : 32];
-	u64 g = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-	if (g >= n_chunks) return;
-	u32 r = lq_find_seg(coff, n_reads, g);
-	u32 len = rlen[r];
-	u32 pos0 = (u32)(g - coff[r]) * LQ_CHUNK;
-	u32 pos1 = pos0 + LQ_CHUNK < len ? pos0 + LQ_CHUNK : len;
-	ReadView rv; rv.init(codes + coff[r] * LQ_CHUNK_WORDS, amb + coff[r] * LQ_CHUNK_WORDS, len);
-	u32 i = pos0;
-	if (P.hpc) while (i < len && !rv.run_start(i)) ++i;        // first iteration this chunk owns
-	SkOut o; o.n = 0; o.y_hi = rid_in_y ? (u64)r << 32 : 0;
-	o.x = o.y = nullptr;
-	if (EMIT) { o.x = out_x + off[g]; o.y = out_y + off[g]; }
-	if (i < pos1) {
-		SkState<STRIDE> s;
-		if (RCAP <= 16) { s.rx = &s_rx[0][threadIdx.x]; s.ry = &s_ry[0][threadIdx.x]; s.rq = &s_rq[0][threadIdx.x]; }
-		else { s.rx = p_rx; s.ry = p_ry; s.rq = p_rq; }
-		sk_warm<STRIDE>(s, rv, P, i);
-		while (i < pos1) {
-			int c, run; u32 last; bool pal;
-			sk_fetch(rv, P, i, c, run, last);
-			sk_step<STRIDE, EMIT>(s, P, c, last, run, true, o, pal);
-			i = last + 1;
+	// A thread owns kpt consecutive chunks.  The machine's state carries over from one chunk to the next of the same read
+	// (the next chunk's first iteration is the one the machine stands at), so the halo is walked once per kpt chunks.
+	const u64 g0 = ((u64)blockIdx.x * blockDim.x + threadIdx.x) * kpt;
+	if (g0 >= n_chunks) return;
+	SkState<STRIDE> s;
+	if (RCAP <= 16) { s.rx = &s_rx[0][threadIdx.x]; s.ry = &s_ry[0][threadIdx.x]; s.rq = &s_rq[0][threadIdx.x]; }
+	else { s.rx = p_rx; s.ry = p_ry; s.rq = p_rq; }
+	bool have = false;                                         // s is the machine's state before the iteration that starts at i_next of read r_prev
+	u32 r_prev = 0, i_next = 0;
+	ReadView rv;
+	for (u32 cc = 0; cc < kpt && g0 + cc < n_chunks; ++cc) {
+		const u64 g = g0 + cc;
+		u32 r;
+		if (have && g < coff[r_prev + 1]) r = r_prev;
+		else { r = lq_find_seg(coff, n_reads, g); have = false; rv.init(codes + coff[r] * LQ_CHUNK_WORDS, amb + coff[r] * LQ_CHUNK_WORDS, rlen[r]); }
+		const u32 len = rv.len;
+		const u32 pos0 = (u32)(g - coff[r]) * LQ_CHUNK;
+		const u32 pos1 = pos0 + LQ_CHUNK < len ? pos0 + LQ_CHUNK : len;
+		u32 i = pos0;
+		if (P.hpc) while (i < len && !rv.run_start(i)) ++i;        // first iteration this chunk owns
+		SkOut o; o.n = 0; o.y_hi = rid_in_y ? (u64)r << 32 : 0;
+		o.x = o.y = nullptr;
+		if (EMIT) { o.x = out_x + off[g]; o.y = out_y + off[g]; }
+		if (i < pos1) {
+			if (!(have && i_next == i)) sk_warm<STRIDE>(s, rv, P, i);
+			while (i < pos1) {
+				int c, run; u32 last; bool pal;
+				sk_fetch(rv, P, i, c, run, last);
+				sk_step<STRIDE, EMIT>(s, P, c, last, run, true, o, pal);
+				i = last + 1;
+			}
+			if (i >= len && s.best_x != LQ_U64MAX)                    // this thread ran the read's last iteration: sketch.c:140-141
+				sk_push<EMIT>(o, true, s.best_x, s.best_y);
+			have = true; r_prev = r; i_next = i;
 		}
-		if (i >= len && s.best_x != LQ_U64MAX)                    // this thread ran the read's last iteration: sketch.c:140-141
-			sk_push<EMIT>(o, true, s.best_x, s.best_y);
+		if (!EMIT) cnt[g] = (u32)o.n;
 	}
-	if (!EMIT) cnt[g] = (u32)o.n;
 }
 
 // per-read minimizer offsets from per-chunk offsets
