@@ -280,12 +280,31 @@ void lqcov_handle::sketch(ReadSetDev &rs, bool rid_in_y)
 		// ring capacity 8 / 16 (LDS) or 256 (private), -H on/off: pick the instantiation
 		// chunks per thread: the halo before a thread's first chunk is walked once per kpt chunks (LQCOV_SKETCH_KPT=1: every chunk its own thread, as measured in round 2)
 		const u32 kpt = getenv("LQCOV_SKETCH_KPT") ? (u32)std::min(64, std::max(1, atoi(getenv("LQCOV_SKETCH_KPT")))) : 4;
-#define LQ_SK_LAUNCH(RC, EM, HP, BS, ...) LQ_LAUNCH((k_sketch<RC, EM, HP>), nblk((nc + kpt - 1) / kpt, BS), BS, stream, rs.codes.as<u64>(), rs.amb.as<u32>(), rs.d_coff.as<u64>(), rs.d_len.as<u32>(), rs.n, nc, kpt, sp, (int)rid_in_y, __VA_ARGS__)
+#define LQ_SK_LAUNCH(RC, EM, HP, BS, ...) LQ_LAUNCH((k_sketch<RC, EM, HP>), nblk((nc + kpt - 1) / kpt, BS), BS, stream, rs.codes.as<u64>(), rs.amb.as<u32>(), rs.d_coff.as<u64>(), rs.d_len.as<u32>(), rs.n, nc, kpt, sp, (int)rid_in_y, __VA_ARGS__, dp_owned)
 #define LQ_SK_DISPATCH(EM, ...) do { \
 		if (P.w <= 8)       { if (P.hpc) LQ_SK_LAUNCH(8, EM, true, LQ_SK_BLOCK, __VA_ARGS__);   else LQ_SK_LAUNCH(8, EM, false, LQ_SK_BLOCK, __VA_ARGS__); } \
 		else if (P.w <= 16) { if (P.hpc) LQ_SK_LAUNCH(16, EM, true, LQ_SK_BLOCK, __VA_ARGS__);  else LQ_SK_LAUNCH(16, EM, false, LQ_SK_BLOCK, __VA_ARGS__); } \
 		else                { if (P.hpc) LQ_SK_LAUNCH(256, EM, true, 64, __VA_ARGS__);          else LQ_SK_LAUNCH(256, EM, false, 64, __VA_ARGS__); } \
 	} while (0)
+		// LQCOV_SKETCH=dp (to be measured): chunks inside N-free stretches away from the read start are decided data-parallel
+		// (k_sketch_dp); the state machine keeps the others
+		const bool sk_dp = getenv("LQCOV_SKETCH") && !strcmp(getenv("LQCOV_SKETCH"), "dp") && !P.hpc && P.w <= 16 && P.k <= 28 && P.w + P.k - 1 <= 48;
+		const u8 *dp_owned = nullptr;
+		if (sk_dp) {
+			sk_owned.ensure(nc);
+			StageTimer t(this, "k_sketch_dp_count", in_bytes + nc * 4);
+			LQ_LAUNCH((k_sketch_dp<false>), (u32)std::min<u64>(nc, 1u << 20), LQ_DP_THREADS, stream, rs.codes.as<u64>(), rs.amb.as<u32>(), rs.d_coff.as<u64>(), rs.d_len.as<u32>(), rs.n, nc, sp, (int)rid_in_y,
+			          cnt.as<u32>(), sk_owned.as<u8>(), (const u64*)nullptr, (u64*)nullptr, (u64*)nullptr);
+			check_launch();
+			dp_owned = sk_owned.as<u8>();
+			if (getenv("LQCOV_DEBUG_SKETCH")) {
+				std::vector<u8> ho(nc);
+				d2h(ho.data(), sk_owned.as<u8>(), nc, stream);
+				u64 n_own = 0;
+				for (u8 v : ho) n_own += v;
+				fprintf(stderr, "[sketch] %llu of %llu chunks decided data-parallel\n", (unsigned long long)n_own, (unsigned long long)nc);
+			}
+		}
 		{
 			StageTimer t(this, "k_sketch_count", in_bytes + nc * 4);
 			LQ_SK_DISPATCH(false, cnt.as<u32>(), (const u64*)nullptr, (u64*)nullptr, (u64*)nullptr);
@@ -297,6 +316,12 @@ void lqcov_handle::sketch(ReadSetDev &rs, bool rid_in_y)
 		d2h(&last_cnt, cnt.as<u32>() + nc - 1, 1, stream);
 		rs.n_mini = last_off + last_cnt;
 		rs.mx.ensure(rs.n_mini * 8 + 8); rs.my.ensure(rs.n_mini * 8 + 8);
+		if (sk_dp) {
+			StageTimer t(this, "k_sketch_dp_emit", in_bytes + nc * 8 + rs.n_mini * 16);
+			LQ_LAUNCH((k_sketch_dp<true>), (u32)std::min<u64>(nc, 1u << 20), LQ_DP_THREADS, stream, rs.codes.as<u64>(), rs.amb.as<u32>(), rs.d_coff.as<u64>(), rs.d_len.as<u32>(), rs.n, nc, sp, (int)rid_in_y,
+			          (u32*)nullptr, sk_owned.as<u8>(), off.as<u64>(), rs.mx.as<u64>(), rs.my.as<u64>());
+			check_launch();
+		}
 		{
 			StageTimer t(this, "k_sketch_emit", in_bytes + nc * 8 + rs.n_mini * 16);
 			LQ_SK_DISPATCH(true, (u32*)nullptr, off.as<u64>(), rs.mx.as<u64>(), rs.my.as<u64>());

@@ -120,7 +120,7 @@ struct lqcov_handle {
 	DBuf dbg_chains, n_dbg; u64 dbg_cap = 0; u64 n_dbg_host = 0;
 	DBuf misc;
 	DBuf ix_key, ix_key2, ix_head, ix_uidx, ix_ukey, ix_ustart, ix_ucnt, ix_sorted;   // build_index workspaces
-	DBuf sk_cnt, sk_off;                  // sketch: per-chunk minimizer counts / offsets
+	DBuf sk_cnt, sk_off, sk_owned;                  // sketch: per-chunk minimizer counts / offsets
 	u64 last_n_anchors = 0;
 	u64 anchor_budget = 0;
 

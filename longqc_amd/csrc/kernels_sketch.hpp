@@ -238,7 +238,7 @@ __device__ __forceinline__ void sk_warm(SkState<STRIDE> &s, ReadView &rv, const 
 #define LQ_SK_BLOCK 256
 template <int RCAP, bool EMIT, bool HPC>
 __global__ void k_sketch(const u64 *codes, const u32 *amb, const u64 *coff, const u32 *rlen, u32 n_reads, u64 n_chunks, u32 kpt,
-                         SkParams P, int rid_in_y, u32 *cnt, const u64 *off, u64 *out_x, u64 *out_y)
+                         SkParams P, int rid_in_y, u32 *cnt, const u64 *off, u64 *out_x, u64 *out_y, const u8 *dp_owned)
 {
 	constexpr int STRIDE = RCAP <= 16 ? LQ_SK_BLOCK : 1;
 	__shared__ u64 s_rx[RCAP <= 16 ? RCAP : 1][LQ_SK_BLOCK];
@@ -259,6 +259,7 @@ __global__ void k_sketch(const u64 *codes, const u32 *amb, const u64 *coff, cons
 	ReadView rv;
 	for (u32 cc = 0; cc < kpt && g0 + cc < n_chunks; ++cc) {
 		const u64 g = g0 + cc;
+		if (dp_owned && dp_owned[g]) { have = false; continue; }   // k_sketch_dp decides this chunk
 		u32 r;
 		if (have && g < coff[r_prev + 1]) r = r_prev;
 		else { r = lq_find_seg(coff, n_reads, g); have = false; rv.init(codes + coff[r] * LQ_CHUNK_WORDS, amb + coff[r] * LQ_CHUNK_WORDS, rlen[r]); }
@@ -283,6 +284,120 @@ __global__ void k_sketch(const u64 *codes, const u32 *amb, const u64 *coff, cons
 			have = true; r_prev = r; i_next = i;
 		}
 		if (!EMIT) cnt[g] = (u32)o.n;
+	}
+}
+
+// ---- the same list, decided data-parallel where the machine is memoryless ------------------------------------------
+// Inside an N-free stretch, LQ_DP_HALO bases or more away from the read start, with at least w + k - 1 non-palindromic
+// positions in the halo, every threshold test on l holds (sketch.c:116-137 with l >= w + k) and every ring slot is a real
+// k-mer: mm_sketch is then a sliding-window minimum over the non-palindromic positions ("slots") with its tie rules, and
+// what step t emits depends on the values of slots t - w .. t only.  With m = the newest minimal slot of [t - w, t - 1]:
+//   v_t <= v_m              -> emit m                                   (sketch.c:122-124)
+//   else m == t - w         -> emit m, then with m' = the newest minimal slot of [t - w + 1, t] every other slot of that
+//                              window with the value of m', oldest first  (sketch.c:125-137)
+// and the read's last step is followed by the minimum of its window (sketch.c:140-141).  One block per 128-base chunk, one
+// thread per position of chunk + halo: k-mer straight from the packed codes, hash, compaction of the slots in LDS, the
+// emissions of every slot counted (count pass) or written at the chunk's offset + rank (emit pass).  A chunk that does not
+// qualify (first chunk of a read, an N within reach, too many palindromes -- AT repeats --, w > 16, -H) is left to k_sketch:
+// owned[g] says which kernel decides chunk g.
+#define LQ_DP_HALO 64
+#define LQ_DP_THREADS (LQ_CHUNK + LQ_DP_HALO)
+__device__ __forceinline__ u64 lq_rev2(u64 x)
+{	// the 2-bit groups of x in reverse order
+	x = ((x >> 2) & 0x3333333333333333ULL) | ((x & 0x3333333333333333ULL) << 2);
+	x = ((x >> 4) & 0x0f0f0f0f0f0f0f0fULL) | ((x & 0x0f0f0f0f0f0f0f0fULL) << 4);
+	x = ((x >> 8) & 0x00ff00ff00ff00ffULL) | ((x & 0x00ff00ff00ff00ffULL) << 8);
+	x = ((x >> 16) & 0x0000ffff0000ffffULL) | ((x & 0x0000ffff0000ffffULL) << 16);
+	return x >> 32 | x << 32;
+}
+
+template <bool EMIT>
+__global__ void __launch_bounds__(LQ_DP_THREADS)
+k_sketch_dp(const u64 *codes, const u32 *amb, const u64 *coff, const u32 *rlen, u32 n_reads, u64 n_chunks, SkParams P, int rid_in_y,
+            u32 *cnt, u8 *owned, const u64 *off, u64 *out_x, u64 *out_y)
+{
+	__shared__ u64 V[LQ_DP_THREADS];
+	__shared__ u32 Y[LQ_DP_THREADS];
+	__shared__ u32 wsum[LQ_DP_THREADS / 64], wsum2[LQ_DP_THREADS / 64], bad;
+	const u32 t = threadIdx.x, lane = t & 63, wv = t >> 6;
+	const i32 w = P.w, k = P.k;
+	for (u64 g = blockIdx.x; g < n_chunks; g += gridDim.x) {
+		if (EMIT && !owned[g]) continue;
+		const u32 r = lq_find_seg(coff, n_reads, g);
+		const u32 len = rlen[r];
+		const u32 pos0 = (u32)(g - coff[r]) * LQ_CHUNK;
+		const u32 pos1 = pos0 + LQ_CHUNK < len ? pos0 + LQ_CHUNK : len;
+		if (pos0 < LQ_CHUNK || pos0 >= len) { if (!EMIT && t == 0) owned[g] = 0; continue; }   // (uniform) the read's first chunk: k_sketch
+		const u64 *cw = codes + coff[r] * LQ_CHUNK_WORDS;
+		const u32 *aw = amb + coff[r] * LQ_CHUNK_WORDS;
+		if (t == 0) bad = 0;
+		__syncthreads();
+		const u32 p = pos0 - LQ_DP_HALO + t;                      // this thread's position; its k-mer is [p - k + 1, p]
+		bool slot = false;
+		u64 x = 0; u32 y = 0;
+		if (p < pos1) {
+			const u32 lo = p - (u32)k + 1, wi = lo >> 5, sh = lo & 31;
+			const u32 last_w = p >> 5;
+			u64 raw = cw[wi] >> (2 * sh);
+			u64 am = (u64)aw[wi] >> sh;
+			if (last_w != wi) { raw |= cw[wi + 1] << (64 - 2 * sh); am |= (u64)aw[wi + 1] << (32 - sh); }
+			raw &= P.mask;
+			if (am & ((1ULL << k) - 1)) atomicOr(&bad, 1u);        // an ambiguous base within reach: the machine's memory matters
+			const u64 rv = ~raw & P.mask;                            // complement, oldest base lowest: the machine's rv
+			const u64 fw = lq_rev2(raw) >> (64 - 2 * k);             // newest base lowest: the machine's fw
+			if (fw != rv) {
+				const u32 z = fw < rv ? 0u : 1u;
+				x = lq_hash64(z ? rv : fw, P.mask) << 8 | (u64)k;
+				y = p << 1 | z;
+				slot = true;
+			}
+		}
+		// slot index = number of slots before this position
+		u32 inc = slot ? 1u : 0u;
+		for (int d = 1; d < 64; d <<= 1) { const u32 o = __shfl_up(inc, d); if ((int)lane >= d) inc += o; }
+		if (lane == 63) wsum[wv] = inc;
+		__syncthreads();
+		u32 ts = inc - (slot ? 1u : 0u), T = 0;
+		for (u32 q = 0; q < LQ_DP_THREADS / 64; ++q) { if (q < wv) ts += wsum[q]; T += wsum[q]; }
+		const u32 T0 = wsum[0];                                   // slots of the halo (the first wave is the halo)
+		const bool ok = !bad && T0 >= (u32)(w + k - 1) && T > T0;  // (uniform)
+		if (!EMIT && t == 0) owned[g] = ok ? 1 : 0;
+		if (!ok) { __syncthreads(); continue; }
+		if (slot) { V[ts] = x; Y[ts] = y; }
+		__syncthreads();
+		// emissions of this thread's step
+		u32 ne = 0;
+		u32 em[17];                                                // slot indices, in emission order (<= 1 + (w - 1) + 1)
+		if (slot && ts >= T0) {
+			u32 m = ts - 1;
+			for (u32 u = 2; u <= (u32)w; ++u) if (V[ts - u] < V[m]) m = ts - u;          // the newest minimal slot of [ts - w, ts - 1]
+			if (x <= V[m]) em[ne++] = m;
+			else if (m == ts - (u32)w) {
+				em[ne++] = m;
+				u32 m2 = ts;
+				for (u32 u = 1; u < (u32)w; ++u) if (V[ts - u] < V[m2]) m2 = ts - u;       // the newest minimal slot of [ts - w + 1, ts]
+				for (u32 u = ts - (u32)w + 1; u <= ts; ++u) if (u != m2 && V[u] == V[m2]) em[ne++] = u;
+			}
+			if (ts == T - 1 && pos1 >= len) {                         // the read's last step: its window's minimum follows
+				u32 m2 = ts;
+				if (x <= V[m]) m2 = ts;                                 // (after the step the minimum is the new slot ...)
+				else if (m == ts - (u32)w) { for (u32 u = 1; u < (u32)w; ++u) if (V[ts - u] < V[m2]) m2 = ts - u; }   // (... the rescanned one ...)
+				else m2 = m;                                            // (... or the old one)
+				em[ne++] = m2;
+			}
+		}
+		// ranks of the emissions in position order
+		u32 inc2 = ne;
+		for (int d = 1; d < 64; d <<= 1) { const u32 o = __shfl_up(inc2, d); if ((int)lane >= d) inc2 += o; }
+		if (lane == 63) wsum2[wv] = inc2;
+		__syncthreads();
+		u32 at = inc2 - ne, tot = 0;
+		for (u32 q = 0; q < LQ_DP_THREADS / 64; ++q) { if (q < wv) at += wsum2[q]; tot += wsum2[q]; }
+		if (EMIT) {
+			const u64 y_hi = rid_in_y ? (u64)r << 32 : 0;
+			for (u32 e = 0; e < ne; ++e) { out_x[off[g] + at + e] = V[em[e]]; out_y[off[g] + at + e] = y_hi | Y[em[e]]; }
+		} else if (t == 0) cnt[g] = tot;
+		__syncthreads();
 	}
 }
 
