@@ -87,6 +87,19 @@ def test_emulated_sketch_equals_mm_sketch_fixture(emu_lib, name, k, w, hpc, fn):
     eng.close()
 
 
+@pytest.mark.parametrize("name,k,w,fn", [("tiny_sketch_k12w5", 12, 5, "tiny_sub.fq.gz"), ("adv_sketch_k12w5", 12, 5, "adv_sub.fq.gz"), ("adv_sketch_k19w10", 19, 10, "adv_sub.fq.gz")])
+def test_emulated_data_parallel_sketch(emu_lib, monkeypatch, name, k, w, fn):
+    """LQCOV_SKETCH=dp: chunks inside N-free stretches away from the read start decided by k_sketch_dp (sliding-window minimum
+    over the non-palindromic positions with minimap2's tie rules), the rest by the state machine: the reference's list"""
+    monkeypatch.setenv("LQCOV_SKETCH", "dp")
+    test_emulated_sketch_equals_mm_sketch_fixture(emu_lib, name, k, w, 0, fn)
+
+
+def test_emulated_data_parallel_sketch_adversarial(emu_lib, monkeypatch):
+    monkeypatch.setenv("LQCOV_SKETCH", "dp")
+    test_emulated_sketch_halo_adversarial(emu_lib)
+
+
 def test_emulated_sketch_halo_adversarial(emu_lib):
     """palindromic / N-rich / homopolymer contexts around every chunk boundary: the warm-up must widen its halo"""
     rng = np.random.default_rng(5)
