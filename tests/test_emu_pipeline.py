@@ -100,6 +100,41 @@ def test_emulated_data_parallel_sketch_adversarial(emu_lib, monkeypatch):
     test_emulated_sketch_halo_adversarial(emu_lib)
 
 
+def test_emulated_data_parallel_sketch_fuzz(emu_lib, monkeypatch):
+    """random reads with sparse Ns, AT stretches (palindromic k-mers), short-period repeats and tandem copies (ties), a
+    two-letter alphabet; random (k, w): the data-parallel kernel and the state machine give the same list"""
+    A = np.frombuffer(b"ACGT", dtype=np.uint8)
+    for it in range(10):
+        rng = np.random.default_rng(100 + it)
+        k = int(rng.choice([4, 6, 10, 12, 15, 19, 24, 28])); w = int(rng.choice([1, 2, 3, 5, 10, 16]))
+        seqs = []
+        for _ in range(6):
+            L = int(rng.integers(130, 3000))
+            s = A[rng.integers(0, 4, L)].copy()
+            mode = int(rng.integers(0, 6))
+            if mode == 1:
+                s[rng.integers(0, L, max(1, L // 300))] = ord("N")
+            elif mode == 2:
+                a = int(rng.integers(0, L - 100)); n = int(rng.integers(20, 100)); s[a:a + n] = np.frombuffer((b"AT" * 60)[:n], np.uint8)
+            elif mode == 3:
+                u = int(rng.integers(1, 7)); a = int(rng.integers(0, L - 120)); s[a:a + 120] = np.tile(s[a:a + u], 120 // u + 1)[:120]
+            elif mode == 4:
+                s = np.frombuffer(b"AC", np.uint8)[rng.integers(0, 2, L)].copy()
+            elif mode == 5:
+                a = int(rng.integers(0, L - 125)); s[a:a + 120] = np.tile(s[a:a + 40], 3)
+            seqs.append(s)
+        names = ["s%d" % i for i in range(len(seqs))]
+        res = []
+        for mode in ("machine", "dp"):
+            monkeypatch.setenv("LQCOV_SKETCH", mode)
+            eng = _engine(emu_lib, k=k, w=w, hpc=0, min_score_med=40, min_score_good=40)
+            eng.set_queries(names, seqs, None)
+            xy, off = eng.query_minimizers()
+            res.append((np.array(xy).copy(), np.array(off).copy()))
+            eng.close()
+        assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1]), (it, k, w)
+
+
 def test_emulated_sketch_halo_adversarial(emu_lib):
     """palindromic / N-rich / homopolymer contexts around every chunk boundary: the warm-up must widen its halo"""
     rng = np.random.default_rng(5)
