@@ -160,10 +160,6 @@ int lqcov_parse_args(int argc, const char *const *argv, lqcov_params *p, const c
 
 lqcov_handle *lqcov_create(const lqcov_params *p, int device)
 {
-	// HIP multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and kernels of streams that share a queue
-	// run one after the other: the mapping lanes (2 streams each) need their own.  Only effective when the HIP runtime has
-	// not started yet in this process (the CLI, LongQC's exec); hosts that initialise HIP first set it themselves (bench.py).
-	if (getenv("LQCOV_HW_QUEUES")) setenv("GPU_MAX_HW_QUEUES", getenv("LQCOV_HW_QUEUES"), 0);
 	try { return new lqcov_handle(*p, device); }
 	catch (const std::exception &e) { g_create_error = e.what(); fprintf(stderr, "lqcov_create: %s\n", e.what()); return nullptr; }
 }
@@ -272,6 +268,11 @@ int lqcov_sync(lqcov_handle *h) { return guard(h, [&] { LQ_HIP_CHECK(hipStreamSy
 int lqcov_workspace_trim(lqcov_handle *h)
 {
 	return guard(h, [&] {
+		LQ_HIP_CHECK(hipDeviceSynchronize());
+		// the lanes' work space (sized for ~80 % of the free HBM at the first batch) is held in grow-only buffers: hand it back,
+		// then the blocks the stream-ordered pool has cached.  Everything regrows on the next part_map.
+		for (auto &L : h->lanes) L->release_buffers();
+		for (DBuf *b : { &h->ix_key, &h->ix_key2, &h->ix_head, &h->ix_uidx, &h->ix_sorted }) b->release();
 		LQ_HIP_CHECK(hipDeviceSynchronize());
 #ifndef LQ_EMU
 		hipMemPool_t pool = nullptr;

@@ -73,6 +73,28 @@ void lqcov_handle::add_stage_bytes(const char *name, u64 bytes)
 }
 
 // ---- handle ---------------------------------------------------------------------------------
+void Knobs::read_env()
+{
+	auto num = [](const char *name, long dflt) { const char *e = getenv(name); return e && *e ? atol(e) : dflt; };
+	auto is = [](const char *name, const char *val) { const char *e = getenv(name); return e && !strcmp(e, val); };
+	lanes = (int)std::min<long>(8, std::max<long>(1, num("LQCOV_LANES", 4)));
+	anchor_budget = getenv("LQCOV_ANCHOR_BUDGET") ? strtoull(getenv("LQCOV_ANCHOR_BUDGET"), 0, 10) : 0;
+	query_order_file = is("LQCOV_QUERY_ORDER", "file");
+	all_klib = is("LQCOV_SORT", "klib");
+	ps_shift = (u32)std::min<long>(12, std::max<long>(0, num("LQCOV_PS_SHIFT", 0)));
+	reg_walker = !is("LQCOV_WALK", "solo");
+	ckpt = !is("LQCOV_CKPT", "0");
+	ckpt3 = num("LQCOV_CKPT3", 0) > 0;
+	sort_tile = (u32)std::max<long>(0, num("LQCOV_SORT_TILE", 0)); if (sort_tile && sort_tile < 64) sort_tile = 64;
+	walk_shift = (u32)std::min<long>(16, std::max<long>(0, num("LQCOV_WALK_SHIFT", 0)));
+	walk_grid = (u32)std::max<long>(64, num("LQCOV_WALK_GRID", 1L << 18));
+	chain_wave_min = (int)std::max<long>(0, num("LQCOV_CHAIN_WAVE_MIN", 0));
+	chain_cap = (int)num("LQCOV_CHAIN_CAP", 128);
+	no_level_skip = getenv("LQCOV_NO_LEVEL_SKIP") != nullptr;
+	debug_sort = getenv("LQCOV_DEBUG_SORT") != nullptr;
+	sketch_kpt = (u32)std::min<long>(64, std::max<long>(1, num("LQCOV_SKETCH_KPT", 4)));
+}
+
 lqcov_handle::lqcov_handle(const lqcov_params &p, int dev) : P(p), device(dev)
 {
 	if (P.k < 1 || P.k > 28 || P.w < 1 || P.w > 255) throw std::invalid_argument("k must be in [1,28] and w in [1,255] (sketch.c:83)");
@@ -90,16 +112,15 @@ lqcov_handle::lqcov_handle(const lqcov_params &p, int dev) : P(p), device(dev)
 	mp.min_sc_med = P.min_score_med; mp.min_sc_good = P.min_score_good;
 	mp.max_overhang = P.max_overhang; mp.min_coverage = P.min_coverage; mp.min_ratio = P.min_ratio;
 	mp.no_self = P.no_self; mp.ava = P.ava;
-	const char *e = getenv("LQCOV_ANCHOR_BUDGET");
-	anchor_budget = e ? strtoull(e, 0, 10) : 0;
-	const char *el = getenv("LQCOV_LANES");
-	n_lanes = el ? std::min(8, std::max(1, atoi(el))) : 4;   // measured at configs[2] (round 2): 2 lanes 2.23 s per step, 3: 2.05, 4: 1.82, 6: 1.88
+	K.read_env();
+	anchor_budget = K.anchor_budget;
+	n_lanes = K.lanes;
 	if (anchor_budget == 0) {
 		size_t fr = 0, tot = 0;
 		hipMemGetInfo(&fr, &tot);
-		anchor_budget = (u64)(fr / 5 * 4 / 104 / n_lanes);  // ~61 B of work space per anchor + per-sub-array tables, 80% of free HBM
+		anchor_budget = (u64)(fr / 5 * 4 / 112 / n_lanes);  // ~86 B of work space per anchor + per-sub-array tables, 80% of free HBM
 	}
-	if (anchor_budget > (1ULL << 31)) anchor_budget = 1ULL << 31;
+	if (anchor_budget > (1ULL << 31) - 4096) anchor_budget = (1ULL << 31) - 4096;   // (a record names its anchor in 31 bits)
 	if (anchor_budget < 1024) anchor_budget = 1024;
 }
 
@@ -279,7 +300,7 @@ void lqcov_handle::sketch(ReadSetDev &rs, bool rid_in_y)
 		const u64 in_bytes = nc * (LQ_CHUNK_WORDS * 12);
 		// ring capacity 8 / 16 (LDS) or 256 (private), -H on/off: pick the instantiation
 		// chunks per thread: the halo before a thread's first chunk is walked once per kpt chunks (LQCOV_SKETCH_KPT=1: every chunk its own thread, as measured in round 2)
-		const u32 kpt = getenv("LQCOV_SKETCH_KPT") ? (u32)std::min(64, std::max(1, atoi(getenv("LQCOV_SKETCH_KPT")))) : 4;
+		const u32 kpt = K.sketch_kpt;
 #define LQ_SK_LAUNCH(RC, EM, HP, BS, ...) LQ_LAUNCH((k_sketch<RC, EM, HP>), nblk((nc + kpt - 1) / kpt, BS), BS, stream, rs.codes.as<u64>(), rs.amb.as<u32>(), rs.d_coff.as<u64>(), rs.d_len.as<u32>(), rs.n, nc, kpt, sp, (int)rid_in_y, __VA_ARGS__, dp_owned)
 #define LQ_SK_DISPATCH(EM, ...) do { \
 		if (P.w <= 8)       { if (P.hpc) LQ_SK_LAUNCH(8, EM, true, LQ_SK_BLOCK, __VA_ARGS__);   else LQ_SK_LAUNCH(8, EM, false, LQ_SK_BLOCK, __VA_ARGS__); } \
@@ -368,7 +389,7 @@ void lqcov_handle::set_queries(u32 n, const u8 *seq_in, const u64 *seq_off_in, c
 	// internal order: longest first (stable); LQCOV_QUERY_ORDER=file keeps the caller's order (A/B and test knob)
 	q_perm.resize(n); q_inv.resize(n);
 	for (u32 i = 0; i < n; ++i) q_perm[i] = i;
-	if (!(getenv("LQCOV_QUERY_ORDER") && !strcmp(getenv("LQCOV_QUERY_ORDER"), "file")))
+	if (!K.query_order_file)
 		std::stable_sort(q_perm.begin(), q_perm.end(), [&](u32 a, u32 b) { return seq_off_in[a + 1] - seq_off_in[a] > seq_off_in[b + 1] - seq_off_in[b]; });
 	for (u32 i = 0; i < n; ++i) q_inv[q_perm[i]] = i;
 	std::vector<u8> pseq, pqual;
@@ -548,29 +569,27 @@ void lqcov_handle::map_batch(MapLane &L, Part &pt, u32 q0, u32 q1, const std::ve
 	if (nA > 0xfffffff0ULL) throw std::domain_error("a single query produces more than 2^32 anchors against this part");
 	L.A.ensure((nA + 1) * 16); L.B.ensure((nA + 1) * 16);
 	mm128 *dA = L.A.as<mm128>(), *dB = L.B.as<mm128>();
-	// 20 B per anchor of scratch with two lives: the X / Y position lists of the two-bucket passes during the sort, then the
-	// run heads / ids and the chain's u[] afterwards.  The chain's f/p/t/v (16 B per anchor) reuse B, which is dead once sorted.
+	// 20 B per anchor of scratch: the X / Y position lists of the two-bucket passes (8 B) and the second record array (8 B, in
+	// the place of the chain's u[]) during the sort.  The chain's f/p/t/v (16 B per anchor) reuse B, which is dead once sorted.
 	const u64 nA4 = ((nA + 1) * 4 + 15) & ~(u64)15;
 	L.scr.ensure(nA4 * 5 + 64);
-	u32 *hx = (u32*)L.scr.p, *py = (u32*)((u8*)L.scr.p + nA4);
-	u32 *d_head = (u32*)L.scr.p; u64 *d_gid = (u64*)((u8*)L.scr.p + nA4), *d_cu = (u64*)((u8*)L.scr.p + 3 * nA4);
+	u64 *d_cu = (u64*)((u8*)L.scr.p + 3 * nA4);
 	i32 *d_cf = (i32*)L.B.p, *d_cp = (i32*)((u8*)L.B.p + nA4), *d_ct = (i32*)((u8*)L.B.p + 2 * nA4), *d_cv = (i32*)((u8*)L.B.p + 3 * nA4);
 	if (nj) {
 		StageTimer t(this, L.stream, "k_seed_emit", nj * 32 + nA * 24);
 		LQ_LAUNCH(k_seed_emit, nblk(nj, LQ_EMIT_THREADS), LQ_EMIT_THREADS, L.stream, q.mx.as<u64>(), q.my.as<u64>(), q_owner.as<u32>(), q.moff.as<u64>(), j0, nj,
 		          pt.pos.as<u64>(), hit_start.as<u64>(), hit_n.as<u32>(), keep.as<u32>(), dup.as<u32>(),
 		          a_off.as<u64>(), a_base, mp_off.as<u64>(), q.d_len.as<u32>(),
-		          (int)P.no_self, pt.self_off.as<u32>(), pt.self_rid.as<u32>(), AvaView{P.ava ? pt.t_rank.as<u32>() : nullptr, P.ava ? pt.q_lo.as<u32>() : nullptr}, dA, mini_pos.as<u64>());
+		          (int)P.no_self, pt.self_off.as<u32>(), pt.self_rid.as<u32>(), AvaView{P.ava ? pt.t_rank.as<u32>() : nullptr, P.ava ? pt.q_lo.as<u32>() : nullptr},
+		          qklib.as<u32>(), dA, dB, mini_pos.as<u64>());
 		check_launch();
 	}
 	if (nA) {
 		const u64 *aqb = aq_off.as<u64>() + q0;          // batch view of the per-query anchor offsets
 		sort_batch(L, pt, q0, nqb, a_base, nA);           // lqmap.c:238
 		// ---- (strand, rid) runs ----
-		// (LQCOV_RUNS=scan: the head / id arrays and library scans of round 1, kept for one round of A/B)
-		const bool runs_two_pass = !(getenv("LQCOV_RUNS") && !strcmp(getenv("LQCOV_RUNS"), "scan"));
 		u64 n_groups = 0;
-		if (runs_two_pass) {
+		{
 			const u32 n_tiles = (u32)((nA + LQ_RUN_TILE - 1) / LQ_RUN_TILE);
 			L.run_tiles.ensure(((u64)n_tiles + 2) * 4);
 			u32 *tiles = L.run_tiles.as<u32>();
@@ -586,16 +605,6 @@ void lqcov_handle::map_batch(MapLane &L, Part &pt, u32 q0, u32 q1, const std::ve
 			L.gstart.ensure((n_groups + 1) * 8);
 			StageTimer t(this, L.stream, "k_run_starts", nA * 16 + n_groups * 8);
 			LQ_LAUNCH(k_run_starts, g, LQ_RUN_THREADS, L.stream, dA, nA, aqb, a_base, nqb, n_tiles, tiles, L.gstart.as<u64>()); check_launch();
-		} else {
-			dzero(d_head, nA * 4, L.stream);
-			LQ_LAUNCH(k_mark_qstart, nblk(nqb, 256), 256, L.stream, aqb, a_base, nqb, d_head); check_launch();
-			LQ_LAUNCH(k_group_heads, nblk(nA, 256), 256, L.stream, dA, nA, d_head); check_launch();
-			L.prim.exclusive_scan_u32_u64(d_head, d_gid, nA);
-			u64 lg = 0; u32 lh = 0;
-			d2h(&lg, d_gid + nA - 1, 1, L.stream); d2h(&lh, d_head + nA - 1, 1, L.stream);
-			n_groups = lg + lh;
-			L.gstart.ensure((n_groups + 1) * 8);
-			LQ_LAUNCH(k_group_starts, nblk(nA, 256), 256, L.stream, d_head, d_gid, nA, n_groups, L.gstart.as<u64>()); check_launch();
 		}
 		// ---- chain + coverage ----
 		const u32 ivl_cap = (u32)std::min<u64>(nA / (P.min_cnt > 0 ? P.min_cnt : 1) + 16, 0xfffffff0ULL);
@@ -609,60 +618,30 @@ void lqcov_handle::map_batch(MapLane &L, Part &pt, u32 q0, u32 q1, const std::ve
 		cs.ivl = L.ivl.as<Ivl>(); cs.n_ivl = L.n_ivl.as<u32>(); cs.ivl_cap = ivl_cap;
 		cs.dbg = dbg ? dbg_chains.as<ChainRec>() : nullptr; cs.n_dbg = n_dbg.as<unsigned long long>(); cs.dbg_cap = dbg_cap;
 		if (n_groups > 0xfffffff0ULL) throw std::domain_error("too many anchor runs in one batch");
-		const int cap_env = getenv("LQCOV_CHAIN_CAP") ? atoi(getenv("LQCOV_CHAIN_CAP")) : 128;   // A/B + test knob: anchors of LDS per wave in k_chain
-		const int cap = cap_env <= 64 ? 64 : cap_env <= 128 ? 128 : 256;
+		const int cap = K.chain_cap <= 64 ? 64 : K.chain_cap <= 128 ? 128 : 256;   // anchors of LDS per wave in k_chain
 		// runs of >= wave_min anchors take the cooperative kernel; a run must fit k_chain's LDS budget on its own
-		const int wave_min = std::min(cap + 1, getenv("LQCOV_CHAIN_WAVE_MIN") ? std::max(1, atoi(getenv("LQCOV_CHAIN_WAVE_MIN"))) : LQ_CHAIN_WAVE_MIN);   // test knob
-		{	// one thread per run, in array order, DP state of a wave's runs packed into LDS (in rounds if they exceed the budget).
-			// Measured alternatives that were slower on MI355X: a compacted longest-first work list for all runs (409 vs 292 ms at
-			// configs[1]), private-array DP for short runs, and a fixed [16][64] LDS column per lane (54 KiB per wave: 160 + 40 ms
-			// vs 113 ms).  wave_min - 1 <= 47 < the smallest budget, so every run fits.
-			// LQCOV_CHAIN_COMPACT=1 (to be measured): the runs of min_cnt .. wave_min - 1 anchors as a dense list in array order --
-			// most runs are shorter, and their lanes idle through the DP of the few that are not
-			const u32 *small_list = nullptr;
-			u32 n_small = (u32)n_groups;
-			if (runs_two_pass && getenv("LQCOV_CHAIN_COMPACT") && atoi(getenv("LQCOV_CHAIN_COMPACT")) > 0 && wave_min - 1 >= (int)P.min_cnt) {
-				const u32 n_tiles = (u32)((n_groups + LQ_RUN_TILE - 1) / LQ_RUN_TILE);
-				L.sel_tiles.ensure(((u64)n_tiles + 2) * 4);
-				LQ_LAUNCH(k_sel_count, std::min<u32>(std::max<u32>(n_tiles, 1), 1u << 16), LQ_RUN_THREADS, L.stream, L.gstart.as<u64>(), n_groups, (i32)P.min_cnt, (i32)(wave_min - 1), n_tiles, L.sel_tiles.as<u32>()); check_launch();
-				LQ_LAUNCH(k_tile_scan, 1, LQ_TSCAN_THREADS, L.stream, L.sel_tiles.as<u32>(), n_tiles); check_launch();
-				d2h(&n_small, L.sel_tiles.as<u32>() + n_tiles, 1, L.stream);
-				L.gsmall.ensure((u64)n_small * 4 + 4);
-				if (n_small) { LQ_LAUNCH(k_sel_write, std::min<u32>(n_tiles, 1u << 16), LQ_RUN_THREADS, L.stream, L.gstart.as<u64>(), n_groups, (i32)P.min_cnt, (i32)(wave_min - 1), n_tiles, L.sel_tiles.as<u32>(), L.gsmall.as<u32>(), (u32*)nullptr); check_launch(); }
-				small_list = L.gsmall.as<u32>();
-			}
-			if (n_small) {
-				StageTimer t(this, L.stream, "k_chain", nA * 16);
-#define LQ_CHAIN_LAUNCH(CAP) LQ_LAUNCH((k_chain<CAP>), nblk(n_small, 64), 64, L.stream, dA, L.gstart.as<u64>(), small_list, n_small, aqb, a_base, nqb, q0, avg_qspan.as<float>(), mp, cs, (i32)P.min_cnt, (i32)(wave_min - 1))
-				if (cap == 64) { LQ_CHAIN_LAUNCH(64); } else if (cap == 128) { LQ_CHAIN_LAUNCH(128); } else { LQ_CHAIN_LAUNCH(256); }
+		const int wave_min = std::min(cap + 1, K.chain_wave_min > 0 ? K.chain_wave_min : LQ_CHAIN_WAVE_MIN);
+		if (n_groups) {	// one thread per run, in array order, DP state of a wave's runs packed into LDS (in rounds if they exceed the budget).
+			// Measured alternatives that were not faster on MI355X: a compacted longest-first work list for all runs (409 vs 292 ms at
+			// configs[1]), a dense list in array order of the runs of min_cnt..47 anchors (configs[2]: within the run-to-run spread),
+			// private-array DP for short runs, and a fixed [16][64] LDS column per lane (54 KiB per wave: 160 + 40 ms vs 113 ms).
+			// wave_min - 1 <= 47 < the smallest budget, so every run fits.
+			StageTimer t(this, L.stream, "k_chain", nA * 16);
+#define LQ_CHAIN_LAUNCH(CAP) LQ_LAUNCH((k_chain<CAP>), nblk(n_groups, 64), 64, L.stream, dA, L.gstart.as<u64>(), (const u32*)nullptr, (u32)n_groups, aqb, a_base, nqb, q0, avg_qspan.as<float>(), mp, cs, (i32)P.min_cnt, (i32)(wave_min - 1))
+			if (cap == 64) { LQ_CHAIN_LAUNCH(64); } else if (cap == 128) { LQ_CHAIN_LAUNCH(128); } else { LQ_CHAIN_LAUNCH(256); }
 #undef LQ_CHAIN_LAUNCH
-				check_launch();
-			}
+			check_launch();
 		}
-		{	// long runs (the tail of the kernel above if left there): one wave per run, longest first
+		{	// long runs: one wave per run, longest first
 			u32 n_sel = 0;
-			if (runs_two_pass) {
-				const u32 n_tiles = (u32)((n_groups + LQ_RUN_TILE - 1) / LQ_RUN_TILE);
-				L.sel_tiles.ensure(((u64)n_tiles + 2) * 4);
-				LQ_LAUNCH(k_sel_count, std::min<u32>(std::max<u32>(n_tiles, 1), 1u << 16), LQ_RUN_THREADS, L.stream, L.gstart.as<u64>(), n_groups, (i32)wave_min, (i32)0x7fffffff, n_tiles, L.sel_tiles.as<u32>()); check_launch();
-				LQ_LAUNCH(k_tile_scan, 1, LQ_TSCAN_THREADS, L.stream, L.sel_tiles.as<u32>(), n_tiles); check_launch();
-				d2h(&n_sel, L.sel_tiles.as<u32>() + n_tiles, 1, L.stream);
-			} else {
-				L.gflag.ensure(n_groups * 4 + 4); L.gidx.ensure(n_groups * 4 + 4);
-				LQ_LAUNCH(k_group_flags, nblk(n_groups, 256), 256, L.stream, L.gstart.as<u64>(), n_groups, (i32)wave_min, L.gflag.as<u32>()); check_launch();
-				L.prim.exclusive_scan_u32_u32(L.gflag.as<u32>(), L.gidx.as<u32>(), n_groups);
-				u32 lgi = 0, lgf = 0;
-				d2h(&lgi, L.gidx.as<u32>() + n_groups - 1, 1, L.stream); d2h(&lgf, L.gflag.as<u32>() + n_groups - 1, 1, L.stream);
-				n_sel = lgi + lgf;
-			}
+			const u32 n_tiles = (u32)((n_groups + LQ_RUN_TILE - 1) / LQ_RUN_TILE);
+			L.sel_tiles.ensure(((u64)n_tiles + 2) * 4);
+			LQ_LAUNCH(k_sel_count, std::min<u32>(std::max<u32>(n_tiles, 1), 1u << 16), LQ_RUN_THREADS, L.stream, L.gstart.as<u64>(), n_groups, (i32)wave_min, (i32)0x7fffffff, n_tiles, L.sel_tiles.as<u32>()); check_launch();
+			LQ_LAUNCH(k_tile_scan, 1, LQ_TSCAN_THREADS, L.stream, L.sel_tiles.as<u32>(), n_tiles); check_launch();
+			d2h(&n_sel, L.sel_tiles.as<u32>() + n_tiles, 1, L.stream);
 			if (n_sel) {
 				L.gsel.ensure((u64)n_sel * 4); L.gkey.ensure((u64)n_sel * 4); L.gsel2.ensure((u64)n_sel * 4); L.gkey2.ensure((u64)n_sel * 4);
-				if (runs_two_pass) {
-					const u32 n_tiles = (u32)((n_groups + LQ_RUN_TILE - 1) / LQ_RUN_TILE);
-					LQ_LAUNCH(k_sel_write, std::min<u32>(n_tiles, 1u << 16), LQ_RUN_THREADS, L.stream, L.gstart.as<u64>(), n_groups, (i32)wave_min, (i32)0x7fffffff, n_tiles, L.sel_tiles.as<u32>(), L.gsel.as<u32>(), L.gkey.as<u32>()); check_launch();
-				} else {
-					LQ_LAUNCH(k_group_compact, nblk(n_groups, 256), 256, L.stream, L.gstart.as<u64>(), L.gflag.as<u32>(), L.gidx.as<u32>(), n_groups, L.gsel.as<u32>(), L.gkey.as<u32>()); check_launch();
-				}
+				LQ_LAUNCH(k_sel_write, std::min<u32>(n_tiles, 1u << 16), LQ_RUN_THREADS, L.stream, L.gstart.as<u64>(), n_groups, (i32)wave_min, (i32)0x7fffffff, n_tiles, L.sel_tiles.as<u32>(), L.gsel.as<u32>(), L.gkey.as<u32>()); check_launch();
 				L.prim.sort_pairs_u32_u32(L.gkey.as<u32>(), L.gkey2.as<u32>(), L.gsel.as<u32>(), L.gsel2.as<u32>(), n_sel);
 				StageTimer t(this, L.stream, "k_chain_wave", nA * 16);
 				LQ_LAUNCH(k_chain_wave, n_sel, 64, L.stream, dA, L.gstart.as<u64>(), L.gsel2.as<u32>(), n_sel, aqb, a_base, nqb, q0, avg_qspan.as<float>(), mp, cb, cs);
@@ -700,82 +679,117 @@ void lqcov_handle::map_batch(MapLane &L, Part &pt, u32 q0, u32 q1, const std::ve
 	}
 }
 
-static u32 ps_shift() { const char *e = getenv("LQCOV_PS_SHIFT"); return e ? (u32)std::min(12, std::max(0, atoi(e))) : 0; }   // test knob: shrinks the size classes of the parallel sort
-
-static PsLists ps_lists(MapLane &L, int set)
+static PsLists ps_lists(MapLane &L, int set, u32 sh)
 {
 	PsWork &W = L.ps[set];
 	PsLists Ls;
 	Ls.big[0] = W.big[0].as<PSeg>(); Ls.big[1] = W.big[1].as<PSeg>(); Ls.fin_s = W.fin_s.as<PSeg>(); Ls.fin_b = W.fin_b.as<PSeg>();
 	Ls.cnt = L.sort_cnt.as<u32>() + (set ? LQ_C_PS1 : LQ_C_PS0);
 	Ls.cap_big = (u32)std::min<u64>(W.big[0].cap / sizeof(PSeg), 0xfffffff0ULL); Ls.cap_fin = (u32)std::min<u64>(W.fin_s.cap / sizeof(PSeg), 0xfffffff0ULL);
-	const u32 sh = ps_shift();
 	Ls.fin_s_max = std::max<u32>(LQ_PS_FIN_SMALL >> sh, 2); Ls.fin_b_max = std::max<u32>(LQ_PS_FIN_BIG >> sh, 4); Ls.child_target = std::max<u32>(LQ_PS_CHILD >> sh, 2);
 	return Ls;
 }
 
-// The parallel sort of the segments of one list set (kernels_psort.hpp): partition passes while segments above the
-// LDS capacity remain, then the two finishing kernels.  Everything is sized by upper bounds and strides over device-side
-// counts: no host round trip.
-void lqcov_handle::psort_run(MapLane &L, int set, hipStream_t s, u64 nA, const KeyMap &km)
+// one partition pass over the big list in slot `cur` of a set (kernels_psort.hpp); the children go to the other slot and the finishing lists
+static void ps_pass(lqcov_handle *h, MapLane &L, int set, hipStream_t s, u64 nA, const KeyMap &km, const PsData &pd, u32 cur)
 {
 	PsWork &W = L.ps[set];
 	u32 *cnt = L.sort_cnt.as<u32>() + (set ? LQ_C_PS1 : LQ_C_PS0);
-	const PsLists Ls = ps_lists(L, set);
+	const PsLists Ls = ps_lists(L, set, h->K.ps_shift);
 	const u32 cap_cnt = (u32)std::min<u64>(W.gcnt.cap / 4, 0xfffffff0ULL);
 	const u32 g_tiles = (u32)std::min<u64>((nA + LQ_PS_TILE - 1) / LQ_PS_TILE + 1, 16384);
 	const u32 g_segs = (u32)std::min<u64>(Ls.cap_big, 4096);
-	mm128 *dA = L.A.as<mm128>(), *dB = L.B.as<mm128>();
-	const int max_pass = ps_shift() ? 16 : 6;
-	for (int pass = 0; pass < max_pass; ++pass) {
-		const u32 cur = pass & 1, nxt = cur ^ 1;
-		dzero(cnt + (nxt ? LQ_P_BIG1 : LQ_P_BIG0), 4, s);
-		LQ_LAUNCH(k_ps_plan, 1, 256, s, Ls.big[cur], cnt + (cur ? LQ_P_BIG1 : LQ_P_BIG0), W.plan.as<PPlan>(), cnt, cap_cnt, Ls.child_target); check_launch();
-		dzero(W.gcnt.p, (size_t)cap_cnt * 4, s);
-		{
-			StageTimer t(this, s, "k_ps_hist");
-			LQ_LAUNCH(k_ps_hist, g_tiles, LQ_PS_THREADS, s, Ls.big[cur], cnt + (cur ? LQ_P_BIG1 : LQ_P_BIG0), W.plan.as<PPlan>(), cnt, dA, dB, km, W.gcnt.as<u32>()); check_launch();
-		}
-		LQ_LAUNCH(k_ps_scan, g_segs, 256, s, Ls.big[cur], cnt + (cur ? LQ_P_BIG1 : LQ_P_BIG0), W.plan.as<PPlan>(), W.gcnt.as<u32>(), W.gcur.as<u32>(), Ls, (u32)(nxt ? LQ_P_BIG1 : LQ_P_BIG0),
-		          (unsigned long long*)(L.sort_cnt.as<u32>() + (set ? LQ_C_PART1 : LQ_C_PART0))); check_launch();
-		{
-			StageTimer t(this, s, "k_ps_scatter");
-			LQ_LAUNCH(k_ps_scatter, g_tiles, LQ_PS_THREADS, s, Ls.big[cur], cnt + (cur ? LQ_P_BIG1 : LQ_P_BIG0), W.plan.as<PPlan>(), cnt, dA, dB, km, W.gcur.as<u32>()); check_launch();
-		}
+	const u32 nxt = cur ^ 1;
+	dzero(cnt + (nxt ? LQ_P_BIG1 : LQ_P_BIG0), 4, s);
+	LQ_LAUNCH(k_ps_plan, 1, 256, s, Ls.big[cur], cnt + (cur ? LQ_P_BIG1 : LQ_P_BIG0), W.plan.as<PPlan>(), cnt, cap_cnt, Ls.child_target); check_launch();
+	dzero(W.gcnt.p, (size_t)cap_cnt * 4, s);
+	dzero(W.gdiff.p, (size_t)Ls.cap_big * 8, s);
+	{
+		StageTimer t(h, s, "k_ps_hist");
+		LQ_LAUNCH(k_ps_hist, g_tiles, LQ_PS_THREADS, s, Ls.big[cur], cnt + (cur ? LQ_P_BIG1 : LQ_P_BIG0), W.plan.as<PPlan>(), cnt, pd, km, W.gcnt.as<u32>(), W.gdiff.as<unsigned long long>()); check_launch();
 	}
+	LQ_LAUNCH(k_ps_scan, g_segs, 256, s, Ls.big[cur], cnt + (cur ? LQ_P_BIG1 : LQ_P_BIG0), W.plan.as<PPlan>(), W.gcnt.as<u32>(), W.gcur.as<u32>(), W.gdiff.as<unsigned long long>(), Ls, (u32)(nxt ? LQ_P_BIG1 : LQ_P_BIG0),
+	          (unsigned long long*)(L.sort_cnt.as<u32>() + (set ? LQ_C_PART1 : LQ_C_PART0))); check_launch();
+	{
+		StageTimer t(h, s, "k_ps_scatter");
+		LQ_LAUNCH(k_ps_scatter, g_tiles, LQ_PS_THREADS, s, Ls.big[cur], cnt + (cur ? LQ_P_BIG1 : LQ_P_BIG0), W.plan.as<PPlan>(), cnt, pd, km, W.gcur.as<u32>()); check_launch();
+	}
+}
+
+// the two finishing kernels over a set's finishing lists
+static void ps_finish(lqcov_handle *h, MapLane &L, int set, hipStream_t s, u64 nA, const KeyMap &km, const PsData &pd)
+{
+	u32 *cnt = L.sort_cnt.as<u32>() + (set ? LQ_C_PS1 : LQ_C_PS0);
+	const PsLists Ls = ps_lists(L, set, h->K.ps_shift);
 	const bool k32 = km.pbits + km.rbits + 1 <= 32 + 8;          // the key bits below the sub-bucket digit fit 32 bits (both kernels' digits are >= 8 bits)
 	{
-		StageTimer t(this, s, "k_ps_finish<8192>");
+		StageTimer t(h, s, "k_ps_finish<8192>");
 		unsigned long long *tl = (unsigned long long*)(L.sort_cnt.as<u32>() + (set ? LQ_C_FINB1 : LQ_C_FINB0));
 		const u32 g = (u32)std::min<u64>(std::min<u64>(Ls.cap_fin, nA / LQ_PS_FIN_SMALL + 64), 4096);
-		// block size (A/B knob): beside the other lanes' kernels a launch takes ~24 ms against ~2.4 ms alone, whatever the block size
-		const int ft = getenv("LQCOV_FIN_THREADS") ? atoi(getenv("LQCOV_FIN_THREADS")) : 1024;   // measured at configs[2], 4 lanes: 256 threads 2.40 s per step, 512: 2.25, 1024: 2.1-2.2
-		if (!k32) LQ_LAUNCH((k_ps_finish<LQ_PS_FIN_BIG, 1024, 10, u64>), g, 1024, s, Ls.fin_b, cnt + LQ_P_FIN_B, dA, dB, km, tl);
-		else if (ft >= 1024) LQ_LAUNCH((k_ps_finish<LQ_PS_FIN_BIG, 1024, 10, u32>), g, 1024, s, Ls.fin_b, cnt + LQ_P_FIN_B, dA, dB, km, tl);
-		else if (ft >= 512) LQ_LAUNCH((k_ps_finish<LQ_PS_FIN_BIG, 512, 10, u32>), g * 2, 512, s, Ls.fin_b, cnt + LQ_P_FIN_B, dA, dB, km, tl);
-		else LQ_LAUNCH((k_ps_finish<LQ_PS_FIN_BIG, 256, 10, u32>), g * 2, 256, s, Ls.fin_b, cnt + LQ_P_FIN_B, dA, dB, km, tl);
+		// 1024 threads (measured at configs[2], 4 lanes, round 2: 256-thread blocks 2.40 s per step, 512: 2.25, 1024: 2.1-2.2)
+		if (!k32) LQ_LAUNCH((k_ps_finish<LQ_PS_FIN_BIG, 1024, 10, u64>), g, 1024, s, Ls.fin_b, cnt + LQ_P_FIN_B, pd, km, tl);
+		else LQ_LAUNCH((k_ps_finish<LQ_PS_FIN_BIG, 1024, 10, u32>), g, 1024, s, Ls.fin_b, cnt + LQ_P_FIN_B, pd, km, tl);
 		check_launch();
 	}
 	{
-		StageTimer t(this, s, "k_ps_finish<1024>");
+		StageTimer t(h, s, "k_ps_finish<1024>");
 		unsigned long long *tl = (unsigned long long*)(L.sort_cnt.as<u32>() + (set ? LQ_C_FINS1 : LQ_C_FINS0));
 		const u32 g = (u32)std::min<u64>(std::min<u64>(Ls.cap_fin, nA / 16 + 256), 32768);
-		if (k32) LQ_LAUNCH((k_ps_finish<LQ_PS_FIN_SMALL, 256, 8, u32>), g, 256, s, Ls.fin_s, cnt + LQ_P_FIN_S, dA, dB, km, tl);
-		else LQ_LAUNCH((k_ps_finish<LQ_PS_FIN_SMALL, 256, 8, u64>), g, 256, s, Ls.fin_s, cnt + LQ_P_FIN_S, dA, dB, km, tl);
+		if (k32) LQ_LAUNCH((k_ps_finish<LQ_PS_FIN_SMALL, 256, 8, u32>), g, 256, s, Ls.fin_s, cnt + LQ_P_FIN_S, pd, km, tl);
+		else LQ_LAUNCH((k_ps_finish<LQ_PS_FIN_SMALL, 256, 8, u64>), g, 256, s, Ls.fin_s, cnt + LQ_P_FIN_S, pd, km, tl);
 		check_launch();
 	}
 }
 
+#define LQ_PS_PASSES 4           // partition passes issued without looking (an even number: the big list ends in slot 0); psort_tail does the rest
+
+// The parallel sort of the segments of one list set (kernels_psort.hpp): partition passes while segments above the
+// LDS capacity remain, then the two finishing kernels.  Everything is sized by upper bounds and strides over device-side
+// counts: no host round trip here; psort_tail() looks at the counters once at the end of the batch's sort.
+// Set 1 holds the buckets that left klib's passes: their anchors are still the originals in B, named by records.  Their
+// finishing lists and the first pass of their big segments read B and write A; only then may a pass use B as its other
+// buffer -- so set 1 finishes what is listed first, then runs the passes, then finishes the passes' children.
+void lqcov_handle::psort_run(MapLane &L, int set, hipStream_t s, u64 nA, const KeyMap &km, const PsData &pd)
+{
+	u32 *cnt = L.sort_cnt.as<u32>() + (set ? LQ_C_PS1 : LQ_C_PS0);
+	if (set == 1) {
+		ps_finish(this, L, set, s, nA, km, pd);
+		dzero(cnt + LQ_P_FIN_S, 8, s);                          // (LQ_P_FIN_S and LQ_P_FIN_B are neighbours)
+	}
+	for (u32 pass = 0; pass < LQ_PS_PASSES; ++pass) ps_pass(this, L, set, s, nA, km, pd, pass & 1);
+	ps_finish(this, L, set, s, nA, km, pd);
+}
+
+// Segments that are still above the LDS capacity after LQ_PS_PASSES passes (keys that agree in many leading bits take a
+// pass per few bits): more passes, two at a time, with a look at the counter in between.  Rare; any input ends here sorted.
+void lqcov_handle::psort_tail(MapLane &L, int set, hipStream_t s, u64 nA, const KeyMap &km, const PsData &pd)
+{
+	u32 *cnt = L.sort_cnt.as<u32>() + (set ? LQ_C_PS1 : LQ_C_PS0);
+	for (int round = 0; round < 40; ++round) {                  // (a pass that moves anything uses up at least one key bit)
+		u32 left = 0;
+		d2h(&left, cnt + LQ_P_BIG0, 1, s);
+		if (!left) return;
+		dzero(cnt + LQ_P_FIN_S, 8, s);
+		ps_pass(this, L, set, s, nA, km, pd, 0); ps_pass(this, L, set, s, nA, km, pd, 1);
+		ps_finish(this, L, set, s, nA, km, pd);
+		u32 ov = 0;
+		d2h(&ov, cnt + LQ_P_OVERFLOW, 1, s);
+		if (ov) throw std::runtime_error("parallel sort: list or counter space overflow");
+	}
+	throw std::logic_error("parallel sort: segments above the LDS capacity left after 84 passes");
+}
+
 // Sort every query's anchors by x, in klib's order wherever that order can be told apart (lqmap.c:238).
 //   * queries without repeated (hash, strand) minimizers hold no equal x: the parallel sort, on the lane's second stream;
-//   * the others go through klib's passes byte by byte (kernels_sort.hpp); buckets of a pass that received fewer than
-//     two marked anchors leave for the parallel sort as well (set 1, after the last pass).
+//   * the others (their anchors are in B, the originals) go through klib's passes byte by byte as 8-byte records
+//     (kernels_sort.hpp, kernels_rsort.hpp); buckets of a pass that received fewer than two marked anchors leave for the
+//     parallel sort as well (set 1, after the last pass), the others are written to A when they are finished.
 void lqcov_handle::sort_batch(MapLane &L, Part &pt, u32 q0, u32 nqb, u64 a_base, u64 nA)
 {
 	const u64 *aqb = aq_off.as<u64>() + q0;
 	mm128 *dA = L.A.as<mm128>(), *dB = L.B.as<mm128>();
 	hipStream_t sD = L.stream, sC = L.stream2;
-	const bool all_klib = getenv("LQCOV_SORT") && !strcmp(getenv("LQCOV_SORT"), "klib");   // A/B + test knob: every query through klib's passes
+	if (nA >= 0x7ffffff0ULL) throw std::domain_error("more than 2^31 anchors in one query batch");
 	// varying key bits of this part: x = strand:1 | rid:31 | position:32 (lqmap.c:190-196)
 	u32 max_len = 0;
 	for (u32 v : pt.rs.h_len) max_len = std::max(max_len, v);
@@ -783,7 +797,7 @@ void lqcov_handle::sort_batch(MapLane &L, Part &pt, u32 q0, u32 nqb, u64 a_base,
 	while (km.pbits < 32 && ((u64)1 << km.pbits) < (u64)max_len) ++km.pbits;
 	while (km.rbits < 31 && ((u64)1 << km.rbits) < (u64)pt.rs.n) ++km.rbits;
 	u32 const_levels = 0;                                    // key bytes that are zero in every anchor of this part
-	if (!getenv("LQCOV_NO_LEVEL_SKIP")) {
+	if (!K.no_level_skip) {
 		if (pt.rs.n <= (1u << 16)) const_levels |= 1u << 6;
 		if (pt.rs.n <= (1u << 8)) const_levels |= 1u << 5;
 		if (max_len <= (1u << 24)) const_levels |= 1u << 3;
@@ -792,7 +806,7 @@ void lqcov_handle::sort_batch(MapLane &L, Part &pt, u32 q0, u32 nqb, u64 a_base,
 	}
 	// list capacities: a segment in any list has more than 64 elements
 	const u64 max_segs = nA / (LQ_RS_MIN + 1) + nqb + 1;
-	const u64 cap_big = nA / ((LQ_PS_FIN_BIG >> ps_shift()) + 1) + nqb + 16;
+	const u64 cap_big = nA / ((LQ_PS_FIN_BIG >> K.ps_shift) + 1) + nqb + 16;
 	L.sort_cnt.ensure(LQ_C_N * 4);
 	for (int set = 0; set < 2; ++set) {
 		PsWork &W = L.ps[set];
@@ -802,58 +816,58 @@ void lqcov_handle::sort_batch(MapLane &L, Part &pt, u32 q0, u32 nqb, u64 a_base,
 		const u64 cap_fin = max_segs + 512 * cap_big;
 		W.fin_s.ensure(cap_fin * sizeof(PSeg)); W.fin_b.ensure(cap_fin * sizeof(PSeg));
 		W.gcnt.ensure(cap_big * 256 * 4); W.gcur.ensure(cap_big * 256 * 4);
+		W.gdiff.ensure(W.big[0].cap / sizeof(PSeg) * 8 + 8);   // (one word per entry the big list can hold)
 	}
 	L.segs0.ensure(max_segs * sizeof(SortSeg)); L.segs1.ensure(max_segs * sizeof(SortSeg));
 	dzero(L.sort_cnt.p, LQ_C_N * 4, sD);
-	auto lists = [&](int set) { return ps_lists(L, set); };
+	auto lists = [&](int set) { return ps_lists(L, set, K.ps_shift); };
 	u32 *cnt = L.sort_cnt.as<u32>();
+	// records: R0 of its own, R1 in the part of the scratch area that is only used after the sort (map_batch)
+	const u64 nA4 = ((nA + 1) * 4 + 15) & ~(u64)15;
+	L.R0.ensure((nA + 1) * sizeof(RRec));
+	RRec *R[2] = { L.R0.as<RRec>(), (RRec*)((u8*)L.scr.p + 3 * nA4) };
+	PsData pd; pd.A = dA; pd.B = dB; pd.R[0] = R[0]; pd.R[1] = R[1];
 	{
 		StageTimer t(this, sD, "k_sort_init");
-		LQ_LAUNCH(k_sort_init, nblk(nqb, 64), 64, sD, aqb, a_base, nqb, qdirty.as<u32>() + q0, dA, L.segs0.as<SortSeg>(), cnt, lists(0), km, (int)all_klib);
+		LQ_LAUNCH(k_sort_init, nblk(nqb, 64), 64, sD, aqb, a_base, nqb, qklib.as<u32>() + q0, dA, L.segs0.as<SortSeg>(), cnt, lists(0), km);
 		check_launch();
 	}
 	// the parallel sort of the clean queries runs beside klib's passes
 	LQ_HIP_CHECK(hipEventRecord(L.ev_fork, sD));
 	LQ_HIP_CHECK(hipStreamWaitEvent(sC, L.ev_fork, 0));
-	psort_run(L, 0, sC, nA, km);
+	psort_run(L, 0, sC, nA, km, pd);
 	LQ_HIP_CHECK(hipEventRecord(L.ev_join, sC));
 	// ---- klib's passes over the queries with repeated minimizers ----
 	u32 ns = 0;
 	d2h(&ns, cnt + LQ_C_KLIB0, 1, sD);
 	if (ns) {
-		const u64 nA4 = ((nA + 1) * 4 + 15) & ~(u64)15;
 		u32 *hx = (u32*)L.scr.p, *py = (u32*)((u8*)L.scr.p + nA4);
 		WalkCaps wcaps; wcaps.c[0] = 4096; wcaps.c[1] = 16384; wcaps.c[2] = 65536; wcaps.c[3] = 159744;
-		if (const char *ws = getenv("LQCOV_WALK_SHIFT")) for (int c = 0; c < 4; ++c) wcaps.c[c] >>= atoi(ws);   // test knob
-		const bool reg_walker = !(getenv("LQCOV_WALK") && !strcmp(getenv("LQCOV_WALK"), "solo"));   // A/B knob
-		const bool sort_tiles = !(getenv("LQCOV_SORT_TILES") && !strcmp(getenv("LQCOV_SORT_TILES"), "0"));   // A/B knob
-		const int xcd_order = !(getenv("LQCOV_XCD") && !strcmp(getenv("LQCOV_XCD"), "0"));   // A/B knob: tile list in XCD-major order
-		const bool gather = getenv("LQCOV_SCATTER") && !strcmp(getenv("LQCOV_SCATTER"), "gather");   // to be measured
-		const bool two_tiles = getenv("LQCOV_TWO_TILES") && atoi(getenv("LQCOV_TWO_TILES")) > 0;   // tiled two-bucket pass: written after the last GPU run of round 2, off until measured
+		for (int c = 0; c < 4; ++c) wcaps.c[c] >>= K.walk_shift;   // test knob
+		const u32 tile = K.sort_tile ? K.sort_tile : LQ_SORT_TILE;
+		const u32 wgrid = K.walk_grid;
 		L.sort_d.ensure(nA + 64); L.sort_dst.ensure((nA + 1) * 4);
+		L.ck_n.ensure(16);
 		SortSeg *cur = L.segs0.as<SortSeg>(), *nxt = L.segs1.as<SortSeg>();
 		u32 cur_slot = LQ_C_KLIB0, nxt_slot = LQ_C_KLIB1;
-		u32 shift = 56;
+		u32 shift = 56, rb = 0;                                // rb: the record array the level reads
 		bool gated = false;
 		for (int level = 0; level < 8 && ns > 0; ++level) {
 			L.hist.ensure((u64)ns * 1024); L.begs.ensure((u64)ns * 1024); L.mhist.ensure((u64)ns * 1024);
 			L.seg_info.ensure((u64)ns * sizeof(SegInfo)); L.walk_list.ensure((u64)ns * 4 * LQ_WALK_CLASSES); L.two_list.ensure((u64)ns * 4);
 			dzero(cnt + nxt_slot, 4, sD); dzero(cnt + LQ_C_TWO, 4 * (1 + LQ_WALK_CLASSES), sD);
 			const u32 g_seg = std::min<u32>(ns, 1u << 18);
-			// tiles of the level's sub-arrays for the two streaming kernels (LQCOV_SORT_TILES=0: one block per sub-array, as in round 1)
-			const u32 tile = getenv("LQCOV_SORT_TILE") ? (u32)std::max(64, atoi(getenv("LQCOV_SORT_TILE"))) : LQ_SORT_TILE;   // test / tuning knob
+			// tiles of the level's sub-arrays for the two streaming kernels
 			const u64 max_tiles = nA / tile + ns + 1;
 			const u32 g_tile = ((u32)std::min<u64>(max_tiles, 1u << 18) + 7) & ~7u;      // a multiple of the XCD count (LQ_TILE_LOOP)
-			if (sort_tiles) {
-				L.tile_list.ensure(max_tiles * sizeof(SortTile));
-				dzero(cnt + LQ_C_TILES, 4, sD);
-				LQ_LAUNCH(k_sort_tiles, std::min<u32>(ns / 256 + 1, 4096), 256, sD, cur, cnt + cur_slot, tile, L.tile_list.as<SortTile>(), cnt + LQ_C_TILES, L.hist.as<u32>(), L.mhist.as<u32>());
-				check_launch();
-			}
+			L.tile_list.ensure(max_tiles * sizeof(SortTile));
+			dzero(cnt + LQ_C_TILES, 4, sD);
+			LQ_LAUNCH(k_sort_tiles, std::min<u32>(ns / 256 + 1, 4096), 256, sD, cur, cnt + cur_slot, tile, L.tile_list.as<SortTile>(), cnt + LQ_C_TILES, L.hist.as<u32>(), L.mhist.as<u32>());
+			check_launch();
 			{
-				StageTimer t(this, sD, sort_tiles ? "k_sort_copy_hist_tiled" : "k_sort_copy_hist");
-				if (sort_tiles) LQ_LAUNCH(k_sort_copy_hist_tiled, g_tile, 256, sD, cur, L.tile_list.as<SortTile>(), cnt + LQ_C_TILES, tile, xcd_order, dA, dB, L.sort_d.as<u8>(), L.hist.as<u32>(), L.mhist.as<u32>(), (unsigned long long*)(cnt + LQ_C_COPIED));
-				else LQ_LAUNCH(k_sort_copy_hist, g_seg, 256, sD, cur, cnt + cur_slot, dA, dB, L.sort_d.as<u8>(), L.hist.as<u32>(), L.mhist.as<u32>(), (unsigned long long*)(cnt + LQ_C_COPIED));
+				StageTimer t(this, sD, level == 0 ? "k_rs_hist<first>" : "k_rs_hist");
+				if (level == 0) LQ_LAUNCH((k_rs_hist<true>), g_tile, 256, sD, cur, L.tile_list.as<SortTile>(), cnt + LQ_C_TILES, tile, 1, dB, R[rb], L.sort_d.as<u8>(), L.hist.as<u32>(), L.mhist.as<u32>(), (unsigned long long*)(cnt + LQ_C_HIST0));
+				else LQ_LAUNCH((k_rs_hist<false>), g_tile, 256, sD, cur, L.tile_list.as<SortTile>(), cnt + LQ_C_TILES, tile, 1, dB, R[rb], L.sort_d.as<u8>(), L.hist.as<u32>(), L.mhist.as<u32>(), (unsigned long long*)(cnt + LQ_C_HIST));
 				check_launch();
 			}
 			LQ_LAUNCH(k_sort_classify, g_seg, LQ_CLASSIFY_THREADS, sD, cur, cnt + cur_slot, ns, L.hist.as<u32>(), L.begs.as<u32>(), L.seg_info.as<SegInfo>(),
@@ -861,29 +875,13 @@ void lqcov_handle::sort_batch(MapLane &L, Part &pt, u32 q0, u32 nqb, u64 a_base,
 			check_launch();
 			{	// closed-form two-bucket passes (the strand bit at the top level)
 				StageTimer t(this, sD, "k_sort_two", nA * 6);
-				if (sort_tiles && two_tiles) {
-					L.two_tiles.ensure(max_tiles * sizeof(SortTile)); L.two_tile0.ensure((u64)ns * 4); L.two_tcnt.ensure(max_tiles * 8); L.two_m.ensure((u64)ns * 4);
-					dzero(cnt + LQ_C_TWO_TILES, 4, sD);
-					const SortTile *tt = L.two_tiles.as<SortTile>();
-					const u32 *ntt = cnt + LQ_C_TWO_TILES;
-					const u32 g_two = std::min<u32>(g_tile, 8192);         // grid-stride: a level without two-bucket sub-arrays costs three near-empty launches
-					LQ_LAUNCH(k_two_tiles, std::min<u32>(ns / 256 + 1, 4096), 256, sD, cur, L.two_list.as<u32>(), cnt + LQ_C_TWO, tile, L.two_tiles.as<SortTile>(), cnt + LQ_C_TWO_TILES, L.two_tile0.as<u32>()); check_launch();
-					LQ_LAUNCH((k_sort_two_tiled<0>), g_two, 256, sD, cur, L.seg_info.as<SegInfo>(), tt, ntt, tile, L.sort_d.as<u8>(), L.two_tcnt.as<u32>(), L.two_m.as<u32>(), hx, py, L.sort_dst.as<u32>()); check_launch();
-					LQ_LAUNCH(k_sort_two_scan, std::min<u32>(ns, 16384), 64, sD, cur, L.two_list.as<u32>(), cnt + LQ_C_TWO, tile, L.two_tile0.as<u32>(), L.two_tcnt.as<u32>(), L.two_m.as<u32>()); check_launch();
-					LQ_LAUNCH((k_sort_two_tiled<1>), g_two, 256, sD, cur, L.seg_info.as<SegInfo>(), tt, ntt, tile, L.sort_d.as<u8>(), L.two_tcnt.as<u32>(), L.two_m.as<u32>(), hx, py, L.sort_dst.as<u32>()); check_launch();
-					LQ_LAUNCH((k_sort_two_tiled<2>), g_two, 256, sD, cur, L.seg_info.as<SegInfo>(), tt, ntt, tile, L.sort_d.as<u8>(), L.two_tcnt.as<u32>(), L.two_m.as<u32>(), hx, py, L.sort_dst.as<u32>()); check_launch();
-				} else {
-					LQ_LAUNCH(k_sort_two, std::min<u32>(ns, 16384), LQ_TWO_THREADS, sD, cur, L.seg_info.as<SegInfo>(), L.two_list.as<u32>(), cnt + LQ_C_TWO, L.sort_d.as<u8>(), hx, py, L.sort_dst.as<u32>());
-					check_launch();
-				}
+				LQ_LAUNCH(k_sort_two, std::min<u32>(ns, 16384), LQ_TWO_THREADS, sD, cur, L.seg_info.as<SegInfo>(), L.two_list.as<u32>(), cnt + LQ_C_TWO, L.sort_d.as<u8>(), hx, py, L.sort_dst.as<u32>());
+				check_launch();
 			}
 			{
 				const u8 *dD = L.sort_d.as<u8>(); const u32 *dH = L.hist.as<u32>(), *dBg = L.begs.as<u32>(); u32 *dDst = L.sort_dst.as<u32>();
 				const u32 *wl = L.walk_list.as<u32>();
 				hipStream_t sW = L.streamW;
-				// resident walker waves are capped: every one of them holds a wave slot for milliseconds with one lane at work, and
-				// blocks of 1024 threads (the parallel sort's finish) cannot start on a CU whose slots are taken by them
-				const u32 wgrid = getenv("LQCOV_WALK_GRID") ? (u32)std::max(64, atoi(getenv("LQCOV_WALK_GRID"))) : (1u << 18);
 				// the largest digit of this level decides how many register groups the long walker needs
 				u32 max_digit = 255;
 				if (shift == 48) max_digit = (pt.rs.n ? pt.rs.n - 1 : 0) >> 16;
@@ -892,93 +890,68 @@ void lqcov_handle::sort_batch(MapLane &L, Part &pt, u32 q0, u32 nqb, u64 a_base,
 				else if (shift == 24) max_digit = (max_len ? max_len - 1 : 0) >> 24;
 				else if (shift == 16 && max_len <= (1u << 24)) max_digit = (max_len ? max_len - 1 : 0) >> 16;
 				else if (shift == 8 && max_len <= (1u << 16)) max_digit = (max_len ? max_len - 1 : 0) >> 8;
-				if (getenv("LQCOV_DEBUG_SORT")) {
+				if (K.debug_sort) {
 					u32 hc[LQ_C_N]; d2h(hc, cnt, LQ_C_N, sD);
 					fprintf(stderr, "[sort] level %d shift %u max_digit %u ns %u two %u walk %u %u %u %u %u nA %llu\n", level, shift, max_digit, ns, hc[LQ_C_TWO],
 					        hc[LQ_C_WALK0], hc[LQ_C_WALK1], hc[LQ_C_WALK2], hc[LQ_C_WALK3], hc[LQ_C_WALK4], (unsigned long long)nA);
 					fflush(stderr);
 				}
 				// the walkers' stream starts where this one stands, and this one resumes when they are done
-				// Passes with few buckets over long sub-arrays (the byte of rid above 65536 targets: the (query, strand) arrays of
-				// the longest queries, millions of anchors each): the walk's state at evenly spread checkpoints is computed
-				// without walking (kernels_ckpt.hpp) and one walker per checkpoint runs a short piece.
+				LQ_HIP_CHECK(hipEventRecord(L.ev_w0, sD)); LQ_HIP_CHECK(hipStreamWaitEvent(sW, L.ev_w0, 0));
+				if (!gated && !L.gate_passed) { L.gate_passed = true; open_gate(); gated = true; }   // let the next lane start under these walks
+				// Long sub-arrays: the walk's state at evenly spread checkpoints is computed without walking (kernels_ckpt.hpp) and
+				// one walker per checkpoint runs a short piece.  Few buckets (the byte of rid above 65536 targets: the (query, strand)
+				// arrays of the longest queries, millions of anchors each): states from prefix counts; up to 256 buckets: bulk-follow
+				// solver, longest size class only (finding the states costs about as much as walking 50-100 k elements there).
+				// The plan (which sub-arrays, their tiles and checkpoints) is laid out on the device from the class lists.
 				int first_plain_class = LQ_WALK_CLASSES - 1;
-				bool forked = false;
-				auto fork_w = [&]() { if (!forked) { LQ_HIP_CHECK(hipEventRecord(L.ev_w0, sD)); LQ_HIP_CHECK(hipStreamWaitEvent(sW, L.ev_w0, 0)); forked = true; } };
-				const bool ck_small = reg_walker && max_digit < LQ_CK_B;      // few buckets: states from prefix counts (k_ck_phases / k_ck_solve); else: k_ck_chain256
-				if (!(getenv("LQCOV_CKPT") && !strcmp(getenv("LQCOV_CKPT"), "0")) && ns <= (1u << 20)) {
-					u32 hc[LQ_C_N]; d2h(hc, cnt, LQ_C_N, sD);
-					// (with many buckets finding the states costs about as much as walking 50-100 k elements: only the longest class)
-					// (LQCOV_CKPT3=1: the 65-160 k class of a many-bucket pass as well -- to be measured)
-					const bool ck3 = ck_small || (getenv("LQCOV_CKPT3") && atoi(getenv("LQCOV_CKPT3")) > 0);
-					const u32 n3 = ck3 ? hc[LQ_C_WALK3] : 0, n4 = hc[LQ_C_WALK4];
-					if (n3 + n4) {
-						std::vector<u32> ids(n3 + n4);
-						if (n3) d2h(ids.data(), wl + (u64)3 * ns, n3, sD);
-						if (n4) d2h(ids.data() + n3, wl + (u64)4 * ns, n4, sD);
-						std::vector<SortSeg> hs(ns);
-						d2h(hs.data(), cur, ns, sD);
-						const u32 unit = std::max<u32>(16384u >> (getenv("LQCOV_WALK_SHIFT") ? atoi(getenv("LQCOV_WALK_SHIFT")) : 0), 8);
-						std::vector<CkSeg> hck(ids.size());
-						u64 tiles = 0, cks_total = 0;
-						for (size_t i = 0; i < ids.size(); ++i) {
-							const u32 len = hs[ids[i]].len;
-							CkSeg c; c.sgi = ids[i]; c.tile0 = (u32)tiles; c.ck0 = (u32)cks_total;
-							c.n_ck = std::min<u32>(ck_small ? 512 : 64, std::max<u32>(2, len / unit));
-							hck[i] = c;
-							tiles += len / LQ_CK_TILE + 1; cks_total += c.n_ck;
+				const bool ck_small = K.reg_walker && max_digit < LQ_CK_B;
+				if (K.ckpt) {
+					const bool ck3 = ck_small || K.ckpt3;
+					const u32 unit = std::max<u32>(16384u >> K.walk_shift, 8);
+					const u32 min_len = wcaps.c[ck3 ? 2 : 3] + 1;
+					const u64 cks_max = std::min<u64>(nA / min_len + 1, ns), ck_max = nA / unit + 2 * cks_max, tiles_max = nA / LQ_CK_TILE + cks_max;
+					const u32 per_ck = ck_small ? LQ_CK_B : 256;          // cursors per checkpoint
+					L.ck_segs.ensure(cks_max * sizeof(CkSeg)); L.ck_S.ensure(ck_max * per_ck * 4); L.ck_slot.ensure(ck_max * 4 + 4);
+					if (ck_small) { L.ck_T.ensure((tiles_max + 1) * LQ_CK_B * 4); L.ck_E.ensure(cks_max * LQ_CK_B * LQ_CK_B * 4); }
+					const CkSeg *dck = L.ck_segs.as<CkSeg>();
+					const u32 *ckn = L.ck_n.as<u32>();
+					LQ_LAUNCH(k_ck_plan, 1, 256, sW, cur, wl, ns, cnt + LQ_C_WALK0, (int)ck3, unit, ck_small ? 512u : 64u, L.ck_segs.as<CkSeg>(), (u32)cks_max, L.ck_n.as<u32>()); check_launch();
+					const u32 g_ck = (u32)std::min<u64>(ck_max, wgrid), g_cks = (u32)std::min<u64>(cks_max, wgrid);
+					if (ck_small) {
+						{
+							StageTimer t(this, sW, "k_ck_prefix", nA);
+							LQ_LAUNCH(k_ck_tilehist, (u32)std::min<u64>(tiles_max, 1u << 16), 256, sW, dck, ckn, cur, dD, L.ck_T.as<u32>()); check_launch();
+							LQ_LAUNCH(k_ck_tilescan, std::min<u32>(g_cks, 8192), 256, sW, dck, ckn, cur, L.ck_T.as<u32>()); check_launch();
 						}
-						if (tiles < 0xfffffff0ULL && cks_total < 0xfffffff0ULL) {
-							const u32 n_cks = (u32)hck.size(), n_tiles = (u32)tiles, n_ck = (u32)cks_total;
-							const u32 per_ck = ck_small ? LQ_CK_B : 256;          // cursors per checkpoint
-							L.ck_segs.ensure(hck.size() * sizeof(CkSeg)); L.ck_S.ensure(cks_total * per_ck * 4); L.ck_slot.ensure(cks_total * 4 + 4); L.ck_n.ensure(4);
-							if (ck_small) { L.ck_T.ensure(tiles * LQ_CK_B * 4); L.ck_E.ensure((u64)n_cks * LQ_CK_B * LQ_CK_B * 4); }
-							h2d(L.ck_segs.as<CkSeg>(), hck.data(), hck.size(), sD);
-							h2d(L.ck_n.as<u32>(), &n_ck, 1, sD);
-							LQ_HIP_CHECK(hipStreamSynchronize(sD));              // (the host vectors die with this scope)
-							const CkSeg *dck = L.ck_segs.as<CkSeg>();
-							fork_w();
-							if (!gated && !L.gate_passed) { L.gate_passed = true; open_gate(); gated = true; }
-							if (ck_small) {
-								{
-									StageTimer t(this, sW, "k_ck_prefix", nA);
-									LQ_LAUNCH(k_ck_tilehist, std::min<u32>(n_tiles, 1u << 16), 256, sW, dck, n_cks, n_tiles, cur, dD, L.ck_T.as<u32>()); check_launch();
-									LQ_LAUNCH(k_ck_tilescan, std::min<u32>(n_cks, 8192), 256, sW, dck, n_cks, cur, L.ck_T.as<u32>()); check_launch();
-								}
-								{
-									StageTimer t(this, sW, "k_ck_solve");
-									LQ_LAUNCH(k_ck_phases, (u32)std::min<u64>((u64)n_cks * LQ_CK_B, 1u << 16), 64, sW, dck, n_cks, cur, dD, dH, dBg, L.ck_T.as<u32>(), L.ck_E.as<u32>()); check_launch();
-									LQ_LAUNCH(k_ck_solve, std::min<u32>(n_ck, wgrid), 64, sW, dck, n_cks, n_ck, cur, dD, dH, dBg, L.ck_T.as<u32>(), L.ck_E.as<u32>(), L.ck_S.as<u32>(), L.ck_slot.as<u32>()); check_launch();
-								}
-								{
-									StageTimer t(this, sW, "k_sort_walk_reg<1>ck", nA * 5);
-									LQ_LAUNCH((k_sort_walk_reg<1>), std::min<u32>(n_ck, wgrid), 64, sW, cur, (const u32*)nullptr, L.ck_n.as<u32>(), dD, dH, dBg, dDst, dck, n_cks, L.ck_S.as<u32>(), L.ck_slot.as<u32>()); check_launch();
-								}
-							} else {
-								{
-									StageTimer t(this, sW, "k_ck_chain256", nA);
-									// LQCOV_CK_SEGS=n (to be measured): up to n coarse parts per sub-array, solved side by side
-									const u32 ck_segs = getenv("LQCOV_CK_SEGS") ? (u32)std::min(16, std::max(1, atoi(getenv("LQCOV_CK_SEGS")))) : 1;
-									LQ_LAUNCH(k_ck_chain256, std::min<u32>(n_cks * ck_segs, wgrid), 64, sW, dck, n_cks, ck_segs, cur, dD, dH, dBg, L.ck_S.as<u32>(), L.ck_slot.as<u32>()); check_launch();
-								}
-								{
-									StageTimer t(this, sW, "k_sort_walk_solo_ck", nA * 5);
-									LQ_LAUNCH(k_sort_walk_solo, std::min<u32>(n_ck, wgrid), 64, sW, cur, (const u32*)nullptr, L.ck_n.as<u32>(), dD, dH, dBg, dDst, dck, n_cks, L.ck_S.as<u32>(), L.ck_slot.as<u32>()); check_launch();
-								}
-							}
-							first_plain_class = ck3 ? 2 : 3;
+						{
+							StageTimer t(this, sW, "k_ck_solve");
+							LQ_LAUNCH(k_ck_phases, (u32)std::min<u64>(cks_max * LQ_CK_B, 1u << 16), 64, sW, dck, ckn, cur, dD, dH, dBg, L.ck_T.as<u32>(), L.ck_E.as<u32>()); check_launch();
+							LQ_LAUNCH(k_ck_solve, g_ck, 64, sW, dck, ckn, cur, dD, dH, dBg, L.ck_T.as<u32>(), L.ck_E.as<u32>(), L.ck_S.as<u32>(), L.ck_slot.as<u32>()); check_launch();
+						}
+						{
+							StageTimer t(this, sW, "k_sort_walk_reg<1>ck", nA * 5);
+							LQ_LAUNCH((k_sort_walk_reg<1>), g_ck, 64, sW, cur, (const u32*)nullptr, ckn, dD, dH, dBg, dDst, dck, ckn, L.ck_S.as<u32>(), L.ck_slot.as<u32>()); check_launch();
+						}
+					} else {
+						{
+							StageTimer t(this, sW, "k_ck_chain256", nA);
+							LQ_LAUNCH(k_ck_chain256, g_cks, 64, sW, dck, ckn, cur, dD, dH, dBg, L.ck_S.as<u32>(), L.ck_slot.as<u32>()); check_launch();
+						}
+						{
+							StageTimer t(this, sW, "k_sort_walk_solo_ck", nA * 5);
+							LQ_LAUNCH(k_sort_walk_solo, g_ck, 64, sW, cur, (const u32*)nullptr, ckn, dD, dH, dBg, dDst, dck, ckn, L.ck_S.as<u32>(), L.ck_slot.as<u32>()); check_launch();
 						}
 					}
+					first_plain_class = ck3 ? 2 : 3;
 				}
 				// long walks first: they outlast everything else of the level on a handful of CUs
-				fork_w();
 				for (int c = first_plain_class; c >= 2; --c) {
-					if (!gated && !L.gate_passed) { L.gate_passed = true; open_gate(); gated = true; }   // let the next lane start under these walks
 					const u32 g = std::min<u32>(ns, std::min<u32>(8192, wgrid));
 					const CkSeg *nock = nullptr;
-					if (reg_walker && max_digit < 64) { StageTimer t(this, sW, "k_sort_walk_reg<1>", nA * 5); LQ_LAUNCH((k_sort_walk_reg<1>), g, 64, sW, cur, wl + (u64)c * ns, cnt + LQ_C_WALK0 + c, dD, dH, dBg, dDst, nock, 0u, (const u32*)nullptr, (const u32*)nullptr); }
-					else if (reg_walker && max_digit < 128) { StageTimer t(this, sW, "k_sort_walk_reg<2>", nA * 5); LQ_LAUNCH((k_sort_walk_reg<2>), g, 64, sW, cur, wl + (u64)c * ns, cnt + LQ_C_WALK0 + c, dD, dH, dBg, dDst, nock, 0u, (const u32*)nullptr, (const u32*)nullptr); }
-					else { StageTimer t(this, sW, "k_sort_walk_solo", nA * 5); LQ_LAUNCH(k_sort_walk_solo, g, 64, sW, cur, wl + (u64)c * ns, cnt + LQ_C_WALK0 + c, dD, dH, dBg, dDst, nock, 0u, (const u32*)nullptr, (const u32*)nullptr); }
+					if (K.reg_walker && max_digit < 64) { StageTimer t(this, sW, "k_sort_walk_reg<1>", nA * 5); LQ_LAUNCH((k_sort_walk_reg<1>), g, 64, sW, cur, wl + (u64)c * ns, cnt + LQ_C_WALK0 + c, dD, dH, dBg, dDst, nock, (const u32*)nullptr, (const u32*)nullptr, (const u32*)nullptr); }
+					else if (K.reg_walker && max_digit < 128) { StageTimer t(this, sW, "k_sort_walk_reg<2>", nA * 5); LQ_LAUNCH((k_sort_walk_reg<2>), g, 64, sW, cur, wl + (u64)c * ns, cnt + LQ_C_WALK0 + c, dD, dH, dBg, dDst, nock, (const u32*)nullptr, (const u32*)nullptr, (const u32*)nullptr); }
+					else { StageTimer t(this, sW, "k_sort_walk_solo", nA * 5); LQ_LAUNCH(k_sort_walk_solo, g, 64, sW, cur, wl + (u64)c * ns, cnt + LQ_C_WALK0 + c, dD, dH, dBg, dDst, nock, (const u32*)nullptr, (const u32*)nullptr, (const u32*)nullptr); }
 					check_launch();
 				}
 				{ StageTimer t(this, sW, "k_sort_walk_lds<16384>"); LQ_LAUNCH((k_sort_walk_lds<16384>), std::min<u32>(ns, std::min<u32>(8192, wgrid)), 64, sW, cur, wl + (u64)1 * ns, cnt + LQ_C_WALK1, dD, dH, dBg, dDst); check_launch(); }
@@ -987,45 +960,40 @@ void lqcov_handle::sort_batch(MapLane &L, Part &pt, u32 q0, u32 nqb, u64 a_base,
 			LQ_HIP_CHECK(hipEventRecord(L.ev_w1, L.streamW));
 			LQ_HIP_CHECK(hipStreamWaitEvent(sD, L.ev_w1, 0));
 			{
-				StageTimer t(this, sD, sort_tiles ? (gather ? "k_sort_gather_tiled" : "k_sort_scatter_tiled") : "k_sort_scatter");
-				if (sort_tiles && gather) {
-					// (hx, the X position list of the level's two-bucket passes, is dead by now: the inverse permutation takes its place)
-					LQ_LAUNCH(k_sort_invert_tiled, g_tile, 256, sD, cur, L.seg_info.as<SegInfo>(), L.tile_list.as<SortTile>(), cnt + LQ_C_TILES, tile, xcd_order, L.sort_dst.as<u32>(), hx); check_launch();
-					LQ_LAUNCH(k_sort_gather_tiled, g_tile, 256, sD, cur, L.seg_info.as<SegInfo>(), L.tile_list.as<SortTile>(), cnt + LQ_C_TILES, tile, xcd_order, dA, dB, hx, (unsigned long long*)(cnt + LQ_C_SCATTERED), (unsigned long long*)(cnt + LQ_C_MOVED));
-				} else if (sort_tiles) LQ_LAUNCH(k_sort_scatter_tiled, g_tile, 256, sD, cur, L.seg_info.as<SegInfo>(), L.tile_list.as<SortTile>(), cnt + LQ_C_TILES, tile, xcd_order, dA, dB, L.sort_dst.as<u32>(), (unsigned long long*)(cnt + LQ_C_SCATTERED), (unsigned long long*)(cnt + LQ_C_MOVED));
-				else LQ_LAUNCH(k_sort_scatter, g_seg, 256, sD, cur, L.seg_info.as<SegInfo>(), cnt + cur_slot, dA, dB, L.sort_dst.as<u32>(), (unsigned long long*)(cnt + LQ_C_SCATTERED));
+				StageTimer t(this, sD, "k_rs_scatter");
+				LQ_LAUNCH(k_rs_scatter, g_tile, 256, sD, cur, L.seg_info.as<SegInfo>(), L.tile_list.as<SortTile>(), cnt + LQ_C_TILES, tile, 1, R[rb], R[rb ^ 1], L.sort_dst.as<u32>(), (unsigned long long*)(cnt + LQ_C_SCATTERED));
 				check_launch();
 			}
 			{
-				StageTimer t(this, sD, "k_sort_children");
-				LQ_LAUNCH(k_sort_children, (u32)std::min<u64>((u64)ns * 4, 1u << 20), LQ_CHILD_THREADS, sD, cur, cnt + cur_slot, dA, L.hist.as<u32>(), L.mhist.as<u32>(), L.begs.as<u32>(),
-				          nxt, cnt + nxt_slot, const_levels, lists(1), km, (int)all_klib);
+				StageTimer t(this, sD, "k_rs_children");
+				LQ_LAUNCH(k_rs_children, (u32)std::min<u64>((u64)ns * 4, 1u << 20), LQ_CHILD_THREADS, sD, cur, cnt + cur_slot, R[rb ^ 1], rb ^ 1, dB, dA, L.hist.as<u32>(), L.mhist.as<u32>(), L.begs.as<u32>(),
+				          nxt, cnt + nxt_slot, const_levels, lists(1), km, (int)K.all_klib);
 				check_launch();
 			}
 			d2h(&ns, cnt + nxt_slot, 1, sD);
 			std::swap(cur, nxt); std::swap(cur_slot, nxt_slot);
+			rb ^= 1;
 			if (shift >= 8) { shift -= 8; while (shift > 0 && (const_levels >> (shift >> 3) & 1)) shift -= 8; }
 		}
-		psort_run(L, 1, sD, nA, km);                          // the buckets that left klib's passes
+		psort_run(L, 1, sD, nA, km, pd);                      // the buckets that left klib's passes
 	}
 	LQ_HIP_CHECK(hipStreamWaitEvent(sD, L.ev_join, 0));
 	{
 		u32 hc[LQ_C_N];
 		d2h(hc, cnt, LQ_C_N, sD);
 		if (hc[LQ_C_PS0 + LQ_P_OVERFLOW] || hc[LQ_C_PS1 + LQ_P_OVERFLOW]) throw std::runtime_error("parallel sort: list or counter space overflow");
-		if (profiling) {	// algorithmic bytes of the sort's stages from what the kernels really moved (16-byte anchors)
+		if (profiling) {	// algorithmic bytes of the sort's stages from what the kernels really moved
 			auto t64 = [&](int i) { return (u64)hc[i] | (u64)hc[i + 1] << 32; };
-			const bool tiled_names = !(getenv("LQCOV_SORT_TILES") && !strcmp(getenv("LQCOV_SORT_TILES"), "0"));
-			const bool gather_name = tiled_names && getenv("LQCOV_SCATTER") && !strcmp(getenv("LQCOV_SCATTER"), "gather");
-			add_stage_bytes(tiled_names ? "k_sort_copy_hist_tiled" : "k_sort_copy_hist", t64(LQ_C_COPIED) * 33);          // anchor in, anchor + digit byte out
-			// 4-byte destination in; anchor in, anchor out for the anchors that move (all of them in the per-sub-array form)
-			add_stage_bytes(tiled_names ? (gather_name ? "k_sort_gather_tiled" : "k_sort_scatter_tiled") : "k_sort_scatter", t64(LQ_C_SCATTERED) * 4 + (t64(LQ_C_MOVED) ? t64(LQ_C_MOVED) : t64(LQ_C_SCATTERED)) * 32);
+			add_stage_bytes("k_rs_hist<first>", t64(LQ_C_HIST0) * 25);          // anchor in, record + digit byte out
+			add_stage_bytes("k_rs_hist", t64(LQ_C_HIST) * 9);                   // record in, digit byte out
+			add_stage_bytes("k_rs_scatter", t64(LQ_C_SCATTERED) * 20);          // destination + record in, record out
 			add_stage_bytes("k_ps_hist", (t64(LQ_C_PART0) + t64(LQ_C_PART1)) * 16);
 			add_stage_bytes("k_ps_scatter", (t64(LQ_C_PART0) + t64(LQ_C_PART1)) * 32);
 			add_stage_bytes("k_ps_finish<8192>", (t64(LQ_C_FINB0) + t64(LQ_C_FINB1)) * 32);
 			add_stage_bytes("k_ps_finish<1024>", (t64(LQ_C_FINS0) + t64(LQ_C_FINS1)) * 32);
 		}
-		if (hc[LQ_C_PS0 + LQ_P_BIG0] || hc[LQ_C_PS1 + LQ_P_BIG0]) throw std::domain_error("parallel sort: segments above the LDS capacity left after the last pass");
+		if (hc[LQ_C_PS0 + LQ_P_BIG0]) psort_tail(L, 0, sD, nA, km, pd);
+		if (hc[LQ_C_PS1 + LQ_P_BIG0]) psort_tail(L, 1, sD, nA, km, pd);
 	}
 }
 
@@ -1082,6 +1050,8 @@ void lqcov_handle::map_part(Part &pt)
 	          q.mx.as<u64>(), a_cnt.as<u32>(), keep.as<u32>(), q.d_len.as<u32>(),
 	          aq_off.as<u64>(), mpq_off.as<u64>(), avg_qspan.as<float>(), lambda.as<u64>(), avg_k.as<float>(), skip.as<u32>(), distributed ? 0 : 1);
 	check_launch();
+	qklib.ensure((u64)n_q * 4 + 4);
+	LQ_LAUNCH(k_query_klib, nblk(n_q, 256), 256, stream, aq_off.as<u64>(), qdirty.as<u32>(), n_q, (int)K.all_klib, qklib.as<u32>()); check_launch();
 	std::vector<u64> h_aq(n_q + 1), h_qmoff(n_q + 1);
 	d2h(h_aq.data(), aq_off.as<u64>(), n_q + 1, stream);
 	d2h(h_qmoff.data(), q.moff.as<u64>(), n_q + 1, stream);
@@ -1114,20 +1084,14 @@ void lqcov_handle::map_part(Part &pt)
 	}
 	while (lanes.size() < (size_t)n_lanes) {
 		lanes.emplace_back(new MapLane());
-		// LQCOV_WALK_EXCL=1 (to be measured): the wide kernels of the lanes stay off the walkers' CUs -- rocprofv3 at configs[2] shows
-		// walk kernels of up to 100 ms beside them where the longest walk alone takes 19
-		const uint32_t wmask = getenv("LQCOV_WALK_CUS") ? (uint32_t)strtoul(getenv("LQCOV_WALK_CUS"), 0, 16) : 0x11111111u;
-		const bool excl = getenv("LQCOV_WALK_EXCL") && atoi(getenv("LQCOV_WALK_EXCL")) > 0 && wmask != 0xffffffffu;
-		for (hipStream_t *ps : { &lanes.back()->stream, &lanes.back()->stream2 }) {
-			uint32_t inv[8];
-			for (int i = 0; i < 8; ++i) inv[i] = ~wmask;
-			if (!excl || hipExtStreamCreateWithCUMask(ps, 8, inv) != hipSuccess) { if (excl) (void)hipGetLastError(); LQ_HIP_CHECK(hipStreamCreate(ps)); }
-		}
+		LQ_HIP_CHECK(hipStreamCreate(&lanes.back()->stream));
+		LQ_HIP_CHECK(hipStreamCreate(&lanes.back()->stream2));
 		{	// Token walks are latency-bound single-lane waves that live for milliseconds: left alone they fill the wave slots and
 			// the LDS of every CU and the bandwidth kernels of the other streams crawl (rocprofv3, configs[2]: k_ps_scatter 66 ms
 			// alone, 1100 ms beside the walkers).  Their stream may only use every fourth CU; 64 CUs x 32 waves are plenty for them.
+			// (Keeping the other streams off those CUs as well was measured in round 3: slower, 2.15 vs 1.85-2.1 s per step.)
 			uint32_t mask[8];
-			for (int i = 0; i < 8; ++i) mask[i] = wmask;
+			for (int i = 0; i < 8; ++i) mask[i] = 0x11111111u;
 			if (hipExtStreamCreateWithCUMask(&lanes.back()->streamW, 8, mask) != hipSuccess) { (void)hipGetLastError(); LQ_HIP_CHECK(hipStreamCreate(&lanes.back()->streamW)); }
 		}
 		LQ_HIP_CHECK(hipEventCreateWithFlags(&lanes.back()->ev_w0, hipEventDisableTiming));
@@ -1169,6 +1133,8 @@ void lqcov_handle::map_part(Part &pt)
 				try {
 					LQ_HIP_CHECK(hipSetDevice(device));
 					MapLane &L = *lanes[li];
+					lq_alloc_stream = L.stream;                              // this thread's buffers grow from the stream-ordered pool (prim.hpp)
+					struct AllocGuard { ~AllocGuard() { lq_alloc_stream = nullptr; } } alloc_guard;
 					{	// staggered start: lane li begins when li batches have reached their long walks (or ended), so that
 						// one lane's serial tails run under another lane's wide kernels instead of side by side
 						std::unique_lock<std::mutex> lk(gate_mu);

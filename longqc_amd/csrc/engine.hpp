@@ -9,6 +9,7 @@
 #include "lq_common.hpp"
 #include "prim.hpp"
 struct KeyMap;
+struct PsData;
 #include "../../include/lqcov.h"
 #include <string>
 #include <vector>
@@ -21,6 +22,25 @@ struct KeyMap;
 #include <exception>
 
 struct StageAcc { double ms = 0; u64 launches = 0; u64 bytes = 0; };
+
+// Environment switches, read once when the handle is made (test and A/B aids; the defaults are the measured choice).
+struct Knobs {
+	int lanes = 4;                        // LQCOV_LANES: concurrent mapping lanes (measured at configs[2]: 1 lane 2.47 s per step, 2: 1.96, 4: 1.85)
+	u64 anchor_budget = 0;                // LQCOV_ANCHOR_BUDGET: anchors per query batch (0 = from free HBM)
+	bool query_order_file = false;        // LQCOV_QUERY_ORDER=file: keep the caller's query order inside
+	bool all_klib = false;                // LQCOV_SORT=klib: every query through klib's passes, no bucket leaves them early
+	u32 ps_shift = 0;                     // LQCOV_PS_SHIFT: shrinks the size classes of the parallel sort (tests)
+	bool reg_walker = true;               // LQCOV_WALK=solo: no register-lane walker
+	bool ckpt = true, ckpt3 = false;      // LQCOV_CKPT=0: no checkpointed walks; LQCOV_CKPT3=1: also for the 65-160 k class of many-bucket passes
+	u32 sort_tile = 0;                    // LQCOV_SORT_TILE: anchors per tile of the sort's streaming kernels (0 = LQ_SORT_TILE)
+	u32 walk_shift = 0;                   // LQCOV_WALK_SHIFT: shrinks the walker size classes and the checkpoint spacing (tests)
+	u32 walk_grid = 1u << 18;             // LQCOV_WALK_GRID: cap on resident walker waves
+	int chain_wave_min = 0, chain_cap = 128;   // LQCOV_CHAIN_WAVE_MIN (0 = LQ_CHAIN_WAVE_MIN), LQCOV_CHAIN_CAP
+	bool no_level_skip = false;           // LQCOV_NO_LEVEL_SKIP: constant key bytes are walked, not stepped over
+	bool debug_sort = false;              // LQCOV_DEBUG_SORT
+	u32 sketch_kpt = 4;                   // LQCOV_SKETCH_KPT: chunks per thread of the sketch state machine
+	void read_env();
+};
 
 struct ReadSetDev {                       // a read set 2-bit packed in HBM, chunk aligned
 	u32 n = 0;
@@ -50,7 +70,7 @@ struct Part {
 // One mapping lane: a stream with its own scan/sort scratch and per-batch work space.  Query batches of a part are
 // independent (lqmap.c:170-330 runs one query at a time), so lanes run them concurrently.
 struct PsWork {                           // one set of psort lists + the scratch of its partition passes (kernels_psort.hpp)
-	DBuf big[2], fin_s, fin_b, plan, gcnt, gcur;
+	DBuf big[2], fin_s, fin_b, plan, gcnt, gcur, gdiff;
 };
 
 struct MapLane {
@@ -63,15 +83,24 @@ struct MapLane {
 	PsWork ps[2];
 	Prim prim;
 	bool gate_passed = false;             // this batch has reached its long walks (see map_part)
-	DBuf A, B, segs0, segs1, n_segs, hist, begs;
-	DBuf tile_list, two_tiles, two_tile0, two_tcnt, two_m;
-	DBuf sort_d, sort_dst, seg_info, walk_list, two_list, scr, wkey, wkey2, walk_list2, walk_list3;
-	DBuf gflag, gidx, gsel, gkey, gsel2, gkey2, gstart, run_tiles, sel_tiles, gsmall;
+	DBuf A, B, R0, segs0, segs1, n_segs, hist, begs;     // A: anchors (final home), B: originals of the klib queries / other buffer of the parallel sort, R0: records (R1 lives in scr)
+	DBuf tile_list;
+	DBuf sort_d, sort_dst, seg_info, walk_list, two_list, scr;
+	DBuf gsel, gkey, gsel2, gkey2, gstart, run_tiles, sel_tiles;
 	DBuf ivl, n_ivl, iv_q, iv_q2, iv_se, iv_se2, ivq_off, iv_scratch;
+	// hand every buffer back (they regrow on the next batch); the caller has drained the lane's streams
+	void release_buffers()
+	{
+		for (DBuf *b : { &sort_cnt, &mhist, &ck_segs, &ck_T, &ck_E, &ck_S, &ck_slot, &ck_n, &prim.tmp, &A, &B, &R0, &segs0, &segs1, &n_segs, &hist, &begs, &tile_list,
+		                 &sort_d, &sort_dst, &seg_info, &walk_list, &two_list, &scr, &gsel, &gkey, &gsel2, &gkey2, &gstart, &run_tiles, &sel_tiles,
+		                 &ivl, &n_ivl, &iv_q, &iv_q2, &iv_se, &iv_se2, &ivq_off, &iv_scratch }) b->release();
+		for (PsWork &W : ps) for (DBuf *b : { &W.big[0], &W.big[1], &W.fin_s, &W.fin_b, &W.plan, &W.gcnt, &W.gcur, &W.gdiff }) b->release();
+	}
 };
 
 struct lqcov_handle {
 	lqcov_params P;
+	Knobs K;
 	MapParams mp;
 	int device = 0;
 	hipStream_t stream = nullptr;
@@ -101,6 +130,7 @@ struct lqcov_handle {
 	DBuf q_owner;                         // query of every query minimizer
 	DBuf lambda, lambda2, avg_k, cnts, qflags, qual_psum;
 	DBuf dup, qdirty, dup_table;          // k_dup_mark: minimizers / queries whose anchors can repeat an x (per part)
+	DBuf qklib;                           // queries that go through klib's passes (per part): marked and more than 64 anchors
 	// counter layout: normally the query minimizer offsets; after adopt_index_params() (prebuilt index with other -k/-w/-H)
 	// the reference's sizes (from the command-line sketch, minimap2-coverage.c:419-422) and the mapping's differ
 	bool own_cnt_layout = false; DBuf cnt_off, d_nsize; std::vector<u32> h_nsize; u64 cnt_total = 0;
@@ -143,7 +173,8 @@ struct lqcov_handle {
 	void map_part(Part &pt);
 	void map_batch(MapLane &L, Part &pt, u32 q0, u32 q1, const std::vector<u64> &h_aq, const std::vector<u64> &h_qmoff, bool dbg);
 	void sort_batch(MapLane &L, Part &pt, u32 q0, u32 nqb, u64 a_base, u64 nA);
-	void psort_run(MapLane &L, int set, hipStream_t s, u64 nA, const KeyMap &km);
+	void psort_run(MapLane &L, int set, hipStream_t s, u64 nA, const KeyMap &km, const struct PsData &pd);
+	void psort_tail(MapLane &L, int set, hipStream_t s, u64 nA, const KeyMap &km, const struct PsData &pd);
 	void reset();
 	void finish();
 	void write_table(FILE *out);

@@ -16,30 +16,7 @@
 #include "kernels_sketch.hpp"
 #include "kernels_sort.hpp"   // LQ_BLOCK_LOOP / LQ_BLOCK_SYNC / LQ_SHARED
 
-__global__ void k_mark_qstart(const u64 *aq_off, u64 a_base, u32 n_q, u32 *head)
-{
-	u32 q = blockIdx.x * blockDim.x + threadIdx.x;
-	if (q >= n_q) return;
-	if (aq_off[q] < aq_off[q + 1]) head[aq_off[q] - a_base] = 1;
-}
-
-__global__ void k_group_heads(const mm128 *A, u64 n, u32 *head)
-{
-	u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-	if (i >= n) return;
-	if (i == 0) { head[0] = 1; return; }
-	if (!head[i]) head[i] = (A[i].x >> 32) != (A[i - 1].x >> 32) ? 1u : 0u;
-}
-
-__global__ void k_group_starts(const u32 *head, const u64 *gid, u64 n, u64 n_groups, u64 *gstart)
-{
-	u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-	if (i == 0) gstart[n_groups] = n;
-	if (i >= n) return;
-	if (head[i]) gstart[gid[i]] = i;
-}
-
-// ---- the same list of run starts in two light passes (count per tile, tiny scan, write) ----------------------------------
+// ---- the list of (strand, rid) run starts in two light passes (count per tile, tiny scan, write) ----------------------------------
 // A run starts at the first anchor of the batch, at the first anchor of every query and wherever the high word of x (strand,
 // rid) changes.  Both passes read only the anchors (no head / id arrays of 4 + 8 bytes per anchor, no library scan over them),
 // have no dependency between blocks and no global atomics: pass 1 counts the starts of every 4096-anchor tile, one block scans
@@ -235,23 +212,8 @@ struct CovState {              // per-query accumulators (minimap2-coverage.c:43
 	ChainRec *dbg; unsigned long long *n_dbg; u64 dbg_cap;   // optional chain dump
 };
 
-// runs that can hold a chain (>= min_cnt anchors), as a dense work list; key = ~size so that an ascending
-// radix sort yields longest-first (lanes of one wave then own runs of similar length, long ones start first)
-__global__ void k_group_flags(const u64 *gstart, u64 n_groups, i32 min_cnt, u32 *flag)
-{
-	u64 g = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-	if (g >= n_groups) return;
-	flag[g] = (i64)(gstart[g + 1] - gstart[g]) >= (i64)min_cnt ? 1u : 0u;
-}
-
-__global__ void k_group_compact(const u64 *gstart, const u32 *flag, const u32 *idx, u64 n_groups, u32 *sel, u32 *key)
-{
-	u64 g = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-	if (g >= n_groups) return;
-	if (flag[g]) { sel[idx[g]] = (u32)g; key[idx[g]] = 0xffffffffu - (u32)(gstart[g + 1] - gstart[g]); }
-}
-
-// the same work list in two light passes over the run starts (count per tile, scan of the tile counts, write)
+// runs of at least min_cnt anchors as a dense work list; key = ~size so that an ascending radix sort yields longest-first
+// (long runs start first): two light passes over the run starts (count per tile, scan of the tile counts, write)
 __global__ void __launch_bounds__(LQ_RUN_THREADS)
 k_sel_count(const u64 *gstart, u64 n_groups, i32 min_cnt, i32 max_cnt, u32 n_tiles, u32 *tile_cnt)
 {

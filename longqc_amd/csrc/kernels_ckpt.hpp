@@ -15,7 +15,7 @@
 //   arriving at c was picked up from the first A'_l - beg_l elements of some R_l and has digit c, and A'_c already counts
 //   all of those.  Hence the state is the LEAST solution above the state at the end of the previous phase (bucket k-1
 //   full) -- and, by the same argument, above the pass's start state: a state can be found from scratch, without the
-//   states before it (the coarse parts of k_ck_chain256).  One caveat: only slots the outer loop really looks at name a
+//   states before it (k_ck_phases, k_ck_solve: every phase end and every checkpoint is found independently).  One caveat: only slots the outer loop really looks at name a
 //   state.  Arrivals fill the head of bucket k before its phase begins; a slot s below the cursor that bucket k has
 //   when the buckets before it are full is never looked at, and "k held at s, or further if its arrivals say so"
 //   (A_k >= s and A_k - beg_k >= arrivals) then yields the state at the bucket's first look.
@@ -35,12 +35,46 @@
 #define LQ_CK_TILE 1024            // elements per prefix-count tile
 
 
+// The level's checkpointed sub-arrays (the longest size classes of k_sort_classify's lists), their prefix tiles and their
+// checkpoints, laid out by one block on the device: ckn = [checkpoints in all, sub-arrays, prefix tiles].  The kernels below
+// are launched with grids sized by upper bounds and read the real counts here -- no host round trip inside a level.
+__global__ void __launch_bounds__(256)
+k_ck_plan(const SortSeg *segs, const u32 *walk_list, u32 list_cap, const u32 *n_walk, int use3, u32 unit, u32 max_ck, CkSeg *out, u32 cap_cks, u32 *ckn)
+{
+	__shared__ u32 st[256], sc[256], tmp[256], tot_t, tot_c, base_t, base_c;
+	const u32 t = threadIdx.x;
+	const u32 n3 = use3 ? n_walk[3] : 0, n4 = n_walk[4];
+	const u32 n = n3 + n4 < cap_cks ? n3 + n4 : cap_cks;        // (the bound holds by construction: every listed sub-array is longer than the class limit)
+	if (t == 0) { base_t = 0; base_c = 0; }
+	__syncthreads();
+	for (u32 s0 = 0; s0 < n; s0 += 256) {
+		const u32 i = s0 + t;
+		u32 id = 0, nt = 0, nc = 0;
+		if (i < n) {
+			id = i < n3 ? walk_list[(u64)3 * list_cap + i] : walk_list[(u64)4 * list_cap + (i - n3)];
+			const u32 len = segs[id].len;
+			nc = len / unit; if (nc < 2) nc = 2; if (nc > max_ck) nc = max_ck;
+			nt = len / LQ_CK_TILE + 1;
+		}
+		st[t] = nt; sc[t] = nc;
+		__syncthreads();
+		lq_scan256(st, tmp, &tot_t);
+		lq_scan256(sc, tmp, &tot_c);
+		if (i < n) { CkSeg c; c.sgi = id; c.tile0 = base_t + st[t]; c.ck0 = base_c + sc[t]; c.n_ck = nc; out[i] = c; }
+		__syncthreads();
+		if (t == 0) { base_t += tot_t; base_c += tot_c; }
+		__syncthreads();
+	}
+	if (t == 0) { ckn[0] = base_c; ckn[1] = n; ckn[2] = base_t; }
+}
+
 // digit counts of every tile (raw), strided over all tiles of all listed sub-arrays
 __global__ void __launch_bounds__(256)
-k_ck_tilehist(const CkSeg *cks, u32 n_cks, u32 n_tiles, const SortSeg *segs, const u8 *D, u32 *T)
+k_ck_tilehist(const CkSeg *cks, const u32 *ckn, const SortSeg *segs, const u8 *D, u32 *T)
 {
 	__shared__ u32 lh[LQ_CK_B];
 	const u32 t = threadIdx.x;
+	const u32 n_cks = ckn[1], n_tiles = ckn[2];
 	for (u32 tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
 		u32 lo = 0, hi = n_cks;
 		while (hi - lo > 1) { const u32 mid = lo + ((hi - lo) >> 1); if (cks[mid].tile0 <= tile) lo = mid; else hi = mid; }
@@ -59,10 +93,11 @@ k_ck_tilehist(const CkSeg *cks, u32 n_cks, u32 n_tiles, const SortSeg *segs, con
 
 // exclusive scan of the tile counts along each sub-array: T[tile][d] = count of digit d before the tile
 __global__ void __launch_bounds__(256)
-k_ck_tilescan(const CkSeg *cks, u32 n_cks, const SortSeg *segs, u32 *T)
+k_ck_tilescan(const CkSeg *cks, const u32 *ckn, const SortSeg *segs, u32 *T)
 {
 	__shared__ u32 part[256][LQ_CK_B + 1];
 	const u32 t = threadIdx.x;
+	const u32 n_cks = ckn[1];
 	for (u32 j = blockIdx.x; j < n_cks; j += gridDim.x) {
 		const CkSeg ck = cks[j];
 		const u32 nt = segs[ck.sgi].len / LQ_CK_TILE + 1;        // one more than needed: the last entry holds the totals
@@ -143,9 +178,10 @@ __device__ __forceinline__ u32 lq_ck_iterate(const u8 *d, const u32 *T, u32 k, u
 // every phase end is found from scratch (the least solution above the start state with the buckets up to k full) instead
 // of from the phase before -- the phases of a sub-array then cost the time of the slowest, not their sum.
 __global__ void __launch_bounds__(64)
-k_ck_phases(const CkSeg *cks, u32 n_cks, const SortSeg *segs, const u8 *D, const u32 *hist, const u32 *begs, const u32 *T, u32 *E)
+k_ck_phases(const CkSeg *cks, const u32 *ckn, const SortSeg *segs, const u8 *D, const u32 *hist, const u32 *begs, const u32 *T, u32 *E)
 {
 	const u32 lane = threadIdx.x;
+	const u32 n_cks = ckn[1];
 	for (u32 wi = blockIdx.x; wi < n_cks * LQ_CK_B; wi += gridDim.x) {
 		const u32 j = wi / LQ_CK_B, k = wi % LQ_CK_B;
 		const CkSeg ck = cks[j];
@@ -170,10 +206,11 @@ k_ck_phases(const CkSeg *cks, u32 n_cks, const SortSeg *segs, const u8 *D, const
 
 // state at every checkpoint (one wave each): checkpoint i of sub-array j sits at slot s of bucket k
 __global__ void __launch_bounds__(64)
-k_ck_solve(const CkSeg *cks, u32 n_cks, u32 n_ck_total, const SortSeg *segs, const u8 *D, const u32 *hist, const u32 *begs, const u32 *T,
+k_ck_solve(const CkSeg *cks, const u32 *ckn, const SortSeg *segs, const u8 *D, const u32 *hist, const u32 *begs, const u32 *T,
            const u32 *E, u32 *S, u32 *CKS)
 {
 	const u32 lane = threadIdx.x;
+	const u32 n_ck_total = ckn[0], n_cks = ckn[1];
 	for (u32 ci = blockIdx.x; ci < n_ck_total; ci += gridDim.x) {
 		u32 lo = 0, hi = n_cks;
 		while (hi - lo > 1) { const u32 mid = lo + ((hi - lo) >> 1); if (cks[mid].ck0 <= ci) lo = mid; else hi = mid; }
@@ -257,32 +294,18 @@ __device__ __forceinline__ void lq_ck_count_range(const u8 *d, u32 lo, u32 hi, u
 		}
 	}
 }
-// Coarse segments (max_segs > 1): the chain above is serial per sub-array -- tens of milliseconds for a sub-array of 10^6
-// elements.  But the state at ANY slot is the least solution above the start state (the argument at the top of this file
-// never used where the iteration starts), so it can be found without the states before it: the outer loop's slots up to the
-// end U of the first bucket that matters (nearly all picking-up happens while the first non-trivial bucket is filled) are cut
-// into NC - 1 equal parts, the rest is the last part; one wave per part finds the state at its first slot from scratch
-// (the buckets before the slot's own are read whole, that one up to the slot) and then chains through its part as above,
-// writing its share of the checkpoints.  max_segs = 1 is the serial chain.
-__device__ __forceinline__ u32 lq_ck_nsegs(u32 n_ck, u32 max_segs)
-{
-	const u32 a = n_ck / 4;
-	return a < 1 ? 1 : a < max_segs ? a : max_segs;
-}
-
+// (Measured and dropped, round 3: the chain cut into coarse parts that start from states found from scratch -- at configs[2]
+// the solver took 818 ms per step against 384 ms for the serial chain: every part reads the buckets before its slot whole.)
 __global__ void __launch_bounds__(64)
-k_ck_chain256(const CkSeg *cks, u32 n_cks, u32 max_segs, const SortSeg *segs, const u8 *D, const u32 *hist, const u32 *begs, u32 *S, u32 *CKS)
+k_ck_chain256(const CkSeg *cks, const u32 *ckn, const SortSeg *segs, const u8 *D, const u32 *hist, const u32 *begs, u32 *S, u32 *CKS)
 {
 	__shared__ u32 arr[256];
 	__shared__ u32 red[64];
 	const u32 lane = threadIdx.x;
-	for (u32 wi = blockIdx.x; wi < n_cks * max_segs; wi += gridDim.x) {
-		const u32 j = wi / max_segs, seg = wi % max_segs;
+	const u32 n_cks = ckn[1];
+	for (u32 j = blockIdx.x; j < n_cks; j += gridDim.x) {
 		const CkSeg ck = cks[j];
-		const u32 NC = lq_ck_nsegs(ck.n_ck, max_segs);
-		if (seg >= NC) continue;
-		const u32 per = ck.n_ck / NC;                           // checkpoints of a part; the last part also owns the remainder
-		const u32 my_ck0 = ck.ck0 + seg * per, my_n = seg + 1 == NC ? ck.n_ck - seg * per : per;
+		const u32 my_ck0 = ck.ck0, my_n = ck.n_ck;
 		const SortSeg sg = segs[ck.sgi];
 		const u8 *d = D + sg.off;
 		const u32 *bg = begs + (u64)ck.sgi * 256, *cn = hist + (u64)ck.sgi * 256;
@@ -291,21 +314,6 @@ k_ck_chain256(const CkSeg *cks, u32 n_cks, u32 max_segs, const SortSeg *segs, co
 		for (int g = 0; g < 4; ++g) { cw[g] = uint4{0, 0, 0, 0}; cwa[g] = 0; }
 		for (int g = 0; g < 4; ++g) { const u32 c = (u32)g * 64 + lane; B0[g] = bg[c]; E0[g] = B0[g] + cn[c]; A[g] = B0[g]; arr[c] = 0; }
 		__syncthreads();
-		// slots [u_lo, u_hi) of the outer loop (absolute slot indices: the buckets' regions follow each other)
-		u32 u_lo = 0, u_hi = sg.len;
-		if (NC > 1) {
-			const u32 thr = (sg.len >> 8) ? (sg.len >> 8) : 1;
-			u32 U = sg.len;
-			for (int g = 0; g < 4; ++g) if (E0[g] >= thr && E0[g] < U) U = E0[g];
-			for (int o = 32; o > 0; o >>= 1) { const u32 v = __shfl_xor(U, o); if (v < U) U = v; }
-			u_lo = seg == 0 ? 0 : (u32)((u64)U * seg / (NC - 1));
-			u_hi = seg + 1 == NC ? sg.len : (u32)((u64)U * (seg + 1) / (NC - 1));
-		}
-		// phase of a slot: the buckets that end at or before it come first
-		u32 k_lo = 0, k_hi = 0;
-		for (int g = 0; g < 4; ++g) { k_lo += (u32)__popcll(__ballot(E0[g] <= u_lo)); k_hi += (u32)__popcll(__ballot(E0[g] <= u_hi)); }
-		if (u_lo == 0) k_lo = 0;
-		if (u_hi >= sg.len) k_hi = 256;
 		// fixed point with the buckets before k full and bucket k held at s
 #define LQ_CK_FIXED_POINT(k, s) \
 		for (;;) { \
@@ -330,26 +338,19 @@ k_ck_chain256(const CkSeg *cks, u32 n_cks, u32 max_segs, const SortSeg *segs, co
 			__syncthreads(); \
 			(out) = p_; \
 		} while (0)
-		// the state at this part's first slot, from scratch.  (A slot that arrivals had filled before the outer loop reached its
-		// bucket is never looked at: the state is then the one at the bucket's first look, and the cursor says where that is.)
-		if (u_lo > 0 && k_lo < 256) {
-			LQ_CK_FIXED_POINT(k_lo, u_lo)
-			for (int g = 0; g < 4; ++g) if ((u32)g == (k_lo >> 6)) u_lo = (u32)__builtin_amdgcn_readlane((int)A[g], (int)(k_lo & 63));
-		}
 		const u64 target = (u64)sg.len / ck.n_ck + 1;
 		u64 picked_at_last = 0, picked_before = 0;
 		LQ_CK_PICKED(picked_before);
 		picked_at_last = picked_before;
 		u32 n_out = 0, est = LQ_CKW_STEP;                       // slots of the phase's bucket that are worth about `target` picked-up elements
-		// first checkpoint of the part: its first slot
+		// first checkpoint: the start state
 		for (int g = 0; g < 4; ++g) S[((u64)my_ck0 + 0) * 256 + (u32)g * 64 + lane] = A[g];
-		if (lane == 0) CKS[my_ck0] = u_lo;
+		if (lane == 0) CKS[my_ck0] = 0;
 		n_out = 1;
-		for (u32 k = k_lo; k < 256 && k <= k_hi; ++k) {          // phases of the outer loop
+		for (u32 k = 0; k < 256; ++k) {                          // phases of the outer loop
 			const u32 kl = k & 63, kg = k >> 6;
 			u32 ek = 0, ak = 0;
 			for (int g = 0; g < 4; ++g) if ((u32)g == kg) { ek = (u32)__builtin_amdgcn_readlane((int)E0[g], (int)kl); ak = (u32)__builtin_amdgcn_readlane((int)A[g], (int)kl); }
-			if (k == k_hi && u_hi < ek) ek = u_hi;                  // the part ends inside this bucket
 			while (ak < ek) {
 				const u32 step = est;
 				u32 s = ek - ak > step ? ak + step : ek;                // the outer loop reaches slot s of bucket k
@@ -375,10 +376,10 @@ k_ck_chain256(const CkSeg *cks, u32 n_cks, u32 max_segs, const SortSeg *segs, co
 		}
 #undef LQ_CK_FIXED_POINT
 #undef LQ_CK_PICKED
-		// unused checkpoints: the state at the part's end -- the next part's first checkpoint (their walkers find nothing to do)
+		// unused checkpoints: the final state (their walkers find nothing to do)
 		for (; n_out < my_n; ++n_out) {
-			for (int g = 0; g < 4; ++g) S[((u64)my_ck0 + n_out) * 256 + (u32)g * 64 + lane] = u_hi >= sg.len ? E0[g] : A[g];
-			if (lane == 0) CKS[my_ck0 + n_out] = u_hi >= sg.len ? sg.len : u_hi;
+			for (int g = 0; g < 4; ++g) S[((u64)my_ck0 + n_out) * 256 + (u32)g * 64 + lane] = E0[g];
+			if (lane == 0) CKS[my_ck0 + n_out] = sg.len;
 		}
 		__syncthreads();
 	}

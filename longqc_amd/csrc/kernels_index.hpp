@@ -171,7 +171,9 @@ __global__ void k_dup_mark(const u64 *qx, const u64 *qy, const u32 *owner, const
 // at a time, a hit per lane: the occurrence list is read and the anchors are written as contiguous runs (a thread
 // walking its own list wrote 16-byte pieces 1 KiB apart: rocprofv3 counted 108 GB of HBM traffic per launch for 19 GB
 // of anchors).  Anchors of minimizers marked by k_dup_mark carry LQ_TIE_MARK in y (never read downstream, like
-// MM_SEED_TANDEM): the sort counts them to tell where klib's order can matter.
+// MM_SEED_TANDEM): the sort counts them to tell where klib's order can matter.  The anchors of a query that goes through
+// klib's passes (qklib) are written to `originals` (the lane's second buffer) instead of `anchors`: the passes permute
+// 8-byte records and gather every anchor once, into `anchors`, when its bucket is finished (kernels_rsort.hpp).
 #define LQ_EMIT_THREADS 256
 struct EmitSetup { u64 st, out0; u32 n, q, span, qp, flags; i32 ql; };
 __global__ void __launch_bounds__(LQ_EMIT_THREADS)
@@ -179,7 +181,7 @@ k_seed_emit(const u64 *qx, const u64 *qy, const u32 *owner, const u64 *qmoff, u6
             const u64 *pos, const u64 *hit_start, const u32 *hit_n, const u32 *keep, const u32 *dup,
             const u64 *a_off, u64 a_base, const u64 *mp_off, const u32 *qlen,
             int no_self, const u32 *self_off, const u32 *self_rid, AvaView ava,
-            mm128 *anchors, u64 *mini_pos)
+            const u32 *qklib, mm128 *anchors, mm128 *originals, u64 *mini_pos)
 {
 	__shared__ EmitSetup su[LQ_EMIT_THREADS];
 	const u64 jt = (u64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -196,6 +198,7 @@ k_seed_emit(const u64 *qx, const u64 *qy, const u32 *owner, const u64 *qmoff, u6
 		if (j + 1 < qmoff[e.q + 1] && (qx[j + 1] >> 8) == (x >> 8)) e.flags |= 1;
 		if (no_self && self_off[e.q] != self_off[e.q + 1]) e.flags |= 2;             // some target carries this query's name
 		if (dup[j]) e.flags |= 4;
+		if (qklib[e.q]) e.flags |= 8;                                                // this query goes through klib's passes: its anchors are "originals"
 		e.n = hit_n[j]; e.st = hit_start[j]; e.out0 = a_off[j] - a_base; e.ql = (i32)qlen[e.q];
 	}
 	su[threadIdx.x] = e;
@@ -208,6 +211,7 @@ k_seed_emit(const u64 *qx, const u64 *qy, const u32 *owner, const u64 *qmoff, u6
 		const u64 y_same = (u64)b.span << 32 | b_qpos | ybits;
 		const u64 y_rev = (u64)b.span << 32 | (u32)(b.ql - (i32)(b_qpos + 1 - b.span) - 1) | ybits;
 		const bool filter = (b.flags & 2) || ava.t_rank;        // wave-uniform
+		mm128 *out = (b.flags & 8) ? originals : anchors;
 		u32 skipped = 0;
 		for (u32 t0 = 0; t0 < b.n; t0 += 64) {
 			const u32 t = t0 + lane;
@@ -227,7 +231,7 @@ k_seed_emit(const u64 *qx, const u64 *qy, const u32 *owner, const u64 *qmoff, u6
 				mm128 a;
 				if ((r & 1) == (b.qp & 1)) { a.x = (r & 0xffffffff00000000ULL) | rpos; a.y = y_same; }
 				else { a.x = 1ULL << 63 | (r & 0xffffffff00000000ULL) | rpos; a.y = y_rev; }
-				anchors[b.out0 + t - before] = a;
+				out[b.out0 + t - before] = a;
 			}
 		}
 	}

@@ -19,13 +19,33 @@
 //     registers, keys in LDS, split by the next 10 / 8 key bits, then every element ranks itself among the (few) elements
 //     of its sub-bucket by the full remaining key; written to A whatever buffer the segment was in.
 // All list lengths live on the device; kernels take upper-bound grids and stride over the lists.
+//
+// Where a segment's anchors are: in A, in B, or -- a bucket that has just left klib's passes (kernels_rsort.hpp) -- still
+// spread over the originals and named by the records of its range (buf 2 / 3: record array 0 / 1): the first kernel that
+// touches such a segment gathers the anchors through the indices, so leaving klib costs no pass of its own.  A gathered
+// segment always goes to A (the originals live in B until every such segment has been read: psort_run finishes them and
+// runs their first partition pass before any pass writes to B).
 #pragma once
 #include "lq_common.hpp"
 #include "kernels_sort.hpp"
+#include "kernels_rsort.hpp"
 
 struct KeyMap { u32 pbits, rbits; };                 // varying low bits of the position and of rid in this part
-struct alignas(16) PSeg { u64 off; u32 len; u8 rem; u8 buf; u8 nbits; u8 pad; };   // buf: 0 = data in A, 1 = in B
+struct alignas(16) PSeg { u64 off; u32 len; u8 rem; u8 buf; u8 nbits; u8 pad; };   // buf: 0 = data in A, 1 = in B, 2 / 3 = originals named by record array 0 / 1
 struct PPlan { u32 tile0, cnt0; };                   // first tile / first counter of a big segment
+struct PsData { mm128 *A, *B; const RRec *R[2]; };   // the lane's buffers; B holds the originals of the klib queries
+#define LQ_PS_SKIP 0xffu                             // PSeg.nbits of a big segment whose pass found every key in one bucket: nothing to move
+
+__device__ __forceinline__ mm128 lq_ps_load(const PSeg &sg, const PsData &P, u32 i)
+{
+	if (sg.buf < 2) return (sg.buf ? P.B : P.A)[sg.off + i];
+	return P.B[LQ_R_IDX(P.R[sg.buf - 2][sg.off + i].im)];
+}
+__device__ __forceinline__ u64 lq_ps_load_x(const PSeg &sg, const PsData &P, u32 i)
+{
+	if (sg.buf < 2) return (sg.buf ? P.B : P.A)[sg.off + i].x;
+	return P.B[LQ_R_IDX(P.R[sg.buf - 2][sg.off + i].im)].x;
+}
 
 #define LQ_PS_FIN_SMALL 1024
 #define LQ_PS_FIN_BIG   8192
@@ -36,11 +56,10 @@ struct PPlan { u32 tile0, cnt0; };                   // first tile / first count
 // counters of one batch's sort (device): indices into L.sort_cnt.  Two sets of psort lists: set 0 takes whole queries
 // (k_sort_init) and is sorted on its own stream while klib's passes run; set 1 collects the buckets that leave them.
 enum { LQ_C_KLIB0 = 0, LQ_C_KLIB1, LQ_C_TWO, LQ_C_WALK0, LQ_C_WALK1, LQ_C_WALK2, LQ_C_WALK3, LQ_C_WALK4, LQ_C_OVERFLOW, LQ_C_TILES,
-       LQ_C_TWO_TILES = 12,    // tiles of the level's two-bucket sub-arrays
-       LQ_C_MOVED = 10,        // (64-bit) anchors the tiled scatter really moved
+       LQ_C_HIST0 = 10,        // (64-bit) anchors the first level's histogram kernel turned into records
        LQ_C_PS0 = 16, LQ_C_PS1 = 32,
        // 64-bit tallies of the elements each kind of kernel really moved (algorithmic bytes of the stage times)
-       LQ_C_COPIED = 48, LQ_C_SCATTERED = 50, LQ_C_PART0 = 52, LQ_C_FINS0 = 54, LQ_C_FINB0 = 56, LQ_C_PART1 = 58, LQ_C_FINS1 = 60, LQ_C_FINB1 = 62, LQ_C_N = 64 };
+       LQ_C_HIST = 48, LQ_C_SCATTERED = 50, LQ_C_PART0 = 52, LQ_C_FINS0 = 54, LQ_C_FINB0 = 56, LQ_C_PART1 = 58, LQ_C_FINS1 = 60, LQ_C_FINB1 = 62, LQ_C_N = 64 };
 enum { LQ_P_BIG0 = 0, LQ_P_BIG1, LQ_P_FIN_S, LQ_P_FIN_B, LQ_P_TILES, LQ_P_CNT, LQ_P_OVERFLOW };   // offsets inside a set's counters
 struct PsLists { struct PSeg *big[2], *fin_s, *fin_b; u32 *cnt; u32 cap_big, cap_fin;
                  u32 fin_s_max, fin_b_max, child_target; };   // size limits of the two finishing kernels, aimed child size of a pass (tests shrink them)
@@ -63,24 +82,6 @@ __device__ __forceinline__ void lq_ps_route(PSeg sg, const PsLists L, u32 big_sl
 	if (sg.len <= L.fin_s_max) { const u32 s = atomicAdd(&L.cnt[LQ_P_FIN_S], 1u); if (s < L.cap_fin) L.fin_s[s] = sg; else atomicOr(&L.cnt[LQ_P_OVERFLOW], 1u); }
 	else if (sg.len <= L.fin_b_max) { const u32 s = atomicAdd(&L.cnt[LQ_P_FIN_B], 1u); if (s < L.cap_fin) L.fin_b[s] = sg; else atomicOr(&L.cnt[LQ_P_OVERFLOW], 1u); }
 	else { const u32 s = atomicAdd(&L.cnt[big_slot], 1u); if (s < L.cap_big) L.big[big_slot][s] = sg; else atomicOr(&L.cnt[LQ_P_OVERFLOW], 1u); }
-}
-
-// block-wide exclusive scan of v[0..256) in LDS (256 or more threads; returns with the result in v, total in *tot)
-__device__ __forceinline__ void lq_scan256(u32 *v, u32 *tmp, u32 *tot)
-{
-	const u32 t = threadIdx.x;
-	for (u32 d = 1; d < 256; d <<= 1) {
-		u32 a = 0;
-		if (t < 256) a = v[t] + (t >= d ? v[t - d] : 0);
-		__syncthreads();
-		if (t < 256) v[t] = a;
-		__syncthreads();
-	}
-	if (t < 256) tmp[t] = t ? v[t - 1] : 0;
-	if (t == 255 && tot) *tot = v[255];
-	__syncthreads();
-	if (t < 256) v[t] = tmp[t];
-	__syncthreads();
 }
 
 // ---- plan of one partition pass: digits, tiles and counters of every big segment (one block) ----------------
@@ -127,10 +128,15 @@ __device__ __forceinline__ u32 lq_ps_seg_of_tile(const PPlan *plan, u32 n, u32 t
 }
 
 // ---- histogram of the pass's digit, per big segment (tiles stride over the grid) ------------------------------
+// Also: gdiff[segment] |= key ^ (key of the segment's first element) -- the key bits that vary inside the segment.  A
+// segment whose keys agree in all the bits of this pass's digit (e.g. 30 000 anchors of an ultra-long query on one target:
+// strand and rid are the top 1 + rbits bits of the key) is not moved at all: k_ps_scan re-lists it with `rem` cut down to
+// its highest varying bit.
 __global__ void __launch_bounds__(LQ_PS_THREADS)
-k_ps_hist(const PSeg *segs, const u32 *n_p, const PPlan *plan, const u32 *cnt, const mm128 *A, const mm128 *B, KeyMap km, u32 *gcnt)
+k_ps_hist(const PSeg *segs, const u32 *n_p, const PPlan *plan, const u32 *cnt, PsData P, KeyMap km, u32 *gcnt, unsigned long long *gdiff)
 {
 	__shared__ u32 lh[256];
+	__shared__ unsigned long long ldiff[LQ_PS_THREADS / 64];
 	const u32 n = *n_p;
 	if (n == 0 || (cnt[LQ_P_OVERFLOW] & 2u)) return;
 	const u32 n_tiles = cnt[LQ_P_TILES], t = threadIdx.x;
@@ -139,20 +145,24 @@ k_ps_hist(const PSeg *segs, const u32 *n_p, const PPlan *plan, const u32 *cnt, c
 		const PSeg sg = segs[s];
 		const PPlan pl = plan[s];
 		const u32 i0 = (tile - pl.tile0) * LQ_PS_TILE, i1 = i0 + LQ_PS_TILE < sg.len ? i0 + LQ_PS_TILE : sg.len;
-		const mm128 *src = (sg.buf ? B : A) + sg.off;
 		const u32 sh = sg.rem - sg.nbits, dm = (1u << sg.nbits) - 1;
+		const u64 key0 = lq_ckey(lq_ps_load_x(sg, P, 0), km);
+		u64 diff = 0;
 		lh[t] = 0;
 		__syncthreads();
-		for (u32 i = i0 + t; i < i1; i += LQ_PS_THREADS) atomicAdd(&lh[(u32)(lq_ckey(src[i].x, km) >> sh) & dm], 1u);
+		for (u32 i = i0 + t; i < i1; i += LQ_PS_THREADS) { const u64 key = lq_ckey(lq_ps_load_x(sg, P, i), km); diff |= key ^ key0; atomicAdd(&lh[(u32)(key >> sh) & dm], 1u); }
+		for (int o = 32; o > 0; o >>= 1) diff |= __shfl_xor(diff, o);
+		if ((t & 63) == 0) ldiff[t >> 6] = diff;
 		__syncthreads();
 		if (t <= dm && lh[t]) atomicAdd(&gcnt[pl.cnt0 + t], lh[t]);
+		if (t == 0) { unsigned long long dd = 0; for (u32 w = 0; w < LQ_PS_THREADS / 64; ++w) dd |= ldiff[w]; if (dd) atomicOr(&gdiff[s], dd); }
 		__syncthreads();
 	}
 }
 
 // ---- bucket offsets and children of every big segment (one block per segment, strided) ----------------------
 __global__ void __launch_bounds__(256)
-k_ps_scan(const PSeg *segs, const u32 *n_p, const PPlan *plan, const u32 *gcnt, u32 *gcur, PsLists L, u32 big_next_slot, unsigned long long *tally)
+k_ps_scan(PSeg *segs, const u32 *n_p, const PPlan *plan, const u32 *gcnt, u32 *gcur, const unsigned long long *gdiff, PsLists L, u32 big_next_slot, unsigned long long *tally)
 {
 	__shared__ u32 v[256], tmp[256];
 	const u32 n = *n_p, t = threadIdx.x;
@@ -161,6 +171,21 @@ k_ps_scan(const PSeg *segs, const u32 *n_p, const PPlan *plan, const u32 *gcnt, 
 		const PSeg sg = segs[s];
 		const PPlan pl = plan[s];
 		const u32 nb = 1u << sg.nbits;
+		{	// every key in one bucket of this pass: the segment stays where it is and is listed again with the bits that do vary
+			const u64 low = sg.rem >= 64 ? ~0ULL : ((1ULL << sg.rem) - 1);
+			const u64 df = (u64)gdiff[s] & low;
+			// (all keys equal and not in A yet: no short cut -- the pass below is then the copy that brings the segment home)
+			if ((df >> (sg.rem - sg.nbits)) == 0 && (df != 0 || sg.buf == 0)) {   // (uniform over the block)
+				if (t == 0) {
+					PSeg ch = sg; ch.nbits = 0;
+					ch.rem = df ? (u8)(64 - __builtin_clzll(df)) : 0;
+					if (ch.rem) lq_ps_route(ch, L, big_next_slot);
+					PSeg mk = sg; mk.nbits = LQ_PS_SKIP; segs[s] = mk;          // k_ps_scatter leaves it alone
+				}
+				__syncthreads();
+				continue;
+			}
+		}
 		if (t == 0 && tally) atomicAdd(tally, (unsigned long long)sg.len);
 		const u32 c = t < nb ? gcnt[pl.cnt0 + t] : 0;
 		v[t] = c;
@@ -169,7 +194,7 @@ k_ps_scan(const PSeg *segs, const u32 *n_p, const PPlan *plan, const u32 *gcnt, 
 		if (t < nb) {
 			gcur[pl.cnt0 + t] = v[t];
 			if (c) {
-				PSeg ch; ch.off = sg.off + v[t]; ch.len = c; ch.rem = (u8)(sg.rem - sg.nbits); ch.buf = sg.buf ^ 1; ch.nbits = 0; ch.pad = 0;
+				PSeg ch; ch.off = sg.off + v[t]; ch.len = c; ch.rem = (u8)(sg.rem - sg.nbits); ch.buf = sg.buf >= 2 ? 0 : sg.buf ^ 1; ch.nbits = 0; ch.pad = 0;
 				if (ch.rem == 0 || c == 1) { if (ch.buf) { ch.rem = 0; lq_ps_route(ch, L, big_next_slot); } }   // nothing left to sort: only bring it home to A
 				else lq_ps_route(ch, L, big_next_slot);
 			}
@@ -180,7 +205,7 @@ k_ps_scan(const PSeg *segs, const u32 *n_p, const PPlan *plan, const u32 *gcnt, 
 
 // ---- the partition pass: every tile moves its elements into their buckets in the other buffer ---------------
 __global__ void __launch_bounds__(LQ_PS_THREADS)
-k_ps_scatter(const PSeg *segs, const u32 *n_p, const PPlan *plan, const u32 *cnt, mm128 *A, mm128 *B, KeyMap km, u32 *gcur)
+k_ps_scatter(const PSeg *segs, const u32 *n_p, const PPlan *plan, const u32 *cnt, PsData P, KeyMap km, u32 *gcur)
 {
 	__shared__ mm128 stage[LQ_PS_TILE];
 	__shared__ u32 lh[256], lo[256], fill[256], gb[256], tmp[256];
@@ -192,16 +217,16 @@ k_ps_scatter(const PSeg *segs, const u32 *n_p, const PPlan *plan, const u32 *cnt
 		const u32 s = lq_ps_seg_of_tile(plan, n, tile);
 		const PSeg sg = segs[s];
 		const PPlan pl = plan[s];
+		if (sg.nbits == LQ_PS_SKIP) continue;                     // (uniform) every key in one bucket: k_ps_scan listed the segment again
 		const u32 i0 = (tile - pl.tile0) * LQ_PS_TILE, i1 = i0 + LQ_PS_TILE < sg.len ? i0 + LQ_PS_TILE : sg.len;
-		const mm128 *src = (sg.buf ? B : A) + sg.off;
-		mm128 *dst = (sg.buf ? A : B) + sg.off;
+		mm128 *dst = (sg.buf == 1 || sg.buf >= 2 ? P.A : P.B) + sg.off;
 		const u32 sh = sg.rem - sg.nbits, dm = (1u << sg.nbits) - 1;
 		lh[t] = 0; fill[t] = 0;
 		__syncthreads();
 		mm128 e[PER];
 		for (u32 k = 0; k < PER; ++k) {
 			const u32 i = i0 + t + k * LQ_PS_THREADS;
-			if (i < i1) { e[k] = src[i]; atomicAdd(&lh[(u32)(lq_ckey(e[k].x, km) >> sh) & dm], 1u); }
+			if (i < i1) { e[k] = lq_ps_load(sg, P, i); atomicAdd(&lh[(u32)(lq_ckey(e[k].x, km) >> sh) & dm], 1u); }
 		}
 		__syncthreads();
 		const u32 mine = lh[t];
@@ -232,7 +257,7 @@ k_ps_scatter(const PSeg *segs, const u32 *n_p, const PPlan *plan, const u32 *cnt
 // usual case: half the LDS, two blocks per CU), u64 otherwise.
 template <int CAP, int THREADS, int SB, class KEY>
 __global__ void __launch_bounds__(THREADS)
-k_ps_finish(const PSeg *segs, const u32 *n_p, mm128 *A, const mm128 *B, KeyMap km, unsigned long long *tally)
+k_ps_finish(const PSeg *segs, const u32 *n_p, PsData P, KeyMap km, unsigned long long *tally)
 {
 	constexpr int NSB = 1 << SB, PER = CAP / THREADS, SPT = NSB / THREADS > 0 ? NSB / THREADS : 1;
 	static_assert(CAP % THREADS == 0 && (NSB % THREADS == 0 || NSB < THREADS), "shape");
@@ -243,11 +268,10 @@ k_ps_finish(const PSeg *segs, const u32 *n_p, mm128 *A, const mm128 *B, KeyMap k
 	for (u32 s = blockIdx.x; s < n_seg; s += gridDim.x) {
 		const PSeg sg = segs[s];
 		const u32 n = sg.len;
-		const mm128 *src = (sg.buf ? B : A) + sg.off;
-		mm128 *out = A + sg.off;
+		mm128 *out = P.A + sg.off;
 		if (t == 0 && tally) atomicAdd(tally, (unsigned long long)n);
 		if (sg.rem == 0 || n == 1) {                             // already in order: home to A
-			if (sg.buf) for (u32 i = t; i < n; i += THREADS) out[i] = src[i];
+			if (sg.buf) for (u32 i = t; i < n; i += THREADS) out[i] = lq_ps_load(sg, P, i);
 			continue;
 		}
 		const u32 nb = sg.rem < SB ? sg.rem : SB, sh = sg.rem - nb;
@@ -258,7 +282,7 @@ k_ps_finish(const PSeg *segs, const u32 *n_p, mm128 *A, const mm128 *B, KeyMap k
 		u32 dg[PER];
 		for (int k = 0; k < PER; ++k) {
 			const u32 i = t + (u32)k * THREADS;
-			if (i < n) { e[k] = src[i]; const u64 key = lq_ckey(e[k].x, km) & km_mask; keys[i] = (KEY)(key & lo_mask); dg[k] = (u32)(key >> sh); atomicAdd(&hist[dg[k]], 1u); }
+			if (i < n) { e[k] = lq_ps_load(sg, P, i); const u64 key = lq_ckey(e[k].x, km) & km_mask; keys[i] = (KEY)(key & lo_mask); dg[k] = (u32)(key >> sh); atomicAdd(&hist[dg[k]], 1u); }
 		}
 		__syncthreads();
 		{	// exclusive scan of hist -> beg: SPT counters per thread, wave scan, wave totals through LDS
@@ -300,15 +324,16 @@ k_ps_finish(const PSeg *segs, const u32 *n_p, mm128 *A, const mm128 *B, KeyMap k
 
 // ---- the two entrances from the klib side -----------------------------------------------------------------
 // radix_sort_128x entry (ksort.h:130-134) for every query of the batch: arrays of <= 64 elements are insertion sorted;
-// a query with marked minimizers starts klib's passes at the top byte; every other query is free of equal x.
-__global__ void k_sort_init(const u64 *aq_off, u64 a_base, u32 n_q, const u32 *qdirty, mm128 *A, SortSeg *klib, u32 *cnt,
-                            PsLists L, KeyMap km, int all_klib)
+// a query with marked minimizers (qklib: its anchors were emitted into B, the originals) starts klib's passes at the top
+// byte; every other query is free of equal x.
+__global__ void k_sort_init(const u64 *aq_off, u64 a_base, u32 n_q, const u32 *qklib, mm128 *A, SortSeg *klib, u32 *cnt,
+                            PsLists L, KeyMap km)
 {
 	const u32 q = blockIdx.x * blockDim.x + threadIdx.x;
 	if (q >= n_q) return;
 	const u64 off = aq_off[q] - a_base, len = aq_off[q + 1] - aq_off[q];
 	if (len <= LQ_RS_MIN) { if (len > 1) lq_insertion_sort_x(A + off, (u32)len); return; }
-	if (qdirty[q] || all_klib) {
+	if (qklib[q]) {
 		const u32 s = atomicAdd(&cnt[LQ_C_KLIB0], 1u);
 		SortSeg sg; sg.off = off; sg.len = (u32)len; sg.shift = 56;
 		klib[s] = sg;
@@ -318,17 +343,25 @@ __global__ void k_sort_init(const u64 *aq_off, u64 a_base, u32 n_q, const u32 *q
 	}
 }
 
-// one wave per 64 buckets of a finished klib pass: recurse, hand over, or finish (ksort.h:121-128).
+// qklib[q] = 1: query q goes through klib's passes (marked minimizers -- or every query, LQCOV_SORT=klib -- and more than 64 anchors)
+__global__ void k_query_klib(const u64 *aq_off, const u32 *qdirty, u32 n_q, int all_klib, u32 *qklib)
+{
+	const u32 q = blockIdx.x * blockDim.x + threadIdx.x;
+	if (q < n_q) qklib[q] = (qdirty[q] || all_klib) && aq_off[q + 1] - aq_off[q] > LQ_RS_MIN ? 1u : 0u;
+}
+
+// one wave per 64 buckets of a finished klib pass over records (Rn = the arrangement the pass left): recurse, hand over,
+// or finish (ksort.h:121-128).
 // Buckets of > 64 elements that received fewer than two marked anchors hold no equal x: they leave klib's passes for the
-// parallel sort above; the others become next-level sub-arrays.  Buckets of <= 64 elements are finished by klib's
-// insertion sort (ksort.h:87-97), which is stable, so its result is the unique stable order by x: the wave finishes them
-// cooperatively instead.  The 64 buckets of a wave are adjacent in memory; whole buckets are packed into chunks of <= 64
-// elements, one element per lane, and every lane ranks its element among the elements of its own bucket (ties by
-// original position) and stores it at that rank.
+// parallel sort above, which gathers their anchors through the records (buf = 2 + rb); the others become next-level
+// sub-arrays.  Buckets of <= 64 elements are finished by klib's insertion sort (ksort.h:87-97), which is stable, so its
+// result is the unique stable order by x: the wave gathers the anchors of whole buckets (adjacent in memory, packed into
+// chunks of <= 64 elements, one element per lane), every lane ranks its element among the elements of its own bucket (ties
+// by position in the arrangement) and writes it to its final place in A.  After the pass on byte 0 everything is final.
 #define LQ_CHILD_THREADS 64
 __global__ void __launch_bounds__(LQ_CHILD_THREADS)
-k_sort_children(const SortSeg *segs, const u32 *n_segs_p, mm128 *A, const u32 *hist, const u32 *mhist, const u32 *begs,
-                SortSeg *next, u32 *n_next, u32 const_levels, PsLists L, KeyMap km, int all_klib)
+k_rs_children(const SortSeg *segs, const u32 *n_segs_p, const RRec *Rn, u32 rb, const mm128 *O, mm128 *A, const u32 *hist, const u32 *mhist, const u32 *begs,
+              SortSeg *next, u32 *n_next, u32 const_levels, PsLists L, KeyMap km, int all_klib)
 {
 	__shared__ u64 xs[64];
 	__shared__ u32 flag[64];
@@ -338,12 +371,12 @@ k_sort_children(const SortSeg *segs, const u32 *n_segs_p, mm128 *A, const u32 *h
 		const u64 t = w * 64 + lane;
 		const u32 sgi = (u32)(t >> 8);
 		const SortSeg sg = segs[sgi];
-		if (sg.shift == 0) continue;                            // (uniform: one sub-array per wave)
 		const u32 n = hist[t], bg = begs[t];
 		if (n > LQ_RS_MIN) {
-			if (mhist[t] < 2 && !all_klib) {
-				PSeg ch; ch.off = sg.off + bg; ch.len = n; ch.rem = (u8)lq_rem_below(sg.shift, km); ch.buf = 0; ch.nbits = 0; ch.pad = 0;
-				if (ch.rem) lq_ps_route(ch, L, LQ_P_BIG0);
+			if (sg.shift == 0 || (mhist[t] < 2 && !all_klib)) {
+				// (after the pass on byte 0 a bucket holds one x: nothing left to sort, the parallel sort's finish brings it home)
+				PSeg ch; ch.off = sg.off + bg; ch.len = n; ch.rem = sg.shift == 0 ? 0 : (u8)lq_rem_below(sg.shift, km); ch.buf = (u8)(2 + rb); ch.nbits = 0; ch.pad = 0;
+				lq_ps_route(ch, L, LQ_P_BIG0);
 			} else {
 				const u32 s = atomicAdd(n_next, 1u);
 				// the next digit that can differ: levels whose byte is the same in every anchor of the part (bits of rid above the
@@ -355,8 +388,9 @@ k_sort_children(const SortSeg *segs, const u32 *n_segs_p, mm128 *A, const u32 *h
 				next[s] = c;
 			}
 		}
+		const RRec *rseg = Rn + sg.off;
 		mm128 *seg = A + sg.off;
-		u64 todo = __ballot(n >= 2 && n <= LQ_RS_MIN);
+		u64 todo = __ballot(n >= 1 && n <= LQ_RS_MIN);
 		while (todo) {                                            // uniform: one chunk of whole buckets per turn
 			const u32 f = (u32)__builtin_ctzll(todo);             // first bucket still to finish
 			const u32 base = __builtin_amdgcn_readlane(bg, f);
@@ -376,7 +410,7 @@ k_sort_children(const SortSeg *segs, const u32 *n_segs_p, mm128 *A, const u32 *h
 			const u32 hi = above ? (u32)__builtin_ctzll(above) : total;
 			const u32 myn = act ? hi - lo : 0;
 			mm128 el; el.x = 0; el.y = 0;
-			if (act) { el = seg[base + i]; xs[i] = el.x; }
+			if (act) { el = O[LQ_R_IDX(rseg[base + i].im)]; xs[i] = el.x; }
 			__syncthreads();
 			u32 rk = 0;
 			for (u32 jj = 0; jj < myn; ++jj) {
@@ -385,7 +419,7 @@ k_sort_children(const SortSeg *segs, const u32 *n_segs_p, mm128 *A, const u32 *h
 				rk += j < i ? (xj <= el.x) : (xj < el.x);
 			}
 			__syncthreads();
-			if (myn > 1 && rk != i - lo) seg[base + lo + rk] = el;
+			if (act) seg[base + lo + rk] = el;
 			todo &= ~fit;
 		}
 	}

@@ -10,18 +10,26 @@
 // klib's pass over a sub-array is a token walk: the token sits on a bucket, takes that bucket's
 // next unread element (original slot order) and jumps to the bucket the element belongs to; an
 // element is written to the next free slot of its own bucket when it is taken; the outer bucket
-// only advances when full.  Only the *digits* (one byte per element) drive the walk, so each level
-// (byte 7 .. byte 0) runs, for all live sub-arrays at once:
-//   k_sort_copy_hist : cooperative copy A->B (the pristine source), digit byte array D, histogram;
+// only advances when full.  Only the *digits* (one byte per element) drive the walk, and the walk of
+// the next level only needs the digits in the arrangement this level leaves behind.  So the 16-byte
+// anchors do not travel through the levels at all: the anchors of a query that needs klib's order
+// stay where the seed stage wrote them (the lane's second buffer, "the originals"), and what the
+// levels permute is an 8-byte record per anchor -- RRec {key = x >> 32 (strand | rid), index of the
+// original | tie mark} -- ping-ponged between two record arrays.  An anchor is written once, to
+// its final place in A, when its bucket is done with klib (kernels_rsort.hpp).  Each level (byte 7
+// .. byte 0) runs, for all live sub-arrays at once:
+//   k_rs_hist        : digit byte array D + histogram + count of marked anchors per bucket, over
+//                      tiles of the sub-arrays (the first level builds the records on the way);
 //   k_sort_classify  : per sub-array: bucket offsets; identity (one bucket), two-bucket, or general;
 //   two-bucket passes (the top level: strand bit) have a closed form -- every element's destination
-//                      follows from two prefix counts -- and run fully parallel (k_two_*);
-//   k_sort_walk      : general passes: one lane per sub-array walks the digit bytes (1 B/element
-//                      instead of 16) with its 256 bucket cursors in LDS ([256][64] u32, lane-minor:
-//                      the 32-lane halves never bank-conflict) and records dst[src];
-//   k_sort_scatter   : A[dst[i]] = B[i], cooperative;
-//   k_sort_children  : buckets > 64 elements become next-level sub-arrays, smaller ones are
-//                      finished with the (stable, hence unique) insertion sort klib uses (ksort.h:87-97).
+//                      follows from two prefix counts -- and run fully parallel (k_sort_two);
+//   k_sort_walk_*    : general passes: a token walk over the digit bytes that records dst[src]
+//                      (here, kernels_walk.hpp; long walks cut at computed states: kernels_ckpt.hpp);
+//   k_rs_scatter     : R'[dst[i]] = R[i], over tiles;
+//   k_rs_children    : buckets > 64 elements become next-level sub-arrays or leave for the parallel
+//                      sort (fewer than two marked anchors: no equal x inside), smaller ones are
+//                      finished with the (stable, hence unique) order of the insertion sort klib uses
+//                      (ksort.h:87-97) and written to A.
 #pragma once
 #include "lq_common.hpp"
 struct CkSeg { u32 sgi, tile0, ck0, n_ck; };      // one long sub-array of a checkpointed pass (kernels_ckpt.hpp): its segment, first prefix tile, first checkpoint, checkpoints
@@ -38,6 +46,25 @@ struct CkSeg { u32 sgi, tile0, ck0, n_ck; };      // one long sub-array of a che
 
 struct SegInfo { u32 kind, c0, c1, cnt0; };
 
+// block-wide exclusive scan of v[0..256) in LDS (256 or more threads; returns with the result in v, total in *tot)
+__device__ __forceinline__ void lq_scan256(u32 *v, u32 *tmp, u32 *tot)
+{
+	const u32 t = threadIdx.x;
+	for (u32 d = 1; d < 256; d <<= 1) {
+		u32 a = 0;
+		if (t < 256) a = v[t] + (t >= d ? v[t - d] : 0);
+		__syncthreads();
+		if (t < 256) v[t] = a;
+		__syncthreads();
+	}
+	if (t < 256) tmp[t] = t ? v[t - 1] : 0;
+	if (t == 255 && tot) *tot = v[255];
+	__syncthreads();
+	if (t < 256) v[t] = tmp[t];
+	__syncthreads();
+}
+
+
 __device__ __forceinline__ void lq_insertion_sort_x(mm128 *a, u32 n)
 {
 	for (u32 i = 1; i < n; ++i) {
@@ -50,39 +77,12 @@ __device__ __forceinline__ void lq_insertion_sort_x(mm128 *a, u32 n)
 	}
 }
 
-// one block per sub-array (strided over the device-side list): B <- A, D <- digit, hist[seg][*] = digit histogram,
-// mhist[seg][*] = how many anchors of each bucket carry LQ_TIE_MARK (both built in LDS, stored once)
-__global__ void k_sort_copy_hist(const SortSeg *segs, const u32 *n_segs_p, const mm128 *A, mm128 *B, u8 *D, u32 *hist, u32 *mhist, unsigned long long *tally)
-{
-	__shared__ u32 lh[256], lm[256];
-	const u32 n_segs = *n_segs_p;
-	for (u32 sgi = blockIdx.x; sgi < n_segs; sgi += gridDim.x) {
-		const SortSeg sg = segs[sgi];
-		const mm128 *a = A + sg.off;
-		mm128 *b = B + sg.off;
-		u8 *d = D + sg.off;
-		if (threadIdx.x == 0 && tally) atomicAdd(tally, (unsigned long long)sg.len);
-		for (u32 c = threadIdx.x; c < 256; c += blockDim.x) { lh[c] = 0; lm[c] = 0; }
-		__syncthreads();
-		for (u32 i = threadIdx.x; i < sg.len; i += blockDim.x) {
-			const mm128 e = a[i];
-			const u32 dg = (u32)(e.x >> sg.shift) & 0xff;
-			b[i] = e; d[i] = (u8)dg;
-			atomicAdd(&lh[dg], 1u);
-			if (e.y & LQ_TIE_MARK) atomicAdd(&lm[dg], 1u);
-		}
-		__syncthreads();
-		for (u32 c = threadIdx.x; c < 256; c += blockDim.x) { hist[(u64)sgi * 256 + c] = lh[c]; mhist[(u64)sgi * 256 + c] = lm[c]; }
-		__syncthreads();
-	}
-}
-
-// ---- the same two streaming kernels over tiles of the sub-arrays -------------------------------------------------
+// ---- tiles of the level's sub-arrays for the streaming kernels -------------------------------------------------------
 // The top passes of a batch have few, long sub-arrays (one per (query, strand) at first: a few hundred of ~10^5..10^6 anchors);
-// one block per sub-array leaves most of the chip idle and every CU with four waves' worth of loads in flight.  Here the level's
-// sub-arrays are cut into tiles of LQ_SORT_TILE anchors (a launch parameter: tests shrink it) (k_sort_tiles: a device-side list, one atomic per wave) and the
-// copy + histogram and the scatter run one block per tile; a sub-array of several tiles adds its tile histograms with atomics
-// into rows zeroed by k_sort_tiles, a sub-array of one tile stores its row as before.
+// one block per sub-array leaves most of the chip idle.  The level's sub-arrays are cut into tiles of LQ_SORT_TILE anchors
+// (a launch parameter: tests shrink it) (k_sort_tiles: a device-side list, one atomic per wave) and the histogram and the
+// scatter run one block per tile; a sub-array of several tiles adds its tile histograms with atomics into rows zeroed by
+// k_sort_tiles, a sub-array of one tile stores its row.
 #define LQ_SORT_TILE 8192
 struct SortTile { u32 sgi, tile; };
 // The tile list in XCD-major order.  Blocks are dealt to the 8 XCDs round-robin (observed, not promised: block b runs on XCD
@@ -111,133 +111,6 @@ k_sort_tiles(const SortSeg *segs, const u32 *n_segs_p, u32 tile, SortTile *tiles
 		const u32 at = wbase + inc - nt;
 		for (u32 t = 0; t < nt; ++t) { SortTile e; e.sgi = sgi; e.tile = t; tiles[at + t] = e; }
 		if (nt > 1) for (u32 c = 0; c < 256; ++c) { hist[(u64)sgi * 256 + c] = 0; mhist[(u64)sgi * 256 + c] = 0; }
-	}
-}
-
-__global__ void __launch_bounds__(256)
-k_sort_copy_hist_tiled(const SortSeg *segs, const SortTile *tiles, const u32 *n_tiles_p, u32 tile, int xcd, const mm128 *A, mm128 *B, u8 *D, u32 *hist, u32 *mhist, unsigned long long *tally)
-{
-	__shared__ u32 lh[256], lm[256];
-	const u32 n_tiles = *n_tiles_p;
-	LQ_TILE_LOOP(ti, n_tiles, xcd) {
-		const SortTile tl = tiles[ti];
-		const SortSeg sg = segs[tl.sgi];
-		const u32 i0 = tl.tile * tile, i1 = sg.len - i0 < tile ? sg.len : i0 + tile;
-		const mm128 *a = A + sg.off;
-		mm128 *b = B + sg.off;
-		u8 *d = D + sg.off;
-		if (tl.tile == 0 && threadIdx.x == 0 && tally) atomicAdd(tally, (unsigned long long)sg.len);
-		for (u32 c = threadIdx.x; c < 256; c += blockDim.x) { lh[c] = 0; lm[c] = 0; }
-		__syncthreads();
-		for (u32 i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
-			const mm128 e = a[i];
-			const u32 dg = (u32)(e.x >> sg.shift) & 0xff;
-			b[i] = e; d[i] = (u8)dg;
-			atomicAdd(&lh[dg], 1u);
-			if (e.y & LQ_TIE_MARK) atomicAdd(&lm[dg], 1u);
-		}
-		__syncthreads();
-		u32 *hrow = hist + (u64)tl.sgi * 256, *mrow = mhist + (u64)tl.sgi * 256;
-		if (sg.len <= tile) {
-			for (u32 c = threadIdx.x; c < 256; c += blockDim.x) { hrow[c] = lh[c]; mrow[c] = lm[c]; }
-		} else {
-			for (u32 c = threadIdx.x; c < 256; c += blockDim.x) { if (lh[c]) atomicAdd(&hrow[c], lh[c]); if (lm[c]) atomicAdd(&mrow[c], lm[c]); }
-		}
-		__syncthreads();
-	}
-}
-
-__global__ void __launch_bounds__(256)
-k_sort_scatter_tiled(const SortSeg *segs, const SegInfo *info, const SortTile *tiles, const u32 *n_tiles_p, u32 tile, int xcd, mm128 *A, const mm128 *B, const u32 *dst, unsigned long long *tally,
-                     unsigned long long *moved)
-{
-	const u32 n_tiles = *n_tiles_p;
-	LQ_TILE_LOOP(ti, n_tiles, xcd) {
-		const SortTile tl = tiles[ti];
-		if (info[tl.sgi].kind == LQ_SEG_IDENTITY) continue;
-		const SortSeg sg = segs[tl.sgi];
-		const u32 i0 = tl.tile * tile, i1 = sg.len - i0 < tile ? sg.len : i0 + tile;
-		uint4 *a = (uint4*)(A + sg.off);                         // (an anchor as one 16-byte register quad)
-		const uint4 *b = (const uint4*)(B + sg.off);
-		const u32 *ds = dst + sg.off;
-		if (tl.tile == 0 && threadIdx.x == 0 && tally) atomicAdd(tally, (unsigned long long)sg.len);
-		u32 i = i0 + threadIdx.x, nm = 0;
-		// An element that stays where it is (klib leaves the elements of a bucket's own region alone: half of a two-bucket
-		// pass, a quarter of a four-bucket one) is neither read nor written: A still holds it.
-		for (; i + 3 * 256 < i1; i += 4 * 256) {                 // four independent loads in flight per thread
-			const u32 d0 = ds[i], d1 = ds[i + 256], d2 = ds[i + 512], d3 = ds[i + 768];
-			const bool m0 = d0 != i, m1 = d1 != i + 256, m2 = d2 != i + 512, m3 = d3 != i + 768;
-			uint4 e0 = {}, e1 = {}, e2 = {}, e3 = {};
-			if (m0) e0 = b[i];
-			if (m1) e1 = b[i + 256];
-			if (m2) e2 = b[i + 512];
-			if (m3) e3 = b[i + 768];
-			if (m0) a[d0] = e0;
-			if (m1) a[d1] = e1;
-			if (m2) a[d2] = e2;
-			if (m3) a[d3] = e3;
-			nm += (u32)m0 + (u32)m1 + (u32)m2 + (u32)m3;
-		}
-		for (; i < i1; i += 256) { const u32 d = ds[i]; if (d != i) { a[d] = b[i]; ++nm; } }
-		if (moved) {
-			for (int o = 32; o > 0; o >>= 1) nm += __shfl_down(nm, o);
-			if ((threadIdx.x & 63) == 0 && nm) atomicAdd(moved, (unsigned long long)nm);
-		}
-	}
-}
-
-// The same move as a gather (LQCOV_SCATTER=gather, to be measured against the scatter): the permutation is inverted first
-// (4-byte stores into the destination streams instead of 16-byte ones), then every destination slot reads its anchor: the
-// 16-byte stores become sequential, the scattered side becomes 16-byte reads, which caches can serve.
-__global__ void __launch_bounds__(256)
-k_sort_invert_tiled(const SortSeg *segs, const SegInfo *info, const SortTile *tiles, const u32 *n_tiles_p, u32 tile, int xcd, const u32 *dst, u32 *inv)
-{
-	const u32 n_tiles = *n_tiles_p;
-	LQ_TILE_LOOP(ti, n_tiles, xcd) {
-		const SortTile tl = tiles[ti];
-		if (info[tl.sgi].kind == LQ_SEG_IDENTITY) continue;
-		const SortSeg sg = segs[tl.sgi];
-		const u32 i0 = tl.tile * tile, i1 = sg.len - i0 < tile ? sg.len : i0 + tile;
-		const u32 *ds = dst + sg.off;
-		u32 *iv = inv + sg.off;
-		for (u32 i = i0 + threadIdx.x; i < i1; i += 256) iv[ds[i]] = i;
-	}
-}
-
-__global__ void __launch_bounds__(256)
-k_sort_gather_tiled(const SortSeg *segs, const SegInfo *info, const SortTile *tiles, const u32 *n_tiles_p, u32 tile, int xcd, mm128 *A, const mm128 *B, const u32 *inv,
-                    unsigned long long *tally, unsigned long long *moved)
-{
-	const u32 n_tiles = *n_tiles_p;
-	LQ_TILE_LOOP(ti, n_tiles, xcd) {
-		const SortTile tl = tiles[ti];
-		if (info[tl.sgi].kind == LQ_SEG_IDENTITY) continue;
-		const SortSeg sg = segs[tl.sgi];
-		const u32 i0 = tl.tile * tile, i1 = sg.len - i0 < tile ? sg.len : i0 + tile;
-		uint4 *a = (uint4*)(A + sg.off);
-		const uint4 *b = (const uint4*)(B + sg.off);
-		const u32 *iv = inv + sg.off;
-		if (tl.tile == 0 && threadIdx.x == 0 && tally) atomicAdd(tally, (unsigned long long)sg.len);
-		u32 j = i0 + threadIdx.x, nm = 0;
-		for (; j + 3 * 256 < i1; j += 4 * 256) {
-			const u32 s0 = iv[j], s1 = iv[j + 256], s2 = iv[j + 512], s3 = iv[j + 768];
-			const bool m0 = s0 != j, m1 = s1 != j + 256, m2 = s2 != j + 512, m3 = s3 != j + 768;
-			uint4 e0 = {}, e1 = {}, e2 = {}, e3 = {};
-			if (m0) e0 = b[s0];
-			if (m1) e1 = b[s1];
-			if (m2) e2 = b[s2];
-			if (m3) e3 = b[s3];
-			if (m0) a[j] = e0;
-			if (m1) a[j + 256] = e1;
-			if (m2) a[j + 512] = e2;
-			if (m3) a[j + 768] = e3;
-			nm += (u32)m0 + (u32)m1 + (u32)m2 + (u32)m3;
-		}
-		for (; j < i1; j += 256) { const u32 sidx = iv[j]; if (sidx != j) { a[j] = b[sidx]; ++nm; } }
-		if (moved) {
-			for (int o = 32; o > 0; o >>= 1) nm += __shfl_down(nm, o);
-			if ((threadIdx.x & 63) == 0 && nm) atomicAdd(moved, (unsigned long long)nm);
-		}
 	}
 }
 
@@ -403,121 +276,6 @@ k_sort_two(const SortSeg *segs, const SegInfo *info, const u32 *two_list, const 
 	}
 }
 
-// ---- the two-bucket pass over tiles ---------------------------------------------------------------------------------
-// The strand pass at the top of every (query) array is a two-bucket pass over the whole array: one block per sub-array
-// (k_sort_two) is a few hundred blocks walking ~10^5..10^6 digits each in a serial loop of tiles.  Here: k_two_tiles lists the
-// tiles of the two-bucket sub-arrays (contiguous per sub-array, first index in tile0[]), <0> counts the X / Y elements of every
-// tile, one wave per sub-array scans its tile counts (k_sort_two_scan; the total is m), <1> writes the position lists HX / PY
-// at tile base + rank, <2> the destinations -- the formulas of k_sort_two above, the ranks from the scanned tile counts.
-__global__ void __launch_bounds__(256)
-k_two_tiles(const SortSeg *segs, const u32 *two_list, const u32 *n_two_p, u32 tile, SortTile *tiles, u32 *n_tiles, u32 *tile0)
-{
-	const u32 n_two = *n_two_p;
-	const u32 lane = threadIdx.x & 63;
-	for (u32 base = blockIdx.x * blockDim.x; base < n_two; base += gridDim.x * blockDim.x) {
-		const u32 li = base + threadIdx.x;
-		u32 nt = 0, sgi = 0;
-		if (li < n_two) { sgi = two_list[li]; nt = (segs[sgi].len + tile - 1) / tile; }
-		u32 inc = nt;
-		for (int d = 1; d < 64; d <<= 1) { const u32 o = __shfl_up(inc, d); if ((int)lane >= d) inc += o; }
-		u32 wbase = 0;
-		if (lane == 63 && inc) wbase = atomicAdd(n_tiles, inc);
-		wbase = __shfl(wbase, 63);
-		const u32 at = wbase + inc - nt;
-		if (li < n_two) tile0[sgi] = at;
-		for (u32 t = 0; t < nt; ++t) { SortTile e; e.sgi = sgi; e.tile = t; tiles[at + t] = e; }
-	}
-}
-
-// exclusive scan of one sub-array's tile counts (X, Y interleaved), one wave per sub-array; two_m[sgi] = number of X (= of Y)
-__global__ void __launch_bounds__(64)
-k_sort_two_scan(const SortSeg *segs, const u32 *two_list, const u32 *n_two_p, u32 tile, const u32 *tile0, u32 *tcnt, u32 *two_m)
-{
-	const u32 n_two = *n_two_p, lane = threadIdx.x;
-	for (u32 li = blockIdx.x; li < n_two; li += gridDim.x) {
-		const u32 sgi = two_list[li];
-		const u32 nt = (segs[sgi].len + tile - 1) / tile;
-		u32 *c = tcnt + 2 * (u64)tile0[sgi];
-		const u32 per = (nt + 63) / 64, a = lane * per < nt ? lane * per : nt, b = a + per < nt ? a + per : nt;
-		u32 sx = 0, sy = 0;
-		for (u32 x = a; x < b; ++x) { sx += c[2 * x]; sy += c[2 * x + 1]; }
-		u32 ix = sx, iy = sy;
-		for (int d = 1; d < 64; d <<= 1) { const u32 ox = __shfl_up(ix, d), oy = __shfl_up(iy, d); if ((int)lane >= d) { ix += ox; iy += oy; } }
-		u32 rx = ix - sx, ry = iy - sy;
-		for (u32 x = a; x < b; ++x) { const u32 vx = c[2 * x], vy = c[2 * x + 1]; c[2 * x] = rx; c[2 * x + 1] = ry; rx += vx; ry += vy; }
-		if (lane == 63) two_m[sgi] = ix;
-	}
-}
-
-template <int MODE>   // 0: count, 1: position lists, 2: destinations
-__global__ void __launch_bounds__(256)
-k_sort_two_tiled(const SortSeg *segs, const SegInfo *info, const SortTile *tiles, const u32 *n_tiles_p, u32 tile, const u8 *D,
-                 u32 *tcnt, const u32 *two_m, u32 *HX, u32 *PY, u32 *dst)
-{
-	__shared__ u32 wx[4], wy[4];
-	const u32 t = threadIdx.x, lane = t & 63, wv = t >> 6;
-	const u32 n_tiles = *n_tiles_p;
-	for (u32 ti = blockIdx.x; ti < n_tiles; ti += gridDim.x) {
-		const SortTile tl = tiles[ti];
-		const SortSeg sg = segs[tl.sgi];
-		const SegInfo si = info[tl.sgi];
-		const u64 off = sg.off;
-		const u32 i0 = tl.tile * tile, i1 = sg.len - i0 < tile ? sg.len : i0 + tile;
-		const u64 lo = off + i0, hi = off + i1, a0 = lo & ~(u64)15;
-		const u32 n_words = (u32)((hi - a0 + 15) >> 4);
-		const u32 cnt0 = si.cnt0, c1 = si.c1;
-		u32 bx = 0, by = 0, m = 0;                              // X / Y elements before the words at hand
-		if (MODE) { bx = tcnt[2 * (u64)ti]; by = tcnt[2 * (u64)ti + 1]; }
-		if (MODE == 2) m = two_m[tl.sgi];
-		u32 *hx = HX + off, *py = PY + off;
-		for (u32 w0 = 0; w0 < n_words; w0 += 256) {
-			const u32 wi = w0 + t;
-			const u64 p = a0 + (u64)wi * 16;
-			TwoW16 W; W.w[0] = W.w[1] = W.w[2] = W.w[3] = 0;
-			u32 cx = 0, cy = 0;
-			if (wi < n_words) {
-				W = *(const TwoW16*)(D + p);
-				for (u32 k = 0; k < 16; ++k) {
-					const u64 g = p + k;
-					if (g >= lo && g < hi) { const u32 i = (u32)(g - off); const bool in0 = i < cnt0, is1 = LQ_TWO_DIGIT(W, k) == c1; cx += in0 && is1; cy += !in0 && !is1; }
-				}
-			}
-			// exclusive ranks of this thread's word among the 256 words at hand, and their totals
-			u32 ix = cx, iy = cy;
-			for (int d = 1; d < 64; d <<= 1) { const u32 ox = __shfl_up(ix, d), oy = __shfl_up(iy, d); if ((int)lane >= d) { ix += ox; iy += oy; } }
-			if (lane == 63) { wx[wv] = ix; wy[wv] = iy; }
-			__syncthreads();
-			u32 rx = bx + ix - cx, ry = by + iy - cy, tx = 0, ty = 0;
-			for (u32 q = 0; q < 4; ++q) { if (q < wv) { rx += wx[q]; ry += wy[q]; } tx += wx[q]; ty += wy[q]; }
-			if (MODE && wi < n_words) {
-				for (u32 k = 0; k < 16; ++k) {
-					const u64 g = p + k;
-					if (g >= lo && g < hi) {
-						const u32 i = (u32)(g - off); const bool in0 = i < cnt0, is1 = LQ_TWO_DIGIT(W, k) == c1;
-						if (MODE == 1) {
-							if (in0 && is1) hx[rx++] = i;
-							else if (!in0 && !is1) py[ry++] = i;
-						} else {
-							u32 d;
-							if (in0) {
-								if (!is1) d = i;
-								else { d = rx == 0 ? cnt0 : py[rx - 1] + 1; ++rx; }      // X_t takes the first slot of run t
-							} else {
-								if (!is1) { d = hx[ry]; ++ry; }                           // Y_t drops into the hole of X_t
-								else d = ry < m ? i + 1 : i;                              // run elements shift right by one
-							}
-							dst[g] = d;
-						}
-					}
-				}
-			}
-			bx += tx; by += ty;
-			__syncthreads();
-		}
-		if (MODE == 0 && t == 0) { tcnt[2 * (u64)ti] = bx; tcnt[2 * (u64)ti + 1] = by; }
-	}
-}
-
 // ---- general pass: the token walk over digit bytes ---------------------------------------------
 // The same walk with the sub-array's digits staged in LDS: one block per sub-array; all threads load the
 // digit bytes, then one lane walks.  Each bucket keeps {cursor (24 bit), digit of the element under the cursor
@@ -633,7 +391,7 @@ __device__ __forceinline__ u64 lq_lds_u64(const u64 *p)
 #define LQ_SOLO_PEND 0x80000000u
 __global__ void __launch_bounds__(64)
 k_sort_walk_solo(const SortSeg *segs, const u32 *list, const u32 *n_list_p, const u8 *D, const u32 *hist, const u32 *begs, u32 *dst,
-                 const CkSeg *cks, u32 n_cks, const u32 *ck_S, const u32 *ck_slot)
+                 const CkSeg *cks, const u32 *ckn, const u32 *ck_S, const u32 *ck_slot)
 {
 	LQ_SHARED __attribute__((aligned(16))) u8 win[256][16];   // DMA landing windows: 16 digits of each bucket's stream
 	LQ_SHARED u64 ent[256];                                   // low: cursor | PEND, high: the digits from the cursor to the next 4-byte boundary
@@ -645,7 +403,7 @@ k_sort_walk_solo(const SortSeg *segs, const u32 *list, const u32 *n_list_p, cons
 	u32 sgi, s_end = 0xffffffffu;
 	const u32 *start = nullptr;
 	if (cks) {
-		u32 lo = 0, hi = n_cks;
+		u32 lo = 0, hi = ckn[1];
 		while (hi - lo > 1) { const u32 mid = lo + ((hi - lo) >> 1); if (cks[mid].ck0 <= li) lo = mid; else hi = mid; }
 		sgi = cks[lo].sgi;
 		start = ck_S + (u64)li * 256;
@@ -706,17 +464,3 @@ k_sort_walk_solo(const SortSeg *segs, const u32 *list, const u32 *n_list_p, cons
 	}
 }
 
-// one block per sub-array (strided): A[dst[i]] = B[i]  (identity passes are skipped)
-__global__ void k_sort_scatter(const SortSeg *segs, const SegInfo *info, const u32 *n_segs_p, mm128 *A, const mm128 *B, const u32 *dst, unsigned long long *tally)
-{
-	const u32 n_segs = *n_segs_p;
-	for (u32 sgi = blockIdx.x; sgi < n_segs; sgi += gridDim.x) {
-		if (info[sgi].kind == LQ_SEG_IDENTITY) continue;
-		const SortSeg sg = segs[sgi];
-		mm128 *a = A + sg.off;
-		const mm128 *b = B + sg.off;
-		const u32 *ds = dst + sg.off;
-		if (threadIdx.x == 0 && tally) atomicAdd(tally, (unsigned long long)sg.len);
-		for (u32 i = threadIdx.x; i < sg.len; i += blockDim.x) a[ds[i]] = b[i];
-	}
-}

@@ -64,7 +64,7 @@ static inline void lq_walk_dma16(const u8 *g, u8 *lds) { LQ_DMA_WIN16(g, lds); }
 template <int NG>
 __global__ void __launch_bounds__(64)
 k_sort_walk_reg(const SortSeg *segs, const u32 *list, const u32 *n_list_p, const u8 *D, const u32 *hist, const u32 *begs, u32 *dst,
-                const CkSeg *cks, u32 n_cks, const u32 *ck_S, const u32 *ck_slot)
+                const CkSeg *cks, const u32 *ckn, const u32 *ck_S, const u32 *ck_slot)
 {
 	LQ_SHARED __attribute__((aligned(16))) u8 win[NG * 64][16];   // DMA landing windows: 16 digits of each bucket's stream
 	const u32 n_list = *n_list_p;
@@ -73,7 +73,7 @@ k_sort_walk_reg(const SortSeg *segs, const u32 *list, const u32 *n_list_p, const
 		u32 sgi, s_end = 0xffffffffu;
 		const u32 *start = nullptr;
 		if (cks) {
-			u32 lo = 0, hi = n_cks;
+			u32 lo = 0, hi = ckn[1];
 			while (hi - lo > 1) { const u32 mid = lo + ((hi - lo) >> 1); if (cks[mid].ck0 <= li) lo = mid; else hi = mid; }
 			sgi = cks[lo].sgi;
 			start = ck_S + (u64)li * LQ_CK_B;

@@ -50,8 +50,25 @@ class LqCovExec:
         self._rc = None
         self._err_path = None
         self.out_path = None
+        self._tmp = []                    # files made for output the caller did not name: removed by close() / on collection
+
+    def close(self):
+        """remove the files that stood in for pipes the caller never named (the reference drops that output too)"""
+        for fn in self._tmp:
+            try:
+                os.unlink(fn)
+            except OSError:
+                pass
+        self._tmp = []
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def exec(self, *args, out=None, err=None):
+        self.close()
         self._err_path = err
         self._rc = None
         if self.subprocess_mode:
@@ -71,8 +88,10 @@ class LqCovExec:
         # its own instead of the host process's stdout / stderr
         if out is None:
             out = self.out_path = tempfile.NamedTemporaryFile(prefix="lqcov_out_", suffix=".tsv", delete=False).name
+            self._tmp.append(out)
         if err is None:
             err = self._err_path = tempfile.NamedTemporaryFile(prefix="lqcov_err_", suffix=".log", delete=False).name
+            self._tmp.append(err)
 
         def work():
             try:

@@ -47,10 +47,11 @@ def test_emulated_tables_read_like_the_reference_consumer(emu_lib, tmp_path):
 
 
 @pytest.mark.parametrize("case", [c for c in _cases("table") if c["name"] in ("tiny_ont", "adv_ont", "adv_parts", "adv_defaults")], ids=lambda c: c["name"])
-@pytest.mark.parametrize("tile", ["64", "8192"])
-def test_emulated_two_bucket_pass_over_tiles(emu_lib, case, tile, monkeypatch):
-    """LQCOV_TWO_TILES=1: the strand pass of every dirty query as count / scan / list / destination kernels over tiles"""
-    monkeypatch.setenv("LQCOV_TWO_TILES", "1"); monkeypatch.setenv("LQCOV_SORT_TILE", tile); monkeypatch.setenv("LQCOV_SORT", "klib")
+@pytest.mark.parametrize("tile", ["64", "1000"])
+def test_emulated_every_query_through_klib_passes(emu_lib, case, tile, monkeypatch):
+    """LQCOV_SORT=klib: every query goes through klib's passes as 8-byte records, no bucket leaves them early (the passes on
+    the bytes of the position run too, reading their digits from the originals); streaming kernels over many small tiles"""
+    monkeypatch.setenv("LQCOV_SORT_TILE", tile); monkeypatch.setenv("LQCOV_SORT", "klib")
     rc, out, err = run_main(emu_lib, case["argv"], cwd=GOLDEN)
     assert rc == 0, err
     assert out == read_gz(case["expect"])
@@ -357,14 +358,11 @@ def check_run_list_variants(lib, tmp_path, monkeypatch):
     argv = ["-Y", "-l", "0", "-q", "40", "-k", "12", "-w", "5", "-I", "4G", "-p", "40", "-m", "20", "-t", "4", tf, qf]
     want = oracle_bind.ref_table(argv) if oracle_bind.have_ref() else oracle_bind.table(argv)
     assert sum(1 for l in want.splitlines() if l.split("\t")[2] != "0") >= 100
-    for runs in ("", "scan", "compact"):           # two light passes over the anchors (default) | round 1's head / id arrays | + dense list of short runs
-        monkeypatch.setenv("LQCOV_RUNS", "" if runs == "compact" else runs)
-        monkeypatch.setenv("LQCOV_CHAIN_COMPACT", "1" if runs == "compact" else "0")
-        for budget in ("", "3000"):                # one batch | batches of a few queries (run lists of a few tiles)
-            monkeypatch.setenv("LQCOV_ANCHOR_BUDGET", budget) if budget else monkeypatch.delenv("LQCOV_ANCHOR_BUDGET", raising=False)
-            rc, out, err = run_main(lib, argv)
-            assert rc == 0, err
-            assert out == want, (runs, budget)
+    for budget in ("", "3000"):                    # one batch | batches of a few queries (run lists of a few tiles)
+        monkeypatch.setenv("LQCOV_ANCHOR_BUDGET", budget) if budget else monkeypatch.delenv("LQCOV_ANCHOR_BUDGET", raising=False)
+        rc, out, err = run_main(lib, argv)
+        assert rc == 0, err
+        assert out == want, budget
 
 
 def test_emulated_run_list_variants(emu_lib, tmp_path, monkeypatch):
@@ -404,7 +402,7 @@ def _repeat_rich_dataset(tmp_path, seed, n_targets=60, n_queries=8, glen=40000):
     return tf, qf
 
 
-def check_repeat_rich_randomised(lib, tmp_path, monkeypatch, seed, two_tiles=False):
+def check_repeat_rich_randomised(lib, tmp_path, monkeypatch, seed):
     tf, qf = _repeat_rich_dataset(tmp_path, seed)
     argv = ONT + [tf, qf]
     want = oracle_bind.ref_table(argv) if oracle_bind.have_ref() else oracle_bind.table(argv)
@@ -412,9 +410,6 @@ def check_repeat_rich_randomised(lib, tmp_path, monkeypatch, seed, two_tiles=Fal
     monkeypatch.setenv("LQCOV_WALK_SHIFT", str([0, 4, 7, 10][seed % 4]))
     monkeypatch.setenv("LQCOV_PS_SHIFT", str([0, 3, 7][seed % 3]))
     monkeypatch.setenv("LQCOV_SORT_TILE", str([8192, 64, 1000][seed % 3]))      # tiles of the streaming kernels: one per sub-array | many
-    monkeypatch.setenv("LQCOV_TWO_TILES", "1" if two_tiles else "0")             # the two-bucket pass over tiles (off by default until measured)
-    monkeypatch.setenv("LQCOV_SCATTER", "gather" if two_tiles and seed == 2 else "scatter")   # the move as a gather (likewise)
-    monkeypatch.setenv("LQCOV_CK_SEGS", str([1, 4, 16][seed % 3]) if two_tiles else "1")      # coarse parts of the many-bucket checkpoint solver (likewise)
     monkeypatch.setenv("LQCOV_CKPT3", str(seed & 1))          # odd seeds: checkpoints for the second-longest class of many-bucket passes too
     rc, out, err = run_main(lib, argv)
     assert rc == 0, err
@@ -427,7 +422,7 @@ def test_emulated_repeat_rich_randomised(emu_lib, tmp_path, monkeypatch, seed):
     """equal-x anchors everywhere (repeats inside the queries): rows equal the reference binary's, whichever path the sub-arrays
     take (parallel passes for those without a tie, klib's walk for the others); and the input has teeth: a stable sort by x
     gives a different table"""
-    argv, want = check_repeat_rich_randomised(emu_lib, tmp_path, monkeypatch, seed, two_tiles=seed != 0)
+    argv, want = check_repeat_rich_randomised(emu_lib, tmp_path, monkeypatch, seed)
     assert sum(1 for l in want.splitlines() if l.split("\t")[2] != "0") >= 4
     if seed == 0:
         assert oracle_bind.table(argv, ["--stable-sort"]) != want
@@ -450,3 +445,39 @@ def test_emulated_ultra_long_reads(emu_lib, tmp_path):
     assert rc == 0, err
     want = oracle_bind.ref_table(argv) if oracle_bind.have_ref() else oracle_bind.table(argv)
     assert out == want
+
+
+def _one_long_pair_among_many_targets(tmp_path, n_small=6000, seed=3):
+    """6000 random 200-base targets plus one 30-kb read; the query is a 99.9 % copy of it: one tie-free (strand, rid) sub-array of
+    more than 8192 anchors whose compact key agrees in its top 1 + 13 bits -- the parallel sort has to step over the constant bits
+    (round-2 advisor: the fixed six partition passes never reached the position bits and the run ended with rc -5)"""
+    from longqc_amd import synth
+    rng = np.random.default_rng(seed)
+    A = synth._ACGT
+    names, seqs = [], []
+    for i in range(n_small):
+        names.append("s%05d" % i); seqs.append(A[rng.integers(0, 4, size=200, dtype=np.uint8)])
+    long_read = A[rng.integers(0, 4, size=30000, dtype=np.uint8)]
+    names.insert(n_small // 2, "long"); seqs.insert(n_small // 2, long_read)
+    q = long_read.copy()
+    for p in rng.choice(q.shape[0], size=30, replace=False):
+        q[p] = A[(int(np.where(A == q[p])[0][0]) + 1) % 4]
+    T = synth.ReadSet(names, seqs, [np.full(s.shape[0], 40 + 33, dtype=np.uint8) for s in seqs])
+    Q = synth.ReadSet(["qcopy"], [q], [np.full(q.shape[0], 40 + 33, dtype=np.uint8)])
+    tf, qf = str(tmp_path / "many_all.fq"), str(tmp_path / "many_sub.fq")
+    synth.write_fastq(tf, T); synth.write_fastq(qf, Q)
+    return tf, qf
+
+
+def check_long_pair_among_many_targets(lib, tmp_path):
+    tf, qf = _one_long_pair_among_many_targets(tmp_path)
+    argv = ["-Y", "-l", "0", "-q", "160", "-k", "15", "-w", "5", "-I", "4G", "-p", "160", "-t", "4", tf, qf]
+    want = oracle_bind.ref_table(argv) if oracle_bind.have_ref() else oracle_bind.table(argv)
+    assert int(want.split("\t")[2]) > 0
+    rc, out, err = run_main(lib, argv)
+    assert rc == 0, err
+    assert out == want
+
+
+def test_emulated_long_pair_among_many_targets(emu_lib, tmp_path):
+    check_long_pair_among_many_targets(emu_lib, tmp_path)

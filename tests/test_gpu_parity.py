@@ -240,9 +240,7 @@ def test_gpu_run_list_variants(gpu_lib, tmp_path, monkeypatch):
 
 @pytest.mark.parametrize("seed", list(range(3, 11)))
 def test_gpu_repeat_rich_randomised(gpu_lib, tmp_path, monkeypatch, seed):
-    # LQCOV_TEST_UNMEASURED=1: also the variants that were written after the last GPU run of their round (tiled two-bucket pass,
-    # gather, coarse parts of the checkpoint solver): first on the GPU by hand, in the default suite once they are defaults
-    E.check_repeat_rich_randomised(gpu_lib, tmp_path, monkeypatch, seed, two_tiles=os.environ.get("LQCOV_TEST_UNMEASURED") == "1")
+    E.check_repeat_rich_randomised(gpu_lib, tmp_path, monkeypatch, seed)
 
 
 @pytest.mark.parametrize("variant", ["ckpt", "ckpt_all_klib", "plain"])
