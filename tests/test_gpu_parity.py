@@ -222,6 +222,68 @@ def test_gpu_ultra_long_reads_vs_reference(gpu_lib, tmp_path):
     assert out == want
 
 
+def test_gpu_ultra_long_reads_2000_vs_reference(gpu_lib, tmp_path):
+    """a larger slice of the shape of BASELINE configs[4]: 2 000 reads of N50 ~100 kb (120 Mbases, 30x) and the 200-read
+    reservoir subsample as queries -- (query, target) runs of 10^4 anchors that the parallel sort has to order by position
+    after stepping over 11 constant bits of rid -- against the reference binary"""
+    import dataclasses
+    cfg = dataclasses.replace(synth.CONFIGS["cfg5"], n_reads=2000, nsample=200, depth=30.0)
+    T, Q = synth.make_dataset(cfg)
+    assert len(Q) == 200 and max(int(s.shape[0]) for s in T.seqs) > 300000
+    tf, qf = str(tmp_path / "all.fq"), str(tmp_path / "sub.fq")
+    synth.write_fastq(tf, T); synth.write_fastq(qf, Q)
+    argv = ONT[:-2] + ["-t", str(os.cpu_count() or 4), tf, qf]
+    rc, out, err = run_main(gpu_lib, argv)
+    assert rc == 0, err
+    want = oracle_bind.ref_table(argv) if oracle_bind.have_ref() else oracle_bind.table(argv)
+    assert out == want
+
+
+def test_gpu_many_parts_at_real_read_lengths_vs_reference(gpu_lib, tmp_path):
+    """the shape of BASELINE configs[3] (5 M ONT reads ~20 kb 40x, ont-rapid preset, 25 index parts of 4 Gbases): 0.25 % of the
+    reads (12 500, 0.25 Gbases) with -I scaled likewise (20M), so that the reference's rule (index.c:244,311-316) cuts a dozen
+    parts at real read lengths: the long part loop (minimap2-coverage.c:449-458), mid_occ frozen by the first part (map.c:50),
+    COVT and avg_k carried across the parts (esterr.c:87-97); 200 queries, table against the reference binary"""
+    import dataclasses
+    cfg = dataclasses.replace(synth.CONFIGS["cfg4"], n_reads=12500, nsample=200)
+    T, Q = synth.make_dataset(cfg)
+    assert len(Q) == 200
+    tf, qf = str(tmp_path / "all.fq"), str(tmp_path / "sub.fq")
+    synth.write_fastq(tf, T); synth.write_fastq(qf, Q)
+    argv = ["-Y", "-l", "0", "-q", "160", "-k", "12", "-w", "5", "-I", "20M", "-p", "160", "-t", str(os.cpu_count() or 4), tf, qf]
+    rc, out, err = run_main(gpu_lib, argv)
+    assert rc == 0, err
+    assert sum(1 for l in err.splitlines() if "mapped" in l) >= 8, err
+    want = oracle_bind.ref_table(argv) if oracle_bind.have_ref() else oracle_bind.table(argv)
+    assert out == want
+    rows = out.splitlines()
+    assert len(rows) == 200 and sum(1 for r in rows if r.split("\t")[2] != "0") > 150
+
+
+def test_gpu_long_pair_among_many_targets(gpu_lib, tmp_path):
+    E.check_long_pair_among_many_targets(gpu_lib, tmp_path)
+
+
+@pytest.mark.parametrize("env", [{"LQCOV_CKPT3": "1"}, {"LQCOV_WALK": "solo"}, {"LQCOV_CKPT": "0"}, {"LQCOV_SORT": "klib"}, {"LQCOV_SKETCH_KPT": "1"},
+                                 {"LQCOV_LANES": "2", "LQCOV_ANCHOR_BUDGET": "400000"}], ids=lambda e: "+".join("%s=%s" % kv for kv in e.items()))
+def test_gpu_every_shipped_switch_on_a_midsize_slice(gpu_lib, tmp_path, monkeypatch, env):
+    """every switch that selects other kernels than the defaults (checkpoints for the second-longest class, solo walkers only,
+    no checkpoints, every query through klib's passes, one chunk per sketch thread, two lanes over small batches) on 1 500 ONT
+    reads ~15 kb with 300 queries: no kernel of liblqcov.so stays unexecuted by the suite"""
+    import dataclasses
+    cfg = dataclasses.replace(synth.CONFIGS["cfg2"], n_reads=1500, nsample=300, depth=15.0)
+    T, Q = synth.make_dataset(cfg)
+    tf, qf = str(tmp_path / "all.fq"), str(tmp_path / "sub.fq")
+    synth.write_fastq(tf, T); synth.write_fastq(qf, Q)
+    argv = ONT + [tf, qf]
+    want = oracle_bind.ref_table(argv) if oracle_bind.have_ref() else oracle_bind.table(argv)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    rc, out, err = run_main(gpu_lib, argv)
+    assert rc == 0, err
+    assert out == want
+
+
 @pytest.mark.parametrize("shift", ["3", "7"])
 def test_gpu_parallel_sort_size_classes(gpu_lib, datasets, monkeypatch, shift):
     """the parallel sort (kernels_psort.hpp) with its size classes shrunk: several partition passes on small inputs"""
