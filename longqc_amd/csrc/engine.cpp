@@ -93,6 +93,7 @@ void Knobs::read_env()
 	no_level_skip = getenv("LQCOV_NO_LEVEL_SKIP") != nullptr;
 	debug_sort = getenv("LQCOV_DEBUG_SORT") != nullptr;
 	sketch_kpt = (u32)std::min<long>(64, std::max<long>(1, num("LQCOV_SKETCH_KPT", 4)));
+	sketch_machine_only = is("LQCOV_SKETCH", "machine");
 }
 
 lqcov_handle::lqcov_handle(const lqcov_params &p, int dev) : P(p), device(dev)
@@ -113,15 +114,8 @@ lqcov_handle::lqcov_handle(const lqcov_params &p, int dev) : P(p), device(dev)
 	mp.max_overhang = P.max_overhang; mp.min_coverage = P.min_coverage; mp.min_ratio = P.min_ratio;
 	mp.no_self = P.no_self; mp.ava = P.ava;
 	K.read_env();
-	anchor_budget = K.anchor_budget;
+	anchor_budget = K.anchor_budget;                        // 0: from the free HBM when the first part is mapped (map_part)
 	n_lanes = K.lanes;
-	if (anchor_budget == 0) {
-		size_t fr = 0, tot = 0;
-		hipMemGetInfo(&fr, &tot);
-		anchor_budget = (u64)(fr / 5 * 4 / 112 / n_lanes);  // ~86 B of work space per anchor + per-sub-array tables, 80% of free HBM
-	}
-	if (anchor_budget > (1ULL << 31) - 4096) anchor_budget = (1ULL << 31) - 4096;   // (a record names its anchor in 31 bits)
-	if (anchor_budget < 1024) anchor_budget = 1024;
 }
 
 lqcov_handle::~lqcov_handle()
@@ -299,36 +293,54 @@ void lqcov_handle::sketch(ReadSetDev &rs, bool rid_in_y)
 		cnt.ensure(nc * 4); off.ensure(nc * 8);
 		const u64 in_bytes = nc * (LQ_CHUNK_WORDS * 12);
 		// ring capacity 8 / 16 (LDS) or 256 (private), -H on/off: pick the instantiation
-		// chunks per thread: the halo before a thread's first chunk is walked once per kpt chunks (LQCOV_SKETCH_KPT=1: every chunk its own thread, as measured in round 2)
+		// chunks per thread: the halo before a thread's first chunk is walked once per kpt chunks
 		const u32 kpt = K.sketch_kpt;
-#define LQ_SK_LAUNCH(RC, EM, HP, BS, ...) LQ_LAUNCH((k_sketch<RC, EM, HP>), nblk((nc + kpt - 1) / kpt, BS), BS, stream, rs.codes.as<u64>(), rs.amb.as<u32>(), rs.d_coff.as<u64>(), rs.d_len.as<u32>(), rs.n, nc, kpt, sp, (int)rid_in_y, __VA_ARGS__, dp_owned)
-#define LQ_SK_DISPATCH(EM, ...) do { \
-		if (P.w <= 8)       { if (P.hpc) LQ_SK_LAUNCH(8, EM, true, LQ_SK_BLOCK, __VA_ARGS__);   else LQ_SK_LAUNCH(8, EM, false, LQ_SK_BLOCK, __VA_ARGS__); } \
-		else if (P.w <= 16) { if (P.hpc) LQ_SK_LAUNCH(16, EM, true, LQ_SK_BLOCK, __VA_ARGS__);  else LQ_SK_LAUNCH(16, EM, false, LQ_SK_BLOCK, __VA_ARGS__); } \
-		else                { if (P.hpc) LQ_SK_LAUNCH(256, EM, true, 64, __VA_ARGS__);          else LQ_SK_LAUNCH(256, EM, false, 64, __VA_ARGS__); } \
+#define LQ_SK_LAUNCH(RC, EM, HP, BS, ...) LQ_LAUNCH((k_sketch<RC, EM, HP>), nblk((nc + kpt - 1) / kpt, BS), BS, stream, rs.codes.as<u64>(), rs.amb.as<u32>(), rs.d_coff.as<u64>(), rs.d_len.as<u32>(), rs.n, nc, kpt, sp, (int)rid_in_y, __VA_ARGS__)
+#define LQ_SK_DISPATCH(EM, HP, ...) do { \
+		if (P.w <= 8)       LQ_SK_LAUNCH(8, EM, HP, LQ_SK_BLOCK, __VA_ARGS__); \
+		else if (P.w <= 16) LQ_SK_LAUNCH(16, EM, HP, LQ_SK_BLOCK, __VA_ARGS__); \
+		else                LQ_SK_LAUNCH(256, EM, HP, 64, __VA_ARGS__); \
 	} while (0)
-		// LQCOV_SKETCH=dp (to be measured): chunks inside N-free stretches away from the read start are decided data-parallel
-		// (k_sketch_dp); the state machine keeps the others
-		const bool sk_dp = getenv("LQCOV_SKETCH") && !strcmp(getenv("LQCOV_SKETCH"), "dp") && !P.hpc && P.w <= 16 && P.k <= 28 && P.w + P.k - 1 <= 48;
-		const u8 *dp_owned = nullptr;
-		if (sk_dp) {
-			sk_owned.ensure(nc);
-			StageTimer t(this, "k_sketch_dp_count", in_bytes + nc * 4);
-			LQ_LAUNCH((k_sketch_dp<false>), (u32)std::min<u64>(nc, 1u << 20), LQ_DP_THREADS, stream, rs.codes.as<u64>(), rs.amb.as<u32>(), rs.d_coff.as<u64>(), rs.d_len.as<u32>(), rs.n, nc, sp, (int)rid_in_y,
-			          cnt.as<u32>(), sk_owned.as<u8>(), (const u64*)nullptr, (u64*)nullptr, (u64*)nullptr);
-			check_launch();
-			dp_owned = sk_owned.as<u8>();
-			if (getenv("LQCOV_DEBUG_SKETCH")) {
-				std::vector<u8> ho(nc);
-				d2h(ho.data(), sk_owned.as<u8>(), nc, stream);
-				u64 n_own = 0;
-				for (u8 v : ho) n_own += v;
-				fprintf(stderr, "[sketch] %llu of %llu chunks decided data-parallel\n", (unsigned long long)n_own, (unsigned long long)nc);
+		if (!P.hpc) {
+			// Which positions are emitted is decided once, as a bit per base (mask: 4 words per chunk): by the data-parallel kernel
+			// over tiles of 12 chunks wherever the machine is memoryless, by the state machine for what that kernel leaves (the
+			// first chunk of every read, tiles within reach of an N, AT-repeat halos).  The list is then made from the mask: no
+			// second run of the machine, no halo for the output pass.
+			sk_mask.ensure(nc * LQ_CHUNK_WORDS * 4 + 64); sk_flag.ensure(4);
+			dzero(sk_mask.p, nc * LQ_CHUNK_WORDS * 4, stream); dzero(sk_flag.p, 4, stream);
+			const bool dp = P.w <= 16 && P.w + P.k - 1 <= 48 && P.k <= 28 && P.k >= 2 && !K.sketch_machine_only;
+			const u8 *dp_owned = nullptr;
+			if (dp) {
+				std::vector<u64> toff(rs.n + 1, 0);
+				for (u32 r = 0; r < rs.n; ++r) toff[r + 1] = toff[r] + (rs.h_coff[r + 1] - rs.h_coff[r] + LQ_DPT_CH - 1) / LQ_DPT_CH;
+				const u64 n_tiles = toff[rs.n];
+				sk_toff.ensure((rs.n + 1) * 8); sk_owned.ensure(nc + 8);
+				h2d(sk_toff.as<u64>(), toff.data(), rs.n + 1, stream);
+				LQ_HIP_CHECK(hipStreamSynchronize(stream));          // (toff dies with this scope)
+				if (n_tiles) {
+					StageTimer t(this, "k_sketch_dp_mask", in_bytes + nc * 17);
+					LQ_LAUNCH(k_sketch_dp_mask, (u32)std::min<u64>(n_tiles, 1u << 22), LQ_DPT_THREADS, stream, rs.codes.as<u64>(), rs.amb.as<u32>(), rs.d_coff.as<u64>(), rs.d_len.as<u32>(), sk_toff.as<u64>(), rs.n, n_tiles, sp,
+					          sk_owned.as<u8>(), sk_mask.as<u32>(), sk_flag.as<u32>());
+					check_launch();
+				}
+				dp_owned = sk_owned.as<u8>();
+				if (K.debug_sort) {
+					std::vector<u8> ho(nc);
+					d2h(ho.data(), sk_owned.as<u8>(), nc, stream);
+					u64 n_own = 0;
+					for (u8 v : ho) n_own += v;
+					fprintf(stderr, "[sketch] %llu of %llu chunks decided data-parallel\n", (unsigned long long)n_own, (unsigned long long)nc);
+				}
 			}
-		}
-		{
+			{
+				StageTimer t(this, "k_sketch_mask", dp ? nc : in_bytes + nc * 16);
+				LQ_SK_DISPATCH(LQ_SK_MASK, false, (u32*)nullptr, (const u64*)nullptr, (u64*)nullptr, (u64*)nullptr, dp_owned, sk_mask.as<u32>(), sk_flag.as<u32>());
+				check_launch();
+			}
+			LQ_LAUNCH(k_mask_count, nblk(nc, 256), 256, stream, sk_mask.as<u32>(), nc, cnt.as<u32>()); check_launch();
+		} else {
 			StageTimer t(this, "k_sketch_count", in_bytes + nc * 4);
-			LQ_SK_DISPATCH(false, cnt.as<u32>(), (const u64*)nullptr, (u64*)nullptr, (u64*)nullptr);
+			LQ_SK_DISPATCH(LQ_SK_COUNT, true, cnt.as<u32>(), (const u64*)nullptr, (u64*)nullptr, (u64*)nullptr, (const u8*)nullptr, (u32*)nullptr, (u32*)nullptr);
 			check_launch();
 		}
 		{ StageTimer t(this, "scan"); prim.exclusive_scan_u32_u64(cnt.as<u32>(), off.as<u64>(), nc); }
@@ -337,17 +349,21 @@ void lqcov_handle::sketch(ReadSetDev &rs, bool rid_in_y)
 		d2h(&last_cnt, cnt.as<u32>() + nc - 1, 1, stream);
 		rs.n_mini = last_off + last_cnt;
 		rs.mx.ensure(rs.n_mini * 8 + 8); rs.my.ensure(rs.n_mini * 8 + 8);
-		if (sk_dp) {
-			StageTimer t(this, "k_sketch_dp_emit", in_bytes + nc * 8 + rs.n_mini * 16);
-			LQ_LAUNCH((k_sketch_dp<true>), (u32)std::min<u64>(nc, 1u << 20), LQ_DP_THREADS, stream, rs.codes.as<u64>(), rs.amb.as<u32>(), rs.d_coff.as<u64>(), rs.d_len.as<u32>(), rs.n, nc, sp, (int)rid_in_y,
-			          (u32*)nullptr, sk_owned.as<u8>(), off.as<u64>(), rs.mx.as<u64>(), rs.my.as<u64>());
+		if (!P.hpc) {
+			u32 dup = 0;
+			d2h(&dup, sk_flag.as<u32>(), 1, stream);
+			if (dup) throw std::logic_error("sketch: a position was emitted twice (mask form of the minimizer list does not hold)");
+			StageTimer t(this, "k_sketch_emit_mask", nc * 24 + rs.n_mini * (16 + 4));
+			LQ_LAUNCH(k_sketch_emit_mask, (u32)std::min<u64>((nc + LQ_EM_CH - 1) / LQ_EM_CH, 1u << 22), LQ_EM_THREADS, stream, rs.codes.as<u64>(), rs.amb.as<u32>(), rs.d_coff.as<u64>(), rs.n, nc, sp, (int)rid_in_y,
+			          sk_mask.as<u32>(), off.as<u64>(), rs.mx.as<u64>(), rs.my.as<u64>());
 			check_launch();
-		}
-		{
+		} else {
 			StageTimer t(this, "k_sketch_emit", in_bytes + nc * 8 + rs.n_mini * 16);
-			LQ_SK_DISPATCH(true, (u32*)nullptr, off.as<u64>(), rs.mx.as<u64>(), rs.my.as<u64>());
+			LQ_SK_DISPATCH(LQ_SK_EMIT, true, (u32*)nullptr, off.as<u64>(), rs.mx.as<u64>(), rs.my.as<u64>(), (const u8*)nullptr, (u32*)nullptr, (u32*)nullptr);
 			check_launch();
 		}
+#undef LQ_SK_DISPATCH
+#undef LQ_SK_LAUNCH
 		LQ_LAUNCH(k_read_moff, nblk(rs.n + 1, 256), 256, stream, rs.d_coff.as<u64>(), off.as<u64>(), rs.n, nc, rs.n_mini, rs.moff.as<u64>());
 		check_launch();
 		LQ_HIP_CHECK(hipStreamSynchronize(stream));
@@ -541,12 +557,8 @@ void lqcov_handle::build_index(Part &pt)
 	h2d(pt.self_rid.as<u32>(), srid.data(), srid.size(), stream);
 	LQ_HIP_CHECK(hipStreamSynchronize(stream));
 	pt.built = true;
-	// the build workspaces stay with the handle so that repeated builds do not re-allocate; for parts of the reference's
-	// default size (4 Gbases: ~60 GB of them) the mapping work space is the better use of that HBM.  (The dump of a part
-	// reads three of them, so it runs before this point is reached again -- run_files dumps right after the build.)
-	if (ix_key.cap + ix_key2.cap + ix_head.cap + ix_uidx.cap + ix_ukey.cap + ix_ustart.cap + ix_ucnt.cap + ix_sorted.cap > (32ULL << 30)) {
-		ix_key.release(); ix_key2.release(); ix_head.release(); ix_uidx.release(); ix_sorted.release();
-	}
+	// (the build workspaces stay with the handle: repeated builds do not re-allocate, and the mapping lanes size their work
+	// space from what is free once the first part stands -- map_part)
 }
 
 void lqcov_handle::build_part(Part &pt)
@@ -1062,6 +1074,17 @@ void lqcov_handle::map_part(Part &pt)
 		dbg_chains.ensure(dbg_cap * sizeof(ChainRec)); n_dbg.ensure(8);
 		dzero(n_dbg.p, 8, stream);
 	}
+	if (anchor_budget == 0) {
+		// The first part stands (reads, minimizers, index, the build's work space -- all kept for the parts to come, of which the
+		// first is the largest: index.c:244) and so do the queries: the lanes share 85 % of what is free now.  Per anchor a lane
+		// holds A and B (32 B), one record array (8), 20 B of scratch, digit + destination (5), ~12 B of lists and per-sub-array
+		// rows, ~6 B of runs and intervals, and the buffers grow with an eighth of head room: ~95 B.
+		size_t fr = 0, tot = 0;
+		hipMemGetInfo(&fr, &tot);
+		anchor_budget = (u64)((double)fr * 0.85 / 104.0 / n_lanes);
+	}
+	if (anchor_budget > (1ULL << 31) - 4096) anchor_budget = (1ULL << 31) - 4096;   // (a record names its anchor in 31 bits)
+	if (anchor_budget < 1024) anchor_budget = 1024;
 	// batches of queries whose anchors fit one lane's work space; lanes (own stream + work space) take batches as they
 	// finish, so the serial tail of one batch (its longest walk / chain) overlaps the wide kernels of another
 	std::vector<std::pair<u32, u32>> batches;

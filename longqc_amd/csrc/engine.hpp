@@ -39,6 +39,7 @@ struct Knobs {
 	bool no_level_skip = false;           // LQCOV_NO_LEVEL_SKIP: constant key bytes are walked, not stepped over
 	bool debug_sort = false;              // LQCOV_DEBUG_SORT
 	u32 sketch_kpt = 4;                   // LQCOV_SKETCH_KPT: chunks per thread of the sketch state machine
+	bool sketch_machine_only = false;     // LQCOV_SKETCH=machine: the state machine decides every chunk (no data-parallel kernel)
 	void read_env();
 };
 
@@ -150,7 +151,7 @@ struct lqcov_handle {
 	DBuf dbg_chains, n_dbg; u64 dbg_cap = 0; u64 n_dbg_host = 0;
 	DBuf misc;
 	DBuf ix_key, ix_key2, ix_head, ix_uidx, ix_ukey, ix_ustart, ix_ucnt, ix_sorted;   // build_index workspaces
-	DBuf sk_cnt, sk_off, sk_owned;                  // sketch: per-chunk minimizer counts / offsets
+	DBuf sk_cnt, sk_off, sk_owned, sk_mask, sk_flag, sk_toff;   // sketch: per-chunk minimizer counts / offsets, which kernel decides a chunk, emitted positions (a bit per base), tile offsets
 	u64 last_n_anchors = 0;
 	u64 anchor_budget = 0;
 

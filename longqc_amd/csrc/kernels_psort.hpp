@@ -174,8 +174,10 @@ k_ps_scan(PSeg *segs, const u32 *n_p, const PPlan *plan, const u32 *gcnt, u32 *g
 		{	// every key in one bucket of this pass: the segment stays where it is and is listed again with the bits that do vary
 			const u64 low = sg.rem >= 64 ? ~0ULL : ((1ULL << sg.rem) - 1);
 			const u64 df = (u64)gdiff[s] & low;
-			// (all keys equal and not in A yet: no short cut -- the pass below is then the copy that brings the segment home)
-			if ((df >> (sg.rem - sg.nbits)) == 0 && (df != 0 || sg.buf == 0)) {   // (uniform over the block)
+			// (all keys equal and not in A yet: no short cut -- the pass below is then the copy that brings the segment home.  A segment
+			// still named by records neither: its pass gathers it into A, and every such segment must have left B by the end of the
+			// set's first pass -- later passes use B as their other buffer.)
+			if ((df >> (sg.rem - sg.nbits)) == 0 && sg.buf < 2 && (df != 0 || sg.buf == 0)) {   // (uniform over the block)
 				if (t == 0) {
 					PSeg ch = sg; ch.nbits = 0;
 					ch.rem = df ? (u8)(64 - __builtin_clzll(df)) : 0;
@@ -187,6 +189,12 @@ k_ps_scan(PSeg *segs, const u32 *n_p, const PPlan *plan, const u32 *gcnt, u32 *g
 			}
 		}
 		if (t == 0 && tally) atomicAdd(tally, (unsigned long long)sg.len);
+		// the children differ in the key bits below this pass's digit that vary inside the segment, at most
+		u32 crem = sg.rem - sg.nbits;
+		{
+			const u64 dl = (u64)gdiff[s] & (crem >= 64 ? ~0ULL : ((1ULL << crem) - 1));
+			crem = dl ? 64 - (u32)__builtin_clzll(dl) : 0;
+		}
 		const u32 c = t < nb ? gcnt[pl.cnt0 + t] : 0;
 		v[t] = c;
 		__syncthreads();
@@ -194,7 +202,7 @@ k_ps_scan(PSeg *segs, const u32 *n_p, const PPlan *plan, const u32 *gcnt, u32 *g
 		if (t < nb) {
 			gcur[pl.cnt0 + t] = v[t];
 			if (c) {
-				PSeg ch; ch.off = sg.off + v[t]; ch.len = c; ch.rem = (u8)(sg.rem - sg.nbits); ch.buf = sg.buf >= 2 ? 0 : sg.buf ^ 1; ch.nbits = 0; ch.pad = 0;
+				PSeg ch; ch.off = sg.off + v[t]; ch.len = c; ch.rem = (u8)crem; ch.buf = sg.buf >= 2 ? 0 : sg.buf ^ 1; ch.nbits = 0; ch.pad = 0;
 				if (ch.rem == 0 || c == 1) { if (ch.buf) { ch.rem = 0; lq_ps_route(ch, L, big_next_slot); } }   // nothing left to sort: only bring it home to A
 				else lq_ps_route(ch, L, big_next_slot);
 			}

@@ -121,21 +121,31 @@ struct SkState {
 
 struct SkOut {
 	u64 n;            // emitted so far by this thread
-	u64 *x, *y;       // destination (emit pass) or null (count pass)
+	u64 *x, *y;       // destination (emit pass) or null
 	u64 y_hi;         // rid << 32
+	u32 *mask;        // mask mode: one bit per base of this read (bit p of the read's mask words = the minimizer ending at p is emitted)
+	u32 *dup_flag;    // mask mode: set if a position is emitted twice (never: see k_sketch_emit_mask)
 };
 
-template <bool EMIT>
+// MODE 0: count, 1: emit (x, y) at the thread's offset, 2: set the emitted position's bit in the read's mask
+#define LQ_SK_COUNT 0
+#define LQ_SK_EMIT  1
+#define LQ_SK_MASK  2
+template <int MODE>
 __device__ __forceinline__ void sk_push(SkOut &o, bool live, u64 x, u32 y32)
 {
 	if (!live) return;
-	if (EMIT) { o.x[o.n] = x; o.y[o.n] = o.y_hi | y32; }
+	if (MODE == LQ_SK_EMIT) { o.x[o.n] = x; o.y[o.n] = o.y_hi | y32; }
+	if (MODE == LQ_SK_MASK) {
+		const u32 pos = y32 >> 1, bit = 1u << (pos & 31);
+		if (atomicOr(&o.mask[pos >> 5], bit) & bit) atomicOr(o.dup_flag, 1u);
+	}
 	++o.n;
 }
 
 // One loop iteration of mm_sketch whose (last) base is at `pos` with code c (4 = ambiguous),
 // run = homopolymer run length (1 unless HPC).  Returns true if a ring slot was produced.
-template <int STRIDE, bool EMIT>
+template <int STRIDE, int EMIT>
 __device__ __forceinline__ bool sk_step(SkState<STRIDE> &s, const SkParams &P, int c, u32 pos, int run, bool live, SkOut &o, bool &was_pal)
 {
 	const int w = P.w, k = P.k;
@@ -203,7 +213,7 @@ template <int STRIDE>
 __device__ __forceinline__ void sk_warm(SkState<STRIDE> &s, ReadView &rv, const SkParams &P, u32 i0)
 {
 	u32 halo = 64;
-	SkOut none; none.n = 0; none.x = none.y = nullptr; none.y_hi = 0;
+	SkOut none; none.n = 0; none.x = none.y = nullptr; none.y_hi = 0; none.mask = none.dup_flag = nullptr;
 	for (;;) {
 		u32 s0 = i0 > halo ? i0 - halo : 0;
 		if (P.hpc) while (s0 > 0 && !rv.run_start(s0)) --s0;
@@ -215,7 +225,7 @@ __device__ __forceinline__ void sk_warm(SkState<STRIDE> &s, ReadView &rv, const 
 		while (i < i0) {
 			int c, run; u32 last; bool pal;
 			sk_fetch(rv, P, i, c, run, last);
-			bool slot = sk_step<STRIDE, false>(s, P, c, last, run, false, none, pal);
+			bool slot = sk_step<STRIDE, LQ_SK_COUNT>(s, P, c, last, run, false, none, pal);
 			if (c >= 4) { lx = nk >= P.k; lsim = 0; ++exact_run; }   // an N slot is (MAX,MAX) whatever the history
 			else {
 				++nk;
@@ -233,12 +243,13 @@ __device__ __forceinline__ void sk_warm(SkState<STRIDE> &s, ReadView &rv, const 
 	}
 }
 
-// count pass: cnt[g] = minimizers decided by chunk g;  emit pass: written at off[g]...
+// count pass: cnt[g] = minimizers decided by chunk g;  emit pass: written at off[g]...; mask pass (no -H): the emitted
+// positions' bits set in `mask` (4 words per chunk, zeroed by the caller; k_sketch_emit_mask turns them into the list).
 // RCAP <= 16: ring in LDS (block of LQ_SK_BLOCK threads); RCAP = 256: private ring, any w < 256.
 #define LQ_SK_BLOCK 256
-template <int RCAP, bool EMIT, bool HPC>
+template <int RCAP, int EMIT, bool HPC>
 __global__ void k_sketch(const u64 *codes, const u32 *amb, const u64 *coff, const u32 *rlen, u32 n_reads, u64 n_chunks, u32 kpt,
-                         SkParams P, int rid_in_y, u32 *cnt, const u64 *off, u64 *out_x, u64 *out_y, const u8 *dp_owned)
+                         SkParams P, int rid_in_y, u32 *cnt, const u64 *off, u64 *out_x, u64 *out_y, const u8 *dp_owned, u32 *mask, u32 *dup_flag)
 {
 	constexpr int STRIDE = RCAP <= 16 ? LQ_SK_BLOCK : 1;
 	__shared__ u64 s_rx[RCAP <= 16 ? RCAP : 1][LQ_SK_BLOCK];
@@ -269,8 +280,9 @@ __global__ void k_sketch(const u64 *codes, const u32 *amb, const u64 *coff, cons
 		u32 i = pos0;
 		if (P.hpc) while (i < len && !rv.run_start(i)) ++i;        // first iteration this chunk owns
 		SkOut o; o.n = 0; o.y_hi = rid_in_y ? (u64)r << 32 : 0;
-		o.x = o.y = nullptr;
-		if (EMIT) { o.x = out_x + off[g]; o.y = out_y + off[g]; }
+		o.x = o.y = nullptr; o.mask = nullptr; o.dup_flag = dup_flag;
+		if (EMIT == LQ_SK_EMIT) { o.x = out_x + off[g]; o.y = out_y + off[g]; }
+		if (EMIT == LQ_SK_MASK) o.mask = mask + coff[r] * LQ_CHUNK_WORDS;
 		if (i < pos1) {
 			if (!(have && i_next == i)) sk_warm<STRIDE>(s, rv, P, i);
 			while (i < pos1) {
@@ -283,7 +295,7 @@ __global__ void k_sketch(const u64 *codes, const u32 *amb, const u64 *coff, cons
 				sk_push<EMIT>(o, true, s.best_x, s.best_y);
 			have = true; r_prev = r; i_next = i;
 		}
-		if (!EMIT) cnt[g] = (u32)o.n;
+		if (EMIT == LQ_SK_COUNT) cnt[g] = (u32)o.n;
 	}
 }
 
@@ -295,13 +307,20 @@ __global__ void k_sketch(const u64 *codes, const u32 *amb, const u64 *coff, cons
 //   v_t <= v_m              -> emit m                                   (sketch.c:122-124)
 //   else m == t - w         -> emit m, then with m' = the newest minimal slot of [t - w + 1, t] every other slot of that
 //                              window with the value of m', oldest first  (sketch.c:125-137)
-// and the read's last step is followed by the minimum of its window (sketch.c:140-141).  One block per 128-base chunk, one
-// thread per position of chunk + halo: k-mer straight from the packed codes, hash, compaction of the slots in LDS, the
-// emissions of every slot counted (count pass) or written at the chunk's offset + rank (emit pass).  A chunk that does not
-// qualify (first chunk of a read, an N within reach, too many palindromes -- AT repeats --, w > 16, -H) is left to k_sketch:
-// owned[g] says which kernel decides chunk g.
+// and the read's last step is followed by the minimum of its window (sketch.c:140-141).
+// One block per tile of LQ_DPT_CH chunks of one read (tile list: toff[r] = tiles of the reads before r) plus a 64-base halo:
+// 5 consecutive positions per thread (their k-mers come out of one 32-base window of the packed codes, one bit reversal for
+// all five), hashes compared as such (x = hash << 8 | k orders like the hash), compaction of the slots in LDS, and every
+// step's emissions set as bits of the emitted positions (LDS, then one atomicOr per mask word).  What is decided here is
+// *which positions are emitted*; k_sketch_emit_mask makes (x, y) of them.
+// A tile does not qualify if an N is within reach or the halo holds too few slots (AT repeats): owned[g] = 0 for its chunks
+// and k_sketch<mask> decides them, as it does every read's first chunk (l < w + k there).  Needs w <= 16, w + k - 1 <= 48, no -H.
 #define LQ_DP_HALO 64
-#define LQ_DP_THREADS (LQ_CHUNK + LQ_DP_HALO)
+#define LQ_DPT_CH 12
+#define LQ_DPT_PER 5
+#define LQ_DPT_N (LQ_DPT_CH * LQ_CHUNK + LQ_DP_HALO)          // 1600 positions
+#define LQ_DPT_THREADS (LQ_DPT_N / LQ_DPT_PER)                // 320
+#define LQ_DPT_WAVES (LQ_DPT_THREADS / 64)
 __device__ __forceinline__ u64 lq_rev2(u64 x)
 {	// the 2-bit groups of x in reverse order
 	x = ((x >> 2) & 0x3333333333333333ULL) | ((x & 0x3333333333333333ULL) << 2);
@@ -311,92 +330,183 @@ __device__ __forceinline__ u64 lq_rev2(u64 x)
 	return x >> 32 | x << 32;
 }
 
-template <bool EMIT>
-__global__ void __launch_bounds__(LQ_DP_THREADS)
-k_sketch_dp(const u64 *codes, const u32 *amb, const u64 *coff, const u32 *rlen, u32 n_reads, u64 n_chunks, SkParams P, int rid_in_y,
-            u32 *cnt, u8 *owned, const u64 *off, u64 *out_x, u64 *out_y)
+// 32 bases of a read starting at base `lo` (2-bit codes, first base lowest) and their ambiguity bits
+__device__ __forceinline__ void lq_window32(const u64 *cw, const u32 *aw, u32 lo, u64 &raw, u32 &am)
 {
-	__shared__ u64 V[LQ_DP_THREADS];
-	__shared__ u32 Y[LQ_DP_THREADS];
-	__shared__ u32 wsum[LQ_DP_THREADS / 64], wsum2[LQ_DP_THREADS / 64], bad;
+	const u32 wi = lo >> 5, sh = lo & 31;
+	raw = cw[wi] >> (2 * sh);
+	am = aw[wi] >> sh;
+	if (sh) { raw |= cw[wi + 1] << (64 - 2 * sh); am |= aw[wi + 1] << (32 - sh); }
+}
+
+__global__ void __launch_bounds__(LQ_DPT_THREADS)
+k_sketch_dp_mask(const u64 *codes, const u32 *amb, const u64 *coff, const u32 *rlen, const u64 *toff, u32 n_reads, u64 n_tiles, SkParams P,
+                 u8 *owned, u32 *mask, u32 *dup_flag)
+{
+	__shared__ u64 V[LQ_DPT_N];
+	__shared__ u16 PS[LQ_DPT_N];
+	__shared__ u32 lmask[LQ_DPT_N / 32];
+	__shared__ u32 wsum[LQ_DPT_WAVES], whalo[LQ_DPT_WAVES], bad;
 	const u32 t = threadIdx.x, lane = t & 63, wv = t >> 6;
 	const i32 w = P.w, k = P.k;
-	for (u64 g = blockIdx.x; g < n_chunks; g += gridDim.x) {
-		if (EMIT && !owned[g]) continue;
-		const u32 r = lq_find_seg(coff, n_reads, g);
+	for (u64 T = blockIdx.x; T < n_tiles; T += gridDim.x) {
+		const u32 r = lq_find_seg(toff, n_reads, T);
 		const u32 len = rlen[r];
-		const u32 pos0 = (u32)(g - coff[r]) * LQ_CHUNK;
-		const u32 pos1 = pos0 + LQ_CHUNK < len ? pos0 + LQ_CHUNK : len;
-		if (pos0 < LQ_CHUNK || pos0 >= len) { if (!EMIT && t == 0) owned[g] = 0; continue; }   // (uniform) the read's first chunk: k_sketch
+		const u64 g0 = coff[r] + (T - toff[r]) * LQ_DPT_CH;        // first chunk of the tile
+		const u32 n_ch = (u32)(coff[r + 1] - g0 < LQ_DPT_CH ? coff[r + 1] - g0 : LQ_DPT_CH);
+		const u32 p0 = (u32)(T - toff[r]) * LQ_DPT_CH * LQ_CHUNK;
+		const u32 a = p0 < LQ_CHUNK ? LQ_CHUNK : p0;              // the read's first chunk is the machine's
+		const u32 b = p0 + n_ch * LQ_CHUNK < len ? p0 + n_ch * LQ_CHUNK : len;
+		if (a >= b) { if (t < n_ch) owned[g0 + t] = 0; continue; }   // (uniform)
 		const u64 *cw = codes + coff[r] * LQ_CHUNK_WORDS;
 		const u32 *aw = amb + coff[r] * LQ_CHUNK_WORDS;
+		const u32 base = a - LQ_DP_HALO;                          // position of index 0 (a multiple of 64)
 		if (t == 0) bad = 0;
+		if (t < LQ_DPT_N / 32) lmask[t] = 0;
 		__syncthreads();
-		const u32 p = pos0 - LQ_DP_HALO + t;                      // this thread's position; its k-mer is [p - k + 1, p]
-		bool slot = false;
-		u64 x = 0; u32 y = 0;
-		if (p < pos1) {
-			const u32 lo = p - (u32)k + 1, wi = lo >> 5, sh = lo & 31;
-			const u32 last_w = p >> 5;
-			u64 raw = cw[wi] >> (2 * sh);
-			u64 am = (u64)aw[wi] >> sh;
-			if (last_w != wi) { raw |= cw[wi + 1] << (64 - 2 * sh); am |= (u64)aw[wi + 1] << (32 - sh); }
-			raw &= P.mask;
-			if (am & ((1ULL << k) - 1)) atomicOr(&bad, 1u);        // an ambiguous base within reach: the machine's memory matters
-			const u64 rv = ~raw & P.mask;                            // complement, oldest base lowest: the machine's rv
-			const u64 fw = lq_rev2(raw) >> (64 - 2 * k);             // newest base lowest: the machine's fw
-			if (fw != rv) {
-				const u32 z = fw < rv ? 0u : 1u;
-				x = lq_hash64(z ? rv : fw, P.mask) << 8 | (u64)k;
-				y = p << 1 | z;
-				slot = true;
+		// this thread's five positions base + 5 t + j; their k-mers are [p - k + 1, p]
+		const u32 i0 = LQ_DPT_PER * t, q0 = base + i0;
+		u64 h[LQ_DPT_PER];
+		u32 sl = 0;                                               // bit j: position j is a slot
+		if (q0 < b) {
+			u64 raw; u32 am;
+			lq_window32(cw, aw, q0 - (u32)k + 1, raw, am);
+			const u64 R = lq_rev2(raw);
+			u32 n_amb = 0;
+#pragma unroll
+			for (int j = 0; j < LQ_DPT_PER; ++j) {
+				h[j] = 0;
+				if (q0 + j < b) {
+					const u64 rj = (raw >> (2 * j)) & P.mask;
+					n_amb |= (am >> j) & (u32)((1ULL << k) - 1);
+					const u64 rv = ~rj & P.mask;                       // complement, oldest base lowest: the machine's rv
+					const u64 fw = (R >> (2 * (32 - j - k))) & P.mask;   // newest base lowest: the machine's fw
+					if (fw != rv) { h[j] = lq_hash64(fw < rv ? fw : rv, P.mask); sl |= 1u << j; }
+				}
 			}
+			if (n_amb) atomicOr(&bad, 1u);                            // an ambiguous base within reach: the machine's memory matters
 		}
-		// slot index = number of slots before this position
-		u32 inc = slot ? 1u : 0u;
+		// slot index = number of slots before the position
+		const u32 mine = (u32)__popc(sl);
+		u32 inc = mine;
 		for (int d = 1; d < 64; d <<= 1) { const u32 o = __shfl_up(inc, d); if ((int)lane >= d) inc += o; }
 		if (lane == 63) wsum[wv] = inc;
+		{	// slots of the halo (indices below 64 = the first 13 threads' positions, the 13th's in part)
+			u32 hm = 0;
+			for (int j = 0; j < LQ_DPT_PER; ++j) if (i0 + j < LQ_DP_HALO) hm |= 1u << j;
+			u32 hs = (u32)__popc(sl & hm);
+			for (int o = 32; o > 0; o >>= 1) hs += __shfl_xor(hs, o);
+			if (lane == 0) whalo[wv] = hs;
+		}
 		__syncthreads();
-		u32 ts = inc - (slot ? 1u : 0u), T = 0;
-		for (u32 q = 0; q < LQ_DP_THREADS / 64; ++q) { if (q < wv) ts += wsum[q]; T += wsum[q]; }
-		const u32 T0 = wsum[0];                                   // slots of the halo (the first wave is the halo)
-		const bool ok = !bad && T0 >= (u32)(w + k - 1) && T > T0;  // (uniform)
-		if (!EMIT && t == 0) owned[g] = ok ? 1 : 0;
+		u32 ts = inc - mine, Tn = 0;
+		for (u32 q = 0; q < LQ_DPT_WAVES; ++q) { if (q < wv) ts += wsum[q]; Tn += wsum[q]; }
+		const u32 T0 = whalo[0];
+		const bool ok = !bad && T0 >= (u32)(w + k - 1) && Tn > T0;    // (uniform; a stretch without a single slot is the machine's)
+		if (t < n_ch) owned[g0 + t] = (ok && p0 + t * LQ_CHUNK >= a) ? 1 : 0;
 		if (!ok) { __syncthreads(); continue; }
-		if (slot) { V[ts] = x; Y[ts] = y; }
+		{
+			u32 s = ts;
+			for (int j = 0; j < LQ_DPT_PER; ++j) if (sl >> j & 1) { V[s] = h[j]; PS[s] = (u16)(i0 + j); ++s; }
+		}
 		__syncthreads();
-		// emissions of this thread's step
-		u32 ne = 0;
-		u32 em[17];                                                // slot indices, in emission order (<= 1 + (w - 1) + 1)
-		if (slot && ts >= T0) {
-			u32 m = ts - 1;
-			for (u32 u = 2; u <= (u32)w; ++u) if (V[ts - u] < V[m]) m = ts - u;          // the newest minimal slot of [ts - w, ts - 1]
-			if (x <= V[m]) em[ne++] = m;
-			else if (m == ts - (u32)w) {
-				em[ne++] = m;
-				u32 m2 = ts;
-				for (u32 u = 1; u < (u32)w; ++u) if (V[ts - u] < V[m2]) m2 = ts - u;       // the newest minimal slot of [ts - w + 1, ts]
-				for (u32 u = ts - (u32)w + 1; u <= ts; ++u) if (u != m2 && V[u] == V[m2]) em[ne++] = u;
-			}
-			if (ts == T - 1 && pos1 >= len) {                         // the read's last step: its window's minimum follows
-				u32 m2 = ts;
-				if (x <= V[m]) m2 = ts;                                 // (after the step the minimum is the new slot ...)
-				else if (m == ts - (u32)w) { for (u32 u = 1; u < (u32)w; ++u) if (V[ts - u] < V[m2]) m2 = ts - u; }   // (... the rescanned one ...)
-				else m2 = m;                                            // (... or the old one)
-				em[ne++] = m2;
+		// emissions of this thread's steps (the steps of the halo belong to whoever owns those positions)
+		{
+			u32 s = ts;
+			for (int j = 0; j < LQ_DPT_PER; ++j) if (sl >> j & 1) {
+				if (i0 + j >= LQ_DP_HALO) {
+					const u64 x = h[j];
+					u32 m = s - 1;
+					for (u32 u = 2; u <= (u32)w; ++u) if (V[s - u] < V[m]) m = s - u;          // the newest minimal slot of [s - w, s - 1]
+					u32 after = m;                                                              // the window's minimum after the step
+					if (x <= V[m]) { const u32 e = PS[m]; atomicOr(&lmask[e >> 5], 1u << (e & 31)); after = s; }
+					else if (m == s - (u32)w) {
+						{ const u32 e = PS[m]; atomicOr(&lmask[e >> 5], 1u << (e & 31)); }
+						u32 m2 = s;
+						for (u32 u = 1; u < (u32)w; ++u) if (V[s - u] < V[m2]) m2 = s - u;       // the newest minimal slot of [s - w + 1, s]
+						for (u32 u = s - (u32)w + 1; u <= s; ++u) if (u != m2 && V[u] == V[m2]) { const u32 e = PS[u]; atomicOr(&lmask[e >> 5], 1u << (e & 31)); }
+						after = m2;
+					}
+					if (s == Tn - 1 && b >= len) { const u32 e = PS[after]; atomicOr(&lmask[e >> 5], 1u << (e & 31)); }   // the read's last step: its window's minimum follows
+				}
+				++s;
 			}
 		}
-		// ranks of the emissions in position order
-		u32 inc2 = ne;
-		for (int d = 1; d < 64; d <<= 1) { const u32 o = __shfl_up(inc2, d); if ((int)lane >= d) inc2 += o; }
-		if (lane == 63) wsum2[wv] = inc2;
 		__syncthreads();
-		u32 at = inc2 - ne, tot = 0;
-		for (u32 q = 0; q < LQ_DP_THREADS / 64; ++q) { if (q < wv) at += wsum2[q]; tot += wsum2[q]; }
-		if (EMIT) {
-			const u64 y_hi = rid_in_y ? (u64)r << 32 : 0;
-			for (u32 e = 0; e < ne; ++e) { out_x[off[g] + at + e] = V[em[e]]; out_y[off[g] + at + e] = y_hi | Y[em[e]]; }
-		} else if (t == 0) cnt[g] = tot;
+		if (t < LQ_DPT_N / 32) {
+			const u32 v = lmask[t];
+			if (v) { u32 *gw = mask + coff[r] * LQ_CHUNK_WORDS + (base >> 5) + t; if (atomicOr(gw, v) & v) atomicOr(dup_flag, 1u); }
+		}
+		__syncthreads();
+	}
+}
+
+// cnt[g] = emitted positions of chunk g
+__global__ void k_mask_count(const u32 *mask, u64 n_chunks, u32 *cnt)
+{
+	const u64 g = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+	if (g >= n_chunks) return;
+	const uint4 m = *(const uint4*)(mask + g * LQ_CHUNK_WORDS);
+	cnt[g] = (u32)(__popc(m.x) + __popc(m.y) + __popc(m.z) + __popc(m.w));
+}
+
+// The list from the mask: (x, y) of every emitted position, in (read, position) order = the order mm_sketch emits them in.
+// (mm_sketch's emissions ascend in position and never repeat one: at any moment the slots of the window that are older
+// than the running minimum either had its value -- and were emitted when it was established, sketch.c:116-121,125-137 --
+// or a larger one and can never become the minimum; so whatever is emitted later is the minimum itself or newer.  The
+// fixtures' lists are strictly ascending, and a bit set twice raises dup_flag.)  No -H here: span = k, the position is the
+// k-mer's last base.
+// One block per LQ_EM_CH chunks: the set bits become a dense list of positions in LDS (rank = bits set before), then one
+// thread per list entry rebuilds the k-mer from the packed codes, hashes it and writes x and y at offset + rank: all lanes
+// busy with a hash, the 16-byte outputs contiguous.
+#define LQ_EM_CH 8
+#define LQ_EM_THREADS 256
+__global__ void __launch_bounds__(LQ_EM_THREADS)
+k_sketch_emit_mask(const u64 *codes, const u32 *amb, const u64 *coff, u32 n_reads, u64 n_chunks, SkParams P, int rid_in_y,
+                   const u32 *mask, const u64 *off, u64 *out_x, u64 *out_y)
+{
+	__shared__ u16 lpos[LQ_EM_CH * LQ_CHUNK];
+	__shared__ u32 woff[LQ_EM_CH * LQ_CHUNK_WORDS + 1], wbits[LQ_EM_CH * LQ_CHUNK_WORDS], rid[LQ_EM_CH];
+	const u32 t = threadIdx.x;
+	const i32 k = P.k;
+	for (u64 g0 = (u64)blockIdx.x * LQ_EM_CH; g0 < n_chunks; g0 += (u64)gridDim.x * LQ_EM_CH) {
+		const u32 n_ch = (u32)(n_chunks - g0 < LQ_EM_CH ? n_chunks - g0 : LQ_EM_CH);
+		const u32 n_w = n_ch * LQ_CHUNK_WORDS;
+		if (t < 64) {                                            // the first wave: mask words and their exclusive bit counts
+			const u32 v = t < n_w ? mask[g0 * LQ_CHUNK_WORDS + t] : 0;
+			const u32 c = (u32)__popc(v);
+			u32 inc = c;
+			for (int d = 1; d < 64; d <<= 1) { const u32 o = __shfl_up(inc, d); if ((int)t >= d) inc += o; }
+			if (t < LQ_EM_CH * LQ_CHUNK_WORDS) { wbits[t] = v; woff[t] = inc - c; }
+			if (t == LQ_EM_CH * LQ_CHUNK_WORDS - 1) woff[LQ_EM_CH * LQ_CHUNK_WORDS] = inc;
+			if (t < n_ch) rid[t] = lq_find_seg(coff, n_reads, g0 + t);
+		}
+		__syncthreads();
+		const u32 n = woff[LQ_EM_CH * LQ_CHUNK_WORDS];
+		for (u32 q = t; q < n_w * 8; q += LQ_EM_THREADS) {          // four positions (a nibble of a mask word) per turn
+			const u32 wi = q >> 3, nb = (q & 7) * 4;
+			const u32 v = wbits[wi];
+			u32 nib = (v >> nb) & 15u;
+			if (nib) {
+				u32 rk = woff[wi] + (u32)__popc(v & ((1u << nb) - 1));
+				for (; nib; nib &= nib - 1) lpos[rk++] = (u16)(wi * 32 + nb + (u32)__builtin_ctz(nib));
+			}
+		}
+		__syncthreads();
+		const u64 o0 = off[g0];
+		for (u32 j = t; j < n; j += LQ_EM_THREADS) {
+			const u32 pi = lpos[j], ch = pi >> 7;
+			const u32 r = rid[ch];
+			const u32 pos = (u32)(g0 + ch - coff[r]) * LQ_CHUNK + (pi & (LQ_CHUNK - 1));
+			u64 raw; u32 am;
+			lq_window32(codes + coff[r] * LQ_CHUNK_WORDS, amb + coff[r] * LQ_CHUNK_WORDS, pos - (u32)k + 1, raw, am);
+			raw &= P.mask;
+			const u64 rv = ~raw & P.mask;
+			const u64 fw = lq_rev2(raw) >> (64 - 2 * k);
+			const u32 z = fw < rv ? 0u : 1u;
+			out_x[o0 + j] = lq_hash64(z ? rv : fw, P.mask) << 8 | (u64)k;
+			out_y[o0 + j] = (rid_in_y ? (u64)r << 32 : 0) | (u64)(pos << 1 | z);
+		}
 		__syncthreads();
 	}
 }

@@ -49,7 +49,7 @@ struct DBuf {
 		size_t want = bytes + bytes / 8 + 256;
 #ifndef LQ_EMU
 		if (lq_alloc_stream) {
-			want = bytes + bytes / 4 + 4096;                       // a little more head room: regrowth is what this is about
+			want = bytes + bytes / 8 + 4096;
 			hipError_t e = hipMallocAsync(&p, want, lq_alloc_stream);
 			if (e == hipErrorOutOfMemory) {
 				(void)hipGetLastError();

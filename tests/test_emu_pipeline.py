@@ -89,15 +89,15 @@ def test_emulated_sketch_equals_mm_sketch_fixture(emu_lib, name, k, w, hpc, fn):
 
 
 @pytest.mark.parametrize("name,k,w,fn", [("tiny_sketch_k12w5", 12, 5, "tiny_sub.fq.gz"), ("adv_sketch_k12w5", 12, 5, "adv_sub.fq.gz"), ("adv_sketch_k19w10", 19, 10, "adv_sub.fq.gz")])
-def test_emulated_data_parallel_sketch(emu_lib, monkeypatch, name, k, w, fn):
-    """LQCOV_SKETCH=dp: chunks inside N-free stretches away from the read start decided by k_sketch_dp (sliding-window minimum
-    over the non-palindromic positions with minimap2's tie rules), the rest by the state machine: the reference's list"""
-    monkeypatch.setenv("LQCOV_SKETCH", "dp")
+def test_emulated_state_machine_decides_every_chunk(emu_lib, monkeypatch, name, k, w, fn):
+    """LQCOV_SKETCH=machine: no chunk is decided by the data-parallel kernel (k_sketch_dp_mask: sliding-window minimum over the
+    non-palindromic positions with minimap2's tie rules, the default wherever the machine is memoryless): the reference's list"""
+    monkeypatch.setenv("LQCOV_SKETCH", "machine")
     test_emulated_sketch_equals_mm_sketch_fixture(emu_lib, name, k, w, 0, fn)
 
 
-def test_emulated_data_parallel_sketch_adversarial(emu_lib, monkeypatch):
-    monkeypatch.setenv("LQCOV_SKETCH", "dp")
+def test_emulated_state_machine_only_adversarial(emu_lib, monkeypatch):
+    monkeypatch.setenv("LQCOV_SKETCH", "machine")
     test_emulated_sketch_halo_adversarial(emu_lib)
 
 
@@ -109,8 +109,8 @@ def test_emulated_data_parallel_sketch_fuzz(emu_lib, monkeypatch):
         rng = np.random.default_rng(100 + it)
         k = int(rng.choice([4, 6, 10, 12, 15, 19, 24, 28])); w = int(rng.choice([1, 2, 3, 5, 10, 16]))
         seqs = []
-        for _ in range(6):
-            L = int(rng.integers(130, 3000))
+        for j in range(6):
+            L = int(rng.integers(130, 3000)) if j < 4 else int(rng.integers(3000, 9000))    # (a tile of the data-parallel kernel is 1536 bases)
             s = A[rng.integers(0, 4, L)].copy()
             mode = int(rng.integers(0, 6))
             if mode == 1:
@@ -126,7 +126,7 @@ def test_emulated_data_parallel_sketch_fuzz(emu_lib, monkeypatch):
             seqs.append(s)
         names = ["s%d" % i for i in range(len(seqs))]
         res = []
-        for mode in ("machine", "dp"):
+        for mode in ("machine", "default"):
             monkeypatch.setenv("LQCOV_SKETCH", mode)
             eng = _engine(emu_lib, k=k, w=w, hpc=0, min_score_med=40, min_score_good=40)
             eng.set_queries(names, seqs, None)
@@ -481,3 +481,16 @@ def check_long_pair_among_many_targets(lib, tmp_path):
 
 def test_emulated_long_pair_among_many_targets(emu_lib, tmp_path):
     check_long_pair_among_many_targets(emu_lib, tmp_path)
+
+
+def test_emulated_parallel_sort_size_classes(emu_lib, datasets, monkeypatch):
+    """the parallel sort with its size classes shrunk 128-fold on cfg1: more partition passes than are issued without looking
+    (the tail with its look at the counter), segments whose keys agree in the bits of a pass (stepped over, unless still named
+    by records: those must have left the originals before any pass writes to B)"""
+    tf, qf = datasets("cfg1")
+    argv = ONT + [tf, qf]
+    want = oracle_bind.table(argv)
+    monkeypatch.setenv("LQCOV_PS_SHIFT", "7")
+    rc, out, err = run_main(emu_lib, argv)
+    assert rc == 0, err
+    assert out == want
