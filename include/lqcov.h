@@ -198,6 +198,12 @@ int lqcov_part_sketch(lqcov_handle *h, int part);
  * with the part-global target lengths and names, then (re)build the index from them */
 int lqcov_part_build_from_minimizers_dev(lqcov_handle *h, int part, const uint64_t *x_dev, const uint64_t *y_dev, uint64_t n,
                                          uint32_t n_targets, const uint32_t *target_len, const char *names, const uint64_t *name_off);
+/* the same from the receive buffers of an all-gather with equally sized send buffers: share i (the minimizers of rank i's reads,
+ * share_n[i] <= stride entries, host array) starts at word i * stride of x_dev / y_dev; the shares are copied back to back
+ * (read order: mm_idx_gen's order, index.c:291-302) -- no concatenated copy on the caller's side */
+int lqcov_part_build_from_minimizer_shares_dev(lqcov_handle *h, int part, const uint64_t *x_dev, const uint64_t *y_dev, uint64_t stride,
+                                               uint32_t n_shares, const uint64_t *share_n,
+                                               uint32_t n_targets, const uint32_t *target_len, const char *names, const uint64_t *name_off);
 
 /* Index parts on different GPUs == the reference's own -I partitioning (minimap2-coverage.c:449-458) run in
  * parallel.  Parts only interact through (i) mid_occ, frozen from part 0 (map.c:50), (ii) the COVT cap, which

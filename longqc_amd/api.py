@@ -121,6 +121,8 @@ def load_library(path: Optional[str] = None):
         "lqcov_accum_import_dev": (C.c_int, [H] + [C.c_void_p] * 6 + [C.c_uint32]),
         "lqcov_part_build_from_minimizers_dev": (C.c_int, [H, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32,
                                                            C.c_void_p, C.c_void_p, C.c_void_p]),
+        "lqcov_part_build_from_minimizer_shares_dev": (C.c_int, [H, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p,
+                                                                 C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)          # AttributeError here == the library does not export the ABI
@@ -444,6 +446,13 @@ class Engine:
 
     def part_minimizers_export(self, part: int, x_ptr: int, y_ptr: int, cap: int, rid_base: int):
         self._ck(self.lib.lqcov_part_minimizers_export_dev(self.h, part, x_ptr, y_ptr, cap, rid_base))
+
+    def part_build_from_minimizer_shares_dev(self, part: int, x_ptr: int, y_ptr: int, stride: int, share_n, target_len: np.ndarray, names: Sequence[str]):
+        """the receive buffers of an all-gather: share i = share_n[i] entries from word i * stride"""
+        tl = np.ascontiguousarray(target_len, dtype=np.uint32)
+        sn = np.ascontiguousarray(share_n, dtype=np.uint64)
+        nb, noff = names if isinstance(names, tuple) else _names(names)
+        self._ck(self.lib.lqcov_part_build_from_minimizer_shares_dev(self.h, part, x_ptr, y_ptr, stride, len(sn), sn.ctypes.data, len(tl), tl.ctypes.data, nb, noff.ctypes.data))
 
     def part_build_from_minimizers_dev(self, part: int, x_ptr: int, y_ptr: int, n: int, target_len: np.ndarray, names: Sequence[str]):
         tl = np.ascontiguousarray(target_len, dtype=np.uint32)

@@ -404,16 +404,25 @@ int lqcov_part_sketch(lqcov_handle *h, int part)
 	return guard(h, [&] { if (!h->have_queries) throw std::logic_error("set the queries first"); h->sketch(h->part(part).rs, true); });
 }
 
-int lqcov_part_build_from_minimizers_dev(lqcov_handle *h, int part, const uint64_t *x_dev, const uint64_t *y_dev, uint64_t n,
-                                         uint32_t n_targets, const uint32_t *target_len, const char *names, const uint64_t *name_off)
+// The minimizers of a part as `n_shares` shares laid out `stride` words apart in x_dev / y_dev (what an all-gather of equally
+// sized send buffers leaves behind: share i holds share_n[i] <= stride entries, in read order): copied back to back into the
+// part, then the index is built.  One share of n entries = a plain array.
+int lqcov_part_build_from_minimizer_shares_dev(lqcov_handle *h, int part, const uint64_t *x_dev, const uint64_t *y_dev, uint64_t stride,
+                                               uint32_t n_shares, const uint64_t *share_n,
+                                               uint32_t n_targets, const uint32_t *target_len, const char *names, const uint64_t *name_off)
 {
 	return guard(h, [&] {
 		Part &pt = h->part(part);
 		ReadSetDev &rs = pt.rs;
+		uint64_t n = 0;
+		for (uint32_t i = 0; i < n_shares; ++i) { if (share_n[i] > stride) throw std::invalid_argument("share longer than the stride"); n += share_n[i]; }
 		rs.mx.ensure(n * 8 + 8); rs.my.ensure(n * 8 + 8);
-		if (n) {
-			LQ_HIP_CHECK(hipMemcpyAsync(rs.mx.p, x_dev, n * 8, hipMemcpyDeviceToDevice, h->stream));
-			LQ_HIP_CHECK(hipMemcpyAsync(rs.my.p, y_dev, n * 8, hipMemcpyDeviceToDevice, h->stream));
+		uint64_t at = 0;
+		for (uint32_t i = 0; i < n_shares; ++i) {
+			if (!share_n[i]) continue;
+			LQ_HIP_CHECK(hipMemcpyAsync(rs.mx.as<u64>() + at, x_dev + (uint64_t)i * stride, share_n[i] * 8, hipMemcpyDeviceToDevice, h->stream));
+			LQ_HIP_CHECK(hipMemcpyAsync(rs.my.as<u64>() + at, y_dev + (uint64_t)i * stride, share_n[i] * 8, hipMemcpyDeviceToDevice, h->stream));
+			at += share_n[i];
 		}
 		rs.n_mini = n; rs.n = n_targets;
 		rs.h_len.assign(target_len, target_len + n_targets);
@@ -425,6 +434,12 @@ int lqcov_part_build_from_minimizers_dev(lqcov_handle *h, int part, const uint64
 		rs.sketched = true;
 		h->build_index(pt);
 	});
+}
+
+int lqcov_part_build_from_minimizers_dev(lqcov_handle *h, int part, const uint64_t *x_dev, const uint64_t *y_dev, uint64_t n,
+                                         uint32_t n_targets, const uint32_t *target_len, const char *names, const uint64_t *name_off)
+{
+	return lqcov_part_build_from_minimizer_shares_dev(h, part, x_dev, y_dev, n, 1, &n, n_targets, target_len, names, name_off);
 }
 
 // ---- multi-GPU plumbing: per-part accumulators in / out (device pointers) ------------------------

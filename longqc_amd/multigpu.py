@@ -52,6 +52,18 @@ def _all_gather(t: torch.Tensor, world: int, group) -> List[torch.Tensor]:
     return out
 
 
+def _all_gather_into(t: torch.Tensor, world: int, group) -> torch.Tensor:
+    """every rank's `t` (equal sizes) side by side in one tensor of world * len(t) entries: one collective, one receive buffer"""
+    if _staged(t, group) or dist.get_backend(group) == "gloo":
+        h = t.cpu()
+        out = torch.empty(world * h.numel(), dtype=h.dtype)
+        dist.all_gather(list(out.view(world, -1).unbind(0)), h, group=group)
+        return out.to(t.device)
+    out = torch.empty(world * t.numel(), dtype=t.dtype, device=t.device)
+    dist.all_gather_into_tensor(out, t, group=group)
+    return out
+
+
 def _all_reduce(t: torch.Tensor, group, op=None) -> None:
     op = op if op is not None else dist.ReduceOp.SUM
     if _staged(t, group):
@@ -226,6 +238,16 @@ def shard_queries(lengths, world: int) -> List[List[int]]:
     return [sorted(v) for v in out]
 
 
+def exchange_peak_bytes(sizes, world: int) -> int:
+    """HBM held at the peak of one part's minimizer exchange on a rank: per array (x and y) one send buffer of cap = max(sizes)
+    words and one receive buffer of world * cap words, plus the part's own copy the engine makes from the shares (16 B per
+    minimizer).  With shares cut by bases (within a percent of each other) that is (1 + 1/world) * 1.01 + 1 <= 2.2 times
+    16 * M_t at world = 8."""
+    cap = max(max(sizes), 1)
+    ex = (world + 1) * cap * 16 if world > 1 else cap * 16
+    return ex + 16 * int(sum(sizes))
+
+
 class QueryShardRunner:
     """One engine handle per rank holding this rank's queries; map_part() replicates the index of one part and maps them."""
 
@@ -253,28 +275,29 @@ class QueryShardRunner:
             sizes = [int(t.item()) for t in sizes]
         else:
             sizes = [n_mine]
+        # Equal send buffers of `cap` words (the shares are cut by bases, so they differ by a percent), one receive buffer of
+        # world * cap words per array, filled in place by all_gather_into_tensor; the engine copies the shares back to back
+        # into the part (lqcov_part_build_from_minimizer_shares_dev): no concatenated copy here.  Peak of the exchange:
+        # (1 + 1 / world) * 16 * M_t * (cap * world / M_t) bytes here + the part's own 16 * M_t.
         cap = max(max(sizes), 1)
+        self.last_sizes = sizes
+        self.last_exchange_bytes = exchange_peak_bytes(sizes, world)      # (tests assert the bound)
         if dev.type == "cuda" and world > 1:
-            # the exchange needs (2 + 4 world) cap words at its peak; the lanes' work space of the previous part is still held by
-            # the engine's pool, which torch's allocator cannot draw from: give it back first if what is free would not do
-            need = (2 + 4 * world) * cap * 8
+            # the lanes' work space of the previous part is still held by the engine's pool, which torch's allocator cannot
+            # draw from: give it back first if what is free would not do
+            need = self.last_exchange_bytes
             if torch.cuda.mem_get_info(dev)[0] < need + need // 4:
                 eng.workspace_trim()
-        xs = torch.zeros(cap, dtype=torch.int64, device=dev); ys = torch.zeros(cap, dtype=torch.int64, device=dev)
+        xs = torch.empty(cap, dtype=torch.int64, device=dev); ys = torch.empty(cap, dtype=torch.int64, device=dev)
         eng.part_minimizers_export(part, xs.data_ptr(), ys.data_ptr(), cap, rid_base)
         if world > 1:
-            gx = _all_gather(xs, world, self.group); gy = _all_gather(ys, world, self.group)   # RCCL all-gather over xGMI
-            x = torch.cat([g[:n] for g, n in zip(gx, sizes)]).contiguous(); y = torch.cat([g[:n] for g, n in zip(gy, sizes)]).contiguous()
-            del gx, gy
+            gx = _all_gather_into(xs, world, self.group); gy = _all_gather_into(ys, world, self.group)   # RCCL all-gather over xGMI
+            del xs, ys
         else:
-            x, y = xs[:n_mine].contiguous(), ys[:n_mine].contiguous()
-        del xs, ys
-        n = int(x.shape[0])
-        if n == 0:
-            x = torch.zeros(1, dtype=torch.int64, device=dev); y = torch.zeros(1, dtype=torch.int64, device=dev)
+            gx, gy = xs, ys
         eng.part_clear(part)                                      # the share's reads are no longer needed: the part becomes the whole index part
-        eng.part_build_from_minimizers_dev(part, x.data_ptr(), y.data_ptr(), n, np.asarray(all_lens, dtype=np.uint32), all_names)
-        del x, y
+        eng.part_build_from_minimizer_shares_dev(part, gx.data_ptr(), gy.data_ptr(), cap, sizes, np.asarray(all_lens, dtype=np.uint32), all_names)
+        del gx, gy
         if dev.type == "cuda":
             torch.cuda.empty_cache()                              # the exchange buffers go back to the device: the mapping sizes its work space from what is free
         eng.part_map(part)

@@ -110,6 +110,7 @@ def _worker_qshard(rank, world, port, argv_I, out_path, use_gpu=False):
             if hi > lo:
                 eng.part_add_targets(pid, tn[s + lo:s + hi], ts[s + lo:s + hi])
             runner.map_part(pid, lo, tn[s:e], lens[s:e])
+            assert len(runner.last_sizes) == world and runner.last_exchange_bytes == multigpu.exchange_peak_bytes(runner.last_sizes, world)
         table = runner.gather_table()
         if rank == 0:
             open(out_path, "w").write(table)
@@ -135,3 +136,13 @@ def test_balanced_ranges_and_query_shards():
     assert sorted(sum(sh, [])) == list(range(len(lens)))
     assert abs(sum(lens[i] for i in sh[0]) - sum(lens[i] for i in sh[1])) <= 2
     assert multigpu.balanced_ranges([3, 3], 4)[-1][1] == 2            # more ranks than reads: empty shares
+
+
+def test_exchange_memory_bound_at_eight_ranks():
+    """the minimizer exchange of a 4-Gbase part (1.34 G minimizers) cut by bases into 8 shares within a percent of each other:
+    one send and one receive buffer per array + the part's own copy stay below 2.2 x 16 B per minimizer"""
+    M = 1340000000
+    rng = np.random.default_rng(3)
+    sizes = [int(M / 8 * (1 + 0.01 * (rng.random() - 0.5))) for _ in range(8)]
+    assert multigpu.exchange_peak_bytes(sizes, 8) <= 2.2 * 16 * sum(sizes)
+    assert multigpu.exchange_peak_bytes([M], 1) == 2 * 16 * M
