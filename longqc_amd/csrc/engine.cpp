@@ -94,6 +94,8 @@ void Knobs::read_env()
 	debug_sort = getenv("LQCOV_DEBUG_SORT") != nullptr;
 	sketch_kpt = (u32)std::min<long>(64, std::max<long>(1, num("LQCOV_SKETCH_KPT", 4)));
 	sketch_machine_only = is("LQCOV_SKETCH", "machine");
+	two_tiled = !is("LQCOV_TWO", "block");
+	walk_mask = is("LQCOV_WALK_MASK", "lane") ? 1 : is("LQCOV_WALK_MASK", "none") ? 2 : 0;
 }
 
 lqcov_handle::lqcov_handle(const lqcov_params &p, int dev) : P(p), device(dev)
@@ -319,8 +321,10 @@ void lqcov_handle::sketch(ReadSetDev &rs, bool rid_in_y)
 				LQ_HIP_CHECK(hipStreamSynchronize(stream));          // (toff dies with this scope)
 				if (n_tiles) {
 					StageTimer t(this, "k_sketch_dp_mask", in_bytes + nc * 17);
-					LQ_LAUNCH(k_sketch_dp_mask, (u32)std::min<u64>(n_tiles, 1u << 22), LQ_DPT_THREADS, stream, rs.codes.as<u64>(), rs.amb.as<u32>(), rs.d_coff.as<u64>(), rs.d_len.as<u32>(), sk_toff.as<u64>(), rs.n, n_tiles, sp,
-					          sk_owned.as<u8>(), sk_mask.as<u32>(), sk_flag.as<u32>());
+					if (P.k <= 16) LQ_LAUNCH(k_sketch_dp_mask<u32>, (u32)std::min<u64>(n_tiles, 1u << 22), LQ_DPT_THREADS, stream, rs.codes.as<u64>(), rs.amb.as<u32>(), rs.d_coff.as<u64>(), rs.d_len.as<u32>(), sk_toff.as<u64>(), rs.n, n_tiles, sp,
+					                         sk_owned.as<u8>(), sk_mask.as<u32>(), sk_flag.as<u32>());
+					else LQ_LAUNCH(k_sketch_dp_mask<u64>, (u32)std::min<u64>(n_tiles, 1u << 22), LQ_DPT_THREADS, stream, rs.codes.as<u64>(), rs.amb.as<u32>(), rs.d_coff.as<u64>(), rs.d_len.as<u32>(), sk_toff.as<u64>(), rs.n, n_tiles, sp,
+					               sk_owned.as<u8>(), sk_mask.as<u32>(), sk_flag.as<u32>());
 					check_launch();
 				}
 				dp_owned = sk_owned.as<u8>();
@@ -887,8 +891,22 @@ void lqcov_handle::sort_batch(MapLane &L, Part &pt, u32 q0, u32 nqb, u64 a_base,
 			check_launch();
 			{	// closed-form two-bucket passes (the strand bit at the top level)
 				StageTimer t(this, sD, "k_sort_two", nA * 6);
-				LQ_LAUNCH(k_sort_two, std::min<u32>(ns, 16384), LQ_TWO_THREADS, sD, cur, L.seg_info.as<SegInfo>(), L.two_list.as<u32>(), cnt + LQ_C_TWO, L.sort_d.as<u8>(), hx, py, L.sort_dst.as<u32>());
-				check_launch();
+				if (K.two_tiled) {
+					// over tiles: count the X / Y elements of every tile, scan per sub-array, position lists, destinations
+					L.two_tiles.ensure(max_tiles * sizeof(SortTile)); L.two_tile0.ensure((u64)ns * 4); L.two_tcnt.ensure(max_tiles * 8); L.two_m.ensure((u64)ns * 4);
+					dzero(cnt + LQ_C_TWO_TILES, 4, sD);
+					const SortTile *tt = L.two_tiles.as<SortTile>();
+					const u32 *ntt = cnt + LQ_C_TWO_TILES;
+					const u32 g_two = std::min<u32>(g_tile, 8192);         // grid-stride: a level without two-bucket sub-arrays costs near-empty launches
+					LQ_LAUNCH(k_two_tiles, std::min<u32>(ns / 256 + 1, 4096), 256, sD, cur, L.two_list.as<u32>(), cnt + LQ_C_TWO, tile, L.two_tiles.as<SortTile>(), cnt + LQ_C_TWO_TILES, L.two_tile0.as<u32>()); check_launch();
+					LQ_LAUNCH((k_sort_two_tiled<0>), g_two, 256, sD, cur, L.seg_info.as<SegInfo>(), tt, ntt, tile, L.sort_d.as<u8>(), L.two_tcnt.as<u32>(), L.two_m.as<u32>(), hx, py, L.sort_dst.as<u32>()); check_launch();
+					LQ_LAUNCH(k_sort_two_scan, std::min<u32>(ns, 16384), 64, sD, cur, L.two_list.as<u32>(), cnt + LQ_C_TWO, tile, L.two_tile0.as<u32>(), L.two_tcnt.as<u32>(), L.two_m.as<u32>()); check_launch();
+					LQ_LAUNCH((k_sort_two_tiled<1>), g_two, 256, sD, cur, L.seg_info.as<SegInfo>(), tt, ntt, tile, L.sort_d.as<u8>(), L.two_tcnt.as<u32>(), L.two_m.as<u32>(), hx, py, L.sort_dst.as<u32>()); check_launch();
+					LQ_LAUNCH((k_sort_two_tiled<2>), g_two, 256, sD, cur, L.seg_info.as<SegInfo>(), tt, ntt, tile, L.sort_d.as<u8>(), L.two_tcnt.as<u32>(), L.two_m.as<u32>(), hx, py, L.sort_dst.as<u32>()); check_launch();
+				} else {
+					LQ_LAUNCH(k_sort_two, std::min<u32>(ns, 16384), LQ_TWO_THREADS, sD, cur, L.seg_info.as<SegInfo>(), L.two_list.as<u32>(), cnt + LQ_C_TWO, L.sort_d.as<u8>(), hx, py, L.sort_dst.as<u32>());
+					check_launch();
+				}
 			}
 			{
 				const u8 *dD = L.sort_d.as<u8>(); const u32 *dH = L.hist.as<u32>(), *dBg = L.begs.as<u32>(); u32 *dDst = L.sort_dst.as<u32>();
@@ -1114,8 +1132,9 @@ void lqcov_handle::map_part(Part &pt)
 			// alone, 1100 ms beside the walkers).  Their stream may only use every fourth CU; 64 CUs x 32 waves are plenty for them.
 			// (Keeping the other streams off those CUs as well was measured in round 3: slower, 2.15 vs 1.85-2.1 s per step.)
 			uint32_t mask[8];
-			for (int i = 0; i < 8; ++i) mask[i] = 0x11111111u;
-			if (hipExtStreamCreateWithCUMask(&lanes.back()->streamW, 8, mask) != hipSuccess) { (void)hipGetLastError(); LQ_HIP_CHECK(hipStreamCreate(&lanes.back()->streamW)); }
+			const uint32_t m = K.walk_mask == 1 ? 0x11111111u << ((lanes.size() - 1) & 3) : 0x11111111u;   // LQCOV_WALK_MASK=lane: a quarter of the CUs per lane
+			for (int i = 0; i < 8; ++i) mask[i] = m;
+			if (K.walk_mask == 2 || hipExtStreamCreateWithCUMask(&lanes.back()->streamW, 8, mask) != hipSuccess) { (void)hipGetLastError(); LQ_HIP_CHECK(hipStreamCreate(&lanes.back()->streamW)); }
 		}
 		LQ_HIP_CHECK(hipEventCreateWithFlags(&lanes.back()->ev_w0, hipEventDisableTiming));
 		LQ_HIP_CHECK(hipEventCreateWithFlags(&lanes.back()->ev_w1, hipEventDisableTiming));

@@ -39,6 +39,8 @@ struct Knobs {
 	bool no_level_skip = false;           // LQCOV_NO_LEVEL_SKIP: constant key bytes are walked, not stepped over
 	bool debug_sort = false;              // LQCOV_DEBUG_SORT
 	u32 sketch_kpt = 4;                   // LQCOV_SKETCH_KPT: chunks per thread of the sketch state machine
+	bool two_tiled = true;                // LQCOV_TWO=block: the two-bucket pass one block per sub-array instead of over tiles
+	int walk_mask = 0;                    // LQCOV_WALK_MASK: the walkers' CUs: every fourth CU for all lanes (default) | lane: a different quarter per lane | none
 	bool sketch_machine_only = false;     // LQCOV_SKETCH=machine: the state machine decides every chunk (no data-parallel kernel)
 	void read_env();
 };
@@ -85,14 +87,14 @@ struct MapLane {
 	Prim prim;
 	bool gate_passed = false;             // this batch has reached its long walks (see map_part)
 	DBuf A, B, R0, segs0, segs1, n_segs, hist, begs;     // A: anchors (final home), B: originals of the klib queries / other buffer of the parallel sort, R0: records (R1 lives in scr)
-	DBuf tile_list;
+	DBuf tile_list, two_tiles, two_tile0, two_tcnt, two_m;
 	DBuf sort_d, sort_dst, seg_info, walk_list, two_list, scr;
 	DBuf gsel, gkey, gsel2, gkey2, gstart, run_tiles, sel_tiles;
 	DBuf ivl, n_ivl, iv_q, iv_q2, iv_se, iv_se2, ivq_off, iv_scratch;
 	// hand every buffer back (they regrow on the next batch); the caller has drained the lane's streams
 	void release_buffers()
 	{
-		for (DBuf *b : { &sort_cnt, &mhist, &ck_segs, &ck_T, &ck_E, &ck_S, &ck_slot, &ck_n, &prim.tmp, &A, &B, &R0, &segs0, &segs1, &n_segs, &hist, &begs, &tile_list,
+		for (DBuf *b : { &sort_cnt, &mhist, &ck_segs, &ck_T, &ck_E, &ck_S, &ck_slot, &ck_n, &prim.tmp, &A, &B, &R0, &segs0, &segs1, &n_segs, &hist, &begs, &tile_list, &two_tiles, &two_tile0, &two_tcnt, &two_m,
 		                 &sort_d, &sort_dst, &seg_info, &walk_list, &two_list, &scr, &gsel, &gkey, &gsel2, &gkey2, &gstart, &run_tiles, &sel_tiles,
 		                 &ivl, &n_ivl, &iv_q, &iv_q2, &iv_se, &iv_se2, &ivq_off, &iv_scratch }) b->release();
 		for (PsWork &W : ps) for (DBuf *b : { &W.big[0], &W.big[1], &W.fin_s, &W.fin_b, &W.plan, &W.gcnt, &W.gcur, &W.gdiff }) b->release();

@@ -57,6 +57,7 @@ __device__ __forceinline__ u64 lq_ps_load_x(const PSeg &sg, const PsData &P, u32
 // (k_sort_init) and is sorted on its own stream while klib's passes run; set 1 collects the buckets that leave them.
 enum { LQ_C_KLIB0 = 0, LQ_C_KLIB1, LQ_C_TWO, LQ_C_WALK0, LQ_C_WALK1, LQ_C_WALK2, LQ_C_WALK3, LQ_C_WALK4, LQ_C_OVERFLOW, LQ_C_TILES,
        LQ_C_HIST0 = 10,        // (64-bit) anchors the first level's histogram kernel turned into records
+       LQ_C_TWO_TILES = 12,    // tiles of the level's two-bucket sub-arrays
        LQ_C_PS0 = 16, LQ_C_PS1 = 32,
        // 64-bit tallies of the elements each kind of kernel really moved (algorithmic bytes of the stage times)
        LQ_C_HIST = 48, LQ_C_SCATTERED = 50, LQ_C_PART0 = 52, LQ_C_FINS0 = 54, LQ_C_FINB0 = 56, LQ_C_PART1 = 58, LQ_C_FINS1 = 60, LQ_C_FINB1 = 62, LQ_C_N = 64 };

@@ -63,8 +63,12 @@ __global__ void k_pack(const u8 *ascii, const u64 *seq_off, const u64 *coff, u32
 // ---- the state machine ------------------------------------------------------------------------
 struct SkParams { i32 k, w, hpc; u64 mask; u32 shift1; };
 
-__device__ __forceinline__ u64 lq_hash64(u64 key, u64 mask)
-{	// sketch.c:27-37 (Thomas Wang's invertible integer hash, masked to 2k bits)
+// sketch.c:27-37 (Thomas Wang's invertible integer hash, masked to 2k bits).  T = u32 is exact for k <= 16: every step is
+// masked to 2k <= 32 bits, the low 32 bits of the sums and left shifts do not depend on the register width, and the right
+// shifts act on masked values.
+template <class T>
+__device__ __forceinline__ T lq_hash(T key, T mask)
+{
 	key = (~key + (key << 21)) & mask;
 	key = key ^ key >> 24;
 	key = ((key + (key << 3)) + (key << 8)) & mask;
@@ -74,6 +78,7 @@ __device__ __forceinline__ u64 lq_hash64(u64 key, u64 mask)
 	key = (key + (key << 31)) & mask;
 	return key;
 }
+__device__ __forceinline__ u64 lq_hash64(u64 key, u64 mask) { return lq_hash<u64>(key, mask); }
 
 struct ReadView {
 	const u64 *codes; const u32 *amb; u32 len;
@@ -125,6 +130,8 @@ struct SkOut {
 	u64 y_hi;         // rid << 32
 	u32 *mask;        // mask mode: one bit per base of this read (bit p of the read's mask words = the minimizer ending at p is emitted)
 	u32 *dup_flag;    // mask mode: set if a position is emitted twice (never: see k_sketch_emit_mask)
+	u32 pos0;         // mask mode: first base of the chunk at hand; its 128 bits are collected in registers (lo, hi), stored once
+	u64 lo, hi;
 };
 
 // MODE 0: count, 1: emit (x, y) at the thread's offset, 2: set the emitted position's bit in the read's mask
@@ -137,8 +144,13 @@ __device__ __forceinline__ void sk_push(SkOut &o, bool live, u64 x, u32 y32)
 	if (!live) return;
 	if (MODE == LQ_SK_EMIT) { o.x[o.n] = x; o.y[o.n] = o.y_hi | y32; }
 	if (MODE == LQ_SK_MASK) {
-		const u32 pos = y32 >> 1, bit = 1u << (pos & 31);
-		if (atomicOr(&o.mask[pos >> 5], bit) & bit) atomicOr(o.dup_flag, 1u);
+		const u32 pos = y32 >> 1, rel = pos - o.pos0;
+		if (rel < 64) { const u64 b = 1ULL << rel; if (o.lo & b) atomicOr(o.dup_flag, 1u); o.lo |= b; }
+		else if (rel < 128) { const u64 b = 1ULL << (rel - 64); if (o.hi & b) atomicOr(o.dup_flag, 1u); o.hi |= b; }
+		else {                                                    // an older slot, in the chunk before: that chunk's owner may be at work on the word
+			const u32 bit = 1u << (pos & 31);
+			if (atomicOr(&o.mask[pos >> 5], bit) & bit) atomicOr(o.dup_flag, 1u);
+		}
 	}
 	++o.n;
 }
@@ -213,7 +225,7 @@ template <int STRIDE>
 __device__ __forceinline__ void sk_warm(SkState<STRIDE> &s, ReadView &rv, const SkParams &P, u32 i0)
 {
 	u32 halo = 64;
-	SkOut none; none.n = 0; none.x = none.y = nullptr; none.y_hi = 0; none.mask = none.dup_flag = nullptr;
+	SkOut none; none.n = 0; none.x = none.y = nullptr; none.y_hi = 0; none.mask = none.dup_flag = nullptr; none.pos0 = 0; none.lo = none.hi = 0;
 	for (;;) {
 		u32 s0 = i0 > halo ? i0 - halo : 0;
 		if (P.hpc) while (s0 > 0 && !rv.run_start(s0)) --s0;
@@ -282,6 +294,7 @@ __global__ void k_sketch(const u64 *codes, const u32 *amb, const u64 *coff, cons
 		SkOut o; o.n = 0; o.y_hi = rid_in_y ? (u64)r << 32 : 0;
 		o.x = o.y = nullptr; o.mask = nullptr; o.dup_flag = dup_flag;
 		if (EMIT == LQ_SK_EMIT) { o.x = out_x + off[g]; o.y = out_y + off[g]; }
+		o.pos0 = pos0; o.lo = o.hi = 0;
 		if (EMIT == LQ_SK_MASK) o.mask = mask + coff[r] * LQ_CHUNK_WORDS;
 		if (i < pos1) {
 			if (!(have && i_next == i)) sk_warm<STRIDE>(s, rv, P, i);
@@ -296,6 +309,11 @@ __global__ void k_sketch(const u64 *codes, const u32 *amb, const u64 *coff, cons
 			have = true; r_prev = r; i_next = i;
 		}
 		if (EMIT == LQ_SK_COUNT) cnt[g] = (u32)o.n;
+		if (EMIT == LQ_SK_MASK) {                                    // (atomics: the steps of the next chunk may emit slots of this one)
+			u32 *mw = o.mask + (pos0 >> 5);
+			const u32 w4[4] = { (u32)o.lo, (u32)(o.lo >> 32), (u32)o.hi, (u32)(o.hi >> 32) };
+			for (int j = 0; j < 4; ++j) if (w4[j] && (atomicOr(&mw[j], w4[j]) & w4[j])) atomicOr(dup_flag, 1u);
+		}
 	}
 }
 
@@ -339,11 +357,12 @@ __device__ __forceinline__ void lq_window32(const u64 *cw, const u32 *aw, u32 lo
 	if (sh) { raw |= cw[wi + 1] << (64 - 2 * sh); am |= aw[wi + 1] << (32 - sh); }
 }
 
+template <class HT>   // u32 for k <= 16 (hashes and k-mers in one register), u64 otherwise
 __global__ void __launch_bounds__(LQ_DPT_THREADS)
 k_sketch_dp_mask(const u64 *codes, const u32 *amb, const u64 *coff, const u32 *rlen, const u64 *toff, u32 n_reads, u64 n_tiles, SkParams P,
                  u8 *owned, u32 *mask, u32 *dup_flag)
 {
-	__shared__ u64 V[LQ_DPT_N];
+	__shared__ HT V[LQ_DPT_N];
 	__shared__ u16 PS[LQ_DPT_N];
 	__shared__ u32 lmask[LQ_DPT_N / 32];
 	__shared__ u32 wsum[LQ_DPT_WAVES], whalo[LQ_DPT_WAVES], bad;
@@ -366,7 +385,8 @@ k_sketch_dp_mask(const u64 *codes, const u32 *amb, const u64 *coff, const u32 *r
 		__syncthreads();
 		// this thread's five positions base + 5 t + j; their k-mers are [p - k + 1, p]
 		const u32 i0 = LQ_DPT_PER * t, q0 = base + i0;
-		u64 h[LQ_DPT_PER];
+		HT h[LQ_DPT_PER];
+		const HT kmask = (HT)P.mask;
 		u32 sl = 0;                                               // bit j: position j is a slot
 		if (q0 < b) {
 			u64 raw; u32 am;
@@ -377,11 +397,11 @@ k_sketch_dp_mask(const u64 *codes, const u32 *amb, const u64 *coff, const u32 *r
 			for (int j = 0; j < LQ_DPT_PER; ++j) {
 				h[j] = 0;
 				if (q0 + j < b) {
-					const u64 rj = (raw >> (2 * j)) & P.mask;
+					const HT rj = (HT)(raw >> (2 * j)) & kmask;
 					n_amb |= (am >> j) & (u32)((1ULL << k) - 1);
-					const u64 rv = ~rj & P.mask;                       // complement, oldest base lowest: the machine's rv
-					const u64 fw = (R >> (2 * (32 - j - k))) & P.mask;   // newest base lowest: the machine's fw
-					if (fw != rv) { h[j] = lq_hash64(fw < rv ? fw : rv, P.mask); sl |= 1u << j; }
+					const HT rv = ~rj & kmask;                         // complement, oldest base lowest: the machine's rv
+					const HT fw = (HT)(R >> (2 * (32 - j - k))) & kmask;   // newest base lowest: the machine's fw
+					if (fw != rv) { h[j] = lq_hash<HT>(fw < rv ? fw : rv, kmask); sl |= 1u << j; }
 				}
 			}
 			if (n_amb) atomicOr(&bad, 1u);                            // an ambiguous base within reach: the machine's memory matters
@@ -415,7 +435,7 @@ k_sketch_dp_mask(const u64 *codes, const u32 *amb, const u64 *coff, const u32 *r
 			u32 s = ts;
 			for (int j = 0; j < LQ_DPT_PER; ++j) if (sl >> j & 1) {
 				if (i0 + j >= LQ_DP_HALO) {
-					const u64 x = h[j];
+					const HT x = h[j];
 					u32 m = s - 1;
 					for (u32 u = 2; u <= (u32)w; ++u) if (V[s - u] < V[m]) m = s - u;          // the newest minimal slot of [s - w, s - 1]
 					u32 after = m;                                                              // the window's minimum after the step
@@ -504,7 +524,8 @@ k_sketch_emit_mask(const u64 *codes, const u32 *amb, const u64 *coff, u32 n_read
 			const u64 rv = ~raw & P.mask;
 			const u64 fw = lq_rev2(raw) >> (64 - 2 * k);
 			const u32 z = fw < rv ? 0u : 1u;
-			out_x[o0 + j] = lq_hash64(z ? rv : fw, P.mask) << 8 | (u64)k;
+			const u64 km = z ? rv : fw;
+			out_x[o0 + j] = (k <= 16 ? (u64)lq_hash<u32>((u32)km, (u32)P.mask) : lq_hash<u64>(km, P.mask)) << 8 | (u64)k;
 			out_y[o0 + j] = (rid_in_y ? (u64)r << 32 : 0) | (u64)(pos << 1 | z);
 		}
 		__syncthreads();

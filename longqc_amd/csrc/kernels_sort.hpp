@@ -276,6 +276,121 @@ k_sort_two(const SortSeg *segs, const SegInfo *info, const u32 *two_list, const 
 	}
 }
 
+// ---- the two-bucket pass over tiles ---------------------------------------------------------------------------------
+// The strand pass at the top of every (query) array is a two-bucket pass over the whole array: one block per sub-array
+// (k_sort_two) is a few hundred blocks walking ~10^5..10^6 digits each in a serial loop of tiles.  Here: k_two_tiles lists the
+// tiles of the two-bucket sub-arrays (contiguous per sub-array, first index in tile0[]), <0> counts the X / Y elements of every
+// tile, one wave per sub-array scans its tile counts (k_sort_two_scan; the total is m), <1> writes the position lists HX / PY
+// at tile base + rank, <2> the destinations -- the formulas of k_sort_two above, the ranks from the scanned tile counts.
+__global__ void __launch_bounds__(256)
+k_two_tiles(const SortSeg *segs, const u32 *two_list, const u32 *n_two_p, u32 tile, SortTile *tiles, u32 *n_tiles, u32 *tile0)
+{
+	const u32 n_two = *n_two_p;
+	const u32 lane = threadIdx.x & 63;
+	for (u32 base = blockIdx.x * blockDim.x; base < n_two; base += gridDim.x * blockDim.x) {
+		const u32 li = base + threadIdx.x;
+		u32 nt = 0, sgi = 0;
+		if (li < n_two) { sgi = two_list[li]; nt = (segs[sgi].len + tile - 1) / tile; }
+		u32 inc = nt;
+		for (int d = 1; d < 64; d <<= 1) { const u32 o = __shfl_up(inc, d); if ((int)lane >= d) inc += o; }
+		u32 wbase = 0;
+		if (lane == 63 && inc) wbase = atomicAdd(n_tiles, inc);
+		wbase = __shfl(wbase, 63);
+		const u32 at = wbase + inc - nt;
+		if (li < n_two) tile0[sgi] = at;
+		for (u32 t = 0; t < nt; ++t) { SortTile e; e.sgi = sgi; e.tile = t; tiles[at + t] = e; }
+	}
+}
+
+// exclusive scan of one sub-array's tile counts (X, Y interleaved), one wave per sub-array; two_m[sgi] = number of X (= of Y)
+__global__ void __launch_bounds__(64)
+k_sort_two_scan(const SortSeg *segs, const u32 *two_list, const u32 *n_two_p, u32 tile, const u32 *tile0, u32 *tcnt, u32 *two_m)
+{
+	const u32 n_two = *n_two_p, lane = threadIdx.x;
+	for (u32 li = blockIdx.x; li < n_two; li += gridDim.x) {
+		const u32 sgi = two_list[li];
+		const u32 nt = (segs[sgi].len + tile - 1) / tile;
+		u32 *c = tcnt + 2 * (u64)tile0[sgi];
+		const u32 per = (nt + 63) / 64, a = lane * per < nt ? lane * per : nt, b = a + per < nt ? a + per : nt;
+		u32 sx = 0, sy = 0;
+		for (u32 x = a; x < b; ++x) { sx += c[2 * x]; sy += c[2 * x + 1]; }
+		u32 ix = sx, iy = sy;
+		for (int d = 1; d < 64; d <<= 1) { const u32 ox = __shfl_up(ix, d), oy = __shfl_up(iy, d); if ((int)lane >= d) { ix += ox; iy += oy; } }
+		u32 rx = ix - sx, ry = iy - sy;
+		for (u32 x = a; x < b; ++x) { const u32 vx = c[2 * x], vy = c[2 * x + 1]; c[2 * x] = rx; c[2 * x + 1] = ry; rx += vx; ry += vy; }
+		if (lane == 63) two_m[sgi] = ix;
+	}
+}
+
+template <int MODE>   // 0: count, 1: position lists, 2: destinations
+__global__ void __launch_bounds__(256)
+k_sort_two_tiled(const SortSeg *segs, const SegInfo *info, const SortTile *tiles, const u32 *n_tiles_p, u32 tile, const u8 *D,
+                 u32 *tcnt, const u32 *two_m, u32 *HX, u32 *PY, u32 *dst)
+{
+	__shared__ u32 wx[4], wy[4];
+	const u32 t = threadIdx.x, lane = t & 63, wv = t >> 6;
+	const u32 n_tiles = *n_tiles_p;
+	for (u32 ti = blockIdx.x; ti < n_tiles; ti += gridDim.x) {
+		const SortTile tl = tiles[ti];
+		const SortSeg sg = segs[tl.sgi];
+		const SegInfo si = info[tl.sgi];
+		const u64 off = sg.off;
+		const u32 i0 = tl.tile * tile, i1 = sg.len - i0 < tile ? sg.len : i0 + tile;
+		const u64 lo = off + i0, hi = off + i1, a0 = lo & ~(u64)15;
+		const u32 n_words = (u32)((hi - a0 + 15) >> 4);
+		const u32 cnt0 = si.cnt0, c1 = si.c1;
+		u32 bx = 0, by = 0, m = 0;                              // X / Y elements before the words at hand
+		if (MODE) { bx = tcnt[2 * (u64)ti]; by = tcnt[2 * (u64)ti + 1]; }
+		if (MODE == 2) m = two_m[tl.sgi];
+		u32 *hx = HX + off, *py = PY + off;
+		for (u32 w0 = 0; w0 < n_words; w0 += 256) {
+			const u32 wi = w0 + t;
+			const u64 p = a0 + (u64)wi * 16;
+			TwoW16 W; W.w[0] = W.w[1] = W.w[2] = W.w[3] = 0;
+			u32 cx = 0, cy = 0;
+			if (wi < n_words) {
+				W = *(const TwoW16*)(D + p);
+				for (u32 k = 0; k < 16; ++k) {
+					const u64 g = p + k;
+					if (g >= lo && g < hi) { const u32 i = (u32)(g - off); const bool in0 = i < cnt0, is1 = LQ_TWO_DIGIT(W, k) == c1; cx += in0 && is1; cy += !in0 && !is1; }
+				}
+			}
+			// exclusive ranks of this thread's word among the 256 words at hand, and their totals
+			u32 ix = cx, iy = cy;
+			for (int d = 1; d < 64; d <<= 1) { const u32 ox = __shfl_up(ix, d), oy = __shfl_up(iy, d); if ((int)lane >= d) { ix += ox; iy += oy; } }
+			if (lane == 63) { wx[wv] = ix; wy[wv] = iy; }
+			__syncthreads();
+			u32 rx = bx + ix - cx, ry = by + iy - cy, tx = 0, ty = 0;
+			for (u32 q = 0; q < 4; ++q) { if (q < wv) { rx += wx[q]; ry += wy[q]; } tx += wx[q]; ty += wy[q]; }
+			if (MODE && wi < n_words) {
+				for (u32 k = 0; k < 16; ++k) {
+					const u64 g = p + k;
+					if (g >= lo && g < hi) {
+						const u32 i = (u32)(g - off); const bool in0 = i < cnt0, is1 = LQ_TWO_DIGIT(W, k) == c1;
+						if (MODE == 1) {
+							if (in0 && is1) hx[rx++] = i;
+							else if (!in0 && !is1) py[ry++] = i;
+						} else {
+							u32 d;
+							if (in0) {
+								if (!is1) d = i;
+								else { d = rx == 0 ? cnt0 : py[rx - 1] + 1; ++rx; }      // X_t takes the first slot of run t
+							} else {
+								if (!is1) { d = hx[ry]; ++ry; }                           // Y_t drops into the hole of X_t
+								else d = ry < m ? i + 1 : i;                              // run elements shift right by one
+							}
+							dst[g] = d;
+						}
+					}
+				}
+			}
+			bx += tx; by += ty;
+			__syncthreads();
+		}
+		if (MODE == 0 && t == 0) { tcnt[2 * (u64)ti] = bx; tcnt[2 * (u64)ti + 1] = by; }
+	}
+}
+
 // ---- general pass: the token walk over digit bytes ---------------------------------------------
 // The same walk with the sub-array's digits staged in LDS: one block per sub-array; all threads load the
 // digit bytes, then one lane walks.  Each bucket keeps {cursor (24 bit), digit of the element under the cursor
