@@ -312,18 +312,21 @@ void lqcov_handle::sketch(ReadSetDev &rs, bool rid_in_y)
 			dzero(sk_mask.p, nc * LQ_CHUNK_WORDS * 4, stream); dzero(sk_flag.p, 4, stream);
 			const bool dp = P.w <= 16 && P.w + P.k - 1 <= 48 && P.k <= 28 && P.k >= 2 && !K.sketch_machine_only;
 			const u8 *dp_owned = nullptr;
+			sk_grid.ensure((nc / LQ_EM_CH + 2) * 4);
+			if (!dp) { LQ_LAUNCH(k_sketch_owners, nblk(rs.n, 256), 256, stream, rs.d_coff.as<u64>(), (const u64*)nullptr, rs.n, (u32*)nullptr, sk_grid.as<u32>()); check_launch(); }
 			if (dp) {
 				std::vector<u64> toff(rs.n + 1, 0);
 				for (u32 r = 0; r < rs.n; ++r) toff[r + 1] = toff[r] + (rs.h_coff[r + 1] - rs.h_coff[r] + LQ_DPT_CH - 1) / LQ_DPT_CH;
 				const u64 n_tiles = toff[rs.n];
-				sk_toff.ensure((rs.n + 1) * 8); sk_owned.ensure(nc + 8);
+				sk_toff.ensure((rs.n + 1) * 8); sk_owned.ensure(nc + 8); sk_trid.ensure(n_tiles * 4 + 4);
 				h2d(sk_toff.as<u64>(), toff.data(), rs.n + 1, stream);
 				LQ_HIP_CHECK(hipStreamSynchronize(stream));          // (toff dies with this scope)
+				LQ_LAUNCH(k_sketch_owners, nblk(rs.n, 256), 256, stream, rs.d_coff.as<u64>(), sk_toff.as<u64>(), rs.n, sk_trid.as<u32>(), sk_grid.as<u32>()); check_launch();
 				if (n_tiles) {
 					StageTimer t(this, "k_sketch_dp_mask", in_bytes + nc * 17);
-					if (P.k <= 16) LQ_LAUNCH(k_sketch_dp_mask<u32>, (u32)std::min<u64>(n_tiles, 1u << 22), LQ_DPT_THREADS, stream, rs.codes.as<u64>(), rs.amb.as<u32>(), rs.d_coff.as<u64>(), rs.d_len.as<u32>(), sk_toff.as<u64>(), rs.n, n_tiles, sp,
+					if (P.k <= 16) LQ_LAUNCH(k_sketch_dp_mask<u32>, (u32)std::min<u64>(n_tiles, 1u << 22), LQ_DPT_THREADS, stream, rs.codes.as<u64>(), rs.amb.as<u32>(), rs.d_coff.as<u64>(), rs.d_len.as<u32>(), sk_toff.as<u64>(), sk_trid.as<u32>(), rs.n, n_tiles, sp,
 					                         sk_owned.as<u8>(), sk_mask.as<u32>(), sk_flag.as<u32>());
-					else LQ_LAUNCH(k_sketch_dp_mask<u64>, (u32)std::min<u64>(n_tiles, 1u << 22), LQ_DPT_THREADS, stream, rs.codes.as<u64>(), rs.amb.as<u32>(), rs.d_coff.as<u64>(), rs.d_len.as<u32>(), sk_toff.as<u64>(), rs.n, n_tiles, sp,
+					else LQ_LAUNCH(k_sketch_dp_mask<u64>, (u32)std::min<u64>(n_tiles, 1u << 22), LQ_DPT_THREADS, stream, rs.codes.as<u64>(), rs.amb.as<u32>(), rs.d_coff.as<u64>(), rs.d_len.as<u32>(), sk_toff.as<u64>(), sk_trid.as<u32>(), rs.n, n_tiles, sp,
 					               sk_owned.as<u8>(), sk_mask.as<u32>(), sk_flag.as<u32>());
 					check_launch();
 				}
@@ -358,7 +361,7 @@ void lqcov_handle::sketch(ReadSetDev &rs, bool rid_in_y)
 			d2h(&dup, sk_flag.as<u32>(), 1, stream);
 			if (dup) throw std::logic_error("sketch: a position was emitted twice (mask form of the minimizer list does not hold)");
 			StageTimer t(this, "k_sketch_emit_mask", nc * 24 + rs.n_mini * (16 + 4));
-			LQ_LAUNCH(k_sketch_emit_mask, (u32)std::min<u64>((nc + LQ_EM_CH - 1) / LQ_EM_CH, 1u << 22), LQ_EM_THREADS, stream, rs.codes.as<u64>(), rs.amb.as<u32>(), rs.d_coff.as<u64>(), rs.n, nc, sp, (int)rid_in_y,
+			LQ_LAUNCH(k_sketch_emit_mask, (u32)std::min<u64>((nc + LQ_EM_CH - 1) / LQ_EM_CH, 1u << 22), LQ_EM_THREADS, stream, rs.codes.as<u64>(), rs.amb.as<u32>(), rs.d_coff.as<u64>(), sk_grid.as<u32>(), rs.n, nc, sp, (int)rid_in_y,
 			          sk_mask.as<u32>(), off.as<u64>(), rs.mx.as<u64>(), rs.my.as<u64>());
 			check_launch();
 		} else {
@@ -717,18 +720,20 @@ static void ps_pass(lqcov_handle *h, MapLane &L, int set, hipStream_t s, u64 nA,
 	const u32 g_segs = (u32)std::min<u64>(Ls.cap_big, 4096);
 	const u32 nxt = cur ^ 1;
 	dzero(cnt + (nxt ? LQ_P_BIG1 : LQ_P_BIG0), 4, s);
-	LQ_LAUNCH(k_ps_plan, 1, 256, s, Ls.big[cur], cnt + (cur ? LQ_P_BIG1 : LQ_P_BIG0), W.plan.as<PPlan>(), cnt, cap_cnt, Ls.child_target); check_launch();
+	const u32 cap_tiles = (u32)std::min<u64>(W.tmap.cap / 4, 0xfffffff0ULL);
+	LQ_LAUNCH(k_ps_plan, 1, 256, s, Ls.big[cur], cnt + (cur ? LQ_P_BIG1 : LQ_P_BIG0), W.plan.as<PPlan>(), cnt, cap_cnt, cap_tiles, Ls.child_target); check_launch();
+	LQ_LAUNCH(k_ps_tilemap, std::min<u32>(g_segs / 4 + 1, 1024), 256, s, W.plan.as<PPlan>(), cnt + (cur ? LQ_P_BIG1 : LQ_P_BIG0), cnt, W.tmap.as<u32>(), cap_tiles); check_launch();
 	dzero(W.gcnt.p, (size_t)cap_cnt * 4, s);
 	dzero(W.gdiff.p, (size_t)Ls.cap_big * 8, s);
 	{
 		StageTimer t(h, s, "k_ps_hist");
-		LQ_LAUNCH(k_ps_hist, g_tiles, LQ_PS_THREADS, s, Ls.big[cur], cnt + (cur ? LQ_P_BIG1 : LQ_P_BIG0), W.plan.as<PPlan>(), cnt, pd, km, W.gcnt.as<u32>(), W.gdiff.as<unsigned long long>()); check_launch();
+		LQ_LAUNCH(k_ps_hist, g_tiles, LQ_PS_THREADS, s, Ls.big[cur], cnt + (cur ? LQ_P_BIG1 : LQ_P_BIG0), W.plan.as<PPlan>(), W.tmap.as<u32>(), cnt, pd, km, W.gcnt.as<u32>(), W.gdiff.as<unsigned long long>()); check_launch();
 	}
 	LQ_LAUNCH(k_ps_scan, g_segs, 256, s, Ls.big[cur], cnt + (cur ? LQ_P_BIG1 : LQ_P_BIG0), W.plan.as<PPlan>(), W.gcnt.as<u32>(), W.gcur.as<u32>(), W.gdiff.as<unsigned long long>(), Ls, (u32)(nxt ? LQ_P_BIG1 : LQ_P_BIG0),
 	          (unsigned long long*)(L.sort_cnt.as<u32>() + (set ? LQ_C_PART1 : LQ_C_PART0))); check_launch();
 	{
 		StageTimer t(h, s, "k_ps_scatter");
-		LQ_LAUNCH(k_ps_scatter, g_tiles, LQ_PS_THREADS, s, Ls.big[cur], cnt + (cur ? LQ_P_BIG1 : LQ_P_BIG0), W.plan.as<PPlan>(), cnt, pd, km, W.gcur.as<u32>()); check_launch();
+		LQ_LAUNCH(k_ps_scatter, g_tiles, LQ_PS_THREADS, s, Ls.big[cur], cnt + (cur ? LQ_P_BIG1 : LQ_P_BIG0), W.plan.as<PPlan>(), W.tmap.as<u32>(), cnt, pd, km, W.gcur.as<u32>()); check_launch();
 	}
 }
 
@@ -833,6 +838,7 @@ void lqcov_handle::sort_batch(MapLane &L, Part &pt, u32 q0, u32 nqb, u64 a_base,
 		W.fin_s.ensure(cap_fin * sizeof(PSeg)); W.fin_b.ensure(cap_fin * sizeof(PSeg));
 		W.gcnt.ensure(cap_big * 256 * 4); W.gcur.ensure(cap_big * 256 * 4);
 		W.gdiff.ensure(W.big[0].cap / sizeof(PSeg) * 8 + 8);   // (one word per entry the big list can hold)
+		W.tmap.ensure((nA / LQ_PS_TILE + W.big[0].cap / sizeof(PSeg) + 2) * 4);   // (a segment's last tile may be partial)
 	}
 	L.segs0.ensure(max_segs * sizeof(SortSeg)); L.segs1.ensure(max_segs * sizeof(SortSeg));
 	dzero(L.sort_cnt.p, LQ_C_N * 4, sD);

@@ -73,7 +73,7 @@ struct Part {
 // One mapping lane: a stream with its own scan/sort scratch and per-batch work space.  Query batches of a part are
 // independent (lqmap.c:170-330 runs one query at a time), so lanes run them concurrently.
 struct PsWork {                           // one set of psort lists + the scratch of its partition passes (kernels_psort.hpp)
-	DBuf big[2], fin_s, fin_b, plan, gcnt, gcur, gdiff;
+	DBuf big[2], fin_s, fin_b, plan, gcnt, gcur, gdiff, tmap;
 };
 
 struct MapLane {
@@ -97,7 +97,7 @@ struct MapLane {
 		for (DBuf *b : { &sort_cnt, &mhist, &ck_segs, &ck_T, &ck_E, &ck_S, &ck_slot, &ck_n, &prim.tmp, &A, &B, &R0, &segs0, &segs1, &n_segs, &hist, &begs, &tile_list, &two_tiles, &two_tile0, &two_tcnt, &two_m,
 		                 &sort_d, &sort_dst, &seg_info, &walk_list, &two_list, &scr, &gsel, &gkey, &gsel2, &gkey2, &gstart, &run_tiles, &sel_tiles,
 		                 &ivl, &n_ivl, &iv_q, &iv_q2, &iv_se, &iv_se2, &ivq_off, &iv_scratch }) b->release();
-		for (PsWork &W : ps) for (DBuf *b : { &W.big[0], &W.big[1], &W.fin_s, &W.fin_b, &W.plan, &W.gcnt, &W.gcur, &W.gdiff }) b->release();
+		for (PsWork &W : ps) for (DBuf *b : { &W.big[0], &W.big[1], &W.fin_s, &W.fin_b, &W.plan, &W.gcnt, &W.gcur, &W.gdiff, &W.tmap }) b->release();
 	}
 };
 
@@ -153,7 +153,7 @@ struct lqcov_handle {
 	DBuf dbg_chains, n_dbg; u64 dbg_cap = 0; u64 n_dbg_host = 0;
 	DBuf misc;
 	DBuf ix_key, ix_key2, ix_head, ix_uidx, ix_ukey, ix_ustart, ix_ucnt, ix_sorted;   // build_index workspaces
-	DBuf sk_cnt, sk_off, sk_owned, sk_mask, sk_flag, sk_toff;   // sketch: per-chunk minimizer counts / offsets, which kernel decides a chunk, emitted positions (a bit per base), tile offsets
+	DBuf sk_cnt, sk_off, sk_owned, sk_mask, sk_flag, sk_toff, sk_trid, sk_grid;   // sketch: per-chunk minimizer counts / offsets, which kernel decides a chunk, emitted positions (a bit per base), tile offsets
 	u64 last_n_anchors = 0;
 	u64 anchor_budget = 0;
 

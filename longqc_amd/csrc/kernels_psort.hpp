@@ -87,7 +87,7 @@ __device__ __forceinline__ void lq_ps_route(PSeg sg, const PsLists L, u32 big_sl
 
 // ---- plan of one partition pass: digits, tiles and counters of every big segment (one block) ----------------
 __global__ void __launch_bounds__(256)
-k_ps_plan(PSeg *segs, const u32 *n_p, PPlan *plan, u32 *cnt, u32 cap_cnt, u32 child_target)
+k_ps_plan(PSeg *segs, const u32 *n_p, PPlan *plan, u32 *cnt, u32 cap_cnt, u32 cap_tiles, u32 child_target)
 {
 	__shared__ u32 st[256], sc[256], tmp[256], tot_t, tot_c, base_t, base_c;
 	const u32 n = *n_p, t = threadIdx.x;
@@ -117,15 +117,18 @@ k_ps_plan(PSeg *segs, const u32 *n_p, PPlan *plan, u32 *cnt, u32 cap_cnt, u32 ch
 	if (t == 0) {
 		PPlan e; e.tile0 = base_t; e.cnt0 = base_c; plan[n] = e;    // sentinel: totals
 		cnt[LQ_P_TILES] = base_t; cnt[LQ_P_CNT] = base_c;
-		if (base_c > cap_cnt) atomicOr(&cnt[LQ_P_OVERFLOW], 2u);
+		if (base_c > cap_cnt || base_t > cap_tiles) atomicOr(&cnt[LQ_P_OVERFLOW], 2u);
 	}
 }
 
-__device__ __forceinline__ u32 lq_ps_seg_of_tile(const PPlan *plan, u32 n, u32 tile)
+// segment of every tile of the pass (one thread per segment fills its tiles' entries: a tile's block then finds its segment
+// with one load instead of a binary search over the plan -- a dozen dependent loads before it could touch an anchor)
+__global__ void k_ps_tilemap(const PPlan *plan, const u32 *n_p, const u32 *cnt, u32 *tmap, u32 cap_tiles)
 {
-	u32 lo = 0, hi = n;                                      // plan[lo].tile0 <= tile < plan[hi].tile0
-	while (hi - lo > 1) { const u32 mid = lo + ((hi - lo) >> 1); if (plan[mid].tile0 <= tile) lo = mid; else hi = mid; }
-	return lo;
+	const u32 n = *n_p;
+	if (cnt[LQ_P_OVERFLOW] & 2u) return;
+	for (u32 s = blockIdx.x * blockDim.x + threadIdx.x; s < n; s += gridDim.x * blockDim.x)
+		for (u32 t = plan[s].tile0; t < plan[s + 1].tile0 && t < cap_tiles; ++t) tmap[t] = s;
 }
 
 // ---- histogram of the pass's digit, per big segment (tiles stride over the grid) ------------------------------
@@ -134,7 +137,7 @@ __device__ __forceinline__ u32 lq_ps_seg_of_tile(const PPlan *plan, u32 n, u32 t
 // strand and rid are the top 1 + rbits bits of the key) is not moved at all: k_ps_scan re-lists it with `rem` cut down to
 // its highest varying bit.
 __global__ void __launch_bounds__(LQ_PS_THREADS)
-k_ps_hist(const PSeg *segs, const u32 *n_p, const PPlan *plan, const u32 *cnt, PsData P, KeyMap km, u32 *gcnt, unsigned long long *gdiff)
+k_ps_hist(const PSeg *segs, const u32 *n_p, const PPlan *plan, const u32 *tmap, const u32 *cnt, PsData P, KeyMap km, u32 *gcnt, unsigned long long *gdiff)
 {
 	__shared__ u32 lh[256];
 	__shared__ unsigned long long ldiff[LQ_PS_THREADS / 64];
@@ -142,7 +145,7 @@ k_ps_hist(const PSeg *segs, const u32 *n_p, const PPlan *plan, const u32 *cnt, P
 	if (n == 0 || (cnt[LQ_P_OVERFLOW] & 2u)) return;
 	const u32 n_tiles = cnt[LQ_P_TILES], t = threadIdx.x;
 	for (u32 tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-		const u32 s = lq_ps_seg_of_tile(plan, n, tile);
+		const u32 s = tmap[tile];
 		const PSeg sg = segs[s];
 		const PPlan pl = plan[s];
 		const u32 i0 = (tile - pl.tile0) * LQ_PS_TILE, i1 = i0 + LQ_PS_TILE < sg.len ? i0 + LQ_PS_TILE : sg.len;
@@ -214,7 +217,7 @@ k_ps_scan(PSeg *segs, const u32 *n_p, const PPlan *plan, const u32 *gcnt, u32 *g
 
 // ---- the partition pass: every tile moves its elements into their buckets in the other buffer ---------------
 __global__ void __launch_bounds__(LQ_PS_THREADS)
-k_ps_scatter(const PSeg *segs, const u32 *n_p, const PPlan *plan, const u32 *cnt, PsData P, KeyMap km, u32 *gcur)
+k_ps_scatter(const PSeg *segs, const u32 *n_p, const PPlan *plan, const u32 *tmap, const u32 *cnt, PsData P, KeyMap km, u32 *gcur)
 {
 	__shared__ mm128 stage[LQ_PS_TILE];
 	__shared__ u32 lh[256], lo[256], fill[256], gb[256], tmp[256];
@@ -223,7 +226,7 @@ k_ps_scatter(const PSeg *segs, const u32 *n_p, const PPlan *plan, const u32 *cnt
 	const u32 n_tiles = cnt[LQ_P_TILES], t = threadIdx.x;
 	constexpr u32 PER = LQ_PS_TILE / LQ_PS_THREADS;
 	for (u32 tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-		const u32 s = lq_ps_seg_of_tile(plan, n, tile);
+		const u32 s = tmap[tile];
 		const PSeg sg = segs[s];
 		const PPlan pl = plan[s];
 		if (sg.nbits == LQ_PS_SKIP) continue;                     // (uniform) every key in one bucket: k_ps_scan listed the segment again

@@ -357,9 +357,21 @@ __device__ __forceinline__ void lq_window32(const u64 *cw, const u32 *aw, u32 lo
 	if (sh) { raw |= cw[wi + 1] << (64 - 2 * sh); am |= aw[wi + 1] << (32 - sh); }
 }
 
+// read of every tile of k_sketch_dp_mask and of the first chunk of every group of LQ_EM_CH chunks of k_sketch_emit_mask: one
+// thread per read fills the entries of its tiles / of the groups that start inside it.  (A block that looks its read up by
+// binary search spends ~20 dependent loads -- longer than the rest of its work -- before it can touch a base.)
+#define LQ_EM_CH 8
+__global__ void k_sketch_owners(const u64 *coff, const u64 *toff, u32 n_reads, u32 *tile_rid, u32 *group_rid)
+{
+	const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
+	if (r >= n_reads) return;
+	if (tile_rid) for (u64 t = toff[r]; t < toff[r + 1]; ++t) tile_rid[t] = r;
+	for (u64 g = (coff[r] + LQ_EM_CH - 1) / LQ_EM_CH; g * LQ_EM_CH < coff[r + 1]; ++g) group_rid[g] = r;
+}
+
 template <class HT>   // u32 for k <= 16 (hashes and k-mers in one register), u64 otherwise
 __global__ void __launch_bounds__(LQ_DPT_THREADS)
-k_sketch_dp_mask(const u64 *codes, const u32 *amb, const u64 *coff, const u32 *rlen, const u64 *toff, u32 n_reads, u64 n_tiles, SkParams P,
+k_sketch_dp_mask(const u64 *codes, const u32 *amb, const u64 *coff, const u32 *rlen, const u64 *toff, const u32 *tile_rid, u32 n_reads, u64 n_tiles, SkParams P,
                  u8 *owned, u32 *mask, u32 *dup_flag)
 {
 	__shared__ HT V[LQ_DPT_N];
@@ -369,7 +381,7 @@ k_sketch_dp_mask(const u64 *codes, const u32 *amb, const u64 *coff, const u32 *r
 	const u32 t = threadIdx.x, lane = t & 63, wv = t >> 6;
 	const i32 w = P.w, k = P.k;
 	for (u64 T = blockIdx.x; T < n_tiles; T += gridDim.x) {
-		const u32 r = lq_find_seg(toff, n_reads, T);
+		const u32 r = tile_rid[T];
 		const u32 len = rlen[r];
 		const u64 g0 = coff[r] + (T - toff[r]) * LQ_DPT_CH;        // first chunk of the tile
 		const u32 n_ch = (u32)(coff[r + 1] - g0 < LQ_DPT_CH ? coff[r + 1] - g0 : LQ_DPT_CH);
@@ -479,10 +491,9 @@ __global__ void k_mask_count(const u32 *mask, u64 n_chunks, u32 *cnt)
 // One block per LQ_EM_CH chunks: the set bits become a dense list of positions in LDS (rank = bits set before), then one
 // thread per list entry rebuilds the k-mer from the packed codes, hashes it and writes x and y at offset + rank: all lanes
 // busy with a hash, the 16-byte outputs contiguous.
-#define LQ_EM_CH 8
 #define LQ_EM_THREADS 256
 __global__ void __launch_bounds__(LQ_EM_THREADS)
-k_sketch_emit_mask(const u64 *codes, const u32 *amb, const u64 *coff, u32 n_reads, u64 n_chunks, SkParams P, int rid_in_y,
+k_sketch_emit_mask(const u64 *codes, const u32 *amb, const u64 *coff, const u32 *group_rid, u32 n_reads, u64 n_chunks, SkParams P, int rid_in_y,
                    const u32 *mask, const u64 *off, u64 *out_x, u64 *out_y)
 {
 	__shared__ u16 lpos[LQ_EM_CH * LQ_CHUNK];
@@ -499,7 +510,11 @@ k_sketch_emit_mask(const u64 *codes, const u32 *amb, const u64 *coff, u32 n_read
 			for (int d = 1; d < 64; d <<= 1) { const u32 o = __shfl_up(inc, d); if ((int)t >= d) inc += o; }
 			if (t < LQ_EM_CH * LQ_CHUNK_WORDS) { wbits[t] = v; woff[t] = inc - c; }
 			if (t == LQ_EM_CH * LQ_CHUNK_WORDS - 1) woff[LQ_EM_CH * LQ_CHUNK_WORDS] = inc;
-			if (t < n_ch) rid[t] = lq_find_seg(coff, n_reads, g0 + t);
+			if (t < n_ch) {                                         // the group's first chunk is in read group_rid[..]; the others a few reads on at most
+				u32 r = group_rid[g0 / LQ_EM_CH];
+				while (g0 + t >= coff[r + 1]) ++r;
+				rid[t] = r;
+			}
 		}
 		__syncthreads();
 		const u32 n = woff[LQ_EM_CH * LQ_CHUNK_WORDS];

@@ -1,6 +1,6 @@
 #!/bin/bash
 cd /tmp && export TMPDIR=/tmp
-B="python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline"
+B="python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --cache /tmp/lqcov_cache"
 ( timeout 400 rocprofv3 --kernel-trace --output-format csv -d /tmp/prof -o b -- $B 2>&1 | tail -2 ) > $GRAFT_REPO_ROOT/gpurun_out/rocprof.log 2>&1
 python - <<'PY'
 import csv, os
