@@ -719,12 +719,9 @@ static void ps_pass(lqcov_handle *h, MapLane &L, int set, hipStream_t s, u64 nA,
 	const u32 g_tiles = (u32)std::min<u64>((nA + LQ_PS_TILE - 1) / LQ_PS_TILE + 1, 16384);
 	const u32 g_segs = (u32)std::min<u64>(Ls.cap_big, 4096);
 	const u32 nxt = cur ^ 1;
-	dzero(cnt + (nxt ? LQ_P_BIG1 : LQ_P_BIG0), 4, s);
 	const u32 cap_tiles = (u32)std::min<u64>(W.tmap.cap / 4, 0xfffffff0ULL);
-	LQ_LAUNCH(k_ps_plan, 1, 256, s, Ls.big[cur], cnt + (cur ? LQ_P_BIG1 : LQ_P_BIG0), W.plan.as<PPlan>(), cnt, cap_cnt, cap_tiles, Ls.child_target); check_launch();
-	LQ_LAUNCH(k_ps_tilemap, std::min<u32>(g_segs / 4 + 1, 1024), 256, s, W.plan.as<PPlan>(), cnt + (cur ? LQ_P_BIG1 : LQ_P_BIG0), cnt, W.tmap.as<u32>(), cap_tiles); check_launch();
-	dzero(W.gcnt.p, (size_t)cap_cnt * 4, s);
-	dzero(W.gdiff.p, (size_t)Ls.cap_big * 8, s);
+	LQ_LAUNCH(k_ps_plan, 1, 256, s, Ls.big[cur], cnt + (cur ? LQ_P_BIG1 : LQ_P_BIG0), W.plan.as<PPlan>(), cnt, cap_cnt, cap_tiles, Ls.child_target, cnt + (nxt ? LQ_P_BIG1 : LQ_P_BIG0)); check_launch();
+	LQ_LAUNCH(k_ps_tilemap, g_segs, 256, s, W.plan.as<PPlan>(), cnt + (cur ? LQ_P_BIG1 : LQ_P_BIG0), cnt, W.tmap.as<u32>(), cap_tiles, W.gcnt.as<u32>(), W.gdiff.as<unsigned long long>()); check_launch();
 	{
 		StageTimer t(h, s, "k_ps_hist");
 		LQ_LAUNCH(k_ps_hist, g_tiles, LQ_PS_THREADS, s, Ls.big[cur], cnt + (cur ? LQ_P_BIG1 : LQ_P_BIG0), W.plan.as<PPlan>(), W.tmap.as<u32>(), cnt, pd, km, W.gcnt.as<u32>(), W.gdiff.as<unsigned long long>()); check_launch();
@@ -877,14 +874,15 @@ void lqcov_handle::sort_batch(MapLane &L, Part &pt, u32 q0, u32 nqb, u64 a_base,
 		for (int level = 0; level < 8 && ns > 0; ++level) {
 			L.hist.ensure((u64)ns * 1024); L.begs.ensure((u64)ns * 1024); L.mhist.ensure((u64)ns * 1024);
 			L.seg_info.ensure((u64)ns * sizeof(SegInfo)); L.walk_list.ensure((u64)ns * 4 * LQ_WALK_CLASSES); L.two_list.ensure((u64)ns * 4);
-			dzero(cnt + nxt_slot, 4, sD); dzero(cnt + LQ_C_TWO, 4 * (1 + LQ_WALK_CLASSES), sD);
 			const u32 g_seg = std::min<u32>(ns, 1u << 18);
 			// tiles of the level's sub-arrays for the two streaming kernels
 			const u64 max_tiles = nA / tile + ns + 1;
 			const u32 g_tile = ((u32)std::min<u64>(max_tiles, 1u << 18) + 7) & ~7u;      // a multiple of the XCD count (LQ_TILE_LOOP)
 			L.tile_list.ensure(max_tiles * sizeof(SortTile));
-			dzero(cnt + LQ_C_TILES, 4, sD);
-			LQ_LAUNCH(k_sort_tiles, std::min<u32>(ns / 256 + 1, 4096), 256, sD, cur, cnt + cur_slot, tile, L.tile_list.as<SortTile>(), cnt + LQ_C_TILES, L.hist.as<u32>(), L.mhist.as<u32>());
+			// (the counters of the level -- next list, two-bucket and walk class lists, two-bucket tiles -- are zeroed by k_sort_tiles, the
+			// tile counter by the k_rs_children of the level before or the batch's memset: no memset dispatches inside the level loop)
+			LQ_LAUNCH(k_sort_tiles, std::min<u32>(ns / 256 + 1, 4096), 256, sD, cur, cnt + cur_slot, tile, L.tile_list.as<SortTile>(), cnt + LQ_C_TILES, L.hist.as<u32>(), L.mhist.as<u32>(),
+			          cnt + nxt_slot, cnt + LQ_C_TWO, (u32)(1 + LQ_WALK_CLASSES), cnt + LQ_C_TWO_TILES);
 			check_launch();
 			{
 				StageTimer t(this, sD, level == 0 ? "k_rs_hist<first>" : "k_rs_hist");
@@ -900,7 +898,6 @@ void lqcov_handle::sort_batch(MapLane &L, Part &pt, u32 q0, u32 nqb, u64 a_base,
 				if (K.two_tiled) {
 					// over tiles: count the X / Y elements of every tile, scan per sub-array, position lists, destinations
 					L.two_tiles.ensure(max_tiles * sizeof(SortTile)); L.two_tile0.ensure((u64)ns * 4); L.two_tcnt.ensure(max_tiles * 8); L.two_m.ensure((u64)ns * 4);
-					dzero(cnt + LQ_C_TWO_TILES, 4, sD);
 					const SortTile *tt = L.two_tiles.as<SortTile>();
 					const u32 *ntt = cnt + LQ_C_TWO_TILES;
 					const u32 g_two = std::min<u32>(g_tile, 8192);         // grid-stride: a level without two-bucket sub-arrays costs near-empty launches
@@ -1003,7 +1000,7 @@ void lqcov_handle::sort_batch(MapLane &L, Part &pt, u32 q0, u32 nqb, u64 a_base,
 			{
 				StageTimer t(this, sD, "k_rs_children");
 				LQ_LAUNCH(k_rs_children, (u32)std::min<u64>((u64)ns * 4, 1u << 20), LQ_CHILD_THREADS, sD, cur, cnt + cur_slot, R[rb ^ 1], rb ^ 1, dB, dA, L.hist.as<u32>(), L.mhist.as<u32>(), L.begs.as<u32>(),
-				          nxt, cnt + nxt_slot, const_levels, lists(1), km, (int)K.all_klib);
+				          nxt, cnt + nxt_slot, const_levels, lists(1), km, (int)K.all_klib, cnt + LQ_C_TILES);
 				check_launch();
 			}
 			d2h(&ns, cnt + nxt_slot, 1, sD);

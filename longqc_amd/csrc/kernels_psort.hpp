@@ -87,11 +87,11 @@ __device__ __forceinline__ void lq_ps_route(PSeg sg, const PsLists L, u32 big_sl
 
 // ---- plan of one partition pass: digits, tiles and counters of every big segment (one block) ----------------
 __global__ void __launch_bounds__(256)
-k_ps_plan(PSeg *segs, const u32 *n_p, PPlan *plan, u32 *cnt, u32 cap_cnt, u32 cap_tiles, u32 child_target)
+k_ps_plan(PSeg *segs, const u32 *n_p, PPlan *plan, u32 *cnt, u32 cap_cnt, u32 cap_tiles, u32 child_target, u32 *n_next_zero)
 {
 	__shared__ u32 st[256], sc[256], tmp[256], tot_t, tot_c, base_t, base_c;
 	const u32 n = *n_p, t = threadIdx.x;
-	if (t == 0) { base_t = 0; base_c = 0; }
+	if (t == 0) { base_t = 0; base_c = 0; *n_next_zero = 0; }    // (the pass appends its children to the other big list)
 	__syncthreads();
 	for (u32 s0 = 0; s0 < n; s0 += 256) {
 		const u32 s = s0 + t;
@@ -121,14 +121,20 @@ k_ps_plan(PSeg *segs, const u32 *n_p, PPlan *plan, u32 *cnt, u32 cap_cnt, u32 ca
 	}
 }
 
-// segment of every tile of the pass (one thread per segment fills its tiles' entries: a tile's block then finds its segment
-// with one load instead of a binary search over the plan -- a dozen dependent loads before it could touch an anchor)
-__global__ void k_ps_tilemap(const PPlan *plan, const u32 *n_p, const u32 *cnt, u32 *tmap, u32 cap_tiles)
+// segment of every tile of the pass (a tile's block then finds its segment with one load instead of a binary search over the
+// plan -- a dozen dependent loads before it could touch an anchor); the pass's bucket counters and varying-bit words start
+// from zero.  One block per segment (strided), its threads over the segment's tiles and counters.
+__global__ void __launch_bounds__(256)
+k_ps_tilemap(const PPlan *plan, const u32 *n_p, const u32 *cnt, u32 *tmap, u32 cap_tiles, u32 *gcnt, unsigned long long *gdiff)
 {
 	const u32 n = *n_p;
 	if (cnt[LQ_P_OVERFLOW] & 2u) return;
-	for (u32 s = blockIdx.x * blockDim.x + threadIdx.x; s < n; s += gridDim.x * blockDim.x)
-		for (u32 t = plan[s].tile0; t < plan[s + 1].tile0 && t < cap_tiles; ++t) tmap[t] = s;
+	for (u32 s = blockIdx.x; s < n; s += gridDim.x) {
+		const PPlan a = plan[s], b = plan[s + 1];
+		for (u32 t = a.tile0 + threadIdx.x; t < b.tile0 && t < cap_tiles; t += blockDim.x) tmap[t] = s;
+		for (u32 c = a.cnt0 + threadIdx.x; c < b.cnt0; c += blockDim.x) gcnt[c] = 0;
+		if (threadIdx.x == 0) gdiff[s] = 0;
+	}
 }
 
 // ---- histogram of the pass's digit, per big segment (tiles stride over the grid) ------------------------------
@@ -373,12 +379,13 @@ __global__ void k_query_klib(const u64 *aq_off, const u32 *qdirty, u32 n_q, int 
 #define LQ_CHILD_THREADS 64
 __global__ void __launch_bounds__(LQ_CHILD_THREADS)
 k_rs_children(const SortSeg *segs, const u32 *n_segs_p, const RRec *Rn, u32 rb, const mm128 *O, mm128 *A, const u32 *hist, const u32 *mhist, const u32 *begs,
-              SortSeg *next, u32 *n_next, u32 const_levels, PsLists L, KeyMap km, int all_klib)
+              SortSeg *next, u32 *n_next, u32 const_levels, PsLists L, KeyMap km, int all_klib, u32 *n_tiles_zero)
 {
 	__shared__ u64 xs[64];
 	__shared__ u32 flag[64];
 	const u32 n_segs = *n_segs_p;
 	const u32 lane = threadIdx.x;
+	if (blockIdx.x == 0 && lane == 0) *n_tiles_zero = 0;          // the tile list is done with for this level: the next k_sort_tiles counts from zero
 	for (u64 w = blockIdx.x; w < (u64)n_segs * 4; w += gridDim.x) {
 		const u64 t = w * 64 + lane;
 		const u32 sgi = (u32)(t >> 8);
