@@ -25,9 +25,10 @@ import tempfile
 import time
 
 # HIP multiplexes its streams onto GPU_MAX_HW_QUEUES hardware queues (default 4); kernels of streams that share a queue run
-# one after the other.  The engine drives 2 streams per mapping lane + 1: ask for enough queues before the runtime starts
-# (liblqcov.so does the same in lqcov_create when it is the first HIP user of the process).
-os.environ.setdefault("GPU_MAX_HW_QUEUES", os.environ.get("LQCOV_HW_QUEUES", "4"))
+# one after the other.  The engine drives 3 streams per mapping lane + 1: ask for eight queues before the runtime starts
+# (liblqcov.so does the same in lqcov_create when it is the first HIP user of the process; measured: 4 queues 1.74-1.77 s
+# per step at configs[2], 8: 1.71-1.73, 16: 1.73).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", os.environ.get("LQCOV_HW_QUEUES", "8"))
 
 import numpy as np
 

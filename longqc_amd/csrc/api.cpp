@@ -160,6 +160,11 @@ int lqcov_parse_args(int argc, const char *const *argv, lqcov_params *p, const c
 
 lqcov_handle *lqcov_create(const lqcov_params *p, int device)
 {
+	// HIP multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and kernels of streams that share a queue run
+	// one after the other: with the default never more than four of the lanes' kernels run at a time (rocprofv3 kernel trace,
+	// configs[2]).  Eight queues: 1.71-1.73 s per step against 1.74-1.77 (16: the same).  Only effective when the HIP runtime
+	// has not started yet in this process (the CLI, LongQC's exec); hosts that initialise HIP first set it themselves (bench.py).
+	setenv("GPU_MAX_HW_QUEUES", "8", 0);
 	try { return new lqcov_handle(*p, device); }
 	catch (const std::exception &e) { g_create_error = e.what(); fprintf(stderr, "lqcov_create: %s\n", e.what()); return nullptr; }
 }

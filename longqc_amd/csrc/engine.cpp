@@ -94,7 +94,7 @@ void Knobs::read_env()
 	debug_sort = getenv("LQCOV_DEBUG_SORT") != nullptr;
 	sketch_kpt = (u32)std::min<long>(64, std::max<long>(1, num("LQCOV_SKETCH_KPT", 4)));
 	sketch_machine_only = is("LQCOV_SKETCH", "machine");
-	two_tiled = !is("LQCOV_TWO", "block");
+	fin_threads = (int)num("LQCOV_FIN_THREADS", 1024);
 	walk_mask = is("LQCOV_WALK_MASK", "lane") ? 1 : is("LQCOV_WALK_MASK", "none") ? 2 : 0;
 }
 
@@ -746,6 +746,7 @@ static void ps_finish(lqcov_handle *h, MapLane &L, int set, hipStream_t s, u64 n
 		const u32 g = (u32)std::min<u64>(std::min<u64>(Ls.cap_fin, nA / LQ_PS_FIN_SMALL + 64), 4096);
 		// 1024 threads (measured at configs[2], 4 lanes, round 2: 256-thread blocks 2.40 s per step, 512: 2.25, 1024: 2.1-2.2)
 		if (!k32) LQ_LAUNCH((k_ps_finish<LQ_PS_FIN_BIG, 1024, 10, u64>), g, 1024, s, Ls.fin_b, cnt + LQ_P_FIN_B, pd, km, tl);
+		else if (h->K.fin_threads == 512) LQ_LAUNCH((k_ps_finish<LQ_PS_FIN_BIG, 512, 10, u32>), g * 2, 512, s, Ls.fin_b, cnt + LQ_P_FIN_B, pd, km, tl);
 		else LQ_LAUNCH((k_ps_finish<LQ_PS_FIN_BIG, 1024, 10, u32>), g, 1024, s, Ls.fin_b, cnt + LQ_P_FIN_B, pd, km, tl);
 		check_launch();
 	}
@@ -893,23 +894,19 @@ void lqcov_handle::sort_batch(MapLane &L, Part &pt, u32 q0, u32 nqb, u64 a_base,
 			LQ_LAUNCH(k_sort_classify, g_seg, LQ_CLASSIFY_THREADS, sD, cur, cnt + cur_slot, ns, L.hist.as<u32>(), L.begs.as<u32>(), L.seg_info.as<SegInfo>(),
 			          L.walk_list.as<u32>(), L.two_list.as<u32>(), cnt + LQ_C_TWO, cnt + LQ_C_WALK0, wcaps);
 			check_launch();
-			{	// closed-form two-bucket passes (the strand bit at the top level)
+			{	// closed-form two-bucket passes (the strand bit at the top level), over tiles: count the X / Y elements of every tile, scan
+				// per sub-array, position lists, then destinations + the move of the records
 				StageTimer t(this, sD, "k_sort_two", nA * 6);
-				if (K.two_tiled) {
-					// over tiles: count the X / Y elements of every tile, scan per sub-array, position lists, destinations
-					L.two_tiles.ensure(max_tiles * sizeof(SortTile)); L.two_tile0.ensure((u64)ns * 4); L.two_tcnt.ensure(max_tiles * 8); L.two_m.ensure((u64)ns * 4);
-					const SortTile *tt = L.two_tiles.as<SortTile>();
-					const u32 *ntt = cnt + LQ_C_TWO_TILES;
-					const u32 g_two = std::min<u32>(g_tile, 8192);         // grid-stride: a level without two-bucket sub-arrays costs near-empty launches
-					LQ_LAUNCH(k_two_tiles, std::min<u32>(ns / 256 + 1, 4096), 256, sD, cur, L.two_list.as<u32>(), cnt + LQ_C_TWO, tile, L.two_tiles.as<SortTile>(), cnt + LQ_C_TWO_TILES, L.two_tile0.as<u32>()); check_launch();
-					LQ_LAUNCH((k_sort_two_tiled<0>), g_two, 256, sD, cur, L.seg_info.as<SegInfo>(), tt, ntt, tile, L.sort_d.as<u8>(), L.two_tcnt.as<u32>(), L.two_m.as<u32>(), hx, py, L.sort_dst.as<u32>()); check_launch();
-					LQ_LAUNCH(k_sort_two_scan, std::min<u32>(ns, 16384), 64, sD, cur, L.two_list.as<u32>(), cnt + LQ_C_TWO, tile, L.two_tile0.as<u32>(), L.two_tcnt.as<u32>(), L.two_m.as<u32>()); check_launch();
-					LQ_LAUNCH((k_sort_two_tiled<1>), g_two, 256, sD, cur, L.seg_info.as<SegInfo>(), tt, ntt, tile, L.sort_d.as<u8>(), L.two_tcnt.as<u32>(), L.two_m.as<u32>(), hx, py, L.sort_dst.as<u32>()); check_launch();
-					LQ_LAUNCH((k_sort_two_tiled<2>), g_two, 256, sD, cur, L.seg_info.as<SegInfo>(), tt, ntt, tile, L.sort_d.as<u8>(), L.two_tcnt.as<u32>(), L.two_m.as<u32>(), hx, py, L.sort_dst.as<u32>()); check_launch();
-				} else {
-					LQ_LAUNCH(k_sort_two, std::min<u32>(ns, 16384), LQ_TWO_THREADS, sD, cur, L.seg_info.as<SegInfo>(), L.two_list.as<u32>(), cnt + LQ_C_TWO, L.sort_d.as<u8>(), hx, py, L.sort_dst.as<u32>());
-					check_launch();
-				}
+				L.two_tiles.ensure(max_tiles * sizeof(SortTile)); L.two_tile0.ensure((u64)ns * 4); L.two_tcnt.ensure(max_tiles * 8); L.two_m.ensure((u64)ns * 4);
+				const SortTile *tt = L.two_tiles.as<SortTile>();
+				const u32 *ntt = cnt + LQ_C_TWO_TILES;
+				const u32 g_two = std::min<u32>(g_tile, 8192);         // grid-stride: a level without two-bucket sub-arrays costs near-empty launches
+				const u64 *rc = (const u64*)R[rb]; u64 *rn = (u64*)R[rb ^ 1];
+				LQ_LAUNCH(k_two_tiles, std::min<u32>(ns / 256 + 1, 4096), 256, sD, cur, L.two_list.as<u32>(), cnt + LQ_C_TWO, tile, L.two_tiles.as<SortTile>(), cnt + LQ_C_TWO_TILES, L.two_tile0.as<u32>()); check_launch();
+				LQ_LAUNCH((k_sort_two_tiled<0>), g_two, 256, sD, cur, L.seg_info.as<SegInfo>(), tt, ntt, tile, L.sort_d.as<u8>(), L.two_tcnt.as<u32>(), L.two_m.as<u32>(), hx, py, rc, rn); check_launch();
+				LQ_LAUNCH(k_sort_two_scan, std::min<u32>(ns, 16384), 64, sD, cur, L.two_list.as<u32>(), cnt + LQ_C_TWO, tile, L.two_tile0.as<u32>(), L.two_tcnt.as<u32>(), L.two_m.as<u32>()); check_launch();
+				LQ_LAUNCH((k_sort_two_tiled<1>), g_two, 256, sD, cur, L.seg_info.as<SegInfo>(), tt, ntt, tile, L.sort_d.as<u8>(), L.two_tcnt.as<u32>(), L.two_m.as<u32>(), hx, py, rc, rn); check_launch();
+				LQ_LAUNCH((k_sort_two_tiled<2>), g_two, 256, sD, cur, L.seg_info.as<SegInfo>(), tt, ntt, tile, L.sort_d.as<u8>(), L.two_tcnt.as<u32>(), L.two_m.as<u32>(), hx, py, rc, rn); check_launch();
 			}
 			{
 				const u8 *dD = L.sort_d.as<u8>(); const u32 *dH = L.hist.as<u32>(), *dBg = L.begs.as<u32>(); u32 *dDst = L.sort_dst.as<u32>();

@@ -90,7 +90,7 @@ k_rs_hist(const SortSeg *segs, const SortTile *tiles, const u32 *n_tiles_p, u32 
 }
 
 // One block per tile: Rn[dst[i]] = Rc[i] (an identity pass -- one bucket holds the whole sub-array -- is a plain copy: the
-// next level reads the other array).  Four independent loads in flight per thread.
+// next level reads the other array; a two-bucket pass has moved its records itself).  Four independent loads in flight per thread.
 __global__ void __launch_bounds__(256)
 k_rs_scatter(const SortSeg *segs, const SegInfo *info, const SortTile *tiles, const u32 *n_tiles_p, u32 tile, int xcd, const RRec *Rc, RRec *Rn, const u32 *dst,
              unsigned long long *tally)
@@ -103,9 +103,11 @@ k_rs_scatter(const SortSeg *segs, const SegInfo *info, const SortTile *tiles, co
 		const u64 *rc = (const u64*)(Rc + sg.off);              // (a record as one 8-byte word)
 		u64 *rn = (u64*)(Rn + sg.off);
 		const u32 *ds = dst + sg.off;
-		if (tl.tile == 0 && threadIdx.x == 0 && tally) atomicAdd(tally, (unsigned long long)sg.len);
 		u32 i = i0 + threadIdx.x;
-		if (info[tl.sgi].kind == LQ_SEG_IDENTITY) { for (; i < i1; i += 256) rn[i] = rc[i]; continue; }
+		const u32 kind = info[tl.sgi].kind;
+		if (kind == LQ_SEG_TWO) continue;                           // (k_sort_two_tiled<2> has moved these records)
+		if (tl.tile == 0 && threadIdx.x == 0 && tally) atomicAdd(tally, (unsigned long long)sg.len);
+		if (kind == LQ_SEG_IDENTITY) { for (; i < i1; i += 256) rn[i] = rc[i]; continue; }
 		for (; i + 3 * 256 < i1; i += 4 * 256) {
 			const u32 d0 = ds[i], d1 = ds[i + 256], d2 = ds[i + 512], d3 = ds[i + 768];
 			const u64 e0 = rc[i], e1 = rc[i + 256], e2 = rc[i + 512], e3 = rc[i + 768];

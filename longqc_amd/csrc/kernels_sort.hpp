@@ -22,7 +22,7 @@
 //                      tiles of the sub-arrays (the first level builds the records on the way);
 //   k_sort_classify  : per sub-array: bucket offsets; identity (one bucket), two-bucket, or general;
 //   two-bucket passes (the top level: strand bit) have a closed form -- every element's destination
-//                      follows from two prefix counts -- and run fully parallel (k_sort_two);
+//                      follows from two prefix counts -- and run fully parallel, over tiles (k_sort_two_tiled), moving their records themselves;
 //   k_sort_walk_*    : general passes: a token walk over the digit bytes that records dst[src]
 //                      (here, kernels_walk.hpp; long walks cut at computed states: kernels_ckpt.hpp);
 //   k_rs_scatter     : R'[dst[i]] = R[i], over tiles;
@@ -180,110 +180,15 @@ k_sort_classify(const SortSeg *segs, const u32 *n_segs_p, u32 list_cap, const u3
 // of R0 in place and drops Y_t into the hole of X_t; in R1 it cuts the slots into runs that end at
 // Y_0, Y_1, ...: X_t lands on the first slot of run t and the run's own elements shift right by one;
 // everything after Y_{m-1} stays.
-// One block per sub-array, two sweeps over its digit bytes in tiles of 256 x 16 elements; every tile counts its X / Y
-// elements per thread, scans the counts in LDS and carries the running totals.  Sweep 1 lists the positions of X_0.. (HX)
-// and Y_0.. (PY) in this sub-array's slice of two scratch arrays, sweep 2 recomputes the same ranks and writes dst.
-#define LQ_TWO_THREADS 256
-#define LQ_TWO_TILE (LQ_TWO_THREADS * 16)
 struct alignas(16) TwoW16 { u32 w[4]; };
 // digit k of the 16 loaded at a 16-byte aligned position
 #define LQ_TWO_DIGIT(W, k) (((W).w[(k) >> 2] >> (((k) & 3) * 8)) & 0xffu)
-// exclusive ranks of thread t's 16 elements among the tile's X / Y elements; totals of the tile in tot
-#define LQ_TWO_SCAN_TILE() \
-		LQ_BLOCK_LOOP(t) { \
-			const u64 p = tile + (u64)t * 16; \
-			u32 cx = 0, cy = 0; \
-			if (p < abs1) { \
-				const TwoW16 W = *(const TwoW16*)(D + p); \
-				for (u32 k = 0; k < 16; ++k) { \
-					const u64 g = p + k; \
-					if (g >= off && g < abs1) { const u32 i = (u32)(g - off); const bool in0 = i < cnt0, is1 = LQ_TWO_DIGIT(W, k) == c1; cx += in0 && is1; cy += !in0 && !is1; } \
-				} \
-			} \
-			cX[t] = cx; cY[t] = cy; \
-		} \
-		LQ_BLOCK_SYNC(); \
-		LQ_BLOCK_LOOP(t) { \
-			if (t < 16) { \
-				u32 ax = 0, ay = 0; \
-				for (u32 k = 0; k < 16; ++k) { const u32 vx = cX[t * 16 + k], vy = cY[t * 16 + k]; cX[t * 16 + k] = ax; cY[t * 16 + k] = ay; ax += vx; ay += vy; } \
-				gX[t] = ax; gY[t] = ay; \
-			} \
-		} \
-		LQ_BLOCK_SYNC();
-__global__ void __launch_bounds__(LQ_TWO_THREADS)
-k_sort_two(const SortSeg *segs, const SegInfo *info, const u32 *two_list, const u32 *n_two_p, const u8 *D, u32 *HX, u32 *PY, u32 *dst)
-{
-	LQ_SHARED u32 cX[LQ_TWO_THREADS], cY[LQ_TWO_THREADS], gX[16], gY[16];
-	const u32 n_two = *n_two_p;
-	for (u32 li = blockIdx.x; li < n_two; li += gridDim.x) {
-	const u32 sgi = two_list[li];
-	const SortSeg sg = segs[sgi];
-	const SegInfo si = info[sgi];
-	const u64 off = sg.off, abs0 = off & ~(u64)15, abs1 = off + sg.len;
-	const u32 cnt0 = si.cnt0, c1 = si.c1;
-	u32 *hx = HX + off, *py = PY + off;
-	u32 bx = 0, by = 0;                                      // X / Y elements before this tile (block-uniform)
-	for (u64 tile = abs0; tile < abs1; tile += LQ_TWO_TILE) {
-		LQ_TWO_SCAN_TILE()
-		LQ_BLOCK_LOOP(t) {
-			u32 rx = bx + cX[t], ry = by + cY[t];
-			for (u32 g16 = 0; g16 < t / 16; ++g16) { rx += gX[g16]; ry += gY[g16]; }
-			const u64 p = tile + (u64)t * 16;
-			if (p < abs1) {
-				const TwoW16 W = *(const TwoW16*)(D + p);
-				for (u32 k = 0; k < 16; ++k) {
-					const u64 g = p + k;
-					if (g >= off && g < abs1) {
-						const u32 i = (u32)(g - off); const bool in0 = i < cnt0, is1 = LQ_TWO_DIGIT(W, k) == c1;
-						if (in0 && is1) hx[rx++] = i;
-						else if (!in0 && !is1) py[ry++] = i;
-					}
-				}
-			}
-		}
-		for (u32 g16 = 0; g16 < 16; ++g16) { bx += gX[g16]; by += gY[g16]; }
-		LQ_BLOCK_SYNC();
-	}
-	const u32 m = bx;                                        // as many X as Y
-	bx = 0; by = 0;
-	for (u64 tile = abs0; tile < abs1; tile += LQ_TWO_TILE) {
-		LQ_TWO_SCAN_TILE()
-		LQ_BLOCK_LOOP(t) {
-			u32 rx = bx + cX[t], ry = by + cY[t];
-			for (u32 g16 = 0; g16 < t / 16; ++g16) { rx += gX[g16]; ry += gY[g16]; }
-			const u64 p = tile + (u64)t * 16;
-			if (p < abs1) {
-				const TwoW16 W = *(const TwoW16*)(D + p);
-				for (u32 k = 0; k < 16; ++k) {
-				const u64 g = p + k;
-				if (g >= off && g < abs1) {
-					const u32 i = (u32)(g - off); const bool in0 = i < cnt0, is1 = LQ_TWO_DIGIT(W, k) == c1;
-					u32 d;
-					if (in0) {
-						if (!is1) d = i;
-						else { d = rx == 0 ? cnt0 : py[rx - 1] + 1; ++rx; }      // X_t takes the first slot of run t
-					} else {
-						if (!is1) { d = hx[ry]; ++ry; }                           // Y_t drops into the hole of X_t
-						else d = ry < m ? i + 1 : i;                              // run elements shift right by one
-					}
-					dst[g] = d;
-				}
-				}
-			}
-		}
-		for (u32 g16 = 0; g16 < 16; ++g16) { bx += gX[g16]; by += gY[g16]; }
-		LQ_BLOCK_SYNC();
-	}
-	}
-}
-
-// ---- the two-bucket pass over tiles ---------------------------------------------------------------------------------
-// The strand pass at the top of every (query) array is a two-bucket pass over the whole array: one block per sub-array
-// (k_sort_two) is a few hundred blocks walking ~10^5..10^6 digits each in a serial loop of tiles.  Here: k_two_tiles lists the
-// tiles of the two-bucket sub-arrays (contiguous per sub-array, first index in tile0[]), <0> counts the X / Y elements of every
-// tile, one wave per sub-array scans its tile counts (k_sort_two_scan; the total is m), <1> writes the position lists HX / PY
-// at tile base + rank, <2> the destinations -- the formulas of k_sort_two above, the ranks from the scanned tile counts.
+// The strand pass at the top of every (query) array is a two-bucket pass over the whole array (a few hundred sub-arrays of
+// ~10^5..10^6 anchors per batch), so it runs over tiles: k_two_tiles lists the tiles of the two-bucket sub-arrays (contiguous
+// per sub-array, first index in tile0[]), <0> counts the X / Y elements of every tile, one wave per sub-array scans its tile
+// counts (k_sort_two_scan; the total is m), <1> writes the position lists HX / PY at tile base + rank, <2> computes every
+// element's destination by the formulas above (ranks from the scanned tile counts) and moves its record there -- no destination
+// array for these passes (rocprofv3 counted 15 B of HBM writes per 4-byte destination stored 64 bytes apart per lane).
 __global__ void __launch_bounds__(256)
 k_two_tiles(const SortSeg *segs, const u32 *two_list, const u32 *n_two_p, u32 tile, SortTile *tiles, u32 *n_tiles, u32 *tile0)
 {
@@ -327,7 +232,7 @@ k_sort_two_scan(const SortSeg *segs, const u32 *two_list, const u32 *n_two_p, u3
 template <int MODE>   // 0: count, 1: position lists, 2: destinations
 __global__ void __launch_bounds__(256)
 k_sort_two_tiled(const SortSeg *segs, const SegInfo *info, const SortTile *tiles, const u32 *n_tiles_p, u32 tile, const u8 *D,
-                 u32 *tcnt, const u32 *two_m, u32 *HX, u32 *PY, u32 *dst)
+                 u32 *tcnt, const u32 *two_m, u32 *HX, u32 *PY, const u64 *Rc, u64 *Rn)
 {
 	__shared__ u32 wx[4], wy[4];
 	const u32 t = threadIdx.x, lane = t & 63, wv = t >> 6;
@@ -381,7 +286,7 @@ k_sort_two_tiled(const SortSeg *segs, const SegInfo *info, const SortTile *tiles
 								if (!is1) { d = hx[ry]; ++ry; }                           // Y_t drops into the hole of X_t
 								else d = ry < m ? i + 1 : i;                              // run elements shift right by one
 							}
-							dst[g] = d;
+							Rn[off + d] = Rc[g];                                          // (a record as one 8-byte word)
 						}
 					}
 				}
