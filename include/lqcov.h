@@ -186,6 +186,12 @@ int lqcov_get_part_minimizers(lqcov_handle *h, int part, uint64_t *xy, uint64_t 
  * (query, rid, rev, score, cnt, qs, qe, rs, re), unordered. */
 int lqcov_get_chains(lqcov_handle *h, int32_t *out, uint64_t cap, uint64_t *n_total);
 
+/* The table text (minimap2-coverage.c:567-605) of rows computed elsewhere: the ranks of a multi-GPU run gather their rows and
+ * region pools as they are (lqcov_get_rows / lqcov_get_regions; reg_off / mreg_off rebased onto the concatenated pools) and
+ * one rank prints them.  No handle: formatting needs nothing but the rows.  names: n_rows NUL-terminated strings. */
+int lqcov_format_rows(int filter_flag, const lqcov_row *rows, uint32_t n_rows, const lqcov_region *regs, const lqcov_region *mregs,
+                      const char *names, const uint64_t *name_off, const char *out_path);
+
 /* ---- multi-GPU plumbing (device pointers; torch.distributed/RCCL moves the bytes) ----------- */
 /* minimizers of a built part as two device arrays (x = hash<<8|span, y = rid<<32|pos<<1|strand) */
 int lqcov_part_minimizers_dev(lqcov_handle *h, int part, const uint64_t **x_dev, const uint64_t **y_dev, uint64_t *n);

@@ -100,6 +100,7 @@ def load_library(path: Optional[str] = None):
         "lqcov_query_order": (C.c_int, [H, C.c_void_p, C.c_uint32]),
         "lqcov_get_rows": (C.c_int, [H, C.POINTER(Row), C.c_uint32]),
         "lqcov_get_regions": (C.c_int, [H, C.POINTER(C.c_void_p), C.POINTER(C.c_uint32), C.POINTER(C.c_void_p), C.POINTER(C.c_uint32)]),
+        "lqcov_format_rows": (C.c_int, [C.c_int, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_char_p, C.c_void_p, C.c_char_p]),
         "lqcov_write_table": (C.c_int, [H, C.c_char_p]),
         "lqcov_run_files": (C.c_int, [H, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p]),
         "lqcov_run_files_ex": (C.c_int, [H, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p]),
@@ -159,6 +160,18 @@ def parse_args(argv: Sequence[str]) -> Tuple[Params, Optional[str], Optional[str
     if rc:
         raise LqcovError(rc, err.value.decode())
     return p, (t.value.decode() if t.value else None), (q.value.decode() if q.value else None)
+
+
+def format_rows(lib, filter_flag: int, rows: np.ndarray, regs: np.ndarray, mregs: np.ndarray, names: Sequence[str]) -> str:
+    """the table text of binary rows (uint8[n, sizeof(lqcov_row)], reg_off / mreg_off pointing into regs / mregs): lqcov_format_rows"""
+    import tempfile
+    rows = np.ascontiguousarray(rows, dtype=np.uint8); regs = np.ascontiguousarray(regs, dtype=np.uint32); mregs = np.ascontiguousarray(mregs, dtype=np.uint32)
+    nb, noff = _names(names)
+    with tempfile.NamedTemporaryFile("r", suffix=".tsv") as f:
+        rc = lib.lqcov_format_rows(int(filter_flag), rows.ctypes.data, rows.shape[0], regs.ctypes.data, mregs.ctypes.data, nb, noff.ctypes.data, f.name.encode())
+        if rc != 0:
+            raise LqcovError(rc, "lqcov_format_rows failed")
+        return open(f.name).read()
 
 
 def _flat(seqs: Sequence[np.ndarray]) -> Tuple[np.ndarray, np.ndarray]:
@@ -344,6 +357,20 @@ class Engine:
                             regs=regs[r.reg_off:r.reg_off + r.n_reg].tolist(),
                             mregs=mregs[r.mreg_off:r.mreg_off + r.n_mreg].tolist()))
         return out
+
+    def rows_binary(self) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+        """the finished rows as they are (one `lqcov_row` per query, caller's order, as uint8[n, sizeof(lqcov_row)]) and the two
+        region pools (uint32[n, 2]): what the ranks of a multi-GPU run exchange"""
+        n = self.lib.lqcov_n_queries(self.h)
+        arr = (Row * max(n, 1))()
+        self._ck(self.lib.lqcov_get_rows(self.h, arr, n))
+        rows = np.frombuffer(arr, dtype=np.uint8).reshape(max(n, 1), C.sizeof(Row))[:n].copy()
+        rp, mp = C.c_void_p(), C.c_void_p()
+        nr, nm = C.c_uint32(), C.c_uint32()
+        self._ck(self.lib.lqcov_get_regions(self.h, C.byref(rp), C.byref(nr), C.byref(mp), C.byref(nm)))
+        regs = np.ctypeslib.as_array(C.cast(rp, C.POINTER(C.c_uint32)), shape=(nr.value, 2)).copy() if nr.value else np.zeros((0, 2), np.uint32)
+        mregs = np.ctypeslib.as_array(C.cast(mp, C.POINTER(C.c_uint32)), shape=(nm.value, 2)).copy() if nm.value else np.zeros((0, 2), np.uint32)
+        return rows, regs, mregs
 
     def write_table(self, path: str):
         self._ck(self.lib.lqcov_write_table(self.h, path.encode()))

@@ -324,6 +324,19 @@ int lqcov_write_table(lqcov_handle *h, const char *out_path)
 	});
 }
 
+int lqcov_format_rows(int filter_flag, const lqcov_row *rows, uint32_t n_rows, const lqcov_region *regs, const lqcov_region *mregs,
+                      const char *names, const uint64_t *name_off, const char *out_path)
+{
+	try {
+		if ((n_rows && (!rows || !names || !name_off)) || !out_path) return LQCOV_E_ARG;
+		FILE *o = fopen(out_path, "w");
+		if (!o) return LQCOV_E_IO;
+		lq_format_rows(o, filter_flag, rows, n_rows, regs, mregs, [&](u32 i) { return names + name_off[i]; });
+		fclose(o);
+		return 0;
+	} catch (const std::exception &e) { g_create_error = e.what(); return LQCOV_E_STATE; }
+}
+
 int32_t lqcov_mid_occ(const lqcov_handle *h) { return h ? h->mid_occ : -1; }
 uint64_t lqcov_part_n_minimizers(const lqcov_handle *h, int part) { return (h && part >= 0 && (size_t)part < h->parts.size() && h->parts[part]) ? h->parts[part]->rs.n_mini : 0; }
 uint64_t lqcov_part_n_keys(const lqcov_handle *h, int part) { return (h && part >= 0 && (size_t)part < h->parts.size() && h->parts[part]) ? h->parts[part]->n_keys : 0; }

@@ -14,6 +14,7 @@
 #include <algorithm>
 #include <unordered_map>
 #include <future>
+#include <functional>
 
 static inline u32 nblk(u64 n, u32 bs)
 {
@@ -1258,20 +1259,20 @@ void lqcov_handle::finish()
 	finished = true;
 }
 
-// rows as text (minimap2-coverage.c:567-605)
-void lqcov_handle::write_table(FILE *out)
+// rows as text (minimap2-coverage.c:567-605); name_of(i) = the name of the query of row i
+void lq_format_rows(FILE *out, int filter_flag, const lqcov_row *rows, u32 n_rows, const lqcov_region *regs, const lqcov_region *mregs,
+                    const std::function<const char *(u32)> &name_of)
 {
-	if (!finished) throw std::logic_error("finish() has not run");
 	std::string line;
 	char buf[128];
-	for (u32 i = 0; i < q.n; ++i) {
+	for (u32 i = 0; i < n_rows; ++i) {
 		const lqcov_row &r = rows[i];
 		const double div = r.n_match > 0 ? logf((float)r.n_mini / (float)(int32_t)r.n_match) / r.avg_k : 1.0;   // :563
 		double mq;
 		if (r.has_qual) mq = -10 * log10(r.qual_psum / (int)r.qlen);                                          // lqutils.c:57
 		else { volatile double z = 0.0; volatile int zl = 0; mq = -10 * log10(z / zl); }                                      // FASTA query: the reference's 0/0
 		line.clear();
-		line += q.names[q_inv[i]]; line += '\t';
+		line += name_of(i); line += '\t';
 		snprintf(buf, sizeof(buf), "%d\t%" PRIu64 "\t", (int)r.qlen, r.lambda); line += buf;
 		if (r.n_reg > 0) {
 			u32 tot = 0;
@@ -1287,7 +1288,7 @@ void lqcov_handle::write_table(FILE *out)
 					snprintf(buf, sizeof(buf), "%s%d-%d", k ? "," : "", (int)g.start, (int)g.end); line += buf;
 				}
 			} else line += '0';
-			if (P.filter_flag) snprintf(buf, sizeof(buf), "\t%.3f\t%.3f\t%.3f\t0.0\n", (double)tot / (int)r.qlen, mq, div);
+			if (filter_flag) snprintf(buf, sizeof(buf), "\t%.3f\t%.3f\t%.3f\t0.0\n", (double)tot / (int)r.qlen, mq, div);
 			else snprintf(buf, sizeof(buf), "\t%.3f\t%.3f\t%.3f\t%.3f\n", (double)r.lambda / tot, mq, div, (double)r.lambda2 / tot);
 			line += buf;
 		} else {
@@ -1295,6 +1296,12 @@ void lqcov_handle::write_table(FILE *out)
 		}
 		fwrite(line.data(), 1, line.size(), out);
 	}
+}
+
+void lqcov_handle::write_table(FILE *out)
+{
+	if (!finished) throw std::logic_error("finish() has not run");
+	lq_format_rows(out, P.filter_flag, rows.data(), q.n, regs.data(), mregs.data(), [&](u32 i) { return q.names[q_inv[i]].c_str(); });
 }
 
 // ---- the whole run from files (minimap2-coverage.c:406-617) -----------------------------------------

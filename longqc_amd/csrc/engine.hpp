@@ -191,6 +191,9 @@ struct lqcov_handle {
 };
 
 u64 lq_packed_chunks(u32 n, const u64 *seq_off);
+#include <functional>
+void lq_format_rows(FILE *out, int filter_flag, const lqcov_row *rows, u32 n_rows, const lqcov_region *regs, const lqcov_region *mregs,
+                    const std::function<const char *(u32)> &name_of);
 void lq_pack_host(u32 n, const u8 *seq, const u64 *seq_off, u64 *codes, u32 *amb, int n_threads);
 
 struct StageTimer {

@@ -235,6 +235,7 @@ k_sort_two_tiled(const SortSeg *segs, const SegInfo *info, const SortTile *tiles
                  u32 *tcnt, const u32 *two_m, u32 *HX, u32 *PY, const u64 *Rc, u64 *Rn)
 {
 	__shared__ u32 wx[4], wy[4];
+	__shared__ u32 sd[MODE == 2 ? 256 * 16 : 1];                // <2>: the destinations of the 4096 elements at hand
 	const u32 t = threadIdx.x, lane = t & 63, wv = t >> 6;
 	const u32 n_tiles = *n_tiles_p;
 	for (u32 ti = blockIdx.x; ti < n_tiles; ti += gridDim.x) {
@@ -286,13 +287,23 @@ k_sort_two_tiled(const SortSeg *segs, const SegInfo *info, const SortTile *tiles
 								if (!is1) { d = hx[ry]; ++ry; }                           // Y_t drops into the hole of X_t
 								else d = ry < m ? i + 1 : i;                              // run elements shift right by one
 							}
-							Rn[off + d] = Rc[g];                                          // (a record as one 8-byte word)
+							sd[t * 16 + k] = d;
 						}
 					}
 				}
 			}
 			bx += tx; by += ty;
 			__syncthreads();
+			if (MODE == 2) {
+				// the move itself with the block's threads across the elements: 512 contiguous bytes of records per wave-load (a thread
+				// moving its own 16 elements read 8 bytes every 128 and took twice the time of the destination array it saved)
+				const u64 g0 = a0 + (u64)w0 * 16;
+				for (u32 e = t; e < 256 * 16; e += 256) {
+					const u64 g = g0 + e;
+					if (g >= lo && g < hi) Rn[off + sd[e]] = Rc[g];               // (a record as one 8-byte word)
+				}
+				__syncthreads();
+			}
 		}
 		if (MODE == 0 && t == 0) { tcnt[2 * (u64)ti] = bx; tcnt[2 * (u64)ti + 1] = by; }
 	}

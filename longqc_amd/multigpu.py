@@ -64,6 +64,18 @@ def _all_gather_into(t: torch.Tensor, world: int, group) -> torch.Tensor:
     return out
 
 
+def _gather(t: torch.Tensor, world: int, rank: int, group) -> Optional[List[torch.Tensor]]:
+    """rank 0 receives every rank's `t` (equal sizes); the others get None"""
+    if _staged(t, group):
+        h = t.cpu()
+        out = [torch.empty_like(h) for _ in range(world)] if rank == 0 else None
+        dist.gather(h, out, dst=0, group=group)
+        return out
+    out = [torch.empty_like(t) for _ in range(world)] if rank == 0 else None
+    dist.gather(t, out, dst=0, group=group)
+    return out
+
+
 def _all_reduce(t: torch.Tensor, group, op=None) -> None:
     op = op if op is not None else dist.ReduceOp.SUM
     if _staged(t, group):
@@ -259,6 +271,7 @@ class QueryShardRunner:
     def set_queries(self, names, seqs, quals=None):
         """every rank passes the whole query set; the handle receives this rank's share"""
         self.n_queries = len(names)
+        self.names = list(names)
         self.my_queries = shard_queries([int(s.shape[0]) for s in seqs], self.world)[self.rank]
         self.eng.set_queries([names[i] for i in self.my_queries], [seqs[i] for i in self.my_queries],
                              [quals[i] for i in self.my_queries] if quals is not None else None)
@@ -303,18 +316,53 @@ class QueryShardRunner:
         eng.part_map(part)
 
     def gather_table(self) -> Optional[str]:
-        """finish on every rank; rank 0 returns the table of all queries in the caller's order, the others None"""
+        """finish on every rank; rank 0 returns the table of all queries in the caller's order, the others None.  What travels
+        is binary: every rank's `lqcov_row` array, its two region pools and its query indices, as padded uint8 tensors through
+        one gather each (RCCL on the GPU box); rank 0 rebases the region offsets, orders the rows and prints them with the
+        engine's own formatter (lqcov_format_rows: the reference's printf arithmetic in one place)."""
+        from . import api as _api
         self.eng.finish()
-        lines = self.eng.table_text().splitlines(keepends=True)
-        assert len(lines) == len(self.my_queries)
         if self.world == 1:
-            return "".join(lines)
-        got = [None] * self.world if self.rank == 0 else None
-        dist.gather_object((self.my_queries, lines), got, dst=0, group=self.group)
+            return self.eng.table_text()
+        rows, regs, mregs = self.eng.rows_binary()
+        assert rows.shape[0] == len(self.my_queries)
+        idx = np.asarray(self.my_queries, dtype=np.int64)
+        dev = self.dev
+        parts = [rows.reshape(-1), regs.reshape(-1).view(np.uint8), mregs.reshape(-1).view(np.uint8), idx.view(np.uint8)]
+        sizes = torch.tensor([p.shape[0] for p in parts], dtype=torch.int64, device=dev)
+        all_sizes = torch.stack(_all_gather(sizes, self.world, self.group)).cpu().numpy()        # [world, 4]
+        got = []
+        for j, p in enumerate(parts):
+            cap = int(all_sizes[:, j].max())
+            buf = torch.zeros(max(cap, 1), dtype=torch.uint8, device=dev)
+            if p.shape[0]:
+                buf[:p.shape[0]] = torch.from_numpy(np.ascontiguousarray(p)).to(dev)
+            got.append(_gather(buf, self.world, self.rank, self.group))
         if self.rank != 0:
             return None
-        out = [None] * self.n_queries
-        for idx, ls in got:
-            for i, l in zip(idx, ls):
-                out[i] = l
-        return "".join(out)
+        row_sz = rows.shape[1] if rows.ndim == 2 and rows.shape[0] else _api.C.sizeof(_api.Row)
+        all_rows, all_regs, all_mregs, all_idx = [], [], [], []
+        reg_base = mreg_base = 0
+        for r in range(self.world):
+            nb = [int(v) for v in all_sizes[r]]
+            rr = got[0][r][:nb[0]].cpu().numpy().reshape(-1, row_sz).copy()
+            rg = got[1][r][:nb[1]].cpu().numpy().view(np.uint32).reshape(-1, 2)
+            mg = got[2][r][:nb[2]].cpu().numpy().view(np.uint32).reshape(-1, 2)
+            ix = got[3][r][:nb[3]].cpu().numpy().view(np.int64)
+            if rr.shape[0]:
+                st = np.frombuffer(rr.tobytes(), dtype=_ROW_DTYPE).copy()
+                st["reg_off"] += reg_base; st["mreg_off"] += mreg_base
+                rr = np.frombuffer(st.tobytes(), dtype=np.uint8).reshape(-1, row_sz)
+            all_rows.append(rr); all_regs.append(rg); all_mregs.append(mg); all_idx.append(ix)
+            reg_base += rg.shape[0]; mreg_base += mg.shape[0]
+        rows_cat = np.concatenate(all_rows) if all_rows else np.zeros((0, row_sz), np.uint8)
+        idx_cat = np.concatenate(all_idx)
+        order = np.argsort(idx_cat, kind="stable")
+        assert idx_cat.shape[0] == self.n_queries and np.array_equal(idx_cat[order], np.arange(self.n_queries))
+        return _api.format_rows(self.eng.lib, int(self.eng.params.filter_flag), rows_cat[order], np.concatenate(all_regs), np.concatenate(all_mregs),
+                                [self.names[i] for i in range(self.n_queries)])
+
+
+# numpy view of lqcov_row (include/lqcov.h): the gatherer rebases the two region offsets
+_ROW_DTYPE = np.dtype([("lambda_", "<u8"), ("lambda2", "<u8"), ("qual_psum", "<f8"), ("qlen", "<u4"), ("n_mini", "<u4"), ("n_match", "<u4"), ("avg_k", "<f4"),
+                       ("reg_off", "<u4"), ("n_reg", "<u4"), ("mreg_off", "<u4"), ("n_mreg", "<u4"), ("has_qual", "<u4"), ("flags", "<u4")])
