@@ -74,9 +74,12 @@ def cpu_baseline(cfg_name, F, Q, n_t, n_q):
             return None
     return {"value": round(sub_t.n_bases / dt / 1e6, 3), "unit": "Mbases/s", "cores": used, "kind": kind,
             "seconds": round(dt, 2),
-            "sample": "first %d target reads (%.1f Mbases, FASTA) + first %d subsample reads as queries, same argv, "
-                      "file parse included; the reference's sketch/index step is ~serial (3 fixed threads, index.c:293-300), "
-                      "so the full %d-read job would take ~%.0f s" % (n_t, sub_t.n_bases / 1e6, n_q, len(F), dt * F.n_bases / max(sub_t.n_bases, 1))}
+            "sample": ("all %d target reads (%.1f Mbases, FASTA) + all %d subsample reads as queries, same argv, file parse included" % (n_t, sub_t.n_bases / 1e6, n_q))
+                      if n_t >= len(F) and n_q >= len(Q) else
+                      ("first %d target reads (%.1f Mbases, FASTA) + first %d subsample reads as queries, same argv, "
+                       "file parse included; the reference's sketch/index step is ~serial (3 fixed threads, index.c:293-300) and seed hits "
+                       "per query grow with the index: the whole job is slower per base (full_job, if present: measured once on all reads)"
+                       % (n_t, sub_t.n_bases / 1e6, n_q))}
 
 
 def golden_check(cfg_name, table_text):
@@ -268,7 +271,7 @@ def main():
         # (tools/gpu_round.sh -> profiles/*pmc_traffic.json; separate rocprofv3 --pmc runs, never inside a timed run)
         if roof and full_config:
             import glob
-            for fn in sorted(glob.glob(os.path.join(ROOT, "profiles", "r02*pmc_traffic*.json")), reverse=True):
+            for fn in sorted(glob.glob(os.path.join(ROOT, "profiles", "r0*pmc_traffic*.json")), reverse=True):
                 try:
                     js = json.load(open(fn))
                     kk = js["kernels"]
@@ -288,11 +291,13 @@ def main():
             "config": {"workload": (CONFIG_LABEL[args.config] % (cfg.n_reads, cfg.mean_len // 1000, cfg.depth)) + ", %d subsample queries" % len(Q),
                        "index_parts": [int(F.off[hi] - F.off[lo]) for lo, hi in parts],
                        "target_bases": int(total_bases), "query_bases": int(Q.n_bases), "anchors_per_step": int(n_anchors),
-                       "clock": "H2D of the packed reads (pinned) -> sketch -> index -> seed -> sort -> chain -> coverage -> rows D2H, all parts (SURVEY 8d)",
+                       "clock": "H2D of the packed reads (pinned) -> sketch -> index -> seed -> sort -> chain -> coverage -> rows D2H, all parts (SURVEY 8d); "
+                                "before the clock: the synthetic generator (= FASTQ parse) and the host-side 2-bit packing (host_pack_s) -- value_incl_host_pack adds the latter, unoverlapped",
                        "parallelism": "single GPU" if world == 1 else "%d GPUs: queries sharded 1/N, index replicated (each rank sketches 1/N of a part, "
                                       "minimizers all-gathered over RCCL, identical index everywhere), rows gathered on rank 0" % world},
             "roofline": roof,
             "host_pack_s": round(t_pack, 3), "synth_gen_s": round(t_gen, 2),
+            "value_incl_host_pack": round(total_bases / (ms_per_step / 1e3 + t_pack) / 1e6, 3),
             "hbm_resident_value": round(resident, 3) if resident else None,
             "anchors_per_s": round(n_anchors / (ms_per_step / 1e3), 1),
         }
@@ -300,7 +305,15 @@ def main():
             line["golden_rows"] = golden_check(args.config, table)
         if world == 1 and not args.no_cpu_baseline:
             n_t = args.cpu_sample or (25000 if args.config == "cfg3" else 35000)
-            line["cpu_baseline"] = cpu_baseline(args.config, F, Q, n_t, max(50, n_t // 100))
+            line["cpu_baseline"] = cpu_baseline(args.config, F, Q, n_t, len(Q) if n_t >= len(F) else max(50, n_t // 100))
+            # the reference on ALL reads and ALL queries of this workload, timed once on a GPU box's host cores (tools/gpu_evidence.sh,
+            # committed under profiles/): a figure from an earlier run, labelled as such, next to this run's bounded sample
+            fj = os.path.join(ROOT, "profiles", "r03_cpu_full_%s.json" % args.config)
+            if line["cpu_baseline"] and os.path.exists(fj):
+                try:
+                    line["cpu_baseline"]["full_job"] = json.load(open(fj))
+                except Exception:
+                    pass
         if one_dev:
             line["note"] = "LQCOV_BENCH_ONE_DEVICE test mode: all ranks share cuda:0 over gloo; not a scaling measurement"
         print(json.dumps(line), flush=True)

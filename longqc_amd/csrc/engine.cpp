@@ -95,8 +95,6 @@ void Knobs::read_env()
 	debug_sort = getenv("LQCOV_DEBUG_SORT") != nullptr;
 	sketch_kpt = (u32)std::min<long>(64, std::max<long>(1, num("LQCOV_SKETCH_KPT", 4)));
 	sketch_machine_only = is("LQCOV_SKETCH", "machine");
-	fin_threads = (int)num("LQCOV_FIN_THREADS", 1024);
-	walk_mask = is("LQCOV_WALK_MASK", "lane") ? 1 : is("LQCOV_WALK_MASK", "none") ? 2 : 0;
 }
 
 lqcov_handle::lqcov_handle(const lqcov_params &p, int dev) : P(p), device(dev)
@@ -745,9 +743,8 @@ static void ps_finish(lqcov_handle *h, MapLane &L, int set, hipStream_t s, u64 n
 		StageTimer t(h, s, "k_ps_finish<8192>");
 		unsigned long long *tl = (unsigned long long*)(L.sort_cnt.as<u32>() + (set ? LQ_C_FINB1 : LQ_C_FINB0));
 		const u32 g = (u32)std::min<u64>(std::min<u64>(Ls.cap_fin, nA / LQ_PS_FIN_SMALL + 64), 4096);
-		// 1024 threads (measured at configs[2], 4 lanes, round 2: 256-thread blocks 2.40 s per step, 512: 2.25, 1024: 2.1-2.2)
+		// 1024 threads (measured at configs[2], 4 lanes, round 2: 256-thread blocks 2.40 s per step, 512: 2.25, 1024: 2.1-2.2; round 3: 512 = 1024)
 		if (!k32) LQ_LAUNCH((k_ps_finish<LQ_PS_FIN_BIG, 1024, 10, u64>), g, 1024, s, Ls.fin_b, cnt + LQ_P_FIN_B, pd, km, tl);
-		else if (h->K.fin_threads == 512) LQ_LAUNCH((k_ps_finish<LQ_PS_FIN_BIG, 512, 10, u32>), g * 2, 512, s, Ls.fin_b, cnt + LQ_P_FIN_B, pd, km, tl);
 		else LQ_LAUNCH((k_ps_finish<LQ_PS_FIN_BIG, 1024, 10, u32>), g, 1024, s, Ls.fin_b, cnt + LQ_P_FIN_B, pd, km, tl);
 		check_launch();
 	}
@@ -1132,10 +1129,10 @@ void lqcov_handle::map_part(Part &pt)
 			// the LDS of every CU and the bandwidth kernels of the other streams crawl (rocprofv3, configs[2]: k_ps_scatter 66 ms
 			// alone, 1100 ms beside the walkers).  Their stream may only use every fourth CU; 64 CUs x 32 waves are plenty for them.
 			// (Keeping the other streams off those CUs as well was measured in round 3: slower, 2.15 vs 1.85-2.1 s per step.)
+			// (Round 3: a different quarter of the CUs per lane: no change, 1.77 vs 1.76-1.79 s per step; no mask at all: 2.03 s.)
 			uint32_t mask[8];
-			const uint32_t m = K.walk_mask == 1 ? 0x11111111u << ((lanes.size() - 1) & 3) : 0x11111111u;   // LQCOV_WALK_MASK=lane: a quarter of the CUs per lane
-			for (int i = 0; i < 8; ++i) mask[i] = m;
-			if (K.walk_mask == 2 || hipExtStreamCreateWithCUMask(&lanes.back()->streamW, 8, mask) != hipSuccess) { (void)hipGetLastError(); LQ_HIP_CHECK(hipStreamCreate(&lanes.back()->streamW)); }
+			for (int i = 0; i < 8; ++i) mask[i] = 0x11111111u;
+			if (hipExtStreamCreateWithCUMask(&lanes.back()->streamW, 8, mask) != hipSuccess) { (void)hipGetLastError(); LQ_HIP_CHECK(hipStreamCreate(&lanes.back()->streamW)); }
 		}
 		LQ_HIP_CHECK(hipEventCreateWithFlags(&lanes.back()->ev_w0, hipEventDisableTiming));
 		LQ_HIP_CHECK(hipEventCreateWithFlags(&lanes.back()->ev_w1, hipEventDisableTiming));

@@ -39,8 +39,6 @@ struct Knobs {
 	bool no_level_skip = false;           // LQCOV_NO_LEVEL_SKIP: constant key bytes are walked, not stepped over
 	bool debug_sort = false;              // LQCOV_DEBUG_SORT
 	u32 sketch_kpt = 4;                   // LQCOV_SKETCH_KPT: chunks per thread of the sketch state machine
-	int fin_threads = 1024;               // LQCOV_FIN_THREADS=512: block size of the 8192-element finish (A/B)
-	int walk_mask = 0;                    // LQCOV_WALK_MASK: the walkers' CUs: every fourth CU for all lanes (default) | lane: a different quarter per lane | none
 	bool sketch_machine_only = false;     // LQCOV_SKETCH=machine: the state machine decides every chunk (no data-parallel kernel)
 	void read_env();
 };
