@@ -106,6 +106,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0, help="target reads in the CPU baseline sample (~20-30 s of reference time)")
     ap.add_argument("--cache", default="", help="directory for the generated reads (re-used by later runs of the same config on this machine)")
+    ap.add_argument("--index-size", default="", help="override the preset's -I (e.g. 2M: many index parts on a small input; tests)")
     ap.add_argument("--workers", type=int, default=0, help="processes of the synthetic generator (0: one per core, at most 64)")
     args = ap.parse_args()
 
@@ -133,7 +134,10 @@ def main():
         cfg = dataclasses.replace(cfg, n_reads=args.reads)
     if args.nsample:
         cfg = dataclasses.replace(cfg, nsample=args.nsample)
-    argv = PRESET[args.config][1]
+    argv = list(PRESET[args.config][1])
+    if args.index_size:
+        argv[argv.index("-I") + 1] = args.index_size
+        full_config = False
     p, _, _ = api.parse_args(argv + ["t", "q"])
 
     t0 = time.time()
@@ -163,18 +167,36 @@ def main():
     anchors = [0]
     if world == 1:
         eng.set_queries(Q.names, Q.seqs, Q.quals)
-        pt = eng.part_begin()
+        pts = [eng.part_begin(), eng.part_begin()] if len(parts) > 1 else [eng.part_begin()]
+        pt = pts[0]
+        if len(parts) > 1:
+            # part i + 1 is uploaded, sketched and indexed (a host thread of its own, the engine's build stream) while part i is
+            # mapped: the lanes leave room for the second part object (0.375 B per base of reads, 24 B per minimizer ~ 3 bases, tables)
+            eng.reserve_hbm(int(max(int(F.off[hi] - F.off[lo]) for lo, hi in parts[1:]) * 9.5))
+        import threading
+
+        def build(i):
+            eng.part_clear(pts[i % 2])
+            eng.part_add_packed(pts[i % 2], P, parts[i][0], parts[i][1])
+            eng.part_build(pts[i % 2])
 
         def step(h2d=True):
             eng.reset()
             a = 0
-            for (lo, hi) in parts:
-                if h2d or len(parts) > 1:
-                    eng.part_clear(pt)
-                    eng.part_add_packed(pt, P, lo, hi)
-                eng.part_build(pt)
-                eng.part_map(pt)
+            if h2d or len(parts) > 1:
+                build(0)
+            else:
+                eng.part_build(pts[0])
+            for i in range(len(parts)):
+                th = None
+                if i + 1 < len(parts) and have_cuda:
+                    th = threading.Thread(target=build, args=(i + 1,)); th.start()
+                eng.part_map(pts[i % 2])
                 a += eng.last_n_anchors
+                if th is not None:
+                    th.join()
+                elif i + 1 < len(parts):
+                    build(i + 1)                                  # (the CPU dry run of this script: the test emulator runs one kernel at a time)
             eng.finish()
             anchors[0] = a
     else:
@@ -291,7 +313,8 @@ def main():
             "config": {"workload": (CONFIG_LABEL[args.config] % (cfg.n_reads, cfg.mean_len // 1000, cfg.depth)) + ", %d subsample queries" % len(Q),
                        "index_parts": [int(F.off[hi] - F.off[lo]) for lo, hi in parts],
                        "target_bases": int(total_bases), "query_bases": int(Q.n_bases), "anchors_per_step": int(n_anchors),
-                       "clock": "H2D of the packed reads (pinned) -> sketch -> index -> seed -> sort -> chain -> coverage -> rows D2H, all parts (SURVEY 8d); "
+                       "clock": "H2D of the packed reads (pinned) -> sketch -> index -> seed -> sort -> chain -> coverage -> rows D2H, all parts (SURVEY 8d), "
+                                "part i+1's upload + sketch + index under part i's mapping; "
                                 "before the clock: the synthetic generator (= FASTQ parse) and the host-side 2-bit packing (host_pack_s) -- value_incl_host_pack adds the latter, unoverlapped",
                        "parallelism": "single GPU" if world == 1 else "%d GPUs: queries sharded 1/N, index replicated (each rank sketches 1/N of a part, "
                                       "minimizers all-gathered over RCCL, identical index everywhere), rows gathered on rank 0" % world},

@@ -156,6 +156,13 @@ int lqcov_part_dump(lqcov_handle *h, int part, const char *path, int append);   
 int lqcov_part_load(lqcov_handle *h, const char *path, uint64_t *offset);                   /* index.c:428-479 */
 int lqcov_reset(lqcov_handle *h);                   /* zero the accumulators, keep resident reads (bench) */
 int lqcov_sync(lqcov_handle *h);                    /* wait for the handle's stream */
+/* One part can be built while another is mapped: lqcov_part_add_* / lqcov_part_sketch / lqcov_part_build on one part object
+ * from one host thread, lqcov_part_map on another part object from another thread (upload, sketch and index run on a stream
+ * and scratch of their own).  mm_idx_reader_read + the mapping of the previous part in a pipeline (minimap2-coverage.c:449-458
+ * runs them one after the other).  The mapping lanes size their work space from the HBM that is free when the first part is
+ * mapped: tell the engine how much to leave for the part that will be built meanwhile. */
+int lqcov_reserve_hbm(lqcov_handle *h, uint64_t bytes);
+
 /* Hand the work space the mapping lanes keep between calls (HIP's stream-ordered pool, kept so that the next part does not
  * pay for it again) back to the device: for a host that needs the HBM for buffers of its own between two parts, e.g. the
  * all-gather buffers of the query-sharded multi-GPU split.  Waits for the device.  No counterpart in the reference. */

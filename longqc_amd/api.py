@@ -100,6 +100,7 @@ def load_library(path: Optional[str] = None):
         "lqcov_query_order": (C.c_int, [H, C.c_void_p, C.c_uint32]),
         "lqcov_get_rows": (C.c_int, [H, C.POINTER(Row), C.c_uint32]),
         "lqcov_get_regions": (C.c_int, [H, C.POINTER(C.c_void_p), C.POINTER(C.c_uint32), C.POINTER(C.c_void_p), C.POINTER(C.c_uint32)]),
+        "lqcov_reserve_hbm": (C.c_int, [H, C.c_uint64]),
         "lqcov_format_rows": (C.c_int, [C.c_int, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_char_p, C.c_void_p, C.c_char_p]),
         "lqcov_write_table": (C.c_int, [H, C.c_char_p]),
         "lqcov_run_files": (C.c_int, [H, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p]),
@@ -315,6 +316,10 @@ class Engine:
 
     def sync(self):
         self._ck(self.lib.lqcov_sync(self.h))
+
+    def reserve_hbm(self, n_bytes: int):
+        """HBM the mapping lanes leave free when they size their work space (a second part that is built while one is mapped)"""
+        self._ck(self.lib.lqcov_reserve_hbm(self.h, int(n_bytes)))
 
     def workspace_trim(self):
         self._ck(self.lib.lqcov_workspace_trim(self.h))

@@ -269,7 +269,8 @@ int lqcov_part_build(lqcov_handle *h, int part) { return guard(h, [&] { h->build
 int lqcov_part_map(lqcov_handle *h, int part) { return guard(h, [&] { h->map_part(h->part(part)); }); }
 int lqcov_part_release(lqcov_handle *h, int part) { return guard(h, [&] { h->part(part); h->parts[part].reset(); }); }
 int lqcov_reset(lqcov_handle *h) { return guard(h, [&] { if (!h->have_queries) throw std::logic_error("no queries"); h->reset(); }); }
-int lqcov_sync(lqcov_handle *h) { return guard(h, [&] { LQ_HIP_CHECK(hipStreamSynchronize(h->stream)); }); }
+int lqcov_sync(lqcov_handle *h) { return guard(h, [&] { LQ_HIP_CHECK(hipStreamSynchronize(h->bstream)); LQ_HIP_CHECK(hipStreamSynchronize(h->stream)); }); }
+int lqcov_reserve_hbm(lqcov_handle *h, uint64_t bytes) { if (!h) return LQCOV_E_ARG; h->hbm_reserve = bytes; return 0; }
 int lqcov_workspace_trim(lqcov_handle *h)
 {
 	return guard(h, [&] {

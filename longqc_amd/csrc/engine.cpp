@@ -95,6 +95,8 @@ void Knobs::read_env()
 	debug_sort = getenv("LQCOV_DEBUG_SORT") != nullptr;
 	sketch_kpt = (u32)std::min<long>(64, std::max<long>(1, num("LQCOV_SKETCH_KPT", 4)));
 	sketch_machine_only = is("LQCOV_SKETCH", "machine");
+	fin_big = !is("LQCOV_FIN_BIG", "0");
+	chain_grid = (u32)std::max<long>(64, num("LQCOV_CHAIN_GRID", 0x7fffffff));
 }
 
 lqcov_handle::lqcov_handle(const lqcov_params &p, int dev) : P(p), device(dev)
@@ -107,8 +109,9 @@ lqcov_handle::lqcov_handle(const lqcov_params &p, int dev) : P(p), device(dev)
 	if (dev < 0 || dev >= ndev) throw std::runtime_error("HIP device index out of range");
 	LQ_HIP_CHECK(hipSetDevice(dev));
 	LQ_HIP_CHECK(hipStreamCreate(&stream));
+	LQ_HIP_CHECK(hipStreamCreate(&bstream));
 	lq_pool_keep_memory(dev);
-	prim.stream = stream;
+	prim.stream = stream; bprim.stream = bstream;
 	mp.k = P.k; mp.w = P.w; mp.hpc = P.hpc;
 	mp.max_gap = P.max_gap; mp.bw = P.bw; mp.max_skip = P.max_chain_skip; mp.min_cnt = P.min_cnt; mp.min_sc = P.min_chain_score;
 	mp.min_sc_med = P.min_score_med; mp.min_sc_good = P.min_score_good;
@@ -136,6 +139,7 @@ lqcov_handle::~lqcov_handle()
 		if (e1) hipEventDestroy(e1);
 		if (e2) hipEventDestroy(e2);
 	}
+	if (bstream) { hipStreamSynchronize(bstream); hipStreamDestroy(bstream); }
 	if (stream) { hipStreamSynchronize(stream); hipStreamDestroy(stream); }
 }
 
@@ -161,6 +165,8 @@ static void grow_keep(DBuf &b, size_t old_bytes, size_t new_bytes, hipStream_t s
 // upload n reads (ASCII) and append them, 2-bit packed, to the set   (index.c:240-288 step 0)
 void lqcov_handle::add_reads(ReadSetDev &rs, u32 n, const u8 *seq, const u64 *seq_off, const char *names, const u64 *name_off)
 {
+	hipStream_t stream = this->bstream; Prim &prim = this->bprim;   // the build side has a stream and scan / sort scratch of its own: a part can be built while another is mapped
+	(void)prim;
 	if (n == 0) return;
 	if ((u64)rs.n + n > 0x7fffffffULL) throw std::domain_error("too many reads in one set");
 	std::vector<u64> coff_local(n + 1, 0);
@@ -183,7 +189,7 @@ void lqcov_handle::add_reads(ReadSetDev &rs, u32 n, const u8 *seq, const u64 *se
 	grow_keep(rs.codes, rs.n_chunks * LQ_CHUNK_WORDS * 8, (rs.n_chunks + new_chunks) * LQ_CHUNK_WORDS * 8, stream);
 	grow_keep(rs.amb, rs.n_chunks * LQ_CHUNK_WORDS * 4, (rs.n_chunks + new_chunks) * LQ_CHUNK_WORDS * 4, stream);
 	if (n_words) {
-		StageTimer t(this, "k_pack", n_bases + n_words * 12);
+		StageTimer t(this, stream, "k_pack", n_bases + n_words * 12);
 		LQ_LAUNCH(k_pack, nblk(n_words, 256), 256, stream, d_ascii.as<u8>(), d_soff.as<u64>(), d_coff.as<u64>(), n, n_words,
 		          rs.codes.as<u64>() + rs.n_chunks * LQ_CHUNK_WORDS, rs.amb.as<u32>() + rs.n_chunks * LQ_CHUNK_WORDS);
 		check_launch();
@@ -254,6 +260,8 @@ void lq_pack_host(u32 n, const u8 *seq, const u64 *seq_off, u64 *codes, u32 *amb
 // append n reads that are already packed (lq_pack_host layout for exactly these reads) to the set
 void lqcov_handle::add_reads_packed(ReadSetDev &rs, u32 n, const u64 *codes, const u32 *amb, const u32 *lens, const char *names, const u64 *name_off)
 {
+	hipStream_t stream = this->bstream; Prim &prim = this->bprim;   // the build side has a stream and scan / sort scratch of its own: a part can be built while another is mapped
+	(void)prim;
 	if (n == 0) return;
 	if ((u64)rs.n + n > 0x7fffffffULL) throw std::domain_error("too many reads in one set");
 	u64 new_chunks = 0, n_bases = 0;
@@ -270,7 +278,7 @@ void lqcov_handle::add_reads_packed(ReadSetDev &rs, u32 n, const u64 *codes, con
 	grow_keep(rs.codes, rs.n_chunks * LQ_CHUNK_WORDS * 8, (rs.n_chunks + new_chunks) * LQ_CHUNK_WORDS * 8, stream);
 	grow_keep(rs.amb, rs.n_chunks * LQ_CHUNK_WORDS * 4, (rs.n_chunks + new_chunks) * LQ_CHUNK_WORDS * 4, stream);
 	{
-		StageTimer t(this, "h2d_packed_reads", n_words * 12);
+		StageTimer t(this, stream, "h2d_packed_reads", n_words * 12);
 		h2d(rs.codes.as<u64>() + rs.n_chunks * LQ_CHUNK_WORDS, codes, n_words, stream);
 		h2d(rs.amb.as<u32>() + rs.n_chunks * LQ_CHUNK_WORDS, amb, n_words, stream);
 	}
@@ -282,6 +290,8 @@ void lqcov_handle::add_reads_packed(ReadSetDev &rs, u32 n, const u64 *codes, con
 // minimizers of every read of the set, in (read, position) order   (sketch.c:76-142)
 void lqcov_handle::sketch(ReadSetDev &rs, bool rid_in_y)
 {
+	hipStream_t stream = this->bstream; Prim &prim = this->bprim;   // the build side has a stream and scan / sort scratch of its own: a part can be built while another is mapped
+	(void)prim;
 	rs.d_coff.ensure((rs.n + 1) * 8); rs.d_len.ensure((rs.n + 1) * 4);
 	h2d(rs.d_coff.as<u64>(), rs.h_coff.data(), rs.n + 1, stream);
 	h2d(rs.d_len.as<u32>(), rs.h_len.data(), rs.n, stream);
@@ -322,7 +332,7 @@ void lqcov_handle::sketch(ReadSetDev &rs, bool rid_in_y)
 				LQ_HIP_CHECK(hipStreamSynchronize(stream));          // (toff dies with this scope)
 				LQ_LAUNCH(k_sketch_owners, nblk(rs.n, 256), 256, stream, rs.d_coff.as<u64>(), sk_toff.as<u64>(), rs.n, sk_trid.as<u32>(), sk_grid.as<u32>()); check_launch();
 				if (n_tiles) {
-					StageTimer t(this, "k_sketch_dp_mask", in_bytes + nc * 17);
+					StageTimer t(this, stream, "k_sketch_dp_mask", in_bytes + nc * 17);
 					if (P.k <= 16) LQ_LAUNCH(k_sketch_dp_mask<u32>, (u32)std::min<u64>(n_tiles, 1u << 22), LQ_DPT_THREADS, stream, rs.codes.as<u64>(), rs.amb.as<u32>(), rs.d_coff.as<u64>(), rs.d_len.as<u32>(), sk_toff.as<u64>(), sk_trid.as<u32>(), rs.n, n_tiles, sp,
 					                         sk_owned.as<u8>(), sk_mask.as<u32>(), sk_flag.as<u32>());
 					else LQ_LAUNCH(k_sketch_dp_mask<u64>, (u32)std::min<u64>(n_tiles, 1u << 22), LQ_DPT_THREADS, stream, rs.codes.as<u64>(), rs.amb.as<u32>(), rs.d_coff.as<u64>(), rs.d_len.as<u32>(), sk_toff.as<u64>(), sk_trid.as<u32>(), rs.n, n_tiles, sp,
@@ -339,17 +349,17 @@ void lqcov_handle::sketch(ReadSetDev &rs, bool rid_in_y)
 				}
 			}
 			{
-				StageTimer t(this, "k_sketch_mask", dp ? nc : in_bytes + nc * 16);
+				StageTimer t(this, stream, "k_sketch_mask", dp ? nc : in_bytes + nc * 16);
 				LQ_SK_DISPATCH(LQ_SK_MASK, false, (u32*)nullptr, (const u64*)nullptr, (u64*)nullptr, (u64*)nullptr, dp_owned, sk_mask.as<u32>(), sk_flag.as<u32>());
 				check_launch();
 			}
 			LQ_LAUNCH(k_mask_count, nblk(nc, 256), 256, stream, sk_mask.as<u32>(), nc, cnt.as<u32>()); check_launch();
 		} else {
-			StageTimer t(this, "k_sketch_count", in_bytes + nc * 4);
+			StageTimer t(this, stream, "k_sketch_count", in_bytes + nc * 4);
 			LQ_SK_DISPATCH(LQ_SK_COUNT, true, cnt.as<u32>(), (const u64*)nullptr, (u64*)nullptr, (u64*)nullptr, (const u8*)nullptr, (u32*)nullptr, (u32*)nullptr);
 			check_launch();
 		}
-		{ StageTimer t(this, "scan"); prim.exclusive_scan_u32_u64(cnt.as<u32>(), off.as<u64>(), nc); }
+		{ StageTimer t(this, stream, "scan"); prim.exclusive_scan_u32_u64(cnt.as<u32>(), off.as<u64>(), nc); }
 		u64 last_off = 0; u32 last_cnt = 0;
 		d2h(&last_off, off.as<u64>() + nc - 1, 1, stream);
 		d2h(&last_cnt, cnt.as<u32>() + nc - 1, 1, stream);
@@ -359,12 +369,12 @@ void lqcov_handle::sketch(ReadSetDev &rs, bool rid_in_y)
 			u32 dup = 0;
 			d2h(&dup, sk_flag.as<u32>(), 1, stream);
 			if (dup) throw std::logic_error("sketch: a position was emitted twice (mask form of the minimizer list does not hold)");
-			StageTimer t(this, "k_sketch_emit_mask", nc * 24 + rs.n_mini * (16 + 4));
+			StageTimer t(this, stream, "k_sketch_emit_mask", nc * 24 + rs.n_mini * (16 + 4));
 			LQ_LAUNCH(k_sketch_emit_mask, (u32)std::min<u64>((nc + LQ_EM_CH - 1) / LQ_EM_CH, 1u << 22), LQ_EM_THREADS, stream, rs.codes.as<u64>(), rs.amb.as<u32>(), rs.d_coff.as<u64>(), sk_grid.as<u32>(), rs.n, nc, sp, (int)rid_in_y,
 			          sk_mask.as<u32>(), off.as<u64>(), rs.mx.as<u64>(), rs.my.as<u64>());
 			check_launch();
 		} else {
-			StageTimer t(this, "k_sketch_emit", in_bytes + nc * 8 + rs.n_mini * 16);
+			StageTimer t(this, stream, "k_sketch_emit", in_bytes + nc * 8 + rs.n_mini * 16);
 			LQ_SK_DISPATCH(LQ_SK_EMIT, true, (u32*)nullptr, off.as<u64>(), rs.mx.as<u64>(), rs.my.as<u64>(), (const u8*)nullptr, (u32*)nullptr, (u32*)nullptr);
 			check_launch();
 		}
@@ -375,12 +385,15 @@ void lqcov_handle::sketch(ReadSetDev &rs, bool rid_in_y)
 		LQ_HIP_CHECK(hipStreamSynchronize(stream));
 	} else {
 		dzero(rs.moff.p, (rs.n + 1) * 8, stream);
+		LQ_HIP_CHECK(hipStreamSynchronize(stream));
 	}
 	rs.sketched = true;
 }
 
 void lqcov_handle::export_minimizers(ReadSetDev &rs, u64 *x_dev, u64 *y_dev, u32 rid_base)
 {
+	hipStream_t stream = this->bstream; Prim &prim = this->bprim;   // the build side has a stream and scan / sort scratch of its own: a part can be built while another is mapped
+	(void)prim;
 	const u64 n = rs.n_mini;
 	if (!n) return;
 	LQ_HIP_CHECK(hipMemcpyAsync(x_dev, rs.mx.p, n * 8, hipMemcpyDeviceToDevice, stream));
@@ -487,6 +500,8 @@ void lqcov_handle::reset()
 // hash -> occurrences sorted by y (index.c:150-201), mid_occ (index.c:123-144)
 void lqcov_handle::build_index(Part &pt)
 {
+	hipStream_t stream = this->bstream; Prim &prim = this->bprim;   // the build side has a stream and scan / sort scratch of its own: a part can be built while another is mapped
+	(void)prim;
 	ReadSetDev &rs = pt.rs;
 	const u64 M = rs.n_mini;
 	pt.n_keys = 0; pt.cap_bits = 4;
@@ -495,7 +510,7 @@ void lqcov_handle::build_index(Part &pt)
 		DBuf &key = ix_key, &key2 = ix_key2, &head = ix_head, &uidx = ix_uidx, &ukey = ix_ukey, &ustart = ix_ustart, &ucnt = ix_ucnt;   // workspaces live with the handle: repeated builds do not re-allocate
 		key.ensure(M * 8); key2.ensure(M * 8); head.ensure(M * 4); uidx.ensure(M * 8);
 		LQ_LAUNCH(k_sort_keys, nblk(M, 256), 256, stream, rs.mx.as<u64>(), M, key.as<u64>()); check_launch();
-		{ StageTimer t(this, "index_radix_sort", M * 32); prim.sort_pairs_u64(key.as<u64>(), key2.as<u64>(), rs.my.as<u64>(), pt.pos.as<u64>(), M, (unsigned)(2 * P.k)); }
+		{ StageTimer t(this, stream, "index_radix_sort", M * 32); prim.sort_pairs_u64(key.as<u64>(), key2.as<u64>(), rs.my.as<u64>(), pt.pos.as<u64>(), M, (unsigned)(2 * P.k)); }
 		LQ_LAUNCH(k_mark_heads, nblk(M, 256), 256, stream, key2.as<u64>(), M, head.as<u32>()); check_launch();
 		prim.exclusive_scan_u32_u64(head.as<u32>(), uidx.as<u64>(), M);
 		u64 lu = 0; u32 lh = 0;
@@ -512,7 +527,7 @@ void lqcov_handle::build_index(Part &pt)
 		pt.tkey.ensure(cap * 8); pt.tstart.ensure(cap * 8); pt.tcnt.ensure(cap * 4);
 		LQ_HIP_CHECK(hipMemsetAsync(pt.tkey.p, 0xff, cap * 8, stream));
 		{
-			StageTimer t(this, "k_table_insert", K * 20 + cap * 8);
+			StageTimer t(this, stream, "k_table_insert", K * 20 + cap * 8);
 			LQ_LAUNCH(k_table_insert, nblk(K, 256), 256, stream, ukey.as<u64>(), ustart.as<u64>(), ucnt.as<u32>(), K, pt.tkey.as<u64>(), pt.tstart.as<u64>(), pt.tcnt.as<u32>(), bits);
 			check_launch();
 		}
@@ -645,7 +660,7 @@ void lqcov_handle::map_batch(MapLane &L, Part &pt, u32 q0, u32 q1, const std::ve
 			// private-array DP for short runs, and a fixed [16][64] LDS column per lane (54 KiB per wave: 160 + 40 ms vs 113 ms).
 			// wave_min - 1 <= 47 < the smallest budget, so every run fits.
 			StageTimer t(this, L.stream, "k_chain", nA * 16);
-#define LQ_CHAIN_LAUNCH(CAP) LQ_LAUNCH((k_chain<CAP>), nblk(n_groups, 64), 64, L.stream, dA, L.gstart.as<u64>(), (const u32*)nullptr, (u32)n_groups, aqb, a_base, nqb, q0, avg_qspan.as<float>(), mp, cs, (i32)P.min_cnt, (i32)(wave_min - 1))
+#define LQ_CHAIN_LAUNCH(CAP) LQ_LAUNCH((k_chain<CAP>), std::min<u32>(nblk(n_groups, 64), K.chain_grid), 64, L.stream, dA, L.gstart.as<u64>(), (const u32*)nullptr, (u32)n_groups, aqb, a_base, nqb, q0, avg_qspan.as<float>(), mp, cs, (i32)P.min_cnt, (i32)(wave_min - 1))
 			if (cap == 64) { LQ_CHAIN_LAUNCH(64); } else if (cap == 128) { LQ_CHAIN_LAUNCH(128); } else { LQ_CHAIN_LAUNCH(256); }
 #undef LQ_CHAIN_LAUNCH
 			check_launch();
@@ -697,7 +712,7 @@ void lqcov_handle::map_batch(MapLane &L, Part &pt, u32 q0, u32 q1, const std::ve
 	}
 }
 
-static PsLists ps_lists(MapLane &L, int set, u32 sh)
+static PsLists ps_lists(MapLane &L, int set, u32 sh, bool fin_big)
 {
 	PsWork &W = L.ps[set];
 	PsLists Ls;
@@ -705,6 +720,7 @@ static PsLists ps_lists(MapLane &L, int set, u32 sh)
 	Ls.cnt = L.sort_cnt.as<u32>() + (set ? LQ_C_PS1 : LQ_C_PS0);
 	Ls.cap_big = (u32)std::min<u64>(W.big[0].cap / sizeof(PSeg), 0xfffffff0ULL); Ls.cap_fin = (u32)std::min<u64>(W.fin_s.cap / sizeof(PSeg), 0xfffffff0ULL);
 	Ls.fin_s_max = std::max<u32>(LQ_PS_FIN_SMALL >> sh, 2); Ls.fin_b_max = std::max<u32>(LQ_PS_FIN_BIG >> sh, 4); Ls.child_target = std::max<u32>(LQ_PS_CHILD >> sh, 2);
+	if (!fin_big) { Ls.fin_b_max = Ls.fin_s_max; Ls.child_target = std::max<u32>(Ls.fin_s_max / 2, 2); }   // no big finishing class: partition down to what the small one takes
 	return Ls;
 }
 
@@ -713,7 +729,7 @@ static void ps_pass(lqcov_handle *h, MapLane &L, int set, hipStream_t s, u64 nA,
 {
 	PsWork &W = L.ps[set];
 	u32 *cnt = L.sort_cnt.as<u32>() + (set ? LQ_C_PS1 : LQ_C_PS0);
-	const PsLists Ls = ps_lists(L, set, h->K.ps_shift);
+	const PsLists Ls = ps_lists(L, set, h->K.ps_shift, h->K.fin_big);
 	const u32 cap_cnt = (u32)std::min<u64>(W.gcnt.cap / 4, 0xfffffff0ULL);
 	const u32 g_tiles = (u32)std::min<u64>((nA + LQ_PS_TILE - 1) / LQ_PS_TILE + 1, 16384);
 	const u32 g_segs = (u32)std::min<u64>(Ls.cap_big, 4096);
@@ -737,7 +753,7 @@ static void ps_pass(lqcov_handle *h, MapLane &L, int set, hipStream_t s, u64 nA,
 static void ps_finish(lqcov_handle *h, MapLane &L, int set, hipStream_t s, u64 nA, const KeyMap &km, const PsData &pd)
 {
 	u32 *cnt = L.sort_cnt.as<u32>() + (set ? LQ_C_PS1 : LQ_C_PS0);
-	const PsLists Ls = ps_lists(L, set, h->K.ps_shift);
+	const PsLists Ls = ps_lists(L, set, h->K.ps_shift, h->K.fin_big);
 	const bool k32 = km.pbits + km.rbits + 1 <= 32 + 8;          // the key bits below the sub-bucket digit fit 32 bits (both kernels' digits are >= 8 bits)
 	{
 		StageTimer t(h, s, "k_ps_finish<8192>");
@@ -823,7 +839,7 @@ void lqcov_handle::sort_batch(MapLane &L, Part &pt, u32 q0, u32 nqb, u64 a_base,
 	}
 	// list capacities: a segment in any list has more than 64 elements
 	const u64 max_segs = nA / (LQ_RS_MIN + 1) + nqb + 1;
-	const u64 cap_big = nA / ((LQ_PS_FIN_BIG >> K.ps_shift) + 1) + nqb + 16;
+	const u64 cap_big = nA / (((K.fin_big ? LQ_PS_FIN_BIG : LQ_PS_FIN_SMALL) >> K.ps_shift) + 1) + nqb + 16;
 	L.sort_cnt.ensure(LQ_C_N * 4);
 	for (int set = 0; set < 2; ++set) {
 		PsWork &W = L.ps[set];
@@ -838,7 +854,7 @@ void lqcov_handle::sort_batch(MapLane &L, Part &pt, u32 q0, u32 nqb, u64 a_base,
 	}
 	L.segs0.ensure(max_segs * sizeof(SortSeg)); L.segs1.ensure(max_segs * sizeof(SortSeg));
 	dzero(L.sort_cnt.p, LQ_C_N * 4, sD);
-	auto lists = [&](int set) { return ps_lists(L, set, K.ps_shift); };
+	auto lists = [&](int set) { return ps_lists(L, set, K.ps_shift, K.fin_big); };
 	u32 *cnt = L.sort_cnt.as<u32>();
 	// records: R0 of its own, R1 in the part of the scratch area that is only used after the sort (map_batch)
 	const u64 nA4 = ((nA + 1) * 4 + 15) & ~(u64)15;
@@ -1097,6 +1113,7 @@ void lqcov_handle::map_part(Part &pt)
 		// rows, ~6 B of runs and intervals, and the buffers grow with an eighth of head room: ~95 B.
 		size_t fr = 0, tot = 0;
 		hipMemGetInfo(&fr, &tot);
+		if (fr > hbm_reserve) fr -= hbm_reserve; else fr = 0;     // (lqcov_reserve_hbm: e.g. the part the caller builds while this one is mapped)
 		anchor_budget = (u64)((double)fr * 0.85 / 104.0 / n_lanes);
 	}
 	if (anchor_budget > (1ULL << 31) - 4096) anchor_budget = (1ULL << 31) - 4096;   // (a record names its anchor in 31 bits)

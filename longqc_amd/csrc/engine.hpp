@@ -39,6 +39,8 @@ struct Knobs {
 	bool no_level_skip = false;           // LQCOV_NO_LEVEL_SKIP: constant key bytes are walked, not stepped over
 	bool debug_sort = false;              // LQCOV_DEBUG_SORT
 	u32 sketch_kpt = 4;                   // LQCOV_SKETCH_KPT: chunks per thread of the sketch state machine
+	u32 chain_grid = 0x7fffffff;          // LQCOV_CHAIN_GRID: cap on k_chain's grid (blocks stride over the runs) (A/B)
+	bool fin_big = true;                  // LQCOV_FIN_BIG=0: no 8192-element finishing class (1024-thread blocks): partition down to 1024 (A/B)
 	bool sketch_machine_only = false;     // LQCOV_SKETCH=machine: the state machine decides every chunk (no data-parallel kernel)
 	void read_env();
 };
@@ -104,8 +106,10 @@ struct lqcov_handle {
 	Knobs K;
 	MapParams mp;
 	int device = 0;
-	hipStream_t stream = nullptr;
-	Prim prim;
+	hipStream_t stream = nullptr;         // queries, the head of map_part, finish
+	hipStream_t bstream = nullptr;        // upload, sketch and index of a part (with bprim): another part may be mapped meanwhile
+	Prim prim, bprim;
+	u64 hbm_reserve = 0;                  // bytes the caller wants left free when the lanes size their work space (a second part being built)
 	std::string err;
 	int profiling = 0;                    // 0 off, 1 per-kernel (waits for every kernel, lanes run in turn), 2 events only (read when asked)
 	std::string profile_only;             // if not empty: only this stage is timed

@@ -12,7 +12,7 @@ import tests.test_host as H
 from longqc_amd import api, synth
 from tests import oracle_bind
 from tests.conftest import GOLDEN, read_gz
-from tests.helpers import ONT, run_main
+from tests.helpers import ONT, read_fastx, run_main
 
 pytestmark = pytest.mark.gpu
 
@@ -258,6 +258,41 @@ def test_gpu_many_parts_at_real_read_lengths_vs_reference(gpu_lib, tmp_path):
     assert out == want
     rows = out.splitlines()
     assert len(rows) == 200 and sum(1 for r in rows if r.split("\t")[2] != "0") > 150
+
+
+def test_gpu_parts_built_while_the_previous_one_is_mapped(gpu_lib):
+    """the pipeline of bench.py at the level of the C ABI: two part objects, a host thread uploads, sketches and indexes part
+    i + 1 (the engine's build stream) while part i is mapped; the 10 parts of the COVT fixture, twice, the reference's table"""
+    import threading
+    from longqc_amd import multigpu
+    tn, ts, _ = read_fastx(os.path.join(GOLDEN, "adv_all.fa.gz"))
+    qn, qs, qq = read_fastx(os.path.join(GOLDEN, "adv_sub.fq.gz"))
+    p = api.Params(); gpu_lib.lqcov_params_default(p)
+    p.no_self = 1; p.min_ovlp = 0; p.min_score_med = 160; p.min_score_good = 160; p.batch_size = 100000
+    eng = api.Engine(p, 0, lib=gpu_lib)
+    eng.set_queries(qn, qs, qq)
+    eng.reserve_hbm(1 << 30)
+    parts = multigpu.split_parts([int(s.shape[0]) for s in ts], 100000)
+    assert len(parts) == 10
+    pts = [eng.part_begin(), eng.part_begin()]
+
+    def build(i):
+        lo, hi = parts[i]
+        eng.part_clear(pts[i % 2]); eng.part_add_targets(pts[i % 2], tn[lo:hi], ts[lo:hi]); eng.part_build(pts[i % 2])
+
+    for rep in range(2):
+        eng.reset()
+        build(0)
+        for i in range(len(parts)):
+            th = threading.Thread(target=build, args=(i + 1,)) if i + 1 < len(parts) else None
+            if th:
+                th.start()
+            eng.part_map(pts[i % 2])
+            if th:
+                th.join()
+        eng.finish()
+        assert eng.table_text() == read_gz("adv_parts.table.gz"), rep
+    eng.close()
 
 
 def test_gpu_long_pair_among_many_targets(gpu_lib, tmp_path):
