@@ -96,6 +96,7 @@ void Knobs::read_env()
 	sketch_kpt = (u32)std::min<long>(64, std::max<long>(1, num("LQCOV_SKETCH_KPT", 4)));
 	sketch_machine_only = is("LQCOV_SKETCH", "machine");
 	fin_big = !is("LQCOV_FIN_BIG", "0");
+	walk_cus = getenv("LQCOV_WALK_CUS") ? (u32)strtoul(getenv("LQCOV_WALK_CUS"), 0, 16) : 0x11111111u;
 	chain_grid = (u32)std::max<long>(64, num("LQCOV_CHAIN_GRID", 0x7fffffff));
 }
 
@@ -126,11 +127,13 @@ lqcov_handle::~lqcov_handle()
 {
 	drain_stages();
 	for (auto &L : lanes) {
-		hipStream_t s1 = L->stream, s2 = L->stream2, s3 = L->streamW;
+		hipStream_t s1 = L->stream, s2 = L->stream2, s3 = L->streamW, s4 = L->streamW2;
 		hipEvent_t e1 = L->ev_fork, e2 = L->ev_join, e3 = L->ev_w0, e4 = L->ev_w1;
 		if (s1) hipStreamSynchronize(s1);
 		if (s2) hipStreamSynchronize(s2);
 		if (s3) { hipStreamSynchronize(s3); hipStreamDestroy(s3); }
+		if (s4) { hipStreamSynchronize(s4); hipStreamDestroy(s4); }
+		if (L->ev_w2) hipEventDestroy(L->ev_w2);
 		if (e3) hipEventDestroy(e3);
 		if (e4) hipEventDestroy(e4);
 		L.reset();                                              // the lane's buffers go back to the pool while its stream still exists
@@ -925,7 +928,9 @@ void lqcov_handle::sort_batch(MapLane &L, Part &pt, u32 q0, u32 nqb, u64 a_base,
 			{
 				const u8 *dD = L.sort_d.as<u8>(); const u32 *dH = L.hist.as<u32>(), *dBg = L.begs.as<u32>(); u32 *dDst = L.sort_dst.as<u32>();
 				const u32 *wl = L.walk_list.as<u32>();
-				hipStream_t sW = L.streamW;
+				// two walker streams: the checkpointed walks with their solvers on one, the whole walks of the shorter size classes on the
+				// other -- they concern different sub-arrays, and a level waits for the slower of the two, not for their sum
+				hipStream_t sW = L.streamW, sW2 = L.streamW2;
 				// the largest digit of this level decides how many register groups the long walker needs
 				u32 max_digit = 255;
 				if (shift == 48) max_digit = (pt.rs.n ? pt.rs.n - 1 : 0) >> 16;
@@ -941,7 +946,7 @@ void lqcov_handle::sort_batch(MapLane &L, Part &pt, u32 q0, u32 nqb, u64 a_base,
 					fflush(stderr);
 				}
 				// the walkers' stream starts where this one stands, and this one resumes when they are done
-				LQ_HIP_CHECK(hipEventRecord(L.ev_w0, sD)); LQ_HIP_CHECK(hipStreamWaitEvent(sW, L.ev_w0, 0));
+				LQ_HIP_CHECK(hipEventRecord(L.ev_w0, sD)); LQ_HIP_CHECK(hipStreamWaitEvent(sW, L.ev_w0, 0)); LQ_HIP_CHECK(hipStreamWaitEvent(sW2, L.ev_w0, 0));
 				if (!gated && !L.gate_passed) { L.gate_passed = true; open_gate(); gated = true; }   // let the next lane start under these walks
 				// Long sub-arrays: the walk's state at evenly spread checkpoints is computed without walking (kernels_ckpt.hpp) and
 				// one walker per checkpoint runs a short piece.  Few buckets (the byte of rid above 65536 targets: the (query, strand)
@@ -993,16 +998,16 @@ void lqcov_handle::sort_batch(MapLane &L, Part &pt, u32 q0, u32 nqb, u64 a_base,
 				for (int c = first_plain_class; c >= 2; --c) {
 					const u32 g = std::min<u32>(ns, std::min<u32>(8192, wgrid));
 					const CkSeg *nock = nullptr;
-					if (K.reg_walker && max_digit < 64) { StageTimer t(this, sW, "k_sort_walk_reg<1>", nA * 5); LQ_LAUNCH((k_sort_walk_reg<1>), g, 64, sW, cur, wl + (u64)c * ns, cnt + LQ_C_WALK0 + c, dD, dH, dBg, dDst, nock, (const u32*)nullptr, (const u32*)nullptr, (const u32*)nullptr); }
-					else if (K.reg_walker && max_digit < 128) { StageTimer t(this, sW, "k_sort_walk_reg<2>", nA * 5); LQ_LAUNCH((k_sort_walk_reg<2>), g, 64, sW, cur, wl + (u64)c * ns, cnt + LQ_C_WALK0 + c, dD, dH, dBg, dDst, nock, (const u32*)nullptr, (const u32*)nullptr, (const u32*)nullptr); }
-					else { StageTimer t(this, sW, "k_sort_walk_solo", nA * 5); LQ_LAUNCH(k_sort_walk_solo, g, 64, sW, cur, wl + (u64)c * ns, cnt + LQ_C_WALK0 + c, dD, dH, dBg, dDst, nock, (const u32*)nullptr, (const u32*)nullptr, (const u32*)nullptr); }
+					if (K.reg_walker && max_digit < 64) { StageTimer t(this, sW2, "k_sort_walk_reg<1>", nA * 5); LQ_LAUNCH((k_sort_walk_reg<1>), g, 64, sW2, cur, wl + (u64)c * ns, cnt + LQ_C_WALK0 + c, dD, dH, dBg, dDst, nock, (const u32*)nullptr, (const u32*)nullptr, (const u32*)nullptr); }
+					else if (K.reg_walker && max_digit < 128) { StageTimer t(this, sW2, "k_sort_walk_reg<2>", nA * 5); LQ_LAUNCH((k_sort_walk_reg<2>), g, 64, sW2, cur, wl + (u64)c * ns, cnt + LQ_C_WALK0 + c, dD, dH, dBg, dDst, nock, (const u32*)nullptr, (const u32*)nullptr, (const u32*)nullptr); }
+					else { StageTimer t(this, sW2, "k_sort_walk_solo", nA * 5); LQ_LAUNCH(k_sort_walk_solo, g, 64, sW2, cur, wl + (u64)c * ns, cnt + LQ_C_WALK0 + c, dD, dH, dBg, dDst, nock, (const u32*)nullptr, (const u32*)nullptr, (const u32*)nullptr); }
 					check_launch();
 				}
-				{ StageTimer t(this, sW, "k_sort_walk_lds<16384>"); LQ_LAUNCH((k_sort_walk_lds<16384>), std::min<u32>(ns, std::min<u32>(8192, wgrid)), 64, sW, cur, wl + (u64)1 * ns, cnt + LQ_C_WALK1, dD, dH, dBg, dDst); check_launch(); }
-				{ StageTimer t(this, sW, "k_sort_walk_lds<4096>"); LQ_LAUNCH((k_sort_walk_lds<4096>), std::min<u32>(ns, std::min<u32>(1u << 16, wgrid * 4)), 64, sW, cur, wl + (u64)0 * ns, cnt + LQ_C_WALK0, dD, dH, dBg, dDst); check_launch(); }
+				{ StageTimer t(this, sW2, "k_sort_walk_lds<16384>"); LQ_LAUNCH((k_sort_walk_lds<16384>), std::min<u32>(ns, std::min<u32>(8192, wgrid)), 64, sW2, cur, wl + (u64)1 * ns, cnt + LQ_C_WALK1, dD, dH, dBg, dDst); check_launch(); }
+				{ StageTimer t(this, sW2, "k_sort_walk_lds<4096>"); LQ_LAUNCH((k_sort_walk_lds<4096>), std::min<u32>(ns, std::min<u32>(1u << 16, wgrid * 4)), 64, sW2, cur, wl + (u64)0 * ns, cnt + LQ_C_WALK0, dD, dH, dBg, dDst); check_launch(); }
 			}
-			LQ_HIP_CHECK(hipEventRecord(L.ev_w1, L.streamW));
-			LQ_HIP_CHECK(hipStreamWaitEvent(sD, L.ev_w1, 0));
+			LQ_HIP_CHECK(hipEventRecord(L.ev_w1, L.streamW)); LQ_HIP_CHECK(hipEventRecord(L.ev_w2, L.streamW2));
+			LQ_HIP_CHECK(hipStreamWaitEvent(sD, L.ev_w1, 0)); LQ_HIP_CHECK(hipStreamWaitEvent(sD, L.ev_w2, 0));
 			{
 				StageTimer t(this, sD, "k_rs_scatter");
 				LQ_LAUNCH(k_rs_scatter, g_tile, 256, sD, cur, L.seg_info.as<SegInfo>(), L.tile_list.as<SortTile>(), cnt + LQ_C_TILES, tile, 1, R[rb], R[rb ^ 1], L.sort_dst.as<u32>(), (unsigned long long*)(cnt + LQ_C_SCATTERED));
@@ -1148,11 +1153,13 @@ void lqcov_handle::map_part(Part &pt)
 			// (Keeping the other streams off those CUs as well was measured in round 3: slower, 2.15 vs 1.85-2.1 s per step.)
 			// (Round 3: a different quarter of the CUs per lane: no change, 1.77 vs 1.76-1.79 s per step; no mask at all: 2.03 s.)
 			uint32_t mask[8];
-			for (int i = 0; i < 8; ++i) mask[i] = 0x11111111u;
+			for (int i = 0; i < 8; ++i) mask[i] = K.walk_cus;
 			if (hipExtStreamCreateWithCUMask(&lanes.back()->streamW, 8, mask) != hipSuccess) { (void)hipGetLastError(); LQ_HIP_CHECK(hipStreamCreate(&lanes.back()->streamW)); }
+			if (hipExtStreamCreateWithCUMask(&lanes.back()->streamW2, 8, mask) != hipSuccess) { (void)hipGetLastError(); LQ_HIP_CHECK(hipStreamCreate(&lanes.back()->streamW2)); }
 		}
 		LQ_HIP_CHECK(hipEventCreateWithFlags(&lanes.back()->ev_w0, hipEventDisableTiming));
 		LQ_HIP_CHECK(hipEventCreateWithFlags(&lanes.back()->ev_w1, hipEventDisableTiming));
+		LQ_HIP_CHECK(hipEventCreateWithFlags(&lanes.back()->ev_w2, hipEventDisableTiming));
 		LQ_HIP_CHECK(hipEventCreateWithFlags(&lanes.back()->ev_fork, hipEventDisableTiming));
 		LQ_HIP_CHECK(hipEventCreateWithFlags(&lanes.back()->ev_join, hipEventDisableTiming));
 		lanes.back()->prim.stream = lanes.back()->stream;

@@ -40,6 +40,7 @@ struct Knobs {
 	bool debug_sort = false;              // LQCOV_DEBUG_SORT
 	u32 sketch_kpt = 4;                   // LQCOV_SKETCH_KPT: chunks per thread of the sketch state machine
 	u32 chain_grid = 0x7fffffff;          // LQCOV_CHAIN_GRID: cap on k_chain's grid (blocks stride over the runs) (A/B)
+	u32 walk_cus = 0x11111111u;           // LQCOV_WALK_CUS: CU mask word of the walkers' streams (hex)
 	bool fin_big = true;                  // LQCOV_FIN_BIG=0: no 8192-element finishing class (1024-thread blocks): partition down to 1024 (A/B)
 	bool sketch_machine_only = false;     // LQCOV_SKETCH=machine: the state machine decides every chunk (no data-parallel kernel)
 	void read_env();
@@ -79,8 +80,9 @@ struct PsWork {                           // one set of psort lists + the scratc
 struct MapLane {
 	hipStream_t stream = nullptr;         // klib's passes (queries with repeated minimizers), then runs and chains
 	hipStream_t stream2 = nullptr;        // the parallel sort of every other query, meanwhile
-	hipStream_t streamW = nullptr;        // the serial token walks: a stream confined to a quarter of the CUs (see map_part)
-	hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_w0 = nullptr, ev_w1 = nullptr;
+	hipStream_t streamW = nullptr;        // the serial token walks: streams confined to a quarter of the CUs (see map_part):
+	hipStream_t streamW2 = nullptr;       //   checkpointed walks + their solvers | whole walks of the shorter size classes
+	hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_w0 = nullptr, ev_w1 = nullptr, ev_w2 = nullptr;
 	DBuf sort_cnt, mhist;
 	DBuf ck_segs, ck_T, ck_E, ck_S, ck_slot, ck_n;   // checkpointed walks (kernels_ckpt.hpp)
 	PsWork ps[2];
