@@ -288,6 +288,13 @@ def main():
                           "kernel_ms_one_step: the same for every kernel in one extra untimed step (concurrent streams overlap, "
                           "so those can add up to more than ms_per_step)",
                 "kernel_ms_one_step": {s["name"]: round(s["total_ms"], 3) for s in sorted(all_st, key=lambda s: -s["total_ms"])}}
+        # The kernel with the most device time may be a latency-bound one (serial token walks, checkpoint solvers: a few bytes per
+        # anchor) or one whose launches wait for room beside the other lanes' kernels; the same figures for every kernel whose
+        # algorithmic bytes are known, from the one untimed step with events around every launch (4 lanes: durations include
+        # the time a launch shares the device with up to seven other kernels)
+        roof["per_kernel_one_step"] = {s["name"]: {"ms": round(s["total_ms"], 2), "launches": s["launches"], "algo_GB": round(s["algo_bytes"] / 1e9, 2),
+                                                   "GB_per_s": round(s["algo_bytes"] / 1e9 / (s["total_ms"] / 1e3), 1) if s["total_ms"] > 0 else None}
+                                       for s in sorted(all_st, key=lambda s: -s["total_ms"]) if s["algo_bytes"]}
     if rank == 0:
         # HBM traffic of the dominant kernel from the PMC passes of this workload, if they were collected
         # (tools/gpu_round.sh -> profiles/*pmc_traffic.json; separate rocprofv3 --pmc runs, never inside a timed run)

@@ -95,9 +95,6 @@ void Knobs::read_env()
 	debug_sort = getenv("LQCOV_DEBUG_SORT") != nullptr;
 	sketch_kpt = (u32)std::min<long>(64, std::max<long>(1, num("LQCOV_SKETCH_KPT", 4)));
 	sketch_machine_only = is("LQCOV_SKETCH", "machine");
-	fin_big = !is("LQCOV_FIN_BIG", "0");
-	walk_cus = getenv("LQCOV_WALK_CUS") ? (u32)strtoul(getenv("LQCOV_WALK_CUS"), 0, 16) : 0x11111111u;
-	chain_grid = (u32)std::max<long>(64, num("LQCOV_CHAIN_GRID", 0x7fffffff));
 }
 
 lqcov_handle::lqcov_handle(const lqcov_params &p, int dev) : P(p), device(dev)
@@ -663,7 +660,7 @@ void lqcov_handle::map_batch(MapLane &L, Part &pt, u32 q0, u32 q1, const std::ve
 			// private-array DP for short runs, and a fixed [16][64] LDS column per lane (54 KiB per wave: 160 + 40 ms vs 113 ms).
 			// wave_min - 1 <= 47 < the smallest budget, so every run fits.
 			StageTimer t(this, L.stream, "k_chain", nA * 16);
-#define LQ_CHAIN_LAUNCH(CAP) LQ_LAUNCH((k_chain<CAP>), std::min<u32>(nblk(n_groups, 64), K.chain_grid), 64, L.stream, dA, L.gstart.as<u64>(), (const u32*)nullptr, (u32)n_groups, aqb, a_base, nqb, q0, avg_qspan.as<float>(), mp, cs, (i32)P.min_cnt, (i32)(wave_min - 1))
+#define LQ_CHAIN_LAUNCH(CAP) LQ_LAUNCH((k_chain<CAP>), nblk(n_groups, 64), 64, L.stream, dA, L.gstart.as<u64>(), (const u32*)nullptr, (u32)n_groups, aqb, a_base, nqb, q0, avg_qspan.as<float>(), mp, cs, (i32)P.min_cnt, (i32)(wave_min - 1))
 			if (cap == 64) { LQ_CHAIN_LAUNCH(64); } else if (cap == 128) { LQ_CHAIN_LAUNCH(128); } else { LQ_CHAIN_LAUNCH(256); }
 #undef LQ_CHAIN_LAUNCH
 			check_launch();
@@ -715,7 +712,7 @@ void lqcov_handle::map_batch(MapLane &L, Part &pt, u32 q0, u32 q1, const std::ve
 	}
 }
 
-static PsLists ps_lists(MapLane &L, int set, u32 sh, bool fin_big)
+static PsLists ps_lists(MapLane &L, int set, u32 sh)
 {
 	PsWork &W = L.ps[set];
 	PsLists Ls;
@@ -723,7 +720,6 @@ static PsLists ps_lists(MapLane &L, int set, u32 sh, bool fin_big)
 	Ls.cnt = L.sort_cnt.as<u32>() + (set ? LQ_C_PS1 : LQ_C_PS0);
 	Ls.cap_big = (u32)std::min<u64>(W.big[0].cap / sizeof(PSeg), 0xfffffff0ULL); Ls.cap_fin = (u32)std::min<u64>(W.fin_s.cap / sizeof(PSeg), 0xfffffff0ULL);
 	Ls.fin_s_max = std::max<u32>(LQ_PS_FIN_SMALL >> sh, 2); Ls.fin_b_max = std::max<u32>(LQ_PS_FIN_BIG >> sh, 4); Ls.child_target = std::max<u32>(LQ_PS_CHILD >> sh, 2);
-	if (!fin_big) { Ls.fin_b_max = Ls.fin_s_max; Ls.child_target = std::max<u32>(Ls.fin_s_max / 2, 2); }   // no big finishing class: partition down to what the small one takes
 	return Ls;
 }
 
@@ -732,7 +728,7 @@ static void ps_pass(lqcov_handle *h, MapLane &L, int set, hipStream_t s, u64 nA,
 {
 	PsWork &W = L.ps[set];
 	u32 *cnt = L.sort_cnt.as<u32>() + (set ? LQ_C_PS1 : LQ_C_PS0);
-	const PsLists Ls = ps_lists(L, set, h->K.ps_shift, h->K.fin_big);
+	const PsLists Ls = ps_lists(L, set, h->K.ps_shift);
 	const u32 cap_cnt = (u32)std::min<u64>(W.gcnt.cap / 4, 0xfffffff0ULL);
 	const u32 g_tiles = (u32)std::min<u64>((nA + LQ_PS_TILE - 1) / LQ_PS_TILE + 1, 16384);
 	const u32 g_segs = (u32)std::min<u64>(Ls.cap_big, 4096);
@@ -756,13 +752,15 @@ static void ps_pass(lqcov_handle *h, MapLane &L, int set, hipStream_t s, u64 nA,
 static void ps_finish(lqcov_handle *h, MapLane &L, int set, hipStream_t s, u64 nA, const KeyMap &km, const PsData &pd)
 {
 	u32 *cnt = L.sort_cnt.as<u32>() + (set ? LQ_C_PS1 : LQ_C_PS0);
-	const PsLists Ls = ps_lists(L, set, h->K.ps_shift, h->K.fin_big);
+	const PsLists Ls = ps_lists(L, set, h->K.ps_shift);
 	const bool k32 = km.pbits + km.rbits + 1 <= 32 + 8;          // the key bits below the sub-bucket digit fit 32 bits (both kernels' digits are >= 8 bits)
 	{
 		StageTimer t(h, s, "k_ps_finish<8192>");
 		unsigned long long *tl = (unsigned long long*)(L.sort_cnt.as<u32>() + (set ? LQ_C_FINB1 : LQ_C_FINB0));
 		const u32 g = (u32)std::min<u64>(std::min<u64>(Ls.cap_fin, nA / LQ_PS_FIN_SMALL + 64), 4096);
-		// 1024 threads (measured at configs[2], 4 lanes, round 2: 256-thread blocks 2.40 s per step, 512: 2.25, 1024: 2.1-2.2; round 3: 512 = 1024)
+		// 1024 threads (measured at configs[2], 4 lanes, round 2: 256-thread blocks 2.40 s per step, 512: 2.25, 1024: 2.1-2.2; round 3: 512 = 1024).
+		// Beside the other lanes' kernels a launch of this kernel takes ~3x its time alone, most of it waiting: with the class
+		// emptied (everything partitioned down to 1024) the empty launches still took 367 ms per step and the step was the same.
 		if (!k32) LQ_LAUNCH((k_ps_finish<LQ_PS_FIN_BIG, 1024, 10, u64>), g, 1024, s, Ls.fin_b, cnt + LQ_P_FIN_B, pd, km, tl);
 		else LQ_LAUNCH((k_ps_finish<LQ_PS_FIN_BIG, 1024, 10, u32>), g, 1024, s, Ls.fin_b, cnt + LQ_P_FIN_B, pd, km, tl);
 		check_launch();
@@ -842,7 +840,7 @@ void lqcov_handle::sort_batch(MapLane &L, Part &pt, u32 q0, u32 nqb, u64 a_base,
 	}
 	// list capacities: a segment in any list has more than 64 elements
 	const u64 max_segs = nA / (LQ_RS_MIN + 1) + nqb + 1;
-	const u64 cap_big = nA / (((K.fin_big ? LQ_PS_FIN_BIG : LQ_PS_FIN_SMALL) >> K.ps_shift) + 1) + nqb + 16;
+	const u64 cap_big = nA / ((LQ_PS_FIN_BIG >> K.ps_shift) + 1) + nqb + 16;
 	L.sort_cnt.ensure(LQ_C_N * 4);
 	for (int set = 0; set < 2; ++set) {
 		PsWork &W = L.ps[set];
@@ -857,7 +855,7 @@ void lqcov_handle::sort_batch(MapLane &L, Part &pt, u32 q0, u32 nqb, u64 a_base,
 	}
 	L.segs0.ensure(max_segs * sizeof(SortSeg)); L.segs1.ensure(max_segs * sizeof(SortSeg));
 	dzero(L.sort_cnt.p, LQ_C_N * 4, sD);
-	auto lists = [&](int set) { return ps_lists(L, set, K.ps_shift, K.fin_big); };
+	auto lists = [&](int set) { return ps_lists(L, set, K.ps_shift); };
 	u32 *cnt = L.sort_cnt.as<u32>();
 	// records: R0 of its own, R1 in the part of the scratch area that is only used after the sort (map_batch)
 	const u64 nA4 = ((nA + 1) * 4 + 15) & ~(u64)15;
@@ -1151,9 +1149,10 @@ void lqcov_handle::map_part(Part &pt)
 			// the LDS of every CU and the bandwidth kernels of the other streams crawl (rocprofv3, configs[2]: k_ps_scatter 66 ms
 			// alone, 1100 ms beside the walkers).  Their stream may only use every fourth CU; 64 CUs x 32 waves are plenty for them.
 			// (Keeping the other streams off those CUs as well was measured in round 3: slower, 2.15 vs 1.85-2.1 s per step.)
-			// (Round 3: a different quarter of the CUs per lane: no change, 1.77 vs 1.76-1.79 s per step; no mask at all: 2.03 s.)
+			// (Round 3: a different quarter of the CUs per lane, or 128 / 192 CUs instead of 64: no change, 1.69-1.71 s per step whatever
+			// the mask; no mask at all: 2.03 s.)
 			uint32_t mask[8];
-			for (int i = 0; i < 8; ++i) mask[i] = K.walk_cus;
+			for (int i = 0; i < 8; ++i) mask[i] = 0x11111111u;
 			if (hipExtStreamCreateWithCUMask(&lanes.back()->streamW, 8, mask) != hipSuccess) { (void)hipGetLastError(); LQ_HIP_CHECK(hipStreamCreate(&lanes.back()->streamW)); }
 			if (hipExtStreamCreateWithCUMask(&lanes.back()->streamW2, 8, mask) != hipSuccess) { (void)hipGetLastError(); LQ_HIP_CHECK(hipStreamCreate(&lanes.back()->streamW2)); }
 		}

@@ -39,9 +39,6 @@ struct Knobs {
 	bool no_level_skip = false;           // LQCOV_NO_LEVEL_SKIP: constant key bytes are walked, not stepped over
 	bool debug_sort = false;              // LQCOV_DEBUG_SORT
 	u32 sketch_kpt = 4;                   // LQCOV_SKETCH_KPT: chunks per thread of the sketch state machine
-	u32 chain_grid = 0x7fffffff;          // LQCOV_CHAIN_GRID: cap on k_chain's grid (blocks stride over the runs) (A/B)
-	u32 walk_cus = 0x11111111u;           // LQCOV_WALK_CUS: CU mask word of the walkers' streams (hex)
-	bool fin_big = true;                  // LQCOV_FIN_BIG=0: no 8192-element finishing class (1024-thread blocks): partition down to 1024 (A/B)
 	bool sketch_machine_only = false;     // LQCOV_SKETCH=machine: the state machine decides every chunk (no data-parallel kernel)
 	void read_env();
 };

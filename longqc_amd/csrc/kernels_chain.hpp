@@ -460,9 +460,7 @@ k_chain(const mm128 *A, const u64 *gstart, const u32 *glist, u32 n_list, const u
 	LQ_SHARED i32 s_f[LQ_CHAIN_LDS_CAP], s_p[LQ_CHAIN_LDS_CAP], s_t[LQ_CHAIN_LDS_CAP], s_v[LQ_CHAIN_LDS_CAP];
 	LQ_SHARED u64 s_u[LQ_CHAIN_LDS_CAP];
 	LQ_SHARED u32 s_n[64], s_q[64], s_done[64];
-	// (a bounded grid striding over the runs: millions of one-wave blocks, each gone after a few microseconds, keep every CU's
-	// wave slots and LDS in small change -- a 1024-thread block of another lane's kernel then waits for this whole kernel)
-	for (u32 gi0 = blockIdx.x * blockDim.x; gi0 < n_list; gi0 += gridDim.x * blockDim.x) {
+	const u32 gi0 = blockIdx.x * blockDim.x;
 	LQ_BLOCK_LOOP(ln) {
 		u32 todo = 0;
 		const u32 gi = gi0 + ln;
@@ -503,7 +501,6 @@ k_chain(const mm128 *A, const u64 *gstart, const u32 *glist, u32 n_list, const u
 		LQ_BLOCK_SYNC();
 		LQ_BLOCK_LOOP(ln) { if (s_done[ln]) { s_n[ln] = 0; s_done[ln] = 0; } }
 		LQ_BLOCK_SYNC();
-	}
 	}
 }
 
