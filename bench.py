@@ -308,7 +308,8 @@ def main():
                     continue
                 if args.config not in js.get("workload", ""):
                     continue
-                hit = [v for k, v in kk.items() if k.split("<")[0] == roof["kernel"].split("<")[0]]
+                want = roof["kernel"].replace(">", "")                    # "k_ps_finish<8192" matches "k_ps_finish<8192, 1024, 10, unsigned int>"
+                hit = [v for k, v in kk.items() if k == roof["kernel"] or k.startswith(want + ",") or k.startswith(want + ">") or (("<" not in want) and k.split("<")[0] == want)]
                 if hit:
                     roof["traffic"] = round(hit[0]["hbm_bytes_per_launch"] / 1e9, 3)
                     roof["traffic_unit"] = "GB per launch (PMC: (2*FETCH_SIZE+WRITE_SIZE)*1024, from the committed %s, not from this run)" % os.path.basename(fn)

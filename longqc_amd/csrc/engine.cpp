@@ -95,6 +95,7 @@ void Knobs::read_env()
 	debug_sort = getenv("LQCOV_DEBUG_SORT") != nullptr;
 	sketch_kpt = (u32)std::min<long>(64, std::max<long>(1, num("LQCOV_SKETCH_KPT", 4)));
 	sketch_machine_only = is("LQCOV_SKETCH", "machine");
+	ps_grid = (u32)std::max<long>(64, num("LQCOV_PS_GRID", 2048));
 }
 
 lqcov_handle::lqcov_handle(const lqcov_params &p, int dev) : P(p), device(dev)
@@ -676,7 +677,7 @@ void lqcov_handle::map_batch(MapLane &L, Part &pt, u32 q0, u32 q1, const std::ve
 				L.gsel.ensure((u64)n_sel * 4); L.gkey.ensure((u64)n_sel * 4); L.gsel2.ensure((u64)n_sel * 4); L.gkey2.ensure((u64)n_sel * 4);
 				LQ_LAUNCH(k_sel_write, std::min<u32>(n_tiles, 1u << 16), LQ_RUN_THREADS, L.stream, L.gstart.as<u64>(), n_groups, (i32)wave_min, (i32)0x7fffffff, n_tiles, L.sel_tiles.as<u32>(), L.gsel.as<u32>(), L.gkey.as<u32>()); check_launch();
 				L.prim.sort_pairs_u32_u32(L.gkey.as<u32>(), L.gkey2.as<u32>(), L.gsel.as<u32>(), L.gsel2.as<u32>(), n_sel);
-				StageTimer t(this, L.stream, "k_chain_wave", nA * 16);
+				StageTimer t(this, L.stream, "k_chain_wave");
 				LQ_LAUNCH(k_chain_wave, n_sel, 64, L.stream, dA, L.gstart.as<u64>(), L.gsel2.as<u32>(), n_sel, aqb, a_base, nqb, q0, avg_qspan.as<float>(), mp, cb, cs);
 				check_launch();
 			}
@@ -730,8 +731,10 @@ static void ps_pass(lqcov_handle *h, MapLane &L, int set, hipStream_t s, u64 nA,
 	u32 *cnt = L.sort_cnt.as<u32>() + (set ? LQ_C_PS1 : LQ_C_PS0);
 	const PsLists Ls = ps_lists(L, set, h->K.ps_shift);
 	const u32 cap_cnt = (u32)std::min<u64>(W.gcnt.cap / 4, 0xfffffff0ULL);
-	const u32 g_tiles = (u32)std::min<u64>((nA + LQ_PS_TILE - 1) / LQ_PS_TILE + 1, 16384);
-	const u32 g_segs = (u32)std::min<u64>(Ls.cap_big, 4096);
+	// grids: a few blocks per CU striding over the device-side lists.  Most passes of a batch find their list short or empty,
+	// and a launch sized for the worst case still has every one of its blocks placed (LDS and wave slots included) to find that out
+	const u32 g_tiles = (u32)std::min<u64>((nA + LQ_PS_TILE - 1) / LQ_PS_TILE + 1, h->K.ps_grid);
+	const u32 g_segs = (u32)std::min<u64>(Ls.cap_big, 1024);
 	const u32 nxt = cur ^ 1;
 	const u32 cap_tiles = (u32)std::min<u64>(W.tmap.cap / 4, 0xfffffff0ULL);
 	LQ_LAUNCH(k_ps_plan, 1, 256, s, Ls.big[cur], cnt + (cur ? LQ_P_BIG1 : LQ_P_BIG0), W.plan.as<PPlan>(), cnt, cap_cnt, cap_tiles, Ls.child_target, cnt + (nxt ? LQ_P_BIG1 : LQ_P_BIG0)); check_launch();
@@ -757,7 +760,7 @@ static void ps_finish(lqcov_handle *h, MapLane &L, int set, hipStream_t s, u64 n
 	{
 		StageTimer t(h, s, "k_ps_finish<8192>");
 		unsigned long long *tl = (unsigned long long*)(L.sort_cnt.as<u32>() + (set ? LQ_C_FINB1 : LQ_C_FINB0));
-		const u32 g = (u32)std::min<u64>(std::min<u64>(Ls.cap_fin, nA / LQ_PS_FIN_SMALL + 64), 4096);
+		const u32 g = (u32)std::min<u64>(std::min<u64>(Ls.cap_fin, nA / LQ_PS_FIN_SMALL + 64), h->K.ps_grid / 4);
 		// 1024 threads (measured at configs[2], 4 lanes, round 2: 256-thread blocks 2.40 s per step, 512: 2.25, 1024: 2.1-2.2; round 3: 512 = 1024).
 		// Beside the other lanes' kernels a launch of this kernel takes ~3x its time alone, most of it waiting: with the class
 		// emptied (everything partitioned down to 1024) the empty launches still took 367 ms per step and the step was the same.
@@ -768,7 +771,7 @@ static void ps_finish(lqcov_handle *h, MapLane &L, int set, hipStream_t s, u64 n
 	{
 		StageTimer t(h, s, "k_ps_finish<1024>");
 		unsigned long long *tl = (unsigned long long*)(L.sort_cnt.as<u32>() + (set ? LQ_C_FINS1 : LQ_C_FINS0));
-		const u32 g = (u32)std::min<u64>(std::min<u64>(Ls.cap_fin, nA / 16 + 256), 32768);
+		const u32 g = (u32)std::min<u64>(std::min<u64>(Ls.cap_fin, nA / 16 + 256), h->K.ps_grid * 2);
 		if (k32) LQ_LAUNCH((k_ps_finish<LQ_PS_FIN_SMALL, 256, 8, u32>), g, 256, s, Ls.fin_s, cnt + LQ_P_FIN_S, pd, km, tl);
 		else LQ_LAUNCH((k_ps_finish<LQ_PS_FIN_SMALL, 256, 8, u64>), g, 256, s, Ls.fin_s, cnt + LQ_P_FIN_S, pd, km, tl);
 		check_launch();
@@ -911,7 +914,7 @@ void lqcov_handle::sort_batch(MapLane &L, Part &pt, u32 q0, u32 nqb, u64 a_base,
 			check_launch();
 			{	// closed-form two-bucket passes (the strand bit at the top level), over tiles: count the X / Y elements of every tile, scan
 				// per sub-array, position lists, then destinations + the move of the records
-				StageTimer t(this, sD, "k_sort_two", nA * 6);
+				StageTimer t(this, sD, "k_sort_two");
 				L.two_tiles.ensure(max_tiles * sizeof(SortTile)); L.two_tile0.ensure((u64)ns * 4); L.two_tcnt.ensure(max_tiles * 8); L.two_m.ensure((u64)ns * 4);
 				const SortTile *tt = L.two_tiles.as<SortTile>();
 				const u32 *ntt = cnt + LQ_C_TWO_TILES;
@@ -967,7 +970,7 @@ void lqcov_handle::sort_batch(MapLane &L, Part &pt, u32 q0, u32 nqb, u64 a_base,
 					const u32 g_ck = (u32)std::min<u64>(ck_max, wgrid), g_cks = (u32)std::min<u64>(cks_max, wgrid);
 					if (ck_small) {
 						{
-							StageTimer t(this, sW, "k_ck_prefix", nA);
+							StageTimer t(this, sW, "k_ck_prefix");
 							LQ_LAUNCH(k_ck_tilehist, (u32)std::min<u64>(tiles_max, 1u << 16), 256, sW, dck, ckn, cur, dD, L.ck_T.as<u32>()); check_launch();
 							LQ_LAUNCH(k_ck_tilescan, std::min<u32>(g_cks, 8192), 256, sW, dck, ckn, cur, L.ck_T.as<u32>()); check_launch();
 						}
@@ -977,16 +980,16 @@ void lqcov_handle::sort_batch(MapLane &L, Part &pt, u32 q0, u32 nqb, u64 a_base,
 							LQ_LAUNCH(k_ck_solve, g_ck, 64, sW, dck, ckn, cur, dD, dH, dBg, L.ck_T.as<u32>(), L.ck_E.as<u32>(), L.ck_S.as<u32>(), L.ck_slot.as<u32>()); check_launch();
 						}
 						{
-							StageTimer t(this, sW, "k_sort_walk_reg<1>ck", nA * 5);
+							StageTimer t(this, sW, "k_sort_walk_reg<1>ck");
 							LQ_LAUNCH((k_sort_walk_reg<1>), g_ck, 64, sW, cur, (const u32*)nullptr, ckn, dD, dH, dBg, dDst, dck, ckn, L.ck_S.as<u32>(), L.ck_slot.as<u32>()); check_launch();
 						}
 					} else {
 						{
-							StageTimer t(this, sW, "k_ck_chain256", nA);
+							StageTimer t(this, sW, "k_ck_chain256");
 							LQ_LAUNCH(k_ck_chain256, g_cks, 64, sW, dck, ckn, cur, dD, dH, dBg, L.ck_S.as<u32>(), L.ck_slot.as<u32>()); check_launch();
 						}
 						{
-							StageTimer t(this, sW, "k_sort_walk_solo_ck", nA * 5);
+							StageTimer t(this, sW, "k_sort_walk_solo_ck");
 							LQ_LAUNCH(k_sort_walk_solo, g_ck, 64, sW, cur, (const u32*)nullptr, ckn, dD, dH, dBg, dDst, dck, ckn, L.ck_S.as<u32>(), L.ck_slot.as<u32>()); check_launch();
 						}
 					}
@@ -996,9 +999,9 @@ void lqcov_handle::sort_batch(MapLane &L, Part &pt, u32 q0, u32 nqb, u64 a_base,
 				for (int c = first_plain_class; c >= 2; --c) {
 					const u32 g = std::min<u32>(ns, std::min<u32>(8192, wgrid));
 					const CkSeg *nock = nullptr;
-					if (K.reg_walker && max_digit < 64) { StageTimer t(this, sW2, "k_sort_walk_reg<1>", nA * 5); LQ_LAUNCH((k_sort_walk_reg<1>), g, 64, sW2, cur, wl + (u64)c * ns, cnt + LQ_C_WALK0 + c, dD, dH, dBg, dDst, nock, (const u32*)nullptr, (const u32*)nullptr, (const u32*)nullptr); }
-					else if (K.reg_walker && max_digit < 128) { StageTimer t(this, sW2, "k_sort_walk_reg<2>", nA * 5); LQ_LAUNCH((k_sort_walk_reg<2>), g, 64, sW2, cur, wl + (u64)c * ns, cnt + LQ_C_WALK0 + c, dD, dH, dBg, dDst, nock, (const u32*)nullptr, (const u32*)nullptr, (const u32*)nullptr); }
-					else { StageTimer t(this, sW2, "k_sort_walk_solo", nA * 5); LQ_LAUNCH(k_sort_walk_solo, g, 64, sW2, cur, wl + (u64)c * ns, cnt + LQ_C_WALK0 + c, dD, dH, dBg, dDst, nock, (const u32*)nullptr, (const u32*)nullptr, (const u32*)nullptr); }
+					if (K.reg_walker && max_digit < 64) { StageTimer t(this, sW2, "k_sort_walk_reg<1>"); LQ_LAUNCH((k_sort_walk_reg<1>), g, 64, sW2, cur, wl + (u64)c * ns, cnt + LQ_C_WALK0 + c, dD, dH, dBg, dDst, nock, (const u32*)nullptr, (const u32*)nullptr, (const u32*)nullptr); }
+					else if (K.reg_walker && max_digit < 128) { StageTimer t(this, sW2, "k_sort_walk_reg<2>"); LQ_LAUNCH((k_sort_walk_reg<2>), g, 64, sW2, cur, wl + (u64)c * ns, cnt + LQ_C_WALK0 + c, dD, dH, dBg, dDst, nock, (const u32*)nullptr, (const u32*)nullptr, (const u32*)nullptr); }
+					else { StageTimer t(this, sW2, "k_sort_walk_solo"); LQ_LAUNCH(k_sort_walk_solo, g, 64, sW2, cur, wl + (u64)c * ns, cnt + LQ_C_WALK0 + c, dD, dH, dBg, dDst, nock, (const u32*)nullptr, (const u32*)nullptr, (const u32*)nullptr); }
 					check_launch();
 				}
 				{ StageTimer t(this, sW2, "k_sort_walk_lds<16384>"); LQ_LAUNCH((k_sort_walk_lds<16384>), std::min<u32>(ns, std::min<u32>(8192, wgrid)), 64, sW2, cur, wl + (u64)1 * ns, cnt + LQ_C_WALK1, dD, dH, dBg, dDst); check_launch(); }
