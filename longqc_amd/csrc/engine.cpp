@@ -95,7 +95,9 @@ void Knobs::read_env()
 	debug_sort = getenv("LQCOV_DEBUG_SORT") != nullptr;
 	sketch_kpt = (u32)std::min<long>(64, std::max<long>(1, num("LQCOV_SKETCH_KPT", 4)));
 	sketch_machine_only = is("LQCOV_SKETCH", "machine");
-	ps_grid = (u32)std::max<long>(64, num("LQCOV_PS_GRID", 2048));
+	ps_grid = (u32)std::max<long>(64, num("LQCOV_PS_GRID", 512));
+	tile_grid = (u32)std::max<long>(64, num("LQCOV_TILE_GRID", 4096));
+	ps_passes = (u32)std::min<long>(16, std::max<long>(0, num("LQCOV_PS_PASSES", LQ_PS_PASSES))) & ~1u;
 }
 
 lqcov_handle::lqcov_handle(const lqcov_params &p, int dev) : P(p), device(dev)
@@ -734,7 +736,7 @@ static void ps_pass(lqcov_handle *h, MapLane &L, int set, hipStream_t s, u64 nA,
 	// grids: a few blocks per CU striding over the device-side lists.  Most passes of a batch find their list short or empty,
 	// and a launch sized for the worst case still has every one of its blocks placed (LDS and wave slots included) to find that out
 	const u32 g_tiles = (u32)std::min<u64>((nA + LQ_PS_TILE - 1) / LQ_PS_TILE + 1, h->K.ps_grid);
-	const u32 g_segs = (u32)std::min<u64>(Ls.cap_big, 1024);
+	const u32 g_segs = (u32)std::min<u64>(Ls.cap_big, 256);
 	const u32 nxt = cur ^ 1;
 	const u32 cap_tiles = (u32)std::min<u64>(W.tmap.cap / 4, 0xfffffff0ULL);
 	LQ_LAUNCH(k_ps_plan, 1, 256, s, Ls.big[cur], cnt + (cur ? LQ_P_BIG1 : LQ_P_BIG0), W.plan.as<PPlan>(), cnt, cap_cnt, cap_tiles, Ls.child_target, cnt + (nxt ? LQ_P_BIG1 : LQ_P_BIG0)); check_launch();
@@ -793,7 +795,7 @@ void lqcov_handle::psort_run(MapLane &L, int set, hipStream_t s, u64 nA, const K
 		ps_finish(this, L, set, s, nA, km, pd);
 		dzero(cnt + LQ_P_FIN_S, 8, s);                          // (LQ_P_FIN_S and LQ_P_FIN_B are neighbours)
 	}
-	for (u32 pass = 0; pass < LQ_PS_PASSES; ++pass) ps_pass(this, L, set, s, nA, km, pd, pass & 1);
+	for (u32 pass = 0; pass < K.ps_passes; ++pass) ps_pass(this, L, set, s, nA, km, pd, pass & 1);
 	ps_finish(this, L, set, s, nA, km, pd);
 }
 
@@ -865,9 +867,11 @@ void lqcov_handle::sort_batch(MapLane &L, Part &pt, u32 q0, u32 nqb, u64 a_base,
 	L.R0.ensure((nA + 1) * sizeof(RRec));
 	RRec *R[2] = { L.R0.as<RRec>(), (RRec*)((u8*)L.scr.p + 3 * nA4) };
 	PsData pd; pd.A = dA; pd.B = dB; pd.R[0] = R[0]; pd.R[1] = R[1];
+	WalkCaps wcaps; wcaps.c[0] = 4096; wcaps.c[1] = 16384; wcaps.c[2] = 65536; wcaps.c[3] = 159744;
+	for (int c = 0; c < 4; ++c) wcaps.c[c] >>= K.walk_shift;   // test knob
 	{
 		StageTimer t(this, sD, "k_sort_init");
-		LQ_LAUNCH(k_sort_init, nblk(nqb, 64), 64, sD, aqb, a_base, nqb, qklib.as<u32>() + q0, dA, L.segs0.as<SortSeg>(), cnt, lists(0), km);
+		LQ_LAUNCH(k_sort_init, nblk(nqb, 64), 64, sD, aqb, a_base, nqb, qklib.as<u32>() + q0, dA, L.segs0.as<SortSeg>(), cnt, lists(0), km, wcaps);
 		check_launch();
 	}
 	// the parallel sort of the clean queries runs beside klib's passes
@@ -876,12 +880,11 @@ void lqcov_handle::sort_batch(MapLane &L, Part &pt, u32 q0, u32 nqb, u64 a_base,
 	psort_run(L, 0, sC, nA, km, pd);
 	LQ_HIP_CHECK(hipEventRecord(L.ev_join, sC));
 	// ---- klib's passes over the queries with repeated minimizers ----
-	u32 ns = 0;
-	d2h(&ns, cnt + LQ_C_KLIB0, 1, sD);
+	u32 hl[LQ_C_N];                                         // the level's counters as the host last saw them
+	d2h(hl, cnt, LQ_C_N, sD);
+	u32 ns = hl[LQ_C_KLIB0];
 	if (ns) {
 		u32 *hx = (u32*)L.scr.p, *py = (u32*)((u8*)L.scr.p + nA4);
-		WalkCaps wcaps; wcaps.c[0] = 4096; wcaps.c[1] = 16384; wcaps.c[2] = 65536; wcaps.c[3] = 159744;
-		for (int c = 0; c < 4; ++c) wcaps.c[c] >>= K.walk_shift;   // test knob
 		const u32 tile = K.sort_tile ? K.sort_tile : LQ_SORT_TILE;
 		const u32 wgrid = K.walk_grid;
 		L.sort_d.ensure(nA + 64); L.sort_dst.ensure((nA + 1) * 4);
@@ -896,12 +899,12 @@ void lqcov_handle::sort_batch(MapLane &L, Part &pt, u32 q0, u32 nqb, u64 a_base,
 			const u32 g_seg = std::min<u32>(ns, 1u << 18);
 			// tiles of the level's sub-arrays for the two streaming kernels
 			const u64 max_tiles = nA / tile + ns + 1;
-			const u32 g_tile = ((u32)std::min<u64>(max_tiles, 1u << 18) + 7) & ~7u;      // a multiple of the XCD count (LQ_TILE_LOOP)
+			const u32 g_tile = ((u32)std::min<u64>(max_tiles, K.tile_grid) + 7) & ~7u;   // a multiple of the XCD count (LQ_TILE_LOOP); blocks stride over the device-side tile list
 			L.tile_list.ensure(max_tiles * sizeof(SortTile));
 			// (the counters of the level -- next list, two-bucket and walk class lists, two-bucket tiles -- are zeroed by k_sort_tiles, the
 			// tile counter by the k_rs_children of the level before or the batch's memset: no memset dispatches inside the level loop)
 			LQ_LAUNCH(k_sort_tiles, std::min<u32>(ns / 256 + 1, 4096), 256, sD, cur, cnt + cur_slot, tile, L.tile_list.as<SortTile>(), cnt + LQ_C_TILES, L.hist.as<u32>(), L.mhist.as<u32>(),
-			          cnt + nxt_slot, cnt + LQ_C_TWO, (u32)(1 + LQ_WALK_CLASSES), cnt + LQ_C_TWO_TILES);
+			          cnt + nxt_slot, cnt + LQ_C_TWO, (u32)(1 + LQ_WALK_CLASSES), cnt + LQ_C_TWO_TILES, cnt + LQ_C_LEN0, (u32)LQ_WALK_CLASSES);
 			check_launch();
 			{
 				StageTimer t(this, sD, level == 0 ? "k_rs_hist<first>" : "k_rs_hist");
@@ -918,7 +921,7 @@ void lqcov_handle::sort_batch(MapLane &L, Part &pt, u32 q0, u32 nqb, u64 a_base,
 				L.two_tiles.ensure(max_tiles * sizeof(SortTile)); L.two_tile0.ensure((u64)ns * 4); L.two_tcnt.ensure(max_tiles * 8); L.two_m.ensure((u64)ns * 4);
 				const SortTile *tt = L.two_tiles.as<SortTile>();
 				const u32 *ntt = cnt + LQ_C_TWO_TILES;
-				const u32 g_two = std::min<u32>(g_tile, 8192);         // grid-stride: a level without two-bucket sub-arrays costs near-empty launches
+				const u32 g_two = std::min<u32>(g_tile, 2048);         // grid-stride: a level without two-bucket sub-arrays costs near-empty launches
 				const u64 *rc = (const u64*)R[rb]; u64 *rn = (u64*)R[rb ^ 1];
 				LQ_LAUNCH(k_two_tiles, std::min<u32>(ns / 256 + 1, 4096), 256, sD, cur, L.two_list.as<u32>(), cnt + LQ_C_TWO, tile, L.two_tiles.as<SortTile>(), cnt + LQ_C_TWO_TILES, L.two_tile0.as<u32>()); check_launch();
 				LQ_LAUNCH((k_sort_two_tiled<0>), g_two, 256, sD, cur, L.seg_info.as<SegInfo>(), tt, ntt, tile, L.sort_d.as<u8>(), L.two_tcnt.as<u32>(), L.two_m.as<u32>(), hx, py, rc, rn); check_launch();
@@ -946,21 +949,32 @@ void lqcov_handle::sort_batch(MapLane &L, Part &pt, u32 q0, u32 nqb, u64 a_base,
 					        hc[LQ_C_WALK0], hc[LQ_C_WALK1], hc[LQ_C_WALK2], hc[LQ_C_WALK3], hc[LQ_C_WALK4], (unsigned long long)nA);
 					fflush(stderr);
 				}
-				// the walkers' stream starts where this one stands, and this one resumes when they are done
-				LQ_HIP_CHECK(hipEventRecord(L.ev_w0, sD)); LQ_HIP_CHECK(hipStreamWaitEvent(sW, L.ev_w0, 0)); LQ_HIP_CHECK(hipStreamWaitEvent(sW2, L.ev_w0, 0));
+				// What the host knows of this level's sub-arrays: how many there are of every walk size class (counted by length when they
+				// were made: an upper bound of the class lists, which hold the general passes only), and whether the level's byte can take
+				// more than two values at all (byte 7 is strand << 7 | rid >> 24: two buckets below 2^24 targets -- no walk, ever).
+				// Launches of empty classes are skipped, the others sized by the bound: a grid sized for the worst case has every block
+				// placed, LDS included, only to find its list empty, and a level has up to ten such launches on its critical path.
+				u32 lenc[LQ_WALK_CLASSES];
+				for (int c = 0; c < LQ_WALK_CLASSES; ++c) lenc[c] = hl[LQ_C_LEN0 + c];
+				const u32 max_buckets = shift == 56 ? 2 * (((pt.rs.n ? pt.rs.n - 1 : 0) >> 24) + 1) : max_digit + 1;
+				const bool any_walk = max_buckets > 2 || K.no_level_skip;
+				const bool ck_small = K.reg_walker && max_digit < LQ_CK_B;
+				const bool ck3 = ck_small || K.ckpt3;
+				const u64 n_ck_segs = K.ckpt ? (u64)(ck3 ? lenc[3] : 0) + lenc[4] : 0;
+				int first_plain_class = K.ckpt ? (ck3 ? 2 : 3) : LQ_WALK_CLASSES - 1;
+				bool w1 = false, w2 = false;                          // which walker streams got work
+				if (any_walk) { LQ_HIP_CHECK(hipEventRecord(L.ev_w0, sD)); }
 				if (!gated && !L.gate_passed) { L.gate_passed = true; open_gate(); gated = true; }   // let the next lane start under these walks
 				// Long sub-arrays: the walk's state at evenly spread checkpoints is computed without walking (kernels_ckpt.hpp) and
 				// one walker per checkpoint runs a short piece.  Few buckets (the byte of rid above 65536 targets: the (query, strand)
 				// arrays of the longest queries, millions of anchors each): states from prefix counts; up to 256 buckets: bulk-follow
 				// solver, longest size class only (finding the states costs about as much as walking 50-100 k elements there).
 				// The plan (which sub-arrays, their tiles and checkpoints) is laid out on the device from the class lists.
-				int first_plain_class = LQ_WALK_CLASSES - 1;
-				const bool ck_small = K.reg_walker && max_digit < LQ_CK_B;
-				if (K.ckpt) {
-					const bool ck3 = ck_small || K.ckpt3;
+				if (any_walk && n_ck_segs) {
+					LQ_HIP_CHECK(hipStreamWaitEvent(sW, L.ev_w0, 0)); w1 = true;
 					const u32 unit = std::max<u32>(16384u >> K.walk_shift, 8);
 					const u32 min_len = wcaps.c[ck3 ? 2 : 3] + 1;
-					const u64 cks_max = std::min<u64>(nA / min_len + 1, ns), ck_max = nA / unit + 2 * cks_max, tiles_max = nA / LQ_CK_TILE + cks_max;
+					const u64 cks_max = std::min<u64>(std::min<u64>(nA / min_len + 1, ns), n_ck_segs), ck_max = nA / unit + 2 * cks_max, tiles_max = nA / LQ_CK_TILE + cks_max;
 					const u32 per_ck = ck_small ? LQ_CK_B : 256;          // cursors per checkpoint
 					L.ck_segs.ensure(cks_max * sizeof(CkSeg)); L.ck_S.ensure(ck_max * per_ck * 4); L.ck_slot.ensure(ck_max * 4 + 4);
 					if (ck_small) { L.ck_T.ensure((tiles_max + 1) * LQ_CK_B * 4); L.ck_E.ensure(cks_max * LQ_CK_B * LQ_CK_B * 4); }
@@ -993,22 +1007,24 @@ void lqcov_handle::sort_batch(MapLane &L, Part &pt, u32 q0, u32 nqb, u64 a_base,
 							LQ_LAUNCH(k_sort_walk_solo, g_ck, 64, sW, cur, (const u32*)nullptr, ckn, dD, dH, dBg, dDst, dck, ckn, L.ck_S.as<u32>(), L.ck_slot.as<u32>()); check_launch();
 						}
 					}
-					first_plain_class = ck3 ? 2 : 3;
 				}
-				// long walks first: they outlast everything else of the level on a handful of CUs
-				for (int c = first_plain_class; c >= 2; --c) {
-					const u32 g = std::min<u32>(ns, std::min<u32>(8192, wgrid));
+				// whole walks, longest class first: they outlast everything else of the level on a handful of CUs
+				auto fork2 = [&]() { if (!w2) { LQ_HIP_CHECK(hipStreamWaitEvent(sW2, L.ev_w0, 0)); w2 = true; } };
+				for (int c = first_plain_class; any_walk && c >= 2; --c) {
+					if (!lenc[c]) continue;
+					fork2();
+					const u32 g = std::min<u32>(lenc[c], std::min<u32>(8192, wgrid));
 					const CkSeg *nock = nullptr;
 					if (K.reg_walker && max_digit < 64) { StageTimer t(this, sW2, "k_sort_walk_reg<1>"); LQ_LAUNCH((k_sort_walk_reg<1>), g, 64, sW2, cur, wl + (u64)c * ns, cnt + LQ_C_WALK0 + c, dD, dH, dBg, dDst, nock, (const u32*)nullptr, (const u32*)nullptr, (const u32*)nullptr); }
 					else if (K.reg_walker && max_digit < 128) { StageTimer t(this, sW2, "k_sort_walk_reg<2>"); LQ_LAUNCH((k_sort_walk_reg<2>), g, 64, sW2, cur, wl + (u64)c * ns, cnt + LQ_C_WALK0 + c, dD, dH, dBg, dDst, nock, (const u32*)nullptr, (const u32*)nullptr, (const u32*)nullptr); }
 					else { StageTimer t(this, sW2, "k_sort_walk_solo"); LQ_LAUNCH(k_sort_walk_solo, g, 64, sW2, cur, wl + (u64)c * ns, cnt + LQ_C_WALK0 + c, dD, dH, dBg, dDst, nock, (const u32*)nullptr, (const u32*)nullptr, (const u32*)nullptr); }
 					check_launch();
 				}
-				{ StageTimer t(this, sW2, "k_sort_walk_lds<16384>"); LQ_LAUNCH((k_sort_walk_lds<16384>), std::min<u32>(ns, std::min<u32>(8192, wgrid)), 64, sW2, cur, wl + (u64)1 * ns, cnt + LQ_C_WALK1, dD, dH, dBg, dDst); check_launch(); }
-				{ StageTimer t(this, sW2, "k_sort_walk_lds<4096>"); LQ_LAUNCH((k_sort_walk_lds<4096>), std::min<u32>(ns, std::min<u32>(1u << 16, wgrid * 4)), 64, sW2, cur, wl + (u64)0 * ns, cnt + LQ_C_WALK0, dD, dH, dBg, dDst); check_launch(); }
+				if (any_walk && lenc[1]) { fork2(); StageTimer t(this, sW2, "k_sort_walk_lds<16384>"); LQ_LAUNCH((k_sort_walk_lds<16384>), std::min<u32>(lenc[1], std::min<u32>(8192, wgrid)), 64, sW2, cur, wl + (u64)1 * ns, cnt + LQ_C_WALK1, dD, dH, dBg, dDst); check_launch(); }
+				if (any_walk && lenc[0]) { fork2(); StageTimer t(this, sW2, "k_sort_walk_lds<4096>"); LQ_LAUNCH((k_sort_walk_lds<4096>), std::min<u32>(lenc[0], std::min<u32>(1u << 16, wgrid * 4)), 64, sW2, cur, wl + (u64)0 * ns, cnt + LQ_C_WALK0, dD, dH, dBg, dDst); check_launch(); }
+				if (w1) { LQ_HIP_CHECK(hipEventRecord(L.ev_w1, sW)); LQ_HIP_CHECK(hipStreamWaitEvent(sD, L.ev_w1, 0)); }
+				if (w2) { LQ_HIP_CHECK(hipEventRecord(L.ev_w2, sW2)); LQ_HIP_CHECK(hipStreamWaitEvent(sD, L.ev_w2, 0)); }
 			}
-			LQ_HIP_CHECK(hipEventRecord(L.ev_w1, L.streamW)); LQ_HIP_CHECK(hipEventRecord(L.ev_w2, L.streamW2));
-			LQ_HIP_CHECK(hipStreamWaitEvent(sD, L.ev_w1, 0)); LQ_HIP_CHECK(hipStreamWaitEvent(sD, L.ev_w2, 0));
 			{
 				StageTimer t(this, sD, "k_rs_scatter");
 				LQ_LAUNCH(k_rs_scatter, g_tile, 256, sD, cur, L.seg_info.as<SegInfo>(), L.tile_list.as<SortTile>(), cnt + LQ_C_TILES, tile, 1, R[rb], R[rb ^ 1], L.sort_dst.as<u32>(), (unsigned long long*)(cnt + LQ_C_SCATTERED));
@@ -1017,10 +1033,11 @@ void lqcov_handle::sort_batch(MapLane &L, Part &pt, u32 q0, u32 nqb, u64 a_base,
 			{
 				StageTimer t(this, sD, "k_rs_children");
 				LQ_LAUNCH(k_rs_children, (u32)std::min<u64>((u64)ns * 4, 1u << 20), LQ_CHILD_THREADS, sD, cur, cnt + cur_slot, R[rb ^ 1], rb ^ 1, dB, dA, L.hist.as<u32>(), L.mhist.as<u32>(), L.begs.as<u32>(),
-				          nxt, cnt + nxt_slot, const_levels, lists(1), km, (int)K.all_klib, cnt + LQ_C_TILES);
+				          nxt, cnt + nxt_slot, const_levels, lists(1), km, (int)K.all_klib, cnt + LQ_C_TILES, cnt + LQ_C_LEN0, wcaps);
 				check_launch();
 			}
-			d2h(&ns, cnt + nxt_slot, 1, sD);
+			d2h(hl, cnt, LQ_C_N, sD);
+			ns = hl[nxt_slot];
 			std::swap(cur, nxt); std::swap(cur_slot, nxt_slot);
 			rb ^= 1;
 			if (shift >= 8) { shift -= 8; while (shift > 0 && (const_levels >> (shift >> 3) & 1)) shift -= 8; }

@@ -60,7 +60,9 @@ enum { LQ_C_KLIB0 = 0, LQ_C_KLIB1, LQ_C_TWO, LQ_C_WALK0, LQ_C_WALK1, LQ_C_WALK2,
        LQ_C_TWO_TILES = 12,    // tiles of the level's two-bucket sub-arrays
        LQ_C_PS0 = 16, LQ_C_PS1 = 32,
        // 64-bit tallies of the elements each kind of kernel really moved (algorithmic bytes of the stage times)
-       LQ_C_HIST = 48, LQ_C_SCATTERED = 50, LQ_C_PART0 = 52, LQ_C_FINS0 = 54, LQ_C_FINB0 = 56, LQ_C_PART1 = 58, LQ_C_FINS1 = 60, LQ_C_FINB1 = 62, LQ_C_N = 64 };
+       LQ_C_HIST = 48, LQ_C_SCATTERED = 50, LQ_C_PART0 = 52, LQ_C_FINS0 = 54, LQ_C_FINB0 = 56, LQ_C_PART1 = 58, LQ_C_FINS1 = 60, LQ_C_FINB1 = 62,
+       LQ_C_LEN0 = 64,         // [5] sub-arrays of the level to come by walk size class (by length alone: an upper bound of the class lists)
+       LQ_C_N = 72 };
 enum { LQ_P_BIG0 = 0, LQ_P_BIG1, LQ_P_FIN_S, LQ_P_FIN_B, LQ_P_TILES, LQ_P_CNT, LQ_P_OVERFLOW };   // offsets inside a set's counters
 struct PsLists { struct PSeg *big[2], *fin_s, *fin_b; u32 *cnt; u32 cap_big, cap_fin;
                  u32 fin_s_max, fin_b_max, child_target; };   // size limits of the two finishing kernels, aimed child size of a pass (tests shrink them)
@@ -345,7 +347,7 @@ k_ps_finish(const PSeg *segs, const u32 *n_p, PsData P, KeyMap km, unsigned long
 // a query with marked minimizers (qklib: its anchors were emitted into B, the originals) starts klib's passes at the top
 // byte; every other query is free of equal x.
 __global__ void k_sort_init(const u64 *aq_off, u64 a_base, u32 n_q, const u32 *qklib, mm128 *A, SortSeg *klib, u32 *cnt,
-                            PsLists L, KeyMap km)
+                            PsLists L, KeyMap km, WalkCaps caps)
 {
 	const u32 q = blockIdx.x * blockDim.x + threadIdx.x;
 	if (q >= n_q) return;
@@ -355,6 +357,7 @@ __global__ void k_sort_init(const u64 *aq_off, u64 a_base, u32 n_q, const u32 *q
 		const u32 s = atomicAdd(&cnt[LQ_C_KLIB0], 1u);
 		SortSeg sg; sg.off = off; sg.len = (u32)len; sg.shift = 56;
 		klib[s] = sg;
+		atomicAdd(&cnt[LQ_C_LEN0 + lq_walk_class((u32)len, caps)], 1u);
 	} else {
 		PSeg sg; sg.off = off; sg.len = (u32)len; sg.rem = (u8)(km.pbits + km.rbits + 1); sg.buf = 0; sg.nbits = 0; sg.pad = 0;
 		lq_ps_route(sg, L, LQ_P_BIG0);
@@ -379,7 +382,7 @@ __global__ void k_query_klib(const u64 *aq_off, const u32 *qdirty, u32 n_q, int 
 #define LQ_CHILD_THREADS 64
 __global__ void __launch_bounds__(LQ_CHILD_THREADS)
 k_rs_children(const SortSeg *segs, const u32 *n_segs_p, const RRec *Rn, u32 rb, const mm128 *O, mm128 *A, const u32 *hist, const u32 *mhist, const u32 *begs,
-              SortSeg *next, u32 *n_next, u32 const_levels, PsLists L, KeyMap km, int all_klib, u32 *n_tiles_zero)
+              SortSeg *next, u32 *n_next, u32 const_levels, PsLists L, KeyMap km, int all_klib, u32 *n_tiles_zero, u32 *len_cnt, WalkCaps caps)
 {
 	__shared__ u64 xs[64];
 	__shared__ u32 flag[64];
@@ -405,6 +408,7 @@ k_rs_children(const SortSeg *segs, const u32 *n_segs_p, const RRec *Rn, u32 rb, 
 				while (sh > 0 && (const_levels >> (sh >> 3) & 1)) sh -= 8;
 				SortSeg c; c.off = sg.off + bg; c.len = n; c.shift = sh;
 				next[s] = c;
+				atomicAdd(&len_cnt[lq_walk_class(n, caps)], 1u);       // (the host sizes the next level's walker launches by these, and skips the empty ones)
 			}
 		}
 		const RRec *rseg = Rn + sg.off;

@@ -95,12 +95,12 @@ struct SortTile { u32 sgi, tile; };
 	         j_ = (xcd) ? blockIdx.x / LQ_XCDS : blockIdx.x, ti = x_ * per_ + j_; j_ < per_; j_ += st_, ti = x_ * per_ + j_) if (ti < (n_tiles))
 
 __global__ void __launch_bounds__(256)
-k_sort_tiles(const SortSeg *segs, const u32 *n_segs_p, u32 tile, SortTile *tiles, u32 *n_tiles, u32 *hist, u32 *mhist, u32 *zero0, u32 *zero1, u32 n_zero1, u32 *zero2)
+k_sort_tiles(const SortSeg *segs, const u32 *n_segs_p, u32 tile, SortTile *tiles, u32 *n_tiles, u32 *hist, u32 *mhist, u32 *zero0, u32 *zero1, u32 n_zero1, u32 *zero2, u32 *zero3, u32 n_zero3)
 {
 	const u32 n_segs = *n_segs_p;
 	const u32 lane = threadIdx.x & 63;
 	// the level's other counters start from zero (kernels later in the stream count into them; none of this kernel's blocks reads them)
-	if (blockIdx.x == 0 && threadIdx.x == 0) { *zero0 = 0; for (u32 i = 0; i < n_zero1; ++i) zero1[i] = 0; *zero2 = 0; }
+	if (blockIdx.x == 0 && threadIdx.x == 0) { *zero0 = 0; for (u32 i = 0; i < n_zero1; ++i) zero1[i] = 0; *zero2 = 0; for (u32 i = 0; i < n_zero3; ++i) zero3[i] = 0; }
 	for (u32 base = blockIdx.x * blockDim.x; base < n_segs; base += gridDim.x * blockDim.x) {
 		const u32 sgi = base + threadIdx.x;
 		u32 nt = 0;
