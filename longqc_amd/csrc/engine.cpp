@@ -97,7 +97,7 @@ void Knobs::read_env()
 	sketch_machine_only = is("LQCOV_SKETCH", "machine");
 	ps_grid = (u32)std::max<long>(64, num("LQCOV_PS_GRID", 512));
 	tile_grid = (u32)std::max<long>(64, num("LQCOV_TILE_GRID", 4096));
-	ps_passes = (u32)std::min<long>(16, std::max<long>(0, num("LQCOV_PS_PASSES", LQ_PS_PASSES))) & ~1u;
+	ps_passes = (u32)std::min<long>(16, std::max<long>(0, num("LQCOV_PS_PASSES", 4))) & ~1u;
 }
 
 lqcov_handle::lqcov_handle(const lqcov_params &p, int dev) : P(p), device(dev)
@@ -780,7 +780,7 @@ static void ps_finish(lqcov_handle *h, MapLane &L, int set, hipStream_t s, u64 n
 	}
 }
 
-#define LQ_PS_PASSES 4           // partition passes issued without looking (an even number: the big list ends in slot 0); psort_tail does the rest
+// (K.ps_passes partition passes are issued without looking -- an even number: the big list ends in slot 0 --; psort_tail does the rest)
 
 // The parallel sort of the segments of one list set (kernels_psort.hpp): partition passes while segments above the
 // LDS capacity remain, then the two finishing kernels.  Everything is sized by upper bounds and strides over device-side
@@ -799,7 +799,7 @@ void lqcov_handle::psort_run(MapLane &L, int set, hipStream_t s, u64 nA, const K
 	ps_finish(this, L, set, s, nA, km, pd);
 }
 
-// Segments that are still above the LDS capacity after LQ_PS_PASSES passes (keys that agree in many leading bits take a
+// Segments that are still above the LDS capacity after the passes issued without looking (keys that agree in many leading bits take a
 // pass per few bits): more passes, two at a time, with a look at the counter in between.  Rare; any input ends here sorted.
 void lqcov_handle::psort_tail(MapLane &L, int set, hipStream_t s, u64 nA, const KeyMap &km, const PsData &pd)
 {
