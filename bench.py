@@ -318,11 +318,12 @@ def main():
             "metric": "Mbases/sec all-vs-all overlap coverage (sampleqc hot path)", "value": round(value, 3), "unit": "Mbases/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True, "scaling": "weak" if world == 1 else "strong", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-            "config": {"workload": (CONFIG_LABEL[args.config] % (cfg.n_reads, cfg.mean_len // 1000, cfg.depth)) + ", %d subsample queries" % len(Q),
+            "config": {"workload": (CONFIG_LABEL[args.config] % (cfg.n_reads, cfg.mean_len // 1000, cfg.depth)) + ", %d subsample queries" % len(Q)
+                                   + (" [-I overridden: %s]" % args.index_size if args.index_size else ""),
                        "index_parts": [int(F.off[hi] - F.off[lo]) for lo, hi in parts],
                        "target_bases": int(total_bases), "query_bases": int(Q.n_bases), "anchors_per_step": int(n_anchors),
                        "clock": "H2D of the packed reads (pinned) -> sketch -> index -> seed -> sort -> chain -> coverage -> rows D2H, all parts (SURVEY 8d), "
-                                "part i+1's upload + sketch + index under part i's mapping; "
+                                + ("part i+1's upload + sketch + index under part i's mapping; " if world == 1 and len(parts) > 1 else "") +
                                 "before the clock: the synthetic generator (= FASTQ parse) and the host-side 2-bit packing (host_pack_s) -- value_incl_host_pack adds the latter, unoverlapped",
                        "parallelism": "single GPU" if world == 1 else "%d GPUs: queries sharded 1/N, index replicated (each rank sketches 1/N of a part, "
                                       "minimizers all-gathered over RCCL, identical index everywhere), rows gathered on rank 0" % world},
