@@ -284,6 +284,7 @@ k_ps_finish(const PSeg *segs, const u32 *n_p, PsData P, KeyMap km, unsigned long
 	__shared__ KEY keys[CAP];                                  // the key bits below the sub-bucket digit
 	__shared__ u16 perm[CAP];
 	__shared__ u32 hist[NSB], beg[NSB], fill[NSB], wsum[THREADS / 64 + 1];
+	__shared__ u64 rmin[THREADS / 64], rmax[THREADS / 64];
 	const u32 n_seg = *n_p, t = threadIdx.x;
 	for (u32 s = blockIdx.x; s < n_seg; s += gridDim.x) {
 		const PSeg sg = segs[s];
@@ -294,15 +295,30 @@ k_ps_finish(const PSeg *segs, const u32 *n_p, PsData P, KeyMap km, unsigned long
 			if (sg.buf) for (u32 i = t; i < n; i += THREADS) out[i] = lq_ps_load(sg, P, i);
 			continue;
 		}
-		const u32 nb = sg.rem < SB ? sg.rem : SB, sh = sg.rem - nb;
-		const u64 km_mask = sg.rem >= 64 ? ~0ULL : ((1ULL << sg.rem) - 1), lo_mask = ((u64)1 << sh) - 1;
+		const u64 km_mask = sg.rem >= 64 ? ~0ULL : ((1ULL << sg.rem) - 1);
 		for (u32 c = t; c < NSB; c += THREADS) { hist[c] = 0; fill[c] = 0; }
-		__syncthreads();
 		mm128 e[PER];
+		u64 kf[PER];
 		u32 dg[PER];
+		u64 kmin = ~0ULL, kmax = 0;
 		for (int k = 0; k < PER; ++k) {
 			const u32 i = t + (u32)k * THREADS;
-			if (i < n) { e[k] = lq_ps_load(sg, P, i); const u64 key = lq_ckey(e[k].x, km) & km_mask; keys[i] = (KEY)(key & lo_mask); dg[k] = (u32)(key >> sh); atomicAdd(&hist[dg[k]], 1u); }
+			kf[k] = 0;
+			if (i < n) { e[k] = lq_ps_load(sg, P, i); kf[k] = lq_ckey(e[k].x, km) & km_mask; kmin = kf[k] < kmin ? kf[k] : kmin; kmax = kf[k] > kmax ? kf[k] : kmax; }
+		}
+		// The sub-bucket digit is taken from the range the segment's keys really span, not from the top of the bits they might
+		// differ in: a child of a partition pass holds a few dozen targets and a stretch of positions, and the top SB bits of its
+		// `rem` say little -- a few crowded sub-buckets, and the rank loop below is quadratic in a sub-bucket's size.
+		for (int o = 32; o > 0; o >>= 1) { const u64 a = __shfl_xor(kmin, o), b = __shfl_xor(kmax, o); kmin = a < kmin ? a : kmin; kmax = b > kmax ? b : kmax; }
+		if ((t & 63) == 0) { rmin[t >> 6] = kmin; rmax[t >> 6] = kmax; }
+		__syncthreads();
+		for (u32 w = 0; w < THREADS / 64; ++w) { kmin = rmin[w] < kmin ? rmin[w] : kmin; kmax = rmax[w] > kmax ? rmax[w] : kmax; }
+		const u64 range = kmax - kmin;
+		const u32 bits = range ? 64 - (u32)__builtin_clzll(range) : 0, sh = bits > (u32)SB ? bits - (u32)SB : 0;
+		const u64 lo_mask = ((u64)1 << sh) - 1;
+		for (int k = 0; k < PER; ++k) {
+			const u32 i = t + (u32)k * THREADS;
+			if (i < n) { const u64 key = kf[k] - kmin; keys[i] = (KEY)(key & lo_mask); dg[k] = (u32)(key >> sh); atomicAdd(&hist[dg[k]], 1u); }
 		}
 		__syncthreads();
 		{	// exclusive scan of hist -> beg: SPT counters per thread, wave scan, wave totals through LDS
