@@ -285,7 +285,6 @@ k_ps_finish(const PSeg *segs, const u32 *n_p, PsData P, KeyMap km, unsigned long
 	__shared__ u16 perm[CAP];
 	__shared__ u32 hist[NSB], beg[NSB], fill[NSB], wsum[THREADS / 64 + 1];
 	__shared__ u64 rmin[THREADS / 64], rmax[THREADS / 64];
-	__shared__ mm128 stage[THREADS];
 	const u32 n_seg = *n_p, t = threadIdx.x;
 	for (u32 s = blockIdx.x; s < n_seg; s += gridDim.x) {
 		const PSeg sg = segs[s];
@@ -351,20 +350,11 @@ k_ps_finish(const PSeg *segs, const u32 *n_p, PsData P, KeyMap km, unsigned long
 				pos[k] = b0 + r;
 			}
 		}
-		// The move, a stretch of THREADS output slots at a time through LDS: 16-byte stores to 64 random places of a 128-KiB segment
-		// per wave left half-written lines behind (rocprofv3: 2.1x the algorithmic bytes as HBM traffic); from the stage the
-		// stores are contiguous.  (All loads are done: the segment may be sorted in place.)
-		for (int c = 0; c < PER; ++c) {
-			if ((u32)c * THREADS >= n) break;                        // (uniform)
-			for (int k = 0; k < PER; ++k) {
-				const u32 i = t + (u32)k * THREADS;
-				if (i < n && pos[k] / THREADS == (u32)c) stage[pos[k] - (u32)c * THREADS] = e[k];
-			}
-			__syncthreads();
-			const u32 p = (u32)c * THREADS + t;
-			if (p < n) out[p] = stage[t];
-			__syncthreads();
+		for (int k = 0; k < PER; ++k) {
+			const u32 i = t + (u32)k * THREADS;
+			if (i < n) out[pos[k]] = e[k];
 		}
+		__syncthreads();
 	}
 }
 
