@@ -1,9 +1,9 @@
 #!/bin/bash
 # A/B of engine knobs on the bench workload in ONE gpurun call: the reads are generated once (bench.py --cache), every
 # variant is one bench run under its own time limit; one line per variant in gpurun_out/ab.log.
-#   VARIANTS="base|LQCOV_RUNS=scan|LQCOV_CKPT3=1|LQCOV_LANES=3 LQCOV_CKPT3=1"  CFG=cfg3  STEPS=3  bash tools/gpu_ab.sh
+#   VARIANTS="base|LQCOV_LANES=1|LQCOV_CKPT3=1|LQCOV_LANES=3 LQCOV_CKPT3=1"  CFG=cfg3  STEPS=3  bash tools/gpu_ab.sh
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out; : > gpurun_out/ab.log
-# PYTEST_K='run_list or randomised' PYTEST_ENV='LQCOV_TWO_TILES=1': a parity subset first (knobs that were never on a GPU)
+# PYTEST_K="randomised or switch": a parity subset first
 if [ -n "$PYTEST_K" ]; then env $PYTEST_ENV timeout ${PYTEST_LIMIT:-120} python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "$PYTEST_K" 2>&1 | tail -3 >> gpurun_out/ab.log; fi
 IFS='|' read -ra VS <<< "${VARIANTS:-base|LQCOV_LANES=1|LQCOV_LANES=2}"
 N=0
