@@ -512,16 +512,25 @@ void lqcov_handle::build_index(Part &pt)
 	if (M) {
 		DBuf &key = ix_key, &key2 = ix_key2, &head = ix_head, &uidx = ix_uidx, &ukey = ix_ukey, &ustart = ix_ustart, &ucnt = ix_ucnt;   // workspaces live with the handle: repeated builds do not re-allocate
 		key.ensure(M * 8); key2.ensure(M * 8); head.ensure(M * 4); uidx.ensure(M * 8);
-		LQ_LAUNCH(k_sort_keys, nblk(M, 256), 256, stream, rs.mx.as<u64>(), M, key.as<u64>()); check_launch();
-		{ StageTimer t(this, stream, "index_radix_sort", M * 32); prim.sort_pairs_u64(key.as<u64>(), key2.as<u64>(), rs.my.as<u64>(), pt.pos.as<u64>(), M, (unsigned)(2 * P.k)); }
-		LQ_LAUNCH(k_mark_heads, nblk(M, 256), 256, stream, key2.as<u64>(), M, head.as<u32>()); check_launch();
+		const bool k32 = 2 * P.k <= 32;                         // the hash fits 32 bits: 4-byte sort keys
+		if (k32) {
+			LQ_LAUNCH(k_sort_keys<u32>, nblk(M, 256), 256, stream, rs.mx.as<u64>(), M, key.as<u32>()); check_launch();
+			{ StageTimer t(this, stream, "index_radix_sort", M * 24); prim.sort_pairs_u32_u64(key.as<u32>(), key2.as<u32>(), rs.my.as<u64>(), pt.pos.as<u64>(), M, (unsigned)(2 * P.k)); }
+			LQ_LAUNCH(k_mark_heads<u32>, nblk(M, 256), 256, stream, key2.as<u32>(), M, head.as<u32>()); check_launch();
+		} else {
+			LQ_LAUNCH(k_sort_keys<u64>, nblk(M, 256), 256, stream, rs.mx.as<u64>(), M, key.as<u64>()); check_launch();
+			{ StageTimer t(this, stream, "index_radix_sort", M * 32); prim.sort_pairs_u64(key.as<u64>(), key2.as<u64>(), rs.my.as<u64>(), pt.pos.as<u64>(), M, (unsigned)(2 * P.k)); }
+			LQ_LAUNCH(k_mark_heads<u64>, nblk(M, 256), 256, stream, key2.as<u64>(), M, head.as<u32>()); check_launch();
+		}
 		prim.exclusive_scan_u32_u64(head.as<u32>(), uidx.as<u64>(), M);
 		u64 lu = 0; u32 lh = 0;
 		d2h(&lu, uidx.as<u64>() + M - 1, 1, stream); d2h(&lh, head.as<u32>() + M - 1, 1, stream);
 		const u64 K = lu + lh;
 		pt.n_keys = K;
 		ukey.ensure(K * 8); ustart.ensure(K * 8); ucnt.ensure(K * 4);
-		LQ_LAUNCH(k_fill_unique, nblk(M, 256), 256, stream, key2.as<u64>(), head.as<u32>(), uidx.as<u64>(), M, ukey.as<u64>(), ustart.as<u64>()); check_launch();
+		if (k32) LQ_LAUNCH(k_fill_unique<u32>, nblk(M, 256), 256, stream, key2.as<u32>(), head.as<u32>(), uidx.as<u64>(), M, ukey.as<u64>(), ustart.as<u64>());
+		else LQ_LAUNCH(k_fill_unique<u64>, nblk(M, 256), 256, stream, key2.as<u64>(), head.as<u32>(), uidx.as<u64>(), M, ukey.as<u64>(), ustart.as<u64>());
+		check_launch();
 		LQ_LAUNCH(k_unique_counts, nblk(K, 256), 256, stream, ustart.as<u64>(), K, M, ucnt.as<u32>()); check_launch();
 		u32 bits = 4;
 		while (((u64)1 << bits) < 2 * K) ++bits;

@@ -21,10 +21,13 @@ __device__ __forceinline__ u64 lq_slot_of(u64 key, u32 cap_bits)
 	return (key * 0x9E3779B97F4A7C15ULL) >> (64 - cap_bits);
 }
 
-__global__ void k_sort_keys(const u64 *x, u64 n, u64 *key)
+// the sort key of a minimizer: its hash (x >> 8).  KT = u32 when the hash has at most 32 bits (k <= 16): the index sort then
+// moves 12 instead of 16 bytes per minimizer and pass
+template <class KT>
+__global__ void k_sort_keys(const u64 *x, u64 n, KT *key)
 {
 	u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-	if (i < n) key[i] = x[i] >> 8;
+	if (i < n) key[i] = (KT)(x[i] >> 8);
 }
 
 // y of a rank's share of a part, rid made part-global (multi-GPU: ranks sketch contiguous read ranges)
@@ -34,18 +37,20 @@ __global__ void k_rebase_y(const u64 *y, u64 n, u64 add, u64 *out)
 	if (i < n) out[i] = y[i] + add;
 }
 
-__global__ void k_mark_heads(const u64 *key, u64 n, u32 *head)
+template <class KT>
+__global__ void k_mark_heads(const KT *key, u64 n, u32 *head)
 {
 	u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
 	if (i < n) head[i] = (i == 0 || key[i] != key[i - 1]) ? 1u : 0u;
 }
 
 // uidx = exclusive scan of head; every head writes its key and start
-__global__ void k_fill_unique(const u64 *key, const u32 *head, const u64 *uidx, u64 n, u64 *ukey, u64 *ustart)
+template <class KT>
+__global__ void k_fill_unique(const KT *key, const u32 *head, const u64 *uidx, u64 n, u64 *ukey, u64 *ustart)
 {
 	u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n) return;
-	if (head[i]) { ukey[uidx[i]] = key[i]; ustart[uidx[i]] = i; }
+	if (head[i]) { ukey[uidx[i]] = (u64)key[i]; ustart[uidx[i]] = i; }
 }
 
 __global__ void k_unique_counts(const u64 *ustart, u64 n_keys, u64 n_mini, u32 *ucnt)

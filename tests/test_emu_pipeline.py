@@ -484,13 +484,14 @@ def test_emulated_long_pair_among_many_targets(emu_lib, tmp_path):
 
 
 def test_emulated_parallel_sort_size_classes(emu_lib, datasets, monkeypatch):
-    """the parallel sort with its size classes shrunk 128-fold on cfg1: more partition passes than are issued without looking
+    """the parallel sort with its size classes shrunk 128-fold: more partition passes than are issued without looking
     (the tail with its look at the counter), segments whose keys agree in the bits of a pass (stepped over, unless still named
     by records: those must have left the originals before any pass writes to B)"""
-    tf, qf = datasets("cfg1")
+    tf, qf = datasets("small")
     argv = ONT + [tf, qf]
     want = oracle_bind.table(argv)
-    monkeypatch.setenv("LQCOV_PS_SHIFT", "7")
-    rc, out, err = run_main(emu_lib, argv)
-    assert rc == 0, err
-    assert out == want
+    for passes in ("4", "0"):
+        monkeypatch.setenv("LQCOV_PS_SHIFT", "7"); monkeypatch.setenv("LQCOV_PS_PASSES", passes)
+        rc, out, err = run_main(emu_lib, argv)
+        assert rc == 0, err
+        assert out == want, passes
