@@ -97,7 +97,7 @@ void Knobs::read_env()
 	sketch_machine_only = is("LQCOV_SKETCH", "machine");
 	ps_grid = (u32)std::max<long>(64, num("LQCOV_PS_GRID", 512));
 	tile_grid = (u32)std::max<long>(64, num("LQCOV_TILE_GRID", 4096));
-	ps_passes = (u32)std::min<long>(16, std::max<long>(0, num("LQCOV_PS_PASSES", 4))) & ~1u;
+	ps_passes = (u32)std::min<long>(16, std::max<long>(0, num("LQCOV_PS_PASSES", 2))) & ~1u;
 }
 
 lqcov_handle::lqcov_handle(const lqcov_params &p, int dev) : P(p), device(dev)
