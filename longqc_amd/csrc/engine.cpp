@@ -632,24 +632,22 @@ void lqcov_handle::map_batch(MapLane &L, Part &pt, u32 q0, u32 q1, const std::ve
 	if (nA) {
 		const u64 *aqb = aq_off.as<u64>() + q0;          // batch view of the per-query anchor offsets
 		sort_batch(L, pt, q0, nqb, a_base, nA);           // lqmap.c:238
-		// ---- (strand, rid) runs ----
+		// ---- (strand, rid) runs long enough to hold a chain ----
 		u64 n_groups = 0;
 		{
 			const u32 n_tiles = (u32)((nA + LQ_RUN_TILE - 1) / LQ_RUN_TILE);
-			L.run_tiles.ensure(((u64)n_tiles + 2) * 4);
-			u32 *tiles = L.run_tiles.as<u32>();
-			const u32 g = std::min<u32>(n_tiles, 1u << 16);
+			const i32 span_max = P.hpc ? 255 : P.k;          // a minimizer's span: k, or up to 255 homopolymer-compressed (sketch.c:99-101)
+			const u32 n_min = (u32)std::max<i32>(std::max<i32>(P.min_cnt, 1), (mp.min_sc + span_max - 1) / span_max);
+			L.run_tiles.ensure(16);
+			L.gstart.ensure((nA / n_min + 1) * 8);
+			dzero(L.run_tiles.p, 4, L.stream);
 			{
-				StageTimer t(this, L.stream, "k_run_count", nA * 16);
-				LQ_LAUNCH(k_run_count, g, LQ_RUN_THREADS, L.stream, dA, nA, aqb, a_base, nqb, n_tiles, tiles); check_launch();
+				StageTimer t(this, L.stream, "k_run_list", nA * 16);
+				LQ_LAUNCH(k_run_list, std::min<u32>(n_tiles, 1u << 16), LQ_RUN_THREADS, L.stream, dA, nA, aqb, a_base, nqb, n_tiles, n_min, L.run_tiles.as<u32>(), L.gstart.as<u64>()); check_launch();
 			}
-			LQ_LAUNCH(k_tile_scan, 1, LQ_TSCAN_THREADS, L.stream, tiles, n_tiles); check_launch();
 			u32 ng = 0;
-			d2h(&ng, tiles + n_tiles, 1, L.stream);
+			d2h(&ng, L.run_tiles.as<u32>(), 1, L.stream);
 			n_groups = ng;
-			L.gstart.ensure((n_groups + 1) * 8);
-			StageTimer t(this, L.stream, "k_run_starts", nA * 16 + n_groups * 8);
-			LQ_LAUNCH(k_run_starts, g, LQ_RUN_THREADS, L.stream, dA, nA, aqb, a_base, nqb, n_tiles, tiles, L.gstart.as<u64>()); check_launch();
 		}
 		// ---- chain + coverage ----
 		const u32 ivl_cap = (u32)std::min<u64>(nA / (P.min_cnt > 0 ? P.min_cnt : 1) + 16, 0xfffffff0ULL);

@@ -16,11 +16,16 @@
 #include "kernels_sketch.hpp"
 #include "kernels_sort.hpp"   // LQ_BLOCK_LOOP / LQ_BLOCK_SYNC / LQ_SHARED
 
-// ---- the list of (strand, rid) run starts in two light passes (count per tile, tiny scan, write) ----------------------------------
+// ---- the list of the (strand, rid) runs that can hold a chain, in one pass over the sorted anchors ------------------------------
 // A run starts at the first anchor of the batch, at the first anchor of every query and wherever the high word of x (strand,
-// rid) changes.  Both passes read only the anchors (no head / id arrays of 4 + 8 bytes per anchor, no library scan over them),
-// have no dependency between blocks and no global atomics: pass 1 counts the starts of every 4096-anchor tile, one block scans
-// the tile counts, pass 2 finds the same starts again and writes them at tile offset + rank in the tile.
+// rid) changes.  Against half a million targets most runs are one or two chance hits; a chain needs min_cnt anchors
+// (chain.c:119-121) and scores at most the sum of its anchors' spans (chain.c:57-67), each at most k (255 with -H), so a run
+// of fewer than n_min = max(min_cnt, ceil(min_sc / span_max)) anchors is never looked at again.  One block per 4096-anchor
+// tile: heads by ballots, the heads as a bitmap in LDS, a head's length = distance to the next head (the last run of a tile,
+// when it goes on past the tile: to the end of its query or to the first different high word, found by bisection -- the
+// query's anchors are sorted), one atomic per tile for the tile's place in the list, entries start | length << 32.  The list
+// is not in array order across tiles; nothing downstream depends on the order (sums, counters, a pool of intervals that is
+// sorted before use).
 #define LQ_RUN_TILE 4096
 #define LQ_RUN_THREADS 256
 #define LQ_RUN_ROWS (LQ_RUN_TILE / LQ_RUN_THREADS)
@@ -55,25 +60,6 @@ __device__ __forceinline__ void lq_run_heads(const mm128 *A, u64 n, const u64 *a
 	}
 }
 
-__global__ void __launch_bounds__(LQ_RUN_THREADS)
-k_run_count(const mm128 *A, u64 n, const u64 *aq_off, u64 a_base, u32 n_q, u32 n_tiles, u32 *tile_cnt)
-{
-	__shared__ u32 qbits[LQ_RUN_TILE / 32];
-	__shared__ u32 tot;
-	for (u32 T = blockIdx.x; T < n_tiles; T += gridDim.x) {
-		if (threadIdx.x == 0) tot = 0;
-		u64 bal[LQ_RUN_ROWS];
-		lq_run_heads(A, n, aq_off, a_base, n_q, (u64)T * LQ_RUN_TILE, qbits, bal);   // (its barriers order the reset of tot)
-		u32 c = 0;
-#pragma unroll
-		for (int j = 0; j < LQ_RUN_ROWS; ++j) c += (u32)__popcll(bal[j]);
-		if ((threadIdx.x & 63) == 0) atomicAdd(&tot, c);
-		__syncthreads();
-		if (threadIdx.x == 0) tile_cnt[T] = tot;
-		__syncthreads();
-	}
-}
-
 // exclusive scan of n counts in place, the total in cnt[n]; one block
 #define LQ_TSCAN_THREADS 1024
 __global__ void __launch_bounds__(LQ_TSCAN_THREADS)
@@ -95,33 +81,72 @@ k_tile_scan(u32 *cnt, u32 n)
 	for (u32 x = a; x < b; ++x) { const u32 v = cnt[x]; cnt[x] = run; run += v; }
 }
 
+#define LQ_RUN_START(e) ((u64)(u32)(e))
+#define LQ_RUN_LEN(e) ((i64)((e) >> 32))
 __global__ void __launch_bounds__(LQ_RUN_THREADS)
-k_run_starts(const mm128 *A, u64 n, const u64 *aq_off, u64 a_base, u32 n_q, u32 n_tiles, const u32 *tile_off, u64 *gstart)
+k_run_list(const mm128 *A, u64 n, const u64 *aq_off, u64 a_base, u32 n_q, u32 n_tiles, u32 n_min, u32 *n_runs, u64 *runs)
 {
 	__shared__ u32 qbits[LQ_RUN_TILE / 32];
+	__shared__ u32 hb[LQ_RUN_TILE / 32];
 	__shared__ u32 pre[LQ_RUN_ROWS * LQ_RUN_WAVES];
+	__shared__ u32 slot0;
 	const u32 t = threadIdx.x, lane = t & 63, w = t >> 6;
-	if (blockIdx.x == 0 && t == 0) gstart[tile_off[n_tiles]] = n;
 	for (u32 T = blockIdx.x; T < n_tiles; T += gridDim.x) {
 		const u64 base = (u64)T * LQ_RUN_TILE;
+		const u32 tl = n - base < LQ_RUN_TILE ? (u32)(n - base) : LQ_RUN_TILE;
 		u64 bal[LQ_RUN_ROWS];
 		lq_run_heads(A, n, aq_off, a_base, n_q, base, qbits, bal);
+		if (lane == 0) {
+#pragma unroll
+			for (int j = 0; j < LQ_RUN_ROWS; ++j) { const u32 o = ((u32)j * LQ_RUN_THREADS + w * 64) >> 5; hb[o] = (u32)bal[j]; hb[o + 1] = (u32)(bal[j] >> 32); }
+		}
+		__syncthreads();
+		u32 len[LQ_RUN_ROWS];
+#pragma unroll
+		for (int j = 0; j < LQ_RUN_ROWS; ++j) {
+			len[j] = 0;
+			if (bal[j] >> lane & 1) {
+				const u32 o = (u32)j * LQ_RUN_THREADS + t;
+				u32 nxt = LQ_RUN_TILE;                            // the next head of the tile
+				if (o + 1 < LQ_RUN_TILE) {
+					u32 wi = (o + 1) >> 5, m = hb[wi] & (~0u << ((o + 1) & 31));
+					for (;;) {
+						if (m) { nxt = wi * 32 + (u32)__builtin_ctz(m); break; }
+						if (++wi == LQ_RUN_TILE / 32) break;
+						m = hb[wi];
+					}
+				}
+				if (nxt < tl) len[j] = nxt - o;
+				else if (base + tl >= n) len[j] = tl - o;
+				else {                                           // goes on past the tile
+					const u32 q = lq_find_seg(aq_off, n_q, base + o + a_base);
+					const u64 qend = aq_off[q + 1] - a_base;
+					const u32 h = (u32)(A[base + o].x >> 32);
+					u64 lo = base + tl, hi = qend;               // first index in [lo, hi) whose high word differs, or hi
+					while (lo < hi) { const u64 mid = lo + ((hi - lo) >> 1); if ((u32)(A[mid].x >> 32) == h) lo = mid + 1; else hi = mid; }
+					len[j] = (u32)(lo - (base + o));
+				}
+			}
+			bal[j] = __ballot(len[j] >= n_min && len[j] != 0);
+		}
 		if (lane == 0) {
 #pragma unroll
 			for (int j = 0; j < LQ_RUN_ROWS; ++j) pre[j * LQ_RUN_WAVES + w] = (u32)__popcll(bal[j]);
 		}
 		__syncthreads();
-		if (t < 64) {                                             // exclusive scan of the 64 (row, wave) counts: index order
+		if (t < 64) {                                             // exclusive scan of the 64 (row, wave) counts
 			const u32 v = pre[t];
 			u32 inc = v;
 			for (int d = 1; d < 64; d <<= 1) { const u32 o = __shfl_up(inc, d); if ((int)lane >= d) inc += o; }
 			pre[t] = inc - v;
+			if (t == 63) slot0 = inc ? atomicAdd(n_runs, inc) : 0u;
 		}
 		__syncthreads();
-		const u32 off = tile_off[T];
+		const u32 off = slot0;
 #pragma unroll
 		for (int j = 0; j < LQ_RUN_ROWS; ++j)
-			if (bal[j] >> lane & 1) gstart[off + pre[j * LQ_RUN_WAVES + w] + (u32)__popcll(bal[j] & ((1ULL << lane) - 1))] = base + (u32)j * LQ_RUN_THREADS + t;
+			if (bal[j] >> lane & 1)
+				runs[off + pre[j * LQ_RUN_WAVES + w] + (u32)__popcll(bal[j] & ((1ULL << lane) - 1))] = (base + (u32)j * LQ_RUN_THREADS + t) | (u64)len[j] << 32;
 		__syncthreads();
 	}
 }
@@ -225,7 +250,7 @@ k_sel_count(const u64 *gstart, u64 n_groups, i32 min_cnt, i32 max_cnt, u32 n_til
 		for (int j = 0; j < LQ_RUN_ROWS; ++j) {
 			const u64 g = (u64)T * LQ_RUN_TILE + (u32)j * LQ_RUN_THREADS + threadIdx.x;
 			i64 l = 0;
-			if (g < n_groups) l = (i64)(gstart[g + 1] - gstart[g]);
+			if (g < n_groups) l = LQ_RUN_LEN(gstart[g]);
 			c += (u32)__popcll(__ballot(g < n_groups && l >= (i64)min_cnt && l <= (i64)max_cnt));
 		}
 		if ((threadIdx.x & 63) == 0) atomicAdd(&tot, c);
@@ -246,7 +271,7 @@ k_sel_write(const u64 *gstart, u64 n_groups, i32 min_cnt, i32 max_cnt, u32 n_til
 #pragma unroll
 		for (int j = 0; j < LQ_RUN_ROWS; ++j) {
 			const u64 g = (u64)T * LQ_RUN_TILE + (u32)j * LQ_RUN_THREADS + t;
-			const u64 l = g < n_groups ? gstart[g + 1] - gstart[g] : 0;
+			const u64 l = g < n_groups ? (u64)LQ_RUN_LEN(gstart[g]) : 0;
 			len[j] = (u32)l;
 			bal[j] = __ballot(g < n_groups && (i64)l >= (i64)min_cnt && (i64)l <= (i64)max_cnt);
 		}
@@ -466,8 +491,8 @@ k_chain(const mm128 *A, const u64 *gstart, const u32 *glist, u32 n_list, const u
 		const u32 gi = gi0 + ln;
 		if (gi < n_list) {
 			const u32 g = glist ? glist[gi] : gi;
-			const u64 gs = gstart[g];
-			const i64 n = (i64)(gstart[g + 1] - gs);
+			const u64 gs = LQ_RUN_START(gstart[g]);
+			const i64 n = LQ_RUN_LEN(gstart[g]);
 			if (n >= min_len && n <= max_len && n <= LQ_CHAIN_LDS_CAP && lq_run_viable(A + gs, n, P)) {
 				const u32 q = q0 + lq_find_seg(aq_off, n_q, gs + a_base);
 				if (!C.skip[q] || C.dbg) { todo = (u32)n; s_q[ln] = q; }
@@ -488,7 +513,7 @@ k_chain(const mm128 *A, const u64 *gstart, const u32 *glist, u32 n_list, const u
 				if (off + n32 <= LQ_CHAIN_LDS_CAP) {             // the first waiting run always fits
 					const u32 gi = gi0 + ln;
 					const u32 g = glist ? glist[gi] : gi;
-					const u64 gs = gstart[g];
+					const u64 gs = LQ_RUN_START(gstart[g]);
 					const i64 n = (i64)n32;
 					const u32 q = s_q[ln];
 					mm128 *la = s_a + off;
@@ -524,8 +549,8 @@ k_chain_wave(const mm128 *A, const u64 *gstart, const u32 *glist, u32 n_list, co
 	LQ_SHARED i32 st_sh[4];                                  // [0] max_f, [1] max_j, [2] n_skip, [3] done
 	if (blockIdx.x >= n_list) return;
 	const u32 g = glist[blockIdx.x];
-	const u64 gs = gstart[g];
-	const i64 n = (i64)(gstart[g + 1] - gs);
+	const u64 gs = LQ_RUN_START(gstart[g]);
+	const i64 n = LQ_RUN_LEN(gstart[g]);
 	const mm128 *a = A + gs;
 	if (!lq_run_viable(a, n, P)) return;
 	const u32 q = q0 + lq_find_seg(aq_off, n_q, gs + a_base);
