@@ -91,6 +91,7 @@ void Knobs::read_env()
 	walk_grid = (u32)std::max<long>(64, num("LQCOV_WALK_GRID", 1L << 18));
 	chain_wave_min = (int)std::max<long>(0, num("LQCOV_CHAIN_WAVE_MIN", 0));
 	chain_cap = (int)num("LQCOV_CHAIN_CAP", 128);
+	run_stage = (u32)std::max<long>(1, num("LQCOV_RUN_STAGE", 3072));
 	no_level_skip = getenv("LQCOV_NO_LEVEL_SKIP") != nullptr;
 	debug_sort = getenv("LQCOV_DEBUG_SORT") != nullptr;
 	sketch_kpt = (u32)std::min<long>(64, std::max<long>(1, num("LQCOV_SKETCH_KPT", 4)));
@@ -643,7 +644,7 @@ void lqcov_handle::map_batch(MapLane &L, Part &pt, u32 q0, u32 q1, const std::ve
 			dzero(L.run_tiles.p, 4, L.stream);
 			{
 				StageTimer t(this, L.stream, "k_run_list", nA * 16);
-				LQ_LAUNCH(k_run_list, std::min<u32>(n_tiles, 1u << 16), LQ_RUN_THREADS, L.stream, dA, nA, aqb, a_base, nqb, n_tiles, n_min, L.run_tiles.as<u32>(), L.gstart.as<u64>()); check_launch();
+				LQ_LAUNCH(k_run_list, std::min<u32>(n_tiles, 2048), LQ_RUN_THREADS, L.stream, dA, nA, aqb, a_base, nqb, n_tiles, n_min, std::min<u32>(K.run_stage, LQ_RUN_STAGE), L.run_tiles.as<u32>(), L.gstart.as<u64>()); check_launch();
 			}
 			u32 ng = 0;
 			d2h(&ng, L.run_tiles.as<u32>(), 1, L.stream);

@@ -83,70 +83,101 @@ k_tile_scan(u32 *cnt, u32 n)
 
 #define LQ_RUN_START(e) ((u64)(u32)(e))
 #define LQ_RUN_LEN(e) ((i64)((e) >> 32))
+#define LQ_RUN_STAGE 3072         // entries a block collects in LDS before it reserves their place in the list
+// A block takes a contiguous stretch of tiles and collects the entries in LDS: one atomic on the list's counter per ~3000
+// entries (a dozen tiles at configs[2]).  One atomic per tile was measured at 4 ms per launch of 77 000 tiles on MI355X -- the
+// same-address atomics of the whole device queue up at ~40 ns each -- against 0.9 ms for reading the anchors.
 __global__ void __launch_bounds__(LQ_RUN_THREADS)
-k_run_list(const mm128 *A, u64 n, const u64 *aq_off, u64 a_base, u32 n_q, u32 n_tiles, u32 n_min, u32 *n_runs, u64 *runs)
+k_run_list(const mm128 *A, u64 n, const u64 *aq_off, u64 a_base, u32 n_q, u32 n_tiles, u32 n_min, u32 stage /* <= LQ_RUN_STAGE (tests shrink it) */, u32 *n_runs, u64 *runs)
 {
 	__shared__ u32 qbits[LQ_RUN_TILE / 32];
-	__shared__ u32 hb[LQ_RUN_TILE / 32];
+	__shared__ u32 hb[LQ_RUN_TILE / 32 + 2];
 	__shared__ u32 pre[LQ_RUN_ROWS * LQ_RUN_WAVES];
-	__shared__ u32 slot0;
+	__shared__ u32 slot0, tot;
+	__shared__ u64 stg[LQ_RUN_STAGE];
 	const u32 t = threadIdx.x, lane = t & 63, w = t >> 6;
-	for (u32 T = blockIdx.x; T < n_tiles; T += gridDim.x) {
-		const u64 base = (u64)T * LQ_RUN_TILE;
-		const u32 tl = n - base < LQ_RUN_TILE ? (u32)(n - base) : LQ_RUN_TILE;
+	const u32 per = (n_tiles + gridDim.x - 1) / gridDim.x;
+	const u32 T0 = blockIdx.x * per < n_tiles ? blockIdx.x * per : n_tiles, T1 = T0 + per < n_tiles ? T0 + per : n_tiles;
+	const u64 near_mask = n_min > 1 ? (n_min > 33 ? ~0ULL >> 31 : (1ULL << (n_min - 1)) - 1) : 0;   // the next n_min - 1 positions (up to 33 of them)
+	u32 fill = 0;                                                 // (block-uniform) entries waiting in stg
+	if (t < 2) hb[LQ_RUN_TILE / 32 + t] = 0;
+	for (u32 T = T0; T <= T1; ++T) {
 		u64 bal[LQ_RUN_ROWS];
-		lq_run_heads(A, n, aq_off, a_base, n_q, base, qbits, bal);
-		if (lane == 0) {
-#pragma unroll
-			for (int j = 0; j < LQ_RUN_ROWS; ++j) { const u32 o = ((u32)j * LQ_RUN_THREADS + w * 64) >> 5; hb[o] = (u32)bal[j]; hb[o + 1] = (u32)(bal[j] >> 32); }
-		}
-		__syncthreads();
 		u32 len[LQ_RUN_ROWS];
+		u32 c = 0;
+		const u64 base = (u64)T * LQ_RUN_TILE;
+		if (T < T1) {
+			const u32 tl = n - base < LQ_RUN_TILE ? (u32)(n - base) : LQ_RUN_TILE;
+			lq_run_heads(A, n, aq_off, a_base, n_q, base, qbits, bal);
+			if (lane == 0) {
 #pragma unroll
-		for (int j = 0; j < LQ_RUN_ROWS; ++j) {
-			len[j] = 0;
-			if (bal[j] >> lane & 1) {
-				const u32 o = (u32)j * LQ_RUN_THREADS + t;
-				u32 nxt = LQ_RUN_TILE;                            // the next head of the tile
-				if (o + 1 < LQ_RUN_TILE) {
-					u32 wi = (o + 1) >> 5, m = hb[wi] & (~0u << ((o + 1) & 31));
-					for (;;) {
-						if (m) { nxt = wi * 32 + (u32)__builtin_ctz(m); break; }
-						if (++wi == LQ_RUN_TILE / 32) break;
-						m = hb[wi];
+				for (int j = 0; j < LQ_RUN_ROWS; ++j) { const u32 o = ((u32)j * LQ_RUN_THREADS + w * 64) >> 5; hb[o] = (u32)bal[j]; hb[o + 1] = (u32)(bal[j] >> 32); }
+			}
+			__syncthreads();
+#pragma unroll
+			for (int j = 0; j < LQ_RUN_ROWS; ++j) {
+				len[j] = 0;
+				if (bal[j] >> lane & 1) {
+					const u32 o = (u32)j * LQ_RUN_THREADS + t;
+					const u32 w0 = (o + 1) >> 5, sh = (o + 1) & 31;
+					const u64 win = (((u64)hb[w0 + 1] << 32 | hb[w0]) >> sh) | (sh ? (u64)hb[w0 + 2] << (64 - sh) : 0);   // heads at o + 1, o + 2, ...
+					if ((win & near_mask) == 0) {                    // no head among the next n_min - 1 anchors of the tile: find the end
+						u32 nxt = LQ_RUN_TILE;                       // the next head of the tile
+						if (win) nxt = o + 1 + (u32)__builtin_ctzll(win);
+						else {
+							for (u32 wi = w0 + 2; wi < LQ_RUN_TILE / 32; ++wi) { const u32 m = hb[wi]; if (m) { nxt = wi * 32 + (u32)__builtin_ctz(m); break; } }
+						}
+						if (nxt < tl) len[j] = nxt - o;
+						else if (base + tl >= n) len[j] = tl - o;
+						else {                                       // goes on past the tile
+							const u32 q = lq_find_seg(aq_off, n_q, base + o + a_base);
+							const u64 qend = aq_off[q + 1] - a_base;
+							const u32 h = (u32)(A[base + o].x >> 32);
+							u64 lo = base + tl, hi = qend;           // first index in [lo, hi) whose high word differs, or hi
+							while (lo < hi) { const u64 mid = lo + ((hi - lo) >> 1); if ((u32)(A[mid].x >> 32) == h) lo = mid + 1; else hi = mid; }
+							len[j] = (u32)(lo - (base + o));
+						}
 					}
 				}
-				if (nxt < tl) len[j] = nxt - o;
-				else if (base + tl >= n) len[j] = tl - o;
-				else {                                           // goes on past the tile
-					const u32 q = lq_find_seg(aq_off, n_q, base + o + a_base);
-					const u64 qend = aq_off[q + 1] - a_base;
-					const u32 h = (u32)(A[base + o].x >> 32);
-					u64 lo = base + tl, hi = qend;               // first index in [lo, hi) whose high word differs, or hi
-					while (lo < hi) { const u64 mid = lo + ((hi - lo) >> 1); if ((u32)(A[mid].x >> 32) == h) lo = mid + 1; else hi = mid; }
-					len[j] = (u32)(lo - (base + o));
-				}
+				bal[j] = __ballot(len[j] >= n_min && len[j] != 0);
 			}
-			bal[j] = __ballot(len[j] >= n_min && len[j] != 0);
-		}
-		if (lane == 0) {
+			if (lane == 0) {
 #pragma unroll
-			for (int j = 0; j < LQ_RUN_ROWS; ++j) pre[j * LQ_RUN_WAVES + w] = (u32)__popcll(bal[j]);
+				for (int j = 0; j < LQ_RUN_ROWS; ++j) pre[j * LQ_RUN_WAVES + w] = (u32)__popcll(bal[j]);
+			}
+			__syncthreads();
+			if (t < 64) {                                         // exclusive scan of the 64 (row, wave) counts
+				const u32 v = pre[t];
+				u32 inc = v;
+				for (int d = 1; d < 64; d <<= 1) { const u32 o = __shfl_up(inc, d); if ((int)lane >= d) inc += o; }
+				pre[t] = inc - v;
+				if (t == 63) tot = inc;
+			}
+			__syncthreads();
+			c = tot;
 		}
-		__syncthreads();
-		if (t < 64) {                                             // exclusive scan of the 64 (row, wave) counts
-			const u32 v = pre[t];
-			u32 inc = v;
-			for (int d = 1; d < 64; d <<= 1) { const u32 o = __shfl_up(inc, d); if ((int)lane >= d) inc += o; }
-			pre[t] = inc - v;
-			if (t == 63) slot0 = inc ? atomicAdd(n_runs, inc) : 0u;
+		// the staged entries go out when this tile's would not fit beside them (and after the last tile)
+		const bool direct = c > stage;
+		if (fill && (T == T1 || direct || fill + c > stage)) {
+			if (t == 0) slot0 = atomicAdd(n_runs, fill);
+			__syncthreads();
+			for (u32 i = t; i < fill; i += LQ_RUN_THREADS) runs[slot0 + i] = stg[i];
+			fill = 0;
+			__syncthreads();
 		}
-		__syncthreads();
-		const u32 off = slot0;
+		if (T == T1 || c == 0) continue;
+		if (direct) {
+			if (t == 0) slot0 = atomicAdd(n_runs, c);
+			__syncthreads();
+		}
 #pragma unroll
 		for (int j = 0; j < LQ_RUN_ROWS; ++j)
-			if (bal[j] >> lane & 1)
-				runs[off + pre[j * LQ_RUN_WAVES + w] + (u32)__popcll(bal[j] & ((1ULL << lane) - 1))] = (base + (u32)j * LQ_RUN_THREADS + t) | (u64)len[j] << 32;
+			if (bal[j] >> lane & 1) {
+				const u32 r = pre[j * LQ_RUN_WAVES + w] + (u32)__popcll(bal[j] & ((1ULL << lane) - 1));
+				const u64 e = (base + (u32)j * LQ_RUN_THREADS + t) | (u64)len[j] << 32;
+				if (direct) runs[slot0 + r] = e; else stg[fill + r] = e;
+			}
+		if (!direct) fill += c;
 		__syncthreads();
 	}
 }
