@@ -92,6 +92,7 @@ void Knobs::read_env()
 	chain_wave_min = (int)std::max<long>(0, num("LQCOV_CHAIN_WAVE_MIN", 0));
 	chain_cap = (int)num("LQCOV_CHAIN_CAP", 128);
 	run_stage = (u32)std::max<long>(1, num("LQCOV_RUN_STAGE", 3072));
+	batch_tail = (int)num("LQCOV_BATCH_TAIL", 1);
 	no_level_skip = getenv("LQCOV_NO_LEVEL_SKIP") != nullptr;
 	debug_sort = getenv("LQCOV_DEBUG_SORT") != nullptr;
 	sketch_kpt = (u32)std::min<long>(64, std::max<long>(1, num("LQCOV_SKETCH_KPT", 4)));
@@ -1121,7 +1122,7 @@ void lqcov_handle::map_part(Part &pt)
 	}
 	last_n_anchors = nA_total;
 	mini_pos.ensure(n_mp_total * 8 + 8);
-	LQ_LAUNCH(k_query_prep, nblk(n_q + 1, 128), 128, stream, q.moff.as<u64>(), a_off.as<u64>(), mp_off.as<u64>(), n_qm, nA_total, n_mp_total, n_q,
+	LQ_LAUNCH(k_query_prep, nblk(n_q + 1, 4), 256, stream, q.moff.as<u64>(), a_off.as<u64>(), mp_off.as<u64>(), n_qm, nA_total, n_mp_total, n_q,
 	          q.mx.as<u64>(), a_cnt.as<u32>(), keep.as<u32>(), q.d_len.as<u32>(),
 	          aq_off.as<u64>(), mpq_off.as<u64>(), avg_qspan.as<float>(), lambda.as<u64>(), avg_k.as<float>(), skip.as<u32>(), distributed ? 0 : 1);
 	check_launch();
@@ -1153,22 +1154,34 @@ void lqcov_handle::map_part(Part &pt)
 	// finish, so the serial tail of one batch (its longest walk / chain) overlaps the wide kernels of another
 	std::vector<std::pair<u32, u32>> batches;
 	{	// as few batches as the work space allows, a multiple of the lane count, of about equal anchor totals: every batch
-		// has a serial critical path (its longest walk and chain) that does not shrink with the batch
+		// has a serial critical path (its longest walk and chain) that does not shrink with the batch.  The last round is cut
+		// finer (halves, then quarters: K.batch_tail): the lanes start staggered and a part ends when its last batch does, so
+		// with whole batches the device runs one or two lanes' kernels for the last third of a batch time.
 		u64 nb = (nA_total + anchor_budget - 1) / anchor_budget;
 		if (nb < (u64)n_lanes && nA_total >= ((u64)n_lanes << 24)) nb = n_lanes;
 		if (nb > (u64)n_lanes) nb = (nb + n_lanes - 1) / n_lanes * n_lanes;
 		if (nb == 0) nb = 1;
-		u64 left = nb;
+		std::vector<double> wt(nb, 1.0);
+		if (K.batch_tail && n_lanes > 1 && nb >= (u64)n_lanes && (nA_total / nb >= (64u << 20) || K.batch_tail == 2)) {
+			wt.resize(nb - n_lanes);
+			wt.insert(wt.end(), n_lanes, 0.5);
+			wt.insert(wt.end(), 2 * (size_t)n_lanes, 0.25);
+		}
+		double wleft = 0;
+		for (double w : wt) wleft += w;
+		size_t b = 0;
 		for (u32 q0 = 0; q0 < n_q; ) {
 			const u64 rem = h_aq[n_q] - h_aq[q0];
-			const u64 lim = std::min(anchor_budget, left > 1 ? (rem + left - 1) / left : rem);
+			const double w = b < wt.size() ? wt[b] : wleft;
+			const u64 lim = std::min<u64>(anchor_budget, b + 1 < wt.size() ? (u64)std::ceil((double)rem * w / wleft) : rem);
 			u32 q1 = q0 + 1;
 			while (q1 < n_q && h_aq[q1 + 1] - h_aq[q0] <= lim) ++q1;
 			batches.emplace_back(q0, q1);
 			q0 = q1;
-			if (left > 1) --left;
+			if (b + 1 < wt.size()) { wleft -= w; ++b; }
 		}
 	}
+	if (getenv("LQCOV_DEBUG_BATCHES")) { fprintf(stderr, "[lqcov] %zu batches:", batches.size()); for (auto &bq : batches) fprintf(stderr, " %llu", (unsigned long long)(h_aq[bq.second] - h_aq[bq.first])); fprintf(stderr, "\n"); }
 	while (lanes.size() < (size_t)n_lanes) {
 		lanes.emplace_back(new MapLane());
 		LQ_HIP_CHECK(hipStreamCreate(&lanes.back()->stream));

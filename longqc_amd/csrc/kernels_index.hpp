@@ -244,24 +244,31 @@ k_seed_emit(const u64 *qx, const u64 *qy, const u32 *owner, const u64 *qmoff, u6
 
 // per query: anchor range, mini_pos range, avg_qspan (chain.c:37-38), lq_cnt_match prologue
 // (esterr.c:85-97): skip flag and avg_k.
-__global__ void k_query_prep(const u64 *qmoff, const u64 *a_off, const u64 *mp_off, u64 n_qm, u64 n_anchor_total, u64 n_mp_total, u32 n_q,
-                             const u64 *qx, const u32 *a_cnt, const u32 *keep, const u32 *qlen,
-                             u64 *aq_off, u64 *mpq_off, float *avg_qspan, const u64 *lambda, float *avg_k, u32 *skip, int covt_on)
+__global__ void __launch_bounds__(256)
+k_query_prep(const u64 *qmoff, const u64 *a_off, const u64 *mp_off, u64 n_qm, u64 n_anchor_total, u64 n_mp_total, u32 n_q,
+             const u64 *qx, const u32 *a_cnt, const u32 *keep, const u32 *qlen,
+             u64 *aq_off, u64 *mpq_off, float *avg_qspan, const u64 *lambda, float *avg_k, u32 *skip, int covt_on)
 {
-	u32 q = blockIdx.x * blockDim.x + threadIdx.x;
+	// one wave per query (the sums are integers: any order)
+	const u32 q = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
 	if (q > n_q) return;
-	u64 j0 = qmoff[q];
-	u64 a0 = j0 < n_qm ? a_off[j0] : n_anchor_total;
-	u64 m0 = j0 < n_qm ? mp_off[j0] : n_mp_total;
-	aq_off[q] = a0; mpq_off[q] = m0;
+	const u64 j0 = qmoff[q];
+	if (lane == 0) {
+		aq_off[q] = j0 < n_qm ? a_off[j0] : n_anchor_total;
+		mpq_off[q] = j0 < n_qm ? mp_off[j0] : n_mp_total;
+	}
 	if (q == n_q) return;
-	u64 j1 = qmoff[q + 1];
+	const u64 j1 = qmoff[q + 1];
 	u64 sum_span = 0, n_a = 0, sum_k = 0, n_mp = 0;
-	for (u64 j = j0; j < j1; ++j) {
-		u64 span = qx[j] & 0xff;
+	for (u64 j = j0 + lane; j < j1; j += 64) {
+		const u64 span = qx[j] & 0xff;
 		sum_span += span * a_cnt[j]; n_a += a_cnt[j];
 		if (keep[j]) { sum_k += span; ++n_mp; }
 	}
+	for (int o = 32; o > 0; o >>= 1) {
+		sum_span += __shfl_xor(sum_span, o); n_a += __shfl_xor(n_a, o); sum_k += __shfl_xor(sum_k, o); n_mp += __shfl_xor(n_mp, o);
+	}
+	if (lane != 0) return;
 	avg_qspan[q] = n_a ? __fdiv_rn((float)sum_span, (float)(i64)n_a) : 0.0f;
 	u32 sk = 0;
 	if (n_mp == 0) sk = 1;                                             // esterr.c:85

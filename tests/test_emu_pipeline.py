@@ -363,6 +363,12 @@ def check_run_list_variants(lib, tmp_path, monkeypatch):
         rc, out, err = run_main(lib, argv)
         assert rc == 0, err
         assert out == want, budget
+    monkeypatch.setenv("LQCOV_ANCHOR_BUDGET", "20000")
+    monkeypatch.setenv("LQCOV_BATCH_TAIL", "2")   # the last round of batches in halves and quarters (map_part)
+    rc, out, err = run_main(lib, argv)
+    assert rc == 0, err
+    assert out == want
+    monkeypatch.delenv("LQCOV_BATCH_TAIL", raising=False)
     monkeypatch.delenv("LQCOV_ANCHOR_BUDGET", raising=False)
     # the list's LDS staging (k_run_list): room for 40 entries, so that a block's tiles flush it again and again and the
     # tiles with more entries than that write theirs directly; -n 1 -m 10: every run of one anchor is listed
