@@ -91,8 +91,7 @@ void Knobs::read_env()
 	walk_grid = (u32)std::max<long>(64, num("LQCOV_WALK_GRID", 1L << 18));
 	chain_wave_min = (int)std::max<long>(0, num("LQCOV_CHAIN_WAVE_MIN", 0));
 	chain_cap = (int)num("LQCOV_CHAIN_CAP", 128);
-	run_stage = (u32)std::max<long>(1, num("LQCOV_RUN_STAGE", 3072));
-	batch_tail = (int)num("LQCOV_BATCH_TAIL", 1);
+	run_stage = (u32)std::max<long>(1, num("LQCOV_RUN_STAGE", LQ_RUN_STAGE));
 	no_level_skip = getenv("LQCOV_NO_LEVEL_SKIP") != nullptr;
 	debug_sort = getenv("LQCOV_DEBUG_SORT") != nullptr;
 	sketch_kpt = (u32)std::min<long>(64, std::max<long>(1, num("LQCOV_SKETCH_KPT", 4)));
@@ -645,7 +644,7 @@ void lqcov_handle::map_batch(MapLane &L, Part &pt, u32 q0, u32 q1, const std::ve
 			dzero(L.run_tiles.p, 4, L.stream);
 			{
 				StageTimer t(this, L.stream, "k_run_list", nA * 16);
-				LQ_LAUNCH(k_run_list, std::min<u32>(n_tiles, 2048), LQ_RUN_THREADS, L.stream, dA, nA, aqb, a_base, nqb, n_tiles, n_min, std::min<u32>(K.run_stage, LQ_RUN_STAGE), L.run_tiles.as<u32>(), L.gstart.as<u64>()); check_launch();
+				LQ_LAUNCH(k_run_list, std::min<u32>(n_tiles, 2048), LQ_RUN_THREADS, L.stream, dA, nA, aqb, a_base, nqb, n_tiles, n_min, std::max<u32>(LQ_RUN_THREADS, std::min<u32>(K.run_stage, LQ_RUN_STAGE)), L.run_tiles.as<u32>(), L.gstart.as<u64>()); check_launch();
 			}
 			u32 ng = 0;
 			d2h(&ng, L.run_tiles.as<u32>(), 1, L.stream);
@@ -1154,31 +1153,22 @@ void lqcov_handle::map_part(Part &pt)
 	// finish, so the serial tail of one batch (its longest walk / chain) overlaps the wide kernels of another
 	std::vector<std::pair<u32, u32>> batches;
 	{	// as few batches as the work space allows, a multiple of the lane count, of about equal anchor totals: every batch
-		// has a serial critical path (its longest walk and chain) that does not shrink with the batch.  The last round is cut
-		// finer (halves, then quarters: K.batch_tail): the lanes start staggered and a part ends when its last batch does, so
-		// with whole batches the device runs one or two lanes' kernels for the last third of a batch time.
+		// has a serial critical path (its longest walk and chain) that does not shrink with the batch.  (Cutting the last round
+		// finer -- halves, then quarters, so that the lanes end together -- was measured on MI355X at configs[2]: 1.75-1.78 s
+		// per step against 1.68-1.70 s; the extra batches cost more than the shorter tail saves.)
 		u64 nb = (nA_total + anchor_budget - 1) / anchor_budget;
 		if (nb < (u64)n_lanes && nA_total >= ((u64)n_lanes << 24)) nb = n_lanes;
 		if (nb > (u64)n_lanes) nb = (nb + n_lanes - 1) / n_lanes * n_lanes;
 		if (nb == 0) nb = 1;
-		std::vector<double> wt(nb, 1.0);
-		if (K.batch_tail && n_lanes > 1 && nb >= (u64)n_lanes && (nA_total / nb >= (64u << 20) || K.batch_tail == 2)) {
-			wt.resize(nb - n_lanes);
-			wt.insert(wt.end(), n_lanes, 0.5);
-			wt.insert(wt.end(), 2 * (size_t)n_lanes, 0.25);
-		}
-		double wleft = 0;
-		for (double w : wt) wleft += w;
-		size_t b = 0;
+		u64 left = nb;
 		for (u32 q0 = 0; q0 < n_q; ) {
 			const u64 rem = h_aq[n_q] - h_aq[q0];
-			const double w = b < wt.size() ? wt[b] : wleft;
-			const u64 lim = std::min<u64>(anchor_budget, b + 1 < wt.size() ? (u64)std::ceil((double)rem * w / wleft) : rem);
+			const u64 lim = std::min(anchor_budget, left > 1 ? (rem + left - 1) / left : rem);
 			u32 q1 = q0 + 1;
 			while (q1 < n_q && h_aq[q1 + 1] - h_aq[q0] <= lim) ++q1;
 			batches.emplace_back(q0, q1);
 			q0 = q1;
-			if (b + 1 < wt.size()) { wleft -= w; ++b; }
+			if (left > 1) --left;
 		}
 	}
 	if (getenv("LQCOV_DEBUG_BATCHES")) { fprintf(stderr, "[lqcov] %zu batches:", batches.size()); for (auto &bq : batches) fprintf(stderr, " %llu", (unsigned long long)(h_aq[bq.second] - h_aq[bq.first])); fprintf(stderr, "\n"); }

@@ -31,35 +31,6 @@
 #define LQ_RUN_ROWS (LQ_RUN_TILE / LQ_RUN_THREADS)
 #define LQ_RUN_WAVES (LQ_RUN_THREADS / 64)
 
-// ballots of "a run starts here" for the rows of one tile (row j = anchors base + j * 256 + [0, 256)); qbits: LDS bitmap of
-// the query starts inside the tile
-__device__ __forceinline__ void lq_run_heads(const mm128 *A, u64 n, const u64 *aq_off, u64 a_base, u32 n_q, u64 base, u32 *qbits, u64 (&bal)[LQ_RUN_ROWS])
-{
-	const u32 t = threadIdx.x, lane = t & 63;
-	if (t < LQ_RUN_TILE / 32) qbits[t] = 0;
-	__syncthreads();
-	{	// queries that start in [base, base + tile): the first candidate is the query that holds `base`
-		u32 lo = 0, hi = n_q;                                 // invariant: aq_off[lo] - a_base <= base
-		while (hi - lo > 1) { const u32 mid = lo + ((hi - lo) >> 1); if (aq_off[mid] - a_base <= base) lo = mid; else hi = mid; }
-		for (u32 q = lo + t; q < n_q; q += LQ_RUN_THREADS) {
-			const u64 p = aq_off[q] - a_base;
-			if (p >= base + LQ_RUN_TILE) break;
-			if (p >= base && aq_off[q] < aq_off[q + 1]) atomicOr(&qbits[(u32)(p - base) >> 5], 1u << ((u32)(p - base) & 31));
-		}
-	}
-	__syncthreads();
-#pragma unroll
-	for (int j = 0; j < LQ_RUN_ROWS; ++j) {
-		const u32 o = (u32)j * LQ_RUN_THREADS + t;
-		const u64 i = base + o;
-		const u32 hi32 = i < n ? (u32)(A[i].x >> 32) : 0u;
-		u32 prev = __shfl_up(hi32, 1);
-		if (lane == 0) prev = (i > 0 && i < n) ? (u32)(A[i - 1].x >> 32) : ~hi32;
-		const bool head = i < n && (i == 0 || hi32 != prev || (qbits[o >> 5] >> (o & 31) & 1));
-		bal[j] = __ballot(head);
-	}
-}
-
 // exclusive scan of n counts in place, the total in cnt[n]; one block
 #define LQ_TSCAN_THREADS 1024
 __global__ void __launch_bounds__(LQ_TSCAN_THREADS)
@@ -81,105 +52,136 @@ k_tile_scan(u32 *cnt, u32 n)
 	for (u32 x = a; x < b; ++x) { const u32 v = cnt[x]; cnt[x] = run; run += v; }
 }
 
+// strand and rid of an anchor: the high word of x, loaded alone
+__device__ __forceinline__ u32 lq_hi32(const mm128 *a) { return ((const u32*)a)[1]; }
 #define LQ_RUN_START(e) ((u64)(u32)(e))
 #define LQ_RUN_LEN(e) ((i64)((e) >> 32))
-#define LQ_RUN_STAGE 3072         // entries a block collects in LDS before it reserves their place in the list
-// A block takes a contiguous stretch of tiles and collects the entries in LDS: one atomic on the list's counter per ~3000
-// entries (a dozen tiles at configs[2]).  One atomic per tile was measured at 4 ms per launch of 77 000 tiles on MI355X -- the
-// same-address atomics of the whole device queue up at ~40 ns each -- against 0.9 ms for reading the anchors.
+#define LQ_RUN_STAGE 2048         // entries a block collects in LDS before it reserves their place in the list
+#define LQ_RUN_PEEK 64            // anchors after the tile that the block looks at for the end of the tile's last run
+// A block takes a contiguous stretch of tiles and collects the entries in LDS: one atomic on the list's counter per ~1500
+// entries (half a dozen tiles at configs[2]).  What a tile costs is its chain of dependent loads and the waves a CU can hold,
+// not its bytes: the tile's first query comes from the previous tile (a bisection for the block's first tile only), the end
+// of the tile's last run from LQ_RUN_PEEK anchors loaded with the tile (a bisection inside the query only for a run that goes
+// on beyond those); heads and entries go through LDS (a bitmap, a staging area filled through an LDS counter), so that a
+// thread holds sixteen high words and little else (a first version kept ballots and lengths of all rows in registers: 184
+// VGPRs, two waves per SIMD, 5 ms per launch against 0.9 ms for reading the anchors).
 __global__ void __launch_bounds__(LQ_RUN_THREADS)
-k_run_list(const mm128 *A, u64 n, const u64 *aq_off, u64 a_base, u32 n_q, u32 n_tiles, u32 n_min, u32 stage /* <= LQ_RUN_STAGE (tests shrink it) */, u32 *n_runs, u64 *runs)
+k_run_list(const mm128 *A, u64 n, const u64 *aq_off, u64 a_base, u32 n_q, u32 n_tiles, u32 n_min, u32 stage /* 256 .. LQ_RUN_STAGE (tests shrink it) */,
+           u32 *n_runs, u64 *runs)
 {
-	__shared__ u32 qbits[LQ_RUN_TILE / 32];
-	__shared__ u32 hb[LQ_RUN_TILE / 32 + 2];
-	__shared__ u32 pre[LQ_RUN_ROWS * LQ_RUN_WAVES];
-	__shared__ u32 slot0, tot;
+	__shared__ u32 qbits[LQ_RUN_TILE / 32];                       // query starts inside the tile
+	__shared__ u32 hb[LQ_RUN_TILE / 32 + 2];                      // run starts inside the tile
+	__shared__ u32 nx[LQ_RUN_PEEK];
+	__shared__ u32 slot0, fill_s;
 	__shared__ u64 stg[LQ_RUN_STAGE];
 	const u32 t = threadIdx.x, lane = t & 63, w = t >> 6;
 	const u32 per = (n_tiles + gridDim.x - 1) / gridDim.x;
 	const u32 T0 = blockIdx.x * per < n_tiles ? blockIdx.x * per : n_tiles, T1 = T0 + per < n_tiles ? T0 + per : n_tiles;
 	const u64 near_mask = n_min > 1 ? (n_min > 33 ? ~0ULL >> 31 : (1ULL << (n_min - 1)) - 1) : 0;   // the next n_min - 1 positions (up to 33 of them)
-	u32 fill = 0;                                                 // (block-uniform) entries waiting in stg
+	u32 qlo = ~0u;                                                // the query that holds the tile's first anchor
 	if (t < 2) hb[LQ_RUN_TILE / 32 + t] = 0;
-	for (u32 T = T0; T <= T1; ++T) {
-		u64 bal[LQ_RUN_ROWS];
-		u32 len[LQ_RUN_ROWS];
-		u32 c = 0;
+	if (t == 0) fill_s = 0;
+	// the staged entries go to the list (block-uniform call; f = fill_s read between two barriers)
+#define LQ_RUN_FLUSH(f) do { if (t == 0) slot0 = atomicAdd(n_runs, (f)); __syncthreads(); \
+		for (u32 i_ = t; i_ < (f); i_ += LQ_RUN_THREADS) runs[slot0 + i_] = stg[i_]; \
+		if (t == 0) fill_s = 0; __syncthreads(); } while (0)
+	for (u32 T = T0; T < T1; ++T) {
 		const u64 base = (u64)T * LQ_RUN_TILE;
-		if (T < T1) {
-			const u32 tl = n - base < LQ_RUN_TILE ? (u32)(n - base) : LQ_RUN_TILE;
-			lq_run_heads(A, n, aq_off, a_base, n_q, base, qbits, bal);
-			if (lane == 0) {
-#pragma unroll
-				for (int j = 0; j < LQ_RUN_ROWS; ++j) { const u32 o = ((u32)j * LQ_RUN_THREADS + w * 64) >> 5; hb[o] = (u32)bal[j]; hb[o + 1] = (u32)(bal[j] >> 32); }
+		const u32 tl = n - base < LQ_RUN_TILE ? (u32)(n - base) : LQ_RUN_TILE;
+		if (t < LQ_RUN_PEEK) nx[t] = base + tl + t < n ? lq_hi32(A + base + tl + t) : 0u;
+		if (t < LQ_RUN_TILE / 32) qbits[t] = 0;
+		__syncthreads();
+		{	// queries that start in [base, base + tile): the first candidate is the query that holds `base`
+			u32 lo = qlo, hi = n_q;                               // invariant: aq_off[lo] - a_base <= base
+			if (lo == ~0u) { lo = 0; while (hi - lo > 1) { const u32 mid = lo + ((hi - lo) >> 1); if (aq_off[mid] - a_base <= base) lo = mid; else hi = mid; } }
+			else while (lo + 1 < n_q && aq_off[lo + 1] - a_base <= base) ++lo;
+			qlo = lo;
+			for (u32 q = lo + t; q < n_q; q += LQ_RUN_THREADS) {
+				const u64 p = aq_off[q] - a_base;
+				if (p >= base + LQ_RUN_TILE) break;
+				if (p >= base && aq_off[q] < aq_off[q + 1]) atomicOr(&qbits[(u32)(p - base) >> 5], 1u << ((u32)(p - base) & 31));
 			}
-			__syncthreads();
+		}
+		__syncthreads();
+		// a run starts where the high word of x changes or a query starts (eight rows of loads in flight per thread)
+		const u32 *hp = (const u32*)(A + base) + 1;               // high word of x of the tile's anchor o: hp[4 * o]
+#pragma unroll 1
+		for (u32 j0 = 0; j0 < LQ_RUN_ROWS; j0 += 8) {
+			u32 h[8];
 #pragma unroll
-			for (int j = 0; j < LQ_RUN_ROWS; ++j) {
-				len[j] = 0;
-				if (bal[j] >> lane & 1) {
-					const u32 o = (u32)j * LQ_RUN_THREADS + t;
-					const u32 w0 = (o + 1) >> 5, sh = (o + 1) & 31;
-					const u64 win = (((u64)hb[w0 + 1] << 32 | hb[w0]) >> sh) | (sh ? (u64)hb[w0 + 2] << (64 - sh) : 0);   // heads at o + 1, o + 2, ...
-					if ((win & near_mask) == 0) {                    // no head among the next n_min - 1 anchors of the tile: find the end
-						u32 nxt = LQ_RUN_TILE;                       // the next head of the tile
-						if (win) nxt = o + 1 + (u32)__builtin_ctzll(win);
-						else {
-							for (u32 wi = w0 + 2; wi < LQ_RUN_TILE / 32; ++wi) { const u32 m = hb[wi]; if (m) { nxt = wi * 32 + (u32)__builtin_ctz(m); break; } }
-						}
-						if (nxt < tl) len[j] = nxt - o;
-						else if (base + tl >= n) len[j] = tl - o;
-						else {                                       // goes on past the tile
-							const u32 q = lq_find_seg(aq_off, n_q, base + o + a_base);
-							const u64 qend = aq_off[q + 1] - a_base;
-							const u32 h = (u32)(A[base + o].x >> 32);
-							u64 lo = base + tl, hi = qend;           // first index in [lo, hi) whose high word differs, or hi
-							while (lo < hi) { const u64 mid = lo + ((hi - lo) >> 1); if ((u32)(A[mid].x >> 32) == h) lo = mid + 1; else hi = mid; }
-							len[j] = (u32)(lo - (base + o));
-						}
+			for (u32 j = 0; j < 8; ++j) { const u32 o = (j0 + j) * LQ_RUN_THREADS + t; h[j] = o < tl ? hp[4 * o] : 0u; }
+#pragma unroll
+			for (u32 j = 0; j < 8; ++j) {
+				const u32 o = (j0 + j) * LQ_RUN_THREADS + t;
+				u32 prev = __shfl_up(h[j], 1);
+				if (lane == 0) prev = (o < tl && base + o > 0) ? hp[4 * (i64)o - 4] : ~h[j];
+				const u64 bal = __ballot(o < tl && (base + o == 0 || h[j] != prev || (qbits[o >> 5] >> (o & 31) & 1)));
+				if (lane == 0) { hb[(o >> 5)] = (u32)bal; hb[(o >> 5) + 1] = (u32)(bal >> 32); }
+			}
+		}
+		__syncthreads();
+		// room for the tile's entries (at most one per n_min anchors); when even an empty stage cannot promise that, per row
+		const u32 worst = tl / n_min + 1;
+		const bool per_row = worst > stage;
+		{
+			const u32 f = fill_s;
+			__syncthreads();
+			if (!per_row && f + worst > stage) LQ_RUN_FLUSH(f);
+		}
+		for (u32 j = 0; j < LQ_RUN_ROWS; ++j) {
+			if (per_row) {
+				__syncthreads();
+				const u32 f = fill_s;
+				__syncthreads();
+				if (f + LQ_RUN_THREADS > stage) LQ_RUN_FLUSH(f);
+			}
+			const u32 o = j * LQ_RUN_THREADS + t;
+			u32 len = 0;
+			if (hb[o >> 5] >> (o & 31) & 1) {
+				const u32 w0 = (o + 1) >> 5, sh = (o + 1) & 31;
+				const u64 win = (((u64)hb[w0 + 1] << 32 | hb[w0]) >> sh) | (sh ? (u64)hb[w0 + 2] << (64 - sh) : 0);   // heads at o + 1, o + 2, ...
+				if ((win & near_mask) == 0) {                    // no head among the next n_min - 1 anchors of the tile: find the end
+					u32 nxt = LQ_RUN_TILE;                       // the next head of the tile
+					if (win) nxt = o + 1 + (u32)__builtin_ctzll(win);
+					else {
+						for (u32 wi = w0 + 2; wi < LQ_RUN_TILE / 32; ++wi) { const u32 m = hb[wi]; if (m) { nxt = wi * 32 + (u32)__builtin_ctz(m); break; } }
+					}
+					if (nxt < tl) len = nxt - o;
+					else if (base + tl >= n) len = tl - o;
+					else {                                       // goes on past the tile: to the end of its query or to the first other high word
+						u32 q = qlo;
+						while (aq_off[q + 1] - a_base <= base + o) ++q;
+						const u64 qend = aq_off[q + 1] - a_base;
+						const u32 h = lq_hi32(A + base + o);
+						u64 lo = base + tl, hi = qend;           // first index in [lo, hi) whose high word differs, or hi
+						const u32 pk = hi - lo < LQ_RUN_PEEK ? (u32)(hi - lo) : LQ_RUN_PEEK;
+						u32 i = 0;
+						while (i < pk && nx[i] == h) ++i;
+						lo += i;
+						if (i == LQ_RUN_PEEK)
+							while (lo < hi) { const u64 mid = lo + ((hi - lo) >> 1); if (lq_hi32(A + mid) == h) lo = mid + 1; else hi = mid; }
+						len = (u32)(lo - (base + o));
 					}
 				}
-				bal[j] = __ballot(len[j] >= n_min && len[j] != 0);
 			}
-			if (lane == 0) {
-#pragma unroll
-				for (int j = 0; j < LQ_RUN_ROWS; ++j) pre[j * LQ_RUN_WAVES + w] = (u32)__popcll(bal[j]);
+			const bool viable = len >= n_min && len != 0;
+			const u64 vb = __ballot(viable);
+			if (vb) {
+				u32 b = 0;
+				if (lane == 0) b = atomicAdd(&fill_s, (u32)__popcll(vb));
+				b = __shfl(b, 0);
+				if (viable) stg[b + (u32)__popcll(vb & ((1ULL << lane) - 1))] = (base + o) | (u64)len << 32;
 			}
-			__syncthreads();
-			if (t < 64) {                                         // exclusive scan of the 64 (row, wave) counts
-				const u32 v = pre[t];
-				u32 inc = v;
-				for (int d = 1; d < 64; d <<= 1) { const u32 o = __shfl_up(inc, d); if ((int)lane >= d) inc += o; }
-				pre[t] = inc - v;
-				if (t == 63) tot = inc;
-			}
-			__syncthreads();
-			c = tot;
 		}
-		// the staged entries go out when this tile's would not fit beside them (and after the last tile)
-		const bool direct = c > stage;
-		if (fill && (T == T1 || direct || fill + c > stage)) {
-			if (t == 0) slot0 = atomicAdd(n_runs, fill);
-			__syncthreads();
-			for (u32 i = t; i < fill; i += LQ_RUN_THREADS) runs[slot0 + i] = stg[i];
-			fill = 0;
-			__syncthreads();
-		}
-		if (T == T1 || c == 0) continue;
-		if (direct) {
-			if (t == 0) slot0 = atomicAdd(n_runs, c);
-			__syncthreads();
-		}
-#pragma unroll
-		for (int j = 0; j < LQ_RUN_ROWS; ++j)
-			if (bal[j] >> lane & 1) {
-				const u32 r = pre[j * LQ_RUN_WAVES + w] + (u32)__popcll(bal[j] & ((1ULL << lane) - 1));
-				const u64 e = (base + (u32)j * LQ_RUN_THREADS + t) | (u64)len[j] << 32;
-				if (direct) runs[slot0 + r] = e; else stg[fill + r] = e;
-			}
-		if (!direct) fill += c;
 		__syncthreads();
 	}
+	{
+		const u32 f = fill_s;
+		__syncthreads();
+		if (f) LQ_RUN_FLUSH(f);
+	}
+#undef LQ_RUN_FLUSH
+	(void)w;
 }
 
 __device__ __forceinline__ int lq_ilog2_32(u32 v) { return 31 - __clz(v); }   // chain.c:15-20 for v > 0

@@ -363,22 +363,16 @@ def check_run_list_variants(lib, tmp_path, monkeypatch):
         rc, out, err = run_main(lib, argv)
         assert rc == 0, err
         assert out == want, budget
-    monkeypatch.setenv("LQCOV_ANCHOR_BUDGET", "20000")
-    monkeypatch.setenv("LQCOV_BATCH_TAIL", "2")   # the last round of batches in halves and quarters (map_part)
-    rc, out, err = run_main(lib, argv)
-    assert rc == 0, err
-    assert out == want
-    monkeypatch.delenv("LQCOV_BATCH_TAIL", raising=False)
     monkeypatch.delenv("LQCOV_ANCHOR_BUDGET", raising=False)
-    # the list's LDS staging (k_run_list): room for 40 entries, so that a block's tiles flush it again and again and the
-    # tiles with more entries than that write theirs directly; -n 1 -m 10: every run of one anchor is listed
-    monkeypatch.setenv("LQCOV_RUN_STAGE", "40")
+    # the list's LDS staging (k_run_list): room for 256 entries (the least it takes), so that a block's tiles flush it again
+    # and again, row by row where a tile may hold more entries than that; -n 1 -m 10: every run of one anchor is listed
+    monkeypatch.setenv("LQCOV_RUN_STAGE", "256")
     rc, out, err = run_main(lib, argv)
     assert rc == 0, err
     assert out == want
     argv1 = ["-Y", "-l", "0", "-q", "40", "-k", "12", "-w", "5", "-I", "4G", "-p", "40", "-m", "10", "-n", "1", "-t", "4", tf, qf]
     want1 = oracle_bind.ref_table(argv1) if oracle_bind.have_ref() else oracle_bind.table(argv1)
-    for stage in ("40", ""):
+    for stage in ("256", ""):
         monkeypatch.setenv("LQCOV_RUN_STAGE", stage) if stage else monkeypatch.delenv("LQCOV_RUN_STAGE", raising=False)
         rc, out, err = run_main(lib, argv1)
         assert rc == 0, err
