@@ -41,6 +41,11 @@ __device__ __forceinline__ mm128 lq_ps_load(const PSeg &sg, const PsData &P, u32
 	if (sg.buf < 2) return (sg.buf ? P.B : P.A)[sg.off + i];
 	return P.B[LQ_R_IDX(P.R[sg.buf - 2][sg.off + i].im)];
 }
+__device__ __forceinline__ u64 lq_ps_load_y(const PSeg &sg, const PsData &P, u32 i)
+{
+	if (sg.buf < 2) return (sg.buf ? P.B : P.A)[sg.off + i].y;
+	return P.B[LQ_R_IDX(P.R[sg.buf - 2][sg.off + i].im)].y;
+}
 __device__ __forceinline__ u64 lq_ps_load_x(const PSeg &sg, const PsData &P, u32 i)
 {
 	if (sg.buf < 2) return (sg.buf ? P.B : P.A)[sg.off + i].x;
@@ -269,22 +274,30 @@ k_ps_scatter(const PSeg *segs, const u32 *n_p, const PPlan *plan, const u32 *tma
 }
 
 // ---- finish: one block sorts a segment by all its remaining key bits and writes it to A -------------------------
-// Every thread keeps the elements it loaded in registers; LDS holds their keys, the sub-bucket histogram (the next
-// SB bits of the key) and the elements' indices grouped by sub-bucket.  An element's place = start of its sub-bucket +
-// the number of smaller keys in it (a handful of elements: about n / 2^SB).  All loads are done before the first store,
-// so the segment may be sorted in place.
+// LDS holds every element's key, split in two: the sub-bucket digit (the top SB bits of the range the segment's keys really
+// span) and the bits below it, plus the sub-bucket histogram and the elements' indices grouped by sub-bucket.  An element's
+// place = start of its sub-bucket + the number of smaller keys in it (a handful of elements: about n / 2^SB).  A thread keeps
+// only y of the elements it loaded: x is the key -- the compact key holds every bit of x that is not zero in the whole part
+// (lq_ckey), so the x that belongs at a place is rebuilt from the key that landed there.  (Holding the anchors, 4 registers
+// each, took 128 registers and 27 spilled ones per lane in the 1024-thread shape: one block per CU.  Now two fit.)
+// All loads are done before the first barrier, so the segment may be sorted in place.
 // KEY = u32 when the key bits below the sub-bucket digit fit 32 bits for every segment of the part (K - SB <= 32, the
-// usual case: half the LDS, two blocks per CU), u64 otherwise.
+// usual case), u64 otherwise.
+__device__ __forceinline__ u64 lq_ckey_inv(u64 ck, const KeyMap km)
+{
+	return (ck & ((1ULL << km.pbits) - 1)) | ((ck >> km.pbits) & ((1ULL << km.rbits) - 1)) << 32 | ((ck >> (km.pbits + km.rbits)) & 1) << 63;
+}
 template <int CAP, int THREADS, int SB, class KEY>
-__global__ void __launch_bounds__(THREADS)
+__global__ void __launch_bounds__(THREADS, 8)
 k_ps_finish(const PSeg *segs, const u32 *n_p, PsData P, KeyMap km, unsigned long long *tally)
 {
 	constexpr int NSB = 1 << SB, PER = CAP / THREADS, SPT = NSB / THREADS > 0 ? NSB / THREADS : 1;
 	static_assert(CAP % THREADS == 0 && (NSB % THREADS == 0 || NSB < THREADS), "shape");
-	__shared__ KEY keys[CAP];                                  // the key bits below the sub-bucket digit
+	__shared__ KEY keys[CAP];                                  // first the low 32 (64) bits of the remaining key, then the bits below the digit
+	__shared__ u16 dgs[CAP];                                   // first the bits above those (u32 keys), then the digit
 	__shared__ u16 perm[CAP];
 	__shared__ u32 hist[NSB], beg[NSB], fill[NSB], wsum[THREADS / 64 + 1];
-	__shared__ u64 rmin[THREADS / 64], rmax[THREADS / 64];
+	__shared__ u64 rmin[THREADS / 64], rmax[THREADS / 64], chigh_s;
 	const u32 n_seg = *n_p, t = threadIdx.x;
 	for (u32 s = blockIdx.x; s < n_seg; s += gridDim.x) {
 		const PSeg sg = segs[s];
@@ -297,14 +310,20 @@ k_ps_finish(const PSeg *segs, const u32 *n_p, PsData P, KeyMap km, unsigned long
 		}
 		const u64 km_mask = sg.rem >= 64 ? ~0ULL : ((1ULL << sg.rem) - 1);
 		for (u32 c = t; c < NSB; c += THREADS) { hist[c] = 0; fill[c] = 0; }
-		mm128 e[PER];
-		u64 kf[PER];
-		u32 dg[PER];
+		u64 y[PER];
 		u64 kmin = ~0ULL, kmax = 0;
-		for (int k = 0; k < PER; ++k) {
+#pragma unroll
+		for (int k = 0; k < PER; ++k) { const u32 i = t + (u32)k * THREADS; y[k] = lq_ps_load_y(sg, P, i < n ? i : n - 1); }   // (no branch: y[] stays in plain registers)
+#pragma unroll
+		for (int k = 0; k < PER; ++k) {                          // (x and y in two loads: x is dead once its key is in LDS, so the loads in flight need half the registers)
 			const u32 i = t + (u32)k * THREADS;
-			kf[k] = 0;
-			if (i < n) { e[k] = lq_ps_load(sg, P, i); kf[k] = lq_ckey(e[k].x, km) & km_mask; kmin = kf[k] < kmin ? kf[k] : kmin; kmax = kf[k] > kmax ? kf[k] : kmax; }
+			if (i < n) {
+				const u64 ck = lq_ckey(lq_ps_load_x(sg, P, i), km), kf = ck & km_mask;
+				if (i == 0) chigh_s = ck & ~km_mask;             // the key bits the whole segment shares
+				keys[i] = (KEY)kf;
+				if (sizeof(KEY) == 4) dgs[i] = (u16)(kf >> 32);
+				kmin = kf < kmin ? kf : kmin; kmax = kf > kmax ? kf : kmax;
+			}
 		}
 		// The sub-bucket digit is taken from the range the segment's keys really span, not from the top of the bits they might
 		// differ in: a child of a partition pass holds a few dozen targets and a stretch of positions, and the top SB bits of its
@@ -313,12 +332,20 @@ k_ps_finish(const PSeg *segs, const u32 *n_p, PsData P, KeyMap km, unsigned long
 		if ((t & 63) == 0) { rmin[t >> 6] = kmin; rmax[t >> 6] = kmax; }
 		__syncthreads();
 		for (u32 w = 0; w < THREADS / 64; ++w) { kmin = rmin[w] < kmin ? rmin[w] : kmin; kmax = rmax[w] > kmax ? rmax[w] : kmax; }
+		const u64 chigh = chigh_s;
 		const u64 range = kmax - kmin;
 		const u32 bits = range ? 64 - (u32)__builtin_clzll(range) : 0, sh = bits > (u32)SB ? bits - (u32)SB : 0;
 		const u64 lo_mask = ((u64)1 << sh) - 1;
-		for (int k = 0; k < PER; ++k) {
+#pragma unroll
+		for (int k = 0; k < PER; ++k) {                          // (a thread rewrites the entries of its own elements only)
 			const u32 i = t + (u32)k * THREADS;
-			if (i < n) { const u64 key = kf[k] - kmin; keys[i] = (KEY)(key & lo_mask); dg[k] = (u32)(key >> sh); atomicAdd(&hist[dg[k]], 1u); }
+			if (i < n) {
+				const u64 kf = sizeof(KEY) == 4 ? ((u64)dgs[i] << 32 | (u64)keys[i]) : (u64)keys[i];
+				const u64 key = kf - kmin;
+				const u32 d = (u32)(key >> sh);
+				keys[i] = (KEY)(key & lo_mask); dgs[i] = (u16)d;
+				atomicAdd(&hist[d], 1u);
+			}
 		}
 		__syncthreads();
 		{	// exclusive scan of hist -> beg: SPT counters per thread, wave scan, wave totals through LDS
@@ -334,25 +361,26 @@ k_ps_finish(const PSeg *segs, const u32 *n_p, PsData P, KeyMap km, unsigned long
 			for (int q = 0; q < SPT; ++q) { const u32 c = t * SPT + q; if (c < (u32)NSB) beg[c] = run; run += v[q]; }
 		}
 		__syncthreads();
+#pragma unroll
 		for (int k = 0; k < PER; ++k) {
 			const u32 i = t + (u32)k * THREADS;
-			if (i < n) perm[beg[dg[k]] + atomicAdd(&fill[dg[k]], 1u)] = (u16)i;
+			if (i < n) { const u32 d = dgs[i]; perm[beg[d] + atomicAdd(&fill[d], 1u)] = (u16)i; }
 		}
 		__syncthreads();
-		u32 pos[PER];
+#pragma unroll
 		for (int k = 0; k < PER; ++k) {
 			const u32 i = t + (u32)k * THREADS;
 			if (i < n) {
+				const u32 d = dgs[i];
 				const KEY key = keys[i];
-				const u32 b0 = beg[dg[k]], b1 = b0 + hist[dg[k]];
+				const u32 b0 = beg[d], b1 = b0 + hist[d];
 				u32 r = 0;
 				for (u32 j = b0; j < b1; ++j) r += keys[perm[j]] < key;
-				pos[k] = b0 + r;
+				mm128 e;
+				e.x = lq_ckey_inv(chigh | (kmin + ((u64)d << sh | (u64)key)), km);
+				e.y = y[k];
+				out[b0 + r] = e;
 			}
-		}
-		for (int k = 0; k < PER; ++k) {
-			const u32 i = t + (u32)k * THREADS;
-			if (i < n) out[pos[k]] = e[k];
 		}
 		__syncthreads();
 	}
