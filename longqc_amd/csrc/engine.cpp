@@ -33,6 +33,9 @@ template <class T> static void d2h(T *dst, const T *src, size_t n, hipStream_t s
 }
 static void dzero(void *p, size_t bytes, hipStream_t s) { if (bytes) LQ_HIP_CHECK(hipMemsetAsync(p, 0, bytes, s)); }
 static void check_launch() { LQ_HIP_CHECK(hipGetLastError()); }
+#ifndef LQ_EMU
+int lq_trace_launches = 0;
+#endif
 
 // ---- stage timing ---------------------------------------------------------------------------
 StageTimer::StageTimer(lqcov_handle *h_, hipStream_t s_, const char *name_, u64 bytes_) : h(h_), s(s_), name(name_), bytes(bytes_)
@@ -92,6 +95,10 @@ void Knobs::read_env()
 	chain_wave_min = (int)std::max<long>(0, num("LQCOV_CHAIN_WAVE_MIN", 0));
 	chain_cap = (int)num("LQCOV_CHAIN_CAP", 128);
 	run_stage = (u32)std::max<long>(1, num("LQCOV_RUN_STAGE", LQ_RUN_STAGE));
+	run_grid = (u32)std::max<long>(1, num("LQCOV_RUN_GRID", 2048));
+#ifndef LQ_EMU
+	lq_trace_launches = (int)num("LQCOV_TRACE_LAUNCHES", 0);
+#endif
 	no_level_skip = getenv("LQCOV_NO_LEVEL_SKIP") != nullptr;
 	debug_sort = getenv("LQCOV_DEBUG_SORT") != nullptr;
 	sketch_kpt = (u32)std::min<long>(64, std::max<long>(1, num("LQCOV_SKETCH_KPT", 4)));
@@ -615,11 +622,11 @@ void lqcov_handle::map_batch(MapLane &L, Part &pt, u32 q0, u32 q1, const std::ve
 	const u32 nqb = q1 - q0;
 	const u64 j0 = h_qmoff[q0], nj = h_qmoff[q1] - j0;
 	if (nA > 0xfffffff0ULL) throw std::domain_error("a single query produces more than 2^32 anchors against this part");
-	L.A.ensure((nA + 1) * 16); L.B.ensure((nA + 1) * 16);
+	const u64 nA4 = ((nA + 1) * 4 + 15) & ~(u64)15;
+	L.A.ensure((nA + 1) * 16); L.B.ensure(std::max<u64>((nA + 1) * 16, nA4 * 4));   // (B: the originals, then the chain's four 4-byte arrays of nA4 bytes each)
 	mm128 *dA = L.A.as<mm128>(), *dB = L.B.as<mm128>();
 	// 20 B per anchor of scratch: the X / Y position lists of the two-bucket passes (8 B) and the second record array (8 B, in
 	// the place of the chain's u[]) during the sort.  The chain's f/p/t/v (16 B per anchor) reuse B, which is dead once sorted.
-	const u64 nA4 = ((nA + 1) * 4 + 15) & ~(u64)15;
 	L.scr.ensure(nA4 * 5 + 64);
 	u64 *d_cu = (u64*)((u8*)L.scr.p + 3 * nA4);
 	i32 *d_cf = (i32*)L.B.p, *d_cp = (i32*)((u8*)L.B.p + nA4), *d_ct = (i32*)((u8*)L.B.p + 2 * nA4), *d_cv = (i32*)((u8*)L.B.p + 3 * nA4);
@@ -646,7 +653,7 @@ void lqcov_handle::map_batch(MapLane &L, Part &pt, u32 q0, u32 q1, const std::ve
 			dzero(L.run_tiles.p, 4, L.stream);
 			{
 				StageTimer t(this, L.stream, "k_run_list", nA * 16);
-				LQ_LAUNCH(k_run_list, std::min<u32>(n_tiles, 2048), LQ_RUN_THREADS, L.stream, dA, nA, aqb, a_base, nqb, n_tiles, n_min, std::max<u32>(LQ_RUN_THREADS, std::min<u32>(K.run_stage, LQ_RUN_STAGE)), L.run_tiles.as<u32>(), L.gstart.as<u64>()); check_launch();
+				LQ_LAUNCH(k_run_list, std::min<u32>(n_tiles, K.run_grid), LQ_RUN_THREADS, L.stream, dA, nA, aqb, a_base, nqb, n_tiles, n_min, std::max<u32>(LQ_RUN_THREADS, std::min<u32>(K.run_stage, LQ_RUN_STAGE)), L.run_tiles.as<u32>(), L.gstart.as<u64>()); check_launch();
 			}
 			u32 ng = 0;
 			d2h(&ng, L.run_tiles.as<u32>(), 1, L.stream);

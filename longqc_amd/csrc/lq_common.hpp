@@ -2,7 +2,13 @@
 #pragma once
 #ifndef LQ_EMU
 #include <hip/hip_runtime.h>
-#define LQ_LAUNCH(kern, grid, block, stream, ...) hipLaunchKernelGGL(kern, dim3(grid), dim3(block), 0, stream, __VA_ARGS__)
+#include <cstdio>
+// LQCOV_TRACE_LAUNCHES=1: every launch is named on stderr and waited for -- the last name before a GPU fault is the kernel at fault
+extern int lq_trace_launches;
+#define LQ_LAUNCH(kern, grid, block, stream, ...) do { \
+		if (lq_trace_launches) { fprintf(stderr, "[lqcov] launch %s grid %u\n", #kern, (unsigned)dim3(grid).x); fflush(stderr); } \
+		hipLaunchKernelGGL(kern, dim3(grid), dim3(block), 0, stream, __VA_ARGS__); \
+		if (lq_trace_launches) (void)hipStreamSynchronize(stream); } while (0)
 #endif
 #include <cstdint>
 #include <cstddef>

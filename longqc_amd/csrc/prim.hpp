@@ -47,6 +47,9 @@ struct DBuf {
 		if (bytes <= cap) return;
 		release();
 		size_t want = bytes + bytes / 8 + 256;
+#ifdef LQ_EXACT_ALLOC
+		want = bytes;                                              // (tools/emu_asan.sh: no slack, so that AddressSanitizer sees the first byte past what was asked for)
+#endif
 #ifndef LQ_EMU
 		if (lq_alloc_stream) {
 			want = bytes + bytes / 8 + 4096;

@@ -47,10 +47,12 @@ def read_gz(name):
 def emu_lib():
     """tests/emu/liblqcov_emu.so: the product's kernel sources compiled as plain C++ against the serial
     HIP stand-in (tests/emu/hipemu.hpp).  Test-only; checks kernel *logic* without a GPU."""
+    from longqc_amd import api
+    if os.environ.get("LQCOV_EMU_LIB"):                  # e.g. an AddressSanitizer build of the same sources (tools/emu_asan.sh)
+        return api.load_library(os.environ["LQCOV_EMU_LIB"])
     csrc = os.path.join(ROOT, "longqc_amd", "csrc")
     r = subprocess.run(["make", "-C", csrc, "emu"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     assert r.returncode == 0, r.stdout[-3000:]
-    from longqc_amd import api
     return api.load_library(os.path.join(ROOT, "tests", "emu", "liblqcov_emu.so"))
 
 

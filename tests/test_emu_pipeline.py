@@ -364,6 +364,11 @@ def check_run_list_variants(lib, tmp_path, monkeypatch):
         assert rc == 0, err
         assert out == want, budget
     monkeypatch.delenv("LQCOV_ANCHOR_BUDGET", raising=False)
+    for grid in ("1", "3"):                        # a block walks all the tiles | a third of them: the tile's query from the previous tile, entries of several tiles staged together
+        monkeypatch.setenv("LQCOV_RUN_GRID", grid)
+        rc, out, err = run_main(lib, argv)
+        assert rc == 0, err
+        assert out == want, grid
     # the list's LDS staging (k_run_list): room for 256 entries (the least it takes), so that a block's tiles flush it again
     # and again, row by row where a tile may hold more entries than that; -n 1 -m 10: every run of one anchor is listed
     monkeypatch.setenv("LQCOV_RUN_STAGE", "256")
@@ -372,7 +377,7 @@ def check_run_list_variants(lib, tmp_path, monkeypatch):
     assert out == want
     argv1 = ["-Y", "-l", "0", "-q", "40", "-k", "12", "-w", "5", "-I", "4G", "-p", "40", "-m", "10", "-n", "1", "-t", "4", tf, qf]
     want1 = oracle_bind.ref_table(argv1) if oracle_bind.have_ref() else oracle_bind.table(argv1)
-    for stage in ("256", ""):
+    for stage in ("256", ""):                      # (still with three blocks)
         monkeypatch.setenv("LQCOV_RUN_STAGE", stage) if stage else monkeypatch.delenv("LQCOV_RUN_STAGE", raising=False)
         rc, out, err = run_main(lib, argv1)
         assert rc == 0, err
