@@ -6,9 +6,10 @@
 // LQCOV_TRACE_LAUNCHES=1: every launch is named on stderr and waited for -- the last name before a GPU fault is the kernel at fault
 extern int lq_trace_launches;
 #define LQ_LAUNCH(kern, grid, block, stream, ...) do { \
-		if (lq_trace_launches) { fprintf(stderr, "[lqcov] launch %s grid %u\n", #kern, (unsigned)dim3(grid).x); fflush(stderr); } \
+		if (lq_trace_launches) { fprintf(stderr, "[lqcov] launch %s grid %u stream %p\n", #kern, (unsigned)dim3(grid).x, (void*)(stream)); fflush(stderr); } \
 		hipLaunchKernelGGL(kern, dim3(grid), dim3(block), 0, stream, __VA_ARGS__); \
-		if (lq_trace_launches) (void)hipStreamSynchronize(stream); } while (0)
+		if (lq_trace_launches) { hipError_t e_ = hipStreamSynchronize(stream); \
+			if (e_ != hipSuccess) { fprintf(stderr, "[lqcov] FAILED (%s) at the end of %s stream %p\n", hipGetErrorString(e_), #kern, (void*)(stream)); fflush(stderr); } } } while (0)
 #endif
 #include <cstdint>
 #include <cstddef>
