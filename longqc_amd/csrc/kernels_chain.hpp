@@ -81,6 +81,7 @@ k_run_list(const mm128 *A, u64 n, const u64 *aq_off, u64 a_base, u32 n_q, u32 n_
 	u32 qlo = ~0u;                                                // the query that holds the tile's first anchor
 	if (t < 2) hb[LQ_RUN_TILE / 32 + t] = 0;
 	if (t == 0) fill_s = 0;
+	__syncthreads();                                              // (a block without tiles reads fill_s right away, at the end)
 	// the staged entries go to the list (block-uniform call; f = fill_s read between two barriers)
 #define LQ_RUN_FLUSH(f) do { if (t == 0) slot0 = atomicAdd(n_runs, (f)); __syncthreads(); \
 		for (u32 i_ = t; i_ < (f); i_ += LQ_RUN_THREADS) runs[slot0 + i_] = stg[i_]; \
