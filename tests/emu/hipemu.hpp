@@ -32,7 +32,10 @@
 #define __forceinline__ inline
 #define __launch_bounds__(...)
 #define __restrict__
-#define __shared__ static
+// LDS: statics collected in one section, so that the emulator can fill all of it with a poison pattern before every block
+// (on the GPU a block finds what other kernels left in the CU's LDS, not what the previous block of this kernel wrote)
+#define __shared__ static __attribute__((section("emu_lds")))
+extern "C" char __start_emu_lds[] __attribute__((weak)), __stop_emu_lds[] __attribute__((weak));
 
 struct dim3 { unsigned x, y, z; dim3(unsigned a = 1, unsigned b = 1, unsigned c = 1) : x(a), y(b), z(c) {} };
 struct emu_idx3 { unsigned x, y, z; };
@@ -136,13 +139,17 @@ inline void emu_die(const char *msg) { std::fprintf(stderr, "hipemu: %s (block %
 
 // leave the running fiber: straight into the next ready fiber of the block (round robin), or back to the scheduler
 // when nobody is ready (everything finished, or a deadlock for it to report)
+// LQ_EMU_ORDER=reverse: the highest ready thread runs first (default: the lowest) -- "thread 0 writes, the others read"
+// without a barrier in between goes unnoticed when thread 0 always runs first
+inline int g_emu_rev = 0;                        // (read from the environment at the start of every block: tests switch it)
+inline int emu_reverse() { return g_emu_rev; }
 inline void emu_yield()
 {
 	const int me = g_emu.cur;
 	const unsigned n = g_emu.n;
-	unsigned t = (unsigned)me + 1;
-	for (unsigned i = 0; i < n; ++i, ++t) {
-		if (t >= n) t = 0;
+	const bool rev = emu_reverse();
+	unsigned t = rev ? ((unsigned)me + n - 1) % n : ((unsigned)me + 1) % n;
+	for (unsigned i = 0; i < n; ++i, t = rev ? (t + n - 1) % n : (t + 1) % n) {
 		if (g_emu.state[t] == EMU_READY) {
 			if ((int)t == me) return;                    // (released by its own arrival)
 			g_emu.cur = (int)t;
@@ -218,6 +225,8 @@ inline void emu_run_block(unsigned nthreads, void (*body)(void *), void *arg)
 		if (g_emu.stacks == (char*)MAP_FAILED) emu_die("cannot map fiber stacks");
 	}
 	g_emu.n = nthreads; g_emu.body = body; g_emu.body_arg = arg;
+	{ const char *e = std::getenv("LQ_EMU_ORDER"); g_emu_rev = e && e[0] == 'r'; }
+	if (__start_emu_lds && __stop_emu_lds > __start_emu_lds) std::memset(__start_emu_lds, 0xA5, (size_t)(__stop_emu_lds - __start_emu_lds));
 	g_emu.block_arrived = 0; g_emu.block_live = (int)nthreads;
 	for (unsigned w = 0; w < (nthreads + 63) / 64; ++w) {
 		g_emu.wave_arrived[w] = 0; g_emu.wave_gen[w] = 0;
@@ -235,8 +244,8 @@ inline void emu_run_block(unsigned nthreads, void (*body)(void *), void *arg)
 	for (unsigned t = 0; t < nthreads; ++t) g_emu.tidx[t] = { t % blockDim.x, (t / blockDim.x) % blockDim.y, t / (blockDim.x * blockDim.y) };
 	for (;;) {                                               // fibers hand over to each other; control returns here when none is ready
 		unsigned t = 0;
-		while (t < nthreads && g_emu.state[t] != EMU_READY) ++t;
-		if (t == nthreads) break;
+		if (emu_reverse()) { t = nthreads; while (t > 0 && g_emu.state[t - 1] != EMU_READY) --t; if (t == 0) break; --t; }
+		else { while (t < nthreads && g_emu.state[t] != EMU_READY) ++t; if (t == nthreads) break; }
 		g_emu.cur = (int)t;
 		threadIdx = g_emu.tidx[t];
 		emu_ctx_switch(&g_emu.sched_sp, g_emu.sp[t]);

@@ -364,11 +364,16 @@ def check_run_list_variants(lib, tmp_path, monkeypatch):
         assert rc == 0, err
         assert out == want, budget
     monkeypatch.delenv("LQCOV_ANCHOR_BUDGET", raising=False)
-    for grid in ("1", "3"):                        # a block walks all the tiles | a third of them: the tile's query from the previous tile, entries of several tiles staged together
+    # a block walks all the tiles | a third of them (the tile's query from the previous tile, entries of several tiles staged
+    # together) | grids that leave the last blocks without a tile; the emulator's threads once in descending order (a block
+    # without tiles read the LDS counter before thread 0 had cleared it: on the GPU, whatever another kernel left there)
+    for grid, order in (("1", ""), ("3", ""), ("7", "reverse"), ("10", "reverse"), ("13", ""), ("29", "reverse")):
         monkeypatch.setenv("LQCOV_RUN_GRID", grid)
+        monkeypatch.setenv("LQ_EMU_ORDER", order)
         rc, out, err = run_main(lib, argv)
         assert rc == 0, err
         assert out == want, grid
+    monkeypatch.delenv("LQ_EMU_ORDER", raising=False)
     # the list's LDS staging (k_run_list): room for 256 entries (the least it takes), so that a block's tiles flush it again
     # and again, row by row where a tile may hold more entries than that; -n 1 -m 10: every run of one anchor is listed
     monkeypatch.setenv("LQCOV_RUN_STAGE", "256")
