@@ -81,7 +81,7 @@ void Knobs::read_env()
 {
 	auto num = [](const char *name, long dflt) { const char *e = getenv(name); return e && *e ? atol(e) : dflt; };
 	auto is = [](const char *name, const char *val) { const char *e = getenv(name); return e && !strcmp(e, val); };
-	lanes = (int)std::min<long>(8, std::max<long>(1, num("LQCOV_LANES", 4)));
+	lanes = (int)std::min<long>(8, std::max<long>(1, num("LQCOV_LANES", 5)));
 	anchor_budget = getenv("LQCOV_ANCHOR_BUDGET") ? strtoull(getenv("LQCOV_ANCHOR_BUDGET"), 0, 10) : 0;
 	query_order_file = is("LQCOV_QUERY_ORDER", "file");
 	all_klib = is("LQCOV_SORT", "klib");

@@ -25,7 +25,7 @@ struct StageAcc { double ms = 0; u64 launches = 0; u64 bytes = 0; };
 
 // Environment switches, read once when the handle is made (test and A/B aids; the defaults are the measured choice).
 struct Knobs {
-	int lanes = 4;                        // LQCOV_LANES: concurrent mapping lanes (measured at configs[2]: 1 lane 2.47 s per step, 2: 1.96, 4: 1.85)
+	int lanes = 5;                        // LQCOV_LANES: concurrent mapping lanes (measured at configs[2], ms per step: 1 lane 1882, 3: 1582, 4: 1532, 5: 1510, 6: 1508, 8: 1610)
 	u64 anchor_budget = 0;                // LQCOV_ANCHOR_BUDGET: anchors per query batch (0 = from free HBM)
 	bool query_order_file = false;        // LQCOV_QUERY_ORDER=file: keep the caller's query order inside
 	bool all_klib = false;                // LQCOV_SORT=klib: every query through klib's passes, no bucket leaves them early

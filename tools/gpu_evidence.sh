@@ -22,13 +22,13 @@ cp /tmp/prof/b_kernel_stats.csv $GRAFT_REPO_ROOT/gpurun_out/kernel_stats_bench_c
 echo "rocprof done $(( $(date +%s) - T0 )) s" >> $GRAFT_REPO_ROOT/gpurun_out/pytest_gpu.log
 if [ "$PMC" = 1 ]; then
   R=$GRAFT_REPO_ROOT
-  RE=${PMC_RE:-'k_ps_finish|k_rs_scatter|k_rs_hist|k_sort_walk_solo|k_chain|k_sort_two_tiled|k_rs_children|k_ps_scatter|k_seed_emit|k_sketch'}
+  RE=${PMC_RE:-'k_ps_finish|k_rs_scatter|k_rs_hist|k_sort_walk_solo|k_chain|k_sort_two_tiled|k_rs_children|k_ps_scatter|k_seed_emit|k_sketch|k_run_list|k_ck_solve'}
   BP="python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline $C"
   for CN in FETCH_SIZE WRITE_SIZE; do
     ( timeout ${PMC_LIMIT:-300} rocprofv3 --pmc $CN --kernel-trace --kernel-include-regex "$RE" --output-format csv -d /tmp/pmc_$CN -o p -- $BP 2>&1 | tail -3 ) > $R/gpurun_out/pmc_$CN.log 2>&1
     echo "pmc $CN done $(( $(date +%s) - T0 )) s" >> $R/gpurun_out/pytest_gpu.log
   done
-  python $R/tools/pmc_to_json.py /tmp/pmc_FETCH_SIZE /tmp/pmc_WRITE_SIZE $R/gpurun_out/pmc_traffic.json "bench.py --config cfg3 (configs[2]: 500000 reads, 5000 queries), 4 lanes, 2 passes; counters for: $RE" > $R/gpurun_out/pmc_summary.txt 2>&1
+  python $R/tools/pmc_to_json.py /tmp/pmc_FETCH_SIZE /tmp/pmc_WRITE_SIZE $R/gpurun_out/pmc_traffic.json "bench.py --config cfg3 (configs[2]: 500000 reads, 5000 queries), default lanes, 1 step; counters for: $RE" > $R/gpurun_out/pmc_summary.txt 2>&1
 fi
 cd $GRAFT_REPO_ROOT
 echo "all done $(( $(date +%s) - T0 )) s" >> gpurun_out/pytest_gpu.log
