@@ -120,15 +120,10 @@ lqcov_handle::lqcov_handle(const lqcov_params &p, int dev) : P(p), device(dev)
 	if (dev < 0 || dev >= ndev) throw std::runtime_error("HIP device index out of range");
 	LQ_HIP_CHECK(hipSetDevice(dev));
 	LQ_HIP_CHECK(hipStreamCreate(&stream));
-	{	// the build side (upload, sketch, index of the next part) runs under the mapping of the current one: with the priority of
-		// the lanes' streams its kernels get a sixth of the device and the part is ready just in time (configs[2]: sketch of part 2
-		// 560 ms under five lanes, 21 ms alone); a higher priority lets it through
-		int lo = 0, hi = 0;
-		if (getenv("LQCOV_BUILD_PRIO") && atoi(getenv("LQCOV_BUILD_PRIO")) == 0) { LQ_HIP_CHECK(hipStreamCreate(&bstream)); }
-		else if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess || hipStreamCreateWithPriority(&bstream, hipStreamDefault, hi) != hipSuccess) {
-			(void)hipGetLastError(); LQ_HIP_CHECK(hipStreamCreate(&bstream));
-		}
-	}
+	// (the build side -- upload, sketch, index of the next part -- runs under the mapping of the current one at the lanes' own
+	// priority: its kernels get a sixth of the device and stretch (configs[2]: sketch of part 2 560 ms under five lanes, 21 ms
+	// alone) but the part is ready in time; a high-priority build stream was measured slower: 1544-1567 vs 1508-1519 ms per step)
+	LQ_HIP_CHECK(hipStreamCreate(&bstream));
 	lq_pool_keep_memory(dev);
 	prim.stream = stream; bprim.stream = bstream;
 	mp.k = P.k; mp.w = P.w; mp.hpc = P.hpc;
