@@ -54,7 +54,9 @@ __device__ __forceinline__ u64 lq_ps_load_x(const PSeg &sg, const PsData &P, u32
 
 #define LQ_PS_FIN_SMALL 1024
 #define LQ_PS_FIN_BIG   8192
+#ifndef LQ_PS_TILE
 #define LQ_PS_TILE      2048
+#endif
 #define LQ_PS_CHILD     4096      // aimed child size of a partition pass: half of what the finish takes
 #define LQ_PS_THREADS   256
 
@@ -312,13 +314,22 @@ k_ps_finish(const PSeg *segs, const u32 *n_p, PsData P, KeyMap km, unsigned long
 		for (u32 c = t; c < NSB; c += THREADS) { hist[c] = 0; fill[c] = 0; }
 		u64 y[PER];
 		u64 kmin = ~0ULL, kmax = 0;
+		// PER > 4 (the 1024-thread shape): x and y in two loads -- x is dead once its key is in LDS, so the loads in flight need half
+		// the registers (64 in all: two blocks per CU).  PER <= 4: one 16-byte load per anchor; most of these segments are read
+		// through records, and two 8-byte gathers cost twice the sectors of one 16-byte gather (PMC: 8.6 vs 6.2 GB per launch)
+		constexpr bool SPLIT = PER > 4;
+		u64 xk[SPLIT ? 1 : PER];
 #pragma unroll
-		for (int k = 0; k < PER; ++k) { const u32 i = t + (u32)k * THREADS; y[k] = lq_ps_load_y(sg, P, i < n ? i : n - 1); }   // (no branch: y[] stays in plain registers)
+		for (int k = 0; k < PER; ++k) {
+			const u32 i = t + (u32)k * THREADS, ic = i < n ? i : n - 1;   // (no branch: y[] stays in plain registers)
+			if (SPLIT) y[k] = lq_ps_load_y(sg, P, ic);
+			else { const mm128 e = lq_ps_load(sg, P, ic); y[k] = e.y; xk[k] = e.x; }
+		}
 #pragma unroll
-		for (int k = 0; k < PER; ++k) {                          // (x and y in two loads: x is dead once its key is in LDS, so the loads in flight need half the registers)
+		for (int k = 0; k < PER; ++k) {
 			const u32 i = t + (u32)k * THREADS;
 			if (i < n) {
-				const u64 ck = lq_ckey(lq_ps_load_x(sg, P, i), km), kf = ck & km_mask;
+				const u64 ck = lq_ckey(SPLIT ? lq_ps_load_x(sg, P, i) : xk[SPLIT ? 0 : k], km), kf = ck & km_mask;
 				if (i == 0) chigh_s = ck & ~km_mask;             // the key bits the whole segment shares
 				keys[i] = (KEY)kf;
 				if (sizeof(KEY) == 4) dgs[i] = (u16)(kf >> 32);
