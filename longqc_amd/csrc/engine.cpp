@@ -645,6 +645,17 @@ void lqcov_handle::map_batch(MapLane &L, Part &pt, u32 q0, u32 q1, const std::ve
 	if (nA) {
 		const u64 *aqb = aq_off.as<u64>() + q0;          // batch view of the per-query anchor offsets
 		sort_batch(L, pt, q0, nqb, a_base, nA);           // lqmap.c:238
+		if (K.debug_sort) {	// every query ascending in x; anchors with equal x must both carry the tie mark (else the parallel sort may have seen them)
+			std::vector<mm128> ha(nA);
+			d2h(ha.data(), dA, nA, L.stream);
+			u64 unsorted = 0, ties = 0, unmarked = 0;
+			for (u32 q = q0; q < q1; ++q)
+				for (u64 i = h_aq[q] - a_base + 1; i < h_aq[q + 1] - a_base; ++i) {
+					if (ha[i].x < ha[i - 1].x) ++unsorted;
+					if (ha[i].x == ha[i - 1].x) { ++ties; if (!(ha[i].y & LQ_TIE_MARK) || !(ha[i - 1].y & LQ_TIE_MARK)) { if (unmarked++ < 4) fprintf(stderr, "[sort] query %u: equal x %016llx, y %016llx / %016llx\n", q, (unsigned long long)ha[i].x, (unsigned long long)ha[i - 1].y, (unsigned long long)ha[i].y); } }
+				}
+			fprintf(stderr, "[sort] batch %u..%u: %llu anchors, %llu out of order, %llu equal-x neighbours, %llu of them with an unmarked anchor\n", q0, q1, (unsigned long long)nA, (unsigned long long)unsorted, (unsigned long long)ties, (unsigned long long)unmarked);
+		}
 		// ---- (strand, rid) runs long enough to hold a chain ----
 		u64 n_groups = 0;
 		{

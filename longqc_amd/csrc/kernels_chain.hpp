@@ -83,9 +83,12 @@ k_run_list(const mm128 *A, u64 n, const u64 *aq_off, u64 a_base, u32 n_q, u32 n_
 	if (t == 0) fill_s = 0;
 	__syncthreads();                                              // (a block without tiles reads fill_s right away, at the end)
 	// the staged entries go to the list (block-uniform call; f = fill_s read between two barriers)
-#define LQ_RUN_FLUSH(f) do { if (t == 0) slot0 = atomicAdd(n_runs, (f)); __syncthreads(); \
+#define LQ_RUN_FLUSH(f) do { \
+		if (t == 0) { slot0 = atomicAdd(n_runs, (f)); } \
+		__syncthreads(); \
 		for (u32 i_ = t; i_ < (f); i_ += LQ_RUN_THREADS) runs[slot0 + i_] = stg[i_]; \
-		if (t == 0) fill_s = 0; __syncthreads(); } while (0)
+		if (t == 0) { fill_s = 0; } \
+		__syncthreads(); } while (0)
 	for (u32 T = T0; T < T1; ++T) {
 		const u64 base = (u64)T * LQ_RUN_TILE;
 		const u32 tl = n - base < LQ_RUN_TILE ? (u32)(n - base) : LQ_RUN_TILE;

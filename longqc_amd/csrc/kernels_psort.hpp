@@ -89,7 +89,10 @@ __device__ __forceinline__ u32 lq_rem_below(u32 shift, const KeyMap km)
 // append a segment to the list its size asks for (big_slot: LQ_P_BIG0 or LQ_P_BIG1)
 __device__ __forceinline__ void lq_ps_route(PSeg sg, const PsLists L, u32 big_slot)
 {
-	if (sg.len <= L.fin_s_max) { const u32 s = atomicAdd(&L.cnt[LQ_P_FIN_S], 1u); if (s < L.cap_fin) L.fin_s[s] = sg; else atomicOr(&L.cnt[LQ_P_OVERFLOW], 1u); }
+	// (rem == 0: nothing to sort, only to bring home to A *in the order it is in* -- a bucket of klib's last pass holds one x, and
+	// the order of its anchors is klib's; the finishing kernels copy such a segment in order whatever its length, a partition
+	// pass would move it in the order its atomics happen to give)
+	if (sg.len <= L.fin_s_max || sg.rem == 0) { const u32 s = atomicAdd(&L.cnt[LQ_P_FIN_S], 1u); if (s < L.cap_fin) L.fin_s[s] = sg; else atomicOr(&L.cnt[LQ_P_OVERFLOW], 1u); }
 	else if (sg.len <= L.fin_b_max) { const u32 s = atomicAdd(&L.cnt[LQ_P_FIN_B], 1u); if (s < L.cap_fin) L.fin_b[s] = sg; else atomicOr(&L.cnt[LQ_P_OVERFLOW], 1u); }
 	else { const u32 s = atomicAdd(&L.cnt[big_slot], 1u); if (s < L.cap_big) L.big[big_slot][s] = sg; else atomicOr(&L.cnt[LQ_P_OVERFLOW], 1u); }
 }
@@ -290,7 +293,7 @@ __device__ __forceinline__ u64 lq_ckey_inv(u64 ck, const KeyMap km)
 	return (ck & ((1ULL << km.pbits) - 1)) | ((ck >> km.pbits) & ((1ULL << km.rbits) - 1)) << 32 | ((ck >> (km.pbits + km.rbits)) & 1) << 63;
 }
 template <int CAP, int THREADS, int SB, class KEY>
-__global__ void __launch_bounds__(THREADS, 8)
+__global__ void __launch_bounds__(THREADS, (sizeof(KEY) == 4 || THREADS < 1024 ? 8 : 4))
 k_ps_finish(const PSeg *segs, const u32 *n_p, PsData P, KeyMap km, unsigned long long *tally)
 {
 	constexpr int NSB = 1 << SB, PER = CAP / THREADS, SPT = NSB / THREADS > 0 ? NSB / THREADS : 1;

@@ -25,6 +25,8 @@
 #include <chrono>
 #include <vector>
 #include <sys/mman.h>
+#include <dlfcn.h>
+#include <elf.h>
 
 #define __global__
 #define __device__
@@ -141,6 +143,7 @@ inline void emu_die(const char *msg) { std::fprintf(stderr, "hipemu: %s (block %
 // when nobody is ready (everything finished, or a deadlock for it to report)
 // LQ_EMU_ORDER=reverse: the highest ready thread runs first (default: the lowest) -- "thread 0 writes, the others read"
 // without a barrier in between goes unnoticed when thread 0 always runs first
+inline const char *g_emu_kernel = "";             // name of the kernel being launched (LQ_EMU_ORDER_KERNEL=<substring>: the order applies to it alone)
 inline int g_emu_rev = 0;                        // (read from the environment at the start of every block: tests switch it)
 inline int emu_reverse() { return g_emu_rev; }
 inline void emu_yield()
@@ -217,6 +220,55 @@ extern "C" inline void emu_fiber_main()
 	emu_die("finished fiber resumed");
 }
 
+// LDS of the kernel templates: GCC does not honour the section attribute for statics of templates (they are unique global
+// objects, "_ZZ<n>k_...E<name>" in the library's dynamic symbol table); found once by reading the library's own ELF headers
+struct EmuRegion { char *p; size_t n; };
+inline std::vector<EmuRegion> &emu_template_lds()
+{
+	static std::vector<EmuRegion> regs;
+	static bool done = false;
+	if (done) return regs;
+	done = true;
+	Dl_info di;
+	if (!dladdr((void*)&g_emu, &di) || !di.dli_fname) return regs;
+	FILE *f = std::fopen(di.dli_fname, "rb");
+	if (!f) return regs;
+	std::vector<char> img;
+	std::fseek(f, 0, SEEK_END); const long sz = std::ftell(f); std::fseek(f, 0, SEEK_SET);
+	img.resize(sz > 0 ? (size_t)sz : 0);
+	if (sz <= 0 || std::fread(img.data(), 1, (size_t)sz, f) != (size_t)sz) { std::fclose(f); return regs; }
+	std::fclose(f);
+	const Elf64_Ehdr *eh = (const Elf64_Ehdr*)img.data();
+	if (std::memcmp(eh->e_ident, ELFMAG, SELFMAG) != 0 || eh->e_shoff == 0) return regs;
+	const Elf64_Shdr *sh = (const Elf64_Shdr*)(img.data() + eh->e_shoff);
+	for (unsigned i = 0; i < eh->e_shnum; ++i) {
+		if (sh[i].sh_type != SHT_DYNSYM) continue;
+		const Elf64_Sym *sym = (const Elf64_Sym*)(img.data() + sh[i].sh_offset);
+		const char *str = img.data() + sh[sh[i].sh_link].sh_offset;
+		const size_t n = sh[i].sh_size / sizeof(Elf64_Sym);
+		for (size_t k = 0; k < n; ++k) {
+			if (ELF64_ST_TYPE(sym[k].st_info) != STT_OBJECT || sym[k].st_size == 0 || sym[k].st_shndx == SHN_UNDEF || sym[k].st_shndx >= eh->e_shnum) continue;
+			if (!(sh[sym[k].st_shndx].sh_flags & SHF_WRITE)) continue;
+			const char *nm = str + sym[k].st_name;
+			if (nm[0] != '_' || nm[1] != 'Z' || nm[2] != 'Z') continue;
+			const char *q = nm + 3;
+			while (*q >= '0' && *q <= '9') ++q;
+			if (q == nm + 3 || q[0] != 'k' || q[1] != '_') continue;     // a static of a function k_...
+			regs.push_back({(char*)di.dli_fbase + sym[k].st_value, (size_t)sym[k].st_size});
+		}
+	}
+	if (std::getenv("LQ_EMU_VERBOSE")) { size_t tot = 0; for (const EmuRegion &r : regs) tot += r.n; std::fprintf(stderr, "hipemu: %zu LDS arrays of kernel templates, %zu bytes\n", regs.size(), tot); }
+	return regs;
+}
+// on the GPU a block finds what other kernels left in the CU's LDS, not what the previous block of this kernel wrote
+inline void emu_poison_lds()
+{
+	static const bool off = std::getenv("LQ_EMU_NOPOISON") != nullptr;
+	if (off) return;
+	if (__start_emu_lds && __stop_emu_lds > __start_emu_lds) std::memset(__start_emu_lds, 0xA5, (size_t)(__stop_emu_lds - __start_emu_lds));
+	for (const EmuRegion &r : emu_template_lds()) std::memset(r.p, 0xA5, r.n);
+}
+
 inline void emu_run_block(unsigned nthreads, void (*body)(void *), void *arg)
 {
 	if (nthreads > EMU_MAX_THREADS) emu_die("block larger than 1024 threads");
@@ -225,8 +277,10 @@ inline void emu_run_block(unsigned nthreads, void (*body)(void *), void *arg)
 		if (g_emu.stacks == (char*)MAP_FAILED) emu_die("cannot map fiber stacks");
 	}
 	g_emu.n = nthreads; g_emu.body = body; g_emu.body_arg = arg;
-	{ const char *e = std::getenv("LQ_EMU_ORDER"); g_emu_rev = e && e[0] == 'r'; }
-	if (__start_emu_lds && __stop_emu_lds > __start_emu_lds) std::memset(__start_emu_lds, 0xA5, (size_t)(__stop_emu_lds - __start_emu_lds));
+	{ const char *e = std::getenv("LQ_EMU_ORDER"); g_emu_rev = e && e[0] == 'r';
+	  const char *o = std::getenv("LQ_EMU_ORDER_THREADS"); if (o && (unsigned)std::atoi(o) != nthreads) g_emu_rev = 0;
+	  const char *k = std::getenv("LQ_EMU_ORDER_KERNEL"); if (k && !std::strstr(g_emu_kernel, k)) g_emu_rev = 0; }   // (only blocks of that many threads: narrows a finding down)
+	emu_poison_lds();
 	g_emu.block_arrived = 0; g_emu.block_live = (int)nthreads;
 	for (unsigned w = 0; w < (nthreads + 63) / 64; ++w) {
 		g_emu.wave_arrived[w] = 0; g_emu.wave_gen[w] = 0;
@@ -324,4 +378,4 @@ inline void emu_launch(K kern, dim3 g, dim3 b, A... args)
 		emu_run_block(b.x * b.y * b.z, &emu_body_thunk<decltype(body)>, &body);
 	}
 }
-#define LQ_LAUNCH(kern, grid, block, stream, ...) emu_launch(kern, dim3(grid), dim3(block), __VA_ARGS__)
+#define LQ_LAUNCH(kern, grid, block, stream, ...) do { g_emu_kernel = #kern; emu_launch(kern, dim3(grid), dim3(block), __VA_ARGS__); } while (0)

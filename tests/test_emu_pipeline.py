@@ -519,3 +519,20 @@ def test_emulated_parallel_sort_size_classes(emu_lib, datasets, monkeypatch):
         rc, out, err = run_main(emu_lib, argv)
         assert rc == 0, err
         assert out == want, passes
+
+
+@pytest.mark.parametrize("case", [c for c in _cases("table") if c["name"] in ("tiny_ont", "adv_parts", "adv_ava_parts")] or _cases("table")[:2], ids=lambda c: c["name"])
+def test_emulated_threads_in_descending_order(emu_lib, case, monkeypatch):
+    """The emulator runs a block's threads lowest first by default and fills the kernels' LDS with a pattern before every
+    block (tests/emu/hipemu.hpp).  With the highest thread first, "thread 0 initialises, the others read" without a barrier in
+    between reads the pattern -- on the GPU: whatever another lane's kernel left in the CU's LDS (round 3's k_run_list fault).
+    The shrunken size classes send the sort through every kernel family on these small inputs."""
+    monkeypatch.setenv("LQ_EMU_ORDER", "reverse")
+    for env in ({}, {"LQCOV_PS_SHIFT": "7", "LQCOV_WALK_SHIFT": "6", "LQCOV_SORT": "klib"}, {"LQCOV_RUN_GRID": "7", "LQCOV_RUN_STAGE": "256"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        rc, out, err = run_main(emu_lib, case["argv"], cwd=GOLDEN)
+        assert rc == 0, err
+        assert out == read_gz(case["expect"]), env
+        for k in env:
+            monkeypatch.delenv(k)
