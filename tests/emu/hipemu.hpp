@@ -16,6 +16,16 @@
 // therefore sit in wave-uniform control flow (the kernels are written that way for the GPU too);
 // lanes meeting at different kinds of collectives abort the process with a message.  __shared__
 // is `static` (one block at a time); atomics are plain read-modify-write.  Wave size 64.
+//
+// What the GPU does differently and the emulator imitates on request (environment, read at every block):
+//   * LDS is filled with 0xA5 before every block: a block on the GPU finds what other kernels left in the CU's LDS.
+//     (LQ_EMU_NOPOISON=1 turns that off.)
+//   * LQ_EMU_ORDER=reverse: the highest ready thread runs first instead of the lowest; LQ_EMU_ORDER=random[:seed]: a random
+//     ready one.  LQ_EMU_ORDER_KERNEL=<substring of the kernel's name> / LQ_EMU_ORDER_THREADS=<block size> restrict that
+//     to some launches: the way to find which kernel a result depends on.
+//   Round 3 found two defects this way that every test on the GPU had passed: a missing barrier after clearing an LDS
+//   counter (k_run_list; a fault only beside other lanes' kernels), and tied anchors moved by a partition pass in the order
+//   of its atomics (lq_ps_route).
 #pragma once
 #include <cstdint>
 #include <cstdlib>
@@ -142,17 +152,21 @@ inline void emu_die(const char *msg) { std::fprintf(stderr, "hipemu: %s (block %
 // leave the running fiber: straight into the next ready fiber of the block (round robin), or back to the scheduler
 // when nobody is ready (everything finished, or a deadlock for it to report)
 // LQ_EMU_ORDER=reverse: the highest ready thread runs first (default: the lowest) -- "thread 0 writes, the others read"
-// without a barrier in between goes unnoticed when thread 0 always runs first
+// without a barrier in between goes unnoticed when thread 0 always runs first.  LQ_EMU_ORDER=random[:seed]: whenever a thread
+// waits, a random ready one goes on (a thread still runs from one barrier or collective to the next without interruption)
 inline const char *g_emu_kernel = "";             // name of the kernel being launched (LQ_EMU_ORDER_KERNEL=<substring>: the order applies to it alone)
 inline int g_emu_rev = 0;                        // (read from the environment at the start of every block: tests switch it)
 inline int emu_reverse() { return g_emu_rev; }
+inline uint64_t g_emu_rng = 0;                    // LQ_EMU_ORDER=random[:seed]: a random ready thread runs next
+inline unsigned emu_rand(unsigned n) { g_emu_rng ^= g_emu_rng << 13; g_emu_rng ^= g_emu_rng >> 7; g_emu_rng ^= g_emu_rng << 17; return (unsigned)((g_emu_rng >> 11) % n); }
 inline void emu_yield()
 {
 	const int me = g_emu.cur;
 	const unsigned n = g_emu.n;
-	const bool rev = emu_reverse();
-	unsigned t = rev ? ((unsigned)me + n - 1) % n : ((unsigned)me + 1) % n;
-	for (unsigned i = 0; i < n; ++i, t = rev ? (t + n - 1) % n : (t + 1) % n) {
+	const int rev = emu_reverse();
+	unsigned t = rev == 2 ? emu_rand(n) : rev ? ((unsigned)me + n - 1) % n : ((unsigned)me + 1) % n;
+	const bool down = rev == 1 || (rev == 2 && (g_emu_rng & 1));
+	for (unsigned i = 0; i < n; ++i, t = down ? (t + n - 1) % n : (t + 1) % n) {
 		if (g_emu.state[t] == EMU_READY) {
 			if ((int)t == me) return;                    // (released by its own arrival)
 			g_emu.cur = (int)t;
@@ -277,7 +291,8 @@ inline void emu_run_block(unsigned nthreads, void (*body)(void *), void *arg)
 		if (g_emu.stacks == (char*)MAP_FAILED) emu_die("cannot map fiber stacks");
 	}
 	g_emu.n = nthreads; g_emu.body = body; g_emu.body_arg = arg;
-	{ const char *e = std::getenv("LQ_EMU_ORDER"); g_emu_rev = e && e[0] == 'r';
+	{ const char *e = std::getenv("LQ_EMU_ORDER"); g_emu_rev = e && e[0] == 'r' ? (e[1] == 'a' ? 2 : 1) : 0;
+	  if (g_emu_rev == 2 && g_emu_rng == 0) { const char *c = std::strchr(e, ':'); g_emu_rng = 0x9E3779B97F4A7C15ULL ^ (c ? std::strtoull(c + 1, nullptr, 10) * 0xD6E8FEB86659FD93ULL : 0); if (!g_emu_rng) g_emu_rng = 1; }
 	  const char *o = std::getenv("LQ_EMU_ORDER_THREADS"); if (o && (unsigned)std::atoi(o) != nthreads) g_emu_rev = 0;
 	  const char *k = std::getenv("LQ_EMU_ORDER_KERNEL"); if (k && !std::strstr(g_emu_kernel, k)) g_emu_rev = 0; }   // (only blocks of that many threads: narrows a finding down)
 	emu_poison_lds();
@@ -298,7 +313,8 @@ inline void emu_run_block(unsigned nthreads, void (*body)(void *), void *arg)
 	for (unsigned t = 0; t < nthreads; ++t) g_emu.tidx[t] = { t % blockDim.x, (t / blockDim.x) % blockDim.y, t / (blockDim.x * blockDim.y) };
 	for (;;) {                                               // fibers hand over to each other; control returns here when none is ready
 		unsigned t = 0;
-		if (emu_reverse()) { t = nthreads; while (t > 0 && g_emu.state[t - 1] != EMU_READY) --t; if (t == 0) break; --t; }
+		if (emu_reverse() == 2) { unsigned r = emu_rand(nthreads), i = 0; while (i < nthreads && g_emu.state[(r + i) % nthreads] != EMU_READY) ++i; if (i == nthreads) break; t = (r + i) % nthreads; }
+		else if (emu_reverse()) { t = nthreads; while (t > 0 && g_emu.state[t - 1] != EMU_READY) --t; if (t == 0) break; --t; }
 		else { while (t < nthreads && g_emu.state[t] != EMU_READY) ++t; if (t == nthreads) break; }
 		g_emu.cur = (int)t;
 		threadIdx = g_emu.tidx[t];
