@@ -644,10 +644,24 @@ void lqcov_handle::map_batch(MapLane &L, Part &pt, u32 q0, u32 q1, const std::ve
 	}
 	if (nA) {
 		const u64 *aqb = aq_off.as<u64>() + q0;          // batch view of the per-query anchor offsets
+		// LQCOV_DEBUG_SORT: the sort is a permutation (a sum over the anchors as emitted = the same sum afterwards: the finishing
+		// kernels rebuild x from the key), every query is ascending in x, anchors with equal x both carry the tie mark
+		auto anchor_sum = [](const mm128 &a) { u64 h = (a.x * 0x9E3779B97F4A7C15ULL) ^ (a.y * 0xD6E8FEB86659FD93ULL); return h ^ (h >> 29); };
+		u64 sum_before = 0;
+		if (K.debug_sort) {
+			std::vector<mm128> ha(nA), hb(nA);
+			std::vector<u32> hk(nqb);
+			d2h(ha.data(), dA, nA, L.stream); d2h(hb.data(), dB, nA, L.stream); d2h(hk.data(), qklib.as<u32>() + q0, nqb, L.stream);
+			for (u32 q = q0; q < q1; ++q)
+				for (u64 i = h_aq[q] - a_base; i < h_aq[q + 1] - a_base; ++i) sum_before += anchor_sum(hk[q - q0] ? hb[i] : ha[i]);
+		}
 		sort_batch(L, pt, q0, nqb, a_base, nA);           // lqmap.c:238
-		if (K.debug_sort) {	// every query ascending in x; anchors with equal x must both carry the tie mark (else the parallel sort may have seen them)
+		if (K.debug_sort) {
 			std::vector<mm128> ha(nA);
 			d2h(ha.data(), dA, nA, L.stream);
+			u64 sum_after = 0;
+			for (u64 i = 0; i < nA; ++i) sum_after += anchor_sum(ha[i]);
+			if (sum_after != sum_before) fprintf(stderr, "[sort] batch %u..%u: NOT A PERMUTATION of the emitted anchors (sums %016llx / %016llx)\n", q0, q1, (unsigned long long)sum_before, (unsigned long long)sum_after);
 			u64 unsorted = 0, ties = 0, unmarked = 0;
 			for (u32 q = q0; q < q1; ++q)
 				for (u64 i = h_aq[q] - a_base + 1; i < h_aq[q + 1] - a_base; ++i) {
@@ -655,6 +669,7 @@ void lqcov_handle::map_batch(MapLane &L, Part &pt, u32 q0, u32 q1, const std::ve
 					if (ha[i].x == ha[i - 1].x) { ++ties; if (!(ha[i].y & LQ_TIE_MARK) || !(ha[i - 1].y & LQ_TIE_MARK)) { if (unmarked++ < 4) fprintf(stderr, "[sort] query %u: equal x %016llx, y %016llx / %016llx\n", q, (unsigned long long)ha[i].x, (unsigned long long)ha[i - 1].y, (unsigned long long)ha[i].y); } }
 				}
 			fprintf(stderr, "[sort] batch %u..%u: %llu anchors, %llu out of order, %llu equal-x neighbours, %llu of them with an unmarked anchor\n", q0, q1, (unsigned long long)nA, (unsigned long long)unsorted, (unsigned long long)ties, (unsigned long long)unmarked);
+			if (sum_after != sum_before || unsorted || unmarked) throw std::logic_error("LQCOV_DEBUG_SORT: the sorted anchors are not a permutation of the emitted ones, not ascending, or hold an unmarked tie (see stderr)");
 		}
 		// ---- (strand, rid) runs long enough to hold a chain ----
 		u64 n_groups = 0;

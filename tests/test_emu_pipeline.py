@@ -536,3 +536,20 @@ def test_emulated_threads_in_descending_order(emu_lib, case, monkeypatch):
         assert out == read_gz(case["expect"]), env
         for k in env:
             monkeypatch.delenv(k)
+
+
+@pytest.mark.parametrize("case", [c for c in _cases("table") if c["name"] in ("tiny_ont", "adv_parts", "adv_ava_parts")] or _cases("table")[:2], ids=lambda c: c["name"])
+def test_emulated_sort_is_a_permutation_with_marked_ties(emu_lib, case, monkeypatch):
+    """LQCOV_DEBUG_SORT: after every batch's sort the engine checks on the host that the anchors are a permutation of the
+    emitted ones (the finishing kernels rebuild x from the compact key: a bit of x outside the key would be lost), that every
+    query ascends in x and that anchors with equal x both carry the tie mark (an unmarked tie could have met the parallel
+    sort, whose order among equal keys is arbitrary); a violation is an error."""
+    monkeypatch.setenv("LQCOV_DEBUG_SORT", "1")
+    for env in ({}, {"LQCOV_PS_SHIFT": "7"}, {"LQCOV_SORT": "klib", "LQCOV_WALK_SHIFT": "6"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        rc, out, err = run_main(emu_lib, case["argv"], cwd=GOLDEN)
+        assert rc == 0, err
+        assert out == read_gz(case["expect"]), env
+        for k in env:
+            monkeypatch.delenv(k)
