@@ -328,7 +328,7 @@ def test_emulated_checkpointed_walks(emu_lib, tmp_path, monkeypatch, variant):
 
 def _many_short_queries_dataset(tmp_path, n_targets=60, n_queries=500, seed=5):
     """hundreds of queries of 150-500 bases: a few dozen anchors each, so that dozens of queries start inside one
-    4096-anchor tile of the run list (kernels_chain.hpp: k_run_count / k_run_starts), some of them without any anchor"""
+    4096-anchor tile of the run list (kernels_chain.hpp: k_run_list), some of them without any anchor"""
     from longqc_amd import synth
     rng = np.random.default_rng(seed)
     A = synth._ACGT
