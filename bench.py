@@ -303,7 +303,7 @@ def main():
                                        for s in sorted(all_st, key=lambda s: -s["total_ms"]) if s["algo_bytes"]}
     if rank == 0:
         # HBM traffic of the dominant kernel from the PMC passes of this workload, if they were collected
-        # (tools/gpu_round.sh -> profiles/*pmc_traffic.json; separate rocprofv3 --pmc runs, never inside a timed run)
+        # (tools/gpu_evidence.sh -> profiles/*pmc_traffic.json; separate rocprofv3 --pmc runs, never inside a timed run)
         if roof and full_config:
             import glob
             for fn in sorted(glob.glob(os.path.join(ROOT, "profiles", "r0*pmc_traffic*.json")), reverse=True):
@@ -314,8 +314,10 @@ def main():
                     continue
                 if args.config not in js.get("workload", ""):
                     continue
-                want = roof["kernel"].replace(">", "")                    # "k_ps_finish<8192" matches "k_ps_finish<8192, 1024, 10, unsigned int>"
-                hit = [v for k, v in kk.items() if k == roof["kernel"] or k.startswith(want + ",") or k.startswith(want + ">") or (("<" not in want) and k.split("<")[0] == want)]
+                alias = {"k_rs_hist": "k_rs_hist<false>", "k_rs_hist<first>": "k_rs_hist<true>"}   # stage name -> kernel name where they differ
+                roof_k = alias.get(roof["kernel"], roof["kernel"])
+                want = roof_k.replace(">", "")                           # "k_ps_finish<8192" matches "k_ps_finish<8192, 1024, 10, unsigned int>"
+                hit = [v for k, v in kk.items() if k == roof_k or k.startswith(want + ",") or k.startswith(want + ">") or (("<" not in want) and k.split("<")[0] == want)]
                 if hit:
                     roof["traffic"] = round(hit[0]["hbm_bytes_per_launch"] / 1e9, 3)
                     roof["traffic_unit"] = "GB per launch (PMC: (2*FETCH_SIZE+WRITE_SIZE)*1024, from the committed %s, not from this run)" % os.path.basename(fn)
