@@ -34,6 +34,8 @@
 #include <algorithm>
 #include <chrono>
 #include <vector>
+#include <string>
+#include <cctype>
 #include <sys/mman.h>
 #include <dlfcn.h>
 #include <elf.h>
@@ -236,7 +238,7 @@ extern "C" inline void emu_fiber_main()
 
 // LDS of the kernel templates: GCC does not honour the section attribute for statics of templates (they are unique global
 // objects, "_ZZ<n>k_...E<name>" in the library's dynamic symbol table); found once by reading the library's own ELF headers
-struct EmuRegion { char *p; size_t n; };
+struct EmuRegion { char *p; size_t n; std::string kernel; };
 inline std::vector<EmuRegion> &emu_template_lds()
 {
 	static std::vector<EmuRegion> regs;
@@ -268,7 +270,7 @@ inline std::vector<EmuRegion> &emu_template_lds()
 			const char *q = nm + 3;
 			while (*q >= '0' && *q <= '9') ++q;
 			if (q == nm + 3 || q[0] != 'k' || q[1] != '_') continue;     // a static of a function k_...
-			regs.push_back({(char*)di.dli_fbase + sym[k].st_value, (size_t)sym[k].st_size});
+			regs.push_back({(char*)di.dli_fbase + sym[k].st_value, (size_t)sym[k].st_size, std::string(q, (size_t)std::atoi(nm + 3))});
 		}
 	}
 	if (std::getenv("LQ_EMU_VERBOSE")) { size_t tot = 0; for (const EmuRegion &r : regs) tot += r.n; std::fprintf(stderr, "hipemu: %zu LDS arrays of kernel templates, %zu bytes\n", regs.size(), tot); }
@@ -280,7 +282,19 @@ inline void emu_poison_lds()
 	static const bool off = std::getenv("LQ_EMU_NOPOISON") != nullptr;
 	if (off) return;
 	if (__start_emu_lds && __stop_emu_lds > __start_emu_lds) std::memset(__start_emu_lds, 0xA5, (size_t)(__stop_emu_lds - __start_emu_lds));
-	for (const EmuRegion &r : emu_template_lds()) std::memset(r.p, 0xA5, r.n);
+	// of the templates' arrays only those of the kernel being launched (all of them: two thirds of a megabyte per block)
+	static const char *last = nullptr;
+	static std::vector<EmuRegion> mine;
+	if (last != g_emu_kernel) {
+		last = g_emu_kernel;
+		const char *b = g_emu_kernel;
+		while (*b == '(' || *b == ' ') ++b;
+		size_t n = 0;
+		while (std::isalnum((unsigned char)b[n]) || b[n] == '_') ++n;
+		mine.clear();
+		for (const EmuRegion &r : emu_template_lds()) if (r.kernel.size() == n && r.kernel.compare(0, n, b, n) == 0) mine.push_back(r);
+	}
+	for (const EmuRegion &r : mine) std::memset(r.p, 0xA5, r.n);
 }
 
 inline void emu_run_block(unsigned nthreads, void (*body)(void *), void *arg)

@@ -46,7 +46,7 @@ def test_emulated_tables_read_like_the_reference_consumer(emu_lib, tmp_path):
                                            w["high_div_frac"], w["control_frac"])
 
 
-@pytest.mark.parametrize("case", [c for c in _cases("table") if c["name"] in ("tiny_ont", "adv_ont", "adv_parts", "adv_defaults")], ids=lambda c: c["name"])
+@pytest.mark.parametrize("case", [c for c in _cases("table") if c["name"] in ("tiny_ont", "adv_ont", "adv_parts")], ids=lambda c: c["name"])
 @pytest.mark.parametrize("tile", ["64", "1000"])
 def test_emulated_every_query_through_klib_passes(emu_lib, case, tile, monkeypatch):
     """LQCOV_SORT=klib: every query goes through klib's passes as 8-byte records, no bucket leaves them early (the passes on
@@ -195,7 +195,7 @@ def test_emulated_chains_mid_occ_and_accumulators(emu_lib, name, tfn, qfn):
     eng.close()
 
 
-@pytest.mark.parametrize("lanes", ["1", "2", "3"])
+@pytest.mark.parametrize("lanes", ["1", "3"])
 def test_emulated_query_batching_is_invisible(emu_lib, datasets, monkeypatch, lanes):
     """many small query batches dealt to 1..3 mapping lanes (own stream + work space each; concurrent threads on the GPU,
     round-robin in the emulator): same table"""
@@ -441,7 +441,7 @@ def check_repeat_rich_randomised(lib, tmp_path, monkeypatch, seed):
     return argv, want
 
 
-@pytest.mark.parametrize("seed", [0, 1, 2])
+@pytest.mark.parametrize("seed", [0, 1])
 def test_emulated_repeat_rich_randomised(emu_lib, tmp_path, monkeypatch, seed):
     """equal-x anchors everywhere (repeats inside the queries): rows equal the reference binary's, whichever path the sub-arrays
     take (parallel passes for those without a tie, klib's walk for the others); and the input has teeth: a stable sort by x
@@ -514,38 +514,28 @@ def test_emulated_parallel_sort_size_classes(emu_lib, datasets, monkeypatch):
     tf, qf = datasets("small")
     argv = ONT + [tf, qf]
     want = oracle_bind.table(argv)
-    for passes in ("4", "0"):
+    for passes in ("2",):                          # (no blind passes at all -- the tail alone: the descending-order test below)
         monkeypatch.setenv("LQCOV_PS_SHIFT", "7"); monkeypatch.setenv("LQCOV_PS_PASSES", passes)
         rc, out, err = run_main(emu_lib, argv)
         assert rc == 0, err
         assert out == want, passes
 
 
-@pytest.mark.parametrize("case", [c for c in _cases("table") if c["name"] in ("tiny_ont", "adv_parts", "adv_ava_parts")] or _cases("table")[:2], ids=lambda c: c["name"])
-def test_emulated_threads_in_descending_order(emu_lib, case, monkeypatch):
-    """The emulator runs a block's threads lowest first by default and fills the kernels' LDS with a pattern before every
-    block (tests/emu/hipemu.hpp).  With the highest thread first, "thread 0 initialises, the others read" without a barrier in
-    between reads the pattern -- on the GPU: whatever another lane's kernel left in the CU's LDS (round 3's k_run_list fault).
-    The shrunken size classes send the sort through every kernel family on these small inputs."""
-    monkeypatch.setenv("LQ_EMU_ORDER", "reverse")
-    for env in ({}, {"LQCOV_PS_SHIFT": "7", "LQCOV_WALK_SHIFT": "6", "LQCOV_SORT": "klib"}, {"LQCOV_RUN_GRID": "7", "LQCOV_RUN_STAGE": "256"}):
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
-        rc, out, err = run_main(emu_lib, case["argv"], cwd=GOLDEN)
-        assert rc == 0, err
-        assert out == read_gz(case["expect"]), env
-        for k in env:
-            monkeypatch.delenv(k)
-
-
-@pytest.mark.parametrize("case", [c for c in _cases("table") if c["name"] in ("tiny_ont", "adv_parts", "adv_ava_parts")] or _cases("table")[:2], ids=lambda c: c["name"])
-def test_emulated_sort_is_a_permutation_with_marked_ties(emu_lib, case, monkeypatch):
-    """LQCOV_DEBUG_SORT: after every batch's sort the engine checks on the host that the anchors are a permutation of the
+@pytest.mark.parametrize("case", [c for c in _cases("table") if c["name"] in ("tiny_ont", "adv_parts")] or _cases("table")[:2], ids=lambda c: c["name"])
+def test_emulated_threads_in_descending_order_and_the_sort_checked(emu_lib, case, monkeypatch):
+    """Two of the emulator's and the engine's self-checks at once.
+    LQ_EMU_ORDER=reverse: the emulator runs a block's threads lowest first by default and fills the kernels' LDS with a pattern
+    before every block (tests/emu/hipemu.hpp).  With the highest thread first, "thread 0 initialises, the others read" without
+    a barrier in between reads the pattern -- on the GPU: whatever another lane's kernel left in the CU's LDS (round 3's
+    k_run_list fault) -- and an order that only the atomics of a partition pass gave shows (round 3: tied anchors of a one-x
+    bucket).  LQCOV_DEBUG_SORT: after every batch's sort the engine checks on the host that the anchors are a permutation of the
     emitted ones (the finishing kernels rebuild x from the compact key: a bit of x outside the key would be lost), that every
     query ascends in x and that anchors with equal x both carry the tie mark (an unmarked tie could have met the parallel
-    sort, whose order among equal keys is arbitrary); a violation is an error."""
+    sort, whose order among equal keys is arbitrary); a violation is an error.
+    The shrunken size classes send the sort through every kernel family on these small inputs."""
+    monkeypatch.setenv("LQ_EMU_ORDER", "reverse")
     monkeypatch.setenv("LQCOV_DEBUG_SORT", "1")
-    for env in ({}, {"LQCOV_PS_SHIFT": "7"}, {"LQCOV_SORT": "klib", "LQCOV_WALK_SHIFT": "6"}):
+    for env in ({}, {"LQCOV_PS_SHIFT": "7", "LQCOV_PS_PASSES": "0", "LQCOV_RUN_GRID": "7", "LQCOV_RUN_STAGE": "256"}, {"LQCOV_WALK_SHIFT": "6", "LQCOV_SORT": "klib"}):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         rc, out, err = run_main(emu_lib, case["argv"], cwd=GOLDEN)

@@ -4,7 +4,7 @@ python tools/kernel_resources.py  ->  one line per kernel (rocPRIM's left out)""
 import os, re, subprocess, sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 csrc = os.path.join(root, "longqc_amd", "csrc")
-r = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-c", "engine.cpp", "-o", "/dev/null",
+r = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", "-c", "engine.cpp", "-o", "/dev/null",
                     "-Rpass-analysis=kernel-resource-usage"], cwd=csrc, stderr=subprocess.PIPE, stdout=subprocess.DEVNULL, text=True)
 rows, cur = [], {}
 for l in r.stderr.splitlines():
