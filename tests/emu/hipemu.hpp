@@ -72,7 +72,16 @@ inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
 inline hipError_t hipExtStreamCreateWithCUMask(hipStream_t *s, unsigned, const unsigned *) { *s = nullptr; return hipSuccess; }
 inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 inline hipError_t hipStreamWaitEvent(hipStream_t, void *, unsigned = 0) { return hipSuccess; }
-inline hipError_t hipMalloc(void **p, size_t n) { *p = std::malloc(n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
+// device memory comes with whatever its last user left in it (large blocks from malloc are fresh zero pages: a kernel that
+// counts on zeros would pass here and fail there): filled with 0xCD unless LQ_EMU_NOPOISON is set
+inline hipError_t hipMalloc(void **p, size_t n)
+{
+	*p = std::malloc(n ? n : 1);
+	if (!*p) return hipErrorOutOfMemory;
+	static const bool off = std::getenv("LQ_EMU_NOPOISON") != nullptr;
+	if (!off) std::memset(*p, 0xCD, n ? n : 1);
+	return hipSuccess;
+}
 inline hipError_t hipFree(void *p) { std::free(p); return hipSuccess; }
 inline hipError_t hipHostMalloc(void **p, size_t n, unsigned = 0) { return hipMalloc(p, n); }
 inline hipError_t hipHostFree(void *p) { return hipFree(p); }
