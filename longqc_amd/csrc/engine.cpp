@@ -104,8 +104,6 @@ void Knobs::read_env()
 	sketch_kpt = (u32)std::min<long>(64, std::max<long>(1, num("LQCOV_SKETCH_KPT", 4)));
 	sketch_machine_only = is("LQCOV_SKETCH", "machine");
 	ps_grid = (u32)std::max<long>(64, num("LQCOV_PS_GRID", 512));
-	fin_grid_b = (u32)std::max<long>(0, num("LQCOV_FIN_GRID_B", 0));
-	fin_grid_s = (u32)std::max<long>(0, num("LQCOV_FIN_GRID_S", 0));
 	tile_grid = (u32)std::max<long>(64, num("LQCOV_TILE_GRID", 4096));
 	ps_passes = (u32)std::min<long>(16, std::max<long>(0, num("LQCOV_PS_PASSES", 2))) & ~1u;
 }
@@ -808,7 +806,7 @@ static void ps_finish(lqcov_handle *h, MapLane &L, int set, hipStream_t s, u64 n
 	{
 		StageTimer t(h, s, "k_ps_finish<8192>");
 		unsigned long long *tl = (unsigned long long*)(L.sort_cnt.as<u32>() + (set ? LQ_C_FINB1 : LQ_C_FINB0));
-		const u32 g = (u32)std::min<u64>(std::min<u64>(Ls.cap_fin, nA / LQ_PS_FIN_SMALL + 64), h->K.fin_grid_b ? h->K.fin_grid_b : h->K.ps_grid / 4);
+		const u32 g = (u32)std::min<u64>(std::min<u64>(Ls.cap_fin, nA / LQ_PS_FIN_SMALL + 64), h->K.ps_grid / 4);
 		// 1024 threads (measured at configs[2], 4 lanes, round 2: 256-thread blocks 2.40 s per step, 512: 2.25, 1024: 2.1-2.2; round 3: 512 = 1024).
 		// Beside the other lanes' kernels a launch of this kernel takes ~3x its time alone, most of it waiting: with the class
 		// emptied (everything partitioned down to 1024) the empty launches still took 367 ms per step and the step was the same.
@@ -819,7 +817,7 @@ static void ps_finish(lqcov_handle *h, MapLane &L, int set, hipStream_t s, u64 n
 	{
 		StageTimer t(h, s, "k_ps_finish<1024>");
 		unsigned long long *tl = (unsigned long long*)(L.sort_cnt.as<u32>() + (set ? LQ_C_FINS1 : LQ_C_FINS0));
-		const u32 g = (u32)std::min<u64>(std::min<u64>(Ls.cap_fin, nA / 16 + 256), h->K.fin_grid_s ? h->K.fin_grid_s : h->K.ps_grid * 2);
+		const u32 g = (u32)std::min<u64>(std::min<u64>(Ls.cap_fin, nA / 16 + 256), h->K.ps_grid * 2);
 		if (k32) LQ_LAUNCH((k_ps_finish<LQ_PS_FIN_SMALL, 256, 8, u32>), g, 256, s, Ls.fin_s, cnt + LQ_P_FIN_S, pd, km, tl);
 		else LQ_LAUNCH((k_ps_finish<LQ_PS_FIN_SMALL, 256, 8, u64>), g, 256, s, Ls.fin_s, cnt + LQ_P_FIN_S, pd, km, tl);
 		check_launch();
@@ -1209,7 +1207,6 @@ void lqcov_handle::map_part(Part &pt)
 			if (left > 1) --left;
 		}
 	}
-	if (getenv("LQCOV_DEBUG_BATCHES")) { fprintf(stderr, "[lqcov] %zu batches:", batches.size()); for (auto &bq : batches) fprintf(stderr, " %llu", (unsigned long long)(h_aq[bq.second] - h_aq[bq.first])); fprintf(stderr, "\n"); }
 	while (lanes.size() < (size_t)n_lanes) {
 		lanes.emplace_back(new MapLane());
 		LQ_HIP_CHECK(hipStreamCreate(&lanes.back()->stream));

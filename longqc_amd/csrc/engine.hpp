@@ -43,8 +43,7 @@ struct Knobs {
 	u32 sketch_kpt = 4;                   // LQCOV_SKETCH_KPT: chunks per thread of the sketch state machine
 	u32 ps_passes = 2;                    // LQCOV_PS_PASSES: partition passes issued without looking (even; the tail looks at the counter and does the rest).  Two cover queries of up to ~500 M anchors against 65 536 targets; measured 4 vs 2 at configs[2]: 1.71-1.77 vs 1.69-1.71 s per step
 	u32 tile_grid = 4096;                 // LQCOV_TILE_GRID: blocks of klib's tile kernels (histogram, scatter)
-	u32 ps_grid = 512;                   // LQCOV_PS_GRID: blocks of the parallel sort's tile kernels (the finishing kernels: a quarter / twice that)
-	u32 fin_grid_b = 0, fin_grid_s = 0;   // LQCOV_FIN_GRID_B / _S: blocks of the two finishing kernels (0: ps_grid / 4 and ps_grid * 2)
+	u32 ps_grid = 512;                   // LQCOV_PS_GRID: blocks of the parallel sort's tile kernels (the finishing kernels: a quarter / twice that; twice as many blocks for them: no change, measured with the 64-register kernels)
 	bool sketch_machine_only = false;     // LQCOV_SKETCH=machine: the state machine decides every chunk (no data-parallel kernel)
 	void read_env();
 };
