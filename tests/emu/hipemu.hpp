@@ -290,6 +290,8 @@ inline void emu_poison_lds()
 {
 	static const bool off = std::getenv("LQ_EMU_NOPOISON") != nullptr;
 	if (off) return;
+	const unsigned b = g_emu.bidx.x;                             // the first blocks of a launch and every fourth after them: a block
+	if (b > 2 && (b & 3) && g_emu.bidx.y == 0) return;          // that counts on what LDS holds does so whatever its number
 	if (__start_emu_lds && __stop_emu_lds > __start_emu_lds) std::memset(__start_emu_lds, 0xA5, (size_t)(__stop_emu_lds - __start_emu_lds));
 	// of the templates' arrays only those of the kernel being launched (all of them: two thirds of a megabyte per block)
 	static const char *last = nullptr;
