@@ -533,13 +533,14 @@ def test_emulated_threads_in_descending_order_and_the_sort_checked(emu_lib, case
     query ascends in x and that anchors with equal x both carry the tie mark (an unmarked tie could have met the parallel
     sort, whose order among equal keys is arbitrary); a violation is an error.
     The shrunken size classes send the sort through every kernel family on these small inputs."""
-    monkeypatch.setenv("LQ_EMU_ORDER", "reverse")
     monkeypatch.setenv("LQCOV_DEBUG_SORT", "1")
-    for env in ({}, {"LQCOV_PS_SHIFT": "7", "LQCOV_PS_PASSES": "0", "LQCOV_RUN_GRID": "7", "LQCOV_RUN_STAGE": "256"}, {"LQCOV_WALK_SHIFT": "6", "LQCOV_SORT": "klib"}):
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
-        rc, out, err = run_main(emu_lib, case["argv"], cwd=GOLDEN)
-        assert rc == 0, err
-        assert out == read_gz(case["expect"]), env
-        for k in env:
-            monkeypatch.delenv(k)
+    for order in ("reverse",) + (("random:5",) if case["name"] == "tiny_ont" else ()):   # (random: whenever a thread waits, any ready one goes on)
+        monkeypatch.setenv("LQ_EMU_ORDER", order)
+        for env in ({}, {"LQCOV_PS_SHIFT": "7", "LQCOV_PS_PASSES": "0", "LQCOV_RUN_GRID": "7", "LQCOV_RUN_STAGE": "256"}, {"LQCOV_WALK_SHIFT": "6", "LQCOV_SORT": "klib"}):
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            rc, out, err = run_main(emu_lib, case["argv"], cwd=GOLDEN)
+            assert rc == 0, err
+            assert out == read_gz(case["expect"]), (order, env)
+            for k in env:
+                monkeypatch.delenv(k)
