@@ -20,16 +20,15 @@
 // A run starts at the first anchor of the batch, at the first anchor of every query and wherever the high word of x (strand,
 // rid) changes.  Against half a million targets most runs are one or two chance hits; a chain needs min_cnt anchors
 // (chain.c:119-121) and scores at most the sum of its anchors' spans (chain.c:57-67), each at most k (255 with -H), so a run
-// of fewer than n_min = max(min_cnt, ceil(min_sc / span_max)) anchors is never looked at again.  One block per 4096-anchor
-// tile: heads by ballots, the heads as a bitmap in LDS, a head's length = distance to the next head (the last run of a tile,
-// when it goes on past the tile: to the end of its query or to the first different high word, found by bisection -- the
-// query's anchors are sorted), one atomic per tile for the tile's place in the list, entries start | length << 32.  The list
-// is not in array order across tiles; nothing downstream depends on the order (sums, counters, a pool of intervals that is
-// sorted before use).
+// of fewer than n_min = max(min_cnt, ceil(min_sc / span_max)) anchors is never looked at again.  Per 4096-anchor tile: heads
+// by ballots, the heads as a bitmap in LDS, a head's length = distance to the next head (the last run of a tile, when it
+// goes on past the tile: to the end of its query or to the first different high word -- the query's anchors are sorted),
+// entries start | length << 32.  The list is in no particular order; nothing downstream depends on it (sums, counters, a
+// pool of intervals that is sorted before use).  k_run_list below has the details.
 #define LQ_RUN_TILE 4096
 #define LQ_RUN_THREADS 256
 #define LQ_RUN_ROWS (LQ_RUN_TILE / LQ_RUN_THREADS)
-#define LQ_RUN_WAVES (LQ_RUN_THREADS / 64)
+#define LQ_RUN_WAVES (LQ_RUN_THREADS / 64)     // (k_sel_write's rows and waves)
 
 // exclusive scan of n counts in place, the total in cnt[n]; one block
 #define LQ_TSCAN_THREADS 1024
@@ -74,7 +73,7 @@ k_run_list(const mm128 *A, u64 n, const u64 *aq_off, u64 a_base, u32 n_q, u32 n_
 	__shared__ u32 nx[LQ_RUN_PEEK];
 	__shared__ u32 slot0, fill_s;
 	__shared__ u64 stg[LQ_RUN_STAGE];
-	const u32 t = threadIdx.x, lane = t & 63, w = t >> 6;
+	const u32 t = threadIdx.x, lane = t & 63;
 	const u32 per = (n_tiles + gridDim.x - 1) / gridDim.x;
 	const u32 T0 = blockIdx.x * per < n_tiles ? blockIdx.x * per : n_tiles, T1 = T0 + per < n_tiles ? T0 + per : n_tiles;
 	const u64 near_mask = n_min > 1 ? (n_min > 33 ? ~0ULL >> 31 : (1ULL << (n_min - 1)) - 1) : 0;   // the next n_min - 1 positions (up to 33 of them)
@@ -185,7 +184,6 @@ k_run_list(const mm128 *A, u64 n, const u64 *aq_off, u64 a_base, u32 n_q, u32 n_
 		if (f) LQ_RUN_FLUSH(f);
 	}
 #undef LQ_RUN_FLUSH
-	(void)w;
 }
 
 __device__ __forceinline__ int lq_ilog2_32(u32 v) { return 31 - __clz(v); }   // chain.c:15-20 for v > 0
