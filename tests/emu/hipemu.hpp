@@ -101,14 +101,15 @@ inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t b)
 { *ms = std::chrono::duration<float, std::milli>(b->t - a->t).count(); return hipSuccess; }
 inline hipError_t hipMemGetInfo(size_t *f, size_t *t) { *f = *t = (size_t)64 << 30; return hipSuccess; }
 
-template <class T> inline T atomicAdd(T *p, T v) { T o = *p; *p = o + v; return o; }
-inline unsigned long long atomicAdd(unsigned long long *p, unsigned long long v) { unsigned long long o = *p; *p = o + v; return o; }
-template <class T> inline T atomicOr(T *p, T v) { T o = *p; *p = o | v; return o; }
-template <class T> inline T atomicAnd(T *p, T v) { T o = *p; *p = o & v; return o; }
-template <class T> inline T atomicMax(T *p, T v) { T o = *p; if (v > o) *p = v; return o; }
-template <class T> inline T atomicMin(T *p, T v) { T o = *p; if (v < o) *p = v; return o; }
-template <class T> inline T atomicCAS(T *p, T cmp, T v) { T o = *p; if (o == cmp) *p = v; return o; }
-template <class T> inline T atomicExch(T *p, T v) { T o = *p; *p = v; return o; }
+inline void emu_atomic_hook();                     // LQ_EMU_ORDER=random: now and then another ready thread runs before an atomic
+template <class T> inline T atomicAdd(T *p, T v) { emu_atomic_hook(); T o = *p; *p = o + v; return o; }
+inline unsigned long long atomicAdd(unsigned long long *p, unsigned long long v) { emu_atomic_hook(); unsigned long long o = *p; *p = o + v; return o; }
+template <class T> inline T atomicOr(T *p, T v) { emu_atomic_hook(); T o = *p; *p = o | v; return o; }
+template <class T> inline T atomicAnd(T *p, T v) { emu_atomic_hook(); T o = *p; *p = o & v; return o; }
+template <class T> inline T atomicMax(T *p, T v) { emu_atomic_hook(); T o = *p; if (v > o) *p = v; return o; }
+template <class T> inline T atomicMin(T *p, T v) { emu_atomic_hook(); T o = *p; if (v < o) *p = v; return o; }
+template <class T> inline T atomicCAS(T *p, T cmp, T v) { emu_atomic_hook(); T o = *p; if (o == cmp) *p = v; return o; }
+template <class T> inline T atomicExch(T *p, T v) { emu_atomic_hook(); T o = *p; *p = v; return o; }
 inline void __threadfence() {}
 inline void __threadfence_block() {}
 
@@ -164,7 +165,8 @@ inline void emu_die(const char *msg) { std::fprintf(stderr, "hipemu: %s (block %
 // when nobody is ready (everything finished, or a deadlock for it to report)
 // LQ_EMU_ORDER=reverse: the highest ready thread runs first (default: the lowest) -- "thread 0 writes, the others read"
 // without a barrier in between goes unnoticed when thread 0 always runs first.  LQ_EMU_ORDER=random[:seed]: whenever a thread
-// waits, a random ready one goes on (a thread still runs from one barrier or collective to the next without interruption)
+// waits, a random ready one goes on, and before one atomic in eight as well (otherwise a thread runs from one barrier or
+// collective to the next without interruption)
 inline const char *g_emu_kernel = "";             // name of the kernel being launched (LQ_EMU_ORDER_KERNEL=<substring>: the order applies to it alone)
 inline int g_emu_rev = 0;                        // (read from the environment at the start of every block: tests switch it)
 inline int emu_reverse() { return g_emu_rev; }
@@ -188,6 +190,8 @@ inline void emu_yield()
 	}
 	emu_ctx_switch(&g_emu.sp[me], g_emu.sched_sp);
 }
+
+inline void emu_atomic_hook() { if (g_emu_rev == 2 && g_emu.cur >= 0 && emu_rand(8) == 0) emu_yield(); }
 
 inline void emu_wave_release(int w)
 {
