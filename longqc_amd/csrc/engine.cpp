@@ -96,6 +96,7 @@ void Knobs::read_env()
 	chain_cap = (int)num("LQCOV_CHAIN_CAP", 128);
 	run_stage = (u32)std::max<long>(1, num("LQCOV_RUN_STAGE", LQ_RUN_STAGE));
 	run_grid = (u32)std::max<long>(1, num("LQCOV_RUN_GRID", 2048));
+	ps_key64 = num("LQCOV_PS_KEY64", 0) != 0;
 #ifndef LQ_EMU
 	lq_trace_launches = (int)num("LQCOV_TRACE_LAUNCHES", 0);
 #endif
@@ -802,7 +803,7 @@ static void ps_finish(lqcov_handle *h, MapLane &L, int set, hipStream_t s, u64 n
 {
 	u32 *cnt = L.sort_cnt.as<u32>() + (set ? LQ_C_PS1 : LQ_C_PS0);
 	const PsLists Ls = ps_lists(L, set, h->K.ps_shift);
-	const bool k32 = km.pbits + km.rbits + 1 <= 32 + 8;          // the key bits below the sub-bucket digit fit 32 bits (both kernels' digits are >= 8 bits)
+	const bool k32 = km.pbits + km.rbits + 1 <= 32 + 8 && !h->K.ps_key64;          // the key bits below the sub-bucket digit fit 32 bits (both kernels' digits are >= 8 bits)
 	{
 		StageTimer t(h, s, "k_ps_finish<8192>");
 		unsigned long long *tl = (unsigned long long*)(L.sort_cnt.as<u32>() + (set ? LQ_C_FINB1 : LQ_C_FINB0));

@@ -514,8 +514,8 @@ def test_emulated_parallel_sort_size_classes(emu_lib, datasets, monkeypatch):
     tf, qf = datasets("small")
     argv = ONT + [tf, qf]
     want = oracle_bind.table(argv)
-    for passes in ("2",):                          # (no blind passes at all -- the tail alone: the descending-order test below)
-        monkeypatch.setenv("LQCOV_PS_SHIFT", "7"); monkeypatch.setenv("LQCOV_PS_PASSES", passes)
+    for passes, key64 in (("2", "0"), ("2", "1")):   # (no blind passes at all -- the tail alone: the descending-order test below); the finishing kernels' 64-bit key shape
+        monkeypatch.setenv("LQCOV_PS_SHIFT", "7"); monkeypatch.setenv("LQCOV_PS_PASSES", passes); monkeypatch.setenv("LQCOV_PS_KEY64", key64)
         rc, out, err = run_main(emu_lib, argv)
         assert rc == 0, err
         assert out == want, passes

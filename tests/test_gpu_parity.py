@@ -301,7 +301,8 @@ def test_gpu_long_pair_among_many_targets(gpu_lib, tmp_path):
 
 @pytest.mark.parametrize("env", [{"LQCOV_CKPT3": "1"}, {"LQCOV_WALK": "solo"}, {"LQCOV_CKPT": "0"}, {"LQCOV_SORT": "klib"}, {"LQCOV_SKETCH_KPT": "1", "LQCOV_SKETCH": "machine"},
                                  {"LQCOV_LANES": "2", "LQCOV_ANCHOR_BUDGET": "400000"},
-                                 {"LQCOV_DEBUG_SORT": "1"}, {"LQCOV_DEBUG_SORT": "1", "LQCOV_PS_SHIFT": "5", "LQCOV_RUN_GRID": "5", "LQCOV_RUN_STAGE": "256"}], ids=lambda e: "+".join("%s=%s" % kv for kv in e.items()))
+                                 {"LQCOV_DEBUG_SORT": "1"}, {"LQCOV_DEBUG_SORT": "1", "LQCOV_PS_SHIFT": "5", "LQCOV_RUN_GRID": "5", "LQCOV_RUN_STAGE": "256"},
+                                 {"LQCOV_DEBUG_SORT": "1", "LQCOV_PS_KEY64": "1"}], ids=lambda e: "+".join("%s=%s" % kv for kv in e.items()))
 def test_gpu_every_shipped_switch_on_a_midsize_slice(gpu_lib, tmp_path, monkeypatch, env):
     """every switch that selects other kernels than the defaults (checkpoints for the second-longest class, solo walkers only,
     no checkpoints, every query through klib's passes, the sketch state machine alone with one chunk per thread, two lanes over small batches) on 1 500 ONT
