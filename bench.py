@@ -108,6 +108,8 @@ def main():
     ap.add_argument("--cache", default="", help="directory for the generated reads (re-used by later runs of the same config on this machine)")
     ap.add_argument("--index-size", default="", help="override the preset's -I (e.g. 2M: many index parts on a small input; tests)")
     ap.add_argument("--workers", type=int, default=0, help="processes of the synthetic generator (0: one per core, at most 64)")
+    ap.add_argument("--front-only", action="store_true", help="not the bench: upload + sketch + index of the first part alone, --steps times, nothing else on the device; "
+                                                                "prints the per-kernel HIP-event times of the build side undisturbed (development aid)")
     args = ap.parse_args()
 
     import torch
@@ -225,6 +227,21 @@ def main():
                 a += eng.last_n_anchors
             table[0] = runner.gather_table()
             anchors[0] = a
+
+    if args.front_only and world == 1:
+        best = {}
+        for _ in range(max(args.steps, 1)):
+            eng.set_profiling(0); eng.set_profiling(2)       # (clears the stage table)
+            eng.reset()
+            t0 = time.time()
+            build(0)
+            eng.sync()
+            wall = (time.time() - t0) * 1e3
+            st = {s["name"]: round(s["total_ms"], 2) for s in eng.stage_times() if s["total_ms"] > 0.05}
+            if not best or wall < best["wall_ms"]:
+                best = {"wall_ms": round(wall, 2), "stages_ms": st}
+        print(json.dumps({"front_only": True, "part_bases": int(F.off[parts[0][1]] - F.off[parts[0][0]]), "best_of": max(args.steps, 1), **best}))
+        return
 
     def barrier():
         if world > 1:
