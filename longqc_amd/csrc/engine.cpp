@@ -97,6 +97,7 @@ void Knobs::read_env()
 	run_stage = (u32)std::max<long>(1, num("LQCOV_RUN_STAGE", LQ_RUN_STAGE));
 	run_grid = (u32)std::max<long>(1, num("LQCOV_RUN_GRID", 2048));
 	ps_key64 = num("LQCOV_PS_KEY64", 0) != 0;
+	sketch_wgen = num("LQCOV_SKETCH_WGEN", 0) != 0;
 #ifndef LQ_EMU
 	lq_trace_launches = (int)num("LQCOV_TRACE_LAUNCHES", 0);
 #endif
@@ -348,10 +349,12 @@ void lqcov_handle::sketch(ReadSetDev &rs, bool rid_in_y)
 				LQ_LAUNCH(k_sketch_owners, nblk(rs.n, 256), 256, stream, rs.d_coff.as<u64>(), sk_toff.as<u64>(), rs.n, sk_trid.as<u32>(), sk_grid.as<u32>()); check_launch();
 				if (n_tiles) {
 					StageTimer t(this, stream, "k_sketch_dp_mask", in_bytes + nc * 17);
-					if (P.k <= 16) LQ_LAUNCH(k_sketch_dp_mask<u32>, (u32)std::min<u64>(n_tiles, 1u << 22), LQ_DPT_THREADS, stream, rs.codes.as<u64>(), rs.amb.as<u32>(), rs.d_coff.as<u64>(), rs.d_len.as<u32>(), sk_toff.as<u64>(), sk_trid.as<u32>(), rs.n, n_tiles, sp,
-					                         sk_owned.as<u8>(), sk_mask.as<u32>(), sk_flag.as<u32>());
-					else LQ_LAUNCH(k_sketch_dp_mask<u64>, (u32)std::min<u64>(n_tiles, 1u << 22), LQ_DPT_THREADS, stream, rs.codes.as<u64>(), rs.amb.as<u32>(), rs.d_coff.as<u64>(), rs.d_len.as<u32>(), sk_toff.as<u64>(), sk_trid.as<u32>(), rs.n, n_tiles, sp,
-					               sk_owned.as<u8>(), sk_mask.as<u32>(), sk_flag.as<u32>());
+#define LQ_DPM(HT, W) LQ_LAUNCH((k_sketch_dp_mask<HT, W>), (u32)std::min<u64>(n_tiles, 1u << 22), LQ_DPT_THREADS, stream, rs.codes.as<u64>(), rs.amb.as<u32>(), rs.d_coff.as<u64>(), rs.d_len.as<u32>(), \
+		sk_toff.as<u64>(), sk_trid.as<u32>(), rs.n, n_tiles, sp, sk_owned.as<u8>(), sk_mask.as<u32>(), sk_flag.as<u32>())
+					const int wc = K.sketch_wgen ? 0 : P.w;               // the presets' windows as compile-time constants
+					if (P.k <= 16) { if (wc == 5) LQ_DPM(u32, 5); else if (wc == 10) LQ_DPM(u32, 10); else LQ_DPM(u32, 0); }
+					else { if (wc == 5) LQ_DPM(u64, 5); else if (wc == 10) LQ_DPM(u64, 10); else LQ_DPM(u64, 0); }
+#undef LQ_DPM
 					check_launch();
 				}
 				dp_owned = sk_owned.as<u8>();

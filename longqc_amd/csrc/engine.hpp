@@ -36,6 +36,7 @@ struct Knobs {
 	u32 walk_shift = 0;                   // LQCOV_WALK_SHIFT: shrinks the walker size classes and the checkpoint spacing (tests)
 	u32 walk_grid = 1u << 18;             // LQCOV_WALK_GRID: cap on resident walker waves
 	int chain_wave_min = 0, chain_cap = 128;   // LQCOV_CHAIN_WAVE_MIN (0 = LQ_CHAIN_WAVE_MIN), LQCOV_CHAIN_CAP
+	bool sketch_wgen = false;             // LQCOV_SKETCH_WGEN=1: k_sketch_dp_mask with the window read at run time although it is 5 or 10 (tests, A/B)
 	bool ps_key64 = false;                // LQCOV_PS_KEY64=1: the finishing kernels' 64-bit key shape although 32 bits would do (tests: parts with more than 2^40 (target, position) pairs are out of their reach)
 	u32 run_grid = 2048;                  // LQCOV_RUN_GRID: blocks of k_run_list, each with a contiguous stretch of tiles (tests: 1 or 2, so that a block walks many)
 	u32 run_stage = 2048;                 // LQCOV_RUN_STAGE: entries of the run list a block collects before it reserves their place (tests shrink it)

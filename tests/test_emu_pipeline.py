@@ -105,9 +105,12 @@ def test_emulated_data_parallel_sketch_fuzz(emu_lib, monkeypatch):
     """random reads with sparse Ns, AT stretches (palindromic k-mers), short-period repeats and tandem copies (ties), a
     two-letter alphabet; random (k, w): the data-parallel kernel and the state machine give the same list"""
     A = np.frombuffer(b"ACGT", dtype=np.uint8)
-    for it in range(10):
+    fixed = [(12, 5), (12, 10), (19, 5), (19, 10)]       # the windows k_sketch_dp_mask knows at compile time, 32- and 64-bit hashes
+    for it in range(10 + len(fixed)):
         rng = np.random.default_rng(100 + it)
         k = int(rng.choice([4, 6, 10, 12, 15, 19, 24, 28])); w = int(rng.choice([1, 2, 3, 5, 10, 16]))
+        if it >= 10:
+            k, w = fixed[it - 10]
         seqs = []
         for j in range(6):
             L = int(rng.integers(130, 3000)) if j < 4 else int(rng.integers(3000, 9000))    # (a tile of the data-parallel kernel is 1536 bases)
@@ -126,14 +129,15 @@ def test_emulated_data_parallel_sketch_fuzz(emu_lib, monkeypatch):
             seqs.append(s)
         names = ["s%d" % i for i in range(len(seqs))]
         res = []
-        for mode in ("machine", "default"):
-            monkeypatch.setenv("LQCOV_SKETCH", mode)
+        for mode, wgen in (("machine", "0"), ("default", "0")) + ((("default", "1"),) if w in (5, 10) else ()):   # (the same window read at run time)
+            monkeypatch.setenv("LQCOV_SKETCH", mode); monkeypatch.setenv("LQCOV_SKETCH_WGEN", wgen)
             eng = _engine(emu_lib, k=k, w=w, hpc=0, min_score_med=40, min_score_good=40)
             eng.set_queries(names, seqs, None)
             xy, off = eng.query_minimizers()
             res.append((np.array(xy).copy(), np.array(off).copy()))
             eng.close()
-        assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1]), (it, k, w)
+        for other in res[1:]:
+            assert np.array_equal(res[0][0], other[0]) and np.array_equal(res[0][1], other[1]), (it, k, w)
 
 
 def test_emulated_sketch_halo_adversarial(emu_lib):
