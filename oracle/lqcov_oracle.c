@@ -495,7 +495,7 @@ static inline int ilog2_32(uint32_t v)              /* chain.c:8-20 */
 typedef VEC(uint64_t) u64_v;
 typedef VEC(lqo_mm128) mm_v;
 
-static void chain_dp_range(const lqo_params *P, float avg_qspan, const lqo_mm128 *a, int64_t n, u64_v *u_out, mm_v *b_out)
+static void chain_dp_range_s(const lqo_params *P, float avg_qspan, const lqo_mm128 *a, int64_t n, u64_v *u_out, mm_v *b_out, int *peak_tie, int *band_tie)
 {
 	int32_t *f, *p, *t, *v, n_u, n_v, k;
 	int64_t i, j, st = 0;
@@ -509,6 +509,7 @@ static void chain_dp_range(const lqo_params *P, float avg_qspan, const lqo_mm128
 		int64_t max_j = -1;
 		int32_t qi = (int32_t)a[i].y, q_span = a[i].y >> 32 & 0xff;
 		int32_t max_f = q_span, n_skip = 0;
+		int have_act = 0; uint64_t act_x = 0;
 		while (st < i && ri - a[st].x > (uint64_t)max_dist_x) ++st;
 		for (j = i - 1; j >= st; --j) {
 			int64_t dr = ri - a[j].x;
@@ -522,11 +523,26 @@ static void chain_dp_range(const lqo_params *P, float avg_qspan, const lqo_mm128
 			log_dd = dd ? ilog2_32(dd) : 0;
 			sc -= (int)(dd * .01 * avg_qspan) + (log_dd >> 1);
 			sc += f[j];
+			if (band_tie) {                                 /* two candidates of equal x inside the band of the same scan */
+				if (have_act && a[j].x == act_x) *band_tie = 1;
+				have_act = 1; act_x = a[j].x;
+			}
 			if (sc > max_f) {
 				max_f = sc, max_j = j;
 				if (n_skip > 0) --n_skip;
 			} else if (t[j] == i) {
-				if (++n_skip > max_skip) break;
+				if (++n_skip > max_skip) {
+					if (band_tie) {                         /* the scan ends at j: in another order a tie partner of j would have been scanned in its place */
+						int64_t jj;
+						for (jj = j - 1; jj >= st && a[jj].x == a[j].x; --jj) {
+							int64_t dr2 = ri - a[jj].x; int32_t dq2 = qi - (int32_t)a[jj].y, dd2;
+							if (dr2 == 0 || dq2 <= 0 || dq2 > max_dist_y) continue;
+							dd2 = dr2 > dq2 ? dr2 - dq2 : dq2 - dr2;
+							if (dd2 <= bw) *band_tie = 1;
+						}
+					}
+					break;
+				}
 			}
 			if (p[j] >= 0) t[p[j]] = i;
 		}
@@ -547,6 +563,9 @@ static void chain_dp_range(const lqo_params *P, float avg_qspan, const lqo_mm128
 		}
 	}
 	lqo_sort_64(u, n_u);                                /* chain.c:102-106 */
+	if (peak_tie)                                       /* two anchors of equal x end chains with the same peak score: the order of the backtracks follows their array order */
+		for (i = 1; i < n_u; ++i)
+			if (u[i] >> 32 == u[i-1] >> 32 && (int32_t)u[i] != (int32_t)u[i-1] && a[(int32_t)u[i]].x == a[(int32_t)u[i-1]].x) *peak_tie = 1;
 	for (i = 0; i < n_u >> 1; ++i) { uint64_t tt = u[i]; u[i] = u[n_u - i - 1], u[n_u - i - 1] = tt; }
 	memset(t, 0, n * 4);                                /* chain.c:108-125 backtrack */
 	for (i = n_v = k = 0; i < n_u; ++i) {
@@ -568,6 +587,39 @@ static void chain_dp_range(const lqo_params *P, float avg_qspan, const lqo_mm128
 	}
 	free(f); free(p); free(t); free(v); free(u);
 }
+
+static void chain_dp_range(const lqo_params *P, float avg_qspan, const lqo_mm128 *a, int64_t n, u64_v *u_out, mm_v *b_out)
+{
+	chain_dp_range_s(P, avg_qspan, a, n, u_out, b_out, 0, 0);
+}
+
+/* ---- "does the order of equal-x anchors matter in this (strand, rid) run?"  (the GPU engine's question: it sorts with any correct
+ * sort and takes klib's order only where it can be observed).  Anchors of equal x never chain to each other (dr == 0, chain.c:52).
+ * For a later anchor i two candidates A, B of equal x are both inside the band only if |dq_A - dq_B| <= 2 bw (chain.c:55), i.e.
+ * |y_A - y_B| <= 2 bw; a candidate outside the band is stepped over before any state changes (the `continue`s of chain.c:52-56
+ * precede chain.c:69-76).  So if all members of every tie group are more than 2 bw apart in y, every scan sees the same sequence
+ * of effective candidates whatever the order inside the groups, and f, p, v are the same per anchor.  The order of the backtracks
+ * (chain.c:102-125) follows (score, array index): it can differ only if two members of a group are peaks of equal score.  Returns
+ * 1 if the first condition fails (static part). */
+static int run_ties_close(const lqo_params *P, const lqo_mm128 *a, int64_t n)
+{
+	int64_t i, j, k;
+	for (i = 0; i < n; i = j) {
+		for (j = i + 1; j < n && a[j].x == a[i].x; ++j) {}
+		for (k = i; k < j; ++k) {
+			int64_t l;
+			for (l = k + 1; l < j; ++l) {
+				int64_t d = (int64_t)(int32_t)a[k].y - (int64_t)(int32_t)a[l].y;
+				if (d < 0) d = -d;
+				if (d <= 2 * (int64_t)P->bw) return 1;
+			}
+		}
+	}
+	return 0;
+}
+static uint64_t g_tie_stats[12];
+void lqo_tie_stats(uint64_t out[12]) { memcpy(out, g_tie_stats, sizeof(g_tie_stats)); }
+void lqo_tie_stats_reset(void) { memset(g_tie_stats, 0, sizeof(g_tie_stats)); }
 
 /* chain.c:139-155: order chains by the x of their first anchor (klib 128x sort on (x, k<<32|i)) */
 static void chains_order_by_x(u64_v *u, mm_v *b)
@@ -818,6 +870,22 @@ static int cmp_anchor_group(const void *a_, const void *b_)    /* stable (x, emi
 	return a < b ? -1 : a > b;
 }
 
+static int cmp_anchor_rev(const void *a_, const void *b_)      /* x ascending, ties in reverse emission order (sort_mode=2) */
+{
+	const lqo_mm128 *a = *(const lqo_mm128* const*)a_, *b = *(const lqo_mm128* const*)b_;
+	if (a->x != b->x) return a->x < b->x ? -1 : 1;
+	return a > b ? -1 : a < b;
+}
+static int cmp_anchor_hash(const void *a_, const void *b_)     /* x ascending, ties by a hash of y (sort_mode=3) */
+{
+	const lqo_mm128 *a = *(const lqo_mm128* const*)a_, *b = *(const lqo_mm128* const*)b_;
+	uint64_t ha, hb;
+	if (a->x != b->x) return a->x < b->x ? -1 : 1;
+	ha = mix64_full(a->y ^ 0x1234567ULL); hb = mix64_full(b->y ^ 0x1234567ULL);
+	if (ha != hb) return ha < hb ? -1 : 1;
+	return a < b ? -1 : a > b;
+}
+
 static void map_query(const lqo_params *P, const part_t *pt, int32_t mid_occ, const fx_rec *q, qstate_t *qst, qmap_out *dbg)
 {
 	lqo_mm128 *mv = 0, *a;
@@ -873,9 +941,57 @@ static void map_query(const lqo_params *P, const part_t *pt, int32_t mid_occ, co
 		const lqo_mm128 **ptr = (const lqo_mm128**)malloc(sizeof(void*) * (n_a ? n_a : 1));
 		lqo_mm128 *a2 = (lqo_mm128*)malloc(sizeof(lqo_mm128) * (n_a ? n_a : 1));
 		for (i = 0; i < (size_t)n_a; ++i) ptr[i] = &a[i];
-		qsort(ptr, n_a, sizeof(void*), cmp_anchor_group);
+		qsort(ptr, n_a, sizeof(void*), P->sort_mode == 1 ? cmp_anchor_group : P->sort_mode == 2 ? cmp_anchor_rev : cmp_anchor_hash);
 		for (i = 0; i < (size_t)n_a; ++i) a2[i] = *ptr[i];
-		free(ptr); free(a); a = a2;
+		free(ptr);
+		if (P->sort_mode >= 2) {
+			/* The engine's scheme: any correct sort (here: an adversarial one), and klib's order only for the (strand, rid) runs
+			 * where the order of equal-x anchors can be observed.  Every other run is chained in both orders and compared. */
+			int64_t lo = 0, hi;
+			int q_any_tie = 0, q_sens = 0;
+			const int span_max = P->hpc ? 255 : P->k;
+			const int64_t n_min = P->min_cnt > (P->min_chain_score + span_max - 1) / span_max ? P->min_cnt : (P->min_chain_score + span_max - 1) / span_max;
+			float avg = 0.0f;
+			uint64_t ss = 0;
+			lqo_sort_128x(a, n_a);                          /* a: klib's order, a2: the adversarial order */
+			for (i = 0; i < (size_t)n_a; ++i) ss += a[i].y >> 32 & 0xff;
+			avg = n_a ? (float)ss / n_a : 0.0f;
+			g_tie_stats[0] += 1; g_tie_stats[1] += n_a;
+			while (lo < n_a) {
+				int has_tie = 0, sens = 0;
+				int64_t z;
+				for (hi = lo + 1; hi < n_a && (a2[hi].x >> 32) == (a2[lo].x >> 32); ++hi) {}
+				for (z = lo + 1; z < hi; ++z) if (a2[z].x == a2[z-1].x) has_tie = 1;
+				if (has_tie) q_any_tie = 1;
+				if (hi - lo >= n_min) {
+					g_tie_stats[2] += 1; g_tie_stats[3] += hi - lo;
+					if (has_tie) {
+						u64_v u1 = {0,0,0}, u2 = {0,0,0}; mm_v b1 = {0,0,0}, b2 = {0,0,0};
+						int peak = 0, band = 0;
+						g_tie_stats[4] += 1;
+						chain_dp_range_s(P, avg, a2 + lo, hi - lo, &u2, &b2, &peak, &band);
+						if (getenv("LQO_TIE_STATIC")) sens = run_ties_close(P, a2 + lo, hi - lo);
+						else if (getenv("LQO_TIE_NONE")) sens = 0;
+						else sens = band;
+						if (peak && !getenv("LQO_TIE_NONE")) sens = 1;
+						if (peak) g_tie_stats[11] += 1;
+						if (sens) { g_tie_stats[5] += 1; g_tie_stats[6] += hi - lo; q_sens = 1; memcpy(a2 + lo, a + lo, (hi - lo) * sizeof(lqo_mm128)); }
+						else {
+							chain_dp_range(P, avg, a + lo, hi - lo, &u1, &b1);
+							if (u1.n != u2.n || b1.n != b2.n || (u1.n && memcmp(u1.a, u2.a, u1.n * 8)) || (b1.n && memcmp(b1.a, b2.a, b1.n * sizeof(lqo_mm128)))) {
+								g_tie_stats[7] += 1;
+								if (getenv("LQO_TIE_VERBOSE")) fprintf(stderr, "[tie] query %s run at %lld len %lld: chains differ between klib's order and another although no tie is observable by the rule\n", q->name, (long long)lo, (long long)(hi - lo));
+							}
+						}
+						free(u1.a); free(u2.a); free(b1.a); free(b2.a);
+					}
+				}
+				lo = hi;
+			}
+			g_tie_stats[8] += q_any_tie; g_tie_stats[9] += q_sens;
+			if (q_sens) g_tie_stats[10] += n_a;
+		}
+		free(a); a = a2;
 	}
 	/* mm_chain_dp (lqmap.c:252) */
 	for (i = 0; i < (size_t)n_a; ++i) sum_qspan += a[i].y >> 32 & 0xff;

@@ -39,7 +39,9 @@ typedef struct {
 	int ava;                    /* -X sets MM_F_AVA (cmp>0 skip) */
 	int filter_flag;            /* --filter row format */
 	/* ---- knobs of the restatement, not of the reference ---- */
-	int sort_mode;              /* 0 = klib in-place radix order (reference), 1 = stable (x, emission) */
+	int sort_mode;              /* 0 = klib in-place radix order (reference), 1 = stable (x, emission),
+	                               2 / 3 = the engine's scheme: an adversarial order of equal-x anchors (reverse emission /
+	                               hashed), klib's order only in the (strand, rid) runs where the order is observable */
 	int chain_mode;             /* 0 = whole-array DP (reference), 1 = per (strand,rid) group DP with
 	                               the <min_cnt group pre-filter (the GPU formulation) */
 } lqo_params;
@@ -72,6 +74,13 @@ void lqo_sort_32(uint32_t *a, size_t n);
 uint32_t lqo_sdust_masked(const char *seq, int l_seq, int T, int W);
 int lqo_sdust_file(const char *fn, int W, int T, FILE *out);
 int lqo_sdust_path(const char *fn, int W, int T, const char *out_fn);
+
+/* sort_mode 2 / 3 bookkeeping: [0] queries [1] anchors [2] runs that can hold a chain [3] their anchors [4] such runs with
+ * equal-x anchors [5] of those, runs where the order is observable [6] their anchors [7] MISMATCHES (runs declared
+ * order-free whose chains differ between klib's order and the adversarial one: must stay 0) [8] queries with any equal x
+ * [9] queries with an observable run [10] anchors of those queries */
+void lqo_tie_stats(uint64_t out[12]);
+void lqo_tie_stats_reset(void);
 
 /* timing breakdown of the last lqo_run_files call, seconds: [0]=parse [1]=sketch+index [2]=map [3]=format */
 void lqo_last_timing(double t[4]);

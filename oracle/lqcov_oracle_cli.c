@@ -7,7 +7,7 @@
  *   lqcov_oracle sketch [opts] <reads>
  *   lqcov_oracle index  [opts] <targets>
  *   lqcov_oracle chains [opts] <targets> <queries>
- *   opts: -k -w -H -I -g -n -m -p -q -s -a -l -c -r -Y -X -f  --stable-sort --grouped
+ *   opts: -k -w -H -I -g -n -m -p -q -s -a -l -c -r -Y -X -f  --stable-sort --grouped --ties-reversed --ties-hashed
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -50,6 +50,8 @@ int main(int argc, char **argv)
 		if (a[0] == '-' && a[1] == '-') {
 			if (!strcmp(a, "--stable-sort")) p.sort_mode = 1;
 			else if (!strcmp(a, "--grouped")) p.chain_mode = 1;
+			else if (!strcmp(a, "--ties-reversed")) p.sort_mode = 2, p.chain_mode = 1;
+			else if (!strcmp(a, "--ties-hashed")) p.sort_mode = 3, p.chain_mode = 1;
 			else if (!strcmp(a, "--filter")) p.filter_flag = 1;
 			else { fprintf(stderr, "unknown option %s\n", a); return 2; }
 		} else if (a[0] == '-' && a[1]) {
@@ -89,7 +91,17 @@ int main(int argc, char **argv)
 	}
 	if (!p_set || p.min_score_med == 0) p.min_score_med = p.min_chain_score;   /* minimap2-coverage.c:324-332 */
 	if (!q_set || p.min_score_good == 0) p.min_score_good = p.min_chain_score;
-	if (!strcmp(argv[1], "table") && npos == 2) return lqo_run_files(&p, pos[0], pos[1], stdout, stderr) ? 1 : 0;
+	if (!strcmp(argv[1], "table") && npos == 2) {
+		int rc = lqo_run_files(&p, pos[0], pos[1], stdout, stderr) ? 1 : 0;
+		if (p.sort_mode >= 2) {
+			uint64_t s[12]; lqo_tie_stats(s);
+			fprintf(stderr, "[ties] queries %llu anchors %llu | runs>=n_min %llu (%llu anchors) with ties %llu observable %llu (%llu anchors) MISMATCH %llu | queries with ties %llu with observable runs %llu (%llu anchors)\n",
+			        (unsigned long long)s[0], (unsigned long long)s[1], (unsigned long long)s[2], (unsigned long long)s[3], (unsigned long long)s[4], (unsigned long long)s[5],
+			        (unsigned long long)s[6], (unsigned long long)s[7], (unsigned long long)s[8], (unsigned long long)s[9], (unsigned long long)s[10]);
+			if (s[7]) rc = 3;
+		}
+		return rc;
+	}
 	if (!strcmp(argv[1], "sketch") && npos == 1) return lqo_dump_sketch(&p, pos[0], stdout) ? 1 : 0;
 	if (!strcmp(argv[1], "index") && npos == 1) return lqo_dump_index(&p, pos[0], stdout) ? 1 : 0;
 	if (!strcmp(argv[1], "chains") && npos == 2) return lqo_dump_chains(&p, pos[0], pos[1], stdout) ? 1 : 0;
