@@ -167,6 +167,8 @@ def main():
 
     eng = api.Engine(p, device=local)
     anchors = [0]
+    written = [0]                                                                 # anchors the first pass of the mapping wrote (k_seed_count's survivors), per step
+    mstats = [None]
     if world == 1:
         eng.set_queries(Q.names, Q.seqs, Q.quals)
         pts = [eng.part_begin(), eng.part_begin()] if len(parts) > 1 else [eng.part_begin()]
@@ -184,23 +186,32 @@ def main():
 
         def step(h2d=True):
             eng.reset()
-            a = 0
+            a = w = 0
             if h2d or len(parts) > 1:
                 build(0)
             else:
                 eng.part_build(pts[0])
             for i in range(len(parts)):
                 th = None
+                err = []
                 if i + 1 < len(parts) and have_cuda:
-                    th = threading.Thread(target=build, args=(i + 1,)); th.start()
+                    def guarded(j=i + 1):
+                        try:
+                            build(j)
+                        except BaseException as e:                # (a thread's exception would vanish: carried to the caller)
+                            err.append(e)
+                    th = threading.Thread(target=guarded); th.start()
                 eng.part_map(pts[i % 2])
                 a += eng.last_n_anchors
+                w += eng.map_stats()["last_written"]
                 if th is not None:
                     th.join()
+                    if err:
+                        raise err[0]
                 elif i + 1 < len(parts):
                     build(i + 1)                                  # (the CPU dry run of this script: the test emulator runs one kernel at a time)
             eng.finish()
-            anchors[0] = a
+            anchors[0] = a; written[0] = w; mstats[0] = eng.map_stats()
     else:
         # N GPUs, the north-star split (longqc_amd/multigpu.py): every rank sketches 1/N of each part, the minimizers are
         # all-gathered over RCCL, every rank builds the same index and maps its 1/N of the queries; rows gathered on rank 0.
@@ -226,7 +237,7 @@ def main():
                 runner.map_part(pt, rid_base, nm, ln)
                 a += eng.last_n_anchors
             table[0] = runner.gather_table()
-            anchors[0] = a
+            anchors[0] = a; mstats[0] = eng.map_stats()
 
     if args.front_only and world == 1:
         best = {}
@@ -347,6 +358,8 @@ def main():
                                    + (" [-I overridden: %s]" % args.index_size if args.index_size else ""),
                        "index_parts": [int(F.off[hi] - F.off[lo]) for lo, hi in parts],
                        "target_bases": int(total_bases), "query_bases": int(Q.n_bases), "anchors_per_step": int(n_anchors),
+                       "anchors_written_per_step": int(written[0]) if world == 1 else None,      # seed hits whose (strand, target) can reach a chain: the others are never written
+                       "klib_order": {k: v for k, v in (mstats[0] or {}).items() if k != "last_written"},   # runs / queries / anchors that needed klib's own order of equal-x anchors (second pass)
                        "clock": "H2D of the packed reads (pinned) -> sketch -> index -> seed -> sort -> chain -> coverage -> rows D2H, all parts (SURVEY 8d), "
                                 + ("part i+1's upload + sketch + index under part i's mapping; " if world == 1 and len(parts) > 1 else "") +
                                 "before the clock: the synthetic generator (= FASTQ parse) and the host-side 2-bit packing (host_pack_s) -- value_incl_host_pack adds the latter, unoverlapped",

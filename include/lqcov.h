@@ -185,6 +185,11 @@ int32_t  lqcov_mid_occ(const lqcov_handle *h);                             /* ma
 uint64_t lqcov_part_n_minimizers(const lqcov_handle *h, int part);
 uint64_t lqcov_part_n_keys(const lqcov_handle *h, int part);
 uint64_t lqcov_last_n_anchors(const lqcov_handle *h);
+/* What the mapping did with the seed hits (collect_seed_hits, lqmap.c:140-205 / radix_sort_128x, lqmap.c:238), for logs and
+ * benchmarks: out[0] = anchors written against the last part (the hits whose (strand, target) can reach a chain), out[1..3] =
+ * since lqcov_reset: runs chained in klib's own order of equal-x anchors, the queries that own them, the anchors those
+ * queries were sorted by klib's passes for.  No counterpart in the reference (it writes and sorts every hit). */
+void lqcov_map_stats(const lqcov_handle *h, uint64_t out[4]);
 /* minimizers of the query set / of a part, reference encoding (sketch.c:70-72): xy[2*i], xy[2*i+1];
  * off[n+1] per-read offsets.  Pass NULL buffers to get the total in *n_total. */
 int lqcov_get_query_minimizers(lqcov_handle *h, uint64_t *xy, uint64_t *off, uint64_t *n_total);

@@ -111,6 +111,7 @@ def load_library(path: Optional[str] = None):
         "lqcov_part_n_minimizers": (C.c_uint64, [H, C.c_int]),
         "lqcov_part_n_keys": (C.c_uint64, [H, C.c_int]),
         "lqcov_last_n_anchors": (C.c_uint64, [H]),
+        "lqcov_map_stats": (None, [H, u64p]),
         "lqcov_get_query_minimizers": (C.c_int, [H, C.c_void_p, C.c_void_p, u64p]),
         "lqcov_get_part_minimizers": (C.c_int, [H, C.c_int, C.c_void_p, C.c_void_p, u64p]),
         "lqcov_get_chains": (C.c_int, [H, C.c_void_p, C.c_uint64, u64p]),
@@ -394,6 +395,12 @@ class Engine:
     @property
     def last_n_anchors(self) -> int:
         return int(self.lib.lqcov_last_n_anchors(self.h))
+
+    def map_stats(self) -> dict:
+        """anchors written against the last part; since reset(): runs / queries / anchors that needed klib's own order"""
+        a = (C.c_uint64 * 4)()
+        self.lib.lqcov_map_stats(self.h, a)
+        return {"last_written": int(a[0]), "klib_runs": int(a[1]), "klib_queries": int(a[2]), "klib_anchors": int(a[3])}
 
     def part_n_minimizers(self, part: int) -> int:
         return int(self.lib.lqcov_part_n_minimizers(self.h, part))

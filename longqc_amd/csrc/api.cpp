@@ -342,6 +342,11 @@ int32_t lqcov_mid_occ(const lqcov_handle *h) { return h ? h->mid_occ : -1; }
 uint64_t lqcov_part_n_minimizers(const lqcov_handle *h, int part) { return (h && part >= 0 && (size_t)part < h->parts.size() && h->parts[part]) ? h->parts[part]->rs.n_mini : 0; }
 uint64_t lqcov_part_n_keys(const lqcov_handle *h, int part) { return (h && part >= 0 && (size_t)part < h->parts.size() && h->parts[part]) ? h->parts[part]->n_keys : 0; }
 uint64_t lqcov_last_n_anchors(const lqcov_handle *h) { return h ? h->last_n_anchors : 0; }
+void lqcov_map_stats(const lqcov_handle *h, uint64_t out[4])
+{
+	if (!out) return;
+	out[0] = h ? h->last_n_written : 0; out[1] = h ? (uint64_t)h->stat_sens_runs : 0; out[2] = h ? (uint64_t)h->stat_p2_queries : 0; out[3] = h ? (uint64_t)h->stat_p2_anchors : 0;
+}
 
 static void copy_minimizers(lqcov_handle *h, ReadSetDev &rs, uint64_t *xy, uint64_t *off, uint64_t *n_total)
 {

@@ -108,6 +108,14 @@ void Knobs::read_env()
 	ps_grid = (u32)std::max<long>(64, num("LQCOV_PS_GRID", 512));
 	tile_grid = (u32)std::max<long>(64, num("LQCOV_TILE_GRID", 4096));
 	ps_passes = (u32)std::min<long>(16, std::max<long>(0, num("LQCOV_PS_PASSES", 2))) & ~1u;
+	ties_klib = is("LQCOV_TIES", "klib") || all_klib;
+	filter = num("LQCOV_FILTER", 1) != 0;
+	{
+		long kc = num("LQCOV_FILTER_KEYS", (long)LQ_FT_WORDS * 16);
+		u32 v = 16; while (v * 2 <= (u32)std::min<long>(std::max<long>(kc, 16), (long)LQ_FT_WORDS * 16)) v *= 2;   // a power of two in [16, 16 * LQ_FT_WORDS]
+		filt_keys = v;
+		filt_acap = (u32)std::max<long>(1, num("LQCOV_FILTER_ACAP", (long)(0.6 * v)));
+	}
 }
 
 lqcov_handle::lqcov_handle(const lqcov_params &p, int dev) : P(p), device(dev)
@@ -510,6 +518,7 @@ void lqcov_handle::reset()
 	dzero(cnts.p, cnt_count() * 4 + 4, stream);
 	dzero(n_pv.p, 4, stream);
 	if (!distributed) mid_occ = -1;
+	stat_sens_runs = 0; stat_p2_queries = 0; stat_p2_anchors = 0;
 	finished = false;
 	LQ_HIP_CHECK(hipStreamSynchronize(stream));
 }
@@ -616,122 +625,226 @@ void lqcov_handle::build_part(Part &pt)
 	build_index(pt);
 }
 
-// one batch of queries [q0, q1) against one part, on lane L: seed emit -> klib-order sort -> chains -> per-query intervals
-void lqcov_handle::map_batch(MapLane &L, Part &pt, u32 q0, u32 q1, const std::vector<u64> &h_aq, const std::vector<u64> &h_qmoff, bool dbg)
+// LQCOV_DEBUG_SORT: the sort is a permutation (a sum over the anchors as emitted = the same sum afterwards: the finishing
+// kernels rebuild x from the key), every query is ascending in x, anchors with equal x both carry the tie mark
+static u64 dbg_anchor_sum(const mm128 &a) { u64 h = (a.x * 0x9E3779B97F4A7C15ULL) ^ (a.y * 0xD6E8FEB86659FD93ULL); return h ^ (h >> 29); }
+
+// sort_batch with the LQCOV_DEBUG_SORT checks around it; h_off: the batch's per-query anchor offsets (relative, nqb + 1), h_klib: which queries' anchors are in B
+void lqcov_handle::sort_checked(MapLane &L, Part &pt, const u64 *aqb, const u32 *qkb, u32 nqb, u64 a_base, u64 nA, const std::vector<u64> &h_off, const std::vector<u32> &h_klib)
+{
+	mm128 *dA = L.A.as<mm128>(), *dB = L.B.as<mm128>();
+	u64 sum_before = 0;
+	if (K.debug_sort) {
+		std::vector<mm128> ha(nA), hb(nA);
+		d2h(ha.data(), dA, nA, L.stream); d2h(hb.data(), dB, nA, L.stream);
+		for (u32 q = 0; q < nqb; ++q)
+			for (u64 i = h_off[q]; i < h_off[q + 1]; ++i) sum_before += dbg_anchor_sum(h_klib[q] ? hb[i] : ha[i]);
+	}
+	sort_batch(L, pt, aqb, qkb, nqb, a_base, nA);           // lqmap.c:238
+	if (K.debug_sort) {
+		std::vector<mm128> ha(nA);
+		d2h(ha.data(), dA, nA, L.stream);
+		u64 sum_after = 0;
+		for (u64 i = 0; i < nA; ++i) sum_after += dbg_anchor_sum(ha[i]);
+		if (sum_after != sum_before) fprintf(stderr, "[sort] batch of %u queries: NOT A PERMUTATION of the emitted anchors (sums %016llx / %016llx)\n", nqb, (unsigned long long)sum_before, (unsigned long long)sum_after);
+		u64 unsorted = 0, ties = 0, unmarked = 0;
+		for (u32 q = 0; q < nqb; ++q)
+			for (u64 i = h_off[q] + 1; i < h_off[q + 1]; ++i) {
+				if (ha[i].x < ha[i - 1].x) ++unsorted;
+				if (ha[i].x == ha[i - 1].x) { ++ties; if (!(ha[i].y & LQ_TIE_MARK) || !(ha[i - 1].y & LQ_TIE_MARK)) { if (unmarked++ < 4) fprintf(stderr, "[sort] query %u of the batch: equal x %016llx, y %016llx / %016llx\n", q, (unsigned long long)ha[i].x, (unsigned long long)ha[i - 1].y, (unsigned long long)ha[i].y); } }
+			}
+		fprintf(stderr, "[sort] batch of %u queries: %llu anchors, %llu out of order, %llu equal-x neighbours, %llu of them with an unmarked anchor\n", nqb, (unsigned long long)nA, (unsigned long long)unsorted, (unsigned long long)ties, (unsigned long long)unmarked);
+		if (sum_after != sum_before || unsorted || unmarked) throw std::logic_error("LQCOV_DEBUG_SORT: the sorted anchors are not a permutation of the emitted ones, not ascending, or hold an unmarked tie (see stderr)");
+	}
+}
+
+// work space of one batch of nA anchors on lane L
+void lqcov_handle::batch_buffers(MapLane &L, u64 nA)
+{
+	if (nA > 0xfffffff0ULL) throw std::domain_error("a single query produces more than 2^32 anchors against this part");
+	const u64 nA4 = ((nA + 1) * 4 + 15) & ~(u64)15;
+	L.A.ensure((nA + 1) * 16); L.B.ensure(std::max<u64>((nA + 1) * 16, nA4 * 4));   // (B: the originals, then the chain's four 4-byte arrays of nA4 bytes each)
+	// 20 B per anchor of scratch: the X / Y position lists of the two-bucket passes (8 B) and the second record array (8 B, in
+	// the place of the chain's u[]) during the sort.  The chain's f/p/t/v (16 B per anchor) reuse B, which is dead once sorted.
+	L.scr.ensure(nA4 * 5 + 64);
+}
+
+// The sorted anchors of a batch (in L.A; per-query offsets aqb, absolute, the batch starts at a_base): the (strand, rid) runs long
+// enough to hold a chain, mm_chain_dp + mm_gen_regs + lq_cnt_match on them (chain.c, hit.c, esterr.c).  tie_mode: CovState.
+void lqcov_handle::chain_stage(MapLane &L, Part &pt, const u64 *aqb, u64 a_base, u32 nqb, u32 q0, const u32 *qmap, u64 nA, int tie_mode, u32 n_want, u32 ivl_cap, bool dbg)
+{
+	mm128 *dA = L.A.as<mm128>();
+	const u64 nA4 = ((nA + 1) * 4 + 15) & ~(u64)15;
+	u64 *d_cu = (u64*)((u8*)L.scr.p + 3 * nA4);
+	i32 *d_cf = (i32*)L.B.p, *d_cp = (i32*)((u8*)L.B.p + nA4), *d_ct = (i32*)((u8*)L.B.p + 2 * nA4), *d_cv = (i32*)((u8*)L.B.p + 3 * nA4);
+	// ---- (strand, rid) runs long enough to hold a chain ----
+	u64 n_groups = 0;
+	{
+		const u32 n_tiles = (u32)((nA + LQ_RUN_TILE - 1) / LQ_RUN_TILE);
+		const u32 n_min = run_n_min();
+		L.run_tiles.ensure(16);
+		L.gstart.ensure((nA / n_min + 1) * 8);
+		dzero(L.run_tiles.p, 4, L.stream);
+		{
+			StageTimer t(this, L.stream, "k_run_list", nA * 16);
+			LQ_LAUNCH(k_run_list, std::min<u32>(n_tiles, K.run_grid), LQ_RUN_THREADS, L.stream, dA, nA, aqb, a_base, nqb, n_tiles, n_min, std::max<u32>(LQ_RUN_THREADS, std::min<u32>(K.run_stage, LQ_RUN_STAGE)), L.run_tiles.as<u32>(), L.gstart.as<u64>()); check_launch();
+		}
+		u32 ng = 0;
+		d2h(&ng, L.run_tiles.as<u32>(), 1, L.stream);
+		n_groups = ng;
+	}
+	// ---- chain + coverage ----
+	ChainBufs cb; cb.f = d_cf; cb.p = d_cp; cb.t = d_ct; cb.v = d_cv; cb.u = d_cu;
+	CovState cs;
+	cs.lambda = lambda.as<unsigned long long>(); cs.lambda2 = lambda2.as<unsigned long long>();
+	cs.cnts = cnts.as<u32>(); cs.qflags = qflags.as<u32>(); cs.skip = skip.as<u32>(); cs.qmoff = cnt_off_dev();
+	cs.mini_pos = mini_pos.as<u64>(); cs.mpq_off = mpq_off.as<u64>(); cs.qlen = q.d_len.as<u32>(); cs.tlen = pt.rs.d_len.as<u32>();
+	cs.ivl = L.ivl.as<Ivl>(); cs.n_ivl = L.n_ivl.as<u32>(); cs.ivl_cap = ivl_cap;
+	cs.dbg = dbg ? dbg_chains.as<ChainRec>() : nullptr; cs.n_dbg = n_dbg.as<unsigned long long>(); cs.dbg_cap = dbg_cap;
+	cs.tie_mode = tie_mode; cs.qmap = qmap;
+	cs.sens = nullptr; cs.n_sens = L.n_sens.as<u32>(); cs.sens_cap = 0; cs.want = L.want.as<unsigned long long>(); cs.n_want = n_want;
+	if (tie_mode == 1) {                                        // (every listed run can end up in the list)
+		L.sens.ensure((n_groups + 1) * 8);
+		cs.sens = L.sens.as<unsigned long long>(); cs.sens_cap = (u32)std::min<u64>(n_groups, 0xfffffff0ULL);
+	}
+	if (n_groups > 0xfffffff0ULL) throw std::domain_error("too many anchor runs in one batch");
+	const int cap = K.chain_cap <= 64 ? 64 : K.chain_cap <= 128 ? 128 : 256;   // anchors of LDS per wave in k_chain
+	// runs of >= wave_min anchors take the cooperative kernel; a run must fit k_chain's LDS budget on its own
+	const int wave_min = std::min(cap + 1, K.chain_wave_min > 0 ? K.chain_wave_min : LQ_CHAIN_WAVE_MIN);
+	if (n_groups) {	// one thread per run, in array order, DP state of a wave's runs packed into LDS (in rounds if they exceed the budget).
+		// Measured alternatives that were not faster on MI355X: a compacted longest-first work list for all runs (409 vs 292 ms at
+		// configs[1]), a dense list in array order of the runs of min_cnt..47 anchors (configs[2]: within the run-to-run spread),
+		// private-array DP for short runs, and a fixed [16][64] LDS column per lane (54 KiB per wave: 160 + 40 ms vs 113 ms).
+		// wave_min - 1 <= 47 < the smallest budget, so every run fits.
+		StageTimer t(this, L.stream, "k_chain", nA * 16);
+#define LQ_CHAIN_LAUNCH(CAP) LQ_LAUNCH((k_chain<CAP>), nblk(n_groups, 64), 64, L.stream, dA, L.gstart.as<u64>(), (const u32*)nullptr, (u32)n_groups, aqb, a_base, nqb, q0, avg_qspan.as<float>(), mp, cs, (i32)P.min_cnt, (i32)(wave_min - 1))
+		if (cap == 64) { LQ_CHAIN_LAUNCH(64); } else if (cap == 128) { LQ_CHAIN_LAUNCH(128); } else { LQ_CHAIN_LAUNCH(256); }
+#undef LQ_CHAIN_LAUNCH
+		check_launch();
+	}
+	{	// long runs: one wave per run, longest first
+		u32 n_sel = 0;
+		const u32 n_tiles = (u32)((n_groups + LQ_RUN_TILE - 1) / LQ_RUN_TILE);
+		L.sel_tiles.ensure(((u64)n_tiles + 2) * 4);
+		LQ_LAUNCH(k_sel_count, std::min<u32>(std::max<u32>(n_tiles, 1), 1u << 16), LQ_RUN_THREADS, L.stream, L.gstart.as<u64>(), n_groups, (i32)wave_min, (i32)0x7fffffff, n_tiles, L.sel_tiles.as<u32>()); check_launch();
+		LQ_LAUNCH(k_tile_scan, 1, LQ_TSCAN_THREADS, L.stream, L.sel_tiles.as<u32>(), n_tiles); check_launch();
+		d2h(&n_sel, L.sel_tiles.as<u32>() + n_tiles, 1, L.stream);
+		if (n_sel) {
+			L.gsel.ensure((u64)n_sel * 4); L.gkey.ensure((u64)n_sel * 4); L.gsel2.ensure((u64)n_sel * 4); L.gkey2.ensure((u64)n_sel * 4);
+			LQ_LAUNCH(k_sel_write, std::min<u32>(n_tiles, 1u << 16), LQ_RUN_THREADS, L.stream, L.gstart.as<u64>(), n_groups, (i32)wave_min, (i32)0x7fffffff, n_tiles, L.sel_tiles.as<u32>(), L.gsel.as<u32>(), L.gkey.as<u32>()); check_launch();
+			L.prim.sort_pairs_u32_u32(L.gkey.as<u32>(), L.gkey2.as<u32>(), L.gsel.as<u32>(), L.gsel2.as<u32>(), n_sel);
+			StageTimer t(this, L.stream, "k_chain_wave");
+			LQ_LAUNCH(k_chain_wave, n_sel, 64, L.stream, dA, L.gstart.as<u64>(), L.gsel2.as<u32>(), n_sel, aqb, a_base, nqb, q0, avg_qspan.as<float>(), mp, cb, cs);
+			check_launch();
+		}
+	}
+}
+
+// one batch of queries [q0, q1) against one part, on lane L: seeds -> sort -> chains -> per-query intervals.
+//
+// Two ways (Knobs::ties_klib):
+//  * klib's order everywhere (the reference's own arrangement, lqmap.c:238): every seed hit is written, queries with repeated
+//    (hash, strand) minimizers go through klib's passes (sort_batch);
+//  * the default: klib's order only where it can be observed.  First pass: only the hits whose (strand, rid) can reach a chain
+//    at all are written (k_seed_count's survivors, h_aqf / aqf_off: their per-query offsets), every query is sorted by the
+//    parallel sort (equal x in no particular order), and the chain kernels list the runs in which the order of equal-x anchors
+//    matters instead of chaining them (kernels_chain.hpp: two of them inside one scan's band, or both peaks of one score;
+//    oracle: sort modes 2 / 3, tests/test_tie_order.py).  Second pass, for the queries that own a listed run: all their seed
+//    hits in the reference's emission order, klib's passes, and only the listed runs are chained.  Runs never interact
+//    (chain.c:47) and everything they feed commutes, so the split is exact.
+void lqcov_handle::map_batch(MapLane &L, Part &pt, u32 q0, u32 q1, const std::vector<u64> &h_aq, const std::vector<u64> &h_aqf, const std::vector<u64> &h_qmoff, bool dbg)
 {
 	const u32 n_q = q.n;
 	L.gate_passed = false;
 	struct GateGuard { lqcov_handle *h; MapLane &L; ~GateGuard() { if (!L.gate_passed) { L.gate_passed = true; h->open_gate(); } } } gate_guard{this, L};
-	L.n_segs.ensure(64); L.n_ivl.ensure(4);
-	const u64 a_base = h_aq[q0], nA = h_aq[q1] - a_base;
+	L.n_segs.ensure(64); L.n_ivl.ensure(4); L.n_sens.ensure(4); L.want.ensure(8);
+	const bool opt = !K.ties_klib;
+	const std::vector<u64> &h_off = opt ? h_aqf : h_aq;
+	const u64 a_base = h_off[q0], nA = h_off[q1] - a_base;
 	const u32 nqb = q1 - q0;
 	const u64 j0 = h_qmoff[q0], nj = h_qmoff[q1] - j0;
-	if (nA > 0xfffffff0ULL) throw std::domain_error("a single query produces more than 2^32 anchors against this part");
-	const u64 nA4 = ((nA + 1) * 4 + 15) & ~(u64)15;
-	L.A.ensure((nA + 1) * 16); L.B.ensure(std::max<u64>((nA + 1) * 16, nA4 * 4));   // (B: the originals, then the chain's four 4-byte arrays of nA4 bytes each)
-	mm128 *dA = L.A.as<mm128>(), *dB = L.B.as<mm128>();
-	// 20 B per anchor of scratch: the X / Y position lists of the two-bucket passes (8 B) and the second record array (8 B, in
-	// the place of the chain's u[]) during the sort.  The chain's f/p/t/v (16 B per anchor) reuse B, which is dead once sorted.
-	L.scr.ensure(nA4 * 5 + 64);
-	u64 *d_cu = (u64*)((u8*)L.scr.p + 3 * nA4);
-	i32 *d_cf = (i32*)L.B.p, *d_cp = (i32*)((u8*)L.B.p + nA4), *d_ct = (i32*)((u8*)L.B.p + 2 * nA4), *d_cv = (i32*)((u8*)L.B.p + 3 * nA4);
-	if (nj) {
+	batch_buffers(L, nA);
+	const AvaView ava{P.ava ? pt.t_rank.as<u32>() : nullptr, P.ava ? pt.q_lo.as<u32>() : nullptr};
+	if (nj && !opt) {
 		StageTimer t(this, L.stream, "k_seed_emit", nj * 32 + nA * 24);
 		LQ_LAUNCH(k_seed_emit, nblk(nj, LQ_EMIT_THREADS), LQ_EMIT_THREADS, L.stream, q.mx.as<u64>(), q.my.as<u64>(), q_owner.as<u32>(), q.moff.as<u64>(), j0, nj,
 		          pt.pos.as<u64>(), hit_start.as<u64>(), hit_n.as<u32>(), keep.as<u32>(), dup.as<u32>(),
 		          a_off.as<u64>(), a_base, mp_off.as<u64>(), q.d_len.as<u32>(),
-		          (int)P.no_self, pt.self_off.as<u32>(), pt.self_rid.as<u32>(), AvaView{P.ava ? pt.t_rank.as<u32>() : nullptr, P.ava ? pt.q_lo.as<u32>() : nullptr},
-		          qklib.as<u32>(), dA, dB, mini_pos.as<u64>());
+		          (int)P.no_self, pt.self_off.as<u32>(), pt.self_rid.as<u32>(), ava,
+		          qklib.as<u32>(), L.A.as<mm128>(), L.B.as<mm128>(), mini_pos.as<u64>(), EmitSub{nullptr, nullptr, nullptr});
 		check_launch();
 	}
+	if (nj && opt) {
+		StageTimer t(this, L.stream, "k_seed_emit_f", nj * 40 + (h_aq[q1] - h_aq[q0]) / 8 + nA * 16);   // (algorithmic: the bitmap in, the surviving anchors out; the lists were read by k_seed_count)
+		LQ_LAUNCH(k_seed_emit_f, nblk(nj, LQ_EMIT_THREADS), LQ_EMIT_THREADS, L.stream, q.mx.as<u64>(), q.my.as<u64>(), q_owner.as<u32>(), q.moff.as<u64>(), j0, nj,
+		          pt.pos.as<u64>(), hit_start.as<u64>(), hit_n.as<u32>(), keep.as<u32>(), dup.as<u32>(),
+		          fm_off.as<u64>(), fmask.as<u64>(), cntf.as<u32>(), af_off.as<u64>(), a_base, mp_off.as<u64>(), q.d_len.as<u32>(),
+		          L.A.as<mm128>(), mini_pos.as<u64>());
+		check_launch();
+	}
+	const u32 ivl_cap = (u32)std::min<u64>(nA / (P.min_cnt > 0 ? P.min_cnt : 1) + 16, 0xfffffff0ULL);
+	L.ivl.ensure((u64)ivl_cap * sizeof(Ivl));
+	dzero(L.n_ivl.p, 4, L.stream); dzero(L.n_sens.p, 4, L.stream);
 	if (nA) {
-		const u64 *aqb = aq_off.as<u64>() + q0;          // batch view of the per-query anchor offsets
-		// LQCOV_DEBUG_SORT: the sort is a permutation (a sum over the anchors as emitted = the same sum afterwards: the finishing
-		// kernels rebuild x from the key), every query is ascending in x, anchors with equal x both carry the tie mark
-		auto anchor_sum = [](const mm128 &a) { u64 h = (a.x * 0x9E3779B97F4A7C15ULL) ^ (a.y * 0xD6E8FEB86659FD93ULL); return h ^ (h >> 29); };
-		u64 sum_before = 0;
+		const u64 *aqb = (opt ? aqf_off.as<u64>() : aq_off.as<u64>()) + q0;          // batch view of the per-query anchor offsets
+		const u32 *qkb = opt ? qzero.as<u32>() : qklib.as<u32>() + q0;               // (first pass: nobody goes through klib's passes)
+		std::vector<u64> rel; std::vector<u32> hk;
 		if (K.debug_sort) {
-			std::vector<mm128> ha(nA), hb(nA);
-			std::vector<u32> hk(nqb);
-			d2h(ha.data(), dA, nA, L.stream); d2h(hb.data(), dB, nA, L.stream); d2h(hk.data(), qklib.as<u32>() + q0, nqb, L.stream);
-			for (u32 q = q0; q < q1; ++q)
-				for (u64 i = h_aq[q] - a_base; i < h_aq[q + 1] - a_base; ++i) sum_before += anchor_sum(hk[q - q0] ? hb[i] : ha[i]);
+			rel.resize(nqb + 1); hk.assign(nqb, 0);
+			for (u32 i = 0; i <= nqb; ++i) rel[i] = h_off[q0 + i] - a_base;
+			if (!opt) d2h(hk.data(), qklib.as<u32>() + q0, nqb, L.stream);
 		}
-		sort_batch(L, pt, q0, nqb, a_base, nA);           // lqmap.c:238
-		if (K.debug_sort) {
-			std::vector<mm128> ha(nA);
-			d2h(ha.data(), dA, nA, L.stream);
-			u64 sum_after = 0;
-			for (u64 i = 0; i < nA; ++i) sum_after += anchor_sum(ha[i]);
-			if (sum_after != sum_before) fprintf(stderr, "[sort] batch %u..%u: NOT A PERMUTATION of the emitted anchors (sums %016llx / %016llx)\n", q0, q1, (unsigned long long)sum_before, (unsigned long long)sum_after);
-			u64 unsorted = 0, ties = 0, unmarked = 0;
-			for (u32 q = q0; q < q1; ++q)
-				for (u64 i = h_aq[q] - a_base + 1; i < h_aq[q + 1] - a_base; ++i) {
-					if (ha[i].x < ha[i - 1].x) ++unsorted;
-					if (ha[i].x == ha[i - 1].x) { ++ties; if (!(ha[i].y & LQ_TIE_MARK) || !(ha[i - 1].y & LQ_TIE_MARK)) { if (unmarked++ < 4) fprintf(stderr, "[sort] query %u: equal x %016llx, y %016llx / %016llx\n", q, (unsigned long long)ha[i].x, (unsigned long long)ha[i - 1].y, (unsigned long long)ha[i].y); } }
-				}
-			fprintf(stderr, "[sort] batch %u..%u: %llu anchors, %llu out of order, %llu equal-x neighbours, %llu of them with an unmarked anchor\n", q0, q1, (unsigned long long)nA, (unsigned long long)unsorted, (unsigned long long)ties, (unsigned long long)unmarked);
-			if (sum_after != sum_before || unsorted || unmarked) throw std::logic_error("LQCOV_DEBUG_SORT: the sorted anchors are not a permutation of the emitted ones, not ascending, or hold an unmarked tie (see stderr)");
-		}
-		// ---- (strand, rid) runs long enough to hold a chain ----
-		u64 n_groups = 0;
-		{
-			const u32 n_tiles = (u32)((nA + LQ_RUN_TILE - 1) / LQ_RUN_TILE);
-			const i32 span_max = P.hpc ? 255 : P.k;          // a minimizer's span: k, or up to 255 homopolymer-compressed (sketch.c:99-101)
-			const u32 n_min = (u32)std::max<i32>(std::max<i32>(P.min_cnt, 1), (mp.min_sc + span_max - 1) / span_max);
-			L.run_tiles.ensure(16);
-			L.gstart.ensure((nA / n_min + 1) * 8);
-			dzero(L.run_tiles.p, 4, L.stream);
-			{
-				StageTimer t(this, L.stream, "k_run_list", nA * 16);
-				LQ_LAUNCH(k_run_list, std::min<u32>(n_tiles, K.run_grid), LQ_RUN_THREADS, L.stream, dA, nA, aqb, a_base, nqb, n_tiles, n_min, std::max<u32>(LQ_RUN_THREADS, std::min<u32>(K.run_stage, LQ_RUN_STAGE)), L.run_tiles.as<u32>(), L.gstart.as<u64>()); check_launch();
+		sort_checked(L, pt, aqb, qkb, nqb, a_base, nA, rel, hk);
+		chain_stage(L, pt, aqb, a_base, nqb, q0, nullptr, nA, opt ? 1 : 0, 0, ivl_cap, dbg);
+	}
+	u32 n_sens = 0;
+	if (nA && opt) d2h(&n_sens, L.n_sens.as<u32>(), 1, L.stream);
+	if (n_sens) {
+		// ---- second pass: the queries that own a run in which klib's order can be observed ----
+		std::vector<u64> want(n_sens);
+		d2h(want.data(), L.sens.as<u64>(), n_sens, L.stream);
+		std::sort(want.begin(), want.end());
+		want.erase(std::unique(want.begin(), want.end()), want.end());
+		std::vector<u32> fq;
+		for (u64 k : want) if (fq.empty() || fq.back() != (u32)(k >> 32)) fq.push_back((u32)(k >> 32));
+		L.want.ensure(want.size() * 8);
+		h2d(L.want.as<u64>(), want.data(), want.size(), L.stream);
+		LQ_HIP_CHECK(hipStreamSynchronize(L.stream));
+		stat_sens_runs += want.size(); stat_p2_queries += fq.size();
+		u64 max_mini = 0;
+		for (size_t i = 0; i < fq.size(); ) {
+			std::vector<u32> sq, sk; std::vector<u64> so{0};
+			size_t k = i;
+			while (k < fq.size() && (k == i || so.back() + (h_aq[fq[k] + 1] - h_aq[fq[k]]) <= anchor_budget)) {
+				const u64 len = h_aq[fq[k] + 1] - h_aq[fq[k]];
+				sq.push_back(fq[k]); sk.push_back(len > LQ_RS_MIN ? 1u : 0u); so.push_back(so.back() + len);
+				max_mini = std::max<u64>(max_mini, h_qmoff[fq[k] + 1] - h_qmoff[fq[k]]);
+				++k;
 			}
-			u32 ng = 0;
-			d2h(&ng, L.run_tiles.as<u32>(), 1, L.stream);
-			n_groups = ng;
-		}
-		// ---- chain + coverage ----
-		const u32 ivl_cap = (u32)std::min<u64>(nA / (P.min_cnt > 0 ? P.min_cnt : 1) + 16, 0xfffffff0ULL);
-		L.ivl.ensure((u64)ivl_cap * sizeof(Ivl));
-		dzero(L.n_ivl.p, 4, L.stream);
-		ChainBufs cb; cb.f = d_cf; cb.p = d_cp; cb.t = d_ct; cb.v = d_cv; cb.u = d_cu;
-		CovState cs;
-		cs.lambda = lambda.as<unsigned long long>(); cs.lambda2 = lambda2.as<unsigned long long>();
-		cs.cnts = cnts.as<u32>(); cs.qflags = qflags.as<u32>(); cs.skip = skip.as<u32>(); cs.qmoff = cnt_off_dev();
-		cs.mini_pos = mini_pos.as<u64>(); cs.mpq_off = mpq_off.as<u64>(); cs.qlen = q.d_len.as<u32>(); cs.tlen = pt.rs.d_len.as<u32>();
-		cs.ivl = L.ivl.as<Ivl>(); cs.n_ivl = L.n_ivl.as<u32>(); cs.ivl_cap = ivl_cap;
-		cs.dbg = dbg ? dbg_chains.as<ChainRec>() : nullptr; cs.n_dbg = n_dbg.as<unsigned long long>(); cs.dbg_cap = dbg_cap;
-		if (n_groups > 0xfffffff0ULL) throw std::domain_error("too many anchor runs in one batch");
-		const int cap = K.chain_cap <= 64 ? 64 : K.chain_cap <= 128 ? 128 : 256;   // anchors of LDS per wave in k_chain
-		// runs of >= wave_min anchors take the cooperative kernel; a run must fit k_chain's LDS budget on its own
-		const int wave_min = std::min(cap + 1, K.chain_wave_min > 0 ? K.chain_wave_min : LQ_CHAIN_WAVE_MIN);
-		if (n_groups) {	// one thread per run, in array order, DP state of a wave's runs packed into LDS (in rounds if they exceed the budget).
-			// Measured alternatives that were not faster on MI355X: a compacted longest-first work list for all runs (409 vs 292 ms at
-			// configs[1]), a dense list in array order of the runs of min_cnt..47 anchors (configs[2]: within the run-to-run spread),
-			// private-array DP for short runs, and a fixed [16][64] LDS column per lane (54 KiB per wave: 160 + 40 ms vs 113 ms).
-			// wave_min - 1 <= 47 < the smallest budget, so every run fits.
-			StageTimer t(this, L.stream, "k_chain", nA * 16);
-#define LQ_CHAIN_LAUNCH(CAP) LQ_LAUNCH((k_chain<CAP>), nblk(n_groups, 64), 64, L.stream, dA, L.gstart.as<u64>(), (const u32*)nullptr, (u32)n_groups, aqb, a_base, nqb, q0, avg_qspan.as<float>(), mp, cs, (i32)P.min_cnt, (i32)(wave_min - 1))
-			if (cap == 64) { LQ_CHAIN_LAUNCH(64); } else if (cap == 128) { LQ_CHAIN_LAUNCH(128); } else { LQ_CHAIN_LAUNCH(256); }
-#undef LQ_CHAIN_LAUNCH
-			check_launch();
-		}
-		{	// long runs: one wave per run, longest first
-			u32 n_sel = 0;
-			const u32 n_tiles = (u32)((n_groups + LQ_RUN_TILE - 1) / LQ_RUN_TILE);
-			L.sel_tiles.ensure(((u64)n_tiles + 2) * 4);
-			LQ_LAUNCH(k_sel_count, std::min<u32>(std::max<u32>(n_tiles, 1), 1u << 16), LQ_RUN_THREADS, L.stream, L.gstart.as<u64>(), n_groups, (i32)wave_min, (i32)0x7fffffff, n_tiles, L.sel_tiles.as<u32>()); check_launch();
-			LQ_LAUNCH(k_tile_scan, 1, LQ_TSCAN_THREADS, L.stream, L.sel_tiles.as<u32>(), n_tiles); check_launch();
-			d2h(&n_sel, L.sel_tiles.as<u32>() + n_tiles, 1, L.stream);
-			if (n_sel) {
-				L.gsel.ensure((u64)n_sel * 4); L.gkey.ensure((u64)n_sel * 4); L.gsel2.ensure((u64)n_sel * 4); L.gkey2.ensure((u64)n_sel * 4);
-				LQ_LAUNCH(k_sel_write, std::min<u32>(n_tiles, 1u << 16), LQ_RUN_THREADS, L.stream, L.gstart.as<u64>(), n_groups, (i32)wave_min, (i32)0x7fffffff, n_tiles, L.sel_tiles.as<u32>(), L.gsel.as<u32>(), L.gkey.as<u32>()); check_launch();
-				L.prim.sort_pairs_u32_u32(L.gkey.as<u32>(), L.gkey2.as<u32>(), L.gsel.as<u32>(), L.gsel2.as<u32>(), n_sel);
-				StageTimer t(this, L.stream, "k_chain_wave");
-				LQ_LAUNCH(k_chain_wave, n_sel, 64, L.stream, dA, L.gstart.as<u64>(), L.gsel2.as<u32>(), n_sel, aqb, a_base, nqb, q0, avg_qspan.as<float>(), mp, cb, cs);
+			const u32 ns = (u32)sq.size();
+			const u64 nA2 = so.back();
+			stat_p2_anchors += nA2;
+			batch_buffers(L, nA2);
+			L.sub_q.ensure(ns * 4 + 4); L.sub_off.ensure((ns + 1) * 8); L.sub_klib.ensure(ns * 4 + 4);
+			h2d(L.sub_q.as<u32>(), sq.data(), ns, L.stream); h2d(L.sub_off.as<u64>(), so.data(), ns + 1, L.stream); h2d(L.sub_klib.as<u32>(), sk.data(), ns, L.stream);
+			LQ_HIP_CHECK(hipStreamSynchronize(L.stream));         // (the host vectors die with this turn of the loop)
+			{
+				StageTimer t(this, L.stream, "k_seed_emit", nA2 * 24);
+				LQ_LAUNCH(k_seed_emit, dim3(nblk(max_mini, LQ_EMIT_THREADS), ns), LQ_EMIT_THREADS, L.stream, q.mx.as<u64>(), q.my.as<u64>(), q_owner.as<u32>(), q.moff.as<u64>(), (u64)0, (u64)0,
+				          pt.pos.as<u64>(), hit_start.as<u64>(), hit_n.as<u32>(), keep.as<u32>(), dup.as<u32>(),
+				          a_off.as<u64>(), (u64)0, mp_off.as<u64>(), q.d_len.as<u32>(),
+				          (int)P.no_self, pt.self_off.as<u32>(), pt.self_rid.as<u32>(), ava,
+				          (const u32*)nullptr, L.A.as<mm128>(), L.B.as<mm128>(), mini_pos.as<u64>(), EmitSub{L.sub_q.as<u32>(), L.sub_off.as<u64>(), L.sub_klib.as<u32>()});
 				check_launch();
 			}
+			if (nA2) {
+				sort_checked(L, pt, L.sub_off.as<u64>(), L.sub_klib.as<u32>(), ns, 0, nA2, so, sk);
+				chain_stage(L, pt, L.sub_off.as<u64>(), 0, ns, 0, L.sub_q.as<u32>(), nA2, 2, (u32)want.size(), ivl_cap, dbg);
+			}
+			i = k;
 		}
+	}
+	if (nA) {
 		// ---- filter_redundant_coords per query (lqmap.c:287) ----
 		u32 ni = 0;
 		d2h(&ni, L.n_ivl.as<u32>(), 1, L.stream);
@@ -871,9 +984,8 @@ void lqcov_handle::psort_tail(MapLane &L, int set, hipStream_t s, u64 nA, const 
 //   * the others (their anchors are in B, the originals) go through klib's passes byte by byte as 8-byte records
 //     (kernels_sort.hpp, kernels_rsort.hpp); buckets of a pass that received fewer than two marked anchors leave for the
 //     parallel sort as well (set 1, after the last pass), the others are written to A when they are finished.
-void lqcov_handle::sort_batch(MapLane &L, Part &pt, u32 q0, u32 nqb, u64 a_base, u64 nA)
+void lqcov_handle::sort_batch(MapLane &L, Part &pt, const u64 *aqb, const u32 *qkb, u32 nqb, u64 a_base, u64 nA)
 {
-	const u64 *aqb = aq_off.as<u64>() + q0;
 	mm128 *dA = L.A.as<mm128>(), *dB = L.B.as<mm128>();
 	hipStream_t sD = L.stream, sC = L.stream2;
 	if (nA >= 0x7ffffff0ULL) throw std::domain_error("more than 2^31 anchors in one query batch");
@@ -919,7 +1031,7 @@ void lqcov_handle::sort_batch(MapLane &L, Part &pt, u32 q0, u32 nqb, u64 a_base,
 	for (int c = 0; c < 4; ++c) wcaps.c[c] >>= K.walk_shift;   // test knob
 	{
 		StageTimer t(this, sD, "k_sort_init");
-		LQ_LAUNCH(k_sort_init, nblk(nqb, 64), 64, sD, aqb, a_base, nqb, qklib.as<u32>() + q0, dA, L.segs0.as<SortSeg>(), cnt, lists(0), km, wcaps);
+		LQ_LAUNCH(k_sort_init, nblk(nqb, 64), 64, sD, aqb, a_base, nqb, qkb, dA, L.segs0.as<SortSeg>(), cnt, lists(0), km, wcaps);
 		check_launch();
 	}
 	// the parallel sort of the clean queries runs beside klib's passes
@@ -1011,6 +1123,16 @@ void lqcov_handle::sort_batch(MapLane &L, Part &pt, u32 q0, u32 nqb, u64 a_base,
 				const u64 n_ck_segs = K.ckpt ? (u64)(ck3 ? lenc[3] : 0) + lenc[4] : 0;
 				int first_plain_class = K.ckpt ? (ck3 ? 2 : 3) : LQ_WALK_CLASSES - 1;
 				bool w1 = false, w2 = false;                          // which walker streams got work
+				// (the checkpoint buffers are sized before the fork: a block that the lane's stream allocates after the event the walker
+				// streams wait for would not be ordered before their kernels)
+				const u32 ck_unit = std::max<u32>(16384u >> K.walk_shift, 8);
+				const u32 ck_min_len = wcaps.c[ck3 ? 2 : 3] + 1;
+				const u64 cks_max = std::min<u64>(std::min<u64>(nA / ck_min_len + 1, ns), n_ck_segs), ck_max = nA / ck_unit + 2 * cks_max, tiles_max = nA / LQ_CK_TILE + cks_max;
+				const u32 per_ck = ck_small ? LQ_CK_B : 256;          // cursors per checkpoint
+				if (any_walk && n_ck_segs) {
+					L.ck_segs.ensure(cks_max * sizeof(CkSeg)); L.ck_S.ensure(ck_max * per_ck * 4); L.ck_slot.ensure(ck_max * 4 + 4);
+					if (ck_small) { L.ck_T.ensure((tiles_max + 1) * LQ_CK_B * 4); L.ck_E.ensure(cks_max * LQ_CK_B * LQ_CK_B * 4); }
+				}
 				if (any_walk) { LQ_HIP_CHECK(hipEventRecord(L.ev_w0, sD)); }
 				if (!gated && !L.gate_passed) { L.gate_passed = true; open_gate(); gated = true; }   // let the next lane start under these walks
 				// Long sub-arrays: the walk's state at evenly spread checkpoints is computed without walking (kernels_ckpt.hpp) and
@@ -1020,12 +1142,7 @@ void lqcov_handle::sort_batch(MapLane &L, Part &pt, u32 q0, u32 nqb, u64 a_base,
 				// The plan (which sub-arrays, their tiles and checkpoints) is laid out on the device from the class lists.
 				if (any_walk && n_ck_segs) {
 					LQ_HIP_CHECK(hipStreamWaitEvent(sW, L.ev_w0, 0)); w1 = true;
-					const u32 unit = std::max<u32>(16384u >> K.walk_shift, 8);
-					const u32 min_len = wcaps.c[ck3 ? 2 : 3] + 1;
-					const u64 cks_max = std::min<u64>(std::min<u64>(nA / min_len + 1, ns), n_ck_segs), ck_max = nA / unit + 2 * cks_max, tiles_max = nA / LQ_CK_TILE + cks_max;
-					const u32 per_ck = ck_small ? LQ_CK_B : 256;          // cursors per checkpoint
-					L.ck_segs.ensure(cks_max * sizeof(CkSeg)); L.ck_S.ensure(ck_max * per_ck * 4); L.ck_slot.ensure(ck_max * 4 + 4);
-					if (ck_small) { L.ck_T.ensure((tiles_max + 1) * LQ_CK_B * 4); L.ck_E.ensure(cks_max * LQ_CK_B * LQ_CK_B * 4); }
+					const u32 unit = ck_unit;
 					const CkSeg *dck = L.ck_segs.as<CkSeg>();
 					const u32 *ckn = L.ck_n.as<u32>();
 					LQ_LAUNCH(k_ck_plan, 1, 256, sW, cur, wl, ns, cnt + LQ_C_WALK0, (int)ck3, unit, ck_small ? 512u : 64u, L.ck_segs.as<CkSeg>(), (u32)cks_max, L.ck_n.as<u32>()); check_launch();
@@ -1167,9 +1284,46 @@ void lqcov_handle::map_part(Part &pt)
 	check_launch();
 	qklib.ensure((u64)n_q * 4 + 4);
 	LQ_LAUNCH(k_query_klib, nblk(n_q, 256), 256, stream, aq_off.as<u64>(), qdirty.as<u32>(), n_q, (int)K.all_klib, qklib.as<u32>()); check_launch();
-	std::vector<u64> h_aq(n_q + 1), h_qmoff(n_q + 1);
+	std::vector<u64> h_aq(n_q + 1), h_qmoff(n_q + 1), h_aqf;
 	d2h(h_aq.data(), aq_off.as<u64>(), n_q + 1, stream);
 	d2h(h_qmoff.data(), q.moff.as<u64>(), n_q + 1, stream);
+	last_n_written = nA_total;
+	if (!K.ties_klib) {
+		// The seed hits that can be part of a chain at all (k_seed_count): one bit per hit, counts per minimizer, offsets per query.
+		// Without the filter (LQCOV_FILTER=0, or a chain may be a single anchor) every hit passes: one code path for the first pass.
+		h_aqf.assign(n_q + 1, 0);
+		qzero.ensure((u64)n_q * 4 + 4); dzero(qzero.p, (u64)n_q * 4 + 4, stream);
+		fm_words.ensure(n_qm * 4 + 4); fm_off.ensure(n_qm * 8 + 8); cntf.ensure(n_qm * 4 + 4); af_off.ensure(n_qm * 8 + 8); aqf_off.ensure((n_q + 1) * 8);
+		u64 n_words = 0, nF = 0;
+		if (n_qm) {
+			LQ_LAUNCH(k_fmask_words, nblk(n_qm, 256), 256, stream, hit_n.as<u32>(), keep.as<u32>(), n_qm, fm_words.as<u32>()); check_launch();
+			prim.exclusive_scan_u32_u64(fm_words.as<u32>(), fm_off.as<u64>(), n_qm);
+			u64 lo = 0; u32 lc = 0;
+			d2h(&lo, fm_off.as<u64>() + n_qm - 1, 1, stream); d2h(&lc, fm_words.as<u32>() + n_qm - 1, 1, stream);
+			n_words = lo + lc;
+			fmask.ensure(n_words * 8 + 8);
+			dzero(fmask.p, n_words * 8, stream); dzero(cntf.p, n_qm * 4, stream);
+			FiltParams fp;
+			const u32 n_min = run_n_min();
+			fp.thr = K.filter && n_min >= 2 ? std::min<u32>(n_min, 3) : 0;
+			fp.n_targets = std::max<u32>(pt.rs.n, 1); fp.keys_cap = K.filt_keys; fp.a_cap = std::max<u32>(K.filt_acap, 1);
+			{
+				StageTimer t(this, "k_seed_count", nA_total * 8 + nA_total / 8);   // (algorithmic: every occurrence list once, a bit per hit out; the kernel reads the lists twice per slice)
+				LQ_LAUNCH(k_seed_count, std::min<u32>(n_q, 1u << 20), LQ_FC_THREADS, stream, q.my.as<u64>(), q.moff.as<u64>(), n_q, pt.pos.as<u64>(), hit_start.as<u64>(), hit_n.as<u32>(), keep.as<u32>(), aq_off.as<u64>(),
+				          (int)P.no_self, pt.self_off.as<u32>(), pt.self_rid.as<u32>(), AvaView{P.ava ? pt.t_rank.as<u32>() : nullptr, P.ava ? pt.q_lo.as<u32>() : nullptr}, fp,
+				          fm_off.as<u64>(), fmask.as<u64>(), cntf.as<u32>());
+				check_launch();
+			}
+			prim.exclusive_scan_u32_u64(cntf.as<u32>(), af_off.as<u64>(), n_qm);
+			d2h(&lo, af_off.as<u64>() + n_qm - 1, 1, stream); d2h(&lc, cntf.as<u32>() + n_qm - 1, 1, stream);
+			nF = lo + lc;
+		}
+		LQ_LAUNCH(k_query_foff, nblk(n_q + 1, 256), 256, stream, q.moff.as<u64>(), af_off.as<u64>(), n_qm, nF, n_q, aqf_off.as<u64>()); check_launch();
+		d2h(h_aqf.data(), aqf_off.as<u64>(), n_q + 1, stream);
+		last_n_written = nF;
+	}
+	const std::vector<u64> &h_boff = K.ties_klib ? h_aq : h_aqf;   // the offsets the batches are cut by: of the anchors the first pass writes
+	const u64 nB_total = h_boff[n_q];
 
 	const bool dbg = (debug_flags & 1) != 0;
 	if (dbg) {
@@ -1196,16 +1350,16 @@ void lqcov_handle::map_part(Part &pt)
 		// has a serial critical path (its longest walk and chain) that does not shrink with the batch.  (Cutting the last round
 		// finer -- halves, then quarters, so that the lanes end together -- was measured on MI355X at configs[2]: 1.75-1.78 s
 		// per step against 1.68-1.70 s; the extra batches cost more than the shorter tail saves.)
-		u64 nb = (nA_total + anchor_budget - 1) / anchor_budget;
-		if (nb < (u64)n_lanes && nA_total >= ((u64)n_lanes << 24)) nb = n_lanes;
+		u64 nb = (nB_total + anchor_budget - 1) / anchor_budget;
+		if (nb < (u64)n_lanes && nB_total >= ((u64)n_lanes << 24)) nb = n_lanes;
 		if (nb > (u64)n_lanes) nb = (nb + n_lanes - 1) / n_lanes * n_lanes;
 		if (nb == 0) nb = 1;
 		u64 left = nb;
 		for (u32 q0 = 0; q0 < n_q; ) {
-			const u64 rem = h_aq[n_q] - h_aq[q0];
+			const u64 rem = h_boff[n_q] - h_boff[q0];
 			const u64 lim = std::min(anchor_budget, left > 1 ? (rem + left - 1) / left : rem);
 			u32 q1 = q0 + 1;
-			while (q1 < n_q && h_aq[q1 + 1] - h_aq[q0] <= lim) ++q1;
+			while (q1 < n_q && h_boff[q1 + 1] - h_boff[q0] <= lim) ++q1;
 			batches.emplace_back(q0, q1);
 			q0 = q1;
 			if (left > 1) --left;
@@ -1252,7 +1406,7 @@ void lqcov_handle::map_part(Part &pt)
 	if (!concurrent) {
 		for (size_t i = 0; i < batches.size(); ++i) {
 			lq_alloc_stream = lanes[i % n_lanes]->stream;
-			map_batch(*lanes[i % n_lanes], pt, batches[i].first, batches[i].second, h_aq, h_qmoff, dbg);
+			map_batch(*lanes[i % n_lanes], pt, batches[i].first, batches[i].second, h_aq, h_aqf, h_qmoff, dbg);
 			lq_alloc_stream = nullptr;
 		}
 		for (auto &L : lanes) LQ_HIP_CHECK(hipStreamSynchronize(L->stream));
@@ -1276,7 +1430,7 @@ void lqcov_handle::map_part(Part &pt)
 					for (;;) {
 						const size_t i = next.fetch_add(1);
 						if (i >= batches.size()) break;
-						map_batch(L, pt, batches[i].first, batches[i].second, h_aq, h_qmoff, dbg);
+						map_batch(L, pt, batches[i].first, batches[i].second, h_aq, h_aqf, h_qmoff, dbg);
 					}
 					LQ_HIP_CHECK(hipStreamSynchronize(L.stream));
 				} catch (...) { errs[li] = std::current_exception(); next.store(batches.size()); gate_cv.notify_all(); }
@@ -1664,7 +1818,8 @@ int lqcov_handle::run_files(const char *target, const char *query, FILE *out, FI
 			if (dump) dump_part(pt, dump);                        // mm_idx_reader_read (index.c:533)
 			if (query) {
 				map_part(pt);
-				if (log) fprintf(log, "[lqcov] part %d: mapped %u queries, %" PRIu64 " anchors\n", n_parts, q.n, last_n_anchors);
+				if (log) fprintf(log, "[lqcov] part %d: mapped %u queries, %" PRIu64 " anchors (%" PRIu64 " written; so far %" PRIu64 " runs of %" PRIu64 " queries chained in klib's order, %" PRIu64 " anchors)\n",
+				                 n_parts, q.n, last_n_anchors, last_n_written, (u64)stat_sens_runs, (u64)stat_p2_queries, (u64)stat_p2_anchors);
 			}
 			parts[id].reset();
 			++n_parts;

@@ -47,6 +47,10 @@ struct Knobs {
 	u32 tile_grid = 4096;                 // LQCOV_TILE_GRID: blocks of klib's tile kernels (histogram, scatter)
 	u32 ps_grid = 512;                   // LQCOV_PS_GRID: blocks of the parallel sort's tile kernels (the finishing kernels: a quarter / twice that; twice as many blocks for them: no change, measured with the 64-register kernels)
 	bool sketch_machine_only = false;     // LQCOV_SKETCH=machine: the state machine decides every chunk (no data-parallel kernel)
+	bool ties_klib = false;               // LQCOV_TIES=klib (or LQCOV_SORT=klib): klib's order of equal-x anchors everywhere, every seed hit written and sorted (rounds 1-3); default: only where it can be observed (map_batch)
+	bool filter = true;                   // LQCOV_FILTER=0: the first pass writes every seed hit (no counting filter)
+	u32 filt_keys = 1u << 19;             // LQCOV_FILTER_KEYS: counters of k_seed_count's table in use (tests shrink it: slices and aliasing on small inputs)
+	u32 filt_acap = 314572;               // LQCOV_FILTER_ACAP: anchors per slice aimed at (0.6 per counter)
 	void read_env();
 };
 
@@ -92,6 +96,7 @@ struct MapLane {
 	PsWork ps[2];
 	Prim prim;
 	bool gate_passed = false;             // this batch has reached its long walks (see map_part)
+	DBuf sens, n_sens, want, sub_q, sub_off, sub_klib;   // runs left to the second pass (map_batch), its queries
 	DBuf A, B, R0, segs0, segs1, n_segs, hist, begs;     // A: anchors (final home), B: originals of the klib queries / other buffer of the parallel sort, R0: records (R1 lives in scr)
 	DBuf tile_list, two_tiles, two_tile0, two_tcnt, two_m;
 	DBuf sort_d, sort_dst, seg_info, walk_list, two_list, scr;
@@ -100,7 +105,7 @@ struct MapLane {
 	// hand every buffer back (they regrow on the next batch); the caller has drained the lane's streams
 	void release_buffers()
 	{
-		for (DBuf *b : { &sort_cnt, &mhist, &ck_segs, &ck_T, &ck_E, &ck_S, &ck_slot, &ck_n, &prim.tmp, &A, &B, &R0, &segs0, &segs1, &n_segs, &hist, &begs, &tile_list, &two_tiles, &two_tile0, &two_tcnt, &two_m,
+		for (DBuf *b : { &sens, &n_sens, &want, &sub_q, &sub_off, &sub_klib, &sort_cnt, &mhist, &ck_segs, &ck_T, &ck_E, &ck_S, &ck_slot, &ck_n, &prim.tmp, &A, &B, &R0, &segs0, &segs1, &n_segs, &hist, &begs, &tile_list, &two_tiles, &two_tile0, &two_tcnt, &two_m,
 		                 &sort_d, &sort_dst, &seg_info, &walk_list, &two_list, &scr, &gsel, &gkey, &gsel2, &gkey2, &gstart, &run_tiles, &sel_tiles,
 		                 &ivl, &n_ivl, &iv_q, &iv_q2, &iv_se, &iv_se2, &ivq_off, &iv_scratch }) b->release();
 		for (PsWork &W : ps) for (DBuf *b : { &W.big[0], &W.big[1], &W.fin_s, &W.fin_b, &W.plan, &W.gcnt, &W.gcur, &W.gdiff, &W.tmap }) b->release();
@@ -142,6 +147,11 @@ struct lqcov_handle {
 	DBuf lambda, lambda2, avg_k, cnts, qflags, qual_psum;
 	DBuf dup, qdirty, dup_table;          // k_dup_mark: minimizers / queries whose anchors can repeat an x (per part)
 	DBuf qklib;                           // queries that go through klib's passes (per part): marked and more than 64 anchors
+	DBuf qzero;                           // zeros: nobody goes through klib's passes (first pass of map_batch)
+	DBuf fm_words, fm_off, fmask, cntf, af_off, aqf_off;   // k_seed_count: survivor bitmap (words per minimizer, offsets, bits), survivors per minimizer, their offsets per minimizer / per query
+	u64 last_n_written = 0;               // anchors the first pass wrote against the last part
+	std::atomic<u64> stat_sens_runs{0}, stat_p2_queries{0}, stat_p2_anchors{0};   // second pass, since reset(): runs, queries, anchors
+	u32 run_n_min() const { const i32 span_max = P.hpc ? 255 : P.k; return (u32)std::max<i32>(std::max<i32>(P.min_cnt, 1), (mp.min_sc + span_max - 1) / span_max); }   // anchors a run needs to hold a chain (k_run_list)
 	// counter layout: normally the query minimizer offsets; after adopt_index_params() (prebuilt index with other -k/-w/-H)
 	// the reference's sizes (from the command-line sketch, minimap2-coverage.c:419-422) and the mapping's differ
 	bool own_cnt_layout = false; DBuf cnt_off, d_nsize; std::vector<u32> h_nsize; u64 cnt_total = 0;
@@ -182,8 +192,11 @@ struct lqcov_handle {
 	void build_part(Part &pt);
 	void open_gate();
 	void map_part(Part &pt);
-	void map_batch(MapLane &L, Part &pt, u32 q0, u32 q1, const std::vector<u64> &h_aq, const std::vector<u64> &h_qmoff, bool dbg);
-	void sort_batch(MapLane &L, Part &pt, u32 q0, u32 nqb, u64 a_base, u64 nA);
+	void map_batch(MapLane &L, Part &pt, u32 q0, u32 q1, const std::vector<u64> &h_aq, const std::vector<u64> &h_aqf, const std::vector<u64> &h_qmoff, bool dbg);
+	void batch_buffers(MapLane &L, u64 nA);
+	void chain_stage(MapLane &L, Part &pt, const u64 *aqb, u64 a_base, u32 nqb, u32 q0, const u32 *qmap, u64 nA, int tie_mode, u32 n_want, u32 ivl_cap, bool dbg);
+	void sort_checked(MapLane &L, Part &pt, const u64 *aqb, const u32 *qkb, u32 nqb, u64 a_base, u64 nA, const std::vector<u64> &h_off, const std::vector<u32> &h_klib);
+	void sort_batch(MapLane &L, Part &pt, const u64 *aqb, const u32 *qkb, u32 nqb, u64 a_base, u64 nA);
 	void psort_run(MapLane &L, int set, hipStream_t s, u64 nA, const KeyMap &km, const struct PsData &pd);
 	void psort_tail(MapLane &L, int set, hipStream_t s, u64 nA, const KeyMap &km, const struct PsData &pd);
 	void reset();

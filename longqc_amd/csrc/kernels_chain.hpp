@@ -270,7 +270,29 @@ struct CovState {              // per-query accumulators (minimap2-coverage.c:43
 	const u32 *tlen;           // target lengths of this part
 	Ivl *ivl; u32 *n_ivl; u32 ivl_cap;             // this part's intervals (esterr.c:122-126)
 	ChainRec *dbg; unsigned long long *n_dbg; u64 dbg_cap;   // optional chain dump
+	// Equal-x anchors (one target minimizer hit by two minimizers of the query) reach mm_chain_dp in the order klib's unstable
+	// sort leaves them (lqmap.c:238), and the DP can tell (chain.c:69-76,102-125).  tie_mode 0: the array order IS klib's, chain
+	// every run.  1: the anchors were sorted by some other correct sort; a run in which the order of equal-x anchors can be
+	// observed (lq_chain_fill / lq_chain_finish say when) is not chained but listed in `sens` as q << 32 | high word of x.
+	// 2: klib's order again, only the runs listed in `want` (sorted) are chained -- the second pass over the listed queries.
+	int tie_mode;
+	unsigned long long *sens; u32 *n_sens; u32 sens_cap;
+	const unsigned long long *want; u32 n_want;
+	const u32 *qmap;           // not null: the batch's i-th query is query qmap[i] (a subset of the queries); else q0 + i
 };
+
+__device__ __forceinline__ bool lq_tie_wanted(const CovState &C, u32 q, u32 hi)
+{
+	const unsigned long long key = (unsigned long long)q << 32 | hi;
+	u32 lo = 0, n = C.n_want;
+	while (lo < n) { const u32 mid = lo + ((n - lo) >> 1); if (C.want[mid] < key) lo = mid + 1; else n = mid; }
+	return lo < C.n_want && C.want[lo] == key;
+}
+__device__ __forceinline__ void lq_tie_list(const CovState &C, u32 q, u32 hi)
+{
+	const u32 s = atomicAdd(C.n_sens, 1u);
+	if (s < C.sens_cap) C.sens[s] = (unsigned long long)q << 32 | hi;
+}
 
 // runs of at least min_cnt anchors as a dense work list; key = ~size so that an ascending radix sort yields longest-first
 // (long runs start first): two light passes over the run starts (count per tile, scan of the tile counts, write)
@@ -335,11 +357,19 @@ k_sel_write(const u64 *gstart, u64 n_groups, i32 min_cnt, i32 max_cnt, u32 n_til
 }
 
 // mm_chain_dp, first half (chain.c:41-81): scores f, predecessors p, peak scores v of one run, serially
+// Returns true when two anchors of equal x were both inside the band of one scan (watch_ties only): then, and only then,
+// the scores can depend on the order of equal-x anchors.  Anchors of equal x never chain to each other (dr == 0), a candidate
+// outside the band is stepped over before any state changes (the `continue`s of chain.c:52-56 precede chain.c:69-76), so
+// with at most one member of every tie group inside the band every scan sees the same sequence of effective candidates
+// whatever the order inside the groups, and f, p, v, t are the same per anchor.  (A scan that breaks off at a candidate
+// (chain.c:72-73) would, in another order, have met that candidate's tie partners in its place: they are looked at too.)
 template <class AP, class IP>
-__device__ __forceinline__ void lq_chain_fill(AP a, const i64 n, IP f, IP p, IP t, IP v, const float avg_qspan, const MapParams &P)
+__device__ __forceinline__ bool lq_chain_fill(AP a, const i64 n, IP f, IP p, IP t, IP v, const float avg_qspan, const MapParams &P, const bool watch_ties)
 {
 	const i32 max_dist = P.max_gap, bw = P.bw, max_skip = P.max_skip;
 	i64 st = 0;
+	bool band_tie = false, have_act = false;
+	u64 act_x = 0;
 	for (i64 i = 0; i < n; ++i) t[i] = 0;
 	// fill the score and backtrack arrays (chain.c:41-81).  Flat form: one candidate predecessor per loop trip,
 	// so that the lanes of a wave (different runs) do not wait for each other's inner loops to finish.
@@ -353,7 +383,7 @@ __device__ __forceinline__ void lq_chain_fill(AP a, const i64 n, IP f, IP p, IP 
 				ri = a[i].x; qi = (i32)a[i].y; q_span = (i32)(a[i].y >> 32 & 0xff);
 				max_f = q_span; max_j = -1; n_skip = 0;
 				while (st < i && ri - a[st].x > (u64)max_dist) ++st;
-				j = i - 1; setup = false;
+				j = i - 1; setup = false; have_act = false;
 			}
 			if (j >= st) {
 				const i64 dr = (i64)(ri - a[j].x);
@@ -367,13 +397,27 @@ __device__ __forceinline__ void lq_chain_fill(AP a, const i64 n, IP f, IP p, IP 
 						sc -= (i32)((double)dd * .01 * (double)avg_qspan) + (log_dd >> 1);     // chain.c:67
 						sc += f[j];
 						bool brk = false;
+						if (watch_ties) {
+							const u64 xj = a[j].x;
+							if (have_act && xj == act_x) band_tie = true;
+							have_act = true; act_x = xj;
+						}
 						if (sc > max_f) {
 							max_f = sc; max_j = j;
 							if (n_skip > 0) --n_skip;
 						} else if (t[j] == (i32)i) {
 							if (++n_skip > max_skip) brk = true;                      // chain.c:72-73
 						}
-						if (brk) j = st;                                              // leave the candidate loop
+						if (brk) {
+							if (watch_ties)
+								for (i64 jj = j - 1; jj >= st && a[jj].x == a[j].x; --jj) {
+									const i32 dq2 = qi - (i32)a[jj].y;
+									if (dq2 <= 0 || dq2 > max_dist) continue;
+									const i32 dd2 = dr > dq2 ? (i32)(dr - dq2) : (i32)(dq2 - dr);
+									if (dd2 <= bw) band_tie = true;
+								}
+							j = st;                                                   // leave the candidate loop
+						}
 						else if (p[j] >= 0) t[p[j]] = (i32)i;
 					}
 				}
@@ -385,12 +429,16 @@ __device__ __forceinline__ void lq_chain_fill(AP a, const i64 n, IP f, IP p, IP 
 			}
 		}
 	}
+	return band_tie;
 }
 
 // mm_chain_dp, second half (chain.c:84-137) + mm_reg_set_coor (hit.c:23-38) + lq_cnt_match (esterr.c:99-138)
+// Returns true -- before anything is accumulated -- when two anchors of equal x are both peaks of the same score
+// (watch_ties only): the backtracks run in (score, array index) order (chain.c:102-108), the one place after the scores
+// where the order inside a tie group still counts.
 template <class AP, class IP, class UP>
-__device__ __forceinline__ void lq_chain_finish(AP a, const i64 n, IP f, IP p, IP t, IP v, UP u,
-                                                const u32 q, const bool accumulate, const MapParams &P, const CovState &C)
+__device__ __forceinline__ bool lq_chain_finish(AP a, const i64 n, IP f, IP p, IP t, IP v, UP u,
+                                                const u32 q, const bool accumulate, const MapParams &P, const CovState &C, const bool watch_ties)
 {
 	const i32 min_sc = P.min_sc;
 	// chain ends (chain.c:84-101)
@@ -405,8 +453,13 @@ __device__ __forceinline__ void lq_chain_finish(AP a, const i64 n, IP f, IP p, I
 			u[n_u++] = (u64)(u32)f[j] << 32 | (u64)j;
 		}
 	}
-	if (n_u == 0) return;
+	if (n_u == 0) return false;
 	lq_heapsort_u64(u, n_u);                                   // keys are distinct: any sort == radix_sort_64 (chain.c:102)
+	if (watch_ties)
+		for (i64 i = 1; i < n_u; ++i) {
+			const u64 u0 = u[i - 1], u1 = u[i];
+			if ((u0 >> 32) == (u1 >> 32) && (u32)u0 != (u32)u1 && a[(i64)(i32)u0].x == a[(i64)(i32)u1].x) return true;
+		}
 	// backtrack from the best end (chain.c:108-125); u[] is ascending, so walk it from the top
 	for (i64 i = 0; i < n; ++i) t[i] = 0;
 	i64 n_v = 0;
@@ -475,6 +528,7 @@ __device__ __forceinline__ void lq_chain_finish(AP a, const i64 n, IP f, IP p, I
 			}
 		}
 	}
+	return false;
 }
 
 // One (strand, rid) run of a query: mm_chain_dp on a[0..n), then per chain mm_reg_set_coor and lq_cnt_match.
@@ -483,8 +537,9 @@ template <class AP, class IP, class UP>
 __device__ __forceinline__ void lq_chain_run(AP a, const i64 n, IP f, IP p, IP t, IP v, UP u,
                                              const u32 q, const bool accumulate, const float *avg_qspan_q, const MapParams &P, const CovState &C)
 {
-	lq_chain_fill(a, n, f, p, t, v, avg_qspan_q[q], P);
-	lq_chain_finish(a, n, f, p, t, v, u, q, accumulate, P, C);
+	const bool watch = C.tie_mode == 1;
+	if (lq_chain_fill(a, n, f, p, t, v, avg_qspan_q[q], P, watch) || lq_chain_finish(a, n, f, p, t, v, u, q, accumulate, P, C, watch))
+		lq_tie_list(C, q, (u32)(a[0].x >> 32));              // the order of its equal-x anchors can be observed: left to the second pass
 }
 
 // does the run have any chance to yield a chain?  A chain of c anchors scores at most the sum of their spans
@@ -529,8 +584,9 @@ k_chain(const mm128 *A, const u64 *gstart, const u32 *glist, u32 n_list, const u
 			const u64 gs = LQ_RUN_START(gstart[g]);
 			const i64 n = LQ_RUN_LEN(gstart[g]);
 			if (n >= min_len && n <= max_len && n <= LQ_CHAIN_LDS_CAP && lq_run_viable(A + gs, n, P)) {
-				const u32 q = q0 + lq_find_seg(aq_off, n_q, gs + a_base);
-				if (!C.skip[q] || C.dbg) { todo = (u32)n; s_q[ln] = q; }
+				const u32 qi = lq_find_seg(aq_off, n_q, gs + a_base);
+				const u32 q = C.qmap ? C.qmap[qi] : q0 + qi;
+				if ((!C.skip[q] || C.dbg) && (C.tie_mode != 2 || lq_tie_wanted(C, q, lq_hi32(A + gs)))) { todo = (u32)n; s_q[ln] = q; }
 			}
 		}
 		s_n[ln] = todo; s_done[ln] = 0;
@@ -575,22 +631,26 @@ k_chain(const mm128 *A, const u64 *gstart, const u32 *glist, u32 n_list, const u
 // __syncthreads() orders it inside the workgroup.  The second half (chain ends, backtrack, regs, coverage) is the
 // serial lq_chain_finish on lane 0.
 #define LQ_CHAIN_WAVE_MIN 48      // measured on MI355X at configs[1]: 192 -> 206 ms, 96 -> 193, 48 -> 184, 24 -> 197 (k_chain + k_chain_wave)
-struct WaveCand { i32 sc, j, flags; };                      // flags: bit0 = passes the filters, bit1 = t[j] == i
+struct WaveCand { i32 sc, j, flags; u32 x32; };             // flags: bit0 = passes the filters, bit1 = t[j] == i; x32: low word of the candidate's x
 __global__ void __launch_bounds__(64)
 k_chain_wave(const mm128 *A, const u64 *gstart, const u32 *glist, u32 n_list, const u64 *aq_off, u64 a_base, u32 n_q, u32 q0,
              const float *avg_qspan_q, MapParams P, ChainBufs B, CovState C)
 {
 	LQ_SHARED WaveCand cand[64];
-	LQ_SHARED i32 st_sh[4];                                  // [0] max_f, [1] max_j, [2] n_skip, [3] done
+	LQ_SHARED i32 st_sh[8];                                  // [0] max_f, [1] max_j, [2] n_skip, [3] done, [4] a tie inside one band, [5] a candidate was inside the band, [6] its x32
 	if (blockIdx.x >= n_list) return;
 	const u32 g = glist[blockIdx.x];
 	const u64 gs = LQ_RUN_START(gstart[g]);
 	const i64 n = LQ_RUN_LEN(gstart[g]);
 	const mm128 *a = A + gs;
 	if (!lq_run_viable(a, n, P)) return;
-	const u32 q = q0 + lq_find_seg(aq_off, n_q, gs + a_base);
+	const u32 qi_ = lq_find_seg(aq_off, n_q, gs + a_base);
+	const u32 q = C.qmap ? C.qmap[qi_] : q0 + qi_;
 	const bool accumulate = !C.skip[q];
 	if (!accumulate && !C.dbg) return;
+	if (C.tie_mode == 2 && !lq_tie_wanted(C, q, lq_hi32(a))) return;
+	const bool watch = C.tie_mode == 1;
+	LQ_BLOCK_LOOP(ln) { if (ln == 0) st_sh[4] = 0; }
 	i32 *f = B.f + gs, *p = B.p + gs, *t = B.t + gs, *v = B.v + gs;
 	u64 *u = B.u + gs;
 	const float avg_qspan = avg_qspan_q[q];
@@ -602,15 +662,16 @@ k_chain_wave(const mm128 *A, const u64 *gstart, const u32 *glist, u32 n_list, co
 		const u64 ri = a[i].x;
 		const i32 qi = (i32)a[i].y, q_span = (i32)(a[i].y >> 32 & 0xff);
 		while (st < i && ri - a[st].x > (u64)max_dist) ++st;    // uniform: every lane computes the same st
-		LQ_BLOCK_LOOP(ln) { if (ln == 0) { st_sh[0] = q_span; st_sh[1] = -1; st_sh[2] = 0; st_sh[3] = 0; } }
+		LQ_BLOCK_LOOP(ln) { if (ln == 0) { st_sh[0] = q_span; st_sh[1] = -1; st_sh[2] = 0; st_sh[3] = 0; st_sh[5] = 0; } }
 		LQ_BLOCK_SYNC();
 		for (i64 top = i - 1; top >= st; top -= 64) {
 			// phase 1: 64 candidates in parallel
 			LQ_BLOCK_LOOP(ln) {
 				const i64 j = top - (i64)ln;
-				WaveCand c; c.sc = 0; c.j = (i32)j; c.flags = 0;
+				WaveCand c; c.sc = 0; c.j = (i32)j; c.flags = 0; c.x32 = 0;
 				if (j >= st) {
 					const mm128 aj = a[j];
+					c.x32 = (u32)aj.x;
 					const i64 dr = (i64)(ri - aj.x);
 					const i32 dq = qi - (i32)aj.y;
 					if (!(dr == 0 || dq <= 0 || dq > max_dist)) {
@@ -636,14 +697,25 @@ k_chain_wave(const mm128 *A, const u64 *gstart, const u32 *glist, u32 n_list, co
 			LQ_BLOCK_LOOP(ln) {
 				if (ln == 0) {
 					i32 max_f = st_sh[0], max_j = st_sh[1], n_skip = st_sh[2], done = 0;
+					i32 have_act = st_sh[5]; u32 act_x = (u32)st_sh[6];
 					const i64 cnt = top - st + 1 < 64 ? top - st + 1 : 64;
 					for (i64 c = 0; c < cnt; ++c) {
 						const WaveCand w = cand[c];
 						if (!(w.flags & 1)) continue;
+						if (watch) { if (have_act && w.x32 == act_x) st_sh[4] = 1; have_act = 1; act_x = w.x32; }   // (see lq_chain_fill)
 						if (w.sc > max_f) { max_f = w.sc; max_j = w.j; if (n_skip > 0) --n_skip; }
-						else if (w.flags & 2) { if (++n_skip > max_skip) { done = 1; break; } }      // chain.c:72-73
+						else if (w.flags & 2) {
+							if (++n_skip > max_skip) {                                                  // chain.c:72-73
+								if (watch) {	// tie partners of the candidate the scan ends at (if they go on into the next 64: assume the worst)
+									i64 c2 = c + 1;
+									for (; c2 < cnt && cand[c2].x32 == w.x32; ++c2) if (cand[c2].flags & 1) st_sh[4] = 1;
+									if (c2 == cnt && top - 64 >= st) st_sh[4] = 1;
+								}
+								done = 1; break;
+							}
+						}
 					}
-					st_sh[0] = max_f; st_sh[1] = max_j; st_sh[2] = n_skip; st_sh[3] = done;
+					st_sh[0] = max_f; st_sh[1] = max_j; st_sh[2] = n_skip; st_sh[3] = done; st_sh[5] = have_act; st_sh[6] = (i32)act_x;
 				}
 			}
 			LQ_BLOCK_SYNC();
@@ -658,7 +730,11 @@ k_chain_wave(const mm128 *A, const u64 *gstart, const u32 *glist, u32 n_list, co
 		}
 		LQ_BLOCK_SYNC();
 	}
-	LQ_BLOCK_LOOP(ln) { if (ln == 0) lq_chain_finish(a, n, f, p, t, v, u, q, accumulate, P, C); }
+	LQ_BLOCK_LOOP(ln) {
+		if (ln == 0) {
+			if (st_sh[4] || lq_chain_finish(a, n, f, p, t, v, u, q, accumulate, P, C, watch)) lq_tie_list(C, q, lq_hi32(a));
+		}
+	}
 }
 
 // ---- filter_redundant_coords (lqmap.c:25-100), one thread per query, on this part's intervals ----

@@ -179,18 +179,32 @@ __global__ void k_dup_mark(const u64 *qx, const u64 *qy, const u32 *owner, const
 // MM_SEED_TANDEM): the sort counts them to tell where klib's order can matter.  The anchors of a query that goes through
 // klib's passes (qklib) are written to `originals` (the lane's second buffer) instead of `anchors`: the passes permute
 // 8-byte records and gather every anchor once, into `anchors`, when its bucket is finished (kernels_rsort.hpp).
+// A subset of the queries (the second pass of map_batch: the queries with a run in which klib's order of equal-x anchors can
+// be observed): blockIdx.y = index into `sub`, the block's minimizers are those of query sub.q[blockIdx.y], the query's anchors
+// go to sub.off[blockIdx.y] + (their place inside the query), to `originals` when sub.klib[...] says so; mini_pos is not
+// written again.
 #define LQ_EMIT_THREADS 256
 struct EmitSetup { u64 st, out0; u32 n, q, span, qp, flags; i32 ql; };
+struct EmitSub { const u32 *q; const u64 *off; const u32 *klib; };     // q == nullptr: all queries of the minimizer range [j0, j0 + nj)
 __global__ void __launch_bounds__(LQ_EMIT_THREADS)
 k_seed_emit(const u64 *qx, const u64 *qy, const u32 *owner, const u64 *qmoff, u64 j0, u64 nj,
             const u64 *pos, const u64 *hit_start, const u32 *hit_n, const u32 *keep, const u32 *dup,
             const u64 *a_off, u64 a_base, const u64 *mp_off, const u32 *qlen,
             int no_self, const u32 *self_off, const u32 *self_rid, AvaView ava,
-            const u32 *qklib, mm128 *anchors, mm128 *originals, u64 *mini_pos)
+            const u32 *qklib, mm128 *anchors, mm128 *originals, u64 *mini_pos, EmitSub sub)
 {
 	__shared__ EmitSetup su[LQ_EMIT_THREADS];
-	const u64 jt = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+	u64 jt = (u64)blockIdx.x * blockDim.x + threadIdx.x;
 	const u32 lane = threadIdx.x & 63, w0 = threadIdx.x & ~63u;
+	u64 sub_shift = 0; u32 sub_klib = 0;
+	if (sub.q) {                                              // (block-uniform)
+		const u32 sq = sub.q[blockIdx.y];
+		j0 = qmoff[sq]; nj = qmoff[sq + 1] - j0;
+		if ((u64)blockIdx.x * blockDim.x >= nj) return;
+		a_base = 0;
+		sub_shift = a_off[j0] - sub.off[blockIdx.y];          // the query's first anchor goes to sub.off[...]
+		sub_klib = sub.klib[blockIdx.y];
+	}
 	const u64 j = j0 + (jt < nj ? jt : 0);
 	const bool act = jt < nj && keep[j];
 	EmitSetup e; e.st = 0; e.out0 = 0; e.n = 0; e.q = 0; e.span = 0; e.qp = 0; e.flags = 0; e.ql = 0;
@@ -198,13 +212,13 @@ k_seed_emit(const u64 *qx, const u64 *qy, const u32 *owner, const u64 *qmoff, u6
 		e.q = owner[j];
 		const u64 x = qx[j];
 		e.span = (u32)(x & 0xff); e.qp = (u32)qy[j];
-		mini_pos[mp_off[j]] = (u64)e.span << 32 | (e.qp >> 1);
+		if (!sub.q) mini_pos[mp_off[j]] = (u64)e.span << 32 | (e.qp >> 1);
 		if (j > qmoff[e.q] && (qx[j - 1] >> 8) == (x >> 8)) e.flags |= 1;            // tandem
 		if (j + 1 < qmoff[e.q + 1] && (qx[j + 1] >> 8) == (x >> 8)) e.flags |= 1;
 		if (no_self && self_off[e.q] != self_off[e.q + 1]) e.flags |= 2;             // some target carries this query's name
 		if (dup[j]) e.flags |= 4;
-		if (qklib[e.q]) e.flags |= 8;                                                // this query goes through klib's passes: its anchors are "originals"
-		e.n = hit_n[j]; e.st = hit_start[j]; e.out0 = a_off[j] - a_base; e.ql = (i32)qlen[e.q];
+		if (sub.q ? sub_klib : qklib[e.q]) e.flags |= 8;                             // this query goes through klib's passes: its anchors are "originals"
+		e.n = hit_n[j]; e.st = hit_start[j]; e.out0 = a_off[j] - a_base - sub_shift; e.ql = (i32)qlen[e.q];
 	}
 	su[threadIdx.x] = e;
 	__syncthreads();
@@ -238,6 +252,189 @@ k_seed_emit(const u64 *qx, const u64 *qy, const u32 *owner, const u64 *qmoff, u6
 				else { a.x = 1ULL << 63 | (r & 0xffffffff00000000ULL) | rpos; a.y = y_rev; }
 				out[b.out0 + t - before] = a;
 			}
+		}
+	}
+}
+
+// ---- anchors that cannot be part of a chain are never written --------------------------------------------------------------
+// mm_chain_dp never lets anchors of different (strand, rid) interact (kernels_chain.hpp), and a run of fewer than
+// n_min = max(min_cnt, ceil(min_sc / span_max)) anchors cannot hold a chain (chain.c:57-67,119-121; k_run_list drops such runs
+// anyway).  Against half a million targets four fifths of a query's seed hits are lone chance hits: they used to be written,
+// sorted and read again only to be dropped.  Here they are counted first: one block per query holds a table of 2-bit
+// saturating counters in LDS, indexed by (rid, relative strand) -- directly while 2 * targets <= the table, else over slices
+// of the rid range (at most as many as make the mapping direct, and only as many as keep the expected load of a counter
+// below ~0.6: a query with few anchors needs no slices, aliasing then only lets a few more anchors through) -- and a hit
+// survives when its counter reached thr = min(n_min, 3).  False positives are harmless (the run list decides exactly);
+// there are no false negatives: every anchor of a run of >= n_min anchors finds its counter saturated or >= thr.
+// Survivors are recorded as one bit per hit (a 64-bit word per 64 hits of a minimizer: plain stores by lane 0 of the wave
+// that owns the minimizer in every slice) and counted per minimizer; k_seed_emit_f then writes them, dense, in (query,
+// minimizer, hit) order.  avg_qspan, mini_pos and the lq_cnt_match prologue keep using the unfiltered totals (chain.c:37-38,
+// lqmap.c:174).  Exact only together with a sort that does not need klib's walk over the *whole* query: map_batch's first pass.
+#define LQ_FT_WORDS 32768u                  // 128 KiB of LDS: 524288 two-bit counters
+#define LQ_FC_THREADS 1024
+#define LQ_FC_UNROLL 4
+struct FiltParams { u32 thr, n_targets, keys_cap /* counters in use: a power of two <= 16 * LQ_FT_WORDS (tests shrink it) */, a_cap /* anchors per slice aimed at */; };
+
+__device__ __forceinline__ u32 lq_ft_get(const u32 *tab, u32 key) { return tab[key >> 4] >> ((key & 15) << 1) & 3u; }
+__device__ __forceinline__ void lq_ft_inc(u32 *tab, u32 key)
+{
+	const u32 w = key >> 4, sh = (key & 15) << 1;
+	u32 old = tab[w];
+	for (;;) {
+		if ((old >> sh & 3u) == 3u) return;                   // saturated
+		const u32 seen = atomicCAS(&tab[w], old, old + (1u << sh));
+		if (seen == old) return;
+		old = seen;
+	}
+}
+
+__global__ void __launch_bounds__(LQ_FC_THREADS)
+k_seed_count(const u64 *qy, const u64 *qmoff, u32 n_q, const u64 *pos, const u64 *hit_start, const u32 *hit_n, const u32 *keep, const u64 *aq_off,
+             int no_self, const u32 *self_off, const u32 *self_rid, AvaView ava, FiltParams fp,
+             const u64 *fm_off, u64 *fmask, u32 *cntf)
+{
+	__shared__ u32 tab[LQ_FT_WORDS];
+	const u32 t = threadIdx.x, lane = t & 63, wv = t >> 6, nw = blockDim.x >> 6;
+	for (u32 q = blockIdx.x; q < n_q; q += gridDim.x) {
+		const u64 j0 = qmoff[q], j1 = qmoff[q + 1];
+		const u64 Aq = aq_off[q + 1] - aq_off[q];
+		if (Aq == 0) continue;                                    // (block-uniform)
+		u32 n_sl = 1;
+		if (fp.thr) {
+			const u64 by_keys = (2ULL * fp.n_targets + fp.keys_cap - 1) / fp.keys_cap, by_load = (Aq + fp.a_cap - 1) / fp.a_cap;
+			n_sl = (u32)(by_keys < by_load ? by_keys : by_load);
+			if (n_sl == 0) n_sl = 1;
+		}
+		const u32 R = (fp.n_targets + n_sl - 1) / n_sl;          // rids per slice
+		const bool self_q = no_self && self_off[q] != self_off[q + 1];
+		const u32 qlo = ava.q_lo ? ava.q_lo[q] : 0;
+		const u32 kmask = fp.keys_cap - 1;
+		for (u32 s = 0; s < n_sl; ++s) {
+			const u32 r_lo = s * R;
+			if (fp.thr) {
+				for (u32 i = t; i < (fp.keys_cap >> 4); i += blockDim.x) tab[i] = 0;
+				__syncthreads();
+				// sweep 1: count the slice's hits per (rid, relative strand).  LQ_FC_UNROLL minimizers per wave and turn: their loads are in flight together
+				for (u64 jb = j0 + (u64)wv * LQ_FC_UNROLL; jb < j1; jb += (u64)nw * LQ_FC_UNROLL) {
+					u32 n[LQ_FC_UNROLL], qs[LQ_FC_UNROLL]; u64 st[LQ_FC_UNROLL]; u32 nmax = 0;
+#pragma unroll
+					for (int u = 0; u < LQ_FC_UNROLL; ++u) {
+						const u64 j = jb + u;
+						n[u] = (j < j1 && keep[j]) ? hit_n[j] : 0; st[u] = n[u] ? hit_start[j] : 0; qs[u] = n[u] ? ((u32)qy[j] & 1u) : 0;
+						nmax = n[u] > nmax ? n[u] : nmax;
+					}
+					for (u32 t0 = 0; t0 < nmax; t0 += 64) {
+						u64 r[LQ_FC_UNROLL];
+#pragma unroll
+						for (int u = 0; u < LQ_FC_UNROLL; ++u) r[u] = t0 + lane < n[u] ? pos[st[u] + t0 + lane] : ~0ULL;
+#pragma unroll
+						for (int u = 0; u < LQ_FC_UNROLL; ++u) {
+							const u32 rid = (u32)(r[u] >> 32);
+							if (t0 + lane < n[u] && rid - r_lo < R) lq_ft_inc(tab, (((rid - r_lo) << 1) | (((u32)r[u] & 1u) ^ qs[u])) & kmask);
+						}
+					}
+				}
+				__syncthreads();
+			}
+			// sweep 2: the slice's hits whose counter reached thr (all of them without a filter), minus the self diagonal and -X
+			for (u64 jb = j0 + (u64)wv * LQ_FC_UNROLL; jb < j1; jb += (u64)nw * LQ_FC_UNROLL) {
+				u32 n[LQ_FC_UNROLL], qp[LQ_FC_UNROLL], c[LQ_FC_UNROLL]; u64 st[LQ_FC_UNROLL]; u32 nmax = 0;
+#pragma unroll
+				for (int u = 0; u < LQ_FC_UNROLL; ++u) {
+					const u64 j = jb + u;
+					n[u] = (j < j1 && keep[j]) ? hit_n[j] : 0; st[u] = n[u] ? hit_start[j] : 0; qp[u] = n[u] ? (u32)qy[j] : 0; c[u] = 0;
+					nmax = n[u] > nmax ? n[u] : nmax;
+				}
+				for (u32 t0 = 0; t0 < nmax; t0 += 64) {
+					u64 r[LQ_FC_UNROLL];
+#pragma unroll
+					for (int u = 0; u < LQ_FC_UNROLL; ++u) r[u] = t0 + lane < n[u] ? pos[st[u] + t0 + lane] : ~0ULL;
+#pragma unroll
+					for (int u = 0; u < LQ_FC_UNROLL; ++u) {
+						const u32 rid = (u32)(r[u] >> 32), rpos = (u32)r[u] >> 1;
+						bool pass = t0 + lane < n[u] && rid - r_lo < R;
+						if (pass && fp.thr) pass = lq_ft_get(tab, (((rid - r_lo) << 1) | (((u32)r[u] & 1u) ^ (qp[u] & 1u))) & kmask) >= fp.thr;
+						if (pass && self_q && rpos == (qp[u] >> 1) && lq_is_self(self_off, self_rid, q, rid)) pass = false;   // lqmap.c:180-186
+						if (pass && ava.t_rank && ava.t_rank[rid] < qlo) pass = false;                                            // lqmap.c:187
+						const u64 sv = __ballot(pass);
+						if (lane == 0 && sv) { fmask[fm_off[jb + u] + (t0 >> 6)] |= sv; c[u] += (u32)__popcll(sv); }
+					}
+				}
+#pragma unroll
+				for (int u = 0; u < LQ_FC_UNROLL; ++u) if (lane == 0 && c[u]) cntf[jb + u] += c[u];
+			}
+			__syncthreads();                                         // (the next slice clears the table)
+		}
+	}
+}
+
+// words of the survivor bitmap per query minimizer (scanned into fm_off)
+__global__ void k_fmask_words(const u32 *hit_n, const u32 *keep, u64 n_qm, u32 *words)
+{
+	const u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+	if (j < n_qm) words[j] = keep[j] ? (hit_n[j] + 63) >> 6 : 0;
+}
+// per query: where its surviving anchors start (af_off = exclusive scan of cntf)
+__global__ void k_query_foff(const u64 *qmoff, const u64 *af_off, u64 n_qm, u64 n_total, u32 n_q, u64 *aqf_off)
+{
+	const u32 q = blockIdx.x * blockDim.x + threadIdx.x;
+	if (q > n_q) return;
+	const u64 j0 = qmoff[q];
+	aqf_off[q] = j0 < n_qm ? af_off[j0] : n_total;
+}
+
+// the surviving anchors (lqmap.c:175-200) of the minimizers [j0, j0 + nj), dense; and mini_pos (lqmap.c:174) of every kept
+// minimizer.  Same shape as k_seed_emit: set-up per lane in LDS, then the wave writes one minimizer's survivors at a time.
+__global__ void __launch_bounds__(LQ_EMIT_THREADS)
+k_seed_emit_f(const u64 *qx, const u64 *qy, const u32 *owner, const u64 *qmoff, u64 j0, u64 nj,
+              const u64 *pos, const u64 *hit_start, const u32 *hit_n, const u32 *keep, const u32 *dup,
+              const u64 *fm_off, const u64 *fmask, const u32 *cntf, const u64 *af_off, u64 a_base, const u64 *mp_off, const u32 *qlen,
+              mm128 *anchors, u64 *mini_pos)
+{
+	__shared__ EmitSetup su[LQ_EMIT_THREADS];
+	__shared__ u64 fo[LQ_EMIT_THREADS];
+	const u64 jt = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+	const u32 lane = threadIdx.x & 63, w0 = threadIdx.x & ~63u;
+	const u64 j = j0 + (jt < nj ? jt : 0);
+	const bool act = jt < nj && keep[j];
+	EmitSetup e; e.st = 0; e.out0 = 0; e.n = 0; e.q = 0; e.span = 0; e.qp = 0; e.flags = 0; e.ql = 0;
+	u64 f0 = 0;
+	if (act) {
+		e.q = owner[j];
+		const u64 x = qx[j];
+		e.span = (u32)(x & 0xff); e.qp = (u32)qy[j];
+		mini_pos[mp_off[j]] = (u64)e.span << 32 | (e.qp >> 1);
+		if (cntf[j]) {
+			if (j > qmoff[e.q] && (qx[j - 1] >> 8) == (x >> 8)) e.flags |= 1;            // tandem
+			if (j + 1 < qmoff[e.q + 1] && (qx[j + 1] >> 8) == (x >> 8)) e.flags |= 1;
+			if (dup[j]) e.flags |= 4;
+			e.n = hit_n[j]; e.st = hit_start[j]; e.out0 = af_off[j] - a_base; e.ql = (i32)qlen[e.q];
+			f0 = fm_off[j];
+		}
+	}
+	su[threadIdx.x] = e; fo[threadIdx.x] = f0;
+	__syncthreads();
+	for (u32 f = 0; f < 64; ++f) {
+		const EmitSetup b = su[w0 + f];                         // the same entry in every lane of the wave
+		if (b.n == 0) continue;
+		const u64 *fm = fmask + fo[w0 + f];
+		const u32 b_qpos = b.qp >> 1;
+		const u64 ybits = ((b.flags & 1) ? LQ_SEED_TANDEM : 0) | ((b.flags & 4) ? LQ_TIE_MARK : 0);
+		const u64 y_same = (u64)b.span << 32 | b_qpos | ybits;
+		const u64 y_rev = (u64)b.span << 32 | (u32)(b.ql - (i32)(b_qpos + 1 - b.span) - 1) | ybits;
+		u32 done = 0;
+		for (u32 t0 = 0; t0 < b.n; t0 += 64) {
+			const u64 sv = fm[t0 >> 6];                             // (wave-uniform)
+			if (sv == 0) continue;
+			if (sv >> lane & 1) {
+				const u64 r = pos[b.st + t0 + lane];
+				const u32 rpos = (u32)r >> 1;
+				mm128 a;
+				if ((r & 1) == (b.qp & 1)) { a.x = (r & 0xffffffff00000000ULL) | rpos; a.y = y_same; }
+				else { a.x = 1ULL << 63 | (r & 0xffffffff00000000ULL) | rpos; a.y = y_rev; }
+				anchors[b.out0 + done + (u32)__popcll(sv & ((1ULL << lane) - 1))] = a;
+			}
+			done += (u32)__popcll(sv);
 		}
 	}
 }

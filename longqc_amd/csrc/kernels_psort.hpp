@@ -388,8 +388,15 @@ k_ps_finish(const PSeg *segs, const u32 *n_p, PsData P, KeyMap km, unsigned long
 				const u32 d = dgs[i];
 				const KEY key = keys[i];
 				const u32 b0 = beg[d], b1 = b0 + hist[d];
+				// (equal keys = equal x, when the sort is not asked for klib's order: any order among them, but a place each -- ties by
+				// the index in the segment, appended to the key where the key leaves room: one comparison)
 				u32 r = 0;
-				for (u32 j = b0; j < b1; ++j) r += keys[perm[j]] < key;
+				if (sizeof(KEY) == 4) {
+					static_assert(CAP <= 8192, "13 bits of index");
+					const u64 me = (u64)key << 13 | i;
+					for (u32 j = b0; j < b1; ++j) { const u32 pj = perm[j]; r += ((u64)keys[pj] << 13 | pj) < me; }
+				} else
+					for (u32 j = b0; j < b1; ++j) { const u32 pj = perm[j]; const KEY kj = keys[pj]; r += (kj < key) || (kj == key && pj < i); }
 				mm128 e;
 				e.x = lq_ckey_inv(chigh | (kmin + ((u64)d << sh | (u64)key)), km);
 				e.y = y[k];

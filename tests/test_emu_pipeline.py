@@ -548,3 +548,57 @@ def test_emulated_threads_in_descending_order_and_the_sort_checked(emu_lib, case
             assert out == read_gz(case["expect"]), (order, env)
             for k in env:
                 monkeypatch.delenv(k)
+
+
+# ---- klib's order only where it can be observed; seed hits that cannot reach a chain never written (map_batch) -------------------
+def check_observable_ties_scheme(lib, tmp_path, monkeypatch, seed, env):
+    """repeat-rich reads (equal-x anchors everywhere, rows depend on klib's order): first pass with the counting filter and any
+    sort, second pass in klib's order for the runs the chain kernels listed; the table equals the reference's under every
+    shape of the filter (table shrunk: rid slices, aliased counters; no filter) and of the second pass (tiny work space: several
+    sub-batches), and with the scheme switched off (LQCOV_TIES=klib: rounds 1-3's path)"""
+    tf, qf = _repeat_rich_dataset(tmp_path, seed)
+    argv = ONT + [tf, qf]
+    want = oracle_bind.ref_table(argv) if oracle_bind.have_ref() else oracle_bind.table(argv)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    rc, out, err = run_main(lib, argv)
+    assert rc == 0, err
+    assert out == want
+    return err
+
+
+OBS_ENVS = [{}, {"LQCOV_FILTER_KEYS": "64"}, {"LQCOV_FILTER_KEYS": "1024", "LQCOV_FILTER_ACAP": "100"}, {"LQCOV_FILTER": "0"},
+            {"LQCOV_ANCHOR_BUDGET": "20000", "LQCOV_LANES": "2"}, {"LQCOV_TIES": "klib"}, {"LQCOV_DEBUG_SORT": "1", "LQCOV_PS_SHIFT": "5"}]
+
+
+@pytest.mark.parametrize("env", OBS_ENVS, ids=lambda e: "+".join("%s=%s" % kv for kv in e.items()) or "default")
+def test_emulated_observable_ties_scheme(emu_lib, tmp_path, monkeypatch, env):
+    err = check_observable_ties_scheme(emu_lib, tmp_path, monkeypatch, 2 + len(env), env)
+    if "LQCOV_TIES" not in env:
+        assert "queries chained in klib's order" in err and " 0 runs of 0 queries" not in err      # the second pass ran
+
+
+def check_filter_drops_chance_hits(lib, tmp_path):
+    """many targets, few of them overlapping a query: most seed hits are lone chance hits and are never written, few queries need
+    klib's order at all; rows equal the reference's"""
+    import dataclasses
+    from longqc_amd import synth
+    cfg = dataclasses.replace(synth.CONFIGS["cfg3"], n_reads=1500, nsample=40, depth=3.0, mean_len=3000)
+    T, Q = synth.make_dataset(cfg)
+    tf, qf = str(tmp_path / "all.fq"), str(tmp_path / "sub.fq")
+    synth.write_fastq(tf, T); synth.write_fastq(qf, Q)
+    argv = ["-Y", "-l", "0", "-q", "160", "-k", "12", "-w", "5", "-I", "4G", "-p", "80", tf, qf]
+    want = oracle_bind.ref_table(argv) if oracle_bind.have_ref() else oracle_bind.table(argv)
+    p, _, _ = api.parse_args(argv)
+    eng = api.Engine(p, 0, lib=lib)
+    out = str(tmp_path / "o.tsv")
+    eng.run_files(tf, qf, out=out, err=str(tmp_path / "e.log"))
+    st, emitted = eng.map_stats(), eng.last_n_anchors
+    eng.close()
+    assert open(out).read() == want
+    assert 0 < st["last_written"] < 0.7 * emitted, (st, emitted)
+    assert st["klib_queries"] < 20, st
+
+
+def test_emulated_filter_drops_chance_hits(emu_lib, tmp_path):
+    check_filter_drops_chance_hits(emu_lib, tmp_path)

@@ -479,3 +479,13 @@ def test_gpu_sdust_midsize_vs_oracle(gpu_lib, tmp_path):
     assert rc == 0, err
     assert out == want
     assert sum(int(l.split("\t")[1]) for l in out.splitlines()) > 100000
+
+
+@pytest.mark.parametrize("env", E.OBS_ENVS, ids=lambda e: "+".join("%s=%s" % kv for kv in e.items()) or "default")
+@pytest.mark.parametrize("seed", [11, 12])
+def test_gpu_observable_ties_scheme(gpu_lib, tmp_path, monkeypatch, seed, env):
+    E.check_observable_ties_scheme(gpu_lib, tmp_path, monkeypatch, seed, env)
+
+
+def test_gpu_filter_drops_chance_hits(gpu_lib, tmp_path):
+    E.check_filter_drops_chance_hits(gpu_lib, tmp_path)
