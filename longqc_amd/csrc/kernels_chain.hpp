@@ -356,20 +356,47 @@ k_sel_write(const u64 *gstart, u64 n_groups, i32 min_cnt, i32 max_cnt, u32 n_til
 	}
 }
 
-// mm_chain_dp, first half (chain.c:41-81): scores f, predecessors p, peak scores v of one run, serially
-// Returns true when two anchors of equal x were both inside the band of one scan (watch_ties only): then, and only then,
-// the scores can depend on the order of equal-x anchors.  Anchors of equal x never chain to each other (dr == 0), a candidate
-// outside the band is stepped over before any state changes (the `continue`s of chain.c:52-56 precede chain.c:69-76), so
-// with at most one member of every tie group inside the band every scan sees the same sequence of effective candidates
-// whatever the order inside the groups, and f, p, v, t are the same per anchor.  (A scan that breaks off at a candidate
-// (chain.c:72-73) would, in another order, have met that candidate's tie partners in its place: they are looked at too.)
+// ---- when does the order of equal-x anchors matter to the scores? ---------------------------------------------------------------
+// Anchors of equal x never chain to each other (dr == 0, chain.c:52) and are neighbours in the sorted array.  A candidate outside
+// the band is stepped over before any state changes (the `continue`s of chain.c:52-56 precede chain.c:69-76), so only the
+// members of a tie group that are inside the band of the same scan (a "group" below) can be told apart by their order.  What
+// a scanned candidate does: raise the best score (sc > max_f: max_f, max_j, one skip forgiven, chain.c:69-71), or count as a
+// skip (t[j] == i, chain.c:72-74), or neither ("quiet") -- and leave its mark (chain.c:76), which every scanned candidate does
+// whatever the order.  A quiet member (sc <= the best score before the group -- it only grows --, t[j] != i) commutes with
+// everything.  Two or more loud members still commute when no skip is pending before the group and none of them counts as one
+// (then n_skip stays 0 in any order) and the highest score among them is reached by one member only (then max_f and max_j end
+// the same).  A scan that breaks off (chain.c:73) does so at a loud member that counts as a skip: its tie partners not yet
+// scanned would, in another order, have come first -- if one of them is loud too, the order matters.  With every group of
+// every scan order-free, f, p, v and the marks are the same per anchor in any order of the ties (oracle: sort modes 2 / 3;
+// tests/test_tie_order.py chains every run the rule calls order-free in two orders and compares).
+struct TieGroup {
+	u32 x; i32 m, top;
+	u32 st;                    // bit0: open, bit1: no skip pending at its start, bit2: a member counts as a skip, bit3: the top score reached twice, bits 4..: loud members
+	__device__ __forceinline__ bool bad() const { return (st & 1u) && (st >> 4) >= 2u && (!(st & 2u) || (st & 12u)); }
+	__device__ __forceinline__ bool quiet(i32 sc, bool tmark) const { return sc <= m && !tmark; }
+	// candidate (low word of x, score, counts as a skip) meets the scan's state (max_f, n_skip) as it is before it; true: the group that closes here was order-dependent
+	__device__ __forceinline__ bool see(u32 xj, i32 sc, bool tmark, i32 max_f, i32 n_skip)
+	{
+		bool r = false;
+		if (!((st & 1u) && xj == x)) { r = bad(); x = xj; m = max_f; top = (i32)0x80000000; st = 1u | (n_skip == 0 ? 2u : 0u); }
+		if (!quiet(sc, tmark)) {
+			st += 16u;
+			if (tmark) st |= 4u;
+			if (sc > top) { top = sc; st &= ~8u; } else if (sc == top) st |= 8u;
+		}
+		return r;
+	}
+};
+
+// mm_chain_dp, first half (chain.c:41-81): scores f, predecessors p, peak scores v of one run, serially.
+// Returns true when the scores may depend on the order of equal-x anchors (watch_ties only; TieGroup above).
 template <class AP, class IP>
 __device__ __forceinline__ bool lq_chain_fill(AP a, const i64 n, IP f, IP p, IP t, IP v, const float avg_qspan, const MapParams &P, const bool watch_ties)
 {
 	const i32 max_dist = P.max_gap, bw = P.bw, max_skip = P.max_skip;
 	i64 st = 0;
-	bool band_tie = false, have_act = false;
-	u64 act_x = 0;
+	bool band_tie = false;
+	TieGroup tg; tg.x = 0; tg.m = 0; tg.top = 0; tg.st = 0;
 	for (i64 i = 0; i < n; ++i) t[i] = 0;
 	// fill the score and backtrack arrays (chain.c:41-81).  Flat form: one candidate predecessor per loop trip,
 	// so that the lanes of a wave (different runs) do not wait for each other's inner loops to finish.
@@ -383,7 +410,7 @@ __device__ __forceinline__ bool lq_chain_fill(AP a, const i64 n, IP f, IP p, IP 
 				ri = a[i].x; qi = (i32)a[i].y; q_span = (i32)(a[i].y >> 32 & 0xff);
 				max_f = q_span; max_j = -1; n_skip = 0;
 				while (st < i && ri - a[st].x > (u64)max_dist) ++st;
-				j = i - 1; setup = false; have_act = false;
+				j = i - 1; setup = false; tg.st = 0;
 			}
 			if (j >= st) {
 				const i64 dr = (i64)(ri - a[j].x);
@@ -397,11 +424,7 @@ __device__ __forceinline__ bool lq_chain_fill(AP a, const i64 n, IP f, IP p, IP 
 						sc -= (i32)((double)dd * .01 * (double)avg_qspan) + (log_dd >> 1);     // chain.c:67
 						sc += f[j];
 						bool brk = false;
-						if (watch_ties) {
-							const u64 xj = a[j].x;
-							if (have_act && xj == act_x) band_tie = true;
-							have_act = true; act_x = xj;
-						}
+						if (watch_ties && tg.see((u32)a[j].x, sc, t[j] == (i32)i, max_f, n_skip)) band_tie = true;
 						if (sc > max_f) {
 							max_f = sc; max_j = j;
 							if (n_skip > 0) --n_skip;
@@ -410,11 +433,14 @@ __device__ __forceinline__ bool lq_chain_fill(AP a, const i64 n, IP f, IP p, IP 
 						}
 						if (brk) {
 							if (watch_ties)
-								for (i64 jj = j - 1; jj >= st && a[jj].x == a[j].x; --jj) {
+								for (i64 jj = j - 1; jj >= st && a[jj].x == a[j].x; --jj) {   // tie partners the scan no longer reaches
 									const i32 dq2 = qi - (i32)a[jj].y;
 									if (dq2 <= 0 || dq2 > max_dist) continue;
 									const i32 dd2 = dr > dq2 ? (i32)(dr - dq2) : (i32)(dq2 - dr);
-									if (dd2 <= bw) band_tie = true;
+									if (dd2 > bw) continue;
+									const i32 md2 = dq2 < dr ? dq2 : (i32)dr;
+									const i32 sc2 = (md2 > q_span ? q_span : md2) - ((i32)((double)dd2 * .01 * (double)avg_qspan) + ((dd2 ? lq_ilog2_32((u32)dd2) : 0) >> 1)) + f[jj];
+									if (!tg.quiet(sc2, t[jj] == (i32)i)) band_tie = true;
 								}
 							j = st;                                                   // leave the candidate loop
 						}
@@ -423,6 +449,7 @@ __device__ __forceinline__ bool lq_chain_fill(AP a, const i64 n, IP f, IP p, IP 
 				}
 				--j;
 			} else {
+				if (watch_ties && tg.bad()) band_tie = true;                      // the scan's last group
 				f[i] = max_f; p[i] = (i32)max_j;
 				v[i] = max_j >= 0 && v[max_j] > max_f ? v[max_j] : max_f;
 				++i; setup = true;
@@ -637,7 +664,7 @@ k_chain_wave(const mm128 *A, const u64 *gstart, const u32 *glist, u32 n_list, co
              const float *avg_qspan_q, MapParams P, ChainBufs B, CovState C)
 {
 	LQ_SHARED WaveCand cand[64];
-	LQ_SHARED i32 st_sh[8];                                  // [0] max_f, [1] max_j, [2] n_skip, [3] done, [4] a tie inside one band, [5] a candidate was inside the band, [6] its x32
+	LQ_SHARED i32 st_sh[10];                                 // [0] max_f, [1] max_j, [2] n_skip, [3] done, [4] the order of equal-x anchors may matter, [5..8] the scan's open TieGroup (x, m, top, st)
 	if (blockIdx.x >= n_list) return;
 	const u32 g = glist[blockIdx.x];
 	const u64 gs = LQ_RUN_START(gstart[g]);
@@ -662,7 +689,7 @@ k_chain_wave(const mm128 *A, const u64 *gstart, const u32 *glist, u32 n_list, co
 		const u64 ri = a[i].x;
 		const i32 qi = (i32)a[i].y, q_span = (i32)(a[i].y >> 32 & 0xff);
 		while (st < i && ri - a[st].x > (u64)max_dist) ++st;    // uniform: every lane computes the same st
-		LQ_BLOCK_LOOP(ln) { if (ln == 0) { st_sh[0] = q_span; st_sh[1] = -1; st_sh[2] = 0; st_sh[3] = 0; st_sh[5] = 0; } }
+		LQ_BLOCK_LOOP(ln) { if (ln == 0) { st_sh[0] = q_span; st_sh[1] = -1; st_sh[2] = 0; st_sh[3] = 0; st_sh[8] = 0; } }
 		LQ_BLOCK_SYNC();
 		for (i64 top = i - 1; top >= st; top -= 64) {
 			// phase 1: 64 candidates in parallel
@@ -697,25 +724,27 @@ k_chain_wave(const mm128 *A, const u64 *gstart, const u32 *glist, u32 n_list, co
 			LQ_BLOCK_LOOP(ln) {
 				if (ln == 0) {
 					i32 max_f = st_sh[0], max_j = st_sh[1], n_skip = st_sh[2], done = 0;
-					i32 have_act = st_sh[5]; u32 act_x = (u32)st_sh[6];
+					TieGroup tg; tg.x = (u32)st_sh[5]; tg.m = st_sh[6]; tg.top = st_sh[7]; tg.st = (u32)st_sh[8];
 					const i64 cnt = top - st + 1 < 64 ? top - st + 1 : 64;
 					for (i64 c = 0; c < cnt; ++c) {
 						const WaveCand w = cand[c];
 						if (!(w.flags & 1)) continue;
-						if (watch) { if (have_act && w.x32 == act_x) st_sh[4] = 1; have_act = 1; act_x = w.x32; }   // (see lq_chain_fill)
+						if (watch && tg.see(w.x32, w.sc, (w.flags & 2) != 0, max_f, n_skip)) st_sh[4] = 1;   // (TieGroup, above lq_chain_fill)
 						if (w.sc > max_f) { max_f = w.sc; max_j = w.j; if (n_skip > 0) --n_skip; }
 						else if (w.flags & 2) {
 							if (++n_skip > max_skip) {                                                  // chain.c:72-73
-								if (watch) {	// tie partners of the candidate the scan ends at (if they go on into the next 64: assume the worst)
+								if (watch) {	// tie partners the scan no longer reaches (if they go on into the next 64: assume the worst)
 									i64 c2 = c + 1;
-									for (; c2 < cnt && cand[c2].x32 == w.x32; ++c2) if (cand[c2].flags & 1) st_sh[4] = 1;
+									for (; c2 < cnt && cand[c2].x32 == w.x32; ++c2) if ((cand[c2].flags & 1) && !tg.quiet(cand[c2].sc, (cand[c2].flags & 2) != 0)) st_sh[4] = 1;
 									if (c2 == cnt && top - 64 >= st) st_sh[4] = 1;
 								}
 								done = 1; break;
 							}
 						}
 					}
-					st_sh[0] = max_f; st_sh[1] = max_j; st_sh[2] = n_skip; st_sh[3] = done; st_sh[5] = have_act; st_sh[6] = (i32)act_x;
+					if (watch && (done || top - 64 < st) && tg.bad()) st_sh[4] = 1;                 // the scan's last group
+					st_sh[0] = max_f; st_sh[1] = max_j; st_sh[2] = n_skip; st_sh[3] = done;
+					st_sh[5] = (i32)tg.x; st_sh[6] = tg.m; st_sh[7] = tg.top; st_sh[8] = (i32)tg.st;
 				}
 			}
 			LQ_BLOCK_SYNC();

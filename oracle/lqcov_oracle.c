@@ -509,7 +509,7 @@ static void chain_dp_range_s(const lqo_params *P, float avg_qspan, const lqo_mm1
 		int64_t max_j = -1;
 		int32_t qi = (int32_t)a[i].y, q_span = a[i].y >> 32 & 0xff;
 		int32_t max_f = q_span, n_skip = 0;
-		int have_act = 0; uint64_t act_x = 0;
+		int have_act = 0, grp_loud = 0, grp_s0 = 0, grp_tm = 0, grp_dup = 0; uint64_t act_x = 0; int32_t grp_m = 0, grp_top = 0;
 		while (st < i && ri - a[st].x > (uint64_t)max_dist_x) ++st;
 		for (j = i - 1; j >= st; --j) {
 			int64_t dr = ri - a[j].x;
@@ -523,22 +523,39 @@ static void chain_dp_range_s(const lqo_params *P, float avg_qspan, const lqo_mm1
 			log_dd = dd ? ilog2_32(dd) : 0;
 			sc -= (int)(dd * .01 * avg_qspan) + (log_dd >> 1);
 			sc += f[j];
-			if (band_tie) {                                 /* two candidates of equal x inside the band of the same scan */
-				if (have_act && a[j].x == act_x) *band_tie = 1;
-				have_act = 1; act_x = a[j].x;
+			if (band_tie) {
+				/* Candidates of equal x inside the band of one scan (a "group"; they are neighbours in the array).  What a candidate
+				 * does: raise the best score (sc > max_f: max_f, max_j, one skip forgiven), or count as a skip (t[j] == i), or
+				 * neither ("quiet") -- and leave its mark (below), which every scanned candidate does whatever the order.  Quiet
+				 * members (sc <= the best score before the group, which only grows; t[j] != i) commute with everything.  Two or
+				 * more loud members still commute when no skip is pending before the group and none of them counts as one (then
+				 * n_skip stays 0 in any order) and the highest score among them is reached by one member only (then max_f, max_j
+				 * end the same). */
+				if (!(have_act && a[j].x == act_x)) {
+					if (have_act && grp_loud >= 2 && (!grp_s0 || grp_tm || grp_dup)) *band_tie = 1;
+					have_act = 1; act_x = a[j].x; grp_m = max_f; grp_s0 = n_skip == 0; grp_loud = 0; grp_tm = 0; grp_dup = 0; grp_top = INT32_MIN;
+				}
+				if (!(sc <= grp_m && t[j] != i)) {
+					++grp_loud;
+					if (t[j] == i) grp_tm = 1;
+					if (sc > grp_top) grp_top = sc, grp_dup = 0; else if (sc == grp_top) grp_dup = 1;
+				}
 			}
 			if (sc > max_f) {
 				max_f = sc, max_j = j;
 				if (n_skip > 0) --n_skip;
 			} else if (t[j] == i) {
 				if (++n_skip > max_skip) {
-					if (band_tie) {                         /* the scan ends at j: in another order a tie partner of j would have been scanned in its place */
+					if (band_tie) {                         /* the scan ends at j (a loud member that counts as a skip): in another order a tie partner of j would have been scanned before it */
 						int64_t jj;
 						for (jj = j - 1; jj >= st && a[jj].x == a[j].x; --jj) {
-							int64_t dr2 = ri - a[jj].x; int32_t dq2 = qi - (int32_t)a[jj].y, dd2;
+							int64_t dr2 = ri - a[jj].x; int32_t dq2 = qi - (int32_t)a[jj].y, dd2, sc2, md2;
 							if (dr2 == 0 || dq2 <= 0 || dq2 > max_dist_y) continue;
 							dd2 = dr2 > dq2 ? dr2 - dq2 : dq2 - dr2;
-							if (dd2 <= bw) *band_tie = 1;
+							if (dd2 > bw) continue;
+							md2 = dq2 < dr2 ? dq2 : dr2;
+							sc2 = (md2 > q_span ? q_span : md2) - ((int)(dd2 * .01 * avg_qspan) + ((dd2 ? ilog2_32(dd2) : 0) >> 1)) + f[jj];
+							if (!(sc2 <= grp_m && t[jj] != i)) *band_tie = 1;      /* a second loud member, and one of the group counts as a skip */
 						}
 					}
 					break;
@@ -546,6 +563,7 @@ static void chain_dp_range_s(const lqo_params *P, float avg_qspan, const lqo_mm1
 			}
 			if (p[j] >= 0) t[p[j]] = i;
 		}
+		if (band_tie && have_act && grp_loud >= 2 && (!grp_s0 || grp_tm || grp_dup)) *band_tie = 1;   /* the scan's last group */
 		f[i] = max_f, p[i] = max_j;
 		v[i] = max_j >= 0 && v[max_j] > max_f ? v[max_j] : max_f;
 	}
@@ -616,6 +634,30 @@ static int run_ties_close(const lqo_params *P, const lqo_mm128 *a, int64_t n)
 		}
 	}
 	return 0;
+}
+/* An upper bound, whatever the order of equal-x anchors, of the score of any chain inside a[0..n): the heaviest path (by
+ * spans) through the pairs that can be chained at all (chain.c:52-56).  A chain's score is at most the sum of its anchors'
+ * spans (chain.c:57-67), so a run whose bound is below min_sc yields nothing in any order. */
+static int run_score_bound(const lqo_params *P, const lqo_mm128 *a, int64_t n)
+{
+	int32_t *w = (int32_t*)malloc(n * 4), best = 0;
+	int64_t i, j, st = 0;
+	for (i = 0; i < n; ++i) {
+		int32_t qi = (int32_t)a[i].y, m = 0;
+		while (st < i && a[i].x - a[st].x > (uint64_t)P->max_gap) ++st;
+		for (j = i - 1; j >= st; --j) {
+			int64_t dr = a[i].x - a[j].x;
+			int32_t dq = qi - (int32_t)a[j].y, dd;
+			if (dr == 0 || dq <= 0 || dq > P->max_gap) continue;
+			dd = dr > dq ? dr - dq : dq - dr;
+			if (dd > P->bw) continue;
+			if (w[j] > m) m = w[j];
+		}
+		w[i] = m + (int32_t)(a[i].y >> 32 & 0xff);
+		if (w[i] > best) best = w[i];
+	}
+	free(w);
+	return best;
 }
 static uint64_t g_tie_stats[12];
 void lqo_tie_stats(uint64_t out[12]) { memcpy(out, g_tie_stats, sizeof(g_tie_stats)); }
@@ -974,6 +1016,7 @@ static void map_query(const lqo_params *P, const part_t *pt, int32_t mid_occ, co
 						else if (getenv("LQO_TIE_NONE")) sens = 0;
 						else sens = band;
 						if (peak && !getenv("LQO_TIE_NONE")) sens = 1;
+						if (sens && !getenv("LQO_TIE_NOBOUND") && run_score_bound(P, a2 + lo, hi - lo) < P->min_chain_score) sens = 0;   /* nothing to chain in any order */
 						if (peak) g_tie_stats[11] += 1;
 						if (sens) { g_tie_stats[5] += 1; g_tie_stats[6] += hi - lo; q_sens = 1; memcpy(a2 + lo, a + lo, (hi - lo) * sizeof(lqo_mm128)); }
 						else {
