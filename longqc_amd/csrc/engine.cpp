@@ -112,9 +112,9 @@ void Knobs::read_env()
 	filter = num("LQCOV_FILTER", 1) != 0;
 	{
 		long kc = num("LQCOV_FILTER_KEYS", (long)LQ_FT_WORDS * 16);
-		u32 v = 16; while (v * 2 <= (u32)std::min<long>(std::max<long>(kc, 16), (long)LQ_FT_WORDS * 16)) v *= 2;   // a power of two in [16, 16 * LQ_FT_WORDS]
+		u32 v = 256; while (v * 2 <= (u32)std::min<long>(std::max<long>(kc, 256), (long)LQ_FT_WORDS * 16)) v *= 2;   // a power of two in [256, 16 * LQ_FT_WORDS]
 		filt_keys = v;
-		filt_acap = (u32)std::max<long>(1, num("LQCOV_FILTER_ACAP", (long)(0.6 * v)));
+		filt_acap = (u32)std::max<long>(1, num("LQCOV_FILTER_ACAP", (long)(0.25 * v)));
 	}
 }
 
@@ -1304,14 +1304,15 @@ void lqcov_handle::map_part(Part &pt)
 			fmask.ensure(n_words * 8 + 8);
 			dzero(fmask.p, n_words * 8, stream); dzero(cntf.p, n_qm * 4, stream);
 			FiltParams fp;
-			const u32 n_min = run_n_min();
-			fp.thr = K.filter && n_min >= 2 ? std::min<u32>(n_min, 3) : 0;
+			fp.n_min = K.filter ? run_n_min() : 0;
 			fp.n_targets = std::max<u32>(pt.rs.n, 1); fp.keys_cap = K.filt_keys; fp.a_cap = std::max<u32>(K.filt_acap, 1);
+			fp.dshift = 1; while (fp.dshift < 30 && (1u << fp.dshift) <= (u32)std::max<i32>(P.bw, 0)) ++fp.dshift;   // bins wider than the band (chain.c:55)
+			fm_cursor.ensure(n_qm * 4 + 4);
 			{
-				StageTimer t(this, "k_seed_count", nA_total * 8 + nA_total / 8);   // (algorithmic: every occurrence list once, a bit per hit out; the kernel reads the lists twice per slice)
-				LQ_LAUNCH(k_seed_count, std::min<u32>(n_q, 1u << 20), LQ_FC_THREADS, stream, q.my.as<u64>(), q.moff.as<u64>(), n_q, pt.pos.as<u64>(), hit_start.as<u64>(), hit_n.as<u32>(), keep.as<u32>(), aq_off.as<u64>(),
+				StageTimer t(this, "k_seed_count", nA_total * 8 + nA_total / 8);   // (algorithmic: every occurrence list once, a bit per hit out; the kernel reads the lists twice)
+				LQ_LAUNCH(k_seed_count, std::min<u32>(n_q, 1u << 20), LQ_FC_THREADS, stream, q.mx.as<u64>(), q.my.as<u64>(), q.moff.as<u64>(), n_q, q.d_len.as<u32>(), pt.pos.as<u64>(), hit_start.as<u64>(), hit_n.as<u32>(), keep.as<u32>(), aq_off.as<u64>(),
 				          (int)P.no_self, pt.self_off.as<u32>(), pt.self_rid.as<u32>(), AvaView{P.ava ? pt.t_rank.as<u32>() : nullptr, P.ava ? pt.q_lo.as<u32>() : nullptr}, fp,
-				          fm_off.as<u64>(), fmask.as<u64>(), cntf.as<u32>());
+				          fm_off.as<u64>(), fmask.as<u8>(), cntf.as<u32>(), fm_cursor.as<u32>());
 				check_launch();
 			}
 			prim.exclusive_scan_u32_u64(cntf.as<u32>(), af_off.as<u64>(), n_qm);

@@ -50,7 +50,7 @@ struct Knobs {
 	bool ties_klib = false;               // LQCOV_TIES=klib (or LQCOV_SORT=klib): klib's order of equal-x anchors everywhere, every seed hit written and sorted (rounds 1-3); default: only where it can be observed (map_batch)
 	bool filter = true;                   // LQCOV_FILTER=0: the first pass writes every seed hit (no counting filter)
 	u32 filt_keys = 1u << 19;             // LQCOV_FILTER_KEYS: counters of k_seed_count's table in use (tests shrink it: slices and aliasing on small inputs)
-	u32 filt_acap = 314572;               // LQCOV_FILTER_ACAP: anchors per slice aimed at (0.6 per counter)
+	u32 filt_acap = 131072;               // LQCOV_FILTER_ACAP: hits per slice of targets aimed at (0.25 per counter)
 	void read_env();
 };
 
@@ -148,6 +148,7 @@ struct lqcov_handle {
 	DBuf dup, qdirty, dup_table;          // k_dup_mark: minimizers / queries whose anchors can repeat an x (per part)
 	DBuf qklib;                           // queries that go through klib's passes (per part): marked and more than 64 anchors
 	DBuf qzero;                           // zeros: nobody goes through klib's passes (first pass of map_batch)
+	DBuf fm_cursor;                       // k_seed_count: where every minimizer's occurrence list goes on in the next slice of targets
 	DBuf fm_words, fm_off, fmask, cntf, af_off, aqf_off;   // k_seed_count: survivor bitmap (words per minimizer, offsets, bits), survivors per minimizer, their offsets per minimizer / per query
 	u64 last_n_written = 0;               // anchors the first pass wrote against the last part
 	std::atomic<u64> stat_sens_runs{0}, stat_p2_queries{0}, stat_p2_anchors{0};   // second pass, since reset(): runs, queries, anchors

@@ -257,23 +257,31 @@ k_seed_emit(const u64 *qx, const u64 *qy, const u32 *owner, const u64 *qmoff, u6
 }
 
 // ---- anchors that cannot be part of a chain are never written --------------------------------------------------------------
-// mm_chain_dp never lets anchors of different (strand, rid) interact (kernels_chain.hpp), and a run of fewer than
-// n_min = max(min_cnt, ceil(min_sc / span_max)) anchors cannot hold a chain (chain.c:57-67,119-121; k_run_list drops such runs
-// anyway).  Against half a million targets four fifths of a query's seed hits are lone chance hits: they used to be written,
-// sorted and read again only to be dropped.  Here they are counted first: one block per query holds a table of 2-bit
-// saturating counters in LDS, indexed by (rid, relative strand) -- directly while 2 * targets <= the table, else over slices
-// of the rid range (at most as many as make the mapping direct, and only as many as keep the expected load of a counter
-// below ~0.6: a query with few anchors needs no slices, aliasing then only lets a few more anchors through) -- and a hit
-// survives when its counter reached thr = min(n_min, 3).  False positives are harmless (the run list decides exactly);
-// there are no false negatives: every anchor of a run of >= n_min anchors finds its counter saturated or >= thr.
-// Survivors are recorded as one bit per hit (a 64-bit word per 64 hits of a minimizer: plain stores by lane 0 of the wave
-// that owns the minimizer in every slice) and counted per minimizer; k_seed_emit_f then writes them, dense, in (query,
-// minimizer, hit) order.  avg_qspan, mini_pos and the lq_cnt_match prologue keep using the unfiltered totals (chain.c:37-38,
-// lqmap.c:174).  Exact only together with a sort that does not need klib's walk over the *whole* query: map_batch's first pass.
+// Against a 4-Gbase part a 10-kb query collects about a million seed hits, four fifths of them lone chance hits; they used to
+// be written, sorted and read again only to be dropped.  Which hits can matter is decided first, exactly:
+//   * mm_chain_dp never lets anchors of different (strand, rid) interact (kernels_chain.hpp), and inside one (strand, rid) run
+//     anchor j is looked at by the scan of anchor i only when 0 < dq, dr <= max_gap and |dr - dq| <= bw (the `continue`s of
+//     chain.c:52-56 come before any state changes).  dr - dq is the difference of the two anchors' diagonals d = x - y, so two
+//     anchors that can interact lie at most bw apart in d, and the anchors of one connected component of "can interact" fill a
+//     gap-free stretch of diagonal bins of width D > bw.
+//   * a chain lives inside one component, needs min_cnt anchors and scores at most the sum of their spans (chain.c:57-67,
+//     119-121): a component of fewer than n_min = max(min_cnt, ceil(min_sc / span_max)) anchors yields nothing and, being
+//     invisible to the scans of every other component, can be left out without changing f, p, v of anything else.
+//   So a hit survives iff the gap-free stretch of non-empty bins around its bin (strand, rid, d / D) holds at least n_min hits
+//   (a stretch of n_min bins does by itself).  No false negatives; false positives (counters saturate at 3: a saturated bin is
+//   taken as enough; bins alias when the diagonals of a pair outnumber the bins it gets) only cost what every hit used to cost.
+// One block per query holds the 2-bit counters in 128 KiB of LDS and takes the rid range in slices of R targets x 2 strands x
+// NB bins (NB >= 8 a power of two; slices so that a counter expects well under one hit).  Every occurrence list is ascending
+// in rid (index.c:188), so a slice's hits are one contiguous piece of every list: a cursor per minimizer (global scratch)
+// walks forward from slice to slice, and every hit is read twice in all -- once to count, once to decide -- eight lanes to a
+// minimizer, 64 bytes a step.  Survivors are recorded as one bit per hit (a byte per step, written by the one group that owns
+// the minimizer) and counted per minimizer; k_seed_emit_f then writes them, dense, in (query, minimizer, hit) order.
+// avg_qspan, mini_pos and the lq_cnt_match prologue keep using the unfiltered totals (chain.c:37-38, lqmap.c:174).  Exact only
+// together with a sort that does not need klib's walk over the *whole* query: map_batch's first pass.
 #define LQ_FT_WORDS 32768u                  // 128 KiB of LDS: 524288 two-bit counters
 #define LQ_FC_THREADS 1024
-#define LQ_FC_UNROLL 4
-struct FiltParams { u32 thr, n_targets, keys_cap /* counters in use: a power of two <= 16 * LQ_FT_WORDS (tests shrink it) */, a_cap /* anchors per slice aimed at */; };
+#define LQ_FC_GROUP 8                        // lanes to a minimizer: one 64-byte line of its occurrence list a step
+struct FiltParams { u32 n_min /* 0 or 1: no filter */, n_targets, keys_cap /* counters in use: a power of two in [256, 16 * LQ_FT_WORDS] (tests shrink it) */, a_cap /* hits per slice aimed at */, dshift /* log2 D, D > bw */; };
 
 __device__ __forceinline__ u32 lq_ft_get(const u32 *tab, u32 key) { return tab[key >> 4] >> ((key & 15) << 1) & 3u; }
 __device__ __forceinline__ void lq_ft_inc(u32 *tab, u32 key)
@@ -287,83 +295,121 @@ __device__ __forceinline__ void lq_ft_inc(u32 *tab, u32 key)
 		old = seen;
 	}
 }
+// does the gap-free stretch of non-empty bins around bin b of the NB bins at `base` hold n_min hits?  (bins wrap: aliasing only adds)
+__device__ __forceinline__ bool lq_ft_alive(const u32 *tab, u32 base, u32 b, u32 nb_mask, u32 n_min)
+{
+	const u32 own = lq_ft_get(tab, base + b);
+	if (own >= 3u || own >= n_min) return true;
+	u32 side = n_min - 1;                                      // bins to look at on either side
+	if (side > (nb_mask >> 1)) return true;                    // (a pair has too few bins to tell: keep)
+	u32 tot = own;
+	for (u32 k = 1; k <= side; ++k) { const u32 c = lq_ft_get(tab, base + ((b + k) & nb_mask)); if (c == 0) break; if (c >= 3u) return true; tot += c; if (k == side) return true; }
+	for (u32 k = 1; k <= side; ++k) { const u32 c = lq_ft_get(tab, base + ((b - k) & nb_mask)); if (c == 0) break; if (c >= 3u) return true; tot += c; if (k == side) return true; }
+	return tot >= n_min;
+}
 
 __global__ void __launch_bounds__(LQ_FC_THREADS)
-k_seed_count(const u64 *qy, const u64 *qmoff, u32 n_q, const u64 *pos, const u64 *hit_start, const u32 *hit_n, const u32 *keep, const u64 *aq_off,
+k_seed_count(const u64 *qx, const u64 *qy, const u64 *qmoff, u32 n_q, const u32 *qlen, const u64 *pos, const u64 *hit_start, const u32 *hit_n, const u32 *keep, const u64 *aq_off,
              int no_self, const u32 *self_off, const u32 *self_rid, AvaView ava, FiltParams fp,
-             const u64 *fm_off, u64 *fmask, u32 *cntf)
+             const u64 *fm_off, u8 *fmask, u32 *cntf, u32 *cursor)
 {
 	__shared__ u32 tab[LQ_FT_WORDS];
-	const u32 t = threadIdx.x, lane = t & 63, wv = t >> 6, nw = blockDim.x >> 6;
+	const u32 t = threadIdx.x, lane = t & 63, gl = t & (LQ_FC_GROUP - 1), gsh = lane & ~(u32)(LQ_FC_GROUP - 1);
+	const u32 grp = t / LQ_FC_GROUP, n_grp = blockDim.x / LQ_FC_GROUP;
+	const bool filt = fp.n_min >= 2;
 	for (u32 q = blockIdx.x; q < n_q; q += gridDim.x) {
 		const u64 j0 = qmoff[q], j1 = qmoff[q + 1];
 		const u64 Aq = aq_off[q + 1] - aq_off[q];
 		if (Aq == 0) continue;                                    // (block-uniform)
-		u32 n_sl = 1;
-		if (fp.thr) {
-			const u64 by_keys = (2ULL * fp.n_targets + fp.keys_cap - 1) / fp.keys_cap, by_load = (Aq + fp.a_cap - 1) / fp.a_cap;
-			n_sl = (u32)(by_keys < by_load ? by_keys : by_load);
-			if (n_sl == 0) n_sl = 1;
+		// slices: R targets each, BPP = 2 * NB bins per target
+		u32 n_sl = 1, R = fp.n_targets, bpp_log = 0;
+		if (filt) {
+			const u64 by_bins = (16ULL * fp.n_targets + fp.keys_cap - 1) / fp.keys_cap, by_load = (Aq + fp.a_cap - 1) / fp.a_cap;
+			u64 s = by_bins > by_load ? by_bins : by_load;
+			if (s > fp.n_targets) s = fp.n_targets;
+			if (s == 0) s = 1;
+			n_sl = (u32)s;
+			R = (fp.n_targets + n_sl - 1) / n_sl;
+			while (bpp_log < 12 && ((u64)R << (bpp_log + 1)) <= fp.keys_cap) ++bpp_log;
+			n_sl = (fp.n_targets + R - 1) / R;
 		}
-		const u32 R = (fp.n_targets + n_sl - 1) / n_sl;          // rids per slice
+		const u32 nb_mask = filt ? (1u << (bpp_log - 1)) - 1 : 0;      // (by_bins makes bpp_log >= 4: at least 8 bins per strand)
 		const bool self_q = no_self && self_off[q] != self_off[q + 1];
 		const u32 qlo = ava.q_lo ? ava.q_lo[q] : 0;
-		const u32 kmask = fp.keys_cap - 1;
+		const i32 ql = (i32)qlen[q];
+		for (u64 j = j0 + t; j < j1; j += blockDim.x) cursor[j] = 0;
+		__syncthreads();
 		for (u32 s = 0; s < n_sl; ++s) {
-			const u32 r_lo = s * R;
-			if (fp.thr) {
-				for (u32 i = t; i < (fp.keys_cap >> 4); i += blockDim.x) tab[i] = 0;
+			const u32 r_lo = s * R, r_hi = s + 1 == n_sl ? 0xffffffffu : r_lo + R;
+			if (filt) {
+				const u32 words = (u32)((((u64)R << bpp_log) + 15) >> 4);
+				for (u32 i = t; i < words; i += blockDim.x) tab[i] = 0;
 				__syncthreads();
-				// sweep 1: count the slice's hits per (rid, relative strand).  LQ_FC_UNROLL minimizers per wave and turn: their loads are in flight together
-				for (u64 jb = j0 + (u64)wv * LQ_FC_UNROLL; jb < j1; jb += (u64)nw * LQ_FC_UNROLL) {
-					u32 n[LQ_FC_UNROLL], qs[LQ_FC_UNROLL]; u64 st[LQ_FC_UNROLL]; u32 nmax = 0;
-#pragma unroll
-					for (int u = 0; u < LQ_FC_UNROLL; ++u) {
-						const u64 j = jb + u;
-						n[u] = (j < j1 && keep[j]) ? hit_n[j] : 0; st[u] = n[u] ? hit_start[j] : 0; qs[u] = n[u] ? ((u32)qy[j] & 1u) : 0;
-						nmax = n[u] > nmax ? n[u] : nmax;
-					}
-					for (u32 t0 = 0; t0 < nmax; t0 += 64) {
-						u64 r[LQ_FC_UNROLL];
-#pragma unroll
-						for (int u = 0; u < LQ_FC_UNROLL; ++u) r[u] = t0 + lane < n[u] ? pos[st[u] + t0 + lane] : ~0ULL;
-#pragma unroll
-						for (int u = 0; u < LQ_FC_UNROLL; ++u) {
-							const u32 rid = (u32)(r[u] >> 32);
-							if (t0 + lane < n[u] && rid - r_lo < R) lq_ft_inc(tab, (((rid - r_lo) << 1) | (((u32)r[u] & 1u) ^ qs[u])) & kmask);
+				// sweep 1: the slice's piece of every list, counted per (rid, relative strand, diagonal bin)
+				for (u64 jb = j0; jb < j1; jb += n_grp) {             // (the same trips for every thread of the block: the ballots below are wave-uniform)
+					const u64 j = jb + grp;
+					const bool act = j < j1 && keep[j];               // (uniform over the group)
+					u32 n = 0, qp = 0, span = 0, c0 = 0; u64 st = 0;
+					if (act) { n = hit_n[j]; qp = (u32)qy[j]; span = (u32)(qx[j] & 0xff); st = hit_start[j]; c0 = cursor[j]; }
+					const i32 y_same = (i32)(qp >> 1), y_rev = ql - (i32)((qp >> 1) + 1 - span) - 1;
+					u32 c = c0 & ~(u32)(LQ_FC_GROUP - 1);             // steps are line-aligned in the list; hits before the cursor belong to earlier slices
+					bool more = act && c < n;
+					while (__ballot(more)) {                          // (every lane of the wave goes round until every group is done)
+						const u32 tt = c + gl;
+						u64 r = ~0ULL;
+						if (more && tt < n) r = pos[st + tt];
+						const u32 rid = (u32)(r >> 32);
+						const bool in = more && tt < n && tt >= c0 && rid < r_hi;
+						if (in) {
+							const u32 rs = ((u32)r & 1u) ^ (qp & 1u);
+							const i32 d = (i32)((u32)r >> 1) - (rs ? y_rev : y_same) + ql + 256;
+							lq_ft_inc(tab, ((rid - r_lo) << bpp_log) + (rs ? nb_mask + 1 : 0) + (((u32)d >> fp.dshift) & nb_mask));
 						}
+						// the group goes on while its last hit of this step is still inside the slice
+						const u64 past = __ballot(more && (tt >= n || rid >= r_hi));
+						if (past >> gsh & 0xffu) more = false;
+						c += LQ_FC_GROUP;
 					}
 				}
 				__syncthreads();
 			}
-			// sweep 2: the slice's hits whose counter reached thr (all of them without a filter), minus the self diagonal and -X
-			for (u64 jb = j0 + (u64)wv * LQ_FC_UNROLL; jb < j1; jb += (u64)nw * LQ_FC_UNROLL) {
-				u32 n[LQ_FC_UNROLL], qp[LQ_FC_UNROLL], c[LQ_FC_UNROLL]; u64 st[LQ_FC_UNROLL]; u32 nmax = 0;
-#pragma unroll
-				for (int u = 0; u < LQ_FC_UNROLL; ++u) {
-					const u64 j = jb + u;
-					n[u] = (j < j1 && keep[j]) ? hit_n[j] : 0; st[u] = n[u] ? hit_start[j] : 0; qp[u] = n[u] ? (u32)qy[j] : 0; c[u] = 0;
-					nmax = n[u] > nmax ? n[u] : nmax;
-				}
-				for (u32 t0 = 0; t0 < nmax; t0 += 64) {
-					u64 r[LQ_FC_UNROLL];
-#pragma unroll
-					for (int u = 0; u < LQ_FC_UNROLL; ++u) r[u] = t0 + lane < n[u] ? pos[st[u] + t0 + lane] : ~0ULL;
-#pragma unroll
-					for (int u = 0; u < LQ_FC_UNROLL; ++u) {
-						const u32 rid = (u32)(r[u] >> 32), rpos = (u32)r[u] >> 1;
-						bool pass = t0 + lane < n[u] && rid - r_lo < R;
-						if (pass && fp.thr) pass = lq_ft_get(tab, (((rid - r_lo) << 1) | (((u32)r[u] & 1u) ^ (qp[u] & 1u))) & kmask) >= fp.thr;
-						if (pass && self_q && rpos == (qp[u] >> 1) && lq_is_self(self_off, self_rid, q, rid)) pass = false;   // lqmap.c:180-186
-						if (pass && ava.t_rank && ava.t_rank[rid] < qlo) pass = false;                                            // lqmap.c:187
-						const u64 sv = __ballot(pass);
-						if (lane == 0 && sv) { fmask[fm_off[jb + u] + (t0 >> 6)] |= sv; c[u] += (u32)__popcll(sv); }
+			// sweep 2: which of them survive (all of them without a filter), minus the self diagonal and -X; the cursor moves on
+			for (u64 jb = j0; jb < j1; jb += n_grp) {
+				const u64 j = jb + grp;
+				const bool act = j < j1 && keep[j];
+				u32 n = 0, qp = 0, span = 0, c0 = 0; u64 st = 0;
+				u8 *fm = fmask;
+				if (act) { n = hit_n[j]; qp = (u32)qy[j]; span = (u32)(qx[j] & 0xff); st = hit_start[j]; c0 = cursor[j]; fm = fmask + fm_off[j] * 8; }
+				const i32 y_same = (i32)(qp >> 1), y_rev = ql - (i32)((qp >> 1) + 1 - span) - 1;
+				u32 c = c0 & ~(u32)(LQ_FC_GROUP - 1), cnt = 0, next = n;
+				bool more = act && c < n;
+				while (__ballot(more)) {
+					const u32 tt = c + gl;
+					u64 r = ~0ULL;
+					if (more && tt < n) r = pos[st + tt];
+					const u32 rid = (u32)(r >> 32), rpos = (u32)r >> 1;
+					const bool in = more && tt < n && tt >= c0 && rid < r_hi;
+					bool pass = in;
+					if (pass && filt) {
+						const u32 rs = ((u32)r & 1u) ^ (qp & 1u);
+						const i32 d = (i32)rpos - (rs ? y_rev : y_same) + ql + 256;
+						pass = lq_ft_alive(tab, ((rid - r_lo) << bpp_log) + (rs ? nb_mask + 1 : 0), ((u32)d >> fp.dshift) & nb_mask, nb_mask, fp.n_min);
 					}
+					if (pass && self_q && rpos == (qp >> 1) && lq_is_self(self_off, self_rid, q, rid)) pass = false;   // lqmap.c:180-186
+					if (pass && ava.t_rank && ava.t_rank[rid] < qlo) pass = false;                                      // lqmap.c:187
+					const u32 bits = (u32)(__ballot(pass) >> gsh) & 0xffu;
+					const u64 pastm = __ballot(more && tt < n && rid >= r_hi);
+					const u32 pastb = (u32)(pastm >> gsh) & 0xffu;
+					if (gl == 0 && more) {
+						if (bits) { fm[c >> 3] |= (u8)bits; cnt += (u32)__popc(bits); }
+						if (pastb) next = c + (u32)__ffs(pastb) - 1;          // the first hit of a later slice
+					}
+					if (more && (pastb || c + LQ_FC_GROUP >= n)) more = false;
+					c += LQ_FC_GROUP;
 				}
-#pragma unroll
-				for (int u = 0; u < LQ_FC_UNROLL; ++u) if (lane == 0 && c[u]) cntf[jb + u] += c[u];
+				if (gl == 0 && act) { if (cnt) cntf[j] += cnt; cursor[j] = next; }
 			}
-			__syncthreads();                                         // (the next slice clears the table)
+			__syncthreads();                                         // (the next slice clears the table; cursors are read by their own group only)
 		}
 	}
 }
