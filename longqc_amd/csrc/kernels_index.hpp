@@ -281,6 +281,7 @@ k_seed_emit(const u64 *qx, const u64 *qy, const u32 *owner, const u64 *qmoff, u6
 #define LQ_FT_WORDS 32768u                  // 128 KiB of LDS: 524288 two-bit counters
 #define LQ_FC_THREADS 1024
 #define LQ_FC_GROUP 8                        // lanes to a minimizer: one 64-byte line of its occurrence list a step
+#define LQ_FC_UNROLL 4                       // minimizers a group walks at a time
 struct FiltParams { u32 n_min /* 0 or 1: no filter */, n_targets, keys_cap /* counters in use: a power of two in [256, 16 * LQ_FT_WORDS] (tests shrink it) */, a_cap /* hits per slice aimed at */, dshift /* log2 D, D > bw */; };
 
 __device__ __forceinline__ u32 lq_ft_get(const u32 *tab, u32 key) { return tab[key >> 4] >> ((key & 15) << 1) & 3u; }
@@ -345,69 +346,91 @@ k_seed_count(const u64 *qx, const u64 *qy, const u64 *qmoff, u32 n_q, const u32 
 				const u32 words = (u32)((((u64)R << bpp_log) + 15) >> 4);
 				for (u32 i = t; i < words; i += blockDim.x) tab[i] = 0;
 				__syncthreads();
-				// sweep 1: the slice's piece of every list, counted per (rid, relative strand, diagonal bin)
-				for (u64 jb = j0; jb < j1; jb += n_grp) {             // (the same trips for every thread of the block: the ballots below are wave-uniform)
-					const u64 j = jb + grp;
-					const bool act = j < j1 && keep[j];               // (uniform over the group)
-					u32 n = 0, qp = 0, span = 0, c0 = 0; u64 st = 0;
-					if (act) { n = hit_n[j]; qp = (u32)qy[j]; span = (u32)(qx[j] & 0xff); st = hit_start[j]; c0 = cursor[j]; }
-					const i32 y_same = (i32)(qp >> 1), y_rev = ql - (i32)((qp >> 1) + 1 - span) - 1;
-					u32 c = c0 & ~(u32)(LQ_FC_GROUP - 1);             // steps are line-aligned in the list; hits before the cursor belong to earlier slices
-					bool more = act && c < n;
-					while (__ballot(more)) {                          // (every lane of the wave goes round until every group is done)
-						const u32 tt = c + gl;
-						u64 r = ~0ULL;
-						if (more && tt < n) r = pos[st + tt];
-						const u32 rid = (u32)(r >> 32);
-						const bool in = more && tt < n && tt >= c0 && rid < r_hi;
-						if (in) {
-							const u32 rs = ((u32)r & 1u) ^ (qp & 1u);
-							const i32 d = (i32)((u32)r >> 1) - (rs ? y_rev : y_same) + ql + 256;
-							lq_ft_inc(tab, ((rid - r_lo) << bpp_log) + (rs ? nb_mask + 1 : 0) + (((u32)d >> fp.dshift) & nb_mask));
+				// sweep 1: the slice's piece of every list, counted per (rid, relative strand, diagonal bin).  LQ_FC_UNROLL minimizers per
+				// group and turn: their loads are in flight together (a group's walk along one list is a chain of dependent loads)
+				for (u64 jb = j0; jb < j1; jb += (u64)n_grp * LQ_FC_UNROLL) {   // (the same trips for every thread of the block: the ballots below are wave-uniform)
+					u32 n[LQ_FC_UNROLL], qp[LQ_FC_UNROLL], c0[LQ_FC_UNROLL], c[LQ_FC_UNROLL]; u64 st[LQ_FC_UNROLL]; i32 ys[LQ_FC_UNROLL], yr[LQ_FC_UNROLL];
+					bool more[LQ_FC_UNROLL], any = false;
+#pragma unroll
+					for (int u = 0; u < LQ_FC_UNROLL; ++u) {
+						const u64 j = jb + (u64)u * n_grp + grp;
+						const bool act = j < j1 && keep[j];               // (uniform over the group)
+						n[u] = 0; qp[u] = 0; c0[u] = 0; st[u] = 0; u32 span = 0;
+						if (act) { n[u] = hit_n[j]; qp[u] = (u32)qy[j]; span = (u32)(qx[j] & 0xff); st[u] = hit_start[j]; c0[u] = cursor[j]; }
+						ys[u] = (i32)(qp[u] >> 1); yr[u] = ql - (i32)((qp[u] >> 1) + 1 - span) - 1;
+						c[u] = c0[u] & ~(u32)(LQ_FC_GROUP - 1);           // steps are line-aligned in the list; hits before the cursor belong to earlier slices
+						more[u] = act && c[u] < n[u];
+						any = any || more[u];
+					}
+					while (__ballot(any)) {                           // (every lane of the wave goes round until every group is done)
+						u64 r[LQ_FC_UNROLL];
+#pragma unroll
+						for (int u = 0; u < LQ_FC_UNROLL; ++u) r[u] = more[u] && c[u] + gl < n[u] ? pos[st[u] + c[u] + gl] : ~0ULL;
+						any = false;
+#pragma unroll
+						for (int u = 0; u < LQ_FC_UNROLL; ++u) {
+							const u32 tt = c[u] + gl, rid = (u32)(r[u] >> 32);
+							if (more[u] && tt < n[u] && tt >= c0[u] && rid < r_hi) {
+								const u32 rs = ((u32)r[u] & 1u) ^ (qp[u] & 1u);
+								const i32 d = (i32)((u32)r[u] >> 1) - (rs ? yr[u] : ys[u]) + ql + 256;
+								lq_ft_inc(tab, ((rid - r_lo) << bpp_log) + (rs ? nb_mask + 1 : 0) + (((u32)d >> fp.dshift) & nb_mask));
+							}
+							// the group goes on while its last hit of this step is still inside the slice
+							const u64 past = __ballot(more[u] && (tt >= n[u] || rid >= r_hi));
+							if (past >> gsh & 0xffu) more[u] = false;
+							c[u] += LQ_FC_GROUP;
+							any = any || more[u];
 						}
-						// the group goes on while its last hit of this step is still inside the slice
-						const u64 past = __ballot(more && (tt >= n || rid >= r_hi));
-						if (past >> gsh & 0xffu) more = false;
-						c += LQ_FC_GROUP;
 					}
 				}
 				__syncthreads();
 			}
 			// sweep 2: which of them survive (all of them without a filter), minus the self diagonal and -X; the cursor moves on
-			for (u64 jb = j0; jb < j1; jb += n_grp) {
-				const u64 j = jb + grp;
-				const bool act = j < j1 && keep[j];
-				u32 n = 0, qp = 0, span = 0, c0 = 0; u64 st = 0;
-				u8 *fm = fmask;
-				if (act) { n = hit_n[j]; qp = (u32)qy[j]; span = (u32)(qx[j] & 0xff); st = hit_start[j]; c0 = cursor[j]; fm = fmask + fm_off[j] * 8; }
-				const i32 y_same = (i32)(qp >> 1), y_rev = ql - (i32)((qp >> 1) + 1 - span) - 1;
-				u32 c = c0 & ~(u32)(LQ_FC_GROUP - 1), cnt = 0, next = n;
-				bool more = act && c < n;
-				while (__ballot(more)) {
-					const u32 tt = c + gl;
-					u64 r = ~0ULL;
-					if (more && tt < n) r = pos[st + tt];
-					const u32 rid = (u32)(r >> 32), rpos = (u32)r >> 1;
-					const bool in = more && tt < n && tt >= c0 && rid < r_hi;
-					bool pass = in;
-					if (pass && filt) {
-						const u32 rs = ((u32)r & 1u) ^ (qp & 1u);
-						const i32 d = (i32)rpos - (rs ? y_rev : y_same) + ql + 256;
-						pass = lq_ft_alive(tab, ((rid - r_lo) << bpp_log) + (rs ? nb_mask + 1 : 0), ((u32)d >> fp.dshift) & nb_mask, nb_mask, fp.n_min);
-					}
-					if (pass && self_q && rpos == (qp >> 1) && lq_is_self(self_off, self_rid, q, rid)) pass = false;   // lqmap.c:180-186
-					if (pass && ava.t_rank && ava.t_rank[rid] < qlo) pass = false;                                      // lqmap.c:187
-					const u32 bits = (u32)(__ballot(pass) >> gsh) & 0xffu;
-					const u64 pastm = __ballot(more && tt < n && rid >= r_hi);
-					const u32 pastb = (u32)(pastm >> gsh) & 0xffu;
-					if (gl == 0 && more) {
-						if (bits) { fm[c >> 3] |= (u8)bits; cnt += (u32)__popc(bits); }
-						if (pastb) next = c + (u32)__ffs(pastb) - 1;          // the first hit of a later slice
-					}
-					if (more && (pastb || c + LQ_FC_GROUP >= n)) more = false;
-					c += LQ_FC_GROUP;
+			for (u64 jb = j0; jb < j1; jb += (u64)n_grp * LQ_FC_UNROLL) {
+				u32 n[LQ_FC_UNROLL], qp[LQ_FC_UNROLL], c0[LQ_FC_UNROLL], c[LQ_FC_UNROLL], cnt[LQ_FC_UNROLL], next[LQ_FC_UNROLL]; u64 st[LQ_FC_UNROLL]; i32 ys[LQ_FC_UNROLL], yr[LQ_FC_UNROLL];
+				u8 *fm[LQ_FC_UNROLL];
+				bool more[LQ_FC_UNROLL], actv[LQ_FC_UNROLL], any = false;
+#pragma unroll
+				for (int u = 0; u < LQ_FC_UNROLL; ++u) {
+					const u64 j = jb + (u64)u * n_grp + grp;
+					const bool act = j < j1 && keep[j];
+					n[u] = 0; qp[u] = 0; c0[u] = 0; st[u] = 0; fm[u] = fmask; u32 span = 0;
+					if (act) { n[u] = hit_n[j]; qp[u] = (u32)qy[j]; span = (u32)(qx[j] & 0xff); st[u] = hit_start[j]; c0[u] = cursor[j]; fm[u] = fmask + fm_off[j] * 8; }
+					ys[u] = (i32)(qp[u] >> 1); yr[u] = ql - (i32)((qp[u] >> 1) + 1 - span) - 1;
+					c[u] = c0[u] & ~(u32)(LQ_FC_GROUP - 1); cnt[u] = 0; next[u] = n[u];
+					actv[u] = act; more[u] = act && c[u] < n[u];
+					any = any || more[u];
 				}
-				if (gl == 0 && act) { if (cnt) cntf[j] += cnt; cursor[j] = next; }
+				while (__ballot(any)) {
+					u64 r[LQ_FC_UNROLL];
+#pragma unroll
+					for (int u = 0; u < LQ_FC_UNROLL; ++u) r[u] = more[u] && c[u] + gl < n[u] ? pos[st[u] + c[u] + gl] : ~0ULL;
+					any = false;
+#pragma unroll
+					for (int u = 0; u < LQ_FC_UNROLL; ++u) {
+						const u32 tt = c[u] + gl, rid = (u32)(r[u] >> 32), rpos = (u32)r[u] >> 1;
+						bool pass = more[u] && tt < n[u] && tt >= c0[u] && rid < r_hi;
+						if (pass && filt) {
+							const u32 rs = ((u32)r[u] & 1u) ^ (qp[u] & 1u);
+							const i32 d = (i32)rpos - (rs ? yr[u] : ys[u]) + ql + 256;
+							pass = lq_ft_alive(tab, ((rid - r_lo) << bpp_log) + (rs ? nb_mask + 1 : 0), ((u32)d >> fp.dshift) & nb_mask, nb_mask, fp.n_min);
+						}
+						if (pass && self_q && rpos == (qp[u] >> 1) && lq_is_self(self_off, self_rid, q, rid)) pass = false;   // lqmap.c:180-186
+						if (pass && ava.t_rank && ava.t_rank[rid] < qlo) pass = false;                                         // lqmap.c:187
+						const u32 bits = (u32)(__ballot(pass) >> gsh) & 0xffu;
+						const u32 pastb = (u32)(__ballot(more[u] && tt < n[u] && rid >= r_hi) >> gsh) & 0xffu;
+						if (gl == 0 && more[u]) {
+							if (bits) { fm[u][c[u] >> 3] |= (u8)bits; cnt[u] += (u32)__popc(bits); }
+							if (pastb) next[u] = c[u] + (u32)__ffs(pastb) - 1;     // the first hit of a later slice
+						}
+						if (more[u] && (pastb || c[u] + LQ_FC_GROUP >= n[u])) more[u] = false;
+						c[u] += LQ_FC_GROUP;
+						any = any || more[u];
+					}
+				}
+#pragma unroll
+				for (int u = 0; u < LQ_FC_UNROLL; ++u)
+					if (gl == 0 && actv[u]) { const u64 j = jb + (u64)u * n_grp + grp; if (cnt[u]) cntf[j] += cnt[u]; cursor[j] = next[u]; }
 			}
 			__syncthreads();                                         // (the next slice clears the table; cursors are read by their own group only)
 		}
