@@ -309,14 +309,20 @@ __device__ __forceinline__ bool lq_ft_alive(const u32 *tab, u32 base, u32 b, u32
 	return tot >= n_min;
 }
 
+struct alignas(16) FMeta { u64 st; u32 n, qp; };   // a query minimizer's occurrence list (start in pos[], length; 0: not kept) and its y (position << 1 | strand)
+
+// One block per query; a group of LQ_FC_GROUP lanes walks one list piece at a time, LQ_FC_UNROLL pieces per group in flight
+// ("workers": group x stream).  A worker takes the minimizers wid, wid + W, ... of the query and moves on to its next one as
+// soon as a piece ends -- nobody waits for the longest piece of a turn (list lengths differ by two orders of magnitude), only
+// the sweeps of a slice are separated by barriers.
 __global__ void __launch_bounds__(LQ_FC_THREADS)
-k_seed_count(const u64 *qx, const u64 *qy, const u64 *qmoff, u32 n_q, const u32 *qlen, const u64 *pos, const u64 *hit_start, const u32 *hit_n, const u32 *keep, const u64 *aq_off,
-             int no_self, const u32 *self_off, const u32 *self_rid, AvaView ava, FiltParams fp,
+k_seed_count(const FMeta *meta, const u64 *qx, const u64 *qmoff, u32 n_q, const u32 *qlen, const u64 *pos, const u64 *aq_off,
+             int no_self, const u32 *self_off, const u32 *self_rid, AvaView ava, FiltParams fp, u32 span_const /* 0: from qx (-H) */,
              const u64 *fm_off, u8 *fmask, u32 *cntf, u32 *cursor)
 {
 	__shared__ u32 tab[LQ_FT_WORDS];
 	const u32 t = threadIdx.x, lane = t & 63, gl = t & (LQ_FC_GROUP - 1), gsh = lane & ~(u32)(LQ_FC_GROUP - 1);
-	const u32 grp = t / LQ_FC_GROUP, n_grp = blockDim.x / LQ_FC_GROUP;
+	const u32 grp = t / LQ_FC_GROUP, n_grp = blockDim.x / LQ_FC_GROUP, W = n_grp * LQ_FC_UNROLL;
 	const bool filt = fp.n_min >= 2;
 	for (u32 q = blockIdx.x; q < n_q; q += gridDim.x) {
 		const u64 j0 = qmoff[q], j1 = qmoff[q + 1];
@@ -342,106 +348,83 @@ k_seed_count(const u64 *qx, const u64 *qy, const u64 *qmoff, u32 n_q, const u32 
 		__syncthreads();
 		for (u32 s = 0; s < n_sl; ++s) {
 			const u32 r_lo = s * R, r_hi = s + 1 == n_sl ? 0xffffffffu : r_lo + R;
-			if (filt) {
-				const u32 words = (u32)((((u64)R << bpp_log) + 15) >> 4);
-				for (u32 i = t; i < words; i += blockDim.x) tab[i] = 0;
-				__syncthreads();
-				// sweep 1: the slice's piece of every list, counted per (rid, relative strand, diagonal bin).  LQ_FC_UNROLL minimizers per
-				// group and turn: their loads are in flight together (a group's walk along one list is a chain of dependent loads)
-				for (u64 jb = j0; jb < j1; jb += (u64)n_grp * LQ_FC_UNROLL) {   // (the same trips for every thread of the block: the ballots below are wave-uniform)
-					u32 n[LQ_FC_UNROLL], qp[LQ_FC_UNROLL], c0[LQ_FC_UNROLL], c[LQ_FC_UNROLL]; u64 st[LQ_FC_UNROLL]; i32 ys[LQ_FC_UNROLL], yr[LQ_FC_UNROLL];
-					bool more[LQ_FC_UNROLL], any = false;
-#pragma unroll
-					for (int u = 0; u < LQ_FC_UNROLL; ++u) {
-						const u64 j = jb + (u64)u * n_grp + grp;
-						const bool act = j < j1 && keep[j];               // (uniform over the group)
-						n[u] = 0; qp[u] = 0; c0[u] = 0; st[u] = 0; u32 span = 0;
-						if (act) { n[u] = hit_n[j]; qp[u] = (u32)qy[j]; span = (u32)(qx[j] & 0xff); st[u] = hit_start[j]; c0[u] = cursor[j]; }
-						ys[u] = (i32)(qp[u] >> 1); yr[u] = ql - (i32)((qp[u] >> 1) + 1 - span) - 1;
-						c[u] = c0[u] & ~(u32)(LQ_FC_GROUP - 1);           // steps are line-aligned in the list; hits before the cursor belong to earlier slices
-						more[u] = act && c[u] < n[u];
-						any = any || more[u];
-					}
-					while (__ballot(any)) {                           // (every lane of the wave goes round until every group is done)
-						u64 r[LQ_FC_UNROLL];
-#pragma unroll
-						for (int u = 0; u < LQ_FC_UNROLL; ++u) r[u] = more[u] && c[u] + gl < n[u] ? pos[st[u] + c[u] + gl] : ~0ULL;
-						any = false;
-#pragma unroll
-						for (int u = 0; u < LQ_FC_UNROLL; ++u) {
-							const u32 tt = c[u] + gl, rid = (u32)(r[u] >> 32);
-							if (more[u] && tt < n[u] && tt >= c0[u] && rid < r_hi) {
-								const u32 rs = ((u32)r[u] & 1u) ^ (qp[u] & 1u);
-								const i32 d = (i32)((u32)r[u] >> 1) - (rs ? yr[u] : ys[u]) + ql + 256;
-								lq_ft_inc(tab, ((rid - r_lo) << bpp_log) + (rs ? nb_mask + 1 : 0) + (((u32)d >> fp.dshift) & nb_mask));
-							}
-							// the group goes on while its last hit of this step is still inside the slice
-							const u64 past = __ballot(more[u] && (tt >= n[u] || rid >= r_hi));
-							if (past >> gsh & 0xffu) more[u] = false;
-							c[u] += LQ_FC_GROUP;
-							any = any || more[u];
-						}
-					}
+			for (int sweep = filt ? 0 : 1; sweep < 2; ++sweep) {
+				// sweep 0: the slice's piece of every list, counted per (rid, relative strand, diagonal bin)
+				// sweep 1: which of them survive (all of them without a filter), minus the self diagonal and -X; the cursors move on
+				if (sweep == 0) {
+					const u32 words = (u32)((((u64)R << bpp_log) + 15) >> 4);
+					for (u32 i = t; i < words; i += blockDim.x) tab[i] = 0;
 				}
 				__syncthreads();
-			}
-			// sweep 2: which of them survive (all of them without a filter), minus the self diagonal and -X; the cursor moves on
-			for (u64 jb = j0; jb < j1; jb += (u64)n_grp * LQ_FC_UNROLL) {
-				u32 n[LQ_FC_UNROLL], qp[LQ_FC_UNROLL], c0[LQ_FC_UNROLL], c[LQ_FC_UNROLL], cnt[LQ_FC_UNROLL], next[LQ_FC_UNROLL]; u64 st[LQ_FC_UNROLL]; i32 ys[LQ_FC_UNROLL], yr[LQ_FC_UNROLL];
-				u8 *fm[LQ_FC_UNROLL];
-				bool more[LQ_FC_UNROLL], actv[LQ_FC_UNROLL], any = false;
+				u64 jn[LQ_FC_UNROLL], st[LQ_FC_UNROLL];               // next minimizer of the worker, its list
+				u32 n[LQ_FC_UNROLL], qp[LQ_FC_UNROLL], c0[LQ_FC_UNROLL], c[LQ_FC_UNROLL], cnt[LQ_FC_UNROLL]; i32 ys[LQ_FC_UNROLL], yr[LQ_FC_UNROLL];
+				bool more[LQ_FC_UNROLL], any = false;
 #pragma unroll
-				for (int u = 0; u < LQ_FC_UNROLL; ++u) {
-					const u64 j = jb + (u64)u * n_grp + grp;
-					const bool act = j < j1 && keep[j];
-					n[u] = 0; qp[u] = 0; c0[u] = 0; st[u] = 0; fm[u] = fmask; u32 span = 0;
-					if (act) { n[u] = hit_n[j]; qp[u] = (u32)qy[j]; span = (u32)(qx[j] & 0xff); st[u] = hit_start[j]; c0[u] = cursor[j]; fm[u] = fmask + fm_off[j] * 8; }
-					ys[u] = (i32)(qp[u] >> 1); yr[u] = ql - (i32)((qp[u] >> 1) + 1 - span) - 1;
-					c[u] = c0[u] & ~(u32)(LQ_FC_GROUP - 1); cnt[u] = 0; next[u] = n[u];
-					actv[u] = act; more[u] = act && c[u] < n[u];
-					any = any || more[u];
-				}
-				while (__ballot(any)) {
+				for (int u = 0; u < LQ_FC_UNROLL; ++u) { jn[u] = j0 + (u64)u * n_grp + grp; more[u] = false; n[u] = 0; qp[u] = 0; c0[u] = 0; c[u] = 0; cnt[u] = 0; st[u] = 0; ys[u] = 0; yr[u] = 0; any = any || jn[u] < j1; }
+				while (__ballot(any)) {                               // (every lane of the wave goes round until every worker of the wave is done)
 					u64 r[LQ_FC_UNROLL];
 #pragma unroll
-					for (int u = 0; u < LQ_FC_UNROLL; ++u) r[u] = more[u] && c[u] + gl < n[u] ? pos[st[u] + c[u] + gl] : ~0ULL;
+					for (int u = 0; u < LQ_FC_UNROLL; ++u) {
+						if (!more[u] && jn[u] < j1) {                     // the worker's next minimizer (uniform over the group)
+							const FMeta m = meta[jn[u]];
+							const u32 cur = cursor[jn[u]];
+							n[u] = m.n; st[u] = m.st; qp[u] = m.qp; c0[u] = cur;
+							const u32 span = span_const ? span_const : (u32)(qx[jn[u]] & 0xff);
+							ys[u] = (i32)(m.qp >> 1); yr[u] = ql - (i32)((m.qp >> 1) + 1 - span) - 1;
+							c[u] = cur & ~(u32)(LQ_FC_GROUP - 1);         // steps are line-aligned in the list; hits before the cursor belong to earlier slices
+							cnt[u] = 0;
+							more[u] = c[u] < m.n;
+							if (!more[u]) jn[u] += W;                     // nothing of it left for this slice
+						}
+						r[u] = more[u] && c[u] + gl < n[u] ? pos[st[u] + c[u] + gl] : ~0ULL;
+					}
 					any = false;
 #pragma unroll
 					for (int u = 0; u < LQ_FC_UNROLL; ++u) {
 						const u32 tt = c[u] + gl, rid = (u32)(r[u] >> 32), rpos = (u32)r[u] >> 1;
 						bool pass = more[u] && tt < n[u] && tt >= c0[u] && rid < r_hi;
+						u32 key = 0, bin = 0;
 						if (pass && filt) {
 							const u32 rs = ((u32)r[u] & 1u) ^ (qp[u] & 1u);
 							const i32 d = (i32)rpos - (rs ? yr[u] : ys[u]) + ql + 256;
-							pass = lq_ft_alive(tab, ((rid - r_lo) << bpp_log) + (rs ? nb_mask + 1 : 0), ((u32)d >> fp.dshift) & nb_mask, nb_mask, fp.n_min);
+							key = ((rid - r_lo) << bpp_log) + (rs ? nb_mask + 1 : 0); bin = ((u32)d >> fp.dshift) & nb_mask;
 						}
-						if (pass && self_q && rpos == (qp[u] >> 1) && lq_is_self(self_off, self_rid, q, rid)) pass = false;   // lqmap.c:180-186
-						if (pass && ava.t_rank && ava.t_rank[rid] < qlo) pass = false;                                         // lqmap.c:187
-						const u32 bits = (u32)(__ballot(pass) >> gsh) & 0xffu;
-						const u32 pastb = (u32)(__ballot(more[u] && tt < n[u] && rid >= r_hi) >> gsh) & 0xffu;
-						if (gl == 0 && more[u]) {
-							if (bits) { fm[u][c[u] >> 3] |= (u8)bits; cnt[u] += (u32)__popc(bits); }
-							if (pastb) next[u] = c[u] + (u32)__ffs(pastb) - 1;     // the first hit of a later slice
+						const u32 pastb = (u32)(__ballot(more[u] && tt < n[u] && rid >= r_hi) >> gsh) & 0xffu;   // hits of later slices
+						const bool ends = more[u] && (pastb || c[u] + LQ_FC_GROUP >= n[u]);
+						if (sweep == 0) {
+							if (pass) lq_ft_inc(tab, key + bin);
+						} else {
+							if (pass && filt) pass = lq_ft_alive(tab, key, bin, nb_mask, fp.n_min);
+							if (pass && self_q && rpos == (qp[u] >> 1) && lq_is_self(self_off, self_rid, q, rid)) pass = false;   // lqmap.c:180-186
+							if (pass && ava.t_rank && ava.t_rank[rid] < qlo) pass = false;                                         // lqmap.c:187
+							const u32 bits = (u32)(__ballot(pass) >> gsh) & 0xffu;
+							if (gl == 0 && more[u]) {
+								if (bits) { fmask[fm_off[jn[u]] * 8 + (c[u] >> 3)] |= (u8)bits; cnt[u] += (u32)__popc(bits); }
+								if (ends) {                                   // the piece is done: survivors of this slice, and where the next slice goes on
+									if (cnt[u]) cntf[jn[u]] += cnt[u];
+									cursor[jn[u]] = pastb ? c[u] + (u32)__ffs(pastb) - 1 : n[u];
+								}
+							}
 						}
-						if (more[u] && (pastb || c[u] + LQ_FC_GROUP >= n[u])) more[u] = false;
+						if (ends) { more[u] = false; jn[u] += W; }
 						c[u] += LQ_FC_GROUP;
-						any = any || more[u];
+						any = any || more[u] || jn[u] < j1;
 					}
 				}
-#pragma unroll
-				for (int u = 0; u < LQ_FC_UNROLL; ++u)
-					if (gl == 0 && actv[u]) { const u64 j = jb + (u64)u * n_grp + grp; if (cnt[u]) cntf[j] += cnt[u]; cursor[j] = next[u]; }
 			}
-			__syncthreads();                                         // (the next slice clears the table; cursors are read by their own group only)
+			__syncthreads();                                         // (the next slice clears the table; a cursor is read by its own group only)
 		}
 	}
 }
 
 // words of the survivor bitmap per query minimizer (scanned into fm_off)
-__global__ void k_fmask_words(const u32 *hit_n, const u32 *keep, u64 n_qm, u32 *words)
+__global__ void k_fmask_words(const u32 *hit_n, const u32 *keep, const u64 *hit_start, const u64 *qy, u64 n_qm, u32 *words, FMeta *meta)
 {
 	const u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-	if (j < n_qm) words[j] = keep[j] ? (hit_n[j] + 63) >> 6 : 0;
+	if (j >= n_qm) return;
+	words[j] = keep[j] ? (hit_n[j] + 63) >> 6 : 0;
+	FMeta m; m.st = hit_start[j]; m.n = keep[j] ? hit_n[j] : 0; m.qp = (u32)qy[j];
+	meta[j] = m;
 }
 // per query: where its surviving anchors start (af_off = exclusive scan of cntf)
 __global__ void k_query_foff(const u64 *qmoff, const u64 *af_off, u64 n_qm, u64 n_total, u32 n_q, u64 *aqf_off)
