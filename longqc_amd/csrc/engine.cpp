@@ -110,6 +110,7 @@ void Knobs::read_env()
 	ps_passes = (u32)std::min<long>(16, std::max<long>(0, num("LQCOV_PS_PASSES", 2))) & ~1u;
 	ties_klib = is("LQCOV_TIES", "klib") || all_klib;
 	filter = num("LQCOV_FILTER", 1) != 0;
+	filt_split = num("LQCOV_FILTER_SPLIT", 1) != 0;
 	{
 		long kc = num("LQCOV_FILTER_KEYS", (long)LQ_FT_WORDS * 16);
 		u32 v = 256; while (v * 2 <= (u32)std::min<long>(std::max<long>(kc, 256), (long)LQ_FT_WORDS * 16)) v *= 2;   // a power of two in [256, 16 * LQ_FT_WORDS]
@@ -1308,6 +1309,7 @@ void lqcov_handle::map_part(Part &pt)
 			fp.n_min = K.filter ? run_n_min() : 0;
 			fp.n_targets = std::max<u32>(pt.rs.n, 1); fp.keys_cap = K.filt_keys; fp.a_cap = std::max<u32>(K.filt_acap, 1);
 			fp.dshift = 1; while (fp.dshift < 30 && (1u << fp.dshift) <= (u32)std::max<i32>(P.bw, 0)) ++fp.dshift;   // bins wider than the band (chain.c:55)
+			fp.split_strands = K.filt_split ? 1 : 0;
 			fm_cursor.ensure(n_qm * 4 + 4);
 			{
 				StageTimer t(this, "k_seed_count", nA_total * 8 + nA_total / 8);   // (algorithmic: every occurrence list once, a bit per hit out; the kernel reads the lists twice)

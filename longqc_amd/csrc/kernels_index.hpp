@@ -282,7 +282,8 @@ k_seed_emit(const u64 *qx, const u64 *qy, const u32 *owner, const u64 *qmoff, u6
 #define LQ_FC_THREADS 1024
 #define LQ_FC_GROUP 8                        // lanes to a minimizer: one 64-byte line of its occurrence list a step
 #define LQ_FC_UNROLL 4                       // minimizers a group walks at a time
-struct FiltParams { u32 n_min /* 0 or 1: no filter */, n_targets, keys_cap /* counters in use: a power of two in [256, 16 * LQ_FT_WORDS] (tests shrink it) */, a_cap /* hits per slice aimed at */, dshift /* log2 D, D > bw */; };
+struct FiltParams { u32 n_min /* 0 or 1: no filter */, n_targets, keys_cap /* counters in use: a power of two in [256, 16 * LQ_FT_WORDS] (tests shrink it) */, a_cap /* hits per slice aimed at */, dshift /* log2 D, D > bw */,
+                    split_strands /* 1: a set of bins per (target, strand); 0: the two strands of a target share its bins (twice the chance hits per bin, half the slices) */; };
 
 __device__ __forceinline__ u32 lq_ft_get(const u32 *tab, u32 key) { return tab[key >> 4] >> ((key & 15) << 1) & 3u; }
 __device__ __forceinline__ void lq_ft_inc(u32 *tab, u32 key)
@@ -331,7 +332,7 @@ k_seed_count(const FMeta *meta, const u64 *qx, const u64 *qmoff, u32 n_q, const 
 		// slices: R targets each, BPP = 2 * NB bins per target
 		u32 n_sl = 1, R = fp.n_targets, bpp_log = 0;
 		if (filt) {
-			const u64 by_bins = (16ULL * fp.n_targets + fp.keys_cap - 1) / fp.keys_cap, by_load = (Aq + fp.a_cap - 1) / fp.a_cap;
+			const u64 by_bins = ((fp.split_strands ? 16ULL : 8ULL) * fp.n_targets + fp.keys_cap - 1) / fp.keys_cap, by_load = (Aq + fp.a_cap - 1) / fp.a_cap;
 			u64 s = by_bins > by_load ? by_bins : by_load;
 			if (s > fp.n_targets) s = fp.n_targets;
 			if (s == 0) s = 1;
@@ -340,7 +341,8 @@ k_seed_count(const FMeta *meta, const u64 *qx, const u64 *qmoff, u32 n_q, const 
 			while (bpp_log < 12 && ((u64)R << (bpp_log + 1)) <= fp.keys_cap) ++bpp_log;
 			n_sl = (fp.n_targets + R - 1) / R;
 		}
-		const u32 nb_mask = filt ? (1u << (bpp_log - 1)) - 1 : 0;      // (by_bins makes bpp_log >= 4: at least 8 bins per strand)
+		const u32 nb_mask = filt ? (1u << (bpp_log - (fp.split_strands ? 1 : 0))) - 1 : 0;      // (by_bins makes that at least 8 bins)
+		const u32 rs_off = fp.split_strands ? nb_mask + 1 : 0;
 		const bool self_q = no_self && self_off[q] != self_off[q + 1];
 		const u32 qlo = ava.q_lo ? ava.q_lo[q] : 0;
 		const i32 ql = (i32)qlen[q];
@@ -387,7 +389,7 @@ k_seed_count(const FMeta *meta, const u64 *qx, const u64 *qmoff, u32 n_q, const 
 						if (pass && filt) {
 							const u32 rs = ((u32)r[u] & 1u) ^ (qp[u] & 1u);
 							const i32 d = (i32)rpos - (rs ? yr[u] : ys[u]) + ql + 256;
-							key = ((rid - r_lo) << bpp_log) + (rs ? nb_mask + 1 : 0); bin = ((u32)d >> fp.dshift) & nb_mask;
+							key = ((rid - r_lo) << bpp_log) + (rs ? rs_off : 0); bin = ((u32)d >> fp.dshift) & nb_mask;
 						}
 						const u32 pastb = (u32)(__ballot(more[u] && tt < n[u] && rid >= r_hi) >> gsh) & 0xffu;   // hits of later slices
 						const bool ends = more[u] && (pastb || c[u] + LQ_FC_GROUP >= n[u]);
