@@ -1298,8 +1298,9 @@ void lqcov_handle::map_part(Part &pt)
 		u64 n_words = 0, nF = 0;
 		if (n_qm) {
 			fm_meta.ensure(n_qm * sizeof(FMeta) + 16);
-			LQ_LAUNCH(k_fmask_words, nblk(n_qm, 256), 256, stream, hit_n.as<u32>(), keep.as<u32>(), hit_start.as<u64>(), q.my.as<u64>(), n_qm, fm_words.as<u32>(), fm_meta.as<FMeta>()); check_launch();
+			LQ_LAUNCH(k_fmask_words, nblk(n_qm, 256), 256, stream, hit_n.as<u32>(), keep.as<u32>(), n_qm, fm_words.as<u32>()); check_launch();
 			prim.exclusive_scan_u32_u64(fm_words.as<u32>(), fm_off.as<u64>(), n_qm);
+			LQ_LAUNCH(k_fmeta, nblk(n_qm, 256), 256, stream, hit_n.as<u32>(), keep.as<u32>(), hit_start.as<u64>(), q.my.as<u64>(), fm_off.as<u64>(), n_qm, fm_meta.as<FMeta>()); check_launch();
 			u64 lo = 0; u32 lc = 0;
 			d2h(&lo, fm_off.as<u64>() + n_qm - 1, 1, stream); d2h(&lc, fm_words.as<u32>() + n_qm - 1, 1, stream);
 			n_words = lo + lc;
@@ -1310,12 +1311,11 @@ void lqcov_handle::map_part(Part &pt)
 			fp.n_targets = std::max<u32>(pt.rs.n, 1); fp.keys_cap = K.filt_keys; fp.a_cap = std::max<u32>(K.filt_acap, 1);
 			fp.dshift = 1; while (fp.dshift < 30 && (1u << fp.dshift) <= (u32)std::max<i32>(P.bw, 0)) ++fp.dshift;   // bins wider than the band (chain.c:55)
 			fp.split_strands = K.filt_split ? 1 : 0;
-			fm_cursor.ensure(n_qm * 4 + 4);
 			{
 				StageTimer t(this, "k_seed_count", nA_total * 8 + nA_total / 8);   // (algorithmic: every occurrence list once, a bit per hit out; the kernel reads the lists twice)
 				LQ_LAUNCH(k_seed_count, std::min<u32>(n_q, 1u << 20), LQ_FC_THREADS, stream, fm_meta.as<FMeta>(), q.mx.as<u64>(), q.moff.as<u64>(), n_q, q.d_len.as<u32>(), pt.pos.as<u64>(), aq_off.as<u64>(),
 				          (int)P.no_self, pt.self_off.as<u32>(), pt.self_rid.as<u32>(), AvaView{P.ava ? pt.t_rank.as<u32>() : nullptr, P.ava ? pt.q_lo.as<u32>() : nullptr}, fp, (u32)(P.hpc ? 0 : P.k),
-				          fm_off.as<u64>(), fmask.as<u8>(), cntf.as<u32>(), fm_cursor.as<u32>());
+				          fmask.as<u8>(), cntf.as<u32>());
 				check_launch();
 			}
 			prim.exclusive_scan_u32_u64(cntf.as<u32>(), af_off.as<u64>(), n_qm);

@@ -149,8 +149,7 @@ struct lqcov_handle {
 	DBuf dup, qdirty, dup_table;          // k_dup_mark: minimizers / queries whose anchors can repeat an x (per part)
 	DBuf qklib;                           // queries that go through klib's passes (per part): marked and more than 64 anchors
 	DBuf qzero;                           // zeros: nobody goes through klib's passes (first pass of map_batch)
-	DBuf fm_meta;                         // k_seed_count: every query minimizer's list (start, length, y) in one 16-byte record
-	DBuf fm_cursor;                       // k_seed_count: where every minimizer's occurrence list goes on in the next slice of targets
+	DBuf fm_meta;                         // k_seed_count: every query minimizer's list (start, length, y), its cursor and the place of its survivor bits in one record
 	DBuf fm_words, fm_off, fmask, cntf, af_off, aqf_off;   // k_seed_count: survivor bitmap (words per minimizer, offsets, bits), survivors per minimizer, their offsets per minimizer / per query
 	u64 last_n_written = 0;               // anchors the first pass wrote against the last part
 	std::atomic<u64> stat_sens_runs{0}, stat_p2_queries{0}, stat_p2_anchors{0};   // second pass, since reset(): runs, queries, anchors

@@ -310,26 +310,114 @@ __device__ __forceinline__ bool lq_ft_alive(const u32 *tab, u32 base, u32 b, u32
 	return tot >= n_min;
 }
 
-struct alignas(16) FMeta { u64 st; u32 n, qp; };   // a query minimizer's occurrence list (start in pos[], length; 0: not kept) and its y (position << 1 | strand)
-
-// One block per query; a group of LQ_FC_GROUP lanes walks one list piece at a time, LQ_FC_UNROLL pieces per group in flight
-// ("workers": group x stream).  A worker takes the minimizers wid, wid + W, ... of the query and moves on to its next one as
-// soon as a piece ends -- nobody waits for the longest piece of a turn (list lengths differ by two orders of magnitude), only
-// the sweeps of a slice are separated by barriers.
-__global__ void __launch_bounds__(LQ_FC_THREADS)
-k_seed_count(const FMeta *meta, const u64 *qx, const u64 *qmoff, u32 n_q, const u32 *qlen, const u64 *pos, const u64 *aq_off,
-             int no_self, const u32 *self_off, const u32 *self_rid, AvaView ava, FiltParams fp, u32 span_const /* 0: from qx (-H) */,
-             const u64 *fm_off, u8 *fmask, u32 *cntf, u32 *cursor)
+// the same for a pair with exactly 8 bins (16 bits of one table word) and n_min <= 4 -- the shape of every preset: no loops
+__device__ __forceinline__ bool lq_ft_alive8(const u32 *tab, u32 base, u32 b, u32 n_min)
 {
-	__shared__ u32 tab[LQ_FT_WORDS];
+	const u32 f = tab[base >> 4] >> ((base & 15u) << 1) & 0xffffu;
+	const u32 sh = ((b + 5u) & 7u) << 1;                       // rotate: bins b-3 .. b+3 to positions 0 .. 6
+	const u32 g = (f >> sh | f << (16u - sh)) & 0xffffu;
+	const u32 own = g >> 6 & 3u;
+	const u32 r1 = g >> 8 & 3u, r2 = r1 ? g >> 10 & 3u : 0u, r3 = r2 ? g >> 12 & 3u : 0u;
+	const u32 l1 = g >> 4 & 3u, l2 = l1 ? g >> 2 & 3u : 0u, l3 = l2 ? g & 3u : 0u;
+	const u32 side = n_min - 1u;                               // 1 .. 3
+	const u32 tot = own + r1 + l1 + (side > 1u ? r2 + l2 : 0u) + (side > 2u ? r3 + l3 : 0u);
+	const bool sat = own == 3u || r1 == 3u || l1 == 3u || (side > 1u && (r2 == 3u || l2 == 3u)) || (side > 2u && (r3 == 3u || l3 == 3u));
+	const bool reach = side == 1u ? (r1 | l1) != 0u : side == 2u ? (r2 | l2) != 0u : (r3 | l3) != 0u;   // n_min bins in a row
+	return sat || reach || tot >= n_min;
+}
+
+// a query minimizer's occurrence list (start in pos[], length; 0: not kept), its y (position << 1 | strand), where the list goes
+// on in the next slice of targets (k_seed_count's cursor), the byte its survivor bits start at
+struct alignas(16) FMeta { u64 st; u32 n, qp; u64 fm_byte; u32 cursor, pad; };
+
+// One sweep of one slice: the piece [cursor, first hit of a later slice) of every list of the query.  COUNT: the hits are
+// counted per (rid, relative strand, diagonal bin); else: which of them survive (all of them without a filter), minus the self
+// diagonal and -X, and the cursors move on.  A group of LQ_FC_GROUP lanes walks one piece at a time, LQ_FC_UNROLL pieces per
+// group in flight ("workers": group x stream).  A worker takes the minimizers wid, wid + W, ... of the query and moves on to
+// its next one as soon as a piece ends -- nobody waits for the longest piece of a turn (list lengths differ by two orders of
+// magnitude); only the sweeps are separated by barriers.
+struct FSlice { u32 r_lo, r_hi, bpp_log, nb_mask, rs_off; i32 ql; u32 q, qlo; bool filt, self_q; };
+template <bool COUNT>
+__device__ __forceinline__ void lq_seed_sweep(u32 *tab, FMeta *meta, const u64 *qx, u64 j0, u64 j1, const u64 *pos, const FSlice S, const FiltParams fp, u32 span_const,
+                                              const u32 *self_off, const u32 *self_rid, AvaView ava, u8 *fmask, u32 *cntf)
+{
 	const u32 t = threadIdx.x, lane = t & 63, gl = t & (LQ_FC_GROUP - 1), gsh = lane & ~(u32)(LQ_FC_GROUP - 1);
 	const u32 grp = t / LQ_FC_GROUP, n_grp = blockDim.x / LQ_FC_GROUP, W = n_grp * LQ_FC_UNROLL;
+	const bool rare = S.self_q || ava.t_rank != nullptr;      // hits to be looked at one by one (lqmap.c:180-187)
+	u64 jn[LQ_FC_UNROLL], st[LQ_FC_UNROLL];                   // next minimizer of the worker, its list
+	u32 n[LQ_FC_UNROLL], qp[LQ_FC_UNROLL], c0[LQ_FC_UNROLL], c[LQ_FC_UNROLL], cnt[LQ_FC_UNROLL]; i32 ys[LQ_FC_UNROLL], yr[LQ_FC_UNROLL];
+	u8 *fm[LQ_FC_UNROLL];
+	bool more[LQ_FC_UNROLL], any = false;
+#pragma unroll
+	for (int u = 0; u < LQ_FC_UNROLL; ++u) { jn[u] = j0 + (u64)u * n_grp + grp; more[u] = false; n[u] = 0; qp[u] = 0; c0[u] = 0; c[u] = 0; cnt[u] = 0; st[u] = 0; ys[u] = 0; yr[u] = 0; fm[u] = fmask; any = any || jn[u] < j1; }
+	while (__ballot(any)) {                                   // (every lane of the wave goes round until every worker of the wave is done)
+		u64 r[LQ_FC_UNROLL];
+#pragma unroll
+		for (int u = 0; u < LQ_FC_UNROLL; ++u) {
+			if (!more[u] && jn[u] < j1) {                         // the worker's next minimizer (uniform over the group)
+				const FMeta m = meta[jn[u]];
+				n[u] = m.n; st[u] = m.st; qp[u] = m.qp; c0[u] = m.cursor;
+				const u32 span = span_const ? span_const : (u32)(qx[jn[u]] & 0xff);
+				ys[u] = (i32)(m.qp >> 1) - S.ql - 256; yr[u] = S.ql - (i32)((m.qp >> 1) + 1 - span) - 1 - S.ql - 256;   // (the diagonal is taken relative to -qlen - 256: never negative)
+				c[u] = m.cursor & ~(u32)(LQ_FC_GROUP - 1);        // steps are line-aligned in the list; hits before the cursor belong to earlier slices
+				if (!COUNT) { cnt[u] = 0; fm[u] = fmask + m.fm_byte; }
+				more[u] = c[u] < m.n;
+				if (!more[u]) jn[u] += W;                         // nothing of it left for this slice
+			}
+			r[u] = more[u] && c[u] + gl < n[u] ? pos[st[u] + c[u] + gl] : ~0ULL;
+		}
+		any = false;
+#pragma unroll
+		for (int u = 0; u < LQ_FC_UNROLL; ++u) {
+			const u32 tt = c[u] + gl, rid = (u32)(r[u] >> 32), rpos = (u32)r[u] >> 1;
+			const bool valid = more[u] && tt < n[u];
+			bool pass = valid && tt >= c0[u] && rid < S.r_hi;
+			u32 key = 0, bin = 0;
+			if (S.filt) {
+				const u32 rs = ((u32)r[u] & 1u) ^ (qp[u] & 1u);
+				const u32 d = (u32)((i32)rpos - (rs ? yr[u] : ys[u]));
+				key = ((rid - S.r_lo) << S.bpp_log) + (rs ? S.rs_off : 0u); bin = (d >> fp.dshift) & S.nb_mask;
+			}
+			const u32 pastb = (u32)(__ballot(valid && rid >= S.r_hi) >> gsh) & 0xffu;   // hits of later slices
+			const bool ends = more[u] && (pastb || c[u] + LQ_FC_GROUP >= n[u]);
+			if (COUNT) {
+				if (pass) lq_ft_inc(tab, key + bin);
+			} else {
+				if (pass && S.filt) pass = S.nb_mask == 7u && fp.n_min <= 4u ? lq_ft_alive8(tab, key, bin, fp.n_min) : lq_ft_alive(tab, key, bin, S.nb_mask, fp.n_min);
+				if (rare && pass) {
+					if (S.self_q && rpos == (qp[u] >> 1) && lq_is_self(self_off, self_rid, S.q, rid)) pass = false;   // lqmap.c:180-186
+					if (pass && ava.t_rank && ava.t_rank[rid] < S.qlo) pass = false;                                      // lqmap.c:187
+				}
+				const u32 bits = (u32)(__ballot(pass) >> gsh) & 0xffu;
+				if (gl == 0 && more[u]) {
+					if (bits) { fm[u][c[u] >> 3] |= (u8)bits; cnt[u] += (u32)__popc(bits); }
+					if (ends) {                                       // the piece is done: survivors of this slice, and where the next slice goes on
+						if (cnt[u]) cntf[jn[u]] += cnt[u];
+						meta[jn[u]].cursor = pastb ? c[u] + (u32)__ffs(pastb) - 1 : n[u];
+					}
+				}
+			}
+			if (ends) { more[u] = false; jn[u] += W; }
+			c[u] += LQ_FC_GROUP;
+			any = any || more[u] || jn[u] < j1;
+		}
+	}
+}
+
+// One block per query.
+__global__ void __launch_bounds__(LQ_FC_THREADS)
+k_seed_count(FMeta *meta, const u64 *qx, const u64 *qmoff, u32 n_q, const u32 *qlen, const u64 *pos, const u64 *aq_off,
+             int no_self, const u32 *self_off, const u32 *self_rid, AvaView ava, FiltParams fp, u32 span_const /* 0: from qx (-H) */,
+             u8 *fmask, u32 *cntf)
+{
+	__shared__ u32 tab[LQ_FT_WORDS];
+	const u32 t = threadIdx.x;
 	const bool filt = fp.n_min >= 2;
 	for (u32 q = blockIdx.x; q < n_q; q += gridDim.x) {
 		const u64 j0 = qmoff[q], j1 = qmoff[q + 1];
 		const u64 Aq = aq_off[q + 1] - aq_off[q];
 		if (Aq == 0) continue;                                    // (block-uniform)
-		// slices: R targets each, BPP = 2 * NB bins per target
+		// slices: R targets each, BPP bins per target (NB per strand, or NB shared by the two)
 		u32 n_sl = 1, R = fp.n_targets, bpp_log = 0;
 		if (filt) {
 			const u64 by_bins = ((fp.split_strands ? 16ULL : 8ULL) * fp.n_targets + fp.keys_cap - 1) / fp.keys_cap, by_load = (Aq + fp.a_cap - 1) / fp.a_cap;
@@ -338,94 +426,44 @@ k_seed_count(const FMeta *meta, const u64 *qx, const u64 *qmoff, u32 n_q, const 
 			if (s == 0) s = 1;
 			n_sl = (u32)s;
 			R = (fp.n_targets + n_sl - 1) / n_sl;
-			while (bpp_log < 12 && ((u64)R << (bpp_log + 1)) <= fp.keys_cap) ++bpp_log;
+			while (bpp_log < (fp.split_strands ? 4u : 3u) || (bpp_log < 12 && ((u64)R << (bpp_log + 1)) <= fp.keys_cap)) ++bpp_log;
+			while (((u64)R << bpp_log) > fp.keys_cap && R > 1) R = (R + 1) / 2;    // (more targets than the table has room for at 8 bins each: cannot happen after by_bins, kept as a guard)
 			n_sl = (fp.n_targets + R - 1) / R;
 		}
-		const u32 nb_mask = filt ? (1u << (bpp_log - (fp.split_strands ? 1 : 0))) - 1 : 0;      // (by_bins makes that at least 8 bins)
-		const u32 rs_off = fp.split_strands ? nb_mask + 1 : 0;
-		const bool self_q = no_self && self_off[q] != self_off[q + 1];
-		const u32 qlo = ava.q_lo ? ava.q_lo[q] : 0;
-		const i32 ql = (i32)qlen[q];
-		for (u64 j = j0 + t; j < j1; j += blockDim.x) cursor[j] = 0;
+		FSlice S;
+		S.bpp_log = bpp_log; S.filt = filt;
+		S.nb_mask = filt ? (1u << (bpp_log - (fp.split_strands ? 1 : 0))) - 1 : 0;      // at least 8 bins
+		S.rs_off = fp.split_strands ? S.nb_mask + 1 : 0;
+		S.self_q = no_self && self_off[q] != self_off[q + 1];
+		S.qlo = ava.q_lo ? ava.q_lo[q] : 0; S.q = q;
+		S.ql = (i32)qlen[q];
 		__syncthreads();
 		for (u32 s = 0; s < n_sl; ++s) {
-			const u32 r_lo = s * R, r_hi = s + 1 == n_sl ? 0xffffffffu : r_lo + R;
-			for (int sweep = filt ? 0 : 1; sweep < 2; ++sweep) {
-				// sweep 0: the slice's piece of every list, counted per (rid, relative strand, diagonal bin)
-				// sweep 1: which of them survive (all of them without a filter), minus the self diagonal and -X; the cursors move on
-				if (sweep == 0) {
-					const u32 words = (u32)((((u64)R << bpp_log) + 15) >> 4);
-					for (u32 i = t; i < words; i += blockDim.x) tab[i] = 0;
-				}
+			S.r_lo = s * R; S.r_hi = s + 1 == n_sl ? 0xffffffffu : S.r_lo + R;
+			if (filt) {
+				const u32 words = (u32)((((u64)R << bpp_log) + 15) >> 4);
+				for (u32 i = t; i < words; i += blockDim.x) tab[i] = 0;
 				__syncthreads();
-				u64 jn[LQ_FC_UNROLL], st[LQ_FC_UNROLL];               // next minimizer of the worker, its list
-				u32 n[LQ_FC_UNROLL], qp[LQ_FC_UNROLL], c0[LQ_FC_UNROLL], c[LQ_FC_UNROLL], cnt[LQ_FC_UNROLL]; i32 ys[LQ_FC_UNROLL], yr[LQ_FC_UNROLL];
-				bool more[LQ_FC_UNROLL], any = false;
-#pragma unroll
-				for (int u = 0; u < LQ_FC_UNROLL; ++u) { jn[u] = j0 + (u64)u * n_grp + grp; more[u] = false; n[u] = 0; qp[u] = 0; c0[u] = 0; c[u] = 0; cnt[u] = 0; st[u] = 0; ys[u] = 0; yr[u] = 0; any = any || jn[u] < j1; }
-				while (__ballot(any)) {                               // (every lane of the wave goes round until every worker of the wave is done)
-					u64 r[LQ_FC_UNROLL];
-#pragma unroll
-					for (int u = 0; u < LQ_FC_UNROLL; ++u) {
-						if (!more[u] && jn[u] < j1) {                     // the worker's next minimizer (uniform over the group)
-							const FMeta m = meta[jn[u]];
-							const u32 cur = cursor[jn[u]];
-							n[u] = m.n; st[u] = m.st; qp[u] = m.qp; c0[u] = cur;
-							const u32 span = span_const ? span_const : (u32)(qx[jn[u]] & 0xff);
-							ys[u] = (i32)(m.qp >> 1); yr[u] = ql - (i32)((m.qp >> 1) + 1 - span) - 1;
-							c[u] = cur & ~(u32)(LQ_FC_GROUP - 1);         // steps are line-aligned in the list; hits before the cursor belong to earlier slices
-							cnt[u] = 0;
-							more[u] = c[u] < m.n;
-							if (!more[u]) jn[u] += W;                     // nothing of it left for this slice
-						}
-						r[u] = more[u] && c[u] + gl < n[u] ? pos[st[u] + c[u] + gl] : ~0ULL;
-					}
-					any = false;
-#pragma unroll
-					for (int u = 0; u < LQ_FC_UNROLL; ++u) {
-						const u32 tt = c[u] + gl, rid = (u32)(r[u] >> 32), rpos = (u32)r[u] >> 1;
-						bool pass = more[u] && tt < n[u] && tt >= c0[u] && rid < r_hi;
-						u32 key = 0, bin = 0;
-						if (pass && filt) {
-							const u32 rs = ((u32)r[u] & 1u) ^ (qp[u] & 1u);
-							const i32 d = (i32)rpos - (rs ? yr[u] : ys[u]) + ql + 256;
-							key = ((rid - r_lo) << bpp_log) + (rs ? rs_off : 0); bin = ((u32)d >> fp.dshift) & nb_mask;
-						}
-						const u32 pastb = (u32)(__ballot(more[u] && tt < n[u] && rid >= r_hi) >> gsh) & 0xffu;   // hits of later slices
-						const bool ends = more[u] && (pastb || c[u] + LQ_FC_GROUP >= n[u]);
-						if (sweep == 0) {
-							if (pass) lq_ft_inc(tab, key + bin);
-						} else {
-							if (pass && filt) pass = lq_ft_alive(tab, key, bin, nb_mask, fp.n_min);
-							if (pass && self_q && rpos == (qp[u] >> 1) && lq_is_self(self_off, self_rid, q, rid)) pass = false;   // lqmap.c:180-186
-							if (pass && ava.t_rank && ava.t_rank[rid] < qlo) pass = false;                                         // lqmap.c:187
-							const u32 bits = (u32)(__ballot(pass) >> gsh) & 0xffu;
-							if (gl == 0 && more[u]) {
-								if (bits) { fmask[fm_off[jn[u]] * 8 + (c[u] >> 3)] |= (u8)bits; cnt[u] += (u32)__popc(bits); }
-								if (ends) {                                   // the piece is done: survivors of this slice, and where the next slice goes on
-									if (cnt[u]) cntf[jn[u]] += cnt[u];
-									cursor[jn[u]] = pastb ? c[u] + (u32)__ffs(pastb) - 1 : n[u];
-								}
-							}
-						}
-						if (ends) { more[u] = false; jn[u] += W; }
-						c[u] += LQ_FC_GROUP;
-						any = any || more[u] || jn[u] < j1;
-					}
-				}
+				lq_seed_sweep<true>(tab, meta, qx, j0, j1, pos, S, fp, span_const, self_off, self_rid, ava, fmask, cntf);
+				__syncthreads();
 			}
+			lq_seed_sweep<false>(tab, meta, qx, j0, j1, pos, S, fp, span_const, self_off, self_rid, ava, fmask, cntf);
 			__syncthreads();                                         // (the next slice clears the table; a cursor is read by its own group only)
 		}
 	}
 }
 
 // words of the survivor bitmap per query minimizer (scanned into fm_off)
-__global__ void k_fmask_words(const u32 *hit_n, const u32 *keep, const u64 *hit_start, const u64 *qy, u64 n_qm, u32 *words, FMeta *meta)
+__global__ void k_fmask_words(const u32 *hit_n, const u32 *keep, u64 n_qm, u32 *words)
+{
+	const u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+	if (j < n_qm) words[j] = keep[j] ? (hit_n[j] + 63) >> 6 : 0;
+}
+__global__ void k_fmeta(const u32 *hit_n, const u32 *keep, const u64 *hit_start, const u64 *qy, const u64 *fm_off, u64 n_qm, FMeta *meta)
 {
 	const u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
 	if (j >= n_qm) return;
-	words[j] = keep[j] ? (hit_n[j] + 63) >> 6 : 0;
-	FMeta m; m.st = hit_start[j]; m.n = keep[j] ? hit_n[j] : 0; m.qp = (u32)qy[j];
+	FMeta m; m.st = hit_start[j]; m.n = keep[j] ? hit_n[j] : 0; m.qp = (u32)qy[j]; m.fm_byte = fm_off[j] * 8; m.cursor = 0; m.pad = 0;
 	meta[j] = m;
 }
 // per query: where its surviving anchors start (af_off = exclusive scan of cntf)
