@@ -13,6 +13,7 @@
 #include <cinttypes>
 #include <algorithm>
 #include <unordered_map>
+#include <deque>
 #include <future>
 #include <functional>
 
@@ -111,6 +112,9 @@ void Knobs::read_env()
 	ties_klib = is("LQCOV_TIES", "klib") || all_klib;
 	filter = num("LQCOV_FILTER", 1) != 0;
 	filt_split = num("LQCOV_FILTER_SPLIT", 1) != 0;
+	head_chunks = (u32)std::min<long>(64, std::max<long>(1, num("LQCOV_HEAD_CHUNKS", 6)));
+	head_chunks_forced = getenv("LQCOV_HEAD_CHUNKS") != nullptr;
+	chunk_batches = (u32)std::min<long>(64, std::max<long>(1, num("LQCOV_CHUNK_BATCHES", 2)));
 	{
 		long kc = num("LQCOV_FILTER_KEYS", (long)LQ_FT_WORDS * 16);
 		u32 v = 256; while (v * 2 <= (u32)std::min<long>(std::max<long>(kc, 256), (long)LQ_FT_WORDS * 16)) v *= 2;   // a power of two in [256, 16 * LQ_FT_WORDS]
@@ -796,6 +800,7 @@ void lqcov_handle::map_batch(MapLane &L, Part &pt, u32 q0, u32 q1, const std::ve
 			if (!opt) d2h(hk.data(), qklib.as<u32>() + q0, nqb, L.stream);
 		}
 		sort_checked(L, pt, aqb, qkb, nqb, a_base, nA, rel, hk);
+		if (opt && !L.gate_passed) { L.gate_passed = true; open_gate(); }          // (no walks in the first pass: the next lane may start under this batch's chains)
 		chain_stage(L, pt, aqb, a_base, nqb, q0, nullptr, nA, opt ? 1 : 0, 0, ivl_cap, dbg);
 	}
 	u32 n_sens = 0;
@@ -1289,13 +1294,20 @@ void lqcov_handle::map_part(Part &pt)
 	d2h(h_aq.data(), aq_off.as<u64>(), n_q + 1, stream);
 	d2h(h_qmoff.data(), q.moff.as<u64>(), n_q + 1, stream);
 	last_n_written = nA_total;
-	if (!K.ties_klib) {
+	const bool opt = !K.ties_klib;
+	const bool dbg = (debug_flags & 1) != 0;
+	if (dbg) {
+		dbg_cap = nA_total / (P.min_cnt > 0 ? P.min_cnt : 1) + 16;
+		dbg_chains.ensure(dbg_cap * sizeof(ChainRec)); n_dbg.ensure(8);
+		dzero(n_dbg.p, 8, stream);
+	}
+	FiltParams fp; memset(&fp, 0, sizeof(fp));
+	if (opt) {
 		// The seed hits that can be part of a chain at all (k_seed_count): one bit per hit, counts per minimizer, offsets per query.
 		// Without the filter (LQCOV_FILTER=0, or a chain may be a single anchor) every hit passes: one code path for the first pass.
 		h_aqf.assign(n_q + 1, 0);
 		qzero.ensure((u64)n_q * 4 + 4); dzero(qzero.p, (u64)n_q * 4 + 4, stream);
 		fm_words.ensure(n_qm * 4 + 4); fm_off.ensure(n_qm * 8 + 8); cntf.ensure(n_qm * 4 + 4); af_off.ensure(n_qm * 8 + 8); aqf_off.ensure((n_q + 1) * 8);
-		u64 n_words = 0, nF = 0;
 		if (n_qm) {
 			fm_meta.ensure(n_qm * sizeof(FMeta) + 16);
 			LQ_LAUNCH(k_fmask_words, nblk(n_qm, 256), 256, stream, hit_n.as<u32>(), keep.as<u32>(), n_qm, fm_words.as<u32>()); check_launch();
@@ -1303,37 +1315,14 @@ void lqcov_handle::map_part(Part &pt)
 			LQ_LAUNCH(k_fmeta, nblk(n_qm, 256), 256, stream, hit_n.as<u32>(), keep.as<u32>(), hit_start.as<u64>(), q.my.as<u64>(), fm_off.as<u64>(), n_qm, fm_meta.as<FMeta>()); check_launch();
 			u64 lo = 0; u32 lc = 0;
 			d2h(&lo, fm_off.as<u64>() + n_qm - 1, 1, stream); d2h(&lc, fm_words.as<u32>() + n_qm - 1, 1, stream);
-			n_words = lo + lc;
+			const u64 n_words = lo + lc;
 			fmask.ensure(n_words * 8 + 8);
 			dzero(fmask.p, n_words * 8, stream); dzero(cntf.p, n_qm * 4, stream);
-			FiltParams fp;
-			fp.n_min = K.filter ? run_n_min() : 0;
-			fp.n_targets = std::max<u32>(pt.rs.n, 1); fp.keys_cap = K.filt_keys; fp.a_cap = std::max<u32>(K.filt_acap, 1);
-			fp.dshift = 1; while (fp.dshift < 30 && (1u << fp.dshift) <= (u32)std::max<i32>(P.bw, 0)) ++fp.dshift;   // bins wider than the band (chain.c:55)
-			fp.split_strands = K.filt_split ? 1 : 0;
-			{
-				StageTimer t(this, "k_seed_count", nA_total * 8 + nA_total / 8);   // (algorithmic: every occurrence list once, a bit per hit out; the kernel reads the lists twice)
-				LQ_LAUNCH(k_seed_count, std::min<u32>(n_q, 1u << 20), LQ_FC_THREADS, stream, fm_meta.as<FMeta>(), q.mx.as<u64>(), q.moff.as<u64>(), n_q, q.d_len.as<u32>(), pt.pos.as<u64>(), aq_off.as<u64>(),
-				          (int)P.no_self, pt.self_off.as<u32>(), pt.self_rid.as<u32>(), AvaView{P.ava ? pt.t_rank.as<u32>() : nullptr, P.ava ? pt.q_lo.as<u32>() : nullptr}, fp, (u32)(P.hpc ? 0 : P.k),
-				          fmask.as<u8>(), cntf.as<u32>());
-				check_launch();
-			}
-			prim.exclusive_scan_u32_u64(cntf.as<u32>(), af_off.as<u64>(), n_qm);
-			d2h(&lo, af_off.as<u64>() + n_qm - 1, 1, stream); d2h(&lc, cntf.as<u32>() + n_qm - 1, 1, stream);
-			nF = lo + lc;
 		}
-		LQ_LAUNCH(k_query_foff, nblk(n_q + 1, 256), 256, stream, q.moff.as<u64>(), af_off.as<u64>(), n_qm, nF, n_q, aqf_off.as<u64>()); check_launch();
-		d2h(h_aqf.data(), aqf_off.as<u64>(), n_q + 1, stream);
-		last_n_written = nF;
-	}
-	const std::vector<u64> &h_boff = K.ties_klib ? h_aq : h_aqf;   // the offsets the batches are cut by: of the anchors the first pass writes
-	const u64 nB_total = h_boff[n_q];
-
-	const bool dbg = (debug_flags & 1) != 0;
-	if (dbg) {
-		dbg_cap = nA_total / (P.min_cnt > 0 ? P.min_cnt : 1) + 16;
-		dbg_chains.ensure(dbg_cap * sizeof(ChainRec)); n_dbg.ensure(8);
-		dzero(n_dbg.p, 8, stream);
+		fp.n_min = K.filter ? run_n_min() : 0;
+		fp.n_targets = std::max<u32>(pt.rs.n, 1); fp.keys_cap = K.filt_keys; fp.a_cap = std::max<u32>(K.filt_acap, 1);
+		fp.dshift = 1; while (fp.dshift < 30 && (1u << fp.dshift) <= (u32)std::max<i32>(P.bw, 0)) ++fp.dshift;   // bins wider than the band (chain.c:55)
+		fp.split_strands = K.filt_split ? 1 : 0;
 	}
 	if (anchor_budget == 0) {
 		// The first part stands (reads, minimizers, index, the build's work space -- all kept for the parts to come, of which the
@@ -1347,28 +1336,6 @@ void lqcov_handle::map_part(Part &pt)
 	}
 	if (anchor_budget > (1ULL << 31) - 4096) anchor_budget = (1ULL << 31) - 4096;   // (a record names its anchor in 31 bits)
 	if (anchor_budget < 1024) anchor_budget = 1024;
-	// batches of queries whose anchors fit one lane's work space; lanes (own stream + work space) take batches as they
-	// finish, so the serial tail of one batch (its longest walk / chain) overlaps the wide kernels of another
-	std::vector<std::pair<u32, u32>> batches;
-	{	// as few batches as the work space allows, a multiple of the lane count, of about equal anchor totals: every batch
-		// has a serial critical path (its longest walk and chain) that does not shrink with the batch.  (Cutting the last round
-		// finer -- halves, then quarters, so that the lanes end together -- was measured on MI355X at configs[2]: 1.75-1.78 s
-		// per step against 1.68-1.70 s; the extra batches cost more than the shorter tail saves.)
-		u64 nb = (nB_total + anchor_budget - 1) / anchor_budget;
-		if (nb < (u64)n_lanes && nB_total >= ((u64)n_lanes << 24)) nb = n_lanes;
-		if (nb > (u64)n_lanes) nb = (nb + n_lanes - 1) / n_lanes * n_lanes;
-		if (nb == 0) nb = 1;
-		u64 left = nb;
-		for (u32 q0 = 0; q0 < n_q; ) {
-			const u64 rem = h_boff[n_q] - h_boff[q0];
-			const u64 lim = std::min(anchor_budget, left > 1 ? (rem + left - 1) / left : rem);
-			u32 q1 = q0 + 1;
-			while (q1 < n_q && h_boff[q1 + 1] - h_boff[q0] <= lim) ++q1;
-			batches.emplace_back(q0, q1);
-			q0 = q1;
-			if (left > 1) --left;
-		}
-	}
 	while (lanes.size() < (size_t)n_lanes) {
 		lanes.emplace_back(new MapLane());
 		LQ_HIP_CHECK(hipStreamCreate(&lanes.back()->stream));
@@ -1403,21 +1370,95 @@ void lqcov_handle::map_part(Part &pt)
 		}
 	}
 #ifndef LQ_EMU
-	const bool concurrent = n_lanes > 1 && batches.size() > 1 && profiling != 1 && !dbg;
+	const bool concurrent = n_lanes > 1 && nA_total >= (1u << 20) && profiling != 1 && !dbg;
 #else
 	const bool concurrent = false;
 #endif
+	// The queries in chunks (of about equal seed hits): the head stream decides chunk c + 1's survivors (k_seed_count, latency-bound)
+	// while the lanes map the batches of chunk c.  One chunk where nothing runs side by side, or without the first-pass filter.
+	std::vector<std::pair<u32, u32>> chunks;
+	{
+		const u32 n_ch = opt && (concurrent || K.head_chunks_forced) ? std::max<u32>(K.head_chunks, 1) : 1;   // (LQCOV_HEAD_CHUNKS set: chunks also where one batch runs after the other -- tests)
+		u32 c0 = 0;
+		for (u32 c = 0; c < n_ch && c0 < n_q; ++c) {
+			const u64 want = nA_total / n_ch * (c + 1);
+			u32 c1 = c + 1 == n_ch ? n_q : c0 + 1;
+			while (c1 < n_q && h_aq[c1] < want) ++c1;
+			chunks.emplace_back(c0, c1);
+			c0 = c1;
+		}
+		if (chunks.empty()) chunks.emplace_back(0, n_q);
+		chunks.back().second = n_q;
+	}
+	// batches of queries whose anchors fit one lane's work space, cut from the offsets of what the first pass writes; lanes (own
+	// streams + work space) take batches as they finish, so the serial tail of one batch overlaps the wide kernels of another
+	auto cut_batches = [&](u32 c0, u32 c1, const std::vector<u64> &off, std::vector<std::pair<u32, u32>> &out) {
+		// as few batches as the work space allows (a multiple of the lane count when the part is one chunk), of about equal anchor
+		// totals: every batch has a serial critical path that does not shrink with the batch.  (Cutting the last round finer was
+		// measured on MI355X at configs[2] in round 3: 1.75-1.78 s per step against 1.68-1.70 s.)
+		const u64 tot = off[c1] - off[c0];
+		u64 nb = (tot + anchor_budget - 1) / anchor_budget;
+		if (chunks.size() == 1) {
+			if (nb < (u64)n_lanes && tot >= ((u64)n_lanes << 24)) nb = n_lanes;
+			if (nb > (u64)n_lanes) nb = (nb + n_lanes - 1) / n_lanes * n_lanes;
+		} else if (nb < K.chunk_batches && tot >= ((u64)K.chunk_batches << 22)) nb = K.chunk_batches;
+		if (nb == 0) nb = 1;
+		u64 left = nb;
+		for (u32 q0 = c0; q0 < c1; ) {
+			const u64 rem = off[c1] - off[q0];
+			const u64 lim = std::min(anchor_budget, left > 1 ? (rem + left - 1) / left : rem);
+			u32 q1 = q0 + 1;
+			while (q1 < c1 && off[q1 + 1] - off[q0] <= lim) ++q1;
+			out.emplace_back(q0, q1);
+			q0 = q1;
+			if (left > 1) --left;
+		}
+	};
+	u64 n_written = 0;
+	// a chunk's head: which of its seed hits survive, where every query's survivors start
+	auto head = [&](u32 c0, u32 c1) {
+		if (!opt) return;
+		const u64 jb = h_qmoff[c0], je = h_qmoff[c1];
+		u64 tot = n_written;
+		if (je > jb) {
+			{
+				StageTimer t(this, "k_seed_count", (h_aq[c1] - h_aq[c0]) * 8 + (h_aq[c1] - h_aq[c0]) / 8);   // (algorithmic: every occurrence list once, a bit per hit out; the kernel reads the lists twice)
+				LQ_LAUNCH(k_seed_count, std::min<u32>(c1 - c0, 1u << 20), LQ_FC_THREADS, stream, fm_meta.as<FMeta>(), q.mx.as<u64>(), q.moff.as<u64>(), c0, c1, q.d_len.as<u32>(), pt.pos.as<u64>(), aq_off.as<u64>(),
+				          (int)P.no_self, pt.self_off.as<u32>(), pt.self_rid.as<u32>(), AvaView{P.ava ? pt.t_rank.as<u32>() : nullptr, P.ava ? pt.q_lo.as<u32>() : nullptr}, fp, (u32)(P.hpc ? 0 : P.k),
+				          fmask.as<u8>(), cntf.as<u32>());
+				check_launch();
+			}
+			prim.exclusive_scan_u32_u64(cntf.as<u32>() + jb, af_off.as<u64>() + jb, je - jb, n_written);
+			u64 lo = 0; u32 lc = 0;
+			d2h(&lo, af_off.as<u64>() + je - 1, 1, stream); d2h(&lc, cntf.as<u32>() + je - 1, 1, stream);
+			tot = lo + lc;
+		}
+		LQ_LAUNCH(k_query_foff, nblk(c1 - c0 + 1, 256), 256, stream, q.moff.as<u64>(), af_off.as<u64>(), c0, c1, je, tot, aqf_off.as<u64>()); check_launch();
+		// (h_aqf[c0] was written as the previous chunk's end: lanes may be reading it)
+		if (c0 == 0) d2h(h_aqf.data(), aqf_off.as<u64>(), c1 + 1, stream);
+		else d2h(h_aqf.data() + c0 + 1, aqf_off.as<u64>() + c0 + 1, c1 - c0, stream);
+		n_written = tot;
+	};
+	const std::vector<u64> &h_boff = opt ? h_aqf : h_aq;             // the offsets the batches are cut by: of the anchors the first pass writes
 	if (!concurrent) {
-		for (size_t i = 0; i < batches.size(); ++i) {
-			lq_alloc_stream = lanes[i % n_lanes]->stream;
-			map_batch(*lanes[i % n_lanes], pt, batches[i].first, batches[i].second, h_aq, h_aqf, h_qmoff, dbg);
-			lq_alloc_stream = nullptr;
+		size_t i = 0;
+		for (auto &ch : chunks) {
+			head(ch.first, ch.second);
+			std::vector<std::pair<u32, u32>> batches;
+			cut_batches(ch.first, ch.second, h_boff, batches);
+			for (auto &b : batches) {
+				lq_alloc_stream = lanes[i % n_lanes]->stream;
+				map_batch(*lanes[i % n_lanes], pt, b.first, b.second, h_aq, h_aqf, h_qmoff, dbg);
+				lq_alloc_stream = nullptr;
+				++i;
+			}
 		}
 		for (auto &L : lanes) LQ_HIP_CHECK(hipStreamSynchronize(L->stream));
 	} else {
-		std::atomic<size_t> next(0);
+		std::deque<std::pair<u32, u32>> todo;                        // under gate_mu, like the staggered start
+		bool producing = true, failed = false;
 		{ std::lock_guard<std::mutex> lk(gate_mu); gate_count = 0; }
-		std::vector<std::exception_ptr> errs(n_lanes);
+		std::vector<std::exception_ptr> errs(n_lanes + 1);
 		std::vector<std::thread> th;
 		for (int li = 0; li < n_lanes; ++li)
 			th.emplace_back([&, li]() {
@@ -1426,22 +1467,40 @@ void lqcov_handle::map_part(Part &pt)
 					MapLane &L = *lanes[li];
 					lq_alloc_stream = L.stream;                              // this thread's buffers grow from the stream-ordered pool (prim.hpp)
 					struct AllocGuard { ~AllocGuard() { lq_alloc_stream = nullptr; } } alloc_guard;
-					{	// staggered start: lane li begins when li batches have reached their long walks (or ended), so that
+					{	// staggered start: lane li begins when li batches have got past their sort (or ended), so that
 						// one lane's serial tails run under another lane's wide kernels instead of side by side
 						std::unique_lock<std::mutex> lk(gate_mu);
-						gate_cv.wait(lk, [&] { return gate_count >= li || next.load() >= batches.size(); });
+						gate_cv.wait(lk, [&] { return gate_count >= li || failed || (!producing && todo.empty()); });
 					}
 					for (;;) {
-						const size_t i = next.fetch_add(1);
-						if (i >= batches.size()) break;
-						map_batch(L, pt, batches[i].first, batches[i].second, h_aq, h_aqf, h_qmoff, dbg);
+						std::pair<u32, u32> b;
+						{
+							std::unique_lock<std::mutex> lk(gate_mu);
+							gate_cv.wait(lk, [&] { return !todo.empty() || !producing || failed; });
+							if (failed || todo.empty()) break;
+							b = todo.front(); todo.pop_front();
+						}
+						map_batch(L, pt, b.first, b.second, h_aq, h_aqf, h_qmoff, dbg);
 					}
 					LQ_HIP_CHECK(hipStreamSynchronize(L.stream));
-				} catch (...) { errs[li] = std::current_exception(); next.store(batches.size()); gate_cv.notify_all(); }
+				} catch (...) { errs[li] = std::current_exception(); { std::lock_guard<std::mutex> lk(gate_mu); failed = true; } gate_cv.notify_all(); }
 			});
+		try {
+			for (auto &ch : chunks) {
+				{ std::lock_guard<std::mutex> lk(gate_mu); if (failed) break; }
+				head(ch.first, ch.second);
+				std::vector<std::pair<u32, u32>> batches;
+				cut_batches(ch.first, ch.second, h_boff, batches);
+				{ std::lock_guard<std::mutex> lk(gate_mu); for (auto &b : batches) todo.push_back(b); }
+				gate_cv.notify_all();
+			}
+		} catch (...) { errs[n_lanes] = std::current_exception(); std::lock_guard<std::mutex> lk(gate_mu); failed = true; }
+		{ std::lock_guard<std::mutex> lk(gate_mu); producing = false; }
+		gate_cv.notify_all();
 		for (auto &t : th) t.join();
 		for (auto &e : errs) if (e) { hipDeviceSynchronize(); std::rethrow_exception(e); }
 	}
+	if (opt) last_n_written = n_written;
 	if (dbg) { unsigned long long nd = 0; d2h(&nd, n_dbg.as<unsigned long long>(), 1, stream); n_dbg_host = nd; }
 	LQ_HIP_CHECK(hipStreamSynchronize(stream));
 }

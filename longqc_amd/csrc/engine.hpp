@@ -49,6 +49,9 @@ struct Knobs {
 	bool sketch_machine_only = false;     // LQCOV_SKETCH=machine: the state machine decides every chunk (no data-parallel kernel)
 	bool ties_klib = false;               // LQCOV_TIES=klib (or LQCOV_SORT=klib): klib's order of equal-x anchors everywhere, every seed hit written and sorted (rounds 1-3); default: only where it can be observed (map_batch)
 	bool filter = true;                   // LQCOV_FILTER=0: the first pass writes every seed hit (no counting filter)
+	u32 head_chunks = 6;                  // LQCOV_HEAD_CHUNKS: chunks of queries whose survivors are decided (k_seed_count) while the lanes map the chunk before
+	bool head_chunks_forced = false;
+	u32 chunk_batches = 2;                // LQCOV_CHUNK_BATCHES: batches a chunk is cut into at least (if it has the anchors for it)
 	bool filt_split = true;               // LQCOV_FILTER_SPLIT=0: the two strands of a target share its diagonal bins
 	u32 filt_keys = 1u << 19;             // LQCOV_FILTER_KEYS: counters of k_seed_count's table in use (tests shrink it: slices and aliasing on small inputs)
 	u32 filt_acap = 131072;               // LQCOV_FILTER_ACAP: hits per slice of targets aimed at (0.25 per counter)

@@ -406,14 +406,14 @@ __device__ __forceinline__ void lq_seed_sweep(u32 *tab, FMeta *meta, const u64 *
 
 // One block per query.
 __global__ void __launch_bounds__(LQ_FC_THREADS)
-k_seed_count(FMeta *meta, const u64 *qx, const u64 *qmoff, u32 n_q, const u32 *qlen, const u64 *pos, const u64 *aq_off,
+k_seed_count(FMeta *meta, const u64 *qx, const u64 *qmoff, u32 q_lo, u32 q_hi, const u32 *qlen, const u64 *pos, const u64 *aq_off,
              int no_self, const u32 *self_off, const u32 *self_rid, AvaView ava, FiltParams fp, u32 span_const /* 0: from qx (-H) */,
              u8 *fmask, u32 *cntf)
 {
 	__shared__ u32 tab[LQ_FT_WORDS];
 	const u32 t = threadIdx.x;
 	const bool filt = fp.n_min >= 2;
-	for (u32 q = blockIdx.x; q < n_q; q += gridDim.x) {
+	for (u32 q = q_lo + blockIdx.x; q < q_hi; q += gridDim.x) {
 		const u64 j0 = qmoff[q], j1 = qmoff[q + 1];
 		const u64 Aq = aq_off[q + 1] - aq_off[q];
 		if (Aq == 0) continue;                                    // (block-uniform)
@@ -467,12 +467,13 @@ __global__ void k_fmeta(const u32 *hit_n, const u32 *keep, const u64 *hit_start,
 	meta[j] = m;
 }
 // per query: where its surviving anchors start (af_off = exclusive scan of cntf)
-__global__ void k_query_foff(const u64 *qmoff, const u64 *af_off, u64 n_qm, u64 n_total, u32 n_q, u64 *aqf_off)
+// (for the queries [q_lo, q_hi] of a chunk whose minimizers end at j_end; n_total: the survivors up to and including the chunk)
+__global__ void k_query_foff(const u64 *qmoff, const u64 *af_off, u32 q_lo, u32 q_hi, u64 j_end, u64 n_total, u64 *aqf_off)
 {
-	const u32 q = blockIdx.x * blockDim.x + threadIdx.x;
-	if (q > n_q) return;
+	const u32 q = q_lo + blockIdx.x * blockDim.x + threadIdx.x;
+	if (q > q_hi) return;
 	const u64 j0 = qmoff[q];
-	aqf_off[q] = j0 < n_qm ? af_off[j0] : n_total;
+	aqf_off[q] = j0 < j_end ? af_off[j0] : n_total;
 }
 
 // the surviving anchors (lqmap.c:175-200) of the minimizers [j0, j0 + nj), dense; and mini_pos (lqmap.c:174) of every kept

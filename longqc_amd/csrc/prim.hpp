@@ -102,16 +102,16 @@ struct Prim {
 	hipStream_t stream = nullptr;
 
 	// out[i] = sum_{j<i} in[j]  (u32 -> u64); returns nothing, total = out[n-1] + in[n-1] (caller reads)
-	void exclusive_scan_u32_u64(const u32 *in, u64 *out, size_t n)
+	void exclusive_scan_u32_u64(const u32 *in, u64 *out, size_t n, u64 init = 0)
 	{
 		if (n == 0) return;
 #ifndef LQ_EMU
 		size_t bytes = 0;
-		LQ_HIP_CHECK(rocprim::exclusive_scan(nullptr, bytes, in, out, (u64)0, n, rocprim::plus<u64>(), stream));
+		LQ_HIP_CHECK(rocprim::exclusive_scan(nullptr, bytes, in, out, init, n, rocprim::plus<u64>(), stream));
 		tmp.ensure(bytes);
-		LQ_HIP_CHECK(rocprim::exclusive_scan(tmp.p, bytes, in, out, (u64)0, n, rocprim::plus<u64>(), stream));
+		LQ_HIP_CHECK(rocprim::exclusive_scan(tmp.p, bytes, in, out, init, n, rocprim::plus<u64>(), stream));
 #else
-		u64 acc = 0;
+		u64 acc = init;
 		for (size_t i = 0; i < n; ++i) { u64 v = in[i]; out[i] = acc; acc += v; }
 #endif
 	}
