@@ -82,7 +82,7 @@ void Knobs::read_env()
 {
 	auto num = [](const char *name, long dflt) { const char *e = getenv(name); return e && *e ? atol(e) : dflt; };
 	auto is = [](const char *name, const char *val) { const char *e = getenv(name); return e && !strcmp(e, val); };
-	lanes = (int)std::min<long>(8, std::max<long>(1, num("LQCOV_LANES", 5)));
+	lanes = (int)std::min<long>(8, std::max<long>(1, num("LQCOV_LANES", 3)));
 	anchor_budget = getenv("LQCOV_ANCHOR_BUDGET") ? strtoull(getenv("LQCOV_ANCHOR_BUDGET"), 0, 10) : 0;
 	query_order_file = is("LQCOV_QUERY_ORDER", "file");
 	all_klib = is("LQCOV_SORT", "klib");
@@ -112,14 +112,14 @@ void Knobs::read_env()
 	ties_klib = is("LQCOV_TIES", "klib") || all_klib;
 	filter = num("LQCOV_FILTER", 1) != 0;
 	filt_split = num("LQCOV_FILTER_SPLIT", 1) != 0;
-	head_chunks = (u32)std::min<long>(64, std::max<long>(1, num("LQCOV_HEAD_CHUNKS", 6)));
+	head_chunks = (u32)std::min<long>(64, std::max<long>(1, num("LQCOV_HEAD_CHUNKS", 1)));
 	head_chunks_forced = getenv("LQCOV_HEAD_CHUNKS") != nullptr;
 	chunk_batches = (u32)std::min<long>(64, std::max<long>(1, num("LQCOV_CHUNK_BATCHES", 2)));
 	{
 		long kc = num("LQCOV_FILTER_KEYS", (long)LQ_FT_WORDS * 16);
 		u32 v = 256; while (v * 2 <= (u32)std::min<long>(std::max<long>(kc, 256), (long)LQ_FT_WORDS * 16)) v *= 2;   // a power of two in [256, 16 * LQ_FT_WORDS]
 		filt_keys = v;
-		filt_acap = (u32)std::max<long>(1, num("LQCOV_FILTER_ACAP", (long)(0.25 * v)));
+		filt_acap = (u32)std::max<long>(1, num("LQCOV_FILTER_ACAP", (long)(0.125 * v)));
 	}
 }
 

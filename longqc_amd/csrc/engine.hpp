@@ -25,7 +25,7 @@ struct StageAcc { double ms = 0; u64 launches = 0; u64 bytes = 0; };
 
 // Environment switches, read once when the handle is made (test and A/B aids; the defaults are the measured choice).
 struct Knobs {
-	int lanes = 5;                        // LQCOV_LANES: concurrent mapping lanes (measured at configs[2], ms per step: 1 lane 1882, 3: 1582, 4: 1532, 5: 1510, 6: 1508, 8: 1610)
+	int lanes = 3;                        // LQCOV_LANES: concurrent mapping lanes (round 4, configs[2], ms per step: 2 lanes 908, 3: 888-922, 4: 964, 5: 995; round 3, every hit sorted: 1 lane 1882, 3: 1582, 5: 1510, 8: 1610)
 	u64 anchor_budget = 0;                // LQCOV_ANCHOR_BUDGET: anchors per query batch (0 = from free HBM)
 	bool query_order_file = false;        // LQCOV_QUERY_ORDER=file: keep the caller's query order inside
 	bool all_klib = false;                // LQCOV_SORT=klib: every query through klib's passes, no bucket leaves them early
@@ -49,12 +49,12 @@ struct Knobs {
 	bool sketch_machine_only = false;     // LQCOV_SKETCH=machine: the state machine decides every chunk (no data-parallel kernel)
 	bool ties_klib = false;               // LQCOV_TIES=klib (or LQCOV_SORT=klib): klib's order of equal-x anchors everywhere, every seed hit written and sorted (rounds 1-3); default: only where it can be observed (map_batch)
 	bool filter = true;                   // LQCOV_FILTER=0: the first pass writes every seed hit (no counting filter)
-	u32 head_chunks = 6;                  // LQCOV_HEAD_CHUNKS: chunks of queries whose survivors are decided (k_seed_count) while the lanes map the chunk before
+	u32 head_chunks = 1;                  // LQCOV_HEAD_CHUNKS: chunks of queries whose survivors are decided (k_seed_count) while the lanes map the chunk before (measured at configs[2]: 6 chunks 1160 ms per step, 10: 1404, 1: 888 -- more batches, more serial tails)
 	bool head_chunks_forced = false;
 	u32 chunk_batches = 2;                // LQCOV_CHUNK_BATCHES: batches a chunk is cut into at least (if it has the anchors for it)
 	bool filt_split = true;               // LQCOV_FILTER_SPLIT=0: the two strands of a target share its diagonal bins
 	u32 filt_keys = 1u << 19;             // LQCOV_FILTER_KEYS: counters of k_seed_count's table in use (tests shrink it: slices and aliasing on small inputs)
-	u32 filt_acap = 131072;               // LQCOV_FILTER_ACAP: hits per slice of targets aimed at (0.25 per counter)
+	u32 filt_acap = 65536;                // LQCOV_FILTER_ACAP: hits per slice of targets aimed at (0.125 per counter; configs[2], 3 lanes: 131072 995 ms per step, 65536 922, 32768 937-955)
 	void read_env();
 };
 
