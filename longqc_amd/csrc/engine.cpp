@@ -7,6 +7,7 @@
 #include "kernels_psort.hpp"
 #include "kernels_chain.hpp"
 #include "fastx.hpp"
+#include "fastx_mem.hpp"
 #include <cstdio>
 #include <cstring>
 #include <cmath>
@@ -34,6 +35,8 @@ template <class T> static void d2h(T *dst, const T *src, size_t n, hipStream_t s
 }
 static void dzero(void *p, size_t bytes, hipStream_t s) { if (bytes) LQ_HIP_CHECK(hipMemsetAsync(p, 0, bytes, s)); }
 static void check_launch() { LQ_HIP_CHECK(hipGetLastError()); }
+#include <chrono>
+static double lq_now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 #ifndef LQ_EMU
 int lq_trace_launches = 0;
 #endif
@@ -114,6 +117,9 @@ void Knobs::read_env()
 	filt_split = num("LQCOV_FILTER_SPLIT", 1) != 0;
 	head_chunks = (u32)std::min<long>(64, std::max<long>(1, num("LQCOV_HEAD_CHUNKS", 1)));
 	head_chunks_forced = getenv("LQCOV_HEAD_CHUNKS") != nullptr;
+	parse_threads = (int)std::min<long>(256, std::max<long>(0, num("LQCOV_PARSE_THREADS", 0)));
+	parse_piece = (u64)std::max<long>(64, num("LQCOV_PARSE_PIECE", 32L << 20));
+	pipeline = num("LQCOV_PIPELINE", 1) != 0;
 	chunk_batches = (u32)std::min<long>(64, std::max<long>(1, num("LQCOV_CHUNK_BATCHES", 2)));
 	{
 		long kc = num("LQCOV_FILTER_KEYS", (long)LQ_FT_WORDS * 16);
@@ -536,6 +542,7 @@ void lqcov_handle::build_index(Part &pt)
 	(void)prim;
 	ReadSetDev &rs = pt.rs;
 	const u64 M = rs.n_mini;
+	ix_owner = &pt;
 	pt.n_keys = 0; pt.cap_bits = 4;
 	pt.pos.ensure(M * 8 + 8);
 	if (M) {
@@ -1687,6 +1694,9 @@ void lqcov_handle::build_part_from_host_minimizers(Part &pt, const std::vector<u
 void lqcov_handle::dump_part(Part &pt, FILE *fp)
 {
 	if (!pt.built) throw std::logic_error("part not built");
+	// (the distinct keys, their starts and counts are the build's work space, which lives with the handle: they describe the part
+	// that was built last)
+	if (ix_owner != &pt) throw std::logic_error("this part's index can no longer be dumped: another part was built after it (dump a part before the next lqcov_part_build)");
 	ReadSetDev &rs = pt.rs;
 	const u64 M = rs.n_mini, K = pt.n_keys;
 	const u32 b = LQ_MMI_BUCKET_BITS, nb = 1u << b;
@@ -1846,47 +1856,161 @@ int lqcov_handle::run_files(const char *target, const char *query, FILE *out, FI
 			++n_parts;
 		}
 	} else {
-		FastxReader ft(target);
+		// One part = mini-batches of `chunk` bases while the running total is <= -I (index.c:244,311-316).  The parts go through a
+		// pipeline of three stages that overlap: the host makes part k + 2 (a plain file: parsed by many threads from the mapping and
+		// 2-bit packed into page-locked memory, fastx_mem.hpp; gzip or a pipe: the streaming reader, one thread like the
+		// reference's kseq), the build stream uploads, sketches and indexes part k + 1, the lanes map part k.  (-d and the index-only
+		// call keep one part at a time.)
 		const int64_t chunk = (int)((u64)P.idx_mini_batch < P.batch_size ? (u64)P.idx_mini_batch : P.batch_size);   // index.c:316
-		// one part = mini-batches while the running total is <= -I (index.c:244).  The host parses the next part while the
-		// device sketches, indexes and maps the current one.
-		auto read_part = [&ft, chunk, this]() {
-			std::vector<ReadBatch> bs;
-			u64 sum_len = 0;
-			for (;;) {
-				if (sum_len > P.batch_size) break;
-				bs.emplace_back();
-				if (ft.read_minibatch(chunk, bs.back(), false) == 0) { bs.pop_back(); break; }
-				sum_len += bs.back().bases();
-			}
-			return bs;
+		struct HostPart {
+			bool packed = false, last = false;                         // last: the input ended inside this part
+			std::vector<ReadBatch> bs;                                 // streaming form (ASCII)
+			u64 *codes = nullptr; u32 *amb = nullptr; u64 cap_words = 0;   // packed form, page-locked
+			std::vector<u32> lens; std::vector<char> names; std::vector<u64> name_off{0};
+			u32 n = 0; u64 bases = 0;
+			bool empty() const { return packed ? n == 0 : bs.empty(); }
+			~HostPart() { if (codes) hipHostFree(codes); if (amb) hipHostFree(amb); }
 		};
-		std::future<std::vector<ReadBatch>> next_part = std::async(std::launch::async, read_part);   // (declared after `ft`: its destructor joins the reader first)
-		for (;;) {
-			std::vector<ReadBatch> bs = next_part.get();
-			if (bs.empty()) break;
-			next_part = std::async(std::launch::async, read_part);
-			parts.emplace_back(new Part());
-			const int id = (int)parts.size() - 1;
-			parts[id]->live = true;
-			for (ReadBatch &tb : bs) {
-				add_reads(parts[id]->rs, tb.size(), tb.seq.data(), tb.seq_off.data(), tb.names.data(), tb.name_off.data());
-				tb = ReadBatch();
+		HostPart hp[2];
+		MemFastx mf;
+		MemRecords recs;
+		struct FlatRec { const u8 *name; u32 name_len; const u8 *seq; u32 seq_len; };
+		std::vector<FlatRec> flat;
+		std::vector<std::pair<size_t, size_t>> ranges;                 // records of every part (memory path)
+		size_t next_range = 0;
+		std::unique_ptr<FastxReader> ft;
+		const bool mem = K.parse_threads != 1 && mf.open(target);
+		if (mem) {
+			const double t0 = lq_now_s();
+			lq_parse_all(mf, K.parse_threads, K.parse_piece, recs);
+			flat.reserve(recs.n_recs);
+			for (MemPiece &pc : recs.pieces) for (MemRec &r : pc.recs)
+				flat.push_back(FlatRec{mf.data() + r.name_off, r.name_len, (r.own ? pc.side.data() : mf.data()) + r.seq_off, r.seq_len});
+			size_t r0 = 0;
+			while (r0 < flat.size()) {                                 // index.c:244,311-316 and bseq.c:86-98 on the record lengths
+				u64 sum_len = 0; size_t r1 = r0;
+				while (r1 < flat.size() && sum_len <= P.batch_size) {
+					i64 size = 0;
+					while (r1 < flat.size()) { size += flat[r1].seq_len; ++r1; if (size >= chunk) break; }
+					sum_len += (u64)size;
+				}
+				ranges.emplace_back(r0, r1);
+				r0 = r1;
 			}
-			Part &pt = *parts[id];
+			if (log) fprintf(log, "[lqcov] parsed %zu target sequence(s) from the mapped file in %.3f s (%zu pieces, %u parsed again in order), %zu part(s)\n",
+			                 flat.size(), lq_now_s() - t0, recs.pieces.size(), recs.reparsed, ranges.size());
+		} else ft.reset(new FastxReader(target));
+		auto produce = [&](int slot) {
+			LQ_HIP_CHECK(hipSetDevice(device));                         // (may run on a thread of its own: page-locked allocations)
+			HostPart &h = hp[slot];
+			h.bs.clear(); h.n = 0; h.bases = 0; h.lens.clear(); h.names.clear(); h.name_off.assign(1, 0); h.last = false;
+			if (!mem) {
+				h.packed = false;
+				u64 sum_len = 0;
+				for (;;) {
+					if (sum_len > P.batch_size) break;
+					h.bs.emplace_back();
+					if (ft->read_minibatch(chunk, h.bs.back(), false) == 0) { h.bs.pop_back(); h.last = true; break; }
+					sum_len += h.bs.back().bases();
+				}
+				for (ReadBatch &b : h.bs) h.bases += b.bases();
+				return;
+			}
+			h.packed = true;
+			if (next_range >= ranges.size()) { h.last = true; return; }
+			const size_t r0 = ranges[next_range].first, r1 = ranges[next_range].second;
+			++next_range;
+			h.last = next_range >= ranges.size();
+			h.n = (u32)(r1 - r0);
+			h.lens.resize(h.n);
+			std::vector<u64> coff(h.n + 1, 0);
+			u64 name_bytes = 0;
+			for (u32 i = 0; i < h.n; ++i) { const FlatRec &r = flat[r0 + i]; h.lens[i] = r.seq_len; coff[i + 1] = coff[i] + ((u64)r.seq_len + LQ_CHUNK - 1) / LQ_CHUNK; h.bases += r.seq_len; name_bytes += r.name_len + 1; }
+			const u64 n_words = coff[h.n] * LQ_CHUNK_WORDS;
+			if (n_words > h.cap_words) {
+				if (h.codes) hipHostFree(h.codes);
+				if (h.amb) hipHostFree(h.amb);
+				h.codes = nullptr; h.amb = nullptr;
+				h.cap_words = n_words + n_words / 16 + 64;
+				LQ_HIP_CHECK(hipHostMalloc((void**)&h.codes, h.cap_words * 8, 0));
+				LQ_HIP_CHECK(hipHostMalloc((void**)&h.amb, h.cap_words * 4, 0));
+			}
+			h.names.resize(name_bytes); h.name_off.resize(h.n + 1);
+			{ u64 o = 0; for (u32 i = 0; i < h.n; ++i) { const FlatRec &r = flat[r0 + i]; h.name_off[i] = o; memcpy(h.names.data() + o, r.name, r.name_len); h.names[o + r.name_len] = 0; o += r.name_len + 1; } h.name_off[h.n] = o; }
+			// pack, read by read, equal shares of bases per thread
+			int nt = K.parse_threads > 0 ? K.parse_threads : (int)std::min<unsigned>(64, std::max(1u, std::thread::hardware_concurrency()));
+			std::atomic<u32> next(0);
+			auto work = [&]() {
+				for (;;) {
+					const u32 i0 = next.fetch_add(64);
+					if (i0 >= h.n) break;
+					for (u32 i = i0; i < std::min<u32>(i0 + 64, h.n); ++i) {
+						const FlatRec &r = flat[r0 + i];
+						const u64 off[2] = {0, r.seq_len};
+						lq_pack_host(1, r.seq, off, h.codes + coff[i] * LQ_CHUNK_WORDS, h.amb + coff[i] * LQ_CHUNK_WORDS, 1);
+					}
+				}
+			};
+			if (nt <= 1 || h.n < 256) work();
+			else { std::vector<std::thread> th; for (int t = 0; t < nt; ++t) th.emplace_back(work); for (auto &t : th) t.join(); }
+		};
+		int n_built = 0;
+		auto build = [&](int slot, Part &pt) {                      // upload + sketch + index of hp[slot] (the build stream)
+			HostPart &h = hp[slot];
+			{	// (a Part object is used again: what lqcov_part_clear does)
+				ReadSetDev &rs = pt.rs;
+				rs.n = 0; rs.n_chunks = 0; rs.n_bases = 0; rs.n_mini = 0; rs.sketched = false;
+				rs.h_coff.assign(1, 0); rs.h_len.clear(); rs.names.clear();
+				pt.built = false; pt.n_keys = 0; pt.live = true;
+			}
+			if (h.packed) add_reads_packed(pt.rs, h.n, h.codes, h.amb, h.lens.data(), h.names.data(), h.name_off.data());
+			else for (ReadBatch &tb : h.bs) { add_reads(pt.rs, tb.size(), tb.seq.data(), tb.seq_off.data(), tb.names.data(), tb.name_off.data()); tb = ReadBatch(); }
 			sketch(pt.rs, true);
 			build_index(pt);
 			if (log) fprintf(log, "[lqcov] part %d: %u target sequence(s), %" PRIu64 " bases, %" PRIu64 " minimizers, %" PRIu64 " distinct, mid_occ = %d\n",
-			                 n_parts, pt.rs.n, pt.rs.n_bases, pt.rs.n_mini, pt.n_keys, mid_occ);
-			if (dump) dump_part(pt, dump);                        // mm_idx_reader_read (index.c:533)
-			if (query) {
-				map_part(pt);
-				if (log) fprintf(log, "[lqcov] part %d: mapped %u queries, %" PRIu64 " anchors (%" PRIu64 " written; so far %" PRIu64 " runs of %" PRIu64 " queries chained in klib's order, %" PRIu64 " anchors)\n",
-				                 n_parts, q.n, last_n_anchors, last_n_written, (u64)stat_sens_runs, (u64)stat_p2_queries, (u64)stat_p2_anchors);
+			                 n_built, pt.rs.n, pt.rs.n_bases, pt.rs.n_mini, pt.n_keys, mid_occ);
+			++n_built;
+			if (dump) dump_part(pt, dump);                          // mm_idx_reader_read (index.c:533)
+		};
+#ifndef LQ_EMU
+		const bool pipeline = K.pipeline && query && !dump && profiling != 1;
+#else
+		const bool pipeline = false;                                // (the test emulator runs one kernel at a time, on the calling thread)
+#endif
+		parts.emplace_back(new Part()); parts.emplace_back(new Part());
+		Part *dev[2] = { parts[parts.size() - 2].get(), parts[parts.size() - 1].get() };
+		produce(0);
+		if (!hp[0].empty()) {
+			std::future<void> fut_h;
+			if (!hp[0].last) fut_h = std::async(std::launch::async, produce, 1);
+			build(0, *dev[0]);
+			// the lanes size their work space from what is free when the first part stands: leave room for the part that is built meanwhile
+			if (pipeline && !hp[0].last && hbm_reserve == 0) hbm_reserve = (u64)((double)std::min<u64>(hp[0].bases, P.batch_size + (u64)chunk) * 9.5);
+			for (int k = 0;; ++k) {
+				const int cur = k & 1, nxt = cur ^ 1;
+				std::future<bool> next_ready;
+				auto advance = [&, k, nxt]() -> bool {                  // part k + 1 from the host, then the host starts on part k + 2
+					LQ_HIP_CHECK(hipSetDevice(device));
+					if (!fut_h.valid()) return false;
+					fut_h.get();
+					if (hp[nxt].empty()) return false;
+					build(nxt, *dev[nxt]);
+					if (!hp[nxt].last) fut_h = std::async(std::launch::async, produce, nxt ^ 1);   // (slot of part k: uploaded long ago)
+					return true;
+				};
+				if (pipeline) next_ready = std::async(std::launch::async, advance);
+				if (query) {
+					map_part(*dev[cur]);
+					if (log) fprintf(log, "[lqcov] part %d: mapped %u queries, %" PRIu64 " anchors (%" PRIu64 " written; so far %" PRIu64 " runs of %" PRIu64 " queries chained in klib's order, %" PRIu64 " anchors)\n",
+					                 n_parts, q.n, last_n_anchors, last_n_written, (u64)stat_sens_runs, (u64)stat_p2_queries, (u64)stat_p2_anchors);
+				}
+				++n_parts;
+				const bool more = pipeline ? next_ready.get() : advance();
+				if (!more) break;
 			}
-			parts[id].reset();
-			++n_parts;
+			if (fut_h.valid()) fut_h.get();
 		}
+		for (Part *d : dev) for (auto &up : parts) if (up.get() == d) up.reset();
 	}
 	if (!query) return 0;                                         // index only (minimap2-coverage.c:460-468)
 	finish();

@@ -51,6 +51,9 @@ struct Knobs {
 	bool filter = true;                   // LQCOV_FILTER=0: the first pass writes every seed hit (no counting filter)
 	u32 head_chunks = 1;                  // LQCOV_HEAD_CHUNKS: chunks of queries whose survivors are decided (k_seed_count) while the lanes map the chunk before (measured at configs[2]: 6 chunks 1160 ms per step, 10: 1404, 1: 888 -- more batches, more serial tails)
 	bool head_chunks_forced = false;
+	int parse_threads = 0;                // LQCOV_PARSE_THREADS: threads that parse and pack a plain target file (0: one per core, at most 64; 1: the streaming reader as for gzip)
+	u64 parse_piece = 32u << 20;          // LQCOV_PARSE_PIECE: bytes of the file a thread parses at a time (tests shrink it: many guessed record starts)
+	bool pipeline = true;                 // LQCOV_PIPELINE=0: run_files builds a part only after the one before is mapped
 	u32 chunk_batches = 2;                // LQCOV_CHUNK_BATCHES: batches a chunk is cut into at least (if it has the anchors for it)
 	bool filt_split = true;               // LQCOV_FILTER_SPLIT=0: the two strands of a target share its diagonal bins
 	u32 filt_keys = 1u << 19;             // LQCOV_FILTER_KEYS: counters of k_seed_count's table in use (tests shrink it: slices and aliasing on small inputs)
@@ -176,6 +179,7 @@ struct lqcov_handle {
 	DBuf dbg_chains, n_dbg; u64 dbg_cap = 0; u64 n_dbg_host = 0;
 	DBuf misc;
 	DBuf ix_key, ix_key2, ix_head, ix_uidx, ix_ukey, ix_ustart, ix_ucnt, ix_sorted;   // build_index workspaces
+	const Part *ix_owner = nullptr;       // the part ix_ukey / ix_ustart / ix_ucnt describe (dump_part reads them)
 	DBuf sk_cnt, sk_off, sk_owned, sk_mask, sk_flag, sk_toff, sk_trid, sk_grid;   // sketch: per-chunk minimizer counts / offsets, which kernel decides a chunk, emitted positions (a bit per base), tile offsets
 	u64 last_n_anchors = 0;
 	u64 anchor_budget = 0;
