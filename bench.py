@@ -104,6 +104,7 @@ def main():
     ap.add_argument("--reads", type=int, default=0, help="override the number of reads (default: the config's)")
     ap.add_argument("--nsample", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-end-to-end", action="store_true", help="skip the files-in / table-out call (lqcov_run_files on the workload written to tmpfs)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="target reads in the CPU baseline sample (~20-30 s of reference time)")
     ap.add_argument("--cache", default="", help="directory for the generated reads (re-used by later runs of the same config on this machine)")
     ap.add_argument("--index-size", default="", help="override the preset's -I (e.g. 2M: many index parts on a small input; tests)")
@@ -376,18 +377,52 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             n_t = args.cpu_sample or (25000 if args.config == "cfg3" else 35000)
             line["cpu_baseline"] = cpu_baseline(args.config, F, Q, n_t, len(Q) if n_t >= len(F) else max(50, n_t // 100))
-            # the reference on ALL reads and ALL queries of this workload, timed once on a GPU box's host cores (tools/gpu_evidence.sh,
-            # committed under profiles/): a figure from an earlier run, labelled as such, next to this run's bounded sample
-            fj = os.path.join(ROOT, "profiles", "r03_cpu_full_%s.json" % args.config)
-            if line["cpu_baseline"] and os.path.exists(fj):
-                try:
-                    line["cpu_baseline"]["full_job"] = json.load(open(fj))
-                except Exception:
-                    pass
         if one_dev:
             line["note"] = "LQCOV_BENCH_ONE_DEVICE test mode: all ranks share cuda:0 over gloo; not a scaling measurement"
-        print(json.dumps(line), flush=True)
     eng.close()
+    if rank == 0 and world == 1 and not args.no_end_to_end:
+        # The drop-in call as LongQC issues it (INTEGRATION.md level 1 / 2): files in, table out -- FASTA/Q parse (targets: plain
+        # FASTA on tmpfs, parsed from the mapping by the host's cores; queries: FASTQ), 2-bit packing, upload, every part, rows,
+        # formatting, with the parts in run_files' own pipeline.  SURVEY 8d: "once including it, to compare like-for-like with
+        # the oracle's Real time" (minimap2-coverage.c:732).  The table must equal the one of the timed steps.
+        del P
+        import shutil
+        base = "/dev/shm" if os.path.isdir("/dev/shm") and shutil.disk_usage("/dev/shm").free > 2.5 * total_bases + (1 << 30) else None
+        with tempfile.TemporaryDirectory(dir=base) as d:
+            tf, qf, of = os.path.join(d, "all.fa"), os.path.join(d, "sub.fq"), os.path.join(d, "out.tsv")
+            t0 = time.time()
+            synth.write_flat_fasta(tf, F)
+            synth.write_fastq(qf, Q)
+            t_write = time.time() - t0
+            best = None
+            for _ in range(2):                                                    # (the first call pages the file in and grows the buffers)
+                e2 = api.Engine(p, device=local)
+                t0 = time.time()
+                e2.run_files(tf, qf, out=of, err=os.path.join(d, "err.log"))
+                dt2 = time.time() - t0
+                e2.close()
+                best = dt2 if best is None else min(best, dt2)
+            same = open(of).read() == table
+            line["end_to_end"] = {"value": round(total_bases / best / 1e6, 3), "unit": "Mbases/s", "seconds": round(best, 3), "table_identical_to_timed_steps": same,
+                                  "files": "targets: plain FASTA (%.1f GB) on %s, queries: FASTQ; best of 2 calls" % (os.path.getsize(tf) / 1e9, base or "the temp dir"),
+                                  "what": "lqcov_run_files: parse (mapped file, %d host threads) + 2-bit pack + H2D + sketch + index + map of every part in run_files' pipeline + rows + table text" % min(64, os.cpu_count() or 1),
+                                  "log_tail": open(os.path.join(d, "err.log")).read().splitlines()[-6:], "file_write_s": round(t_write, 1)}
+            # the reference on the same files, all reads and all queries, when the host has the cores for it (measured, not quoted)
+            cores = os.cpu_count() or 1
+            from tests import oracle_bind
+            if cores >= 64 and oracle_bind.have_ref() and not args.no_cpu_baseline and line.get("cpu_baseline"):
+                t0 = time.time()
+                try:
+                    r = subprocess.run([oracle_bind.REF_BIN] + list(PRESET[args.config][1]) + ["-t", str(cores), tf, qf], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=600)
+                    dtr = time.time() - t0
+                    if r.returncode == 0:
+                        line["cpu_baseline"]["full_job"] = {"value": round(total_bases / dtr / 1e6, 3), "unit": "Mbases/s", "seconds": round(dtr, 1), "cores": cores, "kind": "reference",
+                                                            "sample": "ALL target reads and ALL queries of the workload, same files as end_to_end, measured in this run",
+                                                            "table_identical_to_gpu": r.stdout.decode() == table}
+                except subprocess.TimeoutExpired:
+                    pass
+    if rank == 0:
+        print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
 

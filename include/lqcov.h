@@ -190,6 +190,12 @@ uint64_t lqcov_last_n_anchors(const lqcov_handle *h);
  * since lqcov_reset: runs chained in klib's own order of equal-x anchors, the queries that own them, the anchors those
  * queries were sorted by klib's passes for.  No counterpart in the reference (it writes and sorts every hit). */
 void lqcov_map_stats(const lqcov_handle *h, uint64_t out[4]);
+/* The records of a FASTA/FASTQ file as the target reader sees them (kseq_read + the U -> T of kseq2bseq, kseq.h:179-224,
+ * bseq.c:56-66): out[0] = records, out[1] = bases, out[2] = a hash over the names, out[3] = a hash over the sequences, out[4] =
+ * pieces of the file that had to be parsed again in order (parallel reader only).  mode 0: the streaming reader (one thread,
+ * also gzip); mode 1: the reader over the mapped file with n_threads threads and pieces of piece_bytes (plain files only:
+ * LQCOV_E_ARG otherwise).  Both must agree on every input -- that is what this call is for (tests); no device needed. */
+int lqcov_fastx_digest(const char *path, int mode, int n_threads, uint64_t piece_bytes, uint64_t out[5]);
 /* minimizers of the query set / of a part, reference encoding (sketch.c:70-72): xy[2*i], xy[2*i+1];
  * off[n+1] per-read offsets.  Pass NULL buffers to get the total in *n_total. */
 int lqcov_get_query_minimizers(lqcov_handle *h, uint64_t *xy, uint64_t *off, uint64_t *n_total);

@@ -112,6 +112,7 @@ def load_library(path: Optional[str] = None):
         "lqcov_part_n_keys": (C.c_uint64, [H, C.c_int]),
         "lqcov_last_n_anchors": (C.c_uint64, [H]),
         "lqcov_map_stats": (None, [H, u64p]),
+        "lqcov_fastx_digest": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_uint64, u64p]),
         "lqcov_get_query_minimizers": (C.c_int, [H, C.c_void_p, C.c_void_p, u64p]),
         "lqcov_get_part_minimizers": (C.c_int, [H, C.c_int, C.c_void_p, C.c_void_p, u64p]),
         "lqcov_get_chains": (C.c_int, [H, C.c_void_p, C.c_uint64, u64p]),

@@ -2,6 +2,8 @@
 // reference's option table (minimap2-coverage.c:63-197, defaults :229-388) and thin extern "C"
 // wrappers that turn C++ exceptions into status codes.
 #include "engine.hpp"
+#include "fastx.hpp"
+#include "fastx_mem.hpp"
 #include <cstdio>
 #include <cstring>
 #include <cstdlib>
@@ -342,6 +344,33 @@ int32_t lqcov_mid_occ(const lqcov_handle *h) { return h ? h->mid_occ : -1; }
 uint64_t lqcov_part_n_minimizers(const lqcov_handle *h, int part) { return (h && part >= 0 && (size_t)part < h->parts.size() && h->parts[part]) ? h->parts[part]->rs.n_mini : 0; }
 uint64_t lqcov_part_n_keys(const lqcov_handle *h, int part) { return (h && part >= 0 && (size_t)part < h->parts.size() && h->parts[part]) ? h->parts[part]->n_keys : 0; }
 uint64_t lqcov_last_n_anchors(const lqcov_handle *h) { return h ? h->last_n_anchors : 0; }
+int lqcov_fastx_digest(const char *path, int mode, int n_threads, uint64_t piece_bytes, uint64_t out[5])
+{
+	if (!path || !out) return LQCOV_E_ARG;
+	try {
+		auto mix = [](u64 h, const u8 *p, size_t n, bool u2t) { for (size_t i = 0; i < n; ++i) { u8 c = p[i]; if (u2t && (c == 'u' || c == 'U')) --c; h = (h ^ c) * 0x100000001b3ULL; } return (h ^ (u64)n) * 0x9E3779B97F4A7C15ULL; };
+		u64 n = 0, b = 0, hn = 0xcbf29ce484222325ULL, hs = 0xcbf29ce484222325ULL, rep = 0;
+		if (mode == 0) {
+			FastxReader r(path);
+			std::string nm, sq, ql;
+			while (r.next(nm, sq, ql)) { ++n; b += sq.size(); hn = mix(hn, (const u8*)nm.data(), nm.size(), false); hs = mix(hs, (const u8*)sq.data(), sq.size(), true); }
+		} else {
+			MemFastx mf;
+			if (!mf.open(path)) return LQCOV_E_ARG;
+			MemRecords recs;
+			lq_parse_all(mf, n_threads, piece_bytes, recs);
+			for (MemPiece &pc : recs.pieces) for (MemRec &r : pc.recs) {
+				++n; b += r.seq_len;
+				hn = mix(hn, mf.data() + r.name_off, r.name_len, false);
+				hs = mix(hs, (r.own ? pc.side.data() : mf.data()) + r.seq_off, r.seq_len, true);
+			}
+			rep = recs.reparsed;
+		}
+		out[0] = n; out[1] = b; out[2] = hn; out[3] = hs; out[4] = rep;
+		return 0;
+	} catch (const std::exception &e) { fprintf(stderr, "lqcov_fastx_digest: %s\n", e.what()); return LQCOV_E_IO; }
+}
+
 void lqcov_map_stats(const lqcov_handle *h, uint64_t out[4])
 {
 	if (!out) return;

@@ -107,3 +107,76 @@ def test_lqexec_counterpart_shape(tmp_path):
         assert rc == 0 and open(out).read() == read_gz("tiny_ont.table.gz")
     else:
         assert rc == -3 and "HIP device" in open(err).read()
+
+
+# ---- the reader over the mapped file (fastx_mem.hpp) against the streaming reader (fastx.hpp), record for record -----------------
+def _digest(lib, path, mode, threads=4, piece=64):
+    import ctypes as C
+    out = (C.c_uint64 * 5)()
+    rc = lib.lqcov_fastx_digest(path.encode(), mode, threads, piece, out)
+    assert rc == 0, rc
+    return tuple(int(x) for x in out)
+
+
+def _dialects():
+    rng = np.random.default_rng(5)
+    A = np.frombuffer(b"ACGTNacgtnUu", dtype=np.uint8)
+
+    def seq(n):
+        return A[rng.integers(0, len(A), n)].tobytes()
+
+    def qual(n, first=None):
+        q = (33 + rng.integers(0, 60, n)).astype(np.uint8).tobytes()      # '@' (Q31), '+' (Q10), '>' (Q29) all occur, also at line starts
+        return (first + q[1:]) if first and n else q
+    recs = {}
+    # plain four-line FASTQ, quality lines that start with '@', '+' and '>'
+    recs["fastq"] = b"".join(b"@r%d desc\n%s\n+\n%s\n" % (i, s, qual(len(s), [b"@", b"+", b">", None][i % 4])) for i, s in ((i, seq(int(rng.integers(1, 300)))) for i in range(400)))
+    # CRLF, '+' line repeating the name, blank lines between records, no newline at the end
+    recs["crlf"] = b"".join(b"@r%d\tc\r\n%s\r\n+r%d\r\n%s\r\n%s" % (i, s, i, qual(len(s)), b"\r\n" if i % 5 == 0 else b"") for i, s in ((i, seq(int(rng.integers(2, 200)))) for i in range(300)))[:-2]
+    # wrapped FASTQ (sequence and quality over several lines): the guessed starts do not hold, the stitcher parses in order
+    def wrap(b, w):
+        return b"\n".join(b[j:j + w] for j in range(0, len(b), w))
+    recs["wrapped"] = b"".join(b"@w%d\n%s\n+\n%s\n" % (i, wrap(s, 50), wrap(qual(len(s), b"@" if i % 3 == 0 else None), 50)) for i, s in ((i, seq(int(rng.integers(1, 400)))) for i in range(200)))
+    # FASTA: one line, wrapped, CRLF, comments, empty sequences, a lone '>' at the end
+    recs["fasta"] = b"".join(b">f%d some comment\n%s\n" % (i, wrap(seq(int(rng.integers(0, 500))), [60, 1000, 7][i % 3])) for i in range(300)) + b">"
+    recs["fasta_crlf"] = b"".join(b">f%d\r\n%s\r\n" % (i, wrap(seq(int(rng.integers(1, 300))), 61).replace(b"\n", b"\r\n")) for i in range(200))
+    # mixed FASTA / FASTQ, garbage before the first record
+    recs["mixed"] = b"garbage line\n\n" + b"".join((b">m%d\n%s\n" % (i, seq(40))) if i % 2 else (b"@m%d\n%s\n+\n%s\n" % (i, seq(40), b"I" * 40)) for i in range(100))
+    # a truncated quality string ends the stream (kseq returns -2)
+    recs["truncated"] = b"".join(b"@t%d\n%s\n+\n%s\n" % (i, seq(30), b"I" * 30) for i in range(50)) + b"@bad\nACGTACGT\n+\nIII\n" + b"".join(b"@u%d\n%s\n+\n%s\n" % (i, seq(30), b"I" * 30) for i in range(50))
+    recs["empty"] = b""
+    recs["one"] = b"@a\nACGT\n+\nIIII"
+    return recs
+
+
+@pytest.mark.parametrize("name", sorted(_dialects()))
+def test_mapped_reader_equals_streaming_reader(emu_lib, tmp_path, name):
+    data = _dialects()[name]
+    fn = str(tmp_path / (name + ".fx"))
+    _write(fn, data)
+    want = _digest(emu_lib, fn, 0)
+    assert want[0] > 0 or name == "empty"
+    for piece in (64, 300, 5000, 1 << 20):
+        for threads in (1, 4):
+            got = _digest(emu_lib, fn, 1, threads, piece)
+            assert got[:4] == want[:4], (name, piece, threads)
+    if name == "fastq":
+        assert _digest(emu_lib, fn, 1, 4, 300)[4] == 0          # the guess holds on plain FASTQ even with '@' / '+' / '>' opening quality lines: nothing parsed twice
+    if name == "wrapped":
+        assert _digest(emu_lib, fn, 1, 4, 300)[4] > 0           # (and where it cannot hold, the stitcher notices)
+
+
+def test_run_files_parses_plain_targets_from_the_mapping(emu_lib, tmp_path, monkeypatch):
+    """the whole path on a plain FASTQ cut into tiny pieces and several index parts, against the gzip of the same file (streaming reader)"""
+    from tests.helpers import read_fastx
+    tn, ts, tq = read_fastx(os.path.join(GOLDEN, "tiny_all.fq.gz"))
+    plain = str(tmp_path / "all.fq")
+    _write(plain, b"".join(b"@" + n.encode() + b"\n" + s.tobytes() + b"\n+\n" + q.tobytes() + b"\n" for n, s, q in zip(tn, ts, tq)))
+    argv = ["-Y", "-l", "0", "-q", "160", "-k", "12", "-w", "5", "-I", "100K", "-p", "160"]
+    q = os.path.join(GOLDEN, "tiny_sub.fq.gz")
+    want = read_gz("tiny_parts.table.gz") if False else oracle_bind.table(argv + [os.path.join(GOLDEN, "tiny_all.fq.gz"), q])
+    monkeypatch.setenv("LQCOV_PARSE_PIECE", "3000"); monkeypatch.setenv("LQCOV_PARSE_THREADS", "3")
+    rc, out, err = run_main(emu_lib, argv + [plain, q])
+    assert rc == 0, err
+    assert out == want
+    assert "from the mapped file" in err and "part 3" in err
