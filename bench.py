@@ -406,7 +406,7 @@ def main():
             line["end_to_end"] = {"value": round(total_bases / best / 1e6, 3), "unit": "Mbases/s", "seconds": round(best, 3), "table_identical_to_timed_steps": same,
                                   "files": "targets: plain FASTA (%.1f GB) on %s, queries: FASTQ; best of 2 calls" % (os.path.getsize(tf) / 1e9, base or "the temp dir"),
                                   "what": "lqcov_run_files: parse (mapped file, %d host threads) + 2-bit pack + H2D + sketch + index + map of every part in run_files' pipeline + rows + table text" % min(64, os.cpu_count() or 1),
-                                  "log_tail": open(os.path.join(d, "err.log")).read().splitlines()[-6:], "file_write_s": round(t_write, 1)}
+                                  "log_tail": open(os.path.join(d, "err.log")).read().splitlines()[-8:], "file_write_s": round(t_write, 1)}
             # the reference on the same files, all reads and all queries, when the host has the cores for it (measured, not quoted)
             cores = os.cpu_count() or 1
             from tests import oracle_bind

@@ -1824,12 +1824,14 @@ int lqcov_handle::run_files(const char *target, const char *query, FILE *out, FI
 		fclose(t);
 	}
 	if (is_idx && dump_path) throw std::domain_error("-d with a prebuilt index as the target is not supported");
+	const double t_run0 = lq_now_s();
 	if (query) {
 		FastxReader fq(query);
 		ReadBatch qb;
 		while (fq.read_minibatch(INT64_MAX, qb, true) > 0) {}
+		const double tq = lq_now_s();
 		set_queries(qb.size(), qb.seq.data(), qb.seq_off.data(), qb.any_qual ? qb.qual.data() : nullptr, qb.names.data(), qb.name_off.data());
-		if (log) fprintf(log, "[lqcov] loaded %u query sequence(s), %" PRIu64 " bases, %" PRIu64 " minimizers\n", qb.size(), qb.bases(), q.n_mini);
+		if (log) fprintf(log, "[lqcov] loaded %u query sequence(s), %" PRIu64 " bases, %" PRIu64 " minimizers (read %.3f s, upload + sketch %.3f s)\n", qb.size(), qb.bases(), q.n_mini, tq - t_run0, lq_now_s() - tq);
 	}
 	FILE *dump = nullptr;
 	if (dump_path) { dump = fopen(dump_path, "wb"); if (!dump) throw std::runtime_error(std::string("failed to open file '") + dump_path + "'"); }
@@ -1900,8 +1902,11 @@ int lqcov_handle::run_files(const char *target, const char *query, FILE *out, FI
 			if (log) fprintf(log, "[lqcov] parsed %zu target sequence(s) from the mapped file in %.3f s (%zu pieces, %u parsed again in order), %zu part(s)\n",
 			                 flat.size(), lq_now_s() - t0, recs.pieces.size(), recs.reparsed, ranges.size());
 		} else ft.reset(new FastxReader(target));
+		double t_host[2] = {0, 0}, t_alloc[2] = {0, 0};
 		auto produce = [&](int slot) {
 			LQ_HIP_CHECK(hipSetDevice(device));                         // (may run on a thread of its own: page-locked allocations)
+			const double tp0 = lq_now_s();
+			struct Tm { double &t; double t0; ~Tm() { t = lq_now_s() - t0; } } tm{t_host[slot], tp0};
 			HostPart &h = hp[slot];
 			h.bs.clear(); h.n = 0; h.bases = 0; h.lens.clear(); h.names.clear(); h.name_off.assign(1, 0); h.last = false;
 			if (!mem) {
@@ -1927,6 +1932,7 @@ int lqcov_handle::run_files(const char *target, const char *query, FILE *out, FI
 			u64 name_bytes = 0;
 			for (u32 i = 0; i < h.n; ++i) { const FlatRec &r = flat[r0 + i]; h.lens[i] = r.seq_len; coff[i + 1] = coff[i] + ((u64)r.seq_len + LQ_CHUNK - 1) / LQ_CHUNK; h.bases += r.seq_len; name_bytes += r.name_len + 1; }
 			const u64 n_words = coff[h.n] * LQ_CHUNK_WORDS;
+			const double ta0 = lq_now_s();
 			if (n_words > h.cap_words) {
 				if (h.codes) hipHostFree(h.codes);
 				if (h.amb) hipHostFree(h.amb);
@@ -1934,6 +1940,7 @@ int lqcov_handle::run_files(const char *target, const char *query, FILE *out, FI
 				h.cap_words = n_words + n_words / 16 + 64;
 				LQ_HIP_CHECK(hipHostMalloc((void**)&h.codes, h.cap_words * 8, 0));
 				LQ_HIP_CHECK(hipHostMalloc((void**)&h.amb, h.cap_words * 4, 0));
+				t_alloc[slot] = lq_now_s() - ta0;
 			}
 			h.names.resize(name_bytes); h.name_off.resize(h.n + 1);
 			{ u64 o = 0; for (u32 i = 0; i < h.n; ++i) { const FlatRec &r = flat[r0 + i]; h.name_off[i] = o; memcpy(h.names.data() + o, r.name, r.name_len); h.names[o + r.name_len] = 0; o += r.name_len + 1; } h.name_off[h.n] = o; }
@@ -1963,12 +1970,14 @@ int lqcov_handle::run_files(const char *target, const char *query, FILE *out, FI
 				rs.h_coff.assign(1, 0); rs.h_len.clear(); rs.names.clear();
 				pt.built = false; pt.n_keys = 0; pt.live = true;
 			}
+			const double tb0 = lq_now_s();
 			if (h.packed) add_reads_packed(pt.rs, h.n, h.codes, h.amb, h.lens.data(), h.names.data(), h.name_off.data());
 			else for (ReadBatch &tb : h.bs) { add_reads(pt.rs, tb.size(), tb.seq.data(), tb.seq_off.data(), tb.names.data(), tb.name_off.data()); tb = ReadBatch(); }
+			const double tu = lq_now_s();
 			sketch(pt.rs, true);
 			build_index(pt);
-			if (log) fprintf(log, "[lqcov] part %d: %u target sequence(s), %" PRIu64 " bases, %" PRIu64 " minimizers, %" PRIu64 " distinct, mid_occ = %d\n",
-			                 n_built, pt.rs.n, pt.rs.n_bases, pt.rs.n_mini, pt.n_keys, mid_occ);
+			if (log) fprintf(log, "[lqcov] part %d: %u target sequence(s), %" PRIu64 " bases, %" PRIu64 " minimizers, %" PRIu64 " distinct, mid_occ = %d  (host %.3f s of which page-locked allocation %.3f, upload %.3f s, sketch + index %.3f s)\n",
+			                 n_built, pt.rs.n, pt.rs.n_bases, pt.rs.n_mini, pt.n_keys, mid_occ, t_host[slot], t_alloc[slot], tu - tb0, lq_now_s() - tu);
 			++n_built;
 			if (dump) dump_part(pt, dump);                          // mm_idx_reader_read (index.c:533)
 		};
@@ -2000,9 +2009,10 @@ int lqcov_handle::run_files(const char *target, const char *query, FILE *out, FI
 				};
 				if (pipeline) next_ready = std::async(std::launch::async, advance);
 				if (query) {
+					const double tm0 = lq_now_s();
 					map_part(*dev[cur]);
-					if (log) fprintf(log, "[lqcov] part %d: mapped %u queries, %" PRIu64 " anchors (%" PRIu64 " written; so far %" PRIu64 " runs of %" PRIu64 " queries chained in klib's order, %" PRIu64 " anchors)\n",
-					                 n_parts, q.n, last_n_anchors, last_n_written, (u64)stat_sens_runs, (u64)stat_p2_queries, (u64)stat_p2_anchors);
+					if (log) fprintf(log, "[lqcov] part %d: mapped %u queries in %.3f s, %" PRIu64 " anchors (%" PRIu64 " written; so far %" PRIu64 " runs of %" PRIu64 " queries chained in klib's order, %" PRIu64 " anchors)\n",
+					                 n_parts, q.n, lq_now_s() - tm0, last_n_anchors, last_n_written, (u64)stat_sens_runs, (u64)stat_p2_queries, (u64)stat_p2_anchors);
 				}
 				++n_parts;
 				const bool more = pipeline ? next_ready.get() : advance();
@@ -2013,8 +2023,10 @@ int lqcov_handle::run_files(const char *target, const char *query, FILE *out, FI
 		for (Part *d : dev) for (auto &up : parts) if (up.get() == d) up.reset();
 	}
 	if (!query) return 0;                                         // index only (minimap2-coverage.c:460-468)
+	const double tf0 = lq_now_s();
 	finish();
 	write_table(out);
+	if (log) fprintf(log, "[lqcov] rows and table in %.3f s; the whole call %.3f s\n", lq_now_s() - tf0, lq_now_s() - t_run0);
 	// A uint16 match counter that reaches 65535 makes the reference's result depend on the order in which it happened to
 	// process the chains (esterr.c:130,136 test a[st], not a[j]); the row is printed, but the run says so and does not
 	// report success.
