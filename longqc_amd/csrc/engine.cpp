@@ -1975,9 +1975,10 @@ int lqcov_handle::run_files(const char *target, const char *query, FILE *out, FI
 			else for (ReadBatch &tb : h.bs) { add_reads(pt.rs, tb.size(), tb.seq.data(), tb.seq_off.data(), tb.names.data(), tb.name_off.data()); tb = ReadBatch(); }
 			const double tu = lq_now_s();
 			sketch(pt.rs, true);
+			const double ts = lq_now_s();
 			build_index(pt);
-			if (log) fprintf(log, "[lqcov] part %d: %u target sequence(s), %" PRIu64 " bases, %" PRIu64 " minimizers, %" PRIu64 " distinct, mid_occ = %d  (host %.3f s of which page-locked allocation %.3f, upload %.3f s, sketch + index %.3f s)\n",
-			                 n_built, pt.rs.n, pt.rs.n_bases, pt.rs.n_mini, pt.n_keys, mid_occ, t_host[slot], t_alloc[slot], tu - tb0, lq_now_s() - tu);
+			if (log) fprintf(log, "[lqcov] part %d: %u target sequence(s), %" PRIu64 " bases, %" PRIu64 " minimizers, %" PRIu64 " distinct, mid_occ = %d  (host %.3f s of which page-locked allocation %.3f, upload %.3f s, sketch %.3f s, index %.3f s)\n",
+			                 n_built, pt.rs.n, pt.rs.n_bases, pt.rs.n_mini, pt.n_keys, mid_occ, t_host[slot], t_alloc[slot], tu - tb0, ts - tu, lq_now_s() - ts);
 			++n_built;
 			if (dump) dump_part(pt, dump);                          // mm_idx_reader_read (index.c:533)
 		};
@@ -2026,7 +2027,8 @@ int lqcov_handle::run_files(const char *target, const char *query, FILE *out, FI
 	const double tf0 = lq_now_s();
 	finish();
 	write_table(out);
-	if (log) fprintf(log, "[lqcov] rows and table in %.3f s; the whole call %.3f s\n", lq_now_s() - tf0, lq_now_s() - t_run0);
+	if (log) fprintf(log, "[lqcov] rows and table in %.3f s; the whole call %.3f s (device allocations of this process so far: %.3f s for %.1f GB)\n", lq_now_s() - tf0, lq_now_s() - t_run0,
+	                 (double)lq_alloc_ns * 1e-9, (double)lq_alloc_bytes * 1e-9);
 	// A uint16 match counter that reaches 65535 makes the reference's result depend on the order in which it happened to
 	// process the chains (esterr.c:130,136 test a[st], not a[j]); the row is printed, but the run says so and does not
 	// report success.

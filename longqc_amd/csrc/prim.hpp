@@ -39,6 +39,13 @@ inline thread_local hipStream_t lq_alloc_stream = nullptr;
 inline void lq_pool_keep_memory(int) {}
 #endif
 
+// time and bytes of device allocations (run_files reports them: a fresh process allocates its whole work space once)
+#include <atomic>
+#include <chrono>
+inline std::atomic<uint64_t> lq_alloc_ns{0}, lq_alloc_bytes{0};
+struct LqAllocTimer { std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now(); size_t bytes; explicit LqAllocTimer(size_t b) : bytes(b) {}
+	~LqAllocTimer() { lq_alloc_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(); lq_alloc_bytes += bytes; } };
+
 struct DBuf {
 	void *p = nullptr; size_t cap = 0;
 	hipStream_t pool_stream = nullptr;     // not null: the block came from the stream-ordered pool on this stream
@@ -46,6 +53,7 @@ struct DBuf {
 	{
 		if (bytes <= cap) return;
 		release();
+		LqAllocTimer alloc_timer(bytes);
 		size_t want = bytes + bytes / 8 + 256;
 #ifdef LQ_EXACT_ALLOC
 		want = bytes;                                              // (tools/emu_asan.sh: no slack, so that AddressSanitizer sees the first byte past what was asked for)
