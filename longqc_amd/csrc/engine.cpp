@@ -327,6 +327,9 @@ void lqcov_handle::sketch(ReadSetDev &rs, bool rid_in_y)
 {
 	hipStream_t stream = this->bstream; Prim &prim = this->bprim;   // the build side has a stream and scan / sort scratch of its own: a part can be built while another is mapped
 	(void)prim;
+	static const bool timing = getenv("LQCOV_TIMING") != nullptr;
+	double t_last = lq_now_s();
+	auto lap = [&](const char *what) { if (!timing) return; hipStreamSynchronize(stream); const double t = lq_now_s(); fprintf(stderr, "[timing] sketch %-28s %.3f s (allocations so far %.3f s)\n", what, t - t_last, (double)lq_alloc_ns * 1e-9); t_last = t; };
 	rs.d_coff.ensure((rs.n + 1) * 8); rs.d_len.ensure((rs.n + 1) * 4);
 	h2d(rs.d_coff.as<u64>(), rs.h_coff.data(), rs.n + 1, stream);
 	h2d(rs.d_len.as<u32>(), rs.h_len.data(), rs.n, stream);
@@ -335,8 +338,10 @@ void lqcov_handle::sketch(ReadSetDev &rs, bool rid_in_y)
 	const u64 nc = rs.n_chunks;
 	if (nc) {
 		SkParams sp; sp.k = P.k; sp.w = P.w; sp.hpc = P.hpc; sp.mask = (1ULL << 2 * P.k) - 1; sp.shift1 = 2 * (P.k - 1);
+		lap("offsets up");
 		DBuf &cnt = sk_cnt, &off = sk_off;
 		cnt.ensure(nc * 4); off.ensure(nc * 8);
+		lap("cnt/off ensure");
 		const u64 in_bytes = nc * (LQ_CHUNK_WORDS * 12);
 		// ring capacity 8 / 16 (LDS) or 256 (private), -H on/off: pick the instantiation
 		// chunks per thread: the halo before a thread's first chunk is walked once per kpt chunks
@@ -354,6 +359,7 @@ void lqcov_handle::sketch(ReadSetDev &rs, bool rid_in_y)
 			// second run of the machine, no halo for the output pass.
 			sk_mask.ensure(nc * LQ_CHUNK_WORDS * 4 + 64); sk_flag.ensure(4);
 			dzero(sk_mask.p, nc * LQ_CHUNK_WORDS * 4, stream); dzero(sk_flag.p, 4, stream);
+			lap("mask ensure + zero");
 			const bool dp = P.w <= 16 && P.w + P.k - 1 <= 48 && P.k <= 28 && P.k >= 2 && !K.sketch_machine_only;
 			const u8 *dp_owned = nullptr;
 			sk_grid.ensure((nc / LQ_EM_CH + 2) * 4);
@@ -376,6 +382,7 @@ void lqcov_handle::sketch(ReadSetDev &rs, bool rid_in_y)
 #undef LQ_DPM
 					check_launch();
 				}
+				lap("dp_mask");
 				dp_owned = sk_owned.as<u8>();
 				if (K.debug_sort) {
 					std::vector<u8> ho(nc);
@@ -390,6 +397,7 @@ void lqcov_handle::sketch(ReadSetDev &rs, bool rid_in_y)
 				LQ_SK_DISPATCH(LQ_SK_MASK, false, (u32*)nullptr, (const u64*)nullptr, (u64*)nullptr, (u64*)nullptr, dp_owned, sk_mask.as<u32>(), sk_flag.as<u32>());
 				check_launch();
 			}
+			lap("state machine");
 			LQ_LAUNCH(k_mask_count, nblk(nc, 256), 256, stream, sk_mask.as<u32>(), nc, cnt.as<u32>()); check_launch();
 		} else {
 			StageTimer t(this, stream, "k_sketch_count", in_bytes + nc * 4);
@@ -401,7 +409,9 @@ void lqcov_handle::sketch(ReadSetDev &rs, bool rid_in_y)
 		d2h(&last_off, off.as<u64>() + nc - 1, 1, stream);
 		d2h(&last_cnt, cnt.as<u32>() + nc - 1, 1, stream);
 		rs.n_mini = last_off + last_cnt;
+		lap("count + scan");
 		rs.mx.ensure(rs.n_mini * 8 + 8); rs.my.ensure(rs.n_mini * 8 + 8);
+		lap("mx/my ensure");
 		if (!P.hpc) {
 			u32 dup = 0;
 			d2h(&dup, sk_flag.as<u32>(), 1, stream);
@@ -417,6 +427,7 @@ void lqcov_handle::sketch(ReadSetDev &rs, bool rid_in_y)
 		}
 #undef LQ_SK_DISPATCH
 #undef LQ_SK_LAUNCH
+		lap("emit");
 		LQ_LAUNCH(k_read_moff, nblk(rs.n + 1, 256), 256, stream, rs.d_coff.as<u64>(), off.as<u64>(), rs.n, nc, rs.n_mini, rs.moff.as<u64>());
 		check_launch();
 		LQ_HIP_CHECK(hipStreamSynchronize(stream));
