@@ -166,11 +166,31 @@ lqcov_handle *lqcov_create(const lqcov_params *p, int device)
 	// one after the other: with the default never more than four of the lanes' kernels run at a time (rocprofv3 kernel trace,
 	// configs[2]).  Eight queues: 1.71-1.73 s per step against 1.74-1.77 (16: the same).  Only effective when the HIP runtime
 	// has not started yet in this process (the CLI, LongQC's exec); hosts that initialise HIP first set it themselves (bench.py).
-	setenv("GPU_MAX_HW_QUEUES", "8", 0);
+	// LQCOV_HW_QUEUES=n asks for n instead; LQCOV_HW_QUEUES=0 leaves the host process's environment alone (a host that shares
+	// the HIP runtime with other users -- torch in LqCovExec's in-process mode -- decides for itself).  A value already in the
+	// environment is never overwritten.
+	{
+		const char *hq = getenv("LQCOV_HW_QUEUES");
+		if (!hq || atoi(hq) > 0) setenv("GPU_MAX_HW_QUEUES", hq && atoi(hq) > 0 ? hq : "8", 0);
+	}
 	try { return new lqcov_handle(*p, device); }
 	catch (const std::exception &e) { g_create_error = e.what(); fprintf(stderr, "lqcov_create: %s\n", e.what()); return nullptr; }
 }
-void lqcov_destroy(lqcov_handle *h) { delete h; }
+void lqcov_destroy(lqcov_handle *h)
+{
+	if (!h) return;
+#ifndef LQ_EMU
+	const int dev = h->device;
+#endif
+	delete h;
+#ifndef LQ_EMU
+	// the lanes' work space came from HIP's stream-ordered pool, whose release threshold the handle raised (blocks given back
+	// stay cached): with the handle gone the cache goes back to the device -- the next handle (or another user of the GPU)
+	// would otherwise find the memory taken and pay for the trim in the middle of its first part (5 s for 170 GB, measured)
+	hipMemPool_t pool = nullptr;
+	if (hipSetDevice(dev) == hipSuccess && hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess && pool) { (void)hipDeviceSynchronize(); (void)hipMemPoolTrimTo(pool, 0); }
+#endif
+}
 const char *lqcov_last_error(const lqcov_handle *h) { return h ? h->err.c_str() : g_create_error.c_str(); }
 int lqcov_set_profiling(lqcov_handle *h, int on)
 {
@@ -633,7 +653,9 @@ int lqcov_main(int argc, const char *const *argv, const char *out_path, const ch
 		FILE *e2 = err_path ? fopen(err_path, "a") : stderr;
 		if (e2) { fprintf(e2, "ERROR: %s\n", h->err.c_str()); if (err_path) fclose(e2); }
 	}
-	lqcov_destroy(h);
+	// LQCOV_NO_TEARDOWN=1 (set by the executable's own main, which leaves with _exit): the process is about to end, and handing
+	// a few hundred GB back to the device block by block takes seconds that the caller would wait for
+	if (!getenv("LQCOV_NO_TEARDOWN")) lqcov_destroy(h);
 	return rc == 0 ? 0 : (rc == LQCOV_E_IO ? 1 : rc);
 }
 

@@ -3,9 +3,13 @@
 // longQC.py:438-446 hands to LqExec.  Device: $LQCOV_DEVICE (default 0).
 #include "../../include/lqcov.h"
 #include <cstdlib>
+#include <cstdio>
+#include <unistd.h>
 int main(int argc, char **argv)
 {
 	const char *d = getenv("LQCOV_DEVICE");
+	setenv("LQCOV_NO_TEARDOWN", "1", 0);            // this process ends with the call: no block-by-block release of the device memory (lqcov_main)
 	int rc = lqcov_main(argc, (const char *const *)argv, nullptr, nullptr, d ? atoi(d) : 0);
-	return rc == 0 ? 0 : (rc > 0 ? rc : 3);
+	fflush(stdout); fflush(stderr);
+	_exit(rc == 0 ? 0 : (rc > 0 ? rc : 3));         // (the driver reclaims everything at once)
 }
