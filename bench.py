@@ -37,13 +37,20 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 
+_ONT = ["-Y", "-l", "0", "-q", "160", "-k", "12", "-w", "5", "-I", "4G", "-p", "160"]
 PRESET = {   # the argv longQC.py issues for the config's platform (longQC.py:177-231,440-445)
-    "cfg2": ("ont-ligation", ["-Y", "-l", "0", "-q", "160", "-k", "12", "-w", "5", "-I", "4G", "-p", "160"]),
+    "cfg2": ("ont-ligation", _ONT),
     "cfg3": ("pb-sequel", ["-Y", "-l", "0", "-q", "160", "-k", "12", "-w", "5", "-I", "4G", "-p", "80"]),
+    "cfg4": ("ont-rapid", _ONT), "cfg4s": ("ont-rapid", _ONT),          # (ont-rapid and ont-ligation issue the same minimap parameters)
+    "cfg5": ("ont-ligation", _ONT), "cfg5s": ("ont-ligation", _ONT),
 }
 CONFIG_LABEL = {
     "cfg2": "BASELINE configs[1]: %d synthetic ONT reads ~%d kb %gx, ont-ligation preset (-Y -l 0 -q 160 -k 12 -w 5 -I 4G -p 160)",
     "cfg3": "BASELINE configs[2]: %d synthetic PacBio Sequel CLR reads ~%d kb %gx, pb-sequel preset (-Y -l 0 -q 160 -k 12 -w 5 -I 4G -p 80)",
+    "cfg4": "BASELINE configs[3]: %d synthetic ONT reads ~%d kb %gx, ont-rapid preset (-Y -l 0 -q 160 -k 12 -w 5 -I 4G -p 160)",
+    "cfg4s": "a slice of BASELINE configs[3] with index parts of real size: %d synthetic ONT reads ~%d kb %gx, ont-rapid preset (-Y -l 0 -q 160 -k 12 -w 5 -I 4G -p 160)",
+    "cfg5": "BASELINE configs[4]: %d synthetic ultra-long ONT reads (mean ~%d kb, N50 ~100 kb) %gx, ont-ligation preset (-Y -l 0 -q 160 -k 12 -w 5 -I 4G -p 160)",
+    "cfg5s": "a slice of BASELINE configs[4] with index parts of real size: %d synthetic ultra-long ONT reads (mean ~%d kb, N50 ~100 kb) %gx, ont-ligation preset (-Y -l 0 -q 160 -k 12 -w 5 -I 4G -p 160)",
 }
 
 
@@ -104,6 +111,9 @@ def main():
     ap.add_argument("--reads", type=int, default=0, help="override the number of reads (default: the config's)")
     ap.add_argument("--nsample", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--split", default="auto", choices=["auto", "queries", "parts"], help="N > 1: queries sharded over a replicated index | index parts across the GPUs | whichever the stage-rate model predicts faster")
+    ap.add_argument("--sharded-reads", action="store_true", help="N > 1: every rank generates only the reads of its shares (automatic for configs above 20 Gbases)")
+    ap.add_argument("--no-pipeline", action="store_true", help="N > 1: the front of part i + 1 (upload, sketch, all-gather, index) after the mapping of part i, not under it")
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the files-in / table-out call (lqcov_run_files on the workload written to tmpfs)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="target reads in the CPU baseline sample (~20-30 s of reference time)")
     ap.add_argument("--cache", default="", help="directory for the generated reads (re-used by later runs of the same config on this machine)")
@@ -131,7 +141,7 @@ def main():
 
     import dataclasses
     from longqc_amd import api, synth, multigpu
-    cfg = synth.CONFIGS[args.config]
+    cfg = synth.SCALE_SLICES[args.config] if args.config in synth.SCALE_SLICES else synth.CONFIGS[args.config]
     full_config = not args.reads and not args.nsample
     if args.reads:
         cfg = dataclasses.replace(cfg, n_reads=args.reads)
@@ -147,24 +157,62 @@ def main():
     genome = synth.make_genome(cfg)
     F = None
     cache = None
-    if args.cache:                                                                # A/B loops on one box: generate the reads once
-        cache = os.path.join(args.cache, "lqcov_%s_%d_seed%d" % (args.config, cfg.n_reads, cfg.seed))
-        if os.path.exists(cache + ".off.npy"):
-            F = synth.FlatReads(0, np.load(cache + ".flat.npy"), np.load(cache + ".off.npy"))
-    if F is None:
-        F = synth.make_reads_flat(cfg, genome, workers=args.workers)             # every read of the config, flat ASCII
-        if cache and rank == 0:
-            os.makedirs(args.cache, exist_ok=True)
-            np.save(cache + ".flat.npy", F.flat); np.save(cache + ".off.tmp.npy", F.off); os.replace(cache + ".off.tmp.npy", cache + ".off.npy")
+    sharded = world > 1 and (args.sharded_reads or cfg.n_reads * cfg.mean_len > 2e10)      # N GPUs on a big config: no rank holds all reads
+    if not sharded:
+        if args.cache:                                                            # A/B loops on one box: generate the reads once
+            cache = os.path.join(args.cache, "lqcov_%s_%d_seed%d" % (args.config, cfg.n_reads, cfg.seed))
+            if os.path.exists(cache + ".off.npy"):
+                F = synth.FlatReads(0, np.load(cache + ".flat.npy"), np.load(cache + ".off.npy"))
+        if F is None:
+            F = synth.make_reads_flat(cfg, genome, workers=args.workers)         # every read of the config, flat ASCII
+            if cache and rank == 0:
+                os.makedirs(args.cache, exist_ok=True)
+                np.save(cache + ".flat.npy", F.flat); np.save(cache + ".off.tmp.npy", F.off); os.replace(cache + ".off.tmp.npy", cache + ".off.npy")
+        lens = np.diff(F.off).astype(np.int64)
+        total_bases = float(F.n_bases)
+    else:
+        # Every rank generates a contiguous 1/N of the reads to learn their lengths (a read's length is only known once its errors
+        # are drawn), the lengths are all-gathered, the parts and every rank's shares of them follow from the lengths, and a rank
+        # then generates exactly the reads of its shares (every read has its own RNG stream: synth._one_read).
+        wk = args.workers or max(1, min(64, (os.cpu_count() or 1) // world))
+        n = cfg.n_reads
+        a0, b0 = n * rank // world, n * (rank + 1) // world
+        mine = np.diff(synth.make_reads_flat(cfg, genome, n_reads=b0 - a0, read_offset=a0, workers=wk).off).astype(np.int64)
+        got = [None] * world
+        dist.all_gather_object(got, mine)
+        lens = np.concatenate(got)
+        total_bases = float(lens.sum())
     qidx = synth.reservoir_subsample(cfg.n_reads, cfg.nsample)                   # LongQC's seed-7 subsample (lq_utils.py:371-411)
     Q = synth.make_reads(cfg, genome, indices=qidx)
-    t_gen = time.time() - t0
-    lens = np.diff(F.off).astype(np.int64)
     parts = multigpu.split_parts(lens, int(p.batch_size), int(p.idx_mini_batch))  # index.c:244,311-316
+    # N GPUs, two exact splits (longqc_amd/multigpu.py): queries sharded over a replicated index (the north star; its front --
+    # all-gather + index build -- does not shrink with N) or index parts across the GPUs (needs >= N parts to fill them).  The
+    # one the model of the measured single-GPU stage rates predicts to be faster runs, unless --split says otherwise.
+    part_bases = [int(lens[lo:hi].sum()) for lo, hi in parts]
+    split = "none"
+    if world > 1:
+        tq, tp = multigpu.QueryShardRunner.scaling_model(world, part_bases), multigpu.PartRunner.scaling_model(world, part_bases)
+        split = args.split if args.split != "auto" else ("parts" if tp < tq else "queries")
+    if split == "parts":
+        shares = [(0, hi - lo) if i % world == rank else (0, 0) for i, (lo, hi) in enumerate(parts)]      # whole parts, round robin
+    else:
+        shares = [multigpu.balanced_ranges(lens[lo:hi], world)[rank] for lo, hi in parts] if world > 1 else None
+    t_gen = time.time() - t0
     t0 = time.time()
-    P = api.PackedReads(F.flat, F.off, F.names())                                # what the parser thread does: 2-bit pack into pinned memory
+    if not sharded:
+        P = api.PackedReads(F.flat, F.off, F.names())                            # what the parser thread does: 2-bit pack into pinned memory
+        share_reads = [(P, lo + sa, lo + sb) for (lo, hi), (sa, sb) in zip(parts, shares)] if world > 1 else None
+    else:
+        share_reads = []
+        for (lo, hi), (sa, sb) in zip(parts, shares):
+            Fs = synth.make_reads_flat(cfg, genome, n_reads=sb - sa, read_offset=lo + sa, workers=wk)
+            share_reads.append((api.PackedReads(Fs.flat, Fs.off, Fs.names()), 0, sb - sa))
+            del Fs
+        P = None
     t_pack = time.time() - t0
-    total_bases = float(F.n_bases)
+
+    def names_of(lo, hi):
+        return ["r%07d" % i for i in range(lo, hi)]                               # (synth.FlatReads.names)
 
     eng = api.Engine(p, device=local)
     anchors = [0]
@@ -177,7 +225,7 @@ def main():
         if len(parts) > 1:
             # part i + 1 is uploaded, sketched and indexed (a host thread of its own, the engine's build stream) while part i is
             # mapped: the lanes leave room for the second part object (0.375 B per base of reads, 24 B per minimizer ~ 3 bases, tables)
-            eng.reserve_hbm(int(max(int(F.off[hi] - F.off[lo]) for lo, hi in parts[1:]) * 9.5))
+            eng.reserve_hbm(int(max(int(lens[lo:hi].sum()) for lo, hi in parts[1:]) * 9.5))
         import threading
 
         def build(i):
@@ -213,6 +261,32 @@ def main():
                     build(i + 1)                                  # (the CPU dry run of this script: the test emulator runs one kernel at a time)
             eng.finish()
             anchors[0] = a; written[0] = w; mstats[0] = eng.map_stats()
+    elif split == "parts":
+        # N GPUs, index parts across them: rounds of N consecutive parts, every rank uploads, sketches, indexes and maps ALL queries
+        # against its own part; mid_occ from part 0's owner (map.c:50), the COVT cap and avg_k replayed in part order from the
+        # all-gathered per-part lambdas (esterr.c:87,93-97), sums and counters all-reduced, intervals all-gathered.
+        dev = torch.device("cuda", local) if have_cuda else torch.device("cpu")
+        eng.set_queries(Q.names, Q.seqs, Q.quals)
+        prunner = multigpu.PartRunner(eng, world, rank, dev, [int(x.shape[0]) for x in Q.seqs])
+        pt = eng.part_begin()
+        table = [None]
+
+        def step(h2d=True):
+            prunner.begin()
+            a = 0
+            for base in range(0, len(parts), world):
+                mine = base + rank
+                pid = None
+                if mine < len(parts):
+                    Ps, s0, s1 = share_reads[mine]
+                    eng.part_clear(pt); eng.part_add_packed(pt, Ps, s0, s1); eng.part_build(pt)
+                    pid = pt
+                prunner.map_and_combine(pid, part_index=mine, mid_occ_owner=0, share_mid_occ=(base == 0))
+                if pid is not None:
+                    a += eng.last_n_anchors
+            eng.finish()
+            table[0] = eng.table_text() if rank == 0 else None
+            anchors[0] = a; mstats[0] = eng.map_stats()
     else:
         # N GPUs, the north-star split (longqc_amd/multigpu.py): every rank sketches 1/N of each part, the minimizers are
         # all-gathered over RCCL, every rank builds the same index and maps its 1/N of the queries; rows gathered on rank 0.
@@ -220,25 +294,24 @@ def main():
         dev = torch.device("cuda", local) if have_cuda else torch.device("cpu")
         runner = multigpu.QueryShardRunner(eng, world, rank, dev)
         runner.set_queries(Q.names, Q.seqs, Q.quals)
-        pt = eng.part_begin()
-        names_all = F.names()
+        pts = [eng.part_begin(), eng.part_begin()]
         plan = []
-        for (lo, hi) in parts:
-            a, b = multigpu.balanced_ranges(lens[lo:hi], world)[rank]
-            plan.append((lo + a, lo + b, a, api.encode_names(names_all[lo:hi]), lens[lo:hi].astype(np.uint32)))
+        for (lo, hi), (sa, sb), (Ps, s0, s1) in zip(parts, shares, share_reads):
+            def add(pt, Ps=Ps, s0=s0, s1=s1):
+                if s1 > s0:
+                    eng.part_add_packed(pt, Ps, s0, s1)
+            plan.append((add, sa, api.encode_names(names_of(lo, hi)), lens[lo:hi].astype(np.uint32)))
+        if len(parts) > 1 and have_cuda:
+            # room for the part whose front runs under the mapping (a second part object: 24 B per minimizer ~ 8 B per base, its
+            # tables) and for the exchange buffers (2.2 x 16 B per minimizer)
+            eng.reserve_hbm(int(max(int(lens[lo:hi].sum()) for lo, hi in parts[1:]) * (9.5 + 12.0)))
         table = [None]
 
         def step(h2d=True):
             eng.reset()
-            a = 0
-            for (s0, s1, rid_base, nm, ln) in plan:
-                eng.part_clear(pt)
-                if s1 > s0:
-                    eng.part_add_packed(pt, P, s0, s1)
-                runner.map_part(pt, rid_base, nm, ln)
-                a += eng.last_n_anchors
+            anchors[0] = runner.map_parts(pts, plan, pipeline=have_cuda and not args.no_pipeline)
             table[0] = runner.gather_table()
-            anchors[0] = a; mstats[0] = eng.map_stats()
+            mstats[0] = eng.map_stats()
 
     if args.front_only and world == 1:
         best = {}
@@ -252,7 +325,7 @@ def main():
             st = {s["name"]: round(s["total_ms"], 2) for s in eng.stage_times() if s["total_ms"] > 0.05}
             if not best or wall < best["wall_ms"]:
                 best = {"wall_ms": round(wall, 2), "stages_ms": st}
-        print(json.dumps({"front_only": True, "part_bases": int(F.off[parts[0][1]] - F.off[parts[0][0]]), "best_of": max(args.steps, 1), **best}))
+        print(json.dumps({"front_only": True, "part_bases": int(lens[parts[0][0]:parts[0][1]].sum()), "best_of": max(args.steps, 1), **best}))
         return
 
     def barrier():
@@ -357,15 +430,20 @@ def main():
             "higher_is_better": True, "scaling": "weak" if world == 1 else "strong", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "config": {"workload": (CONFIG_LABEL[args.config] % (cfg.n_reads, cfg.mean_len // 1000, cfg.depth)) + ", %d subsample queries" % len(Q)
                                    + (" [-I overridden: %s]" % args.index_size if args.index_size else ""),
-                       "index_parts": [int(F.off[hi] - F.off[lo]) for lo, hi in parts],
+                       "index_parts": [int(lens[lo:hi].sum()) for lo, hi in parts],
                        "target_bases": int(total_bases), "query_bases": int(Q.n_bases), "anchors_per_step": int(n_anchors),
                        "anchors_written_per_step": int(written[0]) if world == 1 else None,      # seed hits whose (strand, target) can reach a chain: the others are never written
                        "klib_order": {k: v for k, v in (mstats[0] or {}).items() if k != "last_written"},   # runs / queries / anchors that needed klib's own order of equal-x anchors (second pass)
                        "clock": "H2D of the packed reads (pinned) -> sketch -> index -> seed -> sort -> chain -> coverage -> rows D2H, all parts (SURVEY 8d), "
                                 + ("part i+1's upload + sketch + index under part i's mapping; " if world == 1 and len(parts) > 1 else "") +
                                 "before the clock: the synthetic generator (= FASTQ parse) and the host-side 2-bit packing (host_pack_s) -- value_incl_host_pack adds the latter, unoverlapped",
-                       "parallelism": "single GPU" if world == 1 else "%d GPUs: queries sharded 1/N, index replicated (each rank sketches 1/N of a part, "
-                                      "minimizers all-gathered over RCCL, identical index everywhere), rows gathered on rank 0" % world},
+                       "parallelism": "single GPU" if world == 1 else
+                                      ("%d GPUs: index parts across the GPUs in rounds of %d, every rank maps all queries against its part; mid_occ broadcast from part 0, COVT cap and "
+                                       "avg_k replayed in part order, sums all-reduced, intervals all-gathered (RCCL)" % (world, world)) if split == "parts" else
+                                      ("%d GPUs: queries sharded 1/N, index replicated (each rank sketches 1/N of a part, minimizers all-gathered over RCCL, identical index everywhere; "
+                                       "the front of part i + 1 under the mapping of part i), rows gathered on rank 0" % world),
+                       "scaling_model_s": None if world == 1 else {"queries_sharded": round(tq, 3), "parts_across_gpus": round(tp, 3), "single_gpu": round(multigpu.QueryShardRunner.scaling_model(1, part_bases), 3),
+                                                                   "note": "predicted seconds per job from the single-GPU stage rates of round 4 (longqc_amd/multigpu.py); the faster split runs"}},
             "roofline": roof,
             "host_pack_s": round(t_pack, 3), "synth_gen_s": round(t_gen, 2),
             "value_incl_host_pack": round(total_bases / (ms_per_step / 1e3 + t_pack) / 1e6, 3),
@@ -375,7 +453,7 @@ def main():
         if full_config:
             line["golden_rows"] = golden_check(args.config, table)
         if world == 1 and not args.no_cpu_baseline:
-            n_t = args.cpu_sample or (25000 if args.config == "cfg3" else 35000)
+            n_t = args.cpu_sample or {"cfg3": 25000, "cfg2": 35000, "cfg4": 15000, "cfg4s": 15000, "cfg5": 5000, "cfg5s": 5000}.get(args.config, 25000)
             line["cpu_baseline"] = cpu_baseline(args.config, F, Q, n_t, len(Q) if n_t >= len(F) else max(50, n_t // 100))
         if one_dev:
             line["note"] = "LQCOV_BENCH_ONE_DEVICE test mode: all ranks share cuda:0 over gloo; not a scaling measurement"

@@ -15,19 +15,21 @@
 
 static thread_local std::string g_create_error;
 
+// (one thread may build a part while another maps: both may fail, the message is written under the handle's lock)
+static void set_err(lqcov_handle *h, const char *what) { std::lock_guard<std::mutex> g(h->stage_mu); h->err = what; }
 template <class F> static int guard(lqcov_handle *h, F &&f)
 {
 	if (!h) return LQCOV_E_ARG;
 	try { f(); return 0; }
-	catch (const std::invalid_argument &e) { h->err = e.what(); return LQCOV_E_ARG; }
-	catch (const std::domain_error &e) { h->err = e.what(); return LQCOV_E_DOMAIN; }
-	catch (const std::logic_error &e) { h->err = e.what(); return LQCOV_E_STATE; }
-	catch (const std::ios_base::failure &e) { h->err = e.what(); return LQCOV_E_IO; }
+	catch (const std::invalid_argument &e) { set_err(h, e.what()); return LQCOV_E_ARG; }
+	catch (const std::domain_error &e) { set_err(h, e.what()); return LQCOV_E_DOMAIN; }
+	catch (const std::logic_error &e) { set_err(h, e.what()); return LQCOV_E_STATE; }
+	catch (const std::ios_base::failure &e) { set_err(h, e.what()); return LQCOV_E_IO; }
 	catch (const std::runtime_error &e) {
-		h->err = e.what();
-		return h->err.find("failed to open") != std::string::npos ? LQCOV_E_IO : LQCOV_E_DEVICE;
+		set_err(h, e.what());
+		return strstr(e.what(), "failed to open") ? LQCOV_E_IO : LQCOV_E_DEVICE;
 	}
-	catch (const std::exception &e) { h->err = e.what(); return LQCOV_E_DEVICE; }
+	catch (const std::exception &e) { set_err(h, e.what()); return LQCOV_E_DEVICE; }
 }
 
 extern "C" {

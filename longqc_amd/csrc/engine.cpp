@@ -54,7 +54,7 @@ StageTimer::~StageTimer()
 {
 	if (!on) return;
 	hipEventRecord(b, s);
-	if (h->profiling == 1) { hipEventSynchronize(b); h->account_stage(name, a, b, bytes); }
+	if (h->profiling == 1) { hipEventSynchronize(b); std::lock_guard<std::mutex> g(h->stage_mu); h->account_stage(name, a, b, bytes); }
 	else { std::lock_guard<std::mutex> g(h->stage_mu); h->stage_pending.push_back(lqcov_handle::StagePending{name, a, b, bytes}); }   // read later: nothing waits here
 }
 void lqcov_handle::account_stage(const char *name, hipEvent_t a, hipEvent_t b, u64 bytes)

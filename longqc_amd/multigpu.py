@@ -139,6 +139,14 @@ class PartRunner:
     """Drives one handle per rank through rounds of `world` concurrent parts and keeps the combined
     accumulators; `finalize()` imports them into the handle so that lqcov_finish() produces the rows."""
 
+    @staticmethod
+    def scaling_model(world: int, part_bases, upload_s_per_gbase=0.0065, sketch_s_per_gbase=0.013, index_s_per_gbase=0.030, map_s_per_gbase=0.19) -> float:
+        """seconds per job predicted for `world` GPUs: rounds of `world` consecutive parts, a round lasts as long as its largest
+        part takes on one GPU (front + mapping of every query; the exchange is a few KB per part).  Same MI355X figures as
+        QueryShardRunner.scaling_model."""
+        per = [(upload_s_per_gbase + sketch_s_per_gbase + index_s_per_gbase + map_s_per_gbase) * b / 1e9 for b in part_bases]
+        return sum(max(per[i:i + world]) for i in range(0, len(per), world))
+
     def __init__(self, eng, world: int, rank: int, device: torch.device, query_lengths, group=None):
         self.eng, self.world, self.rank, self.dev, self.group = eng, world, rank, device, group
         eng.set_distributed(True)
@@ -276,10 +284,92 @@ class QueryShardRunner:
         self.eng.set_queries([names[i] for i in self.my_queries], [seqs[i] for i in self.my_queries],
                              [quals[i] for i in self.my_queries] if quals is not None else None)
 
+    # ---- the parts in a pipeline (the reference's part loop, minimap2-coverage.c:449-458, overlapped) --------------------------
+    # On N GPUs the front of a part -- upload and sketch of this rank's 1/N share, the all-gather, the replicated index build --
+    # does not shrink with N the way the mapping does (queries are independent, minimap2-coverage.c:434: the mapping is 1/N).  So the
+    # front of part i + 1 runs on a host thread of its own (the engine's build stream, a second part object, persistent
+    # exchange buffers) while part i is mapped; a part then costs max(front, mapping) instead of their sum:
+    #     t(N) ~ front(part 0) + sum over parts of max(front_i(N), map_i / N),   front_i(N) = upload_i / N + sketch_i / N + gather_i(N) + index_i
+    # (scaling_model below).  Every rank's front thread issues the same collectives in the same order, the mapping issues none.
+    def front(self, part: int, add_share, rid_base: int, all_names, all_lens):
+        """the front of one part into part object `part`: add_share(part) uploads this rank's share of its reads (reads
+        [rid_base, ...) of the part, possibly none), then sketch, all-gather, replicated index build"""
+        eng = self.eng
+        eng.part_clear(part)
+        add_share(part)
+        self._exchange_and_build(part, rid_base, all_names, all_lens, trim=False)
+
+    def map_parts(self, parts, shares, pipeline: Optional[bool] = None):
+        """parts: two part objects; shares: one (add_share, rid_base, all_names, all_lens) per index part, in file order.
+        pipeline (default: on a GPU): the front of part i + 1 under the mapping of part i.  Returns the anchors of all parts."""
+        import threading
+        if pipeline is None:
+            pipeline = self.dev.type == "cuda"
+        shares = list(shares)
+        anchors = 0
+        if not shares:
+            return 0
+        self.front(parts[0], *shares[0])
+        for i in range(len(shares)):
+            th, err = None, []
+            if i + 1 < len(shares):
+                if pipeline:
+                    def run(j=i + 1):
+                        try:
+                            if self.dev.type == "cuda":
+                                torch.cuda.set_device(self.dev)
+                            self.front(parts[j & 1], *shares[j])
+                        except BaseException as e:       # (a thread's exception would vanish: carried to the caller)
+                            err.append(e)
+                    th = threading.Thread(target=run); th.start()
+            self.eng.part_map(parts[i & 1])
+            anchors += self.eng.last_n_anchors
+            if th is not None:
+                th.join()
+                if err:
+                    raise err[0]
+            elif i + 1 < len(shares):
+                self.front(parts[(i + 1) & 1], *shares[i + 1])
+        return anchors
+
+    @staticmethod
+    def scaling_model(world: int, part_bases, upload_s_per_gbase=0.0065, sketch_s_per_gbase=0.013, index_s_per_gbase=0.030, map_s_per_gbase=0.19,
+                      link_gbytes_per_s=153.0, minimizers_per_base=1.0 / 3.0, pipelined=True) -> float:
+        """seconds per job predicted for `world` GPUs (the defaults: MI355X figures measured at configs[2] in round 4 -- upload 26 ms,
+        sketch 52 ms, index build incl. sort and table 120 ms, mapping incl. the survivor count 0.75 s per 4.0 Gbases; ring
+        all-gather bound by one xGMI link).  tools/scale.sh prints it beside what it measures."""
+        t, prev_map = 0.0, None
+        for b in part_bases:
+            g = b / 1e9
+            gather = 0.0 if world == 1 else (world - 1) / world * (g * 1e9 * minimizers_per_base * 16) / (link_gbytes_per_s * 1e9)
+            front = (upload_s_per_gbase + sketch_s_per_gbase) * g / world + gather + index_s_per_gbase * g
+            mp = map_s_per_gbase * g / world
+            if prev_map is None or not pipelined:
+                t += front if prev_map is None else front + prev_map
+            else:
+                t += max(front, prev_map)
+            prev_map = mp
+        return t + (prev_map or 0.0)
+
+    def _ensure_exchange(self, cap: int):
+        """send (cap words) and receive (world * cap words) buffers of the minimizer exchange, kept from part to part"""
+        have = getattr(self, "_ex_cap", 0)
+        if cap > have:
+            self._ex = None
+            cap2 = cap + cap // 16 + 1024
+            self._ex = [torch.empty(cap2, dtype=torch.int64, device=self.dev) for _ in range(2)] + \
+                       ([torch.empty(self.world * cap2, dtype=torch.int64, device=self.dev) for _ in range(2)] if self.world > 1 else [])
+            self._ex_cap = cap2
+        return self._ex
+
     def map_part(self, part: int, rid_base: int, all_names, all_lens):
         """`part` holds this rank's contiguous share of the index part's reads (reads [rid_base, ...) of the part, possibly
         none); all_names / all_lens describe every read of the part in order.  Sketch the share, all-gather the minimizers,
         build the replicated index, map this rank's queries.  The part can be cleared / released afterwards."""
+        self._exchange_and_build(part, rid_base, all_names, all_lens, trim=True)
+        self.eng.part_map(part)
+
+    def _exchange_and_build(self, part: int, rid_base: int, all_names, all_lens, trim: bool):
         eng, dev, world = self.eng, self.dev, self.world
         eng.part_sketch(part)
         n_mine = eng.part_n_minimizers(part)
@@ -295,25 +385,43 @@ class QueryShardRunner:
         cap = max(max(sizes), 1)
         self.last_sizes = sizes
         self.last_exchange_bytes = exchange_peak_bytes(sizes, world)      # (tests assert the bound)
-        if dev.type == "cuda" and world > 1:
-            # the lanes' work space of the previous part is still held by the engine's pool, which torch's allocator cannot
-            # draw from: give it back first if what is free would not do
-            need = self.last_exchange_bytes
-            if torch.cuda.mem_get_info(dev)[0] < need + need // 4:
-                eng.workspace_trim()
-        xs = torch.empty(cap, dtype=torch.int64, device=dev); ys = torch.empty(cap, dtype=torch.int64, device=dev)
-        eng.part_minimizers_export(part, xs.data_ptr(), ys.data_ptr(), cap, rid_base)
-        if world > 1:
-            gx = _all_gather_into(xs, world, self.group); gy = _all_gather_into(ys, world, self.group)   # RCCL all-gather over xGMI
-            del xs, ys
+        if trim:
+            if dev.type == "cuda" and world > 1:
+                # the lanes' work space of the previous part is still held by the engine's pool, which torch's allocator cannot
+                # draw from: give it back first if what is free would not do
+                need = self.last_exchange_bytes
+                if torch.cuda.mem_get_info(dev)[0] < need + need // 4:
+                    eng.workspace_trim()
+            xs = torch.empty(cap, dtype=torch.int64, device=dev); ys = torch.empty(cap, dtype=torch.int64, device=dev)
+            eng.part_minimizers_export(part, xs.data_ptr(), ys.data_ptr(), cap, rid_base)
+            if world > 1:
+                gx = _all_gather_into(xs, world, self.group); gy = _all_gather_into(ys, world, self.group)   # RCCL all-gather over xGMI
+                del xs, ys
+            else:
+                gx, gy = xs, ys
+            stride = cap
         else:
-            gx, gy = xs, ys
+            # pipelined: buffers kept from part to part (no allocation, trim or cache flush beside a running mapping), the
+            # gather straight into the persistent receive buffers
+            ex = self._ensure_exchange(cap)
+            stride = self._ex_cap
+            xs, ys = ex[0], ex[1]
+            eng.part_minimizers_export(part, xs.data_ptr(), ys.data_ptr(), stride, rid_base)
+            if world > 1:
+                gx, gy = ex[2], ex[3]
+                if dist.get_backend(self.group) == "gloo":
+                    gx.copy_(_all_gather_into(xs, world, self.group)); gy.copy_(_all_gather_into(ys, world, self.group))
+                else:
+                    dist.all_gather_into_tensor(gx, xs, group=self.group); dist.all_gather_into_tensor(gy, ys, group=self.group)   # RCCL all-gather over xGMI
+                    torch.cuda.current_stream(dev).synchronize()
+            else:
+                gx, gy = xs, ys
         eng.part_clear(part)                                      # the share's reads are no longer needed: the part becomes the whole index part
-        eng.part_build_from_minimizer_shares_dev(part, gx.data_ptr(), gy.data_ptr(), cap, sizes, np.asarray(all_lens, dtype=np.uint32), all_names)
-        del gx, gy
-        if dev.type == "cuda":
-            torch.cuda.empty_cache()                              # the exchange buffers go back to the device: the mapping sizes its work space from what is free
-        eng.part_map(part)
+        eng.part_build_from_minimizer_shares_dev(part, gx.data_ptr(), gy.data_ptr(), stride, sizes, np.asarray(all_lens, dtype=np.uint32), all_names)
+        if trim:
+            del gx, gy
+            if dev.type == "cuda":
+                torch.cuda.empty_cache()                          # the exchange buffers go back to the device: the mapping sizes its work space from what is free
 
     def gather_table(self) -> Optional[str]:
         """finish on every rank; rank 0 returns the table of all queries in the caller's order, the others None.  What travels

@@ -65,6 +65,14 @@ CONFIGS = {
 }
 
 
+# slices of the 8-GPU configs whose index parts have REAL size (-I 4G): what one GPU can be checked on against rows the
+# reference printed in the build container (tests/golden/make_scale_golden.py -> tests/golden/<name>_rows.json)
+SCALE_SLICES = {
+    "cfg4s": dataclasses.replace(CONFIGS["cfg4"], name="cfg4s", n_reads=600000),    # 12 Gbases: three 4-Gbase parts and a rest
+    "cfg5s": dataclasses.replace(CONFIGS["cfg5"], name="cfg5s", n_reads=75000),     # 4.5 Gbases of ~60-kb reads (N50 ~100 kb), 5000 queries ~ 300 Mbases
+}
+
+
 def make_genome(cfg: SynthConfig) -> np.ndarray:
     rng = np.random.default_rng(cfg.seed)
     G = cfg.genome_len

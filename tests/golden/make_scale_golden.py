@@ -31,14 +31,20 @@ N_HEAD, N_LONG = 30, 10
 ARGV = {
     "cfg3": ["-Y", "-l", "0", "-q", "160", "-k", "12", "-w", "5", "-I", "4G", "-p", "80"],    # pb-sequel (longQC.py:171-220)
     "cfg2": ["-Y", "-l", "0", "-q", "160", "-k", "12", "-w", "5", "-I", "4G", "-p", "160"],   # ont-ligation
+    "cfg4s": ["-Y", "-l", "0", "-q", "160", "-k", "12", "-w", "5", "-I", "4G", "-p", "160"],  # ont-rapid: the same minimap parameters (longQC.py:177-231)
+    "cfg5s": ["-Y", "-l", "0", "-q", "160", "-k", "12", "-w", "5", "-I", "4G", "-p", "160"],
 }
+# Slices of the 8-GPU configs with index parts of REAL size (-I 4G): SCALE_SLICES in longqc_amd/synth.py --
+#   cfg4s: the first 600 000 reads' worth of BASELINE configs[3] (ONT ~20 kb, 40x): 12 Gbases = three 4-Gbase parts + a rest;
+#   cfg5s: 75 000 reads of configs[4] (N50 100 kb): 4.5 Gbases = two parts, and a query set of 5000 reads ~ 300 Mbases, near
+#          the 500-Mbase limit of one query mini-batch (bseq.c:86-98).
 
 
 def main():
     name = sys.argv[1]
     work = sys.argv[2] if len(sys.argv) > 2 else "/tmp/scale_golden"
     os.makedirs(work, exist_ok=True)
-    cfg = synth.CONFIGS[name]
+    cfg = synth.SCALE_SLICES[name] if name in synth.SCALE_SLICES else synth.CONFIGS[name]
     t0 = time.time()
     genome = synth.make_genome(cfg)
     tf = os.path.join(work, name + "_all.fa")

@@ -489,3 +489,42 @@ def test_gpu_observable_ties_scheme(gpu_lib, tmp_path, monkeypatch, seed, env):
 
 def test_gpu_filter_drops_chance_hits(gpu_lib, tmp_path):
     E.check_filter_drops_chance_hits(gpu_lib, tmp_path)
+
+
+def test_gpu_run_files_pipeline_on_a_plain_file_in_many_parts(gpu_lib, tmp_path, monkeypatch):
+    """lqcov_run_files' own pipeline on the GPU: a plain FASTQ parsed from the mapping in tiny pieces, four index parts, part k + 1
+    uploaded, sketched and indexed by a second host thread while part k is mapped; against the oracle on the gzip of the same reads"""
+    H.test_run_files_parses_plain_targets_from_the_mapping(gpu_lib, tmp_path, monkeypatch)
+
+
+@pytest.mark.parametrize("name", ["cfg4s", "cfg5s"])
+def test_gpu_real_size_parts_rows_equal_the_reference_fixture(gpu_lib, name):
+    """index parts of REAL size (-I 4G): cfg4s = 600 000 ONT reads ~20 kb of configs[3] (12 Gbases: three 4-Gbase parts and a rest;
+    mid_occ frozen from part 0, map.c:50; COVT across real parts, esterr.c:87), cfg5s = 75 000 ultra-long reads of configs[4]
+    (4.5 Gbases, 5000 queries ~ 300 Mbases: near the 500-Mbase limit of one query mini-batch, bseq.c:86-98).  40 rows each as the
+    reference binary printed them in the build container (tests/golden/make_scale_golden.py)."""
+    fx = os.path.join(GOLDEN, name + "_rows.json")
+    if not os.path.exists(fx):
+        pytest.skip("fixture not made")
+    g = json.load(open(fx))
+    cfg = synth.SCALE_SLICES[name]
+    genome = synth.make_genome(cfg)
+    F = synth.make_reads_flat(cfg, genome)
+    Q = synth.make_reads(cfg, genome, indices=synth.reservoir_subsample(cfg.n_reads, cfg.nsample))
+    p, _, _ = api.parse_args(g["argv"] + ["t", "q"])
+    from longqc_amd import multigpu
+    lens = np.diff(F.off).astype(np.int64)
+    parts = multigpu.split_parts(lens, int(p.batch_size), int(p.idx_mini_batch))
+    assert len(parts) >= (3 if name == "cfg4s" else 2)
+    P = api.PackedReads(F.flat, F.off, F.names())
+    eng = api.Engine(p, device=0, lib=gpu_lib)
+    eng.set_queries(Q.names, Q.seqs, Q.quals)
+    pt = eng.part_begin()
+    for lo, hi in parts:
+        eng.part_clear(pt); eng.part_add_packed(pt, P, lo, hi); eng.part_build(pt); eng.part_map(pt)
+    eng.finish()
+    lines = eng.table_text().splitlines()
+    st = eng.map_stats()
+    eng.close()
+    bad = [s for s, row in zip(g["subsample_slots"], g["rows"]) if lines[s] != row]
+    assert not bad, (bad[:5], st)

@@ -90,7 +90,7 @@ def test_two_ranks_gloo_equal_reference_multipart_table(emu_lib, tmp_path, world
 
 
 # ---- queries sharded, index replicated (BASELINE.json's north star) ----
-def _worker_qshard(rank, world, port, argv_I, out_path, use_gpu=False):
+def _worker_qshard(rank, world, port, argv_I, out_path, use_gpu=False, parts_api=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -103,6 +103,23 @@ def _worker_qshard(rank, world, port, argv_I, out_path, use_gpu=False):
         runner = multigpu.QueryShardRunner(eng, world, rank, torch.device("cuda", 0) if use_gpu else torch.device("cpu"))
         runner.set_queries(qn, qs, qq)
         lens = [int(s.shape[0]) for s in ts]
+        if parts_api:
+            # the parts in a pipeline: two part objects, the front of part i + 1 (upload, sketch, all-gather, index) on a host
+            # thread under the mapping of part i (on a GPU; one after the other on the test emulator), persistent exchange buffers
+            plan = []
+            for (s, e) in multigpu.split_parts(lens, argv_I):
+                lo, hi = multigpu.balanced_ranges(lens[s:e], world)[rank]
+
+                def add(pt, s=s, lo=lo, hi=hi):
+                    if hi > lo:
+                        eng.part_add_targets(pt, tn[s + lo:s + hi], ts[s + lo:s + hi])
+                plan.append((add, lo, tn[s:e], lens[s:e]))
+            runner.map_parts([eng.part_begin(), eng.part_begin()], plan)
+            table = runner.gather_table()
+            if rank == 0:
+                open(out_path, "w").write(table)
+            eng.close()
+            return
         pid = eng.part_begin()
         for (s, e) in multigpu.split_parts(lens, argv_I):
             lo, hi = multigpu.balanced_ranges(lens[s:e], world)[rank]
@@ -126,6 +143,26 @@ def test_query_sharded_replicated_index_equals_reference_table(emu_lib, tmp_path
     out = str(tmp_path / "t.tsv")
     mp.spawn(_worker_qshard, args=(world, _free_port(), I, out), nprocs=world, join=True)
     assert open(out).read() == read_gz(expect)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_query_sharded_parts_in_a_pipeline_equal_reference_table(emu_lib, tmp_path, world):
+    """QueryShardRunner.map_parts: the same split with two part objects and persistent exchange buffers (the fronts run under the
+    mappings on a GPU; here one after the other), 10 parts with the COVT cap"""
+    out = str(tmp_path / "t.tsv")
+    mp.spawn(_worker_qshard, args=(world, _free_port(), 100000, out, False, True), nprocs=world, join=True)
+    assert open(out).read() == read_gz("adv_parts.table.gz")
+
+
+def test_scaling_model_of_the_pipelined_parts():
+    """configs[3] (25 parts of 4 Gbases): the front of a part (all-gather + replicated index build) does not shrink with N like its
+    mapping does; putting the fronts under the mappings helps, index parts across the GPUs help more when there are parts enough"""
+    parts = [4.0e9] * 25
+    t1 = multigpu.QueryShardRunner.scaling_model(1, parts)
+    q8, q8_serial = multigpu.QueryShardRunner.scaling_model(8, parts, pipelined=True), multigpu.QueryShardRunner.scaling_model(8, parts, pipelined=False)
+    assert q8 < 0.8 * q8_serial and 2.5 < t1 / q8 < 3.5              # bound by the replicated front: all-gather + index build per part
+    p8 = multigpu.PartRunner.scaling_model(8, parts)
+    assert t1 / p8 > 4.5 and p8 < q8                                  # 25 parts over 8 GPUs: four rounds -- the split bench.py then picks
 
 
 def test_balanced_ranges_and_query_shards():
