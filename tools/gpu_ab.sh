@@ -10,7 +10,7 @@ N=0
 for V in "${VS[@]}"; do
   E="$V"; [ "$V" = base ] && E=""
   N=$((N+1))
-  env $E timeout ${LIMIT:-300} python bench.py --config ${CFG:-cfg3} --steps ${STEPS:-3} --warmup 1 --no-cpu-baseline --no-end-to-end --cache /tmp/lqcov_cache 2>gpurun_out/ab_err.log | tail -1 | tee gpurun_out/ab_$N.json | python -c "
+  env $E timeout ${LIMIT:-300} python bench.py --config ${CFG:-cfg3} --steps ${STEPS:-3} --warmup 1 --no-cpu-baseline --no-end-to-end --no-north-star --cache /tmp/lqcov_cache 2>gpurun_out/ab_err.log | tail -1 | tee gpurun_out/ab_$N.json | python -c "
 import sys, json
 try:
     j = json.loads(sys.stdin.read())

@@ -16,14 +16,14 @@ CPU=""; [ "$CPUFULL" = 1 ] && CPU="--cpu-sample 500000"
 echo "bench done $(( $(date +%s) - T0 )) s" >> gpurun_out/pytest_gpu.log
 ( timeout 150 python bench.py --config cfg2 --steps 3 --warmup 1 --no-cpu-baseline --no-end-to-end $C 2>&1 | tail -1 ) > gpurun_out/bench_cfg2.json
 cd /tmp && export TMPDIR=/tmp
-B="python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-end-to-end $C"
+B="python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-end-to-end --no-north-star $C"
 ( timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -o b -- $B 2>&1 | tail -1 ) > $GRAFT_REPO_ROOT/gpurun_out/rocprof.log 2>&1
 cp /tmp/prof/b_kernel_stats.csv $GRAFT_REPO_ROOT/gpurun_out/kernel_stats_bench_cfg3.csv 2>/dev/null
 echo "rocprof done $(( $(date +%s) - T0 )) s" >> $GRAFT_REPO_ROOT/gpurun_out/pytest_gpu.log
 if [ "$PMC" = 1 ]; then
   R=$GRAFT_REPO_ROOT
   RE=${PMC_RE:-'k_seed_count|k_seed_emit|k_ps_finish|k_ps_scatter|k_ps_hist|k_chain|k_run_list|k_rs_scatter|k_rs_hist|k_sort_walk_solo|k_ck_chain256|k_sketch'}
-  BP="python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-end-to-end $C"
+  BP="python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-end-to-end --no-north-star $C"
   for CN in FETCH_SIZE WRITE_SIZE; do
     ( timeout ${PMC_LIMIT:-300} rocprofv3 --pmc $CN --kernel-trace --kernel-include-regex "$RE" --output-format csv -d /tmp/pmc_$CN -o p -- $BP 2>&1 | tail -3 ) > $R/gpurun_out/pmc_$CN.log 2>&1
     echo "pmc $CN done $(( $(date +%s) - T0 )) s" >> $R/gpurun_out/pytest_gpu.log
