@@ -280,7 +280,10 @@ k_seed_emit(const u64 *qx, const u64 *qy, const u32 *owner, const u64 *qmoff, u6
 // together with a sort that does not need klib's walk over the *whole* query: map_batch's first pass.
 #define LQ_FT_WORDS 32768u                  // 128 KiB of LDS: 524288 two-bit counters
 #define LQ_FC_THREADS 1024
-#define LQ_FC_GROUP 8                        // lanes to a minimizer: one 64-byte line of its occurrence list a step
+#ifndef LQ_FC_GROUP
+#define LQ_FC_GROUP 8                        // lanes to a minimizer (8 or 16): one or two 64-byte lines of its occurrence list a step
+#endif
+#define LQ_FC_GMASK ((1u << LQ_FC_GROUP) - 1u)
 #define LQ_FC_UNROLL 4                       // minimizers a group walks at a time
 struct FiltParams { u32 n_min /* 0 or 1: no filter */, n_targets, keys_cap /* counters in use: a power of two in [256, 16 * LQ_FT_WORDS] (tests shrink it) */, a_cap /* hits per slice aimed at */, dshift /* log2 D, D > bw */,
                     split_strands /* 1: a set of bins per (target, strand); 0: the two strands of a target share its bins (twice the chance hits per bin, half the slices) */; };
@@ -378,7 +381,7 @@ __device__ __forceinline__ void lq_seed_sweep(u32 *tab, FMeta *meta, const u64 *
 				const u32 d = (u32)((i32)rpos - (rs ? yr[u] : ys[u]));
 				key = ((rid - S.r_lo) << S.bpp_log) + (rs ? S.rs_off : 0u); bin = (d >> fp.dshift) & S.nb_mask;
 			}
-			const u32 pastb = (u32)(__ballot(valid && rid >= S.r_hi) >> gsh) & 0xffu;   // hits of later slices
+			const u32 pastb = (u32)(__ballot(valid && rid >= S.r_hi) >> gsh) & LQ_FC_GMASK;   // hits of later slices
 			const bool ends = more[u] && (pastb || c[u] + LQ_FC_GROUP >= n[u]);
 			if (COUNT) {
 				if (pass) lq_ft_inc(tab, key + bin);
@@ -388,9 +391,12 @@ __device__ __forceinline__ void lq_seed_sweep(u32 *tab, FMeta *meta, const u64 *
 					if (S.self_q && rpos == (qp[u] >> 1) && lq_is_self(self_off, self_rid, S.q, rid)) pass = false;   // lqmap.c:180-186
 					if (pass && ava.t_rank && ava.t_rank[rid] < S.qlo) pass = false;                                      // lqmap.c:187
 				}
-				const u32 bits = (u32)(__ballot(pass) >> gsh) & 0xffu;
+				const u32 bits = (u32)(__ballot(pass) >> gsh) & LQ_FC_GMASK;
 				if (gl == 0 && more[u]) {
-					if (bits) { fm[u][c[u] >> 3] |= (u8)bits; cnt[u] += (u32)__popc(bits); }
+					if (bits) {
+						if (LQ_FC_GROUP == 8) fm[u][c[u] >> 3] |= (u8)bits; else *(u16*)(fm[u] + (c[u] >> 3)) |= (u16)bits;   // (c is a multiple of the group size; the bitmap of a minimizer starts on 8 bytes)
+						cnt[u] += (u32)__popc(bits);
+					}
 					if (ends) {                                       // the piece is done: survivors of this slice, and where the next slice goes on
 						if (cnt[u]) cntf[jn[u]] += cnt[u];
 						meta[jn[u]].cursor = pastb ? c[u] + (u32)__ffs(pastb) - 1 : n[u];
