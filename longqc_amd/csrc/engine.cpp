@@ -1350,7 +1350,10 @@ void lqcov_handle::map_part(Part &pt)
 		size_t fr = 0, tot = 0;
 		hipMemGetInfo(&fr, &tot);
 		if (fr > hbm_reserve) fr -= hbm_reserve; else fr = 0;     // (lqcov_reserve_hbm: e.g. the part the caller builds while this one is mapped)
-		anchor_budget = (u64)((double)fr * 0.85 / 104.0 / n_lanes);
+		// (0.75 since round 4: a lane's buffers now grow in more steps -- a small first pass, second passes of varying size -- and a
+		// block the stream-ordered pool got back is not always the one the next, larger request can use; at 0.85 the ultra-long
+		// slice of configs[4] ran the device out of memory inside the runtime (HSA_STATUS_ERROR_OUT_OF_RESOURCES))
+		anchor_budget = (u64)((double)fr * 0.75 / 104.0 / n_lanes);
 	}
 	if (anchor_budget > (1ULL << 31) - 4096) anchor_budget = (1ULL << 31) - 4096;   // (a record names its anchor in 31 bits)
 	if (anchor_budget < 1024) anchor_budget = 1024;
