@@ -647,24 +647,64 @@ k_chain(const mm128 *A, const u64 *gstart, const u32 *glist, u32 n_list, const u
 	}
 }
 
-// Long runs, one wave per run.  A chain kernel ends when its longest run ends, and the serial DP of a repeat-rich
-// run (thousands of anchors, tens of candidate predecessors each, several dependent loads per candidate) is that
-// tail.  Here the 64 lanes score 64 candidate predecessors j = i-1, i-2, ... of anchor i at once (coalesced loads
-// of a[j], f[j], p[j]); the order-dependent part of chain.c:48-77 -- strict '>' keeps the nearest best, the skip
-// counter counts candidates that an already-scanned anchor chose as predecessor (t[j] == i), and the scan breaks
-// after max_skip of them -- is then replayed by lane 0 over the 64 results in scan order.  Marks t[p[j]] = i are
-// written for the whole chunk before the stamps are read: a mark can only concern a later-scanned candidate
-// (p[j] < j), and marks of candidates beyond the break are never looked at.  DP state stays in global memory;
-// __syncthreads() orders it inside the workgroup.  The second half (chain ends, backtrack, regs, coverage) is the
-// serial lq_chain_finish on lane 0.
+// Long runs, one wave per run.  A chain kernel ends when its longest run ends, and the serial DP of a long run (a true
+// overlap: hundreds to tens of thousands of anchors, tens of candidate predecessors each) is that tail.  The 64 lanes score
+// the 64 nearest candidate predecessors j = i-1 .. i-64 of anchor i at once.
+//   * Those candidates are, but for one, the candidates of the step before: every lane keeps its candidate's x, y, f, p, v in
+//     registers, the window moves by one lane per anchor (__shfl_up) and lane 0 takes the anchor just finished -- no load of
+//     a[j], f[j], p[j] per step (round 3: three dependent global round trips per anchor, ~4 us an anchor; 15 s of a 24-s step
+//     on the ultra-long slice of configs[4]).
+//   * The marks t[p[j]] = i (chain.c:76) of candidates inside the window live in a 64-entry LDS array of stamps (slot = index
+//     mod 64, one anchor per slot while it is in the window); a mark for an older anchor goes to t[] in global memory, where the
+//     rare chunks beyond the window look for it.  Marks are written for the whole chunk before the stamps are read: a mark can
+//     only concern a later-scanned candidate (p[j] < j), and marks of candidates beyond the break are never looked at.
+//   * The order-dependent part of chain.c:48-77 -- strict '>' keeps the nearest best, the skip counter counts candidates that
+//     an already-scanned anchor chose as predecessor (t[j] == i) and forgives one per new best, the scan breaks after max_skip
+//     of them -- is a pair of scans over the wave: "new best" is a prefix maximum, the counter a composition of maps
+//     x -> max(x + a, b) (new best: (-1, 0); skip: (+1, -inf); neither: (0, -inf)), closed under composition.  Six shuffle
+//     steps each instead of a loop of 64 on lane 0.  Where the order of equal-x anchors might show (tie_mode 1: two candidates
+//     of equal x inside the band of this scan) and for the rare candidates beyond the window, lane 0 replays the rules one by
+//     one as before (TieGroup keeps its state across chunks).
+// f, p, v are still written to global memory (the second half reads them); __syncthreads() in a block of one wave is a wait
+// for the wave's own memory operations.  The second half (chain ends, backtrack, regs, coverage) is the serial
+// lq_chain_finish on lane 0.
 #define LQ_CHAIN_WAVE_MIN 48      // measured on MI355X at configs[1]: 192 -> 206 ms, 96 -> 193, 48 -> 184, 24 -> 197 (k_chain + k_chain_wave)
 struct WaveCand { i32 sc, j, flags; u32 x32; };             // flags: bit0 = passes the filters, bit1 = t[j] == i; x32: low word of the candidate's x
+
+// lane 0: the scan-order rules over the `cnt` staged candidates of one chunk; state in st_sh ([0] max_f, [1] max_j, [2] n_skip,
+// [3] done, [4] the order of equal-x anchors may matter, [5..8] the scan's open TieGroup)
+__device__ __forceinline__ void lq_wave_replay(const WaveCand *cand, i32 *st_sh, i64 cnt, bool more_beyond, bool watch, i32 max_skip)
+{
+	i32 max_f = st_sh[0], max_j = st_sh[1], n_skip = st_sh[2], done = 0;
+	TieGroup tg; tg.x = (u32)st_sh[5]; tg.m = st_sh[6]; tg.top = st_sh[7]; tg.st = (u32)st_sh[8];
+	for (i64 c = 0; c < cnt; ++c) {
+		const WaveCand w = cand[c];
+		if (!(w.flags & 1)) continue;
+		if (watch && tg.see(w.x32, w.sc, (w.flags & 2) != 0, max_f, n_skip)) st_sh[4] = 1;   // (TieGroup, above lq_chain_fill)
+		if (w.sc > max_f) { max_f = w.sc; max_j = w.j; if (n_skip > 0) --n_skip; }
+		else if (w.flags & 2) {
+			if (++n_skip > max_skip) {                                                  // chain.c:72-73
+				if (watch) {	// tie partners the scan no longer reaches (if they go on into the next 64: assume the worst)
+					i64 c2 = c + 1;
+					for (; c2 < cnt && cand[c2].x32 == w.x32; ++c2) if ((cand[c2].flags & 1) && !tg.quiet(cand[c2].sc, (cand[c2].flags & 2) != 0)) st_sh[4] = 1;
+					if (c2 == cnt && more_beyond) st_sh[4] = 1;
+				}
+				done = 1; break;
+			}
+		}
+	}
+	if (watch && (done || !more_beyond) && tg.bad()) st_sh[4] = 1;                     // the scan's last group
+	st_sh[0] = max_f; st_sh[1] = max_j; st_sh[2] = n_skip; st_sh[3] = done;
+	st_sh[5] = (i32)tg.x; st_sh[6] = tg.m; st_sh[7] = tg.top; st_sh[8] = (i32)tg.st;
+}
+
 __global__ void __launch_bounds__(64)
 k_chain_wave(const mm128 *A, const u64 *gstart, const u32 *glist, u32 n_list, const u64 *aq_off, u64 a_base, u32 n_q, u32 q0,
              const float *avg_qspan_q, MapParams P, ChainBufs B, CovState C)
 {
 	LQ_SHARED WaveCand cand[64];
-	LQ_SHARED i32 st_sh[10];                                 // [0] max_f, [1] max_j, [2] n_skip, [3] done, [4] the order of equal-x anchors may matter, [5..8] the scan's open TieGroup (x, m, top, st)
+	LQ_SHARED i32 st_sh[10];
+	LQ_SHARED i32 stamp[64];                                 // stamp[j & 63] == i  <=>  t[j] == i, for the anchors j of the window [i - 64, i - 1]
 	if (blockIdx.x >= n_list) return;
 	const u32 g = glist[blockIdx.x];
 	const u64 gs = LQ_RUN_START(gstart[g]);
@@ -677,92 +717,144 @@ k_chain_wave(const mm128 *A, const u64 *gstart, const u32 *glist, u32 n_list, co
 	if (!accumulate && !C.dbg) return;
 	if (C.tie_mode == 2 && !lq_tie_wanted(C, q, lq_hi32(a))) return;
 	const bool watch = C.tie_mode == 1;
-	LQ_BLOCK_LOOP(ln) { if (ln == 0) st_sh[4] = 0; }
+	const u32 ln = threadIdx.x;
+	if (ln == 0) st_sh[4] = 0;
+	stamp[ln] = -1;
 	i32 *f = B.f + gs, *p = B.p + gs, *t = B.t + gs, *v = B.v + gs;
 	u64 *u = B.u + gs;
 	const float avg_qspan = avg_qspan_q[q];
 	const i32 max_dist = P.max_gap, bw = P.bw, max_skip = P.max_skip;
-	LQ_BLOCK_LOOP(ln) { for (i64 i = ln; i < n; i += blockDim.x) t[i] = 0; }
+	for (i64 i = ln; i < n; i += 64) t[i] = 0;
 	LQ_BLOCK_SYNC();
 	i64 st = 0;
+	u32 wx = 0; i32 wy = 0, wf = 0, wp = -1, wv = 0;         // lane c: x (low word), y, f, p, v of anchor i - 1 - c
+	mm128 ai = a[0];
 	for (i64 i = 0; i < n; ++i) {
-		const u64 ri = a[i].x;
-		const i32 qi = (i32)a[i].y, q_span = (i32)(a[i].y >> 32 & 0xff);
+		const mm128 an = i + 1 < n ? a[i + 1] : ai;             // (the next anchor is on its way while this one is scored)
+		const u64 ri = ai.x;
+		const i32 qi = (i32)ai.y, q_span = (i32)(ai.y >> 32 & 0xff);
 		while (st < i && ri - a[st].x > (u64)max_dist) ++st;    // uniform: every lane computes the same st
-		LQ_BLOCK_LOOP(ln) { if (ln == 0) { st_sh[0] = q_span; st_sh[1] = -1; st_sh[2] = 0; st_sh[3] = 0; st_sh[8] = 0; } }
+		i32 max_f = q_span, max_j = -1, n_skip = 0, done = 0;
+		// ---- the 64 nearest candidates, from the window ----
+		const i64 j = i - 1 - (i64)ln;
+		bool active = false; i32 sc = 0;
+		if (j >= st) {
+			const i64 dr = (i64)((u32)ri - wx);                 // (the high words are equal inside a run)
+			const i32 dq = qi - wy;
+			if (!(dr == 0 || dq <= 0 || dq > max_dist)) {
+				const i32 dd = dr > dq ? (i32)(dr - dq) : (i32)(dq - dr);
+				if (dd <= bw) {
+					const i32 min_d = dq < dr ? dq : (i32)dr;
+					sc = min_d > q_span ? q_span : min_d;
+					const i32 log_dd = dd ? lq_ilog2_32((u32)dd) : 0;
+					sc -= (i32)((double)dd * .01 * (double)avg_qspan) + (log_dd >> 1);     // chain.c:67
+					sc += wf;
+					active = true;
+					if (wp >= 0) { if ((i64)wp >= i - 64) stamp[wp & 63] = (i32)i; else t[wp] = (i32)i; }   // chain.c:76
+				}
+			}
+		}
 		LQ_BLOCK_SYNC();
-		for (i64 top = i - 1; top >= st; top -= 64) {
-			// phase 1: 64 candidates in parallel
-			LQ_BLOCK_LOOP(ln) {
-				const i64 j = top - (i64)ln;
-				WaveCand c; c.sc = 0; c.j = (i32)j; c.flags = 0; c.x32 = 0;
-				if (j >= st) {
-					const mm128 aj = a[j];
-					c.x32 = (u32)aj.x;
+		const bool tm = active && stamp[(u32)j & 63u] == (i32)i;
+		// two candidates of equal x inside the band, or one at the window's end whose tie partners may lie beyond: one by one
+		bool serial = false;
+		if (watch) {
+			const u64 act = __ballot(active);
+			const u32 px = __shfl_up(wx, 1);
+			const bool head = ln == 0 || wx != px;
+			const u64 H = __ballot(head);
+			const u32 lo = 63u - (u32)__clzll(H & (~0ULL >> (63 - ln)));                           // my run of equal x starts at lane lo ...
+			const u64 above = ln == 63 ? 0 : (H >> (ln + 1)) << (ln + 1);
+			const u32 hi = above ? (u32)__builtin_ctzll(above) - 1 : 63u;                         // ... and ends at lane hi
+			const u64 gm = (~0ULL >> (63 - hi)) & (~0ULL << lo);
+			serial = active && (__popcll(act & gm) >= 2 || (hi == 63 && i - 65 >= st));
+			serial = __ballot(serial) != 0;
+		}
+		if (!serial) {
+			// new bests: candidates whose score beats everything scanned before them
+			i32 inc = active ? sc : (i32)0x80000000;
+			for (int d = 1; d < 64; d <<= 1) { const i32 o = __shfl_up(inc, d); if ((int)ln >= d && o > inc) inc = o; }
+			i32 exc = __shfl_up(inc, 1); if (ln == 0) exc = (i32)0x80000000;
+			if (exc < max_f) exc = max_f;
+			const bool rec = active && sc > exc;
+			const bool skp = active && !rec && tm;
+			// the skip counter after every candidate: x -> max(x + fa, fb), composed in scan order
+			i32 fa = rec ? -1 : skp ? 1 : 0, fb = rec ? 0 : -(1 << 29);
+			for (int d = 1; d < 64; d <<= 1) {
+				const i32 oa = __shfl_up(fa, d), ob = __shfl_up(fb, d);
+				if ((int)ln >= d) { const i32 nb = ob + fa; fb = nb > fb ? nb : fb; fa = oa + fa; }
+			}
+			const i32 x_after = fa > fb ? fa : fb;               // (the counter starts at 0 with every anchor)
+			const u64 brk = __ballot(skp && x_after > max_skip);
+			const u32 cb = brk ? (u32)__builtin_ctzll(brk) : 64u;   // the scan ends at candidate cb (chain.c:72-73)
+			const u64 recm = __ballot(rec) & (cb >= 63 ? ~0ULL : (2ULL << cb) - 1);
+			if (recm) { const int last = 63 - __clzll(recm); max_f = __shfl(sc, last); max_j = (i32)(i - 1 - last); }
+			done = cb < 64 ? 1 : 0;
+			n_skip = __shfl(x_after, 63);
+		} else {
+			cand[ln].sc = sc; cand[ln].j = (i32)j; cand[ln].flags = (active ? 1 : 0) | (tm ? 2 : 0); cand[ln].x32 = wx;
+			if (ln == 0) { st_sh[0] = max_f; st_sh[1] = max_j; st_sh[2] = 0; st_sh[3] = 0; st_sh[8] = 0; }
+			LQ_BLOCK_SYNC();
+			if (ln == 0) lq_wave_replay(cand, st_sh, i - st < 64 ? i - st : 64, i - 65 >= st, watch, max_skip);
+			LQ_BLOCK_SYNC();
+			max_f = st_sh[0]; max_j = st_sh[1]; n_skip = st_sh[2]; done = st_sh[3];
+		}
+		// ---- candidates beyond the window (rare: 64 of them scanned without the break) ----
+		if (!done && i - 65 >= st) {
+			LQ_BLOCK_SYNC();
+			if (ln == 0) { st_sh[0] = max_f; st_sh[1] = max_j; st_sh[2] = n_skip; st_sh[3] = 0; if (!serial) st_sh[8] = 0; }
+			LQ_BLOCK_SYNC();
+			for (i64 top = i - 65; top >= st; top -= 64) {
+				const i64 jj = top - (i64)ln;
+				i32 c_sc = 0, c_flags = 0; u32 c_x32 = 0;
+				if (jj >= st) {
+					const mm128 aj = a[jj];
+					c_x32 = (u32)aj.x;
 					const i64 dr = (i64)(ri - aj.x);
 					const i32 dq = qi - (i32)aj.y;
 					if (!(dr == 0 || dq <= 0 || dq > max_dist)) {
 						const i32 dd = dr > dq ? (i32)(dr - dq) : (i32)(dq - dr);
 						if (dd <= bw) {
 							const i32 min_d = dq < dr ? dq : (i32)dr;
-							i32 sc = min_d > q_span ? q_span : min_d;
+							i32 s2 = min_d > q_span ? q_span : min_d;
 							const i32 log_dd = dd ? lq_ilog2_32((u32)dd) : 0;
-							sc -= (i32)((double)dd * .01 * (double)avg_qspan) + (log_dd >> 1);     // chain.c:67
-							c.sc = sc + f[j];
-							c.flags = 1;
-							const i32 pj = p[j];
-							if (pj >= 0) t[pj] = (i32)i;                  // chain.c:76 (see the note on marks above)
+							s2 -= (i32)((double)dd * .01 * (double)avg_qspan) + (log_dd >> 1);     // chain.c:67
+							c_sc = s2 + f[jj];
+							c_flags = 1;
+							const i32 pj = p[jj];
+							if (pj >= 0) t[pj] = (i32)i;                  // chain.c:76
 						}
 					}
 				}
-				cand[ln] = c;
+				cand[ln].sc = c_sc; cand[ln].j = (i32)jj; cand[ln].flags = c_flags; cand[ln].x32 = c_x32;
+				LQ_BLOCK_SYNC();
+				if (cand[ln].flags & 1) { if (t[cand[ln].j] == (i32)i) cand[ln].flags |= 2; }
+				LQ_BLOCK_SYNC();
+				if (ln == 0) lq_wave_replay(cand, st_sh, top - st + 1 < 64 ? top - st + 1 : 64, top - 64 >= st, watch, max_skip);
+				LQ_BLOCK_SYNC();
+				if (st_sh[3]) break;
 			}
+			max_f = st_sh[0]; max_j = st_sh[1];
 			LQ_BLOCK_SYNC();
-			LQ_BLOCK_LOOP(ln) { if (cand[ln].flags & 1) { if (t[cand[ln].j] == (i32)i) cand[ln].flags |= 2; } }
-			LQ_BLOCK_SYNC();
-			// phase 2: the scan order semantics, on lane 0
-			LQ_BLOCK_LOOP(ln) {
-				if (ln == 0) {
-					i32 max_f = st_sh[0], max_j = st_sh[1], n_skip = st_sh[2], done = 0;
-					TieGroup tg; tg.x = (u32)st_sh[5]; tg.m = st_sh[6]; tg.top = st_sh[7]; tg.st = (u32)st_sh[8];
-					const i64 cnt = top - st + 1 < 64 ? top - st + 1 : 64;
-					for (i64 c = 0; c < cnt; ++c) {
-						const WaveCand w = cand[c];
-						if (!(w.flags & 1)) continue;
-						if (watch && tg.see(w.x32, w.sc, (w.flags & 2) != 0, max_f, n_skip)) st_sh[4] = 1;   // (TieGroup, above lq_chain_fill)
-						if (w.sc > max_f) { max_f = w.sc; max_j = w.j; if (n_skip > 0) --n_skip; }
-						else if (w.flags & 2) {
-							if (++n_skip > max_skip) {                                                  // chain.c:72-73
-								if (watch) {	// tie partners the scan no longer reaches (if they go on into the next 64: assume the worst)
-									i64 c2 = c + 1;
-									for (; c2 < cnt && cand[c2].x32 == w.x32; ++c2) if ((cand[c2].flags & 1) && !tg.quiet(cand[c2].sc, (cand[c2].flags & 2) != 0)) st_sh[4] = 1;
-									if (c2 == cnt && top - 64 >= st) st_sh[4] = 1;
-								}
-								done = 1; break;
-							}
-						}
-					}
-					if (watch && (done || top - 64 < st) && tg.bad()) st_sh[4] = 1;                 // the scan's last group
-					st_sh[0] = max_f; st_sh[1] = max_j; st_sh[2] = n_skip; st_sh[3] = done;
-					st_sh[5] = (i32)tg.x; st_sh[6] = tg.m; st_sh[7] = tg.top; st_sh[8] = (i32)tg.st;
-				}
-			}
-			LQ_BLOCK_SYNC();
-			if (st_sh[3]) break;
 		}
-		LQ_BLOCK_LOOP(ln) {
-			if (ln == 0) {
-				const i32 max_f = st_sh[0], max_j = st_sh[1];
-				f[i] = max_f; p[i] = max_j;
-				v[i] = max_j >= 0 && v[max_j] > max_f ? v[max_j] : max_f;
-			}
+		// ---- f, p, v of anchor i; the window moves on ----
+		i32 vi = max_f;
+		if (max_j >= 0) {
+			const i64 back = i - 1 - (i64)max_j;
+			const i32 vj = back < 64 ? __shfl(wv, (int)back) : v[max_j];      // (uniform branch: max_j is)
+			if (vj > max_f) vi = vj;
 		}
-		LQ_BLOCK_SYNC();
+		if (ln == 0) { f[i] = max_f; p[i] = max_j; v[i] = vi; }
+		{
+			const u32 sx = __shfl_up(wx, 1); const i32 sy = __shfl_up(wy, 1), sf = __shfl_up(wf, 1), sp = __shfl_up(wp, 1), sv = __shfl_up(wv, 1);
+			if (ln == 0) { wx = (u32)ri; wy = qi; wf = max_f; wp = max_j; wv = vi; }
+			else { wx = sx; wy = sy; wf = sf; wp = sp; wv = sv; }
+		}
+		ai = an;
 	}
-	LQ_BLOCK_LOOP(ln) {
-		if (ln == 0) {
-			if (st_sh[4] || lq_chain_finish(a, n, f, p, t, v, u, q, accumulate, P, C, watch)) lq_tie_list(C, q, lq_hi32(a));
-		}
+	LQ_BLOCK_SYNC();
+	if (ln == 0) {
+		if (st_sh[4] || lq_chain_finish(a, n, f, p, t, v, u, q, accumulate, P, C, watch)) lq_tie_list(C, q, lq_hi32(a));
 	}
 }
 

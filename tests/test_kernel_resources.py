@@ -41,5 +41,9 @@ def test_streaming_kernels_keep_full_occupancy_and_nothing_spills(resources):
     for name in ("k_run_list", "k_rs_scatter", "k_rs_hist<false>", "k_rs_hist<true>", "k_rs_children", "k_seed_emit", "k_sort_two_tiled<2>", "k_ps_hist"):
         r = resources[name]
         assert r["vgpr"] <= 64 and r["scratch"] == 0, (name, r)
-    spilling = {k: v["scratch"] for k, v in resources.items() if v["scratch"] and not k.startswith(("k_sketch<256", "k_ps_finish<8192", "k_ps_scan"))}
+    spilling = {k: v["scratch"] for k, v in resources.items() if v["scratch"] and not k.startswith(("k_sketch<256", "k_ps_finish<8192", "k_ps_scan", "k_chain_wave"))}
     assert not spilling, spilling                                 # (k_sketch<256, ...>: the ring of the rare w > 16 case lives in scratch by design)
+    w = resources["k_chain_wave"]                                 # (one wave per run: 32 bytes of frame for the lane-0 replay of the rare tie / beyond-the-window chunks)
+    assert w["scratch"] <= 64 and w["vgpr"] <= 64, w
+    sc = resources["k_seed_count"]
+    assert sc["vgpr"] <= 128 and sc["scratch"] == 0 and sc["lds"] <= 160 * 1024, sc      # 1024 threads = 4 waves per SIMD: 128 registers at most; one block per CU (the table)
