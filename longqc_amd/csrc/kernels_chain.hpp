@@ -671,6 +671,142 @@ k_chain(const mm128 *A, const u64 *gstart, const u32 *glist, u32 n_list, const u
 #define LQ_CHAIN_WAVE_MIN 48      // measured on MI355X at configs[1]: 192 -> 206 ms, 96 -> 193, 48 -> 184, 24 -> 197 (k_chain + k_chain_wave)
 struct WaveCand { i32 sc, j, flags; u32 x32; };             // flags: bit0 = passes the filters, bit1 = t[j] == i; x32: low word of the candidate's x
 
+// mm_chain_dp's second half for one wave (all 64 lanes; arrays in global memory): what lq_chain_finish does on one lane, with
+// the passes that are independent per anchor spread over the lanes -- has-a-successor marks, chain ends and their peaks
+// (chain.c:84-101), the per-anchor counter increments of lq_cnt_match (esterr.c:131-137: a chain's anchors ascend in query
+// position and every one of them is a kept minimizer of the query, so the reference's merge loop finds anchor k at exactly the
+// index a binary search of mini_pos gives) -- and the order-dependent ones (the sort of the ends when there are more than 64,
+// the backtrack with its used-marks, chain.c:102-125) on lane 0.  For a run of n anchors the serial version was ~8 n dependent
+// global loads on one lane: more than the scoring itself since that moved into registers.  Same return value as lq_chain_finish.
+__device__ __forceinline__ bool lq_chain_finish_wave(const mm128 *a, const i64 n, i32 *f, i32 *p, i32 *t, i32 *v, u64 *u,
+                                                     const u32 q, const bool accumulate, const MapParams &P, const CovState &C, const bool watch, i32 *sh /* 8 ints of LDS */)
+{
+	const u32 ln = threadIdx.x;
+	const i32 min_sc = P.min_sc;
+	for (i64 i = ln; i < n; i += 64) t[i] = 0;
+	LQ_BLOCK_SYNC();
+	for (i64 i = ln; i < n; i += 64) { const i32 pi = p[i]; if (pi >= 0) t[pi] = 1; }
+	LQ_BLOCK_SYNC();
+	i64 n_u = 0;
+	for (i64 base = 0; base < n; base += 64) {                  // chain ends, in no particular order (they are sorted below)
+		const i64 i = base + ln;
+		bool e = false; u64 val = 0;
+		if (i < n && t[i] == 0 && v[i] >= min_sc) {
+			i64 j = i;
+			while (j >= 0 && f[j] < v[j]) j = p[j];
+			if (j < 0) j = i;
+			val = (u64)(u32)f[j] << 32 | (u64)j; e = true;
+		}
+		const u64 bal = __ballot(e);
+		if (e) u[n_u + __popcll(bal & ((1ULL << ln) - 1))] = val;
+		n_u += __popcll(bal);
+	}
+	if (n_u == 0) return false;
+	LQ_BLOCK_SYNC();
+	if (n_u <= 64) {                                             // sorted by rank: the keys are distinct unless two ends share a peak (equal values: any order)
+		const u64 mine = ln < n_u ? u[ln] : 0;
+		u32 r = 0;
+		for (u32 k = 0; k < (u32)n_u; ++k) { const u64 o = __shfl(mine, (int)k); r += (o < mine) || (o == mine && k < ln); }
+		LQ_BLOCK_SYNC();
+		if (ln < n_u) u[r] = mine;
+	} else if (ln == 0) lq_heapsort_u64(u, n_u);
+	LQ_BLOCK_SYNC();
+	if (watch) {
+		bool tie = false;
+		for (i64 i = 1 + ln; i < n_u; i += 64) { const u64 u0 = u[i - 1], u1 = u[i]; if ((u0 >> 32) == (u1 >> 32) && (u32)u0 != (u32)u1 && a[(i64)(i32)u0].x == a[(i64)(i32)u1].x) tie = true; }
+		if (__ballot(tie)) return true;
+	}
+	for (i64 i = ln; i < n; i += 64) t[i] = 0;
+	LQ_BLOCK_SYNC();
+	// backtrack from the best end (chain.c:108-125) on lane 0: the kept chains' anchors in v[], chain k as (first slot, count, score) in u[k], f[k] (f is not needed once a chain's score is known ... it is: f[j] of a chain cut at a used anchor -- so the slots go to the tail of u)
+	i64 n_keep = 0;
+	if (ln == 0) {
+		i64 n_v = 0;
+		for (i64 ui = n_u - 1; ui >= 0; --ui) {
+			const i64 n_v0 = n_v;
+			const u64 ue = u[ui];
+			i64 j = (i64)(i32)ue;
+			do { v[n_v++] = (i32)j; t[j] = 1; j = p[j]; } while (j >= 0 && t[j] == 0);
+			const i32 cnt = (i32)(n_v - n_v0);
+			i32 score; bool keep = false;
+			if (j < 0) { score = (i32)(ue >> 32); keep = cnt >= P.min_cnt; }
+			else { score = (i32)(ue >> 32) - f[j]; keep = score >= min_sc && cnt >= P.min_cnt; }
+			if (!keep) { n_v = n_v0; continue; }
+			// (entries ui .. n_u-1 of u are done with, and n_keep <= n_u - 1 - ui: the kept chains are listed from the top of u down)
+			u[n_u - 1 - n_keep] = (u64)(u32)score << 32 | (u64)(u32)cnt;
+			++n_keep;
+		}
+		sh[0] = (i32)n_keep;
+	}
+	LQ_BLOCK_SYNC();
+	n_keep = sh[0];
+	const i32 qlen = (i32)C.qlen[q];
+	const u64 *mp = C.mini_pos + C.mpq_off[q];
+	const i32 n_mp = (i32)(C.mpq_off[q + 1] - C.mpq_off[q]);
+	i64 n_v0 = 0;
+	for (i64 k = 0; k < n_keep; ++k) {                          // every kept chain: regs and lq_cnt_match, the wave together
+		const u64 e = u[n_u - 1 - k];
+		const i32 score = (i32)(e >> 32), cnt = (i32)(u32)e;
+		const i64 n_v = n_v0 + cnt;
+		// the chain's anchors in ascending x: a[v[n_v-1]], ..., a[v[n_v0]]   (chain.c:131-137)
+		const mm128 first = a[v[n_v - 1]], last = a[v[n_v0]];
+		const i32 q_span = (i32)(first.y >> 32 & 0xff);
+		const u32 rev = (u32)(first.x >> 63);
+		const i32 rid = (i32)(first.x << 1 >> 33);
+		const i32 rs = (i32)first.x + 1 > q_span ? (i32)first.x + 1 - q_span : 0;
+		const i32 re = (i32)last.x + 1;
+		i32 qs, qe;
+		if (!rev) { qs = (i32)first.y + 1 - q_span; qe = (i32)last.y + 1; }
+		else { qs = qlen - ((i32)last.y + 1); qe = qlen - ((i32)first.y + 1 - q_span); }
+		if (C.dbg && ln == 0) {
+			unsigned long long d = atomicAdd(C.n_dbg, 1ULL);
+			if (d < C.dbg_cap) { ChainRec r; r.q = (i32)q; r.rid = rid; r.rev = (i32)rev; r.score = score; r.cnt = cnt; r.qs = qs; r.qe = qe; r.rs = rs; r.re = re; C.dbg[d] = r; }
+		}
+		const i64 c0 = n_v0;
+		n_v0 = n_v;
+		if (!accumulate) continue;
+		// lq_cnt_match for this reg (esterr.c:99-138); everything up to the counters is uniform over the wave
+		const i32 x0 = lq_fwd_qpos(qlen, rev ? last : first);
+		i32 L = 0, R = n_mp - 1, sti = -1;
+		while (L <= R) {                                           // get_mini_idx (esterr.c:26-38)
+			const i32 m = (i32)(((u64)L + (u64)R) >> 1), y = (i32)mp[m];
+			if (y < x0) L = m + 1; else if (y > x0) R = m - 1; else { sti = m; break; }
+		}
+		if (sti < 0) continue;
+		const u32 rl = C.tlen[rid];
+		const u32 uqs = (u32)qs, uqe = (u32)qe, urs = (u32)rs, ure = (u32)re;
+		const u32 hang5 = uqs < urs ? uqs : urs;
+		const u32 hang3 = (u32)qlen - uqe < rl - ure ? (u32)qlen - uqe : rl - ure;
+		if ((double)(uqe - uqs) < (double)(uqe - uqs + hang5 + hang3) * P.min_ratio || hang5 > (u32)P.max_overhang || hang3 > (u32)P.max_overhang)
+			continue;
+		const u32 flag = score >= (i32)(u16)P.min_sc_med ? 2u : 0u;
+		if (ln == 0) {
+			atomicAdd(&C.lambda[q], (unsigned long long)(u32)(uqe - uqs + 1));
+			u32 s = atomicAdd(C.n_ivl, 1u);
+			if (s < C.ivl_cap) { Ivl iv; iv.q = q; iv.start = uqs << 3 | flag; iv.end = uqe << 3 | flag | 1u; C.ivl[s] = iv; }
+		}
+		if (score < (i32)(u16)P.min_sc_good) continue;
+		u32 *cn = C.cnts + C.qmoff[q];
+		if (ln == 0) {
+			atomicAdd(&C.lambda2[q], (unsigned long long)(u32)(uqe - uqs + 1));
+			const u32 old = atomicAdd(&cn[sti], 1u);
+			if (old + 1 >= 65535u) atomicOr(&C.qflags[q], 1u);        // esterr.c:130: saturation regime, order would matter
+		}
+		// anchors 1 .. cnt-1 in query order: each is found by the reference's merge loop at its own place in mini_pos, beyond sti
+		for (i32 kk = 1 + (i32)ln; kk < cnt; kk += 64) {
+			const mm128 ak = rev ? a[v[c0 + kk]] : a[v[n_v - 1 - kk]];
+			const i32 xk = lq_fwd_qpos(qlen, ak);
+			i32 lo = sti + 1, hi = n_mp - 1, at = -1;
+			while (lo <= hi) { const i32 m = (i32)(((u64)lo + (u64)hi) >> 1), y = (i32)mp[m]; if (y < xk) lo = m + 1; else if (y > xk) hi = m - 1; else { at = m; break; } }
+			if (at >= 0) {
+				const u32 o2 = atomicAdd(&cn[at], 1u);
+				if (o2 + 1 >= 65535u) atomicOr(&C.qflags[q], 1u);
+			}
+		}
+	}
+	return false;
+}
+
 // lane 0: the scan-order rules over the `cnt` staged candidates of one chunk; state in st_sh ([0] max_f, [1] max_j, [2] n_skip,
 // [3] done, [4] the order of equal-x anchors may matter, [5..8] the scan's open TieGroup)
 __device__ __forceinline__ void lq_wave_replay(const WaveCand *cand, i32 *st_sh, i64 cnt, bool more_beyond, bool watch, i32 max_skip)
@@ -853,9 +989,10 @@ k_chain_wave(const mm128 *A, const u64 *gstart, const u32 *glist, u32 n_list, co
 		ai = an;
 	}
 	LQ_BLOCK_SYNC();
-	if (ln == 0) {
-		if (st_sh[4] || lq_chain_finish(a, n, f, p, t, v, u, q, accumulate, P, C, watch)) lq_tie_list(C, q, lq_hi32(a));
-	}
+	const bool listed = st_sh[4] != 0;                          // (uniform)
+	LQ_BLOCK_SYNC();
+	const bool peak_tie = !listed && lq_chain_finish_wave(a, n, f, p, t, v, u, q, accumulate, P, C, watch, st_sh);
+	if (ln == 0 && (listed || peak_tie)) lq_tie_list(C, q, lq_hi32(a));
 }
 
 // ---- filter_redundant_coords (lqmap.c:25-100), one thread per query, on this part's intervals ----
