@@ -115,12 +115,10 @@ void Knobs::read_env()
 	ties_klib = is("LQCOV_TIES", "klib") || all_klib;
 	filter = num("LQCOV_FILTER", 1) != 0;
 	filt_split = num("LQCOV_FILTER_SPLIT", 1) != 0;
-	head_chunks = (u32)std::min<long>(64, std::max<long>(1, num("LQCOV_HEAD_CHUNKS", 1)));
-	head_chunks_forced = getenv("LQCOV_HEAD_CHUNKS") != nullptr;
 	parse_threads = (int)std::min<long>(256, std::max<long>(0, num("LQCOV_PARSE_THREADS", 0)));
 	parse_piece = (u64)std::max<long>(64, num("LQCOV_PARSE_PIECE", 32L << 20));
 	pipeline = num("LQCOV_PIPELINE", 1) != 0;
-	chunk_batches = (u32)std::min<long>(64, std::max<long>(1, num("LQCOV_CHUNK_BATCHES", 2)));
+	plan_ahead = num("LQCOV_PLAN_AHEAD", 1) != 0;
 	{
 		long kc = num("LQCOV_FILTER_KEYS", (long)LQ_FT_WORDS * 16);
 		u32 v = 256; while (v * 2 <= (u32)std::min<long>(std::max<long>(kc, 256), (long)LQ_FT_WORDS * 16)) v *= 2;   // a power of two in [256, 16 * LQ_FT_WORDS]
@@ -637,6 +635,9 @@ void lqcov_handle::build_index(Part &pt)
 	h2d(pt.self_rid.as<u32>(), srid.data(), srid.size(), stream);
 	LQ_HIP_CHECK(hipStreamSynchronize(stream));
 	pt.built = true;
+	pt.plan.valid = false;
+	// the part's seed plan right away, on the build stream: under the mapping of the part before when parts are pipelined
+	if (K.plan_ahead && have_queries && mid_occ > 0 && !distributed) plan_part(pt, stream, prim);
 	// (the build workspaces stay with the handle: repeated builds do not re-allocate, and the mapping lanes size their work
 	// space from what is free once the first part stands -- map_part)
 }
@@ -1260,6 +1261,108 @@ void lqcov_handle::open_gate()
 }
 
 // ---- map every query against one part (lqmap.c:207-326) -----------------------------------------
+// a part's seed plan (SeedPlan, engine.hpp) on stream s with scan scratch pr
+void lqcov_handle::plan_part(Part &pt, hipStream_t s, Prim &pr)
+{
+	SeedPlan &S = pt.plan;
+	S.valid = false;
+	const u32 n_q = q.n;
+	const u64 n_qm = q.n_mini;
+	S.n_q = n_q; S.n_qm = n_qm; S.mid_occ = mid_occ; S.nA_total = 0; S.n_mp_total = 0; S.n_written = 0;
+	S.h_aq.assign(n_q + 1, 0); S.h_qmoff.assign(n_q + 1, 0); S.h_aqf.clear();
+	if (n_q == 0) { S.valid = true; return; }
+	const AvaView ava{P.ava ? pt.t_rank.as<u32>() : nullptr, P.ava ? pt.q_lo.as<u32>() : nullptr};
+	S.dup.ensure(n_qm * 4 + 4); S.qdirty.ensure((u64)n_q * 4 + 4);
+	S.hit_start.ensure(n_qm * 8 + 8); S.hit_n.ensure(n_qm * 4 + 4); S.a_cnt.ensure(n_qm * 4 + 4); S.keep.ensure(n_qm * 4 + 4);
+	S.a_off.ensure(n_qm * 8 + 8); S.mp_off.ensure(n_qm * 8 + 8);
+	S.aq_off.ensure((n_q + 1) * 8); S.mpq_off.ensure((n_q + 1) * 8); S.avg_qspan.ensure((n_q + 1) * 4);
+	u64 nA_total = 0, n_mp_total = 0;
+	if (n_qm) {
+		{
+			StageTimer t(this, s, "k_seed_probe", n_qm * (16 + 16 + 20));
+			LQ_LAUNCH(k_seed_probe, nblk(n_qm, 256), 256, s, q.mx.as<u64>(), q.my.as<u64>(), q_owner.as<u32>(), n_qm,
+			          pt.tkey.as<u64>(), pt.tstart.as<u64>(), pt.tcnt.as<u32>(), pt.cap_bits, pt.pos.as<u64>(),
+			          mid_occ, (int)P.no_self, pt.self_off.as<u32>(), pt.self_rid.as<u32>(), ava,
+			          S.hit_start.as<u64>(), S.hit_n.as<u32>(), S.a_cnt.as<u32>(), S.keep.as<u32>());
+			check_launch();
+		}
+		{	// minimizers / queries whose anchors can repeat an x (kernels_psort.hpp): everything else is sorted without klib's walks
+			u32 tbits = 10;
+			while (((u64)1 << tbits) < 2 * n_qm && tbits < 31) ++tbits;
+			S.dup_table.ensure(((u64)1 << tbits) * 4);
+			dzero(S.dup.p, n_qm * 4, s); dzero(S.qdirty.p, (u64)n_q * 4, s); dzero(S.dup_table.p, ((u64)1 << tbits) * 4, s);
+			StageTimer t(this, s, "k_dup_mark", n_qm * 24);
+			LQ_LAUNCH(k_dup_mark, nblk(n_qm, 256), 256, s, q.mx.as<u64>(), q.my.as<u64>(), q_owner.as<u32>(), S.a_cnt.as<u32>(), n_qm,
+			          S.dup_table.as<u32>(), tbits, S.dup.as<u32>(), S.qdirty.as<u32>());
+			check_launch();
+		}
+		pr.exclusive_scan_u32_u64(S.a_cnt.as<u32>(), S.a_off.as<u64>(), n_qm);
+		pr.exclusive_scan_u32_u64(S.keep.as<u32>(), S.mp_off.as<u64>(), n_qm);
+		u64 lo[2]; u32 lc[2];
+		d2h(&lo[0], S.a_off.as<u64>() + n_qm - 1, 1, s); d2h(&lc[0], S.a_cnt.as<u32>() + n_qm - 1, 1, s);
+		d2h(&lo[1], S.mp_off.as<u64>() + n_qm - 1, 1, s); d2h(&lc[1], S.keep.as<u32>() + n_qm - 1, 1, s);
+		nA_total = lo[0] + lc[0]; n_mp_total = lo[1] + lc[1];
+	}
+	S.nA_total = nA_total; S.n_mp_total = n_mp_total; S.n_written = nA_total;
+	S.mini_pos.ensure(n_mp_total * 8 + 8);
+	// (per query: anchor and mini_pos ranges, avg_qspan from the unfiltered totals; the skip verdict of esterr.c:85-91 waits for the mapping)
+	LQ_LAUNCH(k_query_prep, nblk(n_q + 1, 4), 256, s, q.moff.as<u64>(), S.a_off.as<u64>(), S.mp_off.as<u64>(), n_qm, nA_total, n_mp_total, n_q,
+	          q.mx.as<u64>(), S.a_cnt.as<u32>(), S.keep.as<u32>(), q.d_len.as<u32>(),
+	          S.aq_off.as<u64>(), S.mpq_off.as<u64>(), S.avg_qspan.as<float>(), (const u64*)nullptr, (float*)nullptr, (u32*)nullptr, 0, 1);
+	check_launch();
+	S.qklib.ensure((u64)n_q * 4 + 4);
+	LQ_LAUNCH(k_query_klib, nblk(n_q, 256), 256, s, S.aq_off.as<u64>(), S.qdirty.as<u32>(), n_q, (int)K.all_klib, S.qklib.as<u32>()); check_launch();
+	d2h(S.h_aq.data(), S.aq_off.as<u64>(), n_q + 1, s);
+	d2h(S.h_qmoff.data(), q.moff.as<u64>(), n_q + 1, s);
+	if (!K.ties_klib) {
+		// The seed hits that can be part of a chain at all (k_seed_count): one bit per hit, counts per minimizer, offsets per query.
+		// Without the filter (LQCOV_FILTER=0, or a chain may be a single anchor) every hit passes: one code path for the first pass.
+		S.h_aqf.assign(n_q + 1, 0);
+		S.qzero.ensure((u64)n_q * 4 + 4); dzero(S.qzero.p, (u64)n_q * 4 + 4, s);
+		S.fm_words.ensure(n_qm * 4 + 4); S.fm_off.ensure(n_qm * 8 + 8); S.cntf.ensure(n_qm * 4 + 4); S.af_off.ensure(n_qm * 8 + 8); S.aqf_off.ensure((n_q + 1) * 8);
+		u64 nF = 0;
+		if (n_qm) {
+			S.fm_meta.ensure(n_qm * sizeof(FMeta) + 16);
+			LQ_LAUNCH(k_fmask_words, nblk(n_qm, 256), 256, s, S.hit_n.as<u32>(), S.keep.as<u32>(), n_qm, S.fm_words.as<u32>()); check_launch();
+			pr.exclusive_scan_u32_u64(S.fm_words.as<u32>(), S.fm_off.as<u64>(), n_qm);
+			LQ_LAUNCH(k_fmeta, nblk(n_qm, 256), 256, s, S.hit_n.as<u32>(), S.keep.as<u32>(), S.hit_start.as<u64>(), q.my.as<u64>(), S.fm_off.as<u64>(), n_qm, S.fm_meta.as<FMeta>()); check_launch();
+			u64 lo = 0; u32 lc = 0;
+			d2h(&lo, S.fm_off.as<u64>() + n_qm - 1, 1, s); d2h(&lc, S.fm_words.as<u32>() + n_qm - 1, 1, s);
+			const u64 n_words = lo + lc;
+			S.fmask.ensure(n_words * 8 + 8);
+			dzero(S.fmask.p, n_words * 8, s); dzero(S.cntf.p, n_qm * 4, s);
+			FiltParams fp; memset(&fp, 0, sizeof(fp));
+			fp.n_min = K.filter ? run_n_min() : 0;
+			fp.n_targets = std::max<u32>(pt.rs.n, 1); fp.keys_cap = K.filt_keys; fp.a_cap = std::max<u32>(K.filt_acap, 1);
+			fp.dshift = 1; while (fp.dshift < 30 && (1u << fp.dshift) <= (u32)std::max<i32>(P.bw, 0)) ++fp.dshift;   // bins wider than the band (chain.c:55)
+			fp.split_strands = K.filt_split ? 1 : 0;
+			{
+				StageTimer t(this, s, "k_seed_count", nA_total * 8 + nA_total / 8);   // (algorithmic: every occurrence list once, a bit per hit out; the kernel reads the lists twice)
+				LQ_LAUNCH(k_seed_count, std::min<u32>(n_q, 1u << 20), LQ_FC_THREADS, s, S.fm_meta.as<FMeta>(), q.mx.as<u64>(), q.moff.as<u64>(), (u32)0, n_q, q.d_len.as<u32>(), pt.pos.as<u64>(), S.aq_off.as<u64>(),
+				          (int)P.no_self, pt.self_off.as<u32>(), pt.self_rid.as<u32>(), ava, fp, (u32)(P.hpc ? 0 : P.k),
+				          S.fmask.as<u8>(), S.cntf.as<u32>());
+				check_launch();
+			}
+			pr.exclusive_scan_u32_u64(S.cntf.as<u32>(), S.af_off.as<u64>(), n_qm);
+			d2h(&lo, S.af_off.as<u64>() + n_qm - 1, 1, s); d2h(&lc, S.cntf.as<u32>() + n_qm - 1, 1, s);
+			nF = lo + lc;
+		}
+		LQ_LAUNCH(k_query_foff, nblk(n_q + 1, 256), 256, s, q.moff.as<u64>(), S.af_off.as<u64>(), (u32)0, n_q, n_qm, nF, S.aqf_off.as<u64>()); check_launch();
+		d2h(S.h_aqf.data(), S.aqf_off.as<u64>(), n_q + 1, s);
+		S.n_written = nF;
+	}
+	LQ_HIP_CHECK(hipStreamSynchronize(s));
+	S.valid = true;
+}
+
+// the plan's buffers <-> the handle's work buffers of the same names
+void lqcov_handle::swap_plan(SeedPlan &S)
+{
+	hit_start.swap(S.hit_start); hit_n.swap(S.hit_n); a_cnt.swap(S.a_cnt); keep.swap(S.keep); dup.swap(S.dup); qdirty.swap(S.qdirty); dup_table.swap(S.dup_table);
+	a_off.swap(S.a_off); mp_off.swap(S.mp_off); aq_off.swap(S.aq_off); mpq_off.swap(S.mpq_off); avg_qspan.swap(S.avg_qspan); qklib.swap(S.qklib); mini_pos.swap(S.mini_pos); qzero.swap(S.qzero);
+	fm_words.swap(S.fm_words); fm_off.swap(S.fm_off); fm_meta.swap(S.fm_meta); fmask.swap(S.fmask); cntf.swap(S.cntf); af_off.swap(S.af_off); aqf_off.swap(S.aqf_off);
+}
+
 void lqcov_handle::map_part(Part &pt)
 {
 	if (!pt.built) throw std::logic_error("part not built");
@@ -1269,78 +1372,26 @@ void lqcov_handle::map_part(Part &pt)
 	last_n_anchors = 0;
 	n_dbg_host = 0;
 	if (n_q == 0) return;
-	dup.ensure(n_qm * 4 + 4); qdirty.ensure((u64)n_q * 4 + 4);
-	hit_start.ensure(n_qm * 8 + 8); hit_n.ensure(n_qm * 4 + 4); a_cnt.ensure(n_qm * 4 + 4); keep.ensure(n_qm * 4 + 4);
-	a_off.ensure(n_qm * 8 + 8); mp_off.ensure(n_qm * 8 + 8);
-	aq_off.ensure((n_q + 1) * 8); mpq_off.ensure((n_q + 1) * 8); avg_qspan.ensure((n_q + 1) * 4); skip.ensure((n_q + 1) * 4);
-	u64 nA_total = 0, n_mp_total = 0;
-	if (n_qm) {
-		{
-			StageTimer t(this, "k_seed_probe", n_qm * (16 + 16 + 20));
-			LQ_LAUNCH(k_seed_probe, nblk(n_qm, 256), 256, stream, q.mx.as<u64>(), q.my.as<u64>(), q_owner.as<u32>(), n_qm,
-			          pt.tkey.as<u64>(), pt.tstart.as<u64>(), pt.tcnt.as<u32>(), pt.cap_bits, pt.pos.as<u64>(),
-			          mid_occ, (int)P.no_self, pt.self_off.as<u32>(), pt.self_rid.as<u32>(), AvaView{P.ava ? pt.t_rank.as<u32>() : nullptr, P.ava ? pt.q_lo.as<u32>() : nullptr},
-			          hit_start.as<u64>(), hit_n.as<u32>(), a_cnt.as<u32>(), keep.as<u32>());
-			check_launch();
-		}
-		{	// minimizers / queries whose anchors can repeat an x (kernels_psort.hpp): everything else is sorted without klib's walks
-			u32 tbits = 10;
-			while (((u64)1 << tbits) < 2 * n_qm && tbits < 31) ++tbits;
-			dup.ensure(n_qm * 4 + 4); qdirty.ensure((u64)n_q * 4 + 4); dup_table.ensure(((u64)1 << tbits) * 4);
-			dzero(dup.p, n_qm * 4, stream); dzero(qdirty.p, (u64)n_q * 4, stream); dzero(dup_table.p, ((u64)1 << tbits) * 4, stream);
-			StageTimer t(this, "k_dup_mark", n_qm * 24);
-			LQ_LAUNCH(k_dup_mark, nblk(n_qm, 256), 256, stream, q.mx.as<u64>(), q.my.as<u64>(), q_owner.as<u32>(), a_cnt.as<u32>(), n_qm,
-			          dup_table.as<u32>(), tbits, dup.as<u32>(), qdirty.as<u32>());
-			check_launch();
-		}
-		prim.exclusive_scan_u32_u64(a_cnt.as<u32>(), a_off.as<u64>(), n_qm);
-		prim.exclusive_scan_u32_u64(keep.as<u32>(), mp_off.as<u64>(), n_qm);
-		u64 lo[2]; u32 lc[2];
-		d2h(&lo[0], a_off.as<u64>() + n_qm - 1, 1, stream); d2h(&lc[0], a_cnt.as<u32>() + n_qm - 1, 1, stream);
-		d2h(&lo[1], mp_off.as<u64>() + n_qm - 1, 1, stream); d2h(&lc[1], keep.as<u32>() + n_qm - 1, 1, stream);
-		nA_total = lo[0] + lc[0]; n_mp_total = lo[1] + lc[1];
-	}
+	// the part's seed plan: made with its index (build_index), or here if it was not (no queries then) or no longer fits (mid_occ
+	// set afterwards: the parts of a round of PartRunner are built before part 0's mid_occ arrives)
+	if (!pt.plan.valid || pt.plan.mid_occ != mid_occ || pt.plan.n_q != n_q || pt.plan.n_qm != n_qm || pt.plan.h_aqf.empty() != K.ties_klib) plan_part(pt, stream, prim);
+	swap_plan(pt.plan);
+	struct PlanGuard { lqcov_handle *h; SeedPlan &S; ~PlanGuard() { h->swap_plan(S); } } plan_guard{this, pt.plan};
+	const std::vector<u64> &h_aq = pt.plan.h_aq, &h_qmoff = pt.plan.h_qmoff, &h_aqf = pt.plan.h_aqf;
+	const u64 nA_total = pt.plan.nA_total, n_mp_total = pt.plan.n_mp_total;
 	last_n_anchors = nA_total;
-	mini_pos.ensure(n_mp_total * 8 + 8);
+	skip.ensure((n_q + 1) * 4);
 	LQ_LAUNCH(k_query_prep, nblk(n_q + 1, 4), 256, stream, q.moff.as<u64>(), a_off.as<u64>(), mp_off.as<u64>(), n_qm, nA_total, n_mp_total, n_q,
 	          q.mx.as<u64>(), a_cnt.as<u32>(), keep.as<u32>(), q.d_len.as<u32>(),
-	          aq_off.as<u64>(), mpq_off.as<u64>(), avg_qspan.as<float>(), lambda.as<u64>(), avg_k.as<float>(), skip.as<u32>(), distributed ? 0 : 1);
+	          aq_off.as<u64>(), mpq_off.as<u64>(), avg_qspan.as<float>(), lambda.as<u64>(), avg_k.as<float>(), skip.as<u32>(), distributed ? 0 : 1, 2);
 	check_launch();
-	qklib.ensure((u64)n_q * 4 + 4);
-	LQ_LAUNCH(k_query_klib, nblk(n_q, 256), 256, stream, aq_off.as<u64>(), qdirty.as<u32>(), n_q, (int)K.all_klib, qklib.as<u32>()); check_launch();
-	std::vector<u64> h_aq(n_q + 1), h_qmoff(n_q + 1), h_aqf;
-	d2h(h_aq.data(), aq_off.as<u64>(), n_q + 1, stream);
-	d2h(h_qmoff.data(), q.moff.as<u64>(), n_q + 1, stream);
-	last_n_written = nA_total;
+	last_n_written = pt.plan.n_written;
 	const bool opt = !K.ties_klib;
 	const bool dbg = (debug_flags & 1) != 0;
 	if (dbg) {
 		dbg_cap = nA_total / (P.min_cnt > 0 ? P.min_cnt : 1) + 16;
 		dbg_chains.ensure(dbg_cap * sizeof(ChainRec)); n_dbg.ensure(8);
 		dzero(n_dbg.p, 8, stream);
-	}
-	FiltParams fp; memset(&fp, 0, sizeof(fp));
-	if (opt) {
-		// The seed hits that can be part of a chain at all (k_seed_count): one bit per hit, counts per minimizer, offsets per query.
-		// Without the filter (LQCOV_FILTER=0, or a chain may be a single anchor) every hit passes: one code path for the first pass.
-		h_aqf.assign(n_q + 1, 0);
-		qzero.ensure((u64)n_q * 4 + 4); dzero(qzero.p, (u64)n_q * 4 + 4, stream);
-		fm_words.ensure(n_qm * 4 + 4); fm_off.ensure(n_qm * 8 + 8); cntf.ensure(n_qm * 4 + 4); af_off.ensure(n_qm * 8 + 8); aqf_off.ensure((n_q + 1) * 8);
-		if (n_qm) {
-			fm_meta.ensure(n_qm * sizeof(FMeta) + 16);
-			LQ_LAUNCH(k_fmask_words, nblk(n_qm, 256), 256, stream, hit_n.as<u32>(), keep.as<u32>(), n_qm, fm_words.as<u32>()); check_launch();
-			prim.exclusive_scan_u32_u64(fm_words.as<u32>(), fm_off.as<u64>(), n_qm);
-			LQ_LAUNCH(k_fmeta, nblk(n_qm, 256), 256, stream, hit_n.as<u32>(), keep.as<u32>(), hit_start.as<u64>(), q.my.as<u64>(), fm_off.as<u64>(), n_qm, fm_meta.as<FMeta>()); check_launch();
-			u64 lo = 0; u32 lc = 0;
-			d2h(&lo, fm_off.as<u64>() + n_qm - 1, 1, stream); d2h(&lc, fm_words.as<u32>() + n_qm - 1, 1, stream);
-			const u64 n_words = lo + lc;
-			fmask.ensure(n_words * 8 + 8);
-			dzero(fmask.p, n_words * 8, stream); dzero(cntf.p, n_qm * 4, stream);
-		}
-		fp.n_min = K.filter ? run_n_min() : 0;
-		fp.n_targets = std::max<u32>(pt.rs.n, 1); fp.keys_cap = K.filt_keys; fp.a_cap = std::max<u32>(K.filt_acap, 1);
-		fp.dshift = 1; while (fp.dshift < 30 && (1u << fp.dshift) <= (u32)std::max<i32>(P.bw, 0)) ++fp.dshift;   // bins wider than the band (chain.c:55)
-		fp.split_strands = K.filt_split ? 1 : 0;
 	}
 	if (anchor_budget == 0) {
 		// The first part stands (reads, minimizers, index, the build's work space -- all kept for the parts to come, of which the
@@ -1390,96 +1441,46 @@ void lqcov_handle::map_part(Part &pt)
 			pv_cap = (u32)std::min<u64>(pv.cap / sizeof(Ivl), 0xfffffff0ULL);
 		}
 	}
-#ifndef LQ_EMU
-	const bool concurrent = n_lanes > 1 && nA_total >= (1u << 20) && profiling != 1 && !dbg;
-#else
-	const bool concurrent = false;
-#endif
-	// The queries in chunks (of about equal seed hits): the head stream decides chunk c + 1's survivors (k_seed_count, latency-bound)
-	// while the lanes map the batches of chunk c.  One chunk where nothing runs side by side, or without the first-pass filter.
-	std::vector<std::pair<u32, u32>> chunks;
-	{
-		const u32 n_ch = opt && (concurrent || K.head_chunks_forced) ? std::max<u32>(K.head_chunks, 1) : 1;   // (LQCOV_HEAD_CHUNKS set: chunks also where one batch runs after the other -- tests)
-		u32 c0 = 0;
-		for (u32 c = 0; c < n_ch && c0 < n_q; ++c) {
-			const u64 want = nA_total / n_ch * (c + 1);
-			u32 c1 = c + 1 == n_ch ? n_q : c0 + 1;
-			while (c1 < n_q && h_aq[c1] < want) ++c1;
-			chunks.emplace_back(c0, c1);
-			c0 = c1;
-		}
-		if (chunks.empty()) chunks.emplace_back(0, n_q);
-		chunks.back().second = n_q;
-	}
-	// batches of queries whose anchors fit one lane's work space, cut from the offsets of what the first pass writes; lanes (own
-	// streams + work space) take batches as they finish, so the serial tail of one batch overlaps the wide kernels of another
-	auto cut_batches = [&](u32 c0, u32 c1, const std::vector<u64> &off, std::vector<std::pair<u32, u32>> &out) {
-		// as few batches as the work space allows (a multiple of the lane count when the part is one chunk), of about equal anchor
-		// totals: every batch has a serial critical path that does not shrink with the batch.  (Cutting the last round finer was
-		// measured on MI355X at configs[2] in round 3: 1.75-1.78 s per step against 1.68-1.70 s.)
-		const u64 tot = off[c1] - off[c0];
-		u64 nb = (tot + anchor_budget - 1) / anchor_budget;
-		if (chunks.size() == 1) {
-			if (nb < (u64)n_lanes && tot >= ((u64)n_lanes << 24)) nb = n_lanes;
-			if (nb > (u64)n_lanes) nb = (nb + n_lanes - 1) / n_lanes * n_lanes;
-		} else if (nb < K.chunk_batches && tot >= ((u64)K.chunk_batches << 22)) nb = K.chunk_batches;
+	const std::vector<u64> &h_boff = opt ? h_aqf : h_aq;             // the offsets the batches are cut by: of the anchors the first pass writes
+	const u64 nB_total = h_boff[n_q];
+	// batches of queries whose anchors fit one lane's work space; lanes (own streams + work space) take batches as they
+	// finish, so the serial tail of one batch overlaps the wide kernels of another
+	std::vector<std::pair<u32, u32>> batches;
+	{	// as few batches as the work space allows, a multiple of the lane count, of about equal anchor totals: every batch
+		// has a serial critical path that does not shrink with the batch.  (Cutting the last round finer was measured on MI355X at
+		// configs[2] in round 3: 1.75-1.78 s per step against 1.68-1.70 s; round 4: the queries in six chunks with the survivors of
+		// a chunk decided under the mapping of the chunk before: 1160 ms per step against 888.)
+		u64 nb = (nB_total + anchor_budget - 1) / anchor_budget;
+		if (nb < (u64)n_lanes && nB_total >= ((u64)n_lanes << 24)) nb = n_lanes;
+		if (nb > (u64)n_lanes) nb = (nb + n_lanes - 1) / n_lanes * n_lanes;
 		if (nb == 0) nb = 1;
 		u64 left = nb;
-		for (u32 q0 = c0; q0 < c1; ) {
-			const u64 rem = off[c1] - off[q0];
+		for (u32 q0 = 0; q0 < n_q; ) {
+			const u64 rem = h_boff[n_q] - h_boff[q0];
 			const u64 lim = std::min(anchor_budget, left > 1 ? (rem + left - 1) / left : rem);
 			u32 q1 = q0 + 1;
-			while (q1 < c1 && off[q1 + 1] - off[q0] <= lim) ++q1;
-			out.emplace_back(q0, q1);
+			while (q1 < n_q && h_boff[q1 + 1] - h_boff[q0] <= lim) ++q1;
+			batches.emplace_back(q0, q1);
 			q0 = q1;
 			if (left > 1) --left;
 		}
-	};
-	u64 n_written = 0;
-	// a chunk's head: which of its seed hits survive, where every query's survivors start
-	auto head = [&](u32 c0, u32 c1) {
-		if (!opt) return;
-		const u64 jb = h_qmoff[c0], je = h_qmoff[c1];
-		u64 tot = n_written;
-		if (je > jb) {
-			{
-				StageTimer t(this, "k_seed_count", (h_aq[c1] - h_aq[c0]) * 8 + (h_aq[c1] - h_aq[c0]) / 8);   // (algorithmic: every occurrence list once, a bit per hit out; the kernel reads the lists twice)
-				LQ_LAUNCH(k_seed_count, std::min<u32>(c1 - c0, 1u << 20), LQ_FC_THREADS, stream, fm_meta.as<FMeta>(), q.mx.as<u64>(), q.moff.as<u64>(), c0, c1, q.d_len.as<u32>(), pt.pos.as<u64>(), aq_off.as<u64>(),
-				          (int)P.no_self, pt.self_off.as<u32>(), pt.self_rid.as<u32>(), AvaView{P.ava ? pt.t_rank.as<u32>() : nullptr, P.ava ? pt.q_lo.as<u32>() : nullptr}, fp, (u32)(P.hpc ? 0 : P.k),
-				          fmask.as<u8>(), cntf.as<u32>());
-				check_launch();
-			}
-			prim.exclusive_scan_u32_u64(cntf.as<u32>() + jb, af_off.as<u64>() + jb, je - jb, n_written);
-			u64 lo = 0; u32 lc = 0;
-			d2h(&lo, af_off.as<u64>() + je - 1, 1, stream); d2h(&lc, cntf.as<u32>() + je - 1, 1, stream);
-			tot = lo + lc;
-		}
-		LQ_LAUNCH(k_query_foff, nblk(c1 - c0 + 1, 256), 256, stream, q.moff.as<u64>(), af_off.as<u64>(), c0, c1, je, tot, aqf_off.as<u64>()); check_launch();
-		// (h_aqf[c0] was written as the previous chunk's end: lanes may be reading it)
-		if (c0 == 0) d2h(h_aqf.data(), aqf_off.as<u64>(), c1 + 1, stream);
-		else d2h(h_aqf.data() + c0 + 1, aqf_off.as<u64>() + c0 + 1, c1 - c0, stream);
-		n_written = tot;
-	};
-	const std::vector<u64> &h_boff = opt ? h_aqf : h_aq;             // the offsets the batches are cut by: of the anchors the first pass writes
+	}
+#ifndef LQ_EMU
+	const bool concurrent = n_lanes > 1 && batches.size() > 1 && profiling != 1 && !dbg;
+#else
+	const bool concurrent = false;
+#endif
 	if (!concurrent) {
-		size_t i = 0;
-		for (auto &ch : chunks) {
-			head(ch.first, ch.second);
-			std::vector<std::pair<u32, u32>> batches;
-			cut_batches(ch.first, ch.second, h_boff, batches);
-			for (auto &b : batches) {
-				lq_alloc_stream = lanes[i % n_lanes]->stream;
-				map_batch(*lanes[i % n_lanes], pt, b.first, b.second, h_aq, h_aqf, h_qmoff, dbg);
-				lq_alloc_stream = nullptr;
-				++i;
-			}
+		for (size_t i = 0; i < batches.size(); ++i) {
+			lq_alloc_stream = lanes[i % n_lanes]->stream;
+			map_batch(*lanes[i % n_lanes], pt, batches[i].first, batches[i].second, h_aq, h_aqf, h_qmoff, dbg);
+			lq_alloc_stream = nullptr;
 		}
 		for (auto &L : lanes) LQ_HIP_CHECK(hipStreamSynchronize(L->stream));
 	} else {
-		std::deque<std::pair<u32, u32>> todo;                        // under gate_mu, like the staggered start
-		bool producing = true, failed = false;
+		std::atomic<size_t> next(0);
 		{ std::lock_guard<std::mutex> lk(gate_mu); gate_count = 0; }
-		std::vector<std::exception_ptr> errs(n_lanes + 1);
+		std::vector<std::exception_ptr> errs(n_lanes);
 		std::vector<std::thread> th;
 		for (int li = 0; li < n_lanes; ++li)
 			th.emplace_back([&, li]() {
@@ -1491,37 +1492,19 @@ void lqcov_handle::map_part(Part &pt)
 					{	// staggered start: lane li begins when li batches have got past their sort (or ended), so that
 						// one lane's serial tails run under another lane's wide kernels instead of side by side
 						std::unique_lock<std::mutex> lk(gate_mu);
-						gate_cv.wait(lk, [&] { return gate_count >= li || failed || (!producing && todo.empty()); });
+						gate_cv.wait(lk, [&] { return gate_count >= li || next.load() >= batches.size(); });
 					}
 					for (;;) {
-						std::pair<u32, u32> b;
-						{
-							std::unique_lock<std::mutex> lk(gate_mu);
-							gate_cv.wait(lk, [&] { return !todo.empty() || !producing || failed; });
-							if (failed || todo.empty()) break;
-							b = todo.front(); todo.pop_front();
-						}
-						map_batch(L, pt, b.first, b.second, h_aq, h_aqf, h_qmoff, dbg);
+						const size_t i = next.fetch_add(1);
+						if (i >= batches.size()) break;
+						map_batch(L, pt, batches[i].first, batches[i].second, h_aq, h_aqf, h_qmoff, dbg);
 					}
 					LQ_HIP_CHECK(hipStreamSynchronize(L.stream));
-				} catch (...) { errs[li] = std::current_exception(); { std::lock_guard<std::mutex> lk(gate_mu); failed = true; } gate_cv.notify_all(); }
+				} catch (...) { errs[li] = std::current_exception(); next.store(batches.size()); gate_cv.notify_all(); }
 			});
-		try {
-			for (auto &ch : chunks) {
-				{ std::lock_guard<std::mutex> lk(gate_mu); if (failed) break; }
-				head(ch.first, ch.second);
-				std::vector<std::pair<u32, u32>> batches;
-				cut_batches(ch.first, ch.second, h_boff, batches);
-				{ std::lock_guard<std::mutex> lk(gate_mu); for (auto &b : batches) todo.push_back(b); }
-				gate_cv.notify_all();
-			}
-		} catch (...) { errs[n_lanes] = std::current_exception(); std::lock_guard<std::mutex> lk(gate_mu); failed = true; }
-		{ std::lock_guard<std::mutex> lk(gate_mu); producing = false; }
-		gate_cv.notify_all();
 		for (auto &t : th) t.join();
 		for (auto &e : errs) if (e) { hipDeviceSynchronize(); std::rethrow_exception(e); }
 	}
-	if (opt) last_n_written = n_written;
 	if (dbg) { unsigned long long nd = 0; d2h(&nd, n_dbg.as<unsigned long long>(), 1, stream); n_dbg_host = nd; }
 	LQ_HIP_CHECK(hipStreamSynchronize(stream));
 }

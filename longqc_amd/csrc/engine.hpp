@@ -49,12 +49,10 @@ struct Knobs {
 	bool sketch_machine_only = false;     // LQCOV_SKETCH=machine: the state machine decides every chunk (no data-parallel kernel)
 	bool ties_klib = false;               // LQCOV_TIES=klib (or LQCOV_SORT=klib): klib's order of equal-x anchors everywhere, every seed hit written and sorted (rounds 1-3); default: only where it can be observed (map_batch)
 	bool filter = true;                   // LQCOV_FILTER=0: the first pass writes every seed hit (no counting filter)
-	u32 head_chunks = 1;                  // LQCOV_HEAD_CHUNKS: chunks of queries whose survivors are decided (k_seed_count) while the lanes map the chunk before (measured at configs[2]: 6 chunks 1160 ms per step, 10: 1404, 1: 888 -- more batches, more serial tails)
-	bool head_chunks_forced = false;
+	bool plan_ahead = true;               // LQCOV_PLAN_AHEAD=0: a part's seed plan (probe, survivors) is made when the part is mapped, not right after its index
 	int parse_threads = 0;                // LQCOV_PARSE_THREADS: threads that parse and pack a plain target file (0: one per core, at most 64; 1: the streaming reader as for gzip)
 	u64 parse_piece = 32u << 20;          // LQCOV_PARSE_PIECE: bytes of the file a thread parses at a time (tests shrink it: many guessed record starts)
 	bool pipeline = true;                 // LQCOV_PIPELINE=0: run_files builds a part only after the one before is mapped
-	u32 chunk_batches = 2;                // LQCOV_CHUNK_BATCHES: batches a chunk is cut into at least (if it has the anchors for it)
 	bool filt_split = true;               // LQCOV_FILTER_SPLIT=0: the two strands of a target share its diagonal bins
 	u32 filt_keys = 1u << 19;             // LQCOV_FILTER_KEYS: counters of k_seed_count's table in use (tests shrink it: slices and aliasing on small inputs)
 	u32 filt_acap = 65536;                // LQCOV_FILTER_ACAP: hits per slice of targets aimed at (0.125 per counter; configs[2], 3 lanes: 131072 995 ms per step, 65536 922, 32768 937-955)
@@ -75,8 +73,23 @@ struct ReadSetDev {                       // a read set 2-bit packed in HBM, chu
 	bool sketched = false;
 };
 
+// What the mapping of a part needs before its first batch, and what depends only on the part, the query set and mid_occ (not
+// on what earlier parts accumulated): the probe of every query minimizer, which minimizers can repeat an x, the surviving
+// seed hits (k_seed_count) and every offset that follows.  Made right after the part's index on the build stream -- under the
+// mapping of the part before -- and swapped into the handle's work buffers of the same names when the part is mapped.
+struct lqcov_handle;
+struct SeedPlan {
+	DBuf hit_start, hit_n, a_cnt, keep, dup, qdirty, dup_table, a_off, mp_off, aq_off, mpq_off, avg_qspan, qklib, mini_pos, qzero;
+	DBuf fm_words, fm_off, fm_meta, fmask, cntf, af_off, aqf_off;
+	std::vector<u64> h_aq, h_qmoff, h_aqf;
+	u64 nA_total = 0, n_mp_total = 0, n_written = 0;
+	i32 mid_occ = -2; u32 n_q = 0; u64 n_qm = 0;
+	bool valid = false;
+};
+
 struct Part {
 	bool live = false, built = false;
+	SeedPlan plan;
 	ReadSetDev rs;
 	DBuf pos;                             // y of every minimizer, grouped by hash, ascending (index.c:188)
 	DBuf tkey, tstart, tcnt;              // open-addressed table
@@ -200,6 +213,8 @@ struct lqcov_handle {
 	void build_index(Part &pt);
 	void build_part(Part &pt);
 	void open_gate();
+	void plan_part(Part &pt, hipStream_t s, Prim &pr);
+	void swap_plan(SeedPlan &S);
 	void map_part(Part &pt);
 	void map_batch(MapLane &L, Part &pt, u32 q0, u32 q1, const std::vector<u64> &h_aq, const std::vector<u64> &h_aqf, const std::vector<u64> &h_qmoff, bool dbg);
 	void batch_buffers(MapLane &L, u64 nA);

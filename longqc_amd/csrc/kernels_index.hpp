@@ -543,13 +543,13 @@ k_seed_emit_f(const u64 *qx, const u64 *qy, const u32 *owner, const u64 *qmoff, 
 __global__ void __launch_bounds__(256)
 k_query_prep(const u64 *qmoff, const u64 *a_off, const u64 *mp_off, u64 n_qm, u64 n_anchor_total, u64 n_mp_total, u32 n_q,
              const u64 *qx, const u32 *a_cnt, const u32 *keep, const u32 *qlen,
-             u64 *aq_off, u64 *mpq_off, float *avg_qspan, const u64 *lambda, float *avg_k, u32 *skip, int covt_on)
+             u64 *aq_off, u64 *mpq_off, float *avg_qspan, const u64 *lambda, float *avg_k, u32 *skip, int covt_on, int mode /* 0: all; 1: offsets and avg_qspan only (the part's plan); 2: the skip verdict and avg_k only (when the part is mapped: they depend on the parts before) */)
 {
 	// one wave per query (the sums are integers: any order)
 	const u32 q = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
 	if (q > n_q) return;
 	const u64 j0 = qmoff[q];
-	if (lane == 0) {
+	if (lane == 0 && mode != 2) {
 		aq_off[q] = j0 < n_qm ? a_off[j0] : n_anchor_total;
 		mpq_off[q] = j0 < n_qm ? mp_off[j0] : n_mp_total;
 	}
@@ -565,7 +565,8 @@ k_query_prep(const u64 *qmoff, const u64 *a_off, const u64 *mp_off, u64 n_qm, u6
 		sum_span += __shfl_xor(sum_span, o); n_a += __shfl_xor(n_a, o); sum_k += __shfl_xor(sum_k, o); n_mp += __shfl_xor(n_mp, o);
 	}
 	if (lane != 0) return;
-	avg_qspan[q] = n_a ? __fdiv_rn((float)sum_span, (float)(i64)n_a) : 0.0f;
+	if (mode != 2) avg_qspan[q] = n_a ? __fdiv_rn((float)sum_span, (float)(i64)n_a) : 0.0f;
+	if (mode == 1) return;
 	u32 sk = 0;
 	if (n_mp == 0) sk = 1;                                             // esterr.c:85
 	else if (covt_on && lambda[q] / (u64)qlen[q] > LQ_COVT && avg_k[q] != 0.0f) sk = 1;   // esterr.c:87

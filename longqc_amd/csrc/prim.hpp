@@ -4,6 +4,7 @@
 #pragma once
 #include "lq_common.hpp"
 #include <stdexcept>
+#include <utility>
 #include <string>
 
 #ifndef LQ_EMU
@@ -100,6 +101,7 @@ struct DBuf {
 		p = nullptr; cap = 0; pool_stream = nullptr;
 	}
 	template <class T> T *as() const { return (T*)p; }
+	void swap(DBuf &o) { std::swap(p, o.p); std::swap(cap, o.cap); std::swap(pool_stream, o.pool_stream); }
 	~DBuf() { release(); }
 	DBuf() {}
 	DBuf(const DBuf&) = delete; DBuf &operator=(const DBuf&) = delete;

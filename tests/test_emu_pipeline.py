@@ -570,7 +570,7 @@ def check_observable_ties_scheme(lib, tmp_path, monkeypatch, seed, env):
 OBS_ENVS = [{}, {"LQCOV_FILTER_KEYS": "64"}, {"LQCOV_FILTER_KEYS": "1024", "LQCOV_FILTER_ACAP": "100"}, {"LQCOV_FILTER": "0"},
             {"LQCOV_ANCHOR_BUDGET": "20000", "LQCOV_LANES": "2"}, {"LQCOV_TIES": "klib"}, {"LQCOV_DEBUG_SORT": "1", "LQCOV_PS_SHIFT": "5"},
             {"LQCOV_CHAIN_WAVE_MIN": "3"},             # (every run through the wave kernel: its own copy of the tie rule)
-            {"LQCOV_HEAD_CHUNKS": "3", "LQCOV_FILTER_SPLIT": "0"}]   # (the queries in three chunks, each with its own filter launch and batches; strands share a target's bins)
+            {"LQCOV_PLAN_AHEAD": "0", "LQCOV_FILTER_SPLIT": "0"}]   # (the seed plan made when the part is mapped, not with its index; strands share a target's bins)
 
 
 @pytest.mark.parametrize("env", OBS_ENVS, ids=lambda e: "+".join("%s=%s" % kv for kv in e.items()) or "default")
