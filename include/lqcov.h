@@ -79,7 +79,9 @@ typedef struct lqcov_row {
 	uint32_t has_qual;         /* 0 for FASTA queries: meanQ prints as the reference's NaN */
 	uint32_t flags;            /* LQCOV_ROW_* */
 } lqcov_row;
-#define LQCOV_ROW_SATURATED 1u /* a uint16 match counter reached 65535: esterr.c:130,136 order dependence, row not guaranteed */
+#define LQCOV_ROW_SATURATED 1u /* a uint16 match counter reached 65535: esterr.c:130,136 make the result depend on the order of the chains */
+#define LQCOV_ROW_REPLAYED  4u /* ... and the query's counters were replayed in the reference's chain order (hit.c:52-88): the row is exact.
+                                  SATURATED without REPLAYED (counters merged from several ranks): row not guaranteed */
 
 typedef struct lqcov_region { uint32_t start, end; } lqcov_region;
 

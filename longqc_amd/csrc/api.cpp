@@ -570,6 +570,7 @@ int lqcov_accum_import_dev(lqcov_handle *h, const uint64_t *lambda_dev, const ui
 		dcopy(h->pv.p, intervals_dev, (size_t)n_intervals * sizeof(Ivl), h->stream);
 		LQ_HIP_CHECK(hipMemcpyAsync(h->n_pv.p, &n_intervals, 4, hipMemcpyHostToDevice, h->stream));
 		LQ_HIP_CHECK(hipStreamSynchronize(h->stream));
+		h->sat_cnt.clear();                                       // (merged counters: nothing this rank replayed describes them)
 		h->finished = false;
 	});
 }

@@ -53,10 +53,16 @@ struct Knobs {
 	int parse_threads = 0;                // LQCOV_PARSE_THREADS: threads that parse and pack a plain target file (0: one per core, at most 64; 1: the streaming reader as for gzip)
 	u64 parse_piece = 32u << 20;          // LQCOV_PARSE_PIECE: bytes of the file a thread parses at a time (tests shrink it: many guessed record starts)
 	bool pipeline = true;                 // LQCOV_PIPELINE=0: run_files builds a part only after the one before is mapped
+	int cnt_bits = 16;                    // LQCOV_TEST_CNT_BITS (2..16): width of the match counters.  A test hook: narrower counters bring the saturated regime (sat_replay.hpp) within reach of small inputs; the oracle has the same one (LQO_CNT_BITS)
 	bool filt_split = true;               // LQCOV_FILTER_SPLIT=0: the two strands of a target share its diagonal bins
 	u32 filt_keys = 1u << 19;             // LQCOV_FILTER_KEYS: counters of k_seed_count's table in use (tests shrink it: slices and aliasing on small inputs)
 	u32 filt_acap = 65536;                // LQCOV_FILTER_ACAP: hits per slice of targets aimed at (0.125 per counter; configs[2], 3 lanes: 131072 995 ms per step, 65536 922, 32768 937-955)
 	void read_env();
+};
+
+struct SatSink {                          // where the chain kernels record a replayed query's chains (CovState::rec)
+	SatRec *rec; unsigned long long *n_rec; u64 rec_cap;
+	u32 *at; unsigned long long *n_at; u64 at_cap;
 };
 
 struct ReadSetDev {                       // a read set 2-bit packed in HBM, chunk aligned
@@ -170,6 +176,13 @@ struct lqcov_handle {
 	DBuf qzero;                           // zeros: nobody goes through klib's passes (first pass of map_batch)
 	DBuf fm_meta;                         // k_seed_count: every query minimizer's list (start, length, y), its cursor and the place of its survivor bits in one record
 	DBuf fm_words, fm_off, fmask, cntf, af_off, aqf_off;   // k_seed_count: survivor bitmap (words per minimizer, offsets, bits), survivors per minimizer, their offsets per minimizer / per query
+	// Queries one of whose match counters reached cnt_max (uint16 in the reference: 65535; esterr.c:130,136): from the part in
+	// which that happens on, their counters live here, replayed part by part in the reference's chain order (sat_replay.hpp,
+	// sat_replay_part), and go back to the device before the rows are made.  Key: the query in the engine's order.
+	std::map<u32, std::vector<u32>> sat_cnt;
+	u32 cnt_max = 65535;                  // (LQCOV_TEST_CNT_BITS)
+	DBuf sat_rec, sat_at, sat_n;
+	u64 stat_sat_chains = 0;
 	u64 last_n_written = 0;               // anchors the first pass wrote against the last part
 	std::atomic<u64> stat_sens_runs{0}, stat_p2_queries{0}, stat_p2_anchors{0};   // second pass, since reset(): runs, queries, anchors
 	u32 run_n_min() const { const i32 span_max = P.hpc ? 255 : P.k; return (u32)std::max<i32>(std::max<i32>(P.min_cnt, 1), (mp.min_sc + span_max - 1) / span_max); }   // anchors a run needs to hold a chain (k_run_list)
@@ -218,7 +231,9 @@ struct lqcov_handle {
 	void map_part(Part &pt);
 	void map_batch(MapLane &L, Part &pt, u32 q0, u32 q1, const std::vector<u64> &h_aq, const std::vector<u64> &h_aqf, const std::vector<u64> &h_qmoff, bool dbg);
 	void batch_buffers(MapLane &L, u64 nA);
-	void chain_stage(MapLane &L, Part &pt, const u64 *aqb, u64 a_base, u32 nqb, u32 q0, const u32 *qmap, u64 nA, int tie_mode, u32 n_want, u32 ivl_cap, bool dbg);
+	void chain_stage(MapLane &L, Part &pt, const u64 *aqb, u64 a_base, u32 nqb, u32 q0, const u32 *qmap, u64 nA, int tie_mode, u32 n_want, u32 ivl_cap, bool dbg, const SatSink *sink = nullptr);
+	void map_subset(MapLane &L, Part &pt, const std::vector<u32> &sq, const std::vector<u32> &sk, const std::vector<u64> &so, u64 max_mini, int tie_mode, u32 n_want, u32 ivl_cap, bool dbg, const SatSink *sink);
+	void sat_replay_part(Part &pt, const std::vector<u64> &h_aq, const std::vector<u64> &h_qmoff);
 	void sort_checked(MapLane &L, Part &pt, const u64 *aqb, const u32 *qkb, u32 nqb, u64 a_base, u64 nA, const std::vector<u64> &h_off, const std::vector<u32> &h_klib);
 	void sort_batch(MapLane &L, Part &pt, const u64 *aqb, const u32 *qkb, u32 nqb, u64 a_base, u64 nA);
 	void psort_run(MapLane &L, int set, hipStream_t s, u64 nA, const KeyMap &km, const struct PsData &pd);

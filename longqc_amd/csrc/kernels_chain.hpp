@@ -279,6 +279,12 @@ struct CovState {              // per-query accumulators (minimap2-coverage.c:43
 	unsigned long long *sens; u32 *n_sens; u32 sens_cap;
 	const unsigned long long *want; u32 n_want;
 	const u32 *qmap;           // not null: the batch's i-th query is query qmap[i] (a subset of the queries); else q0 + i
+	// The reference's counters are uint16 and the test that should saturate them reads a[st], not a[j] (esterr.c:130,136): once a
+	// counter of a query reaches cnt_max (65535) its final counters depend on the order in which the chains were processed.
+	// The kernels count in 32 bits and flag the query; a flagged query is chained once more with `rec` set: nothing is
+	// accumulated, every kept chain is written out, and the host replays them in mm_gen_regs' order (sat_replay.hpp).
+	u32 cnt_max;
+	SatRec *rec; unsigned long long *n_rec; u64 rec_cap; u32 *rec_at; unsigned long long *n_at; u64 at_cap;
 };
 
 __device__ __forceinline__ bool lq_tie_wanted(const CovState &C, u32 q, u32 hi)
@@ -490,6 +496,7 @@ __device__ __forceinline__ bool lq_chain_finish(AP a, const i64 n, IP f, IP p, I
 	// backtrack from the best end (chain.c:108-125); u[] is ascending, so walk it from the top
 	for (i64 i = 0; i < n; ++i) t[i] = 0;
 	i64 n_v = 0;
+	u32 n_rec_run = 0;
 	const i32 qlen = (i32)C.qlen[q];
 	const u64 *mp = C.mini_pos + C.mpq_off[q];
 	const i32 n_mp = (i32)(C.mpq_off[q + 1] - C.mpq_off[q]);
@@ -527,13 +534,30 @@ __device__ __forceinline__ bool lq_chain_finish(AP a, const i64 n, IP f, IP p, I
 			const i32 m = (i32)(((u64)L + (u64)R) >> 1), y = (i32)mp[m];
 			if (y < x0) L = m + 1; else if (y > x0) R = m - 1; else { sti = m; break; }
 		}
-		if (sti < 0) continue;
 		const u32 rl = C.tlen[rid];
 		const u32 uqs = (u32)qs, uqe = (u32)qe, urs = (u32)rs, ure = (u32)re;
 		const u32 hang5 = uqs < urs ? uqs : urs;
 		const u32 hang3 = (u32)qlen - uqe < rl - ure ? (u32)qlen - uqe : rl - ure;
-		if ((double)(uqe - uqs) < (double)(uqe - uqs + hang5 + hang3) * P.min_ratio || hang5 > (u32)P.max_overhang || hang3 > (u32)P.max_overhang)
+		const bool pass = sti >= 0 && !((double)(uqe - uqs) < (double)(uqe - uqs + hang5 + hang3) * P.min_ratio || hang5 > (u32)P.max_overhang || hang3 > (u32)P.max_overhang);
+		if (C.rec) {                                               // replay of a saturated query: the chain goes to the host as it is
+			const bool good = pass && score >= (i32)(u16)P.min_sc_good;
+			SatRec sr;
+			sr.first_x = first.x; sr.first_y = first.y & ~LQ_TIE_MARK; sr.f_peak = (u32)(ue >> 32); sr.run_hi = (u32)(first.x >> 32); sr.peak_j = (u32)ue; sr.seq = n_rec_run++;
+			sr.score = (u32)score; sr.cnt = (u32)cnt; sr.sti = sti; sr.n_at = 0; sr.at_off = 0; sr.good = good ? 1u : 0u; sr.span = uqe - uqs + 1;
+			if (good && cnt > 1) {
+				sr.at_off = atomicAdd(C.n_at, (unsigned long long)(cnt - 1));
+				const bool room = sr.at_off + (u64)(cnt - 1) <= C.at_cap;
+				i32 k = 1;
+				for (i32 jj = sti + 1; jj < n_mp && k < cnt; ++jj) {
+					const mm128 ak = rev ? a[v[n_v0 + k]] : a[v[n_v - 1 - k]];
+					if (lq_fwd_qpos(qlen, ak) == (i32)mp[jj]) { ++k; if (room) C.rec_at[sr.at_off + sr.n_at] = (u32)jj; ++sr.n_at; }
+				}
+			}
+			const unsigned long long r = atomicAdd(C.n_rec, 1ULL);
+			if (r < C.rec_cap) C.rec[r] = sr;
 			continue;
+		}
+		if (!pass) continue;
 		atomicAdd(&C.lambda[q], (unsigned long long)(u32)(uqe - uqs + 1));
 		u32 flag = score >= (i32)(u16)P.min_sc_med ? 2u : 0u;
 		{
@@ -544,14 +568,14 @@ __device__ __forceinline__ bool lq_chain_finish(AP a, const i64 n, IP f, IP p, I
 		atomicAdd(&C.lambda2[q], (unsigned long long)(u32)(uqe - uqs + 1));
 		u32 *cn = C.cnts + C.qmoff[q];
 		u32 old = atomicAdd(&cn[sti], 1u);
-		if (old + 1 >= 65535u) atomicOr(&C.qflags[q], 1u);        // esterr.c:130: saturation regime, order would matter
+		if (old + 1 >= C.cnt_max) atomicOr(&C.qflags[q], 1u);       // esterr.c:130: saturation regime, the order matters (replayed)
 		i32 k = 1;
 		for (i32 jj = sti + 1; jj < n_mp && k < cnt; ++jj) {
 			const mm128 ak = rev ? a[v[n_v0 + k]] : a[v[n_v - 1 - k]];
 			if (lq_fwd_qpos(qlen, ak) == (i32)mp[jj]) {
 				++k;
 				u32 o2 = atomicAdd(&cn[jj], 1u);
-				if (o2 + 1 >= 65535u) atomicOr(&C.qflags[q], 1u);
+				if (o2 + 1 >= C.cnt_max) atomicOr(&C.qflags[q], 1u);
 			}
 		}
 	}
@@ -790,7 +814,7 @@ __device__ __forceinline__ bool lq_chain_finish_wave(const mm128 *a, const i64 n
 		if (ln == 0) {
 			atomicAdd(&C.lambda2[q], (unsigned long long)(u32)(uqe - uqs + 1));
 			const u32 old = atomicAdd(&cn[sti], 1u);
-			if (old + 1 >= 65535u) atomicOr(&C.qflags[q], 1u);        // esterr.c:130: saturation regime, order would matter
+			if (old + 1 >= C.cnt_max) atomicOr(&C.qflags[q], 1u);     // esterr.c:130: saturation regime, the order matters (replayed)
 		}
 		// anchors 1 .. cnt-1 in query order: each is found by the reference's merge loop at its own place in mini_pos, beyond sti
 		for (i32 kk = 1 + (i32)ln; kk < cnt; kk += 64) {
@@ -800,7 +824,7 @@ __device__ __forceinline__ bool lq_chain_finish_wave(const mm128 *a, const i64 n
 			while (lo <= hi) { const i32 m = (i32)(((u64)lo + (u64)hi) >> 1), y = (i32)mp[m]; if (y < xk) lo = m + 1; else if (y > xk) hi = m - 1; else { at = m; break; } }
 			if (at >= 0) {
 				const u32 o2 = atomicAdd(&cn[at], 1u);
-				if (o2 + 1 >= 65535u) atomicOr(&C.qflags[q], 1u);
+				if (o2 + 1 >= C.cnt_max) atomicOr(&C.qflags[q], 1u);
 			}
 		}
 	}
@@ -991,6 +1015,10 @@ k_chain_wave(const mm128 *A, const u64 *gstart, const u32 *glist, u32 n_list, co
 	LQ_BLOCK_SYNC();
 	const bool listed = st_sh[4] != 0;                          // (uniform)
 	LQ_BLOCK_SYNC();
+	if (C.rec) {                                                 // replay of a saturated query (rare): the serial second half records the chains
+		if (ln == 0) lq_chain_finish(a, n, f, p, t, v, u, q, accumulate, P, C, false);
+		return;
+	}
 	const bool peak_tie = !listed && lq_chain_finish_wave(a, n, f, p, t, v, u, q, accumulate, P, C, watch, st_sh);
 	if (ln == 0 && (listed || peak_tie)) lq_tie_list(C, q, lq_hi32(a));
 }
@@ -1106,14 +1134,14 @@ __global__ void k_reliable(const u64 *se, const u32 *pvq_off, u32 n_q, u32 min_c
 }
 
 // minimap2-coverage.c:552-561: integer mean of the uint16 counters, count of those above it
-__global__ void k_cnt_stats(const u32 *cnts, const u64 *cnt_off, const u32 *nsize, u32 n_q, RowDev *rows, u32 *qflags)
+__global__ void k_cnt_stats(const u32 *cnts, const u64 *cnt_off, const u32 *nsize, u32 n_q, RowDev *rows, u32 *qflags, u32 cnt_max)
 {
 	u32 q = blockIdx.x * blockDim.x + threadIdx.x;
 	if (q >= n_q) return;
 	const u64 lo = cnt_off[q], hi = nsize ? lo + nsize[q] : cnt_off[q + 1];   // mv.n counters (minimap2-coverage.c:552-561)
 	u32 sum = 0, n = (u32)(hi - lo), nm = 0;
 	bool sat = false;
-	for (u64 j = lo; j < hi; ++j) { sum += cnts[j] & 0xffffu; if (cnts[j] >= 65535u) sat = true; }   // uint16 storage wraps (esterr.c:136)
+	for (u64 j = lo; j < hi; ++j) { sum += cnts[j] & cnt_max; if (cnts[j] >= cnt_max) sat = true; }   // uint16 storage wraps (esterr.c:136); a flagged query's counters are the replayed ones by now
 	if (sat) atomicOr(&qflags[q], 1u);
 	if (nsize) {                                            // counters the reference never allocated (see adopt_index_params)
 		bool over = false;
@@ -1121,7 +1149,7 @@ __global__ void k_cnt_stats(const u32 *cnts, const u64 *cnt_off, const u32 *nsiz
 		if (over) atomicOr(&qflags[q], 2u);
 	}
 	if (n) sum /= n;
-	for (u64 j = lo; j < hi; ++j) if ((cnts[j] & 0xffffu) > sum) ++nm;
+	for (u64 j = lo; j < hi; ++j) if ((cnts[j] & cnt_max) > sum) ++nm;
 	rows[q].n_match = nm;
 }
 

@@ -45,6 +45,17 @@ struct Ivl { u32 q, start, end; };
 
 struct ChainRec { i32 q, rid, rev, score, cnt, qs, qe, rs, re; };
 
+// One kept chain of a (query, part) whose match counters are replayed on the host in the reference's order (sat_replay.hpp).
+struct SatRec {
+	u64 first_x, first_y;      // the chain's first anchor: chain.c:141 sorts the chains by its x, hit.c:62 hashes it
+	u32 f_peak, run_hi, peak_j, seq;   // chain.c:99-107: the chains come out in descending (f[peak], peak index); run_hi: the run's strand | rid, seq: ordinal within the run
+	u32 score, cnt;            // the chain's u[] entry (chain.c:117-121)
+	i32 sti;                   // esterr.c:106
+	u32 n_at;                  // counters it increments beyond sti (esterr.c:131-137), listed in the pool from at_off on
+	u64 at_off;
+	u32 good, span;            // good: reaches esterr.c:128; span: esterr.c:121's qe - qs + 1
+};
+
 struct MapParams {
 	i32 k, w, hpc;
 	i32 max_gap, bw, max_skip, min_cnt, min_sc;

@@ -701,7 +701,10 @@ static reg_t *gen_regs(uint32_t hash, int qlen, int n_u, const uint64_t *u, cons
 		k += (int32_t)u[i];
 	}
 	lqo_sort_128x(z, n_u);
-	for (i = 0; i < n_u >> 1; ++i) tmp = z[i], z[i] = z[n_u-1-i], z[n_u-1-i] = tmp;
+	/* LQO_REGS_ASCENDING: a test switch that leaves out the reversal -- the chains then reach lq_cnt_match in the opposite order,
+	 * which only saturated counters can tell (tests use it to show that an input does exercise the order) */
+	if (!getenv("LQO_REGS_ASCENDING"))
+		for (i = 0; i < n_u >> 1; ++i) tmp = z[i], z[i] = z[n_u-1-i], z[n_u-1-i] = tmp;
 	r = (reg_t*)calloc(n_u, sizeof(reg_t));
 	for (i = 0; i < n_u; ++i) {
 		reg_t *ri = &r[i];
@@ -744,6 +747,17 @@ static int mini_idx(int qlen, const lqo_mm128 *a, int32_t n, const uint64_t *min
 	return -1;
 }
 
+/* Width of the match counters: uint16 in the reference (UINT16_MAX, esterr.c:130,136).  LQO_CNT_BITS=b (2..16) narrows them to
+ * b bits -- a test hook (the product has the same one, LQCOV_TEST_CNT_BITS) that brings the saturated regime, where the result
+ * depends on the order of the chains (hit.c:52-88), within reach of small inputs. */
+static uint16_t lqo_cnt_max(void)
+{
+	const char *e = getenv("LQO_CNT_BITS");
+	int b = e ? atoi(e) : 16;
+	if (b < 2 || b > 16) b = 16;
+	return (uint16_t)((1u << b) - 1);
+}
+
 /* lq_cnt_match (esterr.c:72-140) */
 static void cnt_match(const lqo_params *P, const part_t *pt, int qlen, int n_regs, const reg_t *regs, const lqo_mm128 *a,
                       int32_t n, const uint64_t *mini_pos, qstate_t *qs_, subc_v *cv)
@@ -752,6 +766,7 @@ static void cnt_match(const lqo_params *P, const part_t *pt, int qlen, int n_reg
 	uint64_t sum_k = 0;
 	uint32_t qs, qe, rs, re, rl, hang5, hang3;
 	uint16_t min_sc_m = (uint16_t)P->min_score_med, min_sc_g = (uint16_t)P->min_score_good;  /* packed p<<16|q, lqmap.c:841 */
+	const uint16_t cmax = lqo_cnt_max();
 	if (n == 0) return;
 	if (qs_->lambda / qlen > COVT && qs_->avg_k != 0.0) return;   /* esterr.c:87-91; the frac branch cannot trigger */
 	if (qs_->avg_k == 0.0) {
@@ -780,12 +795,12 @@ static void cnt_match(const lqo_params *P, const part_t *pt, int qlen, int n_reg
 		vpush(*cv, s);
 		if (r->score0 < min_sc_g) continue;
 		qs_->lambda2 += (qe - qs + 1);
-		if (qs_->cnt[st] < UINT16_MAX) qs_->cnt[st]++;
+		if (qs_->cnt[st] < cmax) qs_->cnt[st]++;
 		for (k = 1, j = st + 1; j < n && k < r->cnt; ++j) {
 			int32_t x = fwd_qpos(qlen, r->rev ? &a[r->as + r->cnt - 1 - k] : &a[r->as + k]);
 			if (x == (int32_t)mini_pos[j]) {
 				++k;
-				if (qs_->cnt[st] < UINT16_MAX) qs_->cnt[j]++;   /* sic: guard reads [st], esterr.c:136 */
+				if (qs_->cnt[st] < cmax) qs_->cnt[j] = (uint16_t)((qs_->cnt[j] + 1) & cmax);   /* sic: guard reads [st], esterr.c:136 -- cnt[j] wraps */
 			}
 		}
 	}

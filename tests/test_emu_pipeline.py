@@ -15,6 +15,12 @@ from tests.conftest import GOLDEN, read_gz
 from tests.helpers import ONT, parse_chain_dump, parse_sketch_dump, read_fastx, run_main
 
 
+# Tests that take minutes on the test emulator (every wave collective is 64 fiber switches; the default path now runs two passes
+# and the wave chain kernel shuffles per anchor).  Each has a twin in tests/test_gpu_parity.py that runs the same check through the
+# real library; here they run with LQCOV_SLOW_TESTS=1.
+slow_emu = pytest.mark.skipif(os.environ.get("LQCOV_SLOW_TESTS") != "1", reason="minutes on the test emulator; its GPU twin runs in -m gpu (LQCOV_SLOW_TESTS=1 runs it here)")
+
+
 def _cases(kind):
     return [c for c in json.load(open(os.path.join(GOLDEN, "cases.json"))) if c["kind"] == kind]
 
@@ -46,7 +52,7 @@ def test_emulated_tables_read_like_the_reference_consumer(emu_lib, tmp_path):
                                            w["high_div_frac"], w["control_frac"])
 
 
-@pytest.mark.parametrize("case", [c for c in _cases("table") if c["name"] in ("tiny_ont", "adv_ont", "adv_parts")], ids=lambda c: c["name"])
+@pytest.mark.parametrize("case", [pytest.param(c, marks=slow_emu) if c["name"] == "adv_ont" else c for c in _cases("table") if c["name"] in ("tiny_ont", "adv_ont", "adv_parts")], ids=lambda c: c["name"])
 @pytest.mark.parametrize("tile", ["64", "1000"])
 def test_emulated_every_query_through_klib_passes(emu_lib, case, tile, monkeypatch):
     """LQCOV_SORT=klib: every query goes through klib's passes as 8-byte records, no bucket leaves them early (the passes on
@@ -199,7 +205,7 @@ def test_emulated_chains_mid_occ_and_accumulators(emu_lib, name, tfn, qfn):
     eng.close()
 
 
-@pytest.mark.parametrize("lanes", ["1", "3"])
+@pytest.mark.parametrize("lanes", ["1", pytest.param("3", marks=slow_emu)])
 def test_emulated_query_batching_is_invisible(emu_lib, datasets, monkeypatch, lanes):
     """many small query batches dealt to 1..3 mapping lanes (own stream + work space each; concurrent threads on the GPU,
     round-robin in the emulator): same table"""
@@ -229,7 +235,7 @@ def test_emulated_reset_and_rerun(emu_lib):
     eng.close()
 
 
-@pytest.mark.parametrize("shift", ["4", "7", "12"])
+@pytest.mark.parametrize("shift", ["4", pytest.param("7", marks=slow_emu), pytest.param("12", marks=slow_emu)])
 def test_emulated_every_walk_size_class(emu_lib, datasets, monkeypatch, shift):
     """shrinks the LDS-window thresholds of the klib-order sort so that small inputs exercise every size class
     of the digit walk, including the global-memory lane walker used when a sub-array exceeds 156 KiB"""
@@ -242,7 +248,7 @@ def test_emulated_every_walk_size_class(emu_lib, datasets, monkeypatch, shift):
     assert out == want
 
 
-@pytest.mark.parametrize("case", [c for c in _cases("table") if c["name"] in ("tiny_ont", "adv_ont", "adv_parts", "tiny_spike")], ids=lambda c: c["name"])
+@pytest.mark.parametrize("case", [pytest.param(c, marks=slow_emu) if c["name"] == "adv_ont" else c for c in _cases("table") if c["name"] in ("tiny_ont", "adv_ont", "adv_parts", "tiny_spike")], ids=lambda c: c["name"])
 def test_emulated_wave_chain_kernel_on_every_run(emu_lib, case, monkeypatch):
     """LQCOV_CHAIN_WAVE_MIN=3 sends every viable run through the cooperative (64 candidates per step) chain kernel"""
     monkeypatch.setenv("LQCOV_CHAIN_WAVE_MIN", "3")
@@ -262,6 +268,7 @@ def test_emulated_chain_lds_budget_overflow(emu_lib, case, monkeypatch):
     assert out == read_gz(case["expect"])
 
 
+@slow_emu
 def test_emulated_constant_digit_levels_can_be_walked_or_skipped(emu_lib, datasets, monkeypatch):
     """levels of the klib-order sort whose key byte is the same in every anchor of a part are stepped over by default;
     LQCOV_NO_LEVEL_SKIP=1 runs them as identity passes like klib does: same table"""
@@ -312,7 +319,7 @@ def _few_targets_dataset(tmp_path, n_targets=14, tlen=25000, n_queries=6, qlen=2
     return tf, qf
 
 
-@pytest.mark.parametrize("variant", ["ckpt", "ckpt_all_klib", "plain"])
+@pytest.mark.parametrize("variant", ["ckpt", pytest.param("ckpt_all_klib", marks=slow_emu), "plain"])
 def test_emulated_checkpointed_walks(emu_lib, tmp_path, monkeypatch, variant):
     """long sub-arrays of a few-bucket pass are walked in pieces from computed checkpoint states (kernels_ckpt.hpp):
     same table as the oracle, with the size classes shrunk so that this small input reaches them"""
@@ -393,6 +400,7 @@ def check_run_list_variants(lib, tmp_path, monkeypatch):
         assert out == want1, stage
 
 
+@slow_emu
 def test_emulated_run_list_variants(emu_lib, tmp_path, monkeypatch):
     check_run_list_variants(emu_lib, tmp_path, monkeypatch)
 
@@ -445,7 +453,7 @@ def check_repeat_rich_randomised(lib, tmp_path, monkeypatch, seed):
     return argv, want
 
 
-@pytest.mark.parametrize("seed", [0, 1])
+@pytest.mark.parametrize("seed", [0, pytest.param(1, marks=slow_emu)])
 def test_emulated_repeat_rich_randomised(emu_lib, tmp_path, monkeypatch, seed):
     """equal-x anchors everywhere (repeats inside the queries): rows equal the reference binary's, whichever path the sub-arrays
     take (parallel passes for those without a tie, klib's walk for the others); and the input has teeth: a stable sort by x
@@ -456,6 +464,7 @@ def test_emulated_repeat_rich_randomised(emu_lib, tmp_path, monkeypatch, seed):
         assert oracle_bind.table(argv, ["--stable-sort"]) != want
 
 
+@slow_emu
 def test_emulated_ultra_long_reads(emu_lib, tmp_path):
     """reads of 100-350 kb at 30x (the shape of BASELINE configs[4]): (query, strand) sub-arrays of 10^5 anchors and runs
     of thousands per target; the three longest as queries, against the reference binary (or the oracle)"""
@@ -511,6 +520,7 @@ def test_emulated_long_pair_among_many_targets(emu_lib, tmp_path):
     check_long_pair_among_many_targets(emu_lib, tmp_path)
 
 
+@slow_emu
 def test_emulated_parallel_sort_size_classes(emu_lib, datasets, monkeypatch):
     """the parallel sort with its size classes shrunk 128-fold: more partition passes than are issued without looking
     (the tail with its look at the counter), segments whose keys agree in the bits of a pass (stepped over, unless still named
@@ -525,7 +535,7 @@ def test_emulated_parallel_sort_size_classes(emu_lib, datasets, monkeypatch):
         assert out == want, passes
 
 
-@pytest.mark.parametrize("case", [c for c in _cases("table") if c["name"] in ("tiny_ont", "adv_parts")] or _cases("table")[:2], ids=lambda c: c["name"])
+@pytest.mark.parametrize("case", [pytest.param(c, marks=slow_emu) if c["name"] == "adv_parts" else c for c in _cases("table") if c["name"] in ("tiny_ont", "adv_parts")] or _cases("table")[:2], ids=lambda c: c["name"])
 def test_emulated_threads_in_descending_order_and_the_sort_checked(emu_lib, case, monkeypatch):
     """Two of the emulator's and the engine's self-checks at once.
     LQ_EMU_ORDER=reverse: the emulator runs a block's threads lowest first by default and fills the kernels' LDS with a pattern
@@ -551,12 +561,12 @@ def test_emulated_threads_in_descending_order_and_the_sort_checked(emu_lib, case
 
 
 # ---- klib's order only where it can be observed; seed hits that cannot reach a chain never written (map_batch) -------------------
-def check_observable_ties_scheme(lib, tmp_path, monkeypatch, seed, env):
+def check_observable_ties_scheme(lib, tmp_path, monkeypatch, seed, env, small=False):
     """repeat-rich reads (equal-x anchors everywhere, rows depend on klib's order): first pass with the counting filter and any
     sort, second pass in klib's order for the runs the chain kernels listed; the table equals the reference's under every
     shape of the filter (table shrunk: rid slices, aliased counters; no filter) and of the second pass (tiny work space: several
     sub-batches), and with the scheme switched off (LQCOV_TIES=klib: rounds 1-3's path)"""
-    tf, qf = _repeat_rich_dataset(tmp_path, seed)
+    tf, qf = _repeat_rich_dataset(tmp_path, seed, **(dict(n_targets=12, n_queries=2, glen=21000) if small else {}))   # (small: what the test emulator chews in seconds)
     argv = ONT + [tf, qf]
     want = oracle_bind.ref_table(argv) if oracle_bind.have_ref() else oracle_bind.table(argv)
     for k, v in env.items():
@@ -571,11 +581,14 @@ OBS_ENVS = [{}, {"LQCOV_FILTER_KEYS": "64"}, {"LQCOV_FILTER_KEYS": "1024", "LQCO
             {"LQCOV_ANCHOR_BUDGET": "20000", "LQCOV_LANES": "2"}, {"LQCOV_TIES": "klib"}, {"LQCOV_DEBUG_SORT": "1", "LQCOV_PS_SHIFT": "5"},
             {"LQCOV_CHAIN_WAVE_MIN": "3"},             # (every run through the wave kernel: its own copy of the tie rule)
             {"LQCOV_PLAN_AHEAD": "0", "LQCOV_FILTER_SPLIT": "0"}]   # (the seed plan made when the part is mapped, not with its index; strands share a target's bins)
+# the same switches in four runs for the test emulator (a minute each on repeat-rich reads); the GPU suite takes them one by one
+OBS_ENVS_EMU = [{}, {"LQCOV_FILTER_KEYS": "64", "LQCOV_FILTER_ACAP": "100", "LQCOV_FILTER_SPLIT": "0", "LQCOV_CHAIN_WAVE_MIN": "3"},
+                {"LQCOV_FILTER": "0", "LQCOV_PLAN_AHEAD": "0", "LQCOV_ANCHOR_BUDGET": "20000", "LQCOV_DEBUG_SORT": "1", "LQCOV_PS_SHIFT": "5"}, {"LQCOV_TIES": "klib"}]
 
 
-@pytest.mark.parametrize("env", OBS_ENVS, ids=lambda e: "+".join("%s=%s" % kv for kv in e.items()) or "default")
+@pytest.mark.parametrize("env", OBS_ENVS_EMU, ids=lambda e: "+".join("%s=%s" % kv for kv in e.items()) or "default")
 def test_emulated_observable_ties_scheme(emu_lib, tmp_path, monkeypatch, env):
-    err = check_observable_ties_scheme(emu_lib, tmp_path, monkeypatch, 2 + len(env), env)
+    err = check_observable_ties_scheme(emu_lib, tmp_path, monkeypatch, 2 + len(env), env, small=True)
     if "LQCOV_TIES" not in env:
         assert "queries chained in klib's order" in err and " 0 runs of 0 queries" not in err      # the second pass ran
 
@@ -604,3 +617,89 @@ def check_filter_drops_chance_hits(lib, tmp_path):
 
 def test_emulated_filter_drops_chance_hits(emu_lib, tmp_path):
     check_filter_drops_chance_hits(emu_lib, tmp_path)
+
+
+def _pileup_dataset(tmp_path, n_targets, seed=7, n_hot=2, qlen=900):
+    """`n_hot` queries buried under `n_targets` pieces of themselves (half of the pieces of the first query start at one and
+    the same base, so that the counter of one minimizer climbs fastest), plus one query nothing matches"""
+    rng = np.random.default_rng(seed)
+    B = np.array(list("ACGT"))
+    qs = [rng.integers(0, 4, qlen) for _ in range(n_hot + 1)]
+    tf, qf = str(tmp_path / "pile_t.fa"), str(tmp_path / "pile_q.fa")
+    with open(tf, "w") as f:
+        for i in range(n_targets):
+            q = qs[i % n_hot]
+            if i % n_hot == 0 and rng.random() < 0.5:
+                s, L = qlen // 3, int(rng.integers(150, 600))
+            else:
+                L = int(rng.integers(150, 700)); s = int(rng.integers(0, qlen - L + 1))
+            seg = q[s:s + L].copy()
+            for _ in range(int(rng.integers(0, 4))):
+                at = int(rng.integers(20, L)); seg[at] = (seg[at] + 1 + rng.integers(0, 3)) % 4
+            if rng.random() < 0.5:
+                seg = (3 - seg)[::-1]
+            f.write(">t%d\n%s\n" % (i, "".join(B[seg])))
+    with open(qf, "w") as f:
+        for i, q in enumerate(qs):
+            f.write(">q%d\n%s\n" % (i, "".join(B[q])))
+    return tf, qf
+
+
+PILEUP16 = dict(n_targets=130000, f_first=0.85, seed=11, qlen=900)
+PILEUP16_ARGV = ["-Y", "-l", "0", "-q", "40", "-k", "12", "-w", "5", "-I", "4G", "-p", "40", "-m", "20", "-t", "4"]
+
+
+def _pileup16_dataset(tmp_path, n_targets, f_first, seed, qlen):
+    """A pile-up that fills a real uint16 counter: 85 % of 130 000 targets are prefixes of one 900-base query, so the counter of
+    the query's first minimizer reaches 65 535 about half way through its chains and the chains that come later (in mm_gen_regs'
+    order) no longer count (esterr.c:136) -- which ones those are decides the row.  tests/golden/pileup16_rows.json holds what
+    the reference binary printed for it (tests/golden/make_pileup_golden.py)."""
+    rng = np.random.default_rng(seed)
+    B = np.array(list("ACGT"))
+    q = rng.integers(0, 4, qlen)
+    tf, qf = str(tmp_path / "pile16_t.fa"), str(tmp_path / "pile16_q.fa")
+    with open(tf, "w") as f:
+        for i in range(n_targets):
+            if rng.random() < f_first:
+                s, L = 0, int(rng.integers(150, 900))
+            else:
+                L = int(rng.integers(150, 700)); s = int(rng.integers(0, qlen - L + 1))
+            seg = q[s:s + L].copy()
+            for _ in range(int(rng.integers(0, 3))):
+                at = int(rng.integers(20, L)); seg[at] = (seg[at] + 1 + rng.integers(0, 3)) % 4
+            if rng.random() < 0.5:
+                seg = (3 - seg)[::-1]
+            f.write(">t%d\n%s\n" % (i, "".join(B[seg])))
+    with open(qf, "w") as f:
+        f.write(">q0\n" + "".join(B[q]) + "\n")
+        f.write(">q1\n" + "".join(B[rng.integers(0, 4, 700)]) + "\n")
+    return tf, qf
+
+
+def check_saturated_counters_are_replayed(lib, tmp_path, monkeypatch, bits, n_targets, parts, env=""):
+    """esterr.c:130,136: the match counters are uint16 and their saturation test reads the counter of the chain's first minimizer,
+    so once a counter is full the others depend on the order in which lq_cnt_match met the chains (hit.c:52-88).  With the
+    counters narrowed to `bits` bits on both sides (a test hook) a few hundred overlaps get there: the rows must equal the
+    oracle's, which walks the chains serially in the reference's order -- and not the rows of the opposite order."""
+    tf, qf = _pileup_dataset(tmp_path, n_targets)
+    argv = ["-Y", "-l", "0", "-q", "40", "-k", "12", "-w", "5", "-I", parts, "-p", "40", "-m", "20", "-t", "4", tf, qf]
+    monkeypatch.setenv("LQO_CNT_BITS", str(bits))
+    want = oracle_bind.table(argv)
+    monkeypatch.setenv("LQO_REGS_ASCENDING", "1")
+    assert oracle_bind.table(argv) != want                       # the input can tell the order
+    monkeypatch.delenv("LQO_REGS_ASCENDING")
+    monkeypatch.setenv("LQO_CNT_BITS", "16")
+    assert oracle_bind.table(argv) != want                       # ... and the width
+    monkeypatch.setenv("LQCOV_TEST_CNT_BITS", str(bits))
+    for kv in env.split("+"):
+        if kv:
+            monkeypatch.setenv(*kv.split("=", 1))
+    rc, out, err = run_main(lib, argv)
+    assert rc == 0, err[-2000:]
+    assert out == want
+    assert "chains replayed in the reference's order" in err
+
+
+@pytest.mark.parametrize("bits,n_targets,parts,env", [(5, 300, "4G", ""), (5, 400, "40K", "LQCOV_TIES=klib")], ids=["one_part", "parts_all_klib"])
+def test_emulated_saturated_counters_are_replayed(emu_lib, tmp_path, monkeypatch, bits, n_targets, parts, env):
+    check_saturated_counters_are_replayed(emu_lib, tmp_path, monkeypatch, bits, n_targets, parts, env)

@@ -491,6 +491,29 @@ def test_gpu_filter_drops_chance_hits(gpu_lib, tmp_path):
     E.check_filter_drops_chance_hits(gpu_lib, tmp_path)
 
 
+@pytest.mark.parametrize("bits,n_targets,parts,env", [(5, 300, "4G", ""), (5, 400, "40K", "LQCOV_TIES=klib"), (6, 1500, "40K", ""), (7, 3000, "4G", "LQCOV_CHAIN_WAVE_MIN=1000")],
+                         ids=["one_part", "parts_all_klib", "parts_until_the_coverage_cap", "thread_kernel_only"])
+def test_gpu_saturated_counters_are_replayed(gpu_lib, tmp_path, monkeypatch, bits, n_targets, parts, env):
+    E.check_saturated_counters_are_replayed(gpu_lib, tmp_path, monkeypatch, bits, n_targets, parts, env)
+
+
+def test_gpu_a_full_uint16_counter_equals_the_reference_fixture(gpu_lib, tmp_path):
+    """the real thing: 110 000 good overlaps on the first minimizer of one query inside one index part.  The counter stops at
+    65 535, the chains that mm_gen_regs' order puts after that point no longer count (esterr.c:136); the row is what the reference
+    binary printed (tests/golden/pileup16_rows.json) -- the oracle with the chains in the opposite order prints another one"""
+    fx = json.load(open(os.path.join(GOLDEN, "pileup16_rows.json")))
+    tf, qf = E._pileup16_dataset(tmp_path, **fx["dataset"])
+    p, _, _ = api.parse_args(fx["argv"] + [tf, qf])
+    eng = api.Engine(p, 0, lib=gpu_lib)
+    out = str(tmp_path / "o.tsv")
+    eng.run_files(tf, qf, out=out, err=str(tmp_path / "e.log"))
+    rows = eng.rows()
+    eng.close()
+    assert open(out).read() == fx["table"]
+    assert rows[0]["flags"] & 5 == 5 and rows[1]["flags"] == 0      # LQCOV_ROW_SATURATED | LQCOV_ROW_REPLAYED
+    assert "chains replayed in the reference's order" in open(str(tmp_path / "e.log")).read()
+
+
 def test_gpu_run_files_pipeline_on_a_plain_file_in_many_parts(gpu_lib, tmp_path, monkeypatch):
     """lqcov_run_files' own pipeline on the GPU: a plain FASTQ parsed from the mapping in tiny pieces, four index parts, part k + 1
     uploaded, sketched and indexed by a second host thread while part k is mapped; against the oracle on the gzip of the same reads"""

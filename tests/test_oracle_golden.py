@@ -43,3 +43,13 @@ def test_grouped_chaining_and_stable_sort_modes_on_fixture():
     argv = ["-Y", "-l", "0", "-q", "160", "-k", "12", "-w", "5", "-I", "100K", "-p", "160", os.path.join(GOLDEN, "adv_all.fa.gz"), os.path.join(GOLDEN, "adv_sub.fq.gz")]
     want = read_gz("adv_parts.table.gz")
     assert oracle_bind.table(argv, ["--grouped"]) == want
+
+
+def test_oracle_fills_a_uint16_counter_like_the_reference(tmp_path):
+    """esterr.c:130,136 on a pile-up that fills a real uint16 counter: the oracle prints what the reference binary printed
+    (tests/golden/pileup16_rows.json, made by make_pileup_golden.py), and another table with the chains in the opposite order"""
+    import json
+    from tests.test_emu_pipeline import _pileup16_dataset
+    fx = json.load(open(os.path.join(GOLDEN, "pileup16_rows.json")))
+    tf, qf = _pileup16_dataset(tmp_path, **fx["dataset"])
+    assert oracle_bind.table(fx["argv"] + [tf, qf]) == fx["table"]
