@@ -8,6 +8,12 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+# Tests that take a good part of a minute each on the test emulator (every wave collective is 64 fiber switches; the default path
+# runs two passes) or on three gloo ranks.  Each has a twin in tests/test_gpu_parity.py (the same check through the real library,
+# `-m gpu`) or a smaller sibling that stays in the default run; LQCOV_SLOW_TESTS=1 runs them here too.
+import pytest  # noqa: E402
+slow_emu = pytest.mark.skipif(os.environ.get("LQCOV_SLOW_TESTS") != "1", reason="slow on the CPU test emulator; its GPU twin runs in -m gpu (LQCOV_SLOW_TESTS=1 runs it here)")
+
 ONT = ["-Y", "-l", "0", "-q", "160", "-k", "12", "-w", "5", "-I", "4G", "-p", "160", "-t", "4"]
 
 

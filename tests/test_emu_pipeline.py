@@ -12,20 +12,14 @@ import pytest
 from longqc_amd import api
 from tests import oracle_bind
 from tests.conftest import GOLDEN, read_gz
-from tests.helpers import ONT, parse_chain_dump, parse_sketch_dump, read_fastx, run_main
-
-
-# Tests that take minutes on the test emulator (every wave collective is 64 fiber switches; the default path now runs two passes
-# and the wave chain kernel shuffles per anchor).  Each has a twin in tests/test_gpu_parity.py that runs the same check through the
-# real library; here they run with LQCOV_SLOW_TESTS=1.
-slow_emu = pytest.mark.skipif(os.environ.get("LQCOV_SLOW_TESTS") != "1", reason="minutes on the test emulator; its GPU twin runs in -m gpu (LQCOV_SLOW_TESTS=1 runs it here)")
+from tests.helpers import ONT, parse_chain_dump, parse_sketch_dump, read_fastx, run_main, slow_emu
 
 
 def _cases(kind):
     return [c for c in json.load(open(os.path.join(GOLDEN, "cases.json"))) if c["kind"] == kind]
 
 
-@pytest.mark.parametrize("case", _cases("table"), ids=lambda c: c["name"])
+@pytest.mark.parametrize("case", [pytest.param(c, marks=slow_emu) if c["name"] in ("adv_defaults", "adv_fasta_query") else c for c in _cases("table")], ids=lambda c: c["name"])
 def test_emulated_pipeline_reproduces_reference_tables(emu_lib, case):
     rc, out, err = run_main(emu_lib, case["argv"], cwd=GOLDEN)
     assert rc == 0, err
@@ -53,7 +47,7 @@ def test_emulated_tables_read_like_the_reference_consumer(emu_lib, tmp_path):
 
 
 @pytest.mark.parametrize("case", [pytest.param(c, marks=slow_emu) if c["name"] == "adv_ont" else c for c in _cases("table") if c["name"] in ("tiny_ont", "adv_ont", "adv_parts")], ids=lambda c: c["name"])
-@pytest.mark.parametrize("tile", ["64", "1000"])
+@pytest.mark.parametrize("tile", ["64", pytest.param("1000", marks=slow_emu)])
 def test_emulated_every_query_through_klib_passes(emu_lib, case, tile, monkeypatch):
     """LQCOV_SORT=klib: every query goes through klib's passes as 8-byte records, no bucket leaves them early (the passes on
     the bytes of the position run too, reading their digits from the originals); streaming kernels over many small tiles"""
@@ -257,7 +251,7 @@ def test_emulated_wave_chain_kernel_on_every_run(emu_lib, case, monkeypatch):
     assert out == read_gz(case["expect"])
 
 
-@pytest.mark.parametrize("case", [c for c in _cases("table") if c["name"] in ("tiny_ont", "adv_ont", "adv_parts", "tiny_spike")], ids=lambda c: c["name"])
+@pytest.mark.parametrize("case", [pytest.param(c, marks=slow_emu) if c["name"] == "adv_ont" else c for c in _cases("table") if c["name"] in ("tiny_ont", "adv_ont", "adv_parts", "tiny_spike")], ids=lambda c: c["name"])
 def test_emulated_chain_lds_budget_overflow(emu_lib, case, monkeypatch):
     """LQCOV_CHAIN_CAP=64 with LQCOV_CHAIN_WAVE_MIN=200: the smallest LDS budget of k_chain (64 anchors per wave) with every run
     up to 64 anchors in that kernel: the runs of a wave are chained in several rounds"""
@@ -453,7 +447,7 @@ def check_repeat_rich_randomised(lib, tmp_path, monkeypatch, seed):
     return argv, want
 
 
-@pytest.mark.parametrize("seed", [0, pytest.param(1, marks=slow_emu)])
+@pytest.mark.parametrize("seed", [pytest.param(0, marks=slow_emu), pytest.param(1, marks=slow_emu)])
 def test_emulated_repeat_rich_randomised(emu_lib, tmp_path, monkeypatch, seed):
     """equal-x anchors everywhere (repeats inside the queries): rows equal the reference binary's, whichever path the sub-arrays
     take (parallel passes for those without a tie, klib's walk for the others); and the input has teeth: a stable sort by x
@@ -586,7 +580,7 @@ OBS_ENVS_EMU = [{}, {"LQCOV_FILTER_KEYS": "64", "LQCOV_FILTER_ACAP": "100", "LQC
                 {"LQCOV_FILTER": "0", "LQCOV_PLAN_AHEAD": "0", "LQCOV_ANCHOR_BUDGET": "20000", "LQCOV_DEBUG_SORT": "1", "LQCOV_PS_SHIFT": "5"}, {"LQCOV_TIES": "klib"}]
 
 
-@pytest.mark.parametrize("env", OBS_ENVS_EMU, ids=lambda e: "+".join("%s=%s" % kv for kv in e.items()) or "default")
+@pytest.mark.parametrize("env", [pytest.param(e, marks=slow_emu) if "LQCOV_TIES" in e else e for e in OBS_ENVS_EMU], ids=lambda e: "+".join("%s=%s" % kv for kv in e.items()) or "default")
 def test_emulated_observable_ties_scheme(emu_lib, tmp_path, monkeypatch, env):
     err = check_observable_ties_scheme(emu_lib, tmp_path, monkeypatch, 2 + len(env), env, small=True)
     if "LQCOV_TIES" not in env:

@@ -11,7 +11,7 @@ import pytest
 
 from tests import oracle_bind
 from tests.conftest import GOLDEN, read_gz
-from tests.helpers import run_main
+from tests.helpers import run_main, slow_emu
 
 CASES = json.load(open(os.path.join(GOLDEN, "mmi_cases.json")))
 
@@ -80,7 +80,7 @@ def check_dump_equals_reference_dump(lib, case, tmp_path):
     return ours
 
 
-@pytest.mark.parametrize("case", CASES, ids=lambda c: c["name"])
+@pytest.mark.parametrize("case", [pytest.param(c, marks=slow_emu) if c["name"] == "adv_k12w5_300K" else c for c in CASES], ids=lambda c: c["name"])
 def test_emulated_maps_from_the_reference_index_file(emu_lib, case, tmp_path):
     check_maps_from_reference_index(emu_lib, case, tmp_path)
 
@@ -97,6 +97,7 @@ def test_emulated_index_dump_equals_the_reference_dump_and_loads_back(emu_lib, c
         assert r.returncode == 0 and r.stdout.decode() == out
 
 
+@slow_emu
 def test_emulated_dump_while_mapping_and_part_level_calls(emu_lib, tmp_path):
     """-d together with a query file maps as usual and writes the index; lqcov_part_dump / lqcov_part_load"""
     from longqc_amd import api

@@ -13,7 +13,7 @@ import torch.multiprocessing as mp
 from longqc_amd import api, multigpu
 from tests import oracle_bind
 from tests.conftest import GOLDEN, ROOT, read_gz
-from tests.helpers import read_fastx
+from tests.helpers import read_fastx, slow_emu
 
 
 def test_split_parts_matches_reference_rule():
@@ -80,7 +80,7 @@ def _worker(rank, world, port, argv_I, out_path, use_gpu=False):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, pytest.param(3, marks=slow_emu)])
 def test_two_ranks_gloo_equal_reference_multipart_table(emu_lib, tmp_path, world):
     """adv_parts fixture: 10 parts at -I 100K, the pile-up queries hit the COVT cap after part 1 -- the
     distributed run must reproduce the reference's sequential multi-part table byte for byte."""
@@ -136,7 +136,7 @@ def _worker_qshard(rank, world, port, argv_I, out_path, use_gpu=False, parts_api
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,I,expect", [(2, 100000, "adv_parts.table.gz"), (3, 100000, "adv_parts.table.gz"), (2, 4000000000, "adv_ont.table.gz")])
+@pytest.mark.parametrize("world,I,expect", [(2, 100000, "adv_parts.table.gz"), pytest.param(3, 100000, "adv_parts.table.gz", marks=slow_emu), (2, 4000000000, "adv_ont.table.gz")])
 def test_query_sharded_replicated_index_equals_reference_table(emu_lib, tmp_path, world, I, expect):
     """the north-star split: every rank sketches a share of each part, the minimizers are all-gathered, every rank builds the
     same index and maps its share of the queries; rows gathered on rank 0.  10 parts with the COVT cap, and one part."""
@@ -145,7 +145,7 @@ def test_query_sharded_replicated_index_equals_reference_table(emu_lib, tmp_path
     assert open(out).read() == read_gz(expect)
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, pytest.param(3, marks=slow_emu)])
 def test_query_sharded_parts_in_a_pipeline_equal_reference_table(emu_lib, tmp_path, world):
     """QueryShardRunner.map_parts: the same split with two part objects and persistent exchange buffers (the fronts run under the
     mappings on a GPU; here one after the other), 10 parts with the COVT cap"""
