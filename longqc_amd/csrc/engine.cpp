@@ -1905,14 +1905,27 @@ int lqcov_handle::run_files(const char *target, const char *query, FILE *out, FI
 	}
 	if (is_idx && dump_path) throw std::domain_error("-d with a prebuilt index as the target is not supported");
 	const double t_run0 = lq_now_s();
-	if (query) {
+	// The queries (read, upload, sketch: minimap2-coverage.c:406-431) while the host makes the first part -- parse, page-locked
+	// buffers, 2-bit packing, all host work; joined before anything of the targets touches the device.
+	auto load_queries = [&]() {
+		LQ_HIP_CHECK(hipSetDevice(device));
 		FastxReader fq(query);
 		ReadBatch qb;
 		while (fq.read_minibatch(INT64_MAX, qb, true) > 0) {}
 		const double tq = lq_now_s();
 		set_queries(qb.size(), qb.seq.data(), qb.seq_off.data(), qb.any_qual ? qb.qual.data() : nullptr, qb.names.data(), qb.name_off.data());
 		if (log) fprintf(log, "[lqcov] loaded %u query sequence(s), %" PRIu64 " bases, %" PRIu64 " minimizers (read %.3f s, upload + sketch %.3f s)\n", qb.size(), qb.bases(), q.n_mini, tq - t_run0, lq_now_s() - tq);
+	};
+	std::future<void> queries_loaded;
+	if (query) {
+#ifndef LQ_EMU
+		if (!is_idx) queries_loaded = std::async(std::launch::async, load_queries);
+		else load_queries();
+#else
+		load_queries();                                           // (the test emulator runs its kernels on the calling thread, one at a time)
+#endif
 	}
+	struct QueriesJoin { std::future<void> &f; ~QueriesJoin() { if (f.valid()) { try { f.get(); } catch (...) {} } } } queries_join{queries_loaded};   // (never leave the task behind when something else throws)
 	FILE *dump = nullptr;
 	if (dump_path) { dump = fopen(dump_path, "wb"); if (!dump) throw std::runtime_error(std::string("failed to open file '") + dump_path + "'"); }
 	struct Closer { FILE *f; ~Closer() { if (f) fclose(f); } } dump_closer{dump};
@@ -2070,6 +2083,7 @@ int lqcov_handle::run_files(const char *target, const char *query, FILE *out, FI
 		parts.emplace_back(new Part()); parts.emplace_back(new Part());
 		Part *dev[2] = { parts[parts.size() - 2].get(), parts[parts.size() - 1].get() };
 		produce(0);
+		if (queries_loaded.valid()) queries_loaded.get();          // (a query file that cannot be read: reported here)
 		if (!hp[0].empty()) {
 			std::future<void> fut_h;
 			if (!hp[0].last) fut_h = std::async(std::launch::async, produce, 1);
