@@ -162,8 +162,48 @@ int lqcov_parse_args(int argc, const char *const *argv, lqcov_params *p, const c
 	return 0;
 }
 
+#ifndef LQ_EMU
+#include <execinfo.h>
+#include <fcntl.h>
+#include <signal.h>
+#include <unistd.h>
+// LQCOV_SEGV_TRACE=1 (diagnostics, like LQCOV_TRACE_LAUNCHES): the native stack of a thread that faults goes to stderr before
+// the default action takes over -- a fault inside a lane's thread otherwise shows up as the caller waiting in lqcov_part_map
+static int lq_segv_fd = 2;                                // LQCOV_SEGV_TRACE=<path>: the report goes there (a test runner may have captured fd 2); =1: stderr
+static void lq_segv_trace(int sig, siginfo_t *si, void *)
+{
+	void *bt[64];
+	char msg[160];
+	const int m = snprintf(msg, sizeof(msg), "[lqcov] fatal signal %d at address %p, native stack of the faulting thread:\n", sig, si ? si->si_addr : nullptr);
+	(void)!write(lq_segv_fd, msg, (size_t)m);
+	const int n = backtrace(bt, 64);
+	backtrace_symbols_fd(bt, n, lq_segv_fd);
+	signal(sig, SIG_DFL);
+	raise(sig);
+}
+void lq_segv_altstack()                                   // (per thread: the handler must run even when the thread's own stack is the problem)
+{
+	if (!getenv("LQCOV_SEGV_TRACE")) return;
+	static thread_local char alt[1 << 16];
+	stack_t ss; ss.ss_sp = alt; ss.ss_size = sizeof(alt); ss.ss_flags = 0;
+	sigaltstack(&ss, nullptr);
+}
+static void lq_segv_install()
+{
+	const char *e = getenv("LQCOV_SEGV_TRACE");
+	if (e && e[0] == '/' && lq_segv_fd == 2) { const int fd = open(e, O_WRONLY | O_CREAT | O_APPEND, 0644); if (fd >= 0) lq_segv_fd = fd; }
+	struct sigaction sa; memset(&sa, 0, sizeof(sa));
+	sa.sa_sigaction = lq_segv_trace; sa.sa_flags = SA_SIGINFO | SA_ONSTACK;
+	sigaction(SIGSEGV, &sa, nullptr); sigaction(SIGBUS, &sa, nullptr); sigaction(SIGABRT, &sa, nullptr);
+	lq_segv_altstack();
+}
+#endif
+
 lqcov_handle *lqcov_create(const lqcov_params *p, int device)
 {
+#ifndef LQ_EMU
+	if (getenv("LQCOV_SEGV_TRACE")) lq_segv_install();
+#endif
 	// HIP multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and kernels of streams that share a queue run
 	// one after the other: with the default never more than four of the lanes' kernels run at a time (rocprofv3 kernel trace,
 	// configs[2]).  Eight queues: 1.71-1.73 s per step against 1.74-1.77 (16: the same).  Only effective when the HIP runtime

@@ -9,6 +9,9 @@
 #include "fastx.hpp"
 #include "fastx_mem.hpp"
 #include "sat_replay.hpp"
+#ifndef LQ_EMU
+extern "C" void lq_segv_altstack();                      // api.cpp (LQCOV_SEGV_TRACE)
+#endif
 #include <cstdio>
 #include <cstring>
 #include <cmath>
@@ -1562,6 +1565,9 @@ void lqcov_handle::map_part(Part &pt)
 			th.emplace_back([&, li]() {
 				try {
 					LQ_HIP_CHECK(hipSetDevice(device));
+#ifndef LQ_EMU
+					lq_segv_altstack();
+#endif
 					MapLane &L = *lanes[li];
 					lq_alloc_stream = L.stream;                              // this thread's buffers grow from the stream-ordered pool (prim.hpp)
 					struct AllocGuard { ~AllocGuard() { lq_alloc_stream = nullptr; } } alloc_guard;

@@ -495,6 +495,7 @@ static inline int ilog2_32(uint32_t v)              /* chain.c:8-20 */
 typedef VEC(uint64_t) u64_v;
 typedef VEC(lqo_mm128) mm_v;
 
+unsigned long long lqo_tie_reason[8];   /* debug statistics (LQO_TIE_DEBUG): why a run was called observable */
 static void chain_dp_range_s(const lqo_params *P, float avg_qspan, const lqo_mm128 *a, int64_t n, u64_v *u_out, mm_v *b_out, int *peak_tie, int *band_tie)
 {
 	int32_t *f, *p, *t, *v, n_u, n_v, k;
@@ -509,7 +510,7 @@ static void chain_dp_range_s(const lqo_params *P, float avg_qspan, const lqo_mm1
 		int64_t max_j = -1;
 		int32_t qi = (int32_t)a[i].y, q_span = a[i].y >> 32 & 0xff;
 		int32_t max_f = q_span, n_skip = 0;
-		int have_act = 0, grp_loud = 0, grp_s0 = 0, grp_tm = 0, grp_dup = 0; uint64_t act_x = 0; int32_t grp_m = 0, grp_top = 0;
+		int have_act = 0, grp_loud = 0, grp_s0 = 0, grp_tm = 0, grp_dup = 0, grp_R = 0; uint64_t act_x = 0; int32_t grp_m = 0, grp_top = 0;
 		while (st < i && ri - a[st].x > (uint64_t)max_dist_x) ++st;
 		for (j = i - 1; j >= st; --j) {
 			int64_t dr = ri - a[j].x;
@@ -527,16 +528,19 @@ static void chain_dp_range_s(const lqo_params *P, float avg_qspan, const lqo_mm1
 				/* Candidates of equal x inside the band of one scan (a "group"; they are neighbours in the array).  What a candidate
 				 * does: raise the best score (sc > max_f: max_f, max_j, one skip forgiven), or count as a skip (t[j] == i), or
 				 * neither ("quiet") -- and leave its mark (below), which every scanned candidate does whatever the order.  Quiet
-				 * members (sc <= the best score before the group, which only grows; t[j] != i) commute with everything.  Two or
-				 * more loud members still commute when no skip is pending before the group and none of them counts as one (then
-				 * n_skip stays 0 in any order) and the highest score among them is reached by one member only (then max_f, max_j
-				 * end the same). */
+				 * members (sc <= the best score before the group, which only grows; t[j] != i) commute with everything.  A group
+				 * in which no member raises the best score (sc <= the best before the group for all of them) commutes as a whole:
+				 * its marked members count as skips one by one in any order, the scan ends -- if it does -- at the same count, and
+				 * nothing that could have raised the score is left unscanned.  With a member that raises it, two or more loud members
+				 * still commute when no skip is pending before the group and none of them counts as one (then n_skip stays 0 in
+				 * any order) and the highest score among them is reached by one member only (then max_f, max_j end the same). */
 				if (!(have_act && a[j].x == act_x)) {
-					if (have_act && grp_loud >= 2 && (!grp_s0 || grp_tm || grp_dup)) *band_tie = 1;
-					have_act = 1; act_x = a[j].x; grp_m = max_f; grp_s0 = n_skip == 0; grp_loud = 0; grp_tm = 0; grp_dup = 0; grp_top = INT32_MIN;
+					if (have_act && grp_R >= 1 && grp_loud >= 2 && (!grp_s0 || grp_tm || grp_dup)) { *band_tie = 1; ++lqo_tie_reason[grp_dup ? 0 : grp_tm ? 1 : 2]; }
+					have_act = 1; act_x = a[j].x; grp_m = max_f; grp_s0 = n_skip == 0; grp_loud = 0; grp_tm = 0; grp_dup = 0; grp_R = 0; grp_top = INT32_MIN;
 				}
 				if (!(sc <= grp_m && t[j] != i)) {
 					++grp_loud;
+					if (sc > grp_m) ++grp_R;
 					if (t[j] == i) grp_tm = 1;
 					if (sc > grp_top) grp_top = sc, grp_dup = 0; else if (sc == grp_top) grp_dup = 1;
 				}
@@ -555,7 +559,7 @@ static void chain_dp_range_s(const lqo_params *P, float avg_qspan, const lqo_mm1
 							if (dd2 > bw) continue;
 							md2 = dq2 < dr2 ? dq2 : dr2;
 							sc2 = (md2 > q_span ? q_span : md2) - ((int)(dd2 * .01 * avg_qspan) + ((dd2 ? ilog2_32(dd2) : 0) >> 1)) + f[jj];
-							if (!(sc2 <= grp_m && t[jj] != i)) *band_tie = 1;      /* a second loud member, and one of the group counts as a skip */
+							if (sc2 > grp_m) { *band_tie = 1; ++lqo_tie_reason[3]; }      /* a member that would have raised the best score, had it come before the one that ended the scan */
 						}
 					}
 					break;
@@ -563,7 +567,7 @@ static void chain_dp_range_s(const lqo_params *P, float avg_qspan, const lqo_mm1
 			}
 			if (p[j] >= 0) t[p[j]] = i;
 		}
-		if (band_tie && have_act && grp_loud >= 2 && (!grp_s0 || grp_tm || grp_dup)) *band_tie = 1;   /* the scan's last group */
+		if (band_tie && have_act && grp_R >= 1 && grp_loud >= 2 && (!grp_s0 || grp_tm || grp_dup)) { *band_tie = 1; ++lqo_tie_reason[grp_dup ? 0 : grp_tm ? 1 : 2]; }   /* the scan's last group */
 		f[i] = max_f, p[i] = max_j;
 		v[i] = max_j >= 0 && v[max_j] > max_f ? v[max_j] : max_f;
 	}
@@ -583,7 +587,7 @@ static void chain_dp_range_s(const lqo_params *P, float avg_qspan, const lqo_mm1
 	lqo_sort_64(u, n_u);                                /* chain.c:102-106 */
 	if (peak_tie)                                       /* two anchors of equal x end chains with the same peak score: the order of the backtracks follows their array order */
 		for (i = 1; i < n_u; ++i)
-			if (u[i] >> 32 == u[i-1] >> 32 && (int32_t)u[i] != (int32_t)u[i-1] && a[(int32_t)u[i]].x == a[(int32_t)u[i-1]].x) *peak_tie = 1;
+			if (u[i] >> 32 == u[i-1] >> 32 && (int32_t)u[i] != (int32_t)u[i-1] && a[(int32_t)u[i]].x == a[(int32_t)u[i-1]].x) { *peak_tie = 1; ++lqo_tie_reason[4]; }
 	for (i = 0; i < n_u >> 1; ++i) { uint64_t tt = u[i]; u[i] = u[n_u - i - 1], u[n_u - i - 1] = tt; }
 	memset(t, 0, n * 4);                                /* chain.c:108-125 backtrack */
 	for (i = n_v = k = 0; i < n_u; ++i) {

@@ -98,6 +98,7 @@ int main(int argc, char **argv)
 			fprintf(stderr, "[ties] queries %llu anchors %llu | runs>=n_min %llu (%llu anchors) with ties %llu observable %llu (%llu anchors) MISMATCH %llu | queries with ties %llu with observable runs %llu (%llu anchors)\n",
 			        (unsigned long long)s[0], (unsigned long long)s[1], (unsigned long long)s[2], (unsigned long long)s[3], (unsigned long long)s[4], (unsigned long long)s[5],
 			        (unsigned long long)s[6], (unsigned long long)s[7], (unsigned long long)s[8], (unsigned long long)s[9], (unsigned long long)s[10]);
+			if (getenv("LQO_TIE_DEBUG")) { extern unsigned long long lqo_tie_reason[8]; fprintf(stderr, "[ties] events: top score twice %llu, a member counts as a skip %llu, a skip pending %llu, break inside a group %llu, equal peaks %llu, groups without a raiser %llu\n", lqo_tie_reason[0], lqo_tie_reason[1], lqo_tie_reason[2], lqo_tie_reason[3], lqo_tie_reason[4], lqo_tie_reason[5]); }
 			if (s[7]) rc = 3;
 		}
 		return rc;

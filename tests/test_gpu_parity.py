@@ -11,7 +11,7 @@ import tests.test_emu_pipeline as E
 import tests.test_host as H
 from longqc_amd import api, synth
 from tests import oracle_bind
-from tests.conftest import GOLDEN, read_gz
+from tests.conftest import GOLDEN, ROOT, read_gz
 from tests.helpers import ONT, read_fastx, run_main
 
 pytestmark = pytest.mark.gpu
@@ -529,25 +529,11 @@ def test_gpu_real_size_parts_rows_equal_the_reference_fixture(gpu_lib, name):
     fx = os.path.join(GOLDEN, name + "_rows.json")
     if not os.path.exists(fx):
         pytest.skip("fixture not made")
-    g = json.load(open(fx))
-    cfg = synth.SCALE_SLICES[name]
-    genome = synth.make_genome(cfg)
-    F = synth.make_reads_flat(cfg, genome)
-    Q = synth.make_reads(cfg, genome, indices=synth.reservoir_subsample(cfg.n_reads, cfg.nsample))
-    p, _, _ = api.parse_args(g["argv"] + ["t", "q"])
-    from longqc_amd import multigpu
-    lens = np.diff(F.off).astype(np.int64)
-    parts = multigpu.split_parts(lens, int(p.batch_size), int(p.idx_mini_batch))
-    assert len(parts) >= (3 if name == "cfg4s" else 2)
-    P = api.PackedReads(F.flat, F.off, F.names())
-    eng = api.Engine(p, device=0, lib=gpu_lib)
-    eng.set_queries(Q.names, Q.seqs, Q.quals)
-    pt = eng.part_begin()
-    for lo, hi in parts:
-        eng.part_clear(pt); eng.part_add_packed(pt, P, lo, hi); eng.part_build(pt); eng.part_map(pt)
-    eng.finish()
-    lines = eng.table_text().splitlines()
-    st = eng.map_stats()
-    eng.close()
-    bad = [s for s, row in zip(g["subsample_slots"], g["rows"]) if lines[s] != row]
-    assert not bad, (bad[:5], st)
+    # In a process of its own: these two take most of the device's memory, and late in a long pytest process (dozens of engines
+    # created and destroyed before) the HIP runtime has been seen to fault inside its allocator on the way there
+    # (profiles/r04_c_hsa_alloc_fault_stack.txt: pthread_mutex_lock on a null pointer under hipMalloc); alone they pass.
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, "-m", "tests.real_size_runner", name], cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-4000:]
+    assert "real-size rows identical" in r.stdout, r.stdout[-2000:]
