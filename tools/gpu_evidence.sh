@@ -6,7 +6,7 @@
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
 T0=$(date +%s)
 if [ "$SKIP_TESTS" != 1 ]; then
-  timeout 600 python -m pytest tests -m gpu -x -q > gpurun_out/pytest_full.log 2>&1; tail -3 gpurun_out/pytest_full.log > gpurun_out/pytest_gpu.log
+  timeout 900 python -m pytest tests -m gpu -x -q > gpurun_out/pytest_full.log 2>&1; tail -3 gpurun_out/pytest_full.log > gpurun_out/pytest_gpu.log
   echo "pytest done $(( $(date +%s) - T0 )) s" >> gpurun_out/pytest_gpu.log
   ( timeout 120 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 ) > gpurun_out/smoke.log 2>&1
 fi
