@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 from tests import oracle_bind
-from tests.conftest import GOLDEN, read_gz
+from tests.conftest import GOLDEN, ROOT, read_gz
 from tests.helpers import ONT, run_main
 
 
@@ -180,3 +180,44 @@ def test_run_files_parses_plain_targets_from_the_mapping(emu_lib, tmp_path, monk
     assert rc == 0, err
     assert out == want
     assert "from the mapped file" in err and "part 3" in err
+
+
+def test_replay_side_sort_equals_klibs_order_ties_included(tmp_path):
+    """longqc_amd/csrc/sat_replay.hpp re-sorts the chains of a saturated query the way the reference does (chain.c:139-146,
+    hit.c:60-70: radix_sort_128x, klib's unstable in-place MSD sort).  Its order of EQUAL keys is what has to be right, and the
+    pile-up tests hardly ever produce equal keys: here the host routine is held against the oracle's restatement of klib's sort
+    (pinned by the golden anchor orders) on arrays full of ties, of every size class (insertion sort up to 64, bucket recursion
+    above)."""
+    import ctypes as C
+    import subprocess
+    so = str(tmp_path / "sat_shim.so")
+    r = subprocess.run(["g++", "-O1", "-std=c++17", "-shared", "-fPIC", os.path.join(ROOT, "tests", "emu", "sat_replay_shim.cpp"), "-o", so],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout[-3000:]
+    shim = C.CDLL(so)
+    oracle_bind.ensure_oracle()
+    ora = C.CDLL(os.path.join(ROOT, "oracle", "liblqcov_oracle.so"))
+    ora.lqo_sort_128x.argtypes = [C.c_void_p, C.c_size_t]
+    shim.shim_klib_sort_128x.argtypes = [C.c_void_p, C.c_size_t]
+    rng = np.random.default_rng(3)
+    for n in [0, 1, 2, 63, 64, 65, 66, 200, 1000, 5000, 40000]:
+        for shape in range(6):
+            if shape == 0:
+                x = rng.integers(0, 7, size=n, dtype=np.uint64)                                  # few distinct keys, low byte only
+            elif shape == 1:
+                x = rng.integers(0, 5, size=n, dtype=np.uint64) << np.uint64(56)                 # ... top byte only
+            elif shape == 2:
+                x = (rng.integers(0, 3, size=n, dtype=np.uint64) << np.uint64(40)) | rng.integers(0, 4, size=n, dtype=np.uint64)
+            elif shape == 3:
+                x = rng.integers(0, 1 << 62, size=n, dtype=np.uint64); x[rng.integers(0, max(n, 1), size=n // 2)] = x[0] if n else 0   # half of them one key
+            elif shape == 4:
+                x = (rng.integers(0, 2, size=n, dtype=np.uint64) << np.uint64(63)) | (rng.integers(0, 300, size=n, dtype=np.uint64) << np.uint64(32)) | rng.integers(0, 50, size=n, dtype=np.uint64)   # anchors' shape
+            else:
+                x = np.sort(rng.integers(0, 100, size=n, dtype=np.uint64))[::-1].copy()            # descending, many ties
+            a = np.empty(2 * n, dtype=np.uint64)
+            a[0::2] = x; a[1::2] = np.arange(n, dtype=np.uint64)
+            b = a.copy()
+            shim.shim_klib_sort_128x(a.ctypes.data_as(C.c_void_p), n)
+            ora.lqo_sort_128x(b.ctypes.data_as(C.c_void_p), n)
+            assert np.array_equal(a, b), (n, shape)
+            assert np.all(a[0::2][1:] >= a[0::2][:-1])
