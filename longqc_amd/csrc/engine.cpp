@@ -825,7 +825,8 @@ void lqcov_handle::sat_replay_part(Part &pt, const std::vector<u64> &h_aq, const
 		u64 off[2];
 		d2h(off, cnt_off_dev() + qi, 2, L.stream);
 		const size_t nc = (size_t)(off[1] - off[0]);
-		for (const SatRec &c : recs) if (c.good && ((size_t)c.sti >= nc || c.at_off + c.n_at > at.size())) throw std::runtime_error("replay of saturated counters: inconsistent chain record");
+		for (const SatRec &c : recs) if (c.good && (c.sti < 0 || (size_t)c.sti >= nc || c.at_off + c.n_at > at.size())) throw std::runtime_error("replay of saturated counters: inconsistent chain record");
+		for (u32 v : at) if ((size_t)v >= nc) throw std::runtime_error("replay of saturated counters: inconsistent chain record");
 		auto it = sat_cnt.find(qi);
 		if (it == sat_cnt.end()) {
 			std::vector<u32> c(nc);
