@@ -302,10 +302,17 @@ def main():
                 if s1 > s0:
                     eng.part_add_packed(pt, Ps, s0, s1)
             plan.append((add, sa, api.encode_names(names_of(lo, hi)), lens[lo:hi].astype(np.uint32)))
+        reserve = 0
         if len(parts) > 1 and have_cuda:
             # room for the part whose front runs under the mapping (a second part object: 24 B per minimizer ~ 8 B per base, its
             # tables) and for the exchange buffers (2.2 x 16 B per minimizer)
-            eng.reserve_hbm(int(max(int(lens[lo:hi].sum()) for lo, hi in parts[1:]) * (9.5 + 12.0)))
+            reserve = int(max(int(lens[lo:hi].sum()) for lo, hi in parts[1:]) * (9.5 + 12.0))
+        if one_dev and have_cuda:
+            # (test mode: the ranks share one device -- each leaves the others their share of what is free now; the lanes size
+            # their work space from what is free when the first part stands, and two ranks doing that at once ran the device dry)
+            reserve += int(torch.cuda.mem_get_info(local)[0] * (world - 1) / world)
+        if reserve:
+            eng.reserve_hbm(reserve)
         table = [None]
 
         def step(h2d=True):
