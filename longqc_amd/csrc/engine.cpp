@@ -710,7 +710,14 @@ void lqcov_handle::chain_stage(MapLane &L, Part &pt, const u64 *aqb, u64 a_base,
 	i32 *d_cf = (i32*)L.B.p, *d_cp = (i32*)((u8*)L.B.p + nA4), *d_ct = (i32*)((u8*)L.B.p + 2 * nA4), *d_cv = (i32*)((u8*)L.B.p + 3 * nA4);
 	// ---- (strand, rid) runs long enough to hold a chain ----
 	u64 n_groups = 0;
-	{
+	if (tie_mode == 2 && a_base == 0 && qmap) {                  // the second pass: the listed runs only, from their keys
+		L.gstart.ensure(((u64)n_want + 1) * 8);
+		if (n_want) {
+			StageTimer t(this, L.stream, "k_run_list", (u64)n_want * 16);
+			LQ_LAUNCH(k_want_runs, nblk(n_want, 256), 256, L.stream, dA, aqb, nqb, qmap, L.want.as<unsigned long long>(), n_want, L.gstart.as<u64>()); check_launch();
+		}
+		n_groups = n_want;
+	} else {
 		const u32 n_tiles = (u32)((nA + LQ_RUN_TILE - 1) / LQ_RUN_TILE);
 		const u32 n_min = run_n_min();
 		L.run_tiles.ensure(16);
@@ -744,7 +751,9 @@ void lqcov_handle::chain_stage(MapLane &L, Part &pt, const u64 *aqb, u64 a_base,
 	if (n_groups > 0xfffffff0ULL) throw std::domain_error("too many anchor runs in one batch");
 	const int cap = K.chain_cap <= 64 ? 64 : K.chain_cap <= 128 ? 128 : 256;   // anchors of LDS per wave in k_chain
 	// runs of >= wave_min anchors take the cooperative kernel; a run must fit k_chain's LDS budget on its own
-	const int wave_min = std::min(cap + 1, K.chain_wave_min > 0 ? K.chain_wave_min : LQ_CHAIN_WAVE_MIN);
+	// (the second pass chains a few thousand runs, most of them true overlaps of 20-47 anchors: a wave each -- one thread per run
+	// takes them in many rounds of the LDS budget with a handful of lanes busy, 28 ms of a lane's second pass at configs[2])
+	const int wave_min = tie_mode == 2 && K.chain_wave_min <= 0 ? std::min<int>(LQ_CHAIN_WAVE_MIN, std::max<int>(P.min_cnt, 8)) : std::min(cap + 1, K.chain_wave_min > 0 ? K.chain_wave_min : LQ_CHAIN_WAVE_MIN);
 	if (n_groups) {	// one thread per run, in array order, DP state of a wave's runs packed into LDS (in rounds if they exceed the budget).
 		// Measured alternatives that were not faster on MI355X: a compacted longest-first work list for all runs (409 vs 292 ms at
 		// configs[1]), a dense list in array order of the runs of min_cnt..47 anchors (configs[2]: within the run-to-run spread),

@@ -587,6 +587,30 @@ __device__ __forceinline__ bool lq_chain_finish(AP a, const i64 n, IP f, IP p, I
 	return false;
 }
 
+// The second pass chains a few thousand runs out of the tens of millions its queries have: their list entries come straight
+// from their keys -- want[w] = query << 32 | high word of x (strand, target) -- by two bisections in the query's anchors (klib's
+// order: ascending x), instead of a run list of everything (k_run_list) that a full-grid k_chain then searches the keys for
+// (configs[2]: 28 + 4 ms of a lane's second pass).  qmap: the subset's queries, ascending; a key of a query that is not in
+// this subset gets length 0.
+__global__ void k_want_runs(const mm128 *A, const u64 *aq_off, u32 n_q, const u32 *qmap, const unsigned long long *want, u32 n_want, u64 *gstart)
+{
+	const u32 w = blockIdx.x * blockDim.x + threadIdx.x;
+	if (w >= n_want) return;
+	const u32 q = (u32)(want[w] >> 32), hi = (u32)want[w];
+	u32 lo = 0, n = n_q;
+	while (lo < n) { const u32 mid = lo + ((n - lo) >> 1); if (qmap[mid] < q) lo = mid + 1; else n = mid; }
+	u64 e = 0;
+	if (lo < n_q && qmap[lo] == q) {
+		const u64 s1 = aq_off[lo + 1];
+		u64 a = aq_off[lo], b = s1;                            // the first anchor whose high word is >= hi
+		while (a < b) { const u64 m = a + ((b - a) >> 1); if (lq_hi32(A + m) < hi) a = m + 1; else b = m; }
+		u64 c = a, d = s1;                                     // ... > hi
+		while (c < d) { const u64 m = c + ((d - c) >> 1); if (lq_hi32(A + m) <= hi) c = m + 1; else d = m; }
+		e = a | (c - a) << 32;
+	}
+	gstart[w] = e;
+}
+
 // One (strand, rid) run of a query: mm_chain_dp on a[0..n), then per chain mm_reg_set_coor and lq_cnt_match.
 // a, f, p, t, v, u may live in global memory (long runs) or in the calling thread's private arrays (short runs).
 template <class AP, class IP, class UP>
