@@ -146,6 +146,12 @@ def _dialects():
     recs["truncated"] = b"".join(b"@t%d\n%s\n+\n%s\n" % (i, seq(30), b"I" * 30) for i in range(50)) + b"@bad\nACGTACGT\n+\nIII\n" + b"".join(b"@u%d\n%s\n+\n%s\n" % (i, seq(30), b"I" * 30) for i in range(50))
     recs["empty"] = b""
     recs["one"] = b"@a\nACGT\n+\nIIII"
+    # no '>' anywhere (PacBio FASTQ with all-'!' qualities) / no '@' anywhere: the header search must not run to the end of the file per record
+    recs["fastq_no_gt"] = b"".join(b"@p%d\n%s\n+\n%s\n" % (i, s.replace(b"N", b"A").replace(b"n", b"a"), b"!" * len(s)) for i, s in ((i, seq(int(rng.integers(1, 300)))) for i in range(400)))
+    recs["fasta_no_at"] = b"".join(b">g%d\n%s\n" % (i, wrap(seq(int(rng.integers(1, 300))), 80)) for i in range(300))
+    # a sequence line that is a single '\r' and the file's last byte: kseq keeps it (ks_getuntil2 returns at end of file before the strip, kseq.h:98)
+    recs["cr_last_byte"] = b">r1\na\n\r"
+    recs["cr_last_byte_fq"] = b"@q0\nACGT\n+\nIIII\n>r1\nacg\nt\n\r"
     return recs
 
 
@@ -164,6 +170,21 @@ def test_mapped_reader_equals_streaming_reader(emu_lib, tmp_path, name):
         assert _digest(emu_lib, fn, 1, 4, 300)[4] == 0          # the guess holds on plain FASTQ even with '@' / '+' / '>' opening quality lines: nothing parsed twice
     if name == "wrapped":
         assert _digest(emu_lib, fn, 1, 4, 300)[4] > 0           # (and where it cannot hold, the stitcher notices)
+
+
+def test_mapped_reader_is_linear_on_a_fastq_without_any_gt(emu_lib, tmp_path):
+    """round 4's reader searched the rest of the whole file for '>' after every FASTQ record: 40 s for 80 MB.  20 MB here must take well under that."""
+    import time
+    rng = np.random.default_rng(11)
+    s = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, 2000)].tobytes()
+    rec = b"@p\n" + s + b"\n+\n" + b"!" * len(s) + b"\n"
+    fn = str(tmp_path / "big.fq")
+    _write(fn, rec * (20_000_000 // len(rec)))
+    t0 = time.time()
+    got = _digest(emu_lib, fn, 1, 4, 1 << 20)
+    dt = time.time() - t0
+    assert got[0] == 20_000_000 // len(rec)
+    assert dt < 5.0, dt
 
 
 def test_run_files_parses_plain_targets_from_the_mapping(emu_lib, tmp_path, monkeypatch):
