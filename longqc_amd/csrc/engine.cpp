@@ -2,6 +2,7 @@
 #include "engine.hpp"
 #include "kernels_sketch.hpp"
 #include "kernels_index.hpp"
+#include "kernels_seed.hpp"
 #include "kernels_sort.hpp"
 #include "kernels_walk.hpp"
 #include "kernels_psort.hpp"
@@ -118,18 +119,17 @@ void Knobs::read_env()
 	ps_passes = (u32)std::min<long>(16, std::max<long>(0, num("LQCOV_PS_PASSES", 2))) & ~1u;
 	ties_klib = is("LQCOV_TIES", "klib") || all_klib;
 	filter = num("LQCOV_FILTER", 1) != 0;
-	filt_split = num("LQCOV_FILTER_SPLIT", 1) != 0;
 	parse_threads = (int)std::min<long>(256, std::max<long>(0, num("LQCOV_PARSE_THREADS", 0)));
 	parse_piece = (u64)std::max<long>(64, num("LQCOV_PARSE_PIECE", 32L << 20));
 	pipeline = num("LQCOV_PIPELINE", 1) != 0;
 	plan_ahead = num("LQCOV_PLAN_AHEAD", 1) != 0;
 	cnt_bits = (int)std::min<long>(16, std::max<long>(2, num("LQCOV_TEST_CNT_BITS", 16)));
-	{
-		long kc = num("LQCOV_FILTER_KEYS", (long)LQ_FT_WORDS * 16);
-		u32 v = 256; while (v * 2 <= (u32)std::min<long>(std::max<long>(kc, 256), (long)LQ_FT_WORDS * 16)) v *= 2;   // a power of two in [256, 16 * LQ_FT_WORDS]
-		filt_keys = v;
-		filt_acap = (u32)std::max<long>(1, num("LQCOV_FILTER_ACAP", (long)(0.125 * v)));
-	}
+	seed_bucket = (u32)std::min<long>(1L << 24, std::max<long>(16, num("LQCOV_SEED_BUCKET", 6144)));
+	seed_chunk = getenv("LQCOV_SEED_CHUNK") ? std::max<u64>(1024, strtoull(getenv("LQCOV_SEED_CHUNK"), 0, 10)) : 1ULL << 30;
+	if (seed_chunk > 0xfffffff0ULL) seed_chunk = 0xfffffff0ULL;
+	seed_segl = (u32)std::min<long>(LQ_SD_SEGL, std::max<long>(1, num("LQCOV_SEED_SEGL", LQ_SD_SEGL)));
+	seed_pair_bits = (u32)std::min<long>(LQ_SD_PAIR_BITS, std::max<long>(1, num("LQCOV_SEED_PAIR_BITS", LQ_SD_PAIR_BITS)));
+	seed_bin_bits = (u32)std::min<long>(LQ_SD_BIN_BITS, std::max<long>(3, num("LQCOV_SEED_BIN_BITS", LQ_SD_BIN_BITS)));
 }
 
 lqcov_handle::lqcov_handle(const lqcov_params &p, int dev) : P(p), device(dev)
@@ -905,12 +905,20 @@ void lqcov_handle::map_batch(MapLane &L, Part &pt, u32 q0, u32 q1, const std::ve
 		          qklib.as<u32>(), L.A.as<mm128>(), L.B.as<mm128>(), mini_pos.as<u64>(), EmitSub{nullptr, nullptr, nullptr});
 		check_launch();
 	}
-	if (nj && opt) {
-		StageTimer t(this, L.stream, "k_seed_emit_f", nj * 40 + (h_aq[q1] - h_aq[q0]) / 8 + nA * 16);   // (algorithmic: the bitmap in, the surviving anchors out; the lists were read by k_seed_count)
-		LQ_LAUNCH(k_seed_emit_f, nblk(nj, LQ_EMIT_THREADS), LQ_EMIT_THREADS, L.stream, q.mx.as<u64>(), q.my.as<u64>(), q_owner.as<u32>(), q.moff.as<u64>(), j0, nj,
+	if (nj && opt && pt.plan.bucketed) {
+		if (nA) {                                                 // the survivors of the batch's queries (the part's seed plan holds them as records)
+			StageTimer t(this, L.stream, "k_seed_emit_s", nA * 24);
+			LQ_LAUNCH(k_seed_emit_s, nblk(nA, 256), 256, L.stream, surv.as<u64>(), a_base, nA, aqf_off.as<u64>(), q0, q1, SeedBits{pt.plan.rec_jb, pt.plan.rec_db},
+			          q.mx.as<u64>(), q.my.as<u64>(), q.moff.as<u64>(), q.d_len.as<u32>(), dup.as<u32>(), L.A.as<mm128>());
+			check_launch();
+		}
+	} else if (nj && opt) {                                       // no filter: every hit, nobody through klib's passes (h_aqf == h_aq)
+		StageTimer t(this, L.stream, "k_seed_emit", nj * 32 + nA * 24);
+		LQ_LAUNCH(k_seed_emit, nblk(nj, LQ_EMIT_THREADS), LQ_EMIT_THREADS, L.stream, q.mx.as<u64>(), q.my.as<u64>(), q_owner.as<u32>(), q.moff.as<u64>(), j0, nj,
 		          pt.pos.as<u64>(), hit_start.as<u64>(), hit_n.as<u32>(), keep.as<u32>(), dup.as<u32>(),
-		          fm_off.as<u64>(), fmask.as<u64>(), cntf.as<u32>(), af_off.as<u64>(), a_base, mp_off.as<u64>(), q.d_len.as<u32>(),
-		          L.A.as<mm128>(), mini_pos.as<u64>());
+		          a_off.as<u64>(), a_base, mp_off.as<u64>(), q.d_len.as<u32>(),
+		          (int)P.no_self, pt.self_off.as<u32>(), pt.self_rid.as<u32>(), ava,
+		          qzero.as<u32>(), L.A.as<mm128>(), L.B.as<mm128>(), mini_pos.as<u64>(), EmitSub{nullptr, nullptr, nullptr});
 		check_launch();
 	}
 	const u32 ivl_cap = (u32)std::min<u64>(nA / (P.min_cnt > 0 ? P.min_cnt : 1) + 16, 0xfffffff0ULL);
@@ -1349,6 +1357,123 @@ void lqcov_handle::open_gate()
 	gate_cv.notify_all();
 }
 
+// ---- the seed hits that can be part of a chain (kernels_seed.hpp) ------------------------------------------------------------
+// Host side of the bucketed filter: the geometry (slices of targets per query, segments of minimizers, chunks of queries that
+// fit the record buffer), then per chunk count -> scan -> scatter -> decide -> scan -> collect.  One host sync per chunk (the
+// survivors' total sizes the plan's array).
+void lqcov_handle::seed_filter(Part &pt, hipStream_t s, Prim &pr, SeedWork &W, u32 n_min, u32 jb, u32 db)
+{
+	SeedPlan &S = pt.plan;
+	const u32 n_q = q.n;
+	const u64 n_qm = q.n_mini;
+	const u32 n_targets = std::max<u32>(pt.rs.n, 1);
+	const AvaView ava{P.ava ? pt.t_rank.as<u32>() : nullptr, P.ava ? pt.q_lo.as<u32>() : nullptr};
+	const SeedBits bits{jb, db};
+	// hits per kept minimizer, scanned (n_qm + 1 entries: the last one is the total); hits before every query
+	W.hlen.ensure((n_qm + 1) * 4); W.h_off.ensure((n_qm + 1) * 8); W.hq_off.ensure((n_q + 1) * 8);
+	LQ_LAUNCH(k_hit_len, nblk(n_qm, 256), 256, s, S.hit_n.as<u32>(), S.keep.as<u32>(), n_qm, W.hlen.as<u32>()); check_launch();
+	dzero(W.hlen.as<u32>() + n_qm, 4, s);
+	pr.exclusive_scan_u32_u64(W.hlen.as<u32>(), W.h_off.as<u64>(), n_qm + 1);
+	LQ_LAUNCH(k_query_hoff, nblk(n_q + 1, 256), 256, s, q.moff.as<u64>(), W.h_off.as<u64>(), n_q, W.hq_off.as<u64>()); check_launch();
+	std::vector<u64> h_hq(n_q + 1);
+	d2h(h_hq.data(), W.hq_off.as<u64>(), n_q + 1, s);
+	// geometry
+	std::vector<SeedQ> qg(n_q);
+	std::vector<SeedSeg> segs;
+	std::vector<u32> has(n_q, 0);
+	u64 max_hq = 0;
+	for (u32 i = 0; i < n_q; ++i) max_hq = std::max(max_hq, h_hq[i + 1] - h_hq[i]);
+	if (max_hq >= 0xfffffff0ULL) throw std::domain_error("more than 2^32 seed hits of one query against one index part");
+	const u64 chunk_cap = std::max<u64>(K.seed_chunk, max_hq);
+	struct Chunk { u32 q_lo, q_hi, g_lo, g_hi; u64 ne, nb, hits, h0; bool big; size_t bq_at; };
+	std::vector<Chunk> chunks;
+	std::vector<u32> bq_all;
+	for (u32 i = 0; i < n_q; ) {
+		Chunk c; c.q_lo = i; c.g_lo = (u32)segs.size(); c.ne = 0; c.nb = 0; c.hits = 0; c.h0 = h_hq[i]; c.big = false; c.bq_at = bq_all.size();
+		while (i < n_q && (c.hits == 0 || c.hits + (h_hq[i + 1] - h_hq[i]) <= chunk_cap)) {
+			const u64 hq = h_hq[i + 1] - h_hq[i], nm = S.h_qmoff[i + 1] - S.h_qmoff[i];
+			SeedQ g; memset(&g, 0, sizeof(g));
+			g.seg0 = (u32)segs.size(); g.cb = c.ne; g.bk = c.nb;
+			if (hq) {
+				has[i] = 1;
+				u64 nsl = (hq + K.seed_bucket - 1) / K.seed_bucket;
+				nsl = std::min<u64>(nsl, std::min<u64>(LQ_SD_SL_BIG, std::max<u32>(n_targets / 2, 1)));
+				g.nsl = (u32)std::max<u64>(nsl, 1);
+				g.mul = g.nsl == 1 ? 0u : (u32)((((u64)g.nsl) << 32) / n_targets);       // slice of rid = rid * mul >> 32 < nsl for every rid < n_targets
+				g.nseg = (u32)((nm + K.seed_segl - 1) / K.seed_segl);
+				for (u32 p = 0; p < g.nseg; ++p) {
+					SeedSeg sg; memset(&sg, 0, sizeof(sg));
+					sg.j0 = S.h_qmoff[i] + (u64)p * K.seed_segl; sg.j1 = std::min<u64>(sg.j0 + K.seed_segl, S.h_qmoff[i + 1]); sg.q = i; sg.ord = p;
+					segs.push_back(sg);
+				}
+				if (g.nsl > LQ_SD_SL_SMALL) c.big = true;
+				c.ne += (u64)g.nsl * g.nseg; c.nb += g.nsl; c.hits += hq;
+			}
+			bq_all.push_back((u32)g.bk);
+			qg[i] = g;
+			++i;
+		}
+		bq_all.push_back((u32)c.nb);
+		c.q_hi = i; c.g_hi = (u32)segs.size();
+		if (c.ne >= 0xfffffff0ULL || c.nb >= 0x7ffffff0ULL) throw std::domain_error("seed filter: too many (query, slice, segment) pieces in one chunk");
+		chunks.push_back(c);
+	}
+	if (segs.size() >= 0x7ffffff0ULL) throw std::domain_error("seed filter: too many segments");
+	u64 max_ne = 0, max_nb = 0, max_hits = 0;
+	for (const Chunk &c : chunks) { max_ne = std::max(max_ne, c.ne); max_nb = std::max(max_nb, c.nb); max_hits = std::max(max_hits, c.hits); }
+	W.qg.ensure(qg.size() * sizeof(SeedQ) + 16); W.segs.ensure(segs.size() * sizeof(SeedSeg) + 16); W.bq.ensure(bq_all.size() * 4 + 4); W.has.ensure((u64)n_q * 4 + 4);
+	W.cnt.ensure((max_ne + 1) * 4); W.off.ensure((max_ne + 1) * 4); W.scnt.ensure((max_nb + 1) * 4); W.soff.ensure((max_nb + 1) * 4);
+	W.rec.ensure(max_hits * 8 + 8);
+	h2d(W.qg.as<SeedQ>(), qg.data(), qg.size(), s); h2d(W.segs.as<SeedSeg>(), segs.data(), segs.size(), s);
+	h2d(W.bq.as<u32>(), bq_all.data(), bq_all.size(), s); h2d(W.has.as<u32>(), has.data(), has.size(), s);
+	LQ_HIP_CHECK(hipStreamSynchronize(s));                    // (the host vectors above are pageable)
+	SeedIn in; memset(&in, 0, sizeof(in));
+	in.segs = W.segs.as<SeedSeg>(); in.qg = W.qg.as<SeedQ>(); in.h_off = W.h_off.as<u64>(); in.hit_start = S.hit_start.as<u64>(); in.pos = pt.pos.as<u64>();
+	in.qx = q.mx.as<u64>(); in.qy = q.my.as<u64>(); in.qmoff = q.moff.as<u64>(); in.qlen = q.d_len.as<u32>();
+	SeedDecide dp; memset(&dp, 0, sizeof(dp));
+	dp.n_min = n_min; dp.pair_bits = K.seed_pair_bits; dp.bin_bits = K.seed_bin_bits; dp.no_self = (int)P.no_self;
+	dp.dshift = 1; while (dp.dshift < 30 && (1u << dp.dshift) <= (u32)std::max<i32>(P.bw, 0)) ++dp.dshift;   // bins wider than the band (chain.c:55)
+	const u32 span_const = (u32)(P.hpc ? 0 : P.k);
+	u64 n_surv = 0;
+	S.surv.ensure(std::max<u64>(S.nA_total / 16, 1024) * 8);   // (grows by chunk if the survivors outnumber the guess)
+	for (const Chunk &c : chunks) {
+		const u32 ns = c.g_hi - c.g_lo;
+		if (!ns) continue;
+		dzero(W.cnt.as<u32>() + c.ne, 4, s);
+		{
+			StageTimer t(this, s, "k_seed_count", c.hits * 8);
+			LQ_LAUNCH(k_seed_count, ns, LQ_SD_THREADS, s, in, c.g_lo, W.cnt.as<u32>()); check_launch();
+		}
+		pr.exclusive_scan_u32_u32(W.cnt.as<u32>(), W.off.as<u32>(), c.ne + 1);
+		{
+			StageTimer t(this, s, "k_seed_scatter", c.hits * 16);
+			if (c.big) LQ_LAUNCH((k_seed_scatter<LQ_SD_SL_BIG>), ns, LQ_SD_THREADS, s, in, c.g_lo, W.off.as<u32>(), bits, span_const, W.rec.as<u64>());
+			else LQ_LAUNCH((k_seed_scatter<LQ_SD_SL_SMALL>), ns, LQ_SD_THREADS, s, in, c.g_lo, W.off.as<u32>(), bits, span_const, W.rec.as<u64>());
+			check_launch();
+		}
+		SeedDecIn di; memset(&di, 0, sizeof(di));
+		di.qg = W.qg.as<SeedQ>(); di.bq = W.bq.as<u32>() + c.bq_at; di.q_lo = c.q_lo; di.n_qc = c.q_hi - c.q_lo; di.off = W.off.as<u32>();
+		di.qx = q.mx.as<u64>(); di.qy = q.my.as<u64>(); di.qmoff = q.moff.as<u64>(); di.qlen = q.d_len.as<u32>();
+		di.self_off = pt.self_off.as<u32>(); di.self_rid = pt.self_rid.as<u32>(); di.ava = ava;
+		{
+			StageTimer t(this, s, "k_seed_decide", c.hits * 8);
+			LQ_LAUNCH(k_seed_decide, (u32)c.nb, LQ_SD_DTHREADS, s, di, dp, bits, span_const, W.rec.as<u64>(), W.scnt.as<u32>()); check_launch();
+		}
+		dzero(W.scnt.as<u32>() + c.nb, 4, s);
+		pr.exclusive_scan_u32_u32(W.scnt.as<u32>(), W.soff.as<u32>(), c.nb + 1);
+		u32 n_c = 0;
+		d2h(&n_c, W.soff.as<u32>() + c.nb, 1, s);
+		if ((n_surv + n_c) * 8 > S.surv.cap) grow_keep(S.surv, n_surv * 8, (n_surv + n_c) * 8, s);
+		LQ_LAUNCH(k_seed_collect, (u32)c.nb, 64, s, di, W.rec.as<u64>(), W.scnt.as<u32>(), W.soff.as<u32>(), n_surv, S.surv.as<u64>(), S.aqf_off.as<u64>()); check_launch();
+		add_stage_bytes("k_seed_decide", (u64)n_c * 8);
+		n_surv += n_c;
+	}
+	LQ_LAUNCH(k_seed_fill_off, 1, 64, s, W.has.as<u32>(), n_q, n_surv, S.aqf_off.as<u64>()); check_launch();
+	S.h_aqf.assign(n_q + 1, 0);
+	d2h(S.h_aqf.data(), S.aqf_off.as<u64>(), n_q + 1, s);
+	S.n_written = n_surv; S.rec_jb = jb; S.rec_db = db; S.bucketed = true;
+}
+
 // ---- map every query against one part (lqmap.c:207-326) -----------------------------------------
 // a part's seed plan (SeedPlan, engine.hpp) on stream s with scan scratch pr
 void lqcov_handle::plan_part(Part &pt, hipStream_t s, Prim &pr)
@@ -1403,42 +1528,29 @@ void lqcov_handle::plan_part(Part &pt, hipStream_t s, Prim &pr)
 	LQ_LAUNCH(k_query_klib, nblk(n_q, 256), 256, s, S.aq_off.as<u64>(), S.qdirty.as<u32>(), n_q, (int)K.all_klib, S.qklib.as<u32>()); check_launch();
 	d2h(S.h_aq.data(), S.aq_off.as<u64>(), n_q + 1, s);
 	d2h(S.h_qmoff.data(), q.moff.as<u64>(), n_q + 1, s);
+	S.bucketed = false;
 	if (!K.ties_klib) {
-		// The seed hits that can be part of a chain at all (k_seed_count): one bit per hit, counts per minimizer, offsets per query.
-		// Without the filter (LQCOV_FILTER=0, or a chain may be a single anchor) every hit passes: one code path for the first pass.
-		S.h_aqf.assign(n_q + 1, 0);
+		// The seed hits that can be part of a chain at all (kernels_seed.hpp): records, dense per query.  Without the filter
+		// (LQCOV_FILTER=0, a chain may be a single anchor, or a record would not fit 64 bits) the first pass writes every hit.
 		S.qzero.ensure((u64)n_q * 4 + 4); dzero(S.qzero.p, (u64)n_q * 4 + 4, s);
-		S.fm_words.ensure(n_qm * 4 + 4); S.fm_off.ensure(n_qm * 8 + 8); S.cntf.ensure(n_qm * 4 + 4); S.af_off.ensure(n_qm * 8 + 8); S.aqf_off.ensure((n_q + 1) * 8);
-		u64 nF = 0;
-		if (n_qm) {
-			S.fm_meta.ensure(n_qm * sizeof(FMeta) + 16);
-			LQ_LAUNCH(k_fmask_words, nblk(n_qm, 256), 256, s, S.hit_n.as<u32>(), S.keep.as<u32>(), n_qm, S.fm_words.as<u32>()); check_launch();
-			pr.exclusive_scan_u32_u64(S.fm_words.as<u32>(), S.fm_off.as<u64>(), n_qm);
-			LQ_LAUNCH(k_fmeta, nblk(n_qm, 256), 256, s, S.hit_n.as<u32>(), S.keep.as<u32>(), S.hit_start.as<u64>(), q.my.as<u64>(), S.fm_off.as<u64>(), n_qm, S.fm_meta.as<FMeta>()); check_launch();
-			u64 lo = 0; u32 lc = 0;
-			d2h(&lo, S.fm_off.as<u64>() + n_qm - 1, 1, s); d2h(&lc, S.fm_words.as<u32>() + n_qm - 1, 1, s);
-			const u64 n_words = lo + lc;
-			S.fmask.ensure(n_words * 8 + 8);
-			dzero(S.fmask.p, n_words * 8, s); dzero(S.cntf.p, n_qm * 4, s);
-			FiltParams fp; memset(&fp, 0, sizeof(fp));
-			fp.n_min = K.filter ? run_n_min() : 0;
-			fp.n_targets = std::max<u32>(pt.rs.n, 1); fp.keys_cap = K.filt_keys; fp.a_cap = std::max<u32>(K.filt_acap, 1);
-			fp.dshift = 1; while (fp.dshift < 30 && (1u << fp.dshift) <= (u32)std::max<i32>(P.bw, 0)) ++fp.dshift;   // bins wider than the band (chain.c:55)
-			fp.split_strands = K.filt_split ? 1 : 0;
-			{
-				StageTimer t(this, s, "k_seed_count", nA_total * 8 + nA_total / 8);   // (algorithmic: every occurrence list once, a bit per hit out; the kernel reads the lists twice)
-				LQ_LAUNCH(k_seed_count, std::min<u32>(n_q, 1u << 20), LQ_FC_THREADS, s, S.fm_meta.as<FMeta>(), q.mx.as<u64>(), q.moff.as<u64>(), (u32)0, n_q, q.d_len.as<u32>(), pt.pos.as<u64>(), S.aq_off.as<u64>(),
-				          (int)P.no_self, pt.self_off.as<u32>(), pt.self_rid.as<u32>(), ava, fp, (u32)(P.hpc ? 0 : P.k),
-				          S.fmask.as<u8>(), S.cntf.as<u32>());
-				check_launch();
-			}
-			pr.exclusive_scan_u32_u64(S.cntf.as<u32>(), S.af_off.as<u64>(), n_qm);
-			d2h(&lo, S.af_off.as<u64>() + n_qm - 1, 1, s); d2h(&lc, S.cntf.as<u32>() + n_qm - 1, 1, s);
-			nF = lo + lc;
+		S.aqf_off.ensure((n_q + 1) * 8);
+		if (n_qm) { LQ_LAUNCH(k_mini_pos, nblk(n_qm, 256), 256, s, q.mx.as<u64>(), q.my.as<u64>(), S.keep.as<u32>(), S.mp_off.as<u64>(), n_qm, S.mini_pos.as<u64>()); check_launch(); }
+		const u32 n_min = K.filter ? run_n_min() : 0;
+		u32 max_tlen = 0, max_qlen = 0; u64 max_nm = 1;
+		for (u32 v : pt.rs.h_len) max_tlen = std::max(max_tlen, v);
+		for (u32 v : q.h_len) max_qlen = std::max(max_qlen, v);
+		for (u32 i = 0; i < n_q; ++i) max_nm = std::max<u64>(max_nm, S.h_qmoff[i + 1] - S.h_qmoff[i]);
+		auto bits_for = [](u64 v) { u32 b = 1; while (b < 63 && (v >> b)) ++b; return b; };   // bits that hold 0 .. v
+		const u32 jb = bits_for(max_nm - 1), db = bits_for((u64)max_tlen + max_qlen + 257), rb = bits_for(pt.rs.n ? pt.rs.n - 1 : 0);
+		u64 max_hits = 0;
+		for (u32 i = 0; i < n_q; ++i) max_hits = std::max<u64>(max_hits, S.h_aq[i + 1] - S.h_aq[i]);
+		if (n_min >= 2 && nA_total && jb + db + 1 + rb <= 64 && db <= 31 && jb <= 31 && max_hits < 0x7fff0000ULL) {
+			seed_filter(pt, s, pr, seed_ws[s == bstream ? 1 : 0], n_min, jb, db);
+		} else {
+			S.h_aqf = S.h_aq;
+			LQ_HIP_CHECK(hipMemcpyAsync(S.aqf_off.p, S.aq_off.p, (n_q + 1) * 8, hipMemcpyDeviceToDevice, s));
+			S.n_written = nA_total;
 		}
-		LQ_LAUNCH(k_query_foff, nblk(n_q + 1, 256), 256, s, q.moff.as<u64>(), S.af_off.as<u64>(), (u32)0, n_q, n_qm, nF, S.aqf_off.as<u64>()); check_launch();
-		d2h(S.h_aqf.data(), S.aqf_off.as<u64>(), n_q + 1, s);
-		S.n_written = nF;
 	}
 	LQ_HIP_CHECK(hipStreamSynchronize(s));
 	S.valid = true;
@@ -1449,7 +1561,7 @@ void lqcov_handle::swap_plan(SeedPlan &S)
 {
 	hit_start.swap(S.hit_start); hit_n.swap(S.hit_n); a_cnt.swap(S.a_cnt); keep.swap(S.keep); dup.swap(S.dup); qdirty.swap(S.qdirty); dup_table.swap(S.dup_table);
 	a_off.swap(S.a_off); mp_off.swap(S.mp_off); aq_off.swap(S.aq_off); mpq_off.swap(S.mpq_off); avg_qspan.swap(S.avg_qspan); qklib.swap(S.qklib); mini_pos.swap(S.mini_pos); qzero.swap(S.qzero);
-	fm_words.swap(S.fm_words); fm_off.swap(S.fm_off); fm_meta.swap(S.fm_meta); fmask.swap(S.fmask); cntf.swap(S.cntf); af_off.swap(S.af_off); aqf_off.swap(S.aqf_off);
+	surv.swap(S.surv); aqf_off.swap(S.aqf_off);
 }
 
 void lqcov_handle::map_part(Part &pt)

@@ -54,9 +54,10 @@ struct Knobs {
 	u64 parse_piece = 32u << 20;          // LQCOV_PARSE_PIECE: bytes of the file a thread parses at a time (tests shrink it: many guessed record starts)
 	bool pipeline = true;                 // LQCOV_PIPELINE=0: run_files builds a part only after the one before is mapped
 	int cnt_bits = 16;                    // LQCOV_TEST_CNT_BITS (2..16): width of the match counters.  A test hook: narrower counters bring the saturated regime (sat_replay.hpp) within reach of small inputs; the oracle has the same one (LQO_CNT_BITS)
-	bool filt_split = true;               // LQCOV_FILTER_SPLIT=0: the two strands of a target share its diagonal bins
-	u32 filt_keys = 1u << 19;             // LQCOV_FILTER_KEYS: counters of k_seed_count's table in use (tests shrink it: slices and aliasing on small inputs)
-	u32 filt_acap = 65536;                // LQCOV_FILTER_ACAP: hits per slice of targets aimed at (0.125 per counter; configs[2], 3 lanes: 131072 995 ms per step, 65536 922, 32768 937-955)
+	u32 seed_bucket = 6144;               // LQCOV_SEED_BUCKET: hits per (query, slice of targets) bucket aimed at; k_seed_decide holds a bucket of up to 8192 records in registers (tests shrink it: many slices on small inputs)
+	u64 seed_chunk = 1ULL << 30;          // LQCOV_SEED_CHUNK: records (8 B) of the bucket buffer; the queries of a part are bucketed in chunks of that many hits
+	u32 seed_segl = 2048;                 // LQCOV_SEED_SEGL: minimizers per segment (one block of the count / scatter kernels), at most LQ_SD_SEGL (tests shrink it)
+	u32 seed_pair_bits = 13, seed_bin_bits = 15;   // LQCOV_SEED_PAIR_BITS / LQCOV_SEED_BIN_BITS: counters of k_seed_decide in use (tests shrink them: aliasing on small inputs)
 	void read_env();
 };
 
@@ -86,12 +87,17 @@ struct ReadSetDev {                       // a read set 2-bit packed in HBM, chu
 struct lqcov_handle;
 struct SeedPlan {
 	DBuf hit_start, hit_n, a_cnt, keep, dup, qdirty, dup_table, a_off, mp_off, aq_off, mpq_off, avg_qspan, qklib, mini_pos, qzero;
-	DBuf fm_words, fm_off, fm_meta, fmask, cntf, af_off, aqf_off;
+	DBuf surv, aqf_off;                   // the seed hits that can be part of a chain (kernels_seed.hpp), dense, as records; where every query's start
 	std::vector<u64> h_aq, h_qmoff, h_aqf;
 	u64 nA_total = 0, n_mp_total = 0, n_written = 0;
 	i32 mid_occ = -2; u32 n_q = 0; u64 n_qm = 0;
+	u32 rec_jb = 0, rec_db = 0;           // the records' bit layout (SeedBits)
+	bool bucketed = false;                // false: the first pass writes every hit (no filter asked for, or the records do not fit 64 bits): h_aqf == h_aq
 	bool valid = false;
 };
+
+// work space of the seed filter (plan_part): one set per stream that can make a plan
+struct SeedWork { DBuf hlen, h_off, hq_off, qg, segs, bq, cnt, off, scnt, soff, rec, has; };
 
 struct Part {
 	bool live = false, built = false;
@@ -174,8 +180,8 @@ struct lqcov_handle {
 	DBuf dup, qdirty, dup_table;          // k_dup_mark: minimizers / queries whose anchors can repeat an x (per part)
 	DBuf qklib;                           // queries that go through klib's passes (per part): marked and more than 64 anchors
 	DBuf qzero;                           // zeros: nobody goes through klib's passes (first pass of map_batch)
-	DBuf fm_meta;                         // k_seed_count: every query minimizer's list (start, length, y), its cursor and the place of its survivor bits in one record
-	DBuf fm_words, fm_off, fmask, cntf, af_off, aqf_off;   // k_seed_count: survivor bitmap (words per minimizer, offsets, bits), survivors per minimizer, their offsets per minimizer / per query
+	DBuf surv, aqf_off;                   // the part's surviving seed hits as records and their per-query offsets (SeedPlan, swapped in by map_part)
+	SeedWork seed_ws[2];                  // [0]: plans made on `stream` (map_part, when a plan is missing or stale), [1]: on the build stream
 	// Queries one of whose match counters reached cnt_max (uint16 in the reference: 65535; esterr.c:130,136): from the part in
 	// which that happens on, their counters live here, replayed part by part in the reference's chain order (sat_replay.hpp,
 	// sat_replay_part), and go back to the device before the rows are made.  Key: the query in the engine's order.
@@ -227,6 +233,7 @@ struct lqcov_handle {
 	void build_part(Part &pt);
 	void open_gate();
 	void plan_part(Part &pt, hipStream_t s, Prim &pr);
+	void seed_filter(Part &pt, hipStream_t s, Prim &pr, SeedWork &W, u32 n_min, u32 jb, u32 db);
 	void swap_plan(SeedPlan &S);
 	void map_part(Part &pt);
 	void map_batch(MapLane &L, Part &pt, u32 q0, u32 q1, const std::vector<u64> &h_aq, const std::vector<u64> &h_aqf, const std::vector<u64> &h_qmoff, bool dbg);
