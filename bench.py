@@ -407,14 +407,15 @@ def main():
                     "GB_per_s": round(algo / 1e9 / (ms / 1e3), 1) if ms > 0 else None, "frac_of_hbm_peak": round(algo / 1e9 / (ms / 1e3) / HBM_PEAK_GBS, 4) if ms > 0 else None}
         n_qm = float(sum(int(x.shape[0]) for x in Q.seqs)) / 3.0                                  # ~ one minimizer per 3 bases at w = 5
         sk = grp(["k_sketch_dp_mask", "k_sketch_mask", "k_sketch_count", "k_sketch_emit_mask", "k_sketch_emit", "scan"], 0.25 * B0 + 16.0 * M0)
-        sd = grp(["k_seed_probe", "k_dup_mark", "k_seed_count", "k_seed_emit_f", "k_seed_emit"], 32.0 * n_qm + 8.0 * A0 + 16.0 * A0)
+        sd = grp(["k_seed_probe", "k_dup_mark", "k_seed_count", "k_seed_scatter", "k_seed_decide", "k_seed_emit_s", "k_seed_emit"], 32.0 * n_qm + 8.0 * A0 + 16.0 * A0)
         both = {"ms": round(sk["ms"] + sd["ms"], 3), "algo_GB": round(sk["algo_GB"] + sd["algo_GB"], 2)}
         both["GB_per_s"] = round(both["algo_GB"] / (both["ms"] / 1e3), 1) if both["ms"] > 0 else None
         both["frac_of_hbm_peak"] = round(both["GB_per_s"] / HBM_PEAK_GBS, 4) if both["GB_per_s"] else None
         north = {"part_bases": int(B0), "part_minimizers": int(M0), "seed_hits": int(A0), "anchors_written": int(W0), "sketch": sk, "seed": sd, "combined": both,
                  "bytes": "SURVEY 8d: sketch 0.25 B + 16 M; seed 32 M_q + 8 A + 16 A with A = every seed hit below mid_occ (what the reference writes and sorts). "
-                          "This engine reads the occurrence lists twice to decide which hits can reach a chain and writes only those (anchors_written): on its own "
-                          "bytes (2 x 8 A + 16 A_written) the seed stage moves %.1f GB" % ((16.0 * A0 + 16.0 * W0 + 32.0 * n_qm) / 1e9),
+                          "This engine streams the occurrence lists twice (count, scatter), moves every hit once as an 8-byte record to its (query, slice of targets) bucket, "
+                          "decides per bucket which hits can reach a chain and writes only those as anchors (anchors_written): on its own "
+                          "bytes (2 x 8 A lists + 8 A records out + 8 A records in + 8 + 16 per survivor) the seed stage moves %.1f GB" % ((32.0 * A0 + 24.0 * W0 + 32.0 * n_qm) / 1e9),
                  "instruction_ceiling": "60 % of 8 TB/s on 5.6 B per base is 0.86 Tbases/s: 256 CUs x 4 SIMDs at 2.4 GHz issue ~2.5 T wave64 instructions/s = 157 T lane-ops/s, "
                                         "i.e. ~180 lane-instructions per base at the very most, before any stall.  Per k-mer the sketch needs the 2-bit window update and its "
                                         "reverse complement (~10), the 64-bit invertible hash (7 rounds of shift/add/xor on two 32-bit halves: ~30 for k <= 16), the "

@@ -44,6 +44,7 @@
 #define __device__
 #define __host__
 #define __forceinline__ inline
+#define __noinline__ __attribute__((noinline))
 #define __launch_bounds__(...)
 #define __restrict__
 // LDS: statics collected in one section, so that the emulator can fill all of it with a poison pattern before every block
@@ -104,6 +105,7 @@ inline hipError_t hipMemGetInfo(size_t *f, size_t *t) { *f = *t = (size_t)64 << 
 inline void emu_atomic_hook();                     // LQ_EMU_ORDER=random: now and then another ready thread runs before an atomic
 template <class T> inline T atomicAdd(T *p, T v) { emu_atomic_hook(); T o = *p; *p = o + v; return o; }
 inline unsigned long long atomicAdd(unsigned long long *p, unsigned long long v) { emu_atomic_hook(); unsigned long long o = *p; *p = o + v; return o; }
+template <class T> inline T atomicSub(T *p, T v) { emu_atomic_hook(); T o = *p; *p = o - v; return o; }
 template <class T> inline T atomicOr(T *p, T v) { emu_atomic_hook(); T o = *p; *p = o | v; return o; }
 template <class T> inline T atomicAnd(T *p, T v) { emu_atomic_hook(); T o = *p; *p = o & v; return o; }
 template <class T> inline T atomicMax(T *p, T v) { emu_atomic_hook(); T o = *p; if (v > o) *p = v; return o; }
