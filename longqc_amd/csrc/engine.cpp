@@ -124,7 +124,7 @@ void Knobs::read_env()
 	pipeline = num("LQCOV_PIPELINE", 1) != 0;
 	plan_ahead = num("LQCOV_PLAN_AHEAD", 1) != 0;
 	cnt_bits = (int)std::min<long>(16, std::max<long>(2, num("LQCOV_TEST_CNT_BITS", 16)));
-	seed_bucket = (u32)std::min<long>(1L << 24, std::max<long>(16, num("LQCOV_SEED_BUCKET", 6144)));
+	seed_bucket = (u32)std::min<long>(1L << 24, std::max<long>(16, num("LQCOV_SEED_BUCKET", 7600)));
 	seed_chunk = getenv("LQCOV_SEED_CHUNK") ? std::max<u64>(1024, strtoull(getenv("LQCOV_SEED_CHUNK"), 0, 10)) : 1ULL << 30;
 	if (seed_chunk > 0xfffffff0ULL) seed_chunk = 0xfffffff0ULL;
 	seed_segl = (u32)std::min<long>(LQ_SD_SEGL, std::max<long>(1, num("LQCOV_SEED_SEGL", LQ_SD_SEGL)));

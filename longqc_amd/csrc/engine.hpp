@@ -54,11 +54,11 @@ struct Knobs {
 	u64 parse_piece = 32u << 20;          // LQCOV_PARSE_PIECE: bytes of the file a thread parses at a time (tests shrink it: many guessed record starts)
 	bool pipeline = true;                 // LQCOV_PIPELINE=0: run_files builds a part only after the one before is mapped
 	int cnt_bits = 16;                    // LQCOV_TEST_CNT_BITS (2..16): width of the match counters.  A test hook: narrower counters bring the saturated regime (sat_replay.hpp) within reach of small inputs; the oracle has the same one (LQO_CNT_BITS)
-	u32 seed_bucket = 6144;               // LQCOV_SEED_BUCKET: hits per (query, slice of targets) bucket aimed at; k_seed_decide holds a bucket of up to 8192 records in registers (tests shrink it: many slices on small inputs)
+	u32 seed_bucket = 7600;               // LQCOV_SEED_BUCKET: hits per (query, slice of targets) bucket aimed at; k_seed_decide holds a bucket of up to 8192 records in registers (tests shrink it: many slices on small inputs)
 	u64 seed_chunk = 1ULL << 30;          // LQCOV_SEED_CHUNK: records (8 B) of the bucket buffer; the queries of a part are bucketed in chunks of that many hits
 	u32 seed_segl = 256;                  // LQCOV_SEED_SEGL: minimizers per segment (one block of the count / scatter kernels), at most LQ_SD_SEGL (tests shrink it)
 	u32 seed_pair_bits = 13;              // LQCOV_SEED_PAIR_BITS: pair counters of k_seed_decide in use (tests shrink it: pairs alias on small inputs)
-	u32 seed_big_pair = 32;               // LQCOV_SEED_BIG_PAIR: a (query, target, strand) pair with that many hits is kept without a look at its diagonals (tests shrink it)
+	u32 seed_big_pair = 16;               // LQCOV_SEED_BIG_PAIR: a (query, target, strand) pair with that many hits is kept without a look at its diagonals (tests shrink it)
 	void read_env();
 };
 

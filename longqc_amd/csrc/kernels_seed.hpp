@@ -45,8 +45,8 @@
 #define LQ_SD_RPT 8                         // hits per thread and tile of the count / scatter kernels
 #endif
 #define LQ_SD_TILE (LQ_SD_THREADS * LQ_SD_RPT)
-#define LQ_SD_SL_SMALL 256u                 // slices per query: the two shapes of the scatter kernel
-#define LQ_SD_SL_BIG 1024u
+#define LQ_SD_SL_SMALL 512u                 // slices per query: the two shapes of the scatter kernel
+#define LQ_SD_SL_BIG 2048u
 
 // record = rid << (jb + db + 1) | relative strand << (jb + db) | diagonal << jb | minimizer (index inside its query)
 struct SeedBits { u32 jb, db; };
@@ -97,11 +97,11 @@ __device__ __forceinline__ u32 sd_owner(const u32 *off, u32 n, u32 g)
 }
 
 // One step of a wave over 64 consecutive hits of the segment (valid lanes are a prefix): counts them per slice in the wave's
-// own column of `hist` (hist[d * stride + wave]; stride 1, wave 0: one column for the block, when only totals matter) and returns every hit's rank among the wave's hits of its slice so far.
-// Hits of one list ascend in rid, so inside a list a slice is one run: its first lane adds the run's length.  Lists are
-// taken one after the other (a step rarely touches more than two): no two lanes of one instruction ever add to one counter,
-// and the counts a lane sees do not depend on how the hardware orders atomics.
-__device__ __forceinline__ u32 sd_rank_step(u32 *hist, u32 wave, u32 d, u32 jl, bool valid, u32 lane, u32 stride)
+// own 16-bit counter (two waves to a word: hist[d * LQ_SD_WAVES / 2 + wave / 2]; a tile holds fewer than 65536 hits) and returns
+// every hit's rank among the wave's hits of its slice so far.  Hits of one list ascend in rid, so inside a list a slice is one
+// run: its first lane adds the run's length.  Lists are taken one after the other (a step rarely touches more than two): no two
+// lanes of one instruction ever add to one counter, and the counts a lane sees do not depend on how the hardware orders atomics.
+__device__ __forceinline__ u32 sd_rank_step(u32 *hist, u32 wave, u32 d, u32 jl, bool valid, u32 lane)
 {
 	const u32 jp = __shfl_up(jl, 1), dp = __shfl_up(d, 1);
 	const bool lhead = valid && (lane == 0 || jl != jp);
@@ -115,6 +115,8 @@ __device__ __forceinline__ u32 sd_rank_step(u32 *hist, u32 wave, u32 d, u32 jl, 
 	const u64 above = Rm & ~upto;
 	const u32 nxt = above ? (u32)__ffsll((unsigned long long)above) - 1u : 64u;
 	const u32 len = (nxt < nvalid ? nxt : nvalid) - lane;     // (for a run's first lane: the run's length)
+	const u32 sh = (wave & 1u) << 4;
+	u32 *hw = hist + d * (LQ_SD_WAVES / 2) + (wave >> 1);
 	u32 rank = 0;
 	while (Lm) {                                              // (wave-uniform)
 		const u32 lo = (u32)__ffsll((unsigned long long)Lm) - 1u;
@@ -122,11 +124,24 @@ __device__ __forceinline__ u32 sd_rank_step(u32 *hist, u32 wave, u32 d, u32 jl, 
 		const u32 hi = Lm ? (u32)__ffsll((unsigned long long)Lm) - 1u : 64u;
 		const bool in = valid && lane >= lo && lane < hi;
 		u32 base = 0;
-		if (in && rhead) base = atomicAdd(&hist[d * stride + wave], len);
+		if (in && rhead) base = atomicAdd(hw, len << sh) >> sh & 0xffffu;
 		const u32 b = __shfl(base, (int)hp);
 		if (in) rank = b + (lane - hp);
 	}
 	return rank;
+}
+
+// The same step when only the totals per slice matter (one counter per slice for the whole block): the first lane of a run
+// adds what is left of the step from there on and takes the same amount back from the slice of the run before it -- a run of
+// lanes [h, e) ends up with e - h, without anybody looking for e.
+__device__ __forceinline__ void sd_count_step(u32 *hist, u32 d, bool valid, u32 lane)
+{
+	const u32 dp = __shfl_up(d, 1);
+	const u32 left = (u32)__popcll(__ballot(valid)) - lane;
+	if (valid && (lane == 0 || d != dp)) {
+		atomicAdd(&hist[d], left);
+		if (lane) atomicSub(&hist[dp], left);
+	}
 }
 
 struct SeedIn {                             // what the count / scatter kernels read
@@ -161,18 +176,18 @@ k_seed_count(SeedIn in, u32 g_lo, u32 *cnt)
 	for (u32 i = t; i < Q.nsl; i += LQ_SD_THREADS) hist[i] = 0;
 	__syncthreads();
 	for (u32 base = 0; base < nH; base += LQ_SD_TILE) {
-		u32 jl[LQ_SD_RPT]; u64 r[LQ_SD_RPT];
+		u64 r[LQ_SD_RPT];
 #pragma unroll
 		for (int k = 0; k < LQ_SD_RPT; ++k) {
 			const u32 g = base + (u32)k * LQ_SD_THREADS + t;
-			jl[k] = 0; r[k] = 0;
-			if (g < nH) { jl[k] = sd_owner(loff, nj, g); r[k] = in.pos[la[jl[k]] + g]; }
+			r[k] = 0;
+			if (g < nH) r[k] = in.pos[la[sd_owner(loff, nj, g)] + g];
 		}
 #pragma unroll
 		for (int k = 0; k < LQ_SD_RPT; ++k) {
 			const u32 g = base + (u32)k * LQ_SD_THREADS + t;
 			if (base + (u32)k * LQ_SD_THREADS + (t & ~63u) < nH)                      // (wave-uniform)
-				sd_rank_step(hist, 0, sd_slice((u32)(r[k] >> 32), Q.mul), jl[k], g < nH, lane, 1);
+				sd_count_step(hist, sd_slice((u32)(r[k] >> 32), Q.mul), g < nH, lane);
 		}
 	}
 	__syncthreads();
@@ -188,7 +203,7 @@ k_seed_scatter(SeedIn in, u32 g_lo, const u32 *off, SeedBits bits, u32 span_cons
 	__shared__ u32 loff[LQ_SD_SEGL + 1];
 	__shared__ u64 la[LQ_SD_SEGL];
 	__shared__ u32 lqy[LQ_SD_SEGL];                          // the minimizers' position << 1 | strand
-	__shared__ u32 hist[MAXSL * LQ_SD_WAVES + 1];            // per tile: counts, then first places, per (slice, wave); the last entry: the tile's total
+	__shared__ u32 hist[MAXSL * (LQ_SD_WAVES / 2) + 1];      // per tile: counts, then first places, per (slice, wave), 16 bits each; the last word: the tile's total
 	__shared__ u32 cursor[MAXSL];                            // where the segment's piece of every bucket goes on
 	__shared__ u64 sbuf[LQ_SD_TILE];
 	__shared__ u32 ws[17];
@@ -206,7 +221,7 @@ k_seed_scatter(SeedIn in, u32 g_lo, const u32 *off, SeedBits bits, u32 span_cons
 		if (i < nj) { la[i] = in.hit_start[sg.j0 + i] - o; lqy[i] = (u32)in.qy[sg.j0 + i]; }
 	}
 	for (u32 s = t; s < Q.nsl; s += LQ_SD_THREADS) cursor[s] = off[Q.cb + (u64)s * Q.nseg + sg.ord];
-	const u32 nE = Q.nsl * LQ_SD_WAVES;                      // entries of hist in use
+	const u32 nE = Q.nsl * (LQ_SD_WAVES / 2);                // words of hist in use
 	const u32 per = (nE + LQ_SD_THREADS - 1) / LQ_SD_THREADS;
 	for (u32 base = 0; base < nH; base += LQ_SD_TILE) {
 		for (u32 i = t; i < nE; i += LQ_SD_THREADS) hist[i] = 0;
@@ -234,34 +249,35 @@ k_seed_scatter(SeedIn in, u32 g_lo, const u32 *off, SeedBits bits, u32 span_cons
 				rc[k] = (u64)rid << (bits.jb + bits.db + 1) | (u64)rs << (bits.jb + bits.db) | (u64)diag << bits.jb | (u64)(jrel + jl[k]);
 			}
 			rk[k] = 0;
-			if (base + (u32)k * LQ_SD_THREADS + (t & ~63u) < nH) rk[k] = sd_rank_step(hist, wave, d, jl[k], valid, lane, LQ_SD_WAVES);
+			if (base + (u32)k * LQ_SD_THREADS + (t & ~63u) < nH) rk[k] = sd_rank_step(hist, wave, d, jl[k], valid, lane);
 			jl[k] = d;                                             // (from here on: the hit's slice)
 		}
 		__syncthreads();
-		// counts -> first places, in (slice, wave) order: a thread sums a stretch of `per` entries, the block scans the sums
+		// counts -> first places, in (slice, wave) order: a thread sums a stretch of `per` words (two counts each, the even wave's
+		// in the low half), the block scans the sums
 		u32 mine = 0;
-		for (u32 i = 0; i < per; ++i) { const u32 e = t * per + i; if (e < nE) mine += hist[e]; }
+		for (u32 i = 0; i < per; ++i) { const u32 e = t * per + i; if (e < nE) { const u32 c = hist[e]; mine += (c & 0xffffu) + (c >> 16); } }
 		u32 total = 0;
 		u32 run = sd_block_exscan(mine, ws, &total);
 		for (u32 i = 0; i < per; ++i) {
 			const u32 e = t * per + i;
-			if (e < nE) { const u32 c = hist[e]; hist[e] = run; run += c; }
+			if (e < nE) { const u32 c = hist[e]; const u32 mid = run + (c & 0xffffu); hist[e] = run | mid << 16; run = mid + (c >> 16); }
 		}
 		if (t == 0) hist[nE] = total;
 		__syncthreads();
 #pragma unroll
 		for (int k = 0; k < LQ_SD_RPT; ++k) {
 			const u32 g = base + (u32)k * LQ_SD_THREADS + t;
-			if (g < nH) sbuf[hist[jl[k] * LQ_SD_WAVES + wave] + rk[k]] = rc[k];
+			if (g < nH) sbuf[(hist[jl[k] * (LQ_SD_WAVES / 2) + (wave >> 1)] >> ((wave & 1u) << 4) & 0xffffu) + rk[k]] = rc[k];
 		}
 		__syncthreads();
 		for (u32 i = t; i < total; i += LQ_SD_THREADS) {
 			const u64 r = sbuf[i];
 			const u32 d = sd_slice(sd_rid(r, bits), Q.mul);
-			rec[cursor[d] + (i - hist[d * LQ_SD_WAVES])] = r;        // (a slice's first place in the tile: that of its wave 0)
+			rec[cursor[d] + (i - (hist[d * (LQ_SD_WAVES / 2)] & 0xffffu))] = r;      // (a slice's first place in the tile: that of its wave 0)
 		}
 		__syncthreads();
-		for (u32 s = t; s < Q.nsl; s += LQ_SD_THREADS) cursor[s] += hist[(s + 1) * LQ_SD_WAVES] - hist[s * LQ_SD_WAVES];
+		for (u32 s = t; s < Q.nsl; s += LQ_SD_THREADS) cursor[s] += (hist[(s + 1) * (LQ_SD_WAVES / 2)] & 0xffffu) - (hist[s * (LQ_SD_WAVES / 2)] & 0xffffu);   // (after the last slice: the word that holds the total)
 		__syncthreads();                                          // (the next tile clears hist)
 	}
 }
@@ -271,7 +287,7 @@ struct SeedDecide {
 	u32 n_min;                              // hits a component needs (run_n_min; >= 2 here: without a filter nothing is bucketed)
 	u32 dshift;                             // log2 of the bin width, D > bw
 	u32 pair_bits;                          // pair counters in use (a power of two, at most 2^LQ_SD_PAIR_BITS; tests shrink it: pairs alias)
-	u32 big_pair;                           // a pair with that many hits is kept without looking at its diagonals (at most LQ_SD_BIG_PAIR)
+	u32 big_pair;                           // a pair with that many hits is kept without a look at its diagonals (at most LQ_SD_BIG_PAIR)
 	int no_self;
 	unsigned long long *stats;              // LQCOV_SEED_STATS: {records, records whose pair holds n_min, survivors, buckets beyond the LDS path} summed; else null
 };
@@ -282,9 +298,8 @@ struct SeedDecide {
 #define LQ_SD_DCAP (LQ_SD_DTHREADS * LQ_SD_DRPT)
 #define LQ_SD_PAIR_BITS 13                  // 8192 pair counters (16 bits each)
 #define LQ_SD_NPAIR (1u << LQ_SD_PAIR_BITS)
-#define LQ_SD_BIG_PAIR 32u
-#define LQ_SD_KEY_PASS (1u << 31)           // key bits: the record's pair holds n_min hits / the record survives
-#define LQ_SD_KEY_LIVE (1u << 30)
+#define LQ_SD_BIG_PAIR 16u                  // (a bin of a pair's histogram counts to 15)
+#define LQ_SD_HPAIRS 1024u                  // pairs of a bucket that get a histogram (32 B each)
 
 // a bucket (query, slice) of the chunk: records [b0, b0 + n) of the record buffer; rid0: the slice's first target
 struct alignas(16) SeedBk { u32 b0, n, q, rid0; };
@@ -309,26 +324,26 @@ __global__ void k_seed_bdesc(SeedDecIn in, u32 n_bk, SeedBk *bd)
 
 // 16-bit values, two to a word
 __device__ __forceinline__ u32 sd_h16_get(const u32 *tab, u32 p) { return tab[p >> 1] >> ((p & 1u) << 4) & 0xffffu; }
-// (both return the old value; a value never leaves its 16 bits here: sums are bounded by the bucket, and nothing is taken from a zero)
+// (returns the old value; a value never leaves its 16 bits here: sums are bounded by the bucket)
 __device__ __forceinline__ u32 sd_h16_add(u32 *tab, u32 p, u32 v) { const u32 sh = (p & 1u) << 4; return atomicAdd(&tab[p >> 1], v << sh) >> sh & 0xffffu; }
-__device__ __forceinline__ u32 sd_h16_dec(u32 *tab, u32 p) { const u32 sh = (p & 1u) << 4; return atomicSub(&tab[p >> 1], 1u << sh) >> sh & 0xffffu; }
 
-// does the record whose pair's diagonal bins are ent[st .. en) and whose own bin is `mine` lie in a gap-free stretch of
-// non-empty bins that holds n_min hits?  Bins are compared modulo 2^16 (a wrap only adds).  The window is seven bins: a
-// stretch that reaches its edge is taken as long enough (exact for n_min <= 4, the presets'; generous beyond).
-__device__ __forceinline__ bool sd_stretch(const u16 *ent, u32 st, u32 en, u32 mine, u32 n_min)
+// Hits per diagonal bin of one pair: 64 bins of 4 bits in eight words, bin = diagonal bin mod 64 (a pair whose diagonals span
+// more than 64 bins -- a target beyond 32 kb -- wraps: that only adds).  Does the gap-free stretch of non-empty bins around bin
+// `slot` hold n_min hits?  The seven bins slot - 3 .. slot + 3 are cut out of two neighbouring words; a stretch that reaches the
+// window's edge is taken as long enough (exact for n_min <= 4, the presets'; generous beyond).  A bin never holds more than 15:
+// pairs of LQ_SD_BIG_PAIR (16) hits and more get no histogram.
+__device__ __forceinline__ bool sd_window_alive(const u32 *h8, u32 slot, u32 n_min)
 {
-	u64 occ = 0;                                              // hits per bin mine - 3 .. mine + 3, a byte each (fewer than LQ_SD_BIG_PAIR <= 255 entries)
-	for (u32 e = st; e < en; ++e) {
-		const i32 d = (i32)(int16_t)(u16)(ent[e] - (u16)mine) + 3;
-		if ((u32)d <= 6u) occ += 1ULL << (d << 3);
-	}
-	const u32 side = n_min - 1;
-	u32 tot = (u32)(occ >> 24) & 0xffu;                       // (the record itself is one of the entries)
-	if (tot >= n_min) return true;
-	for (u32 k = 1; k <= 3; ++k) { const u32 c = (u32)(occ >> ((3 + k) << 3)) & 0xffu; if (c == 0) break; tot += c; if (k == side || k == 3) return true; }
-	for (u32 k = 1; k <= 3; ++k) { const u32 c = (u32)(occ >> ((3 - k) << 3)) & 0xffu; if (c == 0) break; tot += c; if (k == side || k == 3) return true; }
-	return tot >= n_min;
+	const u32 sb = (slot - 3u) & 63u, w = sb >> 3;
+	const u64 two = (u64)h8[(w + 1u) & 7u] << 32 | h8[w];
+	const u32 g = (u32)(two >> ((sb & 7u) << 2));              // fields 0 .. 6 = bins slot - 3 .. slot + 3
+	const u32 own = g >> 12 & 15u;
+	const u32 r1 = g >> 16 & 15u, r2 = r1 ? g >> 20 & 15u : 0u, r3 = r2 ? g >> 24 & 15u : 0u;
+	const u32 l1 = g >> 8 & 15u, l2 = l1 ? g >> 4 & 15u : 0u, l3 = l2 ? g & 15u : 0u;
+	const u32 side = n_min - 1u;
+	const u32 reach = side <= 1u ? (r1 | l1) : side == 2u ? (r2 | l2) : (r3 | l3);      // n_min bins in a row (or the edge of the window)
+	const u32 tot = own + r1 + l1 + (side > 1u ? r2 + l2 : 0u) + (side > 2u ? r3 + l3 : 0u);
+	return reach != 0u || tot >= n_min;
 }
 
 // the self diagonal and -X (lqmap.c:180-187) for a record of query q that would otherwise survive
@@ -346,21 +361,19 @@ __device__ __forceinline__ bool sd_rare_drop(u64 r, u32 q, const SeedDecIn &in, 
 	return in.ava.t_rank && in.ava.t_rank[rid] < in.ava.q_lo[q];
 }
 
-// One block per bucket.  The records are read once and stay in registers for the final write; what the phases in between need
-// of a record -- its pair and its diagonal bin -- sits in LDS as a 32-bit key, so those phases are short rolled loops:
+// One block per bucket.  The records are read once and stay in registers (eight per thread):
 //   pairs   hits per (target, relative strand), 16-bit counters
-//   ends    inclusive scan of the counts of the pairs that hold n_min hits: where each such pair's bins end in `ent`
-//   group   every record of such a pair drops its bin into its pair's stretch of `ent` (filled from the end: afterwards the
-//           pair's stretch is [ends[p], ends[p + 1]))
-//   decide  a record looks at its own pair's bins only: no other pair can add to them (sd_stretch)
+//   rank    the pairs that hold n_min hits are numbered (a scan over the counters, eight to a thread); a pair of LQ_SD_BIG_PAIR
+//           hits and more is kept as it is, the first LQ_SD_HPAIRS of the others get a histogram of their diagonal bins each
+//   bins    every record of such a pair counts itself in its pair's own histogram: no other pair can add to it
+//   decide  sd_window_alive; the self diagonal and -X (lqmap.c:180-187) for the queries that have any
 //   write   survivors to the front of the bucket, ordered (thread, k); scnt[bucket] = how many
 // A bucket beyond LQ_SD_DCAP records (a query with more hits than slices can divide): pairs only, the records read twice.
 __global__ void __launch_bounds__(LQ_SD_DTHREADS)
 k_seed_decide(SeedDecIn in, const SeedBk *bd, SeedDecide dp, SeedBits bits, u32 span_const, u64 *rec, u32 *scnt)
 {
-	__shared__ u32 key[LQ_SD_DCAP];
-	__shared__ u32 ends[LQ_SD_NPAIR / 2 + 1];                // 16-bit halves; entry NPAIR: the total
-	__shared__ u16 ent[LQ_SD_DCAP];
+	__shared__ u32 ends[LQ_SD_NPAIR / 2];                    // 16-bit halves: a pair's hits, then 0 (too few), 0xffff (kept as it is) or its histogram's number + 1
+	__shared__ u32 hist[LQ_SD_HPAIRS * 8];
 	__shared__ u32 ws[17];
 	const u32 t = threadIdx.x;
 	const u32 bk = blockIdx.x;
@@ -368,16 +381,16 @@ k_seed_decide(SeedDecIn in, const SeedBk *bd, SeedDecide dp, SeedBits bits, u32 
 	const u32 n = B.n, q = B.q;
 	if (n == 0) { if (t == 0) scnt[bk] = 0; return; }
 	const u32 pmask = (1u << dp.pair_bits) - 1u;
+	const u32 sh_p = bits.jb + bits.db, sh_d = bits.jb + dp.dshift, p0 = B.rid0 << 1;   // (rid << 1 | strand) = record >> sh_p
 	u64 *R = rec + B.b0;
 	const bool self_q = dp.no_self && in.self_off[q] != in.self_off[q + 1];
 	const bool rare = self_q || in.ava.t_rank != nullptr;
-	for (u32 i = t; i < LQ_SD_NPAIR / 2 + 1; i += LQ_SD_DTHREADS) ends[i] = 0;
+	for (u32 i = t; i < LQ_SD_NPAIR / 2; i += LQ_SD_DTHREADS) ends[i] = 0;
 	if (n > LQ_SD_DCAP) {
 		// ---- beyond what the block holds: pairs only ----
 		__syncthreads();
 		for (u32 i = t; i < n; i += LQ_SD_DTHREADS) {
-			const u64 r = R[i];
-			const u32 p = (((sd_rid(r, bits) - B.rid0) << 1) | sd_rs(r, bits)) & pmask;
+			const u32 p = ((u32)(R[i] >> sh_p) - p0) & pmask;
 			if (sd_h16_get(ends, p) < 0x8000u) sd_h16_add(ends, p, 1);           // (at most blockDim more adds can slip past the test: no carry)
 		}
 		__syncthreads();
@@ -385,7 +398,7 @@ k_seed_decide(SeedDecIn in, const SeedBk *bd, SeedDecide dp, SeedBits bits, u32 
 		for (u32 base = 0; base < n; base += LQ_SD_DTHREADS) {
 			const u32 i = base + t;
 			const u64 r = i < n ? R[i] : 0;
-			bool a = i < n && sd_h16_get(ends, (((sd_rid(r, bits) - B.rid0) << 1) | sd_rs(r, bits)) & pmask) >= dp.n_min;
+			bool a = i < n && sd_h16_get(ends, ((u32)(r >> sh_p) - p0) & pmask) >= dp.n_min;
 			if (a && rare && sd_rare_drop(r, q, in, bits, span_const, self_q)) a = false;
 			u32 total = 0;
 			const u32 at = sd_block_exscan(a ? 1u : 0u, ws, &total);  // (its barriers stand between this round's reads and writes)
@@ -395,70 +408,59 @@ k_seed_decide(SeedDecIn in, const SeedBk *bd, SeedDecide dp, SeedBits bits, u32 
 		if (t == 0) { scnt[bk] = done; if (dp.stats) { atomicAdd(&dp.stats[0], (unsigned long long)n); atomicAdd(&dp.stats[1], (unsigned long long)done); atomicAdd(&dp.stats[2], (unsigned long long)done); atomicAdd(&dp.stats[3], 1ULL); } }
 		return;
 	}
+	for (u32 i = t; i < LQ_SD_HPAIRS * 8; i += LQ_SD_DTHREADS) hist[i] = 0;
 	u64 rc[LQ_SD_DRPT];
 #pragma unroll
 	for (int k = 0; k < LQ_SD_DRPT; ++k) { const u32 i = (u32)k * LQ_SD_DTHREADS + t; rc[k] = i < n ? R[i] : 0; }
-	__syncthreads();                                          // (ends is clear)
+	__syncthreads();                                          // (ends and hist are clear)
 	// pairs
 #pragma unroll
-	for (int k = 0; k < LQ_SD_DRPT; ++k) {
-		const u32 i = (u32)k * LQ_SD_DTHREADS + t;
-		if (i < n) {
-			const u32 p = (((sd_rid(rc[k], bits) - B.rid0) << 1) | sd_rs(rc[k], bits)) & pmask;
-			key[i] = p | ((sd_diag(rc[k], bits) >> dp.dshift) & 0xffffu) << LQ_SD_PAIR_BITS;
-			sd_h16_add(ends, p, 1);
-		}
-	}
+	for (int k = 0; k < LQ_SD_DRPT; ++k) if ((u32)k * LQ_SD_DTHREADS + t < n) sd_h16_add(ends, ((u32)(rc[k] >> sh_p) - p0) & pmask, 1);
 	__syncthreads();
-	// ends: a thread takes NPAIR / THREADS pairs in a row
+	// rank: a thread takes NPAIR / THREADS pairs in a row
 	{
 		constexpr u32 PER = LQ_SD_NPAIR / LQ_SD_DTHREADS;         // 8 (even: whole words)
-		u32 c[PER], mine = 0;
+		u32 c[PER], mine = 0, held = 0;
 #pragma unroll
-		for (u32 i = 0; i < PER; i += 2) {
-			const u32 w = ends[(t * PER + i) >> 1];
-			c[i] = (w & 0xffffu) >= dp.n_min ? (w & 0xffffu) : 0u; c[i + 1] = (w >> 16) >= dp.n_min ? (w >> 16) : 0u;
-			mine += c[i] + c[i + 1];
-		}
+		for (u32 i = 0; i < PER; i += 2) { const u32 w = ends[(t * PER + i) >> 1]; c[i] = w & 0xffffu; c[i + 1] = w >> 16; }
+#pragma unroll
+		for (u32 i = 0; i < PER; ++i) { if (c[i] >= dp.n_min) { held += c[i]; if (c[i] < dp.big_pair) ++mine; } }
 		u32 total = 0;
-		u32 run = sd_block_exscan(mine, ws, &total);            // (its first barrier: every count is read before any end is written)
+		u32 ord = sd_block_exscan(mine, ws, &total);            // (its first barrier: every count is read before any number is written)
 #pragma unroll
-		for (u32 i = 0; i < PER; i += 2) { const u32 e0 = run + c[i], e1 = e0 + c[i + 1]; ends[(t * PER + i) >> 1] = e0 | e1 << 16; run = e1; }
-		if (t == 0) { ends[LQ_SD_NPAIR / 2] = total; if (dp.stats) { atomicAdd(&dp.stats[0], (unsigned long long)n); atomicAdd(&dp.stats[1], (unsigned long long)total); } }
+		for (u32 i = 0; i < PER; ++i) {
+			u32 v = 0;
+			if (c[i] >= dp.n_min) { v = 0xffffu; if (c[i] < dp.big_pair) { if (ord < LQ_SD_HPAIRS) v = ord + 1u; ++ord; } }
+			c[i] = v;
+		}
+#pragma unroll
+		for (u32 i = 0; i < PER; i += 2) ends[(t * PER + i) >> 1] = c[i] | c[i + 1] << 16;
+		if (dp.stats) { if (held) atomicAdd(&dp.stats[1], (unsigned long long)held); if (t == 0) atomicAdd(&dp.stats[0], (unsigned long long)n); }
 	}
 	__syncthreads();
-	// which records belong to a pair that holds enough (the ends still stand)
-	for (u32 i = t; i < n; i += LQ_SD_DTHREADS) {
-		const u32 kk = key[i], p = kk & (LQ_SD_NPAIR - 1u);
-		if (sd_h16_get(ends, p) != (p ? sd_h16_get(ends, p - 1) : 0u)) key[i] = kk | LQ_SD_KEY_PASS;
-	}
-	__syncthreads();
-	// group: a pair's stretch fills from its end downwards
-	for (u32 i = t; i < n; i += LQ_SD_DTHREADS) {
-		const u32 kk = key[i];
-		if (kk & LQ_SD_KEY_PASS) ent[sd_h16_dec(ends, kk & (LQ_SD_NPAIR - 1u)) - 1u] = (u16)(kk >> LQ_SD_PAIR_BITS);
+	// bins
+#pragma unroll
+	for (int k = 0; k < LQ_SD_DRPT; ++k) {
+		if ((u32)k * LQ_SD_DTHREADS + t < n) {
+			const u32 o = sd_h16_get(ends, ((u32)(rc[k] >> sh_p) - p0) & pmask);
+			if (o - 1u < LQ_SD_HPAIRS) { const u32 slot = (u32)(rc[k] >> sh_d) & 63u; atomicAdd(&hist[(o - 1u) * 8u + (slot >> 3)], 1u << ((slot & 7u) << 2)); }
+		}
 	}
 	__syncthreads();
 	// decide
-	for (u32 i = t; i < n; i += LQ_SD_DTHREADS) {
-		const u32 kk = key[i];
-		if (!(kk & LQ_SD_KEY_PASS)) continue;
-		const u32 p = kk & (LQ_SD_NPAIR - 1u);
-		const u32 st = sd_h16_get(ends, p), en = sd_h16_get(ends, p + 1);
-		bool a = en - st >= dp.big_pair || sd_stretch(ent, st, en, kk >> LQ_SD_PAIR_BITS & 0xffffu, dp.n_min);
-		if (a && rare) a = !sd_rare_drop(R[i], q, in, bits, span_const, self_q);   // (the bucket is still as it was read: nothing is written before the last phase)
-		if (a) key[i] = kk | LQ_SD_KEY_LIVE;
-	}
-	__syncthreads();
-	// write
-	u32 al = 0, mine = 0;
+	u32 al = 0;
 #pragma unroll
 	for (int k = 0; k < LQ_SD_DRPT; ++k) {
-		const u32 i = (u32)k * LQ_SD_DTHREADS + t;
-		if (i < n && (key[i] & LQ_SD_KEY_LIVE)) { al |= 1u << k; ++mine; }
+		if ((u32)k * LQ_SD_DTHREADS + t < n) {
+			const u32 o = sd_h16_get(ends, ((u32)(rc[k] >> sh_p) - p0) & pmask);
+			if (o == 0xffffu || (o && sd_window_alive(hist + (o - 1u) * 8u, (u32)(rc[k] >> sh_d) & 63u, dp.n_min))) al |= 1u << k;
+		}
 	}
+	if (rare) for (u32 k = 0; k < LQ_SD_DRPT; ++k)                // (rolled, the records read again: rare)
+		if ((al >> k & 1u) && sd_rare_drop(R[k * LQ_SD_DTHREADS + t], q, in, bits, span_const, self_q)) al &= ~(1u << k);
+	// write
 	u32 total = 0;
-	u32 at = sd_block_exscan(mine, ws, &total);                // (every record was read long before)
+	u32 at = sd_block_exscan((u32)__popc(al), ws, &total);     // (every record was read long before)
 #pragma unroll
 	for (int k = 0; k < LQ_SD_DRPT; ++k) if (al >> k & 1u) R[at++] = rc[k];
 	if (t == 0) { scnt[bk] = total; if (dp.stats) atomicAdd(&dp.stats[2], (unsigned long long)total); }
