@@ -1435,7 +1435,7 @@ void lqcov_handle::seed_filter(Part &pt, hipStream_t s, Prim &pr, SeedWork &W, u
 	dp.dshift = 1; while (dp.dshift < 30 && (1u << dp.dshift) <= (u32)std::max<i32>(P.bw, 0)) ++dp.dshift;   // bins wider than the band (chain.c:55)
 	const u32 span_const = (u32)(P.hpc ? 0 : P.k);
 	DBuf d_stats;
-	if (getenv("LQCOV_SEED_STATS")) { d_stats.ensure(32); dzero(d_stats.p, 32, s); dp.stats = d_stats.as<unsigned long long>(); }
+	if (getenv("LQCOV_SEED_STATS")) { d_stats.ensure(64); dzero(d_stats.p, 64, s); dp.stats = d_stats.as<unsigned long long>(); }
 	u64 n_surv = 0;
 	S.surv.ensure(std::max<u64>(S.nA_total / 16, 1024) * 8);   // (grows by chunk if the survivors outnumber the guess)
 	for (const Chunk &c : chunks) {
@@ -1476,10 +1476,10 @@ void lqcov_handle::seed_filter(Part &pt, hipStream_t s, Prim &pr, SeedWork &W, u
 	d2h(S.h_aqf.data(), S.aqf_off.as<u64>(), n_q + 1, s);
 	S.n_written = n_surv; S.rec_jb = jb; S.rec_db = db; S.bucketed = true;
 	if (dp.stats) {
-		unsigned long long st[4];
-		d2h(st, dp.stats, 4, s);
-		fprintf(stderr, "[lqcov] seed filter: %llu hits in %zu chunks, %zu segments; pairs with %u hits hold %llu (%.2f %%), survivors %llu (%.2f %%); %llu buckets beyond the LDS path\n",
-		        st[0], chunks.size(), segs.size(), n_min, st[1], st[0] ? 100.0 * st[1] / st[0] : 0.0, st[2], st[0] ? 100.0 * st[2] / st[0] : 0.0, st[3]);
+		unsigned long long st[8];
+		d2h(st, dp.stats, 8, s);
+		fprintf(stderr, "[lqcov] seed filter: %llu hits in %zu chunks, %zu segments; pairs with %u hits hold %llu (%.2f %%), survivors %llu (%.2f %%); %llu buckets beyond the block, %llu hits in pairs kept as they are, %llu in pairs left without a histogram\n",
+		        st[0], chunks.size(), segs.size(), n_min, st[1], st[0] ? 100.0 * st[1] / st[0] : 0.0, st[2], st[0] ? 100.0 * st[2] / st[0] : 0.0, st[3], st[4], st[5]);
 	}
 }
 

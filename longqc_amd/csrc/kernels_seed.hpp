@@ -289,7 +289,7 @@ struct SeedDecide {
 	u32 pair_bits;                          // pair counters in use (a power of two, at most 2^LQ_SD_PAIR_BITS; tests shrink it: pairs alias)
 	u32 big_pair;                           // a pair with that many hits is kept without a look at its diagonals (at most LQ_SD_BIG_PAIR)
 	int no_self;
-	unsigned long long *stats;              // LQCOV_SEED_STATS: {records, records whose pair holds n_min, survivors, buckets beyond the LDS path} summed; else null
+	unsigned long long *stats;              // LQCOV_SEED_STATS: {records, records whose pair holds n_min, survivors, buckets beyond the block, records of big pairs, records of pairs left without a histogram} summed; else null
 };
 #ifndef LQ_SD_DTHREADS
 #define LQ_SD_DTHREADS 1024
@@ -430,7 +430,11 @@ k_seed_decide(SeedDecIn in, const SeedBk *bd, SeedDecide dp, SeedBits bits, u32 
 #pragma unroll
 		for (u32 i = 0; i < PER; ++i) {
 			u32 v = 0;
-			if (c[i] >= dp.n_min) { v = 0xffffu; if (c[i] < dp.big_pair) { if (ord < LQ_SD_HPAIRS) v = ord + 1u; ++ord; } }
+			if (c[i] >= dp.n_min) {
+				v = 0xffffu;
+				if (c[i] < dp.big_pair) { if (ord < LQ_SD_HPAIRS) v = ord + 1u; else if (dp.stats) atomicAdd(&dp.stats[5], (unsigned long long)c[i]); ++ord; }
+				else if (dp.stats) atomicAdd(&dp.stats[4], (unsigned long long)c[i]);
+			}
 			c[i] = v;
 		}
 #pragma unroll

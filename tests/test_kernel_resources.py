@@ -45,10 +45,10 @@ def test_streaming_kernels_keep_full_occupancy_and_nothing_spills(resources):
     assert not spilling, spilling                                 # (k_sketch<256, ...>: the ring of the rare w > 16 case lives in scratch by design)
     w = resources["k_chain_wave"]                                 # (one wave per run: 32 bytes of frame for the lane-0 replay of the rare tie / beyond-the-window chunks)
     assert w["scratch"] <= 64 and w["vgpr"] <= 64, w
-    # the seed filter's streaming kernels (kernels_seed.hpp): nothing spills, three blocks of the count / scatter kernels and
-    # two of the decide kernel (16 records per thread in registers) fit a CU
-    sc, ss, sb, sd = resources["k_seed_count"], resources["k_seed_scatter<256u>"], resources["k_seed_scatter<1024u>"], resources["k_seed_decide"]
+    # the seed filter's kernels (kernels_seed.hpp) are bound by instruction issue: nothing spills, three blocks of the count /
+    # scatter kernels (512 threads) and two of the decide kernel (1024 threads, eight records per thread in registers) fit a CU
+    sc, ss, sb, sd = resources["k_seed_count"], resources["k_seed_scatter<512u>"], resources["k_seed_scatter<2048u>"], resources["k_seed_decide"]
     assert sc["vgpr"] <= 64 and sc["scratch"] == 0 and 3 * sc["lds"] <= 160 * 1024, sc
     assert ss["vgpr"] <= 80 and ss["scratch"] == 0 and 3 * ss["lds"] <= 160 * 1024, ss
-    assert sb["scratch"] == 0 and sb["lds"] <= 160 * 1024, sb
-    assert sd["vgpr"] <= 128 and sd["scratch"] == 0 and 2 * sd["lds"] <= 160 * 1024, sd
+    assert sb["scratch"] == 0 and 2 * sb["lds"] <= 160 * 1024, sb
+    assert sd["vgpr"] <= 64 and sd["scratch"] == 0 and 2 * sd["lds"] <= 160 * 1024, sd
