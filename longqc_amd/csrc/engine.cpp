@@ -129,7 +129,10 @@ void Knobs::read_env()
 	if (seed_chunk > 0xfffffff0ULL) seed_chunk = 0xfffffff0ULL;
 	seed_segl = (u32)std::min<long>(LQ_SD_SEGL, std::max<long>(1, num("LQCOV_SEED_SEGL", LQ_SD_SEGL)));
 	seed_pair_bits = (u32)std::min<long>(LQ_SD_PAIR_BITS, std::max<long>(1, num("LQCOV_SEED_PAIR_BITS", LQ_SD_PAIR_BITS)));
-	seed_big_pair = (u32)std::min<long>(LQ_SD_BIG_PAIR, std::max<long>(2, num("LQCOV_SEED_BIG_PAIR", LQ_SD_BIG_PAIR)));
+	seed_units = (u32)std::min<long>(LQ_SD_HUNITS, std::max<long>(1, num("LQCOV_SEED_UNITS", LQ_SD_HUNITS)));
+	seed_surv_max = getenv("LQCOV_SEED_SURV_MAX") ? strtoull(getenv("LQCOV_SEED_SURV_MAX"), 0, 10) : 3ULL << 30;
+	seed_dcap = (u32)std::min<long>(LQ_SD_DCAP, std::max<long>(1, num("LQCOV_SEED_DCAP", LQ_SD_DCAP)));
+	seed_bigcap = (u32)std::min<long>(LQ_SD_BIGCAP, std::max<long>(1, num("LQCOV_SEED_BIGCAP", LQ_SD_BIGCAP)));
 }
 
 lqcov_handle::lqcov_handle(const lqcov_params &p, int dev) : P(p), device(dev)
@@ -1361,7 +1364,7 @@ void lqcov_handle::open_gate()
 // Host side of the bucketed filter: the geometry (slices of targets per query, segments of minimizers, chunks of queries that
 // fit the record buffer), then per chunk count -> scan -> scatter -> decide -> scan -> collect.  One host sync per chunk (the
 // survivors' total sizes the plan's array).
-void lqcov_handle::seed_filter(Part &pt, hipStream_t s, Prim &pr, SeedWork &W, u32 n_min, u32 jb, u32 db)
+bool lqcov_handle::seed_filter(Part &pt, hipStream_t s, Prim &pr, SeedWork &W, u32 n_min, u32 jb, u32 db)
 {
 	SeedPlan &S = pt.plan;
 	const u32 n_q = q.n;
@@ -1422,7 +1425,7 @@ void lqcov_handle::seed_filter(Part &pt, hipStream_t s, Prim &pr, SeedWork &W, u
 	u64 max_ne = 0, max_nb = 0, max_hits = 0;
 	for (const Chunk &c : chunks) { max_ne = std::max(max_ne, c.ne); max_nb = std::max(max_nb, c.nb); max_hits = std::max(max_hits, c.hits); }
 	W.qg.ensure(qg.size() * sizeof(SeedQ) + 16); W.segs.ensure(segs.size() * sizeof(SeedSeg) + 16); W.bq.ensure(bq_all.size() * 4 + 4); W.has.ensure((u64)n_q * 4 + 4);
-	W.cnt.ensure((max_ne + 1) * 4); W.off.ensure((max_ne + 1) * 4); W.scnt.ensure((max_nb + 1) * 4); W.soff.ensure((max_nb + 1) * 4); W.bd.ensure((max_nb + 1) * sizeof(SeedBk));
+	W.cnt.ensure((max_ne + 1) * 4); W.off.ensure((max_ne + 1) * 4); W.scnt.ensure((max_nb + 1) * 4); W.soff.ensure((max_nb + 1) * 4); W.bd.ensure((max_nb + 1) * sizeof(SeedBk)); W.big.ensure((max_nb + 2) * 4);
 	W.rec.ensure(max_hits * 8 + 8);
 	h2d(W.qg.as<SeedQ>(), qg.data(), qg.size(), s); h2d(W.segs.as<SeedSeg>(), segs.data(), segs.size(), s);
 	h2d(W.bq.as<u32>(), bq_all.data(), bq_all.size(), s); h2d(W.has.as<u32>(), has.data(), has.size(), s);
@@ -1431,7 +1434,8 @@ void lqcov_handle::seed_filter(Part &pt, hipStream_t s, Prim &pr, SeedWork &W, u
 	in.segs = W.segs.as<SeedSeg>(); in.qg = W.qg.as<SeedQ>(); in.h_off = W.h_off.as<u64>(); in.hit_start = S.hit_start.as<u64>(); in.pos = pt.pos.as<u64>();
 	in.qx = q.mx.as<u64>(); in.qy = q.my.as<u64>(); in.qmoff = q.moff.as<u64>(); in.qlen = q.d_len.as<u32>();
 	SeedDecide dp; memset(&dp, 0, sizeof(dp));
-	dp.n_min = n_min; dp.pair_bits = K.seed_pair_bits; dp.big_pair = K.seed_big_pair; dp.no_self = (int)P.no_self;
+	dp.n_min = n_min; dp.pair_bits = K.seed_pair_bits; dp.units = K.seed_units; dp.dcap = K.seed_dcap; dp.bigcap = K.seed_bigcap; dp.no_self = (int)P.no_self;
+	for (u32 v : pt.rs.h_len) dp.max_tlen = std::max(dp.max_tlen, v);
 	dp.dshift = 1; while (dp.dshift < 30 && (1u << dp.dshift) <= (u32)std::max<i32>(P.bw, 0)) ++dp.dshift;   // bins wider than the band (chain.c:55)
 	const u32 span_const = (u32)(P.hpc ? 0 : P.k);
 	DBuf d_stats;
@@ -1457,15 +1461,22 @@ void lqcov_handle::seed_filter(Part &pt, hipStream_t s, Prim &pr, SeedWork &W, u
 		di.qg = W.qg.as<SeedQ>(); di.bq = W.bq.as<u32>() + c.bq_at; di.q_lo = c.q_lo; di.n_qc = c.q_hi - c.q_lo; di.off = W.off.as<u32>();
 		di.qx = q.mx.as<u64>(); di.qy = q.my.as<u64>(); di.qmoff = q.moff.as<u64>(); di.qlen = q.d_len.as<u32>();
 		di.self_off = pt.self_off.as<u32>(); di.self_rid = pt.self_rid.as<u32>(); di.ava = ava;
-		LQ_LAUNCH(k_seed_bdesc, nblk(c.nb, 256), 256, s, di, (u32)c.nb, W.bd.as<SeedBk>()); check_launch();
+		di.tlen = pt.rs.d_len.as<u32>(); di.n_targets = pt.rs.n;
+		dzero(W.big.p, 4, s);
+		LQ_LAUNCH(k_seed_bdesc, nblk(c.nb, 256), 256, s, di, (u32)c.nb, dp.dcap, W.bd.as<SeedBk>(), W.big.as<u32>()); check_launch();
 		{
 			StageTimer t(this, s, "k_seed_decide", c.hits * 8);
 			LQ_LAUNCH(k_seed_decide, (u32)c.nb, LQ_SD_DTHREADS, s, di, W.bd.as<SeedBk>(), dp, bits, span_const, W.rec.as<u64>(), W.scnt.as<u32>()); check_launch();
+			LQ_LAUNCH(k_seed_decide_big, (u32)std::min<u64>(c.nb, 1024), LQ_SD_DTHREADS, s, di, W.bd.as<SeedBk>(), W.big.as<u32>(), dp, bits, span_const, W.rec.as<u64>(), W.scnt.as<u32>()); check_launch();
 		}
 		dzero(W.scnt.as<u32>() + c.nb, 4, s);
 		pr.exclusive_scan_u32_u32(W.scnt.as<u32>(), W.soff.as<u32>(), c.nb + 1);
 		u32 n_c = 0;
 		d2h(&n_c, W.soff.as<u32>() + c.nb, 1, s);
+		if (n_surv + n_c > K.seed_surv_max) {                      // more survivors than the plan may hold (reads that repeat each other): the first pass writes every hit, batch by batch
+			S.surv.release();
+			return false;
+		}
 		if ((n_surv + n_c) * 8 > S.surv.cap) grow_keep(S.surv, n_surv * 8, (n_surv + n_c) * 8, s);
 		LQ_LAUNCH(k_seed_collect, (u32)c.nb, 64, s, W.bd.as<SeedBk>(), W.rec.as<u64>(), W.scnt.as<u32>(), W.soff.as<u32>(), n_surv, S.surv.as<u64>(), S.aqf_off.as<u64>()); check_launch();
 		add_stage_bytes("k_seed_decide", (u64)n_c * 8);
@@ -1474,13 +1485,14 @@ void lqcov_handle::seed_filter(Part &pt, hipStream_t s, Prim &pr, SeedWork &W, u
 	LQ_LAUNCH(k_seed_fill_off, 1, 64, s, W.has.as<u32>(), n_q, n_surv, S.aqf_off.as<u64>()); check_launch();
 	S.h_aqf.assign(n_q + 1, 0);
 	d2h(S.h_aqf.data(), S.aqf_off.as<u64>(), n_q + 1, s);
-	S.n_written = n_surv; S.rec_jb = jb; S.rec_db = db; S.bucketed = true;
+	S.n_written = n_surv; S.rec_jb = jb; S.rec_db = db;
 	if (dp.stats) {
 		unsigned long long st[8];
 		d2h(st, dp.stats, 8, s);
-		fprintf(stderr, "[lqcov] seed filter: %llu hits in %zu chunks, %zu segments; pairs with %u hits hold %llu (%.2f %%), survivors %llu (%.2f %%); %llu buckets beyond the block, %llu hits in pairs kept as they are, %llu in pairs left without a histogram\n",
-		        st[0], chunks.size(), segs.size(), n_min, st[1], st[0] ? 100.0 * st[1] / st[0] : 0.0, st[2], st[0] ? 100.0 * st[2] / st[0] : 0.0, st[3], st[4], st[5]);
+		fprintf(stderr, "[lqcov] seed filter: %llu hits in %zu chunks, %zu segments; pairs with %u hits hold %llu (%.2f %%), survivors %llu (%.2f %%); %llu buckets beyond the block (%llu of them by pairs only), %llu pairs left without a histogram\n",
+		        st[0], chunks.size(), segs.size(), n_min, st[1], st[0] ? 100.0 * st[1] / st[0] : 0.0, st[2], st[0] ? 100.0 * st[2] / st[0] : 0.0, st[3], st[5], st[4]);
 	}
+	return true;
 }
 
 // ---- map every query against one part (lqmap.c:207-326) -----------------------------------------
@@ -1553,9 +1565,10 @@ void lqcov_handle::plan_part(Part &pt, hipStream_t s, Prim &pr)
 		const u32 jb = bits_for(max_nm - 1), db = bits_for((u64)max_tlen + max_qlen + 257), rb = bits_for(pt.rs.n ? pt.rs.n - 1 : 0);
 		u64 max_hits = 0;
 		for (u32 i = 0; i < n_q; ++i) max_hits = std::max<u64>(max_hits, S.h_aq[i + 1] - S.h_aq[i]);
-		if (n_min >= 2 && nA_total && jb + db + 1 + rb <= 64 && db <= 31 && jb <= 31 && max_hits < 0x7fff0000ULL) {
-			seed_filter(pt, s, pr, seed_ws[s == bstream ? 1 : 0], n_min, jb, db);
-		} else {
+		if (n_min >= 2 && n_min <= 15 && nA_total && jb + db + 1 + rb <= 64 && db <= 31 && jb <= 31 && max_hits < 0x7fff0000ULL) {
+			S.bucketed = seed_filter(pt, s, pr, seed_ws[s == bstream ? 1 : 0], n_min, jb, db);
+		}
+		if (!S.bucketed) {
 			S.h_aqf = S.h_aq;
 			LQ_HIP_CHECK(hipMemcpyAsync(S.aqf_off.p, S.aq_off.p, (n_q + 1) * 8, hipMemcpyDeviceToDevice, s));
 			S.n_written = nA_total;

@@ -58,7 +58,9 @@ struct Knobs {
 	u64 seed_chunk = 1ULL << 30;          // LQCOV_SEED_CHUNK: records (8 B) of the bucket buffer; the queries of a part are bucketed in chunks of that many hits
 	u32 seed_segl = 256;                  // LQCOV_SEED_SEGL: minimizers per segment (one block of the count / scatter kernels), at most LQ_SD_SEGL (tests shrink it)
 	u32 seed_pair_bits = 13;              // LQCOV_SEED_PAIR_BITS: pair counters of k_seed_decide in use (tests shrink it: pairs alias on small inputs)
-	u32 seed_big_pair = 16;               // LQCOV_SEED_BIG_PAIR: a (query, target, strand) pair with that many hits is kept without a look at its diagonals (tests shrink it)
+	u32 seed_dcap = 8192, seed_bigcap = 65536;   // LQCOV_SEED_DCAP / LQCOV_SEED_BIGCAP: records of a bucket k_seed_decide takes from registers / in passes over stretches of its targets (tests shrink them)
+	u64 seed_surv_max = 3ULL << 30;       // LQCOV_SEED_SURV_MAX: survivors (8 B each) a part's plan may hold; beyond that the part is mapped without the filter (tests shrink it)
+	u32 seed_units = 1024;                // LQCOV_SEED_UNITS: histogram space of a bucket in 64-bin units (tests shrink it: pairs that find no room are kept as they are)
 	void read_env();
 };
 
@@ -98,7 +100,7 @@ struct SeedPlan {
 };
 
 // work space of the seed filter (plan_part): one set per stream that can make a plan
-struct SeedWork { DBuf hlen, h_off, hq_off, qg, segs, bq, cnt, off, scnt, soff, rec, has, bd; };
+struct SeedWork { DBuf hlen, h_off, hq_off, qg, segs, bq, cnt, off, scnt, soff, rec, has, bd, big; };
 
 struct Part {
 	bool live = false, built = false;
@@ -234,7 +236,7 @@ struct lqcov_handle {
 	void build_part(Part &pt);
 	void open_gate();
 	void plan_part(Part &pt, hipStream_t s, Prim &pr);
-	void seed_filter(Part &pt, hipStream_t s, Prim &pr, SeedWork &W, u32 n_min, u32 jb, u32 db);
+	bool seed_filter(Part &pt, hipStream_t s, Prim &pr, SeedWork &W, u32 n_min, u32 jb, u32 db);
 	void swap_plan(SeedPlan &S);
 	void map_part(Part &pt);
 	void map_batch(MapLane &L, Part &pt, u32 q0, u32 q1, const std::vector<u64> &h_aq, const std::vector<u64> &h_aqf, const std::vector<u64> &h_qmoff, bool dbg);

@@ -284,12 +284,14 @@ k_seed_scatter(SeedIn in, u32 g_lo, const u32 *off, SeedBits bits, u32 span_cons
 
 // ---- which records survive --------------------------------------------------------------------------------------------------
 struct SeedDecide {
-	u32 n_min;                              // hits a component needs (run_n_min; >= 2 here: without a filter nothing is bucketed)
+	u32 n_min;                              // hits a component needs (run_n_min; 2 .. 15 here: else nothing is bucketed)
 	u32 dshift;                             // log2 of the bin width, D > bw
 	u32 pair_bits;                          // pair counters in use (a power of two, at most 2^LQ_SD_PAIR_BITS; tests shrink it: pairs alias)
-	u32 big_pair;                           // a pair with that many hits is kept without a look at its diagonals (at most LQ_SD_BIG_PAIR)
+	u32 max_tlen;                           // longest target of the part (the bins of pairs that share a counter)
+	u32 units;                              // histogram space in use, in 64-bin units (at most LQ_SD_HUNITS; tests shrink it)
+	u32 dcap, bigcap;                       // records of a bucket decided from registers / in passes (at most LQ_SD_DCAP / LQ_SD_BIGCAP; tests shrink them)
 	int no_self;
-	unsigned long long *stats;              // LQCOV_SEED_STATS: {records, records whose pair holds n_min, survivors, buckets beyond the block, records of big pairs, records of pairs left without a histogram} summed; else null
+	unsigned long long *stats;              // LQCOV_SEED_STATS: {records, records whose pair holds n_min, survivors, buckets beyond the block, records of pairs left without a histogram} summed; else null
 };
 #ifndef LQ_SD_DTHREADS
 #define LQ_SD_DTHREADS 1024
@@ -298,19 +300,21 @@ struct SeedDecide {
 #define LQ_SD_DCAP (LQ_SD_DTHREADS * LQ_SD_DRPT)
 #define LQ_SD_PAIR_BITS 13                  // 8192 pair counters (16 bits each)
 #define LQ_SD_NPAIR (1u << LQ_SD_PAIR_BITS)
-#define LQ_SD_BIG_PAIR 16u                  // (a bin of a pair's histogram counts to 15)
-#define LQ_SD_HPAIRS 1024u                  // pairs of a bucket that get a histogram (32 B each)
+#define LQ_SD_HUNITS 1024u                  // histogram space of a bucket: units of 64 bins x 4 bits (32 B each)
+#define LQ_SD_HMAX_LOG 5u                   // a pair's histogram: 64 << 0 .. 64 << 5 bins
 
 // a bucket (query, slice) of the chunk: records [b0, b0 + n) of the record buffer; rid0: the slice's first target
-struct alignas(16) SeedBk { u32 b0, n, q, rid0; };
+struct alignas(32) SeedBk { u32 b0, n, q, rid0, nt, pad0, pad1, pad2; };   // nt: targets in the slice
 struct SeedDecIn {
 	const SeedQ *qg; const u32 *bq;         // bq: first bucket of every query of the chunk (n_qc + 1 entries), q_lo: its first query
 	u32 q_lo, n_qc;
 	const u32 *off;                         // piece table (exclusive scan of cnt), + 1 sentinel
 	const u64 *qx, *qy, *qmoff; const u32 *qlen;
 	const u32 *self_off, *self_rid; AvaView ava;
+	const u32 *tlen; u32 n_targets;         // the part's target lengths
 };
-__global__ void k_seed_bdesc(SeedDecIn in, u32 n_bk, SeedBk *bd)
+// (buckets of more than dcap records are listed for k_seed_decide_big: big[0] = how many, big[1 ..] = which)
+__global__ void k_seed_bdesc(SeedDecIn in, u32 n_bk, u32 dcap, SeedBk *bd, u32 *big)
 {
 	const u32 bk = blockIdx.x * blockDim.x + threadIdx.x;
 	if (bk >= n_bk) return;
@@ -319,7 +323,9 @@ __global__ void k_seed_bdesc(SeedDecIn in, u32 n_bk, SeedBk *bd)
 	const SeedQ Q = in.qg[q];
 	const u64 e0 = Q.cb + (u64)s * Q.nseg;
 	SeedBk b; b.b0 = in.off[e0]; b.n = in.off[e0 + Q.nseg] - b.b0; b.q = q; b.rid0 = sd_slice_first(s, Q.mul);   // (the entry after a query's last one is the next query's first, or the sentinel)
+	b.nt = (s + 1 < Q.nsl ? sd_slice_first(s + 1, Q.mul) : in.n_targets) - b.rid0; b.pad0 = b.pad1 = b.pad2 = 0;
 	bd[bk] = b;
+	if (b.n > dcap) big[1u + atomicAdd(&big[0], 1u)] = bk;
 }
 
 // 16-bit values, two to a word
@@ -327,15 +333,27 @@ __device__ __forceinline__ u32 sd_h16_get(const u32 *tab, u32 p) { return tab[p 
 // (returns the old value; a value never leaves its 16 bits here: sums are bounded by the bucket)
 __device__ __forceinline__ u32 sd_h16_add(u32 *tab, u32 p, u32 v) { const u32 sh = (p & 1u) << 4; return atomicAdd(&tab[p >> 1], v << sh) >> sh & 0xffffu; }
 
-// Hits per diagonal bin of one pair: 64 bins of 4 bits in eight words, bin = diagonal bin mod 64 (a pair whose diagonals span
-// more than 64 bins -- a target beyond 32 kb -- wraps: that only adds).  Does the gap-free stretch of non-empty bins around bin
-// `slot` hold n_min hits?  The seven bins slot - 3 .. slot + 3 are cut out of two neighbouring words; a stretch that reaches the
-// window's edge is taken as long enough (exact for n_min <= 4, the presets'; generous beyond).  A bin never holds more than 15:
-// pairs of LQ_SD_BIG_PAIR (16) hits and more get no histogram.
-__device__ __forceinline__ bool sd_window_alive(const u32 *h8, u32 slot, u32 n_min)
+// Hits per diagonal bin of one pair: a ring of 64 << k bins of 4 bits, eight bins to a word, bin = diagonal bin modulo the ring
+// (sized to the pair's diagonals: query + target length; a ring that is too short only adds).  A bin counts to 15 and stays
+// there: every n_min in use is below that, so "15" is as good as the number.
+__device__ __forceinline__ void sd_bin_inc(u32 *w, u32 field)
 {
-	const u32 sb = (slot - 3u) & 63u, w = sb >> 3;
-	const u64 two = (u64)h8[(w + 1u) & 7u] << 32 | h8[w];
+	const u32 sh = field << 2;
+	u32 old = *w;
+	for (;;) {
+		if ((old >> sh & 15u) == 15u) return;
+		const u32 seen = atomicCAS(w, old, old + (1u << sh));
+		if (seen == old) return;
+		old = seen;
+	}
+}
+// Does the gap-free stretch of non-empty bins around bin `slot` hold n_min hits?  The seven bins slot - 3 .. slot + 3 are cut
+// out of two neighbouring words of the ring (wmask: its words - 1); a stretch that reaches the window's edge is taken as long
+// enough (exact for n_min <= 4, the presets'; generous beyond).
+__device__ __forceinline__ bool sd_window_alive(const u32 *h, u32 wmask, u32 slot, u32 n_min)
+{
+	const u32 sb = slot - 3u, w = sb >> 3 & wmask;
+	const u64 two = (u64)h[(w + 1u) & wmask] << 32 | h[w];
 	const u32 g = (u32)(two >> ((sb & 7u) << 2));              // fields 0 .. 6 = bins slot - 3 .. slot + 3
 	const u32 own = g >> 12 & 15u;
 	const u32 r1 = g >> 16 & 15u, r2 = r1 ? g >> 20 & 15u : 0u, r3 = r2 ? g >> 24 & 15u : 0u;
@@ -361,19 +379,69 @@ __device__ __forceinline__ bool sd_rare_drop(u64 r, u32 q, const SeedDecIn &in, 
 	return in.ava.t_rank && in.ava.t_rank[rid] < in.ava.q_lo[q];
 }
 
+// The pairs that hold n_min hits get a histogram of their diagonal bins each -- a ring as long as the pair's diagonals can be
+// (query + target length) --, handed out by a scan over the pair counters, eight to a thread; pairs that find no room are kept
+// as they are.  ends[]: counts in, 0 (too few) / 0xffff (kept as it is) / (first unit + 1) | log2(units) << 11 out.
+// rid_base: the target of pair 0; shared: a counter may stand for several targets (more pairs than counters in use).
+__device__ __forceinline__ void sd_rank_pairs(u32 *ends, u32 *ws, const SeedDecIn &in, const SeedDecide &dp, u32 ql, u32 rid_base, bool shared, u32 t)
+{
+	constexpr u32 PER = LQ_SD_NPAIR / LQ_SD_DTHREADS;             // 8 (even: whole words)
+	u32 c[PER], mine = 0, held = 0;
+#pragma unroll
+	for (u32 i = 0; i < PER; i += 2) { const u32 w = ends[(t * PER + i) >> 1]; c[i] = w & 0xffffu; c[i + 1] = w >> 16; }
+#pragma unroll
+	for (u32 i = 0; i < PER; ++i) {
+		if (c[i] >= dp.n_min) {
+			held += c[i];
+			const u32 rid = rid_base + ((t * PER + i) >> 1);
+			const u32 tl = shared || rid >= in.n_targets ? dp.max_tlen : in.tlen[rid];
+			const u32 nb = ((ql + tl + 256u) >> dp.dshift) + 1u;  // bins its diagonals can take
+			u32 lg = 0;
+			while (lg < LQ_SD_HMAX_LOG && (64u << lg) < nb) ++lg;
+			c[i] = 0x10000u | lg;                                 // (held, log2 of its units)
+			mine += 1u << lg;
+		} else c[i] = 0;
+	}
+	u32 total = 0;
+	u32 at = sd_block_exscan(mine, ws, &total);                 // (its first barrier: every count is read before any number is written)
+#pragma unroll
+	for (u32 i = 0; i < PER; ++i) {
+		u32 v = 0;
+		if (c[i]) {
+			const u32 lg = c[i] & 0xffu;
+			if (at + (1u << lg) <= dp.units) v = (at + 1u) | lg << 11; else { v = 0xffffu; if (dp.stats) atomicAdd(&dp.stats[4], 1ULL); }
+			at += 1u << lg;
+		}
+		c[i] = v;
+	}
+#pragma unroll
+	for (u32 i = 0; i < PER; i += 2) ends[(t * PER + i) >> 1] = c[i] | c[i + 1] << 16;
+	if (dp.stats && held) atomicAdd(&dp.stats[1], (unsigned long long)held);
+}
+// a record of a pair numbered o (see above) and diagonal bin dbin: count it / decide it
+__device__ __forceinline__ void sd_count_bin(u32 *hist, u32 o, u32 dbin)
+{
+	if (o && o != 0xffffu) { const u32 slot = dbin & ((64u << (o >> 11)) - 1u); sd_bin_inc(&hist[((o & 0x7ffu) - 1u) * 8u + (slot >> 3)], slot & 7u); }
+}
+__device__ __forceinline__ bool sd_decide_bin(const u32 *hist, u32 o, u32 dbin, u32 n_min)
+{
+	return o == 0xffffu || (o && sd_window_alive(hist + ((o & 0x7ffu) - 1u) * 8u, (8u << (o >> 11)) - 1u, dbin & ((64u << (o >> 11)) - 1u), n_min));
+}
+
+#define LQ_SD_BIGCAP 65536u                 // records of a bucket that is decided in passes (a bit each in LDS)
+
 // One block per bucket.  The records are read once and stay in registers (eight per thread):
 //   pairs   hits per (target, relative strand), 16-bit counters
-//   rank    the pairs that hold n_min hits are numbered (a scan over the counters, eight to a thread); a pair of LQ_SD_BIG_PAIR
-//           hits and more is kept as it is, the first LQ_SD_HPAIRS of the others get a histogram of their diagonal bins each
-//   bins    every record of such a pair counts itself in its pair's own histogram: no other pair can add to it
+//   rank    sd_rank_pairs
+//   bins    every record of a pair with a histogram counts itself there: no other pair can add to it
 //   decide  sd_window_alive; the self diagonal and -X (lqmap.c:180-187) for the queries that have any
 //   write   survivors to the front of the bucket, ordered (thread, k); scnt[bucket] = how many
-// A bucket beyond LQ_SD_DCAP records (a query with more hits than slices can divide): pairs only, the records read twice.
-__global__ void __launch_bounds__(LQ_SD_DTHREADS)
+// (a bucket beyond LQ_SD_DCAP records -- a query with more hits than slices can divide --: k_seed_decide_big)
+__global__ void __launch_bounds__(LQ_SD_DTHREADS, 8)          // (eight waves per SIMD: two blocks on a CU)
 k_seed_decide(SeedDecIn in, const SeedBk *bd, SeedDecide dp, SeedBits bits, u32 span_const, u64 *rec, u32 *scnt)
 {
-	__shared__ u32 ends[LQ_SD_NPAIR / 2];                    // 16-bit halves: a pair's hits, then 0 (too few), 0xffff (kept as it is) or its histogram's number + 1
-	__shared__ u32 hist[LQ_SD_HPAIRS * 8];
+	__shared__ u32 ends[LQ_SD_NPAIR / 2];                    // 16-bit halves (sd_rank_pairs)
+	__shared__ u32 hist[LQ_SD_HUNITS * 8];
 	__shared__ u32 ws[17];
 	const u32 t = threadIdx.x;
 	const u32 bk = blockIdx.x;
@@ -385,30 +453,10 @@ k_seed_decide(SeedDecIn in, const SeedBk *bd, SeedDecide dp, SeedBits bits, u32 
 	u64 *R = rec + B.b0;
 	const bool self_q = dp.no_self && in.self_off[q] != in.self_off[q + 1];
 	const bool rare = self_q || in.ava.t_rank != nullptr;
+	const u32 ql = in.qlen[q];
+	if (n > dp.dcap) return;                                  // (k_seed_decide_big's)
 	for (u32 i = t; i < LQ_SD_NPAIR / 2; i += LQ_SD_DTHREADS) ends[i] = 0;
-	if (n > LQ_SD_DCAP) {
-		// ---- beyond what the block holds: pairs only ----
-		__syncthreads();
-		for (u32 i = t; i < n; i += LQ_SD_DTHREADS) {
-			const u32 p = ((u32)(R[i] >> sh_p) - p0) & pmask;
-			if (sd_h16_get(ends, p) < 0x8000u) sd_h16_add(ends, p, 1);           // (at most blockDim more adds can slip past the test: no carry)
-		}
-		__syncthreads();
-		u32 done = 0;                                             // survivors written so far (block-uniform)
-		for (u32 base = 0; base < n; base += LQ_SD_DTHREADS) {
-			const u32 i = base + t;
-			const u64 r = i < n ? R[i] : 0;
-			bool a = i < n && sd_h16_get(ends, ((u32)(r >> sh_p) - p0) & pmask) >= dp.n_min;
-			if (a && rare && sd_rare_drop(r, q, in, bits, span_const, self_q)) a = false;
-			u32 total = 0;
-			const u32 at = sd_block_exscan(a ? 1u : 0u, ws, &total);  // (its barriers stand between this round's reads and writes)
-			if (a) R[done + at] = r;                                  // done + at <= i: never ahead of what is still to be read
-			done += total;
-		}
-		if (t == 0) { scnt[bk] = done; if (dp.stats) { atomicAdd(&dp.stats[0], (unsigned long long)n); atomicAdd(&dp.stats[1], (unsigned long long)done); atomicAdd(&dp.stats[2], (unsigned long long)done); atomicAdd(&dp.stats[3], 1ULL); } }
-		return;
-	}
-	for (u32 i = t; i < LQ_SD_HPAIRS * 8; i += LQ_SD_DTHREADS) hist[i] = 0;
+	for (u32 i = t; i < dp.units * 8; i += LQ_SD_DTHREADS) hist[i] = 0;
 	u64 rc[LQ_SD_DRPT];
 #pragma unroll
 	for (int k = 0; k < LQ_SD_DRPT; ++k) { const u32 i = (u32)k * LQ_SD_DTHREADS + t; rc[k] = i < n ? R[i] : 0; }
@@ -417,49 +465,17 @@ k_seed_decide(SeedDecIn in, const SeedBk *bd, SeedDecide dp, SeedBits bits, u32 
 #pragma unroll
 	for (int k = 0; k < LQ_SD_DRPT; ++k) if ((u32)k * LQ_SD_DTHREADS + t < n) sd_h16_add(ends, ((u32)(rc[k] >> sh_p) - p0) & pmask, 1);
 	__syncthreads();
-	// rank: a thread takes NPAIR / THREADS pairs in a row
-	{
-		constexpr u32 PER = LQ_SD_NPAIR / LQ_SD_DTHREADS;         // 8 (even: whole words)
-		u32 c[PER], mine = 0, held = 0;
-#pragma unroll
-		for (u32 i = 0; i < PER; i += 2) { const u32 w = ends[(t * PER + i) >> 1]; c[i] = w & 0xffffu; c[i + 1] = w >> 16; }
-#pragma unroll
-		for (u32 i = 0; i < PER; ++i) { if (c[i] >= dp.n_min) { held += c[i]; if (c[i] < dp.big_pair) ++mine; } }
-		u32 total = 0;
-		u32 ord = sd_block_exscan(mine, ws, &total);            // (its first barrier: every count is read before any number is written)
-#pragma unroll
-		for (u32 i = 0; i < PER; ++i) {
-			u32 v = 0;
-			if (c[i] >= dp.n_min) {
-				v = 0xffffu;
-				if (c[i] < dp.big_pair) { if (ord < LQ_SD_HPAIRS) v = ord + 1u; else if (dp.stats) atomicAdd(&dp.stats[5], (unsigned long long)c[i]); ++ord; }
-				else if (dp.stats) atomicAdd(&dp.stats[4], (unsigned long long)c[i]);
-			}
-			c[i] = v;
-		}
-#pragma unroll
-		for (u32 i = 0; i < PER; i += 2) ends[(t * PER + i) >> 1] = c[i] | c[i + 1] << 16;
-		if (dp.stats) { if (held) atomicAdd(&dp.stats[1], (unsigned long long)held); if (t == 0) atomicAdd(&dp.stats[0], (unsigned long long)n); }
-	}
+	sd_rank_pairs(ends, ws, in, dp, ql, B.rid0, B.nt * 2u > pmask + 1u, t);
+	if (dp.stats && t == 0) atomicAdd(&dp.stats[0], (unsigned long long)n);
 	__syncthreads();
 	// bins
 #pragma unroll
-	for (int k = 0; k < LQ_SD_DRPT; ++k) {
-		if ((u32)k * LQ_SD_DTHREADS + t < n) {
-			const u32 o = sd_h16_get(ends, ((u32)(rc[k] >> sh_p) - p0) & pmask);
-			if (o - 1u < LQ_SD_HPAIRS) { const u32 slot = (u32)(rc[k] >> sh_d) & 63u; atomicAdd(&hist[(o - 1u) * 8u + (slot >> 3)], 1u << ((slot & 7u) << 2)); }
-		}
-	}
+	for (int k = 0; k < LQ_SD_DRPT; ++k) if ((u32)k * LQ_SD_DTHREADS + t < n) sd_count_bin(hist, sd_h16_get(ends, ((u32)(rc[k] >> sh_p) - p0) & pmask), (u32)(rc[k] >> sh_d));
 	__syncthreads();
 	// decide
 	u32 al = 0;
 #pragma unroll
-	for (int k = 0; k < LQ_SD_DRPT; ++k) {
-		if ((u32)k * LQ_SD_DTHREADS + t < n) {
-			const u32 o = sd_h16_get(ends, ((u32)(rc[k] >> sh_p) - p0) & pmask);
-			if (o == 0xffffu || (o && sd_window_alive(hist + (o - 1u) * 8u, (u32)(rc[k] >> sh_d) & 63u, dp.n_min))) al |= 1u << k;
-		}
-	}
+	for (int k = 0; k < LQ_SD_DRPT; ++k) if ((u32)k * LQ_SD_DTHREADS + t < n && sd_decide_bin(hist, sd_h16_get(ends, ((u32)(rc[k] >> sh_p) - p0) & pmask), (u32)(rc[k] >> sh_d), dp.n_min)) al |= 1u << k;
 	if (rare) for (u32 k = 0; k < LQ_SD_DRPT; ++k)                // (rolled, the records read again: rare)
 		if ((al >> k & 1u) && sd_rare_drop(R[k * LQ_SD_DTHREADS + t], q, in, bits, span_const, self_q)) al &= ~(1u << k);
 	// write
@@ -468,6 +484,81 @@ k_seed_decide(SeedDecIn in, const SeedBk *bd, SeedDecide dp, SeedBits bits, u32 
 #pragma unroll
 	for (int k = 0; k < LQ_SD_DRPT; ++k) if (al >> k & 1u) R[at++] = rc[k];
 	if (t == 0) { scnt[bk] = total; if (dp.stats) atomicAdd(&dp.stats[2], (unsigned long long)total); }
+}
+
+// The buckets beyond LQ_SD_DCAP records (listed by k_seed_bdesc), a few blocks striding over the list: the same phases once per
+// stretch of the bucket's targets, the records read from memory in every phase and the verdicts kept as a bit per record;
+// beyond LQ_SD_BIGCAP records: pairs only.
+__global__ void __launch_bounds__(LQ_SD_DTHREADS)
+k_seed_decide_big(SeedDecIn in, const SeedBk *bd, const u32 *biglist, SeedDecide dp, SeedBits bits, u32 span_const, u64 *rec, u32 *scnt)
+{
+	__shared__ u32 ends[LQ_SD_NPAIR / 2];                    // 16-bit halves (sd_rank_pairs)
+	__shared__ u32 hist[LQ_SD_HUNITS * 8];
+	__shared__ u32 live[LQ_SD_BIGCAP / 32];
+	__shared__ u32 ws[17];
+	const u32 t = threadIdx.x;
+	const u32 n_big = biglist[0];
+	const u32 pmask = (1u << dp.pair_bits) - 1u;
+	const u32 sh_p = bits.jb + bits.db, sh_d = bits.jb + dp.dshift;
+	for (u32 bi = blockIdx.x; bi < n_big; bi += gridDim.x) {
+		const u32 bk = biglist[1u + bi];
+		const SeedBk B = bd[bk];
+		const u32 n = B.n, q = B.q, p0 = B.rid0 << 1;             // (rid << 1 | strand) = record >> sh_p
+		u64 *R = rec + B.b0;
+		const bool self_q = dp.no_self && in.self_off[q] != in.self_off[q + 1];
+		const bool rare = self_q || in.ava.t_rank != nullptr;
+		const u32 ql = in.qlen[q];
+		const bool pairs_only = n > dp.bigcap;
+		u32 width = B.nt, npass = 1;                              // targets per pass
+		if (!pairs_only) {
+			npass = (n + n / 4 + dp.dcap - 1) / dp.dcap;
+			const u32 by_pairs = (2u * B.nt + pmask) / (pmask + 1u);
+			if (npass < by_pairs && dp.pair_bits == LQ_SD_PAIR_BITS) npass = by_pairs;   // (every target a counter of its own, unless a test asked for few)
+			if (npass > B.nt) npass = B.nt ? B.nt : 1;
+			width = (B.nt + npass - 1) / npass;
+			for (u32 i = t; i < (n + 31) / 32; i += LQ_SD_DTHREADS) live[i] = 0;
+		}
+		for (u32 pass = 0; pass < npass; ++pass) {
+			const u32 lo = pass * width * 2u, span = width * 2u;   // the pass's pairs: [lo, lo + span) of the slice's
+			__syncthreads();
+			for (u32 i = t; i < LQ_SD_NPAIR / 2; i += LQ_SD_DTHREADS) ends[i] = 0;
+			if (!pairs_only) for (u32 i = t; i < dp.units * 8; i += LQ_SD_DTHREADS) hist[i] = 0;
+			__syncthreads();
+			for (u32 i = t; i < n; i += LQ_SD_DTHREADS) {
+				const u32 lp = (u32)(R[i] >> sh_p) - p0 - lo;
+				if (lp < span && sd_h16_get(ends, lp & pmask) < 0x8000u) sd_h16_add(ends, lp & pmask, 1);   // (at most blockDim more adds can slip past the test: no carry)
+			}
+			__syncthreads();
+			if (pairs_only) break;
+			sd_rank_pairs(ends, ws, in, dp, ql, B.rid0 + pass * width, span > pmask + 1u, t);
+			__syncthreads();
+			for (u32 i = t; i < n; i += LQ_SD_DTHREADS) {
+				const u64 r = R[i];
+				const u32 lp = (u32)(r >> sh_p) - p0 - lo;
+				if (lp < span) sd_count_bin(hist, sd_h16_get(ends, lp & pmask), (u32)(r >> sh_d));
+			}
+			__syncthreads();
+			for (u32 i = t; i < n; i += LQ_SD_DTHREADS) {
+				const u64 r = R[i];
+				const u32 lp = (u32)(r >> sh_p) - p0 - lo;
+				if (lp < span && sd_decide_bin(hist, sd_h16_get(ends, lp & pmask), (u32)(r >> sh_d), dp.n_min)) atomicOr(&live[i >> 5], 1u << (i & 31u));
+			}
+		}
+		__syncthreads();
+		u32 done = 0;                                             // survivors written so far (block-uniform)
+		for (u32 base = 0; base < n; base += LQ_SD_DTHREADS) {
+			const u32 i = base + t;
+			const u64 r = i < n ? R[i] : 0;
+			bool a = i < n && (pairs_only ? sd_h16_get(ends, ((u32)(r >> sh_p) - p0) & pmask) >= dp.n_min : (live[i >> 5] >> (i & 31u) & 1u) != 0u);
+			if (a && rare && sd_rare_drop(r, q, in, bits, span_const, self_q)) a = false;
+			u32 total = 0;
+			const u32 at = sd_block_exscan(a ? 1u : 0u, ws, &total);  // (its barriers stand between this round's reads and writes)
+			if (a) R[done + at] = r;                                  // done + at <= i: never ahead of what is still to be read
+			done += total;
+		}
+		if (t == 0) { scnt[bk] = done; if (dp.stats) { atomicAdd(&dp.stats[0], (unsigned long long)n); atomicAdd(&dp.stats[2], (unsigned long long)done); atomicAdd(&dp.stats[3], 1ULL); if (pairs_only) atomicAdd(&dp.stats[5], 1ULL); } }
+		__syncthreads();                                          // (the next bucket clears what this one still reads)
+	}
 }
 
 // survivors of every bucket of the chunk, dense: surv[base + soff[bucket] ...] (soff = exclusive scan of scnt); and where
