@@ -1477,7 +1477,12 @@ bool lqcov_handle::seed_filter(Part &pt, hipStream_t s, Prim &pr, SeedWork &W, u
 			S.surv.release();
 			return false;
 		}
-		if ((n_surv + n_c) * 8 > S.surv.cap) grow_keep(S.surv, n_surv * 8, (n_surv + n_c) * 8, s);
+		if (dp.stats) fprintf(stderr, "[lqcov] seed filter: chunk of queries %u..%u: %llu hits, %llu buckets, %llu pieces, %u survivors (%llu before it; room for %zu)\n",
+		                      c.q_lo, c.q_hi, (unsigned long long)c.hits, (unsigned long long)c.nb, (unsigned long long)c.ne, n_c, (unsigned long long)n_surv, S.surv.cap / 8);
+		if ((n_surv + n_c) * 8 > S.surv.cap) {
+			try { grow_keep(S.surv, n_surv * 8, (n_surv + n_c) * 8, s); }
+			catch (const std::runtime_error &) { (void)hipGetLastError(); S.surv.release(); return false; }   // (no room for the survivors: the part is mapped without the filter)
+		}
 		LQ_LAUNCH(k_seed_collect, (u32)c.nb, 64, s, W.bd.as<SeedBk>(), W.rec.as<u64>(), W.scnt.as<u32>(), W.soff.as<u32>(), n_surv, S.surv.as<u64>(), S.aqf_off.as<u64>()); check_launch();
 		add_stage_bytes("k_seed_decide", (u64)n_c * 8);
 		n_surv += n_c;
