@@ -130,7 +130,7 @@ void Knobs::read_env()
 	seed_segl = (u32)std::min<long>(LQ_SD_SEGL, std::max<long>(1, num("LQCOV_SEED_SEGL", LQ_SD_SEGL)));
 	seed_pair_bits = (u32)std::min<long>(LQ_SD_PAIR_BITS, std::max<long>(1, num("LQCOV_SEED_PAIR_BITS", LQ_SD_PAIR_BITS)));
 	seed_units = (u32)std::min<long>(LQ_SD_HUNITS, std::max<long>(1, num("LQCOV_SEED_UNITS", LQ_SD_HUNITS)));
-	seed_surv_max = getenv("LQCOV_SEED_SURV_MAX") ? strtoull(getenv("LQCOV_SEED_SURV_MAX"), 0, 10) : 3ULL << 30;
+	seed_surv_max = getenv("LQCOV_SEED_SURV_MAX") ? std::max<u64>(1, strtoull(getenv("LQCOV_SEED_SURV_MAX"), 0, 10)) : 2ULL << 30;
 	seed_dcap = (u32)std::min<long>(LQ_SD_DCAP, std::max<long>(1, num("LQCOV_SEED_DCAP", LQ_SD_DCAP)));
 	seed_bigcap = (u32)std::min<long>(LQ_SD_BIGCAP, std::max<long>(1, num("LQCOV_SEED_BIGCAP", LQ_SD_BIGCAP)));
 }
@@ -1363,8 +1363,10 @@ void lqcov_handle::open_gate()
 // ---- the seed hits that can be part of a chain (kernels_seed.hpp) ------------------------------------------------------------
 // Host side of the bucketed filter: the geometry (slices of targets per query, segments of minimizers, chunks of queries that
 // fit the record buffer), then per chunk count -> scan -> scatter -> decide -> scan -> collect.  One host sync per chunk (the
-// survivors' total sizes the plan's array).
-bool lqcov_handle::seed_filter(Part &pt, hipStream_t s, Prim &pr, SeedWork &W, u32 n_min, u32 jb, u32 db)
+// survivors' total sizes the plan's array).  The plan holds the survivors of a *group* of chunks -- the queries from q_begin on
+// until LQCOV_SEED_SURV_MAX survivors are reached (ultra-long reads keep a third of tens of billions of hits): map_part maps a
+// group's batches and asks for the next group.  h_aqf / aqf_off of the group's queries count from the group's first survivor.
+bool lqcov_handle::seed_filter(Part &pt, hipStream_t s, Prim &pr, SeedWork &W, u32 n_min, u32 jb, u32 db, u32 q_begin)
 {
 	SeedPlan &S = pt.plan;
 	const u32 n_q = q.n;
@@ -1382,6 +1384,7 @@ bool lqcov_handle::seed_filter(Part &pt, hipStream_t s, Prim &pr, SeedWork &W, u
 	d2h(h_hq.data(), W.hq_off.as<u64>(), n_q + 1, s);
 	// geometry
 	std::vector<SeedQ> qg(n_q);
+	for (u32 i = 0; i < q_begin; ++i) memset(&qg[i], 0, sizeof(SeedQ));
 	std::vector<SeedSeg> segs;
 	std::vector<u32> has(n_q, 0);
 	u64 max_hq = 0;
@@ -1391,7 +1394,7 @@ bool lqcov_handle::seed_filter(Part &pt, hipStream_t s, Prim &pr, SeedWork &W, u
 	struct Chunk { u32 q_lo, q_hi, g_lo, g_hi; u64 ne, nb, hits, h0; bool big; size_t bq_at; };
 	std::vector<Chunk> chunks;
 	std::vector<u32> bq_all;
-	for (u32 i = 0; i < n_q; ) {
+	for (u32 i = q_begin; i < n_q; ) {
 		Chunk c; c.q_lo = i; c.g_lo = (u32)segs.size(); c.ne = 0; c.nb = 0; c.hits = 0; c.h0 = h_hq[i]; c.big = false; c.bq_at = bq_all.size();
 		while (i < n_q && (c.hits == 0 || c.hits + (h_hq[i + 1] - h_hq[i]) <= chunk_cap)) {
 			const u64 hq = h_hq[i + 1] - h_hq[i], nm = S.h_qmoff[i + 1] - S.h_qmoff[i];
@@ -1441,7 +1444,8 @@ bool lqcov_handle::seed_filter(Part &pt, hipStream_t s, Prim &pr, SeedWork &W, u
 	DBuf d_stats;
 	if (getenv("LQCOV_SEED_STATS")) { d_stats.ensure(64); dzero(d_stats.p, 64, s); dp.stats = d_stats.as<unsigned long long>(); }
 	u64 n_surv = 0;
-	S.surv.ensure(std::max<u64>(S.nA_total / 16, 1024) * 8);   // (grows by chunk if the survivors outnumber the guess)
+	S.surv.ensure(std::min<u64>(std::max<u64>(S.nA_total / 16, 1024), K.seed_surv_max) * 8);   // (grows by chunk if the survivors outnumber the guess)
+	u32 q_end = n_q;
 	for (const Chunk &c : chunks) {
 		const u32 ns = c.g_hi - c.g_lo;
 		if (!ns) continue;
@@ -1473,10 +1477,7 @@ bool lqcov_handle::seed_filter(Part &pt, hipStream_t s, Prim &pr, SeedWork &W, u
 		pr.exclusive_scan_u32_u32(W.scnt.as<u32>(), W.soff.as<u32>(), c.nb + 1);
 		u32 n_c = 0;
 		d2h(&n_c, W.soff.as<u32>() + c.nb, 1, s);
-		if (n_surv + n_c > K.seed_surv_max) {                      // more survivors than the plan may hold (reads that repeat each other): the first pass writes every hit, batch by batch
-			S.surv.release();
-			return false;
-		}
+		if (n_surv + n_c > K.seed_surv_max && n_surv) { q_end = c.q_lo; break; }   // the group is full: this chunk opens the next one
 		if (dp.stats) fprintf(stderr, "[lqcov] seed filter: chunk of queries %u..%u: %llu hits, %llu buckets, %llu pieces, %u survivors (%llu before it; room for %zu)\n",
 		                      c.q_lo, c.q_hi, (unsigned long long)c.hits, (unsigned long long)c.nb, (unsigned long long)c.ne, n_c, (unsigned long long)n_surv, S.surv.cap / 8);
 		if ((n_surv + n_c) * 8 > S.surv.cap) {
@@ -1487,15 +1488,15 @@ bool lqcov_handle::seed_filter(Part &pt, hipStream_t s, Prim &pr, SeedWork &W, u
 		add_stage_bytes("k_seed_decide", (u64)n_c * 8);
 		n_surv += n_c;
 	}
-	LQ_LAUNCH(k_seed_fill_off, 1, 64, s, W.has.as<u32>(), n_q, n_surv, S.aqf_off.as<u64>()); check_launch();
+	LQ_LAUNCH(k_seed_fill_off, 1, 64, s, W.has.as<u32>(), q_begin, q_end, n_surv, S.aqf_off.as<u64>()); check_launch();
 	S.h_aqf.assign(n_q + 1, 0);
-	d2h(S.h_aqf.data(), S.aqf_off.as<u64>(), n_q + 1, s);
-	S.n_written = n_surv; S.rec_jb = jb; S.rec_db = db;
+	d2h(S.h_aqf.data() + q_begin, S.aqf_off.as<u64>() + q_begin, q_end - q_begin + 1, s);
+	S.n_written = (q_begin ? S.n_written : 0) + n_surv; S.rec_jb = jb; S.rec_db = db; S.q_begin = q_begin; S.q_end = q_end;
 	if (dp.stats) {
 		unsigned long long st[8];
 		d2h(st, dp.stats, 8, s);
-		fprintf(stderr, "[lqcov] seed filter: %llu hits in %zu chunks, %zu segments; pairs with %u hits hold %llu (%.2f %%), survivors %llu (%.2f %%); %llu buckets beyond the block (%llu of them by pairs only), %llu pairs left without a histogram\n",
-		        st[0], chunks.size(), segs.size(), n_min, st[1], st[0] ? 100.0 * st[1] / st[0] : 0.0, st[2], st[0] ? 100.0 * st[2] / st[0] : 0.0, st[3], st[5], st[4]);
+		fprintf(stderr, "[lqcov] seed filter: %llu hits in %zu chunks, %zu segments; pairs with %u hits hold %llu (%.2f %%), survivors %llu (%.2f %%) of the queries %u..%u; %llu buckets beyond the block (%llu of them by pairs only), %llu pairs left without a histogram\n",
+		        st[0], chunks.size(), segs.size(), n_min, st[1], st[0] ? 100.0 * st[1] / st[0] : 0.0, st[2], st[0] ? 100.0 * st[2] / st[0] : 0.0, q_begin, q_end, st[3], st[5], st[4]);
 	}
 	return true;
 }
@@ -1571,9 +1572,11 @@ void lqcov_handle::plan_part(Part &pt, hipStream_t s, Prim &pr)
 		u64 max_hits = 0;
 		for (u32 i = 0; i < n_q; ++i) max_hits = std::max<u64>(max_hits, S.h_aq[i + 1] - S.h_aq[i]);
 		if (n_min >= 2 && n_min <= 15 && nA_total && jb + db + 1 + rb <= 64 && db <= 31 && jb <= 31 && max_hits < 0x7fff0000ULL) {
-			S.bucketed = seed_filter(pt, s, pr, seed_ws[s == bstream ? 1 : 0], n_min, jb, db);
+			S.bucketed = seed_filter(pt, s, pr, seed_ws[s == bstream ? 1 : 0], n_min, jb, db, 0);
+			S.rec_nmin = n_min;
 		}
 		if (!S.bucketed) {
+			S.q_begin = 0; S.q_end = n_q;
 			S.h_aqf = S.h_aq;
 			LQ_HIP_CHECK(hipMemcpyAsync(S.aqf_off.p, S.aq_off.p, (n_q + 1) * 8, hipMemcpyDeviceToDevice, s));
 			S.n_written = nA_total;
@@ -1602,7 +1605,7 @@ void lqcov_handle::map_part(Part &pt)
 	if (n_q == 0) return;
 	// the part's seed plan: made with its index (build_index), or here if it was not (no queries then) or no longer fits (mid_occ
 	// set afterwards: the parts of a round of PartRunner are built before part 0's mid_occ arrives)
-	if (!pt.plan.valid || pt.plan.mid_occ != mid_occ || pt.plan.n_q != n_q || pt.plan.n_qm != n_qm || pt.plan.h_aqf.empty() != K.ties_klib) plan_part(pt, stream, prim);
+	if (!pt.plan.valid || pt.plan.mid_occ != mid_occ || pt.plan.n_q != n_q || pt.plan.n_qm != n_qm || pt.plan.h_aqf.empty() != K.ties_klib || (pt.plan.bucketed && pt.plan.q_begin != 0)) plan_part(pt, stream, prim);
 	swap_plan(pt.plan);
 	struct PlanGuard { lqcov_handle *h; SeedPlan &S; ~PlanGuard() { h->swap_plan(S); } } plan_guard{this, pt.plan};
 	const std::vector<u64> &h_aq = pt.plan.h_aq, &h_qmoff = pt.plan.h_qmoff, &h_aqf = pt.plan.h_aqf;
@@ -1669,73 +1672,98 @@ void lqcov_handle::map_part(Part &pt)
 			pv_cap = (u32)std::min<u64>(pv.cap / sizeof(Ivl), 0xfffffff0ULL);
 		}
 	}
-	const std::vector<u64> &h_boff = opt ? h_aqf : h_aq;             // the offsets the batches are cut by: of the anchors the first pass writes
-	const u64 nB_total = h_boff[n_q];
-	// batches of queries whose anchors fit one lane's work space; lanes (own streams + work space) take batches as they
-	// finish, so the serial tail of one batch overlaps the wide kernels of another
-	std::vector<std::pair<u32, u32>> batches;
-	{	// as few batches as the work space allows, a multiple of the lane count, of about equal anchor totals: every batch
-		// has a serial critical path that does not shrink with the batch.  (Cutting the last round finer was measured on MI355X at
-		// configs[2] in round 3: 1.75-1.78 s per step against 1.68-1.70 s; round 4: the queries in six chunks with the survivors of
-		// a chunk decided under the mapping of the chunk before: 1160 ms per step against 888.)
-		u64 nb = (nB_total + anchor_budget - 1) / anchor_budget;
-		if (nb < (u64)n_lanes && nB_total >= ((u64)n_lanes << 24)) nb = n_lanes;
-		if (nb > (u64)n_lanes) nb = (nb + n_lanes - 1) / n_lanes * n_lanes;
-		if (nb == 0) nb = 1;
-		u64 left = nb;
-		for (u32 q0 = 0; q0 < n_q; ) {
-			const u64 rem = h_boff[n_q] - h_boff[q0];
-			const u64 lim = std::min(anchor_budget, left > 1 ? (rem + left - 1) / left : rem);
-			u32 q1 = q0 + 1;
-			while (q1 < n_q && h_boff[q1 + 1] - h_boff[q0] <= lim) ++q1;
-			batches.emplace_back(q0, q1);
-			q0 = q1;
-			if (left > 1) --left;
+	// The plan holds the survivors of a group of queries (all of them, unless survivors abound: SeedPlan::q_end); the group's batches
+	// are mapped, then the next group is planned -- with every lane drained, on the handle's own stream.
+	bool regrouped = false;
+	for (u32 g_begin = 0, g_end = n_q; ; ) {
+		if (opt && pt.plan.bucketed) { g_begin = pt.plan.q_begin; g_end = pt.plan.q_end; }
+		const std::vector<u64> &h_boff = opt ? h_aqf : h_aq;             // the offsets the batches are cut by: of the anchors the first pass writes
+		const u64 nB_total = h_boff[g_end] - h_boff[g_begin];
+		// batches of queries whose anchors fit one lane's work space; lanes (own streams + work space) take batches as they
+		// finish, so the serial tail of one batch overlaps the wide kernels of another
+		std::vector<std::pair<u32, u32>> batches;
+		{	// as few batches as the work space allows, a multiple of the lane count, of about equal anchor totals: every batch
+			// has a serial critical path that does not shrink with the batch.  (Cutting the last round finer was measured on MI355X at
+			// configs[2] in round 3: 1.75-1.78 s per step against 1.68-1.70 s; round 4: the queries in six chunks with the survivors of
+			// a chunk decided under the mapping of the chunk before: 1160 ms per step against 888.)
+			u64 nb = (nB_total + anchor_budget - 1) / anchor_budget;
+			if (nb < (u64)n_lanes && nB_total >= ((u64)n_lanes << 24)) nb = n_lanes;
+			if (nb > (u64)n_lanes) nb = (nb + n_lanes - 1) / n_lanes * n_lanes;
+			if (nb == 0) nb = 1;
+			u64 left = nb;
+			for (u32 q0 = g_begin; q0 < g_end; ) {
+				const u64 rem = h_boff[g_end] - h_boff[q0];
+				const u64 lim = std::min(anchor_budget, left > 1 ? (rem + left - 1) / left : rem);
+				u32 q1 = q0 + 1;
+				while (q1 < g_end && h_boff[q1 + 1] - h_boff[q0] <= lim) ++q1;
+				batches.emplace_back(q0, q1);
+				q0 = q1;
+				if (left > 1) --left;
+			}
+		}
+	#ifndef LQ_EMU
+		const bool concurrent = n_lanes > 1 && batches.size() > 1 && profiling != 1 && !dbg;
+	#else
+		const bool concurrent = false;
+	#endif
+		if (!concurrent) {
+			for (size_t i = 0; i < batches.size(); ++i) {
+				lq_alloc_stream = lanes[i % n_lanes]->stream;
+				map_batch(*lanes[i % n_lanes], pt, batches[i].first, batches[i].second, h_aq, h_aqf, h_qmoff, dbg);
+				lq_alloc_stream = nullptr;
+			}
+			for (auto &L : lanes) LQ_HIP_CHECK(hipStreamSynchronize(L->stream));
+		} else {
+			std::atomic<size_t> next(0);
+			{ std::lock_guard<std::mutex> lk(gate_mu); gate_count = 0; }
+			std::vector<std::exception_ptr> errs(n_lanes);
+			std::vector<std::thread> th;
+			for (int li = 0; li < n_lanes; ++li)
+				th.emplace_back([&, li]() {
+					try {
+						LQ_HIP_CHECK(hipSetDevice(device));
+	#ifndef LQ_EMU
+						lq_segv_altstack();
+	#endif
+						MapLane &L = *lanes[li];
+						lq_alloc_stream = L.stream;                              // this thread's buffers grow from the stream-ordered pool (prim.hpp)
+						struct AllocGuard { ~AllocGuard() { lq_alloc_stream = nullptr; } } alloc_guard;
+						{	// staggered start: lane li begins when li batches have got past their sort (or ended), so that
+							// one lane's serial tails run under another lane's wide kernels instead of side by side
+							std::unique_lock<std::mutex> lk(gate_mu);
+							gate_cv.wait(lk, [&] { return gate_count >= li || next.load() >= batches.size(); });
+						}
+						for (;;) {
+							const size_t i = next.fetch_add(1);
+							if (i >= batches.size()) break;
+							map_batch(L, pt, batches[i].first, batches[i].second, h_aq, h_aqf, h_qmoff, dbg);
+						}
+						LQ_HIP_CHECK(hipStreamSynchronize(L.stream));
+					} catch (...) { errs[li] = std::current_exception(); next.store(batches.size()); gate_cv.notify_all(); }
+				});
+			for (auto &t : th) t.join();
+			for (auto &e : errs) if (e) { hipDeviceSynchronize(); std::rethrow_exception(e); }
+		}
+		if (g_end >= n_q) break;
+		{	// the next group (the plan's buffers go back to the plan for the time: seed_filter reads and fills them there)
+			regrouped = true;
+			swap_plan(pt.plan);
+			bool ok = false;
+			try { ok = seed_filter(pt, stream, prim, seed_ws[0], pt.plan.rec_nmin, pt.plan.rec_jb, pt.plan.rec_db, g_end); }
+			catch (...) { swap_plan(pt.plan); throw; }
+			if (!ok) {                                              // (no room: the rest of the part without the filter)
+				pt.plan.bucketed = false;
+				pt.plan.h_aqf = pt.plan.h_aq;
+				LQ_HIP_CHECK(hipMemcpyAsync(pt.plan.aqf_off.p, pt.plan.aq_off.p, (n_q + 1) * 8, hipMemcpyDeviceToDevice, stream));
+				LQ_HIP_CHECK(hipStreamSynchronize(stream));
+				pt.plan.n_written += h_aq[n_q] - h_aq[g_end];
+			}
+			swap_plan(pt.plan);
+			last_n_written = pt.plan.n_written;
+			if (!ok) { g_begin = g_end; g_end = n_q; }
 		}
 	}
-#ifndef LQ_EMU
-	const bool concurrent = n_lanes > 1 && batches.size() > 1 && profiling != 1 && !dbg;
-#else
-	const bool concurrent = false;
-#endif
-	if (!concurrent) {
-		for (size_t i = 0; i < batches.size(); ++i) {
-			lq_alloc_stream = lanes[i % n_lanes]->stream;
-			map_batch(*lanes[i % n_lanes], pt, batches[i].first, batches[i].second, h_aq, h_aqf, h_qmoff, dbg);
-			lq_alloc_stream = nullptr;
-		}
-		for (auto &L : lanes) LQ_HIP_CHECK(hipStreamSynchronize(L->stream));
-	} else {
-		std::atomic<size_t> next(0);
-		{ std::lock_guard<std::mutex> lk(gate_mu); gate_count = 0; }
-		std::vector<std::exception_ptr> errs(n_lanes);
-		std::vector<std::thread> th;
-		for (int li = 0; li < n_lanes; ++li)
-			th.emplace_back([&, li]() {
-				try {
-					LQ_HIP_CHECK(hipSetDevice(device));
-#ifndef LQ_EMU
-					lq_segv_altstack();
-#endif
-					MapLane &L = *lanes[li];
-					lq_alloc_stream = L.stream;                              // this thread's buffers grow from the stream-ordered pool (prim.hpp)
-					struct AllocGuard { ~AllocGuard() { lq_alloc_stream = nullptr; } } alloc_guard;
-					{	// staggered start: lane li begins when li batches have got past their sort (or ended), so that
-						// one lane's serial tails run under another lane's wide kernels instead of side by side
-						std::unique_lock<std::mutex> lk(gate_mu);
-						gate_cv.wait(lk, [&] { return gate_count >= li || next.load() >= batches.size(); });
-					}
-					for (;;) {
-						const size_t i = next.fetch_add(1);
-						if (i >= batches.size()) break;
-						map_batch(L, pt, batches[i].first, batches[i].second, h_aq, h_aqf, h_qmoff, dbg);
-					}
-					LQ_HIP_CHECK(hipStreamSynchronize(L.stream));
-				} catch (...) { errs[li] = std::current_exception(); next.store(batches.size()); gate_cv.notify_all(); }
-			});
-		for (auto &t : th) t.join();
-		for (auto &e : errs) if (e) { hipDeviceSynchronize(); std::rethrow_exception(e); }
-	}
+	if (regrouped) pt.plan.valid = false;                         // (the plan no longer starts at the first query: made again if the part is mapped again)
 	if (dbg) { unsigned long long nd = 0; d2h(&nd, n_dbg.as<unsigned long long>(), 1, stream); n_dbg_host = nd; }
 	sat_replay_part(pt, h_aq, h_qmoff);
 	LQ_HIP_CHECK(hipStreamSynchronize(stream));

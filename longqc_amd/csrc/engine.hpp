@@ -59,7 +59,7 @@ struct Knobs {
 	u32 seed_segl = 256;                  // LQCOV_SEED_SEGL: minimizers per segment (one block of the count / scatter kernels), at most LQ_SD_SEGL (tests shrink it)
 	u32 seed_pair_bits = 13;              // LQCOV_SEED_PAIR_BITS: pair counters of k_seed_decide in use (tests shrink it: pairs alias on small inputs)
 	u32 seed_dcap = 8192, seed_bigcap = 65536;   // LQCOV_SEED_DCAP / LQCOV_SEED_BIGCAP: records of a bucket k_seed_decide takes from registers / in passes over stretches of its targets (tests shrink them)
-	u64 seed_surv_max = 3ULL << 30;       // LQCOV_SEED_SURV_MAX: survivors (8 B each) a part's plan may hold; beyond that the part is mapped without the filter (tests shrink it)
+	u64 seed_surv_max = 2ULL << 30;       // LQCOV_SEED_SURV_MAX: survivors (8 B each) a part's plan may hold; beyond that the part is mapped without the filter (tests shrink it)
 	u32 seed_units = 1024;                // LQCOV_SEED_UNITS: histogram space of a bucket in 64-bin units (tests shrink it: pairs that find no room are kept as they are)
 	void read_env();
 };
@@ -94,7 +94,8 @@ struct SeedPlan {
 	std::vector<u64> h_aq, h_qmoff, h_aqf;
 	u64 nA_total = 0, n_mp_total = 0, n_written = 0;
 	i32 mid_occ = -2; u32 n_q = 0; u64 n_qm = 0;
-	u32 rec_jb = 0, rec_db = 0;           // the records' bit layout (SeedBits)
+	u32 rec_jb = 0, rec_db = 0, rec_nmin = 0;   // the records' bit layout (SeedBits); the filter's n_min
+	u32 q_begin = 0, q_end = 0;           // the queries whose survivors the plan holds right now (a group of chunks; all of them unless survivors abound)
 	bool bucketed = false;                // false: the first pass writes every hit (no filter asked for, or the records do not fit 64 bits): h_aqf == h_aq
 	bool valid = false;
 };
@@ -236,7 +237,7 @@ struct lqcov_handle {
 	void build_part(Part &pt);
 	void open_gate();
 	void plan_part(Part &pt, hipStream_t s, Prim &pr);
-	bool seed_filter(Part &pt, hipStream_t s, Prim &pr, SeedWork &W, u32 n_min, u32 jb, u32 db);
+	bool seed_filter(Part &pt, hipStream_t s, Prim &pr, SeedWork &W, u32 n_min, u32 jb, u32 db, u32 q_begin);
 	void swap_plan(SeedPlan &S);
 	void map_part(Part &pt);
 	void map_batch(MapLane &L, Part &pt, u32 q0, u32 q1, const std::vector<u64> &h_aq, const std::vector<u64> &h_aqf, const std::vector<u64> &h_qmoff, bool dbg);

@@ -574,14 +574,14 @@ __global__ void k_seed_collect(const SeedBk *bd, const u64 *rec, const u32 *scnt
 	u64 *out = surv + base + soff[bk];
 	for (u32 i = threadIdx.x; i < n; i += blockDim.x) out[i] = R[i];
 }
-// queries without a bucket in any chunk (no hits) and the end: aqf_off[q] = the next query's, filled from the back on the host side's order
-__global__ void k_seed_fill_off(const u32 *has, u32 n_q, u64 total, u64 *aqf_off)
+// the queries [q_lo, q_hi) of a group of chunks: those without a bucket (no hits) start where the next one starts; the end
+__global__ void k_seed_fill_off(const u32 *has, u32 q_lo, u32 q_hi, u64 total, u64 *aqf_off)
 {
-	// one thread: n_q is a few thousand
+	// one thread: a few thousand queries
 	if (blockIdx.x || threadIdx.x) return;
 	u64 nxt = total;
-	aqf_off[n_q] = total;
-	for (u32 q = n_q; q-- > 0; ) { if (has[q]) nxt = aqf_off[q]; else aqf_off[q] = nxt; }
+	aqf_off[q_hi] = total;
+	for (u32 q = q_hi; q-- > q_lo; ) { if (has[q]) nxt = aqf_off[q]; else aqf_off[q] = nxt; }
 }
 
 // ---- survivors -> anchors (lqmap.c:175-200) ---------------------------------------------------------------------------------

@@ -581,7 +581,7 @@ OBS_ENVS = [{}, {"LQCOV_SEED_BUCKET": "64", "LQCOV_SEED_SEGL": "7"}, {"LQCOV_SEE
 # the same switches in four runs for the test emulator (a minute each on repeat-rich reads); the GPU suite takes them one by one
 OBS_ENVS_EMU = [{"LQCOV_SEED_BUCKET": "3000", "LQCOV_SEED_DCAP": "300", "LQCOV_SEED_BIGCAP": "1500"}, {"LQCOV_SEED_BUCKET": "64", "LQCOV_SEED_SEGL": "7", "LQCOV_SEED_CHUNK": "1024", "LQCOV_SEED_PAIR_BITS": "3", "LQCOV_SEED_UNITS": "3", "LQCOV_CHAIN_WAVE_MIN": "3"},
                 {"LQCOV_FILTER": "0", "LQCOV_PLAN_AHEAD": "0", "LQCOV_ANCHOR_BUDGET": "20000", "LQCOV_DEBUG_SORT": "1", "LQCOV_PS_SHIFT": "5"}, {"LQCOV_TIES": "klib"},
-                {"LQCOV_SEED_SURV_MAX": "1000", "LQCOV_SEED_CHUNK": "4000"}]      # (the plan gives up after a chunk or two: the part is mapped without the filter)
+                {"LQCOV_SEED_SURV_MAX": "1000", "LQCOV_SEED_CHUNK": "4000"}]      # (the plan holds a chunk or two at a time: the part's queries are mapped in groups)
 
 
 @pytest.mark.parametrize("env", [pytest.param(e, marks=slow_emu) if "LQCOV_TIES" in e else e for e in OBS_ENVS_EMU], ids=lambda e: "+".join("%s=%s" % kv for kv in e.items()) or "default")
