@@ -343,6 +343,11 @@ int lqcov_workspace_trim(lqcov_handle *h)
 		// then the blocks the stream-ordered pool has cached.  Everything regrows on the next part_map.
 		for (auto &L : h->lanes) L->release_buffers();
 		for (DBuf *b : { &h->ix_key, &h->ix_key2, &h->ix_head, &h->ix_uidx, &h->ix_sorted }) b->release();
+		{	// (the seed filter's bucket buffer and tables: as large as a gigabyte-scale chunk of records)
+			std::lock_guard<std::mutex> lk(h->seed_mu);
+			SeedWork &W = h->seed_ws;
+			for (DBuf *b : { &W.hlen, &W.h_off, &W.hq_off, &W.qg, &W.segs, &W.bq, &W.cnt, &W.off, &W.scnt, &W.soff, &W.rec, &W.has, &W.bd, &W.big }) b->release();
+		}
 		LQ_HIP_CHECK(hipDeviceSynchronize());
 #ifndef LQ_EMU
 		hipMemPool_t pool = nullptr;

@@ -1368,6 +1368,7 @@ void lqcov_handle::open_gate()
 // group's batches and asks for the next group.  h_aqf / aqf_off of the group's queries count from the group's first survivor.
 bool lqcov_handle::seed_filter(Part &pt, hipStream_t s, Prim &pr, SeedWork &W, u32 n_min, u32 jb, u32 db, u32 q_begin)
 {
+	std::lock_guard<std::mutex> seed_lock(seed_mu);          // (the build thread plans the next part while this part's groups are made: one at a time)
 	SeedPlan &S = pt.plan;
 	const u32 n_q = q.n;
 	const u64 n_qm = q.n_mini;
@@ -1572,7 +1573,7 @@ void lqcov_handle::plan_part(Part &pt, hipStream_t s, Prim &pr)
 		u64 max_hits = 0;
 		for (u32 i = 0; i < n_q; ++i) max_hits = std::max<u64>(max_hits, S.h_aq[i + 1] - S.h_aq[i]);
 		if (n_min >= 2 && n_min <= 15 && nA_total && jb + db + 1 + rb <= 64 && db <= 31 && jb <= 31 && max_hits < 0x7fff0000ULL) {
-			S.bucketed = seed_filter(pt, s, pr, seed_ws[s == bstream ? 1 : 0], n_min, jb, db, 0);
+			S.bucketed = seed_filter(pt, s, pr, seed_ws, n_min, jb, db, 0);
 			S.rec_nmin = n_min;
 		}
 		if (!S.bucketed) {
@@ -1632,6 +1633,10 @@ void lqcov_handle::map_part(Part &pt)
 		size_t fr = 0, tot = 0;
 		hipMemGetInfo(&fr, &tot);
 		if (fr > hbm_reserve) fr -= hbm_reserve; else fr = 0;     // (lqcov_reserve_hbm: e.g. the part the caller builds while this one is mapped)
+		{	// ... and the survivors of that part's seed plan: as many as this part's, with the head room they grow by
+			const size_t sv = hbm_reserve ? surv.cap + surv.cap / 2 : 0;
+			if (fr > sv) fr -= sv; else fr = 0;
+		}
 		// (0.75 since round 4: a lane's buffers now grow in more steps -- a small first pass, second passes of varying size -- and a
 		// block the stream-ordered pool got back is not always the one the next, larger request can use; at 0.85 the ultra-long
 		// slice of configs[4] ran the device out of memory inside the runtime (HSA_STATUS_ERROR_OUT_OF_RESOURCES))
@@ -1749,7 +1754,7 @@ void lqcov_handle::map_part(Part &pt)
 			regrouped = true;
 			swap_plan(pt.plan);
 			bool ok = false;
-			try { ok = seed_filter(pt, stream, prim, seed_ws[0], pt.plan.rec_nmin, pt.plan.rec_jb, pt.plan.rec_db, g_end); }
+			try { ok = seed_filter(pt, stream, prim, seed_ws, pt.plan.rec_nmin, pt.plan.rec_jb, pt.plan.rec_db, g_end); }
 			catch (...) { swap_plan(pt.plan); throw; }
 			if (!ok) {                                              // (no room: the rest of the part without the filter)
 				pt.plan.bucketed = false;

@@ -185,7 +185,7 @@ struct lqcov_handle {
 	DBuf qklib;                           // queries that go through klib's passes (per part): marked and more than 64 anchors
 	DBuf qzero;                           // zeros: nobody goes through klib's passes (first pass of map_batch)
 	DBuf surv, aqf_off;                   // the part's surviving seed hits as records and their per-query offsets (SeedPlan, swapped in by map_part)
-	SeedWork seed_ws[2];                  // [0]: plans made on `stream` (map_part, when a plan is missing or stale), [1]: on the build stream
+	SeedWork seed_ws; std::mutex seed_mu;  // work space of the seed filter: one plan (or group of a plan) is made at a time, whichever thread asks
 	// Queries one of whose match counters reached cnt_max (uint16 in the reference: 65535; esterr.c:130,136): from the part in
 	// which that happens on, their counters live here, replayed part by part in the reference's chain order (sat_replay.hpp,
 	// sat_replay_part), and go back to the device before the rows are made.  Key: the query in the engine's order.
