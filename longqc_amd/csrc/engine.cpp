@@ -129,7 +129,7 @@ void Knobs::read_env()
 	if (seed_chunk > 0xfffffff0ULL) seed_chunk = 0xfffffff0ULL;
 	seed_segl = (u32)std::min<long>(LQ_SD_SEGL, std::max<long>(1, num("LQCOV_SEED_SEGL", LQ_SD_SEGL)));
 	seed_pair_bits = (u32)std::min<long>(LQ_SD_PAIR_BITS, std::max<long>(1, num("LQCOV_SEED_PAIR_BITS", LQ_SD_PAIR_BITS)));
-	seed_units = (u32)std::min<long>(LQ_SD_HUNITS, std::max<long>(1, num("LQCOV_SEED_UNITS", LQ_SD_HUNITS)));
+	seed_hwords = (u32)std::min<long>(LQ_SD_HWORDS, std::max<long>(2, num("LQCOV_SEED_HWORDS", LQ_SD_HWORDS)));
 	seed_surv_max = getenv("LQCOV_SEED_SURV_MAX") ? std::max<u64>(1, strtoull(getenv("LQCOV_SEED_SURV_MAX"), 0, 10)) : 2ULL << 30;
 	seed_dcap = (u32)std::min<long>(LQ_SD_DCAP, std::max<long>(1, num("LQCOV_SEED_DCAP", LQ_SD_DCAP)));
 	seed_bigcap = (u32)std::min<long>(LQ_SD_BIGCAP, std::max<long>(1, num("LQCOV_SEED_BIGCAP", LQ_SD_BIGCAP)));
@@ -1438,7 +1438,7 @@ bool lqcov_handle::seed_filter(Part &pt, hipStream_t s, Prim &pr, SeedWork &W, u
 	in.segs = W.segs.as<SeedSeg>(); in.qg = W.qg.as<SeedQ>(); in.h_off = W.h_off.as<u64>(); in.hit_start = S.hit_start.as<u64>(); in.pos = pt.pos.as<u64>();
 	in.qx = q.mx.as<u64>(); in.qy = q.my.as<u64>(); in.qmoff = q.moff.as<u64>(); in.qlen = q.d_len.as<u32>();
 	SeedDecide dp; memset(&dp, 0, sizeof(dp));
-	dp.n_min = n_min; dp.pair_bits = K.seed_pair_bits; dp.units = K.seed_units; dp.dcap = K.seed_dcap; dp.bigcap = K.seed_bigcap; dp.no_self = (int)P.no_self;
+	dp.n_min = n_min; dp.pair_bits = K.seed_pair_bits; dp.hwords = K.seed_hwords; dp.dcap = K.seed_dcap; dp.bigcap = K.seed_bigcap; dp.no_self = (int)P.no_self;
 	for (u32 v : pt.rs.h_len) dp.max_tlen = std::max(dp.max_tlen, v);
 	dp.dshift = 1; while (dp.dshift < 30 && (1u << dp.dshift) <= (u32)std::max<i32>(P.bw, 0)) ++dp.dshift;   // bins wider than the band (chain.c:55)
 	const u32 span_const = (u32)(P.hpc ? 0 : P.k);

@@ -60,7 +60,7 @@ struct Knobs {
 	u32 seed_pair_bits = 13;              // LQCOV_SEED_PAIR_BITS: pair counters of k_seed_decide in use (tests shrink it: pairs alias on small inputs)
 	u32 seed_dcap = 8192, seed_bigcap = 65536;   // LQCOV_SEED_DCAP / LQCOV_SEED_BIGCAP: records of a bucket k_seed_decide takes from registers / in passes over stretches of its targets (tests shrink them)
 	u64 seed_surv_max = 2ULL << 30;       // LQCOV_SEED_SURV_MAX: survivors (8 B each) a part's plan may hold; beyond that the part is mapped without the filter (tests shrink it)
-	u32 seed_units = 1024;                // LQCOV_SEED_UNITS: histogram space of a bucket in 64-bin units (tests shrink it: pairs that find no room are kept as they are)
+	u32 seed_hwords = 12288;              // LQCOV_SEED_HWORDS: histogram space of a bucket in words of eight bins (tests shrink it: pairs that find no room are kept as they are)
 	void read_env();
 };
 

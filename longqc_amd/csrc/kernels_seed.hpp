@@ -288,7 +288,7 @@ struct SeedDecide {
 	u32 dshift;                             // log2 of the bin width, D > bw
 	u32 pair_bits;                          // pair counters in use (a power of two, at most 2^LQ_SD_PAIR_BITS; tests shrink it: pairs alias)
 	u32 max_tlen;                           // longest target of the part (the bins of pairs that share a counter)
-	u32 units;                              // histogram space in use, in 64-bin units (at most LQ_SD_HUNITS; tests shrink it)
+	u32 hwords;                             // histogram space in use, in words of eight bins (at most LQ_SD_HWORDS; tests shrink it)
 	u32 dcap, bigcap;                       // records of a bucket decided from registers / in passes (at most LQ_SD_DCAP / LQ_SD_BIGCAP; tests shrink them)
 	int no_self;
 	unsigned long long *stats;              // LQCOV_SEED_STATS: {records, records whose pair holds n_min, survivors, buckets beyond the block, records of pairs left without a histogram} summed; else null
@@ -300,8 +300,8 @@ struct SeedDecide {
 #define LQ_SD_DCAP (LQ_SD_DTHREADS * LQ_SD_DRPT)
 #define LQ_SD_PAIR_BITS 13                  // 8192 pair counters (16 bits each)
 #define LQ_SD_NPAIR (1u << LQ_SD_PAIR_BITS)
-#define LQ_SD_HUNITS 1024u                  // histogram space of a bucket: units of 64 bins x 4 bits (32 B each)
-#define LQ_SD_HMAX_LOG 5u                   // a pair's histogram: 64 << 0 .. 64 << 5 bins
+#define LQ_SD_HWORDS 12288u                 // histogram space of a bucket: words of eight 4-bit bins (48 KiB)
+#define LQ_SD_HBINS_MAX 8192u               // a pair whose diagonals take more bins than that (reads of megabases) is kept as it is
 
 // a bucket (query, slice) of the chunk: records [b0, b0 + n) of the record buffer; rid0: the slice's first target
 struct alignas(32) SeedBk { u32 b0, n, q, rid0, nt, pad0, pad1, pad2; };   // nt: targets in the slice
@@ -333,9 +333,10 @@ __device__ __forceinline__ u32 sd_h16_get(const u32 *tab, u32 p) { return tab[p 
 // (returns the old value; a value never leaves its 16 bits here: sums are bounded by the bucket)
 __device__ __forceinline__ u32 sd_h16_add(u32 *tab, u32 p, u32 v) { const u32 sh = (p & 1u) << 4; return atomicAdd(&tab[p >> 1], v << sh) >> sh & 0xffffu; }
 
-// Hits per diagonal bin of one pair: a ring of 64 << k bins of 4 bits, eight bins to a word, bin = diagonal bin modulo the ring
-// (sized to the pair's diagonals: query + target length; a ring that is too short only adds).  A bin counts to 15 and stays
-// there: every n_min in use is below that, so "15" is as good as the number.
+// Hits per diagonal bin of one pair: 4 bits a bin, eight bins to a word, one bin per D of the pair's diagonals -- a record's
+// diagonal (target position - query coordinate + query length + 256) lies in [0, query + target length + 256), so a pair needs
+// (that >> dshift) + 1 bins, three more on either side for the windows below, and nothing ever wraps.  A bin counts to 15 and
+// stays there: every n_min in use is below that, so "15" is as good as the number.
 __device__ __forceinline__ void sd_bin_inc(u32 *w, u32 field)
 {
 	const u32 sh = field << 2;
@@ -347,14 +348,15 @@ __device__ __forceinline__ void sd_bin_inc(u32 *w, u32 field)
 		old = seen;
 	}
 }
-// Does the gap-free stretch of non-empty bins around bin `slot` hold n_min hits?  The seven bins slot - 3 .. slot + 3 are cut
-// out of two neighbouring words of the ring (wmask: its words - 1); a stretch that reaches the window's edge is taken as long
-// enough (exact for n_min <= 4, the presets'; generous beyond).
-__device__ __forceinline__ bool sd_window_alive(const u32 *h, u32 wmask, u32 slot, u32 n_min)
+__device__ __forceinline__ u32 sd_hist_words(u32 nb) { return (nb + 21u) >> 3; }   // bins 0 .. nb - 1 stand at places 3 .. nb + 2; the two-word window of the last one ends inside
+// Does the gap-free stretch of non-empty bins around bin `dbin` hold n_min hits?  The seven bins dbin - 3 .. dbin + 3 (places
+// dbin .. dbin + 6) are cut out of two neighbouring words; a stretch that reaches the window's edge is taken as long enough
+// (exact for n_min <= 4, the presets'; generous beyond).
+__device__ __forceinline__ bool sd_window_alive(const u32 *h, u32 dbin, u32 n_min)
 {
-	const u32 sb = slot - 3u, w = sb >> 3 & wmask;
-	const u64 two = (u64)h[(w + 1u) & wmask] << 32 | h[w];
-	const u32 g = (u32)(two >> ((sb & 7u) << 2));              // fields 0 .. 6 = bins slot - 3 .. slot + 3
+	const u32 w = dbin >> 3;
+	const u64 two = (u64)h[w + 1u] << 32 | h[w];
+	const u32 g = (u32)(two >> ((dbin & 7u) << 2));            // fields 0 .. 6 = bins dbin - 3 .. dbin + 3
 	const u32 own = g >> 12 & 15u;
 	const u32 r1 = g >> 16 & 15u, r2 = r1 ? g >> 20 & 15u : 0u, r3 = r2 ? g >> 24 & 15u : 0u;
 	const u32 l1 = g >> 8 & 15u, l2 = l1 ? g >> 4 & 15u : 0u, l3 = l2 ? g & 15u : 0u;
@@ -379,10 +381,11 @@ __device__ __forceinline__ bool sd_rare_drop(u64 r, u32 q, const SeedDecIn &in, 
 	return in.ava.t_rank && in.ava.t_rank[rid] < in.ava.q_lo[q];
 }
 
-// The pairs that hold n_min hits get a histogram of their diagonal bins each -- a ring as long as the pair's diagonals can be
-// (query + target length) --, handed out by a scan over the pair counters, eight to a thread; pairs that find no room are kept
-// as they are.  ends[]: counts in, 0 (too few) / 0xffff (kept as it is) / (first unit + 1) | log2(units) << 11 out.
-// rid_base: the target of pair 0; shared: a counter may stand for several targets (more pairs than counters in use).
+// The pairs that hold n_min hits get a histogram of their diagonal bins each, as long as the pair's diagonals can be (query +
+// target length), handed out by a scan over the pair counters, eight to a thread; pairs that find no room (or whose diagonals
+// take more than LQ_SD_HBINS_MAX bins) are kept as they are.  ends[]: counts in, 0 (too few) / 0xffff (kept as it is) / the
+// histogram's first word + 1 out.  rid_base: the target of pair 0; shared: a counter may stand for several targets (more
+// pairs than counters in use).  nbmax: bins of the longest pair of the part (a record's bin is never beyond that).
 __device__ __forceinline__ void sd_rank_pairs(u32 *ends, u32 *ws, const SeedDecIn &in, const SeedDecide &dp, u32 ql, u32 rid_base, bool shared, u32 t)
 {
 	constexpr u32 PER = LQ_SD_NPAIR / LQ_SD_DTHREADS;             // 8 (even: whole words)
@@ -396,21 +399,19 @@ __device__ __forceinline__ void sd_rank_pairs(u32 *ends, u32 *ws, const SeedDecI
 			const u32 rid = rid_base + ((t * PER + i) >> 1);
 			const u32 tl = shared || rid >= in.n_targets ? dp.max_tlen : in.tlen[rid];
 			const u32 nb = ((ql + tl + 256u) >> dp.dshift) + 1u;  // bins its diagonals can take
-			u32 lg = 0;
-			while (lg < LQ_SD_HMAX_LOG && (64u << lg) < nb) ++lg;
-			c[i] = 0x10000u | lg;                                 // (held, log2 of its units)
-			mine += 1u << lg;
+			c[i] = nb <= LQ_SD_HBINS_MAX ? sd_hist_words(nb) : 0xffffu;
+			if (c[i] != 0xffffu) mine += c[i];
 		} else c[i] = 0;
 	}
 	u32 total = 0;
 	u32 at = sd_block_exscan(mine, ws, &total);                 // (its first barrier: every count is read before any number is written)
 #pragma unroll
 	for (u32 i = 0; i < PER; ++i) {
-		u32 v = 0;
-		if (c[i]) {
-			const u32 lg = c[i] & 0xffu;
-			if (at + (1u << lg) <= dp.units) v = (at + 1u) | lg << 11; else { v = 0xffffu; if (dp.stats) atomicAdd(&dp.stats[4], 1ULL); }
-			at += 1u << lg;
+		u32 v = c[i];
+		if (v && v != 0xffffu) {
+			const u32 nw = v;
+			if (at + nw <= dp.hwords) v = at + 1u; else { v = 0xffffu; if (dp.stats) atomicAdd(&dp.stats[4], 1ULL); }
+			at += nw;
 		}
 		c[i] = v;
 	}
@@ -419,13 +420,13 @@ __device__ __forceinline__ void sd_rank_pairs(u32 *ends, u32 *ws, const SeedDecI
 	if (dp.stats && held) atomicAdd(&dp.stats[1], (unsigned long long)held);
 }
 // a record of a pair numbered o (see above) and diagonal bin dbin: count it / decide it
-__device__ __forceinline__ void sd_count_bin(u32 *hist, u32 o, u32 dbin)
+__device__ __forceinline__ void sd_count_bin(u32 *hist, u32 o, u32 dbin, u32 hwords)
 {
-	if (o && o != 0xffffu) { const u32 slot = dbin & ((64u << (o >> 11)) - 1u); sd_bin_inc(&hist[((o & 0x7ffu) - 1u) * 8u + (slot >> 3)], slot & 7u); }
+	if (o && o != 0xffffu) { const u32 place = dbin + 3u, w = o - 1u + (place >> 3); sd_bin_inc(&hist[w < hwords ? w : hwords - 1u], place & 7u); }   // (the clamp never bites: a diagonal is below query + target length + 256)
 }
 __device__ __forceinline__ bool sd_decide_bin(const u32 *hist, u32 o, u32 dbin, u32 n_min)
 {
-	return o == 0xffffu || (o && sd_window_alive(hist + ((o & 0x7ffu) - 1u) * 8u, (8u << (o >> 11)) - 1u, dbin & ((64u << (o >> 11)) - 1u), n_min));
+	return o == 0xffffu || (o && sd_window_alive(hist + (o - 1u), dbin, n_min));
 }
 
 #define LQ_SD_BIGCAP 65536u                 // records of a bucket that is decided in passes (a bit each in LDS)
@@ -441,7 +442,7 @@ __global__ void __launch_bounds__(LQ_SD_DTHREADS, 8)          // (eight waves pe
 k_seed_decide(SeedDecIn in, const SeedBk *bd, SeedDecide dp, SeedBits bits, u32 span_const, u64 *rec, u32 *scnt)
 {
 	__shared__ u32 ends[LQ_SD_NPAIR / 2];                    // 16-bit halves (sd_rank_pairs)
-	__shared__ u32 hist[LQ_SD_HUNITS * 8];
+	__shared__ u32 hist[LQ_SD_HWORDS + 1];
 	__shared__ u32 ws[17];
 	const u32 t = threadIdx.x;
 	const u32 bk = blockIdx.x;
@@ -450,13 +451,14 @@ k_seed_decide(SeedDecIn in, const SeedBk *bd, SeedDecide dp, SeedBits bits, u32 
 	if (n == 0) { if (t == 0) scnt[bk] = 0; return; }
 	const u32 pmask = (1u << dp.pair_bits) - 1u;
 	const u32 sh_p = bits.jb + bits.db, sh_d = bits.jb + dp.dshift, p0 = B.rid0 << 1;   // (rid << 1 | strand) = record >> sh_p
+	const u32 dmask = (1u << (bits.db > dp.dshift ? bits.db - dp.dshift : 0u)) - 1u;     // the diagonal's bin: record >> sh_d & dmask
 	u64 *R = rec + B.b0;
 	const bool self_q = dp.no_self && in.self_off[q] != in.self_off[q + 1];
 	const bool rare = self_q || in.ava.t_rank != nullptr;
 	const u32 ql = in.qlen[q];
 	if (n > dp.dcap) return;                                  // (k_seed_decide_big's)
 	for (u32 i = t; i < LQ_SD_NPAIR / 2; i += LQ_SD_DTHREADS) ends[i] = 0;
-	for (u32 i = t; i < dp.units * 8; i += LQ_SD_DTHREADS) hist[i] = 0;
+	for (u32 i = t; i < dp.hwords + 1u; i += LQ_SD_DTHREADS) hist[i] = 0;
 	u64 rc[LQ_SD_DRPT];
 #pragma unroll
 	for (int k = 0; k < LQ_SD_DRPT; ++k) { const u32 i = (u32)k * LQ_SD_DTHREADS + t; rc[k] = i < n ? R[i] : 0; }
@@ -470,12 +472,12 @@ k_seed_decide(SeedDecIn in, const SeedBk *bd, SeedDecide dp, SeedBits bits, u32 
 	__syncthreads();
 	// bins
 #pragma unroll
-	for (int k = 0; k < LQ_SD_DRPT; ++k) if ((u32)k * LQ_SD_DTHREADS + t < n) sd_count_bin(hist, sd_h16_get(ends, ((u32)(rc[k] >> sh_p) - p0) & pmask), (u32)(rc[k] >> sh_d));
+	for (int k = 0; k < LQ_SD_DRPT; ++k) if ((u32)k * LQ_SD_DTHREADS + t < n) sd_count_bin(hist, sd_h16_get(ends, ((u32)(rc[k] >> sh_p) - p0) & pmask), (u32)(rc[k] >> sh_d) & dmask, dp.hwords);
 	__syncthreads();
 	// decide
 	u32 al = 0;
 #pragma unroll
-	for (int k = 0; k < LQ_SD_DRPT; ++k) if ((u32)k * LQ_SD_DTHREADS + t < n && sd_decide_bin(hist, sd_h16_get(ends, ((u32)(rc[k] >> sh_p) - p0) & pmask), (u32)(rc[k] >> sh_d), dp.n_min)) al |= 1u << k;
+	for (int k = 0; k < LQ_SD_DRPT; ++k) if ((u32)k * LQ_SD_DTHREADS + t < n && sd_decide_bin(hist, sd_h16_get(ends, ((u32)(rc[k] >> sh_p) - p0) & pmask), (u32)(rc[k] >> sh_d) & dmask, dp.n_min)) al |= 1u << k;
 	if (rare) for (u32 k = 0; k < LQ_SD_DRPT; ++k)                // (rolled, the records read again: rare)
 		if ((al >> k & 1u) && sd_rare_drop(R[k * LQ_SD_DTHREADS + t], q, in, bits, span_const, self_q)) al &= ~(1u << k);
 	// write
@@ -493,13 +495,14 @@ __global__ void __launch_bounds__(LQ_SD_DTHREADS)
 k_seed_decide_big(SeedDecIn in, const SeedBk *bd, const u32 *biglist, SeedDecide dp, SeedBits bits, u32 span_const, u64 *rec, u32 *scnt)
 {
 	__shared__ u32 ends[LQ_SD_NPAIR / 2];                    // 16-bit halves (sd_rank_pairs)
-	__shared__ u32 hist[LQ_SD_HUNITS * 8];
+	__shared__ u32 hist[LQ_SD_HWORDS + 1];
 	__shared__ u32 live[LQ_SD_BIGCAP / 32];
 	__shared__ u32 ws[17];
 	const u32 t = threadIdx.x;
 	const u32 n_big = biglist[0];
 	const u32 pmask = (1u << dp.pair_bits) - 1u;
 	const u32 sh_p = bits.jb + bits.db, sh_d = bits.jb + dp.dshift;
+	const u32 dmask = (1u << (bits.db > dp.dshift ? bits.db - dp.dshift : 0u)) - 1u;     // the diagonal's bin: record >> sh_d & dmask
 	for (u32 bi = blockIdx.x; bi < n_big; bi += gridDim.x) {
 		const u32 bk = biglist[1u + bi];
 		const SeedBk B = bd[bk];
@@ -522,7 +525,7 @@ k_seed_decide_big(SeedDecIn in, const SeedBk *bd, const u32 *biglist, SeedDecide
 			const u32 lo = pass * width * 2u, span = width * 2u;   // the pass's pairs: [lo, lo + span) of the slice's
 			__syncthreads();
 			for (u32 i = t; i < LQ_SD_NPAIR / 2; i += LQ_SD_DTHREADS) ends[i] = 0;
-			if (!pairs_only) for (u32 i = t; i < dp.units * 8; i += LQ_SD_DTHREADS) hist[i] = 0;
+			if (!pairs_only) for (u32 i = t; i < dp.hwords + 1u; i += LQ_SD_DTHREADS) hist[i] = 0;
 			__syncthreads();
 			for (u32 i = t; i < n; i += LQ_SD_DTHREADS) {
 				const u32 lp = (u32)(R[i] >> sh_p) - p0 - lo;
@@ -535,13 +538,13 @@ k_seed_decide_big(SeedDecIn in, const SeedBk *bd, const u32 *biglist, SeedDecide
 			for (u32 i = t; i < n; i += LQ_SD_DTHREADS) {
 				const u64 r = R[i];
 				const u32 lp = (u32)(r >> sh_p) - p0 - lo;
-				if (lp < span) sd_count_bin(hist, sd_h16_get(ends, lp & pmask), (u32)(r >> sh_d));
+				if (lp < span) sd_count_bin(hist, sd_h16_get(ends, lp & pmask), (u32)(r >> sh_d) & dmask, dp.hwords);
 			}
 			__syncthreads();
 			for (u32 i = t; i < n; i += LQ_SD_DTHREADS) {
 				const u64 r = R[i];
 				const u32 lp = (u32)(r >> sh_p) - p0 - lo;
-				if (lp < span && sd_decide_bin(hist, sd_h16_get(ends, lp & pmask), (u32)(r >> sh_d), dp.n_min)) atomicOr(&live[i >> 5], 1u << (i & 31u));
+				if (lp < span && sd_decide_bin(hist, sd_h16_get(ends, lp & pmask), (u32)(r >> sh_d) & dmask, dp.n_min)) atomicOr(&live[i >> 5], 1u << (i & 31u));
 			}
 		}
 		__syncthreads();

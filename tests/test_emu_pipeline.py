@@ -573,13 +573,13 @@ def check_observable_ties_scheme(lib, tmp_path, monkeypatch, seed, env, small=Fa
 
 # shapes of the seed filter (kernels_seed.hpp): tiny buckets (dozens of slices per query), one-minimizer-wide segments of 7
 # (many pieces per bucket), a record buffer of 1024 (many chunks), counters so few that pairs and bins alias; no filter at all
-OBS_ENVS = [{}, {"LQCOV_SEED_BUCKET": "64", "LQCOV_SEED_SEGL": "7"}, {"LQCOV_SEED_BUCKET": "300", "LQCOV_SEED_CHUNK": "1024", "LQCOV_SEED_PAIR_BITS": "3", "LQCOV_SEED_UNITS": "3"}, {"LQCOV_FILTER": "0"},
+OBS_ENVS = [{}, {"LQCOV_SEED_BUCKET": "64", "LQCOV_SEED_SEGL": "7"}, {"LQCOV_SEED_BUCKET": "300", "LQCOV_SEED_CHUNK": "1024", "LQCOV_SEED_PAIR_BITS": "3", "LQCOV_SEED_HWORDS": "40"}, {"LQCOV_FILTER": "0"},
             {"LQCOV_ANCHOR_BUDGET": "20000", "LQCOV_LANES": "2"}, {"LQCOV_TIES": "klib"}, {"LQCOV_DEBUG_SORT": "1", "LQCOV_PS_SHIFT": "5"},
             {"LQCOV_CHAIN_WAVE_MIN": "3"},             # (every run through the wave kernel: its own copy of the tie rule)
             {"LQCOV_PLAN_AHEAD": "0", "LQCOV_SEED_BUCKET": "3000", "LQCOV_SEED_DCAP": "500", "LQCOV_SEED_SEGL": "100"},   # (the seed plan made when the part is mapped, not with its index; buckets decided in passes over stretches of their targets)
             {"LQCOV_SEED_BUCKET": "3000", "LQCOV_SEED_DCAP": "300", "LQCOV_SEED_BIGCAP": "1500", "LQCOV_SEED_PAIR_BITS": "4"}]   # (... and buckets beyond that: by pairs only; few pair counters: more passes)
 # the same switches in four runs for the test emulator (a minute each on repeat-rich reads); the GPU suite takes them one by one
-OBS_ENVS_EMU = [{"LQCOV_SEED_BUCKET": "3000", "LQCOV_SEED_DCAP": "300", "LQCOV_SEED_BIGCAP": "1500"}, {"LQCOV_SEED_BUCKET": "64", "LQCOV_SEED_SEGL": "7", "LQCOV_SEED_CHUNK": "1024", "LQCOV_SEED_PAIR_BITS": "3", "LQCOV_SEED_UNITS": "3", "LQCOV_CHAIN_WAVE_MIN": "3"},
+OBS_ENVS_EMU = [{"LQCOV_SEED_BUCKET": "3000", "LQCOV_SEED_DCAP": "300", "LQCOV_SEED_BIGCAP": "1500"}, {"LQCOV_SEED_BUCKET": "64", "LQCOV_SEED_SEGL": "7", "LQCOV_SEED_CHUNK": "1024", "LQCOV_SEED_PAIR_BITS": "3", "LQCOV_SEED_HWORDS": "40", "LQCOV_CHAIN_WAVE_MIN": "3"},
                 {"LQCOV_FILTER": "0", "LQCOV_PLAN_AHEAD": "0", "LQCOV_ANCHOR_BUDGET": "20000", "LQCOV_DEBUG_SORT": "1", "LQCOV_PS_SHIFT": "5"}, {"LQCOV_TIES": "klib"},
                 {"LQCOV_SEED_SURV_MAX": "1000", "LQCOV_SEED_CHUNK": "4000"}]      # (the plan holds a chunk or two at a time: the part's queries are mapped in groups)
 
