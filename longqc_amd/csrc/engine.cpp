@@ -118,6 +118,7 @@ void Knobs::read_env()
 	tile_grid = (u32)std::max<long>(64, num("LQCOV_TILE_GRID", 4096));
 	ps_passes = (u32)std::min<long>(16, std::max<long>(0, num("LQCOV_PS_PASSES", 2))) & ~1u;
 	ties_klib = is("LQCOV_TIES", "klib") || all_klib;
+	walk_cu_mask = getenv("LQCOV_WALK_CU_MASK") ? (u32)strtoul(getenv("LQCOV_WALK_CU_MASK"), 0, 16) : 0x11111111u; if (!walk_cu_mask) walk_cu_mask = 0xffffffffu;
 	filter = num("LQCOV_FILTER", 1) != 0;
 	parse_threads = (int)std::min<long>(256, std::max<long>(0, num("LQCOV_PARSE_THREADS", 0)));
 	parse_piece = (u64)std::max<long>(64, num("LQCOV_PARSE_PIECE", 32L << 20));
@@ -1655,7 +1656,7 @@ void lqcov_handle::map_part(Part &pt)
 			// (Round 3: a different quarter of the CUs per lane, or 128 / 192 CUs instead of 64: no change, 1.69-1.71 s per step whatever
 			// the mask; no mask at all: 2.03 s.)
 			uint32_t mask[8];
-			for (int i = 0; i < 8; ++i) mask[i] = 0x11111111u;
+			for (int i = 0; i < 8; ++i) mask[i] = K.walk_cu_mask;
 			if (hipExtStreamCreateWithCUMask(&lanes.back()->streamW, 8, mask) != hipSuccess) { (void)hipGetLastError(); LQ_HIP_CHECK(hipStreamCreate(&lanes.back()->streamW)); }
 			if (hipExtStreamCreateWithCUMask(&lanes.back()->streamW2, 8, mask) != hipSuccess) { (void)hipGetLastError(); LQ_HIP_CHECK(hipStreamCreate(&lanes.back()->streamW2)); }
 		}
@@ -1692,7 +1693,7 @@ void lqcov_handle::map_part(Part &pt)
 			// configs[2] in round 3: 1.75-1.78 s per step against 1.68-1.70 s; round 4: the queries in six chunks with the survivors of
 			// a chunk decided under the mapping of the chunk before: 1160 ms per step against 888.)
 			u64 nb = (nB_total + anchor_budget - 1) / anchor_budget;
-			if (nb < (u64)n_lanes && nB_total >= ((u64)n_lanes << 24)) nb = n_lanes;
+			if (nb < (u64)n_lanes && h_aq[g_end] - h_aq[g_begin] >= ((u64)n_lanes << 24)) nb = n_lanes;   // (by the seed hits, not by what the filter left of them: the second pass works on the hits)
 			if (nb > (u64)n_lanes) nb = (nb + n_lanes - 1) / n_lanes * n_lanes;
 			if (nb == 0) nb = 1;
 			u64 left = nb;

@@ -35,6 +35,7 @@ struct Knobs {
 	u32 sort_tile = 0;                    // LQCOV_SORT_TILE: anchors per tile of the sort's streaming kernels (0 = LQ_SORT_TILE)
 	u32 walk_shift = 0;                   // LQCOV_WALK_SHIFT: shrinks the walker size classes and the checkpoint spacing (tests)
 	u32 walk_grid = 1u << 18;             // LQCOV_WALK_GRID: cap on resident walker waves
+	u32 walk_cu_mask = 0x11111111u;       // LQCOV_WALK_CU_MASK (hex, repeated over the 256 CUs): the CUs the walkers' streams may use
 	int chain_wave_min = 0, chain_cap = 128;   // LQCOV_CHAIN_WAVE_MIN (0 = LQ_CHAIN_WAVE_MIN), LQCOV_CHAIN_CAP
 	bool sketch_wgen = false;             // LQCOV_SKETCH_WGEN=1: k_sketch_dp_mask with the window read at run time although it is 5 or 10 (tests, A/B)
 	bool ps_key64 = false;                // LQCOV_PS_KEY64=1: the finishing kernels' 64-bit key shape although 32 bits would do (tests: parts with more than 2^40 (target, position) pairs are out of their reach)

@@ -30,13 +30,13 @@ def main():
     for r in step:
         if r[1] == build and r[3] - r[2] > 4_000_000:
             print("  %6.0f ms  +%5.0f  %s" % ((r[2] - t0) / 1e6, (r[3] - r[2]) / 1e6, r[0][:44]))
-    mains = sorted({r[1] for r in step if r[0].startswith("k_seed_emit_f")}, key=int)
+    mains = sorted({r[1] for r in step if r[0].startswith("k_seed_emit_s")}, key=int)
     for m in mains:
         group = [str(int(m) + d) for d in range(4)]
         ev = [r for r in step if r[1] in group]
         batches = []
         for r in ev:
-            if r[0].startswith("k_seed_emit_f"):
+            if r[0].startswith("k_seed_emit_s"):
                 batches.append([])
             if batches:
                 batches[-1].append(r)
