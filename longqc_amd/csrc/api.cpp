@@ -14,6 +14,9 @@
 #include <vector>
 
 static thread_local std::string g_create_error;
+// live handles per device: only the last one to go hands the pool's cache back (lqcov_destroy)
+static std::mutex g_live_mu;
+static std::map<int, int> g_live;
 
 // (one thread may build a part while another maps: both may fail, the message is written under the handle's lock)
 static void set_err(lqcov_handle *h, const char *what) { std::lock_guard<std::mutex> g(h->stage_mu); h->err = what; }
@@ -215,7 +218,7 @@ lqcov_handle *lqcov_create(const lqcov_params *p, int device)
 		const char *hq = getenv("LQCOV_HW_QUEUES");
 		if (!hq || atoi(hq) > 0) setenv("GPU_MAX_HW_QUEUES", hq && atoi(hq) > 0 ? hq : "8", 0);
 	}
-	try { return new lqcov_handle(*p, device); }
+	try { lqcov_handle *h = new lqcov_handle(*p, device); { std::lock_guard<std::mutex> lk(g_live_mu); ++g_live[device]; } return h; }
 	catch (const std::exception &e) { g_create_error = e.what(); fprintf(stderr, "lqcov_create: %s\n", e.what()); return nullptr; }
 }
 void lqcov_destroy(lqcov_handle *h)
@@ -226,6 +229,9 @@ void lqcov_destroy(lqcov_handle *h)
 #endif
 	delete h;
 #ifndef LQ_EMU
+	bool last = false;
+	{ std::lock_guard<std::mutex> lk(g_live_mu); auto it = g_live.find(dev); if (it != g_live.end() && it->second > 0 && --it->second == 0) last = true; }
+	if (!last) return;                                          // (another handle lives on this device: its streams are not to be stalled, nor its cached blocks dropped)
 	// the lanes' work space came from HIP's stream-ordered pool, whose release threshold the handle raised (blocks given back
 	// stay cached): with the handle gone the cache goes back to the device -- the next handle (or another user of the GPU)
 	// would otherwise find the memory taken and pay for the trim in the middle of its first part (5 s for 170 GB, measured)

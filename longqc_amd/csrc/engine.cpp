@@ -122,6 +122,7 @@ void Knobs::read_env()
 	filter = num("LQCOV_FILTER", 1) != 0;
 	parse_threads = (int)std::min<long>(256, std::max<long>(0, num("LQCOV_PARSE_THREADS", 0)));
 	parse_piece = (u64)std::max<long>(64, num("LQCOV_PARSE_PIECE", 32L << 20));
+	parse_side = getenv("LQCOV_PARSE_SIDE") ? strtoull(getenv("LQCOV_PARSE_SIDE"), 0, 10) : 2ULL << 30;
 	pipeline = num("LQCOV_PIPELINE", 1) != 0;
 	plan_ahead = num("LQCOV_PLAN_AHEAD", 1) != 0;
 	cnt_bits = (int)std::min<long>(16, std::max<long>(2, num("LQCOV_TEST_CNT_BITS", 16)));
@@ -2163,10 +2164,16 @@ int lqcov_handle::run_files(const char *target, const char *query, FILE *out, FI
 		std::vector<std::pair<size_t, size_t>> ranges;                 // records of every part (memory path)
 		size_t next_range = 0;
 		std::unique_ptr<FastxReader> ft;
-		const bool mem = K.parse_threads != 1 && mf.open(target);
+		bool mem = K.parse_threads != 1 && mf.open(target);
+		const double t_parse0 = lq_now_s();
 		if (mem) {
-			const double t0 = lq_now_s();
-			lq_parse_all(mf, K.parse_threads, K.parse_piece, recs);
+			// (records of several lines are copied out of the mapping: a wrapped FASTA of many gigabases would be held twice, so
+			// past LQCOV_PARSE_SIDE bytes of copies the file is streamed like a gzip instead, one part in memory at a time)
+			lq_parse_all(mf, K.parse_threads, K.parse_piece, recs, K.parse_side);
+			if (recs.too_wrapped) { mem = false; mf.close(); if (log) fprintf(log, "[lqcov] target records span several lines: streaming reader\n"); }
+		}
+		if (mem) {
+			const double t0 = t_parse0;
 			flat.reserve(recs.n_recs);
 			for (MemPiece &pc : recs.pieces) for (MemRec &r : pc.recs)
 				flat.push_back(FlatRec{mf.data() + r.name_off, r.name_len, (r.own ? pc.side.data() : mf.data()) + r.seq_off, r.seq_len});

@@ -53,6 +53,7 @@ struct Knobs {
 	bool plan_ahead = true;               // LQCOV_PLAN_AHEAD=0: a part's seed plan (probe, survivors) is made when the part is mapped, not right after its index
 	int parse_threads = 0;                // LQCOV_PARSE_THREADS: threads that parse and pack a plain target file (0: one per core, at most 64; 1: the streaming reader as for gzip)
 	u64 parse_piece = 32u << 20;          // LQCOV_PARSE_PIECE: bytes of the file a thread parses at a time (tests shrink it: many guessed record starts)
+	u64 parse_side = 2ULL << 30;          // LQCOV_PARSE_SIDE: bytes of multi-line records the mapped reader may copy before run_files falls back to the streaming reader
 	bool pipeline = true;                 // LQCOV_PIPELINE=0: run_files builds a part only after the one before is mapped
 	int cnt_bits = 16;                    // LQCOV_TEST_CNT_BITS (2..16): width of the match counters.  A test hook: narrower counters bring the saturated regime (sat_replay.hpp) within reach of small inputs; the oracle has the same one (LQO_CNT_BITS)
 	u32 seed_bucket = 7600;               // LQCOV_SEED_BUCKET: hits per (query, slice of targets) bucket aimed at; k_seed_decide holds a bucket of up to 8192 records in registers (tests shrink it: many slices on small inputs)

@@ -203,12 +203,13 @@ struct MemRecords {
 	std::vector<MemPiece> pieces;          // in file order; a record's bytes: own ? pieces[k].side : the mapping
 	u64 n_recs = 0;
 	u32 reparsed = 0;                      // pieces whose guessed start did not hold (parsed again in order)
+	bool too_wrapped = false;              // records of several lines are copied (MemPiece::side): past side_limit bytes of such copies the parse stops and the caller streams the file instead
 };
 
-inline void lq_parse_all(const MemFastx &f, int n_threads, u64 piece_bytes, MemRecords &out)
+inline void lq_parse_all(const MemFastx &f, int n_threads, u64 piece_bytes, MemRecords &out, u64 side_limit = ~0ULL)
 {
 	const u64 n = f.size();
-	out.pieces.clear(); out.n_recs = 0; out.reparsed = 0;
+	out.pieces.clear(); out.n_recs = 0; out.reparsed = 0; out.too_wrapped = false;
 	if (n == 0) return;
 	if (piece_bytes < 64) piece_bytes = 64;
 	if (n_threads <= 0) n_threads = (int)std::min<unsigned>(64, std::max(1u, std::thread::hardware_concurrency()));
@@ -223,21 +224,25 @@ inline void lq_parse_all(const MemFastx &f, int n_threads, u64 piece_bytes, MemR
 	const size_t np = starts.size();
 	out.pieces.resize(np);
 	std::atomic<size_t> next(0);
+	std::atomic<u64> side_bytes(0);
+	std::atomic<bool> stop(false);
 	std::vector<std::exception_ptr> errs((size_t)n_threads);
 	auto work = [&](int ti) {
 		try {
 			for (;;) {
 				const size_t k = next.fetch_add(1);
-				if (k >= np) break;
+				if (k >= np || stop.load()) break;
 				MemPiece &pc = out.pieces[k];
 				pc.begin = starts[k]; pc.end = k + 1 < np ? starts[k + 1] : n;
 				f.parse(pc.begin, 0, pc.end, pc);
+				if (side_bytes.fetch_add(pc.side.size()) + pc.side.size() > side_limit) stop.store(true);
 			}
 		} catch (...) { errs[(size_t)ti] = std::current_exception(); }
 	};
 	if (n_threads == 1 || np == 1) work(0);
 	else { std::vector<std::thread> th; for (int t = 0; t < n_threads; ++t) th.emplace_back(work, t); for (auto &t : th) t.join(); }
 	for (auto &e : errs) if (e) std::rethrow_exception(e);
+	if (stop.load()) { out.pieces.clear(); out.too_wrapped = true; return; }
 	// stitch: piece k + 1 holds iff piece k stopped exactly in front of its guess with nothing pending
 	for (size_t k = 0; k < np; ++k) {
 		MemPiece &pc = out.pieces[k];

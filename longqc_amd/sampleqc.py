@@ -73,64 +73,54 @@ def spikein_argv(filter_ref: str, sample_path: str, ncpu: int = 4) -> List[str]:
 
 
 def subsample_from_chunk(chunk, cum_n_seq, s_reads, param, s_seed=7, elist=None):
-    """lq_utils.py:371-411.  param >= 1: reservoir of `param` reads (slots filled in order, then read n replaces
-    slot int(h*n) if that is < param); param < 1: keep each read with probability param.  The uniform draws are
-    re-seeded per chunk (np.random.seed(7)) and indexed by the position in the chunk *after* skipping elist
-    entries -- reproduced as is."""
-    frac = 0.
-    num = 0
-    n_seqs = cum_n_seq
-    k = 0
-    if param >= 1.:
-        num = int(param)
-        if not s_reads:
-            s_reads = [0] * num
-    else:
-        frac = param
-        a = []
-    rs = np.random.RandomState(s_seed)
-    h = rs.uniform(size=len(chunk) + 1)
-    for read in chunk:
-        name = read[0]
-        if elist and name in elist:
-            continue
-        n_seqs += 1
-        if num:
-            d = n_seqs - 1 if n_seqs - 1 < num else int(h[k] * n_seqs)
-            if d < num:
-                s_reads[d] = [read[0], read[1], read[2]]
-        elif h[k] < frac:
-            a.append([read[0], read[1], read[2]])
-        k += 1
-    return s_reads if num else s_reads + a
+    """The draw of lq_utils.py:371-411 over one chunk of reads, all reads of the chunk at once.
+
+    The reference's generator is re-seeded per chunk (seed 7) and draws len(chunk) + 1 uniforms; the k-th read that is not on
+    `elist` uses the k-th of them.  param >= 1 keeps a reservoir of int(param) reads: the n-th read seen so far (over all
+    chunks, n counted from 1) goes to slot n - 1 while the reservoir fills and to slot floor(u * n) afterwards, if that slot
+    exists; of several reads aimed at one slot the last one stays.  param < 1 keeps a read when its uniform is below param."""
+    take = [r for r in chunk if not (elist and r[0] in elist)]
+    u = np.random.RandomState(s_seed).uniform(size=len(chunk) + 1)[:len(take)]
+    if param < 1.:
+        kept = np.flatnonzero(u < param)
+        return s_reads + [[take[i][0], take[i][1], take[i][2]] for i in kept]
+    size = int(param)
+    if not s_reads:
+        s_reads = [0] * size
+    nth = cum_n_seq + 1 + np.arange(len(take), dtype=np.int64)
+    slot = np.where(nth - 1 < size, nth - 1, (u * nth).astype(np.int64))
+    hit = np.flatnonzero(slot < size)
+    # the last read aimed at a slot wins: walk the hits backwards and keep the first sight of every slot
+    _, first_from_back = np.unique(slot[hit][::-1], return_index=True)
+    for i in hit[::-1][first_from_back]:
+        s_reads[int(slot[i])] = [take[i][0], take[i][1], take[i][2]]
+    return s_reads
 
 
 def replace_masked(s_reads, exclude_seqs: Sequence[str], chunks: Iterable, logger=None):
-    """longQC.py:369-406: drop the empty slots, then replace subsample reads that are on the highly-masked list
-    by a fresh reservoir draw over the input that skips everything already picked or excluded; if the input
-    cannot supply enough replacements the masked ones are simply removed.  `chunks` yields (reads, n_seqs, n_bases)."""
-    s_reads = [i for i in s_reads if i != 0]
-    ng_set = set(exclude_seqs)
-    ng_idx = [i for i, r in enumerate(s_reads) if r[0] in ng_set]
-    if not ng_idx:
-        return s_reads
-    ng_ovlp = len(ng_idx)
-    temp = [0] * ng_ovlp
-    j = 0
-    for r in s_reads:
-        ng_set.add(r[0])
-    for (reads, n_seqs, n_bases) in chunks:
-        subsample_from_chunk(reads, j, temp, ng_ovlp, elist=ng_set)
-        j += n_seqs
-        if len([i for i in temp if i]) >= ng_ovlp:
+    """longQC.py:369-406.  Reads of the subsample that sit on the highly-masked list are swapped for a second reservoir draw
+    over the input -- one slot per masked read, skipping every read that was already picked or is masked itself.  The draw stops
+    at the first chunk after which every slot is taken; if the input runs out first, the masked reads are dropped instead.
+    `chunks` yields (reads, n_seqs, n_bases)."""
+    picked = [r for r in s_reads if r != 0]
+    masked = set(exclude_seqs)
+    where = [i for i, r in enumerate(picked) if r[0] in masked]
+    if not where:
+        return picked
+    avoid = masked | {r[0] for r in picked}
+    spare = [0] * len(where)
+    seen = 0
+    for reads, n_seqs, _n_bases in chunks:
+        subsample_from_chunk(reads, seen, spare, len(where), elist=avoid)
+        seen += n_seqs
+        if all(spare):
             break
-    if len([i for i in temp if i]) < ng_ovlp:
-        for i in ng_idx:
-            s_reads[i] = 0
-        return [i for i in s_reads if i]
-    for i, t in enumerate(temp):
-        s_reads[ng_idx[i]] = t
-    return s_reads
+    if not all(spare):
+        gone = set(where)
+        return [r for i, r in enumerate(picked) if i not in gone]
+    for i, r in zip(where, spare):
+        picked[i] = r
+    return picked
 
 
 def write_fastq(fn, reads, is_chunk=False):

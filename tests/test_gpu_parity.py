@@ -537,3 +537,58 @@ def test_gpu_real_size_parts_rows_equal_the_reference_fixture(gpu_lib, name):
     r = subprocess.run([sys.executable, "-m", "tests.real_size_runner", name], cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-4000:]
     assert "real-size rows identical" in r.stdout, r.stdout[-2000:]
+
+
+# ---- the process-level boundary (lq_exec.py:13-38,70-71; longQC.py:438-446,520-526): both back ends of LqCovExec and the two
+# argv-compatible executables as the subprocesses longQC.py would spawn ---------------------------------------------------------
+TINY_ARGV = ONT + [os.path.join(GOLDEN, "tiny_all.fq.gz"), os.path.join(GOLDEN, "tiny_sub.fq.gz")]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("subprocess_mode", [False, True], ids=["in_process", "subprocess"])
+def test_gpu_lqcovexec_runs_like_lqexec(gpu_lib, tmp_path, subprocess_mode):
+    """exec(*argv, out=, err=) returns at once, get_poll() is None while the run lasts and the exit status afterwards; the file
+    named by out= holds the reference's table"""
+    import time
+    from longqc_amd import LqCovExec
+    le = LqCovExec(subprocess_mode=subprocess_mode)
+    out, err = str(tmp_path / "coverage_out.txt"), str(tmp_path / "coverage_err.txt")
+    le.exec(*TINY_ARGV, out=out, err=err)
+    t0 = time.time()
+    while le.get_poll() is None:                               # (longQC.py:520-526 polls every 10 s)
+        assert time.time() - t0 < 300
+        time.sleep(0.05)
+    assert le.get_poll() == 0, open(err).read()[-2000:]
+    assert open(out).read() == read_gz("tiny_ont.table.gz")
+    assert le.get_bin_path().endswith("minimap2-coverage-mi355x") and le.get_pid().isdigit()
+    le.close()
+
+
+@pytest.mark.gpu
+def test_gpu_executables_as_subprocesses(gpu_lib, tmp_path):
+    """minimap2-coverage-mi355x: table on stdout, log on stderr, LQCOV_DEVICE names the device, exit codes 0 / 1 (bad flags,
+    unopenable target: minimap2-coverage.c:229-234,276-279) / 3 (no such device); sdust-mi355x: the reference's sdust table"""
+    import subprocess
+    exe = os.path.join(ROOT, "longqc_amd", "minimap2-coverage-mi355x")
+    env = dict(os.environ, LQCOV_DEVICE="0")
+    r = subprocess.run([exe] + TINY_ARGV, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    assert r.stdout.decode() == read_gz("tiny_ont.table.gz")
+    assert b"Real time" in r.stderr or b"[lqcov]" in r.stderr or len(r.stderr) > 0      # (free-form, never parsed: lq_exec.py:30-38)
+    r = subprocess.run([exe, "-k", "12", "a", "b"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=300)
+    assert r.returncode == 1 and r.stdout == b""
+    r = subprocess.run([exe] + ONT + [str(tmp_path / "missing.fq"), TINY_ARGV[-1]], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=300)
+    assert r.returncode == 1 and b"failed to open file" in r.stderr
+    r = subprocess.run([exe] + TINY_ARGV, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, LQCOV_DEVICE="63"), timeout=300)
+    assert r.returncode == 3 and r.stdout == b"" and b"device" in r.stderr.lower()
+    sd = os.path.join(ROOT, "longqc_amd", "sdust-mi355x")
+    fq = str(tmp_path / "tiny_all.fq")
+    with open(fq, "wb") as f:
+        import gzip
+        f.write(gzip.open(TINY_ARGV[-2]).read())
+    r = subprocess.run([sd, fq], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    rows = r.stdout.decode().splitlines()
+    names, _, _ = read_fastx(TINY_ARGV[-2])
+    assert [l.split("\t")[0] for l in rows] == list(names)
+    assert r.stdout.decode() == read_gz("tiny_all.sdust.gz")       # (what the reference's sdust printed: tests/golden/make_sdust_golden.py)

@@ -203,6 +203,24 @@ def test_run_files_parses_plain_targets_from_the_mapping(emu_lib, tmp_path, monk
     assert "from the mapped file" in err and "part 3" in err
 
 
+def test_run_files_streams_a_target_of_wrapped_records(emu_lib, tmp_path, monkeypatch):
+    """records of several lines are copied out of the mapping by the parallel reader; beyond LQCOV_PARSE_SIDE bytes of such copies
+    run_files gives the mapped reader up and streams the file, one part in memory at a time: same table"""
+    from tests.helpers import read_fastx
+    tn, ts, tq = read_fastx(os.path.join(GOLDEN, "tiny_all.fq.gz"))
+    wrapped = str(tmp_path / "all.fa")
+    _write(wrapped, b"".join(b">" + n.encode() + b"\n" + b"\n".join(s.tobytes()[j:j + 60] for j in range(0, len(s), 60)) + b"\n" for n, s in zip(tn, ts)))
+    argv = ["-Y", "-l", "0", "-q", "160", "-k", "12", "-w", "5", "-I", "100K", "-p", "160"]
+    q = os.path.join(GOLDEN, "tiny_sub.fq.gz")
+    want = oracle_bind.table(argv + [os.path.join(GOLDEN, "tiny_all.fq.gz"), q])
+    monkeypatch.setenv("LQCOV_PARSE_PIECE", "3000"); monkeypatch.setenv("LQCOV_PARSE_THREADS", "3")
+    rc, out, err = run_main(emu_lib, argv + [wrapped, q])
+    assert rc == 0 and out == want and "from the mapped file" in err
+    monkeypatch.setenv("LQCOV_PARSE_SIDE", "20000")
+    rc, out, err = run_main(emu_lib, argv + [wrapped, q])
+    assert rc == 0 and out == want and "streaming reader" in err and "from the mapped file" not in err
+
+
 def test_replay_side_sort_equals_klibs_order_ties_included(tmp_path):
     """longqc_amd/csrc/sat_replay.hpp re-sorts the chains of a saturated query the way the reference does (chain.c:139-146,
     hit.c:60-70: radix_sort_128x, klib's unstable in-place MSD sort).  Its order of EQUAL keys is what has to be right, and the
