@@ -385,6 +385,12 @@ def main():
         table = table[0] or ""
     else:
         table = eng.table_text()
+    n_qm_counted = None
+    if world == 1:
+        try:
+            n_qm_counted = float(sum(r["n_mini"] for r in eng.rows()))          # the queries' minimizers, counted (the rows carry them)
+        except Exception:
+            n_qm_counted = None
     # the same job with the reads already resident in HBM (single-part workloads only: a multi-part job re-uses the part's buffers)
     resident = None
     if len(parts) == 1 and world == 1:
@@ -405,7 +411,7 @@ def main():
             ms = sum(u[n]["total_ms"] for n in names if n in u)
             return {"kernels": {n: round(u[n]["total_ms"], 3) for n in names if n in u}, "ms": round(ms, 3), "algo_GB": round(algo / 1e9, 2),
                     "GB_per_s": round(algo / 1e9 / (ms / 1e3), 1) if ms > 0 else None, "frac_of_hbm_peak": round(algo / 1e9 / (ms / 1e3) / HBM_PEAK_GBS, 4) if ms > 0 else None}
-        n_qm = float(sum(int(x.shape[0]) for x in Q.seqs)) / 3.0                                  # ~ one minimizer per 3 bases at w = 5
+        n_qm = n_qm_counted if n_qm_counted else float(sum(int(x.shape[0]) for x in Q.seqs)) / 3.0   # (fallback: ~ one minimizer per 3 bases at w = 5)
         sk = grp(["k_sketch_dp_mask", "k_sketch_mask", "k_sketch_count", "k_sketch_emit_mask", "k_sketch_emit", "scan"], 0.25 * B0 + 16.0 * M0)
         sd = grp(["k_seed_probe", "k_dup_mark", "k_seed_count", "k_seed_scatter", "k_seed_decide", "k_seed_emit_s", "k_seed_emit"], 32.0 * n_qm + 8.0 * A0 + 16.0 * A0)
         both = {"ms": round(sk["ms"] + sd["ms"], 3), "algo_GB": round(sk["algo_GB"] + sd["algo_GB"], 2)}
@@ -553,9 +559,12 @@ def main():
                     r = subprocess.run([oracle_bind.REF_BIN] + list(PRESET[args.config][1]) + ["-t", str(cores), tf, qf], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=600)
                     dtr = time.time() - t0
                     if r.returncode == 0:
-                        line["cpu_baseline"]["full_job"] = {"value": round(total_bases / dtr / 1e6, 3), "unit": "Mbases/s", "seconds": round(dtr, 1), "cores": cores, "kind": "reference",
-                                                            "sample": "ALL target reads and ALL queries of the workload, same files as end_to_end, measured in this run",
-                                                            "table_identical_to_gpu": r.stdout.decode() == table}
+                        # the whole job is the baseline; the bounded sample (faster per base: a smaller index, fewer hits per query) stays beside it
+                        sample = line["cpu_baseline"]
+                        line["cpu_baseline"] = {"value": round(total_bases / dtr / 1e6, 3), "unit": "Mbases/s", "seconds": round(dtr, 1), "cores": cores, "kind": "reference",
+                                                "sample": "ALL target reads and ALL queries of the workload, same files as end_to_end, measured in this run",
+                                                "table_identical_to_gpu": r.stdout.decode() == table, "bounded_sample": sample}
+                        line["cpu_baseline"]["full_job"] = {k: line["cpu_baseline"][k] for k in ("value", "unit", "seconds", "cores", "kind", "sample", "table_identical_to_gpu")}
                 except subprocess.TimeoutExpired:
                     pass
     if rank == 0:

@@ -125,6 +125,7 @@ void Knobs::read_env()
 	parse_side = getenv("LQCOV_PARSE_SIDE") ? strtoull(getenv("LQCOV_PARSE_SIDE"), 0, 10) : 2ULL << 30;
 	pipeline = num("LQCOV_PIPELINE", 1) != 0;
 	plan_ahead = num("LQCOV_PLAN_AHEAD", 1) != 0;
+	seed_stream = num("LQCOV_SEED_STREAM", 1) != 0;
 	cnt_bits = (int)std::min<long>(16, std::max<long>(2, num("LQCOV_TEST_CNT_BITS", 16)));
 	seed_bucket = (u32)std::min<long>(1L << 24, std::max<long>(16, num("LQCOV_SEED_BUCKET", 7600)));
 	seed_chunk = getenv("LQCOV_SEED_CHUNK") ? std::max<u64>(1024, strtoull(getenv("LQCOV_SEED_CHUNK"), 0, 10)) : 1ULL << 30;
@@ -888,7 +889,7 @@ void lqcov_handle::map_subset(MapLane &L, Part &pt, const std::vector<u32> &sq, 
 	}
 }
 
-void lqcov_handle::map_batch(MapLane &L, Part &pt, u32 q0, u32 q1, const std::vector<u64> &h_aq, const std::vector<u64> &h_aqf, const std::vector<u64> &h_qmoff, bool dbg)
+void lqcov_handle::map_batch(MapLane &L, Part &pt, u32 q0, u32 q1, const std::vector<u64> &h_aq, const std::vector<u64> &h_aqf, const std::vector<u64> &h_qmoff, bool dbg, const u64 *sv)
 {
 	const u32 n_q = q.n;
 	L.gate_passed = false;
@@ -913,7 +914,7 @@ void lqcov_handle::map_batch(MapLane &L, Part &pt, u32 q0, u32 q1, const std::ve
 	if (nj && opt && pt.plan.bucketed) {
 		if (nA) {                                                 // the survivors of the batch's queries (the part's seed plan holds them as records)
 			StageTimer t(this, L.stream, "k_seed_emit_s", nA * 24);
-			LQ_LAUNCH(k_seed_emit_s, nblk(nA, 256), 256, L.stream, surv.as<u64>(), a_base, nA, aqf_off.as<u64>(), q0, q1, SeedBits{pt.plan.rec_jb, pt.plan.rec_db},
+			LQ_LAUNCH(k_seed_emit_s, nblk(nA, 256), 256, L.stream, sv ? sv : surv.as<u64>(), a_base, nA, aqf_off.as<u64>(), q0, q1, SeedBits{pt.plan.rec_jb, pt.plan.rec_db},
 			          q.mx.as<u64>(), q.my.as<u64>(), q.moff.as<u64>(), q.d_len.as<u32>(), dup.as<u32>(), L.A.as<mm128>());
 			check_launch();
 		}
@@ -1368,10 +1369,11 @@ void lqcov_handle::open_gate()
 // survivors' total sizes the plan's array).  The plan holds the survivors of a *group* of chunks -- the queries from q_begin on
 // until LQCOV_SEED_SURV_MAX survivors are reached (ultra-long reads keep a third of tens of billions of hits): map_part maps a
 // group's batches and asks for the next group.  h_aqf / aqf_off of the group's queries count from the group's first survivor.
-bool lqcov_handle::seed_filter(Part &pt, hipStream_t s, Prim &pr, SeedWork &W, u32 n_min, u32 jb, u32 db, u32 q_begin)
+bool lqcov_handle::seed_filter(Part &pt, hipStream_t s, Prim &pr, SeedWork &W, u32 n_min, u32 jb, u32 db, SeedJob &J)
 {
 	std::lock_guard<std::mutex> seed_lock(seed_mu);          // (the build thread plans the next part while this part's groups are made: one at a time)
-	SeedPlan &S = pt.plan;
+	const u32 q_begin = J.q_begin;
+	const std::vector<u64> &h_qmoff = *J.h_qmoff;
 	const u32 n_q = q.n;
 	const u64 n_qm = q.n_mini;
 	const u32 n_targets = std::max<u32>(pt.rs.n, 1);
@@ -1379,7 +1381,7 @@ bool lqcov_handle::seed_filter(Part &pt, hipStream_t s, Prim &pr, SeedWork &W, u
 	const SeedBits bits{jb, db};
 	// hits per kept minimizer, scanned (n_qm + 1 entries: the last one is the total); hits before every query
 	W.hlen.ensure((n_qm + 1) * 4); W.h_off.ensure((n_qm + 1) * 8); W.hq_off.ensure((n_q + 1) * 8);
-	LQ_LAUNCH(k_hit_len, nblk(n_qm, 256), 256, s, S.hit_n.as<u32>(), S.keep.as<u32>(), n_qm, W.hlen.as<u32>()); check_launch();
+	LQ_LAUNCH(k_hit_len, nblk(n_qm, 256), 256, s, J.hit_n, J.keep, n_qm, W.hlen.as<u32>()); check_launch();
 	dzero(W.hlen.as<u32>() + n_qm, 4, s);
 	pr.exclusive_scan_u32_u64(W.hlen.as<u32>(), W.h_off.as<u64>(), n_qm + 1);
 	LQ_LAUNCH(k_query_hoff, nblk(n_q + 1, 256), 256, s, q.moff.as<u64>(), W.h_off.as<u64>(), n_q, W.hq_off.as<u64>()); check_launch();
@@ -1397,10 +1399,11 @@ bool lqcov_handle::seed_filter(Part &pt, hipStream_t s, Prim &pr, SeedWork &W, u
 	struct Chunk { u32 q_lo, q_hi, g_lo, g_hi; u64 ne, nb, hits, h0; bool big; size_t bq_at; };
 	std::vector<Chunk> chunks;
 	std::vector<u32> bq_all;
-	for (u32 i = q_begin; i < n_q; ) {
+	const u32 q_stop = std::min(J.q_stop, n_q);
+	for (u32 i = q_begin; i < q_stop; ) {
 		Chunk c; c.q_lo = i; c.g_lo = (u32)segs.size(); c.ne = 0; c.nb = 0; c.hits = 0; c.h0 = h_hq[i]; c.big = false; c.bq_at = bq_all.size();
-		while (i < n_q && (c.hits == 0 || c.hits + (h_hq[i + 1] - h_hq[i]) <= chunk_cap)) {
-			const u64 hq = h_hq[i + 1] - h_hq[i], nm = S.h_qmoff[i + 1] - S.h_qmoff[i];
+		while (i < q_stop && (c.hits == 0 || c.hits + (h_hq[i + 1] - h_hq[i]) <= chunk_cap)) {
+			const u64 hq = h_hq[i + 1] - h_hq[i], nm = h_qmoff[i + 1] - h_qmoff[i];
 			SeedQ g; memset(&g, 0, sizeof(g));
 			g.seg0 = (u32)segs.size(); g.cb = c.ne; g.bk = c.nb;
 			if (hq) {
@@ -1412,7 +1415,7 @@ bool lqcov_handle::seed_filter(Part &pt, hipStream_t s, Prim &pr, SeedWork &W, u
 				g.nseg = (u32)((nm + K.seed_segl - 1) / K.seed_segl);
 				for (u32 p = 0; p < g.nseg; ++p) {
 					SeedSeg sg; memset(&sg, 0, sizeof(sg));
-					sg.j0 = S.h_qmoff[i] + (u64)p * K.seed_segl; sg.j1 = std::min<u64>(sg.j0 + K.seed_segl, S.h_qmoff[i + 1]); sg.q = i; sg.ord = p;
+					sg.j0 = h_qmoff[i] + (u64)p * K.seed_segl; sg.j1 = std::min<u64>(sg.j0 + K.seed_segl, h_qmoff[i + 1]); sg.q = i; sg.ord = p;
 					segs.push_back(sg);
 				}
 				if (g.nsl > LQ_SD_SL_SMALL) c.big = true;
@@ -1437,7 +1440,7 @@ bool lqcov_handle::seed_filter(Part &pt, hipStream_t s, Prim &pr, SeedWork &W, u
 	h2d(W.bq.as<u32>(), bq_all.data(), bq_all.size(), s); h2d(W.has.as<u32>(), has.data(), has.size(), s);
 	LQ_HIP_CHECK(hipStreamSynchronize(s));                    // (the host vectors above are pageable)
 	SeedIn in; memset(&in, 0, sizeof(in));
-	in.segs = W.segs.as<SeedSeg>(); in.qg = W.qg.as<SeedQ>(); in.h_off = W.h_off.as<u64>(); in.hit_start = S.hit_start.as<u64>(); in.pos = pt.pos.as<u64>();
+	in.segs = W.segs.as<SeedSeg>(); in.qg = W.qg.as<SeedQ>(); in.h_off = W.h_off.as<u64>(); in.hit_start = J.hit_start; in.pos = pt.pos.as<u64>();
 	in.qx = q.mx.as<u64>(); in.qy = q.my.as<u64>(); in.qmoff = q.moff.as<u64>(); in.qlen = q.d_len.as<u32>();
 	SeedDecide dp; memset(&dp, 0, sizeof(dp));
 	dp.n_min = n_min; dp.pair_bits = K.seed_pair_bits; dp.hwords = K.seed_hwords; dp.dcap = K.seed_dcap; dp.bigcap = K.seed_bigcap; dp.no_self = (int)P.no_self;
@@ -1447,8 +1450,9 @@ bool lqcov_handle::seed_filter(Part &pt, hipStream_t s, Prim &pr, SeedWork &W, u
 	DBuf d_stats;
 	if (getenv("LQCOV_SEED_STATS")) { d_stats.ensure(64); dzero(d_stats.p, 64, s); dp.stats = d_stats.as<unsigned long long>(); }
 	u64 n_surv = 0;
-	S.surv.ensure(std::min<u64>(std::max<u64>(S.nA_total / 16, 1024), K.seed_surv_max) * 8);   // (grows by chunk if the survivors outnumber the guess)
-	u32 q_end = n_q;
+	DBuf &SV = *J.surv;
+	SV.ensure(std::min<u64>(std::max<u64>(J.room_hint, 1024), K.seed_surv_max) * 8);   // (grows by chunk if the survivors outnumber the guess)
+	u32 q_end = q_stop;
 	for (const Chunk &c : chunks) {
 		const u32 ns = c.g_hi - c.g_lo;
 		if (!ns) continue;
@@ -1482,25 +1486,40 @@ bool lqcov_handle::seed_filter(Part &pt, hipStream_t s, Prim &pr, SeedWork &W, u
 		d2h(&n_c, W.soff.as<u32>() + c.nb, 1, s);
 		if (n_surv + n_c > K.seed_surv_max && n_surv) { q_end = c.q_lo; break; }   // the group is full: this chunk opens the next one
 		if (dp.stats) fprintf(stderr, "[lqcov] seed filter: chunk of queries %u..%u: %llu hits, %llu buckets, %llu pieces, %u survivors (%llu before it; room for %zu)\n",
-		                      c.q_lo, c.q_hi, (unsigned long long)c.hits, (unsigned long long)c.nb, (unsigned long long)c.ne, n_c, (unsigned long long)n_surv, S.surv.cap / 8);
-		if ((n_surv + n_c) * 8 > S.surv.cap) {
-			try { grow_keep(S.surv, n_surv * 8, (n_surv + n_c) * 8, s); }
-			catch (const std::runtime_error &) { (void)hipGetLastError(); S.surv.release(); return false; }   // (no room for the survivors: the part is mapped without the filter)
+		                      c.q_lo, c.q_hi, (unsigned long long)c.hits, (unsigned long long)c.nb, (unsigned long long)c.ne, n_c, (unsigned long long)n_surv, SV.cap / 8);
+		if ((n_surv + n_c) * 8 > SV.cap) {
+			try { grow_keep(SV, n_surv * 8, (n_surv + n_c) * 8, s); }
+			catch (const std::runtime_error &) { (void)hipGetLastError(); SV.release(); return false; }   // (no room for the survivors: the part is mapped without the filter)
 		}
-		LQ_LAUNCH(k_seed_collect, (u32)c.nb, 64, s, W.bd.as<SeedBk>(), W.rec.as<u64>(), W.scnt.as<u32>(), W.soff.as<u32>(), n_surv, S.surv.as<u64>(), S.aqf_off.as<u64>()); check_launch();
+		LQ_LAUNCH(k_seed_collect, (u32)c.nb, 64, s, W.bd.as<SeedBk>(), W.rec.as<u64>(), W.scnt.as<u32>(), W.soff.as<u32>(), n_surv, J.base, SV.as<u64>(), J.aqf_off); check_launch();
 		add_stage_bytes("k_seed_decide", (u64)n_c * 8);
 		n_surv += n_c;
 	}
-	LQ_LAUNCH(k_seed_fill_off, 1, 64, s, W.has.as<u32>(), q_begin, q_end, n_surv, S.aqf_off.as<u64>()); check_launch();
-	S.h_aqf.assign(n_q + 1, 0);
-	d2h(S.h_aqf.data() + q_begin, S.aqf_off.as<u64>() + q_begin, q_end - q_begin + 1, s);
-	S.n_written = (q_begin ? S.n_written : 0) + n_surv; S.rec_jb = jb; S.rec_db = db; S.q_begin = q_begin; S.q_end = q_end;
+	LQ_LAUNCH(k_seed_fill_off, 1, 64, s, W.has.as<u32>(), q_begin, q_end, J.base + n_surv, J.aqf_off); check_launch();
+	if (J.h_aqf->size() != (size_t)n_q + 1) J.h_aqf->assign(n_q + 1, 0);
+	d2h(J.h_aqf->data() + q_begin, J.aqf_off + q_begin, q_end - q_begin + 1, s);
+	J.q_end = q_end; J.n_surv = n_surv;
 	if (dp.stats) {
 		unsigned long long st[8];
 		d2h(st, dp.stats, 8, s);
 		fprintf(stderr, "[lqcov] seed filter: %llu hits in %zu chunks, %zu segments; pairs with %u hits hold %llu (%.2f %%), survivors %llu (%.2f %%) of the queries %u..%u; %llu buckets beyond the block (%llu of them by pairs only), %llu pairs left without a histogram\n",
 		        st[0], chunks.size(), segs.size(), n_min, st[1], st[0] ? 100.0 * st[1] / st[0] : 0.0, st[2], st[0] ? 100.0 * st[2] / st[0] : 0.0, q_begin, q_end, st[3], st[5], st[4]);
 	}
+	return true;
+}
+
+// The plan's next group of queries, from q_begin on (SeedPlan::q_begin / q_end, h_aqf, surv).  swapped: the part is being mapped and
+// its plan's buffers stand in the handle's members of the same names (swap_plan).
+bool lqcov_handle::seed_group(Part &pt, SeedPlan &S, bool swapped, hipStream_t s, Prim &pr, u32 q_begin)
+{
+	SeedJob J;
+	J.hit_start = (swapped ? hit_start : S.hit_start).as<u64>(); J.hit_n = (swapped ? hit_n : S.hit_n).as<u32>(); J.keep = (swapped ? keep : S.keep).as<u32>();
+	J.aqf_off = (swapped ? aqf_off : S.aqf_off).as<u64>();
+	J.h_qmoff = &S.h_qmoff; J.h_aqf = &S.h_aqf;
+	J.surv = swapped ? &surv : &S.surv; J.base = 0; J.room_hint = S.nA_total / 16;
+	J.q_begin = q_begin; J.q_stop = q.n;
+	if (!seed_filter(pt, s, pr, seed_ws, S.rec_nmin, S.rec_jb, S.rec_db, J)) return false;
+	S.n_written = (q_begin ? S.n_written : 0) + J.n_surv; S.q_begin = q_begin; S.q_end = J.q_end;
 	return true;
 }
 
@@ -1558,7 +1577,7 @@ void lqcov_handle::plan_part(Part &pt, hipStream_t s, Prim &pr)
 	LQ_LAUNCH(k_query_klib, nblk(n_q, 256), 256, s, S.aq_off.as<u64>(), S.qdirty.as<u32>(), n_q, (int)K.all_klib, S.qklib.as<u32>()); check_launch();
 	d2h(S.h_aq.data(), S.aq_off.as<u64>(), n_q + 1, s);
 	d2h(S.h_qmoff.data(), q.moff.as<u64>(), n_q + 1, s);
-	S.bucketed = false;
+	S.bucketed = false; S.deferred = false;
 	if (!K.ties_klib) {
 		// The seed hits that can be part of a chain at all (kernels_seed.hpp): records, dense per query.  Without the filter
 		// (LQCOV_FILTER=0, a chain may be a single anchor, or a record would not fit 64 bits) the first pass writes every hit.
@@ -1575,8 +1594,12 @@ void lqcov_handle::plan_part(Part &pt, hipStream_t s, Prim &pr)
 		u64 max_hits = 0;
 		for (u32 i = 0; i < n_q; ++i) max_hits = std::max<u64>(max_hits, S.h_aq[i + 1] - S.h_aq[i]);
 		if (n_min >= 2 && n_min <= 15 && nA_total && jb + db + 1 + rb <= 64 && db <= 31 && jb <= 31 && max_hits < 0x7fff0000ULL) {
-			S.bucketed = seed_filter(pt, s, pr, seed_ws, n_min, jb, db, 0);
-			S.rec_nmin = n_min;
+			S.rec_nmin = n_min; S.rec_jb = jb; S.rec_db = db;
+			// A part built while another is mapped gets its whole plan now, under that mapping.  With nothing to hide under (the first
+			// part of a job, a single part) the filter waits for map_part, which runs it batch by batch: a lane starts as soon as
+			// its batch is decided instead of after the whole plan.
+			if (K.seed_stream && s == bstream && mapping_active.load() == 0) { S.bucketed = true; S.deferred = true; S.q_begin = S.q_end = 0; S.h_aqf.assign(n_q + 1, 0); S.n_written = 0; }
+			else S.bucketed = seed_group(pt, S, false, s, pr, 0);
 		}
 		if (!S.bucketed) {
 			S.q_begin = 0; S.q_end = n_q;
@@ -1635,8 +1658,10 @@ void lqcov_handle::map_part(Part &pt)
 		size_t fr = 0, tot = 0;
 		hipMemGetInfo(&fr, &tot);
 		if (fr > hbm_reserve) fr -= hbm_reserve; else fr = 0;     // (lqcov_reserve_hbm: e.g. the part the caller builds while this one is mapped)
-		{	// ... and the survivors of that part's seed plan: as many as this part's, with the head room they grow by
-			const size_t sv = hbm_reserve ? surv.cap + surv.cap / 2 : 0;
+		{	// ... and the survivors of that part's seed plan: as many as this part's, with the head room they grow by; this part's own
+			// plan, if it is still to be made (SeedPlan::deferred): the bucket buffer and the survivors
+			size_t sv = hbm_reserve ? surv.cap + surv.cap / 2 : 0;
+			if (pt.plan.deferred) sv += (size_t)std::min<u64>(nA_total, K.seed_chunk) * 9 + (size_t)(nA_total / 8) * 8 + ((size_t)1 << 30);
 			if (fr > sv) fr -= sv; else fr = 0;
 		}
 		// (0.75 since round 4: a lane's buffers now grow in more steps -- a small first pass, second passes of varying size -- and a
@@ -1679,97 +1704,166 @@ void lqcov_handle::map_part(Part &pt)
 			pv_cap = (u32)std::min<u64>(pv.cap / sizeof(Ivl), 0xfffffff0ULL);
 		}
 	}
-	// The plan holds the survivors of a group of queries (all of them, unless survivors abound: SeedPlan::q_end); the group's batches
-	// are mapped, then the next group is planned -- with every lane drained, on the handle's own stream.
-	bool regrouped = false;
-	for (u32 g_begin = 0, g_end = n_q; ; ) {
-		if (opt && pt.plan.bucketed) { g_begin = pt.plan.q_begin; g_end = pt.plan.q_end; }
-		const std::vector<u64> &h_boff = opt ? h_aqf : h_aq;             // the offsets the batches are cut by: of the anchors the first pass writes
-		const u64 nB_total = h_boff[g_end] - h_boff[g_begin];
-		// batches of queries whose anchors fit one lane's work space; lanes (own streams + work space) take batches as they
-		// finish, so the serial tail of one batch overlaps the wide kernels of another
-		std::vector<std::pair<u32, u32>> batches;
-		{	// as few batches as the work space allows, a multiple of the lane count, of about equal anchor totals: every batch
-			// has a serial critical path that does not shrink with the batch.  (Cutting the last round finer was measured on MI355X at
-			// configs[2] in round 3: 1.75-1.78 s per step against 1.68-1.70 s; round 4: the queries in six chunks with the survivors of
-			// a chunk decided under the mapping of the chunk before: 1160 ms per step against 888.)
-			u64 nb = (nB_total + anchor_budget - 1) / anchor_budget;
-			if (nb < (u64)n_lanes && h_aq[g_end] - h_aq[g_begin] >= ((u64)n_lanes << 24)) nb = n_lanes;   // (by the seed hits, not by what the filter left of them: the second pass works on the hits)
-			if (nb > (u64)n_lanes) nb = (nb + n_lanes - 1) / n_lanes * n_lanes;
-			if (nb == 0) nb = 1;
-			u64 left = nb;
-			for (u32 q0 = g_begin; q0 < g_end; ) {
-				const u64 rem = h_boff[g_end] - h_boff[q0];
-				const u64 lim = std::min(anchor_budget, left > 1 ? (rem + left - 1) / left : rem);
-				u32 q1 = q0 + 1;
-				while (q1 < g_end && h_boff[q1 + 1] - h_boff[q0] <= lim) ++q1;
-				batches.emplace_back(q0, q1);
-				q0 = q1;
-				if (left > 1) --left;
-			}
-		}
-	#ifndef LQ_EMU
-		const bool concurrent = n_lanes > 1 && batches.size() > 1 && profiling != 1 && !dbg;
-	#else
-		const bool concurrent = false;
-	#endif
+	struct ActiveGuard { std::atomic<int> &a; ActiveGuard(std::atomic<int> &x) : a(x) { ++a; } ~ActiveGuard() { --a; } } active_guard(mapping_active);
+	const bool can_thread =
+#ifndef LQ_EMU
+		profiling != 1 && !dbg;
+#else
+		false;
+#endif
+	// runs the batches on the lanes; ready (optional): batch i may start only once ready(i) says so (false: give up)
+	auto run_batches = [&](const std::vector<std::pair<u32, u32>> &batches, const std::function<bool(size_t)> &wait_ready, const std::function<const u64 *(size_t)> &sv_of) {
+		const bool concurrent = can_thread && n_lanes > 1 && batches.size() > 1;
 		if (!concurrent) {
 			for (size_t i = 0; i < batches.size(); ++i) {
+				if (wait_ready && !wait_ready(i)) break;
 				lq_alloc_stream = lanes[i % n_lanes]->stream;
-				map_batch(*lanes[i % n_lanes], pt, batches[i].first, batches[i].second, h_aq, h_aqf, h_qmoff, dbg);
-				lq_alloc_stream = nullptr;
+				struct AllocGuard { ~AllocGuard() { lq_alloc_stream = nullptr; } } alloc_guard;
+				map_batch(*lanes[i % n_lanes], pt, batches[i].first, batches[i].second, h_aq, h_aqf, h_qmoff, dbg, sv_of ? sv_of(i) : nullptr);
 			}
 			for (auto &L : lanes) LQ_HIP_CHECK(hipStreamSynchronize(L->stream));
-		} else {
-			std::atomic<size_t> next(0);
-			{ std::lock_guard<std::mutex> lk(gate_mu); gate_count = 0; }
-			std::vector<std::exception_ptr> errs(n_lanes);
-			std::vector<std::thread> th;
-			for (int li = 0; li < n_lanes; ++li)
-				th.emplace_back([&, li]() {
+			return;
+		}
+		std::atomic<size_t> next(0);
+		{ std::lock_guard<std::mutex> lk(gate_mu); gate_count = 0; }
+		std::vector<std::exception_ptr> errs(n_lanes);
+		std::vector<std::thread> th;
+		for (int li = 0; li < n_lanes; ++li)
+			th.emplace_back([&, li]() {
+				try {
+					LQ_HIP_CHECK(hipSetDevice(device));
+#ifndef LQ_EMU
+					lq_segv_altstack();
+#endif
+					MapLane &L = *lanes[li];
+					lq_alloc_stream = L.stream;                              // this thread's buffers grow from the stream-ordered pool (prim.hpp)
+					struct AllocGuard { ~AllocGuard() { lq_alloc_stream = nullptr; } } alloc_guard;
+					{	// staggered start: lane li begins when li batches have got past their sort (or ended), so that
+						// one lane's serial tails run under another lane's wide kernels instead of side by side
+						std::unique_lock<std::mutex> lk(gate_mu);
+						gate_cv.wait(lk, [&] { return gate_count >= li || next.load() >= batches.size(); });
+					}
+					for (;;) {
+						const size_t i = next.fetch_add(1);
+						if (i >= batches.size()) break;
+						if (wait_ready && !wait_ready(i)) break;
+						map_batch(L, pt, batches[i].first, batches[i].second, h_aq, h_aqf, h_qmoff, dbg, sv_of ? sv_of(i) : nullptr);
+					}
+					LQ_HIP_CHECK(hipStreamSynchronize(L.stream));
+				} catch (...) { errs[li] = std::current_exception(); next.store(batches.size()); gate_cv.notify_all(); }
+			});
+		for (auto &t : th) t.join();
+		for (auto &e : errs) if (e) { hipDeviceSynchronize(); std::rethrow_exception(e); }
+	};
+	// as few batches as the work space allows, a multiple of the lane count, of about equal totals of `off` (the anchors the first
+	// pass writes, or the seed hits): every batch has a serial critical path that does not shrink with the batch.  (Cutting the
+	// last round finer was measured on MI355X at configs[2] in round 3: 1.75-1.78 s per step against 1.68-1.70 s; round 4: the
+	// queries in six chunks with the survivors of a chunk decided under the mapping of the chunk before: 1160 ms per step against 888.)
+	auto cut_batches = [&](const std::vector<u64> &off, u32 g_begin, u32 g_end) {
+		std::vector<std::pair<u32, u32>> batches;
+		const u64 total = off[g_end] - off[g_begin];
+		u64 nb = (total + anchor_budget - 1) / anchor_budget;
+		if (nb < (u64)n_lanes && h_aq[g_end] - h_aq[g_begin] >= ((u64)n_lanes << 24)) nb = n_lanes;   // (by the seed hits, not by what the filter left of them: the second pass works on the hits)
+		if (nb > (u64)n_lanes) nb = (nb + n_lanes - 1) / n_lanes * n_lanes;
+		if (nb == 0) nb = 1;
+		u64 left = nb;
+		for (u32 q0 = g_begin; q0 < g_end; ) {
+			const u64 rem = off[g_end] - off[q0];
+			const u64 lim = std::min(anchor_budget, left > 1 ? (rem + left - 1) / left : rem);
+			u32 q1 = q0 + 1;
+			while (q1 < g_end && off[q1 + 1] - off[q0] <= lim) ++q1;
+			batches.emplace_back(q0, q1);
+			q0 = q1;
+			if (left > 1) --left;
+		}
+		return batches;
+	};
+	bool regrouped = false;
+	if (opt && pt.plan.bucketed && pt.plan.deferred) {
+		// ---- the seed filter has not run yet (SeedPlan::deferred): batch by batch, a lane starting as soon as its batch is decided ----
+		pt.plan.deferred = false; regrouped = true;                // (whatever happens below, this plan is not one to map the part from again)
+		std::vector<std::pair<u32, u32>> batches = cut_batches(h_aq, 0, n_q);
+		u64 worst = 0;
+		for (auto &bq : batches) worst = std::max(worst, h_aq[bq.second] - h_aq[bq.first]);
+		if (batches.size() <= 8 && worst <= std::min<u64>(anchor_budget, K.seed_surv_max)) {
+			// (every batch fits a lane and the plan even if all of its hits survive: a batch is one run of the filter)
+			std::mutex mu; std::condition_variable cv;
+			std::vector<int> ready(batches.size(), 0);
+			std::vector<u64> first(batches.size(), 0);
+			bool failed = false; std::exception_ptr perr;
+			pt.plan.h_aqf.assign(n_q + 1, 0); pt.plan.n_written = 0;
+			auto plan_one = [&](size_t b, u64 base) -> u64 {
+				SeedJob J;
+				J.hit_start = hit_start.as<u64>(); J.hit_n = hit_n.as<u32>(); J.keep = keep.as<u32>(); J.aqf_off = aqf_off.as<u64>();
+				J.h_qmoff = &pt.plan.h_qmoff; J.h_aqf = &pt.plan.h_aqf;
+				J.surv = &surv_b[b]; J.base = base; J.room_hint = (h_aq[batches[b].second] - h_aq[batches[b].first]) / 16;
+				J.q_begin = batches[b].first; J.q_stop = batches[b].second;
+				if (!seed_filter(pt, stream, prim, seed_ws, pt.plan.rec_nmin, pt.plan.rec_jb, pt.plan.rec_db, J) || J.q_end != J.q_stop)
+					throw std::runtime_error("seed plan: no room for the survivors of a batch");
+				first[b] = base;
+				return J.n_surv;
+			};
+			auto sv_of = [&](size_t b) -> const u64 * { return surv_b[b].as<u64>() - first[b]; };   // (survivor number n of the part stands at sv[n])
+			const bool threaded = can_thread && n_lanes > 1 && batches.size() > 1;
+			if (!threaded) {
+				u64 base = 0;
+				for (size_t b = 0; b < batches.size(); ++b) {
+					base += plan_one(b, base);
+					pt.plan.n_written = base; last_n_written = base;
+					run_batches(std::vector<std::pair<u32, u32>>{batches[b]}, nullptr, [&](size_t) { return sv_of(b); });
+				}
+			} else {
+				std::thread planner([&]() {
 					try {
 						LQ_HIP_CHECK(hipSetDevice(device));
-	#ifndef LQ_EMU
-						lq_segv_altstack();
-	#endif
-						MapLane &L = *lanes[li];
-						lq_alloc_stream = L.stream;                              // this thread's buffers grow from the stream-ordered pool (prim.hpp)
-						struct AllocGuard { ~AllocGuard() { lq_alloc_stream = nullptr; } } alloc_guard;
-						{	// staggered start: lane li begins when li batches have got past their sort (or ended), so that
-							// one lane's serial tails run under another lane's wide kernels instead of side by side
-							std::unique_lock<std::mutex> lk(gate_mu);
-							gate_cv.wait(lk, [&] { return gate_count >= li || next.load() >= batches.size(); });
+						u64 base = 0;
+						for (size_t b = 0; b < batches.size(); ++b) {
+							base += plan_one(b, base);
+							{ std::lock_guard<std::mutex> lk(mu); ready[b] = 1; pt.plan.n_written = base; }
+							cv.notify_all();
 						}
-						for (;;) {
-							const size_t i = next.fetch_add(1);
-							if (i >= batches.size()) break;
-							map_batch(L, pt, batches[i].first, batches[i].second, h_aq, h_aqf, h_qmoff, dbg);
-						}
-						LQ_HIP_CHECK(hipStreamSynchronize(L.stream));
-					} catch (...) { errs[li] = std::current_exception(); next.store(batches.size()); gate_cv.notify_all(); }
+					} catch (...) { std::lock_guard<std::mutex> lk(mu); failed = true; perr = std::current_exception(); cv.notify_all(); }
 				});
-			for (auto &t : th) t.join();
-			for (auto &e : errs) if (e) { hipDeviceSynchronize(); std::rethrow_exception(e); }
-		}
-		if (g_end >= n_q) break;
-		{	// the next group (the plan's buffers go back to the plan for the time: seed_filter reads and fills them there)
-			regrouped = true;
-			swap_plan(pt.plan);
-			bool ok = false;
-			try { ok = seed_filter(pt, stream, prim, seed_ws, pt.plan.rec_nmin, pt.plan.rec_jb, pt.plan.rec_db, g_end); }
-			catch (...) { swap_plan(pt.plan); throw; }
-			if (!ok) {                                              // (no room: the rest of the part without the filter)
-				pt.plan.bucketed = false;
-				pt.plan.h_aqf = pt.plan.h_aq;
-				LQ_HIP_CHECK(hipMemcpyAsync(pt.plan.aqf_off.p, pt.plan.aq_off.p, (n_q + 1) * 8, hipMemcpyDeviceToDevice, stream));
-				LQ_HIP_CHECK(hipStreamSynchronize(stream));
-				pt.plan.n_written += h_aq[n_q] - h_aq[g_end];
+				std::exception_ptr lerr;
+				try {
+					run_batches(batches, [&](size_t i) { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return ready[i] || failed; }); return !failed; }, sv_of);
+				} catch (...) { lerr = std::current_exception(); }
+				planner.join();
+				if (perr) std::rethrow_exception(perr);
+				if (lerr) std::rethrow_exception(lerr);
+				last_n_written = pt.plan.n_written;
 			}
-			swap_plan(pt.plan);
-			last_n_written = pt.plan.n_written;
-			if (!ok) { g_begin = g_end; g_end = n_q; }
+			goto mapped;
 		}
+		// (a batch of this part could outgrow a lane or the plan: the plan in groups, below)
+		if (!seed_group(pt, pt.plan, true, stream, prim, 0)) {
+			pt.plan.bucketed = false; pt.plan.q_begin = 0; pt.plan.q_end = n_q;
+			pt.plan.h_aqf = pt.plan.h_aq;
+			LQ_HIP_CHECK(hipMemcpyAsync(aqf_off.p, aq_off.p, (n_q + 1) * 8, hipMemcpyDeviceToDevice, stream));
+			LQ_HIP_CHECK(hipStreamSynchronize(stream));
+			pt.plan.n_written = nA_total;
+		}
+		last_n_written = pt.plan.n_written;
 	}
+	// The plan holds the survivors of a group of queries (all of them, unless survivors abound: SeedPlan::q_end); the group's batches
+	// are mapped, then the next group is planned -- with every lane drained, on the handle's own stream.
+	for (u32 g_begin = 0, g_end = n_q; ; ) {
+		if (opt && pt.plan.bucketed) { g_begin = pt.plan.q_begin; g_end = pt.plan.q_end; }
+		run_batches(cut_batches(opt ? h_aqf : h_aq, g_begin, g_end), nullptr, nullptr);   // (cut by the anchors the first pass writes)
+		if (g_end >= n_q) break;
+		regrouped = true;
+		const bool ok = seed_group(pt, pt.plan, true, stream, prim, g_end);
+		if (!ok) {                                                  // (no room: the rest of the part without the filter)
+			pt.plan.bucketed = false;
+			pt.plan.h_aqf = pt.plan.h_aq;
+			LQ_HIP_CHECK(hipMemcpyAsync(aqf_off.p, aq_off.p, (n_q + 1) * 8, hipMemcpyDeviceToDevice, stream));
+			LQ_HIP_CHECK(hipStreamSynchronize(stream));
+			pt.plan.n_written += h_aq[n_q] - h_aq[g_end];
+			g_begin = g_end; g_end = n_q;
+		}
+		last_n_written = pt.plan.n_written;
+	}
+mapped:
 	if (regrouped) pt.plan.valid = false;                         // (the plan no longer starts at the first query: made again if the part is mapped again)
 	if (dbg) { unsigned long long nd = 0; d2h(&nd, n_dbg.as<unsigned long long>(), 1, stream); n_dbg_host = nd; }
 	sat_replay_part(pt, h_aq, h_qmoff);

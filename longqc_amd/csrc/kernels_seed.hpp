@@ -566,11 +566,12 @@ k_seed_decide_big(SeedDecIn in, const SeedBk *bd, const u32 *biglist, SeedDecide
 
 // survivors of every bucket of the chunk, dense: surv[base + soff[bucket] ...] (soff = exclusive scan of scnt); and where
 // every query's survivors start (aqf_off[q], for the chunk's queries)
-__global__ void k_seed_collect(const SeedBk *bd, const u64 *rec, const u32 *scnt, const u32 *soff, u64 base, u64 *surv, u64 *aqf_off)
+// (surv[i] is survivor number `first` + i of the part)
+__global__ void k_seed_collect(const SeedBk *bd, const u64 *rec, const u32 *scnt, const u32 *soff, u64 base, u64 first, u64 *surv, u64 *aqf_off)
 {
 	const u32 bk = blockIdx.x;
 	const SeedBk B = bd[bk];
-	if (B.rid0 == 0 && threadIdx.x == 0) aqf_off[B.q] = base + soff[bk];     // (a query's first slice starts at target 0, and only that one)
+	if (B.rid0 == 0 && threadIdx.x == 0) aqf_off[B.q] = first + base + soff[bk];     // (a query's first slice starts at target 0, and only that one)
 	const u32 n = scnt[bk];
 	if (n == 0) return;
 	const u64 *R = rec + B.b0;
