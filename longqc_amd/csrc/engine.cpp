@@ -125,7 +125,6 @@ void Knobs::read_env()
 	parse_side = getenv("LQCOV_PARSE_SIDE") ? strtoull(getenv("LQCOV_PARSE_SIDE"), 0, 10) : 2ULL << 30;
 	pipeline = num("LQCOV_PIPELINE", 1) != 0;
 	plan_ahead = num("LQCOV_PLAN_AHEAD", 1) != 0;
-	seed_stream = num("LQCOV_SEED_STREAM", 1) != 0;
 	cnt_bits = (int)std::min<long>(16, std::max<long>(2, num("LQCOV_TEST_CNT_BITS", 16)));
 	seed_bucket = (u32)std::min<long>(1L << 24, std::max<long>(16, num("LQCOV_SEED_BUCKET", 7600)));
 	seed_chunk = getenv("LQCOV_SEED_CHUNK") ? std::max<u64>(1024, strtoull(getenv("LQCOV_SEED_CHUNK"), 0, 10)) : 1ULL << 30;
@@ -889,7 +888,7 @@ void lqcov_handle::map_subset(MapLane &L, Part &pt, const std::vector<u32> &sq, 
 	}
 }
 
-void lqcov_handle::map_batch(MapLane &L, Part &pt, u32 q0, u32 q1, const std::vector<u64> &h_aq, const std::vector<u64> &h_aqf, const std::vector<u64> &h_qmoff, bool dbg, const u64 *sv)
+void lqcov_handle::map_batch(MapLane &L, Part &pt, u32 q0, u32 q1, const std::vector<u64> &h_aq, const std::vector<u64> &h_aqf, const std::vector<u64> &h_qmoff, bool dbg)
 {
 	const u32 n_q = q.n;
 	L.gate_passed = false;
@@ -914,7 +913,7 @@ void lqcov_handle::map_batch(MapLane &L, Part &pt, u32 q0, u32 q1, const std::ve
 	if (nj && opt && pt.plan.bucketed) {
 		if (nA) {                                                 // the survivors of the batch's queries (the part's seed plan holds them as records)
 			StageTimer t(this, L.stream, "k_seed_emit_s", nA * 24);
-			LQ_LAUNCH(k_seed_emit_s, nblk(nA, 256), 256, L.stream, sv ? sv : surv.as<u64>(), a_base, nA, aqf_off.as<u64>(), q0, q1, SeedBits{pt.plan.rec_jb, pt.plan.rec_db},
+			LQ_LAUNCH(k_seed_emit_s, nblk(nA, 256), 256, L.stream, surv.as<u64>(), a_base, nA, aqf_off.as<u64>(), q0, q1, SeedBits{pt.plan.rec_jb, pt.plan.rec_db},
 			          q.mx.as<u64>(), q.my.as<u64>(), q.moff.as<u64>(), q.d_len.as<u32>(), dup.as<u32>(), L.A.as<mm128>());
 			check_launch();
 		}
@@ -1577,7 +1576,7 @@ void lqcov_handle::plan_part(Part &pt, hipStream_t s, Prim &pr)
 	LQ_LAUNCH(k_query_klib, nblk(n_q, 256), 256, s, S.aq_off.as<u64>(), S.qdirty.as<u32>(), n_q, (int)K.all_klib, S.qklib.as<u32>()); check_launch();
 	d2h(S.h_aq.data(), S.aq_off.as<u64>(), n_q + 1, s);
 	d2h(S.h_qmoff.data(), q.moff.as<u64>(), n_q + 1, s);
-	S.bucketed = false; S.deferred = false;
+	S.bucketed = false;
 	if (!K.ties_klib) {
 		// The seed hits that can be part of a chain at all (kernels_seed.hpp): records, dense per query.  Without the filter
 		// (LQCOV_FILTER=0, a chain may be a single anchor, or a record would not fit 64 bits) the first pass writes every hit.
@@ -1595,11 +1594,9 @@ void lqcov_handle::plan_part(Part &pt, hipStream_t s, Prim &pr)
 		for (u32 i = 0; i < n_q; ++i) max_hits = std::max<u64>(max_hits, S.h_aq[i + 1] - S.h_aq[i]);
 		if (n_min >= 2 && n_min <= 15 && nA_total && jb + db + 1 + rb <= 64 && db <= 31 && jb <= 31 && max_hits < 0x7fff0000ULL) {
 			S.rec_nmin = n_min; S.rec_jb = jb; S.rec_db = db;
-			// A part built while another is mapped gets its whole plan now, under that mapping.  With nothing to hide under (the first
-			// part of a job, a single part) the filter waits for map_part, which runs it batch by batch: a lane starts as soon as
-			// its batch is decided instead of after the whole plan.
-			if (K.seed_stream && s == bstream && mapping_active.load() == 0) { S.bucketed = true; S.deferred = true; S.q_begin = S.q_end = 0; S.h_aqf.assign(n_q + 1, 0); S.n_written = 0; }
-			else S.bucketed = seed_group(pt, S, false, s, pr, 0);
+			// (measured and dropped, round 5: the filter run batch by batch inside map_part, each lane starting as soon as its batch is
+			// decided -- 586-588 ms per step at configs[2] against 576: beside the lanes' kernels the filter's take three times as long)
+			S.bucketed = seed_group(pt, S, false, s, pr, 0);
 		}
 		if (!S.bucketed) {
 			S.q_begin = 0; S.q_end = n_q;
@@ -1658,10 +1655,8 @@ void lqcov_handle::map_part(Part &pt)
 		size_t fr = 0, tot = 0;
 		hipMemGetInfo(&fr, &tot);
 		if (fr > hbm_reserve) fr -= hbm_reserve; else fr = 0;     // (lqcov_reserve_hbm: e.g. the part the caller builds while this one is mapped)
-		{	// ... and the survivors of that part's seed plan: as many as this part's, with the head room they grow by; this part's own
-			// plan, if it is still to be made (SeedPlan::deferred): the bucket buffer and the survivors
-			size_t sv = hbm_reserve ? surv.cap + surv.cap / 2 : 0;
-			if (pt.plan.deferred) sv += (size_t)std::min<u64>(nA_total, K.seed_chunk) * 9 + (size_t)(nA_total / 8) * 8 + ((size_t)1 << 30);
+		{	// ... and the survivors of that part's seed plan: as many as this part's, with the head room they grow by
+			const size_t sv = hbm_reserve ? surv.cap + surv.cap / 2 : 0;
 			if (fr > sv) fr -= sv; else fr = 0;
 		}
 		// (0.75 since round 4: a lane's buffers now grow in more steps -- a small first pass, second passes of varying size -- and a
@@ -1704,22 +1699,20 @@ void lqcov_handle::map_part(Part &pt)
 			pv_cap = (u32)std::min<u64>(pv.cap / sizeof(Ivl), 0xfffffff0ULL);
 		}
 	}
-	struct ActiveGuard { std::atomic<int> &a; ActiveGuard(std::atomic<int> &x) : a(x) { ++a; } ~ActiveGuard() { --a; } } active_guard(mapping_active);
 	const bool can_thread =
 #ifndef LQ_EMU
 		profiling != 1 && !dbg;
 #else
 		false;
 #endif
-	// runs the batches on the lanes; ready (optional): batch i may start only once ready(i) says so (false: give up)
-	auto run_batches = [&](const std::vector<std::pair<u32, u32>> &batches, const std::function<bool(size_t)> &wait_ready, const std::function<const u64 *(size_t)> &sv_of) {
+	// runs the batches on the lanes
+	auto run_batches = [&](const std::vector<std::pair<u32, u32>> &batches) {
 		const bool concurrent = can_thread && n_lanes > 1 && batches.size() > 1;
 		if (!concurrent) {
 			for (size_t i = 0; i < batches.size(); ++i) {
-				if (wait_ready && !wait_ready(i)) break;
 				lq_alloc_stream = lanes[i % n_lanes]->stream;
 				struct AllocGuard { ~AllocGuard() { lq_alloc_stream = nullptr; } } alloc_guard;
-				map_batch(*lanes[i % n_lanes], pt, batches[i].first, batches[i].second, h_aq, h_aqf, h_qmoff, dbg, sv_of ? sv_of(i) : nullptr);
+				map_batch(*lanes[i % n_lanes], pt, batches[i].first, batches[i].second, h_aq, h_aqf, h_qmoff, dbg);
 			}
 			for (auto &L : lanes) LQ_HIP_CHECK(hipStreamSynchronize(L->stream));
 			return;
@@ -1746,8 +1739,7 @@ void lqcov_handle::map_part(Part &pt)
 					for (;;) {
 						const size_t i = next.fetch_add(1);
 						if (i >= batches.size()) break;
-						if (wait_ready && !wait_ready(i)) break;
-						map_batch(L, pt, batches[i].first, batches[i].second, h_aq, h_aqf, h_qmoff, dbg, sv_of ? sv_of(i) : nullptr);
+						map_batch(L, pt, batches[i].first, batches[i].second, h_aq, h_aqf, h_qmoff, dbg);
 					}
 					LQ_HIP_CHECK(hipStreamSynchronize(L.stream));
 				} catch (...) { errs[li] = std::current_exception(); next.store(batches.size()); gate_cv.notify_all(); }
@@ -1779,77 +1771,11 @@ void lqcov_handle::map_part(Part &pt)
 		return batches;
 	};
 	bool regrouped = false;
-	if (opt && pt.plan.bucketed && pt.plan.deferred) {
-		// ---- the seed filter has not run yet (SeedPlan::deferred): batch by batch, a lane starting as soon as its batch is decided ----
-		pt.plan.deferred = false; regrouped = true;                // (whatever happens below, this plan is not one to map the part from again)
-		std::vector<std::pair<u32, u32>> batches = cut_batches(h_aq, 0, n_q);
-		u64 worst = 0;
-		for (auto &bq : batches) worst = std::max(worst, h_aq[bq.second] - h_aq[bq.first]);
-		if (batches.size() <= 8 && worst <= std::min<u64>(anchor_budget, K.seed_surv_max)) {
-			// (every batch fits a lane and the plan even if all of its hits survive: a batch is one run of the filter)
-			std::mutex mu; std::condition_variable cv;
-			std::vector<int> ready(batches.size(), 0);
-			std::vector<u64> first(batches.size(), 0);
-			bool failed = false; std::exception_ptr perr;
-			pt.plan.h_aqf.assign(n_q + 1, 0); pt.plan.n_written = 0;
-			auto plan_one = [&](size_t b, u64 base) -> u64 {
-				SeedJob J;
-				J.hit_start = hit_start.as<u64>(); J.hit_n = hit_n.as<u32>(); J.keep = keep.as<u32>(); J.aqf_off = aqf_off.as<u64>();
-				J.h_qmoff = &pt.plan.h_qmoff; J.h_aqf = &pt.plan.h_aqf;
-				J.surv = &surv_b[b]; J.base = base; J.room_hint = (h_aq[batches[b].second] - h_aq[batches[b].first]) / 16;
-				J.q_begin = batches[b].first; J.q_stop = batches[b].second;
-				if (!seed_filter(pt, stream, prim, seed_ws, pt.plan.rec_nmin, pt.plan.rec_jb, pt.plan.rec_db, J) || J.q_end != J.q_stop)
-					throw std::runtime_error("seed plan: no room for the survivors of a batch");
-				first[b] = base;
-				return J.n_surv;
-			};
-			auto sv_of = [&](size_t b) -> const u64 * { return surv_b[b].as<u64>() - first[b]; };   // (survivor number n of the part stands at sv[n])
-			const bool threaded = can_thread && n_lanes > 1 && batches.size() > 1;
-			if (!threaded) {
-				u64 base = 0;
-				for (size_t b = 0; b < batches.size(); ++b) {
-					base += plan_one(b, base);
-					pt.plan.n_written = base; last_n_written = base;
-					run_batches(std::vector<std::pair<u32, u32>>{batches[b]}, nullptr, [&](size_t) { return sv_of(b); });
-				}
-			} else {
-				std::thread planner([&]() {
-					try {
-						LQ_HIP_CHECK(hipSetDevice(device));
-						u64 base = 0;
-						for (size_t b = 0; b < batches.size(); ++b) {
-							base += plan_one(b, base);
-							{ std::lock_guard<std::mutex> lk(mu); ready[b] = 1; pt.plan.n_written = base; }
-							cv.notify_all();
-						}
-					} catch (...) { std::lock_guard<std::mutex> lk(mu); failed = true; perr = std::current_exception(); cv.notify_all(); }
-				});
-				std::exception_ptr lerr;
-				try {
-					run_batches(batches, [&](size_t i) { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return ready[i] || failed; }); return !failed; }, sv_of);
-				} catch (...) { lerr = std::current_exception(); }
-				planner.join();
-				if (perr) std::rethrow_exception(perr);
-				if (lerr) std::rethrow_exception(lerr);
-				last_n_written = pt.plan.n_written;
-			}
-			goto mapped;
-		}
-		// (a batch of this part could outgrow a lane or the plan: the plan in groups, below)
-		if (!seed_group(pt, pt.plan, true, stream, prim, 0)) {
-			pt.plan.bucketed = false; pt.plan.q_begin = 0; pt.plan.q_end = n_q;
-			pt.plan.h_aqf = pt.plan.h_aq;
-			LQ_HIP_CHECK(hipMemcpyAsync(aqf_off.p, aq_off.p, (n_q + 1) * 8, hipMemcpyDeviceToDevice, stream));
-			LQ_HIP_CHECK(hipStreamSynchronize(stream));
-			pt.plan.n_written = nA_total;
-		}
-		last_n_written = pt.plan.n_written;
-	}
 	// The plan holds the survivors of a group of queries (all of them, unless survivors abound: SeedPlan::q_end); the group's batches
 	// are mapped, then the next group is planned -- with every lane drained, on the handle's own stream.
 	for (u32 g_begin = 0, g_end = n_q; ; ) {
 		if (opt && pt.plan.bucketed) { g_begin = pt.plan.q_begin; g_end = pt.plan.q_end; }
-		run_batches(cut_batches(opt ? h_aqf : h_aq, g_begin, g_end), nullptr, nullptr);   // (cut by the anchors the first pass writes)
+		run_batches(cut_batches(opt ? h_aqf : h_aq, g_begin, g_end));   // (cut by the anchors the first pass writes)
 		if (g_end >= n_q) break;
 		regrouped = true;
 		const bool ok = seed_group(pt, pt.plan, true, stream, prim, g_end);
@@ -1863,7 +1789,6 @@ void lqcov_handle::map_part(Part &pt)
 		}
 		last_n_written = pt.plan.n_written;
 	}
-mapped:
 	if (regrouped) pt.plan.valid = false;                         // (the plan no longer starts at the first query: made again if the part is mapped again)
 	if (dbg) { unsigned long long nd = 0; d2h(&nd, n_dbg.as<unsigned long long>(), 1, stream); n_dbg_host = nd; }
 	sat_replay_part(pt, h_aq, h_qmoff);

@@ -50,7 +50,6 @@ struct Knobs {
 	bool sketch_machine_only = false;     // LQCOV_SKETCH=machine: the state machine decides every chunk (no data-parallel kernel)
 	bool ties_klib = false;               // LQCOV_TIES=klib (or LQCOV_SORT=klib): klib's order of equal-x anchors everywhere, every seed hit written and sorted (rounds 1-3); default: only where it can be observed (map_batch)
 	bool filter = true;                   // LQCOV_FILTER=0: the first pass writes every seed hit (no counting filter)
-	bool seed_stream = true;              // LQCOV_SEED_STREAM=0: a part built with nothing to hide under still gets its whole seed plan before its first batch
 	bool plan_ahead = true;               // LQCOV_PLAN_AHEAD=0: a part's seed plan (probe, survivors) is made when the part is mapped, not right after its index
 	int parse_threads = 0;                // LQCOV_PARSE_THREADS: threads that parse and pack a plain target file (0: one per core, at most 64; 1: the streaming reader as for gzip)
 	u64 parse_piece = 32u << 20;          // LQCOV_PARSE_PIECE: bytes of the file a thread parses at a time (tests shrink it: many guessed record starts)
@@ -99,7 +98,6 @@ struct SeedPlan {
 	i32 mid_occ = -2; u32 n_q = 0; u64 n_qm = 0;
 	u32 rec_jb = 0, rec_db = 0, rec_nmin = 0;   // the records' bit layout (SeedBits); the filter's n_min
 	u32 q_begin = 0, q_end = 0;           // the queries whose survivors the plan holds right now (a group of chunks; all of them unless survivors abound)
-	bool deferred = false;                // the filter has not run yet: map_part runs it batch by batch, each lane starting when its batch is decided (a part built with no mapping to hide under)
 	bool bucketed = false;                // false: the first pass writes every hit (no filter asked for, or the records do not fit 64 bits): h_aqf == h_aq
 	bool valid = false;
 };
@@ -201,8 +199,6 @@ struct lqcov_handle {
 	DBuf qklib;                           // queries that go through klib's passes (per part): marked and more than 64 anchors
 	DBuf qzero;                           // zeros: nobody goes through klib's passes (first pass of map_batch)
 	DBuf surv, aqf_off;                   // the part's surviving seed hits as records and their per-query offsets (SeedPlan, swapped in by map_part)
-	DBuf surv_b[8];                       // streamed plan (SeedPlan::deferred): the survivors of every lane's batch
-	std::atomic<int> mapping_active{0};   // a part is being mapped (a part built meanwhile has its seed plan made at once: it hides under the mapping)
 	SeedWork seed_ws; std::mutex seed_mu;  // work space of the seed filter: one plan (or group of a plan) is made at a time, whichever thread asks
 	// Queries one of whose match counters reached cnt_max (uint16 in the reference: 65535; esterr.c:130,136): from the part in
 	// which that happens on, their counters live here, replayed part by part in the reference's chain order (sat_replay.hpp,
@@ -259,7 +255,7 @@ struct lqcov_handle {
 	bool seed_group(Part &pt, SeedPlan &S, bool swapped, hipStream_t s, Prim &pr, u32 q_begin);
 	void swap_plan(SeedPlan &S);
 	void map_part(Part &pt);
-	void map_batch(MapLane &L, Part &pt, u32 q0, u32 q1, const std::vector<u64> &h_aq, const std::vector<u64> &h_aqf, const std::vector<u64> &h_qmoff, bool dbg, const u64 *sv = nullptr);
+	void map_batch(MapLane &L, Part &pt, u32 q0, u32 q1, const std::vector<u64> &h_aq, const std::vector<u64> &h_aqf, const std::vector<u64> &h_qmoff, bool dbg);
 	void batch_buffers(MapLane &L, u64 nA);
 	void chain_stage(MapLane &L, Part &pt, const u64 *aqb, u64 a_base, u32 nqb, u32 q0, const u32 *qmap, u64 nA, int tie_mode, u32 n_want, u32 ivl_cap, bool dbg, const SatSink *sink = nullptr);
 	void map_subset(MapLane &L, Part &pt, const std::vector<u32> &sq, const std::vector<u32> &sk, const std::vector<u64> &so, u64 max_mini, int tie_mode, u32 n_want, u32 ivl_cap, bool dbg, const SatSink *sink);
