@@ -566,27 +566,58 @@ void lqcov_handle::build_index(Part &pt)
 	ix_owner = &pt;
 	pt.n_keys = 0; pt.cap_bits = 4;
 	pt.pos.ensure(M * 8 + 8);
+	// same-name targets per query (self diagonal, lqmap.c:180-186) and -X's name ranks: host work on the read names, done while
+	// the device sorts (host_names is called between the last launch and the first wait)
+	std::vector<u32> soff(q.n + 1, 0), srid;
+	bool names_done = false;
+	auto host_names = [&]() {
+		names_done = true;
+		if (P.no_self && q.n) {
+			std::unordered_map<std::string, std::vector<u32>> byname;
+			for (u32 i = 0; i < q.n; ++i) byname[q.names[i]].push_back(i);
+			std::vector<std::vector<u32>> per(q.n);
+			for (u32 r = 0; r < rs.n; ++r) {
+				auto it = byname.find(rs.names[r]);
+				if (it != byname.end()) for (u32 qi : it->second) per[qi].push_back(r);
+			}
+			for (u32 i = 0; i < q.n; ++i) { soff[i + 1] = soff[i] + (u32)per[i].size(); srid.insert(srid.end(), per[i].begin(), per[i].end()); }
+		}
+		if (P.ava) {	// -X: strcmp(qname, tname) > 0 drops the hit (lqmap.c:187) -> ranks among the part's distinct names
+			std::vector<std::string> names(rs.names.begin(), rs.names.end());
+			std::sort(names.begin(), names.end());
+			names.erase(std::unique(names.begin(), names.end()), names.end());
+			std::vector<u32> tr(rs.n + 1, 0), ql(q.n + 1, 0);
+			for (u32 r = 0; r < rs.n; ++r) tr[r] = (u32)(std::lower_bound(names.begin(), names.end(), rs.names[r]) - names.begin());
+			for (u32 i = 0; i < q.n; ++i) ql[i] = (u32)(std::lower_bound(names.begin(), names.end(), q.names[i]) - names.begin());
+			pt.t_rank.ensure((rs.n + 1) * 4); pt.q_lo.ensure((q.n + 1) * 4);
+			h2d(pt.t_rank.as<u32>(), tr.data(), rs.n + 1, stream);
+			h2d(pt.q_lo.as<u32>(), ql.data(), q.n + 1, stream);
+			LQ_HIP_CHECK(hipStreamSynchronize(stream));
+		}
+	};
 	if (M) {
 		DBuf &key = ix_key, &key2 = ix_key2, &head = ix_head, &uidx = ix_uidx, &ukey = ix_ukey, &ustart = ix_ustart, &ucnt = ix_ucnt;   // workspaces live with the handle: repeated builds do not re-allocate
-		key.ensure(M * 8); key2.ensure(M * 8); head.ensure(M * 4); uidx.ensure(M * 8);
+		const u64 n_tiles = (M + LQ_HEAD_TILE - 1) / LQ_HEAD_TILE;
+		key.ensure(M * 8); key2.ensure(M * 8); head.ensure((n_tiles + 1) * 4); uidx.ensure((n_tiles + 1) * 8);   // (head / uidx: run heads per tile of keys, scanned)
 		const bool k32 = 2 * P.k <= 32;                         // the hash fits 32 bits: 4-byte sort keys
 		if (k32) {
 			LQ_LAUNCH(k_sort_keys<u32>, nblk(M, 256), 256, stream, rs.mx.as<u64>(), M, key.as<u32>()); check_launch();
 			{ StageTimer t(this, stream, "index_radix_sort", M * 24); prim.sort_pairs_u32_u64(key.as<u32>(), key2.as<u32>(), rs.my.as<u64>(), pt.pos.as<u64>(), M, (unsigned)(2 * P.k)); }
-			LQ_LAUNCH(k_mark_heads<u32>, nblk(M, 256), 256, stream, key2.as<u32>(), M, head.as<u32>()); check_launch();
+			LQ_LAUNCH(k_head_count<u32>, (u32)n_tiles, LQ_HEAD_THREADS, stream, key2.as<u32>(), M, head.as<u32>()); check_launch();
 		} else {
 			LQ_LAUNCH(k_sort_keys<u64>, nblk(M, 256), 256, stream, rs.mx.as<u64>(), M, key.as<u64>()); check_launch();
 			{ StageTimer t(this, stream, "index_radix_sort", M * 32); prim.sort_pairs_u64(key.as<u64>(), key2.as<u64>(), rs.my.as<u64>(), pt.pos.as<u64>(), M, (unsigned)(2 * P.k)); }
-			LQ_LAUNCH(k_mark_heads<u64>, nblk(M, 256), 256, stream, key2.as<u64>(), M, head.as<u32>()); check_launch();
+			LQ_LAUNCH(k_head_count<u64>, (u32)n_tiles, LQ_HEAD_THREADS, stream, key2.as<u64>(), M, head.as<u32>()); check_launch();
 		}
-		prim.exclusive_scan_u32_u64(head.as<u32>(), uidx.as<u64>(), M);
-		u64 lu = 0; u32 lh = 0;
-		d2h(&lu, uidx.as<u64>() + M - 1, 1, stream); d2h(&lh, head.as<u32>() + M - 1, 1, stream);
-		const u64 K = lu + lh;
+		dzero(head.as<u32>() + n_tiles, 4, stream);
+		prim.exclusive_scan_u32_u64(head.as<u32>(), uidx.as<u64>(), n_tiles + 1);
+		host_names();                                              // (host work while the sort runs: the first wait for the device is below)
+		u64 K = 0;
+		d2h(&K, uidx.as<u64>() + n_tiles, 1, stream);
 		pt.n_keys = K;
 		ukey.ensure(K * 8); ustart.ensure(K * 8); ucnt.ensure(K * 4);
-		if (k32) LQ_LAUNCH(k_fill_unique<u32>, nblk(M, 256), 256, stream, key2.as<u32>(), head.as<u32>(), uidx.as<u64>(), M, ukey.as<u64>(), ustart.as<u64>());
-		else LQ_LAUNCH(k_fill_unique<u64>, nblk(M, 256), 256, stream, key2.as<u64>(), head.as<u32>(), uidx.as<u64>(), M, ukey.as<u64>(), ustart.as<u64>());
+		if (k32) LQ_LAUNCH(k_head_fill<u32>, (u32)n_tiles, LQ_HEAD_THREADS, stream, key2.as<u32>(), M, uidx.as<u64>(), ukey.as<u64>(), ustart.as<u64>());
+		else LQ_LAUNCH(k_head_fill<u64>, (u32)n_tiles, LQ_HEAD_THREADS, stream, key2.as<u64>(), M, uidx.as<u64>(), ukey.as<u64>(), ustart.as<u64>());
 		check_launch();
 		LQ_LAUNCH(k_unique_counts, nblk(K, 256), 256, stream, ustart.as<u64>(), K, M, ucnt.as<u32>()); check_launch();
 		u32 bits = 4;
@@ -618,30 +649,7 @@ void lqcov_handle::build_index(Part &pt)
 		LQ_HIP_CHECK(hipMemsetAsync(pt.tkey.p, 0xff, cap * 8, stream));
 		if (mid_occ <= 0) mid_occ = P.mid_occ_frac <= 0.0f ? INT32_MAX : 1;   // reference reads an empty array here; unobservable
 	}
-	// same-name targets per query (self diagonal, lqmap.c:180-186)
-	std::vector<u32> soff(q.n + 1, 0), srid;
-	if (P.no_self && q.n) {
-		std::unordered_map<std::string, std::vector<u32>> byname;
-		for (u32 i = 0; i < q.n; ++i) byname[q.names[i]].push_back(i);
-		std::vector<std::vector<u32>> per(q.n);
-		for (u32 r = 0; r < rs.n; ++r) {
-			auto it = byname.find(rs.names[r]);
-			if (it != byname.end()) for (u32 qi : it->second) per[qi].push_back(r);
-		}
-		for (u32 i = 0; i < q.n; ++i) { soff[i + 1] = soff[i] + (u32)per[i].size(); srid.insert(srid.end(), per[i].begin(), per[i].end()); }
-	}
-	if (P.ava) {	// -X: strcmp(qname, tname) > 0 drops the hit (lqmap.c:187) -> ranks among the part's distinct names
-		std::vector<std::string> names(rs.names.begin(), rs.names.end());
-		std::sort(names.begin(), names.end());
-		names.erase(std::unique(names.begin(), names.end()), names.end());
-		std::vector<u32> tr(rs.n + 1, 0), ql(q.n + 1, 0);
-		for (u32 r = 0; r < rs.n; ++r) tr[r] = (u32)(std::lower_bound(names.begin(), names.end(), rs.names[r]) - names.begin());
-		for (u32 i = 0; i < q.n; ++i) ql[i] = (u32)(std::lower_bound(names.begin(), names.end(), q.names[i]) - names.begin());
-		pt.t_rank.ensure((rs.n + 1) * 4); pt.q_lo.ensure((q.n + 1) * 4);
-		h2d(pt.t_rank.as<u32>(), tr.data(), rs.n + 1, stream);
-		h2d(pt.q_lo.as<u32>(), ql.data(), q.n + 1, stream);
-		LQ_HIP_CHECK(hipStreamSynchronize(stream));
-	}
+	if (!names_done) host_names();
 	pt.self_off.ensure((q.n + 1) * 4); pt.self_rid.ensure(srid.size() * 4 + 4);
 	h2d(pt.self_off.as<u32>(), soff.data(), q.n + 1, stream);
 	h2d(pt.self_rid.as<u32>(), srid.data(), srid.size(), stream);

@@ -37,20 +37,59 @@ __global__ void k_rebase_y(const u64 *y, u64 n, u64 add, u64 *out)
 	if (i < n) out[i] = y[i] + add;
 }
 
+// The distinct keys of the sorted key array and where each one's run starts (ukey, ustart), in two passes over the keys and no
+// array as long as the keys in between: a tile of LQ_HEAD_TILE keys counts its run heads (key[i] != key[i - 1]); the tile counts
+// are scanned; the same tile then ranks its heads (block scan) and writes them.  (Round 4 wrote a flag per minimizer, scanned
+// the flags into 8-byte indices and read both back: 13.6 ms per 4-Gbase part against 4.)
+#define LQ_HEAD_THREADS 256
+#define LQ_HEAD_PER 8
+#define LQ_HEAD_TILE (LQ_HEAD_THREADS * LQ_HEAD_PER)
 template <class KT>
-__global__ void k_mark_heads(const KT *key, u64 n, u32 *head)
+__device__ __forceinline__ u32 lq_head_bits(const KT *key, u64 n, u64 i0, KT *mine)
 {
-	u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-	if (i < n) head[i] = (i == 0 || key[i] != key[i - 1]) ? 1u : 0u;
+	u32 bits = 0;
+	KT prev = i0 > 0 && i0 <= n ? key[i0 - 1] : (KT)0;
+#pragma unroll
+	for (int k = 0; k < LQ_HEAD_PER; ++k) {
+		const u64 i = i0 + (u64)k;
+		if (i < n) { const KT v = key[i]; mine[k] = v; if (i == 0 || v != prev) bits |= 1u << k; prev = v; }
+	}
+	return bits;
 }
-
-// uidx = exclusive scan of head; every head writes its key and start
 template <class KT>
-__global__ void k_fill_unique(const KT *key, const u32 *head, const u64 *uidx, u64 n, u64 *ukey, u64 *ustart)
+__global__ void __launch_bounds__(LQ_HEAD_THREADS)
+k_head_count(const KT *key, u64 n, u32 *tile_cnt)
 {
-	u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-	if (i >= n) return;
-	if (head[i]) { ukey[uidx[i]] = (u64)key[i]; ustart[uidx[i]] = i; }
+	__shared__ u32 acc;
+	if (threadIdx.x == 0) acc = 0;
+	__syncthreads();
+	KT mine[LQ_HEAD_PER];
+	const u32 c = (u32)__popc(lq_head_bits(key, n, (u64)blockIdx.x * LQ_HEAD_TILE + (u64)threadIdx.x * LQ_HEAD_PER, mine));
+	u32 w = c;
+	for (int o = 32; o > 0; o >>= 1) w += __shfl_xor(w, o);
+	if ((threadIdx.x & 63) == 0) atomicAdd(&acc, w);
+	__syncthreads();
+	if (threadIdx.x == 0) tile_cnt[blockIdx.x] = acc;
+}
+// tile_off = exclusive scan of tile_cnt
+template <class KT>
+__global__ void __launch_bounds__(LQ_HEAD_THREADS)
+k_head_fill(const KT *key, u64 n, const u64 *tile_off, u64 *ukey, u64 *ustart)
+{
+	__shared__ u32 wsum[LQ_HEAD_THREADS / 64 + 1];
+	KT mine[LQ_HEAD_PER];
+	const u64 i0 = (u64)blockIdx.x * LQ_HEAD_TILE + (u64)threadIdx.x * LQ_HEAD_PER;
+	const u32 bits = lq_head_bits(key, n, i0, mine);
+	const u32 c = (u32)__popc(bits), lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	u32 x = c;
+	for (u32 o = 1; o < 64; o <<= 1) { const u32 y = __shfl_up(x, o); if (lane >= o) x += y; }
+	if (lane == 63) wsum[wv] = x;
+	__syncthreads();
+	u32 before = 0;
+	for (u32 w = 0; w < wv; ++w) before += wsum[w];
+	u64 at = tile_off[blockIdx.x] + before + x - c;
+#pragma unroll
+	for (int k = 0; k < LQ_HEAD_PER; ++k) if (bits >> k & 1u) { ukey[at] = (u64)mine[k]; ustart[at] = i0 + (u64)k; ++at; }
 }
 
 __global__ void k_unique_counts(const u64 *ustart, u64 n_keys, u64 n_mini, u32 *ucnt)
