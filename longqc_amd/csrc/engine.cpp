@@ -114,6 +114,8 @@ void Knobs::read_env()
 	debug_sort = getenv("LQCOV_DEBUG_SORT") != nullptr;
 	sketch_kpt = (u32)std::min<long>(64, std::max<long>(1, num("LQCOV_SKETCH_KPT", 4)));
 	sketch_machine_only = is("LQCOV_SKETCH", "machine");
+	upload_slices = (u32)std::min<long>(8, std::max<long>(1, num("LQCOV_UPLOAD_SLICES", 4)));
+	upload_min_chunks = (u64)std::max<long>(1, num("LQCOV_UPLOAD_MIN_CHUNKS", 1L << 16));
 	ps_grid = (u32)std::max<long>(64, num("LQCOV_PS_GRID", 512));
 	tile_grid = (u32)std::max<long>(64, num("LQCOV_TILE_GRID", 4096));
 	ps_passes = (u32)std::min<long>(16, std::max<long>(0, num("LQCOV_PS_PASSES", 2))) & ~1u;
@@ -151,6 +153,8 @@ lqcov_handle::lqcov_handle(const lqcov_params &p, int dev) : P(p), device(dev)
 	// priority: its kernels get a sixth of the device and stretch (configs[2]: sketch of part 2 560 ms under five lanes, 21 ms
 	// alone) but the part is ready in time; a high-priority build stream was measured slower: 1544-1567 vs 1508-1519 ms per step)
 	LQ_HIP_CHECK(hipStreamCreate(&bstream));
+	LQ_HIP_CHECK(hipStreamCreate(&cstream));
+	for (hipEvent_t &e : ev_up) LQ_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
 	lq_pool_keep_memory(dev);
 	prim.stream = stream; bprim.stream = bstream;
 	mp.k = P.k; mp.w = P.w; mp.hpc = P.hpc;
@@ -183,6 +187,8 @@ lqcov_handle::~lqcov_handle()
 		if (e1) hipEventDestroy(e1);
 		if (e2) hipEventDestroy(e2);
 	}
+	if (cstream) { hipStreamSynchronize(cstream); hipStreamDestroy(cstream); }
+	for (hipEvent_t e : ev_up) if (e) hipEventDestroy(e);
 	if (bstream) { hipStreamSynchronize(bstream); hipStreamDestroy(bstream); }
 	if (stream) { hipStreamSynchronize(stream); hipStreamDestroy(stream); }
 }
@@ -321,14 +327,82 @@ void lqcov_handle::add_reads_packed(ReadSetDev &rs, u32 n, const u64 *codes, con
 	const u64 n_words = new_chunks * LQ_CHUNK_WORDS;
 	grow_keep(rs.codes, rs.n_chunks * LQ_CHUNK_WORDS * 8, (rs.n_chunks + new_chunks) * LQ_CHUNK_WORDS * 8, stream);
 	grow_keep(rs.amb, rs.n_chunks * LQ_CHUNK_WORDS * 4, (rs.n_chunks + new_chunks) * LQ_CHUNK_WORDS * 4, stream);
+	const bool first = rs.n == 0;
+	const u64 chunk0 = rs.n_chunks;
+	rs.n += n; rs.n_chunks += new_chunks; rs.n_bases += n_bases;
+	rs.sketched = false; rs.dp_n = 0; rs.dp_tiles = 0;
+	u64 n_tiles = 0;
+	if (first && K.upload_slices > 1 && new_chunks >= K.upload_min_chunks && sketch_dp_setup(rs, n_tiles)) {
+		// The reads go up in slices on a stream of their own; the data-parallel sketch kernel takes the tiles of a slice on the build
+		// stream as soon as the slice has arrived -- under the upload of the next one (a 4-Gbase part: 26 ms of upload and 34 ms of
+		// kernel one after the other before).  The caller's buffers are free when this returns; the last slice may still be sketched.
+		StageTimer t(this, stream, "h2d_packed_reads", n_words * 12);
+		const u32 ns = K.upload_slices;
+		u32 r0 = 0;
+		for (u32 sl = 0; sl < ns; ++sl) {
+			u32 r1 = sl + 1 == ns ? n : r0;
+			const u64 want = new_chunks * (u64)(sl + 1) / ns;
+			while (r1 < n && rs.h_coff[r1] < want) ++r1;           // (h_coff[r] = chunks before read r: chunk0 == 0 here)
+			if (r1 > r0) {
+				const u64 w0 = rs.h_coff[r0] * LQ_CHUNK_WORDS, w1 = rs.h_coff[r1] * LQ_CHUNK_WORDS;
+				LQ_HIP_CHECK(hipMemcpyAsync(rs.codes.as<u64>() + w0, codes + w0, (w1 - w0) * 8, hipMemcpyHostToDevice, cstream));
+				LQ_HIP_CHECK(hipMemcpyAsync(rs.amb.as<u32>() + w0, amb + w0, (w1 - w0) * 4, hipMemcpyHostToDevice, cstream));
+				LQ_HIP_CHECK(hipEventRecord(ev_up[sl], cstream));
+				LQ_HIP_CHECK(hipStreamWaitEvent(stream, ev_up[sl], 0));
+				sketch_dp_launch(rs, sk_h_toff[r0], sk_h_toff[r1]);
+			}
+			r0 = r1;
+		}
+		LQ_HIP_CHECK(hipStreamSynchronize(cstream));          // the caller's buffers are free again
+		rs.dp_n = rs.n; rs.dp_tiles = n_tiles;
+		return;
+	}
+	(void)first; (void)chunk0;
 	{
 		StageTimer t(this, stream, "h2d_packed_reads", n_words * 12);
-		h2d(rs.codes.as<u64>() + rs.n_chunks * LQ_CHUNK_WORDS, codes, n_words, stream);
-		h2d(rs.amb.as<u32>() + rs.n_chunks * LQ_CHUNK_WORDS, amb, n_words, stream);
+		h2d(rs.codes.as<u64>() + chunk0 * LQ_CHUNK_WORDS, codes, n_words, stream);
+		h2d(rs.amb.as<u32>() + chunk0 * LQ_CHUNK_WORDS, amb, n_words, stream);
 	}
 	LQ_HIP_CHECK(hipStreamSynchronize(stream));               // the caller's buffers are free again
-	rs.n += n; rs.n_chunks += new_chunks; rs.n_bases += n_bases;
-	rs.sketched = false;
+}
+
+// What k_sketch_dp_mask needs before its first tile: read offsets and lengths, the tiles of every read, an empty mask.  false: the
+// data-parallel kernel does not apply (-H, a window or k-mer beyond its reach, LQCOV_SKETCH=machine).
+bool lqcov_handle::sketch_dp_setup(ReadSetDev &rs, u64 &n_tiles)
+{
+	hipStream_t stream = this->bstream;
+	const u64 nc = rs.n_chunks;
+	if (P.hpc || !(P.w <= 16 && P.w + P.k - 1 <= 48 && P.k <= 28 && P.k >= 2) || K.sketch_machine_only || !nc) return false;
+	rs.d_coff.ensure((rs.n + 1) * 8); rs.d_len.ensure((rs.n + 1) * 4);
+	h2d(rs.d_coff.as<u64>(), rs.h_coff.data(), rs.n + 1, stream);
+	h2d(rs.d_len.as<u32>(), rs.h_len.data(), rs.n, stream);
+	sk_mask.ensure(nc * LQ_CHUNK_WORDS * 4 + 64); sk_flag.ensure(4);
+	dzero(sk_mask.p, nc * LQ_CHUNK_WORDS * 4, stream); dzero(sk_flag.p, 4, stream);
+	sk_grid.ensure((nc / LQ_EM_CH + 2) * 4);
+	sk_h_toff.assign(rs.n + 1, 0);
+	for (u32 r = 0; r < rs.n; ++r) sk_h_toff[r + 1] = sk_h_toff[r] + (rs.h_coff[r + 1] - rs.h_coff[r] + LQ_DPT_CH - 1) / LQ_DPT_CH;
+	n_tiles = sk_h_toff[rs.n];
+	sk_toff.ensure((rs.n + 1) * 8); sk_owned.ensure(nc + 8); sk_trid.ensure(n_tiles * 4 + 4);
+	h2d(sk_toff.as<u64>(), sk_h_toff.data(), rs.n + 1, stream);
+	LQ_LAUNCH(k_sketch_owners, nblk(rs.n, 256), 256, stream, rs.d_coff.as<u64>(), sk_toff.as<u64>(), rs.n, sk_trid.as<u32>(), sk_grid.as<u32>()); check_launch();
+	return true;
+}
+
+// k_sketch_dp_mask over the tiles [tile0, tile1) of the read set
+void lqcov_handle::sketch_dp_launch(ReadSetDev &rs, u64 tile0, u64 tile1)
+{
+	hipStream_t stream = this->bstream;
+	if (tile1 <= tile0) return;
+	SkParams sp; sp.k = P.k; sp.w = P.w; sp.hpc = P.hpc; sp.mask = (1ULL << 2 * P.k) - 1; sp.shift1 = 2 * (P.k - 1);
+	const u64 nt = tile1 - tile0;
+	StageTimer t(this, stream, "k_sketch_dp_mask", nt * LQ_DPT_CH * (LQ_CHUNK_WORDS * 12 + 17));
+#define LQ_DPM(HT, W) LQ_LAUNCH((k_sketch_dp_mask<HT, W>), (u32)std::min<u64>(nt, 1u << 22), LQ_DPT_THREADS, stream, rs.codes.as<u64>(), rs.amb.as<u32>(), rs.d_coff.as<u64>(), rs.d_len.as<u32>(), \
+		sk_toff.as<u64>(), sk_trid.as<u32>(), rs.n, tile0, tile1, sp, sk_owned.as<u8>(), sk_mask.as<u32>(), sk_flag.as<u32>())
+	const int wc = K.sketch_wgen ? 0 : P.w;                       // the presets' windows as compile-time constants
+	if (P.k <= 16) { if (wc == 5) LQ_DPM(u32, 5); else if (wc == 10) LQ_DPM(u32, 10); else LQ_DPM(u32, 0); }
+	else { if (wc == 5) LQ_DPM(u64, 5); else if (wc == 10) LQ_DPM(u64, 10); else LQ_DPM(u64, 0); }
+#undef LQ_DPM
+	check_launch();
 }
 
 // minimizers of every read of the set, in (read, position) order   (sketch.c:76-142)
@@ -366,31 +440,18 @@ void lqcov_handle::sketch(ReadSetDev &rs, bool rid_in_y)
 			// over tiles of 12 chunks wherever the machine is memoryless, by the state machine for what that kernel leaves (the
 			// first chunk of every read, tiles within reach of an N, AT-repeat halos).  The list is then made from the mask: no
 			// second run of the machine, no halo for the output pass.
-			sk_mask.ensure(nc * LQ_CHUNK_WORDS * 4 + 64); sk_flag.ensure(4);
-			dzero(sk_mask.p, nc * LQ_CHUNK_WORDS * 4, stream); dzero(sk_flag.p, 4, stream);
-			lap("mask ensure + zero");
 			const bool dp = P.w <= 16 && P.w + P.k - 1 <= 48 && P.k <= 28 && P.k >= 2 && !K.sketch_machine_only;
 			const u8 *dp_owned = nullptr;
-			sk_grid.ensure((nc / LQ_EM_CH + 2) * 4);
-			if (!dp) { LQ_LAUNCH(k_sketch_owners, nblk(rs.n, 256), 256, stream, rs.d_coff.as<u64>(), (const u64*)nullptr, rs.n, (u32*)nullptr, sk_grid.as<u32>()); check_launch(); }
+			if (!dp) {
+				sk_mask.ensure(nc * LQ_CHUNK_WORDS * 4 + 64); sk_flag.ensure(4);
+				dzero(sk_mask.p, nc * LQ_CHUNK_WORDS * 4, stream); dzero(sk_flag.p, 4, stream);
+				sk_grid.ensure((nc / LQ_EM_CH + 2) * 4);
+				LQ_LAUNCH(k_sketch_owners, nblk(rs.n, 256), 256, stream, rs.d_coff.as<u64>(), (const u64*)nullptr, rs.n, (u32*)nullptr, sk_grid.as<u32>()); check_launch();
+			}
 			if (dp) {
-				std::vector<u64> toff(rs.n + 1, 0);
-				for (u32 r = 0; r < rs.n; ++r) toff[r + 1] = toff[r] + (rs.h_coff[r + 1] - rs.h_coff[r] + LQ_DPT_CH - 1) / LQ_DPT_CH;
-				const u64 n_tiles = toff[rs.n];
-				sk_toff.ensure((rs.n + 1) * 8); sk_owned.ensure(nc + 8); sk_trid.ensure(n_tiles * 4 + 4);
-				h2d(sk_toff.as<u64>(), toff.data(), rs.n + 1, stream);
-				LQ_HIP_CHECK(hipStreamSynchronize(stream));          // (toff dies with this scope)
-				LQ_LAUNCH(k_sketch_owners, nblk(rs.n, 256), 256, stream, rs.d_coff.as<u64>(), sk_toff.as<u64>(), rs.n, sk_trid.as<u32>(), sk_grid.as<u32>()); check_launch();
-				if (n_tiles) {
-					StageTimer t(this, stream, "k_sketch_dp_mask", in_bytes + nc * 17);
-#define LQ_DPM(HT, W) LQ_LAUNCH((k_sketch_dp_mask<HT, W>), (u32)std::min<u64>(n_tiles, 1u << 22), LQ_DPT_THREADS, stream, rs.codes.as<u64>(), rs.amb.as<u32>(), rs.d_coff.as<u64>(), rs.d_len.as<u32>(), \
-		sk_toff.as<u64>(), sk_trid.as<u32>(), rs.n, n_tiles, sp, sk_owned.as<u8>(), sk_mask.as<u32>(), sk_flag.as<u32>())
-					const int wc = K.sketch_wgen ? 0 : P.w;               // the presets' windows as compile-time constants
-					if (P.k <= 16) { if (wc == 5) LQ_DPM(u32, 5); else if (wc == 10) LQ_DPM(u32, 10); else LQ_DPM(u32, 0); }
-					else { if (wc == 5) LQ_DPM(u64, 5); else if (wc == 10) LQ_DPM(u64, 10); else LQ_DPM(u64, 0); }
-#undef LQ_DPM
-					check_launch();
-				}
+				// (the tiles may be done already: add_reads_packed runs the kernel slice by slice under the upload)
+				u64 n_tiles = rs.dp_tiles;
+				if (rs.dp_n != rs.n) { if (!sketch_dp_setup(rs, n_tiles)) throw std::logic_error("sketch: set-up of the data-parallel kernel"); sketch_dp_launch(rs, 0, n_tiles); }
 				lap("dp_mask");
 				dp_owned = sk_owned.as<u8>();
 				if (K.debug_sort) {

@@ -47,6 +47,8 @@ struct Knobs {
 	u32 ps_passes = 2;                    // LQCOV_PS_PASSES: partition passes issued without looking (even; the tail looks at the counter and does the rest).  Two cover queries of up to ~500 M anchors against 65 536 targets; measured 4 vs 2 at configs[2]: 1.71-1.77 vs 1.69-1.71 s per step
 	u32 tile_grid = 4096;                 // LQCOV_TILE_GRID: blocks of klib's tile kernels (histogram, scatter)
 	u32 ps_grid = 512;                   // LQCOV_PS_GRID: blocks of the parallel sort's tile kernels (the finishing kernels: a quarter / twice that; twice as many blocks for them: no change, measured with the 64-register kernels)
+	u64 upload_min_chunks = 1u << 16;     // LQCOV_UPLOAD_MIN_CHUNKS: only read sets of that many 128-base chunks go up in slices (tests lower it)
+	u32 upload_slices = 4;                // LQCOV_UPLOAD_SLICES (1..8): packed reads go up in slices, the data-parallel sketch kernel takes a slice while the next one is on its way (1: one copy, then the sketch)
 	bool sketch_machine_only = false;     // LQCOV_SKETCH=machine: the state machine decides every chunk (no data-parallel kernel)
 	bool ties_klib = false;               // LQCOV_TIES=klib (or LQCOV_SORT=klib): klib's order of equal-x anchors everywhere, every seed hit written and sorted (rounds 1-3); default: only where it can be observed (map_batch)
 	bool filter = true;                   // LQCOV_FILTER=0: the first pass writes every seed hit (no counting filter)
@@ -83,6 +85,7 @@ struct ReadSetDev {                       // a read set 2-bit packed in HBM, chu
 	DBuf mx, my, moff;                    // minimizers (x, y) in emission order + per-read offsets
 	u64 n_mini = 0;
 	bool sketched = false;
+	u32 dp_n = 0; u64 dp_tiles = 0;       // add_reads_packed has already run k_sketch_dp_mask over the tiles of these reads (slice by slice, under the upload of the next slice)
 };
 
 // What the mapping of a part needs before its first batch, and what depends only on the part, the query set and mid_occ (not
@@ -169,6 +172,8 @@ struct lqcov_handle {
 	int device = 0;
 	hipStream_t stream = nullptr;         // queries, the head of map_part, finish
 	hipStream_t bstream = nullptr;        // upload, sketch and index of a part (with bprim): another part may be mapped meanwhile
+	hipStream_t cstream = nullptr;        // the upload of packed reads in slices: a slice is sketched on bstream while the next one arrives
+	hipEvent_t ev_up[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 	Prim prim, bprim;
 	u64 hbm_reserve = 0;                  // bytes the caller wants left free when the lanes size their work space (a second part being built)
 	std::string err;
@@ -231,6 +236,7 @@ struct lqcov_handle {
 	DBuf ix_key, ix_key2, ix_head, ix_uidx, ix_ukey, ix_ustart, ix_ucnt, ix_sorted;   // build_index workspaces
 	const Part *ix_owner = nullptr;       // the part ix_ukey / ix_ustart / ix_ucnt describe (dump_part reads them)
 	DBuf sk_cnt, sk_off, sk_owned, sk_mask, sk_flag, sk_toff, sk_trid, sk_grid;   // sketch: per-chunk minimizer counts / offsets, which kernel decides a chunk, emitted positions (a bit per base), tile offsets
+	std::vector<u64> sk_h_toff;           // tiles of k_sketch_dp_mask before every read (host copy of sk_toff)
 	u64 last_n_anchors = 0;
 	u64 anchor_budget = 0;
 
@@ -245,6 +251,8 @@ struct lqcov_handle {
 	void add_reads(ReadSetDev &rs, u32 n, const u8 *seq, const u64 *seq_off, const char *names, const u64 *name_off);
 	void add_reads_packed(ReadSetDev &rs, u32 n, const u64 *codes, const u32 *amb, const u32 *lens, const char *names, const u64 *name_off);
 	void sketch(ReadSetDev &rs, bool rid_in_y);
+	bool sketch_dp_setup(ReadSetDev &rs, u64 &n_tiles);
+	void sketch_dp_launch(ReadSetDev &rs, u64 tile0, u64 tile1);
 	void export_minimizers(ReadSetDev &rs, u64 *x_dev, u64 *y_dev, u32 rid_base);
 	void set_queries(u32 n, const u8 *seq, const u64 *seq_off, const u8 *qual, const char *names, const u64 *name_off);
 	void build_index(Part &pt);

@@ -371,7 +371,7 @@ __global__ void k_sketch_owners(const u64 *coff, const u64 *toff, u32 n_reads, u
 
 template <class HT, int W>   // HT: u32 for k <= 16 (hashes and k-mers in one register), u64 otherwise; W: the window as a constant
 __global__ void __launch_bounds__(LQ_DPT_THREADS)   // (5, 10: the presets'; the window scans below unroll), 0 = P.w at run time
-k_sketch_dp_mask(const u64 *codes, const u32 *amb, const u64 *coff, const u32 *rlen, const u64 *toff, const u32 *tile_rid, u32 n_reads, u64 n_tiles, SkParams P,
+k_sketch_dp_mask(const u64 *codes, const u32 *amb, const u64 *coff, const u32 *rlen, const u64 *toff, const u32 *tile_rid, u32 n_reads, u64 tile0 /* tiles [tile0, n_tiles) */, u64 n_tiles, SkParams P,
                  u8 *owned, u32 *mask, u32 *dup_flag)
 {
 	__shared__ HT V[LQ_DPT_N];
@@ -380,7 +380,7 @@ k_sketch_dp_mask(const u64 *codes, const u32 *amb, const u64 *coff, const u32 *r
 	__shared__ u32 wsum[LQ_DPT_WAVES], whalo[LQ_DPT_WAVES], bad;
 	const u32 t = threadIdx.x, lane = t & 63, wv = t >> 6;
 	const i32 w = W ? W : P.w, k = P.k;
-	for (u64 T = blockIdx.x; T < n_tiles; T += gridDim.x) {
+	for (u64 T = tile0 + blockIdx.x; T < n_tiles; T += gridDim.x) {
 		const u32 r = tile_rid[T];
 		const u32 len = rlen[r];
 		const u64 g0 = coff[r] + (T - toff[r]) * LQ_DPT_CH;        // first chunk of the tile

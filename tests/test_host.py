@@ -201,6 +201,10 @@ def test_run_files_parses_plain_targets_from_the_mapping(emu_lib, tmp_path, monk
     assert rc == 0, err
     assert out == want
     assert "from the mapped file" in err and "part 3" in err
+    # the packed reads of a part in three slices, the data-parallel sketch kernel taking a slice while the next one goes up
+    monkeypatch.setenv("LQCOV_UPLOAD_MIN_CHUNKS", "1"); monkeypatch.setenv("LQCOV_UPLOAD_SLICES", "3")
+    rc, out, err = run_main(emu_lib, argv + [plain, q])
+    assert rc == 0 and out == want, err
 
 
 def test_run_files_streams_a_target_of_wrapped_records(emu_lib, tmp_path, monkeypatch):
