@@ -922,10 +922,16 @@ k_chain_wave(const mm128 *A, const u64 *gstart, const u32 *glist, u32 n_list, co
 		const mm128 an = i + 1 < n ? a[i + 1] : ai;             // (the next anchor is on its way while this one is scored)
 		const u64 ri = ai.x;
 		const i32 qi = (i32)ai.y, q_span = (i32)(ai.y >> 32 & 0xff);
-		while (st < i && ri - a[st].x > (u64)max_dist) ++st;    // uniform: every lane computes the same st
+		const i64 j = i - 1 - (i64)ln;
+		{	// st: the first anchor within max_dist of this one (chain.c:47).  x ascends, so the anchors out of reach are a prefix of the
+			// run: among the 64 anchors of the window the nearest one out of reach says where it ends -- no load; only when the whole
+			// window is within reach (more than 64 anchors inside max_dist) are older anchors looked at in memory
+			const u64 far = __ballot(j >= 0 && (u32)ri - wx > (u32)max_dist);
+			if (far) { const i64 s2 = i - (i64)__builtin_ctzll(far); if (s2 > st) st = s2; }
+			else while (st < i - 64 && ri - a[st].x > (u64)max_dist) ++st;   // uniform: every lane computes the same st
+		}
 		i32 max_f = q_span, max_j = -1, n_skip = 0, done = 0;
 		// ---- the 64 nearest candidates, from the window ----
-		const i64 j = i - 1 - (i64)ln;
 		bool active = false; i32 sc = 0;
 		if (j >= st) {
 			const i64 dr = (i64)((u32)ri - wx);                 // (the high words are equal inside a run)
