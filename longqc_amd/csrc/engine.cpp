@@ -452,6 +452,7 @@ void lqcov_handle::sketch(ReadSetDev &rs, bool rid_in_y)
 				// (the tiles may be done already: add_reads_packed runs the kernel slice by slice under the upload)
 				u64 n_tiles = rs.dp_tiles;
 				if (rs.dp_n != rs.n) { if (!sketch_dp_setup(rs, n_tiles)) throw std::logic_error("sketch: set-up of the data-parallel kernel"); sketch_dp_launch(rs, 0, n_tiles); }
+				rs.dp_n = 0; rs.dp_tiles = 0;                          // (the mask is used up below: a second sketch of the same reads starts from an empty one)
 				lap("dp_mask");
 				dp_owned = sk_owned.as<u8>();
 				if (K.debug_sort) {

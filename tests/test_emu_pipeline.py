@@ -213,13 +213,22 @@ def test_emulated_query_batching_is_invisible(emu_lib, datasets, monkeypatch, la
     assert out == want
 
 
-def test_emulated_reset_and_rerun(emu_lib):
+def check_reset_and_rerun(emu_lib, packed):
     tn, ts, _ = read_fastx(os.path.join(GOLDEN, "tiny_all.fq.gz"))
     qn, qs, qq = read_fastx(os.path.join(GOLDEN, "tiny_sub.fq.gz"))
-    eng = _engine(emu_lib)
+    if packed:      # (packed reads go up in slices with the data-parallel sketch kernel under the upload: the second build finds them resident)
+        os.environ["LQCOV_UPLOAD_MIN_CHUNKS"] = "1"; os.environ["LQCOV_UPLOAD_SLICES"] = "3"
+    try:
+        eng = _engine(emu_lib)
+    finally:
+        os.environ.pop("LQCOV_UPLOAD_MIN_CHUNKS", None); os.environ.pop("LQCOV_UPLOAD_SLICES", None)
     eng.set_queries(qn, qs, qq)
     pt = eng.part_begin()
-    eng.part_add_targets(pt, tn, ts)
+    if packed:
+        flat = np.concatenate(ts); off = np.concatenate([[0], np.cumsum([len(x) for x in ts])]).astype(np.uint64)
+        eng.part_add_packed(pt, api.PackedReads(flat, off, list(tn), lib=emu_lib))
+    else:
+        eng.part_add_targets(pt, tn, ts)
     tables = []
     for _ in range(2):
         eng.reset()
@@ -227,6 +236,11 @@ def test_emulated_reset_and_rerun(emu_lib):
         tables.append(eng.table_text())
     assert tables[0] == tables[1] == read_gz("tiny_ont.table.gz")
     eng.close()
+
+
+@pytest.mark.parametrize("packed", [False, True], ids=["ascii", "packed_in_slices"])
+def test_emulated_reset_and_rerun(emu_lib, packed):
+    check_reset_and_rerun(emu_lib, packed)
 
 
 @pytest.mark.parametrize("shift", ["4", pytest.param("7", marks=slow_emu), pytest.param("12", marks=slow_emu)])

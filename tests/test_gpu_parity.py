@@ -51,7 +51,8 @@ def test_gpu_chains_mid_occ_and_accumulators(gpu_lib, name, tfn, qfn):
 
 
 def test_gpu_reset_and_rerun(gpu_lib):
-    E.test_emulated_reset_and_rerun(gpu_lib)
+    E.check_reset_and_rerun(gpu_lib, False)
+    E.check_reset_and_rerun(gpu_lib, True)
 
 
 def test_gpu_input_dialects(gpu_lib, tmp_path):
