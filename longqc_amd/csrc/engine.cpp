@@ -970,6 +970,10 @@ void lqcov_handle::map_batch(MapLane &L, Part &pt, u32 q0, u32 q1, const std::ve
 	const u64 a_base = h_off[q0], nA = h_off[q1] - a_base;
 	const u32 nqb = q1 - q0;
 	const u64 j0 = h_qmoff[q0], nj = h_qmoff[q1] - j0;
+	// (the second pass of this batch takes every seed hit of the queries it lists, up to anchor_budget at a time: the lane's buffers
+	// are sized for that now, before the batch's first kernel, not again in the middle of it)
+	struct BoostGuard { ~BoostGuard() { lq_alloc_boost = 1.0; } } boost_guard;
+	if (opt) lq_alloc_boost = std::min(64.0, std::max(1.0, (double)std::min<u64>(anchor_budget, h_aq[q1] - h_aq[q0]) / (double)std::max<u64>(nA, 1)));
 	batch_buffers(L, nA);
 	const AvaView ava{P.ava ? pt.t_rank.as<u32>() : nullptr, P.ava ? pt.q_lo.as<u32>() : nullptr};
 	if (nj && !opt) {

@@ -25,6 +25,10 @@
 // lanes were inside long kernels).  A lane thread therefore names its stream in lq_alloc_stream and its buffers are taken
 // from and returned to HIP's stream-ordered pool (hipMallocAsync / hipFreeAsync, release threshold raised so that
 // returned blocks stay cached).
+// A lane's first pass writes a few per cent of its batch's seed hits, its second pass may hold many times that: a lane thread sets
+// lq_alloc_boost so that a work buffer that has to grow is sized for the largest batch the lane can meet at once -- one round of
+// allocations per lane instead of a second one in the middle of the mapping (hipMalloc waits for the device every time).
+inline thread_local double lq_alloc_boost = 1.0;
 #ifndef LQ_EMU
 inline thread_local hipStream_t lq_alloc_stream = nullptr;
 inline void lq_pool_keep_memory(int device)
@@ -54,6 +58,7 @@ struct DBuf {
 	{
 		if (bytes <= cap) return;
 		release();
+		if (lq_alloc_boost > 1.0 && bytes >= ((size_t)1 << 20)) bytes = (size_t)((double)bytes * lq_alloc_boost);
 		LqAllocTimer alloc_timer(bytes);
 		size_t want = bytes + bytes / 8 + 256;
 #ifdef LQ_EXACT_ALLOC
