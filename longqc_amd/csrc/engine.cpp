@@ -961,6 +961,11 @@ void lqcov_handle::map_subset(MapLane &L, Part &pt, const std::vector<u32> &sq, 
 
 void lqcov_handle::map_batch(MapLane &L, Part &pt, u32 q0, u32 q1, const std::vector<u64> &h_aq, const std::vector<u64> &h_aqf, const std::vector<u64> &h_qmoff, bool dbg)
 {
+	// (a batch starts with an empty arena: what the lane's last batch cut from it is dead -- its kernels are ahead of this batch's on
+	// the lane's stream, its side streams were joined)
+	L.drop_arena_buffers();
+	lq_arena = L.arena.base ? &L.arena : nullptr;
+	struct ArenaGuard { ~ArenaGuard() { lq_arena = nullptr; } } arena_guard;
 	const u32 n_q = q.n;
 	L.gate_passed = false;
 	struct GateGuard { lqcov_handle *h; MapLane &L; ~GateGuard() { if (!L.gate_passed) { L.gate_passed = true; h->open_gate(); } } } gate_guard{this, L};
@@ -970,10 +975,6 @@ void lqcov_handle::map_batch(MapLane &L, Part &pt, u32 q0, u32 q1, const std::ve
 	const u64 a_base = h_off[q0], nA = h_off[q1] - a_base;
 	const u32 nqb = q1 - q0;
 	const u64 j0 = h_qmoff[q0], nj = h_qmoff[q1] - j0;
-	// (the second pass of this batch takes every seed hit of the queries it lists, up to anchor_budget at a time: the lane's buffers
-	// are sized for that now, before the batch's first kernel, not again in the middle of it)
-	struct BoostGuard { ~BoostGuard() { lq_alloc_boost = 1.0; } } boost_guard;
-	if (opt) lq_alloc_boost = std::min(64.0, std::max(1.0, (double)std::min<u64>(anchor_budget, h_aq[q1] - h_aq[q0]) / (double)std::max<u64>(nA, 1)));
 	batch_buffers(L, nA);
 	const AvaView ava{P.ava ? pt.t_rank.as<u32>() : nullptr, P.ava ? pt.q_lo.as<u32>() : nullptr};
 	if (nj && !opt) {
@@ -1762,6 +1763,14 @@ void lqcov_handle::map_part(Part &pt)
 		LQ_HIP_CHECK(hipEventCreateWithFlags(&lanes.back()->ev_fork, hipEventDisableTiming));
 		LQ_HIP_CHECK(hipEventCreateWithFlags(&lanes.back()->ev_join, hipEventDisableTiming));
 		lanes.back()->prim.stream = lanes.back()->stream;
+	}
+	for (auto &Lp : lanes) if (!Lp->arena.base) {                 // every lane's work space, once, while the device is idle (prim.hpp, LqArena)
+		size_t bytes = (size_t)anchor_budget * 104 / 9 * 8;          // (the lane's share of the HBM, less the head room DBuf adds)
+#ifdef LQ_EMU
+		bytes = std::min<size_t>(bytes, (size_t)64 << 20);        // (the test emulator fills fresh memory with a pattern)
+#endif
+		try { Lp->arena_buf.ensure(bytes); Lp->arena.base = Lp->arena_buf.as<char>(); Lp->arena.size = bytes; Lp->arena.used = 0; }
+		catch (const std::runtime_error &) { (void)hipGetLastError(); Lp->arena.base = nullptr; Lp->arena.size = 0; }   // (no room for it in one piece: the lane allocates buffer by buffer)
 	}
 	{
 		u32 npv = 0;

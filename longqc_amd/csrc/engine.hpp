@@ -156,14 +156,19 @@ struct MapLane {
 	DBuf sort_d, sort_dst, seg_info, walk_list, two_list, scr;
 	DBuf gsel, gkey, gsel2, gkey2, gstart, run_tiles, sel_tiles;
 	DBuf ivl, n_ivl, iv_q, iv_q2, iv_se, iv_se2, ivq_off, iv_scratch;
-	// hand every buffer back (they regrow on the next batch); the caller has drained the lane's streams
-	void release_buffers()
+	DBuf arena_buf; LqArena arena;        // the lane's work space (prim.hpp): its buffers are pieces of it, for the length of a batch
+	// every buffer of the lane, for the two functions below
+	template <class F> void each_buffer(F f)
 	{
 		for (DBuf *b : { &sens, &n_sens, &want, &sub_q, &sub_off, &sub_klib, &sort_cnt, &mhist, &ck_segs, &ck_T, &ck_E, &ck_S, &ck_slot, &ck_n, &prim.tmp, &A, &B, &R0, &segs0, &segs1, &n_segs, &hist, &begs, &tile_list, &two_tiles, &two_tile0, &two_tcnt, &two_m,
 		                 &sort_d, &sort_dst, &seg_info, &walk_list, &two_list, &scr, &gsel, &gkey, &gsel2, &gkey2, &gstart, &run_tiles, &sel_tiles,
-		                 &ivl, &n_ivl, &iv_q, &iv_q2, &iv_se, &iv_se2, &ivq_off, &iv_scratch }) b->release();
-		for (PsWork &W : ps) for (DBuf *b : { &W.big[0], &W.big[1], &W.fin_s, &W.fin_b, &W.plan, &W.gcnt, &W.gcur, &W.gdiff, &W.tmap }) b->release();
+		                 &ivl, &n_ivl, &iv_q, &iv_q2, &iv_se, &iv_se2, &ivq_off, &iv_scratch }) f(*b);
+		for (PsWork &W : ps) for (DBuf *b : { &W.big[0], &W.big[1], &W.fin_s, &W.fin_b, &W.plan, &W.gcnt, &W.gcur, &W.gdiff, &W.tmap }) f(*b);
 	}
+	// hand every buffer back (they regrow on the next batch); the caller has drained the lane's streams
+	void release_buffers() { each_buffer([](DBuf &b) { b.release(); }); arena.used = 0; arena.base = nullptr; arena.size = 0; arena_buf.release(); }
+	// a new batch starts with an empty arena: the pieces the last batch cut from it are forgotten
+	void drop_arena_buffers() { each_buffer([](DBuf &b) { if (b.in_arena) b.release(); }); arena.used = 0; }
 };
 
 struct lqcov_handle {

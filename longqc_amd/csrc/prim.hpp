@@ -25,10 +25,13 @@
 // lanes were inside long kernels).  A lane thread therefore names its stream in lq_alloc_stream and its buffers are taken
 // from and returned to HIP's stream-ordered pool (hipMallocAsync / hipFreeAsync, release threshold raised so that
 // returned blocks stay cached).
-// A lane's first pass writes a few per cent of its batch's seed hits, its second pass may hold many times that: a lane thread sets
-// lq_alloc_boost so that a work buffer that has to grow is sized for the largest batch the lane can meet at once -- one round of
-// allocations per lane instead of a second one in the middle of the mapping (hipMalloc waits for the device every time).
-inline thread_local double lq_alloc_boost = 1.0;
+// A mapping lane's work space: one block per lane, taken when the lanes are made (the device idle: hipMalloc waits for every
+// stream), from which the lane's buffers are cut one after the other while a batch is mapped -- no call into the runtime, nothing
+// handed back, nothing that another stream could be given while it is still in use.  The lane starts every batch with an empty
+// arena (MapLane::drop_arena_buffers): a buffer lives for one batch, like a fresh allocation.  What does not fit is allocated
+// the ordinary way.
+struct LqArena { char *base = nullptr; size_t size = 0, used = 0; };
+inline thread_local LqArena *lq_arena = nullptr;
 #ifndef LQ_EMU
 inline thread_local hipStream_t lq_alloc_stream = nullptr;
 inline void lq_pool_keep_memory(int device)
@@ -54,11 +57,17 @@ struct LqAllocTimer { std::chrono::steady_clock::time_point t0 = std::chrono::st
 struct DBuf {
 	void *p = nullptr; size_t cap = 0;
 	hipStream_t pool_stream = nullptr;     // not null: the block came from the stream-ordered pool on this stream
+	bool in_arena = false;                 // the block is a piece of the calling lane's arena (not freed, just forgotten)
 	void ensure(size_t bytes)
 	{
 		if (bytes <= cap) return;
 		release();
-		if (lq_alloc_boost > 1.0 && bytes >= ((size_t)1 << 20)) bytes = (size_t)((double)bytes * lq_alloc_boost);
+#ifndef LQ_EXACT_ALLOC
+		if (lq_arena && lq_arena->base) {
+			const size_t off = (lq_arena->used + 255) & ~(size_t)255, need = bytes + bytes / 8 + 256;
+			if (off + need <= lq_arena->size) { p = lq_arena->base + off; lq_arena->used = off + need; cap = need; in_arena = true; return; }
+		}
+#endif
 		LqAllocTimer alloc_timer(bytes);
 		size_t want = bytes + bytes / 8 + 256;
 #ifdef LQ_EXACT_ALLOC
@@ -96,6 +105,7 @@ struct DBuf {
 	}
 	void release()
 	{
+		if (in_arena) { p = nullptr; cap = 0; in_arena = false; return; }
 		if (p) {
 #ifndef LQ_EMU
 			if (pool_stream) (void)hipFreeAsync(p, lq_alloc_stream ? lq_alloc_stream : pool_stream);
@@ -106,7 +116,7 @@ struct DBuf {
 		p = nullptr; cap = 0; pool_stream = nullptr;
 	}
 	template <class T> T *as() const { return (T*)p; }
-	void swap(DBuf &o) { std::swap(p, o.p); std::swap(cap, o.cap); std::swap(pool_stream, o.pool_stream); }
+	void swap(DBuf &o) { std::swap(p, o.p); std::swap(cap, o.cap); std::swap(pool_stream, o.pool_stream); std::swap(in_arena, o.in_arena); }
 	~DBuf() { release(); }
 	DBuf() {}
 	DBuf(const DBuf&) = delete; DBuf &operator=(const DBuf&) = delete;
