@@ -1764,13 +1764,22 @@ void lqcov_handle::map_part(Part &pt)
 		LQ_HIP_CHECK(hipEventCreateWithFlags(&lanes.back()->ev_join, hipEventDisableTiming));
 		lanes.back()->prim.stream = lanes.back()->stream;
 	}
-	for (auto &Lp : lanes) if (!Lp->arena.base) {                 // every lane's work space, once, while the device is idle (prim.hpp, LqArena)
-		size_t bytes = (size_t)anchor_budget * 104 / 9 * 8;          // (the lane's share of the HBM, less the head room DBuf adds)
+	{	// every lane's work space (prim.hpp, LqArena): as much as its largest batch of this part can need, taken while the device is
+		// idle -- from the stream-ordered pool (one block, handed back only when the lanes go: plain hipMalloc of tens of gigabytes
+		// takes seconds here, 30 ms per GB measured)
+		size_t need = (size_t)std::min<u64>(anchor_budget, std::max<u64>(nA_total, 1)) * 104 / 9 * 8 + ((size_t)16 << 20);
 #ifdef LQ_EMU
-		bytes = std::min<size_t>(bytes, (size_t)64 << 20);        // (the test emulator fills fresh memory with a pattern)
+		need = std::min<size_t>(need, (size_t)64 << 20);            // (the test emulator fills fresh memory with a pattern)
 #endif
-		try { Lp->arena_buf.ensure(bytes); Lp->arena.base = Lp->arena_buf.as<char>(); Lp->arena.size = bytes; Lp->arena.used = 0; }
-		catch (const std::runtime_error &) { (void)hipGetLastError(); Lp->arena.base = nullptr; Lp->arena.size = 0; }   // (no room for it in one piece: the lane allocates buffer by buffer)
+		for (auto &Lp : lanes) if (Lp->arena.size < need) {
+			Lp->drop_arena_buffers();
+			Lp->arena.base = nullptr; Lp->arena.size = 0; Lp->arena.used = 0;
+			lq_alloc_stream = stream;
+			struct AllocGuard { ~AllocGuard() { lq_alloc_stream = nullptr; } } alloc_guard;
+			try { Lp->arena_buf.ensure(need); Lp->arena.base = Lp->arena_buf.as<char>(); Lp->arena.size = need; }
+			catch (const std::runtime_error &) { (void)hipGetLastError(); }   // (no room for it in one piece: the lane allocates buffer by buffer)
+		}
+		LQ_HIP_CHECK(hipStreamSynchronize(stream));
 	}
 	{
 		u32 npv = 0;
