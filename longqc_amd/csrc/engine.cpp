@@ -1776,7 +1776,7 @@ void lqcov_handle::map_part(Part &pt)
 			Lp->arena.base = nullptr; Lp->arena.size = 0; Lp->arena.used = 0;
 			lq_alloc_stream = stream;
 			struct AllocGuard { ~AllocGuard() { lq_alloc_stream = nullptr; } } alloc_guard;
-			try { Lp->arena_buf.ensure(need); Lp->arena.base = Lp->arena_buf.as<char>(); Lp->arena.size = need; }
+			try { Lp->arena_buf.ensure(need); Lp->arena.base = Lp->arena_buf.as<char>(); Lp->arena.size = Lp->arena_buf.cap; }
 			catch (const std::runtime_error &) { (void)hipGetLastError(); }   // (no room for it in one piece: the lane allocates buffer by buffer)
 		}
 		LQ_HIP_CHECK(hipStreamSynchronize(stream));

@@ -64,7 +64,7 @@ struct DBuf {
 		release();
 #ifndef LQ_EXACT_ALLOC
 		if (lq_arena && lq_arena->base) {
-			const size_t off = (lq_arena->used + 255) & ~(size_t)255, need = bytes + bytes / 8 + 256;
+			const size_t off = (lq_arena->used + 255) & ~(size_t)255, need = bytes + 256;   // (no head room here: the arena is the lane's whole share, 104 B per anchor of its largest batch, and a piece lives for one batch)
 			if (off + need <= lq_arena->size) { p = lq_arena->base + off; lq_arena->used = off + need; cap = need; in_arena = true; return; }
 		}
 #endif
