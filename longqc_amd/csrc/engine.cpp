@@ -1771,7 +1771,13 @@ void lqcov_handle::map_part(Part &pt)
 #ifdef LQ_EMU
 		need = std::min<size_t>(need, (size_t)64 << 20);            // (the test emulator fills fresh memory with a pattern)
 #endif
-		for (auto &Lp : lanes) if (Lp->arena.size < need) {
+		// (only where the first pass leaves a small part of the hits: a batch whose first pass fills the lane's share by itself --
+		// ultra-long reads keep a third of their hits -- needs its buffers again in the second pass, and pieces of an arena are not
+		// given back: there the lanes allocate buffer by buffer, grow-only, as before)
+		const u64 group_hits = opt && pt.plan.bucketed ? h_aq[pt.plan.q_end] - h_aq[pt.plan.q_begin] : 0;
+		const bool few = opt && pt.plan.bucketed && pt.plan.q_begin == 0 && pt.plan.n_written * 4 <= group_hits;
+		if (!few) for (auto &Lp : lanes) if (Lp->arena.base) { Lp->drop_arena_buffers(); Lp->arena.base = nullptr; Lp->arena.size = 0; Lp->arena_buf.release(); }
+		if (few) for (auto &Lp : lanes) if (Lp->arena.size < need) {
 			Lp->drop_arena_buffers();
 			Lp->arena.base = nullptr; Lp->arena.size = 0; Lp->arena.used = 0;
 			lq_alloc_stream = stream;
