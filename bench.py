@@ -466,8 +466,10 @@ def main():
                 want = roof_k.replace(">", "")                           # "k_ps_finish<8192" matches "k_ps_finish<8192, 1024, 10, unsigned int>"
                 hit = [v for k, v in kk.items() if k == roof_k or k.startswith(want + ",") or k.startswith(want + ">") or (("<" not in want) and k.split("<")[0] == want)]
                 if hit:
-                    roof["traffic"] = round(hit[0]["hbm_bytes_per_launch"] / 1e9, 3)
-                    roof["traffic_unit"] = "GB per launch (PMC: (2*FETCH_SIZE+WRITE_SIZE)*1024, from the committed %s, not from this run)" % os.path.basename(fn)
+                    nd = sum(v["dispatches"] for v in hit)                     # (a kernel with several shapes: all its launches)
+                    roof["traffic"] = round(sum(v["hbm_bytes_per_launch"] * v["dispatches"] for v in hit) / max(nd, 1) / 1e9, 3)
+                    roof["traffic_unit"] = ("GB per launch (PMC: (2*FETCH_SIZE+WRITE_SIZE)*1024 over %d launches, from the committed %s -- separate rocprofv3 --pmc passes "
+                                            "of this workload at an earlier commit of the same kernels, not from this run)" % (nd, os.path.basename(fn)))
                     break
         line = {
             "metric": "Mbases/sec all-vs-all overlap coverage (sampleqc hot path)", "value": round(value, 3), "unit": "Mbases/s",
