@@ -140,7 +140,7 @@ class PartRunner:
     accumulators; `finalize()` imports them into the handle so that lqcov_finish() produces the rows."""
 
     @staticmethod
-    def scaling_model(world: int, part_bases, upload_s_per_gbase=0.0065, sketch_s_per_gbase=0.013, index_s_per_gbase=0.030, map_s_per_gbase=0.19) -> float:
+    def scaling_model(world: int, part_bases, upload_s_per_gbase=0.0065, sketch_s_per_gbase=0.0134, index_s_per_gbase=0.014, map_s_per_gbase=0.075) -> float:
         """seconds per job predicted for `world` GPUs: rounds of `world` consecutive parts, a round lasts as long as its largest
         part takes on one GPU (front + mapping of every query; the exchange is a few KB per part).  Same MI355X figures as
         QueryShardRunner.scaling_model."""
@@ -333,11 +333,11 @@ class QueryShardRunner:
         return anchors
 
     @staticmethod
-    def scaling_model(world: int, part_bases, upload_s_per_gbase=0.0065, sketch_s_per_gbase=0.013, index_s_per_gbase=0.030, map_s_per_gbase=0.19,
+    def scaling_model(world: int, part_bases, upload_s_per_gbase=0.0065, sketch_s_per_gbase=0.0134, index_s_per_gbase=0.014, map_s_per_gbase=0.075,
                       link_gbytes_per_s=153.0, minimizers_per_base=1.0 / 3.0, pipelined=True) -> float:
-        """seconds per job predicted for `world` GPUs (the defaults: MI355X figures measured at configs[2] in round 4 -- upload 26 ms,
-        sketch 52 ms, index build incl. sort and table 120 ms, mapping incl. the survivor count 0.75 s per 4.0 Gbases; ring
-        all-gather bound by one xGMI link).  tools/scale.sh prints it beside what it measures."""
+        """seconds per job predicted for `world` GPUs (the defaults: MI355X figures measured at configs[2] in round 5 -- upload 26 ms,
+        sketch 53.5 ms, index build incl. sort, run heads, table and name work 57 ms, seed plan + mapping 0.30 s per 4.0 Gbases
+        and 5000 queries; ring all-gather bound by one xGMI link).  tools/scale.sh prints it beside what it measures."""
         t, prev_map = 0.0, None
         for b in part_bases:
             g = b / 1e9

@@ -155,14 +155,19 @@ def test_query_sharded_parts_in_a_pipeline_equal_reference_table(emu_lib, tmp_pa
 
 
 def test_scaling_model_of_the_pipelined_parts():
-    """configs[3] (25 parts of 4 Gbases): the front of a part (all-gather + replicated index build) does not shrink with N like its
-    mapping does; putting the fronts under the mappings helps, index parts across the GPUs help more when there are parts enough"""
+    """configs[3] (25 parts of 4 Gbases) with round 5's stage rates: the front of a part (all-gather at one xGMI link + the
+    replicated index build: 0.19 s) does not shrink with N and is now longer than the part's mapping on ONE GPU's eighth of the
+    queries (0.30 s / 8), so sharded queries stop near 1.6x; putting the fronts under the mappings still helps, index parts
+    across the GPUs help more when there are parts enough"""
     parts = [4.0e9] * 25
     t1 = multigpu.QueryShardRunner.scaling_model(1, parts)
     q8, q8_serial = multigpu.QueryShardRunner.scaling_model(8, parts, pipelined=True), multigpu.QueryShardRunner.scaling_model(8, parts, pipelined=False)
-    assert q8 < 0.8 * q8_serial and 2.5 < t1 / q8 < 3.5              # bound by the replicated front: all-gather + index build per part
+    assert q8 < 0.9 * q8_serial and 1.3 < t1 / q8 < 2.0              # bound by the replicated front: all-gather + index build per part
     p8 = multigpu.PartRunner.scaling_model(8, parts)
-    assert t1 / p8 > 4.5 and p8 < q8                                  # 25 parts over 8 GPUs: four rounds -- the split bench.py then picks
+    assert t1 / p8 > 4.0 and p8 < q8                                  # 25 parts over 8 GPUs: four rounds -- the split bench.py then picks
+    two = [4.0e9, 1.18e9]                                             # configs[2]: two parts cannot fill eight GPUs, queries are sharded
+    assert multigpu.QueryShardRunner.scaling_model(8, two) < multigpu.PartRunner.scaling_model(8, two)
+    assert abs(multigpu.QueryShardRunner.scaling_model(1, two) - 0.539) < 0.05   # the single-GPU step the rates were read from
 
 
 def test_balanced_ranges_and_query_shards():
