@@ -89,6 +89,33 @@ def cpu_baseline(cfg_name, F, Q, n_t, n_q):
                        % (n_t, sub_t.n_bases / 1e6, n_q))}
 
 
+def copy_ceiling(local):
+    """What a plain device copy reaches on this box ("also report against a measured device-copy ceiling"): bytes read +
+    written per second of a 2-GiB torch copy on cuda:<local>, best of five, with nothing else on the device.  None if it cannot run."""
+    try:
+        import torch
+        n = 1 << 31
+        dev = torch.device("cuda", local)
+        a = torch.zeros(n, dtype=torch.uint8, device=dev)
+        b = torch.empty_like(a)
+        b.copy_(a)
+        torch.cuda.synchronize(dev)
+        best = None
+        for _ in range(5):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            b.copy_(a)
+            e1.record()
+            e1.synchronize()
+            ms = e0.elapsed_time(e1)
+            best = ms if best is None else min(best, ms)
+        del a, b
+        torch.cuda.empty_cache()
+        return round(2.0 * n / (best / 1e3) / 1e9, 1) if best and best > 0 else None
+    except Exception:
+        return None
+
+
 def golden_check(cfg_name, table_text):
     """rows of the reference itself for 40 of the queries, made on the whole read set in the build container
     (tests/golden/make_scale_golden.py); None if the fixture is not there or the run is not the full config"""
@@ -505,6 +532,11 @@ def main():
         if one_dev:
             line["note"] = "LQCOV_BENCH_ONE_DEVICE test mode: all ranks share cuda:0 over gloo; not a scaling measurement"
     eng.close()
+    if rank == 0 and world == 1 and have_cuda and line.get("roofline"):
+        cc = copy_ceiling(local)                                                  # (the engine is closed: the device is idle)
+        if cc:
+            line["roofline"]["measured_copy_ceiling"] = {"GB/s": cc, "frac_of_it": round(line["roofline"]["achieved"] / cc, 4),
+                                                         "what": "bytes read + written per second of a 2-GiB device-to-device copy on this box, best of 5"}
     if rank == 0 and world == 1 and not args.no_end_to_end:
         # The drop-in call as LongQC issues it (INTEGRATION.md level 1 / 2): files in, table out -- FASTA/Q parse (targets: plain
         # FASTA on tmpfs, parsed from the mapping by the host's cores; queries: FASTQ), 2-bit packing, upload, every part, rows,
