@@ -631,6 +631,42 @@ def test_emulated_filter_drops_chance_hits(emu_lib, tmp_path):
     check_filter_drops_chance_hits(emu_lib, tmp_path)
 
 
+def check_filter_thresholds(lib, tmp_path, monkeypatch):
+    """the filter's threshold n_min = max(-n, ceil(-m / k)) from 2 to 15 (pair counters and 4-bit bins saturate at 15; the seven-bin
+    window is exact up to 4 and lets a stretch that reaches its edge pass beyond), 16 and 1 (no filter possible): the reference's rows
+    each time, with the default geometry and with few pair counters / histogram words (pairs that alias, pairs left without bins)"""
+    import dataclasses
+    from longqc_amd import synth
+    cfg = dataclasses.replace(synth.CONFIGS["cfg3"], n_reads=500, nsample=20, depth=8.0, mean_len=2500)
+    T, Q = synth.make_dataset(cfg)
+    tf, qf = str(tmp_path / "all.fq"), str(tmp_path / "sub.fq")
+    synth.write_fastq(tf, T); synth.write_fastq(qf, Q)
+    seen = set()
+    for n, m, filtered in ((2, 20, True), (5, 40, True), (3, 100, True), (15, 40, True), (16, 40, False), (1, 10, False)):
+        argv = ["-Y", "-l", "0", "-q", "160", "-k", "12", "-w", "5", "-I", "4G", "-p", "160", "-n", str(n), "-m", str(m), tf, qf]
+        want = oracle_bind.ref_table(argv) if oracle_bind.have_ref() else oracle_bind.table(argv)
+        seen.add(want)
+        for env in ({}, {"LQCOV_SEED_BUCKET": "300", "LQCOV_SEED_PAIR_BITS": "3", "LQCOV_SEED_HWORDS": "40", "LQCOV_SEED_SEGL": "50"}):
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            p, _, _ = api.parse_args(argv)
+            eng = api.Engine(p, 0, lib=lib)
+            out = str(tmp_path / "o.tsv")
+            eng.run_files(tf, qf, out=out, err=str(tmp_path / "e.log"))
+            st, emitted = eng.map_stats(), eng.last_n_anchors
+            eng.close()
+            for k in env:
+                monkeypatch.delenv(k)
+            assert open(out).read() == want, (n, m, env)
+            if not env:
+                assert (st["last_written"] < emitted) == filtered, (n, m, st, emitted)
+    assert len(seen) >= 4                           # (the thresholds do change the rows: the comparison is not vacuous)
+
+
+def test_emulated_filter_thresholds(emu_lib, tmp_path, monkeypatch):
+    check_filter_thresholds(emu_lib, tmp_path, monkeypatch)
+
+
 def _pileup_dataset(tmp_path, n_targets, seed=7, n_hot=2, qlen=900):
     """`n_hot` queries buried under `n_targets` pieces of themselves (half of the pieces of the first query start at one and
     the same base, so that the counter of one minimizer climbs fastest), plus one query nothing matches"""
