@@ -5,6 +5,7 @@ klib-order sort walk, chaining and coverage arithmetic -- not the GPU execution 
 tests do that through the real liblqcov.so)."""
 import json
 import os
+import re
 
 import numpy as np
 import pytest
@@ -598,7 +599,7 @@ OBS_ENVS_EMU = [{"LQCOV_SEED_BUCKET": "3000", "LQCOV_SEED_DCAP": "300", "LQCOV_S
                 {"LQCOV_SEED_SURV_MAX": "1000", "LQCOV_SEED_CHUNK": "4000"}]      # (the plan holds a chunk or two at a time: the part's queries are mapped in groups)
 
 
-@pytest.mark.parametrize("env", [pytest.param(e, marks=slow_emu) if "LQCOV_TIES" in e else e for e in OBS_ENVS_EMU], ids=lambda e: "+".join("%s=%s" % kv for kv in e.items()) or "default")
+@pytest.mark.parametrize("env", [pytest.param(e, marks=slow_emu) if "LQCOV_TIES" in e or "LQCOV_SEED_BIGCAP" in e else e for e in OBS_ENVS_EMU], ids=lambda e: "+".join("%s=%s" % kv for kv in e.items()) or "default")
 def test_emulated_observable_ties_scheme(emu_lib, tmp_path, monkeypatch, env):
     err = check_observable_ties_scheme(emu_lib, tmp_path, monkeypatch, 2 + len(env), env, small=True)
     if "LQCOV_TIES" not in env:
@@ -631,7 +632,7 @@ def test_emulated_filter_drops_chance_hits(emu_lib, tmp_path):
     check_filter_drops_chance_hits(emu_lib, tmp_path)
 
 
-def check_filter_thresholds(lib, tmp_path, monkeypatch):
+def check_filter_thresholds(lib, tmp_path, monkeypatch, capfd):
     """the filter's threshold n_min = max(-n, ceil(-m / k)) from 2 to 15 (pair counters and 4-bit bins saturate at 15; the seven-bin
     window is exact up to 4 and lets a stretch that reaches its edge pass beyond), 16 and 1 (no filter possible): the reference's rows
     each time, with the default geometry and with few pair counters / histogram words (pairs that alias, pairs left without bins)"""
@@ -642,11 +643,15 @@ def check_filter_thresholds(lib, tmp_path, monkeypatch):
     tf, qf = str(tmp_path / "all.fq"), str(tmp_path / "sub.fq")
     synth.write_fastq(tf, T); synth.write_fastq(qf, Q)
     seen = set()
-    for n, m, filtered in ((2, 20, True), (5, 40, True), (3, 100, True), (15, 40, True), (16, 40, False), (1, 10, False)):
+    big = {"LQCOV_SEED_BUCKET": "3000", "LQCOV_SEED_DCAP": "300", "LQCOV_SEED_BIGCAP": "1500", "LQCOV_SEED_PAIR_BITS": "4"}   # buckets decided in passes, the largest by pairs only
+    for n, m, filtered in ((2, 20, True), (3, 40, True), (5, 40, True), (3, 100, True), (15, 40, True), (16, 40, False), (1, 10, False)):
         argv = ["-Y", "-l", "0", "-q", "160", "-k", "12", "-w", "5", "-I", "4G", "-p", "160", "-n", str(n), "-m", str(m), tf, qf]
         want = oracle_bind.ref_table(argv) if oracle_bind.have_ref() else oracle_bind.table(argv)
         seen.add(want)
-        for env in ({}, {"LQCOV_SEED_BUCKET": "300", "LQCOV_SEED_PAIR_BITS": "3", "LQCOV_SEED_HWORDS": "40", "LQCOV_SEED_SEGL": "50"}):
+        for env in ({}, {"LQCOV_SEED_BUCKET": "300", "LQCOV_SEED_PAIR_BITS": "3", "LQCOV_SEED_HWORDS": "40", "LQCOV_SEED_SEGL": "50"}, big):
+            if env is big:
+                monkeypatch.setenv("LQCOV_SEED_STATS", "1")
+                capfd.readouterr()
             for k, v in env.items():
                 monkeypatch.setenv(k, v)
             p, _, _ = api.parse_args(argv)
@@ -658,13 +663,19 @@ def check_filter_thresholds(lib, tmp_path, monkeypatch):
             for k in env:
                 monkeypatch.delenv(k)
             assert open(out).read() == want, (n, m, env)
+            if env is big:
+                monkeypatch.delenv("LQCOV_SEED_STATS")
+                if filtered:                        # "... N buckets beyond the block (M of them by pairs only) ..."
+                    log = capfd.readouterr().err   # (the counters go to the process's stderr, not to the call's log)
+                    mt = re.search(r"(\d+) buckets beyond the block \((\d+) of them by pairs only\)", log)
+                    assert mt and int(mt.group(1)) > int(mt.group(2)) > 0, log[-600:]
             if not env:
                 assert (st["last_written"] < emitted) == filtered, (n, m, st, emitted)
     assert len(seen) >= 4                           # (the thresholds do change the rows: the comparison is not vacuous)
 
 
-def test_emulated_filter_thresholds(emu_lib, tmp_path, monkeypatch):
-    check_filter_thresholds(emu_lib, tmp_path, monkeypatch)
+def test_emulated_filter_thresholds(emu_lib, tmp_path, monkeypatch, capfd):
+    check_filter_thresholds(emu_lib, tmp_path, monkeypatch, capfd)
 
 
 def _pileup_dataset(tmp_path, n_targets, seed=7, n_hot=2, qlen=900):
