@@ -593,8 +593,3 @@ def test_gpu_executables_as_subprocesses(gpu_lib, tmp_path):
     names, _, _ = read_fastx(TINY_ARGV[-2])
     assert [l.split("\t")[0] for l in rows] == list(names)
     assert r.stdout.decode() == read_gz("tiny_all.sdust.gz")       # (what the reference's sdust printed: tests/golden/make_sdust_golden.py)
-
-
-def test_gpu_filter_thresholds(gpu_lib, tmp_path, monkeypatch, capfd):
-    """-n / -m from a filter threshold of 2 to 15, 16 and 1 (no filter): the reference's rows each time (kernels_seed.hpp)"""
-    E.check_filter_thresholds(gpu_lib, tmp_path, monkeypatch, capfd)
