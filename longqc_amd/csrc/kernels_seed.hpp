@@ -22,8 +22,10 @@
 //   (scan)          -> where every (query, slice, segment) piece starts: the buckets (query, slice) are contiguous
 //   k_seed_scatter  the lists once more; every hit becomes an 8-byte record {rid, relative strand, diagonal, minimizer} and
 //                   goes to its bucket -- a tile of records is sorted by slice in LDS and leaves as runs
-//   k_seed_decide   per bucket: the records in registers, pair counters and hashed diagonal-bin counters in LDS (one fresh
-//                   table per bucket: no aliasing inside a pair, bins as wide as the band), survivors compacted in place
+//   k_seed_decide   per bucket: the records in registers, 16-bit pair counters in LDS; every pair that holds n_min hits gets a
+//                   histogram of 4-bit diagonal bins as long as its diagonals can be, private to the pair (nothing aliases;
+//                   bins wider than the band); a record counts itself in, then reads the bins around its own; survivors
+//                   compacted in place.  Buckets beyond a block's registers: k_seed_decide_big, in passes over their targets
 //   k_seed_collect  survivors of all buckets, dense, in (query, slice) order: the part's seed plan keeps them
 //   k_seed_emit_s   (when a batch is mapped) survivors -> anchors (lqmap.c:190-197)
 // Everything is deterministic: ranks come from wave-private counts scanned in (slice, wave) order, never from the order in
