@@ -101,10 +101,9 @@ k_sort_walk_reg(const SortSeg *segs, const u32 *list, const u32 *n_list_p, const
 			LQ_WALK_LANE_INIT(vcur, g, b); LQ_WALK_LANE_INIT(vend, g, bg[c] + cnt[c]); LQ_WALK_LANE_INIT(vwin, g, dq);
 		}
 		LQ_BLOCK_SYNC();
-#ifdef LQ_EMU
-		if (lane == 0)
-#endif
-		{
+		{	// wave-uniform: every lane runs the walk, the state sits in the lanes of registers.  (The test emulator runs the same
+			// code on every fiber of the wave: the first one scheduled does the work on the shared "registers", the others find
+			// every bucket finished -- or the next checkpoint's slot reached -- and leave.)
 			u32 k = 0;
 			for (;;) {
 				// START: next bucket with unread slots; the element under its cursor is picked up, leaving a hole there
