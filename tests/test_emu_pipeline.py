@@ -762,3 +762,15 @@ def check_saturated_counters_are_replayed(lib, tmp_path, monkeypatch, bits, n_ta
 @pytest.mark.parametrize("bits,n_targets,parts,env", [(5, 300, "4G", ""), (5, 400, "40K", "LQCOV_TIES=klib")], ids=["one_part", "parts_all_klib"])
 def test_emulated_saturated_counters_are_replayed(emu_lib, tmp_path, monkeypatch, bits, n_targets, parts, env):
     check_saturated_counters_are_replayed(emu_lib, tmp_path, monkeypatch, bits, n_targets, parts, env)
+
+
+def test_fuzz_tool_runs_a_case(emu_lib):
+    """tools/fuzz_emu.py (random read sets, argv and knobs; the emulator build's table against the reference binary's): one seed of
+    the campaign recorded in profiles/README.md still comes out identical"""
+    import subprocess
+    import sys
+    if not oracle_bind.have_ref():
+        pytest.skip("needs the reference binary (oracle/_ref)")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_emu.py"), "--one", "1"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0 and "identical (20 rows" in r.stdout, r.stdout[-2000:]
