@@ -147,19 +147,23 @@ public:
 				if (!e) { out.stream_over = true; last_char = 0; pos = n; break; }        // no quality string: kseq returns -2
 				pos = (u64)(e - p) + 1;
 			}
-			u64 qlen = 0; bool got_any_line = false;
+			// kseq appends every quality line to the string so far and then drops ONE trailing '\r' of that whole string if it is
+			// longer than one character (kseq.h:98-99, append mode) -- so an empty line after a line that ended in "\r\r" drops
+			// the second one.  Only the length matters here: qlen and the number of '\r' the string so far ends with.
+			u64 qlen = 0, trail = 0;
 			const u64 want = own ? r.seq_len : s_len;
 			for (;;) {                                                  // while (until_(qual) && qual.size() < seq.size())
 				if (pos >= n) break;
 				const u8 *e = (const u8*)memchr(p + pos, '\n', n - pos);
 				const u64 l1 = e ? (u64)(e - p) : n;
+				u64 t = 0;
+				while (t < l1 - pos && p[l1 - 1 - t] == '\r') ++t;
+				trail = (t == l1 - pos) ? trail + t : t;
 				qlen += l1 - pos;
-				if (qlen > 1 && l1 > pos && p[l1 - 1] == '\r') --qlen;
-				got_any_line = true;
+				if (qlen > 1 && trail > 0) { --qlen; --trail; }
 				pos = e ? l1 + 1 : n;
 				if (qlen >= want) break;
 			}
-			(void)got_any_line;
 			last_char = 0;
 			if (qlen != want) { out.stream_over = true; break; }         // truncated quality: kseq returns -2, the stream ends
 			out.recs.push_back(r);

@@ -112,6 +112,31 @@ def run_one(seed: int, keep: str = "", verbose: bool = False) -> int:
             print("  knobs replaced: %s" % env, flush=True)
         os.environ.update(env)
         lib = api.load_library(emu)
+        # a third of the cases go through an index file (sampleqc --db, longQC.py:266-277): the engine writes one with -d and maps from
+        # it, or maps from the one the reference wrote; the reference's table from its own file is the same `want` (checked)
+        via = seed % 3 if "-I" in argv or seed % 2 else 0
+        if via:
+            import subprocess
+            kw = [a for i, a in enumerate(argv) if a in ("-k", "-w", "-H", "-I") or (i and argv[i - 1] in ("-k", "-w", "-I"))]
+            # (the mapping call keeps -k / -w / -H: the reference sizes its match counters from the command line's sketch,
+            # minimap2-coverage.c:419-422, and writes past them when the index file's parameters yield more minimizers)
+            rest = [a for i, a in enumerate(argv) if not (a == "-I" or (i and argv[i - 1] == "-I"))]
+            mmi_ref, mmi_own = os.path.join(d, "ref.mmi"), os.path.join(d, "own.mmi")
+            r = subprocess.run([oracle_bind.REF_BIN] + kw + ["-d", mmi_ref, tf], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+            if r.returncode != 0:
+                return 2
+            want2 = oracle_bind.ref_table(rest + [mmi_ref, qf])
+            if want2 != want:                       # (the reference itself: mapping from its dump = mapping from the reads)
+                print("seed %d: the reference's table from its own index file differs from its table from the reads" % seed)
+                return 1
+            if via == 1:
+                rc, out, err = run_main(lib, kw + ["-d", mmi_own, tf])
+                if rc != 0:
+                    print("seed %d DIFFERS: -d failed (rc %d): %s" % (seed, rc, err[-500:]))
+                    return 1
+            full = rest + [mmi_own if via == 1 else mmi_ref, qf]
+            if verbose:
+                print("  through an index file written by %s" % ("the engine" if via == 1 else "the reference"), flush=True)
         rc, out, err = run_main(lib, full)
         if rc == 0 and out == want:
             if verbose:
