@@ -86,6 +86,7 @@ def free_port():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seeds", default="0:12")
+    ap.add_argument("--limit", type=int, default=600, help="seconds per case")
     args = ap.parse_args()
     import numpy as np
     import torch.multiprocessing as mp
@@ -98,6 +99,8 @@ def main():
         cfg = dataclasses.replace(synth.CONFIGS["cfg2"], n_reads=int(rng.integers(40, 260)), mean_len=int(rng.integers(400, 2500)), min_len=int(rng.integers(50, 300)),
                                   depth=float(rng.choice([3, 8, 20, 60])), err=float(rng.choice([0.02, 0.08, 0.13])), seed=9000 + seed, nsample=int(rng.integers(4, 25)),
                                   qual=str(rng.choice(["ont", "none"])), junk_frac=float(rng.choice([0.0, 0.05])))
+        if cfg.genome_len < 12000:                 # (a genome of a few kb is one tandem repeat away from a mid_occ of thousands: millions of seed hits,
+            cfg = dataclasses.replace(cfg, depth=max(1.5, cfg.n_reads * cfg.mean_len / 12000.0))   # minutes per case on the emulator; tools/fuzz_emu.py has those)
         T, Q = synth.make_dataset(cfg)
         world = int(rng.choice([2, 2, 3]))
         mode = str(rng.choice(["parts", "queries", "queries_pipeline"]))
@@ -113,7 +116,13 @@ def main():
             synth.write_fastq(tf, T); synth.write_fastq(qf, Q)
             want = oracle_bind.ref_table(argv + [tf, qf])
             try:
-                mp.spawn(worker, args=(world, free_port(), mode, argv, tf, qf, out), nprocs=world, join=True)
+                ctx = mp.spawn(worker, args=(world, free_port(), mode, argv, tf, qf, out), nprocs=world, join=False)
+                deadline = time.time() + args.limit
+                while not ctx.join(timeout=1.0):
+                    if time.time() > deadline:
+                        for pr in ctx.processes:
+                            pr.kill()
+                        raise TimeoutError("not finished within %d s" % args.limit)
                 got = open(out).read()
             except Exception as e:
                 got = "EXCEPTION %r" % (e,)
