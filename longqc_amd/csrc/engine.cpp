@@ -97,7 +97,8 @@ void Knobs::read_env()
 	ps_shift = (u32)std::min<long>(12, std::max<long>(0, num("LQCOV_PS_SHIFT", 0)));
 	reg_walker = !is("LQCOV_WALK", "solo");
 	ckpt = !is("LQCOV_CKPT", "0");
-	ckpt3 = num("LQCOV_CKPT3", 0) > 0;
+	ckpt3 = num("LQCOV_CKPT3", 1) > 0;
+	ck_unit = (u32)std::max<long long>(num("LQCOV_CK_UNIT", 16384), 64); ck_unit_many = (u32)std::max<long long>(num("LQCOV_CK_UNIT_MANY", 4096), 64);
 	sort_tile = (u32)std::max<long>(0, num("LQCOV_SORT_TILE", 0)); if (sort_tile && sort_tile < 64) sort_tile = 64;
 	walk_shift = (u32)std::min<long>(16, std::max<long>(0, num("LQCOV_WALK_SHIFT", 0)));
 	walk_grid = (u32)std::max<long>(64, num("LQCOV_WALK_GRID", 1L << 18));
@@ -1250,7 +1251,7 @@ void lqcov_handle::sort_batch(MapLane &L, Part &pt, const u64 *aqb, const u32 *q
 		u32 *hx = (u32*)L.scr.p, *py = (u32*)((u8*)L.scr.p + nA4);
 		const u32 tile = K.sort_tile ? K.sort_tile : LQ_SORT_TILE;
 		const u32 wgrid = K.walk_grid;
-		L.sort_d.ensure(nA + 64); L.sort_dst.ensure((nA + 1) * 4);
+		L.sort_d.ensure(nA + 256); L.sort_dst.ensure((nA + 1) * 4);
 		L.ck_n.ensure(16);
 		SortSeg *cur = L.segs0.as<SortSeg>(), *nxt = L.segs1.as<SortSeg>();
 		u32 cur_slot = LQ_C_KLIB0, nxt_slot = LQ_C_KLIB1;
@@ -1322,15 +1323,16 @@ void lqcov_handle::sort_batch(MapLane &L, Part &pt, const u64 *aqb, const u32 *q
 				const u32 max_buckets = shift == 56 ? 2 * (((pt.rs.n ? pt.rs.n - 1 : 0) >> 24) + 1) : max_digit + 1;
 				const bool any_walk = max_buckets > 2 || K.no_level_skip;
 				const bool ck_small = K.reg_walker && max_digit < LQ_CK_B;
-				const bool ck3 = ck_small || K.ckpt3;
+				const bool ck3 = ck_small || K.ckpt3;                             // (round 6: on by default for passes with many buckets too -- their states are found by sub-chains side by side, a 65-160 k walk took 8-21 ms whole)
 				const u64 n_ck_segs = K.ckpt ? (u64)(ck3 ? lenc[3] : 0) + lenc[4] : 0;
 				int first_plain_class = K.ckpt ? (ck3 ? 2 : 3) : LQ_WALK_CLASSES - 1;
 				bool w1 = false, w2 = false;                          // which walker streams got work
 				// (the checkpoint buffers are sized before the fork: a block that the lane's stream allocates after the event the walker
 				// streams wait for would not be ordered before their kernels)
-				const u32 ck_unit = std::max<u32>(16384u >> K.walk_shift, 8);
+				const u32 ck_unit = std::max<u32>((ck_small ? K.ck_unit : K.ck_unit_many) >> K.walk_shift, 8);
+				const u32 ck_quantum = ck_small ? 1u : (u32)LQ_CKM_Q;   // many buckets: checkpoints come in sub-chains of LQ_CKM_Q (k_ck_chain256)
 				const u32 ck_min_len = wcaps.c[ck3 ? 2 : 3] + 1;
-				const u64 cks_max = std::min<u64>(std::min<u64>(nA / ck_min_len + 1, ns), n_ck_segs), ck_max = nA / ck_unit + 2 * cks_max, tiles_max = nA / LQ_CK_TILE + cks_max;
+				const u64 cks_max = std::min<u64>(std::min<u64>(nA / ck_min_len + 1, ns), n_ck_segs), ck_max = nA / ck_unit + (2 + ck_quantum) * cks_max, tiles_max = nA / LQ_CK_TILE + cks_max;
 				const u32 per_ck = ck_small ? LQ_CK_B : 256;          // cursors per checkpoint
 				if (any_walk && n_ck_segs) {
 					L.ck_segs.ensure(cks_max * sizeof(CkSeg)); L.ck_S.ensure(ck_max * per_ck * 4); L.ck_slot.ensure(ck_max * 4 + 4);
@@ -1348,7 +1350,7 @@ void lqcov_handle::sort_batch(MapLane &L, Part &pt, const u64 *aqb, const u32 *q
 					const u32 unit = ck_unit;
 					const CkSeg *dck = L.ck_segs.as<CkSeg>();
 					const u32 *ckn = L.ck_n.as<u32>();
-					LQ_LAUNCH(k_ck_plan, 1, 256, sW, cur, wl, ns, cnt + LQ_C_WALK0, (int)ck3, unit, ck_small ? 512u : 64u, L.ck_segs.as<CkSeg>(), (u32)cks_max, L.ck_n.as<u32>()); check_launch();
+					LQ_LAUNCH(k_ck_plan, 1, 256, sW, cur, wl, ns, cnt + LQ_C_WALK0, (int)ck3, unit, ck_small ? 512u : 256u, ck_quantum, L.ck_segs.as<CkSeg>(), (u32)cks_max, L.ck_n.as<u32>()); check_launch();
 					const u32 g_ck = (u32)std::min<u64>(ck_max, wgrid), g_cks = (u32)std::min<u64>(cks_max, wgrid);
 					if (ck_small) {
 						{
@@ -1368,7 +1370,7 @@ void lqcov_handle::sort_batch(MapLane &L, Part &pt, const u64 *aqb, const u32 *q
 					} else {
 						{
 							StageTimer t(this, sW, "k_ck_chain256");
-							LQ_LAUNCH(k_ck_chain256, g_cks, 64, sW, dck, ckn, cur, dD, dH, dBg, L.ck_S.as<u32>(), L.ck_slot.as<u32>()); check_launch();
+							LQ_LAUNCH(k_ck_chain256, (u32)std::min<u64>(ck_max / LQ_CKM_Q + 1, wgrid), LQ_CKM_THREADS, sW, dck, ckn, cur, dD, dH, dBg, L.ck_S.as<u32>(), L.ck_slot.as<u32>()); check_launch();
 						}
 						{
 							StageTimer t(this, sW, "k_sort_walk_solo_ck");

@@ -31,7 +31,8 @@ struct Knobs {
 	bool all_klib = false;                // LQCOV_SORT=klib: every query through klib's passes, no bucket leaves them early
 	u32 ps_shift = 0;                     // LQCOV_PS_SHIFT: shrinks the size classes of the parallel sort (tests)
 	bool reg_walker = true;               // LQCOV_WALK=solo: no register-lane walker
-	bool ckpt = true, ckpt3 = false;      // LQCOV_CKPT=0: no checkpointed walks; LQCOV_CKPT3=1: also for the 65-160 k class of many-bucket passes
+	bool ckpt = true, ckpt3 = true;       // LQCOV_CKPT=0: no checkpointed walks; LQCOV_CKPT3=0: the 65-160 k class is walked whole
+	u32 ck_unit = 16384, ck_unit_many = 4096;   // LQCOV_CK_UNIT / LQCOV_CK_UNIT_MANY: elements per walker's piece, passes of up to 16 / up to 256 buckets
 	u32 sort_tile = 0;                    // LQCOV_SORT_TILE: anchors per tile of the sort's streaming kernels (0 = LQ_SORT_TILE)
 	u32 walk_shift = 0;                   // LQCOV_WALK_SHIFT: shrinks the walker size classes and the checkpoint spacing (tests)
 	u32 walk_grid = 1u << 18;             // LQCOV_WALK_GRID: cap on resident walker waves

@@ -435,7 +435,7 @@ __device__ __forceinline__ bool lq_chain_fill(AP a, const i64 n, IP f, IP p, IP 
 						sc -= (i32)((double)dd * .01 * (double)avg_qspan) + (log_dd >> 1);     // chain.c:67
 						sc += f[j];
 						bool brk = false;
-						if (watch_ties && tg.see((u32)a[j].x, sc, t[j] == (i32)i, max_f, n_skip)) band_tie = true;
+						if (watch_ties && tg.see((u32)a[j].x, sc, t[j] == (i32)i, max_f, n_skip)) return true;   // (the run is listed, not chained: nothing it would compute from here on is used)
 						if (sc > max_f) {
 							max_f = sc; max_j = j;
 							if (n_skip > 0) --n_skip;
@@ -451,7 +451,7 @@ __device__ __forceinline__ bool lq_chain_fill(AP a, const i64 n, IP f, IP p, IP 
 									if (dd2 > bw) continue;
 									const i32 md2 = dq2 < dr ? dq2 : (i32)dr;
 									const i32 sc2 = (md2 > q_span ? q_span : md2) - ((i32)((double)dd2 * .01 * (double)avg_qspan) + ((dd2 ? lq_ilog2_32((u32)dd2) : 0) >> 1)) + f[jj];
-									if (tg.raises(sc2)) band_tie = true;
+									if (tg.raises(sc2)) return true;
 								}
 							j = st;                                                   // leave the candidate loop
 						}
@@ -460,7 +460,7 @@ __device__ __forceinline__ bool lq_chain_fill(AP a, const i64 n, IP f, IP p, IP 
 				}
 				--j;
 			} else {
-				if (watch_ties && tg.bad()) band_tie = true;                      // the scan's last group
+				if (watch_ties && tg.bad()) return true;                          // the scan's last group
 				f[i] = max_f; p[i] = (i32)max_j;
 				v[i] = max_j >= 0 && v[max_j] > max_f ? v[max_j] : max_f;
 				++i; setup = true;
@@ -721,6 +721,50 @@ k_chain(const mm128 *A, const u64 *gstart, const u32 *glist, u32 n_list, const u
 // f, p, v are still written to global memory (the second half reads them); __syncthreads() in a block of one wave is a wait
 // for the wave's own memory operations.  The second half (chain ends, backtrack, regs, coverage) is the serial
 // lq_chain_finish on lane 0.
+// The wave's scans and the one-lane shift of the window as DPP operations (round 6).  __shfl_up is a ds_bpermute -- a trip through the
+// LDS crossbar, ~100 cycles when the next step waits for it -- and an anchor's step was two dependent scans of six such steps plus five
+// shifts: ~2000 cycles, a 30 000-anchor run 30 ms on one wave.  A DPP operand (row_shr within a row of 16, row_bcast:15 / :31 across
+// rows, wave_shr:1 -- gfx9's cross-lane modes) is read by the ALU instruction itself.  The emulator keeps the shuffles.
+#ifndef LQ_EMU
+#define LQ_DPP(fill, v, ctrl, rows, banks) __builtin_amdgcn_update_dpp((int)(fill), (int)(v), (ctrl), (rows), (banks), false)
+// lane l takes lane l - 1's value, lane 0 takes `fill`
+__device__ __forceinline__ i32 lq_wave_shr1(i32 v, i32 fill) { return LQ_DPP(fill, v, 0x138, 0xf, 0xf); }
+// inclusive prefix maximum over the wave
+__device__ __forceinline__ i32 lq_wave_scan_max(i32 v)
+{
+	const i32 NEG = (i32)0x80000000;
+	i32 o;
+	o = LQ_DPP(NEG, v, 0x111, 0xf, 0xf); v = o > v ? o : v;    // row_shr:1
+	o = LQ_DPP(NEG, v, 0x112, 0xf, 0xf); v = o > v ? o : v;    // row_shr:2
+	o = LQ_DPP(NEG, v, 0x114, 0xf, 0xf); v = o > v ? o : v;    // row_shr:4
+	o = LQ_DPP(NEG, v, 0x118, 0xf, 0xf); v = o > v ? o : v;    // row_shr:8
+	o = LQ_DPP(NEG, v, 0x142, 0xa, 0xf); v = o > v ? o : v;    // row_bcast:15 -> rows 1 and 3
+	o = LQ_DPP(NEG, v, 0x143, 0xc, 0xf); v = o > v ? o : v;    // row_bcast:31 -> rows 2 and 3
+	return v;
+}
+// inclusive scan of the maps x -> max(x + a, b) under composition (the earlier map first).  A lane without a source composes with
+// the identity (0, -2^29): "minus infinity" may come out as -2^29 + a few -- it is only ever compared with counts of at most 64
+#define LQ_WAVE_COMPOSE_STEP(ctrl, rows) do { \
+		const i32 oa_ = LQ_DPP(0, fa, ctrl, rows, 0xf), ob_ = LQ_DPP(-(1 << 29), fb, ctrl, rows, 0xf); \
+		const i32 nb_ = ob_ + fa; fb = nb_ > fb ? nb_ : fb; fa = oa_ + fa; } while (0)
+__device__ __forceinline__ void lq_wave_scan_compose(i32 &fa, i32 &fb)
+{
+	LQ_WAVE_COMPOSE_STEP(0x111, 0xf); LQ_WAVE_COMPOSE_STEP(0x112, 0xf); LQ_WAVE_COMPOSE_STEP(0x114, 0xf); LQ_WAVE_COMPOSE_STEP(0x118, 0xf);
+	LQ_WAVE_COMPOSE_STEP(0x142, 0xa); LQ_WAVE_COMPOSE_STEP(0x143, 0xc);
+}
+#define LQ_WAVE_LANE(v, l) ((i32)__builtin_amdgcn_readlane((int)(v), (int)(l)))     // l uniform
+#else
+static inline i32 lq_wave_shr1(i32 v, i32 fill) { const i32 o = __shfl_up(v, 1); return threadIdx.x == 0 ? fill : o; }
+static inline i32 lq_wave_scan_max(i32 v) { for (int d = 1; d < 64; d <<= 1) { const i32 o = __shfl_up(v, d); if ((int)threadIdx.x >= d && o > v) v = o; } return v; }
+static inline void lq_wave_scan_compose(i32 &fa, i32 &fb)
+{
+	for (int d = 1; d < 64; d <<= 1) {
+		const i32 oa = __shfl_up(fa, d), ob = __shfl_up(fb, d);
+		if ((int)threadIdx.x >= d) { const i32 nb = ob + fa; fb = nb > fb ? nb : fb; fa = oa + fa; }
+	}
+}
+#define LQ_WAVE_LANE(v, l) __shfl((v), (int)(l))
+#endif
 #define LQ_CHAIN_WAVE_MIN 48      // measured on MI355X at configs[1]: 192 -> 206 ms, 96 -> 193, 48 -> 184, 24 -> 197 (k_chain + k_chain_wave)
 struct WaveCand { i32 sc, j, flags; u32 x32; };             // flags: bit0 = passes the filters, bit1 = t[j] == i; x32: low word of the candidate's x
 
@@ -955,7 +999,7 @@ k_chain_wave(const mm128 *A, const u64 *gstart, const u32 *glist, u32 n_list, co
 		bool serial = false;
 		if (watch) {
 			const u64 act = __ballot(active);
-			const u32 px = __shfl_up(wx, 1);
+			const u32 px = (u32)lq_wave_shr1((i32)wx, 0);
 			const bool head = ln == 0 || wx != px;
 			const u64 H = __ballot(head);
 			const u32 lo = 63u - (u32)__clzll(H & (~0ULL >> (63 - ln)));                           // my run of equal x starts at lane lo ...
@@ -967,25 +1011,21 @@ k_chain_wave(const mm128 *A, const u64 *gstart, const u32 *glist, u32 n_list, co
 		}
 		if (!serial) {
 			// new bests: candidates whose score beats everything scanned before them
-			i32 inc = active ? sc : (i32)0x80000000;
-			for (int d = 1; d < 64; d <<= 1) { const i32 o = __shfl_up(inc, d); if ((int)ln >= d && o > inc) inc = o; }
-			i32 exc = __shfl_up(inc, 1); if (ln == 0) exc = (i32)0x80000000;
+			const i32 inc = lq_wave_scan_max(active ? sc : (i32)0x80000000);
+			i32 exc = lq_wave_shr1(inc, (i32)0x80000000);
 			if (exc < max_f) exc = max_f;
 			const bool rec = active && sc > exc;
 			const bool skp = active && !rec && tm;
 			// the skip counter after every candidate: x -> max(x + fa, fb), composed in scan order
 			i32 fa = rec ? -1 : skp ? 1 : 0, fb = rec ? 0 : -(1 << 29);
-			for (int d = 1; d < 64; d <<= 1) {
-				const i32 oa = __shfl_up(fa, d), ob = __shfl_up(fb, d);
-				if ((int)ln >= d) { const i32 nb = ob + fa; fb = nb > fb ? nb : fb; fa = oa + fa; }
-			}
+			lq_wave_scan_compose(fa, fb);
 			const i32 x_after = fa > fb ? fa : fb;               // (the counter starts at 0 with every anchor)
 			const u64 brk = __ballot(skp && x_after > max_skip);
 			const u32 cb = brk ? (u32)__builtin_ctzll(brk) : 64u;   // the scan ends at candidate cb (chain.c:72-73)
 			const u64 recm = __ballot(rec) & (cb >= 63 ? ~0ULL : (2ULL << cb) - 1);
-			if (recm) { const int last = 63 - __clzll(recm); max_f = __shfl(sc, last); max_j = (i32)(i - 1 - last); }
+			if (recm) { const int last = 63 - __clzll(recm); max_f = LQ_WAVE_LANE(sc, last); max_j = (i32)(i - 1 - last); }
 			done = cb < 64 ? 1 : 0;
-			n_skip = __shfl(x_after, 63);
+			n_skip = LQ_WAVE_LANE(x_after, 63);
 		} else {
 			cand[ln].sc = sc; cand[ln].j = (i32)j; cand[ln].flags = (active ? 1 : 0) | (tm ? 2 : 0); cand[ln].x32 = wx;
 			if (ln == 0) { st_sh[0] = max_f; st_sh[1] = max_j; st_sh[2] = 0; st_sh[3] = 0; st_sh[8] = 0; }
@@ -995,6 +1035,7 @@ k_chain_wave(const mm128 *A, const u64 *gstart, const u32 *glist, u32 n_list, co
 			max_f = st_sh[0]; max_j = st_sh[1]; n_skip = st_sh[2]; done = st_sh[3];
 		}
 		// ---- candidates beyond the window (rare: 64 of them scanned without the break) ----
+		bool beyond = false;
 		if (!done && i - 65 >= st) {
 			LQ_BLOCK_SYNC();
 			if (ln == 0) { st_sh[0] = max_f; st_sh[1] = max_j; st_sh[2] = n_skip; st_sh[3] = 0; if (!serial) st_sh[8] = 0; }
@@ -1031,19 +1072,21 @@ k_chain_wave(const mm128 *A, const u64 *gstart, const u32 *glist, u32 n_list, co
 			}
 			max_f = st_sh[0]; max_j = st_sh[1];
 			LQ_BLOCK_SYNC();
+			beyond = true;
 		}
+		// the run is known to be listed (first pass): it is not chained, nothing it would compute from here on is used -- and the
+		// longest runs of all are pile-ups of one repeated minimizer, where that is known after a few anchors (uniform: LDS)
+		if (watch && (serial || beyond) && st_sh[4]) break;
 		// ---- f, p, v of anchor i; the window moves on ----
 		i32 vi = max_f;
 		if (max_j >= 0) {
 			const i64 back = i - 1 - (i64)max_j;
-			const i32 vj = back < 64 ? __shfl(wv, (int)back) : v[max_j];      // (uniform branch: max_j is)
+			const i32 vj = back < 64 ? LQ_WAVE_LANE(wv, back) : v[max_j];      // (uniform branch: max_j is)
 			if (vj > max_f) vi = vj;
 		}
 		if (ln == 0) { f[i] = max_f; p[i] = max_j; v[i] = vi; }
 		{
-			const u32 sx = __shfl_up(wx, 1); const i32 sy = __shfl_up(wy, 1), sf = __shfl_up(wf, 1), sp = __shfl_up(wp, 1), sv = __shfl_up(wv, 1);
-			if (ln == 0) { wx = (u32)ri; wy = qi; wf = max_f; wp = max_j; wv = vi; }
-			else { wx = sx; wy = sy; wf = sf; wp = sp; wv = sv; }
+			wx = (u32)lq_wave_shr1((i32)wx, (i32)(u32)ri); wy = lq_wave_shr1(wy, qi); wf = lq_wave_shr1(wf, max_f); wp = lq_wave_shr1(wp, max_j); wv = lq_wave_shr1(wv, vi);
 		}
 		ai = an;
 	}

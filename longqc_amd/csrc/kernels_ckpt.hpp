@@ -39,7 +39,7 @@
 // checkpoints, laid out by one block on the device: ckn = [checkpoints in all, sub-arrays, prefix tiles].  The kernels below
 // are launched with grids sized by upper bounds and read the real counts here -- no host round trip inside a level.
 __global__ void __launch_bounds__(256)
-k_ck_plan(const SortSeg *segs, const u32 *walk_list, u32 list_cap, const u32 *n_walk, int use3, u32 unit, u32 max_ck, CkSeg *out, u32 cap_cks, u32 *ckn)
+k_ck_plan(const SortSeg *segs, const u32 *walk_list, u32 list_cap, const u32 *n_walk, int use3, u32 unit, u32 max_ck, u32 quantum /* checkpoints per sub-array: a multiple of it */, CkSeg *out, u32 cap_cks, u32 *ckn)
 {
 	__shared__ u32 st[256], sc[256], tmp[256], tot_t, tot_c, base_t, base_c;
 	const u32 t = threadIdx.x;
@@ -54,6 +54,7 @@ k_ck_plan(const SortSeg *segs, const u32 *walk_list, u32 list_cap, const u32 *n_
 			id = i < n3 ? walk_list[(u64)3 * list_cap + i] : walk_list[(u64)4 * list_cap + (i - n3)];
 			const u32 len = segs[id].len;
 			nc = len / unit; if (nc < 2) nc = 2; if (nc > max_ck) nc = max_ck;
+			nc = (nc + quantum - 1) / quantum * quantum;
 			nt = len / LQ_CK_TILE + 1;
 		}
 		st[t] = nt; sc[t] = nc;
@@ -270,117 +271,290 @@ k_ck_solve(const CkSeg *cks, const u32 *ckn, const SortSeg *segs, const u8 *D, c
 // ---- passes with many buckets (up to 256): the same states by following the elements in bulk ----------------------
 // With B buckets the rounds of the iteration above number about B ln(mass) and each would cost B prefix look-ups.  Here
 // the solver keeps, per bucket, the cursor A_c up to which the region has been read and the number of elements seen so
-// far with digit c (arr[c], in LDS); "bucket c has A_c - beg_c < arr[c]" means arrivals are waiting: the lane that owns c
+// far with digit c (arr[c], in LDS); "bucket c has A_c - beg_c < arr[c]" means arrivals are waiting: the thread that owns c
 // reads the next elements of R_c and counts their digits.  Any order of doing that ends in the same least fixed point
-// (chaotic iteration of a monotone system), and every element is read once per sub-array.  One wave walks the outer
-// loop's slots in steps sized by the yield of the previous step (slots of the phase's bucket worth about len / n_ck
-// picked-up elements: a bigger step costs only logarithmically more rounds), and writes a checkpoint -- all 256 cursors and
-// the slot -- after each: the pieces come out balanced whatever the data looks like.
+// (chaotic iteration of a monotone system).
+//
+// What that costs is not bytes but depth: one look of the outer loop at a slot of bucket k sets off a cascade that dies out
+// only when elements of digit k turn up -- about (256 - k) ln(mass) rounds, whatever the step.  Round 5's form (one wave per
+// sub-array, every phase of the outer loop solved after the one before: 256 cascades at the very least) took 25-78 ms per
+// launch for 8 % of a step's seed hits.  Three things cut the depth (round 6):
+//   * A state can be found from scratch (the least solution above the START state with the buckets before k full and k held
+//     at s -- kernels_ckpt.hpp's opening comment), so a sub-array's checkpoints are shared out over SUB-CHAINS, one block
+//     each: sub-chain i finds its first state from scratch -- the regions before its bucket counted by the whole block, then
+//     one cascade -- and follows the walk from there to the first state of sub-chain i + 1, which it reaches exactly (the
+//     same least solution), writing up to LQ_CKM_Q checkpoints on the way; quota it does not use repeats that last state
+//     (a walker that starts there stops at once).
+//   * Nearly all of a pass's work is done while the outer loop looks at the FIRST bucket in use, k0 (every cycle runs until
+//     it finds one of its rare digits; when its last one is placed most regions are read to their tails): the sub-chains
+//     start at evenly spaced slots of k0, and a few at the first look at buckets k0 + 1, k0 + 2, k0 + 4, ...
+//   * After k0 a phase does little: the chain does not stop at every bucket but asks for "the buckets before k + jump full"
+//     in one cascade, jump doubling while the yield stays below a checkpoint's worth of elements.
+// One thread per bucket (256), so a round is one LDS look, at most a few counted elements and a barrier.
 #define LQ_CKW_STEP 16
-// arr[digit] += 1 for the elements [lo, hi) of the sub-array, read as aligned 16-byte words (a lane's backlog of hundreds of
-// elements costs a sixteenth of the load latencies it would byte by byte).  The last word read stays in registers (cw, tag
-// cwa = its address): in the long tail of a fixed point a bucket takes in an element or two per round, and sixteen of them
-// then cost one load.
-__device__ __forceinline__ void lq_ck_count_range(const u8 *d, u32 lo, u32 hi, u32 *arr, uint4 &cw, size_t &cwa)
+#define LQ_CKM_THREADS 256
+#define LQ_CKM_Q 8                 // checkpoints per sub-chain: CkSeg.n_ck of a many-bucket pass is a multiple of it.  A sub-array gets twice the
+                                   // checkpoints its length asks for (len / unit): a sub-chain whose stretch of the walk holds twice the average still
+                                   // cuts it into pieces of the aimed-at size, and quota not used costs a walker that starts and stops
+#ifndef LQ_CKM_SPINS
+#define LQ_CKM_SPINS 8             // looks at its bucket a thread takes between two barriers of the fixed point (4: 15.2 ms, 8: 14.3 ms for 400 sub-arrays of 440 k)
+#endif
+// A round of the fixed point must not wait for global memory (a first form did: 2400 cycles per round, an L2 round trip -- with 64
+// buckets per wave some lane crosses a 16-byte word in nearly every round, and a wave's loads are waited for together, so a word
+// asked for ahead of time by one lane is only as early as the latest request of any lane).  So every bucket has a WINDOW of its
+// digit stream in LDS -- the LQ_CKM_WINB bytes from its cursor on, filled by its thread when a fixed point begins (its loads in
+// flight together, one wait per solve, nobody else reads them: no barrier) -- and the rounds read that; what a fixed point takes in beyond
+// the window comes from global memory, 64 bytes per trip.  The block's barrier is the bare instruction behind a wait for LDS only.
+#ifndef LQ_CKM_WINW
+#define LQ_CKM_WINW 4              // (64 bytes: a fixed point takes in ~32 elements per bucket.  With 128 the LDS of a block allowed four blocks per CU instead of eight: 19.9 against 14.3 ms)
+#endif
+#define LQ_CKM_WINB (LQ_CKM_WINW * 16)
+#ifdef LQ_EMU
+#define LQ_CKM_BARRIER() __syncthreads()
+#else
+#define LQ_CKM_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#endif
+// (Two more things the first forms paid for, seen in the ISA: a `volatile` read of arr[] through a generic pointer is a FLAT load with
+// system scope -- hundreds of cycles per look --, and HIP's uint4 is a union with an array, so picking a digit of it with a run-time
+// index moved the word to scratch memory.  Hence the workgroup-scope atomic load below and the two 64-bit halves.)
+#ifdef LQ_EMU
+#define LQ_LDS_LOOK(p) (*(volatile u32*)(p))
+#else
+#define LQ_LDS_LOOK(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+#endif
+struct CkmWin { u64 lo, hi; u32 cwi, wsi; };      // the 16-byte word the cursor is in (two halves), its index; the index of the window's first word.
+                                                  // Word i = the 16 bytes at dA + 16 i, dA = the sub-array's digits rounded down to 16 bytes
+__device__ __forceinline__ void lq_ckm_count16(u64 lo, u64 hi, u32 k0, u32 k1, u32 *arr)   // digits k0 .. k1 - 1 of a word
 {
-	const u8 *p_lo = d + lo, *p_hi = d + hi;
-	for (const u8 *wa = (const u8*)((size_t)p_lo & ~(size_t)15); wa < p_hi; wa += 16) {
-		if ((size_t)wa != cwa) { cw = *(const uint4*)wa; cwa = (size_t)wa; }
-		const u32 ww[4] = { cw.x, cw.y, cw.z, cw.w };
+	if (k0 == 0 && k1 == 16) {
 #pragma unroll
-		for (u32 k = 0; k < 16; ++k) {
-			const u8 *g = wa + k;
-			if (g >= p_lo && g < p_hi) atomicAdd(&arr[(ww[k >> 2] >> ((k & 3) * 8)) & 0xff], 1u);
-		}
+		for (u32 k = 0; k < 8; ++k) atomicAdd(&arr[(u32)(lo >> (8 * k)) & 0xff], 1u);
+#pragma unroll
+		for (u32 k = 0; k < 8; ++k) atomicAdd(&arr[(u32)(hi >> (8 * k)) & 0xff], 1u);
+	} else {
+		for (u32 k = k0; k < k1; ++k) atomicAdd(&arr[(u32)((k < 8 ? lo : hi) >> (8 * (k & 7))) & 0xff], 1u);
 	}
 }
-// (Measured and dropped, round 3: the chain cut into coarse parts that start from states found from scratch -- at configs[2]
-// the solver took 818 ms per step against 384 ms for the serial chain: every part reads the buckets before its slot whole.)
-__global__ void __launch_bounds__(64)
+__device__ __forceinline__ void lq_ckm_refill(const u8 *dA, u32 pos, uint4 (*win)[LQ_CKM_THREADS], u32 c, CkmWin &W)
+{
+	W.wsi = pos >> 4;
+	const uint4 *g = (const uint4*)dA + W.wsi;
+	uint4 t[LQ_CKM_WINW];
+#pragma unroll
+	for (u32 j = 0; j < LQ_CKM_WINW; ++j) t[j] = g[j];         // (the digit array has 256 bytes of slack behind the last sub-array)
+#pragma unroll
+	for (u32 j = 0; j < LQ_CKM_WINW; ++j) win[j][c] = t[j];
+	W.cwi = 0xffffffffu;
+}
+// arr[digit] += 1 for the elements at positions [lo, hi) (position = index in the sub-array + its misalignment): the owner of a
+// bucket taking in its arrivals
+__device__ __forceinline__ void lq_ckm_take(const u8 *dA, u32 lo, u32 hi, u32 *arr, const uint4 (*win)[LQ_CKM_THREADS], u32 c, CkmWin &W)
+{
+	while (lo < hi) {
+		const u32 wi = lo >> 4, k0 = lo & 15;
+		if (wi != W.cwi) {
+			const u32 off = wi - W.wsi;
+			uint4 t;
+			if (off < LQ_CKM_WINW) t = win[off][c];
+			else if (hi - lo >= 64 + 16) {                         // far beyond the window: four words per trip
+				const uint4 *g = (const uint4*)dA + wi;
+				const uint4 a0 = g[0], a1 = g[1], a2 = g[2], a3 = g[3];
+				lq_ckm_count16(a0.x | (u64)a0.y << 32, a0.z | (u64)a0.w << 32, k0, 16, arr);
+				lq_ckm_count16(a1.x | (u64)a1.y << 32, a1.z | (u64)a1.w << 32, 0, 16, arr);
+				lq_ckm_count16(a2.x | (u64)a2.y << 32, a2.z | (u64)a2.w << 32, 0, 16, arr);
+				lq_ckm_count16(a3.x | (u64)a3.y << 32, a3.z | (u64)a3.w << 32, 0, 16, arr);
+				lo += 64 - k0;
+				continue;
+			}
+			else t = ((const uint4*)dA)[wi];
+			W.lo = t.x | (u64)t.y << 32; W.hi = t.z | (u64)t.w << 32;
+			W.cwi = wi;
+		}
+		const u32 n = hi - lo < 16 - k0 ? hi - lo : 16 - k0;
+		lq_ckm_count16(W.lo, W.hi, k0, k0 + n, arr);
+		lo += n;
+	}
+}
+// where sub-chain i of n_sub starts: bucket k, held at slot s (absolute; 0: not held -- the outer loop's first look at k);
+// i == n_sub: the end of the pass (k = 256).  k0 / kl: the first / last bucket in use, beg0 / cnt0: k0's region.
+__device__ __forceinline__ void lq_ckm_start(u32 i, u32 n_sub, u32 k0, u32 kl, u32 beg0, u32 cnt0, u32 &k, u32 &s)
+{
+	u32 T = 0;                                                 // starts after k0: at k0 + 1, k0 + 2, k0 + 4, ... <= kl
+	while (T < 8 && k0 + (1u << T) <= kl) ++T;
+	const u32 cap = n_sub / 4 ? n_sub / 4 : (n_sub > 1 ? 1u : 0u);
+	if (T > cap) T = cap;
+	const u32 P0 = n_sub - T;
+	if (i >= n_sub) { k = 256; s = 0; }
+	else if (i < P0) { k = k0; s = i ? beg0 + (u32)((u64)i * cnt0 / P0) : 0; }
+	else { k = k0 + (1u << (i - P0)); s = 0; }
+}
+// (Measured and dropped, round 3: the chain cut into coarse parts that start from states found from scratch BY ONE WAVE -- at
+// configs[2] the solver took 818 ms per step against 384 ms for the serial chain: every part read the buckets before its slot
+// whole, element by element.  Here a block counts them in one sweep.)
+#ifdef LQ_CKM_STATS
+__device__ unsigned long long lq_ckm_stats[8];   // (tools/microbench: rounds in all, rounds of the from-scratch states, blocks, cycles, cycles from scratch, most rounds of a block, solves)
+#endif
+__global__ void __launch_bounds__(LQ_CKM_THREADS)
 k_ck_chain256(const CkSeg *cks, const u32 *ckn, const SortSeg *segs, const u8 *D, const u32 *hist, const u32 *begs, u32 *S, u32 *CKS)
 {
 	__shared__ u32 arr[256];
-	__shared__ u32 red[64];
-	const u32 lane = threadIdx.x;
-	const u32 n_cks = ckn[1];
-	for (u32 j = blockIdx.x; j < n_cks; j += gridDim.x) {
-		const CkSeg ck = cks[j];
-		const u32 my_ck0 = ck.ck0, my_n = ck.n_ck;
+	__shared__ uint4 win[LQ_CKM_WINW][LQ_CKM_THREADS];
+	__shared__ u32 pend[3];
+	__shared__ u32 red[LQ_CKM_THREADS / 64];
+	__shared__ unsigned long long bal[LQ_CKM_THREADS / 64];
+	const u32 c = threadIdx.x, lane = c & 63, wv = c >> 6;
+	const u32 n_cks = ckn[1], n_sub_total = ckn[0] / LQ_CKM_Q;
+	for (u32 g = blockIdx.x; g < n_sub_total; g += gridDim.x) {
+		u32 lo = 0, hi = n_cks;
+		while (hi - lo > 1) { const u32 mid = lo + ((hi - lo) >> 1); if (cks[mid].ck0 <= g * LQ_CKM_Q) lo = mid; else hi = mid; }
+		const CkSeg ck = cks[lo];
+		const u32 n_sub = ck.n_ck / LQ_CKM_Q, sub = g - ck.ck0 / LQ_CKM_Q;
+		const u32 ckb = ck.ck0 + sub * LQ_CKM_Q;                  // this sub-chain's first checkpoint
 		const SortSeg sg = segs[ck.sgi];
 		const u8 *d = D + sg.off;
-		const u32 *bg = begs + (u64)ck.sgi * 256, *cn = hist + (u64)ck.sgi * 256;
-		u32 A[4], B0[4], E0[4];
-		uint4 cw[4]; size_t cwa[4];
-		for (int g = 0; g < 4; ++g) { cw[g] = uint4{0, 0, 0, 0}; cwa[g] = 0; }
-		for (int g = 0; g < 4; ++g) { const u32 c = (u32)g * 64 + lane; B0[g] = bg[c]; E0[g] = B0[g] + cn[c]; A[g] = B0[g]; arr[c] = 0; }
-		__syncthreads();
-		// fixed point with the buckets before k full and bucket k held at s
-#define LQ_CK_FIXED_POINT(k, s) \
-		for (;;) { \
-			bool pending = false; \
-			for (int g = 0; g < 4; ++g) { \
-				const u32 c = (u32)g * 64 + lane; \
-				u32 need = c < (k) ? E0[g] : B0[g] + arr[c]; \
-				if (c == (k) && need < (s)) need = (s);            /* held at s -- or further, where arrivals filled the bucket beyond s before its phase began */ \
-				if (need > E0[g]) need = E0[g]; \
-				if (A[g] < need) { lq_ck_count_range(d, A[g], need, arr, cw[g], cwa[g]); A[g] = need; pending = true; } \
-			} \
-			__syncthreads(); \
-			if (!__ballot(pending)) break; \
+		const u32 B0 = begs[(u64)ck.sgi * 256 + c], E0 = B0 + hist[(u64)ck.sgi * 256 + c];
+		u32 A = B0;
+		CkmWin W; W.lo = W.hi = 0; W.cwi = 0xffffffffu; W.wsi = 0;
+		const u32 mis = (u32)((size_t)d & 15);                    // positions = indices + mis, counted from dA
+		const u8 *dA = d - mis;
+		arr[c] = 0;
+		if (c < 3) pend[c] = 0;
+		u32 it = 0;                                               // rounds so far (which pend[] slot is whose)
+#ifdef LQ_CKM_STATS
+		const long long t_begin = clock64(); long long t_scratch = t_begin; u32 it_scratch = 0, n_solves = 0;
+#endif
+		// the first and the last bucket in use
+		u32 k0, kl;
+		{
+			const unsigned long long b = __ballot(E0 > B0);
+			if (lane == 0) bal[wv] = b;
+			__syncthreads();
+			k0 = 256; kl = 0;
+			for (u32 w = 0; w < LQ_CKM_THREADS / 64; ++w) if (bal[w]) { if (k0 == 256) k0 = w * 64 + (u32)__builtin_ctzll(bal[w]); kl = w * 64 + 63 - (u32)__builtin_clzll(bal[w]); }
+			__syncthreads();
 		}
-#define LQ_CK_PICKED(out) do { \
-			u32 mine_ = 0; \
-			for (int g = 0; g < 4; ++g) mine_ += A[g] - B0[g]; \
-			red[lane] = mine_; \
+		// block-uniform helpers -------------------------------------------------------------------------------------------
+		// the least solution above the state at hand with the buckets before kt full and kt held at st
+#define LQ_CKM_SOLVE(kt, st) \
+		lq_ckm_refill(dA, mis + A, win, c, W); \
+		for (;; ++it) { \
+			if (c == 0) pend[(it + 1) % 3] = 0; \
+			bool did_ = false; \
+			for (int sp_ = 0; sp_ < LQ_CKM_SPINS; ++sp_) { \
+				u32 need = c < (kt) ? E0 : B0 + LQ_LDS_LOOK(&arr[c]); \
+				if (c == (kt) && need < (st)) need = (st);         /* held at st -- or further, where arrivals filled the bucket beyond st before its phase began */ \
+				if (need > E0) need = E0; \
+				if (A < need) { lq_ckm_take(dA, mis + A, mis + need, arr, win, c, W); A = need; did_ = true; } \
+			} \
+			if (did_) pend[it % 3] = 1; \
+			LQ_CKM_BARRIER(); \
+			if (!pend[it % 3]) { ++it; break; } \
+		}
+		// where the outer loop is in the state at hand: the first bucket from kt on with unread slots and its cursor (256, len: none)
+#define LQ_CKM_WHERE(kt, kc, ac) do { \
+			const unsigned long long b_ = __ballot(c >= (kt) && A < E0); \
+			if (lane == 0) bal[wv] = b_; \
+			__syncthreads(); \
+			(kc) = 256; \
+			for (u32 w_ = 0; w_ < LQ_CKM_THREADS / 64; ++w_) if (bal[w_]) { (kc) = w_ * 64 + (u32)__builtin_ctzll(bal[w_]); break; } \
+			if (c == (kc)) red[0] = A; \
+			__syncthreads(); \
+			(ac) = (kc) < 256 ? red[0] : sg.len; \
+			__syncthreads(); \
+		} while (0)
+		// elements picked up so far
+#define LQ_CKM_PICKED(out) do { \
+			u32 m_ = A - B0; \
+			for (int o_ = 32; o_ > 0; o_ >>= 1) m_ += __shfl_xor(m_, o_); \
+			if (lane == 0) red[wv] = m_; \
 			__syncthreads(); \
 			u64 p_ = 0; \
-			for (u32 x = 0; x < 64; ++x) p_ += red[x]; \
+			for (u32 w_ = 0; w_ < LQ_CKM_THREADS / 64; ++w_) p_ += red[w_]; \
 			__syncthreads(); \
 			(out) = p_; \
 		} while (0)
-		const u64 target = (u64)sg.len / ck.n_ck + 1;
-		u64 picked_at_last = 0, picked_before = 0;
-		LQ_CK_PICKED(picked_before);
+#define LQ_CKM_WRITE(x, slot) do { S[((u64)ckb + (x)) * 256 + c] = A; if (c == 0) CKS[ckb + (x)] = (slot); } while (0)
+		u32 ks, ss, ke, se;
+		lq_ckm_start(sub, n_sub, k0, kl, k0 < 256 ? begs[(u64)ck.sgi * 256 + k0] : 0, k0 < 256 ? hist[(u64)ck.sgi * 256 + k0] : 0, ks, ss);
+		lq_ckm_start(sub + 1, n_sub, k0, kl, k0 < 256 ? begs[(u64)ck.sgi * 256 + k0] : 0, k0 < 256 ? hist[(u64)ck.sgi * 256 + k0] : 0, ke, se);
+		if (sub) {
+			// this sub-chain's first state from scratch: the regions of the buckets before ks, and the slots of ks up to ss, are read
+			// whole -- counted by all threads, 16 bytes at a time --, then the cascade
+			const u32 full_hi = begs[(u64)ck.sgi * 256 + ks];     // (the regions lie one after the other: [0, beg of ks) is what the buckets before ks own)
+			const u32 hold_hi = ss > full_hi ? ss : full_hi;
+			{
+				const u8 *p_lo = d, *p_hi = d + hold_hi;
+				for (const u8 *wa = (const u8*)((size_t)p_lo & ~(size_t)15) + (size_t)c * 16; wa < p_hi; wa += (size_t)LQ_CKM_THREADS * 16) {
+					const uint4 w4 = *(const uint4*)wa;
+					const u32 ww[4] = { w4.x, w4.y, w4.z, w4.w };
+#pragma unroll
+					for (u32 k = 0; k < 16; ++k) {
+						const u8 *gq = wa + k;
+						if (gq >= p_lo && gq < p_hi) atomicAdd(&arr[(ww[k >> 2] >> ((k & 3) * 8)) & 0xff], 1u);
+					}
+				}
+			}
+			if (c < ks) A = E0; else if (c == ks && A < hold_hi) A = hold_hi < E0 ? hold_hi : E0;
+			__syncthreads();
+			LQ_CKM_SOLVE(ks, ss)
+#ifdef LQ_CKM_STATS
+			t_scratch = clock64(); it_scratch = it;
+#endif
+		}
+		u32 kc, ac;
+		LQ_CKM_WHERE(ks, kc, ac);
+		const u64 target = 2 * ((u64)sg.len / ck.n_ck) + 1;       // elements a walker's piece should hold (half the quota is slack, LQ_CKM_Q)
+		u64 picked_before = 0, picked_at_last = 0;
+		LQ_CKM_PICKED(picked_before);
 		picked_at_last = picked_before;
-		u32 n_out = 0, est = LQ_CKW_STEP;                       // slots of the phase's bucket that are worth about `target` picked-up elements
-		// first checkpoint: the start state
-		for (int g = 0; g < 4; ++g) S[((u64)my_ck0 + 0) * 256 + (u32)g * 64 + lane] = A[g];
-		if (lane == 0) CKS[my_ck0] = 0;
-		n_out = 1;
-		for (u32 k = 0; k < 256; ++k) {                          // phases of the outer loop
-			const u32 kl = k & 63, kg = k >> 6;
-			u32 ek = 0, ak = 0;
-			for (int g = 0; g < 4; ++g) if ((u32)g == kg) { ek = (u32)__builtin_amdgcn_readlane((int)E0[g], (int)kl); ak = (u32)__builtin_amdgcn_readlane((int)A[g], (int)kl); }
-			while (ak < ek) {
-				const u32 step = est;
-				u32 s = ek - ak > step ? ak + step : ek;                // the outer loop reaches slot s of bucket k
-				LQ_CK_FIXED_POINT(k, s)
-				// bucket k's cursor: slots filled = held value, unless arrivals already pushed it further
-				for (int g = 0; g < 4; ++g) if ((u32)g == kg) ak = (u32)__builtin_amdgcn_readlane((int)A[g], (int)kl);
-				if (ak < s) ak = s;
-				u64 picked;
-				LQ_CK_PICKED(picked);
-				{	// one step per checkpoint: the next step covers the slots that the last one's yield says are worth `target`
-					const u64 got = picked - picked_before;
-					picked_before = picked;
+		LQ_CKM_WRITE(0, ac);
+		u32 n_out = 1, est = LQ_CKW_STEP, jump = 1;
+		// follow the walk to the first state of the next sub-chain
+		while (kc < ke || (kc == ke && ac < se)) {
+			const u32 ek = begs[(u64)ck.sgi * 256 + kc] + hist[(u64)ck.sgi * 256 + kc];
+			u32 kt, st; bool by_slots;
+			if (ek - ac > est) { kt = kc; st = ac + est; by_slots = true; }
+			else { kt = kc + jump < 256 ? kc + jump : 256; st = 0; by_slots = false; }
+			// never beyond the next sub-chain's start: (ke, se) -- a first look (st == 0) at ke comes before any of its slots
+			if (kt > ke || (kt == ke && st != 0 && st >= se)) { kt = ke; st = se; }
+			const u32 step = by_slots ? st - ac : 0;
+			LQ_CKM_SOLVE(kt, st)
+#ifdef LQ_CKM_STATS
+			++n_solves;
+#endif
+			LQ_CKM_WHERE(kt, kc, ac);
+			u64 picked;
+			LQ_CKM_PICKED(picked);
+			{	// the next step covers what the last one's yield says is worth `target`
+				const u64 got = picked - picked_before;
+				picked_before = picked;
+				if (by_slots && step) {
 					u64 e2 = got ? (u64)step * target / got : (u64)step * 4;
 					if (e2 > (u64)step * 4) e2 = (u64)step * 4;
 					est = (u32)(e2 < LQ_CKW_STEP ? LQ_CKW_STEP : e2 > (1u << 24) ? (1u << 24) : e2);
-				}
-				if (picked - picked_at_last >= target / 2 && n_out < my_n && ak < ek) {
-					for (int g = 0; g < 4; ++g) S[((u64)my_ck0 + n_out) * 256 + (u32)g * 64 + lane] = A[g];
-					if (lane == 0) CKS[my_ck0 + n_out] = ak;
-					++n_out; picked_at_last = picked;
+				} else if (!by_slots) {
+					if (got < target / 2) jump = jump < 128 ? jump * 2 : 256;
+					else if (got > target && jump > 1) jump /= 2;
 				}
 			}
+			if (picked - picked_at_last >= target / 2 && n_out < LQ_CKM_Q && (kc < ke || (kc == ke && ac < se))) {
+				LQ_CKM_WRITE(n_out, ac);
+				++n_out; picked_at_last = picked;
+			}
 		}
-#undef LQ_CK_FIXED_POINT
-#undef LQ_CK_PICKED
-		// unused checkpoints: the final state (their walkers find nothing to do)
-		for (; n_out < my_n; ++n_out) {
-			for (int g = 0; g < 4; ++g) S[((u64)my_ck0 + n_out) * 256 + (u32)g * 64 + lane] = E0[g];
-			if (lane == 0) CKS[my_ck0 + n_out] = sg.len;
+		// quota not used: the state at hand -- the next sub-chain's first, or the pass's last (a walker finds nothing to do)
+		for (; n_out < LQ_CKM_Q; ++n_out) LQ_CKM_WRITE(n_out, ac);
+#ifdef LQ_CKM_STATS
+		if (c == 0) {
+			atomicAdd(&lq_ckm_stats[0], (unsigned long long)it); atomicAdd(&lq_ckm_stats[1], (unsigned long long)it_scratch); atomicAdd(&lq_ckm_stats[2], 1ULL);
+			atomicAdd(&lq_ckm_stats[3], (unsigned long long)(clock64() - t_begin)); atomicAdd(&lq_ckm_stats[4], (unsigned long long)(t_scratch - t_begin));
+			atomicMax(&lq_ckm_stats[5], (unsigned long long)it); atomicAdd(&lq_ckm_stats[6], (unsigned long long)n_solves);
 		}
+#endif
+#undef LQ_CKM_SOLVE
+#undef LQ_CKM_WHERE
+#undef LQ_CKM_PICKED
+#undef LQ_CKM_WRITE
 		__syncthreads();
 	}
 }

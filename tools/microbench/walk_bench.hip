@@ -1,6 +1,9 @@
-// tools/microbench/walk_bench.hip -- development aid: ns per trip of the klib token walkers on MI355X.
+// tools/microbench/walk_bench.hip -- development aid: the klib token walkers and the checkpoint solvers on MI355X, kernel by kernel.
 //   hipcc --offload-arch=gfx950 -O3 -I longqc_amd/csrc tools/microbench/walk_bench.hip -o tools/microbench/walk_bench
-// Random digit streams (B buckets, N elements), the walk's destinations checked against a host walk.
+//   walk_bench N copies B shape [unit]      shape: r = random digits, s = sawtooth (ascending lists of random length: what a query's hits
+//                                           look like below the strand byte -- minimizer-major, ascending rid inside a minimizer), rNN = runs of NN
+// Digit streams of B buckets, N elements, `copies` sub-arrays; the destinations of every walk are compared with a host walk.
+#define LQ_CKM_STATS
 #include "kernels_sort.hpp"
 #include "kernels_walk.hpp"
 #include <vector>
@@ -8,6 +11,7 @@
 #include <cstdlib>
 #include <random>
 #include <string>
+#include <algorithm>
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
@@ -29,99 +33,92 @@ static void host_walk(const std::vector<u8> &d, const u32 *cnt, const u32 *bg, s
 int main(int argc, char **argv)
 {
 	const u32 N = argc > 1 ? (u32)atol(argv[1]) : 1000000;
-	const int copies_hi = argc > 2 ? atoi(argv[2]) : 1024;
-	const int only_b = argc > 3 ? atoi(argv[3]) : 0;
-	struct Case { const char *name; int B; int runs; };
-	const Case cases[] = { {"B=6 random", 6, 1}, {"B=6 runs of 37", 6, 37}, {"B=16 random", 16, 1}, {"B=3 runs of 5", 3, 5}, {"B=50 random", 50, 1}, {"B=79 random", 79, 1}, {"B=100 random", 100, 1}, {"B=196 random", 196, 1}, {"B=200 runs of 3", 200, 3}, {"B=256 random", 256, 1} };
-	for (const Case &cs : cases) {
-		if (only_b && cs.B != only_b) continue;
-		std::mt19937_64 rng(12345 + cs.B);
-		const u32 pad = 7;                                     // misaligned start
-		std::vector<u8> d(N);
-		for (u32 i = 0; i < N; ) { u8 v = (u8)(rng() % cs.B); for (int r = 0; r < cs.runs && i < N; ++r) d[i++] = v; }
-		u32 cnt[256] = {0}, bg[256];
-		for (u8 v : d) ++cnt[v];
-		u32 acc = 0; for (int c = 0; c < 256; ++c) { bg[c] = acc; acc += cnt[c]; }
-		std::vector<u32> ref; host_walk(d, cnt, bg, ref);
-		for (int copies : {1, copies_hi}) {
-			const u64 stride = ((u64)N + pad + 63) & ~(u64)15;
-			u8 *dD; u32 *dH, *dB, *dDst, *dList, *dN; SortSeg *dS;
-			CK(hipMalloc(&dD, stride * copies + 64)); CK(hipMalloc(&dH, 1024 * copies)); CK(hipMalloc(&dB, 1024 * copies));
-			CK(hipMalloc(&dDst, (stride * copies + 64) * 4)); CK(hipMalloc(&dList, 4 * copies)); CK(hipMalloc(&dN, 4)); CK(hipMalloc(&dS, sizeof(SortSeg) * copies));
-			std::vector<SortSeg> segs(copies); std::vector<u32> list(copies);
-			for (int c = 0; c < copies; ++c) {
-				segs[c].off = stride * c + pad; segs[c].len = N; segs[c].shift = 40; list[c] = c;
-				CK(hipMemcpy(dD + segs[c].off, d.data(), N, hipMemcpyHostToDevice));
-				CK(hipMemcpy(dH + 256 * c, cnt, 1024, hipMemcpyHostToDevice)); CK(hipMemcpy(dB + 256 * c, bg, 1024, hipMemcpyHostToDevice));
-			}
-			CK(hipMemcpy(dS, segs.data(), sizeof(SortSeg) * copies, hipMemcpyHostToDevice)); CK(hipMemcpy(dList, list.data(), 4 * copies, hipMemcpyHostToDevice));
-			u32 nl = copies; CK(hipMemcpy(dN, &nl, 4, hipMemcpyHostToDevice));
-			hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-			auto run = [&](const char *name, auto launch) {
-				CK(hipMemset(dDst, 0xff, (stride * copies + 64) * 4));
-				launch(); CK(hipDeviceSynchronize());       // warm
-				CK(hipMemset(dDst, 0xff, (stride * copies + 64) * 4));
-				CK(hipEventRecord(e0)); launch(); CK(hipEventRecord(e1)); CK(hipDeviceSynchronize());
-				float ms; CK(hipEventElapsedTime(&ms, e0, e1));
-				std::vector<u32> got(N);
-				bool ok = true;
-				for (int c : {0, copies - 1}) {
-					CK(hipMemcpy(got.data(), dDst + segs[c].off, (u64)N * 4, hipMemcpyDeviceToHost));
-					if (got != ref) ok = false;
-				}
-				printf("%-16s copies %5d  %-22s %9.3f ms  %7.1f ns/trip  %s\n", cs.name, copies, name, ms, ms * 1e6 / N, ok ? "ok" : "MISMATCH");
-				fflush(stdout);
-			};
-			run("solo (LDS state)", [&] { hipLaunchKernelGGL(k_sort_walk_solo, dim3(copies), dim3(64), 0, 0, dS, dList, dN, dD, dH, dB, dDst, (const CkSeg*)nullptr, 0u, (const u32*)nullptr, (const u32*)nullptr); });
-			const CkSeg *nock = nullptr; const u32 *nou = nullptr;
-			if (cs.B <= 64) run("reg<1>", [&] { hipLaunchKernelGGL((k_sort_walk_reg<1>), dim3(copies), dim3(64), 0, 0, dS, dList, dN, dD, dH, dB, dDst, nock, 0u, nou, nou); });
-			if (cs.B <= 128) run("reg<2>", [&] { hipLaunchKernelGGL((k_sort_walk_reg<2>), dim3(copies), dim3(64), 0, 0, dS, dList, dN, dD, dH, dB, dDst, nock, 0u, nou, nou); });
-			run("reg<4>", [&] { hipLaunchKernelGGL((k_sort_walk_reg<4>), dim3(copies), dim3(64), 0, 0, dS, dList, dN, dD, dH, dB, dDst, nock, 0u, nou, nou); });
-			if (cs.B > LQ_CK_B) {
-				// many buckets: states by following the elements in bulk (k_ck_chain256), pieces by the solo walker
-				const u32 n_ck1 = std::min<u32>(64, std::max<u32>(2, N / 16384));
-				std::vector<CkSeg> hck(copies);
-				u32 ckt = 0;
-				for (int c = 0; c < copies; ++c) { hck[c].sgi = c; hck[c].tile0 = 0; hck[c].ck0 = ckt; hck[c].n_ck = n_ck1; ckt += n_ck1; }
-				CkSeg *dck; u32 *dSt, *dSl, *dNck;
-				CK(hipMalloc(&dck, sizeof(CkSeg) * copies)); CK(hipMalloc(&dSt, (u64)ckt * 256 * 4)); CK(hipMalloc(&dSl, (u64)ckt * 4 + 4)); CK(hipMalloc(&dNck, 4));
-				CK(hipMemcpy(dck, hck.data(), sizeof(CkSeg) * copies, hipMemcpyHostToDevice)); CK(hipMemcpy(dNck, &ckt, 4, hipMemcpyHostToDevice));
-				char nm[64]; snprintf(nm, sizeof(nm), "ckpt256 x%u (all)", n_ck1);
-				const u32 *nou2 = nullptr;
-				run(nm, [&] {
-					hipLaunchKernelGGL(k_ck_chain256, dim3(copies), dim3(64), 0, 0, dck, (u32)copies, dS, dD, dH, dB, dSt, dSl);
-					hipLaunchKernelGGL(k_sort_walk_solo, dim3(std::min<u32>(ckt, 1u << 18)), dim3(64), 0, 0, dS, nou2, dNck, dD, dH, dB, dDst, dck, (u32)copies, dSt, dSl);
-				});
-				run("  of which walk pieces", [&] {
-					hipLaunchKernelGGL(k_sort_walk_solo, dim3(std::min<u32>(ckt, 1u << 18)), dim3(64), 0, 0, dS, nou2, dNck, dD, dH, dB, dDst, dck, (u32)copies, dSt, dSl);
-				});
-				hipFree(dck); hipFree(dSt); hipFree(dSl); hipFree(dNck);
-			}
-			if (cs.B <= LQ_CK_B) {
-				// checkpointed: the walk of every copy cut into n_ck pieces from computed states (kernels_ckpt.hpp)
-				const u32 n_ck1 = std::min<u32>(512, std::max<u32>(2, N / 16384));
-				std::vector<CkSeg> hck(copies);
-				u32 tiles = 0, ckt = 0;
-				for (int c = 0; c < copies; ++c) { hck[c].sgi = c; hck[c].tile0 = tiles; hck[c].ck0 = ckt; hck[c].n_ck = n_ck1; tiles += N / LQ_CK_TILE + 1; ckt += n_ck1; }
-				CkSeg *dck; u32 *dT, *dE, *dSt, *dSl, *dNck;
-				CK(hipMalloc(&dck, sizeof(CkSeg) * copies)); CK(hipMalloc(&dT, (u64)tiles * LQ_CK_B * 4)); CK(hipMalloc(&dE, (u64)copies * LQ_CK_B * LQ_CK_B * 4));
-				CK(hipMalloc(&dSt, (u64)ckt * LQ_CK_B * 4)); CK(hipMalloc(&dSl, (u64)ckt * 4 + 4)); CK(hipMalloc(&dNck, 4));
-				CK(hipMemcpy(dck, hck.data(), sizeof(CkSeg) * copies, hipMemcpyHostToDevice)); CK(hipMemcpy(dNck, &ckt, 4, hipMemcpyHostToDevice));
-				char nm[64]; snprintf(nm, sizeof(nm), "ckpt x%u (all kernels)", n_ck1);
-				run(nm, [&] {
-					hipLaunchKernelGGL(k_ck_tilehist, dim3(std::min<u32>(tiles, 65536)), dim3(256), 0, 0, dck, (u32)copies, tiles, dS, dD, dT);
-					hipLaunchKernelGGL(k_ck_tilescan, dim3(copies), dim3(256), 0, 0, dck, (u32)copies, dS, dT);
-					hipLaunchKernelGGL(k_ck_phases, dim3(copies), dim3(64), 0, 0, dck, (u32)copies, dS, dD, dH, dB, dT, dE);
-					hipLaunchKernelGGL(k_ck_solve, dim3(std::min<u32>(ckt, 1u << 18)), dim3(64), 0, 0, dck, (u32)copies, ckt, dS, dD, dH, dB, dT, dE, dSt, dSl);
-					hipLaunchKernelGGL((k_sort_walk_reg<1>), dim3(std::min<u32>(ckt, 1u << 18)), dim3(64), 0, 0, dS, nou, dNck, dD, dH, dB, dDst, dck, (u32)copies, dSt, dSl);
-				});
-				run("  of which walk pieces", [&] {
-					hipLaunchKernelGGL((k_sort_walk_reg<1>), dim3(std::min<u32>(ckt, 1u << 18)), dim3(64), 0, 0, dS, nou, dNck, dD, dH, dB, dDst, dck, (u32)copies, dSt, dSl);
-				});
-				hipFree(dck); hipFree(dT); hipFree(dE); hipFree(dSt); hipFree(dSl); hipFree(dNck);
-			}
-			hipFree(dD); hipFree(dH); hipFree(dB); hipFree(dDst); hipFree(dList); hipFree(dN); hipFree(dS);
+	const int copies = argc > 2 ? atoi(argv[2]) : 64;
+	const int B = argc > 3 ? atoi(argv[3]) : 256;
+	const std::string shape = argc > 4 ? argv[4] : "r";
+	const u32 unit = argc > 5 ? (u32)atol(argv[5]) : (B <= LQ_CK_B ? 16384u : 4096u);
+	const int variants = 4;                                 // different streams among the copies (copy c uses stream c % variants)
+	std::vector<std::vector<u8>> dv(variants);
+	std::vector<std::vector<u32>> refs(variants), cnts(variants, std::vector<u32>(256)), bgs(variants, std::vector<u32>(256));
+	for (int v = 0; v < variants; ++v) {
+		std::mt19937_64 rng(12345 + B * 7 + v);
+		std::vector<u8> &d = dv[v]; d.resize(N);
+		if (shape[0] == 's') { for (u32 i = 0; i < N; ) { u32 len = 1 + (u32)(rng() % 80); std::vector<u8> l(len); for (u8 &x : l) x = (u8)(rng() % B); std::sort(l.begin(), l.end()); for (u32 j = 0; j < len && i < N; ++j) d[i++] = l[j]; } }
+		else { const int runs = shape.size() > 1 ? atoi(shape.c_str() + 1) : 1; for (u32 i = 0; i < N; ) { u8 x = (u8)(rng() % B); for (int r = 0; r < runs && i < N; ++r) d[i++] = x; } }
+		for (u8 x : d) ++cnts[v][x];
+		u32 acc = 0; for (int c = 0; c < 256; ++c) { bgs[v][c] = acc; acc += cnts[v][c]; }
+		host_walk(d, cnts[v].data(), bgs[v].data(), refs[v]);
+	}
+	const u32 pad = 7;                                      // misaligned start
+	const u64 stride = ((u64)N + pad + 63) & ~(u64)15;
+	u8 *dD; u32 *dH, *dB, *dDst, *dList, *dN; SortSeg *dS;
+	CK(hipMalloc(&dD, stride * copies + 256)); CK(hipMalloc(&dH, 1024 * (size_t)copies)); CK(hipMalloc(&dB, 1024 * (size_t)copies));
+	CK(hipMalloc(&dDst, (stride * copies + 64) * 4)); CK(hipMalloc(&dList, 4 * (size_t)copies * LQ_WALK_CLASSES)); CK(hipMalloc(&dN, 64)); CK(hipMalloc(&dS, sizeof(SortSeg) * copies));
+	std::vector<SortSeg> segs(copies); std::vector<u32> list((size_t)copies * LQ_WALK_CLASSES, 0);
+	for (int c = 0; c < copies; ++c) {
+		const int v = c % variants;
+		segs[c].off = stride * c + pad; segs[c].len = N; segs[c].shift = 40; list[(size_t)4 * copies + c] = c; list[c] = c;
+		CK(hipMemcpy(dD + segs[c].off, dv[v].data(), N, hipMemcpyHostToDevice));
+		CK(hipMemcpy(dH + 256 * c, cnts[v].data(), 1024, hipMemcpyHostToDevice)); CK(hipMemcpy(dB + 256 * c, bgs[v].data(), 1024, hipMemcpyHostToDevice));
+	}
+	CK(hipMemcpy(dS, segs.data(), sizeof(SortSeg) * copies, hipMemcpyHostToDevice)); CK(hipMemcpy(dList, list.data(), 4 * list.size(), hipMemcpyHostToDevice));
+	u32 nw[8] = {0, 0, 0, 0, (u32)copies, 0, 0, 0};     // n_walk[c]: every copy in class 4 (the longest)
+	u32 nl = copies;
+	CK(hipMemcpy(dN, nw, 32, hipMemcpyHostToDevice)); CK(hipMemcpy(dN + 8, &nl, 4, hipMemcpyHostToDevice));
+	hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+	auto timed = [&](const char *name, auto launch) {
+		CK(hipEventRecord(e0)); launch(); CK(hipEventRecord(e1)); CK(hipDeviceSynchronize());
+		CK(hipGetLastError());
+		float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+		printf("    %-28s %9.3f ms\n", name, ms); fflush(stdout);
+		return ms;
+	};
+	auto check = [&](const char *what) {
+		std::vector<u32> got(N);
+		int bad = 0;
+		for (int c = 0; c < copies; ++c) {
+			if (c >= 2 * variants && c < copies - variants) continue;
+			CK(hipMemcpy(got.data(), dDst + segs[c].off, (u64)N * 4, hipMemcpyDeviceToHost));
+			if (got != refs[c % variants]) { ++bad; if (bad == 1) { u32 i = 0; while (got[i] == refs[c % variants][i]) ++i; printf("    first difference: copy %d element %u got %u want %u\n", c, i, got[i], refs[c % variants][i]); } }
 		}
+		printf("  %-30s destinations %s\n", what, bad ? "MISMATCH" : "ok"); fflush(stdout);
+	};
+	printf("N %u copies %d (%.1f M elements) B %d shape %s unit %u\n", N, copies, (double)N * copies / 1e6, B, shape.c_str(), unit);
+	const u32 cap_cks = copies;
+	CkSeg *dck; u32 *dckn;
+	CK(hipMalloc(&dck, sizeof(CkSeg) * copies)); CK(hipMalloc(&dckn, 64));
+	const u64 ck_max = (u64)N / unit * copies + (u64)(2 + LQ_CKM_Q) * copies, tiles_max = ((u64)N / LQ_CK_TILE + 1) * copies;
+	u32 *dSt, *dSl, *dT = nullptr, *dE = nullptr;
+	const bool small = B <= LQ_CK_B;
+	CK(hipMalloc(&dSt, ck_max * (small ? LQ_CK_B : 256) * 4)); CK(hipMalloc(&dSl, ck_max * 4 + 4));
+	if (small) { CK(hipMalloc(&dT, (tiles_max + 1) * LQ_CK_B * 4)); CK(hipMalloc(&dE, (u64)copies * LQ_CK_B * LQ_CK_B * 4)); }
+	for (int rep = 0; rep < 2; ++rep) {
+		printf(" pass %d\n", rep);
+		CK(hipMemset(dDst, 0xff, (stride * copies + 64) * 4));
+		timed("k_ck_plan", [&] { hipLaunchKernelGGL(k_ck_plan, dim3(1), dim3(256), 0, 0, dS, dList, (u32)copies, dN, 0, unit, small ? 512u : 256u, small ? 1u : (u32)LQ_CKM_Q, dck, cap_cks, dckn); });
+		u32 hn[3]; CK(hipMemcpy(hn, dckn, 12, hipMemcpyDeviceToHost));
+		if (rep == 0) printf("    checkpoints %u sub-arrays %u tiles %u\n", hn[0], hn[1], hn[2]);
+		float tot = 0;
+		if (small) {
+			tot += timed("k_ck_tilehist", [&] { hipLaunchKernelGGL(k_ck_tilehist, dim3((u32)std::min<u64>(tiles_max, 1u << 16)), dim3(256), 0, 0, dck, dckn, dS, dD, dT); });
+			tot += timed("k_ck_tilescan", [&] { hipLaunchKernelGGL(k_ck_tilescan, dim3(std::min<u32>(copies, 8192)), dim3(256), 0, 0, dck, dckn, dS, dT); });
+			tot += timed("k_ck_phases", [&] { hipLaunchKernelGGL(k_ck_phases, dim3((u32)std::min<u64>((u64)copies * LQ_CK_B, 1u << 16)), dim3(64), 0, 0, dck, dckn, dS, dD, dH, dB, dT, dE); });
+			tot += timed("k_ck_solve", [&] { hipLaunchKernelGGL(k_ck_solve, dim3((u32)std::min<u64>(ck_max, 1u << 18)), dim3(64), 0, 0, dck, dckn, dS, dD, dH, dB, dT, dE, dSt, dSl); });
+			tot += timed("k_sort_walk_reg<1> pieces", [&] { hipLaunchKernelGGL((k_sort_walk_reg<1>), dim3((u32)std::min<u64>(ck_max, 1u << 18)), dim3(64), 0, 0, dS, (const u32*)nullptr, dckn, dD, dH, dB, dDst, dck, dckn, dSt, dSl); });
+		} else {
+			tot += timed("k_ck_chain256", [&] { hipLaunchKernelGGL(k_ck_chain256, dim3((u32)std::min<u64>(ck_max / LQ_CKM_Q + 1, 1u << 18)), dim3(LQ_CKM_THREADS), 0, 0, dck, dckn, dS, dD, dH, dB, dSt, dSl); });
+			{ unsigned long long st[8]; CK(hipMemcpyFromSymbol(st, HIP_SYMBOL(lq_ckm_stats), 64)); const double nb = (double)std::max<unsigned long long>(st[2], 1);
+			  printf("    blocks %llu: rounds per block %.0f (from scratch %.0f, most %llu), solves per block %.1f, cycles per block %.0f (from scratch %.0f) -> %.0f cycles per round\n", st[2], st[0] / nb, st[1] / nb, st[5], st[6] / nb, st[3] / nb, st[4] / nb, (double)st[3] / std::max<double>((double)st[0], 1));
+			  unsigned long long z[8] = {0}; CK(hipMemcpyToSymbol(HIP_SYMBOL(lq_ckm_stats), z, 64)); }
+			tot += timed("k_sort_walk_solo pieces", [&] { hipLaunchKernelGGL(k_sort_walk_solo, dim3((u32)std::min<u64>(ck_max, 1u << 18)), dim3(64), 0, 0, dS, (const u32*)nullptr, dckn, dD, dH, dB, dDst, dck, dckn, dSt, dSl); });
+		}
+		printf("    %-28s %9.3f ms\n", "checkpointed, in all", tot);
+		check("checkpointed");
+	}
+	if (argc > 6) {                                         // whole walks for comparison (slow for long sub-arrays)
+		CK(hipMemset(dDst, 0xff, (stride * copies + 64) * 4));
+		timed("k_sort_walk_solo whole", [&] { hipLaunchKernelGGL(k_sort_walk_solo, dim3(copies), dim3(64), 0, 0, dS, dList, dN + 8, dD, dH, dB, dDst, (const CkSeg*)nullptr, (const u32*)nullptr, (const u32*)nullptr, (const u32*)nullptr); });
+		check("whole walks");
 	}
 	return 0;
 }
