@@ -42,6 +42,16 @@ static void dzero(void *p, size_t bytes, hipStream_t s) { if (bytes) LQ_HIP_CHEC
 static void check_launch() { LQ_HIP_CHECK(hipGetLastError()); }
 #include <chrono>
 static double lq_now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+// LQCOV_TIMELINE=1: host times (ms since the handle's last reset) at the points where a thread has just waited for its stream --
+// what a step's critical path is made of, without a profiler in the way (rocprofv3 serialises dispatches and stretches the picture)
+static const bool lq_timeline = getenv("LQCOV_TIMELINE") != nullptr;
+static double lq_timeline_t0 = 0;
+static void lq_tl(const char *who, int id, const char *what, double extra = -1)
+{
+	if (!lq_timeline) return;
+	if (extra >= 0) fprintf(stderr, "[tl] %8.2f %s%d %s %.0f\n", (lq_now_s() - lq_timeline_t0) * 1e3, who, id, what, extra);
+	else fprintf(stderr, "[tl] %8.2f %s%d %s\n", (lq_now_s() - lq_timeline_t0) * 1e3, who, id, what);
+}
 #ifndef LQ_EMU
 int lq_trace_launches = 0;
 #endif
@@ -98,7 +108,8 @@ void Knobs::read_env()
 	reg_walker = !is("LQCOV_WALK", "solo");
 	ckpt = !is("LQCOV_CKPT", "0");
 	ckpt3 = num("LQCOV_CKPT3", 1) > 0;
-	ck_unit = (u32)std::max<long long>(num("LQCOV_CK_UNIT", 16384), 64); ck_unit_many = (u32)std::max<long long>(num("LQCOV_CK_UNIT_MANY", 4096), 64);
+	build_prio = num("LQCOV_BUILD_PRIO", 1) > 0;
+	ck_unit = (u32)std::max<long long>(num("LQCOV_CK_UNIT", 65536), 64); ck_unit_many = (u32)std::max<long long>(num("LQCOV_CK_UNIT_MANY", 8192), 64);
 	sort_tile = (u32)std::max<long>(0, num("LQCOV_SORT_TILE", 0)); if (sort_tile && sort_tile < 64) sort_tile = 64;
 	walk_shift = (u32)std::min<long>(16, std::max<long>(0, num("LQCOV_WALK_SHIFT", 0)));
 	walk_grid = (u32)std::max<long>(64, num("LQCOV_WALK_GRID", 1L << 18));
@@ -151,11 +162,23 @@ lqcov_handle::lqcov_handle(const lqcov_params &p, int dev) : P(p), device(dev)
 	if (dev < 0 || dev >= ndev) throw std::runtime_error("HIP device index out of range");
 	LQ_HIP_CHECK(hipSetDevice(dev));
 	LQ_HIP_CHECK(hipStreamCreate(&stream));
-	// (the build side -- upload, sketch, index of the next part -- runs under the mapping of the current one at the lanes' own
-	// priority: its kernels get a sixth of the device and stretch (configs[2]: sketch of part 2 560 ms under five lanes, 21 ms
-	// alone) but the part is ready in time; a high-priority build stream was measured slower: 1544-1567 vs 1508-1519 ms per step)
-	LQ_HIP_CHECK(hipStreamCreate(&bstream));
-	LQ_HIP_CHECK(hipStreamCreate(&cstream));
+	// (rounds 2-3, steps of 1.5 s: the build side at the lanes' own priority stretched -- the sketch of part 2 560 ms under five lanes,
+	// 21 ms alone -- but the part was ready in time, and a high-priority build stream was measured slower: 1544-1567 vs 1508-1519 ms)
+	{	// The build side -- upload, sketch, index and seed plan of the NEXT part -- runs beside the mapping lanes, whose second passes
+		// are thousands of single-lane waves that live for milliseconds and hold every wave slot they are given.  Round 5's trace:
+		// the sketch of part 2 stretched from 33 to 164 ms under them and its plan ended after the lanes were done with part 1 -- the
+		// build side had become the critical path.  Its streams get the queue priority that lets their blocks take the slots that
+		// free up first (LQCOV_BUILD_PRIO=0: plain streams).
+		int lo = 0, hi = 0;
+		if (K.build_prio && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi < lo) {
+			LQ_HIP_CHECK(hipStreamCreateWithPriority(&bstream, hipStreamDefault, hi));
+			LQ_HIP_CHECK(hipStreamCreateWithPriority(&cstream, hipStreamDefault, hi));
+		} else {
+			(void)hipGetLastError();
+			LQ_HIP_CHECK(hipStreamCreate(&bstream));
+			LQ_HIP_CHECK(hipStreamCreate(&cstream));
+		}
+	}
 	for (hipEvent_t &e : ev_up) LQ_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
 	lq_pool_keep_memory(dev);
 	prim.stream = stream; bprim.stream = bstream;
@@ -617,6 +640,7 @@ void lqcov_handle::reset()
 	sat_cnt.clear(); stat_sat_chains = 0;
 	finished = false;
 	LQ_HIP_CHECK(hipStreamSynchronize(stream));
+	if (lq_timeline) { lq_timeline_t0 = lq_now_s(); lq_tl("main", 0, "reset"); }
 }
 
 // ---- index part -------------------------------------------------------------------------------
@@ -721,6 +745,7 @@ void lqcov_handle::build_index(Part &pt)
 	pt.built = true;
 	pt.plan.valid = false;
 	// the part's seed plan right away, on the build stream: under the mapping of the part before when parts are pipelined
+	lq_tl("build", 0, "index done");
 	if (K.plan_ahead && have_queries && mid_occ > 0 && !distributed) plan_part(pt, stream, prim);
 	// (the build workspaces stay with the handle: repeated builds do not re-allocate, and the mapping lanes size their work
 	// space from what is free once the first part stands -- map_part)
@@ -729,8 +754,11 @@ void lqcov_handle::build_index(Part &pt)
 void lqcov_handle::build_part(Part &pt)
 {
 	if (!have_queries) throw std::logic_error("set the queries before building a part");
+	lq_tl("build", 0, "build_part begins (reads uploaded)");
 	sketch(pt.rs, true);
+	lq_tl("build", 0, "sketched");
 	build_index(pt);
+	lq_tl("build", 0, "index + seed plan done");
 }
 
 // LQCOV_DEBUG_SORT: the sort is a permutation (a sum over the anchors as emitted = the same sum afterwards: the finishing
@@ -956,6 +984,7 @@ void lqcov_handle::map_subset(MapLane &L, Part &pt, const std::vector<u32> &sq, 
 	}
 	if (nA2) {
 		sort_checked(L, pt, L.sub_off.as<u64>(), L.sub_klib.as<u32>(), ns, 0, nA2, so, sk);
+		if (lq_timeline) { LQ_HIP_CHECK(hipStreamSynchronize(L.stream)); int lane_id = 0; for (size_t i_ = 0; i_ < lanes.size(); ++i_) if (lanes[i_].get() == &L) lane_id = (int)i_; lq_tl("lane", lane_id, "  second pass sorted"); }
 		chain_stage(L, pt, L.sub_off.as<u64>(), 0, ns, 0, L.sub_q.as<u32>(), nA2, tie_mode, n_want, ivl_cap, dbg, sink);
 	}
 }
@@ -968,6 +997,8 @@ void lqcov_handle::map_batch(MapLane &L, Part &pt, u32 q0, u32 q1, const std::ve
 	lq_arena = L.arena.base ? &L.arena : nullptr;
 	struct ArenaGuard { ~ArenaGuard() { lq_arena = nullptr; } } arena_guard;
 	const u32 n_q = q.n;
+	int lane_id = 0; for (size_t i_ = 0; i_ < lanes.size(); ++i_) if (lanes[i_].get() == &L) lane_id = (int)i_;
+	lq_tl("lane", lane_id, "batch begins, queries", (double)(q1 - q0));
 	L.gate_passed = false;
 	struct GateGuard { lqcov_handle *h; MapLane &L; ~GateGuard() { if (!L.gate_passed) { L.gate_passed = true; h->open_gate(); } } } gate_guard{this, L};
 	L.n_segs.ensure(64); L.n_ivl.ensure(4); L.n_sens.ensure(4); L.want.ensure(8);
@@ -1021,6 +1052,7 @@ void lqcov_handle::map_batch(MapLane &L, Part &pt, u32 q0, u32 q1, const std::ve
 	}
 	u32 n_sens = 0;
 	if (nA && opt) d2h(&n_sens, L.n_sens.as<u32>(), 1, L.stream);
+	lq_tl("lane", lane_id, "first pass done, anchors", (double)nA);
 	if (n_sens) {
 		// ---- second pass: the queries that own a run in which klib's order can be observed ----
 		std::vector<u64> want(n_sens);
@@ -1044,7 +1076,9 @@ void lqcov_handle::map_batch(MapLane &L, Part &pt, u32 q0, u32 q1, const std::ve
 				++k;
 			}
 			stat_p2_anchors += so.back();
+			lq_tl("lane", lane_id, "second pass begins, anchors", (double)so.back());
 			map_subset(L, pt, sq, sk, so, max_mini, 2, (u32)want.size(), ivl_cap, dbg, nullptr);
+			if (lq_timeline) { LQ_HIP_CHECK(hipStreamSynchronize(L.stream)); lq_tl("lane", lane_id, "second pass done"); }
 			i = k;
 		}
 	}
@@ -1407,6 +1441,7 @@ void lqcov_handle::sort_batch(MapLane &L, Part &pt, const u64 *aqb, const u32 *q
 				check_launch();
 			}
 			d2h(hl, cnt, LQ_C_N, sD);
+			if (lq_timeline) { int lane_id = 0; for (size_t i_ = 0; i_ < lanes.size(); ++i_) if (lanes[i_].get() == &L) lane_id = (int)i_; lq_tl("lane", lane_id, "  klib level done, shift", (double)shift); }
 			ns = hl[nxt_slot];
 			std::swap(cur, nxt); std::swap(cur_slot, nxt_slot);
 			rb ^= 1;
@@ -1707,6 +1742,7 @@ void lqcov_handle::map_part(Part &pt)
 	// the part's seed plan: made with its index (build_index), or here if it was not (no queries then) or no longer fits (mid_occ
 	// set afterwards: the parts of a round of PartRunner are built before part 0's mid_occ arrives)
 	if (!pt.plan.valid || pt.plan.mid_occ != mid_occ || pt.plan.n_q != n_q || pt.plan.n_qm != n_qm || pt.plan.h_aqf.empty() != K.ties_klib || (pt.plan.bucketed && pt.plan.q_begin != 0)) plan_part(pt, stream, prim);
+	lq_tl("main", 0, "map_part begins");
 	swap_plan(pt.plan);
 	struct PlanGuard { lqcov_handle *h; SeedPlan &S; ~PlanGuard() { h->swap_plan(S); } } plan_guard{this, pt.plan};
 	const std::vector<u64> &h_aq = pt.plan.h_aq, &h_qmoff = pt.plan.h_qmoff, &h_aqf = pt.plan.h_aqf;
@@ -1894,6 +1930,7 @@ void lqcov_handle::map_part(Part &pt)
 	if (dbg) { unsigned long long nd = 0; d2h(&nd, n_dbg.as<unsigned long long>(), 1, stream); n_dbg_host = nd; }
 	sat_replay_part(pt, h_aq, h_qmoff);
 	LQ_HIP_CHECK(hipStreamSynchronize(stream));
+	lq_tl("main", 0, "map_part ends");
 }
 
 // ---- pass 2 (minimap2-coverage.c:545-566) ---------------------------------------------------------

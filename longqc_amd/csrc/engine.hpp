@@ -32,7 +32,8 @@ struct Knobs {
 	u32 ps_shift = 0;                     // LQCOV_PS_SHIFT: shrinks the size classes of the parallel sort (tests)
 	bool reg_walker = true;               // LQCOV_WALK=solo: no register-lane walker
 	bool ckpt = true, ckpt3 = true;       // LQCOV_CKPT=0: no checkpointed walks; LQCOV_CKPT3=0: the 65-160 k class is walked whole
-	u32 ck_unit = 16384, ck_unit_many = 4096;   // LQCOV_CK_UNIT / LQCOV_CK_UNIT_MANY: elements per walker's piece, passes of up to 16 / up to 256 buckets
+	bool build_prio = true;               // LQCOV_BUILD_PRIO=0: the build side's streams without the higher queue priority
+	u32 ck_unit = 65536, ck_unit_many = 8192;   // LQCOV_CK_UNIT / LQCOV_CK_UNIT_MANY: elements per checkpoint, passes of up to 16 / up to 256 buckets (configs[2], ms per step: 16384 / 4096: 502, 65536 / 4096: 502, 65536 / 8192: 491, 65536 / 16384: 491, 131072 / 8192: 494)
 	u32 sort_tile = 0;                    // LQCOV_SORT_TILE: anchors per tile of the sort's streaming kernels (0 = LQ_SORT_TILE)
 	u32 walk_shift = 0;                   // LQCOV_WALK_SHIFT: shrinks the walker size classes and the checkpoint spacing (tests)
 	u32 walk_grid = 1u << 18;             // LQCOV_WALK_GRID: cap on resident walker waves
