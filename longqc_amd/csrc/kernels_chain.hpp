@@ -753,7 +753,12 @@ __device__ __forceinline__ void lq_wave_scan_compose(i32 &fa, i32 &fb)
 	LQ_WAVE_COMPOSE_STEP(0x142, 0xa); LQ_WAVE_COMPOSE_STEP(0x143, 0xc);
 }
 #define LQ_WAVE_LANE(v, l) ((i32)__builtin_amdgcn_readlane((int)(v), (int)(l)))     // l uniform
+// What one wave's lanes tell each other through LDS needs the LDS operations done, nothing else.  __syncthreads() also waits for
+// every global access in flight -- in k_chain_wave's loop that was the load of the next anchor and the stores of f, p, v: a round
+// trip to memory per anchor, most of the microsecond an anchor took.
+#define LQ_WAVE_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 #else
+#define LQ_WAVE_SYNC() __syncthreads()
 static inline i32 lq_wave_shr1(i32 v, i32 fill) { const i32 o = __shfl_up(v, 1); return threadIdx.x == 0 ? fill : o; }
 static inline i32 lq_wave_scan_max(i32 v) { for (int d = 1; d < 64; d <<= 1) { const i32 o = __shfl_up(v, d); if ((int)threadIdx.x >= d && o > v) v = o; } return v; }
 static inline void lq_wave_scan_compose(i32 &fa, i32 &fb)
@@ -959,26 +964,36 @@ k_chain_wave(const mm128 *A, const u64 *gstart, const u32 *glist, u32 n_list, co
 	const i32 max_dist = P.max_gap, bw = P.bw, max_skip = P.max_skip;
 	for (i64 i = ln; i < n; i += 64) t[i] = 0;
 	LQ_BLOCK_SYNC();
-	i64 st = 0;
+	// Round 6: nothing in the loop waits for global memory.  (Rounds 3-5: the next anchor came as "a[i + 1] or else ai" -- choosing
+	// between a load and a local made the compiler keep ai in scratch memory and fetch through a flat pointer it waited for at once --
+	// and f, p, v went out one anchor at a time from lane 0, stores the next iteration's wait counted too: a memory round trip or two
+	// per anchor.)  Anchors: every lane holds one of the 64 at hand in registers (and one of the next 64, asked for 64 steps before
+	// their turn), the anchor of a step is a v_readlane of its lane.  f, p, v: the window holds them of the last 64 anchors -- every 64
+	// steps the lanes write theirs, 64 consecutive words each.  An anchor older than the window has been written by then: the chunks
+	// beyond the window and the second half read it from memory after a full wait.
+	const u32 n32 = (u32)n, x_hi = lq_hi32(a);
+	u32 st = 0;
 	u32 wx = 0; i32 wy = 0, wf = 0, wp = -1, wv = 0;         // lane c: x (low word), y, f, p, v of anchor i - 1 - c
-	mm128 ai = a[0];
-	for (i64 i = 0; i < n; ++i) {
-		const mm128 an = i + 1 < n ? a[i + 1] : ai;             // (the next anchor is on its way while this one is scored)
-		const u64 ri = ai.x;
-		const i32 qi = (i32)ai.y, q_span = (i32)(ai.y >> 32 & 0xff);
-		const i64 j = i - 1 - (i64)ln;
+	mm128 cur = a[ln < n32 ? ln : n32 - 1], nxt = a[64 + ln < n32 ? 64 + ln : n32 - 1];
+	for (u32 i = 0; i < n32; ++i) {
+		const u32 bi = i & 63;
+		if (bi == 0 && i) { cur = nxt; const u32 k2 = i + 64 + ln; nxt = a[k2 < n32 ? k2 : n32 - 1]; }   // (uniform)
+		const u32 rx = (u32)LQ_WAVE_LANE((u32)cur.x, bi);       // the low word of this anchor's x (the high words are equal inside a run)
+		const i32 qi = LQ_WAVE_LANE((u32)cur.y, bi), q_span = LQ_WAVE_LANE((u32)(cur.y >> 32), bi) & 0xff;
+		const u64 ri = (u64)x_hi << 32 | rx;
+		const i32 j = (i32)i - 1 - (i32)ln;
 		{	// st: the first anchor within max_dist of this one (chain.c:47).  x ascends, so the anchors out of reach are a prefix of the
 			// run: among the 64 anchors of the window the nearest one out of reach says where it ends -- no load; only when the whole
 			// window is within reach (more than 64 anchors inside max_dist) are older anchors looked at in memory
-			const u64 far = __ballot(j >= 0 && (u32)ri - wx > (u32)max_dist);
-			if (far) { const i64 s2 = i - (i64)__builtin_ctzll(far); if (s2 > st) st = s2; }
-			else while (st < i - 64 && ri - a[st].x > (u64)max_dist) ++st;   // uniform: every lane computes the same st
+			const u64 far = __ballot(j >= 0 && rx - wx > (u32)max_dist);
+			if (far) { const u32 s2 = i - (u32)__builtin_ctzll(far); if (s2 > st) st = s2; }
+			else while (st + 64 < i && ri - a[st].x > (u64)max_dist) ++st;   // uniform: every lane computes the same st
 		}
 		i32 max_f = q_span, max_j = -1, n_skip = 0, done = 0;
 		// ---- the 64 nearest candidates, from the window ----
 		bool active = false; i32 sc = 0;
-		if (j >= st) {
-			const i64 dr = (i64)((u32)ri - wx);                 // (the high words are equal inside a run)
+		if (j >= (i32)st) {
+			const i64 dr = (i64)(rx - wx);
 			const i32 dq = qi - wy;
 			if (!(dr == 0 || dq <= 0 || dq > max_dist)) {
 				const i32 dd = dr > dq ? (i32)(dr - dq) : (i32)(dq - dr);
@@ -989,27 +1004,32 @@ k_chain_wave(const mm128 *A, const u64 *gstart, const u32 *glist, u32 n_list, co
 					sc -= (i32)((double)dd * .01 * (double)avg_qspan) + (log_dd >> 1);     // chain.c:67
 					sc += wf;
 					active = true;
-					if (wp >= 0) { if ((i64)wp >= i - 64) stamp[wp & 63] = (i32)i; else t[wp] = (i32)i; }   // chain.c:76
+					if (wp >= 0) { if (wp + 64 >= (i32)i) stamp[wp & 63] = (i32)i; else t[wp] = (i32)i; }   // chain.c:76
 				}
 			}
 		}
-		LQ_BLOCK_SYNC();
+		LQ_WAVE_SYNC();
 		const bool tm = active && stamp[(u32)j & 63u] == (i32)i;
-		// two candidates of equal x inside the band, or one at the window's end whose tie partners may lie beyond: one by one
-		bool serial = false;
+		const bool more = i >= 65 + st;                          // candidates beyond the window are within reach
+		// Where the order of equal-x anchors may show in this scan (first pass only): a candidate that is one of two or more of
+		// equal x inside the band, or the window's last one when its tie partners may lie beyond.  The scan by the wave's two
+		// prefix scans below is exact up to the first such candidate -- and most scans end (chain.c:72-73) before they get there.
+		u64 ties = 0;
 		if (watch) {
-			const u64 act = __ballot(active);
 			const u32 px = (u32)lq_wave_shr1((i32)wx, 0);
 			const bool head = ln == 0 || wx != px;
 			const u64 H = __ballot(head);
-			const u32 lo = 63u - (u32)__clzll(H & (~0ULL >> (63 - ln)));                           // my run of equal x starts at lane lo ...
-			const u64 above = ln == 63 ? 0 : (H >> (ln + 1)) << (ln + 1);
-			const u32 hi = above ? (u32)__builtin_ctzll(above) - 1 : 63u;                         // ... and ends at lane hi
-			const u64 gm = (~0ULL >> (63 - hi)) & (~0ULL << lo);
-			serial = active && (__popcll(act & gm) >= 2 || (hi == 63 && i - 65 >= st));
-			serial = __ballot(serial) != 0;
+			if (~H) {                                              // (uniform) some x is repeated in the window
+				const u64 act = __ballot(active);
+				const u32 lo = 63u - (u32)__clzll(H & (~0ULL >> (63 - ln)));                           // my run of equal x starts at lane lo ...
+				const u64 above = ln == 63 ? 0 : (H >> (ln + 1)) << (ln + 1);
+				const u32 hi = above ? (u32)__builtin_ctzll(above) - 1 : 63u;                         // ... and ends at lane hi
+				const u64 gm = (~0ULL >> (63 - hi)) & (~0ULL << lo);
+				ties = __ballot(active && (__popcll(act & gm) >= 2 || (hi == 63 && more)));
+			} else ties = __ballot(active && ln == 63 && more);
 		}
-		if (!serial) {
+		bool serial = false;
+		{
 			// new bests: candidates whose score beats everything scanned before them
 			const i32 inc = lq_wave_scan_max(active ? sc : (i32)0x80000000);
 			i32 exc = lq_wave_shr1(inc, (i32)0x80000000);
@@ -1022,28 +1042,32 @@ k_chain_wave(const mm128 *A, const u64 *gstart, const u32 *glist, u32 n_list, co
 			const i32 x_after = fa > fb ? fa : fb;               // (the counter starts at 0 with every anchor)
 			const u64 brk = __ballot(skp && x_after > max_skip);
 			const u32 cb = brk ? (u32)__builtin_ctzll(brk) : 64u;   // the scan ends at candidate cb (chain.c:72-73)
-			const u64 recm = __ballot(rec) & (cb >= 63 ? ~0ULL : (2ULL << cb) - 1);
-			if (recm) { const int last = 63 - __clzll(recm); max_f = LQ_WAVE_LANE(sc, last); max_j = (i32)(i - 1 - last); }
-			done = cb < 64 ? 1 : 0;
-			n_skip = LQ_WAVE_LANE(x_after, 63);
-		} else {
-			cand[ln].sc = sc; cand[ln].j = (i32)j; cand[ln].flags = (active ? 1 : 0) | (tm ? 2 : 0); cand[ln].x32 = wx;
+			serial = ties && (u32)__builtin_ctzll(ties) <= cb;      // (uniform) a candidate whose tie order may show is scanned
+			if (!serial) {
+				const u64 recm = __ballot(rec) & (cb >= 63 ? ~0ULL : (2ULL << cb) - 1);
+				if (recm) { const int last = 63 - __clzll(recm); max_f = LQ_WAVE_LANE(sc, last); max_j = (i32)i - 1 - last; }
+				done = cb < 64 ? 1 : 0;
+				n_skip = LQ_WAVE_LANE(x_after, 63);
+			}
+		}
+		if (serial) {                                              // one by one, with the rule of TieGroup
+			cand[ln].sc = sc; cand[ln].j = j; cand[ln].flags = (active ? 1 : 0) | (tm ? 2 : 0); cand[ln].x32 = wx;
 			if (ln == 0) { st_sh[0] = max_f; st_sh[1] = max_j; st_sh[2] = 0; st_sh[3] = 0; st_sh[8] = 0; }
-			LQ_BLOCK_SYNC();
-			if (ln == 0) lq_wave_replay(cand, st_sh, i - st < 64 ? i - st : 64, i - 65 >= st, watch, max_skip);
-			LQ_BLOCK_SYNC();
+			LQ_WAVE_SYNC();
+			if (ln == 0) lq_wave_replay(cand, st_sh, i - st < 64 ? i - st : 64, more, watch, max_skip);
+			LQ_WAVE_SYNC();
 			max_f = st_sh[0]; max_j = st_sh[1]; n_skip = st_sh[2]; done = st_sh[3];
 		}
 		// ---- candidates beyond the window (rare: 64 of them scanned without the break) ----
 		bool beyond = false;
-		if (!done && i - 65 >= st) {
+		if (!done && more) {
 			LQ_BLOCK_SYNC();
 			if (ln == 0) { st_sh[0] = max_f; st_sh[1] = max_j; st_sh[2] = n_skip; st_sh[3] = 0; if (!serial) st_sh[8] = 0; }
 			LQ_BLOCK_SYNC();
-			for (i64 top = i - 65; top >= st; top -= 64) {
+			for (i64 top = (i64)i - 65; top >= (i64)st; top -= 64) {
 				const i64 jj = top - (i64)ln;
 				i32 c_sc = 0, c_flags = 0; u32 c_x32 = 0;
-				if (jj >= st) {
+				if (jj >= (i64)st) {
 					const mm128 aj = a[jj];
 					c_x32 = (u32)aj.x;
 					const i64 dr = (i64)(ri - aj.x);
@@ -1066,7 +1090,7 @@ k_chain_wave(const mm128 *A, const u64 *gstart, const u32 *glist, u32 n_list, co
 				LQ_BLOCK_SYNC();
 				if (cand[ln].flags & 1) { if (t[cand[ln].j] == (i32)i) cand[ln].flags |= 2; }
 				LQ_BLOCK_SYNC();
-				if (ln == 0) lq_wave_replay(cand, st_sh, top - st + 1 < 64 ? top - st + 1 : 64, top - 64 >= st, watch, max_skip);
+				if (ln == 0) lq_wave_replay(cand, st_sh, top - (i64)st + 1 < 64 ? top - (i64)st + 1 : 64, top - 64 >= (i64)st, watch, max_skip);
 				LQ_BLOCK_SYNC();
 				if (st_sh[3]) break;
 			}
@@ -1080,15 +1104,15 @@ k_chain_wave(const mm128 *A, const u64 *gstart, const u32 *glist, u32 n_list, co
 		// ---- f, p, v of anchor i; the window moves on ----
 		i32 vi = max_f;
 		if (max_j >= 0) {
-			const i64 back = i - 1 - (i64)max_j;
+			const u32 back = i - 1 - (u32)max_j;
+			if (back >= 64) LQ_BLOCK_SYNC();                         // (v[] of an anchor that has left the window: from memory, where its lane stored it)
 			const i32 vj = back < 64 ? LQ_WAVE_LANE(wv, back) : v[max_j];      // (uniform branch: max_j is)
 			if (vj > max_f) vi = vj;
 		}
-		if (ln == 0) { f[i] = max_f; p[i] = max_j; v[i] = vi; }
-		{
-			wx = (u32)lq_wave_shr1((i32)wx, (i32)(u32)ri); wy = lq_wave_shr1(wy, qi); wf = lq_wave_shr1(wf, max_f); wp = lq_wave_shr1(wp, max_j); wv = lq_wave_shr1(wv, vi);
+		wx = (u32)lq_wave_shr1((i32)wx, (i32)rx); wy = lq_wave_shr1(wy, qi); wf = lq_wave_shr1(wf, max_f); wp = lq_wave_shr1(wp, max_j); wv = lq_wave_shr1(wv, vi);
+		if (bi == 63 || i + 1 == n32) {                          // (uniform) lane c holds anchor i - c: the anchors of this block of 64 go to memory
+			if (ln <= bi) { const u32 k = i - ln; f[k] = wf; p[k] = wp; v[k] = wv; }
 		}
-		ai = an;
 	}
 	LQ_BLOCK_SYNC();
 	const bool listed = st_sh[4] != 0;                          // (uniform)
