@@ -329,7 +329,7 @@ int lqcov_part_clear(lqcov_handle *h, int part)
 	return guard(h, [&] {
 		Part &pt = h->part(part);
 		ReadSetDev &rs = pt.rs;
-		rs.n = 0; rs.n_chunks = 0; rs.n_bases = 0; rs.n_mini = 0; rs.sketched = false;
+		rs.n = 0; rs.n_chunks = 0; rs.n_bases = 0; rs.n_mini = 0; rs.sketched = false; rs.dp_n = 0; rs.dp_tiles = 0;
 		rs.h_coff.assign(1, 0); rs.h_len.clear(); rs.names.clear();
 		pt.built = false; pt.n_keys = 0;
 	});

@@ -271,7 +271,7 @@ void lqcov_handle::add_reads(ReadSetDev &rs, u32 n, const u8 *seq, const u64 *se
 	}
 	LQ_HIP_CHECK(hipStreamSynchronize(stream));              // staging buffers die here
 	rs.n += n; rs.n_chunks += new_chunks; rs.n_bases += n_bases;
-	rs.sketched = false;
+	rs.sketched = false; rs.dp_n = 0; rs.dp_tiles = 0;
 }
 
 // ---- packed reads from the host -----------------------------------------------------------------
@@ -379,7 +379,7 @@ void lqcov_handle::add_reads_packed(ReadSetDev &rs, u32 n, const u64 *codes, con
 			r0 = r1;
 		}
 		LQ_HIP_CHECK(hipStreamSynchronize(cstream));          // the caller's buffers are free again
-		rs.dp_n = rs.n; rs.dp_tiles = n_tiles;
+		rs.dp_n = rs.n; rs.dp_tiles = n_tiles; rs.dp_gen = sk_gen;
 		return;
 	}
 	(void)first; (void)chunk0;
@@ -404,6 +404,7 @@ bool lqcov_handle::sketch_dp_setup(ReadSetDev &rs, u64 &n_tiles)
 	sk_mask.ensure(nc * LQ_CHUNK_WORDS * 4 + 64); sk_flag.ensure(4);
 	dzero(sk_mask.p, nc * LQ_CHUNK_WORDS * 4, stream); dzero(sk_flag.p, 4, stream);
 	sk_grid.ensure((nc / LQ_EM_CH + 2) * 4);
+	sk_owner = &rs; ++sk_gen;                                 // (the handle's mask, owner and tile buffers now describe these reads and nobody else's)
 	sk_h_toff.assign(rs.n + 1, 0);
 	for (u32 r = 0; r < rs.n; ++r) sk_h_toff[r + 1] = sk_h_toff[r] + (rs.h_coff[r + 1] - rs.h_coff[r] + LQ_DPT_CH - 1) / LQ_DPT_CH;
 	n_tiles = sk_h_toff[rs.n];
@@ -468,6 +469,7 @@ void lqcov_handle::sketch(ReadSetDev &rs, bool rid_in_y)
 			const bool dp = P.w <= 16 && P.w + P.k - 1 <= 48 && P.k <= 28 && P.k >= 2 && !K.sketch_machine_only;
 			const u8 *dp_owned = nullptr;
 			if (!dp) {
+				sk_owner = &rs; ++sk_gen;
 				sk_mask.ensure(nc * LQ_CHUNK_WORDS * 4 + 64); sk_flag.ensure(4);
 				dzero(sk_mask.p, nc * LQ_CHUNK_WORDS * 4, stream); dzero(sk_flag.p, 4, stream);
 				sk_grid.ensure((nc / LQ_EM_CH + 2) * 4);
@@ -476,7 +478,9 @@ void lqcov_handle::sketch(ReadSetDev &rs, bool rid_in_y)
 			if (dp) {
 				// (the tiles may be done already: add_reads_packed runs the kernel slice by slice under the upload)
 				u64 n_tiles = rs.dp_tiles;
-				if (rs.dp_n != rs.n) { if (!sketch_dp_setup(rs, n_tiles)) throw std::logic_error("sketch: set-up of the data-parallel kernel"); sketch_dp_launch(rs, 0, n_tiles); }
+				// (the tiles done ahead of time count only if the handle's mask buffers are still this read set's: a query set, or another
+				// part added in packed form, sketched in between has taken them over)
+				if (rs.dp_n != rs.n || sk_owner != &rs || rs.dp_gen != sk_gen) { if (!sketch_dp_setup(rs, n_tiles)) throw std::logic_error("sketch: set-up of the data-parallel kernel"); sketch_dp_launch(rs, 0, n_tiles); }
 				rs.dp_n = 0; rs.dp_tiles = 0;                          // (the mask is used up below: a second sketch of the same reads starts from an empty one)
 				lap("dp_mask");
 				dp_owned = sk_owned.as<u8>();
@@ -1709,7 +1713,9 @@ void lqcov_handle::plan_part(Part &pt, hipStream_t s, Prim &pr)
 			S.rec_nmin = n_min; S.rec_jb = jb; S.rec_db = db;
 			// (measured and dropped, round 5: the filter run batch by batch inside map_part, each lane starting as soon as its batch is
 			// decided -- 586-588 ms per step at configs[2] against 576: beside the lanes' kernels the filter's take three times as long)
-			S.bucketed = seed_group(pt, S, false, s, pr, 0);
+			// (an allocation that fails inside the filter -- its bucket buffer is up to 8 GB -- leaves the part without one: every hit is written)
+			try { S.bucketed = seed_group(pt, S, false, s, pr, 0); }
+			catch (const std::runtime_error &) { (void)hipGetLastError(); S.surv.release(); for (DBuf *b : { &seed_ws.rec, &seed_ws.cnt, &seed_ws.off, &seed_ws.bd }) b->release(); S.bucketed = false; }
 		}
 		if (!S.bucketed) {
 			S.q_begin = 0; S.q_end = n_q;
@@ -1915,7 +1921,9 @@ void lqcov_handle::map_part(Part &pt)
 		run_batches(cut_batches(opt ? h_aqf : h_aq, g_begin, g_end));   // (cut by the anchors the first pass writes)
 		if (g_end >= n_q) break;
 		regrouped = true;
-		const bool ok = seed_group(pt, pt.plan, true, stream, prim, g_end);
+		bool ok = false;
+		try { ok = seed_group(pt, pt.plan, true, stream, prim, g_end); }
+		catch (const std::runtime_error &) { (void)hipGetLastError(); for (DBuf *b : { &seed_ws.rec, &seed_ws.cnt, &seed_ws.off, &seed_ws.bd }) b->release(); ok = false; }
 		if (!ok) {                                                  // (no room: the rest of the part without the filter)
 			pt.plan.bucketed = false;
 			pt.plan.h_aqf = pt.plan.h_aq;
@@ -2412,7 +2420,7 @@ int lqcov_handle::run_files(const char *target, const char *query, FILE *out, FI
 			HostPart &h = hp[slot];
 			{	// (a Part object is used again: what lqcov_part_clear does)
 				ReadSetDev &rs = pt.rs;
-				rs.n = 0; rs.n_chunks = 0; rs.n_bases = 0; rs.n_mini = 0; rs.sketched = false;
+				rs.n = 0; rs.n_chunks = 0; rs.n_bases = 0; rs.n_mini = 0; rs.sketched = false; rs.dp_n = 0; rs.dp_tiles = 0;
 				rs.h_coff.assign(1, 0); rs.h_len.clear(); rs.names.clear();
 				pt.built = false; pt.n_keys = 0; pt.live = true;
 			}

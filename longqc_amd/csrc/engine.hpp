@@ -89,6 +89,7 @@ struct ReadSetDev {                       // a read set 2-bit packed in HBM, chu
 	u64 n_mini = 0;
 	bool sketched = false;
 	u32 dp_n = 0; u64 dp_tiles = 0;       // add_reads_packed has already run k_sketch_dp_mask over the tiles of these reads (slice by slice, under the upload of the next slice)
+	u64 dp_gen = 0;                       // ... into the handle's mask buffers of that generation (lqcov_handle::sk_gen): another read set sketched since, and dp_n is void
 };
 
 // What the mapping of a part needs before its first batch, and what depends only on the part, the query set and mid_occ (not
@@ -245,6 +246,7 @@ struct lqcov_handle {
 	const Part *ix_owner = nullptr;       // the part ix_ukey / ix_ustart / ix_ucnt describe (dump_part reads them)
 	DBuf sk_cnt, sk_off, sk_owned, sk_mask, sk_flag, sk_toff, sk_trid, sk_grid;   // sketch: per-chunk minimizer counts / offsets, which kernel decides a chunk, emitted positions (a bit per base), tile offsets
 	std::vector<u64> sk_h_toff;           // tiles of k_sketch_dp_mask before every read (host copy of sk_toff)
+	const ReadSetDev *sk_owner = nullptr; u64 sk_gen = 0;   // whose reads the sk_* buffers describe right now (sketch_dp_setup): a read set's dp_n counts only while they are its own
 	u64 last_n_anchors = 0;
 	u64 anchor_budget = 0;
 

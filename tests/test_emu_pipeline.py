@@ -244,6 +244,46 @@ def test_emulated_reset_and_rerun(emu_lib, packed):
     check_reset_and_rerun(emu_lib, packed)
 
 
+@pytest.mark.parametrize("order", ["queries_after_add", "two_parts_added_first", "clear_and_add_again"])
+def test_emulated_packed_upload_mask_belongs_to_one_read_set(emu_lib, order):
+    """The data-parallel sketch kernel runs under the upload of packed reads into mask buffers the handle shares between read sets
+    (round-5 advice): whatever is sketched between a part's add_packed and its build -- the queries, another part -- must not leave
+    the part with somebody else's mask.  Legal API orders the in-repo drivers never use."""
+    tn, ts, _ = read_fastx(os.path.join(GOLDEN, "tiny_all.fq.gz"))
+    qn, qs, qq = read_fastx(os.path.join(GOLDEN, "tiny_sub.fq.gz"))
+    os.environ["LQCOV_UPLOAD_MIN_CHUNKS"] = "1"; os.environ["LQCOV_UPLOAD_SLICES"] = "3"
+    try:
+        eng = _engine(emu_lib)
+    finally:
+        os.environ.pop("LQCOV_UPLOAD_MIN_CHUNKS", None); os.environ.pop("LQCOV_UPLOAD_SLICES", None)
+    flat = np.concatenate(ts); off = np.concatenate([[0], np.cumsum([len(x) for x in ts])]).astype(np.uint64)
+    P = api.PackedReads(flat, off, list(tn), lib=emu_lib)
+    want = read_gz("tiny_ont.table.gz")
+    if order == "queries_after_add":
+        pt = eng.part_begin()
+        eng.part_add_packed(pt, P)
+        eng.set_queries(qn, qs, qq)                       # (sketches the queries: the shared buffers change hands)
+        eng.reset(); eng.part_build(pt); eng.part_map(pt); eng.finish()
+        assert eng.table_text() == want
+    elif order == "two_parts_added_first":
+        eng.set_queries(qn, qs, qq)
+        half = len(tn) // 2
+        a, b = eng.part_begin(), eng.part_begin()
+        eng.part_add_packed(a, P, 0, len(tn))             # the whole set in a ...
+        eng.part_add_packed(b, P, 0, half)                # ... and another read set added before a is built
+        eng.reset(); eng.part_build(a); eng.part_map(a); eng.finish()
+        assert eng.table_text() == want
+    else:
+        eng.set_queries(qn, qs, qq)
+        pt = eng.part_begin()
+        eng.part_add_packed(pt, P, 0, len(tn) // 2)
+        eng.part_clear(pt)
+        eng.part_add_packed(pt, P)                        # the same part object, other reads
+        eng.reset(); eng.part_build(pt); eng.part_map(pt); eng.finish()
+        assert eng.table_text() == want
+    eng.close()
+
+
 @pytest.mark.parametrize("shift", ["4", pytest.param("7", marks=slow_emu), pytest.param("12", marks=slow_emu)])
 def test_emulated_every_walk_size_class(emu_lib, datasets, monkeypatch, shift):
     """shrinks the LDS-window thresholds of the klib-order sort so that small inputs exercise every size class
