@@ -449,8 +449,8 @@ class Engine:
         self._ck(self.lib.lqcov_set_profiling(self.h, int(on)))
 
     def stage_times(self) -> List[dict]:
-        arr = (StageTime * 64)()
-        n = self._ck(self.lib.lqcov_get_stage_times(self.h, arr, 64))
+        arr = (StageTime * 160)()
+        n = self._ck(self.lib.lqcov_get_stage_times(self.h, arr, 160))
         return [dict(name=arr[i].name.decode(), total_ms=arr[i].total_ms, launches=arr[i].launches, algo_bytes=arr[i].algo_bytes)
                 for i in range(n)]
 

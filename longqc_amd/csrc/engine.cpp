@@ -59,7 +59,8 @@ int lq_trace_launches = 0;
 // ---- stage timing ---------------------------------------------------------------------------
 StageTimer::StageTimer(lqcov_handle *h_, hipStream_t s_, const char *name_, u64 bytes_) : h(h_), s(s_), name(name_), bytes(bytes_)
 {
-	on = h->profiling && (h->profile_only.empty() || h->profile_only == name_);
+	// (profile_only: one stage name, or several separated by '|' -- bench.py times the group of kernels that bounds the step)
+	on = h->profiling && (h->profile_only.empty() || h->profile_only == name_ || ("|" + h->profile_only + "|").find(std::string("|") + name_ + "|") != std::string::npos);
 	if (!on) return;
 	hipEventCreate(&a); hipEventCreate(&b);
 	hipEventRecord(a, s);
@@ -139,7 +140,6 @@ void Knobs::read_env()
 	parse_side = getenv("LQCOV_PARSE_SIDE") ? strtoull(getenv("LQCOV_PARSE_SIDE"), 0, 10) : 2ULL << 30;
 	pipeline = num("LQCOV_PIPELINE", 1) != 0;
 	plan_ahead = num("LQCOV_PLAN_AHEAD", 1) != 0;
-	pool = num("LQCOV_POOL", 0) != 0;
 	cnt_bits = (int)std::min<long>(16, std::max<long>(2, num("LQCOV_TEST_CNT_BITS", 16)));
 	seed_bucket = (u32)std::min<long>(1L << 24, std::max<long>(16, num("LQCOV_SEED_BUCKET", 7600)));
 	seed_chunk = getenv("LQCOV_SEED_CHUNK") ? std::max<u64>(1024, strtoull(getenv("LQCOV_SEED_CHUNK"), 0, 10)) : 1ULL << 30;
@@ -930,8 +930,6 @@ void lqcov_handle::sat_replay_part(Part &pt, const std::vector<u64> &h_aq, const
 		sat_rec.ensure(rec_cap * sizeof(SatRec)); sat_at.ensure(at_cap * 4 + 4);
 		dzero(sat_n.p, 16, L.stream);
 		const SatSink sink{sat_rec.as<SatRec>(), sat_n.as<unsigned long long>(), rec_cap, sat_at.as<u32>(), sat_n.as<unsigned long long>() + 1, at_cap};
-		lq_alloc_stream = K.pool ? L.stream : nullptr;
-		struct AllocGuard { ~AllocGuard() { lq_alloc_stream = nullptr; } } alloc_guard;
 		L.n_segs.ensure(64); L.n_ivl.ensure(4); L.n_sens.ensure(4); L.want.ensure(8); L.ivl.ensure(sizeof(Ivl));
 		map_subset(L, pt, std::vector<u32>{qi}, std::vector<u32>{len > LQ_RS_MIN ? 1u : 0u}, std::vector<u64>{0, len}, h_qmoff[qi + 1] - h_qmoff[qi], 0, 0, 0, false, &sink);
 		unsigned long long nn[2] = {0, 0};
@@ -1853,8 +1851,6 @@ void lqcov_handle::map_part(Part &pt)
 		const bool concurrent = can_thread && n_lanes > 1 && batches.size() > 1;
 		if (!concurrent) {
 			for (size_t i = 0; i < batches.size(); ++i) {
-				lq_alloc_stream = K.pool ? lanes[i % n_lanes]->stream : nullptr;
-				struct AllocGuard { ~AllocGuard() { lq_alloc_stream = nullptr; } } alloc_guard;
 				map_batch(*lanes[i % n_lanes], pt, batches[i].first, batches[i].second, h_aq, h_aqf, h_qmoff, dbg);
 			}
 			for (auto &L : lanes) LQ_HIP_CHECK(hipStreamSynchronize(L->stream));
@@ -1872,8 +1868,8 @@ void lqcov_handle::map_part(Part &pt)
 					lq_segv_altstack();
 #endif
 					MapLane &L = *lanes[li];
-					lq_alloc_stream = K.pool ? L.stream : nullptr;           // (LQCOV_POOL=1: this thread's buffers grow from the stream-ordered pool, prim.hpp)
-					struct AllocGuard { ~AllocGuard() { lq_alloc_stream = nullptr; } } alloc_guard;
+					// (round 6: the switch that let a lane's buffers grow from HIP's stream-ordered pool -- rounds 2-4's way, under ROCm 7.2 a
+					// GPU memory fault waiting to happen, see DESIGN.md section 2 -- is gone; only the lanes' arenas come from the pool, taken once)
 					{	// staggered start: lane li begins when li batches have got past their sort (or ended), so that
 						// one lane's serial tails run under another lane's wide kernels instead of side by side
 						std::unique_lock<std::mutex> lk(gate_mu);

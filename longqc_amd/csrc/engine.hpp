@@ -54,7 +54,6 @@ struct Knobs {
 	bool sketch_machine_only = false;     // LQCOV_SKETCH=machine: the state machine decides every chunk (no data-parallel kernel)
 	bool ties_klib = false;               // LQCOV_TIES=klib (or LQCOV_SORT=klib): klib's order of equal-x anchors everywhere, every seed hit written and sorted (rounds 1-3); default: only where it can be observed (map_batch)
 	bool filter = true;                   // LQCOV_FILTER=0: the first pass writes every seed hit (no counting filter)
-	bool pool = false;                    // LQCOV_POOL=1: the lanes' work buffers grow from HIP's stream-ordered pool (hipMallocAsync) instead of hipMalloc.  Off since round 5: with a first pass of a few per cent of the hits the lanes' buffers grow again inside their first second pass, three lanes at once, and under ROCm 7.2's runtime blocks the pool took back were handed out while still in use (a GPU memory fault in the executable; tables that differed from run to run)
 	bool plan_ahead = true;               // LQCOV_PLAN_AHEAD=0: a part's seed plan (probe, survivors) is made when the part is mapped, not right after its index
 	int parse_threads = 0;                // LQCOV_PARSE_THREADS: threads that parse and pack a plain target file (0: one per core, at most 64; 1: the streaming reader as for gzip)
 	u64 parse_piece = 32u << 20;          // LQCOV_PARSE_PIECE: bytes of the file a thread parses at a time (tests shrink it: many guessed record starts)

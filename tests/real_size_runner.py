@@ -1,4 +1,5 @@
-"""One real-size parity case in a process of its own (tests/test_gpu_parity.py::test_gpu_real_size_parts_rows_equal_the_reference_fixture):
+"""One real-size parity case (tests/test_gpu_parity.py::test_gpu_real_size_parts_rows_equal_the_reference_fixture calls main() in the
+test process; on its own:)
     python -m tests.real_size_runner cfg4s|cfg5s
 Index parts of REAL size (-I 4G) through the part-level C ABI, 40 rows compared with what the reference binary printed in the
 build container (tests/golden/<name>_rows.json, made by tests/golden/make_scale_golden.py)."""
@@ -14,7 +15,7 @@ sys.path.insert(0, ROOT)
 from longqc_amd import api, multigpu, synth  # noqa: E402
 
 
-def main(name):
+def main(name, lib=None):
     g = json.load(open(os.path.join(ROOT, "tests", "golden", name + "_rows.json")))
     cfg = synth.SCALE_SLICES[name]
     genome = synth.make_genome(cfg)
@@ -25,7 +26,7 @@ def main(name):
     parts = multigpu.split_parts(lens, int(p.batch_size), int(p.idx_mini_batch))
     assert len(parts) >= (3 if name == "cfg4s" else 2)
     P = api.PackedReads(F.flat, F.off, F.names())
-    eng = api.Engine(p, device=0, lib=api.load_library())
+    eng = api.Engine(p, device=0, lib=lib or api.load_library())
     eng.set_queries(Q.names, Q.seqs, Q.quals)
     pt = eng.part_begin()
     for lo, hi in parts:

@@ -27,7 +27,12 @@ def main():
     fd, wd, out = sys.argv[1], sys.argv[2], sys.argv[3]
     tag = sys.argv[4] if len(sys.argv) > 4 else ""
     F, W = per_kernel(fd, "FETCH_SIZE"), per_kernel(wd, "WRITE_SIZE")
-    res = {"workload": tag, "formula": "hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950 read correction)", "kernels": {}}
+    commit = ""
+    try:
+        commit = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), ".build_commit")).read().strip()
+    except Exception:
+        pass
+    res = {"workload": tag, "commit": commit, "steps": 1, "formula": "hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950 read correction)", "kernels": {}}
     for k in sorted(set(F) | set(W)):
         fs, fn = F.get(k, [0.0, 0]); ws, wn = W.get(k, [0.0, 0])
         n = max(fn, wn, 1)
