@@ -129,6 +129,47 @@ def golden_check(cfg_name, table_text):
             "fixture": os.path.basename(fn), "note": "rows printed by the reference binary for these queries against the whole read set"}
 
 
+def table_properties(table_text, names, lengths):
+    """Size-independent checks of a coverage table (configs too large for reference rows): one row per query in the queries' order, the
+    name and length columns, regions inside [0, length], ascending and disjoint, the coverage columns finite and equal to lambda / covered
+    bases (minimap2-coverage.c:563-605).  Returns counts; "ok" only if every row passes."""
+    lines = table_text.splitlines()
+    bad = []
+    n_reg = 0; cov = []
+    if len(lines) != len(names):
+        bad.append("rows %d != queries %d" % (len(lines), len(names)))
+    for i, (l, nm, ln) in enumerate(zip(lines, names, lengths)):
+        f = l.split("\t")
+        try:
+            assert len(f) == 9, "columns"
+            assert f[0] == nm, "name"
+            assert int(f[1]) == int(ln), "length"
+            lam = int(f[2]); assert lam >= 0
+            tot = 0
+            for col in (3, 4):
+                if f[col] == "0":
+                    continue
+                prev = -1
+                for r in f[col].split(","):
+                    a, b = (int(x) for x in r.split("-"))
+                    assert 0 <= a < b <= int(ln) and a >= prev, "region"
+                    prev = b
+                    if col == 3:
+                        tot += b - a
+            if f[3] != "0":
+                n_reg += 1
+                assert abs(float(f[5]) - lam / tot) < 6e-4 + 1e-6 * lam / tot, "coverage column"
+                cov.append(lam / tot)
+            for col in (5, 6, 7, 8):
+                v = float(f[col]); assert v == v or col == 6, "nan"     # (meanQ of a FASTA query prints -nan, lqutils.c:57)
+        except Exception as e:
+            bad.append("row %d: %s" % (i, e))
+            if len(bad) > 5:
+                break
+    return {"ok": not bad, "rows": len(lines), "rows_with_regions": n_reg, "mean_coverage_of_covered": round(float(np.mean(cov)), 3) if cov else None,
+            "max_coverage": round(float(np.max(cov)), 3) if cov else None, "problems": bad[:5]}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -325,15 +366,20 @@ def main():
         pts = [eng.part_begin(), eng.part_begin()]
         plan = []
         for (lo, hi), (sa, sb), (Ps, s0, s1) in zip(parts, shares, share_reads):
-            def add(pt, Ps=Ps, s0=s0, s1=s1):
-                if s1 > s0:
-                    eng.part_add_packed(pt, Ps, s0, s1)
-            plan.append((add, sa, api.encode_names(names_of(lo, hi)), lens[lo:hi].astype(np.uint32)))
+            # (this rank's share of the part as packed reads on the host: the runner all-gathers the packed reads -- 0.375 B per base --
+            # and every rank sketches and indexes the whole part; LQCOV_EXCHANGE=minimizers: rounds 4-5's all-gather of per-rank sketches)
+            if os.environ.get("LQCOV_EXCHANGE") == "minimizers":
+                def add(pt, Ps=Ps, s0=s0, s1=s1):
+                    if s1 > s0:
+                        eng.part_add_packed(pt, Ps, s0, s1)
+                plan.append((add, sa, api.encode_names(names_of(lo, hi)), lens[lo:hi].astype(np.uint32)))
+            else:
+                plan.append(((Ps, s0, s1), sa, api.encode_names(names_of(lo, hi)), lens[lo:hi].astype(np.uint32)))
         reserve = 0
         if len(parts) > 1 and have_cuda:
             # room for the part whose front runs under the mapping (a second part object: 24 B per minimizer ~ 8 B per base, its
-            # tables) and for the exchange buffers (2.2 x 16 B per minimizer)
-            reserve = int(max(int(lens[lo:hi].sum()) for lo, hi in parts[1:]) * (9.5 + 12.0))
+            # tables) and for the exchange buffers (packed reads: (N + 1) x 0.4 B per base; minimizers: 2.2 x 16 B per minimizer)
+            reserve = int(max(int(lens[lo:hi].sum()) for lo, hi in parts[1:]) * (9.5 + (12.0 if os.environ.get("LQCOV_EXCHANGE") == "minimizers" else 0.42 * (world + 1) / 3.0)))
         if one_dev and have_cuda:
             # (test mode: the ranks share one device -- each leaves the others their share of what is free now; the lanes size
             # their work space from what is free when the first part stands, and two ranks doing that at once ran the device dry)
@@ -576,10 +622,11 @@ def main():
                                 + ("part i+1's upload + sketch + index under part i's mapping; " if world == 1 and len(parts) > 1 else "") +
                                 "before the clock: the synthetic generator (= FASTQ parse) and the host-side 2-bit packing (host_pack_s) -- value_incl_host_pack adds the latter, unoverlapped",
                        "parallelism": "single GPU" if world == 1 else
-                                      ("%d GPUs: index parts across the GPUs in rounds of %d, every rank maps all queries against its part; mid_occ broadcast from part 0, COVT cap and "
-                                       "avg_k replayed in part order, sums all-reduced, intervals all-gathered (RCCL)" % (world, world)) if split == "parts" else
-                                      ("%d GPUs: queries sharded 1/N, index replicated (each rank sketches 1/N of a part, minimizers all-gathered over RCCL, identical index everywhere; "
-                                       "the front of part i + 1 under the mapping of part i), rows gathered on rank 0" % world),
+                                      ("%d GPUs (torch.distributed world size %d, backend %s): index parts across the GPUs in rounds of %d, every rank maps all queries against its part; mid_occ broadcast from part 0, COVT cap and "
+                                       "avg_k replayed in part order, sums all-reduced, intervals all-gathered (RCCL)" % (world, dist.get_world_size(), dist.get_backend(), world)) if split == "parts" else
+                                      ("%d GPUs (torch.distributed world size %d, backend %s): queries sharded 1/N, index replicated (each rank uploads 1/N of a part's packed reads, the packed reads are "
+                                       "all-gathered over RCCL -- 0.375 B per base --, every rank sketches the part and builds the identical index; "
+                                       "the front of part i + 1 under the mapping of part i), rows gathered on rank 0" % (world, dist.get_world_size(), dist.get_backend())),
                        "scaling_model_s": None if world == 1 else {"queries_sharded": round(tq, 3), "parts_across_gpus": round(tp, 3), "single_gpu": round(multigpu.QueryShardRunner.scaling_model(1, part_bases), 3),
                                                                    "note": "predicted seconds per job from the single-GPU stage rates of round 4 (longqc_amd/multigpu.py); the faster split runs"}},
             "roofline": roof, "north_star": north,
@@ -590,6 +637,7 @@ def main():
         }
         if full_config:
             line["golden_rows"] = golden_check(args.config, table)
+        line["table_properties"] = table_properties(table, Q.names, [int(x.shape[0]) for x in Q.seqs])
         if world == 1 and not args.no_cpu_baseline:
             n_t = args.cpu_sample or {"cfg3": 25000, "cfg2": 35000, "cfg4": 15000, "cfg4s": 15000, "cfg5": 5000, "cfg5s": 5000}.get(args.config, 25000)
             line["cpu_baseline"] = cpu_baseline(args.config, F, Q, n_t, len(Q) if n_t >= len(F) else max(50, n_t // 100))

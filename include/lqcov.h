@@ -147,6 +147,14 @@ void *lqcov_host_alloc(size_t bytes);
 void  lqcov_host_free(void *p);
 int lqcov_part_add_packed(lqcov_handle *h, int part, uint32_t n, const uint64_t *codes, const uint32_t *amb, const uint32_t *lens,
                           const char *names, const uint64_t *name_off);
+/* The same reads from DEVICE memory, in shares: share i (share_chunks[i] 128-base chunks, a whole number of reads) starts at chunk
+ * i * stride_chunks of codes_dev (4 x u64 per chunk) / amb_dev (4 x u32 per chunk); the shares are copied back to back in
+ * share order = read order.  For a host that received the packed reads of a part from its peers (the query-sharded multi-GPU
+ * split all-gathers 0.375 B per base over RCCL instead of 16 B per minimizer): lens / names describe every read of the part.
+ * No counterpart in the reference (its parts come from one file, bseq.c:68-102). */
+int lqcov_part_add_packed_shares_dev(lqcov_handle *h, int part, const uint64_t *codes_dev, const uint32_t *amb_dev, uint64_t stride_chunks,
+                                     uint32_t n_shares, const uint64_t *share_chunks, uint32_t n, const uint32_t *lens,
+                                     const char *names, const uint64_t *name_off);
 int lqcov_part_clear(lqcov_handle *h, int part);    /* forget the part's reads and index, keep its device buffers (bench: the same part object every step) */
 int lqcov_part_build(lqcov_handle *h, int part);    /* sketch + index (+ mid_occ once): index.c:291-330, map.c:46-54 */
 int lqcov_part_map(lqcov_handle *h, int part);      /* == lq_map_file (lqmap.c:852): accumulates into the handle */

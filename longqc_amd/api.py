@@ -87,6 +87,7 @@ def load_library(path: Optional[str] = None):
         "lqcov_host_alloc": (C.c_void_p, [C.c_size_t]),
         "lqcov_host_free": (None, [C.c_void_p]),
         "lqcov_part_add_packed": (C.c_int, [H, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+        "lqcov_part_add_packed_shares_dev": (C.c_int, [H, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
         "lqcov_part_clear": (C.c_int, [H, C.c_int]),
         "lqcov_part_build": (C.c_int, [H, C.c_int]),
         "lqcov_part_sketch": (C.c_int, [H, C.c_int]),
@@ -297,6 +298,14 @@ class Engine:
         blob = packed.names_blob[int(packed.name_off[lo]):int(packed.name_off[hi])]
         self._ck(self.lib.lqcov_part_add_packed(self.h, part, hi - lo, packed.codes_ptr + c0 * 32, packed.amb_ptr + c0 * 16,
                                                 lens.ctypes.data, blob, noff.ctypes.data))
+
+    def part_add_packed_shares_dev(self, part: int, codes_ptr: int, amb_ptr: int, stride_chunks: int, share_chunks, lens: np.ndarray, names: Sequence[str]):
+        """the packed reads of a whole part from device memory: share i (share_chunks[i] chunks of 128 bases) at chunk i * stride_chunks of
+        codes_ptr (32 B per chunk) / amb_ptr (16 B per chunk), copied back to back; lens / names: every read of the part in order"""
+        sc = np.ascontiguousarray(share_chunks, dtype=np.uint64)
+        ln = np.ascontiguousarray(lens, dtype=np.uint32)
+        nb, noff = names if isinstance(names, tuple) else _names(names)
+        self._ck(self.lib.lqcov_part_add_packed_shares_dev(self.h, part, codes_ptr, amb_ptr, int(stride_chunks), len(sc), sc.ctypes.data, len(ln), ln.ctypes.data, nb, noff.ctypes.data))
 
     def part_clear(self, part: int):
         self._ck(self.lib.lqcov_part_clear(self.h, part))

@@ -324,6 +324,21 @@ int lqcov_part_add_packed(lqcov_handle *h, int part, uint32_t n, const uint64_t 
 	});
 }
 
+int lqcov_part_add_packed_shares_dev(lqcov_handle *h, int part, const uint64_t *codes_dev, const uint32_t *amb_dev, uint64_t stride_chunks,
+                                     uint32_t n_shares, const uint64_t *share_chunks, uint32_t n, const uint32_t *lens,
+                                     const char *names, const uint64_t *name_off)
+{
+	return guard(h, [&] {
+		if (n && (!codes_dev || !amb_dev || !lens || !share_chunks)) throw std::invalid_argument("null read buffers");
+		Part &pt = h->part(part);
+		if (pt.built) throw std::logic_error("part already built");
+		if (pt.rs.n) throw std::logic_error("packed shares go into an empty part");
+		std::vector<u64> sc(share_chunks, share_chunks + n_shares);
+		for (u64 v : sc) if (v > stride_chunks) throw std::invalid_argument("a share is longer than the stride");
+		h->add_reads_packed(pt.rs, n, nullptr, nullptr, lens, names, name_off, codes_dev, amb_dev, stride_chunks, &sc);
+	});
+}
+
 int lqcov_part_clear(lqcov_handle *h, int part)
 {
 	return guard(h, [&] {

@@ -333,7 +333,8 @@ void lq_pack_host(u32 n, const u8 *seq, const u64 *seq_off, u64 *codes, u32 *amb
 }
 
 // append n reads that are already packed (lq_pack_host layout for exactly these reads) to the set
-void lqcov_handle::add_reads_packed(ReadSetDev &rs, u32 n, const u64 *codes, const u32 *amb, const u32 *lens, const char *names, const u64 *name_off)
+void lqcov_handle::add_reads_packed(ReadSetDev &rs, u32 n, const u64 *codes, const u32 *amb, const u32 *lens, const char *names, const u64 *name_off,
+                                    const u64 *codes_dev, const u32 *amb_dev, u64 stride_chunks, const std::vector<u64> *share_chunks)
 {
 	hipStream_t stream = this->bstream; Prim &prim = this->bprim;   // the build side has a stream and scan / sort scratch of its own: a part can be built while another is mapped
 	(void)prim;
@@ -356,6 +357,22 @@ void lqcov_handle::add_reads_packed(ReadSetDev &rs, u32 n, const u64 *codes, con
 	const u64 chunk0 = rs.n_chunks;
 	rs.n += n; rs.n_chunks += new_chunks; rs.n_bases += n_bases;
 	rs.sketched = false; rs.dp_n = 0; rs.dp_tiles = 0;
+	if (share_chunks) {
+		// the packed reads are on the device already, in shares of a common stride (lqcov_part_add_packed_shares_dev): back to back into the part
+		u64 at = chunk0, tot = 0;
+		for (u64 v : *share_chunks) tot += v;
+		if (tot != new_chunks) throw std::invalid_argument("the shares' chunks do not add up to the reads' chunks");
+		StageTimer t(this, stream, "d2d_packed_shares", n_words * 12);
+		for (size_t i = 0; i < share_chunks->size(); ++i) {
+			const u64 c = (*share_chunks)[i];
+			if (!c) continue;
+			LQ_HIP_CHECK(hipMemcpyAsync(rs.codes.as<u64>() + at * LQ_CHUNK_WORDS, codes_dev + (u64)i * stride_chunks * LQ_CHUNK_WORDS, c * LQ_CHUNK_WORDS * 8, hipMemcpyDeviceToDevice, stream));
+			LQ_HIP_CHECK(hipMemcpyAsync(rs.amb.as<u32>() + at * LQ_CHUNK_WORDS, amb_dev + (u64)i * stride_chunks * LQ_CHUNK_WORDS, c * LQ_CHUNK_WORDS * 4, hipMemcpyDeviceToDevice, stream));
+			at += c;
+		}
+		LQ_HIP_CHECK(hipStreamSynchronize(stream));               // the caller's buffers are free again
+		return;
+	}
 	u64 n_tiles = 0;
 	if (first && K.upload_slices > 1 && new_chunks >= K.upload_min_chunks && sketch_dp_setup(rs, n_tiles)) {
 		// The reads go up in slices on a stream of their own; the data-parallel sketch kernel takes the tiles of a slice on the build

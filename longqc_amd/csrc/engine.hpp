@@ -258,7 +258,8 @@ struct lqcov_handle {
 	~lqcov_handle();
 
 	void add_reads(ReadSetDev &rs, u32 n, const u8 *seq, const u64 *seq_off, const char *names, const u64 *name_off);
-	void add_reads_packed(ReadSetDev &rs, u32 n, const u64 *codes, const u32 *amb, const u32 *lens, const char *names, const u64 *name_off);
+	void add_reads_packed(ReadSetDev &rs, u32 n, const u64 *codes, const u32 *amb, const u32 *lens, const char *names, const u64 *name_off,
+	                      const u64 *codes_dev = nullptr, const u32 *amb_dev = nullptr, u64 stride_chunks = 0, const std::vector<u64> *share_chunks = nullptr);
 	void sketch(ReadSetDev &rs, bool rid_in_y);
 	bool sketch_dp_setup(ReadSetDev &rs, u64 &n_tiles);
 	void sketch_dp_launch(ReadSetDev &rs, u64 tile0, u64 tile1);

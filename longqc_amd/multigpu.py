@@ -1,9 +1,10 @@
 """Two exact ways to put the path on N GPUs, one process per GPU, `torch.distributed` for the exchange:
 
 1. QueryShardRunner (the default of bench.py --gpus N; BASELINE.json's north star): queries are split across the ranks,
-   the index of every part is replicated.  Per part, rank r sketches a contiguous 1/N of the part's reads, the ranks
-   all-gather the minimizer arrays (RCCL over xGMI: the only data-path collective), every rank builds the same index --
-   hence the same mid_occ -- and maps its own queries; after the last part rank 0 gathers the rows.  Exact because every
+   the index of every part is replicated.  Per part, rank r uploads a contiguous 1/N of the part's 2-bit packed reads, the
+   ranks all-gather the packed reads (RCCL over xGMI: the only data-path collective, 0.375 B per base), every rank sketches the
+   whole part and builds the same index -- hence the same mid_occ -- and maps its own queries; after the last part rank 0 gathers
+   the rows.  (Rounds 4-5 all-gathered the minimizers of per-rank sketches: 16 B each, 21.5 GB per 4-Gbase part.)  Exact because every
    query owns its accumulators (minimap2-coverage.c:434, lqmap.c:788): nothing else crosses queries.
 2. PartRunner: index parts across GPUs (below), for inputs of at least N parts.
 
@@ -140,7 +141,7 @@ class PartRunner:
     accumulators; `finalize()` imports them into the handle so that lqcov_finish() produces the rows."""
 
     @staticmethod
-    def scaling_model(world: int, part_bases, upload_s_per_gbase=0.0065, sketch_s_per_gbase=0.0134, index_s_per_gbase=0.014, map_s_per_gbase=0.075) -> float:
+    def scaling_model(world: int, part_bases, upload_s_per_gbase=0.0065, sketch_s_per_gbase=0.0134, index_s_per_gbase=0.0105, map_s_per_gbase=0.066) -> float:
         """seconds per job predicted for `world` GPUs: rounds of `world` consecutive parts, a round lasts as long as its largest
         part takes on one GPU (front + mapping of every query; the exchange is a few KB per part).  Same MI355X figures as
         QueryShardRunner.scaling_model."""
@@ -291,13 +292,19 @@ class QueryShardRunner:
     # exchange buffers) while part i is mapped; a part then costs max(front, mapping) instead of their sum:
     #     t(N) ~ front(part 0) + sum over parts of max(front_i(N), map_i / N),   front_i(N) = upload_i / N + sketch_i / N + gather_i(N) + index_i
     # (scaling_model below).  Every rank's front thread issues the same collectives in the same order, the mapping issues none.
-    def front(self, part: int, add_share, rid_base: int, all_names, all_lens):
-        """the front of one part into part object `part`: add_share(part) uploads this rank's share of its reads (reads
-        [rid_base, ...) of the part, possibly none), then sketch, all-gather, replicated index build"""
+    def front(self, part: int, share, rid_base: int, all_names, all_lens):
+        """the front of one part into part object `part`.  share = (PackedReads, lo, hi): this rank's contiguous share of the part's reads
+        (reads [rid_base, ...) of the part, possibly none), 2-bit packed on the host -- the ranks all-gather the PACKED READS (0.375 B per
+        base: 1.5 GB per 4-Gbase part), every rank then holds the whole part, sketches it and builds the same index (round 6).  share =
+        a callable add_share(part): rounds 4-5's exchange -- the rank uploads and sketches its share, the MINIMIZERS are all-gathered
+        (16 B each: 21.5 GB per part, 0.12 s on a ring of xGMI links to save a 53-ms sketch) -- kept for hosts that hold no packed reads."""
         eng = self.eng
         eng.part_clear(part)
-        add_share(part)
-        self._exchange_and_build(part, rid_base, all_names, all_lens, trim=False)
+        if callable(share):
+            share(part)
+            self._exchange_and_build(part, rid_base, all_names, all_lens, trim=False)
+        else:
+            self._exchange_packed_and_build(part, share, all_names, all_lens)
 
     def map_parts(self, parts, shares, pipeline: Optional[bool] = None):
         """parts: two part objects; shares: one (add_share, rid_base, all_names, all_lens) per index part, in file order.
@@ -333,16 +340,17 @@ class QueryShardRunner:
         return anchors
 
     @staticmethod
-    def scaling_model(world: int, part_bases, upload_s_per_gbase=0.0065, sketch_s_per_gbase=0.0134, index_s_per_gbase=0.014, map_s_per_gbase=0.075,
-                      link_gbytes_per_s=153.0, minimizers_per_base=1.0 / 3.0, pipelined=True) -> float:
-        """seconds per job predicted for `world` GPUs (the defaults: MI355X figures measured at configs[2] in round 5 -- upload 26 ms,
-        sketch 53.5 ms, index build incl. sort, run heads, table and name work 57 ms, seed plan + mapping 0.30 s per 4.0 Gbases
-        and 5000 queries; ring all-gather bound by one xGMI link).  tools/scale.sh prints it beside what it measures."""
+    def scaling_model(world: int, part_bases, upload_s_per_gbase=0.0065, sketch_s_per_gbase=0.0134, index_s_per_gbase=0.0105, map_s_per_gbase=0.066,
+                      link_gbytes_per_s=153.0, packed_bytes_per_base=0.375, pipelined=True) -> float:
+        """seconds per job predicted for `world` GPUs (the defaults: MI355X figures measured at configs[2] -- upload 26 ms, sketch 53.5 ms,
+        index build incl. sort, run heads, table and name work 42 ms, seed plan + mapping 0.26 s per 4.0 Gbases and 5000 queries
+        (round 6); ring all-gather of the packed reads bound by one xGMI link).  The front of a part: this rank's 1 / N of the upload,
+        the all-gather, then sketch and index of the WHOLE part on every rank.  tools/scale.sh prints it beside what it measures."""
         t, prev_map = 0.0, None
         for b in part_bases:
             g = b / 1e9
-            gather = 0.0 if world == 1 else (world - 1) / world * (g * 1e9 * minimizers_per_base * 16) / (link_gbytes_per_s * 1e9)
-            front = (upload_s_per_gbase + sketch_s_per_gbase) * g / world + gather + index_s_per_gbase * g
+            gather = 0.0 if world == 1 else (world - 1) / world * (g * 1e9 * packed_bytes_per_base) / (link_gbytes_per_s * 1e9)
+            front = upload_s_per_gbase * g / world + gather + (sketch_s_per_gbase + index_s_per_gbase) * g
             mp = map_s_per_gbase * g / world
             if prev_map is None or not pipelined:
                 t += front if prev_map is None else front + prev_map
@@ -361,6 +369,47 @@ class QueryShardRunner:
                        ([torch.empty(self.world * cap2, dtype=torch.int64, device=self.dev) for _ in range(2)] if self.world > 1 else [])
             self._ex_cap = cap2
         return self._ex
+
+    def _exchange_packed_and_build(self, part: int, share, all_names, all_lens):
+        """all-gather of the ranks' packed shares (codes: 4 x u64 per 128-base chunk, ambiguity bits: 4 x u32), the part from the receive
+        buffers (lqcov_part_add_packed_shares_dev: the shares back to back = the reads in file order, every read starts on a chunk), then
+        the ordinary build: sketch + index (+ mid_occ on the first part) -- the same reads on every rank, hence the same index"""
+        import ctypes
+        eng, dev, world = self.eng, self.dev, self.world
+        packed, lo, hi = share
+        c0, c1 = int(packed.coff[lo]), int(packed.coff[hi])
+        n_ch = c1 - c0
+        if world > 1:
+            sizes = [int(t.item()) for t in _all_gather(torch.tensor([n_ch], dtype=torch.int64, device=dev), world, self.group)]
+        else:
+            sizes = [n_ch]
+        cap = max(max(sizes), 1)
+        have = getattr(self, "_pk_cap", 0)
+        if cap > have:                                            # send and receive buffers, kept from part to part
+            self._pk = None
+            cap2 = cap + cap // 16 + 64
+            self._pk = [torch.empty(cap2 * 4, dtype=torch.int64, device=dev), torch.empty(cap2 * 4, dtype=torch.int32, device=dev)] + \
+                       ([torch.empty(world * cap2 * 4, dtype=torch.int64, device=dev), torch.empty(world * cap2 * 4, dtype=torch.int32, device=dev)] if world > 1 else [])
+            self._pk_cap = cap2
+        stride = self._pk_cap
+        sc, sa = self._pk[0], self._pk[1]
+        if n_ch:
+            hc = np.ctypeslib.as_array(ctypes.cast(packed.codes_ptr + c0 * 32, ctypes.POINTER(ctypes.c_int64)), shape=(n_ch * 4,))
+            ha = np.ctypeslib.as_array(ctypes.cast(packed.amb_ptr + c0 * 16, ctypes.POINTER(ctypes.c_int32)), shape=(n_ch * 4,))
+            sc[:n_ch * 4].copy_(torch.from_numpy(hc)); sa[:n_ch * 4].copy_(torch.from_numpy(ha))      # this rank's 1 / N of the upload
+        self.last_sizes = sizes
+        self.last_exchange_bytes = (world + 1) * stride * 48 if world > 1 else stride * 48           # (tests assert the bound: 0.375 B per base and buffer)
+        if world > 1:
+            gc, ga = self._pk[2], self._pk[3]
+            if dist.get_backend(self.group) == "gloo":
+                gc.copy_(_all_gather_into(sc, world, self.group)); ga.copy_(_all_gather_into(sa, world, self.group))
+            else:
+                dist.all_gather_into_tensor(gc, sc, group=self.group); dist.all_gather_into_tensor(ga, sa, group=self.group)   # RCCL all-gather over xGMI
+                torch.cuda.current_stream(dev).synchronize()
+        else:
+            gc, ga = sc, sa
+        eng.part_add_packed_shares_dev(part, gc.data_ptr(), ga.data_ptr(), stride, sizes, np.asarray(all_lens, dtype=np.uint32), all_names)
+        eng.part_build(part)
 
     def map_part(self, part: int, rid_base: int, all_names, all_lens):
         """`part` holds this rank's contiguous share of the index part's reads (reads [rid_base, ...) of the part, possibly
