@@ -109,6 +109,8 @@ void Knobs::read_env()
 	reg_walker = !is("LQCOV_WALK", "solo");
 	ckpt = !is("LQCOV_CKPT", "0");
 	ckpt3 = num("LQCOV_CKPT3", 1) > 0;
+	prune = num("LQCOV_PRUNE", 1) > 0;
+	sketch_grid = (u32)std::min<long long>(std::max<long long>(num("LQCOV_SKETCH_GRID", 1L << 22), 1), 1L << 22);
 	build_prio = num("LQCOV_BUILD_PRIO", 1) > 0;
 	ck_unit = (u32)std::max<long long>(num("LQCOV_CK_UNIT", 65536), 64); ck_unit_many = (u32)std::max<long long>(num("LQCOV_CK_UNIT_MANY", 8192), 64);
 	sort_tile = (u32)std::max<long>(0, num("LQCOV_SORT_TILE", 0)); if (sort_tile && sort_tile < 64) sort_tile = 64;
@@ -439,7 +441,7 @@ void lqcov_handle::sketch_dp_launch(ReadSetDev &rs, u64 tile0, u64 tile1)
 	SkParams sp; sp.k = P.k; sp.w = P.w; sp.hpc = P.hpc; sp.mask = (1ULL << 2 * P.k) - 1; sp.shift1 = 2 * (P.k - 1);
 	const u64 nt = tile1 - tile0;
 	StageTimer t(this, stream, "k_sketch_dp_mask", nt * LQ_DPT_CH * (LQ_CHUNK_WORDS * 12 + 17));
-#define LQ_DPM(HT, W) LQ_LAUNCH((k_sketch_dp_mask<HT, W>), (u32)std::min<u64>(nt, 1u << 22), LQ_DPT_THREADS, stream, rs.codes.as<u64>(), rs.amb.as<u32>(), rs.d_coff.as<u64>(), rs.d_len.as<u32>(), \
+#define LQ_DPM(HT, W) LQ_LAUNCH((k_sketch_dp_mask<HT, W>), (u32)std::min<u64>(nt, K.sketch_grid), LQ_DPT_THREADS, stream, rs.codes.as<u64>(), rs.amb.as<u32>(), rs.d_coff.as<u64>(), rs.d_len.as<u32>(), \
 		sk_toff.as<u64>(), sk_trid.as<u32>(), rs.n, tile0, tile1, sp, sk_owned.as<u8>(), sk_mask.as<u32>(), sk_flag.as<u32>())
 	const int wc = K.sketch_wgen ? 0 : P.w;                       // the presets' windows as compile-time constants
 	if (P.k <= 16) { if (wc == 5) LQ_DPM(u32, 5); else if (wc == 10) LQ_DPM(u32, 10); else LQ_DPM(u32, 0); }
@@ -1002,6 +1004,9 @@ void lqcov_handle::map_subset(MapLane &L, Part &pt, const std::vector<u32> &sq, 
 		check_launch();
 	}
 	if (nA2) {
+		// (second pass: only the listed runs are chained -- klib's levels drop every bucket without one, k_rs_children)
+		L.prune = tie_mode == 2 && !sink; L.prune_n_want = n_want; L.prune_n_sub = ns;
+		struct PruneGuard { MapLane &L; ~PruneGuard() { L.prune = false; } } prune_guard{L};
 		sort_checked(L, pt, L.sub_off.as<u64>(), L.sub_klib.as<u32>(), ns, 0, nA2, so, sk);
 		if (lq_timeline) { LQ_HIP_CHECK(hipStreamSynchronize(L.stream)); int lane_id = 0; for (size_t i_ = 0; i_ < lanes.size(); ++i_) if (lanes[i_].get() == &L) lane_id = (int)i_; lq_tl("lane", lane_id, "  second pass sorted"); }
 		chain_stage(L, pt, L.sub_off.as<u64>(), 0, ns, 0, L.sub_q.as<u32>(), nA2, tie_mode, n_want, ivl_cap, dbg, sink);
@@ -1456,7 +1461,8 @@ void lqcov_handle::sort_batch(MapLane &L, Part &pt, const u64 *aqb, const u32 *q
 			{
 				StageTimer t(this, sD, "k_rs_children");
 				LQ_LAUNCH(k_rs_children, (u32)std::min<u64>((u64)ns * 4, 1u << 20), LQ_CHILD_THREADS, sD, cur, cnt + cur_slot, R[rb ^ 1], rb ^ 1, dB, dA, L.hist.as<u32>(), L.mhist.as<u32>(), L.begs.as<u32>(),
-				          nxt, cnt + nxt_slot, const_levels, lists(1), km, (int)K.all_klib, cnt + LQ_C_TILES, cnt + LQ_C_LEN0, wcaps);
+				          nxt, cnt + nxt_slot, const_levels, lists(1), km, (int)K.all_klib, cnt + LQ_C_TILES, cnt + LQ_C_LEN0, wcaps,
+			          L.prune && !K.debug_sort && K.prune ? PruneWant{L.want.as<unsigned long long>(), L.prune_n_want, L.sub_off.as<u64>(), L.sub_q.as<u32>(), L.prune_n_sub} : PruneWant{nullptr, 0, nullptr, nullptr, 0});
 				check_launch();
 			}
 			d2h(hl, cnt, LQ_C_N, sD);

@@ -32,6 +32,8 @@ struct Knobs {
 	u32 ps_shift = 0;                     // LQCOV_PS_SHIFT: shrinks the size classes of the parallel sort (tests)
 	bool reg_walker = true;               // LQCOV_WALK=solo: no register-lane walker
 	bool ckpt = true, ckpt3 = true;       // LQCOV_CKPT=0: no checkpointed walks; LQCOV_CKPT3=0: the 65-160 k class is walked whole
+	bool prune = true;                    // LQCOV_PRUNE=0: the second pass sorts every bucket of its queries (rounds 4-5), not only those that hold a listed run
+	u32 sketch_grid = 1u << 22;           // LQCOV_SKETCH_GRID: blocks of k_sketch_dp_mask (a block strides over the tiles)
 	bool build_prio = true;               // LQCOV_BUILD_PRIO=0: the build side's streams without the higher queue priority
 	u32 ck_unit = 65536, ck_unit_many = 8192;   // LQCOV_CK_UNIT / LQCOV_CK_UNIT_MANY: elements per checkpoint, passes of up to 16 / up to 256 buckets (configs[2], ms per step: 16384 / 4096: 502, 65536 / 4096: 502, 65536 / 8192: 491, 65536 / 16384: 491, 131072 / 8192: 494)
 	u32 sort_tile = 0;                    // LQCOV_SORT_TILE: anchors per tile of the sort's streaming kernels (0 = LQ_SORT_TILE)
@@ -152,6 +154,7 @@ struct MapLane {
 	PsWork ps[2];
 	Prim prim;
 	bool gate_passed = false;             // this batch has reached its long walks (see map_part)
+	bool prune = false; u32 prune_n_want = 0, prune_n_sub = 0;   // second pass: klib's levels drop the buckets without a listed run (k_rs_children; L.want, L.sub_off, L.sub_q)
 	DBuf sens, n_sens, want, sub_q, sub_off, sub_klib;   // runs left to the second pass (map_batch), its queries
 	DBuf A, B, R0, segs0, segs1, n_segs, hist, begs;     // A: anchors (final home), B: originals of the klib queries / other buffer of the parallel sort, R0: records (R1 lives in scr)
 	DBuf tile_list, two_tiles, two_tile0, two_tcnt, two_m;

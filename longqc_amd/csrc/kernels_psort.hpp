@@ -444,10 +444,18 @@ __global__ void k_query_klib(const u64 *aq_off, const u32 *qdirty, u32 n_q, int 
 // result is the unique stable order by x: the wave gathers the anchors of whole buckets (adjacent in memory, packed into
 // chunks of <= 64 elements, one element per lane), every lane ranks its element among the elements of its own bucket (ties
 // by position in the arrangement) and writes it to its final place in A.  After the pass on byte 0 everything is final.
+// Round 6, second pass only (want != null): klib's order is needed in the listed runs and nowhere else -- the second pass chains
+// nothing but those -- so a bucket of a level on strand / rid (shift >= 32: its anchors share the bits of x >> 32 above the level's
+// byte... and that byte) that holds no listed run's (strand, rid) is DROPPED: no next level, no parallel sort, no insertion sort.
+// What the walk of ITS level needed -- every element of the parent sub-array -- has been walked; nothing below depends on a dropped
+// bucket (a level's walk only reads its own sub-array, ksort.h:99-129).  At configs[2] a query's ~40 listed runs sit in ~40 of the
+// ~4000 buckets of the rid >> 8 level: the levels below shrink a hundredfold.  The dropped bucket's place in A is filled with its
+// smallest possible key, so that A stays ascending in x >> 32 per query and k_want_runs' bisections still find the listed runs.
+struct PruneWant { const unsigned long long *want; u32 n_want; const u64 *sub_off; const u32 *sub_q; u32 n_sub; };
 #define LQ_CHILD_THREADS 64
 __global__ void __launch_bounds__(LQ_CHILD_THREADS)
 k_rs_children(const SortSeg *segs, const u32 *n_segs_p, const RRec *Rn, u32 rb, const mm128 *O, mm128 *A, const u32 *hist, const u32 *mhist, const u32 *begs,
-              SortSeg *next, u32 *n_next, u32 const_levels, PsLists L, KeyMap km, int all_klib, u32 *n_tiles_zero, u32 *len_cnt, WalkCaps caps)
+              SortSeg *next, u32 *n_next, u32 const_levels, PsLists L, KeyMap km, int all_klib, u32 *n_tiles_zero, u32 *len_cnt, WalkCaps caps, PruneWant pw)
 {
 	__shared__ u64 xs[64];
 	__shared__ u32 flag[64];
@@ -458,7 +466,31 @@ k_rs_children(const SortSeg *segs, const u32 *n_segs_p, const RRec *Rn, u32 rb, 
 		const u64 t = w * 64 + lane;
 		const u32 sgi = (u32)(t >> 8);
 		const SortSeg sg = segs[sgi];
-		const u32 n = hist[t], bg = begs[t];
+		u32 n = hist[t];
+		const u32 bg = begs[t];
+		if (pw.want && sg.shift >= 32) {                          // (uniform: a wave's 64 buckets belong to one sub-array)
+			u32 qlo = 0, qhi = pw.n_sub;                          // the sub-array's query: the last one whose anchors start at or before it
+			while (qhi - qlo > 1) { const u32 mid = qlo + ((qhi - qlo) >> 1); if (pw.sub_off[mid] <= sg.off) qlo = mid; else qhi = mid; }
+			const unsigned long long qk = (unsigned long long)pw.sub_q[qlo] << 32;
+			bool drop = false; u32 klo = 0;
+			if (n) {
+				const u32 key = Rn[sg.off + bg].key, m = sg.shift > 32 ? (1u << (sg.shift - 32)) - 1 : 0u;
+				klo = key & ~m;
+				const unsigned long long a = qk | klo, b = qk | (key | m);
+				u32 lo = 0, hi = pw.n_want;
+				while (lo < hi) { const u32 mid = lo + ((hi - lo) >> 1); if (pw.want[mid] < a) lo = mid + 1; else hi = mid; }
+				drop = !(lo < pw.n_want && pw.want[lo] <= b);
+			}
+			u64 dm = __ballot(drop);
+			while (dm) {                                              // the wave fills a dropped bucket's place together
+				const u32 f = (u32)__builtin_ctzll(dm);
+				const u32 fb = (u32)__builtin_amdgcn_readlane((int)bg, (int)f), fn = (u32)__builtin_amdgcn_readlane((int)n, (int)f), fk = (u32)__builtin_amdgcn_readlane((int)klo, (int)f);
+				mm128 e; e.x = (u64)fk << 32; e.y = 0;
+				for (u32 i = lane; i < fn; i += 64) A[sg.off + fb + i] = e;
+				dm &= dm - 1;
+			}
+			if (drop) n = 0;
+		}
 		if (n > LQ_RS_MIN) {
 			if (sg.shift == 0 || (mhist[t] < 2 && !all_klib)) {
 				// (after the pass on byte 0 a bucket holds one x: nothing left to sort, the parallel sort's finish brings it home)
