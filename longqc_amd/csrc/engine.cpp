@@ -110,6 +110,8 @@ void Knobs::read_env()
 	ckpt = !is("LQCOV_CKPT", "0");
 	ckpt3 = num("LQCOV_CKPT3", 1) > 0;
 	prune = num("LQCOV_PRUNE", 1) > 0;
+	plan_lazy = num("LQCOV_PLAN_LAZY", 0) > 0;
+	lazy_batches = (int)std::min<long>(16, std::max<long>(1, num("LQCOV_LAZY_BATCHES", 1)));
 	sketch_grid = (u32)std::min<long long>(std::max<long long>(num("LQCOV_SKETCH_GRID", 1L << 22), 1), 1L << 22);
 	build_prio = num("LQCOV_BUILD_PRIO", 1) > 0;
 	ck_unit = (u32)std::max<long long>(num("LQCOV_CK_UNIT", 65536), 64); ck_unit_many = (u32)std::max<long long>(num("LQCOV_CK_UNIT_MANY", 8192), 64);
@@ -769,7 +771,9 @@ void lqcov_handle::build_index(Part &pt)
 	pt.plan.valid = false;
 	// the part's seed plan right away, on the build stream: under the mapping of the part before when parts are pipelined
 	lq_tl("build", 0, "index done");
-	if (K.plan_ahead && have_queries && mid_occ > 0 && !distributed) plan_part(pt, stream, prim);
+	// (with the lanes idle -- the first part of a job -- nothing hides the filter, the plan's longest stage: it is left to the lanes,
+	// each of which decides its own batch of queries and starts mapping while the next lane decides its batch: map_part)
+	if (K.plan_ahead && have_queries && mid_occ > 0 && !distributed) plan_part(pt, stream, prim, K.plan_lazy && active_maps.load() == 0);
 	// (the build workspaces stay with the handle: repeated builds do not re-allocate, and the mapping lanes size their work
 	// space from what is free once the first part stands -- map_part)
 }
@@ -1045,7 +1049,7 @@ void lqcov_handle::map_batch(MapLane &L, Part &pt, u32 q0, u32 q1, const std::ve
 	if (nj && opt && pt.plan.bucketed) {
 		if (nA) {                                                 // the survivors of the batch's queries (the part's seed plan holds them as records)
 			StageTimer t(this, L.stream, "k_seed_emit_s", nA * 24);
-			LQ_LAUNCH(k_seed_emit_s, nblk(nA, 256), 256, L.stream, surv.as<u64>(), a_base, nA, aqf_off.as<u64>(), q0, q1, SeedBits{pt.plan.rec_jb, pt.plan.rec_db},
+			LQ_LAUNCH(k_seed_emit_s, nblk(nA, 256), 256, L.stream, L.use_surv ? L.use_surv : surv.as<u64>(), a_base, nA, L.use_aqf ? L.use_aqf : aqf_off.as<u64>(), q0, q1, SeedBits{pt.plan.rec_jb, pt.plan.rec_db},
 			          q.mx.as<u64>(), q.my.as<u64>(), q.moff.as<u64>(), q.d_len.as<u32>(), dup.as<u32>(), L.A.as<mm128>());
 			check_launch();
 		}
@@ -1062,7 +1066,7 @@ void lqcov_handle::map_batch(MapLane &L, Part &pt, u32 q0, u32 q1, const std::ve
 	L.ivl.ensure((u64)ivl_cap * sizeof(Ivl));
 	dzero(L.n_ivl.p, 4, L.stream); dzero(L.n_sens.p, 4, L.stream);
 	if (nA) {
-		const u64 *aqb = (opt ? aqf_off.as<u64>() : aq_off.as<u64>()) + q0;          // batch view of the per-query anchor offsets
+		const u64 *aqb = (opt ? (L.use_aqf ? L.use_aqf : aqf_off.as<u64>()) : aq_off.as<u64>()) + q0;          // batch view of the per-query anchor offsets
 		const u32 *qkb = opt ? qzero.as<u32>() : qklib.as<u32>() + q0;               // (first pass: nobody goes through klib's passes)
 		std::vector<u64> rel; std::vector<u32> hk;
 		if (K.debug_sort) {
@@ -1662,10 +1666,10 @@ bool lqcov_handle::seed_group(Part &pt, SeedPlan &S, bool swapped, hipStream_t s
 
 // ---- map every query against one part (lqmap.c:207-326) -----------------------------------------
 // a part's seed plan (SeedPlan, engine.hpp) on stream s with scan scratch pr
-void lqcov_handle::plan_part(Part &pt, hipStream_t s, Prim &pr)
+void lqcov_handle::plan_part(Part &pt, hipStream_t s, Prim &pr, bool defer_filter)
 {
 	SeedPlan &S = pt.plan;
-	S.valid = false;
+	S.valid = false; S.lazy = false;
 	const u32 n_q = q.n;
 	const u64 n_qm = q.n_mini;
 	S.n_q = n_q; S.n_qm = n_qm; S.mid_occ = mid_occ; S.nA_total = 0; S.n_mp_total = 0; S.n_written = 0;
@@ -1735,8 +1739,11 @@ void lqcov_handle::plan_part(Part &pt, hipStream_t s, Prim &pr)
 			// (measured and dropped, round 5: the filter run batch by batch inside map_part, each lane starting as soon as its batch is
 			// decided -- 586-588 ms per step at configs[2] against 576: beside the lanes' kernels the filter's take three times as long)
 			// (an allocation that fails inside the filter -- its bucket buffer is up to 8 GB -- leaves the part without one: every hit is written)
-			try { S.bucketed = seed_group(pt, S, false, s, pr, 0); }
-			catch (const std::runtime_error &) { (void)hipGetLastError(); S.surv.release(); for (DBuf *b : { &seed_ws.rec, &seed_ws.cnt, &seed_ws.off, &seed_ws.bd }) b->release(); S.bucketed = false; }
+			if (defer_filter) { S.lazy = true; S.bucketed = true; S.q_begin = 0; S.q_end = n_q; S.h_aqf = S.h_aq; S.n_written = 0; }
+			else {
+				try { S.bucketed = seed_group(pt, S, false, s, pr, 0); }
+				catch (const std::runtime_error &) { (void)hipGetLastError(); S.surv.release(); for (DBuf *b : { &seed_ws.rec, &seed_ws.cnt, &seed_ws.off, &seed_ws.bd }) b->release(); S.bucketed = false; }
+			}
 		}
 		if (!S.bucketed) {
 			S.q_begin = 0; S.q_end = n_q;
@@ -1772,6 +1779,8 @@ void lqcov_handle::map_part(Part &pt)
 	lq_tl("main", 0, "map_part begins");
 	swap_plan(pt.plan);
 	struct PlanGuard { lqcov_handle *h; SeedPlan &S; ~PlanGuard() { h->swap_plan(S); } } plan_guard{this, pt.plan};
+	++active_maps;
+	struct ActiveGuard { lqcov_handle *h; ~ActiveGuard() { --h->active_maps; } } active_guard{this};
 	const std::vector<u64> &h_aq = pt.plan.h_aq, &h_qmoff = pt.plan.h_qmoff, &h_aqf = pt.plan.h_aqf;
 	const u64 nA_total = pt.plan.nA_total, n_mp_total = pt.plan.n_mp_total;
 	last_n_anchors = nA_total;
@@ -1870,11 +1879,44 @@ void lqcov_handle::map_part(Part &pt)
 		false;
 #endif
 	// runs the batches on the lanes
+	const bool lazy = opt && pt.plan.lazy && pt.plan.bucketed;
+	std::atomic<u64> lazy_written{0};
+	// one batch on one lane.  A lazy plan (the first part of a job): the lane first decides which of its queries' seed hits can reach
+	// a chain -- the filter of kernels_seed.hpp on the lane's own stream, one lane at a time (they share its work space) -- into a
+	// survivor list of its own, then maps them; the next lane decides its batch under this one's mapping.
+	auto one_batch = [&](MapLane &L, u32 q0, u32 q1) {
+		if (!lazy) { map_batch(L, pt, q0, q1, h_aq, h_aqf, h_qmoff, dbg); return; }
+		int lane_id = 0; for (size_t i_ = 0; i_ < lanes.size(); ++i_) if (lanes[i_].get() == &L) lane_id = (int)i_;
+		L.aqf_l.ensure(((u64)n_q + 1) * 8);
+		for (u32 qb = q0; qb < q1; ) {
+			SeedJob J;
+			J.hit_start = hit_start.as<u64>(); J.hit_n = hit_n.as<u32>(); J.keep = keep.as<u32>();
+			J.aqf_off = L.aqf_l.as<u64>(); J.h_qmoff = &h_qmoff; J.h_aqf = &L.h_aqf_l;
+			J.surv = &L.surv_l; J.base = 0; J.room_hint = (h_aq[q1] - h_aq[qb]) / 16;
+			J.q_begin = qb; J.q_stop = q1;
+			bool ok = false;
+			try { ok = seed_filter(pt, L.stream, L.prim, seed_ws, pt.plan.rec_nmin, pt.plan.rec_jb, pt.plan.rec_db, J); }
+			catch (const std::runtime_error &) { (void)hipGetLastError(); ok = false; }
+			if (!ok) throw std::runtime_error("seed filter: no room for a batch's survivors (LQCOV_PLAN_LAZY=0 maps the part without the filter instead)");
+			lq_tl("lane", lane_id, "batch decided, survivors", (double)J.n_surv);
+			lazy_written += J.n_surv;
+			L.use_surv = L.surv_l.as<u64>(); L.use_aqf = L.aqf_l.as<u64>();
+			struct UseGuard { MapLane &L; ~UseGuard() { L.use_surv = nullptr; L.use_aqf = nullptr; } } use_guard{L};
+			// (what the filter left of [qb, q_end), in pieces the lane's work space holds)
+			for (u32 a = qb; a < J.q_end; ) {
+				u32 b = a + 1;
+				while (b < J.q_end && L.h_aqf_l[b + 1] - L.h_aqf_l[a] <= anchor_budget) ++b;
+				map_batch(L, pt, a, b, h_aq, L.h_aqf_l, h_qmoff, dbg);
+				a = b;
+			}
+			qb = J.q_end;
+		}
+	};
 	auto run_batches = [&](const std::vector<std::pair<u32, u32>> &batches) {
 		const bool concurrent = can_thread && n_lanes > 1 && batches.size() > 1;
 		if (!concurrent) {
 			for (size_t i = 0; i < batches.size(); ++i) {
-				map_batch(*lanes[i % n_lanes], pt, batches[i].first, batches[i].second, h_aq, h_aqf, h_qmoff, dbg);
+				one_batch(*lanes[i % n_lanes], batches[i].first, batches[i].second);
 			}
 			for (auto &L : lanes) LQ_HIP_CHECK(hipStreamSynchronize(L->stream));
 			return;
@@ -1901,7 +1943,7 @@ void lqcov_handle::map_part(Part &pt)
 					for (;;) {
 						const size_t i = next.fetch_add(1);
 						if (i >= batches.size()) break;
-						map_batch(L, pt, batches[i].first, batches[i].second, h_aq, h_aqf, h_qmoff, dbg);
+						one_batch(L, batches[i].first, batches[i].second);
 					}
 					LQ_HIP_CHECK(hipStreamSynchronize(L.stream));
 				} catch (...) { errs[li] = std::current_exception(); next.store(batches.size()); gate_cv.notify_all(); }
@@ -1933,6 +1975,24 @@ void lqcov_handle::map_part(Part &pt)
 		return batches;
 	};
 	bool regrouped = false;
+	if (lazy) {
+		// batches of about equal seed hits, one per lane (the filter's cost and the second pass go by the hits)
+		std::vector<std::pair<u32, u32>> batches;
+		const u64 total = h_aq[n_q] - h_aq[0];
+		const u32 nb = (u32)std::max<int>(1, n_lanes * K.lazy_batches);
+		u32 q0 = 0;
+		for (u32 b = 0; b < nb && q0 < n_q; ++b) {
+			const u64 lim = h_aq[q0] + (total - (h_aq[q0] - h_aq[0])) / (nb - b);
+			u32 q1 = q0 + 1;
+			while (q1 < n_q && h_aq[q1 + 1] <= lim) ++q1;
+			if (b + 1 == nb) q1 = n_q;
+			batches.emplace_back(q0, q1);
+			q0 = q1;
+		}
+		run_batches(batches);
+		pt.plan.n_written = lazy_written.load(); last_n_written = pt.plan.n_written;
+		pt.plan.valid = false;                                      // (no survivor list to map the part from again: the next map_part plans anew)
+	} else
 	// The plan holds the survivors of a group of queries (all of them, unless survivors abound: SeedPlan::q_end); the group's batches
 	// are mapped, then the next group is planned -- with every lane drained, on the handle's own stream.
 	for (u32 g_begin = 0, g_end = n_q; ; ) {

@@ -32,6 +32,8 @@ struct Knobs {
 	u32 ps_shift = 0;                     // LQCOV_PS_SHIFT: shrinks the size classes of the parallel sort (tests)
 	bool reg_walker = true;               // LQCOV_WALK=solo: no register-lane walker
 	bool ckpt = true, ckpt3 = true;       // LQCOV_CKPT=0: no checkpointed walks; LQCOV_CKPT3=0: the 65-160 k class is walked whole
+	int lazy_batches = 1;                 // LQCOV_LAZY_BATCHES: batches per lane of a lazy plan
+	bool plan_lazy = false;               // LQCOV_PLAN_LAZY=1: the first part's seed filter is left to the mapping lanes, each deciding its own batch of queries before it maps them (the next lane decides under this one's mapping).  Measured in round 6 at configs[2]: 425 ms per step against 399 -- beside a mapping lane and the next part's sketch the filter's kernels take twice as long (60 + 55 + 56 ms for the three batches, 85 ms for all of them alone) and the last lane starts later than it does after a whole plan; two / three batches per lane: 449 / 483 ms.  Round 5 had found the same with the filter inside map_part (586 vs 576 ms)
 	bool prune = true;                    // LQCOV_PRUNE=0: the second pass sorts every bucket of its queries (rounds 4-5), not only those that hold a listed run
 	u32 sketch_grid = 1u << 22;           // LQCOV_SKETCH_GRID: blocks of k_sketch_dp_mask (a block strides over the tiles)
 	bool build_prio = true;               // LQCOV_BUILD_PRIO=0: the build side's streams without the higher queue priority
@@ -106,6 +108,8 @@ struct SeedPlan {
 	i32 mid_occ = -2; u32 n_q = 0; u64 n_qm = 0;
 	u32 rec_jb = 0, rec_db = 0, rec_nmin = 0;   // the records' bit layout (SeedBits); the filter's n_min
 	u32 q_begin = 0, q_end = 0;           // the queries whose survivors the plan holds right now (a group of chunks; all of them unless survivors abound)
+	bool lazy = false;                    // the survivors are not made yet: every mapping lane runs the filter for its own batch of queries before it maps
+	                                      // them (map_part) -- the first part of a job, whose plan nothing else could hide (round 6)
 	bool bucketed = false;                // false: the first pass writes every hit (no filter asked for, or the records do not fit 64 bits): h_aqf == h_aq
 	bool valid = false;
 };
@@ -154,6 +158,8 @@ struct MapLane {
 	PsWork ps[2];
 	Prim prim;
 	bool gate_passed = false;             // this batch has reached its long walks (see map_part)
+	DBuf surv_l, aqf_l; std::vector<u64> h_aqf_l;   // a lazy plan (SeedPlan::lazy): the survivors of the lane's own batch and their per-query offsets
+	const u64 *use_surv = nullptr, *use_aqf = nullptr;   // ... which map_batch then reads instead of the plan's
 	bool prune = false; u32 prune_n_want = 0, prune_n_sub = 0;   // second pass: klib's levels drop the buckets without a listed run (k_rs_children; L.want, L.sub_off, L.sub_q)
 	DBuf sens, n_sens, want, sub_q, sub_off, sub_klib;   // runs left to the second pass (map_batch), its queries
 	DBuf A, B, R0, segs0, segs1, n_segs, hist, begs;     // A: anchors (final home), B: originals of the klib queries / other buffer of the parallel sort, R0: records (R1 lives in scr)
@@ -271,7 +277,8 @@ struct lqcov_handle {
 	void build_index(Part &pt);
 	void build_part(Part &pt);
 	void open_gate();
-	void plan_part(Part &pt, hipStream_t s, Prim &pr);
+	void plan_part(Part &pt, hipStream_t s, Prim &pr, bool defer_filter = false);
+	std::atomic<int> active_maps{0};      // map_part calls in progress: a part built meanwhile gets its whole plan ahead of time, a part built with the lanes idle a lazy one
 	bool seed_filter(Part &pt, hipStream_t s, Prim &pr, SeedWork &W, u32 n_min, u32 jb, u32 db, SeedJob &J);
 	bool seed_group(Part &pt, SeedPlan &S, bool swapped, hipStream_t s, Prim &pr, u32 q_begin);
 	void swap_plan(SeedPlan &S);
