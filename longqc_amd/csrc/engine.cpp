@@ -124,6 +124,7 @@ void Knobs::read_env()
 	run_grid = (u32)std::max<long>(1, num("LQCOV_RUN_GRID", 2048));
 	ps_key64 = num("LQCOV_PS_KEY64", 0) != 0;
 	sketch_wgen = num("LQCOV_SKETCH_WGEN", 0) != 0;
+	sketch_fast = num("LQCOV_SKETCH_FAST", 1) != 0;
 #ifndef LQ_EMU
 	lq_trace_launches = (int)num("LQCOV_TRACE_LAUNCHES", 0);
 #endif
@@ -446,7 +447,13 @@ void lqcov_handle::sketch_dp_launch(ReadSetDev &rs, u64 tile0, u64 tile1)
 #define LQ_DPM(HT, W) LQ_LAUNCH((k_sketch_dp_mask<HT, W>), (u32)std::min<u64>(nt, K.sketch_grid), LQ_DPT_THREADS, stream, rs.codes.as<u64>(), rs.amb.as<u32>(), rs.d_coff.as<u64>(), rs.d_len.as<u32>(), \
 		sk_toff.as<u64>(), sk_trid.as<u32>(), rs.n, tile0, tile1, sp, sk_owned.as<u8>(), sk_mask.as<u32>(), sk_flag.as<u32>())
 	const int wc = K.sketch_wgen ? 0 : P.w;                       // the presets' windows as compile-time constants
-	if (P.k <= 16) { if (wc == 5) LQ_DPM(u32, 5); else if (wc == 10) LQ_DPM(u32, 10); else LQ_DPM(u32, 0); }
+	if (K.sketch_fast && !K.sketch_wgen && P.k == 12 && (P.w == 5 || P.w == 10)) {   // LongQC's own -k 12 -w 5: k and w as constants (LQCOV_SKETCH_FAST=0: the general kernel)
+#define LQ_DPF(KK, WW) LQ_LAUNCH((k_sketch_dp_fast<KK, WW>), (u32)std::min<u64>(nt, K.sketch_grid), LQ_DPT_THREADS, stream, rs.codes.as<u64>(), rs.amb.as<u32>(), rs.d_coff.as<u64>(), rs.d_len.as<u32>(), \
+		sk_toff.as<u64>(), sk_trid.as<u32>(), rs.n, tile0, tile1, sk_owned.as<u8>(), sk_mask.as<u32>(), sk_flag.as<u32>())
+		if (P.w == 5) LQ_DPF(12, 5); else LQ_DPF(12, 10);
+#undef LQ_DPF
+	}
+	else if (P.k <= 16) { if (wc == 5) LQ_DPM(u32, 5); else if (wc == 10) LQ_DPM(u32, 10); else LQ_DPM(u32, 0); }
 	else { if (wc == 5) LQ_DPM(u64, 5); else if (wc == 10) LQ_DPM(u64, 10); else LQ_DPM(u64, 0); }
 #undef LQ_DPM
 	check_launch();

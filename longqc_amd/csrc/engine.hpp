@@ -43,6 +43,7 @@ struct Knobs {
 	u32 walk_grid = 1u << 18;             // LQCOV_WALK_GRID: cap on resident walker waves
 	u32 walk_cu_mask = 0x11111111u;       // LQCOV_WALK_CU_MASK (hex, repeated over the 256 CUs): the CUs the walkers' streams may use
 	int chain_wave_min = 0, chain_cap = 128;   // LQCOV_CHAIN_WAVE_MIN (0 = LQ_CHAIN_WAVE_MIN), LQCOV_CHAIN_CAP
+	bool sketch_fast = true;              // LQCOV_SKETCH_FAST=0: k_sketch_dp_mask although k_sketch_dp_fast applies (-k 12 with -w 5 or 10; tests, A/B)
 	bool sketch_wgen = false;             // LQCOV_SKETCH_WGEN=1: k_sketch_dp_mask with the window read at run time although it is 5 or 10 (tests, A/B)
 	bool ps_key64 = false;                // LQCOV_PS_KEY64=1: the finishing kernels' 64-bit key shape although 32 bits would do (tests: parts with more than 2^40 (target, position) pairs are out of their reach)
 	u32 run_grid = 2048;                  // LQCOV_RUN_GRID: blocks of k_run_list, each with a contiguous stretch of tiles (tests: 1 or 2, so that a block walks many)

@@ -473,6 +473,197 @@ k_sketch_dp_mask(const u64 *codes, const u32 *amb, const u64 *coff, const u32 *r
 	}
 }
 
+// ---- the same decision with the presets' k and w as constants (round 6) -------------------------------------------------------
+// k_sketch_dp_mask spends ~170 lane-instructions per base (profiles/r06_a_sketch_counters.txt: 754 VALU + 304 SALU + 147 LDS
+// instructions per thread of five positions) -- 64-bit window and bit reversal, a run-time hash, a rescan of the window in LDS for
+// every step behind per-position branches.  With K + 4 <= 16 the five k-mers of a thread are one 32-bit window of a tile whose
+// codes were staged in LDS once (and one v_bfrev for all five reverse strands); with 2 K + 4 <= 32 a slot is one word `hash << 4 |
+// 15 - i`, i its place among the thread's W + 5 slots, so that "the newest minimal slot of a window" is a plain unsigned minimum
+// (v_min3_u32) and the same word with the low bits flipped gives the oldest one: the two differ exactly when the minimum is tied.
+// A thread whose five positions and the W slots before them are all slots, that holds no tie where sketch.c:125-137 would list
+// one, and that does not run the read's last step goes through straight-line code and leaves with one 15-bit set of emitted
+// positions; every other thread (a palindrome nearby: 1 in 4^(K/2) positions; tied minima: low-complexity sequence) walks the
+// rules literally as k_sketch_dp_mask does.  Which tiles qualify, the halo, owned[] and the mask are k_sketch_dp_mask's.
+__device__ __forceinline__ u32 lq_rev2_32(u32 x)
+{	// the 2-bit groups of x in reverse order
+	x = __brev(x);
+	return ((x >> 1) & 0x55555555u) | ((x & 0x55555555u) << 1);
+}
+// inclusive prefix sum over the wave
+#ifndef LQ_EMU
+#define LQ_SK_DPP(v, ctrl, rows) __builtin_amdgcn_update_dpp(0, (int)(v), (ctrl), (rows), 0xf, false)
+__device__ __forceinline__ u32 lq_wave_scan_add(u32 v)
+{
+	v += (u32)LQ_SK_DPP(v, 0x111, 0xf);    // row_shr:1
+	v += (u32)LQ_SK_DPP(v, 0x112, 0xf);    // row_shr:2
+	v += (u32)LQ_SK_DPP(v, 0x114, 0xf);    // row_shr:4
+	v += (u32)LQ_SK_DPP(v, 0x118, 0xf);    // row_shr:8
+	v += (u32)LQ_SK_DPP(v, 0x142, 0xa);    // row_bcast:15 -> rows 1 and 3
+	v += (u32)LQ_SK_DPP(v, 0x143, 0xc);    // row_bcast:31 -> rows 2 and 3
+	return v;
+}
+#else
+static inline u32 lq_wave_scan_add(u32 v) { for (int d = 1; d < 64; d <<= 1) { const u32 o = __shfl_up(v, d); if ((int)(threadIdx.x & 63) >= d) v += o; } return v; }
+#endif
+__device__ __forceinline__ u32 lq_min3(u32 a, u32 b, u32 c) { const u32 m = a < b ? a : b; return m < c ? m : c; }
+
+#define LQ_DPF_CW (LQ_DPT_N / 16 + 4)                          // 16-base words of a tile's codes, from base - 32
+template <int K, int W>
+__global__ void __launch_bounds__(LQ_DPT_THREADS)
+k_sketch_dp_fast(const u64 *codes, const u32 *amb, const u64 *coff, const u32 *rlen, const u64 *toff, const u32 *tile_rid, u32 n_reads, u64 tile0 /* tiles [tile0, n_tiles) */, u64 n_tiles,
+                 u8 *owned, u32 *mask, u32 *dup_flag)
+{
+	static_assert(K >= 2 && K + LQ_DPT_PER - 1 <= 16 && 2 * K + 4 <= 32 && W >= 2 && W + LQ_DPT_PER <= 16 && W + K - 1 <= LQ_DP_HALO - 16, "reach of the constant-k kernel");
+	constexpr u32 KM = (1u << (2 * K)) - 1;
+	constexpr int NW = W + LQ_DPT_PER;                          // slots a thread looks at: W before its own, its five
+	constexpr int NPREV = (W + LQ_DPT_PER - 1) / LQ_DPT_PER;    // threads before this one that hold them when nothing is missing
+	__shared__ u32 CW[LQ_DPF_CW];
+	__shared__ uint2 VP[LQ_DPT_N];                               // slot -> (hash, index of its position in the tile)
+	__shared__ u32 lmask[LQ_DPT_N / 32];
+	__shared__ u8 full[LQ_DPT_THREADS + 4];                      // thread t's five positions are all slots (entry t + NPREV)
+	__shared__ u32 wsum[LQ_DPT_WAVES], whalo, bad;
+	const u32 t = threadIdx.x, lane = t & 63, wv = t >> 6;
+	for (u64 T = tile0 + blockIdx.x; T < n_tiles; T += gridDim.x) {
+		const u32 r = tile_rid[T];
+		const u32 len = rlen[r];
+		const u64 g0 = coff[r] + (T - toff[r]) * LQ_DPT_CH;        // first chunk of the tile
+		const u32 n_ch = (u32)(coff[r + 1] - g0 < LQ_DPT_CH ? coff[r + 1] - g0 : LQ_DPT_CH);
+		const u32 p0 = (u32)(T - toff[r]) * LQ_DPT_CH * LQ_CHUNK;
+		const u32 a = p0 < LQ_CHUNK ? LQ_CHUNK : p0;              // the read's first chunk is the machine's
+		const u32 b = p0 + n_ch * LQ_CHUNK < len ? p0 + n_ch * LQ_CHUNK : len;
+		if (a >= b) { if (t < n_ch) owned[g0 + t] = 0; continue; }   // (uniform)
+		const u64 *cw = codes + coff[r] * LQ_CHUNK_WORDS;
+		const u32 *aw = amb + coff[r] * LQ_CHUNK_WORDS;
+		const u32 base = a - LQ_DP_HALO;                          // position of index 0 (a multiple of 64)
+		if (t < 64) {                                              // the first wave: the tile's codes into LDS, "an ambiguous base within reach"
+			u32 am = 0;
+			if (t < LQ_DPF_CW / 2) {
+				const u32 pw = base - 32 + 32 * t;                    // first position of word t
+				const u64 wi = pw >> 5, nw = (coff[r + 1] - coff[r]) * LQ_CHUNK_WORDS;
+				u64 c = 0;
+				if (wi < nw) { c = cw[wi]; am = aw[wi]; }
+				CW[2 * t] = (u32)c; CW[2 * t + 1] = (u32)(c >> 32);
+				const u32 lo = base - (u32)K + 1;                      // k-mers of [base, b) cover [lo, b)
+				if (pw + 32 <= lo || pw >= b) am = 0;
+				else { if (pw < lo) am &= ~0u << (lo - pw); if (pw + 32 > b) am &= ~0u >> (pw + 32 - b); }
+			}
+			const bool any = __ballot(am != 0) != 0;
+			if (t == 0) bad = any ? 1u : 0u;
+		}
+		if (t < LQ_DPT_N / 32) lmask[t] = 0;
+		if (t < NPREV) full[t] = 0;
+		__syncthreads();
+		// this thread's five positions base + 5 t + j; their k-mers are [p - K + 1, p]
+		const u32 i0 = LQ_DPT_PER * t, q0 = base + i0;
+		u32 h[LQ_DPT_PER];
+		u32 sl = 0;                                               // bit j: position j is a slot
+		if (q0 < b) {
+			const u32 rel = i0 + 33 - (u32)K;                       // q0 - K + 1 - (base - 32)
+			const u32 wi = rel >> 4, sh = 2 * (rel & 15);
+			const u32 win = (u32)((((u64)CW[wi + 1] << 32) | CW[wi]) >> sh);   // 16 bases from q0 - K + 1 on, first base lowest
+			const u32 R = lq_rev2_32(win);                           // the same, last base lowest
+#pragma unroll
+			for (int j = 0; j < LQ_DPT_PER; ++j) {
+				const u32 rv = ((win >> (2 * j)) & KM) ^ KM;           // complement, oldest base lowest: the machine's rv
+				const u32 fw = (R >> (2 * (16 - j - K))) & KM;         // newest base lowest: the machine's fw
+				h[j] = lq_hash<u32>(fw < rv ? fw : rv, KM);
+				if (fw != rv && q0 + j < b) sl |= 1u << j;
+			}
+		} else {
+#pragma unroll
+			for (int j = 0; j < LQ_DPT_PER; ++j) h[j] = 0;
+		}
+		// slot index = number of slots before the position
+		const u32 mine = (u32)__popc(sl);
+		const u32 inc = lq_wave_scan_add(mine);
+		if (lane == 63) wsum[wv] = inc;
+		if (t == LQ_DP_HALO / LQ_DPT_PER) whalo = inc - mine + (u32)__popc(sl & ((1u << (LQ_DP_HALO % LQ_DPT_PER)) - 1));   // slots of the halo (indices below 64)
+		full[t + NPREV] = sl == (1u << LQ_DPT_PER) - 1 ? 1 : 0;
+		__syncthreads();
+		u32 ts = inc - mine, Tn = 0;
+		for (u32 q = 0; q < LQ_DPT_WAVES; ++q) { if (q < wv) ts += wsum[q]; Tn += wsum[q]; }
+		const u32 T0 = whalo;
+		const bool ok = !bad && T0 >= (u32)(W + K - 1) && Tn > T0;    // (uniform; a stretch without a single slot is the machine's)
+		if (t < n_ch) owned[g0 + t] = (ok && p0 + t * LQ_CHUNK >= a) ? 1 : 0;
+		if (!ok) { __syncthreads(); continue; }
+		const bool all5 = sl == (1u << LQ_DPT_PER) - 1;
+		if (all5) {
+#pragma unroll
+			for (int j = 0; j < LQ_DPT_PER; ++j) VP[ts + j] = make_uint2(h[j], i0 + j);
+		} else {
+			u32 s = ts;
+			for (int j = 0; j < LQ_DPT_PER; ++j) if (sl >> j & 1) { VP[s] = make_uint2(h[j], i0 + j); ++s; }
+		}
+		__syncthreads();
+		// emissions of this thread's steps (the steps of the halo belong to whoever owns those positions)
+		bool prev_full = true;
+#pragma unroll
+		for (int q = 0; q < NPREV; ++q) prev_full = prev_full && full[t + q];
+		bool slow = mine != 0 && i0 + LQ_DPT_PER > LQ_DP_HALO;     // (a thread with steps to run)
+		if (all5 && prev_full && i0 >= LQ_DP_HALO && !(ts + LQ_DPT_PER == Tn && b >= len)) {
+			// the slots ts - W .. ts + 4 are the positions i0 - W .. i0 + 4: A[i] orders them by (hash, newest first), ^ 15: (hash, oldest first)
+			u32 A[NW];
+#pragma unroll
+			for (int i = 0; i < W; ++i) A[i] = VP[ts - W + i].x << 4 | (u32)(15 - i);
+#pragma unroll
+			for (int j = 0; j < LQ_DPT_PER; ++j) A[W + j] = h[j] << 4 | (u32)(15 - W - j);
+			u32 Mn[LQ_DPT_PER + 1], Mo[LQ_DPT_PER + 1];               // minimum of A[j .. j + W - 1], newest / oldest of the tied
+#pragma unroll
+			for (int j = 0; j <= LQ_DPT_PER; ++j) {
+				u32 mn = A[j], mo = A[j] ^ 15u;
+				int i = 1;
+				for (; i + 1 < W; i += 2) { mn = lq_min3(mn, A[j + i], A[j + i + 1]); mo = lq_min3(mo, A[j + i] ^ 15u, A[j + i + 1] ^ 15u); }
+				for (; i < W; ++i) { mn = mn < A[j + i] ? mn : A[j + i]; mo = mo < (A[j + i] ^ 15u) ? mo : (A[j + i] ^ 15u); }
+				Mn[j] = mn; Mo[j] = mo;
+			}
+			u32 em = 0;                                              // bit i: the position of A[i] is emitted
+			bool tie = false;
+#pragma unroll
+			for (int j = 0; j < LQ_DPT_PER; ++j) {
+				const u32 m = Mn[j];                                    // the newest minimal slot of the W slots before step W + j
+				const bool ca = h[j] <= (m >> 4);                       // sketch.c:122-124
+				const bool cb = !ca && m == A[j];                       // sketch.c:125-137: the minimum leaves the window
+				if (ca || cb) em |= 0x8000u >> (m & 15u);
+				if (cb && (Mn[j + 1] ^ Mo[j + 1]) != 15u) tie = true;   // the new window's minimum is tied: its other holders are listed
+			}
+			slow = tie;
+			if (em) {
+				const u32 e0 = i0 - (u32)W;                             // index of A[0]'s position
+				const u64 v = (u64)em << (e0 & 31);
+				atomicOr(&lmask[e0 >> 5], (u32)v);
+				if ((u32)(v >> 32)) atomicOr(&lmask[(e0 >> 5) + 1], (u32)(v >> 32));
+			}
+		}
+		if (slow) {
+			u32 s = ts;
+			for (int j = 0; j < LQ_DPT_PER; ++j) if (sl >> j & 1) {
+				if (i0 + j >= LQ_DP_HALO) {
+					const u32 x = h[j];
+					u32 m = s - 1;
+					for (u32 u = 2; u <= (u32)W; ++u) if (VP[s - u].x < VP[m].x) m = s - u;          // the newest minimal slot of [s - W, s - 1]
+					u32 after = m;                                                                  // the window's minimum after the step
+					if (x <= VP[m].x) { const u32 e = VP[m].y; atomicOr(&lmask[e >> 5], 1u << (e & 31)); after = s; }
+					else if (m == s - (u32)W) {
+						{ const u32 e = VP[m].y; atomicOr(&lmask[e >> 5], 1u << (e & 31)); }
+						u32 m2 = s;
+						for (u32 u = 1; u < (u32)W; ++u) if (VP[s - u].x < VP[m2].x) m2 = s - u;     // the newest minimal slot of [s - W + 1, s]
+						for (u32 u = s - (u32)W + 1; u <= s; ++u) if (u != m2 && VP[u].x == VP[m2].x) { const u32 e = VP[u].y; atomicOr(&lmask[e >> 5], 1u << (e & 31)); }
+						after = m2;
+					}
+					if (s == Tn - 1 && b >= len) { const u32 e = VP[after].y; atomicOr(&lmask[e >> 5], 1u << (e & 31)); }   // the read's last step: its window's minimum follows
+				}
+				++s;
+			}
+		}
+		__syncthreads();
+		if (t < LQ_DPT_N / 32) {
+			const u32 v = lmask[t];
+			if (v) { u32 *gw = mask + coff[r] * LQ_CHUNK_WORDS + (base >> 5) + t; if (atomicOr(gw, v) & v) atomicOr(dup_flag, 1u); }
+		}
+		__syncthreads();
+	}
+}
+
 // cnt[g] = emitted positions of chunk g
 __global__ void k_mask_count(const u32 *mask, u64 n_chunks, u32 *cnt)
 {

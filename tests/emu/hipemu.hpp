@@ -120,6 +120,8 @@ inline void __threadfence_block() {}
 
 struct alignas(16) uint4 { unsigned x, y, z, w; };
 struct alignas(8) uint2 { unsigned x, y; };
+inline uint2 make_uint2(unsigned x, unsigned y) { uint2 v; v.x = x; v.y = y; return v; }
+inline unsigned __brev(unsigned v) { unsigned r = 0; for (int i = 0; i < 32; ++i) if (v >> i & 1) r |= 1u << (31 - i); return r; }
 
 inline int __clz(unsigned v) { return v ? __builtin_clz(v) : 32; }
 inline int __clzll(unsigned long long v) { return v ? __builtin_clzll(v) : 64; }

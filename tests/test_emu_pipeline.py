@@ -141,6 +141,50 @@ def test_emulated_data_parallel_sketch_fuzz(emu_lib, monkeypatch):
             assert np.array_equal(res[0][0], other[0]) and np.array_equal(res[0][1], other[1]), (it, k, w)
 
 
+def test_emulated_constant_k_sketch_fuzz(emu_lib, monkeypatch):
+    """k_sketch_dp_fast (-k 12 with -w 5 / 10: k and w as constants, straight-line steps for threads without palindromes and ties,
+    the literal rules for the others) against the state machine and against the general kernel (LQCOV_SKETCH_FAST=0): reads of
+    several tiles with tandem repeats of short periods (tied minima inside a window), two- and three-letter alphabets, AT and
+    GC stretches (palindromes), Ns, reads that end inside and right after a tile"""
+    A = np.frombuffer(b"ACGT", dtype=np.uint8)
+    for it in range(12):
+        rng = np.random.default_rng(700 + it)
+        w = 5 if it % 3 else 10
+        seqs = []
+        for j in range(8):
+            L = [1536 + 128, 1536 * 2 + 128 - 1, 1536 + 128 + 5, 1664 + 64][j] if j < 4 else int(rng.integers(2000, 12000))
+            s = A[rng.integers(0, 4, L)].copy()
+            for _ in range(int(rng.integers(0, 12))):
+                mode = int(rng.integers(0, 7))
+                a = int(rng.integers(0, L - 200)); n = int(rng.integers(20, 200))
+                if mode == 0:
+                    u = int(rng.integers(1, 9)); s[a:a + n] = np.tile(s[a:a + u], n // u + 1)[:n]          # tandem repeat, period 1..8
+                elif mode == 1:
+                    s[a:a + n] = np.frombuffer((b"AT" * 100)[:n], np.uint8)
+                elif mode == 2:
+                    s[a:a + n] = np.frombuffer(b"AC", np.uint8)[rng.integers(0, 2, n)]
+                elif mode == 3:
+                    s[a:a + n] = np.tile(s[a:a + 13], n // 13 + 1)[:n]                                    # period k + 1
+                elif mode == 4:
+                    s[a] = ord("N")
+                elif mode == 5:
+                    s[a:a + n] = np.frombuffer((b"GC" * 100)[:n], np.uint8)
+                else:
+                    h = n // 2; s[a + h:a + 2 * h] = (3 - (s[a:a + h][::-1] == A[:, None]).argmax(0)).astype(np.uint8).choose(A)   # a reverse-complement copy next to its source
+            seqs.append(s)
+        names = ["s%d" % i for i in range(len(seqs))]
+        res = []
+        for mode, fast in (("machine", "1"), ("default", "1"), ("default", "0")):
+            monkeypatch.setenv("LQCOV_SKETCH", mode); monkeypatch.setenv("LQCOV_SKETCH_FAST", fast)
+            eng = _engine(emu_lib, k=12, w=w, hpc=0, min_score_med=40, min_score_good=40)
+            eng.set_queries(names, seqs, None)
+            xy, off = eng.query_minimizers()
+            res.append((np.array(xy).copy(), np.array(off).copy()))
+            eng.close()
+        for other in res[1:]:
+            assert np.array_equal(res[0][0], other[0]) and np.array_equal(res[0][1], other[1]), (it, w)
+
+
 def test_emulated_sketch_halo_adversarial(emu_lib):
     """palindromic / N-rich / homopolymer contexts around every chunk boundary: the warm-up must widen its halo"""
     rng = np.random.default_rng(5)
