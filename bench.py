@@ -170,12 +170,68 @@ def table_properties(table_text, names, lengths):
             "max_coverage": round(float(np.max(cov)), 3) if cov else None, "problems": bad[:5]}
 
 
+def sdust_bench(args):
+    """`bench.py --config sdust`: the low-complexity table of every read of configs[1] (50 000 synthetic ONT reads ~15 kb, 744 Mbases) --
+    what lq_mask.py gets from the reference's `sdust` binary chunk by chunk (lq_mask.py:17-23,99-121; sdust.c:136-222).  A step is one call
+    of lqsdust_main on the FASTQ file (tmpfs): parse + upload + k_sdust + meanQ + rows written; value = bases / step.  cpu_baseline: the
+    reference's own `sdust` (oracle/_ref) on the same reads, cut into one chunk file per worker as lq_mask.py cuts them, all workers at
+    once on the host's cores; its concatenated output must equal the GPU's table."""
+    import dataclasses, shutil
+    import torch
+    from longqc_amd import synth, sdust
+    from tests import oracle_bind
+    n = args.reads or 50000
+    cfg = dataclasses.replace(synth.CONFIGS["cfg2"], n_reads=n, nsample=10)
+    t0 = time.time()
+    T, _ = synth.make_dataset(cfg)
+    gen_s = time.time() - t0
+    base = "/dev/shm" if os.path.isdir("/dev/shm") and shutil.disk_usage("/dev/shm").free > 6 * T.n_bases else None
+    with tempfile.TemporaryDirectory(dir=base) as d:
+        fq, out = os.path.join(d, "all.fq"), os.path.join(d, "sdust.tsv")
+        synth.write_fastq(fq, T)
+        for _ in range(args.warmup):
+            sdust.run_sdust(fq, out)
+        ts = []
+        for _ in range(args.steps):
+            torch.cuda.synchronize()
+            t0 = time.time(); sdust.run_sdust(fq, out); ts.append(time.time() - t0)
+        dt = sum(ts) / len(ts)
+        table = open(out).read()
+        line = {"metric": "Mbases/sec sdust low-complexity table (sampleqc, lq_mask.py)", "value": round(T.n_bases / dt / 1e6, 3), "unit": "Mbases/s", "n_gpus": 1,
+                "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "dtype": "u8", "data": "synthetic",
+                "config": {"workload": "SURVEY 8(f)-4: `sdust <all reads>` on BASELINE configs[1]'s reads (%d synthetic ONT reads ~15 kb, %d bases, FASTQ on %s): masked bases, length, fraction, meanQ, "
+                                       "QV7 count per read" % (len(T), T.n_bases, base or "the temp dir"),
+                           "clock": "one lqsdust_main call: FASTQ parse + H2D + k_sdust (one read per thread, sdust.c:70-134) + meanQ / QV7 + rows written; wall clock", "parallelism": "single GPU"},
+                "rows": table.count("\n"), "synth_gen_s": round(gen_s, 1)}
+        ref = os.path.join(os.path.dirname(oracle_bind.REF_BIN), "sdust")
+        if os.path.exists(ref) and not args.no_cpu_baseline:
+            cores = min(os.cpu_count() or 1, 64)
+            cuts = [len(T) * i // cores for i in range(cores + 1)]
+            files = []
+            for i in range(cores):
+                if cuts[i + 1] > cuts[i]:
+                    f = os.path.join(d, "chunk%d.fq" % i); synth.write_fastq(f, T.subset(range(cuts[i], cuts[i + 1]))); files.append(f)
+            t0 = time.time()
+            procs = [subprocess.Popen([ref, f], stdout=open(f + ".out", "w"), stderr=subprocess.DEVNULL) for f in files]
+            rcs = [pr.wait() for pr in procs]
+            dtr = time.time() - t0
+            ref_table = "".join(open(f + ".out").read() for f in files)
+            line["cpu_baseline"] = {"value": round(T.n_bases / dtr / 1e6, 3), "unit": "Mbases/s", "seconds": round(dtr, 2), "cores": len(files), "kind": "reference",
+                                    "sample": "ALL reads of the workload in %d chunk files, one reference `sdust` process per chunk, all at once (lq_mask.py's pool)" % len(files),
+                                    "table_identical_to_gpu": all(r == 0 for r in rcs) and ref_table == table}
+            t0 = time.time(); subprocess.run([ref, files[0]], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL); d1 = time.time() - t0
+            nb1 = sum(int(x.shape[0]) for x in T.seqs[cuts[0]:cuts[1]])
+            line["cpu_baseline"]["one_process"] = {"value": round(nb1 / d1 / 1e6, 3), "unit": "Mbases/s", "cores": 1, "sample": "the first chunk alone"}
+    print(json.dumps(line), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", default="cfg3", choices=sorted(PRESET))
+    ap.add_argument("--config", default="cfg3", choices=sorted(PRESET) + ["sdust"], help="sdust: the other native binary of sampleqc (SURVEY 8(f)-4), a bench line of its own")
     ap.add_argument("--reads", type=int, default=0, help="override the number of reads (default: the config's)")
     ap.add_argument("--nsample", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -183,6 +239,7 @@ def main():
     ap.add_argument("--sharded-reads", action="store_true", help="N > 1: every rank generates only the reads of its shares (automatic for configs above 20 Gbases)")
     ap.add_argument("--no-pipeline", action="store_true", help="N > 1: the front of part i + 1 (upload, sketch, all-gather, index) after the mapping of part i, not under it")
     ap.add_argument("--no-north-star", action="store_true", help="skip the extra pass that times the sketch and seed kernels alone on the device")
+    ap.add_argument("--gz-end-to-end", action="store_true", help="end_to_end once more with the targets as one gzip stream (LongQC's usual .fastq.gz input): reported as end_to_end.gz")
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the files-in / table-out call (lqcov_run_files on the workload written to tmpfs)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="target reads in the CPU baseline sample (~20-30 s of reference time)")
     ap.add_argument("--cache", default="", help="directory for the generated reads (re-used by later runs of the same config on this machine)")
@@ -191,6 +248,8 @@ def main():
     ap.add_argument("--front-only", action="store_true", help="not the bench: upload + sketch + index of the first part alone, --steps times, nothing else on the device; "
                                                                 "prints the per-kernel HIP-event times of the build side undisturbed (development aid)")
     args = ap.parse_args()
+    if args.config == "sdust":
+        return sdust_bench(args)
 
     import torch
     import torch.distributed as dist
@@ -691,11 +750,27 @@ def main():
                     cs = [l for l in elog if "the whole call" in l]
                     call_s = float(cs[-1].split("the whole call")[1].split()[0]) if cs else None
             same = open(of).read() == table
+            gz = None
+            if args.gz_end_to_end and os.path.exists(exe) and have_cuda:
+                # the same call with the targets as ONE gzip stream (LongQC's inputs are usually .fastq.gz): the streaming reader inflates on one
+                # host thread (fastx.hpp, zlib), so the call is bound by it
+                tg = tf + ".gz"
+                t0 = time.time(); subprocess.run("pigz -1 -k -c %s > %s 2>/dev/null || gzip -1 -c %s > %s" % (tf, tg, tf, tg), shell=True, check=True); t_gz = time.time() - t0
+                time.sleep(8.0)
+                t0 = time.time()
+                r = subprocess.run([exe] + list(PRESET[args.config][1]) + ["-t", "8", tg, qf], stdout=open(of + ".gz.tsv", "w"), stderr=subprocess.PIPE, env=env)
+                dtg = time.time() - t0
+                gz = {"value": round(total_bases / dtg / 1e6, 3), "unit": "Mbases/s", "seconds": round(dtg, 3), "table_identical_to_timed_steps": r.returncode == 0 and open(of + ".gz.tsv").read() == table,
+                      "files": "targets: the same FASTA as one gzip -1 stream (%.2f GB, made in %.0f s)" % (os.path.getsize(tg) / 1e9, t_gz),
+                      "log_tail": [l for l in r.stderr.decode(errors="replace").splitlines() if l.startswith("[lqcov]")][-6:]}
+                os.remove(tg)
             line["end_to_end"] = {"value": round(total_bases / best / 1e6, 3), "unit": "Mbases/s", "seconds": round(best, 3), "seconds_inside_the_call": call_s, "table_identical_to_timed_steps": same,
                                   "files": "targets: plain FASTA (%.1f GB) on %s, queries: FASTQ; best of 2 runs, device idle for 8 s before each" % (os.path.getsize(tf) / 1e9, base or "the temp dir"),
                                   "what": "the executable minimap2-coverage-mi355x as a subprocess, LongQC's argv: process start + HIP start-up + parse (mapped file, %d host threads) + 2-bit pack + H2D + sketch + index + map "
                                           "of every part in run_files' pipeline + rows + table text; wall clock around the process" % min(64, os.cpu_count() or 1),
                                   "log_tail": log_tail, "file_write_s": round(t_write, 1)}
+            if gz:
+                line["end_to_end"]["gz"] = gz
             # the reference on the same files, all reads and all queries, when the host has the cores for it (measured, not quoted)
             cores = os.cpu_count() or 1
             from tests import oracle_bind

@@ -200,6 +200,13 @@ uint64_t lqcov_last_n_anchors(const lqcov_handle *h);
  * since lqcov_reset: runs chained in klib's own order of equal-x anchors, the queries that own them, the anchors those
  * queries were sorted by klib's passes for.  No counterpart in the reference (it writes and sorts every hit). */
 void lqcov_map_stats(const lqcov_handle *h, uint64_t out[4]);
+/* Why runs were left to klib's own order (since lqcov_reset; a run is counted once, by the first reason found -- the rule is in
+ * kernels_chain.hpp, TieGroup, and restates where mm_chain_dp, chain.c:41-108, can see the order radix_sort_128x, lqmap.c:238, leaves
+ * equal-x anchors in): out[0] a skip was pending when a group of tied candidates began (chain.c:72-74), out[1] a member of the
+ * group counts as a skip, out[2] the group's top score is reached by two members (chain.c:69-71: max_j), out[3] the scan broke off
+ * (chain.c:73) before a tie partner that would have raised the best score, out[4] two equal-x peaks of one score in the backtrack
+ * order (chain.c:102-108), out[5] other.  No counterpart in the reference. */
+void lqcov_tie_reasons(const lqcov_handle *h, uint64_t out[6]);
 /* The records of a FASTA/FASTQ file as the target reader sees them (kseq_read + the U -> T of kseq2bseq, kseq.h:179-224,
  * bseq.c:56-66): out[0] = records, out[1] = bases, out[2] = a hash over the names, out[3] = a hash over the sequences, out[4] =
  * pieces of the file that had to be parsed again in order (parallel reader only).  mode 0: the streaming reader (one thread,

@@ -113,6 +113,7 @@ def load_library(path: Optional[str] = None):
         "lqcov_part_n_keys": (C.c_uint64, [H, C.c_int]),
         "lqcov_last_n_anchors": (C.c_uint64, [H]),
         "lqcov_map_stats": (None, [H, u64p]),
+        "lqcov_tie_reasons": (None, [H, u64p]),
         "lqcov_fastx_digest": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_uint64, u64p]),
         "lqcov_get_query_minimizers": (C.c_int, [H, C.c_void_p, C.c_void_p, u64p]),
         "lqcov_get_part_minimizers": (C.c_int, [H, C.c_int, C.c_void_p, C.c_void_p, u64p]),
@@ -410,7 +411,10 @@ class Engine:
         """anchors written against the last part; since reset(): runs / queries / anchors that needed klib's own order"""
         a = (C.c_uint64 * 4)()
         self.lib.lqcov_map_stats(self.h, a)
-        return {"last_written": int(a[0]), "klib_runs": int(a[1]), "klib_queries": int(a[2]), "klib_anchors": int(a[3])}
+        r = (C.c_uint64 * 6)()
+        self.lib.lqcov_tie_reasons(self.h, r)
+        why = dict(zip(("skip_pending_at_group", "member_counts_as_skip", "top_score_twice", "scan_broke_off", "equal_peaks_in_backtrack", "other"), (int(v) for v in r)))
+        return {"last_written": int(a[0]), "klib_runs": int(a[1]), "klib_queries": int(a[2]), "klib_anchors": int(a[3]), "reasons": why}
 
     def part_n_minimizers(self, part: int) -> int:
         return int(self.lib.lqcov_part_n_minimizers(self.h, part))

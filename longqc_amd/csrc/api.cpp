@@ -364,6 +364,7 @@ int lqcov_workspace_trim(lqcov_handle *h)
 		// then the blocks the stream-ordered pool has cached.  Everything regrows on the next part_map.
 		for (auto &L : h->lanes) L->release_buffers();
 		for (DBuf *b : { &h->ix_key, &h->ix_key2, &h->ix_head, &h->ix_uidx, &h->ix_sorted }) b->release();
+		h->ix_key_stamp = 0;
 		{	// (the seed filter's bucket buffer and tables: as large as a gigabyte-scale chunk of records)
 			std::lock_guard<std::mutex> lk(h->seed_mu);
 			SeedWork &W = h->seed_ws;
@@ -465,6 +466,12 @@ void lqcov_map_stats(const lqcov_handle *h, uint64_t out[4])
 	out[0] = h ? h->last_n_written : 0; out[1] = h ? (uint64_t)h->stat_sens_runs : 0; out[2] = h ? (uint64_t)h->stat_p2_queries : 0; out[3] = h ? (uint64_t)h->stat_p2_anchors : 0;
 }
 
+void lqcov_tie_reasons(const lqcov_handle *h, uint64_t out[6])
+{
+	if (!out) return;
+	for (int i = 0; i < 6; ++i) out[i] = h ? (uint64_t)h->stat_tie_why[i] : 0;
+}
+
 static void copy_minimizers(lqcov_handle *h, ReadSetDev &rs, uint64_t *xy, uint64_t *off, uint64_t *n_total)
 {
 	if (!rs.sketched) throw std::logic_error("read set not sketched");
@@ -557,6 +564,7 @@ int lqcov_part_build_from_minimizer_shares_dev(lqcov_handle *h, int part, const 
 		ReadSetDev &rs = pt.rs;
 		uint64_t n = 0;
 		for (uint32_t i = 0; i < n_shares; ++i) { if (share_n[i] > stride) throw std::invalid_argument("share longer than the stride"); n += share_n[i]; }
+		rs.key_stamp = 0;
 		rs.mx.ensure(n * 8 + 8); rs.my.ensure(n * 8 + 8);
 		uint64_t at = 0;
 		for (uint32_t i = 0; i < n_shares; ++i) {

@@ -104,6 +104,7 @@ void Knobs::read_env()
 	lanes = (int)std::min<long>(8, std::max<long>(1, num("LQCOV_LANES", 3)));
 	anchor_budget = getenv("LQCOV_ANCHOR_BUDGET") ? strtoull(getenv("LQCOV_ANCHOR_BUDGET"), 0, 10) : 0;
 	query_order_file = is("LQCOV_QUERY_ORDER", "file");
+	query_order_length = is("LQCOV_QUERY_ORDER", "length");
 	all_klib = is("LQCOV_SORT", "klib");
 	ps_shift = (u32)std::min<long>(12, std::max<long>(0, num("LQCOV_PS_SHIFT", 0)));
 	reg_walker = !is("LQCOV_WALK", "solo");
@@ -124,6 +125,9 @@ void Knobs::read_env()
 	run_grid = (u32)std::max<long>(1, num("LQCOV_RUN_GRID", 2048));
 	ps_key64 = num("LQCOV_PS_KEY64", 0) != 0;
 	sketch_wgen = num("LQCOV_SKETCH_WGEN", 0) != 0;
+	sketch_key = num("LQCOV_SKETCH_KEY", 1) != 0;
+	emit_grid = (u32)std::min<long>(1L << 22, std::max<long>(1, num("LQCOV_EMIT_GRID", 1L << 22)));
+	sketch_list = num("LQCOV_SKETCH_LIST", 1) != 0;
 	sketch_fast = num("LQCOV_SKETCH_FAST", 1) != 0;
 #ifndef LQ_EMU
 	lq_trace_launches = (int)num("LQCOV_TRACE_LAUNCHES", 0);
@@ -472,6 +476,7 @@ void lqcov_handle::sketch(ReadSetDev &rs, bool rid_in_y)
 	h2d(rs.d_len.as<u32>(), rs.h_len.data(), rs.n, stream);
 	rs.moff.ensure((rs.n + 1) * 8);
 	rs.n_mini = 0;
+	rs.key_stamp = 0;
 	const u64 nc = rs.n_chunks;
 	if (nc) {
 		SkParams sp; sp.k = P.k; sp.w = P.w; sp.hpc = P.hpc; sp.mask = (1ULL << 2 * P.k) - 1; sp.shift1 = 2 * (P.k - 1);
@@ -483,7 +488,8 @@ void lqcov_handle::sketch(ReadSetDev &rs, bool rid_in_y)
 		// ring capacity 8 / 16 (LDS) or 256 (private), -H on/off: pick the instantiation
 		// chunks per thread: the halo before a thread's first chunk is walked once per kpt chunks
 		const u32 kpt = K.sketch_kpt;
-#define LQ_SK_LAUNCH(RC, EM, HP, BS, ...) LQ_LAUNCH((k_sketch<RC, EM, HP>), nblk((nc + kpt - 1) / kpt, BS), BS, stream, rs.codes.as<u64>(), rs.amb.as<u32>(), rs.d_coff.as<u64>(), rs.d_len.as<u32>(), rs.n, nc, kpt, sp, (int)rid_in_y, __VA_ARGS__)
+		const u32 *sk_list = nullptr, *sk_nlist = nullptr;           // mask mode beside the data-parallel kernel: the chunks it left, listed
+#define LQ_SK_LAUNCH(RC, EM, HP, BS, ...) LQ_LAUNCH((k_sketch<RC, EM, HP>), sk_list ? (u32)std::min<u64>(nblk(nc, BS), 2048) : nblk((nc + kpt - 1) / kpt, BS), BS, stream, rs.codes.as<u64>(), rs.amb.as<u32>(), rs.d_coff.as<u64>(), rs.d_len.as<u32>(), rs.n, nc, kpt, sp, (int)rid_in_y, __VA_ARGS__, sk_list, sk_nlist)
 #define LQ_SK_DISPATCH(EM, HP, ...) do { \
 		if (P.w <= 8)       LQ_SK_LAUNCH(8, EM, HP, LQ_SK_BLOCK, __VA_ARGS__); \
 		else if (P.w <= 16) LQ_SK_LAUNCH(16, EM, HP, LQ_SK_BLOCK, __VA_ARGS__); \
@@ -520,12 +526,19 @@ void lqcov_handle::sketch(ReadSetDev &rs, bool rid_in_y)
 					fprintf(stderr, "[sketch] %llu of %llu chunks decided data-parallel\n", (unsigned long long)n_own, (unsigned long long)nc);
 				}
 			}
+			if (dp && K.sketch_list && nc < 0xffffffffULL) {
+				sk_ulist.ensure(nc * 4 + 4);                             // (entry nc: the count)
+				dzero(sk_ulist.as<u32>() + nc, 4, stream);
+				LQ_LAUNCH(k_sketch_unowned, nblk(nc, 256), 256, stream, dp_owned, nc, sk_ulist.as<u32>(), sk_ulist.as<u32>() + nc); check_launch();
+				sk_list = sk_ulist.as<u32>(); sk_nlist = sk_ulist.as<u32>() + nc;
+			}
 			{
 				StageTimer t(this, stream, "k_sketch_mask", dp ? nc : in_bytes + nc * 16);
 				LQ_SK_DISPATCH(LQ_SK_MASK, false, (u32*)nullptr, (const u64*)nullptr, (u64*)nullptr, (u64*)nullptr, dp_owned, sk_mask.as<u32>(), sk_flag.as<u32>());
 				check_launch();
 			}
 			lap("state machine");
+			sk_list = sk_nlist = nullptr;
 			LQ_LAUNCH(k_mask_count, nblk(nc, 256), 256, stream, sk_mask.as<u32>(), nc, cnt.as<u32>()); check_launch();
 		} else {
 			StageTimer t(this, stream, "k_sketch_count", in_bytes + nc * 4);
@@ -545,8 +558,11 @@ void lqcov_handle::sketch(ReadSetDev &rs, bool rid_in_y)
 			d2h(&dup, sk_flag.as<u32>(), 1, stream);
 			if (dup) throw std::logic_error("sketch: a position was emitted twice (mask form of the minimizer list does not hold)");
 			StageTimer t(this, stream, "k_sketch_emit_mask", nc * 24 + rs.n_mini * (16 + 4));
-			LQ_LAUNCH(k_sketch_emit_mask, (u32)std::min<u64>((nc + LQ_EM_CH - 1) / LQ_EM_CH, 1u << 22), LQ_EM_THREADS, stream, rs.codes.as<u64>(), rs.amb.as<u32>(), rs.d_coff.as<u64>(), sk_grid.as<u32>(), rs.n, nc, sp, (int)rid_in_y,
-			          sk_mask.as<u32>(), off.as<u64>(), rs.mx.as<u64>(), rs.my.as<u64>());
+			// (a part's minimizers: the hash alone as well, where it fits 32 bits -- the index sort's key, which k_sort_keys otherwise makes from x)
+			u32 *okey = nullptr;
+			if (rid_in_y && 2 * P.k <= 32 && K.sketch_key) { ix_key.ensure(rs.n_mini * 8); okey = ix_key.as<u32>(); rs.key_stamp = ix_key_stamp = ++ix_key_seq; }
+			LQ_LAUNCH(k_sketch_emit_mask, (u32)std::min<u64>((nc + LQ_EM_CH - 1) / LQ_EM_CH, K.emit_grid), LQ_EM_THREADS, stream, rs.codes.as<u64>(), rs.amb.as<u32>(), rs.d_coff.as<u64>(), sk_grid.as<u32>(), rs.n, nc, sp, (int)rid_in_y,
+			          sk_mask.as<u32>(), off.as<u64>(), rs.mx.as<u64>(), rs.my.as<u64>(), okey);
 			check_launch();
 		} else {
 			StageTimer t(this, stream, "k_sketch_emit", in_bytes + nc * 8 + rs.n_mini * 16);
@@ -600,8 +616,19 @@ void lqcov_handle::set_queries(u32 n, const u8 *seq_in, const u64 *seq_off_in, c
 	// internal order: longest first (stable); LQCOV_QUERY_ORDER=file keeps the caller's order (A/B and test knob)
 	q_perm.resize(n); q_inv.resize(n);
 	for (u32 i = 0; i < n; ++i) q_perm[i] = i;
-	if (!K.query_order_file)
+	if (!K.query_order_file) {
 		std::stable_sort(q_perm.begin(), q_perm.end(), [&](u32 a, u32 b) { return seq_off_in[a + 1] - seq_off_in[a] > seq_off_in[b + 1] - seq_off_in[b]; });
+		// Dealt to as many stripes as there are mapping lanes, the stripes one after the other (round 6).  A part's batches are
+		// contiguous ranges of this order, one per lane; with the plain longest-first order the first lane held the longest queries
+		// -- and with them most of the second pass (klib's order for the queries that own an observable tie: 267 M of part 1's 467 M
+		// such anchors at configs[2], 118 ms against 65 and 45 on the other lanes).  LQCOV_QUERY_ORDER=length keeps rounds 1-5's order.
+		const u32 ns = (u32)std::max(1, K.lanes);
+		if (!K.query_order_length && ns > 1 && n > ns) {
+			std::vector<u32> dealt; dealt.reserve(n);
+			for (u32 st = 0; st < ns; ++st) for (u32 i = st; i < n; i += ns) dealt.push_back(q_perm[i]);
+			q_perm.swap(dealt);
+		}
+	}
 	for (u32 i = 0; i < n; ++i) q_inv[q_perm[i]] = i;
 	std::vector<u8> pseq, pqual;
 	std::vector<u64> pseq_off(n + 1, 0), pname_off(n + 1, 0);
@@ -669,6 +696,7 @@ void lqcov_handle::reset()
 	dzero(n_pv.p, 4, stream);
 	if (!distributed) mid_occ = -1;
 	stat_sens_runs = 0; stat_p2_queries = 0; stat_p2_anchors = 0;
+	for (auto &v : stat_tie_why) v = 0;
 	sat_cnt.clear(); stat_sat_chains = 0;
 	finished = false;
 	LQ_HIP_CHECK(hipStreamSynchronize(stream));
@@ -721,10 +749,12 @@ void lqcov_handle::build_index(Part &pt)
 		key.ensure(M * 8); key2.ensure(M * 8); head.ensure((n_tiles + 1) * 4); uidx.ensure((n_tiles + 1) * 8);   // (head / uidx: run heads per tile of keys, scanned)
 		const bool k32 = 2 * P.k <= 32;                         // the hash fits 32 bits: 4-byte sort keys
 		if (k32) {
-			LQ_LAUNCH(k_sort_keys<u32>, nblk(M, 256), 256, stream, rs.mx.as<u64>(), M, key.as<u32>()); check_launch();
+			if (!(rs.key_stamp && rs.key_stamp == ix_key_stamp)) { LQ_LAUNCH(k_sort_keys<u32>, nblk(M, 256), 256, stream, rs.mx.as<u64>(), M, key.as<u32>()); check_launch(); }   // (k_sketch_emit_mask has written them)
+			ix_key_stamp = 0;
 			{ StageTimer t(this, stream, "index_radix_sort", M * 24); prim.sort_pairs_u32_u64(key.as<u32>(), key2.as<u32>(), rs.my.as<u64>(), pt.pos.as<u64>(), M, (unsigned)(2 * P.k)); }
 			LQ_LAUNCH(k_head_count<u32>, (u32)n_tiles, LQ_HEAD_THREADS, stream, key2.as<u32>(), M, head.as<u32>()); check_launch();
 		} else {
+			ix_key_stamp = 0;
 			LQ_LAUNCH(k_sort_keys<u64>, nblk(M, 256), 256, stream, rs.mx.as<u64>(), M, key.as<u64>()); check_launch();
 			{ StageTimer t(this, stream, "index_radix_sort", M * 32); prim.sort_pairs_u64(key.as<u64>(), key2.as<u64>(), rs.my.as<u64>(), pt.pos.as<u64>(), M, (unsigned)(2 * P.k)); }
 			LQ_LAUNCH(k_head_count<u64>, (u32)n_tiles, LQ_HEAD_THREADS, stream, key2.as<u64>(), M, head.as<u32>()); check_launch();
@@ -960,7 +990,7 @@ void lqcov_handle::sat_replay_part(Part &pt, const std::vector<u64> &h_aq, const
 		sat_rec.ensure(rec_cap * sizeof(SatRec)); sat_at.ensure(at_cap * 4 + 4);
 		dzero(sat_n.p, 16, L.stream);
 		const SatSink sink{sat_rec.as<SatRec>(), sat_n.as<unsigned long long>(), rec_cap, sat_at.as<u32>(), sat_n.as<unsigned long long>() + 1, at_cap};
-		L.n_segs.ensure(64); L.n_ivl.ensure(4); L.n_sens.ensure(4); L.want.ensure(8); L.ivl.ensure(sizeof(Ivl));
+		L.n_segs.ensure(64); L.n_ivl.ensure(4); L.n_sens.ensure(32); L.want.ensure(8); L.ivl.ensure(sizeof(Ivl));
 		map_subset(L, pt, std::vector<u32>{qi}, std::vector<u32>{len > LQ_RS_MIN ? 1u : 0u}, std::vector<u64>{0, len}, h_qmoff[qi + 1] - h_qmoff[qi], 0, 0, 0, false, &sink);
 		unsigned long long nn[2] = {0, 0};
 		d2h(nn, sat_n.as<unsigned long long>(), 2, L.stream);
@@ -1036,7 +1066,7 @@ void lqcov_handle::map_batch(MapLane &L, Part &pt, u32 q0, u32 q1, const std::ve
 	lq_tl("lane", lane_id, "batch begins, queries", (double)(q1 - q0));
 	L.gate_passed = false;
 	struct GateGuard { lqcov_handle *h; MapLane &L; ~GateGuard() { if (!L.gate_passed) { L.gate_passed = true; h->open_gate(); } } } gate_guard{this, L};
-	L.n_segs.ensure(64); L.n_ivl.ensure(4); L.n_sens.ensure(4); L.want.ensure(8);
+	L.n_segs.ensure(64); L.n_ivl.ensure(4); L.n_sens.ensure(32); L.want.ensure(8);
 	const bool opt = !K.ties_klib;
 	const std::vector<u64> &h_off = opt ? h_aqf : h_aq;
 	const u64 a_base = h_off[q0], nA = h_off[q1] - a_base;
@@ -1071,7 +1101,7 @@ void lqcov_handle::map_batch(MapLane &L, Part &pt, u32 q0, u32 q1, const std::ve
 	}
 	const u32 ivl_cap = (u32)std::min<u64>(nA / (P.min_cnt > 0 ? P.min_cnt : 1) + 16, 0xfffffff0ULL);
 	L.ivl.ensure((u64)ivl_cap * sizeof(Ivl));
-	dzero(L.n_ivl.p, 4, L.stream); dzero(L.n_sens.p, 4, L.stream);
+	dzero(L.n_ivl.p, 4, L.stream); dzero(L.n_sens.p, 32, L.stream);
 	if (nA) {
 		const u64 *aqb = (opt ? (L.use_aqf ? L.use_aqf : aqf_off.as<u64>()) : aq_off.as<u64>()) + q0;          // batch view of the per-query anchor offsets
 		const u32 *qkb = opt ? qzero.as<u32>() : qklib.as<u32>() + q0;               // (first pass: nobody goes through klib's passes)
@@ -1086,7 +1116,12 @@ void lqcov_handle::map_batch(MapLane &L, Part &pt, u32 q0, u32 q1, const std::ve
 		chain_stage(L, pt, aqb, a_base, nqb, q0, nullptr, nA, opt ? 1 : 0, 0, ivl_cap, dbg);
 	}
 	u32 n_sens = 0;
-	if (nA && opt) d2h(&n_sens, L.n_sens.as<u32>(), 1, L.stream);
+	if (nA && opt) {
+		u32 ns8[8] = {0};                                         // [0] listed runs, [1..6] by reason (lq_tie_list)
+		d2h(ns8, L.n_sens.as<u32>(), 8, L.stream);
+		n_sens = ns8[0];
+		for (int i = 1; i <= 6; ++i) stat_tie_why[i - 1] += ns8[i];
+	}
 	lq_tl("lane", lane_id, "first pass done, anchors", (double)nA);
 	if (n_sens) {
 		// ---- second pass: the queries that own a run in which klib's order can be observed ----
@@ -2193,6 +2228,7 @@ void lqcov_handle::build_part_from_host_minimizers(Part &pt, const std::vector<u
 {
 	ReadSetDev &rs = pt.rs;
 	const u64 n = x.size();
+	rs.key_stamp = 0;
 	rs.mx.ensure(n * 8 + 8); rs.my.ensure(n * 8 + 8);
 	h2d(rs.mx.as<u64>(), x.data(), n, stream);
 	h2d(rs.my.as<u64>(), y.data(), n, stream);

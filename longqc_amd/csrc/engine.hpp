@@ -27,6 +27,7 @@ struct StageAcc { double ms = 0; u64 launches = 0; u64 bytes = 0; };
 struct Knobs {
 	int lanes = 3;                        // LQCOV_LANES: concurrent mapping lanes (round 4, configs[2], ms per step: 2 lanes 908, 3: 888-922, 4: 964, 5: 995; round 3, every hit sorted: 1 lane 1882, 3: 1582, 5: 1510, 8: 1610)
 	u64 anchor_budget = 0;                // LQCOV_ANCHOR_BUDGET: anchors per query batch (0 = from free HBM)
+	bool query_order_length = false;      // LQCOV_QUERY_ORDER=length: longest first without dealing the queries to the lanes' stripes (rounds 1-5)
 	bool query_order_file = false;        // LQCOV_QUERY_ORDER=file: keep the caller's query order inside
 	bool all_klib = false;                // LQCOV_SORT=klib: every query through klib's passes, no bucket leaves them early
 	u32 ps_shift = 0;                     // LQCOV_PS_SHIFT: shrinks the size classes of the parallel sort (tests)
@@ -44,6 +45,9 @@ struct Knobs {
 	u32 walk_cu_mask = 0x11111111u;       // LQCOV_WALK_CU_MASK (hex, repeated over the 256 CUs): the CUs the walkers' streams may use
 	int chain_wave_min = 0, chain_cap = 128;   // LQCOV_CHAIN_WAVE_MIN (0 = LQ_CHAIN_WAVE_MIN), LQCOV_CHAIN_CAP
 	bool sketch_fast = true;              // LQCOV_SKETCH_FAST=0: k_sketch_dp_mask although k_sketch_dp_fast applies (-k 12 with -w 5 or 10; tests, A/B)
+	bool sketch_list = true;              // LQCOV_SKETCH_LIST=0: the state machine looks for the chunks the data-parallel kernel left in every wave of 64 consecutive chunks (rounds 3-5) instead of taking them from a list
+	bool sketch_key = true;               // LQCOV_SKETCH_KEY=0: the index sort's keys by k_sort_keys from x instead of by k_sketch_emit_mask
+	u32 emit_grid = 1u << 22;             // LQCOV_EMIT_GRID: blocks of k_sketch_emit_mask (a block strides over the groups of 32 chunks)
 	bool sketch_wgen = false;             // LQCOV_SKETCH_WGEN=1: k_sketch_dp_mask with the window read at run time although it is 5 or 10 (tests, A/B)
 	bool ps_key64 = false;                // LQCOV_PS_KEY64=1: the finishing kernels' 64-bit key shape although 32 bits would do (tests: parts with more than 2^40 (target, position) pairs are out of their reach)
 	u32 run_grid = 2048;                  // LQCOV_RUN_GRID: blocks of k_run_list, each with a contiguous stretch of tiles (tests: 1 or 2, so that a block walks many)
@@ -92,6 +96,7 @@ struct ReadSetDev {                       // a read set 2-bit packed in HBM, chu
 	DBuf mx, my, moff;                    // minimizers (x, y) in emission order + per-read offsets
 	u64 n_mini = 0;
 	bool sketched = false;
+	u64 key_stamp = 0;                    // not 0: the handle's ix_key held this set's sort keys when ix_key_stamp had the same value
 	u32 dp_n = 0; u64 dp_tiles = 0;       // add_reads_packed has already run k_sketch_dp_mask over the tiles of these reads (slice by slice, under the upload of the next slice)
 	u64 dp_gen = 0;                       // ... into the handle's mask buffers of that generation (lqcov_handle::sk_gen): another read set sketched since, and dp_n is void
 };
@@ -231,6 +236,7 @@ struct lqcov_handle {
 	DBuf sat_rec, sat_at, sat_n;
 	u64 stat_sat_chains = 0;
 	u64 last_n_written = 0;               // anchors the first pass wrote against the last part
+	std::atomic<u64> stat_tie_why[6] = {};   // listed runs by the first reason that listed them (lq_tie_list: skip pending, member counts as a skip, top score twice, scan broke off, peak tie, other), since reset()
 	std::atomic<u64> stat_sens_runs{0}, stat_p2_queries{0}, stat_p2_anchors{0};   // second pass, since reset(): runs, queries, anchors
 	u32 run_n_min() const { const i32 span_max = P.hpc ? 255 : P.k; return (u32)std::max<i32>(std::max<i32>(P.min_cnt, 1), (mp.min_sc + span_max - 1) / span_max); }   // anchors a run needs to hold a chain (k_run_list)
 	// counter layout: normally the query minimizer offsets; after adopt_index_params() (prebuilt index with other -k/-w/-H)
@@ -253,6 +259,8 @@ struct lqcov_handle {
 	DBuf misc;
 	DBuf ix_key, ix_key2, ix_head, ix_uidx, ix_ukey, ix_ustart, ix_ucnt, ix_sorted;   // build_index workspaces
 	const Part *ix_owner = nullptr;       // the part ix_ukey / ix_ustart / ix_ucnt describe (dump_part reads them)
+	u64 ix_key_stamp = 0, ix_key_seq = 0; // ix_key holds the sort keys of the read set with this stamp (written by k_sketch_emit_mask with its x and y)
+	DBuf sk_ulist;                        // sketch: the chunks the data-parallel kernel left to the machine + their count
 	DBuf sk_cnt, sk_off, sk_owned, sk_mask, sk_flag, sk_toff, sk_trid, sk_grid;   // sketch: per-chunk minimizer counts / offsets, which kernel decides a chunk, emitted positions (a bit per base), tile offsets
 	std::vector<u64> sk_h_toff;           // tiles of k_sketch_dp_mask before every read (host copy of sk_toff)
 	const ReadSetDev *sk_owner = nullptr; u64 sk_gen = 0;   // whose reads the sk_* buffers describe right now (sketch_dp_setup): a read set's dp_n counts only while they are its own

@@ -294,8 +294,14 @@ __device__ __forceinline__ bool lq_tie_wanted(const CovState &C, u32 q, u32 hi)
 	while (lo < n) { const u32 mid = lo + ((n - lo) >> 1); if (C.want[mid] < key) lo = mid + 1; else n = mid; }
 	return lo < C.n_want && C.want[lo] == key;
 }
-__device__ __forceinline__ void lq_tie_list(const CovState &C, u32 q, u32 hi)
+// why: 1 a skip was pending when the group began, 2 a member of the group counts as a skip, 3 the group's top score is reached twice,
+// 4 the scan broke off before a tie partner that would have raised the best score, 5 two equal-x peaks of one score in the backtrack
+// order (chain.c:102-108); n_sens[why] counts the listed runs by their first reason (bench.py: klib_order.reasons)
+#define LQ_TIE_WHY_BREAK 4u
+#define LQ_TIE_WHY_PEAK 5u
+__device__ __forceinline__ void lq_tie_list(const CovState &C, u32 q, u32 hi, u32 why)
 {
+	atomicAdd(C.n_sens + (why >= 1u && why <= 5u ? why : 6u), 1u);
 	const u32 s = atomicAdd(C.n_sens, 1u);
 	if (s < C.sens_cap) C.sens[s] = (unsigned long long)q << 32 | hi;
 }
@@ -383,12 +389,13 @@ struct TieGroup {
 	u32 x; i32 m, top;
 	u32 st;                    // bit0: open, bit1: no skip pending at its start, bit2: a member counts as a skip, bit3: the top score reached twice, bit4: a member raises the best score, bits 5..: loud members
 	__device__ __forceinline__ bool bad() const { return (st & 1u) && (st & 16u) && (st >> 5) >= 2u && (!(st & 2u) || (st & 12u)); }
+	__device__ __forceinline__ u32 why() const { return !bad() ? 0u : !(st & 2u) ? 1u : (st & 4u) ? 2u : 3u; }   // (lq_tie_list)
 	__device__ __forceinline__ bool raises(i32 sc) const { return sc > m; }
-	// candidate (low word of x, score, counts as a skip) meets the scan's state (max_f, n_skip) as it is before it; true: the group that closes here was order-dependent
-	__device__ __forceinline__ bool see(u32 xj, i32 sc, bool tmark, i32 max_f, i32 n_skip)
+	// candidate (low word of x, score, counts as a skip) meets the scan's state (max_f, n_skip) as it is before it; not 0: the group that closes here was order-dependent (why())
+	__device__ __forceinline__ u32 see(u32 xj, i32 sc, bool tmark, i32 max_f, i32 n_skip)
 	{
-		bool r = false;
-		if (!((st & 1u) && xj == x)) { r = bad(); x = xj; m = max_f; top = (i32)0x80000000; st = 1u | (n_skip == 0 ? 2u : 0u); }
+		u32 r = 0;
+		if (!((st & 1u) && xj == x)) { r = why(); x = xj; m = max_f; top = (i32)0x80000000; st = 1u | (n_skip == 0 ? 2u : 0u); }
 		if (!(sc <= m && !tmark)) {
 			st += 32u;
 			if (sc > m) st |= 16u;
@@ -400,9 +407,9 @@ struct TieGroup {
 };
 
 // mm_chain_dp, first half (chain.c:41-81): scores f, predecessors p, peak scores v of one run, serially.
-// Returns true when the scores may depend on the order of equal-x anchors (watch_ties only; TieGroup above).
+// Returns why (not 0) when the scores may depend on the order of equal-x anchors (watch_ties only; TieGroup above, lq_tie_list).
 template <class AP, class IP>
-__device__ __forceinline__ bool lq_chain_fill(AP a, const i64 n, IP f, IP p, IP t, IP v, const float avg_qspan, const MapParams &P, const bool watch_ties)
+__device__ __forceinline__ u32 lq_chain_fill(AP a, const i64 n, IP f, IP p, IP t, IP v, const float avg_qspan, const MapParams &P, const bool watch_ties)
 {
 	const i32 max_dist = P.max_gap, bw = P.bw, max_skip = P.max_skip;
 	i64 st = 0;
@@ -435,7 +442,7 @@ __device__ __forceinline__ bool lq_chain_fill(AP a, const i64 n, IP f, IP p, IP 
 						sc -= (i32)((double)dd * .01 * (double)avg_qspan) + (log_dd >> 1);     // chain.c:67
 						sc += f[j];
 						bool brk = false;
-						if (watch_ties && tg.see((u32)a[j].x, sc, t[j] == (i32)i, max_f, n_skip)) return true;   // (the run is listed, not chained: nothing it would compute from here on is used)
+						if (watch_ties) { const u32 why = tg.see((u32)a[j].x, sc, t[j] == (i32)i, max_f, n_skip); if (why) return why; }   // (the run is listed, not chained: nothing it would compute from here on is used)
 						if (sc > max_f) {
 							max_f = sc; max_j = j;
 							if (n_skip > 0) --n_skip;
@@ -451,7 +458,7 @@ __device__ __forceinline__ bool lq_chain_fill(AP a, const i64 n, IP f, IP p, IP 
 									if (dd2 > bw) continue;
 									const i32 md2 = dq2 < dr ? dq2 : (i32)dr;
 									const i32 sc2 = (md2 > q_span ? q_span : md2) - ((i32)((double)dd2 * .01 * (double)avg_qspan) + ((dd2 ? lq_ilog2_32((u32)dd2) : 0) >> 1)) + f[jj];
-									if (tg.raises(sc2)) return true;
+									if (tg.raises(sc2)) return LQ_TIE_WHY_BREAK;
 								}
 							j = st;                                                   // leave the candidate loop
 						}
@@ -460,14 +467,14 @@ __device__ __forceinline__ bool lq_chain_fill(AP a, const i64 n, IP f, IP p, IP 
 				}
 				--j;
 			} else {
-				if (watch_ties && tg.bad()) return true;                          // the scan's last group
+				if (watch_ties && tg.bad()) return tg.why();                      // the scan's last group
 				f[i] = max_f; p[i] = (i32)max_j;
 				v[i] = max_j >= 0 && v[max_j] > max_f ? v[max_j] : max_f;
 				++i; setup = true;
 			}
 		}
 	}
-	return band_tie;
+	return band_tie ? 1u : 0u;
 }
 
 // mm_chain_dp, second half (chain.c:84-137) + mm_reg_set_coor (hit.c:23-38) + lq_cnt_match (esterr.c:99-138)
@@ -618,8 +625,9 @@ __device__ __forceinline__ void lq_chain_run(AP a, const i64 n, IP f, IP p, IP t
                                              const u32 q, const bool accumulate, const float *avg_qspan_q, const MapParams &P, const CovState &C)
 {
 	const bool watch = C.tie_mode == 1;
-	if (lq_chain_fill(a, n, f, p, t, v, avg_qspan_q[q], P, watch) || lq_chain_finish(a, n, f, p, t, v, u, q, accumulate, P, C, watch))
-		lq_tie_list(C, q, (u32)(a[0].x >> 32));              // the order of its equal-x anchors can be observed: left to the second pass
+	u32 why = lq_chain_fill(a, n, f, p, t, v, avg_qspan_q[q], P, watch);
+	if (!why && lq_chain_finish(a, n, f, p, t, v, u, q, accumulate, P, C, watch)) why = LQ_TIE_WHY_PEAK;
+	if (why) lq_tie_list(C, q, (u32)(a[0].x >> 32), why);   // the order of its equal-x anchors can be observed: left to the second pass
 }
 
 // does the run have any chance to yield a chain?  A chain of c anchors scores at most the sum of their spans
@@ -918,20 +926,20 @@ __device__ __forceinline__ void lq_wave_replay(const WaveCand *cand, i32 *st_sh,
 	for (i64 c = 0; c < cnt; ++c) {
 		const WaveCand w = cand[c];
 		if (!(w.flags & 1)) continue;
-		if (watch && tg.see(w.x32, w.sc, (w.flags & 2) != 0, max_f, n_skip)) st_sh[4] = 1;   // (TieGroup, above lq_chain_fill)
+		if (watch) { const u32 why = tg.see(w.x32, w.sc, (w.flags & 2) != 0, max_f, n_skip); if (why && !st_sh[4]) st_sh[4] = (i32)why; }   // (TieGroup, above lq_chain_fill)
 		if (w.sc > max_f) { max_f = w.sc; max_j = w.j; if (n_skip > 0) --n_skip; }
 		else if (w.flags & 2) {
 			if (++n_skip > max_skip) {                                                  // chain.c:72-73
 				if (watch) {	// tie partners the scan no longer reaches (if they go on into the next 64: assume the worst)
 					i64 c2 = c + 1;
-					for (; c2 < cnt && cand[c2].x32 == w.x32; ++c2) if ((cand[c2].flags & 1) && tg.raises(cand[c2].sc)) st_sh[4] = 1;
-					if (c2 == cnt && more_beyond) st_sh[4] = 1;
+					for (; c2 < cnt && cand[c2].x32 == w.x32; ++c2) if ((cand[c2].flags & 1) && tg.raises(cand[c2].sc) && !st_sh[4]) st_sh[4] = (i32)LQ_TIE_WHY_BREAK;
+					if (c2 == cnt && more_beyond && !st_sh[4]) st_sh[4] = (i32)LQ_TIE_WHY_BREAK;
 				}
 				done = 1; break;
 			}
 		}
 	}
-	if (watch && (done || !more_beyond) && tg.bad()) st_sh[4] = 1;                     // the scan's last group
+	if (watch && (done || !more_beyond) && tg.bad() && !st_sh[4]) st_sh[4] = (i32)tg.why();   // the scan's last group
 	st_sh[0] = max_f; st_sh[1] = max_j; st_sh[2] = n_skip; st_sh[3] = done;
 	st_sh[5] = (i32)tg.x; st_sh[6] = tg.m; st_sh[7] = tg.top; st_sh[8] = (i32)tg.st;
 }
@@ -1122,7 +1130,7 @@ k_chain_wave(const mm128 *A, const u64 *gstart, const u32 *glist, u32 n_list, co
 		return;
 	}
 	const bool peak_tie = !listed && lq_chain_finish_wave(a, n, f, p, t, v, u, q, accumulate, P, C, watch, st_sh);
-	if (ln == 0 && (listed || peak_tie)) lq_tie_list(C, q, lq_hi32(a));
+	if (ln == 0 && (listed || peak_tie)) lq_tie_list(C, q, lq_hi32(a), listed ? (u32)st_sh[4] : LQ_TIE_WHY_PEAK);
 }
 
 // ---- filter_redundant_coords (lqmap.c:25-100), one thread per query, on this part's intervals ----

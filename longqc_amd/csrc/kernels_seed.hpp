@@ -98,6 +98,17 @@ __device__ __forceinline__ u32 sd_owner(const u32 *off, u32 n, u32 g)
 	return lo;
 }
 
+// The owners of 64 consecutive hits, from the owner `ow` of a hit at or before the first of them (wave-uniform): a lane steps over
+// the list ends between that hit and its own -- a step of 64 hits rarely touches more than two lists, where the binary search
+// above is eight dependent LDS reads per hit (round 6: ~40 % of k_seed_count's instructions).  loff[n] = the segment's hits > g.
+__device__ __forceinline__ u32 sd_owner_from(const u32 *off, u32 ow, u32 g, bool valid)
+{
+	u32 o = ow;
+	if (valid) while (off[o + 1] <= g) ++o;
+	return o;
+}
+#define LQ_SD_WAVE_HITS (LQ_SD_RPT * 64u)                   // a wave's hits of a tile: consecutive, 64 per step
+
 // One step of a wave over 64 consecutive hits of the segment (valid lanes are a prefix): counts them per slice in the wave's
 // own 16-bit counter (two waves to a word: hist[d * LQ_SD_WAVES / 2 + wave / 2]; a tile holds fewer than 65536 hits) and returns
 // every hit's rank among the wave's hits of its slice so far.  Hits of one list ascend in rid, so inside a list a slice is one
@@ -177,18 +188,23 @@ k_seed_count(SeedIn in, u32 g_lo, u32 *cnt)
 	}
 	for (u32 i = t; i < Q.nsl; i += LQ_SD_THREADS) hist[i] = 0;
 	__syncthreads();
+	const u32 wave = t >> 6;
 	for (u32 base = 0; base < nH; base += LQ_SD_TILE) {
 		u64 r[LQ_SD_RPT];
+		const u32 gw = base + wave * LQ_SD_WAVE_HITS;            // the wave's first hit of the tile
+		u32 ow = sd_owner(loff, nj, gw < nH ? gw : nH - 1u);     // (wave-uniform)
 #pragma unroll
 		for (int k = 0; k < LQ_SD_RPT; ++k) {
-			const u32 g = base + (u32)k * LQ_SD_THREADS + t;
+			const u32 g = gw + (u32)k * 64u + lane;
+			const u32 o = sd_owner_from(loff, ow, g, g < nH);
 			r[k] = 0;
-			if (g < nH) r[k] = in.pos[la[sd_owner(loff, nj, g)] + g];
+			if (g < nH) r[k] = in.pos[la[o] + g];
+			ow = (u32)__shfl((int)o, 63);
 		}
 #pragma unroll
 		for (int k = 0; k < LQ_SD_RPT; ++k) {
-			const u32 g = base + (u32)k * LQ_SD_THREADS + t;
-			if (base + (u32)k * LQ_SD_THREADS + (t & ~63u) < nH)                      // (wave-uniform)
+			const u32 g = gw + (u32)k * 64u + lane;
+			if (gw + (u32)k * 64u < nH)                              // (wave-uniform)
 				sd_count_step(hist, sd_slice((u32)(r[k] >> 32), Q.mul), g < nH, lane);
 		}
 	}
@@ -229,15 +245,18 @@ k_seed_scatter(SeedIn in, u32 g_lo, const u32 *off, SeedBits bits, u32 span_cons
 		for (u32 i = t; i < nE; i += LQ_SD_THREADS) hist[i] = 0;
 		__syncthreads();
 		u64 rc[LQ_SD_RPT]; u32 jl[LQ_SD_RPT], rk[LQ_SD_RPT];
+		const u32 gw = base + wave * LQ_SD_WAVE_HITS;            // the wave's first hit of the tile: a wave takes consecutive hits, 64 per step
+		u32 ow = sd_owner(loff, nj, gw < nH ? gw : nH - 1u);     // (wave-uniform)
 #pragma unroll
 		for (int k = 0; k < LQ_SD_RPT; ++k) {                    // owners, then every load in flight
-			const u32 g = base + (u32)k * LQ_SD_THREADS + t;
-			jl[k] = 0; rc[k] = 0;
-			if (g < nH) { jl[k] = sd_owner(loff, nj, g); rc[k] = in.pos[la[jl[k]] + g]; }
+			const u32 g = gw + (u32)k * 64u + lane;
+			jl[k] = sd_owner_from(loff, ow, g, g < nH); rc[k] = 0;
+			if (g < nH) rc[k] = in.pos[la[jl[k]] + g];
+			ow = (u32)__shfl((int)jl[k], 63);
 		}
 #pragma unroll
 		for (int k = 0; k < LQ_SD_RPT; ++k) {
-			const u32 g = base + (u32)k * LQ_SD_THREADS + t;
+			const u32 g = gw + (u32)k * 64u + lane;
 			const bool valid = g < nH;
 			u32 d = 0;
 			if (valid) {
@@ -251,7 +270,7 @@ k_seed_scatter(SeedIn in, u32 g_lo, const u32 *off, SeedBits bits, u32 span_cons
 				rc[k] = (u64)rid << (bits.jb + bits.db + 1) | (u64)rs << (bits.jb + bits.db) | (u64)diag << bits.jb | (u64)(jrel + jl[k]);
 			}
 			rk[k] = 0;
-			if (base + (u32)k * LQ_SD_THREADS + (t & ~63u) < nH) rk[k] = sd_rank_step(hist, wave, d, jl[k], valid, lane);
+			if (gw + (u32)k * 64u < nH) rk[k] = sd_rank_step(hist, wave, d, jl[k], valid, lane);
 			jl[k] = d;                                             // (from here on: the hit's slice)
 		}
 		__syncthreads();
@@ -269,7 +288,7 @@ k_seed_scatter(SeedIn in, u32 g_lo, const u32 *off, SeedBits bits, u32 span_cons
 		__syncthreads();
 #pragma unroll
 		for (int k = 0; k < LQ_SD_RPT; ++k) {
-			const u32 g = base + (u32)k * LQ_SD_THREADS + t;
+			const u32 g = gw + (u32)k * 64u + lane;
 			if (g < nH) sbuf[(hist[jl[k] * (LQ_SD_WAVES / 2) + (wave >> 1)] >> ((wave & 1u) << 4) & 0xffffu) + rk[k]] = rc[k];
 		}
 		__syncthreads();

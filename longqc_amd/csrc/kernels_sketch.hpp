@@ -261,7 +261,8 @@ __device__ __forceinline__ void sk_warm(SkState<STRIDE> &s, ReadView &rv, const 
 #define LQ_SK_BLOCK 256
 template <int RCAP, int EMIT, bool HPC>
 __global__ void k_sketch(const u64 *codes, const u32 *amb, const u64 *coff, const u32 *rlen, u32 n_reads, u64 n_chunks, u32 kpt,
-                         SkParams P, int rid_in_y, u32 *cnt, const u64 *off, u64 *out_x, u64 *out_y, const u8 *dp_owned, u32 *mask, u32 *dup_flag)
+                         SkParams P, int rid_in_y, u32 *cnt, const u64 *off, u64 *out_x, u64 *out_y, const u8 *dp_owned, u32 *mask, u32 *dup_flag,
+                         const u32 *list, const u32 *n_list)
 {
 	constexpr int STRIDE = RCAP <= 16 ? LQ_SK_BLOCK : 1;
 	__shared__ u64 s_rx[RCAP <= 16 ? RCAP : 1][LQ_SK_BLOCK];
@@ -272,17 +273,23 @@ __global__ void k_sketch(const u64 *codes, const u32 *amb, const u64 *coff, cons
 	i32 p_rq[RCAP <= 16 ? 1 : 32];
 	// A thread owns kpt consecutive chunks.  The machine's state carries over from one chunk to the next of the same read
 	// (the next chunk's first iteration is the one the machine stands at), so the halo is walked once per kpt chunks.
-	const u64 g0 = ((u64)blockIdx.x * blockDim.x + threadIdx.x) * kpt;
-	if (g0 >= n_chunks) return;
+	// With a list (mask mode beside the data-parallel kernel: the chunks that kernel left, k_sketch_unowned): one listed chunk per
+	// turn of a thread -- every lane of a wave has a chunk to decide.  (Without it a wave of 64 consecutive chunks held one or two
+	// of them, the first chunk of a read and little else: 6.9 ms per 4 Gbases for 1.2 % of the chunks.)
+	const u64 tid = (u64)blockIdx.x * blockDim.x + threadIdx.x, n_thr = (u64)gridDim.x * blockDim.x;
+	const u64 n_items = list ? (u64)*n_list : (n_chunks + kpt - 1) / kpt;
 	SkState<STRIDE> s;
 	if (RCAP <= 16) { s.rx = &s_rx[0][threadIdx.x]; s.ry = &s_ry[0][threadIdx.x]; s.rq = &s_rq[0][threadIdx.x]; }
 	else { s.rx = p_rx; s.ry = p_ry; s.rq = p_rq; }
+	ReadView rv;
+	for (u64 item = tid; item < n_items; item += n_thr) {
+	const u64 g0 = list ? (u64)list[item] : item * kpt;
+	const u32 span = list ? 1u : kpt;
 	bool have = false;                                         // s is the machine's state before the iteration that starts at i_next of read r_prev
 	u32 r_prev = 0, i_next = 0;
-	ReadView rv;
-	for (u32 cc = 0; cc < kpt && g0 + cc < n_chunks; ++cc) {
+	for (u32 cc = 0; cc < span && g0 + cc < n_chunks; ++cc) {
 		const u64 g = g0 + cc;
-		if (dp_owned && dp_owned[g]) { have = false; continue; }   // k_sketch_dp decides this chunk
+		if (!list && dp_owned && dp_owned[g]) { have = false; continue; }   // k_sketch_dp decides this chunk
 		u32 r;
 		if (have && g < coff[r_prev + 1]) r = r_prev;
 		else { r = lq_find_seg(coff, n_reads, g); have = false; rv.init(codes + coff[r] * LQ_CHUNK_WORDS, amb + coff[r] * LQ_CHUNK_WORDS, rlen[r]); }
@@ -315,6 +322,21 @@ __global__ void k_sketch(const u64 *codes, const u32 *amb, const u64 *coff, cons
 			for (int j = 0; j < 4; ++j) if (w4[j] && (atomicOr(&mw[j], w4[j]) & w4[j])) atomicOr(dup_flag, 1u);
 		}
 	}
+	}
+}
+
+// the chunks k_sketch_dp_mask / k_sketch_dp_fast left to the machine, as a list (in no particular order: what the machine decides are bits of a mask)
+__global__ void k_sketch_unowned(const u8 *owned, u64 n_chunks, u32 *list, u32 *n_list)
+{
+	const u64 g = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+	const bool un = g < n_chunks && !owned[g];
+	const u64 b = __ballot(un);
+	if (!b) return;                                            // (uniform)
+	const u32 lane = threadIdx.x & 63, lead = (u32)__ffsll((unsigned long long)b) - 1;
+	u32 base = 0;
+	if (lane == lead) base = atomicAdd(n_list, (u32)__popcll(b));
+	base = __shfl(base, (int)lead);
+	if (un) list[base + (u32)__popcll(b & ((1ULL << lane) - 1))] = (u32)g;
 }
 
 // ---- the same list, decided data-parallel where the machine is memoryless ------------------------------------------
@@ -360,7 +382,7 @@ __device__ __forceinline__ void lq_window32(const u64 *cw, const u32 *aw, u32 lo
 // read of every tile of k_sketch_dp_mask and of the first chunk of every group of LQ_EM_CH chunks of k_sketch_emit_mask: one
 // thread per read fills the entries of its tiles / of the groups that start inside it.  (A block that looks its read up by
 // binary search spends ~20 dependent loads -- longer than the rest of its work -- before it can touch a base.)
-#define LQ_EM_CH 8
+#define LQ_EM_CH 32
 __global__ void k_sketch_owners(const u64 *coff, const u64 *toff, u32 n_reads, u32 *tile_rid, u32 *group_rid)
 {
 	const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
@@ -683,38 +705,43 @@ __global__ void k_mask_count(const u32 *mask, u64 n_chunks, u32 *cnt)
 // thread per list entry rebuilds the k-mer from the packed codes, hashes it and writes x and y at offset + rank: all lanes
 // busy with a hash, the 16-byte outputs contiguous.
 #define LQ_EM_THREADS 256
+#define LQ_EM_WORDS (LQ_EM_CH * LQ_CHUNK_WORDS)                // mask words of a group: at most one per thread of the first half of the block
 __global__ void __launch_bounds__(LQ_EM_THREADS)
 k_sketch_emit_mask(const u64 *codes, const u32 *amb, const u64 *coff, const u32 *group_rid, u32 n_reads, u64 n_chunks, SkParams P, int rid_in_y,
-                   const u32 *mask, const u64 *off, u64 *out_x, u64 *out_y)
+                   const u32 *mask, const u64 *off, u64 *out_x, u64 *out_y, u32 *out_key /* not null: the hash alone as well (k <= 16: the index sort's key) */)
 {
+	static_assert(LQ_EM_WORDS <= LQ_EM_THREADS / 2 && LQ_EM_WORDS % 64 == 0 && LQ_EM_CH <= LQ_EM_THREADS / 2, "one mask word per thread of the block's first waves");
 	__shared__ u16 lpos[LQ_EM_CH * LQ_CHUNK];
-	__shared__ u32 woff[LQ_EM_CH * LQ_CHUNK_WORDS + 1], wbits[LQ_EM_CH * LQ_CHUNK_WORDS], rid[LQ_EM_CH];
+	__shared__ u32 woff[LQ_EM_WORDS], wbits[LQ_EM_WORDS], wtot[LQ_EM_WORDS / 64], rid[LQ_EM_CH];
 	const u32 t = threadIdx.x;
 	const i32 k = P.k;
 	for (u64 g0 = (u64)blockIdx.x * LQ_EM_CH; g0 < n_chunks; g0 += (u64)gridDim.x * LQ_EM_CH) {
 		const u32 n_ch = (u32)(n_chunks - g0 < LQ_EM_CH ? n_chunks - g0 : LQ_EM_CH);
 		const u32 n_w = n_ch * LQ_CHUNK_WORDS;
-		if (t < 64) {                                            // the first wave: mask words and their exclusive bit counts
+		if (t < LQ_EM_WORDS) {                                    // the first waves: mask words and their exclusive bit counts (inside the wave)
 			const u32 v = t < n_w ? mask[g0 * LQ_CHUNK_WORDS + t] : 0;
 			const u32 c = (u32)__popc(v);
-			u32 inc = c;
-			for (int d = 1; d < 64; d <<= 1) { const u32 o = __shfl_up(inc, d); if ((int)t >= d) inc += o; }
-			if (t < LQ_EM_CH * LQ_CHUNK_WORDS) { wbits[t] = v; woff[t] = inc - c; }
-			if (t == LQ_EM_CH * LQ_CHUNK_WORDS - 1) woff[LQ_EM_CH * LQ_CHUNK_WORDS] = inc;
-			if (t < n_ch) {                                         // the group's first chunk is in read group_rid[..]; the others a few reads on at most
-				u32 r = group_rid[g0 / LQ_EM_CH];
-				while (g0 + t >= coff[r + 1]) ++r;
-				rid[t] = r;
-			}
+			const u32 inc = lq_wave_scan_add(c);
+			wbits[t] = v; woff[t] = inc - c;
+			if ((t & 63) == 63) wtot[t >> 6] = inc;
+		} else if (t - LQ_EM_WORDS < n_ch) {                      // the group's first chunk is in read group_rid[..]; the others a few reads on at most
+			const u32 c = t - LQ_EM_WORDS;
+			u32 r = group_rid[g0 / LQ_EM_CH];
+			while (g0 + c >= coff[r + 1]) ++r;
+			rid[c] = r;
 		}
 		__syncthreads();
-		const u32 n = woff[LQ_EM_CH * LQ_CHUNK_WORDS];
+		u32 n = 0, wbase[LQ_EM_WORDS / 64];
+#pragma unroll
+		for (u32 q = 0; q < LQ_EM_WORDS / 64; ++q) { wbase[q] = n; n += wtot[q]; }
 		for (u32 q = t; q < n_w * 8; q += LQ_EM_THREADS) {          // four positions (a nibble of a mask word) per turn
 			const u32 wi = q >> 3, nb = (q & 7) * 4;
 			const u32 v = wbits[wi];
 			u32 nib = (v >> nb) & 15u;
 			if (nib) {
 				u32 rk = woff[wi] + (u32)__popc(v & ((1u << nb) - 1));
+#pragma unroll
+				for (u32 q2 = 0; q2 < LQ_EM_WORDS / 64; ++q2) if ((wi >> 6) == q2) rk += wbase[q2];
 				for (; nib; nib &= nib - 1) lpos[rk++] = (u16)(wi * 32 + nb + (u32)__builtin_ctz(nib));
 			}
 		}
@@ -723,16 +750,19 @@ k_sketch_emit_mask(const u64 *codes, const u32 *amb, const u64 *coff, const u32 
 		for (u32 j = t; j < n; j += LQ_EM_THREADS) {
 			const u32 pi = lpos[j], ch = pi >> 7;
 			const u32 r = rid[ch];
-			const u32 pos = (u32)(g0 + ch - coff[r]) * LQ_CHUNK + (pi & (LQ_CHUNK - 1));
+			const u64 c0 = coff[r];
+			const u32 pos = (u32)(g0 + ch - c0) * LQ_CHUNK + (pi & (LQ_CHUNK - 1));
 			u64 raw; u32 am;
-			lq_window32(codes + coff[r] * LQ_CHUNK_WORDS, amb + coff[r] * LQ_CHUNK_WORDS, pos - (u32)k + 1, raw, am);
+			lq_window32(codes + c0 * LQ_CHUNK_WORDS, amb + c0 * LQ_CHUNK_WORDS, pos - (u32)k + 1, raw, am);
 			raw &= P.mask;
 			const u64 rv = ~raw & P.mask;
 			const u64 fw = lq_rev2(raw) >> (64 - 2 * k);
 			const u32 z = fw < rv ? 0u : 1u;
 			const u64 km = z ? rv : fw;
-			out_x[o0 + j] = (k <= 16 ? (u64)lq_hash<u32>((u32)km, (u32)P.mask) : lq_hash<u64>(km, P.mask)) << 8 | (u64)k;
+			const u64 hv = k <= 16 ? (u64)lq_hash<u32>((u32)km, (u32)P.mask) : lq_hash<u64>(km, P.mask);
+			out_x[o0 + j] = hv << 8 | (u64)k;
 			out_y[o0 + j] = (rid_in_y ? (u64)r << 32 : 0) | (u64)(pos << 1 | z);
+			if (out_key) out_key[o0 + j] = (u32)hv;
 		}
 		__syncthreads();
 	}

@@ -14,7 +14,7 @@ def main():
         f = line.rstrip("\n").split(",")
         rows.append((f[0].replace("void ", ""), int(f[1]), int(f[2]), int(f[3]), int(f[4])))
     rows.sort(key=lambda r: r[2])
-    dp = [r for r in rows if r[0].startswith("k_sketch_dp_mask")]
+    dp = [r for r in rows if r[0].startswith("k_sketch_dp")]
     big = max(r[4] for r in dp)
     firsts = [r[2] for r in dp if r[4] == big]
     t0 = firsts[-k] - 30_000_000
