@@ -38,6 +38,9 @@ def run_sdust(fin: str, fout: str, device: int = 0, w: Optional[int] = None, t: 
     msg = open(err).read() if os.path.exists(err) else ""
     if os.path.exists(err):
         os.remove(err)
+    if rc == 0 and msg and os.environ.get("LQCOV_TIMING"):
+        import sys
+        sys.stderr.write(msg)
     if rc != 0:
         raise api.LqcovError(rc if rc < 0 else -2, msg.strip() or "sdust failed")
 
