@@ -147,11 +147,16 @@ void *lqcov_host_alloc(size_t bytes);
 void  lqcov_host_free(void *p);
 int lqcov_part_add_packed(lqcov_handle *h, int part, uint32_t n, const uint64_t *codes, const uint32_t *amb, const uint32_t *lens,
                           const char *names, const uint64_t *name_off);
+/* amb == NULL in lqcov_part_add_packed: none of the n reads holds an ambiguous base -- only `codes` crosses PCIe (0.25 B per base) and the
+ * device makes the bits beyond the reads' ends itself.  lqcov_packed_ambiguous_reads says which reads of a packed set do hold one
+ * (flags[i] = 1: a bit of `amb` below read i's length is set), so that a caller can tell for any range of reads.  (seq_nt4_table,
+ * sketch.c:8-25: an ambiguous base resets mm_sketch's k-mer, sketch.c:114.) */
+int lqcov_packed_ambiguous_reads(uint32_t n, const uint32_t *amb, const uint32_t *lens, uint8_t *flags);
 /* The same reads from DEVICE memory, in shares: share i (share_chunks[i] 128-base chunks, a whole number of reads) starts at chunk
  * i * stride_chunks of codes_dev (4 x u64 per chunk) / amb_dev (4 x u32 per chunk); the shares are copied back to back in
  * share order = read order.  For a host that received the packed reads of a part from its peers (the query-sharded multi-GPU
  * split all-gathers 0.375 B per base over RCCL instead of 16 B per minimizer): lens / names describe every read of the part.
- * No counterpart in the reference (its parts come from one file, bseq.c:68-102). */
+ * amb_dev == NULL: as amb == NULL above.  No counterpart in the reference (its parts come from one file, bseq.c:68-102). */
 int lqcov_part_add_packed_shares_dev(lqcov_handle *h, int part, const uint64_t *codes_dev, const uint32_t *amb_dev, uint64_t stride_chunks,
                                      uint32_t n_shares, const uint64_t *share_chunks, uint32_t n, const uint32_t *lens,
                                      const char *names, const uint64_t *name_off);

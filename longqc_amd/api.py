@@ -113,6 +113,7 @@ def load_library(path: Optional[str] = None):
         "lqcov_part_n_keys": (C.c_uint64, [H, C.c_int]),
         "lqcov_last_n_anchors": (C.c_uint64, [H]),
         "lqcov_map_stats": (None, [H, u64p]),
+        "lqcov_packed_ambiguous_reads": (C.c_int, [C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
         "lqcov_tie_reasons": (None, [H, u64p]),
         "lqcov_fastx_digest": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_uint64, u64p]),
         "lqcov_get_query_minimizers": (C.c_int, [H, C.c_void_p, C.c_void_p, u64p]),
@@ -228,6 +229,15 @@ class PackedReads:
         if rc:
             raise LqcovError(rc, "lqcov_pack_reads failed")
         self.names_blob, self.name_off = _names(names)
+        # which reads hold an ambiguous base: a range without one is uploaded as codes alone (lqcov_part_add_packed with amb == NULL)
+        self.has_amb = np.zeros(max(n, 1), dtype=np.uint8)
+        rc = self.lib.lqcov_packed_ambiguous_reads(n, self.amb_ptr, self.lens.ctypes.data, self.has_amb.ctypes.data)
+        if rc:
+            raise LqcovError(rc, "lqcov_packed_ambiguous_reads failed")
+        self.cum_amb = np.concatenate([[0], np.cumsum(self.has_amb[:n], dtype=np.int64)])
+
+    def any_ambiguous(self, lo: int, hi: int) -> bool:
+        return bool(self.cum_amb[hi] - self.cum_amb[lo])
 
     def __len__(self):
         return self.n
@@ -297,7 +307,8 @@ class Engine:
         lens = np.ascontiguousarray(packed.lens[lo:hi])
         noff = np.ascontiguousarray(packed.name_off[lo:hi + 1] - packed.name_off[lo])
         blob = packed.names_blob[int(packed.name_off[lo]):int(packed.name_off[hi])]
-        self._ck(self.lib.lqcov_part_add_packed(self.h, part, hi - lo, packed.codes_ptr + c0 * 32, packed.amb_ptr + c0 * 16,
+        send_amb = packed.any_ambiguous(lo, hi) or os.environ.get("LQCOV_UPLOAD_AMB") == "1"     # (no N in these reads: 0.25 instead of 0.375 B per base cross PCIe)
+        self._ck(self.lib.lqcov_part_add_packed(self.h, part, hi - lo, packed.codes_ptr + c0 * 32, (packed.amb_ptr + c0 * 16) if send_amb else None,
                                                 lens.ctypes.data, blob, noff.ctypes.data))
 
     def part_add_packed_shares_dev(self, part: int, codes_ptr: int, amb_ptr: int, stride_chunks: int, share_chunks, lens: np.ndarray, names: Sequence[str]):

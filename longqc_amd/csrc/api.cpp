@@ -313,11 +313,19 @@ void *lqcov_host_alloc(size_t bytes)
 }
 void lqcov_host_free(void *p) { if (p) hipHostFree(p); }
 
+int lqcov_packed_ambiguous_reads(uint32_t n, const uint32_t *amb, const uint32_t *lens, uint8_t *flags)
+{
+	if (n && (!amb || !lens || !flags)) return LQCOV_E_ARG;
+	uint64_t c = 0;
+	for (uint32_t i = 0; i < n; ++i) { flags[i] = lq_packed_read_ambiguous(amb + c * LQ_CHUNK_WORDS, lens[i]) ? 1 : 0; c += ((uint64_t)lens[i] + LQ_CHUNK - 1) / LQ_CHUNK; }
+	return 0;
+}
+
 int lqcov_part_add_packed(lqcov_handle *h, int part, uint32_t n, const uint64_t *codes, const uint32_t *amb, const uint32_t *lens,
                           const char *names, const uint64_t *name_off)
 {
 	return guard(h, [&] {
-		if (n && (!codes || !amb || !lens)) throw std::invalid_argument("null read buffers");
+		if (n && (!codes || !lens)) throw std::invalid_argument("null read buffers");   // (amb == NULL: no read holds an ambiguous base)
 		Part &pt = h->part(part);
 		if (pt.built) throw std::logic_error("part already built");
 		h->add_reads_packed(pt.rs, n, codes, amb, lens, names, name_off);
@@ -329,7 +337,7 @@ int lqcov_part_add_packed_shares_dev(lqcov_handle *h, int part, const uint64_t *
                                      const char *names, const uint64_t *name_off)
 {
 	return guard(h, [&] {
-		if (n && (!codes_dev || !amb_dev || !lens || !share_chunks)) throw std::invalid_argument("null read buffers");
+		if (n && (!codes_dev || !lens || !share_chunks)) throw std::invalid_argument("null read buffers");   // (amb_dev == NULL: no read holds an ambiguous base)
 		Part &pt = h->part(part);
 		if (pt.built) throw std::logic_error("part already built");
 		if (pt.rs.n) throw std::logic_error("packed shares go into an empty part");

@@ -125,6 +125,7 @@ void Knobs::read_env()
 	run_grid = (u32)std::max<long>(1, num("LQCOV_RUN_GRID", 2048));
 	ps_key64 = num("LQCOV_PS_KEY64", 0) != 0;
 	sketch_wgen = num("LQCOV_SKETCH_WGEN", 0) != 0;
+	upload_amb = num("LQCOV_UPLOAD_AMB", 0) != 0;
 	sketch_key = num("LQCOV_SKETCH_KEY", 1) != 0;
 	emit_grid = (u32)std::min<long>(1L << 22, std::max<long>(1, num("LQCOV_EMIT_GRID", 1L << 22)));
 	sketch_list = num("LQCOV_SKETCH_LIST", 1) != 0;
@@ -294,6 +295,14 @@ u64 lq_packed_chunks(u32 n, const u64 *seq_off)
 	return c;
 }
 
+// does a packed read hold an ambiguous base (a bit of `aw` set at a position below len)?
+bool lq_packed_read_ambiguous(const u32 *aw, u64 len)
+{
+	const u64 full = len >> 5;
+	for (u64 wi = 0; wi < full; ++wi) if (aw[wi]) return true;
+	return (len & 31) && (aw[full] & ((1u << (len & 31)) - 1u));
+}
+
 void lq_pack_host(u32 n, const u8 *seq, const u64 *seq_off, u64 *codes, u32 *amb, int n_threads)
 {
 	static u8 tab[256];
@@ -376,8 +385,14 @@ void lqcov_handle::add_reads_packed(ReadSetDev &rs, u32 n, const u64 *codes, con
 			const u64 c = (*share_chunks)[i];
 			if (!c) continue;
 			LQ_HIP_CHECK(hipMemcpyAsync(rs.codes.as<u64>() + at * LQ_CHUNK_WORDS, codes_dev + (u64)i * stride_chunks * LQ_CHUNK_WORDS, c * LQ_CHUNK_WORDS * 8, hipMemcpyDeviceToDevice, stream));
-			LQ_HIP_CHECK(hipMemcpyAsync(rs.amb.as<u32>() + at * LQ_CHUNK_WORDS, amb_dev + (u64)i * stride_chunks * LQ_CHUNK_WORDS, c * LQ_CHUNK_WORDS * 4, hipMemcpyDeviceToDevice, stream));
+			if (amb_dev) LQ_HIP_CHECK(hipMemcpyAsync(rs.amb.as<u32>() + at * LQ_CHUNK_WORDS, amb_dev + (u64)i * stride_chunks * LQ_CHUNK_WORDS, c * LQ_CHUNK_WORDS * 4, hipMemcpyDeviceToDevice, stream));
 			at += c;
+		}
+		if (!amb_dev) {                                            // (no read of the part holds an ambiguous base: the ranks exchanged the codes alone)
+			rs.d_coff.ensure((rs.n + 1) * 8); rs.d_len.ensure((rs.n + 1) * 4);
+			h2d(rs.d_coff.as<u64>(), rs.h_coff.data(), rs.n + 1, stream);
+			h2d(rs.d_len.as<u32>(), rs.h_len.data(), rs.n, stream);
+			amb_tails(rs, rs.n - n, rs.n, chunk0, new_chunks);
 		}
 		LQ_HIP_CHECK(hipStreamSynchronize(stream));               // the caller's buffers are free again
 		return;
@@ -387,7 +402,8 @@ void lqcov_handle::add_reads_packed(ReadSetDev &rs, u32 n, const u64 *codes, con
 		// The reads go up in slices on a stream of their own; the data-parallel sketch kernel takes the tiles of a slice on the build
 		// stream as soon as the slice has arrived -- under the upload of the next one (a 4-Gbase part: 26 ms of upload and 34 ms of
 		// kernel one after the other before).  The caller's buffers are free when this returns; the last slice may still be sketched.
-		StageTimer t(this, stream, "h2d_packed_reads", n_words * 12);
+		StageTimer t(this, stream, "h2d_packed_reads", n_words * (amb ? 12 : 8));
+		if (!amb) amb_tails(rs, 0, n, chunk0, new_chunks);         // (no read holds an ambiguous base: the bits past the reads' ends are made here, on the build stream, before the first tile)
 		const u32 ns = K.upload_slices;
 		u32 r0 = 0;
 		for (u32 sl = 0; sl < ns; ++sl) {
@@ -397,7 +413,7 @@ void lqcov_handle::add_reads_packed(ReadSetDev &rs, u32 n, const u64 *codes, con
 			if (r1 > r0) {
 				const u64 w0 = rs.h_coff[r0] * LQ_CHUNK_WORDS, w1 = rs.h_coff[r1] * LQ_CHUNK_WORDS;
 				LQ_HIP_CHECK(hipMemcpyAsync(rs.codes.as<u64>() + w0, codes + w0, (w1 - w0) * 8, hipMemcpyHostToDevice, cstream));
-				LQ_HIP_CHECK(hipMemcpyAsync(rs.amb.as<u32>() + w0, amb + w0, (w1 - w0) * 4, hipMemcpyHostToDevice, cstream));
+				if (amb) LQ_HIP_CHECK(hipMemcpyAsync(rs.amb.as<u32>() + w0, amb + w0, (w1 - w0) * 4, hipMemcpyHostToDevice, cstream));
 				LQ_HIP_CHECK(hipEventRecord(ev_up[sl], cstream));
 				LQ_HIP_CHECK(hipStreamWaitEvent(stream, ev_up[sl], 0));
 				sketch_dp_launch(rs, sk_h_toff[r0], sk_h_toff[r1]);
@@ -410,11 +426,27 @@ void lqcov_handle::add_reads_packed(ReadSetDev &rs, u32 n, const u64 *codes, con
 	}
 	(void)first; (void)chunk0;
 	{
-		StageTimer t(this, stream, "h2d_packed_reads", n_words * 12);
+		StageTimer t(this, stream, "h2d_packed_reads", n_words * (amb ? 12 : 8));
 		h2d(rs.codes.as<u64>() + chunk0 * LQ_CHUNK_WORDS, codes, n_words, stream);
-		h2d(rs.amb.as<u32>() + chunk0 * LQ_CHUNK_WORDS, amb, n_words, stream);
+		if (amb) h2d(rs.amb.as<u32>() + chunk0 * LQ_CHUNK_WORDS, amb, n_words, stream);
+		else {
+			rs.d_coff.ensure((rs.n + 1) * 8); rs.d_len.ensure((rs.n + 1) * 4);
+			h2d(rs.d_coff.as<u64>(), rs.h_coff.data(), rs.n + 1, stream);
+			h2d(rs.d_len.as<u32>(), rs.h_len.data(), rs.n, stream);
+			amb_tails(rs, rs.n - n, rs.n, chunk0, new_chunks);
+		}
 	}
 	LQ_HIP_CHECK(hipStreamSynchronize(stream));               // the caller's buffers are free again
+}
+
+// the ambiguity words of the reads [r0, r1) -- chunks [chunk0, chunk0 + n_chunks) -- when none of them holds an ambiguous base: zero but for the
+// positions past every read's end (rs.d_coff / rs.d_len describe the reads already)
+void lqcov_handle::amb_tails(ReadSetDev &rs, u32 r0, u32 r1, u64 chunk0, u64 n_chunks)
+{
+	hipStream_t stream = this->bstream;
+	if (r1 <= r0) return;
+	dzero(rs.amb.as<u32>() + chunk0 * LQ_CHUNK_WORDS, n_chunks * LQ_CHUNK_WORDS * 4, stream);
+	LQ_LAUNCH(k_amb_tails, nblk(r1 - r0, 256), 256, stream, rs.d_coff.as<u64>(), rs.d_len.as<u32>(), r0, r1, rs.amb.as<u32>()); check_launch();
 }
 
 // What k_sketch_dp_mask needs before its first tile: read offsets and lengths, the tiles of every read, an empty mask.  false: the
@@ -2440,6 +2472,7 @@ int lqcov_handle::run_files(const char *target, const char *query, FILE *out, FI
 			u64 *codes = nullptr; u32 *amb = nullptr; u64 cap_words = 0;   // packed form, page-locked
 			std::vector<u32> lens; std::vector<char> names; std::vector<u64> name_off{0};
 			u32 n = 0; u64 bases = 0;
+			std::atomic<bool> any_amb{false};                           // packed form: a read of the part holds an ambiguous base
 			bool empty() const { return packed ? n == 0 : bs.empty(); }
 			~HostPart() { if (codes) hipHostFree(codes); if (amb) hipHostFree(amb); }
 		};
@@ -2484,7 +2517,7 @@ int lqcov_handle::run_files(const char *target, const char *query, FILE *out, FI
 			const double tp0 = lq_now_s();
 			struct Tm { double &t; double t0; ~Tm() { t = lq_now_s() - t0; } } tm{t_host[slot], tp0};
 			HostPart &h = hp[slot];
-			h.bs.clear(); h.n = 0; h.bases = 0; h.lens.clear(); h.names.clear(); h.name_off.assign(1, 0); h.last = false;
+			h.bs.clear(); h.n = 0; h.bases = 0; h.lens.clear(); h.names.clear(); h.name_off.assign(1, 0); h.last = false; h.any_amb.store(false);
 			if (!mem) {
 				h.packed = false;
 				u64 sum_len = 0;
@@ -2531,6 +2564,7 @@ int lqcov_handle::run_files(const char *target, const char *query, FILE *out, FI
 						const FlatRec &r = flat[r0 + i];
 						const u64 off[2] = {0, r.seq_len};
 						lq_pack_host(1, r.seq, off, h.codes + coff[i] * LQ_CHUNK_WORDS, h.amb + coff[i] * LQ_CHUNK_WORDS, 1);
+						if (!h.any_amb.load(std::memory_order_relaxed) && lq_packed_read_ambiguous(h.amb + coff[i] * LQ_CHUNK_WORDS, r.seq_len)) h.any_amb.store(true);
 					}
 				}
 			};
@@ -2547,7 +2581,7 @@ int lqcov_handle::run_files(const char *target, const char *query, FILE *out, FI
 				pt.built = false; pt.n_keys = 0; pt.live = true;
 			}
 			const double tb0 = lq_now_s();
-			if (h.packed) add_reads_packed(pt.rs, h.n, h.codes, h.amb, h.lens.data(), h.names.data(), h.name_off.data());
+			if (h.packed) add_reads_packed(pt.rs, h.n, h.codes, h.any_amb.load() || K.upload_amb ? h.amb : nullptr, h.lens.data(), h.names.data(), h.name_off.data());   // (a part without an N: the codes alone cross PCIe)
 			else for (ReadBatch &tb : h.bs) { add_reads(pt.rs, tb.size(), tb.seq.data(), tb.seq_off.data(), tb.names.data(), tb.name_off.data()); tb = ReadBatch(); }
 			const double tu = lq_now_s();
 			sketch(pt.rs, true);

@@ -48,6 +48,7 @@ struct Knobs {
 	bool sketch_list = true;              // LQCOV_SKETCH_LIST=0: the state machine looks for the chunks the data-parallel kernel left in every wave of 64 consecutive chunks (rounds 3-5) instead of taking them from a list
 	bool sketch_key = true;               // LQCOV_SKETCH_KEY=0: the index sort's keys by k_sort_keys from x instead of by k_sketch_emit_mask
 	u32 emit_grid = 1u << 22;             // LQCOV_EMIT_GRID: blocks of k_sketch_emit_mask (a block strides over the groups of 32 chunks)
+	bool upload_amb = false;              // LQCOV_UPLOAD_AMB=1: lqcov_run_files uploads the ambiguity words of a part although none of its reads holds an ambiguous base (rounds 2-5)
 	bool sketch_wgen = false;             // LQCOV_SKETCH_WGEN=1: k_sketch_dp_mask with the window read at run time although it is 5 or 10 (tests, A/B)
 	bool ps_key64 = false;                // LQCOV_PS_KEY64=1: the finishing kernels' 64-bit key shape although 32 bits would do (tests: parts with more than 2^40 (target, position) pairs are out of their reach)
 	u32 run_grid = 2048;                  // LQCOV_RUN_GRID: blocks of k_run_list, each with a contiguous stretch of tiles (tests: 1 or 2, so that a block walks many)
@@ -276,6 +277,7 @@ struct lqcov_handle {
 	~lqcov_handle();
 
 	void add_reads(ReadSetDev &rs, u32 n, const u8 *seq, const u64 *seq_off, const char *names, const u64 *name_off);
+	void amb_tails(ReadSetDev &rs, u32 r0, u32 r1, u64 chunk0, u64 n_chunks);
 	void add_reads_packed(ReadSetDev &rs, u32 n, const u64 *codes, const u32 *amb, const u32 *lens, const char *names, const u64 *name_off,
 	                      const u64 *codes_dev = nullptr, const u32 *amb_dev = nullptr, u64 stride_chunks = 0, const std::vector<u64> *share_chunks = nullptr);
 	void sketch(ReadSetDev &rs, bool rid_in_y);
@@ -318,6 +320,7 @@ u64 lq_packed_chunks(u32 n, const u64 *seq_off);
 void lq_format_rows(FILE *out, int filter_flag, const lqcov_row *rows, u32 n_rows, const lqcov_region *regs, const lqcov_region *mregs,
                     const std::function<const char *(u32)> &name_of);
 void lq_pack_host(u32 n, const u8 *seq, const u64 *seq_off, u64 *codes, u32 *amb, int n_threads);
+bool lq_packed_read_ambiguous(const u32 *aw, u64 len);
 
 struct StageTimer {
 	lqcov_handle *h; hipStream_t s; const char *name; u64 bytes;

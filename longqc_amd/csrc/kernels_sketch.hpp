@@ -60,6 +60,20 @@ __global__ void k_pack(const u8 *ascii, const u64 *seq_off, const u64 *coff, u32
 	codes[g] = w; amb[g] = m;
 }
 
+// ---- ambiguity bits of reads that hold no ambiguous base: only the positions past a read's end, inside its last chunk ---------
+// (lqcov_part_add_packed with amb == NULL: a quarter of the packed reads' bytes stays off PCIe; the words are zero before this runs)
+__global__ void k_amb_tails(const u64 *coff, const u32 *rlen, u32 r0, u32 r1, u32 *amb)
+{
+	const u32 r = r0 + blockIdx.x * blockDim.x + threadIdx.x;
+	if (r >= r1) return;
+	const u32 len = rlen[r];
+	const u64 w0 = coff[r] * LQ_CHUNK_WORDS, nw = (coff[r + 1] - coff[r]) * LQ_CHUNK_WORDS;
+	for (u64 wi = len >> 5; wi < nw; ++wi) {
+		const u64 p0 = wi * 32;
+		amb[w0 + wi] = p0 >= len ? 0xffffffffu : ~0u << (len - p0);   // (as lq_pack_host / k_pack mark them)
+	}
+}
+
 // ---- the state machine ------------------------------------------------------------------------
 struct SkParams { i32 k, w, hpc; u64 mask; u32 shift1; };
 
@@ -752,14 +766,26 @@ k_sketch_emit_mask(const u64 *codes, const u32 *amb, const u64 *coff, const u32 
 			const u32 r = rid[ch];
 			const u64 c0 = coff[r];
 			const u32 pos = (u32)(g0 + ch - c0) * LQ_CHUNK + (pi & (LQ_CHUNK - 1));
-			u64 raw; u32 am;
-			lq_window32(codes + c0 * LQ_CHUNK_WORDS, amb + c0 * LQ_CHUNK_WORDS, pos - (u32)k + 1, raw, am);
-			raw &= P.mask;
-			const u64 rv = ~raw & P.mask;
-			const u64 fw = lq_rev2(raw) >> (64 - 2 * k);
-			const u32 z = fw < rv ? 0u : 1u;
-			const u64 km = z ? rv : fw;
-			const u64 hv = k <= 16 ? (u64)lq_hash<u32>((u32)km, (u32)P.mask) : lq_hash<u64>(km, P.mask);
+			u32 z; u64 hv;
+			if (k <= 16) {                                          // the k-mer is inside 16 bases = one 32-bit window of the codes
+				const u32 *c32 = (const u32*)(codes + c0 * LQ_CHUNK_WORDS);
+				const u32 p = pos - (u32)k + 1, wi = p >> 4, sh = 2 * (p & 15);
+				const u32 w0 = c32[wi], w1 = (p & 15) + (u32)k > 16 ? c32[wi + 1] : 0u;   // (the word after only if the k-mer reaches into it: it may lie past the read's chunks)
+				const u32 win = (u32)((((u64)w1 << 32) | w0) >> sh);
+				const u32 km32 = (u32)P.mask;
+				const u32 rv = (win & km32) ^ km32;
+				const u32 fw = lq_rev2_32(win << (32 - 2 * k));       // the k groups of the window in reverse order: the machine's fw
+				z = fw < rv ? 0u : 1u;
+				hv = (u64)lq_hash<u32>(z ? rv : fw, km32);
+			} else {
+				u64 raw; u32 am;
+				lq_window32(codes + c0 * LQ_CHUNK_WORDS, amb + c0 * LQ_CHUNK_WORDS, pos - (u32)k + 1, raw, am);
+				raw &= P.mask;
+				const u64 rv = ~raw & P.mask;
+				const u64 fw = lq_rev2(raw) >> (64 - 2 * k);
+				z = fw < rv ? 0u : 1u;
+				hv = lq_hash<u64>(z ? rv : fw, P.mask);
+			}
 			out_x[o0 + j] = hv << 8 | (u64)k;
 			out_y[o0 + j] = (rid_in_y ? (u64)r << 32 : 0) | (u64)(pos << 1 | z);
 			if (out_key) out_key[o0 + j] = (u32)hv;

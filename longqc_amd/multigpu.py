@@ -379,10 +379,14 @@ class QueryShardRunner:
         packed, lo, hi = share
         c0, c1 = int(packed.coff[lo]), int(packed.coff[hi])
         n_ch = c1 - c0
+        mine_amb = 1 if (n_ch and packed.any_ambiguous(lo, hi)) else 0      # (a part without an N: the codes alone are exchanged, 0.25 B per base)
         if world > 1:
-            sizes = [int(t.item()) for t in _all_gather(torch.tensor([n_ch], dtype=torch.int64, device=dev), world, self.group)]
+            got = [t.cpu().tolist() for t in _all_gather(torch.tensor([n_ch, mine_amb], dtype=torch.int64, device=dev), world, self.group)]
+            sizes = [int(g[0]) for g in got]
+            any_amb = any(int(g[1]) for g in got)
         else:
             sizes = [n_ch]
+            any_amb = bool(mine_amb)
         cap = max(max(sizes), 1)
         have = getattr(self, "_pk_cap", 0)
         if cap > have:                                            # send and receive buffers, kept from part to part
@@ -396,19 +400,26 @@ class QueryShardRunner:
         if n_ch:
             hc = np.ctypeslib.as_array(ctypes.cast(packed.codes_ptr + c0 * 32, ctypes.POINTER(ctypes.c_int64)), shape=(n_ch * 4,))
             ha = np.ctypeslib.as_array(ctypes.cast(packed.amb_ptr + c0 * 16, ctypes.POINTER(ctypes.c_int32)), shape=(n_ch * 4,))
-            sc[:n_ch * 4].copy_(torch.from_numpy(hc)); sa[:n_ch * 4].copy_(torch.from_numpy(ha))      # this rank's 1 / N of the upload
+            sc[:n_ch * 4].copy_(torch.from_numpy(hc))                                                  # this rank's 1 / N of the upload
+            if any_amb:
+                sa[:n_ch * 4].copy_(torch.from_numpy(ha))
         self.last_sizes = sizes
+        self.last_any_amb = any_amb
         self.last_exchange_bytes = (world + 1) * stride * 48 if world > 1 else stride * 48           # (tests assert the bound: 0.375 B per base and buffer)
         if world > 1:
             gc, ga = self._pk[2], self._pk[3]
             if dist.get_backend(self.group) == "gloo":
-                gc.copy_(_all_gather_into(sc, world, self.group)); ga.copy_(_all_gather_into(sa, world, self.group))
+                gc.copy_(_all_gather_into(sc, world, self.group))
+                if any_amb:
+                    ga.copy_(_all_gather_into(sa, world, self.group))
             else:
-                dist.all_gather_into_tensor(gc, sc, group=self.group); dist.all_gather_into_tensor(ga, sa, group=self.group)   # RCCL all-gather over xGMI
+                dist.all_gather_into_tensor(gc, sc, group=self.group)                                # RCCL all-gather over xGMI
+                if any_amb:
+                    dist.all_gather_into_tensor(ga, sa, group=self.group)
                 torch.cuda.current_stream(dev).synchronize()
         else:
             gc, ga = sc, sa
-        eng.part_add_packed_shares_dev(part, gc.data_ptr(), ga.data_ptr(), stride, sizes, np.asarray(all_lens, dtype=np.uint32), all_names)
+        eng.part_add_packed_shares_dev(part, gc.data_ptr(), ga.data_ptr() if any_amb else 0, stride, sizes, np.asarray(all_lens, dtype=np.uint32), all_names)
         eng.part_build(part)
 
     def map_part(self, part: int, rid_base: int, all_names, all_lens):

@@ -288,6 +288,37 @@ def test_emulated_reset_and_rerun(emu_lib, packed):
     check_reset_and_rerun(emu_lib, packed)
 
 
+@pytest.mark.parametrize("slices", ["1", "3"])
+def test_emulated_packed_upload_without_ambiguity_words(emu_lib, monkeypatch, slices):
+    """lqcov_part_add_packed with amb == NULL (round 6: a range of reads without an ambiguous base goes up as codes alone, the device
+    makes the bits past the reads' ends itself): the adversarial set -- reads with N runs among reads without -- added read range by
+    read range, so that some ranges carry their ambiguity words and others do not; the reference's table.  Also: the flags say what
+    the reads hold, and forcing the words up (LQCOV_UPLOAD_AMB=1) changes nothing."""
+    tn, ts, _ = read_fastx(os.path.join(GOLDEN, "adv_all.fa.gz"))
+    qn, qs, qq = read_fastx(os.path.join(GOLDEN, "adv_sub.fq.gz"))
+    flat = np.concatenate(ts); off = np.concatenate([[0], np.cumsum([len(x) for x in ts])]).astype(np.uint64)
+    P = api.PackedReads(flat, off, list(tn), lib=emu_lib)
+    acgt = np.zeros(256, bool); acgt[[ord(c) for c in "ACGTUacgtu"]] = True
+    want_flags = np.array([0 if acgt[x].all() else 1 for x in ts], dtype=np.uint8)
+    assert np.array_equal(P.has_amb[:len(ts)], want_flags) and 0 < want_flags.sum() < len(ts)
+    want = read_gz("adv_ont.table.gz")
+    for force in ("0", "1"):
+        monkeypatch.setenv("LQCOV_UPLOAD_AMB", force)
+        monkeypatch.setenv("LQCOV_UPLOAD_MIN_CHUNKS", "1"); monkeypatch.setenv("LQCOV_UPLOAD_SLICES", slices)
+        eng = _engine(emu_lib)
+        eng.set_queries(qn, qs, qq)
+        pt = eng.part_begin()
+        cuts = sorted(set([0, len(tn)] + [int(i) for i in np.flatnonzero(np.diff(want_flags.astype(np.int8)))[:6] + 1]))
+        sent = []
+        for lo, hi in zip(cuts[:-1], cuts[1:]):
+            sent.append(P.any_ambiguous(lo, hi))
+            eng.part_add_packed(pt, P, lo, hi)
+        assert True in sent and False in sent
+        eng.reset(); eng.part_build(pt); eng.part_map(pt); eng.finish()
+        assert eng.table_text() == want, force
+        eng.close()
+
+
 @pytest.mark.parametrize("order", ["queries_after_add", "two_parts_added_first", "clear_and_add_again"])
 def test_emulated_packed_upload_mask_belongs_to_one_read_set(emu_lib, order):
     """The data-parallel sketch kernel runs under the upload of packed reads into mask buffers the handle shares between read sets
