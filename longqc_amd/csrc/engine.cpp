@@ -104,7 +104,7 @@ void Knobs::read_env()
 	lanes = (int)std::min<long>(8, std::max<long>(1, num("LQCOV_LANES", 3)));
 	anchor_budget = getenv("LQCOV_ANCHOR_BUDGET") ? strtoull(getenv("LQCOV_ANCHOR_BUDGET"), 0, 10) : 0;
 	query_order_file = is("LQCOV_QUERY_ORDER", "file");
-	query_order_length = is("LQCOV_QUERY_ORDER", "length");
+	query_order_striped = is("LQCOV_QUERY_ORDER", "striped");
 	all_klib = is("LQCOV_SORT", "klib");
 	ps_shift = (u32)std::min<long>(12, std::max<long>(0, num("LQCOV_PS_SHIFT", 0)));
 	reg_walker = !is("LQCOV_WALK", "solo");
@@ -334,7 +334,7 @@ void lq_pack_host(u32 n, const u8 *seq, const u64 *seq_off, u64 *codes, u32 *amb
 			}
 		}
 	};
-	if (n_threads <= 0) n_threads = (int)std::min<unsigned>(16, std::max(1u, std::thread::hardware_concurrency()));
+	if (n_threads <= 0) n_threads = (int)std::min<unsigned>(64, std::max(1u, std::thread::hardware_concurrency()));   // (a memory-bound loop over page-locked buffers: 16 threads packed 5.2 Gbases in 0.37 s on the 256-thread host, the parser of lqcov_run_files uses up to 64 as well)
 	const u64 total = seq_off[n] - seq_off[0];
 	if (n_threads == 1 || total < (1u << 22)) { work(0, n); return; }
 	std::vector<std::thread> th;
@@ -650,12 +650,13 @@ void lqcov_handle::set_queries(u32 n, const u8 *seq_in, const u64 *seq_off_in, c
 	for (u32 i = 0; i < n; ++i) q_perm[i] = i;
 	if (!K.query_order_file) {
 		std::stable_sort(q_perm.begin(), q_perm.end(), [&](u32 a, u32 b) { return seq_off_in[a + 1] - seq_off_in[a] > seq_off_in[b + 1] - seq_off_in[b]; });
-		// Dealt to as many stripes as there are mapping lanes, the stripes one after the other (round 6).  A part's batches are
-		// contiguous ranges of this order, one per lane; with the plain longest-first order the first lane held the longest queries
-		// -- and with them most of the second pass (klib's order for the queries that own an observable tie: 267 M of part 1's 467 M
-		// such anchors at configs[2], 118 ms against 65 and 45 on the other lanes).  LQCOV_QUERY_ORDER=length keeps rounds 1-5's order.
+		// LQCOV_QUERY_ORDER=striped (round 6, measured, not the default): dealt to as many stripes as there are mapping lanes, the stripes
+		// one after the other, so that a part's batches -- contiguous ranges of this order, cut by the anchors the first pass writes --
+		// hold like samples of the queries.  At configs[2] the lanes' second passes then carry 151 / 167 / 149 M anchors instead of
+		// 178 / 165 / 124 M and the step takes as long (373 against 366-370 ms): a lane's second pass is a chain of a dozen kernels
+		// whose length does not go by the batch (profiles/README.md, round 6).
 		const u32 ns = (u32)std::max(1, K.lanes);
-		if (!K.query_order_length && ns > 1 && n > ns) {
+		if (K.query_order_striped && ns > 1 && n > ns) {
 			std::vector<u32> dealt; dealt.reserve(n);
 			for (u32 st = 0; st < ns; ++st) for (u32 i = st; i < n; i += ns) dealt.push_back(q_perm[i]);
 			q_perm.swap(dealt);

@@ -27,7 +27,7 @@ struct StageAcc { double ms = 0; u64 launches = 0; u64 bytes = 0; };
 struct Knobs {
 	int lanes = 3;                        // LQCOV_LANES: concurrent mapping lanes (round 4, configs[2], ms per step: 2 lanes 908, 3: 888-922, 4: 964, 5: 995; round 3, every hit sorted: 1 lane 1882, 3: 1582, 5: 1510, 8: 1610)
 	u64 anchor_budget = 0;                // LQCOV_ANCHOR_BUDGET: anchors per query batch (0 = from free HBM)
-	bool query_order_length = false;      // LQCOV_QUERY_ORDER=length: longest first without dealing the queries to the lanes' stripes (rounds 1-5)
+	bool query_order_striped = false;     // LQCOV_QUERY_ORDER=striped: longest first, then dealt to the lanes' stripes (round 6: measured, no gain)
 	bool query_order_file = false;        // LQCOV_QUERY_ORDER=file: keep the caller's query order inside
 	bool all_klib = false;                // LQCOV_SORT=klib: every query through klib's passes, no bucket leaves them early
 	u32 ps_shift = 0;                     // LQCOV_PS_SHIFT: shrinks the size classes of the parallel sort (tests)

@@ -405,11 +405,12 @@ def test_emulated_constant_digit_levels_can_be_walked_or_skipped(emu_lib, datase
     assert out == want
 
 
+@pytest.mark.parametrize("order", ["file", "striped"])
 @pytest.mark.parametrize("case", [c for c in _cases("table") if c["name"] in ("adv_parts", "tiny_ont")], ids=lambda c: c["name"])
-def test_emulated_query_order_is_internal_only(emu_lib, case, monkeypatch):
-    """the engine holds the queries longest first; LQCOV_QUERY_ORDER=file keeps the caller's order inside as well: same rows,
-    in the caller's order, either way"""
-    monkeypatch.setenv("LQCOV_QUERY_ORDER", "file")
+def test_emulated_query_order_is_internal_only(emu_lib, case, monkeypatch, order):
+    """the engine holds the queries longest first; LQCOV_QUERY_ORDER=file keeps the caller's order inside as well, =striped deals the
+    sorted queries to the lanes' stripes: same rows, in the caller's order, either way"""
+    monkeypatch.setenv("LQCOV_QUERY_ORDER", order)
     rc, out, err = run_main(emu_lib, case["argv"], cwd=GOLDEN)
     assert rc == 0, err
     assert out == read_gz(case["expect"])
