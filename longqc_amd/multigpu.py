@@ -141,10 +141,10 @@ class PartRunner:
     accumulators; `finalize()` imports them into the handle so that lqcov_finish() produces the rows."""
 
     @staticmethod
-    def scaling_model(world: int, part_bases, upload_s_per_gbase=0.0065, sketch_s_per_gbase=0.0134, index_s_per_gbase=0.0105, map_s_per_gbase=0.066) -> float:
+    def scaling_model(world: int, part_bases, upload_s_per_gbase=0.0056, sketch_s_per_gbase=0.0068, index_s_per_gbase=0.0097, map_s_per_gbase=0.0555) -> float:
         """seconds per job predicted for `world` GPUs: rounds of `world` consecutive parts, a round lasts as long as its largest
         part takes on one GPU (front + mapping of every query; the exchange is a few KB per part).  Same MI355X figures as
-        QueryShardRunner.scaling_model."""
+        QueryShardRunner.scaling_model (round 6)."""
         per = [(upload_s_per_gbase + sketch_s_per_gbase + index_s_per_gbase + map_s_per_gbase) * b / 1e9 for b in part_bases]
         return sum(max(per[i:i + world]) for i in range(0, len(per), world))
 
@@ -340,12 +340,14 @@ class QueryShardRunner:
         return anchors
 
     @staticmethod
-    def scaling_model(world: int, part_bases, upload_s_per_gbase=0.0065, sketch_s_per_gbase=0.0134, index_s_per_gbase=0.0105, map_s_per_gbase=0.066,
-                      link_gbytes_per_s=153.0, packed_bytes_per_base=0.375, pipelined=True) -> float:
-        """seconds per job predicted for `world` GPUs (the defaults: MI355X figures measured at configs[2] -- upload 26 ms, sketch 53.5 ms,
-        index build incl. sort, run heads, table and name work 42 ms, seed plan + mapping 0.26 s per 4.0 Gbases and 5000 queries
-        (round 6); ring all-gather of the packed reads bound by one xGMI link).  The front of a part: this rank's 1 / N of the upload,
-        the all-gather, then sketch and index of the WHOLE part on every rank.  tools/scale.sh prints it beside what it measures."""
+    def scaling_model(world: int, part_bases, upload_s_per_gbase=0.0056, sketch_s_per_gbase=0.0068, index_s_per_gbase=0.0097, map_s_per_gbase=0.0555,
+                      link_gbytes_per_s=153.0, packed_bytes_per_base=0.25, pipelined=True) -> float:
+        """seconds per job predicted for `world` GPUs (the defaults: MI355X figures measured at configs[2] at the end of round 6 -- upload
+        22.5 ms (codes alone: reads without an N), sketch 27 ms, index build incl. sort, run heads, table and name work 39 ms, seed plan +
+        mapping 0.22 s per 4.0 Gbases and 5000 queries; ring all-gather of the packed reads, 0.25 B per base without ambiguity words (0.375
+        with), bound by one xGMI link).  The front of a part: this rank's 1 / N of the upload, the all-gather, then sketch and index of the
+        WHOLE part on every rank.  The mapping's rate is configs[2]'s; a 40x ONT set takes three times as long per base (profiles/README.md,
+        the full-size configs[3] run), which only helps the split that shares the mapping.  tools/scale.sh prints it beside what it measures."""
         t, prev_map = 0.0, None
         for b in part_bases:
             g = b / 1e9

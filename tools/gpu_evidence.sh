@@ -12,7 +12,7 @@ if [ "$SKIP_TESTS" != 1 ]; then
 fi
 C="--cache /tmp/lqcov_cache"
 CPU=""; [ "$CPUFULL" = 1 ] && CPU="--cpu-sample 500000"
-( timeout 900 python bench.py --steps ${STEPS:-5} --warmup 2 $C $CPU 2>gpurun_out/bench_err.log | tail -1 ) > gpurun_out/bench_cfg3.json
+( timeout ${BENCH_LIMIT:-900} python bench.py --steps ${STEPS:-5} --warmup 2 $C $CPU $BENCH_EXTRA 2>gpurun_out/bench_err.log | tail -1 ) > gpurun_out/bench_cfg3.json   # BENCH_EXTRA="--gz-end-to-end": the files-in / table-out call once more on a .gz
 echo "bench done $(( $(date +%s) - T0 )) s" >> gpurun_out/pytest_gpu.log
 ( timeout 150 python bench.py --config cfg2 --steps 3 --warmup 1 --no-cpu-baseline --no-end-to-end $C 2>&1 | tail -1 ) > gpurun_out/bench_cfg2.json
 cd /tmp && export TMPDIR=/tmp
