@@ -334,7 +334,7 @@ void lq_pack_host(u32 n, const u8 *seq, const u64 *seq_off, u64 *codes, u32 *amb
 			}
 		}
 	};
-	if (n_threads <= 0) n_threads = (int)std::min<unsigned>(64, std::max(1u, std::thread::hardware_concurrency()));   // (a memory-bound loop over page-locked buffers: 16 threads packed 5.2 Gbases in 0.37 s on the 256-thread host, the parser of lqcov_run_files uses up to 64 as well)
+	if (n_threads <= 0) n_threads = (int)std::min<unsigned>(16, std::max(1u, std::thread::hardware_concurrency()));   // (a memory-bound loop into page-locked buffers: 16 threads pack 5.2 Gbases in 0.37 s on the 256-thread host, 64 threads in 0.53 s -- round 6)
 	const u64 total = seq_off[n] - seq_off[0];
 	if (n_threads == 1 || total < (1u << 22)) { work(0, n); return; }
 	std::vector<std::thread> th;

@@ -55,6 +55,21 @@ def test_gpu_reset_and_rerun(gpu_lib):
     E.check_reset_and_rerun(gpu_lib, True)
 
 
+def test_gpu_constant_k_sketch_fuzz(gpu_lib, monkeypatch):
+    """k_sketch_dp_fast (round 6) against the state machine and the general data-parallel kernel, on the device"""
+    E.test_emulated_constant_k_sketch_fuzz(gpu_lib, monkeypatch)
+
+
+def test_gpu_data_parallel_sketch_fuzz(gpu_lib, monkeypatch):
+    E.test_emulated_data_parallel_sketch_fuzz(gpu_lib, monkeypatch)
+
+
+@pytest.mark.parametrize("slices", ["1", "3"])
+def test_gpu_packed_upload_without_ambiguity_words(gpu_lib, monkeypatch, slices):
+    """lqcov_part_add_packed with amb == NULL for the read ranges without an N (round 6), on the device"""
+    E.test_emulated_packed_upload_without_ambiguity_words(gpu_lib, monkeypatch, slices)
+
+
 def test_gpu_input_dialects(gpu_lib, tmp_path):
     H.test_input_dialects_agree_with_reference_semantics(gpu_lib, tmp_path)
 
