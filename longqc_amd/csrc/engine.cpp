@@ -784,12 +784,12 @@ void lqcov_handle::build_index(Part &pt)
 		if (k32) {
 			if (!(rs.key_stamp && rs.key_stamp == ix_key_stamp)) { LQ_LAUNCH(k_sort_keys<u32>, nblk(M, 256), 256, stream, rs.mx.as<u64>(), M, key.as<u32>()); check_launch(); }   // (k_sketch_emit_mask has written them)
 			ix_key_stamp = 0;
-			{ StageTimer t(this, stream, "index_radix_sort", M * 24); prim.sort_pairs_u32_u64(key.as<u32>(), key2.as<u32>(), rs.my.as<u64>(), pt.pos.as<u64>(), M, (unsigned)(2 * P.k)); }
+			{ StageTimer t(this, stream, "index_radix_sort", M * 24); prim.sort_pairs_u32_u64(key.as<u32>(), key2.as<u32>(), rs.my.as<u64>(), pt.pos.as<u64>(), M, (unsigned)(2 * P.k), key.as<u32>()); }   // (the unsorted keys are not needed again: their array is the sort's second key buffer)
 			LQ_LAUNCH(k_head_count<u32>, (u32)n_tiles, LQ_HEAD_THREADS, stream, key2.as<u32>(), M, head.as<u32>()); check_launch();
 		} else {
 			ix_key_stamp = 0;
 			LQ_LAUNCH(k_sort_keys<u64>, nblk(M, 256), 256, stream, rs.mx.as<u64>(), M, key.as<u64>()); check_launch();
-			{ StageTimer t(this, stream, "index_radix_sort", M * 32); prim.sort_pairs_u64(key.as<u64>(), key2.as<u64>(), rs.my.as<u64>(), pt.pos.as<u64>(), M, (unsigned)(2 * P.k)); }
+			{ StageTimer t(this, stream, "index_radix_sort", M * 32); prim.sort_pairs_u64(key.as<u64>(), key2.as<u64>(), rs.my.as<u64>(), pt.pos.as<u64>(), M, (unsigned)(2 * P.k), key.as<u64>()); }
 			LQ_LAUNCH(k_head_count<u64>, (u32)n_tiles, LQ_HEAD_THREADS, stream, key2.as<u64>(), M, head.as<u32>()); check_launch();
 		}
 		dzero(head.as<u32>() + n_tiles, 4, stream);

@@ -1,0 +1,255 @@
+// longqc_amd/csrc/kernels_isort.hpp -- the index sort, hand-written for gfx950.
+//
+// What it replaces: worker_post's radix_sort_128x over a bucket's minimizers (index.c:150-201) -- semantically "every
+// minimizer's occurrences grouped by hash, ascending y inside a hash".  The sketch emits a part's minimizers in ascending
+// y, so a STABLE sort of (hash, y) pairs on the 2k bits of the hash gives exactly that (rounds 1-5 called rocPRIM's
+// radix_sort_pairs here; this file is the same algorithm family written for this data and this chip).
+//
+// Shape: least-significant-digit radix sort, 8-bit digits, one sweep over the data per digit ("onesweep"):
+//   k_is_hist   one read of the keys: the digit histograms of every pass at once (LDS counters, one u64 atomic per
+//               non-empty counter and block);
+//   k_is_bases  per pass the exclusive scan of its 256 counts: where each digit's output range begins;
+//   k_is_pass   one launch per digit.  A block takes the next tile of 4096 pairs (a ticket, so that a tile's
+//               predecessors have always started), ranks its pairs by digit *stably* -- per wave and 64 consecutive
+//               pairs the lanes with the same digit find each other with 8 ballots, the first of them bumps the wave's
+//               counter of that digit in LDS, the others read the old value from its lane --, publishes the tile's 256
+//               digit counts as 8-byte {flag, count} granules (relaxed agent-scope stores: written through to memory,
+//               visible across XCDs, never torn: MI355X_MICROARCH.md, inter-workgroup visibility), looks back over the
+//               predecessors' granules until it meets an inclusive prefix (decoupled look-back: no tile waits for more
+//               than its predecessors' *counting* phases), then moves its pairs through LDS into digit order and writes
+//               every digit's run to its place with consecutive lanes on consecutive addresses.
+// Bytes per pair and pass: 12 read + 12 written for 4-byte keys (k <= 16), 16 + 16 for 8-byte keys, + 0.5 B of granules.
+// LDS per block: 48 KB of staged pairs + 4 KB of wave counters + 3 KB: three blocks per CU.
+#pragma once
+#include "lq_common.hpp"
+
+#define LQ_IS_THREADS 256
+#define LQ_IS_WAVES   (LQ_IS_THREADS / 64)
+#define LQ_IS_MAXPASS 8
+
+// {flag, count} granule of one (tile, digit): flag = 2 * pass + 1 (the tile's own count) or 2 * pass + 2 (count of the tile and
+// every tile before it); granules are zeroed once per sort, the pass number keeps the passes apart
+#define LQ_IS_VAL(g)  ((g) & 0x00ffffffffffffffULL)
+#define LQ_IS_FLAG(g) ((u32)((g) >> 56))
+
+#ifndef LQ_EMU
+__device__ __forceinline__ void lq_is_publish(u64 *p, u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ u64 lq_is_peek(const u64 *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void lq_is_nap() { __builtin_amdgcn_s_sleep(2); }
+#else
+inline void lq_is_publish(u64 *p, u64 v) { *p = v; }
+inline u64 lq_is_peek(const u64 *p) { return *p; }
+inline void lq_is_nap() {}
+#endif
+
+template <class KT>
+__global__ void __launch_bounds__(256)
+k_is_hist(const KT *key, u64 n, u32 n_pass, u32 last_mask, u64 per_block, unsigned long long *ghist)
+{
+	__shared__ u32 h[LQ_IS_MAXPASS * 256];
+	for (u32 i = threadIdx.x; i < n_pass * 256; i += 256) h[i] = 0;
+	__syncthreads();
+	const u64 lo = (u64)blockIdx.x * per_block, hi = lo + per_block < n ? lo + per_block : n;
+	for (u64 base = lo; base < hi; base += 256 * 4) {
+		KT k[4];
+#pragma unroll
+		for (int j = 0; j < 4; ++j) { const u64 i = base + (u64)j * 256 + threadIdx.x; k[j] = i < hi ? key[i] : (KT)0; }
+#pragma unroll
+		for (int j = 0; j < 4; ++j) {
+			const u64 i = base + (u64)j * 256 + threadIdx.x;
+			if (i < hi) for (u32 p = 0; p < n_pass; ++p) atomicAdd(&h[p * 256 + ((u32)(k[j] >> (8 * p)) & (p + 1 == n_pass ? last_mask : 255u))], 1u);
+		}
+	}
+	__syncthreads();
+	for (u32 i = threadIdx.x; i < n_pass * 256; i += 256) if (h[i]) atomicAdd(&ghist[i], (unsigned long long)h[i]);
+}
+
+// exclusive scan of every pass's 256 counts, in place (block p: pass p)
+template <int PASSES_MAX>
+__global__ void __launch_bounds__(256)
+k_is_bases(unsigned long long *ghist)
+{
+	__shared__ u64 s[256];
+	unsigned long long *g = ghist + (size_t)blockIdx.x * 256;
+	const u32 t = threadIdx.x;
+	const u64 mine = g[t];
+	s[t] = mine;
+	__syncthreads();
+	for (u32 o = 1; o < 256; o <<= 1) {
+		const u64 add = t >= o ? s[t - o] : 0;
+		__syncthreads();
+		s[t] += add;
+		__syncthreads();
+	}
+	g[t] = s[t] - mine;
+}
+
+// pairs per thread: as many as keep the staged tile at 45 KB (three blocks per CU), 16 at most
+template <class KT, class VT, bool PAIRS>
+struct LqIsShape { static constexpr int BYTES = (int)sizeof(KT) + (PAIRS ? (int)sizeof(VT) : 0);
+                   static constexpr int FIT = 45 * 1024 / (LQ_IS_THREADS * BYTES);
+                   static constexpr int E = FIT > 16 ? 16 : FIT; };
+
+template <class KT, class VT, bool PAIRS>
+__global__ void __launch_bounds__(LQ_IS_THREADS)
+k_is_pass(const KT *kin, KT *kout, const VT *vin, VT *vout, u64 n, u32 shift, u32 mask, u32 pass, const unsigned long long *gbase, u64 *status, u32 *ticket)
+{
+	constexpr int E = LqIsShape<KT, VT, PAIRS>::E;
+	constexpr u32 TILE = LQ_IS_THREADS * E;
+	__shared__ u32 wc[LQ_IS_WAVES][256];        // a wave's count of every digit, then its exclusive prefix over the waves before it
+	__shared__ u32 toff[256];                   // where the digit's run begins inside the tile
+	__shared__ u64 gdel[256];                   // global index of a staged pair = gdel[digit] + its slot in the tile
+	__shared__ u32 wsum[LQ_IS_WAVES];
+	__shared__ u32 s_tile;
+	__shared__ KT sk[TILE];
+	__shared__ VT sv[PAIRS ? TILE : 1];
+	const u32 tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+	if (tid == 0) s_tile = atomicAdd(ticket, 1u);
+	for (u32 i = tid; i < LQ_IS_WAVES * 256; i += LQ_IS_THREADS) (&wc[0][0])[i] = 0;
+	__syncthreads();
+	const u32 tile = s_tile;
+	const u64 t0 = (u64)tile * TILE;
+	const u32 tn = n - t0 < (u64)TILE ? (u32)(n - t0) : TILE;
+	// the wave's E * 64 consecutive pairs, 64 at a time
+	KT k[E]; VT v[PAIRS ? E : 1]; u32 r[E];
+#pragma unroll
+	for (int e = 0; e < E; ++e) {
+		const u32 idx = w * (E * 64) + e * 64 + lane;
+		k[e] = 0;
+		if (PAIRS) v[e] = 0;
+		if (idx < tn) { k[e] = kin[t0 + idx]; if (PAIRS) v[e] = vin[t0 + idx]; }
+	}
+	const u64 below_me = lane ? (~0ULL >> (64 - lane)) : 0ULL;
+#pragma unroll
+	for (int e = 0; e < E; ++e) {
+		const u32 idx = w * (E * 64) + e * 64 + lane;
+		const bool valid = idx < tn;
+		const u32 d = ((u32)(k[e] >> shift) & mask);
+		u64 peers = __ballot(valid);
+#pragma unroll
+		for (int b = 0; b < 8; ++b) {
+			const bool bit = (d >> b) & 1;
+			const u64 bal = __ballot(valid && bit);
+			peers &= bit ? bal : ~bal;
+		}
+		const u32 below = (u32)__popcll(peers & below_me);
+		u32 old = 0;
+		if (valid && below == 0) { old = wc[w][d]; wc[w][d] = old + (u32)__popcll(peers); }
+		old = __shfl(old, valid ? __ffsll((long long)peers) - 1 : (int)lane);
+		r[e] = old + below;
+	}
+	__syncthreads();
+	// per digit (thread d): the waves' counts -> exclusive over the waves, the tile's count, its granule, the look-back
+	{
+		const u32 d = tid;
+		u32 run = 0;
+#pragma unroll
+		for (int i = 0; i < LQ_IS_WAVES; ++i) { const u32 c = wc[i][d]; wc[i][d] = run; run += c; }
+		u64 *mine = status + (size_t)tile * 256 + d;
+		const u64 f_own = (u64)(2 * pass + 1) << 56, f_all = (u64)(2 * pass + 2) << 56;
+		if (tile > 0) lq_is_publish(mine, f_own | run);
+		// exclusive scan of the tile's counts over the digits
+		u32 inc = run;
+#pragma unroll
+		for (int o = 1; o < 64; o <<= 1) { const u32 up = __shfl_up(inc, o); if (lane >= (u32)o) inc += up; }
+		if (lane == 63) wsum[w] = inc;
+		__syncthreads();
+		u32 before = 0;
+#pragma unroll
+		for (int i = 0; i < LQ_IS_WAVES; ++i) if ((u32)i < w) before += wsum[i];
+		const u32 off = before + inc - run;
+		toff[d] = off;
+		u64 excl = 0;
+		for (u32 p = tile; p-- > 0; ) {
+			const u64 *g = status + (size_t)p * 256 + d;
+			u64 s = lq_is_peek(g);
+			while (LQ_IS_FLAG(s) != 2 * pass + 1 && LQ_IS_FLAG(s) != 2 * pass + 2) { lq_is_nap(); s = lq_is_peek(g); }
+			excl += LQ_IS_VAL(s);
+			if (LQ_IS_FLAG(s) == 2 * pass + 2) break;
+		}
+		lq_is_publish(mine, f_all | (excl + run));
+		gdel[d] = (u64)gbase[pass * 256 + d] + excl - off;
+	}
+	__syncthreads();
+#pragma unroll
+	for (int e = 0; e < E; ++e) {
+		const u32 idx = w * (E * 64) + e * 64 + lane;
+		if (idx < tn) {
+			const u32 d = ((u32)(k[e] >> shift) & mask);
+			const u32 slot = toff[d] + wc[w][d] + r[e];
+			sk[slot] = k[e];
+			if (PAIRS) sv[slot] = v[e];
+		}
+	}
+	__syncthreads();
+#pragma unroll
+	for (int e = 0; e < E; ++e) {
+		const u32 s = e * LQ_IS_THREADS + tid;
+		if (s < tn) {
+			const KT kk = sk[s];
+			const u64 g = gdel[(u32)(kk >> shift) & mask] + s;
+			kout[g] = kk;
+			if (PAIRS) vout[g] = sv[s];
+		}
+	}
+}
+
+// ---- exclusive scan of u32 counts (device-wide, one pass over the data) ----------------------------------------------------------
+// The same decoupled look-back with one granule per tile: a tile of 256 x 16 counts is scanned in registers (wave scans over 64
+// consecutive counts, carried along the wave's 16 rounds), its total published, the predecessors' granules summed 64 at a time by
+// the first wave until one holds an inclusive prefix.  Sums are 64-bit whatever the output type.
+#define LQ_SC_E 16
+#define LQ_SC_TILE (256 * LQ_SC_E)
+template <class TO>
+__global__ void __launch_bounds__(256)
+k_scan_lookback(const u32 *in, TO *out, u64 n, u64 init, u64 *status, u32 *ticket)
+{
+	__shared__ u64 wtot[4];
+	__shared__ u64 s_excl;
+	__shared__ u32 s_tile;
+	const u32 tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+	if (tid == 0) s_tile = atomicAdd(ticket, 1u);
+	__syncthreads();
+	const u32 tile = s_tile;
+	const u64 t0 = (u64)tile * LQ_SC_TILE;
+	u32 x[LQ_SC_E]; u64 ex[LQ_SC_E];
+#pragma unroll
+	for (int e = 0; e < LQ_SC_E; ++e) { const u64 i = t0 + w * (LQ_SC_E * 64) + e * 64 + lane; x[e] = i < n ? in[i] : 0u; }
+	u64 carry = 0;
+#pragma unroll
+	for (int e = 0; e < LQ_SC_E; ++e) {
+		u64 inc = x[e];
+#pragma unroll
+		for (int o = 1; o < 64; o <<= 1) { const u64 up = __shfl_up(inc, o); if (lane >= (u32)o) inc += up; }
+		ex[e] = carry + inc - x[e];
+		carry += __shfl(inc, 63);
+	}
+	if (lane == 0) wtot[w] = carry;
+	__syncthreads();
+	u64 before = 0, total = 0;
+#pragma unroll
+	for (int i = 0; i < 4; ++i) { if ((u32)i < w) before += wtot[i]; total += wtot[i]; }
+	if (w == 0) {
+		u64 *mine = status + tile;
+		if (tile > 0 && lane == 0) lq_is_publish(mine, (1ULL << 56) | total);
+		u64 excl = 0;
+		u32 done = tile == 0;
+		for (u32 base = tile; !done; ) {                        // predecessors base - 1 - lane, nearest first
+			const bool have = lane < base;
+			u64 s = 0;
+			if (have) { const u64 *g = status + (base - 1 - lane); s = lq_is_peek(g); while (LQ_IS_FLAG(s) == 0) { lq_is_nap(); s = lq_is_peek(g); } }
+			const u64 full = __ballot(have && LQ_IS_FLAG(s) == 2);
+			const u32 stop = full ? (u32)__ffsll((long long)full) - 1 : 63u;   // the nearest predecessor with an inclusive prefix
+			u64 part = have && lane <= stop ? LQ_IS_VAL(s) : 0;
+#pragma unroll
+			for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
+			excl += part;
+			if (full || base <= 64) done = 1; else base -= 64;
+		}
+		if (lane == 0) { lq_is_publish(mine, (2ULL << 56) | (excl + total)); s_excl = excl; }
+	}
+	__syncthreads();
+	const u64 add = init + s_excl + before;
+#pragma unroll
+	for (int e = 0; e < LQ_SC_E; ++e) { const u64 i = t0 + w * (LQ_SC_E * 64) + e * 64 + lane; if (i < n) out[i] = (TO)(add + ex[e]); }
+}

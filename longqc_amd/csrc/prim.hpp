@@ -1,15 +1,15 @@
-// longqc_amd/csrc/prim.hpp -- device-wide primitives (stable LSD radix sort, exclusive scan).
-// On the GPU these are rocPRIM (ROCm's native primitive library); the test-only emulator build
-// (tests/emu) substitutes std:: algorithms with the same contracts.
+// longqc_amd/csrc/prim.hpp -- device buffers and the device-wide primitives (stable LSD radix sort, exclusive scan):
+// the host side of kernels_isort.hpp.  Rounds 1-5 called rocPRIM here; since round 6 every kernel the engine launches is
+// its own (the test-only emulator build runs the same kernels).
 #pragma once
 #include "lq_common.hpp"
+#include "kernels_isort.hpp"
 #include <stdexcept>
 #include <utility>
 #include <string>
 
 #ifndef LQ_EMU
 #include <cstring>
-#include <rocprim/rocprim.hpp>
 #define LQ_HIP_CHECK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) \
 	throw std::runtime_error(std::string(#expr) + ": " + hipGetErrorString(e_)); } while (0)
 #else
@@ -50,6 +50,7 @@ inline void lq_pool_keep_memory(int) {}
 // time and bytes of device allocations (run_files reports them: a fresh process allocates its whole work space once)
 #include <atomic>
 #include <chrono>
+#include <algorithm>
 inline std::atomic<uint64_t> lq_alloc_ns{0}, lq_alloc_bytes{0};
 struct LqAllocTimer { std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now(); size_t bytes; explicit LqAllocTimer(size_t b) : bytes(b) {}
 	~LqAllocTimer() { lq_alloc_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(); lq_alloc_bytes += bytes; } };
@@ -126,96 +127,58 @@ struct Prim {
 	DBuf tmp;
 	hipStream_t stream = nullptr;
 
-	// out[i] = sum_{j<i} in[j]  (u32 -> u64); returns nothing, total = out[n-1] + in[n-1] (caller reads)
-	void exclusive_scan_u32_u64(const u32 *in, u64 *out, size_t n, u64 init = 0)
+	// out[i] = init + sum_{j<i} in[j]; the total is out[n-1] + in[n-1] (callers scan n + 1 counts and read the last)
+	template <class TO> void scan_u32(const u32 *in, TO *out, size_t n, u64 init)
 	{
 		if (n == 0) return;
-#ifndef LQ_EMU
-		size_t bytes = 0;
-		LQ_HIP_CHECK(rocprim::exclusive_scan(nullptr, bytes, in, out, init, n, rocprim::plus<u64>(), stream));
-		tmp.ensure(bytes);
-		LQ_HIP_CHECK(rocprim::exclusive_scan(tmp.p, bytes, in, out, init, n, rocprim::plus<u64>(), stream));
-#else
-		u64 acc = init;
-		for (size_t i = 0; i < n; ++i) { u64 v = in[i]; out[i] = acc; acc += v; }
-#endif
+		const size_t n_tiles = (n + LQ_SC_TILE - 1) / LQ_SC_TILE, ctl = n_tiles * 8 + 64;
+		tmp.ensure(ctl);
+		LQ_HIP_CHECK(hipMemsetAsync(tmp.p, 0, ctl, stream));
+		LQ_LAUNCH(k_scan_lookback<TO>, (u32)n_tiles, 256, stream, in, out, (u64)n, init, tmp.as<u64>(), (u32*)(tmp.as<u64>() + n_tiles));
+		LQ_HIP_CHECK(hipGetLastError());
+	}
+	void exclusive_scan_u32_u64(const u32 *in, u64 *out, size_t n, u64 init = 0) { scan_u32<u64>(in, out, n, init); }
+	void exclusive_scan_u32_u32(const u32 *in, u32 *out, size_t n) { scan_u32<u32>(in, out, n, 0); }
+
+	// stable sort of keys (and their values) on key bits [0, end_bit): kernels_isort.hpp.  The inputs are left as they are; one
+	// more array of keys and of values is needed when there are two passes or more: ktmp / vtmp, or the scratch of this object
+	// (ktmp may be kin itself when the caller has no use for the unsorted keys and the number of passes is odd).
+	template <class KT, class VT, bool PAIRS>
+	void radix(const KT *kin, KT *kout, const VT *vin, VT *vout, size_t n, unsigned end_bit, KT *ktmp = nullptr, VT *vtmp = nullptr)
+	{
+		if (n == 0) return;
+		if (end_bit == 0 || end_bit > 8 * sizeof(KT)) end_bit = 8 * sizeof(KT);
+		const u32 n_pass = (end_bit + 7) / 8, last_mask = (1u << (end_bit - 8 * (n_pass - 1))) - 1;
+		constexpr size_t TILE = (size_t)LQ_IS_THREADS * LqIsShape<KT, VT, PAIRS>::E;
+		const size_t n_tiles = (n + TILE - 1) / TILE;
+		if (n_tiles > 0x7fffffffULL) throw std::domain_error("radix sort: too many tiles");
+		if (ktmp == kin && n_pass % 2 == 0) ktmp = nullptr;
+		const auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+		const size_t b_status = up(n_tiles * 256 * 8), b_hist = LQ_IS_MAXPASS * 256 * 8, b_ticket = 256, ctl = b_status + b_hist + b_ticket;
+		const size_t b_k = n_pass > 1 && !ktmp ? up(n * sizeof(KT)) : 0, b_v = PAIRS && n_pass > 1 && !vtmp ? up(n * sizeof(VT)) : 0;
+		tmp.ensure(ctl + b_k + b_v);
+		char *base = tmp.as<char>();
+		u64 *status = (u64*)base;
+		unsigned long long *ghist = (unsigned long long*)(base + b_status);
+		u32 *ticket = (u32*)(base + b_status + b_hist);
+		if (b_k) ktmp = (KT*)(base + ctl);
+		if (b_v) vtmp = (VT*)(base + ctl + b_k);
+		LQ_HIP_CHECK(hipMemsetAsync(base, 0, ctl, stream));
+		const size_t hb = std::min<size_t>(4096, (n + 1023) / 1024), per = ((n + hb - 1) / hb + 1023) / 1024 * 1024;
+		LQ_LAUNCH(k_is_hist<KT>, (u32)((n + per - 1) / per), 256, stream, kin, (u64)n, n_pass, last_mask, (u64)per, ghist);
+		LQ_LAUNCH(k_is_bases<LQ_IS_MAXPASS>, n_pass, 256, stream, ghist);
+		const KT *ki = kin; const VT *vi = vin;
+		for (u32 p = 0; p < n_pass; ++p) {
+			const bool to_out = (n_pass - 1 - p) % 2 == 0;
+			KT *ko = to_out ? kout : ktmp; VT *vo = to_out ? vout : vtmp;
+			LQ_LAUNCH((k_is_pass<KT, VT, PAIRS>), (u32)n_tiles, LQ_IS_THREADS, stream, ki, ko, vi, vo, (u64)n, 8 * p, p + 1 == n_pass ? last_mask : 255u, p, ghist, status, ticket + p);
+			ki = ko; vi = vo;
+		}
+		LQ_HIP_CHECK(hipGetLastError());
 	}
 
-	void exclusive_scan_u32_u32(const u32 *in, u32 *out, size_t n)
-	{
-		if (n == 0) return;
-#ifndef LQ_EMU
-		size_t bytes = 0;
-		LQ_HIP_CHECK(rocprim::exclusive_scan(nullptr, bytes, in, out, (u32)0, n, rocprim::plus<u32>(), stream));
-		tmp.ensure(bytes);
-		LQ_HIP_CHECK(rocprim::exclusive_scan(tmp.p, bytes, in, out, (u32)0, n, rocprim::plus<u32>(), stream));
-#else
-		u32 acc = 0;
-		for (size_t i = 0; i < n; ++i) { u32 v = in[i]; out[i] = acc; acc += v; }
-#endif
-	}
-
-	// stable sort of (key,value) pairs on key bits [0, end_bit)
-	void sort_pairs_u64(const u64 *kin, u64 *kout, const u64 *vin, u64 *vout, size_t n, unsigned end_bit)
-	{
-		if (n == 0) return;
-#ifndef LQ_EMU
-		size_t bytes = 0;
-		LQ_HIP_CHECK(rocprim::radix_sort_pairs(nullptr, bytes, kin, kout, vin, vout, n, 0u, end_bit, stream));
-		tmp.ensure(bytes);
-		LQ_HIP_CHECK(rocprim::radix_sort_pairs(tmp.p, bytes, kin, kout, vin, vout, n, 0u, end_bit, stream));
-#else
-		std::vector<size_t> idx(n);
-		std::iota(idx.begin(), idx.end(), (size_t)0);
-		u64 mask = end_bit >= 64 ? ~0ULL : ((1ULL << end_bit) - 1);
-		std::stable_sort(idx.begin(), idx.end(), [&](size_t a, size_t b) { return (kin[a] & mask) < (kin[b] & mask); });
-		for (size_t i = 0; i < n; ++i) { kout[i] = kin[idx[i]]; vout[i] = vin[idx[i]]; }
-#endif
-	}
-
-	void sort_pairs_u32_u64(const u32 *kin, u32 *kout, const u64 *vin, u64 *vout, size_t n, unsigned end_bit)
-	{
-		if (n == 0) return;
-#ifndef LQ_EMU
-		size_t bytes = 0;
-		LQ_HIP_CHECK(rocprim::radix_sort_pairs(nullptr, bytes, kin, kout, vin, vout, n, 0u, end_bit, stream));
-		tmp.ensure(bytes);
-		LQ_HIP_CHECK(rocprim::radix_sort_pairs(tmp.p, bytes, kin, kout, vin, vout, n, 0u, end_bit, stream));
-#else
-		std::vector<size_t> idx(n);
-		std::iota(idx.begin(), idx.end(), (size_t)0);
-		std::stable_sort(idx.begin(), idx.end(), [&](size_t a, size_t b) { return kin[a] < kin[b]; });
-		for (size_t i = 0; i < n; ++i) { kout[i] = kin[idx[i]]; vout[i] = vin[idx[i]]; }
-#endif
-	}
-
-	void sort_pairs_u32_u32(const u32 *kin, u32 *kout, const u32 *vin, u32 *vout, size_t n)
-	{
-		if (n == 0) return;
-#ifndef LQ_EMU
-		size_t bytes = 0;
-		LQ_HIP_CHECK(rocprim::radix_sort_pairs(nullptr, bytes, kin, kout, vin, vout, n, 0u, 32u, stream));
-		tmp.ensure(bytes);
-		LQ_HIP_CHECK(rocprim::radix_sort_pairs(tmp.p, bytes, kin, kout, vin, vout, n, 0u, 32u, stream));
-#else
-		std::vector<size_t> idx(n);
-		std::iota(idx.begin(), idx.end(), (size_t)0);
-		std::stable_sort(idx.begin(), idx.end(), [&](size_t a, size_t b) { return kin[a] < kin[b]; });
-		for (size_t i = 0; i < n; ++i) { kout[i] = kin[idx[i]]; vout[i] = vin[idx[i]]; }
-#endif
-	}
-
-	void sort_keys_u32(const u32 *kin, u32 *kout, size_t n)
-	{
-		if (n == 0) return;
-#ifndef LQ_EMU
-		size_t bytes = 0;
-		LQ_HIP_CHECK(rocprim::radix_sort_keys(nullptr, bytes, kin, kout, n, 0u, 32u, stream));
-		tmp.ensure(bytes);
-		LQ_HIP_CHECK(rocprim::radix_sort_keys(tmp.p, bytes, kin, kout, n, 0u, 32u, stream));
-#else
-		std::copy(kin, kin + n, kout);
-		std::sort(kout, kout + n);
-#endif
-	}
+	void sort_pairs_u64(const u64 *kin, u64 *kout, const u64 *vin, u64 *vout, size_t n, unsigned end_bit, u64 *ktmp = nullptr) { radix<u64, u64, true>(kin, kout, vin, vout, n, end_bit, ktmp); }
+	void sort_pairs_u32_u64(const u32 *kin, u32 *kout, const u64 *vin, u64 *vout, size_t n, unsigned end_bit, u32 *ktmp = nullptr) { radix<u32, u64, true>(kin, kout, vin, vout, n, end_bit, ktmp); }
+	void sort_pairs_u32_u32(const u32 *kin, u32 *kout, const u32 *vin, u32 *vout, size_t n) { radix<u32, u32, true>(kin, kout, vin, vout, n, 32); }
+	void sort_keys_u32(const u32 *kin, u32 *kout, size_t n) { radix<u32, u32, false>(kin, kout, nullptr, nullptr, n, 32); }
 };
