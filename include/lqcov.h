@@ -226,6 +226,13 @@ int lqcov_get_part_minimizers(lqcov_handle *h, int part, uint64_t *xy, uint64_t 
  * (query, rid, rev, score, cnt, qs, qe, rs, re), unordered. */
 int lqcov_get_chains(lqcov_handle *h, int32_t *out, uint64_t cap, uint64_t *n_total);
 
+/* Test access to the engine's device-wide primitives (kernels_isort.hpp; they stand where the reference calls klib's
+ * radix_sort_128x on a bucket of minimizers, index.c:150-201): a stable sort of n (key, value) pairs by the low `bits` bits of
+ * the keys (key_bytes 4: the keys travel as 32-bit words, as for k <= 16; 8: as 64-bit words; vals == NULL: keys only, 4-byte
+ * keys), and out[i] = sum of in[0..i-1].  Host arrays in and out. */
+int lqcov_debug_sort_pairs(lqcov_handle *h, uint64_t *keys, uint64_t *vals, uint64_t n, unsigned bits, int key_bytes);
+int lqcov_debug_scan(lqcov_handle *h, const uint32_t *in, uint64_t *out, uint64_t n);
+
 /* The table text (minimap2-coverage.c:567-605) of rows computed elsewhere: the ranks of a multi-GPU run gather their rows and
  * region pools as they are (lqcov_get_rows / lqcov_get_regions; reg_off / mreg_off rebased onto the concatenated pools) and
  * one rank prints them.  No handle: formatting needs nothing but the rows.  names: n_rows NUL-terminated strings. */

@@ -119,6 +119,8 @@ def load_library(path: Optional[str] = None):
         "lqcov_get_query_minimizers": (C.c_int, [H, C.c_void_p, C.c_void_p, u64p]),
         "lqcov_get_part_minimizers": (C.c_int, [H, C.c_int, C.c_void_p, C.c_void_p, u64p]),
         "lqcov_get_chains": (C.c_int, [H, C.c_void_p, C.c_uint64, u64p]),
+        "lqcov_debug_sort_pairs": (C.c_int, [H, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint, C.c_int]),
+        "lqcov_debug_scan": (C.c_int, [H, C.c_void_p, C.c_void_p, C.c_uint64]),
         "lqcov_part_minimizers_dev": (C.c_int, [H, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), u64p]),
         "lqcov_part_minimizers_export_dev": (C.c_int, [H, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32]),
         "lqcov_set_distributed": (C.c_int, [H, C.c_int]),
@@ -465,6 +467,20 @@ class Engine:
         self._ck(self.lib.lqcov_get_chains(self.h, None, 0, C.byref(n)))
         out = np.zeros((n.value, 9), dtype=np.int32)
         self._ck(self.lib.lqcov_get_chains(self.h, out.ctypes.data, n.value, C.byref(n)))
+        return out
+
+    def debug_sort_pairs(self, keys: np.ndarray, vals: Optional[np.ndarray], bits: int, key_bytes: int = 4):
+        """tests: the engine's stable radix sort (kernels_isort.hpp) on host arrays; returns (keys, vals) sorted"""
+        k = np.ascontiguousarray(keys, dtype=np.uint64).copy()
+        v = None if vals is None else np.ascontiguousarray(vals, dtype=np.uint64).copy()
+        self._ck(self.lib.lqcov_debug_sort_pairs(self.h, k.ctypes.data, None if v is None else v.ctypes.data, k.shape[0], bits, key_bytes))
+        return k, v
+
+    def debug_scan(self, counts: np.ndarray) -> np.ndarray:
+        """tests: the engine's exclusive scan of u32 counts (u64 sums)"""
+        c = np.ascontiguousarray(counts, dtype=np.uint32)
+        out = np.zeros(c.shape[0], dtype=np.uint64)
+        self._ck(self.lib.lqcov_debug_scan(self.h, c.ctypes.data, out.ctypes.data, c.shape[0]))
         return out
 
     def set_profiling(self, on, only: Optional[str] = None):

@@ -535,6 +535,15 @@ int lqcov_get_chains(lqcov_handle *h, int32_t *out, uint64_t cap, uint64_t *n_to
 	});
 }
 
+int lqcov_debug_sort_pairs(lqcov_handle *h, uint64_t *keys, uint64_t *vals, uint64_t n, unsigned bits, int key_bytes)
+{
+	return guard(h, [&] { h->debug_sort_pairs(keys, vals, n, bits, key_bytes); });
+}
+int lqcov_debug_scan(lqcov_handle *h, const uint32_t *in, uint64_t *out, uint64_t n)
+{
+	return guard(h, [&] { h->debug_scan(in, out, n); });
+}
+
 int lqcov_part_minimizers_dev(lqcov_handle *h, int part, const uint64_t **x_dev, const uint64_t **y_dev, uint64_t *n)
 {
 	return guard(h, [&] {

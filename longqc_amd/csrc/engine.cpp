@@ -2655,3 +2655,37 @@ int lqcov_handle::run_files(const char *target, const char *query, FILE *out, FI
 	if (n_sat) throw std::domain_error(std::to_string(n_sat) + " quer" + (n_sat == 1 ? "y" : "ies") + " with a saturated uint16 match counter (esterr.c:130,136) in merged counters: table written, rows flagged LQCOV_ROW_SATURATED without LQCOV_ROW_REPLAYED are not guaranteed");
 	return 0;
 }
+
+// ---- tests: the device-wide primitives on host arrays (lqcov_debug_sort_pairs / lqcov_debug_scan) ----------------------------------
+void lqcov_handle::debug_sort_pairs(u64 *keys, u64 *vals, u64 n, unsigned bits, int key_bytes)
+{
+	if (key_bytes != 4 && key_bytes != 8) throw std::invalid_argument("key_bytes must be 4 or 8");
+	if (!vals && key_bytes != 4) throw std::invalid_argument("keys-only sorts have 4-byte keys");
+	DBuf ki, ko, vi, vo;
+	ki.ensure(n * 8 + 8); ko.ensure(n * 8 + 8); vi.ensure(n * 8 + 8); vo.ensure(n * 8 + 8);
+	if (key_bytes == 4) {
+		std::vector<u32> k32(n);
+		for (u64 i = 0; i < n; ++i) k32[i] = (u32)keys[i];
+		h2d(ki.as<u32>(), k32.data(), n, stream);
+		if (vals) { h2d(vi.as<u64>(), vals, n, stream); prim.sort_pairs_u32_u64(ki.as<u32>(), ko.as<u32>(), vi.as<u64>(), vo.as<u64>(), n, bits); }
+		else prim.sort_keys_u32(ki.as<u32>(), ko.as<u32>(), n);
+		d2h(k32.data(), ko.as<u32>(), n, stream);
+		for (u64 i = 0; i < n; ++i) keys[i] = k32[i];
+	} else {
+		h2d(ki.as<u64>(), keys, n, stream); h2d(vi.as<u64>(), vals, n, stream);
+		prim.sort_pairs_u64(ki.as<u64>(), ko.as<u64>(), vi.as<u64>(), vo.as<u64>(), n, bits);
+		d2h(keys, ko.as<u64>(), n, stream);
+	}
+	if (vals) d2h(vals, vo.as<u64>(), n, stream);
+	LQ_HIP_CHECK(hipStreamSynchronize(stream));
+}
+
+void lqcov_handle::debug_scan(const u32 *in, u64 *out, u64 n)
+{
+	DBuf di, dout;
+	di.ensure(n * 4 + 4); dout.ensure(n * 8 + 8);
+	h2d(di.as<u32>(), in, n, stream);
+	prim.exclusive_scan_u32_u64(di.as<u32>(), dout.as<u64>(), n);
+	d2h(out, dout.as<u64>(), n, stream);
+	LQ_HIP_CHECK(hipStreamSynchronize(stream));
+}

@@ -298,6 +298,8 @@ struct lqcov_handle {
 	void batch_buffers(MapLane &L, u64 nA);
 	void chain_stage(MapLane &L, Part &pt, const u64 *aqb, u64 a_base, u32 nqb, u32 q0, const u32 *qmap, u64 nA, int tie_mode, u32 n_want, u32 ivl_cap, bool dbg, const SatSink *sink = nullptr);
 	void map_subset(MapLane &L, Part &pt, const std::vector<u32> &sq, const std::vector<u32> &sk, const std::vector<u64> &so, u64 max_mini, int tie_mode, u32 n_want, u32 ivl_cap, bool dbg, const SatSink *sink);
+	void debug_sort_pairs(u64 *keys, u64 *vals, u64 n, unsigned bits, int key_bytes);   // tests: the primitives of kernels_isort.hpp on host arrays
+	void debug_scan(const u32 *in, u64 *out, u64 n);
 	void sat_replay_part(Part &pt, const std::vector<u64> &h_aq, const std::vector<u64> &h_qmoff);
 	void sort_checked(MapLane &L, Part &pt, const u64 *aqb, const u32 *qkb, u32 nqb, u64 a_base, u64 nA, const std::vector<u64> &h_off, const std::vector<u32> &h_klib);
 	void sort_batch(MapLane &L, Part &pt, const u64 *aqb, const u32 *qkb, u32 nqb, u64 a_base, u64 nA);

@@ -36,20 +36,27 @@
 __device__ __forceinline__ void lq_is_publish(u64 *p, u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ u64 lq_is_peek(const u64 *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void lq_is_nap() { __builtin_amdgcn_s_sleep(2); }
+__device__ __forceinline__ u32 lq_xcc_id() { return (u32)__builtin_amdgcn_s_getreg(20 | (3 << 11)) & 15u; }   // HW_REG_XCC_ID, bits 3:0: the XCD this wave runs on
 #else
 inline void lq_is_publish(u64 *p, u64 v) { *p = v; }
 inline u64 lq_is_peek(const u64 *p) { return *p; }
 inline void lq_is_nap() {}
+inline u32 lq_xcc_id() { return blockIdx.x & 7u; }
 #endif
 
 template <class KT>
 __global__ void __launch_bounds__(256)
-k_is_hist(const KT *key, u64 n, u32 n_pass, u32 last_mask, u64 per_block, unsigned long long *ghist)
+k_is_hist(const KT *key, u64 n, u32 p0, u32 n_here, u32 n_pass, u32 last_mask, u64 per_block, u64 per_range, unsigned long long *ghist)
 {
+	// the digits of the passes p0 .. p0 + n_here - 1 of n_pass (all of them up front when the tiles are dealt in one range: the
+	// totals do not depend on the order of the keys; pass by pass on each pass's input when there is a histogram per range)
 	__shared__ u32 h[LQ_IS_MAXPASS * 256];
-	for (u32 i = threadIdx.x; i < n_pass * 256; i += 256) h[i] = 0;
+	for (u32 i = threadIdx.x; i < n_here * 256; i += 256) h[i] = 0;
 	__syncthreads();
-	const u64 lo = (u64)blockIdx.x * per_block, hi = lo + per_block < n ? lo + per_block : n;
+	// blockIdx.y: the range of tiles (one per XCD, k_is_pass) whose histogram this is
+	const u64 r_lo = (u64)blockIdx.y * per_range, r_hi = r_lo + per_range < n ? r_lo + per_range : n;
+	const u64 lo = r_lo + (u64)blockIdx.x * per_block, hi = lo + per_block < r_hi ? lo + per_block : r_hi;
+	ghist += (size_t)blockIdx.y * LQ_IS_MAXPASS * 256;
 	for (u64 base = lo; base < hi; base += 256 * 4) {
 		KT k[4];
 #pragma unroll
@@ -57,22 +64,23 @@ k_is_hist(const KT *key, u64 n, u32 n_pass, u32 last_mask, u64 per_block, unsign
 #pragma unroll
 		for (int j = 0; j < 4; ++j) {
 			const u64 i = base + (u64)j * 256 + threadIdx.x;
-			if (i < hi) for (u32 p = 0; p < n_pass; ++p) atomicAdd(&h[p * 256 + ((u32)(k[j] >> (8 * p)) & (p + 1 == n_pass ? last_mask : 255u))], 1u);
+			if (i < hi) for (u32 p = p0; p < p0 + n_here; ++p) atomicAdd(&h[(p - p0) * 256 + ((u32)(k[j] >> (8 * p)) & (p + 1 == n_pass ? last_mask : 255u))], 1u);
 		}
 	}
 	__syncthreads();
-	for (u32 i = threadIdx.x; i < n_pass * 256; i += 256) if (h[i]) atomicAdd(&ghist[i], (unsigned long long)h[i]);
+	for (u32 i = threadIdx.x; i < n_here * 256; i += 256) if (h[i]) atomicAdd(&ghist[p0 * 256 + i], (unsigned long long)h[i]);
 }
 
-// exclusive scan of every pass's 256 counts, in place (block p: pass p)
+// per pass (block p): where the output of every (range, digit) begins -- the digits' totals scanned, then the ranges in order
 template <int PASSES_MAX>
 __global__ void __launch_bounds__(256)
-k_is_bases(unsigned long long *ghist)
+k_is_bases(unsigned long long *ghist, u32 n_ranges, u32 p0)
 {
 	__shared__ u64 s[256];
-	unsigned long long *g = ghist + (size_t)blockIdx.x * 256;
+	unsigned long long *g = ghist + (size_t)(p0 + blockIdx.x) * 256;
 	const u32 t = threadIdx.x;
-	const u64 mine = g[t];
+	u64 mine = 0;
+	for (u32 r = 0; r < n_ranges; ++r) mine += g[(size_t)r * PASSES_MAX * 256 + t];
 	s[t] = mine;
 	__syncthreads();
 	for (u32 o = 1; o < 256; o <<= 1) {
@@ -81,7 +89,8 @@ k_is_bases(unsigned long long *ghist)
 		s[t] += add;
 		__syncthreads();
 	}
-	g[t] = s[t] - mine;
+	u64 at = s[t] - mine;
+	for (u32 r = 0; r < n_ranges; ++r) { const u64 c = g[(size_t)r * PASSES_MAX * 256 + t]; g[(size_t)r * PASSES_MAX * 256 + t] = at; at += c; }
 }
 
 // pairs per thread: as many as keep the staged tile at 45 KB (three blocks per CU), 16 at most
@@ -92,7 +101,8 @@ struct LqIsShape { static constexpr int BYTES = (int)sizeof(KT) + (PAIRS ? (int)
 
 template <class KT, class VT, bool PAIRS>
 __global__ void __launch_bounds__(LQ_IS_THREADS)
-k_is_pass(const KT *kin, KT *kout, const VT *vin, VT *vout, u64 n, u32 shift, u32 mask, u32 pass, const unsigned long long *gbase, u64 *status, u32 *ticket)
+k_is_pass(const KT *kin, KT *kout, const VT *vin, VT *vout, u64 n, u32 shift, u32 mask, u32 pass, const unsigned long long *gbase, u64 *status, u32 *ticket,
+          u32 n_ranges, u32 range_tiles, u32 n_tiles)
 {
 	constexpr int E = LqIsShape<KT, VT, PAIRS>::E;
 	constexpr u32 TILE = LQ_IS_THREADS * E;
@@ -100,14 +110,29 @@ k_is_pass(const KT *kin, KT *kout, const VT *vin, VT *vout, u64 n, u32 shift, u3
 	__shared__ u32 toff[256];                   // where the digit's run begins inside the tile
 	__shared__ u64 gdel[256];                   // global index of a staged pair = gdel[digit] + its slot in the tile
 	__shared__ u32 wsum[LQ_IS_WAVES];
-	__shared__ u32 s_tile;
+	__shared__ u32 s_tile, s_first;
 	__shared__ KT sk[TILE];
 	__shared__ VT sv[PAIRS ? TILE : 1];
 	const u32 tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-	if (tid == 0) s_tile = atomicAdd(ticket, 1u);
+	// The tiles are dealt in n_ranges contiguous ranges, one per XCD: a block takes the next tile of the range of the XCD it runs on
+	// (a ticket per range: a tile's predecessors have always started), so that the runs neighbouring tiles write for a digit -- a
+	// few dozen bytes each -- meet in ONE L2 and leave it as whole lines.  Placement is only a matter of speed: a block whose
+	// range is used up takes a tile of the next one (as many blocks as tiles: every block finds one).
+	if (tid == 0) {
+		const u32 x = lq_xcc_id() % n_ranges;
+		u32 r = x, j = 0;
+		for (u32 a = 0; a < n_ranges; ++a) {
+			r = x + a < n_ranges ? x + a : x + a - n_ranges;
+			const u32 first = r * range_tiles, cap = first >= n_tiles ? 0u : (n_tiles - first < range_tiles ? n_tiles - first : range_tiles);
+			j = cap ? atomicAdd(&ticket[r], 1u) : 0u;
+			if (j < cap) break;
+		}
+		s_first = r * range_tiles; s_tile = r * range_tiles + j;
+	}
 	for (u32 i = tid; i < LQ_IS_WAVES * 256; i += LQ_IS_THREADS) (&wc[0][0])[i] = 0;
 	__syncthreads();
-	const u32 tile = s_tile;
+	const u32 tile = s_tile, first = s_first;
+	gbase += (size_t)(first / range_tiles) * LQ_IS_MAXPASS * 256;
 	const u64 t0 = (u64)tile * TILE;
 	const u32 tn = n - t0 < (u64)TILE ? (u32)(n - t0) : TILE;
 	// the wave's E * 64 consecutive pairs, 64 at a time
@@ -147,7 +172,7 @@ k_is_pass(const KT *kin, KT *kout, const VT *vin, VT *vout, u64 n, u32 shift, u3
 		for (int i = 0; i < LQ_IS_WAVES; ++i) { const u32 c = wc[i][d]; wc[i][d] = run; run += c; }
 		u64 *mine = status + (size_t)tile * 256 + d;
 		const u64 f_own = (u64)(2 * pass + 1) << 56, f_all = (u64)(2 * pass + 2) << 56;
-		if (tile > 0) lq_is_publish(mine, f_own | run);
+		if (tile > first) lq_is_publish(mine, f_own | run);
 		// exclusive scan of the tile's counts over the digits
 		u32 inc = run;
 #pragma unroll
@@ -160,7 +185,7 @@ k_is_pass(const KT *kin, KT *kout, const VT *vin, VT *vout, u64 n, u32 shift, u3
 		const u32 off = before + inc - run;
 		toff[d] = off;
 		u64 excl = 0;
-		for (u32 p = tile; p-- > 0; ) {
+		for (u32 p = tile; p-- > first; ) {
 			const u64 *g = status + (size_t)p * 256 + d;
 			u64 s = lq_is_peek(g);
 			while (LQ_IS_FLAG(s) != 2 * pass + 1 && LQ_IS_FLAG(s) != 2 * pass + 2) { lq_is_nap(); s = lq_is_peek(g); }

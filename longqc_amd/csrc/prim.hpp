@@ -5,6 +5,7 @@
 #include "lq_common.hpp"
 #include "kernels_isort.hpp"
 #include <stdexcept>
+#include <cstdlib>
 #include <utility>
 #include <string>
 
@@ -123,6 +124,19 @@ struct DBuf {
 	DBuf(const DBuf&) = delete; DBuf &operator=(const DBuf&) = delete;
 };
 
+// ranges of tiles of the radix sort's passes (kernels_isort.hpp): one per XCD; LQCOV_IS_RANGES=1: one range, tiles in start order
+inline u32 lq_is_ranges()
+{
+	const char *e = std::getenv("LQCOV_IS_RANGES"); const long x = e ? std::atol(e) : 8;
+	return (u32)(x < 1 ? 1 : x > 8 ? 8 : x);
+}
+
+inline size_t lq_is_ranges_min_tiles()                        // (tests: LQCOV_IS_RANGES_MIN_TILES=2 brings the ranges to small inputs)
+{
+	const char *e = std::getenv("LQCOV_IS_RANGES_MIN_TILES"); const long x = e ? std::atol(e) : 64;
+	return (size_t)(x < 1 ? 1 : x);
+}
+
 struct Prim {
 	DBuf tmp;
 	hipStream_t stream = nullptr;
@@ -154,7 +168,8 @@ struct Prim {
 		if (n_tiles > 0x7fffffffULL) throw std::domain_error("radix sort: too many tiles");
 		if (ktmp == kin && n_pass % 2 == 0) ktmp = nullptr;
 		const auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
-		const size_t b_status = up(n_tiles * 256 * 8), b_hist = LQ_IS_MAXPASS * 256 * 8, b_ticket = 256, ctl = b_status + b_hist + b_ticket;
+		const u32 n_ranges = n_tiles >= lq_is_ranges_min_tiles() ? lq_is_ranges() : 1u, range_tiles = (u32)((n_tiles + n_ranges - 1) / n_ranges);
+		const size_t b_status = up(n_tiles * 256 * 8), b_hist = (size_t)n_ranges * LQ_IS_MAXPASS * 256 * 8, b_ticket = LQ_IS_MAXPASS * 8 * 4, ctl = b_status + b_hist + b_ticket;
 		const size_t b_k = n_pass > 1 && !ktmp ? up(n * sizeof(KT)) : 0, b_v = PAIRS && n_pass > 1 && !vtmp ? up(n * sizeof(VT)) : 0;
 		tmp.ensure(ctl + b_k + b_v);
 		char *base = tmp.as<char>();
@@ -164,14 +179,21 @@ struct Prim {
 		if (b_k) ktmp = (KT*)(base + ctl);
 		if (b_v) vtmp = (VT*)(base + ctl + b_k);
 		LQ_HIP_CHECK(hipMemsetAsync(base, 0, ctl, stream));
-		const size_t hb = std::min<size_t>(4096, (n + 1023) / 1024), per = ((n + hb - 1) / hb + 1023) / 1024 * 1024;
-		LQ_LAUNCH(k_is_hist<KT>, (u32)((n + per - 1) / per), 256, stream, kin, (u64)n, n_pass, last_mask, (u64)per, ghist);
-		LQ_LAUNCH(k_is_bases<LQ_IS_MAXPASS>, n_pass, 256, stream, ghist);
+		const size_t per_range = (size_t)range_tiles * TILE, hb = std::min<size_t>(4096 / n_ranges, (per_range + 1023) / 1024), per = ((per_range + hb - 1) / hb + 1023) / 1024 * 1024;
+		const dim3 hgrid((u32)((per_range + per - 1) / per), n_ranges);
+		if (n_ranges == 1) {
+			LQ_LAUNCH(k_is_hist<KT>, hgrid, 256, stream, kin, (u64)n, 0u, n_pass, n_pass, last_mask, (u64)per, (u64)per_range, ghist);
+			LQ_LAUNCH(k_is_bases<LQ_IS_MAXPASS>, n_pass, 256, stream, ghist, n_ranges, 0u);
+		}
 		const KT *ki = kin; const VT *vi = vin;
 		for (u32 p = 0; p < n_pass; ++p) {
 			const bool to_out = (n_pass - 1 - p) % 2 == 0;
 			KT *ko = to_out ? kout : ktmp; VT *vo = to_out ? vout : vtmp;
-			LQ_LAUNCH((k_is_pass<KT, VT, PAIRS>), (u32)n_tiles, LQ_IS_THREADS, stream, ki, ko, vi, vo, (u64)n, 8 * p, p + 1 == n_pass ? last_mask : 255u, p, ghist, status, ticket + p);
+			if (n_ranges > 1) {                                     // a histogram per range of tiles: of this pass's input order
+				LQ_LAUNCH(k_is_hist<KT>, hgrid, 256, stream, ki, (u64)n, p, 1u, n_pass, last_mask, (u64)per, (u64)per_range, ghist);
+				LQ_LAUNCH(k_is_bases<LQ_IS_MAXPASS>, 1, 256, stream, ghist, n_ranges, p);
+			}
+			LQ_LAUNCH((k_is_pass<KT, VT, PAIRS>), (u32)n_tiles, LQ_IS_THREADS, stream, ki, ko, vi, vo, (u64)n, 8 * p, p + 1 == n_pass ? last_mask : 255u, p, ghist, status, ticket + 8 * p, n_ranges, range_tiles, (u32)n_tiles);
 			ki = ko; vi = vo;
 		}
 		LQ_HIP_CHECK(hipGetLastError());
