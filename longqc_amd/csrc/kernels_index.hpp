@@ -49,6 +49,17 @@ __device__ __forceinline__ u32 lq_head_bits(const KT *key, u64 n, u64 i0, KT *mi
 {
 	u32 bits = 0;
 	KT prev = i0 > 0 && i0 <= n ? key[i0 - 1] : (KT)0;
+	if (i0 + LQ_HEAD_PER <= n) {                                 // the thread's 8 keys as 16-byte loads (i0 is a multiple of 8: aligned): a wave reads 2 or 4 KB in one piece
+		constexpr int NV = LQ_HEAD_PER * (int)sizeof(KT) / 16;
+		const uint4 *src = reinterpret_cast<const uint4*>(key + i0);
+		uint4 q[NV];
+#pragma unroll
+		for (int j = 0; j < NV; ++j) q[j] = src[j];
+		memcpy(mine, q, sizeof(q));
+#pragma unroll
+		for (int k = 0; k < LQ_HEAD_PER; ++k) { if ((i0 == 0 && k == 0) || mine[k] != prev) bits |= 1u << k; prev = mine[k]; }
+		return bits;
+	}
 #pragma unroll
 	for (int k = 0; k < LQ_HEAD_PER; ++k) {
 		const u64 i = i0 + (u64)k;

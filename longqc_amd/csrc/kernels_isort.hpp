@@ -26,6 +26,15 @@
 #define LQ_IS_THREADS 256
 #define LQ_IS_WAVES   (LQ_IS_THREADS / 64)
 #define LQ_IS_MAXPASS 8
+#ifndef LQ_IS_FIT_KB
+#define LQ_IS_FIT_KB 45
+#endif
+#ifndef LQ_IS_EMAX
+#define LQ_IS_EMAX 22
+#endif
+#ifndef LQ_IS_FASTPATH
+#define LQ_IS_FASTPATH 0
+#endif
 
 // {flag, count} granule of one (tile, digit): flag = 2 * pass + 1 (the tile's own count) or 2 * pass + 2 (count of the tile and
 // every tile before it); granules are zeroed once per sort, the pass number keeps the passes apart
@@ -95,9 +104,9 @@ k_is_bases(unsigned long long *ghist, u32 n_ranges, u32 p0)
 
 // pairs per thread: as many as keep the staged tile at 45 KB (three blocks per CU), 16 at most
 template <class KT, class VT, bool PAIRS>
-struct LqIsShape { static constexpr int BYTES = (int)sizeof(KT) + (PAIRS ? (int)sizeof(VT) : 0);
-                   static constexpr int FIT = 45 * 1024 / (LQ_IS_THREADS * BYTES);
-                   static constexpr int E = FIT > 16 ? 16 : FIT; };
+struct LqIsShape { static constexpr int BYTES = PAIRS && sizeof(VT) > sizeof(KT) ? (int)sizeof(VT) : (int)sizeof(KT);   // keys and values take turns in the staging buffer
+                   static constexpr int FIT = LQ_IS_FIT_KB * 1024 / (LQ_IS_THREADS * (BYTES + (PAIRS ? 1 : 0)));   // (+ the digit byte of a slot)
+                   static constexpr int E = FIT > LQ_IS_EMAX ? LQ_IS_EMAX : FIT; };
 
 template <class KT, class VT, bool PAIRS>
 __global__ void __launch_bounds__(LQ_IS_THREADS)
@@ -111,8 +120,10 @@ k_is_pass(const KT *kin, KT *kout, const VT *vin, VT *vout, u64 n, u32 shift, u3
 	__shared__ u64 gdel[256];                   // global index of a staged pair = gdel[digit] + its slot in the tile
 	__shared__ u32 wsum[LQ_IS_WAVES];
 	__shared__ u32 s_tile, s_first;
-	__shared__ KT sk[TILE];
-	__shared__ VT sv[PAIRS ? TILE : 1];
+	__shared__ __attribute__((aligned(16))) char stage[TILE * LqIsShape<KT, VT, PAIRS>::BYTES];   // the tile in digit order: first its values, then its keys
+	__shared__ u8 sdig[PAIRS ? TILE : 1];      // the digit of every slot (the values' pass has no key to take it from)
+	KT *sk = reinterpret_cast<KT*>(stage);
+	VT *sv = reinterpret_cast<VT*>(stage);
 	const u32 tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
 	// The tiles are dealt in n_ranges contiguous ranges, one per XCD: a block takes the next tile of the range of the XCD it runs on
 	// (a ticket per range: a tile's predecessors have always started), so that the runs neighbouring tiles write for a digit -- a
@@ -172,7 +183,13 @@ k_is_pass(const KT *kin, KT *kout, const VT *vin, VT *vout, u64 n, u32 shift, u3
 		for (int i = 0; i < LQ_IS_WAVES; ++i) { const u32 c = wc[i][d]; wc[i][d] = run; run += c; }
 		u64 *mine = status + (size_t)tile * 256 + d;
 		const u64 f_own = (u64)(2 * pass + 1) << 56, f_all = (u64)(2 * pass + 2) << 56;
-		if (tile > first) lq_is_publish(mine, f_own | run);
+		u64 excl = 0;
+		bool have_excl = tile == first;
+		if (LQ_IS_FASTPATH && tile > first) {                      // the predecessor's inclusive prefix is already there: one granule instead of two
+			const u64 s = lq_is_peek(mine - 256);
+			if (LQ_IS_FLAG(s) == 2 * pass + 2) { excl = LQ_IS_VAL(s); have_excl = true; }
+		}
+		if (!have_excl) lq_is_publish(mine, f_own | run);
 		// exclusive scan of the tile's counts over the digits
 		u32 inc = run;
 #pragma unroll
@@ -184,8 +201,7 @@ k_is_pass(const KT *kin, KT *kout, const VT *vin, VT *vout, u64 n, u32 shift, u3
 		for (int i = 0; i < LQ_IS_WAVES; ++i) if ((u32)i < w) before += wsum[i];
 		const u32 off = before + inc - run;
 		toff[d] = off;
-		u64 excl = 0;
-		for (u32 p = tile; p-- > first; ) {
+		if (!have_excl) for (u32 p = tile; p-- > first; ) {
 			const u64 *g = status + (size_t)p * 256 + d;
 			u64 s = lq_is_peek(g);
 			while (LQ_IS_FLAG(s) != 2 * pass + 1 && LQ_IS_FLAG(s) != 2 * pass + 2) { lq_is_nap(); s = lq_is_peek(g); }
@@ -196,26 +212,39 @@ k_is_pass(const KT *kin, KT *kout, const VT *vin, VT *vout, u64 n, u32 shift, u3
 		gdel[d] = (u64)gbase[pass * 256 + d] + excl - off;
 	}
 	__syncthreads();
+	// slot of every pair in digit order (kept in r[]), then the values through the staging buffer, then the keys
 #pragma unroll
 	for (int e = 0; e < E; ++e) {
 		const u32 idx = w * (E * 64) + e * 64 + lane;
 		if (idx < tn) {
 			const u32 d = ((u32)(k[e] >> shift) & mask);
-			const u32 slot = toff[d] + wc[w][d] + r[e];
-			sk[slot] = k[e];
-			if (PAIRS) sv[slot] = v[e];
+			r[e] = toff[d] + wc[w][d] + r[e];
 		}
+	}
+	if (PAIRS) {
+#pragma unroll
+		for (int e = 0; e < E; ++e) {
+			const u32 idx = w * (E * 64) + e * 64 + lane;
+			if (idx < tn) { sv[r[e]] = v[e]; sdig[r[e]] = (u8)((u32)(k[e] >> shift) & mask); }
+		}
+		__syncthreads();
+#pragma unroll
+		for (int e = 0; e < E; ++e) {
+			const u32 s = e * LQ_IS_THREADS + tid;
+			if (s < tn) vout[gdel[sdig[s]] + s] = sv[s];
+		}
+		__syncthreads();
+	}
+#pragma unroll
+	for (int e = 0; e < E; ++e) {
+		const u32 idx = w * (E * 64) + e * 64 + lane;
+		if (idx < tn) sk[r[e]] = k[e];
 	}
 	__syncthreads();
 #pragma unroll
 	for (int e = 0; e < E; ++e) {
 		const u32 s = e * LQ_IS_THREADS + tid;
-		if (s < tn) {
-			const KT kk = sk[s];
-			const u64 g = gdel[(u32)(kk >> shift) & mask] + s;
-			kout[g] = kk;
-			if (PAIRS) vout[g] = sv[s];
-		}
+		if (s < tn) { const KT kk = sk[s]; kout[gdel[(u32)(kk >> shift) & mask] + s] = kk; }
 	}
 }
 

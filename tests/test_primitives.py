@@ -37,7 +37,7 @@ def _check_sort(eng, rng, n, bits, key_bytes, kind, pairs=True):
         assert np.array_equal(v, vals[order])
 
 
-SIZES = [0, 1, 63, 64, 65, 3839, 3840, 3841, 4096, 11000, 40000]
+SIZES = [0, 1, 63, 64, 65, 3839, 3840, 3841, 5119, 5120, 5121, 11000, 40000]
 
 
 def _run_all(eng, sizes, big):
