@@ -226,6 +226,26 @@ int lqcov_get_part_minimizers(lqcov_handle *h, int part, uint64_t *xy, uint64_t 
  * (query, rid, rev, score, cnt, qs, qe, rs, re), unordered. */
 int lqcov_get_chains(lqcov_handle *h, int32_t *out, uint64_t cap, uint64_t *n_total);
 
+/* Saturated uint16 match counters with the index parts spread over ranks (esterr.c:127-138: once a counter is at 65535 the
+ * others depend on the order in which lq_cnt_match met the chains, hit.c:52-88 -- on one handle the engine replays that by
+ * itself).  The ranks see a counter reach the limit only in the merged sums; then, for that query (engine order:
+ * lqcov_query_order) and every part of the round in part order:
+ *   lqcov_part_sat_records   on the rank that mapped the part: the query is chained once more against it, every kept chain
+ *                            recorded (records of lqcov_sat_record_bytes() bytes + a pool of counter indices); call with
+ *                            recs == NULL to get the two counts in n_out first (the chaining is done once and kept);
+ *   lqcov_sat_replay         on every rank, host arithmetic only: the records replayed in the reference's order on the query's
+ *                            counters (lqcov_counter_offsets: counters[off[q]] .. counters[off[q + 1] - 1] of the exported
+ *                            array) as they stood before the part; lqcov_counter_max: 65535 (the uint16 limit);
+ *   lqcov_accum_set_replayed after lqcov_accum_import_dev: these counters take the place of the merged sums, the row carries
+ *                            LQCOV_ROW_REPLAYED. */
+uint32_t lqcov_sat_record_bytes(void);
+uint32_t lqcov_counter_max(const lqcov_handle *h);
+int lqcov_counter_offsets(lqcov_handle *h, uint64_t *off /* n_queries + 1 */);
+int lqcov_part_sat_records(lqcov_handle *h, int part, uint32_t query, void *recs, uint64_t rec_cap, uint32_t *at, uint64_t at_cap, uint64_t n_out[2]);
+int lqcov_sat_replay(lqcov_handle *h, uint32_t query, const void *recs, uint64_t n_recs, const uint32_t *at, uint64_t n_at,
+                     uint32_t *counters, uint64_t n_counters);
+int lqcov_accum_set_replayed(lqcov_handle *h, uint32_t query, const uint32_t *counters, uint64_t n_counters);
+
 /* Test access to the engine's device-wide primitives (kernels_isort.hpp; they stand where the reference calls klib's
  * radix_sort_128x on a bucket of minimizers, index.c:150-201): a stable sort of n (key, value) pairs by the low `bits` bits of
  * the keys (key_bytes 4: the keys travel as 32-bit words, as for k <= 16; 8: as 64-bit words; vals == NULL: keys only, 4-byte

@@ -119,6 +119,12 @@ def load_library(path: Optional[str] = None):
         "lqcov_get_query_minimizers": (C.c_int, [H, C.c_void_p, C.c_void_p, u64p]),
         "lqcov_get_part_minimizers": (C.c_int, [H, C.c_int, C.c_void_p, C.c_void_p, u64p]),
         "lqcov_get_chains": (C.c_int, [H, C.c_void_p, C.c_uint64, u64p]),
+        "lqcov_sat_record_bytes": (C.c_uint32, []),
+        "lqcov_counter_max": (C.c_uint32, [H]),
+        "lqcov_counter_offsets": (C.c_int, [H, C.c_void_p]),
+        "lqcov_part_sat_records": (C.c_int, [H, C.c_int, C.c_uint32, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, u64p]),
+        "lqcov_sat_replay": (C.c_int, [H, C.c_uint32, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64]),
+        "lqcov_accum_set_replayed": (C.c_int, [H, C.c_uint32, C.c_void_p, C.c_uint64]),
         "lqcov_debug_sort_pairs": (C.c_int, [H, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint, C.c_int]),
         "lqcov_debug_scan": (C.c_int, [H, C.c_void_p, C.c_void_p, C.c_uint64]),
         "lqcov_part_minimizers_dev": (C.c_int, [H, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), u64p]),
@@ -468,6 +474,35 @@ class Engine:
         out = np.zeros((n.value, 9), dtype=np.int32)
         self._ck(self.lib.lqcov_get_chains(self.h, out.ctypes.data, n.value, C.byref(n)))
         return out
+
+    # -- saturated counters with the parts spread over ranks (multigpu.PartRunner) --
+    def counter_max(self) -> int:
+        return int(self.lib.lqcov_counter_max(self.h))
+
+    def counter_offsets(self) -> np.ndarray:
+        """off[q] .. off[q + 1]: the counters of query q (engine order) in the exported counter array"""
+        off = np.zeros(self.lib.lqcov_n_queries(self.h) + 1, dtype=np.uint64)
+        self._ck(self.lib.lqcov_counter_offsets(self.h, off.ctypes.data))
+        return off
+
+    def part_sat_records(self, part: int, query: int) -> Tuple[np.ndarray, np.ndarray]:
+        """every kept chain of `query` (engine order) against the mapped part: (records as uint8[n, record bytes], counter index pool)"""
+        n = (C.c_uint64 * 2)()
+        self._ck(self.lib.lqcov_part_sat_records(self.h, part, query, None, 0, None, 0, n))
+        rb = int(self.lib.lqcov_sat_record_bytes())
+        recs = np.zeros((max(int(n[0]), 1), rb), dtype=np.uint8); at = np.zeros(max(int(n[1]), 1), dtype=np.uint32)
+        self._ck(self.lib.lqcov_part_sat_records(self.h, part, query, recs.ctypes.data, int(n[0]), at.ctypes.data, int(n[1]), n))
+        return recs[:int(n[0])], at[:int(n[1])]
+
+    def sat_replay(self, query: int, recs: np.ndarray, at: np.ndarray, counters: np.ndarray) -> np.ndarray:
+        recs = np.ascontiguousarray(recs, dtype=np.uint8); at = np.ascontiguousarray(at, dtype=np.uint32)
+        c = np.ascontiguousarray(counters, dtype=np.uint32).copy()
+        self._ck(self.lib.lqcov_sat_replay(self.h, query, recs.ctypes.data, recs.shape[0], at.ctypes.data, at.shape[0], c.ctypes.data, c.shape[0]))
+        return c
+
+    def accum_set_replayed(self, query: int, counters: np.ndarray):
+        c = np.ascontiguousarray(counters, dtype=np.uint32)
+        self._ck(self.lib.lqcov_accum_set_replayed(self.h, query, c.ctypes.data, c.shape[0]))
 
     def debug_sort_pairs(self, keys: np.ndarray, vals: Optional[np.ndarray], bits: int, key_bytes: int = 4):
         """tests: the engine's stable radix sort (kernels_isort.hpp) on host arrays; returns (keys, vals) sorted"""

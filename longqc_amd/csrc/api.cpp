@@ -535,6 +535,55 @@ int lqcov_get_chains(lqcov_handle *h, int32_t *out, uint64_t cap, uint64_t *n_to
 	});
 }
 
+uint32_t lqcov_sat_record_bytes(void) { return (uint32_t)sizeof(SatRec); }
+
+uint32_t lqcov_counter_max(const lqcov_handle *h) { return h ? h->cnt_max : 0u; }
+
+int lqcov_counter_offsets(lqcov_handle *h, uint64_t *off)
+{
+	return guard(h, [&] {
+		if (!h->have_queries || !off) throw std::invalid_argument("no queries / no buffer");
+		LQ_HIP_CHECK(hipMemcpy(off, h->cnt_off_dev(), ((size_t)h->q.n + 1) * 8, hipMemcpyDeviceToHost));
+	});
+}
+
+int lqcov_part_sat_records(lqcov_handle *h, int part, uint32_t query, void *recs, uint64_t rec_cap, uint32_t *at, uint64_t at_cap, uint64_t n_out[2])
+{
+	return guard(h, [&] {
+		Part &pt = h->part(part);
+		if (!(h->sat_last_part == part && h->sat_last_query == query && h->sat_last_valid)) {
+			h->sat_last_valid = false;
+			h->part_sat_records(pt, query, h->sat_last_recs, h->sat_last_at);
+			h->sat_last_part = part; h->sat_last_query = query; h->sat_last_valid = true;
+		}
+		if (n_out) { n_out[0] = h->sat_last_recs.size(); n_out[1] = h->sat_last_at.size(); }
+		if (recs) {
+			if (rec_cap < h->sat_last_recs.size() || at_cap < h->sat_last_at.size() || (!at && !h->sat_last_at.empty())) throw std::invalid_argument("record buffers too small");
+			if (!h->sat_last_recs.empty()) memcpy(recs, h->sat_last_recs.data(), h->sat_last_recs.size() * sizeof(SatRec));
+			if (!h->sat_last_at.empty()) memcpy(at, h->sat_last_at.data(), h->sat_last_at.size() * 4);
+			h->sat_last_valid = false; h->sat_last_recs.clear(); h->sat_last_at.clear();
+		}
+	});
+}
+
+int lqcov_sat_replay(lqcov_handle *h, uint32_t query, const void *recs, uint64_t n_recs, const uint32_t *at, uint64_t n_at, uint32_t *counters, uint64_t n_counters)
+{
+	return guard(h, [&] {
+		if (!h->have_queries) throw std::logic_error("no queries");
+		if ((n_recs && !recs) || (n_at && !at) || (n_counters && !counters)) throw std::invalid_argument("null buffers");
+		h->sat_replay_host(query, (const SatRec*)recs, n_recs, at, n_at, counters, n_counters);
+	});
+}
+
+int lqcov_accum_set_replayed(lqcov_handle *h, uint32_t query, const uint32_t *counters, uint64_t n_counters)
+{
+	return guard(h, [&] {
+		if (!h->have_queries || query >= h->q.n) throw std::invalid_argument("no such query");
+		h->sat_cnt[query] = std::vector<u32>(counters, counters + n_counters);
+		h->finished = false;
+	});
+}
+
 int lqcov_debug_sort_pairs(lqcov_handle *h, uint64_t *keys, uint64_t *vals, uint64_t n, unsigned bits, int key_bytes)
 {
 	return guard(h, [&] { h->debug_sort_pairs(keys, vals, n, bits, key_bytes); });

@@ -1012,30 +1012,15 @@ void lqcov_handle::sat_replay_part(Part &pt, const std::vector<u64> &h_aq, const
 	for (u32 i = 0; i < n_q; ++i) any |= (hf[i] & 1u) != 0;
 	if (!any) return;
 	d2h(hs.data(), skip.as<u32>(), n_q, stream);
-	MapLane &L = *lanes[0];
-	sat_n.ensure(16);
 	for (u32 qi = 0; qi < n_q; ++qi) {
 		if (!(hf[qi] & 1u) || hs[qi]) continue;               // (skip: esterr.c:87 returned before anything was counted)
-		const u64 len = h_aq[qi + 1] - h_aq[qi];
-		if (!len) continue;
-		if (len > (1ULL << 31) - 4096) throw std::domain_error("query " + q.names[qi] + ": too many anchors against one index part for the replay of its saturated counters");
-		const u64 rec_cap = len / (u64)std::max<i32>(P.min_cnt, 1) + 1, at_cap = len;
-		sat_rec.ensure(rec_cap * sizeof(SatRec)); sat_at.ensure(at_cap * 4 + 4);
-		dzero(sat_n.p, 16, L.stream);
-		const SatSink sink{sat_rec.as<SatRec>(), sat_n.as<unsigned long long>(), rec_cap, sat_at.as<u32>(), sat_n.as<unsigned long long>() + 1, at_cap};
-		L.n_segs.ensure(64); L.n_ivl.ensure(4); L.n_sens.ensure(32); L.want.ensure(8); L.ivl.ensure(sizeof(Ivl));
-		map_subset(L, pt, std::vector<u32>{qi}, std::vector<u32>{len > LQ_RS_MIN ? 1u : 0u}, std::vector<u64>{0, len}, h_qmoff[qi + 1] - h_qmoff[qi], 0, 0, 0, false, &sink);
-		unsigned long long nn[2] = {0, 0};
-		d2h(nn, sat_n.as<unsigned long long>(), 2, L.stream);
-		if (nn[0] > rec_cap || nn[1] > at_cap) throw std::runtime_error("replay of saturated counters: record pool overflow");
-		std::vector<SatRec> recs(nn[0]); std::vector<u32> at(nn[1]);
-		d2h(recs.data(), sat_rec.as<SatRec>(), nn[0], L.stream); d2h(at.data(), sat_at.as<u32>(), nn[1], L.stream);
-		stat_sat_chains += nn[0];
+		std::vector<SatRec> recs; std::vector<u32> at;
+		if (!sat_chains(pt, qi, h_aq, h_qmoff, recs, at)) continue;
+		MapLane &L = *lanes[0];
 		u64 off[2];
 		d2h(off, cnt_off_dev() + qi, 2, L.stream);
 		const size_t nc = (size_t)(off[1] - off[0]);
-		for (const SatRec &c : recs) if (c.good && (c.sti < 0 || (size_t)c.sti >= nc || c.at_off + c.n_at > at.size())) throw std::runtime_error("replay of saturated counters: inconsistent chain record");
-		for (u32 v : at) if ((size_t)v >= nc) throw std::runtime_error("replay of saturated counters: inconsistent chain record");
+		sat_check(recs, at, nc);
 		auto it = sat_cnt.find(qi);
 		if (it == sat_cnt.end()) {
 			std::vector<u32> c(nc);
@@ -1052,6 +1037,61 @@ void lqcov_handle::sat_replay_part(Part &pt, const std::vector<u64> &h_aq, const
 		const std::vector<u32> order = satreplay::regs_order(recs, satreplay::query_hash(q.names[qi], (i32)q.h_len[qi], 11 /* map.c:15 */));
 		satreplay::replay(it->second, recs, at, order, cnt_max);
 	}
+}
+
+// every kept chain of query qi against this part, recorded (the part's plan in place, the lanes made: after map_part); false: no anchors
+bool lqcov_handle::sat_chains(Part &pt, u32 qi, const std::vector<u64> &h_aq, const std::vector<u64> &h_qmoff, std::vector<SatRec> &recs, std::vector<u32> &at)
+{
+	recs.clear(); at.clear();
+	if (lanes.empty()) throw std::logic_error("the part has not been mapped yet");
+	MapLane &L = *lanes[0];
+	sat_n.ensure(16);
+	const u64 len = h_aq[qi + 1] - h_aq[qi];
+	if (!len) return false;
+	if (len > (1ULL << 31) - 4096) throw std::domain_error("query " + q.names[qi] + ": too many anchors against one index part for the replay of its saturated counters");
+	const u64 rec_cap = len / (u64)std::max<i32>(P.min_cnt, 1) + 1, at_cap = len;
+	sat_rec.ensure(rec_cap * sizeof(SatRec)); sat_at.ensure(at_cap * 4 + 4);
+	dzero(sat_n.p, 16, L.stream);
+	const SatSink sink{sat_rec.as<SatRec>(), sat_n.as<unsigned long long>(), rec_cap, sat_at.as<u32>(), sat_n.as<unsigned long long>() + 1, at_cap};
+	L.n_segs.ensure(64); L.n_ivl.ensure(4); L.n_sens.ensure(32); L.want.ensure(8); L.ivl.ensure(sizeof(Ivl));
+	map_subset(L, pt, std::vector<u32>{qi}, std::vector<u32>{len > LQ_RS_MIN ? 1u : 0u}, std::vector<u64>{0, len}, h_qmoff[qi + 1] - h_qmoff[qi], 0, 0, 0, false, &sink);
+	unsigned long long nn[2] = {0, 0};
+	d2h(nn, sat_n.as<unsigned long long>(), 2, L.stream);
+	if (nn[0] > rec_cap || nn[1] > at_cap) throw std::runtime_error("replay of saturated counters: record pool overflow");
+	recs.resize(nn[0]); at.resize(nn[1]);
+	d2h(recs.data(), sat_rec.as<SatRec>(), nn[0], L.stream); d2h(at.data(), sat_at.as<u32>(), nn[1], L.stream);
+	stat_sat_chains += nn[0];
+	return true;
+}
+
+void lqcov_handle::sat_check(const std::vector<SatRec> &recs, const std::vector<u32> &at, size_t nc)
+{
+	for (const SatRec &c : recs) if (c.good && (c.sti < 0 || (size_t)c.sti >= nc || c.at_off + c.n_at > at.size())) throw std::runtime_error("replay of saturated counters: inconsistent chain record");
+	for (u32 v : at) if ((size_t)v >= nc) throw std::runtime_error("replay of saturated counters: inconsistent chain record");
+}
+
+// ---- the same for index parts spread over ranks (multigpu.PartRunner): the rank that mapped a part records a flagged query's chains
+// against it (lqcov_part_sat_records), every rank replays the gathered records part by part on the counters the query had before the
+// first part of the round (lqcov_sat_replay: host arithmetic only) and hands the result to finish() (lqcov_accum_set_replayed)
+void lqcov_handle::part_sat_records(Part &pt, u32 qi, std::vector<SatRec> &recs, std::vector<u32> &at)
+{
+	if (qi >= q.n) throw std::invalid_argument("no such query");
+	if (!pt.built) throw std::logic_error("part not built");
+	if (!pt.plan.valid || pt.plan.mid_occ != mid_occ || pt.plan.n_q != q.n || pt.plan.n_qm != q.n_mini || (pt.plan.bucketed && pt.plan.q_begin != 0)) plan_part(pt, stream, prim);   // (as map_part does)
+	swap_plan(pt.plan);
+	struct PlanGuard { lqcov_handle *h; SeedPlan &S; ~PlanGuard() { h->swap_plan(S); } } plan_guard{this, pt.plan};
+	sat_chains(pt, qi, pt.plan.h_aq, pt.plan.h_qmoff, recs, at);
+	LQ_HIP_CHECK(hipStreamSynchronize(lanes[0]->stream));
+}
+
+void lqcov_handle::sat_replay_host(u32 qi, const SatRec *recs, u64 n_recs, const u32 *at, u64 n_at, u32 *counters, u64 n_counters)
+{
+	if (qi >= q.n) throw std::invalid_argument("no such query");
+	std::vector<SatRec> r(recs, recs + n_recs); std::vector<u32> a(at, at + n_at), c(counters, counters + n_counters);
+	sat_check(r, a, (size_t)n_counters);
+	const std::vector<u32> order = satreplay::regs_order(r, satreplay::query_hash(q.names[qi], (i32)q.h_len[qi], 11 /* map.c:15 */));
+	satreplay::replay(c, r, a, order, cnt_max);
+	std::copy(c.begin(), c.end(), counters);
 }
 
 // A subset of the queries through klib's passes and the chain kernels: every anchor of the listed queries (nothing is filtered

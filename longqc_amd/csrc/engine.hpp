@@ -236,6 +236,8 @@ struct lqcov_handle {
 	u32 cnt_max = 65535;                  // (LQCOV_TEST_CNT_BITS)
 	DBuf sat_rec, sat_at, sat_n;
 	u64 stat_sat_chains = 0;
+	std::vector<SatRec> sat_last_recs; std::vector<u32> sat_last_at;   // lqcov_part_sat_records: the records between the sizing call and the copying one
+	int sat_last_part = -1; u32 sat_last_query = 0; bool sat_last_valid = false;
 	u64 last_n_written = 0;               // anchors the first pass wrote against the last part
 	std::atomic<u64> stat_tie_why[6] = {};   // listed runs by the first reason that listed them (lq_tie_list: skip pending, member counts as a skip, top score twice, scan broke off, peak tie, other), since reset()
 	std::atomic<u64> stat_sens_runs{0}, stat_p2_queries{0}, stat_p2_anchors{0};   // second pass, since reset(): runs, queries, anchors
@@ -300,6 +302,10 @@ struct lqcov_handle {
 	void map_subset(MapLane &L, Part &pt, const std::vector<u32> &sq, const std::vector<u32> &sk, const std::vector<u64> &so, u64 max_mini, int tie_mode, u32 n_want, u32 ivl_cap, bool dbg, const SatSink *sink);
 	void debug_sort_pairs(u64 *keys, u64 *vals, u64 n, unsigned bits, int key_bytes);   // tests: the primitives of kernels_isort.hpp on host arrays
 	void debug_scan(const u32 *in, u64 *out, u64 n);
+	bool sat_chains(Part &pt, u32 qi, const std::vector<u64> &h_aq, const std::vector<u64> &h_qmoff, std::vector<SatRec> &recs, std::vector<u32> &at);
+	void sat_check(const std::vector<SatRec> &recs, const std::vector<u32> &at, size_t nc);
+	void part_sat_records(Part &pt, u32 qi, std::vector<SatRec> &recs, std::vector<u32> &at);
+	void sat_replay_host(u32 qi, const SatRec *recs, u64 n_recs, const u32 *at, u64 n_at, u32 *counters, u64 n_counters);
 	void sat_replay_part(Part &pt, const std::vector<u64> &h_aq, const std::vector<u64> &h_qmoff);
 	void sort_checked(MapLane &L, Part &pt, const u64 *aqb, const u32 *qkb, u32 nqb, u64 a_base, u64 nA, const std::vector<u64> &h_off, const std::vector<u32> &h_klib);
 	void sort_batch(MapLane &L, Part &pt, const u64 *aqb, const u32 *qkb, u32 nqb, u64 a_base, u64 nA);

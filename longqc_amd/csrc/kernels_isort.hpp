@@ -1,25 +1,35 @@
-// longqc_amd/csrc/kernels_isort.hpp -- the index sort, hand-written for gfx950.
+// longqc_amd/csrc/kernels_isort.hpp -- the engine's device-wide primitives, hand-written for gfx950: the index sort and the
+// exclusive scan (rounds 1-5 called rocPRIM for both; since round 6 the engine launches no library kernel).
 //
-// What it replaces: worker_post's radix_sort_128x over a bucket's minimizers (index.c:150-201) -- semantically "every
+// What the sort replaces: worker_post's radix_sort_128x over a bucket's minimizers (index.c:150-201) -- semantically "every
 // minimizer's occurrences grouped by hash, ascending y inside a hash".  The sketch emits a part's minimizers in ascending
-// y, so a STABLE sort of (hash, y) pairs on the 2k bits of the hash gives exactly that (rounds 1-5 called rocPRIM's
-// radix_sort_pairs here; this file is the same algorithm family written for this data and this chip).
+// y, so a STABLE sort of (hash, y) pairs on the 2k bits of the hash gives exactly that.
 //
-// Shape: least-significant-digit radix sort, 8-bit digits, one sweep over the data per digit ("onesweep"):
-//   k_is_hist   one read of the keys: the digit histograms of every pass at once (LDS counters, one u64 atomic per
-//               non-empty counter and block);
-//   k_is_bases  per pass the exclusive scan of its 256 counts: where each digit's output range begins;
-//   k_is_pass   one launch per digit.  A block takes the next tile of 4096 pairs (a ticket, so that a tile's
-//               predecessors have always started), ranks its pairs by digit *stably* -- per wave and 64 consecutive
-//               pairs the lanes with the same digit find each other with 8 ballots, the first of them bumps the wave's
-//               counter of that digit in LDS, the others read the old value from its lane --, publishes the tile's 256
-//               digit counts as 8-byte {flag, count} granules (relaxed agent-scope stores: written through to memory,
-//               visible across XCDs, never torn: MI355X_MICROARCH.md, inter-workgroup visibility), looks back over the
-//               predecessors' granules until it meets an inclusive prefix (decoupled look-back: no tile waits for more
-//               than its predecessors' *counting* phases), then moves its pairs through LDS into digit order and writes
-//               every digit's run to its place with consecutive lanes on consecutive addresses.
-// Bytes per pair and pass: 12 read + 12 written for 4-byte keys (k <= 16), 16 + 16 for 8-byte keys, + 0.5 B of granules.
-// LDS per block: 48 KB of staged pairs + 4 KB of wave counters + 3 KB: three blocks per CU.
+// Shape: least-significant-digit radix sort, 8-bit digits, one sweep over the data per digit:
+//   k_is_hist   the digit histogram(s) of a pass's input, one per range of tiles (LDS counters, one u64 atomic per non-empty
+//               counter and block);
+//   k_is_bases  where the output of every (range, digit) begins: the digits' totals scanned, then the ranges in order;
+//   k_is_pass   one launch per digit.  A block takes the next tile of 5120 pairs (4-byte keys with 8-byte values), ranks its
+//               pairs by digit *stably* -- per wave and 64 consecutive pairs the lanes with the same digit find each other
+//               with 8 ballots, the first of them bumps the wave's counter of that digit in LDS, the others read the old
+//               value from its lane --, publishes the tile's 256 digit counts as 8-byte {flag, count} granules (relaxed
+//               agent-scope stores: written through, visible across XCDs, never torn: MI355X_MICROARCH.md, inter-workgroup
+//               visibility), looks back over the predecessors' granules until it meets an inclusive prefix (decoupled
+//               look-back: a tile waits for its predecessors' *counting* phases only), then moves first its keys and then its
+//               values through one LDS buffer into digit order and writes every digit's run with consecutive lanes on
+//               consecutive addresses.
+// XCD-aware: a tile gives every digit a run of ~20 pairs (80 B of keys, 160 B of values); neighbouring tiles' runs are
+// neighbours in memory, and on eight XCDs with an L2 each a line put together by tiles in start order leaves eight L2s in
+// pieces.  So the tiles are dealt in eight contiguous RANGES, one per XCD (HW_REG_XCC_ID; a ticket per range; per-range
+// histograms make every range's first tile independent of the ranges before it): the pieces of a line meet in one L2.
+// Measured on 1.34 G pairs (configs[2]'s first part): tiles in start order 37.1 ms, ranges 31.9 ms although every pass then
+// needs its own histogram read (rocPRIM's onesweep: 32 ms); keys and values taking turns in the staging buffer (tiles of
+// 5120 instead of 3840 pairs at three blocks per CU) 27.4 ms.  Smaller tiles at four blocks per CU (36.5), larger ones at two
+// (35.1), 5632 pairs with 5 spilled registers (30.6) and skipping a tile's own granule when the predecessor's inclusive one is
+// already there (33.2 against 32.2) all lost.  Placement is only a matter of speed: a block whose range is used up takes a
+// tile of the next range; the emulator build runs the same code with blockIdx & 7 as the XCD.
+// Bytes per pair and pass: 12 read + 12 written for 4-byte keys (k <= 16) + 4 for the pass's histogram + 0.8 B of granules;
+// LDS per block 47 KB (40 KB staging, 4 KB wave counters, 3 KB): three blocks per CU.
 #pragma once
 #include "lq_common.hpp"
 
@@ -30,7 +40,7 @@
 #define LQ_IS_FIT_KB 45
 #endif
 #ifndef LQ_IS_EMAX
-#define LQ_IS_EMAX 22
+#define LQ_IS_EMAX 20
 #endif
 #ifndef LQ_IS_FASTPATH
 #define LQ_IS_FASTPATH 0
@@ -105,7 +115,7 @@ k_is_bases(unsigned long long *ghist, u32 n_ranges, u32 p0)
 // pairs per thread: as many as keep the staged tile at 45 KB (three blocks per CU), 16 at most
 template <class KT, class VT, bool PAIRS>
 struct LqIsShape { static constexpr int BYTES = PAIRS && sizeof(VT) > sizeof(KT) ? (int)sizeof(VT) : (int)sizeof(KT);   // keys and values take turns in the staging buffer
-                   static constexpr int FIT = LQ_IS_FIT_KB * 1024 / (LQ_IS_THREADS * (BYTES + (PAIRS ? 1 : 0)));   // (+ the digit byte of a slot)
+                   static constexpr int FIT = LQ_IS_FIT_KB * 1024 / (LQ_IS_THREADS * BYTES);
                    static constexpr int E = FIT > LQ_IS_EMAX ? LQ_IS_EMAX : FIT; };
 
 template <class KT, class VT, bool PAIRS>
@@ -120,8 +130,7 @@ k_is_pass(const KT *kin, KT *kout, const VT *vin, VT *vout, u64 n, u32 shift, u3
 	__shared__ u64 gdel[256];                   // global index of a staged pair = gdel[digit] + its slot in the tile
 	__shared__ u32 wsum[LQ_IS_WAVES];
 	__shared__ u32 s_tile, s_first;
-	__shared__ __attribute__((aligned(16))) char stage[TILE * LqIsShape<KT, VT, PAIRS>::BYTES];   // the tile in digit order: first its values, then its keys
-	__shared__ u8 sdig[PAIRS ? TILE : 1];      // the digit of every slot (the values' pass has no key to take it from)
+	__shared__ __attribute__((aligned(16))) char stage[TILE * LqIsShape<KT, VT, PAIRS>::BYTES];   // the tile in digit order: first its keys, then its values
 	KT *sk = reinterpret_cast<KT*>(stage);
 	VT *sv = reinterpret_cast<VT*>(stage);
 	const u32 tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -212,7 +221,7 @@ k_is_pass(const KT *kin, KT *kout, const VT *vin, VT *vout, u64 n, u32 shift, u3
 		gdel[d] = (u64)gbase[pass * 256 + d] + excl - off;
 	}
 	__syncthreads();
-	// slot of every pair in digit order (kept in r[]), then the values through the staging buffer, then the keys
+	// slot of every pair in digit order (kept in r[]), then the keys through the staging buffer, then the values
 #pragma unroll
 	for (int e = 0; e < E; ++e) {
 		const u32 idx = w * (E * 64) + e * 64 + lane;
@@ -221,30 +230,38 @@ k_is_pass(const KT *kin, KT *kout, const VT *vin, VT *vout, u64 n, u32 shift, u3
 			r[e] = toff[d] + wc[w][d] + r[e];
 		}
 	}
-	if (PAIRS) {
-#pragma unroll
-		for (int e = 0; e < E; ++e) {
-			const u32 idx = w * (E * 64) + e * 64 + lane;
-			if (idx < tn) { sv[r[e]] = v[e]; sdig[r[e]] = (u8)((u32)(k[e] >> shift) & mask); }
-		}
-		__syncthreads();
-#pragma unroll
-		for (int e = 0; e < E; ++e) {
-			const u32 s = e * LQ_IS_THREADS + tid;
-			if (s < tn) vout[gdel[sdig[s]] + s] = sv[s];
-		}
-		__syncthreads();
-	}
 #pragma unroll
 	for (int e = 0; e < E; ++e) {
 		const u32 idx = w * (E * 64) + e * 64 + lane;
 		if (idx < tn) sk[r[e]] = k[e];
 	}
 	__syncthreads();
+	u32 dd[(E + 3) / 4];                          // the digits of the slots this thread writes, a byte each: the values go where their keys went
+#pragma unroll
+	for (int e = 0; e < (E + 3) / 4; ++e) dd[e] = 0;
 #pragma unroll
 	for (int e = 0; e < E; ++e) {
 		const u32 s = e * LQ_IS_THREADS + tid;
-		if (s < tn) { const KT kk = sk[s]; kout[gdel[(u32)(kk >> shift) & mask] + s] = kk; }
+		if (s < tn) {
+			const KT kk = sk[s];
+			const u32 d = (u32)(kk >> shift) & mask;
+			dd[e >> 2] |= d << (8 * (e & 3));
+			kout[gdel[d] + s] = kk;
+		}
+	}
+	if (PAIRS) {
+		__syncthreads();
+#pragma unroll
+		for (int e = 0; e < E; ++e) {
+			const u32 idx = w * (E * 64) + e * 64 + lane;
+			if (idx < tn) sv[r[e]] = v[e];
+		}
+		__syncthreads();
+#pragma unroll
+		for (int e = 0; e < E; ++e) {
+			const u32 s = e * LQ_IS_THREADS + tid;
+			if (s < tn) vout[gdel[(dd[e >> 2] >> (8 * (e & 3))) & 255u] + s] = sv[s];
+		}
 	}
 }
 

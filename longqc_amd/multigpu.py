@@ -167,6 +167,8 @@ class PartRunner:
         self.avgk, self.flags = z(self.n_q, torch.float32), z(self.n_q, torch.int32)
         self.cnts = z(self.n_cnt, torch.int32)
         self.ivl: List[torch.Tensor] = []
+        self.sat = {}                                        # query (engine order) -> its counters, replayed in the reference's chain order (uint32 numpy)
+        self.cnt_off = self.eng.counter_offsets().astype(np.int64) if self.n_q else np.zeros(1, np.int64)
 
     def share_mid_occ(self, owner_rank: int = 0):
         """mid_occ comes from part 0 (map.c:50): its owner broadcasts it after building."""
@@ -217,6 +219,8 @@ class PartRunner:
             pad[:ivlc.shape[0]] = ivlc
             got = _all_gather(pad, self.world, self.group)
             ivlc = torch.cat([g[:int(s.item())] for g, s in zip(got, sizes)], dim=0)
+        if n_cnt:
+            self._replay_saturated(part, inc, cntc)
         self.lam[:n_q], self.avgk[:n_q] = lam_tot, avgk_tot
         self.lam2[:n_q] += lam2c
         if n_cnt:
@@ -225,11 +229,63 @@ class PartRunner:
         self.ivl.append(ivlc)
         self.finalize()
 
+    def _replay_saturated(self, part: Optional[int], inc: torch.Tensor, cntc: torch.Tensor):
+        """esterr.c:127-138: the match counters are uint16 and the saturation tests read the counter of the chain's FIRST minimizer,
+        so once a counter of a query is at 65535 its other counters depend on the order in which lq_cnt_match met the chains
+        (hit.c:52-88).  Until then the 32-bit sums over the ranks are the reference's values.  A query one of whose merged counters
+        reaches the limit in this round (or did in an earlier one) is chained once more against every included part of the round by
+        the rank that holds the part, every kept chain recorded (lqcov_part_sat_records); the records go to all ranks (broadcast
+        from the part's rank: the one exchange of this corner) and every rank replays them, part by part in part order, on the
+        counters the query had before the round (lqcov_sat_replay) -- what one handle does by itself."""
+        eng, dev, n_cnt = self.eng, self.dev, self.n_cnt
+        cm = eng.counter_max()
+        hot = torch.nonzero((self.cnts[:n_cnt].to(torch.int64) + cntc.to(torch.int64)) >= cm).flatten()
+        new = set()
+        if hot.numel():
+            new = set(int(v) for v in np.unique(np.searchsorted(self.cnt_off[1:], hot.cpu().numpy(), side="right")))
+        inc_any = inc.any(dim=0).cpu().numpy()
+        todo = sorted(q for q in (new | set(self.sat)) if inc_any[q])
+        if not todo:
+            return
+        if self.world > 1:
+            have = [int(t.item()) for t in _all_gather(torch.tensor([1 if part is not None else 0], dtype=torch.int32, device=dev), self.world, self.group)]
+        else:
+            have = [1 if part is not None else 0]
+        inc_h = inc.cpu().numpy()
+        rb = int(eng.lib.lqcov_sat_record_bytes())
+        for q in todo:
+            lo, hi = int(self.cnt_off[q]), int(self.cnt_off[q + 1])
+            c = self.sat[q] if q in self.sat else self.cnts[lo:hi].cpu().numpy().astype(np.uint32)
+            for r in range(self.world):
+                if not have[r] or not inc_h[r][q]:
+                    continue
+                if r == self.rank:
+                    recs, at = eng.part_sat_records(part, q)
+                    size = torch.tensor([recs.shape[0], at.shape[0]], dtype=torch.int64, device=dev)
+                else:
+                    recs = at = None
+                    size = torch.zeros(2, dtype=torch.int64, device=dev)
+                if self.world > 1:
+                    _broadcast(size, r, self.group)
+                    nr, na = int(size[0].item()), int(size[1].item())
+                    tr = torch.zeros(max(nr * rb, 1), dtype=torch.uint8, device=dev)
+                    ta = torch.zeros(max(na, 1), dtype=torch.int32, device=dev)
+                    if r == self.rank:
+                        tr[:nr * rb] = torch.from_numpy(recs.reshape(-1)).to(dev)
+                        ta[:na] = torch.from_numpy(at.view(np.int32)).to(dev)
+                    _broadcast(tr, r, self.group); _broadcast(ta, r, self.group)
+                    recs = tr[:nr * rb].cpu().numpy().reshape(nr, rb)
+                    at = ta[:na].cpu().numpy().view(np.uint32)
+                c = eng.sat_replay(q, recs, at, c)
+            self.sat[q] = c
+
     def finalize(self):
         ivl = torch.cat(self.ivl, dim=0).contiguous() if self.ivl else torch.zeros((0, 3), dtype=torch.int32, device=self.dev)
         self._ivl_keep = ivl if ivl.shape[0] else torch.zeros((1, 3), dtype=torch.int32, device=self.dev)
         self.eng.accum_import(self.lam.data_ptr(), self.lam2.data_ptr(), self.avgk.data_ptr(), self.flags.data_ptr(),
                               self.cnts.data_ptr(), self._ivl_keep.data_ptr(), int(ivl.shape[0]))
+        for q, c in self.sat.items():                             # (replayed counters take the place of the merged sums; the rows carry LQCOV_ROW_REPLAYED)
+            self.eng.accum_set_replayed(q, c)
 
 
 # ---- queries sharded, index replicated (the north-star split) --------------------------------------------------

@@ -380,6 +380,13 @@ def test_gpu_two_ranks_share_the_device_exchange_accumulators(gpu_lib, tmp_path)
     assert open(out).read() == read_gz("adv_parts.table.gz")
 
 
+def test_gpu_two_ranks_replay_saturated_counters_across_parts(gpu_lib, tmp_path, monkeypatch):
+    """index parts spread over two ranks (gloo, both on cuda:0), 5-bit match counters that fill up in the merged sums: the ranks
+    exchange the flagged queries' chains and replay them in the reference's order (esterr.c:127-138)"""
+    import tests.test_multigpu_cpu as M
+    M.check_ranks_replay_saturated_counters(tmp_path, monkeypatch, 2, True)
+
+
 @pytest.mark.parametrize("I,expect", [(100000, "adv_parts.table.gz"), (4000000000, "adv_ont.table.gz")])
 def test_gpu_two_ranks_share_the_device_query_sharded_replicated_index(gpu_lib, tmp_path, I, expect):
     """the north-star split with real device pointers: two ranks (gloo, both on cuda:0) each sketch half of every part,

@@ -89,6 +89,74 @@ def test_two_ranks_gloo_equal_reference_multipart_table(emu_lib, tmp_path, world
     assert open(out).read() == read_gz("adv_parts.table.gz")
 
 
+def _worker_saturated(rank, world, port, tf, qf, argv, out_path, bits, use_gpu=False):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    os.environ["LQCOV_TEST_CNT_BITS"] = str(bits)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import ctypes as C
+        lib = api.load_library() if use_gpu else api.load_library(os.path.join(ROOT, "tests", "emu", "liblqcov_emu.so"))
+        full = [b"minimap2-coverage"] + [a.encode() for a in argv] + [tf.encode(), qf.encode()]
+        arr = (C.c_char_p * len(full))(*full)
+        p = api.Params()
+        t, q, d = C.c_char_p(), C.c_char_p(), C.c_char_p()
+        err = C.create_string_buffer(256)
+        assert lib.lqcov_parse_args(len(full), arr, C.byref(p), C.byref(t), C.byref(q), C.byref(d), err, 256) == 0, err.value
+        tn, ts, _ = read_fastx(tf)
+        qn, qs, qq = read_fastx(qf)
+        eng = api.Engine(p, 0, lib=lib)
+        eng.set_queries(qn, qs, qq)
+        parts = multigpu.split_parts([int(x.shape[0]) for x in ts], int(p.batch_size))
+        assert len(parts) >= 2 * world                       # several rounds: a query flagged in one round is replayed in the next ones too
+        runner = multigpu.PartRunner(eng, world, rank, torch.device("cuda", 0) if use_gpu else torch.device("cpu"), [int(x.shape[0]) for x in qs])
+        runner.begin()
+        for base in range(0, len(parts), world):
+            mine = base + rank
+            pid = None
+            if mine < len(parts):
+                s, e = parts[mine]
+                pid = eng.part_begin()
+                eng.part_add_targets(pid, tn[s:e], ts[s:e])
+                eng.part_build(pid)
+            runner.map_and_combine(pid, part_index=mine, mid_occ_owner=0, share_mid_occ=(base == 0))
+            if pid is not None:
+                eng.part_release(pid)
+        eng.finish()
+        if rank == 0:
+            eng.write_table(out_path)
+            flags = [r["flags"] for r in eng.rows()]
+            open(out_path + ".flags", "w").write(" ".join(str(f) for f in flags))
+            open(out_path + ".sat", "w").write(" ".join(str(k) for k in sorted(runner.sat)))
+        eng.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, pytest.param(3, marks=slow_emu)])
+def test_ranks_replay_saturated_counters_across_parts(emu_lib, tmp_path, monkeypatch, world):
+    check_ranks_replay_saturated_counters(tmp_path, monkeypatch, world, False)
+
+
+def check_ranks_replay_saturated_counters(tmp_path, monkeypatch, world, use_gpu):
+    """esterr.c:127-138 with the index parts spread over ranks: match counters narrowed to 5 bits on both sides (the test hook of
+    tests/test_emu_pipeline.py's one-handle case) fill up in the MERGED sums; the ranks exchange the chains of the flagged queries
+    (lqcov_part_sat_records -> broadcast -> lqcov_sat_replay) and the table equals the oracle's, which walks the parts and their
+    chains serially in the reference's order.  Rounds 1-5 refused this case (rows flagged SATURATED without REPLAYED)."""
+    from tests.test_emu_pipeline import _pileup_dataset
+    tf, qf = _pileup_dataset(tmp_path, 400)
+    argv = ["-Y", "-l", "0", "-q", "40", "-k", "12", "-w", "5", "-I", "25K", "-p", "40", "-m", "20", "-t", "4"]
+    monkeypatch.setenv("LQO_CNT_BITS", "5")
+    want = oracle_bind.table(argv + [tf, qf])
+    monkeypatch.setenv("LQO_CNT_BITS", "16")
+    assert oracle_bind.table(argv + [tf, qf]) != want           # the width shows in the table
+    out = str(tmp_path / "sat.tsv")
+    mp.spawn(_worker_saturated, args=(world, _free_port(), tf, qf, argv, out, 5, use_gpu), nprocs=world, join=True)
+    assert open(out).read() == want
+    flags = [int(f) for f in open(out + ".flags").read().split()]
+    assert any(f & 1 for f in flags) and all((f & 4) for f in flags if f & 1)     # LQCOV_ROW_SATURATED rows all carry LQCOV_ROW_REPLAYED
+    assert open(out + ".sat").read().split()
+
+
 # ---- queries sharded, index replicated (BASELINE.json's north star) ----
 def _worker_qshard(rank, world, port, argv_I, out_path, use_gpu=False, parts_api=False, packed=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
