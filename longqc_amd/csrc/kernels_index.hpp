@@ -2,7 +2,7 @@
 //
 // Index (reference index.c:150-236, semantic result "hash -> occurrences sorted by y"): the part's
 // minimizers are produced in ascending y by k_sketch, a stable LSD radix sort on the 2k-bit hash
-// groups them (rocPRIM device radix sort), run heads become the distinct keys, and an
+// groups them (kernels_isort.hpp), run heads become the distinct keys, and an
 // open-addressed, linearly probed table (16-B aligned key / start / count arrays, capacity a power
 // of two >= 2*K_t) maps hash -> (start, n) into the sorted position array: one 8-byte probe per
 // lookup in the common case, neighbouring lanes probing neighbouring query minimizers.
