@@ -26,7 +26,10 @@
 // needs its own histogram read (rocPRIM's onesweep: 32 ms); keys and values taking turns in the staging buffer (tiles of
 // 5120 instead of 3840 pairs at three blocks per CU) 27.4 ms.  Smaller tiles at four blocks per CU (36.5), larger ones at two
 // (35.1), 5632 pairs with 5 spilled registers (30.6) and skipping a tile's own granule when the predecessor's inclusive one is
-// already there (33.2 against 32.2) all lost.  Placement is only a matter of speed: a block whose range is used up takes a
+// already there (33.2 against 32.2) all lost.  So did dropping the sorted digit from the keys in every sweep (u32 -> u16 -> u8, the
+// full key put together again in the last sweep from the pair's position: 53 instead of 72 bytes per pair; built, bit-exact, and
+// measured at 7.8 + 15.0 + 11.2 ms for the three sweeps against 3 x 8.1: 2- and 1-byte stores cost an instruction each like 8-byte
+// ones, the sweep is not byte-bound enough for 26 % fewer bytes to pay for them) -- taken out again.  Placement is only a matter of speed: a block whose range is used up takes a
 // tile of the next range; the emulator build runs the same code with blockIdx & 7 as the XCD.
 // Bytes per pair and pass: 12 read + 12 written for 4-byte keys (k <= 16) + 4 for the pass's histogram + 0.8 B of granules;
 // LDS per block 47 KB (40 KB staging, 4 KB wave counters, 3 KB): three blocks per CU.
