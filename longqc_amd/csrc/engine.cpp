@@ -781,27 +781,46 @@ void lqcov_handle::build_index(Part &pt)
 		const u64 n_tiles = (M + LQ_HEAD_TILE - 1) / LQ_HEAD_TILE;
 		key.ensure(M * 8); key2.ensure(M * 8); head.ensure((n_tiles + 1) * 4); uidx.ensure((n_tiles + 1) * 8);   // (head / uidx: run heads per tile of keys, scanned)
 		const bool k32 = 2 * P.k <= 32;                         // the hash fits 32 bits: 4-byte sort keys
+		const bool fused_heads = 2 * P.k <= 24;                   // at most 2^24 distinct keys: the run heads in one pass (k_head_lookback)
 		if (k32) {
 			if (!(rs.key_stamp && rs.key_stamp == ix_key_stamp)) { LQ_LAUNCH(k_sort_keys<u32>, nblk(M, 256), 256, stream, rs.mx.as<u64>(), M, key.as<u32>()); check_launch(); }   // (k_sketch_emit_mask has written them)
 			ix_key_stamp = 0;
 			{ StageTimer t(this, stream, "index_radix_sort", M * 24); prim.sort_pairs_u32_u64(key.as<u32>(), key2.as<u32>(), rs.my.as<u64>(), pt.pos.as<u64>(), M, (unsigned)(2 * P.k), key.as<u32>()); }   // (the unsorted keys are not needed again: their array is the sort's second key buffer)
-			LQ_LAUNCH(k_head_count<u32>, (u32)n_tiles, LQ_HEAD_THREADS, stream, key2.as<u32>(), M, head.as<u32>()); check_launch();
+			if (!fused_heads) { LQ_LAUNCH(k_head_count<u32>, (u32)n_tiles, LQ_HEAD_THREADS, stream, key2.as<u32>(), M, head.as<u32>()); check_launch(); }
 		} else {
 			ix_key_stamp = 0;
 			LQ_LAUNCH(k_sort_keys<u64>, nblk(M, 256), 256, stream, rs.mx.as<u64>(), M, key.as<u64>()); check_launch();
 			{ StageTimer t(this, stream, "index_radix_sort", M * 32); prim.sort_pairs_u64(key.as<u64>(), key2.as<u64>(), rs.my.as<u64>(), pt.pos.as<u64>(), M, (unsigned)(2 * P.k), key.as<u64>()); }
 			LQ_LAUNCH(k_head_count<u64>, (u32)n_tiles, LQ_HEAD_THREADS, stream, key2.as<u64>(), M, head.as<u32>()); check_launch();
 		}
-		dzero(head.as<u32>() + n_tiles, 4, stream);
-		prim.exclusive_scan_u32_u64(head.as<u32>(), uidx.as<u64>(), n_tiles + 1);
-		host_names();                                              // (host work while the sort runs: the first wait for the device is below)
 		u64 K = 0;
-		d2h(&K, uidx.as<u64>() + n_tiles, 1, stream);
-		pt.n_keys = K;
-		ukey.ensure(K * 8); ustart.ensure(K * 8); ucnt.ensure(K * 4);
-		if (k32) LQ_LAUNCH(k_head_fill<u32>, (u32)n_tiles, LQ_HEAD_THREADS, stream, key2.as<u32>(), M, uidx.as<u64>(), ukey.as<u64>(), ustart.as<u64>());
-		else LQ_LAUNCH(k_head_fill<u64>, (u32)n_tiles, LQ_HEAD_THREADS, stream, key2.as<u64>(), M, uidx.as<u64>(), ukey.as<u64>(), ustart.as<u64>());
-		check_launch();
+		if (fused_heads) {
+			const u64 k_max = std::min<u64>(M, (u64)1 << (2 * P.k));
+			ukey.ensure(k_max * 8); ustart.ensure(k_max * 8);
+			const u64 n_blocks = (n_tiles + LQ_HEADLB_SUB - 1) / LQ_HEADLB_SUB;
+			uidx.ensure((n_blocks + 2) * 8 + 64);                   // (one look-back granule per block, the count, the ticket)
+			dzero(uidx.p, (n_blocks + 2) * 8 + 64, stream);
+			u64 *granules = uidx.as<u64>(), *count = granules + n_blocks; u32 *ticket = (u32*)(granules + n_blocks + 1);
+			{
+				StageTimer t(this, stream, "k_head_lookback", M * 4);
+				LQ_LAUNCH(k_head_lookback<u32>, (u32)n_blocks, LQ_HEAD_THREADS, stream, key2.as<u32>(), M, granules, ticket, ukey.as<u64>(), ustart.as<u64>(), count);
+				check_launch();
+			}
+			host_names();                                              // (host work while the sort runs: the first wait for the device is below)
+			d2h(&K, count, 1, stream);
+			pt.n_keys = K;
+			ucnt.ensure(K * 4);
+		} else {
+			dzero(head.as<u32>() + n_tiles, 4, stream);
+			prim.exclusive_scan_u32_u64(head.as<u32>(), uidx.as<u64>(), n_tiles + 1);
+			host_names();                                              // (host work while the sort runs: the first wait for the device is below)
+			d2h(&K, uidx.as<u64>() + n_tiles, 1, stream);
+			pt.n_keys = K;
+			ukey.ensure(K * 8); ustart.ensure(K * 8); ucnt.ensure(K * 4);
+			if (k32) LQ_LAUNCH(k_head_fill<u32>, (u32)n_tiles, LQ_HEAD_THREADS, stream, key2.as<u32>(), M, uidx.as<u64>(), ukey.as<u64>(), ustart.as<u64>());
+			else LQ_LAUNCH(k_head_fill<u64>, (u32)n_tiles, LQ_HEAD_THREADS, stream, key2.as<u64>(), M, uidx.as<u64>(), ukey.as<u64>(), ustart.as<u64>());
+			check_launch();
+		}
 		LQ_LAUNCH(k_unique_counts, nblk(K, 256), 256, stream, ustart.as<u64>(), K, M, ucnt.as<u32>()); check_launch();
 		u32 bits = 4;
 		while (((u64)1 << bits) < 2 * K) ++bits;

@@ -13,6 +13,7 @@
 #pragma once
 #include "lq_common.hpp"
 #include "kernels_sketch.hpp"
+#include "kernels_isort.hpp"
 
 #define LQ_EMPTY_KEY LQ_U64MAX
 
@@ -101,6 +102,55 @@ k_head_fill(const KT *key, u64 n, const u64 *tile_off, u64 *ukey, u64 *ustart)
 	u64 at = tile_off[blockIdx.x] + before + x - c;
 #pragma unroll
 	for (int k = 0; k < LQ_HEAD_PER; ++k) if (bits >> k & 1u) { ukey[at] = (u64)mine[k]; ustart[at] = i0 + (u64)k; ++at; }
+}
+
+// The two kernels above in one pass over the keys (round 6, keys of at most 24 bits: at most 2^24 distinct ones, so ukey / ustart can
+// be sized before their number is known): a block takes LQ_HEADLB_SUB tiles of keys in a row (one ticket per 16 384 keys: with one
+// per 2048 the kernel ran at the pace of the atomic on the ticket, 7.7 ms for 1.34 G keys), counts their run heads, looks back
+// over the blocks before it (one granule per block, kernels_isort.hpp) and writes its heads where they belong; the last block
+// leaves the number of distinct keys in *n_keys.
+#define LQ_HEADLB_SUB 8
+template <class KT>
+__global__ void __launch_bounds__(LQ_HEAD_THREADS)
+k_head_lookback(const KT *key, u64 n, u64 *status, u32 *ticket, u64 *ukey, u64 *ustart, u64 *n_keys)
+{
+	__shared__ u32 wsum[LQ_HEADLB_SUB][LQ_HEAD_THREADS / 64];
+	__shared__ u64 s_excl;
+	__shared__ u32 s_tile;
+	if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1u);
+	__syncthreads();
+	const u32 tile = s_tile, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	const u64 b0 = (u64)tile * (LQ_HEADLB_SUB * LQ_HEAD_TILE);
+	u32 bits[LQ_HEADLB_SUB], x[LQ_HEADLB_SUB];
+#pragma unroll
+	for (int j = 0; j < LQ_HEADLB_SUB; ++j) {
+		KT mine[LQ_HEAD_PER];
+		bits[j] = lq_head_bits(key, n, b0 + (u64)j * LQ_HEAD_TILE + (u64)threadIdx.x * LQ_HEAD_PER, mine);
+		u32 v = (u32)__popc(bits[j]);
+		for (u32 o = 1; o < 64; o <<= 1) { const u32 y = __shfl_up(v, o); if (lane >= o) v += y; }
+		x[j] = v;                                                  // heads of this sub-tile up to and including this thread, within its wave
+		if (lane == 63) wsum[j][wv] = v;
+	}
+	__syncthreads();
+	u32 total = 0, before[LQ_HEADLB_SUB];
+#pragma unroll
+	for (int j = 0; j < LQ_HEADLB_SUB; ++j) {
+		before[j] = total;
+		for (u32 w = 0; w < LQ_HEAD_THREADS / 64; ++w) { if (w < wv) before[j] += wsum[j][w]; total += wsum[j][w]; }
+	}
+	if (wv == 0) {
+		const u64 excl = lq_tile_lookback(status, tile, (u64)total, lane);
+		if (lane == 0) { s_excl = excl; if (b0 + (u64)LQ_HEADLB_SUB * LQ_HEAD_TILE >= n) *n_keys = excl + total; }
+	}
+	__syncthreads();
+#pragma unroll
+	for (int j = 0; j < LQ_HEADLB_SUB; ++j) {
+		if (!bits[j]) continue;
+		const u64 i0 = b0 + (u64)j * LQ_HEAD_TILE + (u64)threadIdx.x * LQ_HEAD_PER;
+		u64 at = s_excl + before[j] + x[j] - (u32)__popc(bits[j]);
+#pragma unroll
+		for (int k = 0; k < LQ_HEAD_PER; ++k) if (bits[j] >> k & 1u) { ukey[at] = (u64)key[i0 + (u64)k]; ustart[at] = i0 + (u64)k; ++at; }   // (the few keys that are heads are read again: they are in L2)
+	}
 }
 
 __global__ void k_unique_counts(const u64 *ustart, u64 n_keys, u64 n_mini, u32 *ucnt)

@@ -272,6 +272,31 @@ k_is_pass(const KT *kin, KT *kout, const VT *vin, VT *vout, u64 n, u32 shift, u3
 // The same decoupled look-back with one granule per tile: a tile of 256 x 16 counts is scanned in registers (wave scans over 64
 // consecutive counts, carried along the wave's 16 rounds), its total published, the predecessors' granules summed 64 at a time by
 // the first wave until one holds an inclusive prefix.  Sums are 64-bit whatever the output type.
+// One granule per tile: the first wave of a block publishes its tile's total and returns the sum of the totals of every tile
+// before it -- the predecessors' granules 64 at a time, nearest first, up to the first that holds an inclusive prefix.  The
+// granules are zeroed before the launch; the tiles are taken in ticket order (a tile's predecessors have always started).
+__device__ __forceinline__ u64 lq_tile_lookback(u64 *status, u32 tile, u64 total, u32 lane)
+{
+	u64 *mine = status + tile;
+	if (tile > 0 && lane == 0) lq_is_publish(mine, (1ULL << 56) | total);
+	u64 excl = 0;
+	u32 done = tile == 0;
+	for (u32 base = tile; !done; ) {                        // predecessors base - 1 - lane
+		const bool have = lane < base;
+		u64 s = 0;
+		if (have) { const u64 *g = status + (base - 1 - lane); s = lq_is_peek(g); while (LQ_IS_FLAG(s) == 0) { lq_is_nap(); s = lq_is_peek(g); } }
+		const u64 full = __ballot(have && LQ_IS_FLAG(s) == 2);
+		const u32 stop = full ? (u32)__ffsll((long long)full) - 1 : 63u;   // the nearest predecessor with an inclusive prefix
+		u64 part = have && lane <= stop ? LQ_IS_VAL(s) : 0;
+#pragma unroll
+		for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
+		excl += part;
+		if (full || base <= 64) done = 1; else base -= 64;
+	}
+	if (lane == 0) lq_is_publish(mine, (2ULL << 56) | (excl + total));
+	return excl;
+}
+
 #define LQ_SC_E 16
 #define LQ_SC_TILE (256 * LQ_SC_E)
 template <class TO>
@@ -303,25 +328,7 @@ k_scan_lookback(const u32 *in, TO *out, u64 n, u64 init, u64 *status, u32 *ticke
 	u64 before = 0, total = 0;
 #pragma unroll
 	for (int i = 0; i < 4; ++i) { if ((u32)i < w) before += wtot[i]; total += wtot[i]; }
-	if (w == 0) {
-		u64 *mine = status + tile;
-		if (tile > 0 && lane == 0) lq_is_publish(mine, (1ULL << 56) | total);
-		u64 excl = 0;
-		u32 done = tile == 0;
-		for (u32 base = tile; !done; ) {                        // predecessors base - 1 - lane, nearest first
-			const bool have = lane < base;
-			u64 s = 0;
-			if (have) { const u64 *g = status + (base - 1 - lane); s = lq_is_peek(g); while (LQ_IS_FLAG(s) == 0) { lq_is_nap(); s = lq_is_peek(g); } }
-			const u64 full = __ballot(have && LQ_IS_FLAG(s) == 2);
-			const u32 stop = full ? (u32)__ffsll((long long)full) - 1 : 63u;   // the nearest predecessor with an inclusive prefix
-			u64 part = have && lane <= stop ? LQ_IS_VAL(s) : 0;
-#pragma unroll
-			for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
-			excl += part;
-			if (full || base <= 64) done = 1; else base -= 64;
-		}
-		if (lane == 0) { lq_is_publish(mine, (2ULL << 56) | (excl + total)); s_excl = excl; }
-	}
+	if (w == 0) { const u64 excl = lq_tile_lookback(status, tile, total, lane); if (lane == 0) s_excl = excl; }
 	__syncthreads();
 	const u64 add = init + s_excl + before;
 #pragma unroll
