@@ -51,6 +51,7 @@
 
 // {flag, count} granule of one (tile, digit): flag = 2 * pass + 1 (the tile's own count) or 2 * pass + 2 (count of the tile and
 // every tile before it); granules are zeroed once per sort, the pass number keeps the passes apart
+#define LQ_IS_SPIN_MAX (1u << 21)   // polls of one granule (each a load from L2 or further: seconds in all): a predecessor has always started, so this never comes close
 #define LQ_IS_VAL(g)  ((g) & 0x00ffffffffffffffULL)
 #define LQ_IS_FLAG(g) ((u32)((g) >> 56))
 
@@ -58,11 +59,13 @@
 __device__ __forceinline__ void lq_is_publish(u64 *p, u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ u64 lq_is_peek(const u64 *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void lq_is_nap() { __builtin_amdgcn_s_sleep(2); }
+__device__ __forceinline__ void lq_is_stuck() { __builtin_trap(); }                    // a bounded spin that ran out: the launch fails instead of hanging the device
 __device__ __forceinline__ u32 lq_xcc_id() { return (u32)__builtin_amdgcn_s_getreg(20 | (3 << 11)) & 15u; }   // HW_REG_XCC_ID, bits 3:0: the XCD this wave runs on
 #else
 inline void lq_is_publish(u64 *p, u64 v) { *p = v; }
 inline u64 lq_is_peek(const u64 *p) { return *p; }
 inline void lq_is_nap() {}
+inline void lq_is_stuck() { fprintf(stderr, "hipemu: a look-back waited for a granule that never came\n"); abort(); }
 inline u32 lq_xcc_id() { return blockIdx.x & 7u; }
 #endif
 
@@ -216,7 +219,7 @@ k_is_pass(const KT *kin, KT *kout, const VT *vin, VT *vout, u64 n, u32 shift, u3
 		if (!have_excl) for (u32 p = tile; p-- > first; ) {
 			const u64 *g = status + (size_t)p * 256 + d;
 			u64 s = lq_is_peek(g);
-			while (LQ_IS_FLAG(s) != 2 * pass + 1 && LQ_IS_FLAG(s) != 2 * pass + 2) { lq_is_nap(); s = lq_is_peek(g); }
+			for (u32 spins = 0; LQ_IS_FLAG(s) != 2 * pass + 1 && LQ_IS_FLAG(s) != 2 * pass + 2; ) { if (++spins > LQ_IS_SPIN_MAX) lq_is_stuck(); lq_is_nap(); s = lq_is_peek(g); }
 			excl += LQ_IS_VAL(s);
 			if (LQ_IS_FLAG(s) == 2 * pass + 2) break;
 		}
@@ -284,7 +287,7 @@ __device__ __forceinline__ u64 lq_tile_lookback(u64 *status, u32 tile, u64 total
 	for (u32 base = tile; !done; ) {                        // predecessors base - 1 - lane
 		const bool have = lane < base;
 		u64 s = 0;
-		if (have) { const u64 *g = status + (base - 1 - lane); s = lq_is_peek(g); while (LQ_IS_FLAG(s) == 0) { lq_is_nap(); s = lq_is_peek(g); } }
+		if (have) { const u64 *g = status + (base - 1 - lane); s = lq_is_peek(g); for (u32 spins = 0; LQ_IS_FLAG(s) == 0; ) { if (++spins > LQ_IS_SPIN_MAX) lq_is_stuck(); lq_is_nap(); s = lq_is_peek(g); } }
 		const u64 full = __ballot(have && LQ_IS_FLAG(s) == 2);
 		const u32 stop = full ? (u32)__ffsll((long long)full) - 1 : 63u;   // the nearest predecessor with an inclusive prefix
 		u64 part = have && lane <= stop ? LQ_IS_VAL(s) : 0;

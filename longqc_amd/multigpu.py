@@ -141,7 +141,7 @@ class PartRunner:
     accumulators; `finalize()` imports them into the handle so that lqcov_finish() produces the rows."""
 
     @staticmethod
-    def scaling_model(world: int, part_bases, upload_s_per_gbase=0.0056, sketch_s_per_gbase=0.0068, index_s_per_gbase=0.0097, map_s_per_gbase=0.0555) -> float:
+    def scaling_model(world: int, part_bases, upload_s_per_gbase=0.0056, sketch_s_per_gbase=0.0068, index_s_per_gbase=0.0083, map_s_per_gbase=0.0555) -> float:
         """seconds per job predicted for `world` GPUs: rounds of `world` consecutive parts, a round lasts as long as its largest
         part takes on one GPU (front + mapping of every query; the exchange is a few KB per part).  Same MI355X figures as
         QueryShardRunner.scaling_model (round 6)."""
@@ -396,7 +396,7 @@ class QueryShardRunner:
         return anchors
 
     @staticmethod
-    def scaling_model(world: int, part_bases, upload_s_per_gbase=0.0056, sketch_s_per_gbase=0.0068, index_s_per_gbase=0.0097, map_s_per_gbase=0.0555,
+    def scaling_model(world: int, part_bases, upload_s_per_gbase=0.0056, sketch_s_per_gbase=0.0068, index_s_per_gbase=0.0083, map_s_per_gbase=0.0555,
                       link_gbytes_per_s=153.0, packed_bytes_per_base=0.25, pipelined=True) -> float:
         """seconds per job predicted for `world` GPUs (the defaults: MI355X figures measured at configs[2] at the end of round 6 -- upload
         22.5 ms (codes alone: reads without an N), sketch 27 ms, index build incl. sort, run heads, table and name work 39 ms, seed plan +
