@@ -22,7 +22,7 @@ cp /tmp/prof/b_kernel_stats.csv $GRAFT_REPO_ROOT/gpurun_out/kernel_stats_bench_c
 echo "rocprof done $(( $(date +%s) - T0 )) s" >> $GRAFT_REPO_ROOT/gpurun_out/pytest_gpu.log
 if [ "$PMC" = 1 ]; then
   R=$GRAFT_REPO_ROOT
-  RE=${PMC_RE:-'k_seed_count|k_seed_scatter|k_seed_decide|k_seed_emit|k_ps_finish|k_ps_scatter|k_ps_hist|k_chain|k_run_list|k_rs_scatter|k_rs_hist|k_sort_walk_solo|k_ck_chain256|k_sketch'}
+  RE=${PMC_RE:-'k_seed_count|k_seed_scatter|k_seed_decide|k_seed_emit|k_ps_finish|k_ps_scatter|k_ps_hist|k_chain|k_run_list|k_rs_scatter|k_rs_hist|k_sort_walk_solo|k_ck_chain256|k_sketch|k_is_pass|k_is_hist|k_head_lookback'}
   BP="python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-end-to-end --no-north-star $C"
   for CN in FETCH_SIZE WRITE_SIZE; do
     ( timeout ${PMC_LIMIT:-300} rocprofv3 --pmc $CN --kernel-trace --kernel-include-regex "$RE" --output-format csv -d /tmp/pmc_$CN -o p -- $BP 2>&1 | tail -3 ) > $R/gpurun_out/pmc_$CN.log 2>&1
