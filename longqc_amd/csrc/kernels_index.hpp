@@ -105,8 +105,8 @@ k_head_fill(const KT *key, u64 n, const u64 *tile_off, u64 *ukey, u64 *ustart)
 }
 
 // The two kernels above in one pass over the keys (round 6, keys of at most 24 bits: at most 2^24 distinct ones, so ukey / ustart can
-// be sized before their number is known): a block takes LQ_HEADLB_SUB tiles of keys in a row (one ticket per 16 384 keys: with one
-// per 2048 the kernel ran at the pace of the atomic on the ticket, 7.7 ms for 1.34 G keys), counts their run heads, looks back
+// be sized before their number is known): a block takes LQ_HEADLB_SUB tiles of keys in a row (one ticket and one granule per 16 384 keys: 5.0 ms for 1.34 G keys; per 2048 keys
+// the kernel ran at the pace of the atomic on the ticket, 7.7 ms; per 32 768 keys 182 registers and 6.1 ms), counts their run heads, looks back
 // over the blocks before it (one granule per block, kernels_isort.hpp) and writes its heads where they belong; the last block
 // leaves the number of distinct keys in *n_keys.
 #define LQ_HEADLB_SUB 8
