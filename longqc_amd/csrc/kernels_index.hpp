@@ -49,18 +49,23 @@ template <class KT>
 __device__ __forceinline__ u32 lq_head_bits(const KT *key, u64 n, u64 i0, KT *mine)
 {
 	u32 bits = 0;
-	KT prev = i0 > 0 && i0 <= n ? key[i0 - 1] : (KT)0;
-	if (i0 + LQ_HEAD_PER <= n) {                                 // the thread's 8 keys as 16-byte loads (i0 is a multiple of 8: aligned): a wave reads 2 or 4 KB in one piece
+	const u32 lane = threadIdx.x & 63;
+	if (i0 - (u64)lane * LQ_HEAD_PER + 64 * LQ_HEAD_PER <= n) {   // the whole wave's 512 keys exist (the same answer in every lane: the shuffle below is wave-uniform)
+		// the thread's 8 keys as 16-byte loads (i0 is a multiple of 8: aligned): a wave reads 2 or 4 KB in one piece; the key before them
+		// is the last key of the lane before (only the wave's first lane reads it from memory)
 		constexpr int NV = LQ_HEAD_PER * (int)sizeof(KT) / 16;
 		const uint4 *src = reinterpret_cast<const uint4*>(key + i0);
 		uint4 q[NV];
 #pragma unroll
 		for (int j = 0; j < NV; ++j) q[j] = src[j];
 		memcpy(mine, q, sizeof(q));
+		KT prev = __shfl_up(mine[LQ_HEAD_PER - 1], 1);
+		if (lane == 0) prev = i0 > 0 ? key[i0 - 1] : (KT)0;
 #pragma unroll
 		for (int k = 0; k < LQ_HEAD_PER; ++k) { if ((i0 == 0 && k == 0) || mine[k] != prev) bits |= 1u << k; prev = mine[k]; }
 		return bits;
 	}
+	KT prev = i0 > 0 && i0 <= n ? key[i0 - 1] : (KT)0;
 #pragma unroll
 	for (int k = 0; k < LQ_HEAD_PER; ++k) {
 		const u64 i = i0 + (u64)k;
