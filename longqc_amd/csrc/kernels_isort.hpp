@@ -26,7 +26,7 @@
 // needs its own histogram read (rocPRIM's onesweep: 32 ms); keys and values taking turns in the staging buffer (tiles of
 // 5120 instead of 3840 pairs at three blocks per CU) 27.4 ms.  Smaller tiles at four blocks per CU (36.5), larger ones at two
 // (35.1), 5632 pairs with 5 spilled registers (30.6) and skipping a tile's own granule when the predecessor's inclusive one is
-// already there (33.2 against 32.2) all lost.  So did dropping the sorted digit from the keys in every sweep (u32 -> u16 -> u8, the
+// already there (33.2 against 32.2), blocks of 512 threads with the same tiles (32.5 against 27.7) all lost.  So did dropping the sorted digit from the keys in every sweep (u32 -> u16 -> u8, the
 // full key put together again in the last sweep from the pair's position: 53 instead of 72 bytes per pair; built, bit-exact, and
 // measured at 7.8 + 15.0 + 11.2 ms for the three sweeps against 3 x 8.1: 2- and 1-byte stores cost an instruction each like 8-byte
 // ones, the sweep is not byte-bound enough for 26 % fewer bytes to pay for them) -- taken out again.  Placement is only a matter of speed: a block whose range is used up takes a
@@ -36,7 +36,9 @@
 #pragma once
 #include "lq_common.hpp"
 
+#ifndef LQ_IS_THREADS
 #define LQ_IS_THREADS 256
+#endif
 #define LQ_IS_WAVES   (LQ_IS_THREADS / 64)
 #define LQ_IS_MAXPASS 8
 #ifndef LQ_IS_FIT_KB
@@ -192,39 +194,45 @@ k_is_pass(const KT *kin, KT *kout, const VT *vin, VT *vout, u64 n, u32 shift, u3
 	__syncthreads();
 	// per digit (thread d): the waves' counts -> exclusive over the waves, the tile's count, its granule, the look-back
 	{
-		const u32 d = tid;
+		const bool dthr = tid < 256;                              // (blocks of more than 256 threads: the first four waves own the digits)
+		const u32 d = tid & 255;
 		u32 run = 0;
-#pragma unroll
-		for (int i = 0; i < LQ_IS_WAVES; ++i) { const u32 c = wc[i][d]; wc[i][d] = run; run += c; }
 		u64 *mine = status + (size_t)tile * 256 + d;
 		const u64 f_own = (u64)(2 * pass + 1) << 56, f_all = (u64)(2 * pass + 2) << 56;
 		u64 excl = 0;
 		bool have_excl = tile == first;
-		if (LQ_IS_FASTPATH && tile > first) {                      // the predecessor's inclusive prefix is already there: one granule instead of two
-			const u64 s = lq_is_peek(mine - 256);
-			if (LQ_IS_FLAG(s) == 2 * pass + 2) { excl = LQ_IS_VAL(s); have_excl = true; }
-		}
-		if (!have_excl) lq_is_publish(mine, f_own | run);
-		// exclusive scan of the tile's counts over the digits
-		u32 inc = run;
+		u32 inc = 0;
+		if (dthr) {
 #pragma unroll
-		for (int o = 1; o < 64; o <<= 1) { const u32 up = __shfl_up(inc, o); if (lane >= (u32)o) inc += up; }
-		if (lane == 63) wsum[w] = inc;
+			for (int i = 0; i < LQ_IS_WAVES; ++i) { const u32 c = wc[i][d]; wc[i][d] = run; run += c; }
+			if (LQ_IS_FASTPATH && tile > first) {                    // the predecessor's inclusive prefix is already there: one granule instead of two
+				const u64 s = lq_is_peek(mine - 256);
+				if (LQ_IS_FLAG(s) == 2 * pass + 2) { excl = LQ_IS_VAL(s); have_excl = true; }
+			}
+			if (!have_excl) lq_is_publish(mine, f_own | run);
+			// exclusive scan of the tile's counts over the digits
+			inc = run;
+#pragma unroll
+			for (int o = 1; o < 64; o <<= 1) { const u32 up = __shfl_up(inc, o); if (lane >= (u32)o) inc += up; }
+			if (lane == 63) wsum[w] = inc;
+		}
 		__syncthreads();
-		u32 before = 0;
+		if (dthr) {
+			u32 before = 0;
 #pragma unroll
-		for (int i = 0; i < LQ_IS_WAVES; ++i) if ((u32)i < w) before += wsum[i];
-		const u32 off = before + inc - run;
-		toff[d] = off;
-		if (!have_excl) for (u32 p = tile; p-- > first; ) {
-			const u64 *g = status + (size_t)p * 256 + d;
-			u64 s = lq_is_peek(g);
-			for (u32 spins = 0; LQ_IS_FLAG(s) != 2 * pass + 1 && LQ_IS_FLAG(s) != 2 * pass + 2; ) { if (++spins > LQ_IS_SPIN_MAX) lq_is_stuck(); lq_is_nap(); s = lq_is_peek(g); }
-			excl += LQ_IS_VAL(s);
-			if (LQ_IS_FLAG(s) == 2 * pass + 2) break;
+			for (int i = 0; i < 4; ++i) if ((u32)i < w) before += wsum[i];
+			const u32 off = before + inc - run;
+			toff[d] = off;
+			if (!have_excl) for (u32 p = tile; p-- > first; ) {
+				const u64 *g = status + (size_t)p * 256 + d;
+				u64 s = lq_is_peek(g);
+				for (u32 spins = 0; LQ_IS_FLAG(s) != 2 * pass + 1 && LQ_IS_FLAG(s) != 2 * pass + 2; ) { if (++spins > LQ_IS_SPIN_MAX) lq_is_stuck(); lq_is_nap(); s = lq_is_peek(g); }
+				excl += LQ_IS_VAL(s);
+				if (LQ_IS_FLAG(s) == 2 * pass + 2) break;
+			}
+			lq_is_publish(mine, f_all | (excl + run));
+			gdel[d] = (u64)gbase[pass * 256 + d] + excl - off;
 		}
-		lq_is_publish(mine, f_all | (excl + run));
-		gdel[d] = (u64)gbase[pass * 256 + d] + excl - off;
 	}
 	__syncthreads();
 	// slot of every pair in digit order (kept in r[]), then the keys through the staging buffer, then the values
