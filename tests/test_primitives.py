@@ -49,12 +49,13 @@ def _run_all(eng, sizes, big):
         _check_sort(eng, rng, n, 24, 4, "one")
         _check_sort(eng, rng, n, 32, 4, "skewed", pairs=False)
         c = rng.integers(0, 1 << 32, size=n, dtype=np.uint64).astype(np.uint32)
-        want = np.concatenate([[0], np.cumsum(c.astype(np.uint64))[:-1]]).astype(np.uint64) if n else np.zeros(0, np.uint64)
+        want = np.zeros(n, dtype=np.uint64); want[1:] = np.cumsum(c.astype(np.uint64))[:-1]   # (all in uint64)
         assert np.array_equal(eng.debug_scan(c), want)
     if big:
         _check_sort(eng, rng, big, 24, 4, "skewed")
         c = rng.integers(0, 1 << 20, size=big, dtype=np.uint64).astype(np.uint32)
-        assert np.array_equal(eng.debug_scan(c), np.concatenate([[0], np.cumsum(c.astype(np.uint64))[:-1]]).astype(np.uint64))
+        want = np.zeros(big, dtype=np.uint64); want[1:] = np.cumsum(c.astype(np.uint64))[:-1]
+        assert np.array_equal(eng.debug_scan(c), want)
 
 
 @pytest.mark.parametrize("ranges", ["1", "8", "3"])
