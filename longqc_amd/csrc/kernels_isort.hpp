@@ -282,7 +282,8 @@ k_is_pass(const KT *kin, KT *kout, const VT *vin, VT *vout, u64 n, u32 shift, u3
 // ---- exclusive scan of u32 counts (device-wide, one pass over the data) ----------------------------------------------------------
 // The same decoupled look-back with one granule per tile: a tile of 256 x 16 counts is scanned in registers (wave scans over 64
 // consecutive counts, carried along the wave's 16 rounds), its total published, the predecessors' granules summed 64 at a time by
-// the first wave until one holds an inclusive prefix.  Sums are 64-bit whatever the output type.
+// the first wave until one holds an inclusive prefix.  Sums are 64-bit whatever the output type; a granule carries 56 bits of them
+// (the engine scans counts of hits, minimizers and records: below 2^40).
 // One granule per tile: the first wave of a block publishes its tile's total and returns the sum of the totals of every tile
 // before it -- the predecessors' granules 64 at a time, nearest first, up to the first that holds an inclusive prefix.  The
 // granules are zeroed before the launch; the tiles are taken in ticket order (a tile's predecessors have always started).
