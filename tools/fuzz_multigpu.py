@@ -87,6 +87,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seeds", default="0:12")
     ap.add_argument("--limit", type=int, default=600, help="seconds per case")
+    ap.add_argument("--cnt-bits", type=int, default=0, help="match counters narrowed to this many bits on both sides (LQCOV_TEST_CNT_BITS / LQO_CNT_BITS): deep read sets "
+                    "then fill them in the sums merged over the ranks, and PartRunner must replay the flagged queries' chains across ranks (esterr.c:127-138); "
+                    "index parts across the ranks only, against the oracle (the reference binary's counters are 16 bits wide)")
     args = ap.parse_args()
     import numpy as np
     import torch.multiprocessing as mp
@@ -99,13 +102,19 @@ def main():
         cfg = dataclasses.replace(synth.CONFIGS["cfg2"], n_reads=int(rng.integers(40, 260)), mean_len=int(rng.integers(400, 2500)), min_len=int(rng.integers(50, 300)),
                                   depth=float(rng.choice([3, 8, 20, 60])), err=float(rng.choice([0.02, 0.08, 0.13])), seed=9000 + seed, nsample=int(rng.integers(4, 25)),
                                   qual=str(rng.choice(["ont", "none"])), junk_frac=float(rng.choice([0.0, 0.05])))
+        if args.cnt_bits:
+            cfg = dataclasses.replace(cfg, depth=float(rng.choice([40, 80, 160])), n_reads=int(rng.integers(150, 400)))
         if cfg.genome_len < 12000:                 # (a genome of a few kb is one tandem repeat away from a mid_occ of thousands: millions of seed hits,
             cfg = dataclasses.replace(cfg, depth=max(1.5, cfg.n_reads * cfg.mean_len / 12000.0))   # minutes per case on the emulator; tools/fuzz_emu.py has those)
         T, Q = synth.make_dataset(cfg)
         world = int(rng.choice([2, 2, 3]))
         mode = str(rng.choice(["parts", "queries", "queries_pipeline"]))
+        if args.cnt_bits:
+            mode = "parts"
         total = T.n_bases
         I = str(rng.choice(["4G", "%dK" % max(5, total // 1000 // int(rng.integers(2, 12)))]))
+        if args.cnt_bits:
+            I = "%dK" % max(5, total // 1000 // int(rng.integers(3, 12)))
         k, w = int(rng.choice([10, 12, 12, 15])), int(rng.choice([5, 5, 10]))
         m = int(rng.choice([20, 40, 40, 60]))
         argv = ["-Y", "-l", "0", "-k", str(k), "-w", str(w), "-I", I, "-m", str(m), "-p", str(m + int(rng.choice([0, 40, 120]))), "-q", str(m + 120), "-t", "2"]
@@ -114,7 +123,14 @@ def main():
         with tempfile.TemporaryDirectory() as d:
             tf, qf, out = os.path.join(d, "all.fq"), os.path.join(d, "sub.fq"), os.path.join(d, "t.tsv")
             synth.write_fastq(tf, T); synth.write_fastq(qf, Q)
-            want = oracle_bind.ref_table(argv + [tf, qf])
+            if args.cnt_bits:
+                os.environ["LQO_CNT_BITS"] = str(args.cnt_bits); os.environ["LQCOV_TEST_CNT_BITS"] = str(args.cnt_bits)
+                want = oracle_bind.table(argv + [tf, qf])
+                os.environ["LQO_CNT_BITS"] = "16"
+                wide = oracle_bind.table(argv + [tf, qf])
+                os.environ["LQO_CNT_BITS"] = str(args.cnt_bits)
+            else:
+                want = oracle_bind.ref_table(argv + [tf, qf])
             try:
                 ctx = mp.spawn(worker, args=(world, free_port(), mode, argv, tf, qf, out), nprocs=world, join=False)
                 deadline = time.time() + args.limit
@@ -127,8 +143,9 @@ def main():
             except Exception as e:
                 got = "EXCEPTION %r" % (e,)
             ok = got == want
-            print("seed %d: %s, %d ranks, %s: %s (%d rows, %d with coverage)" % (seed, mode, world, " ".join(argv), "identical" if ok else "DIFFERS", len(want.splitlines()),
-                                                                                sum(1 for l in want.splitlines() if l.split("\t")[2] != "0")), flush=True)
+            print("seed %d: %s, %d ranks, %s: %s (%d rows, %d with coverage%s)" % (seed, mode, world, " ".join(argv), "identical" if ok else "DIFFERS", len(want.splitlines()),
+                                                                                  sum(1 for l in want.splitlines() if l.split("\t")[2] != "0"),
+                                                                                  ", the counters' width shows in the table" if args.cnt_bits and wide != want else ""), flush=True)
             if not ok:
                 bad.append(seed)
                 print(got[:600])
