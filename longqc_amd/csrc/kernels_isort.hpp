@@ -284,6 +284,24 @@ k_is_pass(const KT *kin, KT *kout, const VT *vin, VT *vout, u64 n, u32 shift, u3
 // consecutive counts, carried along the wave's 16 rounds), its total published, the predecessors' granules summed 64 at a time by
 // the first wave until one holds an inclusive prefix.  Sums are 64-bit whatever the output type; a granule carries 56 bits of them
 // (the engine scans counts of hits, minimizers and records: below 2^40).
+// inclusive prefix sum over the wave: DPP operands (row_shr inside a row of 16 lanes, row_bcast across rows) instead of six trips
+// through the LDS crossbar (__shfl_up is a ds_bpermute)
+#ifndef LQ_EMU
+#define LQ_SK_DPP(v, ctrl, rows) __builtin_amdgcn_update_dpp(0, (int)(v), (ctrl), (rows), 0xf, false)
+__device__ __forceinline__ u32 lq_wave_scan_add(u32 v)
+{
+	v += (u32)LQ_SK_DPP(v, 0x111, 0xf);    // row_shr:1
+	v += (u32)LQ_SK_DPP(v, 0x112, 0xf);    // row_shr:2
+	v += (u32)LQ_SK_DPP(v, 0x114, 0xf);    // row_shr:4
+	v += (u32)LQ_SK_DPP(v, 0x118, 0xf);    // row_shr:8
+	v += (u32)LQ_SK_DPP(v, 0x142, 0xa);    // row_bcast:15 -> rows 1 and 3
+	v += (u32)LQ_SK_DPP(v, 0x143, 0xc);    // row_bcast:31 -> rows 2 and 3
+	return v;
+}
+#else
+static inline u32 lq_wave_scan_add(u32 v) { for (int d = 1; d < 64; d <<= 1) { const u32 o = __shfl_up(v, d); if ((int)(threadIdx.x & 63) >= d) v += o; } return v; }
+#endif
+
 // One granule per tile: the first wave of a block publishes its tile's total and returns the sum of the totals of every tile
 // before it -- the predecessors' granules 64 at a time, nearest first, up to the first that holds an inclusive prefix.  The
 // granules are zeroed before the launch; the tiles are taken in ticket order (a tile's predecessors have always started).
@@ -329,9 +347,11 @@ k_scan_lookback(const u32 *in, TO *out, u64 n, u64 init, u64 *status, u32 *ticke
 	u64 carry = 0;
 #pragma unroll
 	for (int e = 0; e < LQ_SC_E; ++e) {
-		u64 inc = x[e];
-#pragma unroll
-		for (int o = 1; o < 64; o <<= 1) { const u64 up = __shfl_up(inc, o); if (lane >= (u32)o) inc += up; }
+		// 64 counts of up to 32 bits sum to 38: the two 16-bit halves are scanned apart (each sum fits 32 bits) -- unless the output
+		// type says the grand total fits 32 bits
+		u64 inc;
+		if (sizeof(TO) == 4) inc = lq_wave_scan_add(x[e]);
+		else inc = (u64)lq_wave_scan_add(x[e] & 0xffffu) + ((u64)lq_wave_scan_add(x[e] >> 16) << 16);
 		ex[e] = carry + inc - x[e];
 		carry += __shfl(inc, 63);
 	}

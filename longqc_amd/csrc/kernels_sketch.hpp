@@ -17,6 +17,7 @@
 // array comes out in (read, position) order == the reference's emission order, deterministically.
 #pragma once
 #include "lq_common.hpp"
+#include "kernels_isort.hpp"   // lq_wave_scan_add
 
 __device__ __forceinline__ int lq_nt4(u8 c)
 {	// seq_nt4_table (sketch.c:8-25): A/C/G/T/U in either case, raw 0..3; everything else ambiguous
@@ -525,22 +526,6 @@ __device__ __forceinline__ u32 lq_rev2_32(u32 x)
 	x = __brev(x);
 	return ((x >> 1) & 0x55555555u) | ((x & 0x55555555u) << 1);
 }
-// inclusive prefix sum over the wave
-#ifndef LQ_EMU
-#define LQ_SK_DPP(v, ctrl, rows) __builtin_amdgcn_update_dpp(0, (int)(v), (ctrl), (rows), 0xf, false)
-__device__ __forceinline__ u32 lq_wave_scan_add(u32 v)
-{
-	v += (u32)LQ_SK_DPP(v, 0x111, 0xf);    // row_shr:1
-	v += (u32)LQ_SK_DPP(v, 0x112, 0xf);    // row_shr:2
-	v += (u32)LQ_SK_DPP(v, 0x114, 0xf);    // row_shr:4
-	v += (u32)LQ_SK_DPP(v, 0x118, 0xf);    // row_shr:8
-	v += (u32)LQ_SK_DPP(v, 0x142, 0xa);    // row_bcast:15 -> rows 1 and 3
-	v += (u32)LQ_SK_DPP(v, 0x143, 0xc);    // row_bcast:31 -> rows 2 and 3
-	return v;
-}
-#else
-static inline u32 lq_wave_scan_add(u32 v) { for (int d = 1; d < 64; d <<= 1) { const u32 o = __shfl_up(v, d); if ((int)(threadIdx.x & 63) >= d) v += o; } return v; }
-#endif
 __device__ __forceinline__ u32 lq_min3(u32 a, u32 b, u32 c) { const u32 m = a < b ? a : b; return m < c ? m : c; }
 
 #define LQ_DPF_CW (LQ_DPT_N / 16 + 4)                          // 16-base words of a tile's codes, from base - 32
