@@ -52,3 +52,16 @@ def test_streaming_kernels_keep_full_occupancy_and_nothing_spills(resources):
     assert ss["vgpr"] <= 80 and ss["scratch"] == 0 and 3 * ss["lds"] <= 160 * 1024, ss
     assert sb["scratch"] == 0 and 2 * sb["lds"] <= 160 * 1024, sb
     assert sd["vgpr"] <= 64 and sd["scratch"] == 0 and 2 * sd["lds"] <= 160 * 1024, sd
+
+
+def test_index_sort_sweep_fits_three_blocks_per_cu(resources):
+    """kernels_isort.hpp: the sweep of (4-byte hash, 8-byte y) pairs is measured at three blocks of 256 threads per CU (tiles of 5120
+    pairs: 27.4 ms per 1.34 G pairs; at two blocks 35, with spilled registers 30.6): 168 registers at most, nothing spilled, LDS a
+    third of the CU's."""
+    name = [k for k in resources if k.startswith("k_is_pass<unsigned int, unsigned long, true")]
+    assert len(name) == 1, sorted(k for k in resources if k.startswith("k_is_"))
+    r = resources[name[0]]
+    assert r["vgpr"] <= 168 and r["scratch"] == 0 and r["occ"] >= 3 and 3 * r["lds"] <= 160 * 1024, r
+    for k, v in resources.items():
+        if k.startswith(("k_is_", "k_scan_lookback", "k_head_lookback")):
+            assert v["scratch"] == 0, (k, v)
